@@ -1,0 +1,94 @@
+"""Seeded synthetic CNF generators for benchmarks, tests and golden-vector generation.
+
+The reference ships richer generators (reference: src/pdp/generator.py:98-377, out of scope per
+SURVEY.md section 2 row 12).  The hot path only needs reproducible *uniform random k-SAT* inputs of
+the shape BASELINE.json names (n=200, m=840, k=3 ...), so this module provides exactly that plus
+the DIMACS writer used by the CLI tests.  Everything is driven by ``numpy.random.RandomState`` so
+the same (seed, n, m, k) always yields the same instance on every machine.
+"""
+
+import os
+
+import numpy as np
+
+
+def uniform_ksat(n, m, k, rng):
+    """Return ``m`` clauses over ``n`` variables, each with ``k`` distinct variables drawn uniformly
+    and independent fair signs.  Clauses are lists of non-zero signed 1-based ints (DIMACS style)."""
+    clauses = []
+    for _ in range(m):
+        variables = rng.choice(n, size=k, replace=False) + 1
+        signs = rng.randint(0, 2, size=k) * 2 - 1
+        clauses.append([int(v * s) for v, s in zip(variables, signs)])
+    return clauses
+
+
+def clause_count(n, k, alpha=None):
+    """Number of clauses for the benchmark family: threshold-ish ratios."""
+    if alpha is None:
+        alpha = {3: 4.2, 4: 0.9 * 9.93, 5: 0.9 * 21.12}.get(k, 4.2)
+    return int(round(alpha * n))
+
+
+def write_dimacs(path, n, clauses):
+    """Write the single-space / ' 0'-terminated DIMACS dialect the reference parser accepts
+    (reference: src/dimacs2json.py:30-45)."""
+    with open(path, 'w') as f:
+        f.write("p cnf %d %d\n" % (n, len(clauses)))
+        for c in clauses:
+            f.write(" ".join(str(l) for l in c) + " 0\n")
+
+
+def compact_instance(n, clauses):
+    """Canonicalise an instance the way the reference's DIMACS->JSON converter does
+    (reference: src/dimacs2json.py:43-51,85-91): within a clause the last occurrence of a variable
+    wins, empty clauses are dropped, unused variables are removed (remaining ones renumbered in
+    ascending order), literals are listed clause-major with ascending variable index.
+
+    Returns (var_num, clause_num, signed_vars int32[E], clause_ids int32[E]) with 1-based ids."""
+    rows = []
+    for c in clauses:
+        lit = {}
+        for l in c:
+            l = int(l)
+            if l == 0:
+                continue
+            lit[abs(l)] = 1 if l > 0 else -1
+        if lit:
+            rows.append(lit)
+    used = sorted({v for r in rows for v in r})
+    remap = {v: i + 1 for i, v in enumerate(used)}
+    signed_vars, clause_ids = [], []
+    for ci, r in enumerate(rows):
+        for v in sorted(r):
+            signed_vars.append(remap[v] * r[v])
+            clause_ids.append(ci + 1)
+    return (len(used), len(rows), np.asarray(signed_vars, dtype=np.int32),
+            np.asarray(clause_ids, dtype=np.int32))
+
+
+def json_line(n, clauses, label=-1, name=""):
+    """One line of the compact JSON dataset format (reference: src/dimacs2json.py:85-91,
+    src/pdp/factorgraph/dataset.py:120-136)."""
+    var_num, clause_num, sv, ci = compact_instance(n, clauses)
+    label_txt = repr(float(label)) if isinstance(label, float) else str(label)
+    return "[[%d, %d], [%s], [%s], %s, [\"%s\"]]" % (
+        var_num, clause_num, ", ".join(str(int(x)) for x in sv), ", ".join(str(int(x)) for x in ci),
+        label_txt, name)
+
+
+def generate_batch(batch, n, k=3, m=None, seed=0):
+    """``batch`` independent instances; instance ``i`` uses RandomState(seed + i)."""
+    if m is None:
+        m = clause_count(n, k)
+    return [(n, uniform_ksat(n, m, k, np.random.RandomState(seed + i))) for i in range(batch)]
+
+
+def write_dimacs_directory(directory, instances, stem="inst"):
+    os.makedirs(directory, exist_ok=True)
+    paths = []
+    for i, (n, clauses) in enumerate(instances):
+        p = os.path.join(directory, "%s_%04d.cnf" % (stem, i))
+        write_dimacs(p, n, clauses)
+        paths.append(p)
+    return paths

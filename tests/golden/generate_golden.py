@@ -1,0 +1,506 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: drives the UNMODIFIED reference (/root/reference/src) on small seeded
+problems and dumps inputs + outputs as .npz/.json fixtures next to this file.
+
+Runs ONLY in a container that has /root/reference (it never travels to the GPU box; the fixtures
+do).  Nothing from the reference is copied: the reference is imported, executed, and its tensors
+are recorded.  Compatibility shims for a modern stack are applied on
+the oracle side only and do not change semantics:
+  B-1 yaml.load default Loader, B-2 numpy legacy scalar repr for dimacs2json,
+  B-3 termination check with a cloned index (same semantics, avoids self-aliased index_put),
+  B-4 integer division in _deduplicate (batch replication).
+
+Usage:  python tests/golden/generate_golden.py            # regenerates every fixture
+"""
+
+import io
+import json
+import logging
+import os
+import sys
+import tempfile
+import warnings
+
+import numpy as np
+
+warnings.filterwarnings('ignore')
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference/src'
+
+import torch  # noqa: E402
+import yaml  # noqa: E402
+
+# ---- shims (oracle side only) -------------------------------------------------------------
+np.set_printoptions(legacy='1.25')                                                    # B-2
+_yl = yaml.load
+yaml.load = lambda s, Loader=None: _yl(s, Loader=Loader or yaml.FullLoader)           # B-1
+
+sys.path.insert(0, REF)
+import pdp.trainer as RT  # noqa: E402   (the reference)
+import pdp.nn.solver as RS  # noqa: E402
+import pdp.nn.util as RU  # noqa: E402
+import pdp.nn.pdp_predict as RP  # noqa: E402
+import pdp.nn.pdp_propagate as RPR  # noqa: E402
+import pdp.nn.pdp_decimate as RD  # noqa: E402
+from pdp.factorgraph.dataset import FactorGraphDataset  # noqa: E402
+
+# our own generator lives in a package that is also called `pdp`; load it by path
+import importlib.util  # noqa: E402
+_spec = importlib.util.spec_from_file_location(
+    'pdp_amd_generator', os.path.join(REPO, 'pdp-solver_amd', 'pdp', 'generator.py'))
+gen = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(gen)
+
+
+def _check(self, active, prediction, sp):                                             # B-3
+    out, _ = self._cnf_evaluator(variable_prediction=prediction[0], graph_map=sp._graph_map,
+                                 batch_variable_map=sp._batch_variable_map,
+                                 batch_function_map=sp._batch_function_map,
+                                 edge_feature=sp._edge_feature, meta_data=sp._meta_data)
+    idx = active[:, 0].clone().bool()
+    if sp._batch_replication > 1:
+        real = torch.mm(sp._replication_mask_tuple[1], (out > 0.5).float())
+        dup = torch.mm(sp._replication_mask_tuple[0], (real == 0).float())
+        active[idx, 0] = (dup[idx, 0] > 0).to(active.dtype)
+    else:
+        active[idx, 0] = (out[idx, 0] <= 0.5).to(active.dtype)
+
+
+RT.SatFactorGraphTrainer._check_recurrence_termination = _check
+
+
+def _dedup(self, prediction, propagator_state, decimator_state, sp):                  # B-4
+    if sp._batch_replication <= 1 or sp._replication_mask_tuple is None:
+        return None, None, None
+    assignment = 2 * prediction[0] - 1.0
+    energy, _ = self._compute_energy(assignment, sp)
+    max_ind = RU.sparse_argmax(-energy.squeeze(1), sp._replication_mask_tuple[0], device=self._device)
+    batch_flag = torch.zeros(sp._batch_size, 1, device=self._device)
+    batch_flag[max_ind, 0] = 1
+    flag = torch.mm(sp._batch_mask_tuple[0], batch_flag)
+    variable_prediction = (flag * prediction[0]).view(sp._batch_replication, -1).sum(dim=0).unsqueeze(1)
+    flag = torch.mm(sp._graph_mask_tuple[1], flag)
+    r, e = sp._batch_replication, sp._edge_num // sp._batch_replication
+    new_p = tuple((flag * x).view(r, e, -1).sum(dim=0) for x in propagator_state) \
+        if propagator_state is not None else None
+    new_d = tuple((flag * x).view(r, e, -1).sum(dim=0) for x in decimator_state) \
+        if decimator_state is not None else None
+    return (variable_prediction, None), new_p, new_d
+
+
+RS.PropagatorDecimatorSolverBase._deduplicate = _dedup
+
+LOG = logging.getLogger('golden')
+
+# ---- recording torch.rand -------------------------------------------------------------------
+_real_rand = torch.rand
+RAND_LOG = []
+
+
+def _rec_rand(*a, **k):
+    out = _real_rand(*a, **k)
+    RAND_LOG.append(out.detach().clone().reshape(-1).numpy())
+    return out
+
+
+def np_(t):
+    return None if t is None else t.detach().cpu().numpy().copy()
+
+
+# ---- problems -------------------------------------------------------------------------------
+
+def make_lines(specs, seed0):
+    """specs: list of (n, m, k_choices). Returns JSON lines (compact format)."""
+    lines = []
+    for i, (n, m, ks) in enumerate(specs):
+        rng = np.random.RandomState(seed0 + i)
+        clauses = []
+        for _ in range(m):
+            k = int(ks[rng.randint(0, len(ks))])
+            variables = rng.choice(n, size=min(k, n), replace=False) + 1
+            signs = rng.randint(0, 2, size=len(variables)) * 2 - 1
+            clauses.append([int(v * s) for v, s in zip(variables, signs)])
+        lines.append(gen.json_line(n, clauses, label=i % 2, name="g%d" % i))
+    return lines
+
+
+def collate(lines, limit=10 ** 12, hidden_dim=1):
+    """Run the reference loader (parse + collate) on JSON lines -> list of torch tensors."""
+    with tempfile.NamedTemporaryFile('w', suffix='.json', delete=False) as f:
+        f.write("\n".join(lines) + "\n")
+        path = f.name
+    ds = FactorGraphDataset(path, limit=limit, hidden_dim=hidden_dim)
+    items = [ds._convert_line(l) for l in lines]
+    out = ds.dag_collate_fn(items)
+    os.unlink(path)
+    return out
+
+
+def batch_tensors(lines):
+    gm, bvm, bfm, ef, gf, lab, misc = collate(lines)
+    assert len(gm) == 1
+    return gm[0], bvm[0], bfm[0], ef[0], lab[0], misc[0]
+
+
+def base_cfg(model_type, **kw):
+    cfg = dict(model_type=model_type, model_name='golden-' + model_type, verbose=False, dropout=0,
+               error_dim=1, exploration=0, hidden_dim=3, local_search_iteration=0, epsilon=0.5,
+               tolerance=0.02, t_max=100, pi=0.01, decimation_probability=0.5,
+               edge_feature_dim=1, meta_feature_dim=0, prediction_dim=1, mem_hidden_dim=100,
+               agg_hidden_dim=100, mem_agg_hidden_dim=50, classifier_dim=50, loss_sharpness=5)
+    cfg.update(kw)
+    return cfg
+
+
+def build(cfg, seed=1234):
+    torch.manual_seed(seed)
+    tr = RT.SatFactorGraphTrainer(cfg, use_cuda=False, logger=LOG)
+    return tr, tr._model_list[0]
+
+
+def problem_arrays(gm, bvm, bfm, ef):
+    return dict(graph_map=np_(gm).astype(np.int32), batch_variable_map=np_(bvm).astype(np.int32),
+                batch_function_map=np_(bfm).astype(np.int32), edge_feature=np_(ef).astype(np.float32))
+
+
+def save(name, **arrs):
+    arrs = {k: v for k, v in arrs.items() if v is not None}
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **arrs)
+    print('wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024.0))
+
+
+# ---- A. loader + problem set-up + simplify ---------------------------------------------------
+
+MIXED_SPECS = [(20, 60, (3,)), (12, 30, (2, 3)), (20, 85, (3,)), (15, 40, (1, 2, 3)), (25, 60, (3, 4)),
+               (10, 42, (3,)), (18, 50, (2, 3, 4, 5)), (20, 84, (3,))]
+
+
+def gen_loader_and_simplify():
+    lines = make_lines(MIXED_SPECS, seed0=100)
+    gm, bvm, bfm, ef, lab, misc = batch_tensors(lines)
+    out = problem_arrays(gm, bvm, bfm, ef)
+    out['label'] = np_(lab)
+    with open(os.path.join(HERE, 'mixed_batch.jsonl'), 'w') as f:
+        f.write("\n".join(lines) + "\n")
+    dev = torch.device('cpu')
+    sp = RS.SATProblem((gm, bvm, bfm, ef, None, None), dev, 1)
+    sp.simplify()
+    out['simplify_active_variables'] = np_(sp._active_variables[:, 0])
+    out['simplify_active_functions'] = np_(sp._active_functions[:, 0])
+    out['simplify_solution'] = np_(sp._solution)
+    out['simplify_is_sat'] = np_(sp._is_sat)
+    # set_variables with a hand-made partial assignment on the simplified problem
+    rng = np.random.RandomState(5)
+    assign = np.zeros((bvm.numel(), 1), dtype=np.float32)
+    pick = rng.choice(bvm.numel(), size=12, replace=False)
+    assign[pick, 0] = rng.randint(0, 2, size=12) * 2 - 1
+    out['setvar_assignment'] = assign[:, 0].copy()
+    sp.set_variables(torch.from_numpy(assign.copy()))
+    out['setvar_active_variables'] = np_(sp._active_variables[:, 0])
+    out['setvar_active_functions'] = np_(sp._active_functions[:, 0])
+    out['setvar_solution'] = np_(sp._solution)
+    out['setvar_is_sat'] = np_(sp._is_sat)
+    # replication map sanity (a18): replicated problem arrays
+    sp3 = RS.SATProblem((gm, bvm, bfm, ef, None, None), dev, 3)
+    out['rep3_graph_map'] = np_(sp3._graph_map).astype(np.int32)
+    out['rep3_batch_variable_map'] = np_(sp3._batch_variable_map).astype(np.int32)
+    out['rep3_batch_function_map'] = np_(sp3._batch_function_map).astype(np.int32)
+    out['rep3_edge_feature'] = np_(sp3._edge_feature)
+    save('problem_simplify', **out)
+    return lines
+
+
+# ---- B. per-operator vectors (K-groups) ------------------------------------------------------
+
+def gen_ops(lines):
+    gm, bvm, bfm, ef, lab, misc = batch_tensors(lines)
+    dev = torch.device('cpu')
+    E, V, F = gm.size(1), bvm.numel(), bfm.numel()
+    B = int(bvm.max()) + 1
+    out = problem_arrays(gm, bvm, bfm, ef)
+    rng = np.random.RandomState(11)
+
+    sp = RS.SATProblem((gm, bvm, bfm, ef, None, None), dev, 1)
+    sp.simplify()
+    # de-activate a few more things by fixing variables so masks are non-trivial
+    assign = torch.zeros(V, 1)
+    pick = rng.choice(V, size=10, replace=False)
+    assign[pick, 0] = torch.from_numpy((rng.randint(0, 2, size=10) * 2 - 1).astype(np.float32))
+    sp.set_variables(assign)
+    out['active_variables'] = np_(sp._active_variables[:, 0])
+    out['active_functions'] = np_(sp._active_functions[:, 0])
+    out['solution'] = np_(sp._solution)
+    edge_mask = torch.mm(sp._graph_mask_tuple[1], sp._active_variables) * \
+        torch.mm(sp._graph_mask_tuple[3], sp._active_functions)
+    sp._edge_mask = edge_mask
+    out['edge_mask'] = np_(edge_mask[:, 0])
+
+    # --- smooth max / max / argmax (K4, K5)
+    x_e = torch.from_numpy(rng.rand(E, 1).astype(np.float32))
+    x_e[rng.rand(E) < 0.1] = 0
+    out['smax_in'] = np_(x_e[:, 0])
+    out['smax_out'] = np_(RU.sparse_smooth_max(x_e, sp._graph_mask_tuple[0], dev)[:, 0])
+    x_v = torch.from_numpy((rng.rand(V).astype(np.float32) * 0.5))
+    x_v[rng.rand(V) < 0.2] = 0
+    x_v[3] = x_v[5] = x_v.max()  # ties
+    out['vmax_in'] = np_(x_v)
+    out['vmax_out'] = np_(RU.sparse_max(x_v, sp._batch_mask_tuple[0], dev))
+    out['vargmax_out'] = np_(RU.sparse_argmax(x_v, sp._batch_mask_tuple[0], dev)).astype(np.int64)
+    x_neg = torch.from_numpy((rng.randn(V).astype(np.float32)))
+    out['vmax_neg_in'] = np_(x_neg)
+    out['vmax_neg_out'] = np_(RU.sparse_max(x_neg, sp._batch_mask_tuple[0], dev))
+    out['vargmax_neg_out'] = np_(RU.sparse_argmax(x_neg, sp._batch_mask_tuple[0], dev)).astype(np.int64)
+
+    # --- CNF evaluator (K9)
+    ev = RU.SatCNFEvaluator(dev)
+    pred = torch.from_numpy(rng.rand(V, 1).astype(np.float32))
+    pred[rng.rand(V) < 0.3] = 0.5
+    pred[rng.rand(V) < 0.2] = 1.0
+    pred[rng.rand(V) < 0.2] = 0.0
+    solved, unsat = ev(pred, gm, bvm, bfm, ef, None)
+    out['cnf_pred'] = np_(pred[:, 0]); out['cnf_solved'] = np_(solved[:, 0]); out['cnf_unsat'] = np_(unsat[:, 0])
+
+    # --- Survey propagator (K1-K3) with and without masks, pi = 0 and pi = 0.1
+    for tag, pi in (('pi0', 0.0), ('pi1', 0.1)):
+        prop = RPR.SurveyPropagator(dev, decimator_dimension=1, include_adaptors=False, pi=pi)
+        q = torch.from_numpy(rng.rand(E, 3).astype(np.float32)); q = q / q.sum(1, keepdim=True)
+        q[rng.rand(E) < 0.05, 0] = 0.0          # exercise the 1e-40 clamp
+        fs = torch.from_numpy(rng.rand(E, 2).astype(np.float32))
+        fs[rng.rand(E) < 0.05, 0] = 1.0         # 1 - eta == 0 -> clamp
+        fs[:, 1] = torch.from_numpy(rng.randint(-1, 2, size=E).astype(np.float32)) if pi > 0 else 0
+        init_q = torch.from_numpy(rng.rand(E, 3).astype(np.float32))
+        init_fs = torch.from_numpy(rng.rand(E, 2).astype(np.float32))
+        am = torch.ones(B, 1, dtype=torch.uint8); am[1] = 0; am[6] = 0
+        out['sp_%s_q' % tag] = np_(q); out['sp_%s_fs' % tag] = np_(fs)
+        out['sp_%s_init_q' % tag] = np_(init_q); out['sp_%s_init_fs' % tag] = np_(init_fs)
+        out['sp_%s_active_mask' % tag] = np_(am[:, 0])
+        o1 = prop((init_q, init_fs), (q, fs, edge_mask), sp, False, am)
+        out['sp_%s_masked_q' % tag] = np_(o1[0]); out['sp_%s_masked_fs' % tag] = np_(o1[1])
+        o2 = prop((init_q, init_fs), (q, fs), sp, False, None)
+        out['sp_%s_plain_q' % tag] = np_(o2[0]); out['sp_%s_plain_fs' % tag] = np_(o2[1])
+        # scorer (K6)
+        sc = RP.SurveyScorer(dev, message_dimension=1, include_adaptors=False, pi=pi)
+        s, _ = sc((q, fs), sp)
+        out['score_%s' % tag] = np_(s[:, 0])
+
+    # --- energy / delta energy (K14 pieces)
+    base = RS.PropagatorDecimatorSolverBase(dev, 'x', None, None, RP.IdentityPredictor(dev, True), 5, 0.5)
+    a = torch.from_numpy((rng.randint(0, 2, size=(V, 1)) * 2 - 1).astype(np.float32)) * sp._active_variables
+    en, uf = base._compute_energy(a, sp)
+    out['energy_assignment'] = np_(a[:, 0]); out['energy_per_instance'] = np_(en[:, 0]); out['energy_unsat_functions'] = np_(uf[:, 0])
+    out['energy_delta'] = np_(base._compute_energy_diff(a, sp)[:, 0])
+    save('ops_classical', **out)
+
+
+# ---- C. traces of the full solver ------------------------------------------------------------
+
+def run_trace(model_type, lines, T, w, seed, replication=1, cfg_kw=None, float_iters=(0, 1, 2, 5, 10),
+              randomized=False, tag=None):
+    cfg = base_cfg(model_type, local_search_iteration=w, **(cfg_kw or {}))
+    tr, m = build(cfg)
+    gm, bvm, bfm, ef, lab, misc = batch_tensors(lines)
+    out = problem_arrays(gm, bvm, bfm, ef)
+    out['meta'] = np.array([T, w, seed, replication], dtype=np.int64)
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    del RAND_LOG[:]
+    torch.rand = _rec_rand
+    try:
+        with torch.no_grad():
+            st = m.get_init_state(gm, bvm, bfm, ef, None, randomized=randomized, batch_replication=replication)
+            it = {'i': 0}
+            ints = {k: [] for k in ('active_variables', 'active_functions', 'solution', 'active_mask')}
+            floats = {}
+            orig_check = tr._check_recurrence_termination
+
+            def check(active, prediction, sp):
+                orig_check(active, prediction, sp)
+                ints['active_variables'].append(np_(sp._active_variables[:, 0]))
+                ints['active_functions'].append(np_(sp._active_functions[:, 0]))
+                ints['solution'].append(np_(sp._solution))
+                ints['active_mask'].append(np_(active[:, 0]))
+                it['i'] += 1
+
+            prop_states = []
+
+            def prop_hook(mod, inp, outp):
+                i = it['i']
+                if i in float_iters or i == T - 1:
+                    floats['prop_q_%d' % i] = np_(outp[0])
+                    floats['prop_fs_%d' % i] = np_(outp[1])
+
+            h = None
+            if m._propagator is not None:
+                h = m._propagator.register_forward_hook(prop_hook)
+            pred, (ps, dsn) = m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm,
+                                edge_feature=ef, meta_data=None, is_training=False, iteration_num=T,
+                                check_termination=check, batch_replication=replication)
+            if h is not None:
+                h.remove()
+    finally:
+        torch.rand = _real_rand
+    out['iterations_run'] = np.array([it['i']], dtype=np.int64)
+    for k, v in ints.items():
+        if v:
+            out['trace_' + k] = np.stack(v)
+    out.update(floats)
+    out['final_prediction'] = np_(pred[0][:, 0])
+    if ps is not None:
+        for j, x in enumerate(ps):
+            out['final_prop_%d' % j] = np_(x)
+        for j, x in enumerate(dsn):
+            out['final_dec_%d' % j] = np_(x)
+    ev = RU.SatCNFEvaluator(torch.device('cpu'))
+    if replication == 1:
+        solved, unsat = ev(pred[0], gm, bvm, bfm, ef, None)
+        out['final_solved'] = np_(solved[:, 0]); out['final_unsat'] = np_(unsat[:, 0])
+    out['rand_sizes'] = np.array([len(r) for r in RAND_LOG], dtype=np.int64)
+    out['rand_stream'] = np.concatenate(RAND_LOG).astype(np.float32) if RAND_LOG else np.zeros(0, np.float32)
+    save(tag or ('trace_' + model_type), **out)
+    return m, tr
+
+
+def gen_traces():
+    specs50 = [(50, 210, (3,))] * 8
+    lines50 = make_lines(specs50, seed0=500)
+    with open(os.path.join(HERE, 'sat50_batch.jsonl'), 'w') as f:
+        f.write("\n".join(lines50) + "\n")
+    # easier instances (alpha = 3.5) so that decimation + walksat actually solve some
+    easy = make_lines([(40, 140, (3,))] * 10, seed0=900)
+    with open(os.path.join(HERE, 'sat40_easy_batch.jsonl'), 'w') as f:
+        f.write("\n".join(easy) + "\n")
+    run_trace('p-d-p', lines50, T=40, w=0, seed=7, tag='trace_pdp_n50')
+    run_trace('p-d-p', easy, T=60, w=30, seed=7, tag='trace_pdp_easy_ws',
+              cfg_kw=dict(tolerance=0.05, t_max=10))
+    run_trace('p-d-p', make_lines(MIXED_SPECS, seed0=100), T=30, w=10, seed=3, tag='trace_pdp_mixed',
+              cfg_kw=dict(tolerance=0.05, t_max=8))
+    run_trace('walk-sat', easy, T=50, w=50, seed=11, tag='trace_walksat_easy')
+    run_trace('p-d-p', easy[:4], T=25, w=20, seed=5, replication=3, tag='trace_pdp_rep3',
+              cfg_kw=dict(tolerance=0.05, t_max=6))
+    run_trace('reinforce', easy, T=40, w=10, seed=13, tag='trace_reinforce_easy')
+
+
+# ---- D. neural operators + traces ------------------------------------------------------------
+
+def flat_state_dict(m):
+    """Canonical (non-aliased) tensors only; the alias map is stored separately as JSON."""
+    sd = m.state_dict()
+    keep = {}
+    for k, v in sd.items():
+        if k.startswith(('_propagator.', '_decimator.', '_predictor.')) and '_module_list' not in k:
+            keep['w__' + k.replace('.', '__')] = np_(v)
+    return keep
+
+
+def alias_map(m):
+    """Every state-dict key -> the canonical key holding the same storage."""
+    sd = m.state_dict()
+    canon = {}
+    for k, v in sd.items():
+        if k.startswith(('_propagator.', '_decimator.', '_predictor.')) and '_module_list' not in k:
+            canon[v.data_ptr()] = k
+    return {k: canon.get(v.data_ptr(), k) for k, v in sd.items()}
+
+
+def gen_neural():
+    big = make_lines([(20, 70, (3,))] * 5 + [(14, 40, (2, 3, 4))], seed0=1300)
+    small = make_lines([(12, 36, (3,)), (10, 30, (2, 3, 4)), (12, 40, (3,))], seed0=1400)
+    with open(os.path.join(HERE, 'neural_batch.jsonl'), 'w') as f:
+        f.write("\n".join(big) + "\n")
+    with open(os.path.join(HERE, 'neural_batch_small.jsonl'), 'w') as f:
+        f.write("\n".join(small) + "\n")
+    for tag, H, lines, T in (('h32', 32, big, 5), ('h128', 128, small, 2)):
+        gm, bvm, bfm, ef, lab, misc = batch_tensors(lines)
+        cfg = base_cfg('np-nd-np', hidden_dim=H, local_search_iteration=0)
+        tr, m = build(cfg, seed=1234)
+        out = problem_arrays(gm, bvm, bfm, ef)
+        out.update(flat_state_dict(m))
+        if H == 32:
+            with open(os.path.join(HERE, 'state_dict_alias_map.json'), 'w') as f:
+                json.dump(alias_map(m), f, indent=0, sort_keys=True)
+        keep_iters = (0, 1, T - 1)
+        it = {'i': 0}
+        rec = {}
+        orig_check = tr._check_recurrence_termination
+
+        def check(active, prediction, sp):
+            i = it['i']
+            rec['pred_%d' % i] = np_(prediction[0][:, 0])
+            orig_check(active, prediction, sp)
+            rec['active_mask_%d' % i] = np_(active[:, 0])
+            it['i'] += 1
+
+        def prop_hook(mod, inp, outp):
+            if it['i'] in keep_iters:
+                rec['prop_v_%d' % it['i']] = np_(outp[0]); rec['prop_f_%d' % it['i']] = np_(outp[1])
+
+        def dec_hook(mod, inp, outp):
+            if it['i'] in keep_iters:
+                rec['dec_v_%d' % it['i']] = np_(outp[0]); rec['dec_f_%d' % it['i']] = np_(outp[1])
+
+        h1 = m._propagator.register_forward_hook(prop_hook)
+        h2 = m._decimator.register_forward_hook(dec_hook)
+        torch.manual_seed(3)
+        with torch.no_grad():
+            st = m.get_init_state(gm, bvm, bfm, ef, None, randomized=True, batch_replication=1)
+            out['init_prop_v'] = np_(st[0][0]); out['init_prop_f'] = np_(st[0][1])
+            out['init_dec_v'] = np_(st[1][0]); out['init_dec_f'] = np_(st[1][1])
+            pred, _ = m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm,
+                        edge_feature=ef, meta_data=None, is_training=False, iteration_num=T,
+                        check_termination=check, batch_replication=1)
+        h1.remove(); h2.remove()
+        out.update(rec)
+        out['final_prediction'] = np_(pred[0][:, 0])
+        out['meta'] = np.array([T, H], dtype=np.int64)
+        save('trace_neural_' + tag, **out)
+
+
+# ---- E. CLI -------------------------------------------------------------------------------------
+
+def gen_cli():
+    import runpy
+    import shutil
+    ddir = os.path.join(HERE, 'dimacs20')
+    if os.path.isdir(ddir):
+        shutil.rmtree(ddir)
+    insts = []
+    for i in range(20):
+        n = 30 + (i % 3) * 10
+        rng = np.random.RandomState(7000 + i)
+        insts.append((n, gen.uniform_ksat(n, int(round(3.6 * n)), 3, rng)))
+    os.makedirs(ddir)
+    for i, (n, cl) in enumerate(insts):
+        gen.write_dimacs(os.path.join(ddir, 'uf_%02d_%d.cnf' % (i, i % 2)), n, cl)
+    out_path = os.path.join(HERE, 'cli_pdp_dimacs20.out.jsonl')
+    argv = ['satyr.py', '/root/reference/config/Predict/PDP-p-d-p-sp-pytorch.yaml', ddir, '50', '-d', '-c',
+            '-z', '8', '-s', '7', '-w', '40', '-o', out_path]
+    old_argv, old_cwd = sys.argv, os.getcwd()
+    sys.argv = argv
+    sys.path.insert(0, REF)
+    try:
+        runpy.run_path(os.path.join(REF, 'satyr.py'), run_name='__main__')
+    finally:
+        sys.argv = old_argv
+        os.chdir(old_cwd)
+    # also keep the intermediate JSON the reference converter produced (loader golden vector)
+    import dimacs2json as RDJ
+    RDJ.convert_directory(ddir, os.path.join(HERE, 'cli_dimacs20.converted.jsonl'), False)
+    print('wrote', out_path)
+
+
+if __name__ == '__main__':
+    what = sys.argv[1:] or ['problem', 'ops', 'traces', 'neural', 'cli']
+    lines = None
+    if 'problem' in what or 'ops' in what:
+        lines = gen_loader_and_simplify()
+    if 'ops' in what:
+        gen_ops(lines)
+    if 'traces' in what:
+        gen_traces()
+    if 'neural' in what:
+        gen_neural()
+    if 'cli' in what:
+        gen_cli()
