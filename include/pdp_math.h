@@ -1,0 +1,194 @@
+/*
+ * pdp_math.h -- exact, platform-independent fp32 math shared by the HIP kernels and the CPU oracle.
+ *
+ * Why this exists: the PDP hot path takes DISCRETE decisions (decimation arg-max, convergence
+ * thresholds, clause satisfaction) on top of fp32 messages that go through exp/log
+ * (reference: src/pdp/nn/pdp_propagate.py:133-137, src/pdp/nn/pdp_predict.py:149-153,
+ * src/pdp/nn/util.py:277-286).  A vendor libm on the host (glibc / Sleef inside torch) and OCML on
+ * gfx950 differ in the last bit, which makes end-to-end integer parity unprovable.  Every function
+ * below is therefore written ONLY in terms of IEEE-754 basic operations (+ - * / fma, compares,
+ * integer bit moves), which round identically on x86-64 (SSE/FMA) and on gfx950 (denormals
+ * enabled, correctly rounded division = hipcc defaults).  Both sides must be compiled with
+ * -ffp-contract=off so that no additional fusion happens.
+ *
+ * Accuracy: pdp_expf / pdp_logf are Cephes-style minimax kernels, < 1.5 ulp over the ranges the
+ * path uses, denormal inputs and outputs handled exactly (the reference relies on
+ * log(1e-40) = -92.1034 and exp(-92.1034) = 1e-40).
+ *
+ * NaN semantics follow torch: max/min propagate NaN (torch.max(x, eps)), sign(NaN) = 0.
+ */
+#ifndef PDP_MATH_H
+#define PDP_MATH_H
+
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define PDP_HD __host__ __device__ __forceinline__
+#else
+#define PDP_HD static inline
+#endif
+
+typedef union { uint32_t u; float f; } pdp_f32_bits;
+
+PDP_HD float pdp_bits2f(uint32_t u) { pdp_f32_bits c; c.u = u; return c.f; }
+PDP_HD uint32_t pdp_f2bits(float f) { pdp_f32_bits c; c.f = f; return c.u; }
+
+#define PDP_INF  (pdp_bits2f(0x7f800000u))
+#define PDP_NAN  (pdp_bits2f(0x7fc00000u))
+
+/* torch.max / torch.min (elementwise, NaN-propagating) */
+PDP_HD float pdp_max(float a, float b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
+PDP_HD float pdp_min(float a, float b) { return (a != a) ? a : ((b != b) ? b : (a < b ? a : b)); }
+/* torch.sign: sign(NaN) == 0 */
+PDP_HD float pdp_sign(float x) { return (float)((x > 0.0f) - (x < 0.0f)); }
+PDP_HD float pdp_abs(float x) { return pdp_bits2f(pdp_f2bits(x) & 0x7fffffffu); }
+
+/* 2^n for -126 <= n <= 127 */
+PDP_HD float pdp_pow2i(int n) { return pdp_bits2f((uint32_t)(n + 127) << 23); }
+
+/* e^x.  Result is correctly scaled into the denormal range (single final rounding). */
+PDP_HD float pdp_expf(float x)
+{
+    if (x != x) return x;
+    if (x > 88.7228394f) return PDP_INF;
+    if (x < -104.0f) return 0.0f;
+    const float t = x * 1.44269504088896341f;
+    const float nf = (t + 12582912.0f) - 12582912.0f;     /* round-to-nearest-even integer */
+    float r = fmaf(nf, -0.693359375f, x);                  /* x - n*ln2 (hi, exact product) */
+    r = fmaf(nf, 2.12194440e-4f, r);                       /*           (lo)                */
+    const float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    p = fmaf(p, z, r);
+    p = p + 1.0f;
+    const int n = (int)nf;                                 /* |n| <= 151: safe conversion */
+    const int n1 = n / 2;
+    const int n2 = n - n1;
+    return (p * pdp_pow2i(n1)) * pdp_pow2i(n2);            /* first product exact, second rounds once */
+}
+
+/* e^x - 1, accurate near 0 (used by tanh) */
+PDP_HD float pdp_expm1f(float x)
+{
+    if (x != x) return x;
+    if (pdp_abs(x) < 0.34657359f) {
+        const float z = x * x;
+        float p = 1.9875691500e-4f;
+        p = fmaf(p, x, 1.3981999507e-3f);
+        p = fmaf(p, x, 8.3334519073e-3f);
+        p = fmaf(p, x, 4.1665795894e-2f);
+        p = fmaf(p, x, 1.6666665459e-1f);
+        p = fmaf(p, x, 5.0000001201e-1f);
+        return fmaf(p, z, x);
+    }
+    return pdp_expf(x) - 1.0f;
+}
+
+/* natural log, x > 0 expected (denormals fine); x == 0 -> -inf, x < 0 -> NaN */
+PDP_HD float pdp_logf(float x)
+{
+    if (x != x) return x;
+    if (x <= 0.0f) return (x == 0.0f) ? -PDP_INF : PDP_NAN;
+    uint32_t u = pdp_f2bits(x);
+    if (u == 0x7f800000u) return x;
+    int e = 0;
+    if (u < 0x00800000u) { x = x * 8388608.0f; e = -23; u = pdp_f2bits(x); }
+    e += (int)(u >> 23) - 126;                             /* x = m * 2^e, m in [0.5, 1) */
+    float m = pdp_bits2f((u & 0x007fffffu) | 0x3f000000u);
+    if (m < 0.707106781186547524f) { e -= 1; m = (m + m) - 1.0f; } else { m = m - 1.0f; }
+    const float z = m * m;
+    float y = 7.0376836292e-2f;
+    y = fmaf(y, m, -1.1514610310e-1f);
+    y = fmaf(y, m, 1.1676998740e-1f);
+    y = fmaf(y, m, -1.2420140846e-1f);
+    y = fmaf(y, m, 1.4249322787e-1f);
+    y = fmaf(y, m, -1.6668057665e-1f);
+    y = fmaf(y, m, 2.0000714765e-1f);
+    y = fmaf(y, m, -2.4999993993e-1f);
+    y = fmaf(y, m, 3.3333331174e-1f);
+    y = (y * m) * z;
+    const float fe = (float)e;
+    y = fmaf(fe, -2.12194440e-4f, y);
+    y = fmaf(-0.5f, z, y);
+    float r = m + y;
+    r = fmaf(fe, 0.693359375f, r);
+    return r;
+}
+
+/* log(1 + t) for t >= 0 (compensated) */
+PDP_HD float pdp_log1pf(float t)
+{
+    const float u = 1.0f + t;
+    if (u == 1.0f) return t;
+    if (u != u || u == PDP_INF) return u;
+    return pdp_logf(u) - ((u - 1.0f) - t) / u;
+}
+
+/* torch F.logsigmoid: min(x, 0) - log1p(exp(-|x|)) */
+PDP_HD float pdp_logsigmoidf(float x)
+{
+    if (x != x) return x;
+    const float mn = x < 0.0f ? x : 0.0f;
+    return mn - pdp_log1pf(pdp_expf(-pdp_abs(x)));
+}
+
+PDP_HD float pdp_sigmoidf(float x) { return 1.0f / (1.0f + pdp_expf(-x)); }
+
+PDP_HD float pdp_tanhf(float x)
+{
+    if (x != x) return x;
+    const float a = pdp_abs(x);
+    float r;
+    if (a > 10.0f) {
+        r = 1.0f;
+    } else {
+        const float em = pdp_expm1f(a + a);
+        r = em / (em + 2.0f);
+    }
+    return x < 0.0f ? -r : r;
+}
+
+/* ---- the reference's clamped forms ------------------------------------------------------- */
+/* safe_log(x) = log(max(x, eps))  (reference: pdp_propagate.py:133-134, pdp_predict.py:149-150) */
+PDP_HD float pdp_safe_log(float x, float eps) { return pdp_logf(pdp_max(x, eps)); }
+/* safe_exp(x) = exp(min(x, 30))   (reference: pdp_propagate.py:136-137, util.py:277-280) */
+PDP_HD float pdp_safe_exp(float x) { return pdp_expf(pdp_min(x, 30.0f)); }
+
+#define PDP_SP_EPS      1e-40f   /* SurveyPropagator eps (pdp_propagate.py:124), fp32 denormal */
+#define PDP_SCORER_EPS  1e-10f   /* SurveyScorer eps (pdp_predict.py:141) */
+
+/* ---- Philox4x32-10 counter RNG (device-side random numbers for Walk-SAT / random fill) ----
+ * Stateless: value = f(seed, stream, step, index), so the CPU oracle reproduces it bit-for-bit in
+ * any order.  Returns a float in [0, 1) with 24 random bits (same grid as torch.rand fp32). */
+PDP_HD uint32_t pdp_mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
+
+PDP_HD uint32_t pdp_philox_u32(uint64_t seed, uint32_t stream, uint32_t step, uint32_t index)
+{
+    uint32_t c0 = index, c1 = step, c2 = stream, c3 = 0x5044502du;   /* "PDP-" */
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t hi0 = pdp_mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = pdp_mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+
+PDP_HD float pdp_philox_uniform(uint64_t seed, uint32_t stream, uint32_t step, uint32_t index)
+{
+    return (float)(pdp_philox_u32(seed, stream, step, index) >> 8) * 5.9604644775390625e-8f;  /* 2^-24 */
+}
+
+#define PDP_RNG_STREAM_FILL   1u   /* IdentityPredictor random fill (pdp_predict.py:121-126) */
+#define PDP_RNG_STREAM_WSVAR  2u   /* Walk-SAT per-variable draw  (solver.py:457) */
+#define PDP_RNG_STREAM_WSCOIN 3u   /* Walk-SAT per-instance coin  (solver.py:460) */
+#define PDP_RNG_STREAM_REINF  4u   /* Reinforce decimation coin   (pdp_decimate.py:218) */
+
+#endif /* PDP_MATH_H */

@@ -1,0 +1,260 @@
+"""ctypes binding of the CPU oracle (oracle/libpdp_oracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never from the
+product package (pdp-solver_amd/).  Arrays are numpy, fp32 / int32 / uint8, C-contiguous.
+"""
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libpdp_oracle.so')
+
+_lib = None
+
+
+def build(force=False):
+    if force or not os.path.exists(LIB_PATH) or any(
+            os.path.getmtime(os.path.join(HERE, f)) > os.path.getmtime(LIB_PATH)
+            for f in ('pdp_oracle.c', 'pdp_oracle_neural.c', '../include/pdp_math.h')):
+        subprocess.check_call(['make', '-s', '-C', HERE])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = C.CDLL(LIB_PATH)
+        _lib.orc_problem_create.restype = C.c_void_p
+        _lib.orc_decimator_create.restype = C.c_void_p
+        _lib.orc_refresh_edge_mask.restype = C.c_double
+        _lib.orc_sequential_decimate.restype = C.c_int
+        _lib.orc_local_search.restype = C.c_int
+    return _lib
+
+
+def _f(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class ForwardArgs(C.Structure):
+    _fields_ = [
+        ('model', C.c_int), ('iterations', C.c_int), ('local_search_iterations', C.c_int),
+        ('epsilon', C.c_float), ('tolerance', C.c_float), ('t_max', C.c_float), ('pi', C.c_float),
+        ('decimation_probability', C.c_float),
+        ('rng_mode', C.c_int), ('stream', C.c_void_p), ('n_stream', C.c_int64), ('seed', C.c_uint64),
+        ('prediction', C.c_void_p), ('q', C.c_void_p), ('fs', C.c_void_p),
+        ('iterations_run', C.c_void_p), ('rand_consumed', C.c_void_p), ('walksat_steps', C.c_void_p),
+        ('trace_active_var', C.c_void_p), ('trace_active_fn', C.c_void_p), ('trace_solution', C.c_void_p),
+        ('trace_active_mask', C.c_void_p), ('trace_q', C.c_void_p), ('trace_fs', C.c_void_p),
+    ]
+
+
+MODELS = {'p-d-p': 0, 'walk-sat': 1, 'reinforce': 2}
+
+
+class Problem(object):
+    """A batch of CNF instances (the oracle's SATProblem)."""
+
+    def __init__(self, graph_map, batch_variable_map, batch_function_map, edge_feature, replication=1):
+        L = lib()
+        gm = np.ascontiguousarray(graph_map, dtype=np.int32)
+        bvm = np.ascontiguousarray(batch_variable_map, dtype=np.int32)
+        bfm = np.ascontiguousarray(batch_function_map, dtype=np.int32)
+        ef = _f(np.asarray(edge_feature).reshape(-1))
+        self._h = C.c_void_p(L.orc_problem_create(C.c_int(gm.shape[1]), C.c_int(bvm.size), C.c_int(bfm.size),
+                                                 _p(gm), _p(bvm), _p(bfm), _p(ef), C.c_int(replication)))
+        dims = np.zeros(5, dtype=np.int32)
+        L.orc_problem_dims(self._h, _p(dims))
+        self.E, self.V, self.F, self.B, self.R = [int(x) for x in dims]
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().orc_problem_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # -- state ---------------------------------------------------------------------------
+    def state(self):
+        av = np.zeros(self.V, np.float32); af = np.zeros(self.F, np.float32)
+        sol = np.zeros(self.V, np.float32); sat = np.zeros(self.B, np.float32)
+        lib().orc_problem_get_state(self._h, _p(av), _p(af), _p(sol), _p(sat))
+        return av, af, sol, sat
+
+    def set_state(self, active_var=None, active_fn=None, solution=None):
+        lib().orc_problem_set_state(self._h, _p(_f(active_var)), _p(_f(active_fn)), _p(_f(solution)))
+
+    def graph(self):
+        ev = np.zeros(self.E, np.int32); ec = np.zeros(self.E, np.int32); es = np.zeros(self.E, np.float32)
+        vi = np.zeros(self.V, np.int32); fi = np.zeros(self.F, np.int32)
+        lib().orc_problem_get_graph(self._h, _p(ev), _p(ec), _p(es), _p(vi), _p(fi))
+        return ev, ec, es, vi, fi
+
+    # -- K7 -----------------------------------------------------------------------------
+    def simplify(self):
+        lib().orc_simplify(self._h)
+
+    def set_variables(self, assignment):
+        a = _f(assignment).copy()
+        lib().orc_set_variables(self._h, _p(a))
+        return a
+
+    # -- K8 -----------------------------------------------------------------------------
+    def refresh_edge_mask(self):
+        s = lib().orc_refresh_edge_mask(self._h)
+        m = np.zeros(self.E, np.float32)
+        lib().orc_get_edge_mask(self._h, _p(m))
+        return m, s
+
+    def set_edge_mask(self, m):
+        lib().orc_set_edge_mask(self._h, _p(_f(m)))
+
+    # -- K4/K5 --------------------------------------------------------------------------
+    def smooth_max(self, x):
+        out = np.zeros(self.V, np.float32)
+        lib().orc_smooth_max(self._h, _p(_f(x)), _p(out))
+        return out
+
+    def instance_max(self, x):
+        out = np.zeros(self.B, np.float32)
+        lib().orc_instance_max(self._h, _p(_f(x)), _p(out))
+        return out
+
+    def instance_argmax(self, x):
+        out = np.zeros(self.B, np.int64)
+        lib().orc_instance_argmax(self._h, _p(_f(x)), _p(out))
+        return out
+
+    # -- K1-K3, K6 ----------------------------------------------------------------------
+    def sp_propagate(self, dec_q, dec_fs, edge_mask, active_mask, init_q, init_fs, pi=0.0):
+        oq = np.zeros((self.E, 3), np.float32); ofs = np.zeros((self.E, 2), np.float32)
+        am = None if active_mask is None else np.ascontiguousarray(active_mask, dtype=np.uint8)
+        lib().orc_sp_propagate(self._h, _p(_f(dec_q)), _p(_f(dec_fs)), _p(_f(edge_mask)), _p(am),
+                               _p(_f(init_q)), _p(_f(init_fs)), C.c_float(pi), _p(oq), _p(ofs))
+        return oq, ofs
+
+    def survey_score(self, fs, pi=0.0):
+        out = np.zeros(self.V, np.float32)
+        lib().orc_survey_score(self._h, _p(_f(fs)), C.c_float(pi), _p(out))
+        return out
+
+    # -- K9, K13 ------------------------------------------------------------------------
+    def cnf_eval(self, pred):
+        s = np.zeros(self.B, np.float32); u = np.zeros(self.B, np.float32)
+        lib().orc_cnf_eval(self._h, _p(_f(pred)), _p(s), _p(u))
+        return s, u
+
+    def update_solution(self, pred):
+        out = np.zeros(self.V, np.float32)
+        lib().orc_update_solution(self._h, _p(_f(pred)), _p(out))
+        return out
+
+    def check_termination(self, active_mask, pred):
+        am = np.ascontiguousarray(active_mask, dtype=np.uint8).copy()
+        lib().orc_check_termination(self._h, _p(am), _p(_f(pred)))
+        return am
+
+    # -- decimators ---------------------------------------------------------------------
+    def new_decimator(self):
+        return C.c_void_p(lib().orc_decimator_create(self._h))
+
+    def free_decimator(self, d):
+        lib().orc_decimator_destroy(d)
+
+    def decimator_set(self, d, prev, counters, has_prev):
+        lib().orc_decimator_set(self._h, d, _p(_f(prev)), _p(_f(counters)), C.c_int(int(has_prev)))
+
+    def decimator_get(self, d):
+        prev = np.zeros(self.E, np.float32); cnt = np.zeros(self.B, np.float32); fl = np.zeros(2, np.int32)
+        lib().orc_decimator_get(self._h, d, _p(prev), _p(cnt), _p(fl))
+        return prev, cnt, fl
+
+    def sequential_decimate(self, d, fs, active_mask, tolerance, t_max, pi=0.0):
+        am = None if active_mask is None else np.ascontiguousarray(active_mask, dtype=np.uint8).copy()
+        n = lib().orc_sequential_decimate(self._h, d, _p(_f(fs)), _p(am), C.c_float(tolerance), C.c_float(t_max), C.c_float(pi))
+        return am, n
+
+    # -- K14 ----------------------------------------------------------------------------
+    def energy(self, assignment):
+        en = np.zeros(self.B, np.float32); uf = np.zeros(self.F, np.float32)
+        lib().orc_energy(self._h, _p(_f(assignment)), _p(en), _p(uf))
+        return en, uf
+
+    def energy_diff(self, assignment):
+        d = np.zeros(self.V, np.float32)
+        lib().orc_energy_diff(self._h, _p(_f(assignment)), _p(d))
+        return d
+
+    def local_search(self, pred, iterations, epsilon, stream=None, seed=0, cursor=0):
+        out = np.zeros(self.V, np.float32)
+        cur = C.c_int64(cursor)
+        st = _f(stream)
+        n = lib().orc_local_search(self._h, _p(_f(pred)), C.c_int(iterations), C.c_float(epsilon),
+                                   C.c_int(0 if stream is not None else 1), _p(st),
+                                   C.c_int64(0 if st is None else st.size), C.byref(cur), C.c_uint64(seed), _p(out))
+        return out, n, cur.value
+
+    def random_fill(self, stream=None, seed=0, cursor=0):
+        cur = C.c_int64(cursor)
+        st = _f(stream)
+        lib().orc_random_fill(self._h, C.c_int(0 if stream is not None else 1), _p(st),
+                              C.c_int64(0 if st is None else st.size), C.byref(cur), C.c_uint64(seed))
+        return cur.value
+
+    def deduplicate(self, pred):
+        out = np.zeros(self.V // self.R, np.float32); ch = np.zeros(self.B // self.R, np.int32)
+        lib().orc_deduplicate(self._h, _p(_f(pred)), _p(out), _p(ch))
+        return out, ch
+
+    # -- whole forward ------------------------------------------------------------------
+    def forward(self, model, iterations, local_search_iterations=0, epsilon=0.5, tolerance=0.02, t_max=100,
+                pi=0.0, decimation_probability=0.5, stream=None, seed=0, trace=False, trace_float=False):
+        a = ForwardArgs()
+        a.model = MODELS[model]; a.iterations = iterations; a.local_search_iterations = local_search_iterations
+        a.epsilon = epsilon; a.tolerance = tolerance; a.t_max = t_max; a.pi = pi
+        a.decimation_probability = decimation_probability
+        st = _f(stream)
+        a.rng_mode = 0 if stream is not None else 1
+        a.stream = _p(st); a.n_stream = 0 if st is None else st.size; a.seed = seed
+        T = max(iterations, 1)
+        res = dict(prediction=np.zeros(self.V // self.R, np.float32), q=np.zeros((self.E, 3), np.float32),
+                   fs=np.zeros((self.E, 2), np.float32), iterations_run=np.zeros(1, np.int32),
+                   rand_consumed=np.zeros(1, np.int64), walksat_steps=np.zeros(1, np.int32))
+        for k in ('prediction', 'q', 'fs', 'iterations_run', 'rand_consumed', 'walksat_steps'):
+            setattr(a, k, _p(res[k]))
+        if trace:
+            res['trace_active_var'] = np.zeros((T, self.V), np.float32)
+            res['trace_active_fn'] = np.zeros((T, self.F), np.float32)
+            res['trace_solution'] = np.zeros((T, self.V), np.float32)
+            res['trace_active_mask'] = np.zeros((T, self.B), np.uint8)
+            for k in ('trace_active_var', 'trace_active_fn', 'trace_solution', 'trace_active_mask'):
+                setattr(a, k, _p(res[k]))
+        if trace_float:
+            res['trace_q'] = np.zeros((T, self.E, 3), np.float32)
+            res['trace_fs'] = np.zeros((T, self.E, 2), np.float32)
+            a.trace_q = _p(res['trace_q']); a.trace_fs = _p(res['trace_fs'])
+        lib().orc_forward(self._h, C.byref(a))
+        res['iterations_run'] = int(res['iterations_run'][0])
+        res['rand_consumed'] = int(res['rand_consumed'][0])
+        res['walksat_steps'] = int(res['walksat_steps'][0])
+        return res
+
+
+def math_apply(fn, x):
+    names = {'exp': 0, 'log': 1, 'logsigmoid': 2, 'sigmoid': 3, 'tanh': 4, 'safe_exp': 5, 'safe_log': 6,
+             'philox': 7, 'rcp': 8}
+    x = _f(x)
+    y = np.zeros_like(x)
+    lib().orc_math_apply(C.c_int(names[fn]), _p(x), _p(y), C.c_int64(x.size))
+    return y

@@ -1,0 +1,978 @@
+/*
+ * pdp_oracle.c -- CPU restatement of the reference's PDP hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the parity oracle for the HIP kernels in pdp-solver_amd/csrc.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the product never does.
+ *
+ * It restates, operation by operation and in the reference's evaluation order, the functions
+ * listed in SURVEY.md section 8(a).  Batch-wide ("strict") semantics are kept, including the
+ * accidental cross-instance couplings of the reference (global x.min() inside sparse_max /
+ * sparse_argmax, global `.sum() > 0` guards, NaN poisoning -- SURVEY.md App. B-6).
+ * All sparse-matrix products of the reference (torch.mm(sparse COO, dense)) are sequential fp32
+ * accumulations in ascending edge id starting from +0.0f, which is what torch's CPU kernel does.
+ *
+ * Transcendentals come from include/pdp_math.h (IEEE-basic-op only), the same header the HIP
+ * kernels use, so HIP-vs-oracle comparisons are bit exact; oracle-vs-reference comparisons
+ * (tests/golden) are tolerance based for floats and exact for integer outputs.
+ * Parity is PINNED: tests/test_oracle_golden.py checks every function below against vectors
+ * captured from the unmodified reference (tests/golden/generate_golden.py).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -mfma -ffp-contract=off).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <math.h>
+
+#include "../include/pdp_math.h"
+
+#define ORC_API __attribute__((visibility("default")))
+
+typedef struct orc_problem {
+    int E, V, F, B;
+    int replication;          /* batch replication factor R (B = B0 * R) */
+    int *edge_var;            /* [E] graph_map row 0  (reference: solver.py:161) */
+    int *edge_fn;             /* [E] graph_map row 1 */
+    float *edge_sign;         /* [E] edge_feature */
+    int *var_ptr, *var_edges; /* CSR by variable, ascending edge id */
+    int *fn_ptr, *fn_edges;   /* CSR by clause,   ascending edge id */
+    int *var_inst, *fn_inst;  /* batch_variable_map / batch_function_map */
+    float *active_var;        /* [V] sat_problem._active_variables (solver.py:49) */
+    float *active_fn;         /* [F] sat_problem._active_functions (solver.py:50) */
+    float *solution;          /* [V] sat_problem._solution         (solver.py:51) */
+    float *is_sat;            /* [B] sat_problem._is_sat           (solver.py:54) */
+    float *edge_mask;         /* [E] sat_problem._edge_mask or NULL-equivalent (has_edge_mask) */
+    int has_edge_mask;
+} orc_problem;
+
+static void *xcalloc(size_t n, size_t s) { void *p = calloc(n ? n : 1, s); if (!p) { fprintf(stderr, "oracle: OOM\n"); abort(); } return p; }
+
+/* ------------------------------------------------------------------------------------------
+ * Problem set-up.  reference: SATProblem.setup_problem solver.py:28-54; the 24 sparse masks of
+ * solver.py:84-178 are represented by two CSR structures + the batch maps.
+ * ------------------------------------------------------------------------------------------ */
+static void build_csr(int n_rows, int E, const int *row_of_edge, int **ptr_out, int **idx_out)
+{
+    int *ptr = (int *)xcalloc((size_t)n_rows + 1, sizeof(int));
+    int *idx = (int *)xcalloc((size_t)E, sizeof(int));
+    for (int e = 0; e < E; ++e) ptr[row_of_edge[e] + 1]++;
+    for (int r = 0; r < n_rows; ++r) ptr[r + 1] += ptr[r];
+    int *cur = (int *)xcalloc((size_t)n_rows, sizeof(int));
+    for (int e = 0; e < E; ++e) { int r = row_of_edge[e]; idx[ptr[r] + cur[r]++] = e; }
+    free(cur);
+    *ptr_out = ptr; *idx_out = idx;
+}
+
+ORC_API orc_problem *orc_problem_create(int E, int V, int F, const int32_t *graph_map /*[2,E]*/,
+                                        const int32_t *batch_variable_map, const int32_t *batch_function_map,
+                                        const float *edge_feature, int replication)
+{
+    /* batch replication: replica r of instance i gets id i + r*B0, variables offset r*V0,
+     * clauses offset r*F0 (reference: SATProblem._replicate_batch solver.py:56-82). */
+    int R = replication < 1 ? 1 : replication;
+    int B0 = 0;
+    for (int i = 0; i < V; ++i) if (batch_variable_map[i] + 1 > B0) B0 = batch_variable_map[i] + 1;
+    orc_problem *p = (orc_problem *)xcalloc(1, sizeof(orc_problem));
+    p->E = E * R; p->V = V * R; p->F = F * R; p->B = B0 * R; p->replication = R;
+    p->edge_var = (int *)xcalloc((size_t)p->E, sizeof(int));
+    p->edge_fn = (int *)xcalloc((size_t)p->E, sizeof(int));
+    p->edge_sign = (float *)xcalloc((size_t)p->E, sizeof(float));
+    p->var_inst = (int *)xcalloc((size_t)p->V, sizeof(int));
+    p->fn_inst = (int *)xcalloc((size_t)p->F, sizeof(int));
+    for (int r = 0; r < R; ++r) {
+        for (int e = 0; e < E; ++e) {
+            p->edge_var[r * E + e] = graph_map[e] + r * V;
+            p->edge_fn[r * E + e] = graph_map[E + e] + r * F;
+            p->edge_sign[r * E + e] = edge_feature[e];
+        }
+        for (int i = 0; i < V; ++i) p->var_inst[r * V + i] = batch_variable_map[i] + r * B0;
+        for (int c = 0; c < F; ++c) p->fn_inst[r * F + c] = batch_function_map[c] + r * B0;
+    }
+    build_csr(p->V, p->E, p->edge_var, &p->var_ptr, &p->var_edges);
+    build_csr(p->F, p->E, p->edge_fn, &p->fn_ptr, &p->fn_edges);
+    p->active_var = (float *)xcalloc((size_t)p->V, sizeof(float));
+    p->active_fn = (float *)xcalloc((size_t)p->F, sizeof(float));
+    p->solution = (float *)xcalloc((size_t)p->V, sizeof(float));
+    p->is_sat = (float *)xcalloc((size_t)p->B, sizeof(float));
+    p->edge_mask = (float *)xcalloc((size_t)p->E, sizeof(float));
+    for (int i = 0; i < p->V; ++i) { p->active_var[i] = 1.0f; p->solution[i] = 0.5f; }
+    for (int c = 0; c < p->F; ++c) p->active_fn[c] = 1.0f;
+    for (int b = 0; b < p->B; ++b) p->is_sat[b] = 0.5f;
+    p->has_edge_mask = 0;
+    return p;
+}
+
+ORC_API void orc_problem_destroy(orc_problem *p)
+{
+    if (!p) return;
+    free(p->edge_var); free(p->edge_fn); free(p->edge_sign); free(p->var_ptr); free(p->var_edges);
+    free(p->fn_ptr); free(p->fn_edges); free(p->var_inst); free(p->fn_inst); free(p->active_var);
+    free(p->active_fn); free(p->solution); free(p->is_sat); free(p->edge_mask); free(p);
+}
+
+ORC_API void orc_problem_dims(const orc_problem *p, int *dims /*[5]: E,V,F,B,R*/)
+{ dims[0] = p->E; dims[1] = p->V; dims[2] = p->F; dims[3] = p->B; dims[4] = p->replication; }
+
+/* accessors (copy out / in) */
+ORC_API void orc_problem_get_state(const orc_problem *p, float *active_var, float *active_fn, float *solution, float *is_sat)
+{
+    if (active_var) memcpy(active_var, p->active_var, sizeof(float) * (size_t)p->V);
+    if (active_fn) memcpy(active_fn, p->active_fn, sizeof(float) * (size_t)p->F);
+    if (solution) memcpy(solution, p->solution, sizeof(float) * (size_t)p->V);
+    if (is_sat) memcpy(is_sat, p->is_sat, sizeof(float) * (size_t)p->B);
+}
+ORC_API void orc_problem_set_state(orc_problem *p, const float *active_var, const float *active_fn, const float *solution)
+{
+    if (active_var) memcpy(p->active_var, active_var, sizeof(float) * (size_t)p->V);
+    if (active_fn) memcpy(p->active_fn, active_fn, sizeof(float) * (size_t)p->F);
+    if (solution) memcpy(p->solution, solution, sizeof(float) * (size_t)p->V);
+}
+ORC_API void orc_problem_get_graph(const orc_problem *p, int32_t *edge_var, int32_t *edge_fn, float *edge_sign,
+                                   int32_t *var_inst, int32_t *fn_inst)
+{
+    if (edge_var) memcpy(edge_var, p->edge_var, sizeof(int) * (size_t)p->E);
+    if (edge_fn) memcpy(edge_fn, p->edge_fn, sizeof(int) * (size_t)p->E);
+    if (edge_sign) memcpy(edge_sign, p->edge_sign, sizeof(float) * (size_t)p->E);
+    if (var_inst) memcpy(var_inst, p->var_inst, sizeof(int) * (size_t)p->V);
+    if (fn_inst) memcpy(fn_inst, p->fn_inst, sizeof(int) * (size_t)p->F);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * sparse-mm building blocks (sequential fp32 accumulation, ascending edge id, from +0.0f)
+ * ------------------------------------------------------------------------------------------ */
+/* out[v] = sum_{e in v} w(e) * x[e]   with w = 1 (mode 0), [s==+1] (1), [s==-1] (2), s (3) */
+static void var_sum(const orc_problem *p, const float *x, int mode, float *out)
+{
+    for (int v = 0; v < p->V; ++v) {
+        float acc = 0.0f;
+        for (int k = p->var_ptr[v]; k < p->var_ptr[v + 1]; ++k) {
+            const int e = p->var_edges[k];
+            const float s = p->edge_sign[e];
+            float w = 1.0f;
+            if (mode == 1) w = (s == 1.0f) ? 1.0f : 0.0f;
+            else if (mode == 2) w = (s == -1.0f) ? 1.0f : 0.0f;
+            else if (mode == 3) w = s;
+            acc = acc + w * x[e];
+        }
+        out[v] = acc;
+    }
+}
+static void fn_sum(const orc_problem *p, const float *x, float *out)
+{
+    for (int c = 0; c < p->F; ++c) {
+        float acc = 0.0f;
+        for (int k = p->fn_ptr[c]; k < p->fn_ptr[c + 1]; ++k) acc = acc + x[p->fn_edges[k]];
+        out[c] = acc;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * K7: fixing variables, unit propagation, pure-literal peeling
+ * ------------------------------------------------------------------------------------------ */
+/* reference: SATProblem._set_variable_core solver.py:205-226 (assignment is modified in place) */
+static void set_variable_core(orc_problem *p, float *assignment)
+{
+    const int V = p->V, F = p->F;
+    for (int v = 0; v < V; ++v) assignment[v] = assignment[v] * p->active_var[v];
+    float *deact = (float *)xcalloc((size_t)F, sizeof(float));
+    for (int c = 0; c < F; ++c) {
+        float input_num = 0.0f, function_eval = 0.0f;
+        for (int k = p->fn_ptr[c]; k < p->fn_ptr[c + 1]; ++k) {
+            const int e = p->fn_edges[k];
+            const float a = assignment[p->edge_var[e]];
+            input_num = input_num + pdp_abs(a);
+            function_eval = function_eval + p->edge_sign[e] * a;
+        }
+        deact[c] = ((function_eval > -input_num) ? 1.0f : 0.0f) * p->active_fn[c];
+    }
+    for (int v = 0; v < V; ++v) if (pdp_abs(assignment[v]) == 1.0f) p->active_var[v] = 0.0f;
+    for (int c = 0; c < F; ++c) if (deact[c] == 1.0f) p->active_fn[c] = 0.0f;
+    for (int v = 0; v < V; ++v) if (pdp_abs(assignment[v]) == 1.0f) p->solution[v] = (assignment[v] + 1.0f) / 2.0f;
+    free(deact);
+}
+
+/* reference: SATProblem._propagate_single_clauses solver.py:228-273 */
+static void propagate_single_clauses(orc_problem *p)
+{
+    const int V = p->V, F = p->F, B = p->B;
+    float *single = (float *)xcalloc((size_t)F, sizeof(float));
+    float *input_num = (float *)xcalloc((size_t)V, sizeof(float));
+    float *var_eval = (float *)xcalloc((size_t)V, sizeof(float));
+    float *conflict = (float *)xcalloc((size_t)V, sizeof(float));
+    float *unsat_ex = (float *)xcalloc((size_t)B, sizeof(float));
+    float *assignment = (float *)xcalloc((size_t)V, sizeof(float));
+    for (;;) {
+        float total = 0.0f;
+        for (int c = 0; c < F; ++c) {
+            float deg = 0.0f;
+            for (int k = p->fn_ptr[c]; k < p->fn_ptr[c + 1]; ++k) deg = deg + p->active_var[p->edge_var[p->fn_edges[k]]];
+            single[c] = ((deg == 1.0f) ? 1.0f : 0.0f) * p->active_fn[c];
+            total += single[c];
+        }
+        if (total <= 0.0f) break;
+        float n_conf = 0.0f;
+        for (int v = 0; v < V; ++v) {
+            float in = 0.0f, ev = 0.0f;
+            for (int k = p->var_ptr[v]; k < p->var_ptr[v + 1]; ++k) {
+                const int e = p->var_edges[k];
+                in = in + single[p->edge_fn[e]];
+                ev = ev + p->edge_sign[e] * single[p->edge_fn[e]];
+            }
+            input_num[v] = in; var_eval[v] = ev;
+            conflict[v] = ((pdp_abs(ev) != in) ? 1.0f : 0.0f) * p->active_var[v];
+            n_conf += conflict[v];
+        }
+        if (n_conf > 0.0f) {
+            for (int b = 0; b < B; ++b) unsat_ex[b] = 0.0f;
+            for (int v = 0; v < V; ++v) unsat_ex[p->var_inst[v]] = unsat_ex[p->var_inst[v]] + conflict[v];
+            for (int b = 0; b < B; ++b) if (unsat_ex[b] >= 1.0f) p->is_sat[b] = 0.0f;
+            /* NB the reference compares the (count * active) products with == 1 (solver.py:257,261) */
+            for (int c = 0; c < F; ++c) if (unsat_ex[p->fn_inst[c]] * p->active_fn[c] == 1.0f) p->active_fn[c] = 0.0f;
+            for (int v = 0; v < V; ++v) if (unsat_ex[p->var_inst[v]] * p->active_var[v] == 1.0f) p->active_var[v] = 0.0f;
+        }
+        for (int v = 0; v < V; ++v) {
+            const float assigned = ((pdp_abs(var_eval[v]) == input_num[v]) ? 1.0f : 0.0f) * p->active_var[v];
+            assignment[v] = pdp_sign(var_eval[v]) * assigned;
+        }
+        for (int c = 0; c < F; ++c) if (single[c] == 1.0f) p->active_fn[c] = 0.0f;
+        set_variable_core(p, assignment);
+    }
+    free(single); free(input_num); free(var_eval); free(conflict); free(unsat_ex); free(assignment);
+}
+
+/* reference: SATProblem._peel solver.py:180-203 */
+static void peel(orc_problem *p)
+{
+    const int V = p->V, F = p->F;
+    float *deg = (float *)xcalloc((size_t)V, sizeof(float));
+    float *sdeg = (float *)xcalloc((size_t)V, sizeof(float));
+    float *single_v = (float *)xcalloc((size_t)V, sizeof(float));
+    float *single_f = (float *)xcalloc((size_t)F, sizeof(float));
+    for (int v = 0; v < V; ++v) {
+        float d = 0.0f, s = 0.0f;
+        for (int k = p->var_ptr[v]; k < p->var_ptr[v + 1]; ++k) {
+            const int e = p->var_edges[k];
+            d = d + p->active_fn[p->edge_fn[e]];
+            s = s + p->edge_sign[e] * p->active_fn[p->edge_fn[e]];
+        }
+        deg[v] = d; sdeg[v] = s;
+    }
+    for (;;) {
+        float total = 0.0f;
+        for (int v = 0; v < V; ++v) {
+            single_v[v] = ((deg[v] == pdp_abs(sdeg[v])) ? 1.0f : 0.0f) * p->active_var[v];
+            total += single_v[v];
+        }
+        if (total <= 0.0f) break;
+        for (int c = 0; c < F; ++c) {
+            float acc = 0.0f;
+            for (int k = p->fn_ptr[c]; k < p->fn_ptr[c + 1]; ++k) acc = acc + single_v[p->edge_var[p->fn_edges[k]]];
+            single_f[c] = ((acc > 0.0f) ? 1.0f : 0.0f) * p->active_fn[c];
+        }
+        for (int v = 0; v < V; ++v) {
+            float dd = 0.0f, sd = 0.0f;
+            for (int k = p->var_ptr[v]; k < p->var_ptr[v + 1]; ++k) {
+                const int e = p->var_edges[k];
+                dd = dd + single_f[p->edge_fn[e]];
+                sd = sd + p->edge_sign[e] * single_f[p->edge_fn[e]];
+            }
+            dd = dd * p->active_var[v]; sd = sd * p->active_var[v];
+            if (single_v[v] == 1.0f) p->solution[v] = (pdp_sign(sdeg[v]) + 1.0f) / 2.0f;
+            deg[v] = deg[v] - dd; sdeg[v] = sdeg[v] - sd;
+        }
+        for (int v = 0; v < V; ++v) if (single_v[v] == 1.0f) p->active_var[v] = 0.0f;
+        for (int c = 0; c < F; ++c) if (single_f[c] == 1.0f) p->active_fn[c] = 0.0f;
+    }
+    free(deg); free(sdeg); free(single_v); free(single_f);
+}
+
+/* reference: SATProblem.simplify solver.py:281-285 */
+ORC_API void orc_simplify(orc_problem *p) { propagate_single_clauses(p); peel(p); }
+
+/* reference: SATProblem.set_variables solver.py:275-279; `assignment` [V] is modified in place */
+ORC_API void orc_set_variables(orc_problem *p, float *assignment) { set_variable_core(p, assignment); orc_simplify(p); }
+
+/* K8. reference: solver.py:370-371 / 439-440.  Returns the float sum (compared with E by the caller). */
+ORC_API double orc_refresh_edge_mask(orc_problem *p)
+{
+    double s = 0.0;
+    for (int e = 0; e < p->E; ++e) {
+        const float a = 0.0f + p->active_var[p->edge_var[e]];
+        const float b = 0.0f + p->active_fn[p->edge_fn[e]];
+        p->edge_mask[e] = a * b;
+        s += p->edge_mask[e];
+    }
+    p->has_edge_mask = 1;
+    return s;
+}
+ORC_API void orc_get_edge_mask(const orc_problem *p, float *out) { memcpy(out, p->edge_mask, sizeof(float) * (size_t)p->E); }
+ORC_API void orc_set_edge_mask(orc_problem *p, const float *in) { memcpy(p->edge_mask, in, sizeof(float) * (size_t)p->E); p->has_edge_mask = 1; }
+
+/* ------------------------------------------------------------------------------------------
+ * K4 / K5: smooth max per variable, exact max / arg-max per instance
+ * ------------------------------------------------------------------------------------------ */
+/* reference: util.sparse_smooth_max util.py:282-286 (mask = variable_mask [V x E], alpha = 30) */
+ORC_API void orc_smooth_max(const orc_problem *p, const float *x /*[E]*/, float *out /*[V]*/)
+{
+    for (int v = 0; v < p->V; ++v) {
+        float num = 0.0f, den = 0.0f;
+        for (int k = p->var_ptr[v]; k < p->var_ptr[v + 1]; ++k) {
+            const float xe = x[p->var_edges[k]];
+            const float coeff = pdp_safe_exp(30.0f * xe);
+            num = num + xe * coeff;
+            den = den + coeff;
+        }
+        out[v] = num / pdp_max(den, 1.0f);
+    }
+}
+
+static float global_min(const float *x, int n)
+{
+    float m = PDP_INF;
+    for (int i = 0; i < n; ++i) { if (x[i] != x[i]) return x[i]; if (x[i] < m) m = x[i]; }
+    return m;
+}
+
+/* generic "dense [N x G] column max" of the reference: rows i with group[i] == g hold
+ * (x[i] - min(x)) + 1, every other row holds 0 (reference: util.sparse_max util.py:267-275). */
+static void group_max(const float *x, const int *group, int N, int G, float *out)
+{
+    const float gmin = global_min(x, N);
+    int *cnt = (int *)xcalloc((size_t)G, sizeof(int));
+    for (int g = 0; g < G; ++g) out[g] = -PDP_INF;
+    for (int i = 0; i < N; ++i) {
+        const float t = (x[i] - gmin) + 1.0f;
+        const int g = group[i];
+        cnt[g]++;
+        out[g] = pdp_max(out[g], t);
+    }
+    for (int g = 0; g < G; ++g) {
+        if (cnt[g] < N) out[g] = pdp_max(out[g], 0.0f);   /* zero rows of the dense matrix */
+        out[g] = (out[g] + gmin) - 1.0f;
+    }
+    free(cnt);
+}
+/* reference: util.sparse_argmax util.py:257-265; first index wins ties, NaN counts as maximal */
+static void group_argmax(const float *x, const int *group, int N, int G, int64_t *out)
+{
+    const float gmin = global_min(x, N);
+    float *best = (float *)xcalloc((size_t)G, sizeof(float));
+    int *state = (int *)xcalloc((size_t)G, sizeof(int));   /* 0: nothing seen, 1: value, 2: NaN locked */
+    for (int g = 0; g < G; ++g) out[g] = -1;
+    /* torch.argmax over the dense column scans rows 0..N-1: zeros before the first member row can
+     * win only if every member value is <= 0, impossible for finite data since values are >= 1. */
+    for (int i = 0; i < N; ++i) {
+        const float t = (x[i] - gmin) + 1.0f;
+        const int g = group[i];
+        if (state[g] == 2) continue;
+        if (t != t) { out[g] = i; state[g] = 2; continue; }
+        if (state[g] == 0 || t > best[g]) { best[g] = t; out[g] = i; state[g] = 1; }
+    }
+    for (int g = 0; g < G; ++g) if (state[g] == 0) out[g] = 0;   /* empty column: argmax of zeros */
+    free(best); free(state);
+}
+
+ORC_API void orc_instance_max(const orc_problem *p, const float *x /*[V]*/, float *out /*[B]*/)
+{ group_max(x, p->var_inst, p->V, p->B, out); }
+ORC_API void orc_instance_argmax(const orc_problem *p, const float *x /*[V]*/, int64_t *out /*[B]*/)
+{ group_argmax(x, p->var_inst, p->V, p->B, out); }
+
+/* ------------------------------------------------------------------------------------------
+ * K1-K3: Survey propagation sweep.  reference: SurveyPropagator.forward pdp_propagate.py:139-221
+ * (include_adaptors = False).  q_* are [E,3] row-major, fs_* are [E,2] row-major.
+ * `dec_q`/`dec_fs` = decimator_state, `init_q`/`init_fs` = init_state (previous propagator state).
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_sp_propagate(const orc_problem *p, const float *dec_q, const float *dec_fs, const float *edge_mask /*or NULL*/,
+                              const uint8_t *active_mask /*[B] or NULL*/, const float *init_q, const float *init_fs,
+                              float pi, float *out_q, float *out_fs)
+{
+    const int E = p->E, V = p->V, F = p->F;
+    float *x = (float *)xcalloc((size_t)E, sizeof(float));
+    float *y = (float *)xcalloc((size_t)E, sizeof(float));
+    float *S = (float *)xcalloc((size_t)F, sizeof(float));
+    float *P = (float *)xcalloc((size_t)V, sizeof(float));
+    float *N = (float *)xcalloc((size_t)V, sizeof(float));
+    for (int e = 0; e < E; ++e) {
+        x[e] = pdp_safe_log(dec_q[3 * e + 0], PDP_SP_EPS);
+        y[e] = pdp_safe_log(1.0f - dec_fs[2 * e + 0], PDP_SP_EPS);
+        if (edge_mask) { x[e] = x[e] * edge_mask[e]; y[e] = y[e] * edge_mask[e]; }
+    }
+    fn_sum(p, x, S);
+    var_sum(p, y, 1, P);
+    var_sum(p, y, 2, N);
+    for (int e = 0; e < E; ++e) {
+        const int v = p->edge_var[e], c = p->edge_fn[e];
+        const float s = p->edge_sign[e];
+        const float mask = active_mask ? (0.0f + (0.0f + (float)active_mask[p->var_inst[v]])) : 1.0f;
+        /* functions --> variables (pdp_propagate.py:166-175) */
+        const float agg = (0.0f + S[c]) - x[e];
+        const float eta = mask * pdp_safe_exp(agg) + (1.0f - mask) * init_fs[2 * e + 0];
+        /* variables --> functions (pdp_propagate.py:184-218) */
+        const float force = dec_fs[2 * e + 1];
+        const float pos = 0.0f + P[v], neg = 0.0f + N[v];
+        float same = (0.5f * (1.0f + s)) * pos + (0.5f * (1.0f - s)) * neg;
+        same = same - y[e];
+        same = same + pdp_safe_log(1.0f - pi * ((force == s) ? 1.0f : 0.0f), PDP_SP_EPS);
+        float opp = (0.5f * (1.0f - s)) * pos + (0.5f * (1.0f + s)) * neg;
+        opp = opp + pdp_safe_log(1.0f - pi * ((force == -s) ? 1.0f : 0.0f), PDP_SP_EPS);
+        float dc = same + opp;
+        dc = pdp_safe_exp(dc);
+        const float A = pdp_safe_exp(same), Bv = pdp_safe_exp(opp);
+        const float qu = A * (1.0f - Bv), qs = Bv * (1.0f - A);
+        const float total = (qu + qs) + dc;
+        out_q[3 * e + 0] = mask * (qu / total) + (1.0f - mask) * init_q[3 * e + 0];
+        out_q[3 * e + 1] = mask * (qs / total) + (1.0f - mask) * init_q[3 * e + 1];
+        out_q[3 * e + 2] = mask * (dc / total) + (1.0f - mask) * init_q[3 * e + 2];
+        out_fs[2 * e + 0] = eta;
+        out_fs[2 * e + 1] = force;
+    }
+    free(x); free(y); free(S); free(P); free(N);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * K6: SP bias scorer.  reference: SurveyScorer.forward pdp_predict.py:155-192 (no adaptors)
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_survey_score(const orc_problem *p, const float *fs /*[E,2]*/, float pi, float *score /*[V]*/)
+{
+    const int E = p->E, V = p->V;
+    float *fm = (float *)xcalloc((size_t)E, sizeof(float));
+    float *frc = (float *)xcalloc((size_t)E, sizeof(float));
+    float *ext = (float *)xcalloc((size_t)V, sizeof(float));
+    float *pos = (float *)xcalloc((size_t)V, sizeof(float));
+    float *neg = (float *)xcalloc((size_t)V, sizeof(float));
+    float *all = (float *)xcalloc((size_t)V, sizeof(float));
+    for (int e = 0; e < E; ++e) {
+        frc[e] = fs[2 * e + 1];
+        fm[e] = pdp_safe_log(1.0f - fs[2 * e + 0], PDP_SCORER_EPS) * (0.0f + p->active_fn[p->edge_fn[e]]);
+    }
+    var_sum(p, frc, 0, ext);
+    var_sum(p, fm, 1, pos); var_sum(p, fm, 2, neg); var_sum(p, fm, 0, all);
+    for (int v = 0; v < V; ++v) {
+        const float ef = pdp_sign(ext[v]);
+        float ps = pos[v] + pdp_safe_log(1.0f - pi * ((ef == 1.0f) ? 1.0f : 0.0f), PDP_SCORER_EPS);
+        float ng = neg[v] + pdp_safe_log(1.0f - pi * ((ef == -1.0f) ? 1.0f : 0.0f), PDP_SCORER_EPS);
+        float pns = ps + ng;
+        float dc = all[v] + pdp_safe_log(1.0f - pi, PDP_SCORER_EPS);
+        const float bias = (2.0f * pns + dc) / 4.0f;
+        ps = ps - bias; ng = ng - bias; pns = pns - bias;
+        dc = pdp_safe_exp(dc - bias);
+        const float q0 = pdp_safe_exp(ps) - pdp_safe_exp(pns);
+        const float q1 = pdp_safe_exp(ng) - pdp_safe_exp(pns);
+        const float total = pdp_safe_log((q0 + q1) + dc, PDP_SCORER_EPS);
+        score[v] = pdp_safe_exp(pdp_safe_log(q1, PDP_SCORER_EPS) - total) - pdp_safe_exp(pdp_safe_log(q0, PDP_SCORER_EPS) - total);
+    }
+    free(fm); free(frc); free(ext); free(pos); free(neg); free(all);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * K9: clause-satisfaction check.  reference: SatCNFEvaluator.forward util.py:210-236
+ * Always evaluated on the ORIGINAL (non-replicated-view) graph the problem holds.
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_cnf_eval(const orc_problem *p, const float *pred /*[V]*/, float *solved /*[B]*/, float *unsat /*[B]*/)
+{
+    const int F = p->F, B = p->B;
+    float *max_sat = (float *)xcalloc((size_t)B, sizeof(float));
+    float *batch_values = (float *)xcalloc((size_t)B, sizeof(float));
+    for (int c = 0; c < F; ++c) {
+        float clause = 0.0f;
+        for (int k = p->fn_ptr[c]; k < p->fn_ptr[c + 1]; ++k) {
+            const int e = p->fn_edges[k];
+            const float s = p->edge_sign[e];
+            float ev = 0.0f + s * pred[p->edge_var[e]];
+            ev = ev + (1.0f - s) / 2.0f;
+            clause = clause + ((ev > 0.5f) ? 1.0f : 0.0f);
+        }
+        const int b = p->fn_inst[c];
+        max_sat[b] = max_sat[b] + 1.0f;
+        batch_values[b] = batch_values[b] + ((clause > 0.0f) ? 1.0f : 0.0f);
+    }
+    for (int b = 0; b < B; ++b) {
+        solved[b] = (max_sat[b] == batch_values[b]) ? 1.0f : 0.0f;
+        unsat[b] = max_sat[b] - batch_values[b];
+    }
+    free(max_sat); free(batch_values);
+}
+
+/* K13. reference: PropagatorDecimatorSolverBase._update_solution solver.py:388-399 */
+ORC_API void orc_update_solution(orc_problem *p, const float *pred /*[V]*/, float *out /*[V]*/)
+{
+    for (int v = 0; v < p->V; ++v) {
+        const float a = p->active_var[v];
+        out[v] = a * pred[v] + (1.0f - a) * p->solution[v];
+    }
+    for (int v = 0; v < p->V; ++v) if (p->active_var[v] == 1.0f) p->solution[v] = out[v];
+}
+
+/* reference: SatFactorGraphTrainer._check_recurrence_termination trainer.py:150-162 (B-3 semantics) */
+ORC_API void orc_check_termination(const orc_problem *p, uint8_t *active_mask /*[B]*/, const float *pred /*[V]*/)
+{
+    const int B = p->B, R = p->replication, B0 = B / R;
+    float *solved = (float *)xcalloc((size_t)B, sizeof(float));
+    float *unsat = (float *)xcalloc((size_t)B, sizeof(float));
+    orc_cnf_eval(p, pred, solved, unsat);
+    if (R > 1) {
+        /* an original instance stays active (in all its replicas) until ANY replica is solved */
+        for (int b0 = 0; b0 < B0; ++b0) {
+            float real = 0.0f;
+            for (int r = 0; r < R; ++r) real = real + ((solved[b0 + r * B0] > 0.5f) ? 1.0f : 0.0f);
+            for (int r = 0; r < R; ++r) {
+                const int b = b0 + r * B0;
+                if (active_mask[b]) active_mask[b] = (real == 0.0f) ? 1 : 0;
+            }
+        }
+    } else {
+        for (int b = 0; b < B; ++b) if (active_mask[b]) active_mask[b] = (solved[b] <= 0.5f) ? 1 : 0;
+    }
+    free(solved); free(unsat);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Decimators
+ * ------------------------------------------------------------------------------------------ */
+typedef struct orc_decimator_state {
+    int has_prev;           /* SequentialDecimator._previous_function_state is not None */
+    int has_counters;
+    float *prev;            /* [E] */
+    float *counters;        /* [B] */
+} orc_decimator_state;
+
+ORC_API orc_decimator_state *orc_decimator_create(const orc_problem *p)
+{
+    orc_decimator_state *d = (orc_decimator_state *)xcalloc(1, sizeof(*d));
+    d->prev = (float *)xcalloc((size_t)p->E, sizeof(float));
+    d->counters = (float *)xcalloc((size_t)p->B, sizeof(float));
+    return d;
+}
+ORC_API void orc_decimator_destroy(orc_decimator_state *d) { if (d) { free(d->prev); free(d->counters); free(d); } }
+ORC_API void orc_decimator_get(const orc_problem *p, const orc_decimator_state *d, float *prev, float *counters, int *flags)
+{
+    if (prev) memcpy(prev, d->prev, sizeof(float) * (size_t)p->E);
+    if (counters) memcpy(counters, d->counters, sizeof(float) * (size_t)p->B);
+    if (flags) { flags[0] = d->has_prev; flags[1] = d->has_counters; }
+}
+ORC_API void orc_decimator_set(const orc_problem *p, orc_decimator_state *d, const float *prev, const float *counters, int has_prev)
+{
+    if (prev) memcpy(d->prev, prev, sizeof(float) * (size_t)p->E);
+    if (counters) { memcpy(d->counters, counters, sizeof(float) * (size_t)p->B); d->has_counters = 1; }
+    d->has_prev = has_prev;
+}
+
+static float sum_f(const float *x, int n) { float s = 0.0f; for (int i = 0; i < n; ++i) s += x[i]; return s; }
+/* torch `t.sum() > 0` for t >= 0 elementwise (or NaN): true iff no NaN and some element > 0 */
+static int positive_sum(const float *x, int n)
+{
+    int any = 0;
+    for (int i = 0; i < n; ++i) { if (x[i] != x[i]) return 0; if (x[i] > 0.0f) any = 1; }
+    return any;
+}
+
+/* reference: SequentialDecimator.forward pdp_decimate.py:122-177 (scorer = SurveyScorer).
+ * Returns the number of variables fixed by this call (0 if no decimation happened). */
+ORC_API int orc_sequential_decimate(orc_problem *p, orc_decimator_state *d, const float *fs /*[E,2] message_state[1]*/,
+                                    uint8_t *active_mask /*[B] or NULL*/, float tolerance, float t_max, float pi)
+{
+    const int E = p->E, V = p->V, B = p->B;
+    int fixed = 0;
+    float *tmp_e = (float *)xcalloc((size_t)E, sizeof(float));
+    float *tmp_v = (float *)xcalloc((size_t)V, sizeof(float));
+    float *tmp_b = (float *)xcalloc((size_t)B, sizeof(float));
+    if (!d->has_counters) { for (int b = 0; b < B; ++b) d->counters[b] = 0.0f; d->has_counters = 1; }
+
+    if (active_mask) {
+        for (int e = 0; e < E; ++e) tmp_e[e] = fs[2 * e + 0];
+        orc_smooth_max(p, tmp_e, tmp_v);
+        for (int v = 0; v < V; ++v) tmp_v[v] = tmp_v[v] * p->active_var[v];
+        orc_instance_max(p, tmp_v, tmp_b);
+        for (int b = 0; b < B; ++b) if (tmp_b[b] <= 1e-10f) active_mask[b] = 0;
+    }
+
+    if (d->has_prev && sum_f(p->active_var, V) > 0.0f) {
+        for (int e = 0; e < E; ++e) {
+            tmp_e[e] = pdp_abs(d->prev[e] - fs[2 * e + 0]);
+            if (p->has_edge_mask) tmp_e[e] = tmp_e[e] * p->edge_mask[e];
+        }
+        orc_smooth_max(p, tmp_e, tmp_v);
+        for (int v = 0; v < V; ++v) tmp_v[v] = tmp_v[v] * p->active_var[v];
+        orc_instance_max(p, tmp_v, tmp_b);
+        float *conv_b = (float *)xcalloc((size_t)B, sizeof(float));
+        for (int b = 0; b < B; ++b) if (tmp_b[b] < tolerance) d->counters[b] = 0.0f;
+        for (int b = 0; b < B; ++b) conv_b[b] = (tmp_b[b] < tolerance) ? 1.0f : 0.0f;
+        for (int b = 0; b < B; ++b) if (d->counters[b] >= t_max) conv_b[b] = 1.0f;
+        for (int b = 0; b < B; ++b) if (d->counters[b] >= t_max) d->counters[b] = 0.0f;
+        float *conv_v = (float *)xcalloc((size_t)V, sizeof(float));
+        for (int v = 0; v < V; ++v) conv_v[v] = 0.0f + conv_b[p->var_inst[v]];
+        if (positive_sum(conv_v, V)) {
+            float *score = (float *)xcalloc((size_t)V, sizeof(float));
+            float *coeff = (float *)xcalloc((size_t)V, sizeof(float));
+            orc_survey_score(p, fs, pi, score);
+            for (int v = 0; v < V; ++v) coeff[v] = (pdp_abs(score[v]) * p->active_var[v]) * conv_v[v];
+            if (positive_sum(coeff, V)) {
+                int64_t *max_ind = (int64_t *)xcalloc((size_t)B, sizeof(int64_t));
+                float *norm = (float *)xcalloc((size_t)B, sizeof(float));
+                orc_instance_argmax(p, coeff, max_ind);
+                for (int v = 0; v < V; ++v) norm[p->var_inst[v]] = norm[p->var_inst[v]] + coeff[v];
+                float *assignment = (float *)xcalloc((size_t)V, sizeof(float));
+                int n_sel = 0;
+                for (int b = 0; b < B; ++b) {
+                    const int sel = active_mask ? (active_mask[b] && (norm[b] != 0.0f)) : (norm[b] != 0.0f);
+                    if (sel) { assignment[max_ind[b]] = pdp_sign(score[max_ind[b]]); n_sel++; }
+                }
+                if (n_sel > 0) {
+                    for (int v = 0; v < V; ++v) if (assignment[v] != 0.0f && p->active_var[v] == 1.0f) fixed++;
+                    orc_set_variables(p, assignment);
+                }
+                free(max_ind); free(norm); free(assignment);
+            }
+            free(score); free(coeff);
+        }
+        for (int b = 0; b < B; ++b) d->counters[b] = d->counters[b] + 1.0f;
+        free(conv_b); free(conv_v);
+    }
+    for (int e = 0; e < E; ++e) d->prev[e] = fs[2 * e + 0];
+    d->has_prev = 1;
+    free(tmp_e); free(tmp_v); free(tmp_b);
+    return fixed;
+}
+
+/* reference: ReinforceDecimator.forward pdp_decimate.py:202-234.  `fs` [E,2] is updated in place
+ * (column 1 = external force).  `coin` is the value of torch.rand(1) drawn by the caller. */
+ORC_API void orc_reinforce_decimate(orc_problem *p, orc_decimator_state *d, float *fs, uint8_t *active_mask /*or NULL*/,
+                                    float coin, float decimation_probability, float pi)
+{
+    const int E = p->E, V = p->V, B = p->B;
+    if (active_mask && d->has_prev && sum_f(p->active_var, V) > 0.0f) {
+        float *tmp_e = (float *)xcalloc((size_t)E, sizeof(float));
+        float *tmp_v = (float *)xcalloc((size_t)V, sizeof(float));
+        float *tmp_b = (float *)xcalloc((size_t)B, sizeof(float));
+        for (int e = 0; e < E; ++e) {
+            tmp_e[e] = pdp_abs(d->prev[e] - fs[2 * e + 0]);
+            if (p->has_edge_mask) tmp_e[e] = tmp_e[e] * p->edge_mask[e];
+        }
+        orc_smooth_max(p, tmp_e, tmp_v);
+        for (int v = 0; v < V; ++v) tmp_v[v] = tmp_v[v] * p->active_var[v];
+        orc_instance_max(p, tmp_v, tmp_b);
+        for (int b = 0; b < B; ++b) if (tmp_b[b] <= 0.01f) active_mask[b] = 0;
+        free(tmp_e); free(tmp_v); free(tmp_b);
+    }
+    for (int e = 0; e < E; ++e) d->prev[e] = fs[2 * e + 0];
+    d->has_prev = 1;
+    if (coin < decimation_probability) {
+        float *score = (float *)xcalloc((size_t)V, sizeof(float));
+        orc_survey_score(p, fs, pi, score);
+        for (int e = 0; e < E; ++e) {
+            const int v = p->edge_var[e];
+            const float mask = active_mask ? (0.0f + (0.0f + (float)active_mask[p->var_inst[v]])) : 1.0f;
+            const float sc = 0.0f + pdp_sign(score[v]);
+            fs[2 * e + 1] = mask * sc + (1.0f - mask) * fs[2 * e + 1];
+        }
+        free(score);
+    }
+}
+
+/* reference: ReinforcePredictor.forward pdp_predict.py:221-226 */
+ORC_API void orc_reinforce_predict(const orc_problem *p, const float *fs, float *pred /*[V]*/)
+{
+    float *frc = (float *)xcalloc((size_t)p->E, sizeof(float));
+    for (int e = 0; e < p->E; ++e) frc[e] = fs[2 * e + 1];
+    var_sum(p, frc, 0, pred);
+    for (int v = 0; v < p->V; ++v) pred[v] = (pred[v] > 0.0f) ? 1.0f : 0.0f;
+    free(frc);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * K14: Walk-SAT.  reference: _compute_energy solver.py:486-496, _compute_energy_diff :469-484,
+ * _local_search :433-467
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_energy(const orc_problem *p, const float *assignment /*[V]*/, float *energy /*[B]*/, float *unsat_fn /*[F]*/)
+{
+    for (int b = 0; b < p->B; ++b) energy[b] = 0.0f;
+    for (int c = 0; c < p->F; ++c) {
+        float agg = 0.0f, deg = 0.0f;
+        for (int k = p->fn_ptr[c]; k < p->fn_ptr[c + 1]; ++k) {
+            const int e = p->fn_edges[k];
+            const int v = p->edge_var[e];
+            agg = agg + (0.0f + p->edge_sign[e] * (assignment[v] * p->active_var[v]));
+            deg = deg + (0.0f + p->active_var[v]);
+        }
+        unsat_fn[c] = ((agg == -deg) ? 1.0f : 0.0f) * p->active_fn[c];
+        energy[p->fn_inst[c]] = energy[p->fn_inst[c]] + unsat_fn[c];
+    }
+}
+
+ORC_API void orc_energy_diff(const orc_problem *p, const float *assignment /*[V]*/, float *delta /*[V]*/)
+{
+    const int E = p->E, F = p->F;
+    float *dist = (float *)xcalloc((size_t)E, sizeof(float));
+    float *agg = (float *)xcalloc((size_t)F, sizeof(float));
+    float *deg = (float *)xcalloc((size_t)F, sizeof(float));
+    float *tmp = (float *)xcalloc((size_t)E, sizeof(float));
+    for (int e = 0; e < E; ++e) {
+        const int v = p->edge_var[e];
+        dist[e] = 0.0f + p->edge_sign[e] * (assignment[v] * p->active_var[v]);
+        tmp[e] = 0.0f + p->active_var[v];
+    }
+    fn_sum(p, dist, agg);
+    fn_sum(p, tmp, deg);
+    for (int e = 0; e < E; ++e) {
+        const int c = p->edge_fn[e];
+        const float others = (0.0f + agg[c]) - dist[e];
+        const float fd = 0.0f + deg[c];
+        const float critical = ((others == (1.0f - fd)) ? 1.0f : 0.0f) * p->edge_mask[e];
+        tmp[e] = critical * dist[e];
+    }
+    var_sum(p, tmp, 0, delta);
+    free(dist); free(agg); free(deg); free(tmp);
+}
+
+/* Random-number source: either a recorded stream (torch.rand order of the reference) or Philox. */
+typedef struct orc_rng {
+    int mode;                 /* 0: stream, 1: philox */
+    const float *stream; int64_t n_stream; int64_t cursor;
+    uint64_t seed;
+} orc_rng;
+
+static float rng_next_stream(orc_rng *r)
+{
+    if (r->cursor >= r->n_stream) { fprintf(stderr, "oracle: random stream exhausted\n"); abort(); }
+    return r->stream[r->cursor++];
+}
+
+/* reference: _local_search solver.py:433-467. `pred` [V] in, `out` [V] = (assignment + 1) / 2.
+ * Returns the number of Walk-SAT iterations that were executed (flip steps). */
+static int local_search(orc_problem *p, const float *pred, int iterations, float epsilon, orc_rng *rng, float *out)
+{
+    const int V = p->V, F = p->F, B = p->B, R = p->replication, B0 = B / R;
+    float *a = (float *)xcalloc((size_t)V, sizeof(float));
+    float *energy = (float *)xcalloc((size_t)B, sizeof(float));
+    float *unsat_fn = (float *)xcalloc((size_t)F, sizeof(float));
+    float *delta = (float *)xcalloc((size_t)V, sizeof(float));
+    float *neg_delta = (float *)xcalloc((size_t)V, sizeof(float));
+    float *uv = (float *)xcalloc((size_t)V, sizeof(float));
+    int64_t *greedy = (int64_t *)xcalloc((size_t)B, sizeof(int64_t));
+    int64_t *randind = (int64_t *)xcalloc((size_t)B, sizeof(int64_t));
+    for (int v = 0; v < V; ++v) {
+        const float bit = (pred[v] > 0.5f) ? 1.0f : 0.0f;
+        a[v] = p->active_var[v] * (2.0f * bit - 1.0f);
+    }
+    orc_refresh_edge_mask(p);
+    int it = 0;
+    for (; it < iterations; ++it) {
+        orc_energy(p, a, energy, unsat_fn);
+        float total = 0.0f;
+        for (int b = 0; b < B; ++b) { energy[b] = (energy[b] > 0.0f) ? 1.0f : 0.0f; }
+        if (R > 1) {
+            for (int b0 = 0; b0 < B0; ++b0) {
+                float s = 0.0f;
+                for (int r = 0; r < R; ++r) s = s + (1.0f - energy[b0 + r * B0]);
+                total += 1.0f - ((s > 0.0f) ? 1.0f : 0.0f);
+            }
+        } else {
+            for (int b = 0; b < B; ++b) total += energy[b];
+        }
+        if (total == 0.0f) break;
+        orc_energy_diff(p, a, delta);
+        for (int v = 0; v < V; ++v) neg_delta[v] = -delta[v];
+        orc_instance_argmax(p, neg_delta, greedy);
+        /* unsat_variables = (vf_mask @ unsat_functions) * active > 0, times U(0,1) */
+        for (int v = 0; v < V; ++v) {
+            float acc = 0.0f;
+            for (int k = p->var_ptr[v]; k < p->var_ptr[v + 1]; ++k) acc = acc + unsat_fn[p->edge_fn[p->var_edges[k]]];
+            acc = acc * p->active_var[v];
+            const float u = (rng->mode == 0) ? rng_next_stream(rng)
+                                             : pdp_philox_uniform(rng->seed, PDP_RNG_STREAM_WSVAR, (uint32_t)it, (uint32_t)v);
+            uv[v] = ((acc > 0.0f) ? 1.0f : 0.0f) * u;
+        }
+        orc_instance_argmax(p, uv, randind);
+        for (int b = 0; b < B; ++b) {
+            const float u = (rng->mode == 0) ? rng_next_stream(rng)
+                                             : pdp_philox_uniform(rng->seed, PDP_RNG_STREAM_WSCOIN, (uint32_t)it, (uint32_t)b);
+            const int64_t coin = (u > epsilon) ? 1 : 0;
+            const int64_t ind = coin * greedy[b] + (1 - coin) * randind[b];
+            greedy[b] = ind;
+        }
+        /* flips are applied with advanced indexing: later duplicates overwrite, no accumulation */
+        {
+            float *flipped = (float *)xcalloc((size_t)V, sizeof(float));
+            for (int v = 0; v < V; ++v) flipped[v] = a[v];
+            for (int b = 0; b < B; ++b) if (energy[b] > 0.0f) flipped[greedy[b]] = -a[greedy[b]];
+            memcpy(a, flipped, sizeof(float) * (size_t)V);
+            free(flipped);
+        }
+    }
+    for (int v = 0; v < V; ++v) out[v] = (a[v] + 1.0f) / 2.0f;
+    free(a); free(energy); free(unsat_fn); free(delta); free(neg_delta); free(uv); free(greedy); free(randind);
+    return it;
+}
+
+ORC_API int orc_local_search(orc_problem *p, const float *pred, int iterations, float epsilon, int rng_mode,
+                             const float *stream, int64_t n_stream, int64_t *cursor, uint64_t seed, float *out)
+{
+    orc_rng r; r.mode = rng_mode; r.stream = stream; r.n_stream = n_stream; r.cursor = cursor ? *cursor : 0; r.seed = seed;
+    const int it = local_search(p, pred, iterations, epsilon, &r, out);
+    if (cursor) *cursor = r.cursor;
+    return it;
+}
+
+/* reference: IdentityPredictor.forward pdp_predict.py:118-128 with last_call=True, random_fill=True.
+ * Writes into sat_problem._solution (the prediction is a view of it). */
+static void random_fill(orc_problem *p, orc_rng *rng)
+{
+    for (int v = 0; v < p->V; ++v) {
+        if (p->active_var[v] > 0.0f) {
+            p->solution[v] = (rng->mode == 0) ? rng_next_stream(rng)
+                                              : pdp_philox_uniform(rng->seed, PDP_RNG_STREAM_FILL, 0u, (uint32_t)v);
+        }
+    }
+}
+ORC_API void orc_random_fill(orc_problem *p, int rng_mode, const float *stream, int64_t n_stream, int64_t *cursor, uint64_t seed)
+{
+    orc_rng r; r.mode = rng_mode; r.stream = stream; r.n_stream = n_stream; r.cursor = cursor ? *cursor : 0; r.seed = seed;
+    random_fill(p, &r);
+    if (cursor) *cursor = r.cursor;
+}
+
+/* reference: PropagatorDecimatorSolverBase._deduplicate solver.py:401-431 (with the B-4 fix).
+ * pred [V] (replicated) -> out [V / R]; also returns the index of the chosen replica per instance. */
+ORC_API void orc_deduplicate(const orc_problem *p, const float *pred, float *out /*[V/R]*/, int32_t *chosen /*[B/R] or NULL*/)
+{
+    const int V = p->V, B = p->B, R = p->replication, B0 = B / R, V0 = V / R;
+    float *a = (float *)xcalloc((size_t)V, sizeof(float));
+    float *energy = (float *)xcalloc((size_t)B, sizeof(float));
+    float *unsat_fn = (float *)xcalloc((size_t)p->F, sizeof(float));
+    float *neg = (float *)xcalloc((size_t)B, sizeof(float));
+    int *group = (int *)xcalloc((size_t)B, sizeof(int));
+    int64_t *best = (int64_t *)xcalloc((size_t)B0, sizeof(int64_t));
+    for (int v = 0; v < V; ++v) a[v] = 2.0f * pred[v] - 1.0f;
+    orc_energy(p, a, energy, unsat_fn);
+    for (int b = 0; b < B; ++b) { neg[b] = -energy[b]; group[b] = b % B0; }
+    group_argmax(neg, group, B, B0, best);
+    for (int i = 0; i < V0; ++i) out[i] = 0.0f;
+    for (int v = 0; v < V; ++v) {
+        const int b = p->var_inst[v];
+        const float flag = (best[b % B0] == b) ? 1.0f : 0.0f;
+        out[v % V0] = out[v % V0] + flag * pred[v];   /* .view(R, -1).sum(dim=0): r ascending */
+    }
+    if (chosen) for (int b0 = 0; b0 < B0; ++b0) chosen[b0] = (int32_t)(best[b0] / B0);
+    free(a); free(energy); free(unsat_fn); free(neg); free(group); free(best);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Whole forward pass of the classical solvers.  reference: PropagatorDecimatorSolverBase.forward
+ * solver.py:324-353 + _forward_core :355-386, with the plug-in triples of
+ *   model 0 'p-d-p'     SurveyPropagatorSolver solver.py:567-578
+ *   model 1 'walk-sat'  WalkSATSolver :584-592
+ *   model 2 'reinforce' ReinforceSurveyPropagatorSolver :598-610
+ * State initialisation = get_init_state(randomized=False) (pdp_propagate.py:233-235).
+ * Optional per-iteration trace buffers (may be NULL) mirror tests/golden/generate_golden.py.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct orc_forward_args {
+    int model;                 /* 0 p-d-p, 1 walk-sat, 2 reinforce */
+    int iterations;            /* T */
+    int local_search_iterations;
+    float epsilon, tolerance, t_max, pi, decimation_probability;
+    int rng_mode;              /* 0 stream, 1 philox */
+    const float *stream; int64_t n_stream; uint64_t seed;
+    /* outputs */
+    float *prediction;         /* [V/R] */
+    float *q;                  /* [E,3] final propagator state[0] (replicated size) or NULL */
+    float *fs;                 /* [E,2] final propagator state[1] or NULL */
+    int32_t *iterations_run;   /* [1] */
+    int64_t *rand_consumed;    /* [1] */
+    int32_t *walksat_steps;    /* [1] */
+    /* traces [T, .] or NULL */
+    float *trace_active_var, *trace_active_fn, *trace_solution; uint8_t *trace_active_mask;
+    float *trace_q, *trace_fs; /* [T,E,3], [T,E,2] or NULL */
+} orc_forward_args;
+
+ORC_API void orc_forward(orc_problem *p, orc_forward_args *a)
+{
+    const int E = p->E, V = p->V, B = p->B;
+    orc_rng rng; rng.mode = a->rng_mode; rng.stream = a->stream; rng.n_stream = a->n_stream; rng.cursor = 0; rng.seed = a->seed;
+    float *q = (float *)xcalloc((size_t)E * 3, sizeof(float));
+    float *fs = (float *)xcalloc((size_t)E * 2, sizeof(float));
+    float *q2 = (float *)xcalloc((size_t)E * 3, sizeof(float));
+    float *fs2 = (float *)xcalloc((size_t)E * 2, sizeof(float));
+    float *pred = (float *)xcalloc((size_t)V, sizeof(float));
+    float *pred2 = (float *)xcalloc((size_t)V, sizeof(float));
+    uint8_t *active_mask = (uint8_t *)xcalloc((size_t)B, 1);
+    orc_decimator_state *d = orc_decimator_create(p);
+    int it_run = 0;
+
+    orc_simplify(p);                                                     /* solver.py:332-333 */
+
+    if (a->model != 1) {
+        for (int e = 0; e < E; ++e) {
+            q[3 * e] = q[3 * e + 1] = q[3 * e + 2] = 1.0f / 3.0f;          /* ones / 3 */
+            fs[2 * e] = 0.5f; fs[2 * e + 1] = 0.0f;
+        }
+        for (int b = 0; b < B; ++b) active_mask[b] = 1;
+        int use_edge_mask = 0;
+        for (int t = 0; t < a->iterations; ++t) {
+            orc_sp_propagate(p, q, fs, use_edge_mask ? p->edge_mask : NULL, active_mask, q, fs, a->pi, q2, fs2);
+            { float *s = q; q = q2; q2 = s; s = fs; fs = fs2; fs2 = s; }
+            if (a->trace_q) memcpy(a->trace_q + (size_t)t * E * 3, q, sizeof(float) * (size_t)E * 3);
+            if (a->model == 0) {
+                orc_sequential_decimate(p, d, fs, active_mask, a->tolerance, a->t_max, a->pi);
+            } else {
+                const float coin = (rng.mode == 0) ? rng_next_stream(&rng)
+                                                   : pdp_philox_uniform(rng.seed, PDP_RNG_STREAM_REINF, (uint32_t)t, 0u);
+                orc_reinforce_decimate(p, d, fs, active_mask, coin, a->decimation_probability, a->pi);
+            }
+            if (a->trace_fs) memcpy(a->trace_fs + (size_t)t * E * 2, fs, sizeof(float) * (size_t)E * 2);
+            const double s = orc_refresh_edge_mask(p);
+            if (s < (double)E) use_edge_mask = 1;
+            if (a->model == 0) memcpy(pred, p->solution, sizeof(float) * (size_t)V);
+            else orc_reinforce_predict(p, fs, pred);
+            orc_update_solution(p, pred, pred2);
+            orc_check_termination(p, active_mask, pred2);
+            if (a->trace_active_var) memcpy(a->trace_active_var + (size_t)t * V, p->active_var, sizeof(float) * (size_t)V);
+            if (a->trace_active_fn) memcpy(a->trace_active_fn + (size_t)t * p->F, p->active_fn, sizeof(float) * (size_t)p->F);
+            if (a->trace_solution) memcpy(a->trace_solution + (size_t)t * V, p->solution, sizeof(float) * (size_t)V);
+            if (a->trace_active_mask) memcpy(a->trace_active_mask + (size_t)t * B, active_mask, (size_t)B);
+            it_run = t + 1;
+            int n_active = 0;
+            for (int b = 0; b < B; ++b) n_active += active_mask[b];
+            if (n_active <= 0) break;
+        }
+    }
+    /* final predictor call (last_call=True) */
+    if (a->model == 2) {
+        orc_reinforce_predict(p, fs, pred);
+    } else {
+        random_fill(p, &rng);
+        memcpy(pred, p->solution, sizeof(float) * (size_t)V);
+    }
+    int ws = local_search(p, pred, a->local_search_iterations, a->epsilon, &rng, pred2);
+    orc_update_solution(p, pred2, pred);
+    if (p->replication > 1) orc_deduplicate(p, pred, a->prediction, NULL);
+    else memcpy(a->prediction, pred, sizeof(float) * (size_t)V);
+    if (a->q) memcpy(a->q, q, sizeof(float) * (size_t)E * 3);
+    if (a->fs) memcpy(a->fs, fs, sizeof(float) * (size_t)E * 2);
+    if (a->iterations_run) a->iterations_run[0] = it_run;
+    if (a->rand_consumed) a->rand_consumed[0] = rng.cursor;
+    if (a->walksat_steps) a->walksat_steps[0] = ws;
+    orc_decimator_destroy(d);
+    free(q); free(fs); free(q2); free(fs2); free(pred); free(pred2); free(active_mask);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * math probes (used by the math-parity tests)
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_math_apply(int fn, const float *x, float *y, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        switch (fn) {
+        case 0: y[i] = pdp_expf(x[i]); break;
+        case 1: y[i] = pdp_logf(x[i]); break;
+        case 2: y[i] = pdp_logsigmoidf(x[i]); break;
+        case 3: y[i] = pdp_sigmoidf(x[i]); break;
+        case 4: y[i] = pdp_tanhf(x[i]); break;
+        case 5: y[i] = pdp_safe_exp(x[i]); break;
+        case 6: y[i] = pdp_safe_log(x[i], PDP_SP_EPS); break;
+        case 7: y[i] = pdp_philox_uniform(0x1234abcdULL, 2u, 7u, (uint32_t)i); break;
+        case 8: y[i] = 1.0f / x[i]; break;
+        default: y[i] = x[i];
+        }
+    }
+}

@@ -1,0 +1,165 @@
+"""Pins the CPU oracle (oracle/pdp_oracle.c) against vectors captured from the unmodified
+reference (tests/golden/generate_golden.py).  Integer-valued outputs must match exactly; fp32
+messages within FP_RTOL/FP_ATOL (the oracle's exp/log are <1.5 ulp, torch's Sleef kernels 1 ulp)."""
+import os
+
+import numpy as np
+import pytest
+
+FP_RTOL = 2e-5
+FP_ATOL = 2e-6
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + '.npz'))
+
+
+def make_problem(oracle, d, replication=1):
+    return oracle.Problem(d['graph_map'], d['batch_variable_map'], d['batch_function_map'], d['edge_feature'], replication)
+
+
+def test_math_accuracy(oracle):
+    rng = np.random.RandomState(0)
+    x = np.concatenate([rng.uniform(-100, 30, 200000), rng.uniform(-1, 1, 50000), [-92.1034, -103.9, 0.0, 30.0]]).astype(np.float32)
+    y = oracle.math_apply('exp', x)
+    ref = np.exp(x.astype(np.float64))
+    ok = ref > 1e-37
+    assert np.max(np.abs(y[ok] - ref[ok]) / ref[ok]) < 2.0e-7
+    assert np.max(np.abs(y[~ok] - ref[~ok])) < 1.5e-45 + 2e-7 * 1e-37  # denormal grid
+    assert abs(float(oracle.math_apply('exp', [-92.1034])[0]) - 1e-40) < 3e-45
+    xl = np.concatenate([np.exp(rng.uniform(-95, 5, 200000)), rng.uniform(0.5, 2.0, 100000), [1e-40, 1.0, 1e-10]]).astype(np.float32)
+    yl = oracle.math_apply('log', xl)
+    refl = np.log(xl.astype(np.float64))
+    err = np.abs(yl - refl) / np.maximum(np.abs(refl), 1e-30)
+    assert np.max(err[np.abs(refl) > 1e-3]) < 2.0e-7
+    assert np.max(np.abs(yl - refl)[np.abs(refl) <= 1e-3]) < 1e-9
+    assert oracle.math_apply('log', [1.0])[0] == 0.0
+    xs = rng.uniform(-40, 40, 100000).astype(np.float32)
+    ls = oracle.math_apply('logsigmoid', xs)
+    refs = -np.logaddexp(0, -xs.astype(np.float64))
+    assert np.max(np.abs(ls - refs) / np.maximum(np.abs(refs), 1e-30)) < 4e-7
+    th = oracle.math_apply('tanh', xs / 4)
+    assert np.max(np.abs(th - np.tanh(xs.astype(np.float64) / 4))) < 2e-7
+    sg = oracle.math_apply('sigmoid', xs)
+    assert np.max(np.abs(sg - 1 / (1 + np.exp(-xs.astype(np.float64))))) < 1.5e-7
+    u = oracle.math_apply('philox', np.zeros(100000))
+    assert u.min() >= 0 and u.max() < 1 and abs(u.mean() - 0.5) < 0.01
+
+
+def test_simplify_and_set_variables(oracle, golden_dir):
+    d = load(golden_dir, 'problem_simplify')
+    p = make_problem(oracle, d)
+    p.simplify()
+    av, af, sol, sat = p.state()
+    np.testing.assert_array_equal(av, d['simplify_active_variables'])
+    np.testing.assert_array_equal(af, d['simplify_active_functions'])
+    np.testing.assert_array_equal(sol, d['simplify_solution'])
+    np.testing.assert_array_equal(sat, d['simplify_is_sat'])
+    p.set_variables(d['setvar_assignment'])
+    av, af, sol, sat = p.state()
+    np.testing.assert_array_equal(av, d['setvar_active_variables'])
+    np.testing.assert_array_equal(af, d['setvar_active_functions'])
+    np.testing.assert_array_equal(sol, d['setvar_solution'])
+    np.testing.assert_array_equal(sat, d['setvar_is_sat'])
+
+
+def test_replication_layout(oracle, golden_dir):
+    d = load(golden_dir, 'problem_simplify')
+    p = make_problem(oracle, d, replication=3)
+    ev, ec, es, vi, fi = p.graph()
+    np.testing.assert_array_equal(np.stack([ev, ec]), d['rep3_graph_map'])
+    np.testing.assert_array_equal(vi, d['rep3_batch_variable_map'])
+    np.testing.assert_array_equal(fi, d['rep3_batch_function_map'])
+    np.testing.assert_array_equal(es, d['rep3_edge_feature'][:, 0])
+
+
+@pytest.fixture(scope='module')
+def ops(oracle, golden_dir):
+    d = load(golden_dir, 'ops_classical')
+    p = make_problem(oracle, d)
+    p.set_state(d['active_variables'], d['active_functions'], d['solution'])
+    p.set_edge_mask(d['edge_mask'])
+    return d, p
+
+
+def test_edge_mask(ops):
+    d, p = ops
+    m, s = p.refresh_edge_mask()
+    np.testing.assert_array_equal(m, d['edge_mask'])
+
+
+def test_smooth_max_and_instance_max(ops):
+    d, p = ops
+    np.testing.assert_allclose(p.smooth_max(d['smax_in']), d['smax_out'], rtol=FP_RTOL, atol=FP_ATOL)
+    np.testing.assert_array_equal(p.instance_max(d['vmax_in']), d['vmax_out'])
+    np.testing.assert_array_equal(p.instance_argmax(d['vmax_in']), d['vargmax_out'])
+    np.testing.assert_array_equal(p.instance_max(d['vmax_neg_in']), d['vmax_neg_out'])
+    np.testing.assert_array_equal(p.instance_argmax(d['vmax_neg_in']), d['vargmax_neg_out'])
+
+
+def test_cnf_eval(ops):
+    d, p = ops
+    s, u = p.cnf_eval(d['cnf_pred'])
+    np.testing.assert_array_equal(s, d['cnf_solved'])
+    np.testing.assert_array_equal(u, d['cnf_unsat'])
+
+
+@pytest.mark.parametrize('tag,pi', [('pi0', 0.0), ('pi1', 0.1)])
+def test_sp_propagate_and_score(ops, tag, pi):
+    d, p = ops
+    g = lambda k: d['sp_%s_%s' % (tag, k)]
+    q, fs = p.sp_propagate(g('q'), g('fs'), d['edge_mask'], g('active_mask'), g('init_q'), g('init_fs'), pi)
+    np.testing.assert_allclose(q, g('masked_q'), rtol=FP_RTOL, atol=FP_ATOL)
+    np.testing.assert_allclose(fs, g('masked_fs'), rtol=FP_RTOL, atol=FP_ATOL)
+    q, fs = p.sp_propagate(g('q'), g('fs'), None, None, g('init_q'), g('init_fs'), pi)
+    np.testing.assert_allclose(q, g('plain_q'), rtol=FP_RTOL, atol=FP_ATOL)
+    np.testing.assert_allclose(fs, g('plain_fs'), rtol=FP_RTOL, atol=FP_ATOL)
+    np.testing.assert_allclose(p.survey_score(g('fs'), pi), d['score_%s' % tag], rtol=1e-4, atol=2e-6)
+
+
+def test_energy(ops):
+    d, p = ops
+    en, uf = p.energy(d['energy_assignment'])
+    np.testing.assert_array_equal(en, d['energy_per_instance'])
+    np.testing.assert_array_equal(uf, d['energy_unsat_functions'])
+    np.testing.assert_array_equal(p.energy_diff(d['energy_assignment']), d['energy_delta'])
+
+
+TRACES = [('trace_pdp_n50', 'p-d-p', dict(tolerance=0.02, t_max=100)),
+          ('trace_pdp_easy_ws', 'p-d-p', dict(tolerance=0.05, t_max=10)),
+          ('trace_pdp_mixed', 'p-d-p', dict(tolerance=0.05, t_max=8)),
+          ('trace_walksat_easy', 'walk-sat', {}),
+          ('trace_pdp_rep3', 'p-d-p', dict(tolerance=0.05, t_max=6)),
+          ('trace_reinforce_easy', 'reinforce', dict(pi=0.01, decimation_probability=0.5))]
+
+
+@pytest.mark.parametrize('name,model,kw', TRACES)
+def test_full_forward_trace(oracle, golden_dir, name, model, kw):
+    """End-to-end: same inputs, same recorded torch.rand stream -> identical integer trajectory
+    (active flags, solution, active mask per iteration), identical final assignment, same number of
+    random numbers consumed, and fp32 states within tolerance."""
+    d = load(golden_dir, name)
+    T, w, seed, R = [int(x) for x in d['meta']]
+    p = make_problem(oracle, d, replication=R)
+    res = p.forward(model, T, local_search_iterations=w, epsilon=0.5, stream=d['rand_stream'], trace=True,
+                    trace_float=True, **kw)
+    it = int(d['iterations_run'][0])
+    assert res['iterations_run'] == it
+    if it:
+        np.testing.assert_array_equal(res['trace_active_mask'][:it], d['trace_active_mask'])
+        np.testing.assert_array_equal(res['trace_active_var'][:it], d['trace_active_variables'])
+        np.testing.assert_array_equal(res['trace_active_fn'][:it], d['trace_active_functions'])
+        np.testing.assert_array_equal(res['trace_solution'][:it], d['trace_solution'])
+        for k in d.files:
+            if k.startswith('prop_q_'):
+                i = int(k.split('_')[-1])
+                np.testing.assert_allclose(res['trace_q'][i], d[k], rtol=2e-4, atol=2e-6, err_msg=k)
+    assert res['rand_consumed'] == int(d['rand_sizes'].sum())
+    np.testing.assert_array_equal(res['prediction'], d['final_prediction'])
+    if 'final_prop_0' in d.files and R == 1:
+        np.testing.assert_allclose(res['q'], d['final_prop_0'], rtol=5e-4, atol=5e-6)
+        np.testing.assert_allclose(res['fs'], d['final_prop_1'], rtol=5e-4, atol=5e-6)
+    if 'final_solved' in d.files:
+        s, u = p.cnf_eval(res['prediction'])
+        np.testing.assert_array_equal(s, d['final_solved'])
+        np.testing.assert_array_equal(u, d['final_unsat'])
