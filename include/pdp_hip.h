@@ -1,0 +1,169 @@
+/*
+ * pdp_hip.h -- C ABI of the MI355X-native PDP hot path (libpdp_hip.so).
+ *
+ * The reference (microsoft/PDP-Solver) has no FFI: its hot path is Python calling torch operators.
+ * This header is therefore the boundary a maintainer binds (ctypes stub in INTEGRATION.md) in place
+ * of those operator call-site groups.  Every entry point names the reference code it replaces.
+ * All pointers are DEVICE pointers unless the name ends in `_host`; all arrays are dense,
+ * C-contiguous, fp32 / int32 / uint8 / int64 as declared; `stream` is a hipStream_t (may be NULL).
+ * Functions return PDP_OK (0) or an error code; pdp_last_error() gives the message.  Unless stated
+ * otherwise calls are asynchronous on `stream`.
+ *
+ * Batch layout (reference: src/pdp/factorgraph/dataset.py:165-187): instance ids in
+ * batch_variable_map / batch_function_map are non-decreasing, variable / clause ids are global and
+ * contiguous per instance, edges of one instance are contiguous.  Anything else -> PDP_ERR_LAYOUT.
+ */
+#ifndef PDP_HIP_H
+#define PDP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDP_ABI_VERSION 1
+
+enum {
+    PDP_OK = 0,
+    PDP_ERR_INVALID = 1,      /* bad argument */
+    PDP_ERR_LAYOUT = 2,       /* batch not in the loader's instance-contiguous layout */
+    PDP_ERR_HIP = 3,          /* HIP runtime error (no device, OOM, launch failure) */
+    PDP_ERR_UNSUPPORTED = 4,
+    PDP_ERR_SPECULATION = 5   /* persistent solve hit a cross-instance coupling; rerun step-wise */
+};
+
+enum { PDP_RNG_STREAM = 0, PDP_RNG_PHILOX = 1 };
+enum { PDP_MODEL_SP = 0, PDP_MODEL_WALKSAT = 1, PDP_MODEL_REINFORCE = 2 };
+
+typedef struct pdp_problem pdp_problem;       /* a batch of CNF instances resident in HBM */
+typedef struct pdp_decimator pdp_decimator;   /* SequentialDecimator / ReinforceDecimator state */
+
+int pdp_abi_version(void);
+const char *pdp_last_error(void);
+int pdp_device_count(void);
+
+/* ---- problem container --------------------------------------------------------------------
+ * replaces: SATProblem.__init__/setup_problem, the 24 sparse COO masks and _replicate_batch
+ * (reference: src/pdp/nn/solver.py:22-178).  graph_map is [2,E] (row 0 variable id, row 1 clause
+ * id), edge_feature [E] in {-1,+1}.  With replication R > 1 the handle holds R copies laid out as
+ * solver.py:56-82 does (replica r of instance i has id i + r*B).  Synchronous. */
+int pdp_problem_create(pdp_problem **out, int E, int V, int F, int B, int replication,
+                       const int32_t *graph_map, const int32_t *batch_variable_map,
+                       const int32_t *batch_function_map, const float *edge_feature, void *stream);
+int pdp_problem_destroy(pdp_problem *p);
+/* dims_host[8] = {E, V, F, B, R, max_vars, max_clauses, max_edges} of the (replicated) batch */
+int pdp_problem_dims(const pdp_problem *p, int32_t *dims_host);
+/* replicated graph arrays for the Python-visible attributes (_graph_map ...); any may be NULL */
+int pdp_problem_export_graph(const pdp_problem *p, int32_t *graph_map, int32_t *batch_variable_map,
+                             int32_t *batch_function_map, float *edge_feature, void *stream);
+/* binds caller-owned state tensors: _active_variables [V], _active_functions [F], _solution [V],
+ * _is_sat [B], _edge_mask [E] (reference: solver.py:49-54,370) and initialises them (1, 1, 0.5, 0.5, 1) */
+int pdp_problem_bind_state(pdp_problem *p, float *active_variables, float *active_functions,
+                           float *solution, float *is_sat, float *edge_mask, void *stream);
+
+/* ---- K7: simplification ---------------------------------------------------------------------
+ * replaces: SATProblem.simplify/_propagate_single_clauses/_peel (solver.py:180-203,228-285) */
+int pdp_simplify(pdp_problem *p, void *stream);
+/* replaces: SATProblem.set_variables/_set_variable_core (solver.py:205-226,275-279);
+ * assignment [V] in {-1,0,+1} is masked in place by the active flags like the reference does */
+int pdp_set_variables(pdp_problem *p, float *assignment, void *stream);
+/* K8 replaces: solver.py:370-371 / 439-440.  Writes the bound _edge_mask; if all_active_host is
+ * non-NULL the call synchronises and stores 1 when every edge is still active, else 0. */
+int pdp_refresh_edge_mask(pdp_problem *p, int32_t *all_active_host, void *stream);
+
+/* ---- K4 / K5 ----------------------------------------------------------------------------------
+ * replaces: util.sparse_smooth_max (util.py:282-286) with mask = variable mask: x [E] -> out [V] */
+int pdp_smooth_max(pdp_problem *p, const float *x, float *out, void *stream);
+/* replaces: util.sparse_max / sparse_argmax (util.py:257-275) with mask = batch-variable mask,
+ * including the batch-global `x - x.min() + 1` shift: x [V] -> out [B] */
+int pdp_instance_max(pdp_problem *p, const float *x, float *out, void *stream);
+int pdp_instance_argmax(pdp_problem *p, const float *x, int64_t *out, void *stream);
+
+/* ---- K1-K3: survey propagation sweep ------------------------------------------------------------
+ * replaces: SurveyPropagator.forward (pdp_propagate.py:139-221, include_adaptors=False).
+ * dec_q [E,3], dec_fs [E,2] = decimator_state; edge_mask [E] or NULL; active_mask uint8 [B] or NULL;
+ * init_q / init_fs = init_state; outputs out_q [E,3], out_fs [E,2] (may not alias the inputs). */
+int pdp_sp_propagate(pdp_problem *p, const float *dec_q, const float *dec_fs, const float *edge_mask,
+                     const uint8_t *active_mask, const float *init_q, const float *init_fs, float pi,
+                     float *out_q, float *out_fs, void *stream);
+/* K6 replaces: SurveyScorer.forward (pdp_predict.py:155-192): fs [E,2] -> score [V] */
+int pdp_survey_score(pdp_problem *p, const float *fs, float pi, float *score, void *stream);
+
+/* ---- K9 / K13 -------------------------------------------------------------------------------------
+ * replaces: SatCNFEvaluator.forward (util.py:210-236): pred [V] -> solved [B], unsat_clauses [B] */
+int pdp_cnf_eval(pdp_problem *p, const float *pred, float *solved, float *unsat, void *stream);
+/* replaces: PropagatorDecimatorSolverBase._update_solution (solver.py:388-399): out [V] */
+int pdp_update_solution(pdp_problem *p, const float *pred, float *out, void *stream);
+/* replaces: SatFactorGraphTrainer._check_recurrence_termination (trainer.py:150-162), replication aware */
+int pdp_check_termination(pdp_problem *p, uint8_t *active_mask, const float *pred, void *stream);
+
+/* ---- decimators --------------------------------------------------------------------------------------
+ * replaces: SequentialDecimator state (_previous_function_state, _counters; pdp_decimate.py:115-125,179-183) */
+int pdp_decimator_create(pdp_decimator **out, pdp_problem *p);
+int pdp_decimator_destroy(pdp_decimator *d);
+int pdp_decimator_reset(pdp_decimator *d, void *stream);
+/* replaces: SequentialDecimator.forward with scorer = SurveyScorer (pdp_decimate.py:122-177) */
+int pdp_sequential_decimate(pdp_problem *p, pdp_decimator *d, const float *fs, uint8_t *active_mask,
+                            float tolerance, float t_max, float pi, void *stream);
+/* the same in two halves for a non-native scorer plug-in: gate = :124-150 (returns via
+ * any_converged_host, synchronises), apply = :156-173 with a caller-computed score [V] */
+int pdp_sequential_decimate_gate(pdp_problem *p, pdp_decimator *d, const float *fs, uint8_t *active_mask,
+                                 float tolerance, float t_max, int32_t *any_converged_host, void *stream);
+int pdp_sequential_decimate_apply(pdp_problem *p, pdp_decimator *d, const float *fs, const float *score,
+                                  const uint8_t *active_mask, void *stream);
+/* replaces: ReinforceDecimator.forward (pdp_decimate.py:202-234); fs [E,2] updated in place; coin =
+ * the caller's torch.rand(1) draw */
+int pdp_reinforce_decimate(pdp_problem *p, pdp_decimator *d, float *fs, uint8_t *active_mask, float coin,
+                           float decimation_probability, float pi, void *stream);
+/* replaces: ReinforcePredictor.forward (pdp_predict.py:221-226): fs [E,2] -> pred [V] */
+int pdp_reinforce_predict(pdp_problem *p, const float *fs, float *pred, void *stream);
+
+/* ---- K14: Walk-SAT ------------------------------------------------------------------------------------
+ * replaces: _compute_energy (solver.py:486-496): assignment [V] -> energy [B], unsat_functions [F] */
+int pdp_energy(pdp_problem *p, const float *assignment, float *energy, float *unsat_functions, void *stream);
+/* replaces: _compute_energy_diff (solver.py:469-484) using the bound _edge_mask: -> delta [V] */
+int pdp_energy_diff(pdp_problem *p, const float *assignment, float *delta, void *stream);
+/* replaces: IdentityPredictor.forward(last_call=True) random fill (pdp_predict.py:121-126).
+ * PDP_RNG_STREAM: values [n_active] are consumed in variable order; PDP_RNG_PHILOX: in-kernel. */
+int pdp_random_fill(pdp_problem *p, int rng_mode, const float *values, uint64_t seed, void *stream);
+/* replaces: PropagatorDecimatorSolverBase._local_search (solver.py:433-467).  pred [V] -> out [V].
+ * PDP_RNG_STREAM: var_rand [iterations,V] and coin_rand [iterations,B] hold the torch.rand draws of
+ * each step.  Synchronises; steps_host receives the number of executed steps (global early exit). */
+int pdp_local_search(pdp_problem *p, const float *pred, int iterations, float epsilon, int rng_mode,
+                     const float *var_rand, const float *coin_rand, uint64_t seed, float *out,
+                     int32_t *steps_host, void *stream);
+/* replaces: _deduplicate (solver.py:401-431, with the integer-division fix): pred [V] -> out [V/R],
+ * chosen replica per original instance [B/R] (may be NULL) */
+int pdp_deduplicate(pdp_problem *p, const float *pred, float *out, int32_t *chosen, void *stream);
+
+/* ---- persistent solve: the whole _forward_core loop in one launch ------------------------------------
+ * replaces: PropagatorDecimatorSolverBase._forward_core (solver.py:355-386) for the classical
+ * triples (SurveyPropagator + SequentialDecimator + IdentityPredictor, or the Reinforce triple),
+ * one workgroup per instance with the instance resident in LDS.  The kernel assumes the
+ * reference's accidental cross-instance couplings are inert (batch-global min == 0, no NaN); it
+ * records violations and the call returns PDP_ERR_SPECULATION, in which case the caller reruns
+ * the batch through the step-wise entry points above.  Synchronises. */
+typedef struct pdp_solve_args {
+    int32_t model;                /* PDP_MODEL_SP or PDP_MODEL_REINFORCE */
+    int32_t iterations;           /* T */
+    float tolerance, t_max, pi, decimation_probability;
+    uint64_t seed;                /* Reinforce coin (Philox) */
+    const float *coins;           /* Reinforce: [T] host-drawn coins or NULL for Philox */
+    float *q;                     /* [E,3] in: init propagator state[0], out: final */
+    float *fs;                    /* [E,2] in/out */
+    uint8_t *active_mask;         /* [B] in/out */
+    pdp_decimator *decimator;     /* in/out */
+    int32_t check_termination;    /* 1: per-iteration CNF check de-activates solved instances */
+    int32_t iterations_run_host;  /* out: executed iterations (max over instances) */
+    int32_t used_lds_host;        /* out: 1 if the LDS-resident variant ran */
+} pdp_solve_args;
+int pdp_sp_solve(pdp_problem *p, pdp_solve_args *args, void *stream);
+
+/* ---- math probes (tests: device exp/log must equal the host header bit for bit) ---------------------- */
+int pdp_math_apply(int fn, const float *x, float *y, int64_t n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDP_HIP_H */

@@ -1,0 +1,223 @@
+// pdp_common.hpp -- handle layout, error plumbing and workgroup primitives shared by the kernels.
+//
+// Design: one workgroup per CNF instance.  Nothing in the PDP path couples two
+// instances except a handful of batch-global reductions in the reference;
+// those are separate tiny kernels here.  Instance topology is stored with instance-LOCAL ids so a
+// workgroup can copy it into LDS verbatim (u16 when the instance is small enough).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/pdp_hip.h"
+#include "../../include/pdp_math.h"
+
+#define PDP_WAVE 64
+#define PDP_NT 256            // threads per workgroup of the step-wise kernels
+
+// ---- error plumbing -------------------------------------------------------------------------
+void pdp_set_error(const char *fmt, ...);
+
+#define PDP_HIP_CHECK(expr)                                                                      \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            pdp_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return PDP_ERR_HIP;                                                                  \
+        }                                                                                        \
+    } while (0)
+
+#define PDP_LAUNCH_CHECK()                                                                       \
+    do {                                                                                         \
+        hipError_t _e = hipGetLastError();                                                       \
+        if (_e != hipSuccess) {                                                                  \
+            pdp_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return PDP_ERR_HIP;                                                                  \
+        }                                                                                        \
+    } while (0)
+
+#define PDP_REQUIRE(cond, msg)                                                                   \
+    do { if (!(cond)) { pdp_set_error("%s (%s:%d)", msg, __FILE__, __LINE__); return PDP_ERR_INVALID; } } while (0)
+
+// ---- device flag slots (uint32 words in pdp_problem::flags) -----------------------------------
+enum {
+    FL_LAYOUT_BAD = 0,
+    FL_GMIN0 = 1,        // encoded global min #0
+    FL_GMIN1 = 2,
+    FL_GMIN2 = 3,
+    FL_NAN0 = 4,         // NaN seen in the vector reduced into GMIN0
+    FL_NAN1 = 5,
+    FL_NAN2 = 6,
+    FL_ANY_ACTIVE_VAR = 7,
+    FL_ANY_CONV = 8,
+    FL_ANY_POS = 9,
+    FL_N_SEL = 10,
+    FL_ACTIVE_EDGES = 11,
+    FL_ANY_UNSAT = 12,
+    FL_SPEC_VIOLATION = 13,
+    FL_ITERS_RUN = 14,
+    FL_WS_STEPS = 15,
+    FL_COUNT = 32
+};
+
+// ---- handle -------------------------------------------------------------------------------------
+struct pdp_problem {
+    int E, V, F, B, R;          // sizes of the (replicated) batch
+    int E0, V0, F0, B0;         // sizes of one replica
+    int max_n, max_m, max_e;    // largest instance
+    int fn_edges_identity;      // edges are clause-major sorted (f_edges[k] == k)
+    // topology
+    int32_t *graph_map;         // [2,E] global ids (replicated)
+    int32_t *var_inst, *fn_inst;// [V], [F]
+    float *edge_sign;           // [E]
+    int8_t *e_sgn;              // [E]
+    int32_t *e_var, *e_fn;      // [E] instance-local ids
+    int32_t *inst_v0, *inst_f0, *inst_e0;   // [B+1]
+    int32_t *v_ptr, *v_edges;   // [V+B] local CSR offsets (instance b at v0+b, n+1 entries), [E] local edge ids
+    int32_t *f_ptr, *f_edges;   // [F+B], [E]
+    // bound state (caller owned)
+    float *av, *af, *sol, *is_sat, *emask;
+    int has_edge_mask;          // refresh_edge_mask was called (sat_problem._edge_mask is not None)
+    // workspace
+    float *ws_e[4];             // [E] each
+    float *ws_v[6];             // [V] each
+    float *ws_f[2];             // [F] each
+    float *ws_b[4];             // [B] each
+    int64_t *ws_bi[2];          // [B] each
+    int32_t *ws_vi[3];          // [V] each
+    uint8_t *ws_fu[2];          // [F] each
+    uint32_t *flags;            // [FL_COUNT] device
+    uint32_t *flags_host;       // pinned host mirror
+    void *cub_tmp; size_t cub_tmp_bytes;
+};
+
+struct pdp_decimator {
+    pdp_problem *p;
+    float *prev;                // [E] SequentialDecimator._previous_function_state
+    float *counters;            // [B] SequentialDecimator._counters
+    int has_prev;
+};
+
+// ---- by-value view handed to kernels -----------------------------------------------------------
+struct PView {
+    const int32_t *inst_v0, *inst_f0, *inst_e0;
+    const int32_t *e_var, *e_fn, *v_ptr, *v_edges, *f_ptr, *f_edges;
+    const int8_t *e_sgn;
+    const int32_t *var_inst, *fn_inst;
+    float *av, *af, *sol, *is_sat, *emask;
+    uint32_t *flags;
+    int B, R, B0, V, F, E;
+};
+
+static inline PView make_view(const pdp_problem *p)
+{
+    PView v;
+    v.inst_v0 = p->inst_v0; v.inst_f0 = p->inst_f0; v.inst_e0 = p->inst_e0;
+    v.e_var = p->e_var; v.e_fn = p->e_fn; v.v_ptr = p->v_ptr; v.v_edges = p->v_edges;
+    v.f_ptr = p->f_ptr; v.f_edges = p->f_edges; v.e_sgn = p->e_sgn;
+    v.var_inst = p->var_inst; v.fn_inst = p->fn_inst;
+    v.av = p->av; v.af = p->af; v.sol = p->sol; v.is_sat = p->is_sat; v.emask = p->emask;
+    v.flags = p->flags; v.B = p->B; v.R = p->R; v.B0 = p->B0; v.V = p->V; v.F = p->F; v.E = p->E;
+    return v;
+}
+
+// One instance as seen by its workgroup (pointers already offset to the instance's slice).
+struct Inst {
+    int b, v0, f0, e0, n, m, e;
+    const int32_t *e_var, *e_fn, *v_ptr, *v_edges, *f_ptr, *f_edges;
+    const int8_t *sgn;
+    float *av, *af, *sol, *emask;
+};
+
+__device__ __forceinline__ Inst load_inst(const PView &pv, int b)
+{
+    Inst I;
+    I.b = b;
+    I.v0 = pv.inst_v0[b]; I.f0 = pv.inst_f0[b]; I.e0 = pv.inst_e0[b];
+    I.n = pv.inst_v0[b + 1] - I.v0; I.m = pv.inst_f0[b + 1] - I.f0; I.e = pv.inst_e0[b + 1] - I.e0;
+    I.e_var = pv.e_var + I.e0; I.e_fn = pv.e_fn + I.e0; I.sgn = pv.e_sgn + I.e0;
+    I.v_ptr = pv.v_ptr + I.v0 + b; I.v_edges = pv.v_edges + I.e0;
+    I.f_ptr = pv.f_ptr + I.f0 + b; I.f_edges = pv.f_edges + I.e0;
+    I.av = pv.av + I.v0; I.af = pv.af + I.f0; I.sol = pv.sol + I.v0;
+    I.emask = pv.emask ? pv.emask + I.e0 : nullptr;
+    return I;
+}
+
+// ---- ordered encoding of floats for atomicMin ------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t pdp_enc_ordered(float f)
+{
+    const uint32_t u = pdp_f2bits(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ __forceinline__ float pdp_dec_ordered(uint32_t k)
+{
+    const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return pdp_bits2f(u);
+}
+#define PDP_ENC_PLUS_INF 0xff800000u   /* enc(+inf) */
+
+// ---- workgroup primitives ----------------------------------------------------------------------------
+// All take a small LDS scratch array (>= 2 * nwaves entries of the payload type) and must be called by
+// every thread of the workgroup.  They end with a barrier, so the scratch can be reused immediately.
+
+template <typename T, typename Op>
+__device__ __forceinline__ T wave_reduce(T v, Op op)
+{
+#pragma unroll
+    for (int off = PDP_WAVE / 2; off > 0; off >>= 1) v = op(v, __shfl_down(v, off, PDP_WAVE));
+    return v;
+}
+
+template <typename T, typename Op>
+__device__ __forceinline__ T block_reduce(T v, Op op, T identity, T *scratch)
+{
+    const int lane = threadIdx.x & (PDP_WAVE - 1), wid = threadIdx.x / PDP_WAVE;
+    const int nw = (blockDim.x + PDP_WAVE - 1) / PDP_WAVE;
+    v = wave_reduce(v, op);
+    if (lane == 0) scratch[wid] = v;
+    __syncthreads();
+    T r = identity;
+    for (int i = 0; i < nw; ++i) r = op(r, scratch[i]);
+    __syncthreads();
+    return r;
+}
+
+struct OpMaxNan { __device__ float operator()(float a, float b) const { return pdp_max(a, b); } };
+struct OpMinNan { __device__ float operator()(float a, float b) const { return pdp_min(a, b); } };
+struct OpAddI { __device__ int operator()(int a, int b) const { return a + b; } };
+struct OpOrI { __device__ int operator()(int a, int b) const { return a | b; } };
+
+// arg-max with torch.argmax semantics: larger value wins, NaN is maximal, first index wins ties.
+struct ArgPair { float v; int i; };
+__device__ __forceinline__ bool arg_better(float av, int ai, float bv, int bi)
+{
+    if (ai < 0) return false;
+    if (bi < 0) return true;
+    const bool an = av != av, bn = bv != bv;
+    if (an || bn) { if (an && bn) return ai < bi; return an; }
+    if (av > bv) return true;
+    if (av < bv) return false;
+    return ai < bi;
+}
+__device__ __forceinline__ ArgPair block_argmax(float v, int i, float *sv, int *si)
+{
+    const int lane = threadIdx.x & (PDP_WAVE - 1), wid = threadIdx.x / PDP_WAVE;
+    const int nw = (blockDim.x + PDP_WAVE - 1) / PDP_WAVE;
+#pragma unroll
+    for (int off = PDP_WAVE / 2; off > 0; off >>= 1) {
+        const float ov = __shfl_down(v, off, PDP_WAVE);
+        const int oi = __shfl_down(i, off, PDP_WAVE);
+        if (arg_better(ov, oi, v, i)) { v = ov; i = oi; }
+    }
+    if (lane == 0) { sv[wid] = v; si[wid] = i; }
+    __syncthreads();
+    ArgPair r; r.v = sv[0]; r.i = si[0];
+    for (int k = 1; k < nw; ++k) if (arg_better(sv[k], si[k], r.v, r.i)) { r.v = sv[k]; r.i = si[k]; }
+    __syncthreads();
+    return r;
+}
+
+// number of LDS scratch floats the primitives need
+#define PDP_RED_SCRATCH 64

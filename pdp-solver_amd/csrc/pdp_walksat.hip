@@ -1,0 +1,290 @@
+// pdp_walksat.hip -- Walk-SAT post-processing, random fill and replica de-duplication.
+// replaces: PropagatorDecimatorSolverBase._local_search / _compute_energy / _compute_energy_diff /
+// _deduplicate (reference: src/pdp/nn/solver.py:401-496) and IdentityPredictor's random fill
+// (src/pdp/nn/pdp_predict.py:118-128).  One workgroup per instance; all quantities except the
+// uniform draws are small integers.
+#include "pdp_device.hpp"
+
+#include <hipcub/hipcub.hpp>
+
+#define ST(s) ((hipStream_t)(s))
+#define DECL_RED __shared__ float redf[PDP_RED_SCRATCH]; __shared__ int redi[PDP_RED_SCRATCH];
+
+static inline int grid_for(int64_t n, int nt = 256) { int64_t g = (n + nt - 1) / nt; if (g < 1) g = 1; if (g > 4096) g = 4096; return (int)g; }
+
+// ---- energy ---------------------------------------------------------------------------------------
+// per clause: agg = sum s * (a * active), deg = sum active; unsat = (agg == -deg) * active_fn
+template <class I>
+__device__ __forceinline__ int d_clause_energy(const I &in, const float *a /*[n]*/, float *agg_out, float *deg_out, uint8_t *unsat_out)
+{
+    int cnt = 0;
+    for (int c = threadIdx.x; c < in.m; c += blockDim.x) {
+        float agg = 0.0f, deg = 0.0f;
+        for (int k = in.f_ptr[c]; k < in.f_ptr[c + 1]; ++k) {
+            const int e = in.f_edges[k];
+            const int v = in.e_var[e];
+            agg = agg + (0.0f + (float)in.sgn[e] * (a[v] * in.av[v]));
+            deg = deg + (0.0f + in.av[v]);
+        }
+        const float u = ((agg == -deg) ? 1.0f : 0.0f) * in.af[c];
+        if (agg_out) { agg_out[c] = agg; deg_out[c] = deg; }
+        if (unsat_out) unsat_out[c] = (u == 1.0f) ? 1 : 0;
+        cnt += (u == 1.0f) ? 1 : 0;
+    }
+    return cnt;
+}
+
+__global__ void __launch_bounds__(PDP_NT) k_energy(PView pv, const float *assignment, float *energy, float *unsat_fn, uint8_t *unsat_u8,
+                                                   float *agg_ws, float *deg_ws)
+{
+    DECL_RED
+    (void)redf;
+    const Inst I = load_inst(pv, blockIdx.x);
+    int cnt = d_clause_energy(I, assignment + I.v0, agg_ws + I.f0, deg_ws + I.f0, unsat_u8 + I.f0);
+    cnt = block_reduce(cnt, OpAddI(), 0, redi);
+    if (unsat_fn) for (int c = threadIdx.x; c < I.m; c += blockDim.x) unsat_fn[I.f0 + c] = (float)unsat_u8[I.f0 + c];
+    if (threadIdx.x == 0) energy[I.b] = (float)cnt;
+}
+
+extern "C" int pdp_energy(pdp_problem *p, const float *assignment, float *energy, float *unsat_functions, void *stream)
+{
+    PDP_REQUIRE(p && p->av && assignment && energy, "NULL argument / state not bound");
+    hipLaunchKernelGGL(k_energy, dim3(p->B), dim3(PDP_NT), 0, ST(stream), make_view(p), assignment, energy, unsat_functions, p->ws_fu[0],
+                       p->ws_f[0], p->ws_f[1]);
+    PDP_LAUNCH_CHECK();
+    return PDP_OK;
+}
+
+// delta[v] = sum over edges of critical * dist (solver.py:469-484); needs agg/deg per clause
+template <class I>
+__device__ __forceinline__ float d_var_delta(const I &in, int v, const float *a, const float *agg, const float *deg, const float *emask)
+{
+    float delta = 0.0f;
+    const float dist_v = a[v] * in.av[v];
+    for (int k = in.v_ptr[v]; k < in.v_ptr[v + 1]; ++k) {
+        const int e = in.v_edges[k];
+        const int c = in.e_fn[e];
+        const float dist = 0.0f + (float)in.sgn[e] * dist_v;
+        const float others = (0.0f + agg[c]) - dist;
+        const float fd = 0.0f + deg[c];
+        const float critical = ((others == (1.0f - fd)) ? 1.0f : 0.0f) * emask[e];
+        delta = delta + critical * dist;
+    }
+    return delta;
+}
+
+__global__ void __launch_bounds__(PDP_NT) k_energy_diff(PView pv, const float *assignment, float *delta, float *agg_ws, float *deg_ws)
+{
+    const Inst I = load_inst(pv, blockIdx.x);
+    d_clause_energy(I, assignment + I.v0, agg_ws + I.f0, deg_ws + I.f0, (uint8_t *)nullptr);
+    __syncthreads();
+    for (int v = threadIdx.x; v < I.n; v += blockDim.x)
+        delta[I.v0 + v] = d_var_delta(I, v, assignment + I.v0, agg_ws + I.f0, deg_ws + I.f0, I.emask);
+}
+
+extern "C" int pdp_energy_diff(pdp_problem *p, const float *assignment, float *delta, void *stream)
+{
+    PDP_REQUIRE(p && p->av && assignment && delta, "NULL argument / state not bound");
+    hipLaunchKernelGGL(k_energy_diff, dim3(p->B), dim3(PDP_NT), 0, ST(stream), make_view(p), assignment, delta, p->ws_f[0], p->ws_f[1]);
+    PDP_LAUNCH_CHECK();
+    return PDP_OK;
+}
+
+// ---- random fill ---------------------------------------------------------------------------------------
+__global__ void k_active_flags(int V, const float *av, int32_t *flag)
+{
+    for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < V; v += (int64_t)gridDim.x * blockDim.x) flag[v] = (av[v] > 0.0f) ? 1 : 0;
+}
+__global__ void k_fill_stream(int V, const float *av, const int32_t *rank, const float *values, float *sol)
+{
+    for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < V; v += (int64_t)gridDim.x * blockDim.x)
+        if (av[v] > 0.0f) sol[v] = values[rank[v]];
+}
+__global__ void k_fill_philox(int V, const float *av, uint64_t seed, float *sol)
+{
+    for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < V; v += (int64_t)gridDim.x * blockDim.x)
+        if (av[v] > 0.0f) sol[v] = pdp_philox_uniform(seed, PDP_RNG_STREAM_FILL, 0u, (uint32_t)v);
+}
+
+extern "C" int pdp_random_fill(pdp_problem *p, int rng_mode, const float *values, uint64_t seed, void *stream)
+{
+    PDP_REQUIRE(p && p->av, "NULL argument / state not bound");
+    hipStream_t st = ST(stream);
+    if (rng_mode == PDP_RNG_PHILOX) {
+        hipLaunchKernelGGL(k_fill_philox, dim3(grid_for(p->V)), dim3(256), 0, st, p->V, p->av, seed, p->sol);
+    } else {
+        PDP_REQUIRE(values, "stream mode needs the drawn values");
+        hipLaunchKernelGGL(k_active_flags, dim3(grid_for(p->V)), dim3(256), 0, st, p->V, p->av, p->ws_vi[0]);
+        size_t need = 0;
+        PDP_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, p->ws_vi[0], p->ws_vi[1], p->V, st));
+        if (need > p->cub_tmp_bytes) {
+            if (p->cub_tmp) (void)hipFree(p->cub_tmp);
+            PDP_HIP_CHECK(hipMalloc(&p->cub_tmp, need));
+            p->cub_tmp_bytes = need;
+        }
+        PDP_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(p->cub_tmp, need, p->ws_vi[0], p->ws_vi[1], p->V, st));
+        hipLaunchKernelGGL(k_fill_stream, dim3(grid_for(p->V)), dim3(256), 0, st, p->V, p->av, p->ws_vi[1], values, p->sol);
+    }
+    PDP_LAUNCH_CHECK();
+    return PDP_OK;
+}
+
+// ---- Walk-SAT, strict step-wise form ---------------------------------------------------------------------
+__global__ void k_ws_init(int V, const float *av, const float *pred, float *a)
+{
+    for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < V; v += (int64_t)gridDim.x * blockDim.x) {
+        const float bit = (pred[v] > 0.5f) ? 1.0f : 0.0f;
+        a[v] = av[v] * (2.0f * bit - 1.0f);
+    }
+}
+
+// (a) energies; unsat flag per (replica) instance
+__global__ void __launch_bounds__(PDP_NT) k_ws_energy(PView pv, const float *a, float *unsat_b, uint8_t *unsat_u8, float *agg_ws, float *deg_ws)
+{
+    DECL_RED
+    (void)redf;
+    const Inst I = load_inst(pv, blockIdx.x);
+    int cnt = d_clause_energy(I, a + I.v0, agg_ws + I.f0, deg_ws + I.f0, unsat_u8 + I.f0);
+    cnt = block_reduce(cnt, OpAddI(), 0, redi);
+    if (threadIdx.x == 0) {
+        unsat_b[I.b] = (cnt > 0) ? 1.0f : 0.0f;
+        if (pv.R == 1 && cnt > 0) atomicOr(&pv.flags[FL_ANY_UNSAT], 1u);
+    }
+}
+// (a') replication: an original instance counts as unsat while ALL its replicas are unsat (solver.py:446-449)
+__global__ void k_ws_compact(int B0, int R, const float *unsat_b, uint32_t *flags)
+{
+    const int b0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b0 >= B0) return;
+    float s = 0.0f;
+    for (int r = 0; r < R; ++r) s = s + (1.0f - unsat_b[b0 + r * B0]);
+    if (!(s > 0.0f)) atomicOr(&flags[FL_ANY_UNSAT], 1u);
+}
+
+// (b) delta energy + random candidates; batch-global min of the candidate vector
+__global__ void __launch_bounds__(PDP_NT) k_ws_delta(PView pv, const float *a, const uint8_t *unsat_u8, const float *agg_ws, const float *deg_ws,
+                                                     int rng_mode, const float *var_rand, uint64_t seed, int step, float *negdelta, float *uv)
+{
+    DECL_RED
+    const Inst I = load_inst(pv, blockIdx.x);
+    float m = PDP_INF; bool nn = false;
+    for (int v = threadIdx.x; v < I.n; v += blockDim.x) {
+        negdelta[I.v0 + v] = -d_var_delta(I, v, a + I.v0, agg_ws + I.f0, deg_ws + I.f0, I.emask);
+        float acc = 0.0f;
+        for (int k = I.v_ptr[v]; k < I.v_ptr[v + 1]; ++k) acc = acc + (float)unsat_u8[I.f0 + I.e_fn[I.v_edges[k]]];
+        acc = acc * I.av[v];
+        const float u = (rng_mode == PDP_RNG_STREAM) ? var_rand[I.v0 + v]
+                                                     : pdp_philox_uniform(seed, PDP_RNG_STREAM_WSVAR, (uint32_t)step, (uint32_t)(I.v0 + v));
+        const float r = ((acc > 0.0f) ? 1.0f : 0.0f) * u;
+        uv[I.v0 + v] = r;
+        if (r != r) nn = true; else if (r < m) m = r;
+    }
+    publish_min(m, nn, pv.flags, FL_GMIN0, FL_NAN0, redf, redi);
+}
+
+// (c) choose and flip (solver.py:454-465)
+__global__ void __launch_bounds__(PDP_NT) k_ws_flip(PView pv, float *a, const float *unsat_b, const float *negdelta, const float *uv,
+                                                    int rng_mode, const float *coin_rand, uint64_t seed, int step, float epsilon)
+{
+    DECL_RED
+    const Inst I = load_inst(pv, blockIdx.x);
+    // -delta holds small integers: the (x - min + 1) shift is exact for any min, so a local shift of 0 gives
+    // the reference's arg-max; the random candidates need the batch-global min (rounding of x - min + 1)
+    const int greedy = d_instance_argmax(I, negdelta + I.v0, 0.0f, redf, redi);
+    const float gmin = pdp_dec_ordered(pv.flags[FL_GMIN0]);
+    const int randi = d_instance_argmax(I, uv + I.v0, pv.flags[FL_NAN0] ? PDP_NAN : gmin, redf, redi);
+    if (threadIdx.x == 0 && unsat_b[I.b] > 0.0f && I.n > 0) {
+        const float u = (rng_mode == PDP_RNG_STREAM) ? coin_rand[I.b]
+                                                     : pdp_philox_uniform(seed, PDP_RNG_STREAM_WSCOIN, (uint32_t)step, (uint32_t)I.b);
+        const int ind = (u > epsilon) ? greedy : randi;
+        a[I.v0 + ind] = -a[I.v0 + ind];
+    }
+}
+
+__global__ void k_ws_finish(int V, const float *a, float *out)
+{
+    for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < V; v += (int64_t)gridDim.x * blockDim.x) out[v] = (a[v] + 1.0f) / 2.0f;
+}
+
+__global__ void k_ws_reset(uint32_t *flags)
+{
+    if (threadIdx.x == 0) { flags[FL_ANY_UNSAT] = 0u; flags[FL_GMIN0] = PDP_ENC_PLUS_INF; flags[FL_NAN0] = 0u; }
+}
+
+__global__ void __launch_bounds__(PDP_NT) k_edge_mask2(PView pv)
+{
+    const Inst I = load_inst(pv, blockIdx.x);
+    for (int e = threadIdx.x; e < I.e; e += blockDim.x) {
+        const float a = 0.0f + I.av[I.e_var[e]];
+        const float b = 0.0f + I.af[I.e_fn[e]];
+        I.emask[e] = a * b;
+    }
+}
+
+extern "C" int pdp_local_search(pdp_problem *p, const float *pred, int iterations, float epsilon, int rng_mode,
+                                const float *var_rand, const float *coin_rand, uint64_t seed, float *out,
+                                int32_t *steps_host, void *stream)
+{
+    PDP_REQUIRE(p && p->av && pred && out, "NULL argument / state not bound");
+    PDP_REQUIRE(rng_mode == PDP_RNG_PHILOX || iterations == 0 || (var_rand && coin_rand), "stream mode needs the drawn values");
+    hipStream_t st = ST(stream);
+    const PView pv = make_view(p);
+    float *a = p->ws_v[0], *negdelta = p->ws_v[1], *uv = p->ws_v[2], *unsat_b = p->ws_b[0];
+    hipLaunchKernelGGL(k_ws_init, dim3(grid_for(p->V)), dim3(256), 0, st, p->V, p->av, pred, a);
+    hipLaunchKernelGGL(k_edge_mask2, dim3(p->B), dim3(PDP_NT), 0, st, pv);       // solver.py:439-440
+    p->has_edge_mask = 1;
+    int it = 0;
+    for (; it < iterations; ++it) {
+        hipLaunchKernelGGL(k_ws_reset, dim3(1), dim3(64), 0, st, p->flags);
+        hipLaunchKernelGGL(k_ws_energy, dim3(p->B), dim3(PDP_NT), 0, st, pv, a, unsat_b, p->ws_fu[0], p->ws_f[0], p->ws_f[1]);
+        if (p->R > 1) hipLaunchKernelGGL(k_ws_compact, dim3((p->B0 + 255) / 256), dim3(256), 0, st, p->B0, p->R, unsat_b, p->flags);
+        PDP_HIP_CHECK(hipMemcpyAsync(p->flags_host, p->flags + FL_ANY_UNSAT, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        PDP_HIP_CHECK(hipStreamSynchronize(st));
+        if (p->flags_host[0] == 0u) break;
+        hipLaunchKernelGGL(k_ws_delta, dim3(p->B), dim3(PDP_NT), 0, st, pv, a, p->ws_fu[0], p->ws_f[0], p->ws_f[1], rng_mode,
+                           var_rand ? var_rand + (size_t)it * p->V : nullptr, seed, it, negdelta, uv);
+        hipLaunchKernelGGL(k_ws_flip, dim3(p->B), dim3(PDP_NT), 0, st, pv, a, unsat_b, negdelta, uv, rng_mode,
+                           coin_rand ? coin_rand + (size_t)it * p->B : nullptr, seed, it, epsilon);
+    }
+    hipLaunchKernelGGL(k_ws_finish, dim3(grid_for(p->V)), dim3(256), 0, st, p->V, a, out);
+    PDP_LAUNCH_CHECK();
+    PDP_HIP_CHECK(hipStreamSynchronize(st));
+    if (steps_host) *steps_host = it;
+    return PDP_OK;
+}
+
+// ---- de-duplication -----------------------------------------------------------------------------------------
+__global__ void k_dedup_assign(int V, const float *pred, float *a)
+{
+    for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < V; v += (int64_t)gridDim.x * blockDim.x) a[v] = 2.0f * pred[v] - 1.0f;
+}
+__global__ void k_dedup_choose(int B0, int R, const float *energy, int32_t *chosen)
+{
+    const int b0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b0 >= B0) return;
+    // arg-max of -energy over the replicas, first (lowest replica) index wins ties
+    int best = 0; float bv = -energy[b0];
+    for (int r = 1; r < R; ++r) { const float v = -energy[b0 + r * B0]; if (v > bv) { bv = v; best = r; } }
+    chosen[b0] = best;
+}
+__global__ void k_dedup_select(int V0, const int32_t *var_inst, const int32_t *chosen, const float *pred, float *out)
+{
+    for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < V0; v += (int64_t)gridDim.x * blockDim.x) {
+        const int b0 = var_inst[v];              // replica 0 carries the original instance ids
+        out[v] = 0.0f + pred[v + (int64_t)chosen[b0] * V0];
+    }
+}
+
+extern "C" int pdp_deduplicate(pdp_problem *p, const float *pred, float *out, int32_t *chosen, void *stream)
+{
+    PDP_REQUIRE(p && p->av && pred && out, "NULL argument / state not bound");
+    hipStream_t st = ST(stream);
+    int32_t *ch = chosen ? chosen : p->ws_vi[0];
+    hipLaunchKernelGGL(k_dedup_assign, dim3(grid_for(p->V)), dim3(256), 0, st, p->V, pred, p->ws_v[0]);
+    hipLaunchKernelGGL(k_energy, dim3(p->B), dim3(PDP_NT), 0, st, make_view(p), p->ws_v[0], p->ws_b[0], (float *)nullptr, p->ws_fu[0],
+                       p->ws_f[0], p->ws_f[1]);
+    hipLaunchKernelGGL(k_dedup_choose, dim3((p->B0 + 255) / 256), dim3(256), 0, st, p->B0, p->R, p->ws_b[0], ch);
+    hipLaunchKernelGGL(k_dedup_select, dim3(grid_for(p->V0)), dim3(256), 0, st, p->V0, p->var_inst, ch, pred, out);
+    PDP_LAUNCH_CHECK();
+    return PDP_OK;
+}

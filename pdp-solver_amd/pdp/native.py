@@ -1,0 +1,309 @@
+"""ctypes binding of libpdp_hip.so (the C ABI declared in include/pdp_hip.h).
+
+PyTorch is used for device memory and streams only: every call hands raw device pointers
+(``tensor.data_ptr()``) and the current HIP stream to the library.  There is NO CPU fallback: if the
+library is missing or no GPU is visible the calls raise (loudly), they never reroute.
+"""
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libpdp_hip.so')
+
+PDP_OK = 0
+PDP_ERR_SPECULATION = 5
+RNG_STREAM, RNG_PHILOX = 0, 1
+MODEL_SP, MODEL_WALKSAT, MODEL_REINFORCE = 0, 1, 2
+
+EXPORTED_SYMBOLS = [
+    'pdp_abi_version', 'pdp_last_error', 'pdp_device_count', 'pdp_problem_create', 'pdp_problem_destroy',
+    'pdp_problem_dims', 'pdp_problem_export_graph', 'pdp_problem_bind_state', 'pdp_simplify', 'pdp_set_variables',
+    'pdp_refresh_edge_mask', 'pdp_smooth_max', 'pdp_instance_max', 'pdp_instance_argmax', 'pdp_sp_propagate',
+    'pdp_survey_score', 'pdp_cnf_eval', 'pdp_update_solution', 'pdp_check_termination', 'pdp_decimator_create',
+    'pdp_decimator_destroy', 'pdp_decimator_reset', 'pdp_sequential_decimate', 'pdp_sequential_decimate_gate',
+    'pdp_sequential_decimate_apply', 'pdp_reinforce_decimate', 'pdp_reinforce_predict', 'pdp_energy',
+    'pdp_energy_diff', 'pdp_random_fill', 'pdp_local_search', 'pdp_deduplicate', 'pdp_sp_solve', 'pdp_math_apply',
+]
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class SpeculationFailed(NativeError):
+    """The persistent solver met one of the reference's cross-instance couplings; rerun step-wise."""
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError("libpdp_hip.so is not built (%s); run `make -C pdp-solver_amd/csrc` or "
+                              "__graft_entry__.build()" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.pdp_last_error.restype = C.c_char_p
+        for name in EXPORTED_SYMBOLS:
+            if name != 'pdp_last_error':
+                getattr(_lib, name).restype = C.c_int
+    return _lib
+
+
+def check(status):
+    if status == PDP_OK:
+        return
+    msg = lib().pdp_last_error().decode('utf-8', 'replace')
+    if status == PDP_ERR_SPECULATION:
+        raise SpeculationFailed(msg)
+    raise NativeError("libpdp_hip error %d: %s" % (status, msg))
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise NativeError("no HIP device visible: the PDP hot path has no CPU fallback")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_DT = {torch.float32: 'f32', torch.int32: 'i32', torch.uint8: 'u8', torch.int64: 'i64'}
+
+
+def ptr(t, dtype=None, numel=None, name='tensor'):
+    """Device pointer of a dense tensor (None -> NULL)."""
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_cuda:
+        raise NativeError("%s must live on the GPU" % name)
+    if not t.is_contiguous():
+        raise NativeError("%s must be contiguous" % name)
+    if dtype is not None and t.dtype != dtype:
+        raise NativeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if numel is not None and t.numel() != numel:
+        raise NativeError("%s must have %d elements, got %d" % (name, numel, t.numel()))
+    return C.c_void_p(t.data_ptr())
+
+
+class SolveArgs(C.Structure):
+    _fields_ = [('model', C.c_int32), ('iterations', C.c_int32), ('tolerance', C.c_float), ('t_max', C.c_float),
+                ('pi', C.c_float), ('decimation_probability', C.c_float), ('seed', C.c_uint64),
+                ('coins', C.c_void_p), ('q', C.c_void_p), ('fs', C.c_void_p), ('active_mask', C.c_void_p),
+                ('decimator', C.c_void_p), ('check_termination', C.c_int32), ('iterations_run_host', C.c_int32),
+                ('used_lds_host', C.c_int32)]
+
+
+class Decimator(object):
+    """Native SequentialDecimator / ReinforceDecimator state (previous survey + counters)."""
+
+    def __init__(self, problem):
+        self.problem = problem
+        h = C.c_void_p()
+        check(lib().pdp_decimator_create(C.byref(h), problem._h))
+        self._h = h
+
+    def reset(self):
+        check(lib().pdp_decimator_reset(self._h, _stream()))
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().pdp_decimator_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class Problem(object):
+    """HBM-resident batch of CNF instances (native SATProblem)."""
+
+    def __init__(self, graph_map, batch_variable_map, batch_function_map, edge_feature, batch_size=None, replication=1):
+        require_gpu()
+        L = lib()
+        self.device = graph_map.device
+        gm = graph_map.to(torch.int32).contiguous()
+        bvm = batch_variable_map.to(torch.int32).contiguous()
+        bfm = batch_function_map.to(torch.int32).contiguous()
+        ef = edge_feature.to(torch.float32).reshape(-1).contiguous()
+        E, V, F = gm.size(1), bvm.numel(), bfm.numel()
+        if batch_size is None:
+            batch_size = int(bvm.max().item()) + 1
+        h = C.c_void_p()
+        check(L.pdp_problem_create(C.byref(h), C.c_int(E), C.c_int(V), C.c_int(F), C.c_int(batch_size), C.c_int(replication),
+                                   ptr(gm, torch.int32), ptr(bvm, torch.int32), ptr(bfm, torch.int32), ptr(ef, torch.float32),
+                                   _stream()))
+        self._h = h
+        dims = (C.c_int32 * 8)()
+        check(L.pdp_problem_dims(self._h, dims))
+        self.E, self.V, self.F, self.B, self.R, self.max_n, self.max_m, self.max_e = [int(x) for x in dims]
+        dev = self.device
+        self.active_variables = torch.empty(self.V, 1, dtype=torch.float32, device=dev)
+        self.active_functions = torch.empty(self.F, 1, dtype=torch.float32, device=dev)
+        self.solution = torch.empty(self.V, dtype=torch.float32, device=dev)
+        self.is_sat = torch.empty(self.B, dtype=torch.float32, device=dev)
+        self.edge_mask = torch.empty(self.E, 1, dtype=torch.float32, device=dev)
+        check(L.pdp_problem_bind_state(self._h, ptr(self.active_variables), ptr(self.active_functions), ptr(self.solution),
+                                       ptr(self.is_sat), ptr(self.edge_mask), _stream()))
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().pdp_problem_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # -- graph export (replicated arrays for the python-visible attributes) --------------------------------
+    def export_graph(self):
+        dev = self.device
+        gm = torch.empty(2, self.E, dtype=torch.int32, device=dev)
+        bvm = torch.empty(self.V, dtype=torch.int32, device=dev)
+        bfm = torch.empty(self.F, dtype=torch.int32, device=dev)
+        ef = torch.empty(self.E, 1, dtype=torch.float32, device=dev)
+        check(lib().pdp_problem_export_graph(self._h, ptr(gm), ptr(bvm), ptr(bfm), ptr(ef), _stream()))
+        return gm, bvm, bfm, ef
+
+    # -- K7 / K8 ---------------------------------------------------------------------------------------------
+    def simplify(self):
+        check(lib().pdp_simplify(self._h, _stream()))
+
+    def set_variables(self, assignment):
+        check(lib().pdp_set_variables(self._h, ptr(assignment, torch.float32, self.V, 'assignment'), _stream()))
+
+    def refresh_edge_mask(self, want_flag=True):
+        flag = C.c_int32(0)
+        check(lib().pdp_refresh_edge_mask(self._h, C.byref(flag) if want_flag else None, _stream()))
+        return bool(flag.value) if want_flag else None
+
+    # -- K4 / K5 ---------------------------------------------------------------------------------------------
+    def smooth_max(self, x):
+        out = torch.empty(self.V, 1, dtype=torch.float32, device=self.device)
+        check(lib().pdp_smooth_max(self._h, ptr(x, torch.float32, self.E, 'x'), ptr(out), _stream()))
+        return out
+
+    def instance_max(self, x):
+        out = torch.empty(self.B, dtype=torch.float32, device=self.device)
+        check(lib().pdp_instance_max(self._h, ptr(x, torch.float32, self.V, 'x'), ptr(out), _stream()))
+        return out
+
+    def instance_argmax(self, x):
+        out = torch.empty(self.B, dtype=torch.int64, device=self.device)
+        check(lib().pdp_instance_argmax(self._h, ptr(x, torch.float32, self.V, 'x'), ptr(out), _stream()))
+        return out
+
+    # -- K1-K3, K6 -------------------------------------------------------------------------------------------
+    def sp_propagate(self, dec_q, dec_fs, edge_mask, active_mask, init_q, init_fs, pi=0.0):
+        out_q = torch.empty(self.E, 3, dtype=torch.float32, device=self.device)
+        out_fs = torch.empty(self.E, 2, dtype=torch.float32, device=self.device)
+        check(lib().pdp_sp_propagate(self._h, ptr(dec_q, torch.float32, 3 * self.E, 'decimator_state[0]'),
+                                     ptr(dec_fs, torch.float32, 2 * self.E, 'decimator_state[1]'),
+                                     ptr(edge_mask, torch.float32, self.E, 'edge_mask'),
+                                     ptr(active_mask, torch.uint8, self.B, 'active_mask'),
+                                     ptr(init_q, torch.float32, 3 * self.E, 'init_state[0]'),
+                                     ptr(init_fs, torch.float32, 2 * self.E, 'init_state[1]'),
+                                     C.c_float(pi), ptr(out_q), ptr(out_fs), _stream()))
+        return out_q, out_fs
+
+    def survey_score(self, fs, pi=0.0):
+        out = torch.empty(self.V, 1, dtype=torch.float32, device=self.device)
+        check(lib().pdp_survey_score(self._h, ptr(fs, torch.float32, 2 * self.E, 'message_state[1]'), C.c_float(pi), ptr(out), _stream()))
+        return out
+
+    # -- K9 / K13 --------------------------------------------------------------------------------------------
+    def cnf_eval(self, pred):
+        solved = torch.empty(self.B, 1, dtype=torch.float32, device=self.device)
+        unsat = torch.empty(self.B, 1, dtype=torch.float32, device=self.device)
+        check(lib().pdp_cnf_eval(self._h, ptr(pred, torch.float32, self.V, 'prediction'), ptr(solved), ptr(unsat), _stream()))
+        return solved, unsat
+
+    def update_solution(self, pred):
+        out = torch.empty(self.V, 1, dtype=torch.float32, device=self.device)
+        check(lib().pdp_update_solution(self._h, ptr(pred, torch.float32, self.V, 'prediction'), ptr(out), _stream()))
+        return out
+
+    def check_termination(self, active_mask, pred):
+        check(lib().pdp_check_termination(self._h, ptr(active_mask, torch.uint8, self.B, 'active_mask'),
+                                          ptr(pred, torch.float32, self.V, 'prediction'), _stream()))
+
+    # -- decimators --------------------------------------------------------------------------------------------
+    def sequential_decimate(self, dec, fs, active_mask, tolerance, t_max, pi=0.0):
+        check(lib().pdp_sequential_decimate(self._h, dec._h, ptr(fs, torch.float32, 2 * self.E, 'message_state[1]'),
+                                            ptr(active_mask, torch.uint8, self.B, 'active_mask'), C.c_float(tolerance),
+                                            C.c_float(t_max), C.c_float(pi), _stream()))
+
+    def sequential_decimate_gate(self, dec, fs, active_mask, tolerance, t_max):
+        flag = C.c_int32(0)
+        check(lib().pdp_sequential_decimate_gate(self._h, dec._h, ptr(fs, torch.float32, 2 * self.E), ptr(active_mask, torch.uint8, self.B),
+                                                 C.c_float(tolerance), C.c_float(t_max), C.byref(flag), _stream()))
+        return bool(flag.value)
+
+    def sequential_decimate_apply(self, dec, fs, score, active_mask):
+        check(lib().pdp_sequential_decimate_apply(self._h, dec._h, ptr(fs, torch.float32, 2 * self.E),
+                                                  ptr(score, torch.float32, self.V), ptr(active_mask, torch.uint8, self.B), _stream()))
+
+    def reinforce_decimate(self, dec, fs, active_mask, coin, decimation_probability, pi):
+        check(lib().pdp_reinforce_decimate(self._h, dec._h, ptr(fs, torch.float32, 2 * self.E), ptr(active_mask, torch.uint8, self.B),
+                                           C.c_float(coin), C.c_float(decimation_probability), C.c_float(pi), _stream()))
+
+    def reinforce_predict(self, fs):
+        out = torch.empty(self.V, 1, dtype=torch.float32, device=self.device)
+        check(lib().pdp_reinforce_predict(self._h, ptr(fs, torch.float32, 2 * self.E), ptr(out), _stream()))
+        return out
+
+    # -- K14 ---------------------------------------------------------------------------------------------------
+    def energy(self, assignment):
+        en = torch.empty(self.B, 1, dtype=torch.float32, device=self.device)
+        uf = torch.empty(self.F, 1, dtype=torch.float32, device=self.device)
+        check(lib().pdp_energy(self._h, ptr(assignment, torch.float32, self.V), ptr(en), ptr(uf), _stream()))
+        return en, uf
+
+    def energy_diff(self, assignment):
+        d = torch.empty(self.V, 1, dtype=torch.float32, device=self.device)
+        check(lib().pdp_energy_diff(self._h, ptr(assignment, torch.float32, self.V), ptr(d), _stream()))
+        return d
+
+    def random_fill(self, values=None, seed=0):
+        mode = RNG_STREAM if values is not None else RNG_PHILOX
+        check(lib().pdp_random_fill(self._h, C.c_int(mode), ptr(values, torch.float32), C.c_uint64(seed), _stream()))
+
+    def local_search(self, pred, iterations, epsilon, var_rand=None, coin_rand=None, seed=0):
+        out = torch.empty(self.V, 1, dtype=torch.float32, device=self.device)
+        steps = C.c_int32(0)
+        mode = RNG_STREAM if var_rand is not None else RNG_PHILOX
+        check(lib().pdp_local_search(self._h, ptr(pred, torch.float32, self.V, 'prediction'), C.c_int(iterations), C.c_float(epsilon),
+                                     C.c_int(mode), ptr(var_rand, torch.float32), ptr(coin_rand, torch.float32),
+                                     C.c_uint64(seed), ptr(out), C.byref(steps), _stream()))
+        return out, int(steps.value)
+
+    def deduplicate(self, pred):
+        out = torch.empty(self.V // self.R, 1, dtype=torch.float32, device=self.device)
+        chosen = torch.empty(self.B // self.R, dtype=torch.int32, device=self.device)
+        check(lib().pdp_deduplicate(self._h, ptr(pred, torch.float32, self.V), ptr(out), ptr(chosen), _stream()))
+        return out, chosen
+
+    # -- persistent solve -----------------------------------------------------------------------------------------
+    def sp_solve(self, q, fs, active_mask, dec, iterations, tolerance, t_max, pi=0.0, model=MODEL_SP,
+                 decimation_probability=0.5, seed=0, coins=None, check_termination=True):
+        a = SolveArgs()
+        a.model = model; a.iterations = iterations; a.tolerance = tolerance; a.t_max = t_max; a.pi = pi
+        a.decimation_probability = decimation_probability; a.seed = seed
+        a.coins = ptr(coins, torch.float32).value if coins is not None else None
+        a.q = ptr(q, torch.float32, 3 * self.E).value; a.fs = ptr(fs, torch.float32, 2 * self.E).value
+        a.active_mask = ptr(active_mask, torch.uint8, self.B).value
+        a.decimator = dec._h.value
+        a.check_termination = 1 if check_termination else 0
+        check(lib().pdp_sp_solve(self._h, C.byref(a), _stream()))
+        return int(a.iterations_run_host), bool(a.used_lds_host)
+
+
+def math_apply(fn, x):
+    names = {'exp': 0, 'log': 1, 'logsigmoid': 2, 'sigmoid': 3, 'tanh': 4, 'safe_exp': 5, 'safe_log': 6, 'philox': 7, 'rcp': 8}
+    require_gpu()
+    y = torch.empty_like(x)
+    check(lib().pdp_math_apply(C.c_int(names[fn]), ptr(x, torch.float32), ptr(y), C.c_int64(x.numel()), _stream()))
+    return y

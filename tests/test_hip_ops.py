@@ -1,0 +1,241 @@
+"""GPU parity tests: every step-wise C-ABI entry point (include/pdp_hip.h) against the CPU oracle on the
+same inputs.  The kernels and the oracle share only include/pdp_math.h, so results must be BIT-EXACT
+(floats compared with array_equal), and the oracle itself is pinned to the reference by
+tests/test_oracle_golden.py."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import random_batch, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def t(a, dtype=None):
+    x = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        x = x.to(dtype)
+    return x.to(dev())
+
+
+def npy(x):
+    return x.detach().cpu().numpy()
+
+
+def make_pair(oracle, batch, replication=1):
+    from pdp import native
+    hp = native.Problem(t(batch['graph_map']), t(batch['batch_variable_map']), t(batch['batch_function_map']),
+                        t(batch['edge_feature']), replication=replication)
+    op = oracle.Problem(batch['graph_map'], batch['batch_variable_map'], batch['batch_function_map'], batch['edge_feature'], replication)
+    return hp, op
+
+
+def assert_state_equal(hp, op):
+    av, af, sol, sat = op.state()
+    np.testing.assert_array_equal(npy(hp.active_variables)[:, 0], av)
+    np.testing.assert_array_equal(npy(hp.active_functions)[:, 0], af)
+    np.testing.assert_array_equal(npy(hp.solution), sol)
+    np.testing.assert_array_equal(npy(hp.is_sat), sat)
+
+
+BATCHES = [dict(batch=8, n=20, mixed=True, seed=1), dict(batch=64, n=40, mixed=True, seed=100),
+           dict(batch=16, n=50, k=3, seed=7), dict(batch=3, n=300, k=3, seed=9), dict(batch=1, n=30, k=3, seed=3),
+           dict(batch=40, n=12, mixed=True, seed=1000)]
+
+
+def test_device_math_bit_exact(oracle):
+    from pdp import native
+    rng = np.random.RandomState(0)
+    x = np.concatenate([rng.uniform(-110, 35, 300000), rng.uniform(-1, 1, 100000), [-92.1034, 0.0, 30.0, np.nan, np.inf, -np.inf]]).astype(np.float32)
+    for fn in ('exp', 'safe_exp', 'logsigmoid', 'sigmoid', 'tanh', 'philox'):
+        np.testing.assert_array_equal(npy(native.math_apply(fn, t(x))), oracle.math_apply(fn, x), err_msg=fn)
+    xl = np.concatenate([np.exp(rng.uniform(-100, 10, 300000)), rng.uniform(0, 2, 100000), [1e-40, 1e-45, 0.0, -1.0, np.nan, np.inf]]).astype(np.float32)
+    for fn in ('log', 'safe_log', 'rcp'):
+        np.testing.assert_array_equal(npy(native.math_apply(fn, t(xl))), oracle.math_apply(fn, xl), err_msg=fn)
+
+
+@pytest.mark.parametrize('spec', BATCHES)
+def test_layout_and_simplify(oracle, spec):
+    b = random_batch(**spec)
+    hp, op = make_pair(oracle, b)
+    assert (hp.E, hp.V, hp.F, hp.B) == (op.E, op.V, op.F, op.B)
+    hp.simplify(); op.simplify()
+    assert_state_equal(hp, op)
+    rng = np.random.RandomState(5)
+    assign = np.zeros(op.V, np.float32)
+    pick = rng.choice(op.V, size=max(1, op.V // 10), replace=False)
+    assign[pick] = rng.randint(0, 2, size=len(pick)) * 2 - 1
+    ta = t(assign)
+    hp.set_variables(ta); a2 = op.set_variables(assign)
+    assert_state_equal(hp, op)
+    np.testing.assert_array_equal(npy(ta), a2)
+    all_active = hp.refresh_edge_mask()
+    m, s = op.refresh_edge_mask()
+    np.testing.assert_array_equal(npy(hp.edge_mask)[:, 0], m)
+    assert all_active == (s == op.E)
+
+
+def test_replicated_layout(oracle):
+    b = random_batch(batch=5, n=15, mixed=True, seed=11)
+    hp, op = make_pair(oracle, b, replication=3)
+    gm, bvm, bfm, ef = hp.export_graph()
+    ev, ec, es, vi, fi = op.graph()
+    np.testing.assert_array_equal(npy(gm), np.stack([ev, ec]))
+    np.testing.assert_array_equal(npy(bvm), vi)
+    np.testing.assert_array_equal(npy(bfm), fi)
+    np.testing.assert_array_equal(npy(ef)[:, 0], es)
+    hp.simplify(); op.simplify()
+    assert_state_equal(hp, op)
+
+
+def test_bad_layout_is_rejected():
+    from pdp import native
+    b = random_batch(batch=4, n=10, seed=1)
+    bvm = b['batch_variable_map'].copy(); bvm[0] = 3
+    with pytest.raises(native.NativeError):
+        native.Problem(t(b['graph_map']), t(bvm), t(b['batch_function_map']), t(b['edge_feature']))
+
+
+def prepared_pair(oracle, spec, seed=0):
+    """Problem pair after simplify + a few fixed variables, with a refreshed edge mask."""
+    b = random_batch(**spec)
+    hp, op = make_pair(oracle, b)
+    hp.simplify(); op.simplify()
+    rng = np.random.RandomState(seed)
+    assign = np.zeros(op.V, np.float32)
+    pick = rng.choice(op.V, size=max(1, op.V // 8), replace=False)
+    assign[pick] = rng.randint(0, 2, size=len(pick)) * 2 - 1
+    hp.set_variables(t(assign)); op.set_variables(assign)
+    hp.refresh_edge_mask(); op.refresh_edge_mask()
+    return hp, op, rng
+
+
+@pytest.mark.parametrize('spec', BATCHES[:4])
+def test_reductions(oracle, spec):
+    hp, op, rng = prepared_pair(oracle, spec)
+    x = rng.rand(op.E).astype(np.float32); x[rng.rand(op.E) < 0.1] = 0
+    np.testing.assert_array_equal(npy(hp.smooth_max(t(x)))[:, 0], op.smooth_max(x))
+    for xv in (rng.rand(op.V).astype(np.float32) * (rng.rand(op.V) > 0.2), rng.randn(op.V).astype(np.float32),
+               0.3 + rng.rand(op.V).astype(np.float32), np.round(rng.randn(op.V) * 3).astype(np.float32)):
+        xv = xv.astype(np.float32)
+        np.testing.assert_array_equal(npy(hp.instance_max(t(xv))), op.instance_max(xv))
+        np.testing.assert_array_equal(npy(hp.instance_argmax(t(xv))), op.instance_argmax(xv))
+    xn = rng.rand(op.V).astype(np.float32); xn[op.V // 2] = np.nan
+    np.testing.assert_array_equal(npy(hp.instance_max(t(xn))), op.instance_max(xn))
+    np.testing.assert_array_equal(npy(hp.instance_argmax(t(xn))), op.instance_argmax(xn))
+
+
+@pytest.mark.parametrize('spec', BATCHES[:4])
+@pytest.mark.parametrize('pi', [0.0, 0.1])
+def test_sp_propagate_score_cnf(oracle, spec, pi):
+    hp, op, rng = prepared_pair(oracle, spec)
+    E, V, B = op.E, op.V, op.B
+    q = rng.rand(E, 3).astype(np.float32); q /= q.sum(1, keepdims=True); q[rng.rand(E) < 0.05, 0] = 0
+    fs = rng.rand(E, 2).astype(np.float32); fs[rng.rand(E) < 0.05, 0] = 1.0
+    fs[:, 1] = rng.randint(-1, 2, size=E) if pi > 0 else 0
+    iq = rng.rand(E, 3).astype(np.float32); ifs = rng.rand(E, 2).astype(np.float32)
+    am = (rng.rand(B) > 0.3).astype(np.uint8)
+    em, _ = op.refresh_edge_mask()
+    for use_mask in (True, False):
+        hq, hfs = hp.sp_propagate(t(q), t(fs), hp.edge_mask if use_mask else None, t(am) if use_mask else None, t(iq), t(ifs), pi)
+        oq, ofs = op.sp_propagate(q, fs, em if use_mask else None, am if use_mask else None, iq, ifs, pi)
+        np.testing.assert_array_equal(npy(hq), oq)
+        np.testing.assert_array_equal(npy(hfs), ofs)
+    np.testing.assert_array_equal(npy(hp.survey_score(t(fs), pi))[:, 0], op.survey_score(fs, pi))
+    pred = rng.rand(V).astype(np.float32); pred[rng.rand(V) < 0.3] = 0.5; pred[rng.rand(V) < 0.2] = 1; pred[rng.rand(V) < 0.2] = 0
+    hs, hu = hp.cnf_eval(t(pred)); os_, ou = op.cnf_eval(pred)
+    np.testing.assert_array_equal(npy(hs)[:, 0], os_); np.testing.assert_array_equal(npy(hu)[:, 0], ou)
+    np.testing.assert_array_equal(npy(hp.update_solution(t(pred)))[:, 0], op.update_solution(pred))
+    assert_state_equal(hp, op)
+    ham = t(np.ones(B, np.uint8)); hp.check_termination(ham, t(pred))
+    np.testing.assert_array_equal(npy(ham), op.check_termination(np.ones(B, np.uint8), pred))
+
+
+@pytest.mark.parametrize('spec', BATCHES[:4])
+def test_energy_and_walksat_pieces(oracle, spec):
+    hp, op, rng = prepared_pair(oracle, spec)
+    av = op.state()[0]
+    a = ((rng.randint(0, 2, size=op.V) * 2 - 1) * av).astype(np.float32)
+    he, hu = hp.energy(t(a)); oe, ou = op.energy(a)
+    np.testing.assert_array_equal(npy(he)[:, 0], oe); np.testing.assert_array_equal(npy(hu)[:, 0], ou)
+    np.testing.assert_array_equal(npy(hp.energy_diff(t(a)))[:, 0], op.energy_diff(a))
+
+
+@pytest.mark.parametrize('spec', BATCHES[:5])
+@pytest.mark.parametrize('mode', ['stream', 'philox'])
+def test_random_fill_and_local_search(oracle, spec, mode):
+    hp, op, rng = prepared_pair(oracle, spec)
+    w = 25
+    n_active = int((op.state()[0] > 0).sum())
+    if mode == 'stream':
+        stream = rng.rand(n_active + w * (op.V + op.B)).astype(np.float32)
+        hp.random_fill(values=t(stream[:n_active]))
+        cur = op.random_fill(stream=stream)
+        assert cur == n_active
+        rest = stream[n_active:].reshape(w, op.V + op.B)
+        var_rand = np.ascontiguousarray(rest[:, :op.V]); coin = np.ascontiguousarray(rest[:, op.V:])
+        assert_state_equal(hp, op)
+        pred = op.state()[2]
+        hout, hsteps = hp.local_search(t(pred), w, 0.5, t(var_rand), t(coin))
+        oout, osteps, cur2 = op.local_search(pred, w, 0.5, stream=stream, cursor=cur)
+        assert cur2 == n_active + osteps * (op.V + op.B)
+    else:
+        hp.random_fill(seed=1234); op.random_fill(seed=1234)
+        assert_state_equal(hp, op)
+        pred = op.state()[2]
+        hout, hsteps = hp.local_search(t(pred), w, 0.5, seed=99)
+        oout, osteps, _ = op.local_search(pred, w, 0.5, seed=99)
+    assert hsteps == osteps
+    np.testing.assert_array_equal(npy(hout)[:, 0], oout)
+
+
+@pytest.mark.parametrize('spec', BATCHES[:4])
+def test_sequential_decimator_steps(oracle, spec):
+    """Drive propagate + decimate for a number of iterations through the step-wise entry points and compare
+    the complete state with the oracle after every step (tolerance chosen so decimation fires)."""
+    from pdp import native
+    b = random_batch(**spec)
+    hp, op = make_pair(oracle, b)
+    hp.simplify(); op.simplify()
+    E, B = op.E, op.B
+    q = np.full((E, 3), 1.0 / 3.0, np.float32); fs = np.zeros((E, 2), np.float32); fs[:, 0] = 0.5
+    hq, hfs = t(q), t(fs)
+    ham = t(np.ones(B, np.uint8)); oam = np.ones(B, np.uint8)
+    hd = native.Decimator(hp); od = op.new_decimator()
+    use_mask = False
+    for it in range(25):
+        hq, hfs = hp.sp_propagate(hq, hfs, hp.edge_mask if use_mask else None, ham, hq, hfs, 0.0)
+        em = op.refresh_edge_mask()[0] if use_mask else None
+        q, fs = op.sp_propagate(q, fs, em, oam, q, fs, 0.0)
+        np.testing.assert_array_equal(npy(hq), q, err_msg='q it %d' % it)
+        hp.sequential_decimate(hd, hfs, ham, 0.05, 6, 0.0)
+        oam, _ = op.sequential_decimate(od, fs, oam, 0.05, 6, 0.0)
+        np.testing.assert_array_equal(npy(ham), oam, err_msg='active mask it %d' % it)
+        assert_state_equal(hp, op)
+        all_active = hp.refresh_edge_mask()
+        m, s = op.refresh_edge_mask()
+        assert all_active == (s == E)
+        if not all_active:
+            use_mask = True
+        pred = op.state()[2]
+        hpred = hp.update_solution(hp.solution.clone())
+        opred = op.update_solution(pred)
+        hp.check_termination(ham, hpred.view(-1)); oam = op.check_termination(oam, opred)
+        np.testing.assert_array_equal(npy(ham), oam)
+    prev, cnt, fl = op.decimator_get(od)
+    op.free_decimator(od)
+
+
+def test_deduplicate(oracle):
+    b = random_batch(batch=6, n=20, mixed=True, seed=21)
+    hp, op = make_pair(oracle, b, replication=4)
+    hp.simplify(); op.simplify()
+    rng = np.random.RandomState(1)
+    pred = (rng.rand(op.V) > 0.5).astype(np.float32)
+    hout, hch = hp.deduplicate(t(pred)); oout, och = op.deduplicate(pred)
+    np.testing.assert_array_equal(npy(hout)[:, 0], oout)
+    np.testing.assert_array_equal(npy(hch), och)
