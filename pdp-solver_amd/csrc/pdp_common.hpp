@@ -59,6 +59,7 @@ enum {
     FL_SPEC_VIOLATION = 13,
     FL_ITERS_RUN = 14,
     FL_WS_STEPS = 15,
+    FL_PERM_ZERO = 16,   // first iteration from which an exited instance guarantees exact zeros
     FL_COUNT = 32
 };
 

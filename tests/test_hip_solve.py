@@ -1,0 +1,94 @@
+"""GPU parity tests of the persistent solver (pdp_sp_solve): one launch for the whole PDP loop must leave
+exactly the state the oracle's iteration loop leaves (bit-exact floats, identical integer trajectories)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import random_batch, load_golden
+from test_hip_ops import t, npy, make_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def run_pair(oracle, batch, T, tol, t_max):
+    from pdp import native
+    hp, op = make_pair(oracle, batch)
+    res = op.forward('p-d-p', T, local_search_iterations=0, tolerance=tol, t_max=t_max, seed=5, trace=True)
+    hp.simplify()
+    E, B = hp.E, hp.B
+    q = torch.full((E, 3), 1.0, device='cuda:0') / 3.0
+    fs = torch.zeros(E, 2, device='cuda:0'); fs[:, 0] = 0.5
+    am = torch.ones(B, dtype=torch.uint8, device='cuda:0')
+    dec = native.Decimator(hp)
+    try:
+        iters, used_lds = hp.sp_solve(q, fs, am, dec, T, tol, t_max)
+        spec_ok = True
+    except native.SpeculationFailed:
+        spec_ok = False
+        iters, used_lds = -1, None
+    return hp, res, q, fs, am, iters, used_lds, spec_ok
+
+
+SPECS = [(dict(batch=16, n=50, k=3, seed=7), 40, 0.02, 100),
+         (dict(batch=64, n=40, mixed=True, seed=100), 30, 0.05, 6),
+         (dict(batch=40, n=40, k=3, m=140, seed=900), 60, 0.05, 10),
+         (dict(batch=200, n=30, k=3, m=100, seed=300), 50, 0.05, 8),
+         (dict(batch=6, n=200, k=3, seed=11), 30, 0.02, 100)]
+
+
+@pytest.mark.parametrize('spec,T,tol,t_max', SPECS)
+def test_persistent_solve_matches_oracle_loop(oracle, spec, T, tol, t_max):
+    b = random_batch(**spec)
+    hp, res, q, fs, am, iters, used_lds, spec_ok = run_pair(oracle, b, T, tol, t_max)
+    assert spec_ok, "speculation unexpectedly failed on a benign batch"
+    assert used_lds
+    it = res['iterations_run']
+    assert iters == it
+    np.testing.assert_array_equal(npy(am), res['trace_active_mask'][it - 1])
+    np.testing.assert_array_equal(npy(hp.active_variables)[:, 0], res['trace_active_var'][it - 1])
+    np.testing.assert_array_equal(npy(hp.active_functions)[:, 0], res['trace_active_fn'][it - 1])
+    np.testing.assert_array_equal(npy(hp.solution), res['trace_solution'][it - 1])
+    np.testing.assert_array_equal(npy(q), res['q'])
+    np.testing.assert_array_equal(npy(fs), res['fs'])
+
+
+def test_persistent_solve_golden_trace():
+    """Against the reference itself (golden trace): identical integer trajectory end state."""
+    from pdp import native
+    d = load_golden('trace_pdp_easy_ws')
+    T = int(d['meta'][0])
+    hp = native.Problem(t(d['graph_map']), t(d['batch_variable_map']), t(d['batch_function_map']), t(d['edge_feature']))
+    hp.simplify()
+    q = torch.full((hp.E, 3), 1.0, device='cuda:0') / 3.0
+    fs = torch.zeros(hp.E, 2, device='cuda:0'); fs[:, 0] = 0.5
+    am = torch.ones(hp.B, dtype=torch.uint8, device='cuda:0')
+    dec = native.Decimator(hp)
+    iters, _ = hp.sp_solve(q, fs, am, dec, T, 0.05, 10)
+    it = int(d['iterations_run'][0])
+    assert iters == it
+    np.testing.assert_array_equal(npy(hp.active_variables)[:, 0], d['trace_active_variables'][it - 1])
+    np.testing.assert_array_equal(npy(hp.active_functions)[:, 0], d['trace_active_functions'][it - 1])
+    np.testing.assert_array_equal(npy(hp.solution), d['trace_solution'][it - 1])
+    np.testing.assert_array_equal(npy(am), d['trace_active_mask'][it - 1])
+    np.testing.assert_allclose(npy(q), d['final_prop_0'], rtol=5e-4, atol=5e-6)
+
+
+def test_speculation_detects_coupling(oracle):
+    """A single instance without any inactive variable has batch-global min > 0: the persistent solver must
+    refuse (PDP_ERR_SPECULATION) instead of returning a result that differs from the reference."""
+    from pdp import native
+    from pdp.factorgraph import dataset
+    n = 12
+    clauses = []
+    for v in range(1, n + 1):
+        a, b2 = (v % n) + 1, ((v + 4) % n) + 1
+        clauses.append([v, -a, b2]); clauses.append([-v, a, -b2]); clauses.append([v, a, -b2]); clauses.append([-v, -a, b2])
+    b = dataset.collate_segment([dataset.instance_from_clauses(n, clauses)])
+    hp, op = make_pair(oracle, b)
+    hp.simplify(); op.simplify()
+    assert op.state()[0].min() == 1.0     # nothing got de-activated: no exact zero in the batch
+    q = torch.full((hp.E, 3), 1.0, device='cuda:0') / 3.0
+    fs = torch.zeros(hp.E, 2, device='cuda:0'); fs[:, 0] = 0.5
+    am = torch.ones(hp.B, dtype=torch.uint8, device='cuda:0')
+    with pytest.raises(native.SpeculationFailed):
+        hp.sp_solve(q, fs, am, native.Decimator(hp), 5, 0.02, 100)
