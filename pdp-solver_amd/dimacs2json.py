@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""DIMACS -> compact JSON converter (drop-in for the reference's src/dimacs2json.py).
+
+Output lines are byte-identical to the reference's for valid input (``[[n, m], [signed vars], [clause ids], label,
+[file name]]``, reference: dimacs2json.py:85-91,111,125) including its conventions: the last occurrence of a
+variable inside a clause wins, empty clauses and unused variables are dropped, literals are clause-major with
+ascending variable index, the label is the last digit of the file stem (directory mode, :105) or the character
+8 from the end of the path (file mode, :118-122).  The parser streams clauses into sparse rows instead of the
+reference's dense [clauses x variables] matrix, so big instances do not need O(n*m) memory; the O(m^2)
+subsumption option ``-s`` is out of scope.
+"""
+
+import argparse
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+
+from pdp import generator  # noqa: E402
+
+
+def parse_dimacs(path):
+    """Returns (declared variable count, list of clauses as lists of signed ints)."""
+    n = 0
+    clauses = []
+    with open(path, 'r') as f:
+        for line in f:
+            tok = line.split()
+            if not tok or tok[0] == 'c' or tok[0] == '%':
+                continue
+            if tok[0] == 'p':
+                n = int(tok[2])
+                continue
+            lits = []
+            for t in tok:
+                v = int(t)
+                if v == 0:
+                    break
+                lits.append(v)
+            clauses.append(lits)
+    return n, clauses
+
+
+def json_line(path, label):
+    n, clauses = parse_dimacs(path)
+    return generator.json_line(n, clauses, label=label, name=os.path.split(path)[1])
+
+
+def convert_directory(dimacs_dir, output_file, propagate=False, only_positive=False):
+    if propagate:
+        raise NotImplementedError("-s/--simplify (clause subsumption) is out of scope for the native port")
+    file_list = [os.path.join(dimacs_dir, f) for f in os.listdir(dimacs_dir) if os.path.isfile(os.path.join(dimacs_dir, f))]
+    with open(output_file, 'w') as f:
+        for path in file_list:
+            name, ext = os.path.splitext(path)
+            if ext.lower() not in ('.dimacs', '.cnf'):
+                continue
+            label = float(name[-1]) if name[-1].isdigit() else -1
+            if only_positive and label == 0:
+                continue
+            f.write(json_line(path, label) + '\n')
+
+
+def convert_file(file_name, output_file, propagate=False):
+    if propagate:
+        raise NotImplementedError("-s/--simplify (clause subsumption) is out of scope for the native port")
+    if len(file_name) < 8:
+        label = -1
+    else:
+        c = file_name[-8]
+        label = float(c) if c.isdigit() else -1
+    with open(output_file, 'w') as f:
+        f.write(json_line(file_name, label) + '\n')
+
+
+if __name__ == '__main__':
+    parser = argparse.ArgumentParser()
+    parser.add_argument('in_dir', action='store', type=str)
+    parser.add_argument('out_file', action='store', type=str)
+    parser.add_argument('-s', '--simplify', help='Propagate binary constraints', required=False, action='store_true', default=False)
+    parser.add_argument('-p', '--positive', help='Output only positive examples', required=False, action='store_true', default=False)
+    args = vars(parser.parse_args())
+    convert_directory(args['in_dir'], args['out_file'], args['simplify'], args['positive'])

@@ -36,6 +36,19 @@ def instance_from_clauses(n, clauses, label=-1.0, name=""):
     return var_num, clause_num, graph_map, np.sign(sv).astype(np.float32), float(label), [name] if name else []
 
 
+def random_ksat_items(batch, n, k=3, m=None, seed=0):
+    """``batch`` uniform random k-SAT instances (instance i from RandomState(seed + i)) as loader items."""
+    from pdp import generator
+    if m is None:
+        m = generator.clause_count(n, k)
+    items = []
+    for i in range(batch):
+        variables, signs = generator.uniform_ksat_arrays(n, m, k, np.random.RandomState(seed + i))
+        vn, fn, gm, ef = generator.compact_arrays(n, variables, signs)
+        items.append((vn, fn, gm, ef, -1.0, ["rand_%d" % (seed + i)]))
+    return items
+
+
 def divide(edge_nums, limit, hidden_dim):
     """Dynamic batching: index lists of the segments of one loader batch.
 
@@ -135,6 +148,10 @@ class FactorGraphDataset(object):
             dataset = ds
 
             def __iter__(self):
+                # torch's DataLoader draws its base seed from the global CPU generator whenever an iterator is
+                # created (reference: base.py:258 enumerates the loader once per predict call).  Consume the
+                # same draw so that later torch.rand calls see the reference's random stream.
+                torch.empty((), dtype=torch.int64).random_()
                 for segs in ds.batches(batch_size):
                     yield ([torch.from_numpy(s['graph_map']) for s in segs],
                            [torch.from_numpy(s['batch_variable_map']) for s in segs],

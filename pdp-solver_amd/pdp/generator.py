@@ -23,6 +23,40 @@ def uniform_ksat(n, m, k, rng):
     return clauses
 
 
+def uniform_ksat_arrays(n, m, k, rng):
+    """Vectorised uniform k-SAT: returns (variables int32 [m,k] 0-based, ascending within a clause;
+    signs int8 [m,k] in {-1,+1}).  Same distribution as ``uniform_ksat`` (distinct variables per
+    clause, fair signs) but a different random stream; used for the large benchmark batches."""
+    variables = rng.randint(0, n, size=(m, k))
+    while True:
+        srt = np.sort(variables, axis=1)
+        dup = (srt[:, 1:] == srt[:, :-1]).any(axis=1)
+        if not dup.any():
+            break
+        variables[dup] = rng.randint(0, n, size=(int(dup.sum()), k))
+    signs = (rng.randint(0, 2, size=(m, k)) * 2 - 1).astype(np.int8)
+    order = np.argsort(variables, axis=1, kind='stable')
+    variables = np.take_along_axis(variables, order, axis=1).astype(np.int32)
+    signs = np.take_along_axis(signs, order, axis=1)
+    return variables, signs
+
+
+def compact_arrays(n, variables, signs):
+    """Array form of ``compact_instance`` for fixed-k clause matrices with distinct variables per clause:
+    drops unused variables (ascending renumbering).  Returns (var_num, clause_num, graph_map int32 [2,E],
+    edge_feature float32 [E]) in the loader's clause-major order."""
+    m, k = variables.shape
+    used = np.unique(variables)
+    if used.size == n:
+        local = variables
+    else:
+        remap = np.full(n, -1, dtype=np.int32)
+        remap[used] = np.arange(used.size, dtype=np.int32)
+        local = remap[variables]
+    graph_map = np.stack((local.reshape(-1), np.repeat(np.arange(m, dtype=np.int32), k))).astype(np.int32)
+    return int(used.size), int(m), graph_map, signs.reshape(-1).astype(np.float32)
+
+
 def clause_count(n, k, alpha=None):
     """Number of clauses for the benchmark family: threshold-ish ratios."""
     if alpha is None:

@@ -1,0 +1,79 @@
+"""Decimators of the PDP framework (reference: src/pdp/nn/pdp_decimate.py)."""
+
+import torch
+import torch.nn as nn
+
+from pdp import native
+from pdp.nn import pdp_predict
+
+
+class SequentialDecimator(nn.Module):
+    """Convergence-gated greedy decimation, one variable per converged instance and call
+    (reference: pdp_decimate.py:106-183).  The stateful parts of the reference (``_previous_function_state``,
+    ``_counters``) live in a native decimator handle that is re-created by ``get_init_state``."""
+
+    def __init__(self, device, message_dimension, scorer, tolerance, t_max):
+        super(SequentialDecimator, self).__init__()
+        self._device = device
+        self._tolerance = tolerance
+        self._scorer = scorer
+        self._message_dimension = message_dimension
+        self._t_max = t_max
+        self._module_list = nn.ModuleList([self._scorer])
+        self._handle = None
+        self._handle_problem = None
+
+    def native_handle(self, sat_problem):
+        if self._handle is None or self._handle_problem is not sat_problem._native:
+            self._handle = native.Decimator(sat_problem._native)
+            self._handle_problem = sat_problem._native
+        return self._handle
+
+    def forward(self, init_state, message_state, sat_problem, is_training, active_mask=None):
+        handle = self.native_handle(sat_problem)
+        fs = message_state[1].contiguous()
+        am = None if active_mask is None else active_mask.reshape(-1)
+        if isinstance(self._scorer, pdp_predict.SurveyScorer):
+            sat_problem._native.sequential_decimate(handle, fs, am, self._tolerance, self._t_max, self._scorer._pi)
+        else:
+            # foreign scorer plug-in: native gate, python scorer, native apply (pdp_decimate.py:152-171)
+            if sat_problem._native.sequential_decimate_gate(handle, fs, am, self._tolerance, self._t_max):
+                score, _ = self._scorer(message_state, sat_problem)
+                sat_problem._native.sequential_decimate_apply(handle, fs, score.reshape(-1).contiguous(), am)
+            else:
+                sat_problem._native.sequential_decimate_apply(handle, fs, None, am)
+        return message_state
+
+    def get_init_state(self, graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, randomized, batch_replication):
+        self._handle = None
+        self._handle_problem = None
+        return self._scorer.get_init_state(graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, randomized, batch_replication)
+
+
+class ReinforceDecimator(nn.Module):
+    "Distributed decimation through an external force (reference: pdp_decimate.py:189-250)."
+
+    def __init__(self, device, scorer, decimation_probability=0.5):
+        super(ReinforceDecimator, self).__init__()
+        self._device = device
+        self._scorer = scorer
+        self._decimation_probability = decimation_probability
+        self._function_message_dim = 3
+        self._variable_message_dim = 2
+        self._handle = None
+        self._handle_problem = None
+
+    def forward(self, init_state, message_state, sat_problem, is_training, active_mask=None):
+        if self._handle is None or self._handle_problem is not sat_problem._native:
+            self._handle = native.Decimator(sat_problem._native)
+            self._handle_problem = sat_problem._native
+        variable_state, function_state = message_state
+        coin = float(torch.rand(1).item())          # one shared coin per batch (pdp_decimate.py:218)
+        am = None if active_mask is None else active_mask.reshape(-1)
+        sat_problem._native.reinforce_decimate(self._handle, function_state, am, coin, self._decimation_probability, self._scorer._pi)
+        return variable_state, function_state
+
+    def get_init_state(self, graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, randomized, batch_replication):
+        self._handle = None
+        self._handle_problem = None
+        return pdp_predict._init_sp_state(self._device, graph_map.size(1) * batch_replication, randomized)

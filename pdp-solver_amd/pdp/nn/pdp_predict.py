@@ -1,0 +1,73 @@
+"""Predictors and scorers of the PDP framework (reference: src/pdp/nn/pdp_predict.py)."""
+
+import torch
+import torch.nn as nn
+
+from pdp import native
+
+
+def _init_sp_state(device, edge_num, randomized):
+    "reference: SurveyScorer.get_init_state pdp_predict.py:194-208"
+    if randomized:
+        variable_state = torch.rand(edge_num, 3, dtype=torch.float32)
+        function_state = torch.rand(edge_num, 2, dtype=torch.float32)
+        function_state[:, 1] = 0
+        return (variable_state.to(device), function_state.to(device))
+    variable_state = torch.ones(edge_num, 3, dtype=torch.float32, device=device) / 3.0
+    function_state = 0.5 * torch.ones(edge_num, 2, dtype=torch.float32, device=device)
+    function_state[:, 1] = 0
+    return (variable_state, function_state)
+
+
+class IdentityPredictor(nn.Module):
+    """Prediction = the problem's current solution; on the last call the still-undecided variables are filled
+    with uniform random numbers (reference: pdp_predict.py:110-128).  ``rng`` selects where those numbers come
+    from: 'torch' draws them from the global torch CPU generator in the reference's order (bit-compatible
+    with the reference's --cpu_mode run for the same seed), 'philox' draws them on the device."""
+
+    def __init__(self, device, random_fill=False, rng='torch', seed=0):
+        super(IdentityPredictor, self).__init__()
+        self._random_fill = random_fill
+        self._device = device
+        self._rng = rng
+        self._seed = seed
+
+    def forward(self, decimator_state, sat_problem, last_call=False):
+        pred = sat_problem._solution.unsqueeze(1)
+        if self._random_fill and last_call:
+            if self._rng == 'torch':
+                active_var_num = int((sat_problem._active_variables[:, 0] > 0).long().sum().item())
+                if active_var_num > 0:
+                    sat_problem._native.random_fill(values=torch.rand(active_var_num).to(self._device))
+            else:
+                sat_problem._native.random_fill(seed=self._seed)
+        return pred, None
+
+
+class SurveyScorer(nn.Module):
+    "SP bias W+ - W- per variable (reference: pdp_predict.py:134-208)."
+
+    def __init__(self, device, message_dimension, include_adaptors=False, pi=0.0):
+        super(SurveyScorer, self).__init__()
+        if include_adaptors:
+            raise native.NativeError("SurveyScorer(include_adaptors=True) has no native kernel")
+        self._device = device
+        self._include_adaptors = False
+        self._pi = float(pi)
+
+    def forward(self, message_state, sat_problem, last_call=False):
+        return sat_problem._native.survey_score(message_state[1].contiguous(), self._pi), None
+
+    def get_init_state(self, graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, randomized, batch_replication):
+        return _init_sp_state(self._device, graph_map.size(1) * batch_replication, randomized)
+
+
+class ReinforcePredictor(nn.Module):
+    "x_i = [sum of the external force over the variable's edges > 0] (reference: pdp_predict.py:214-226)."
+
+    def __init__(self, device):
+        super(ReinforcePredictor, self).__init__()
+        self._device = device
+
+    def forward(self, decimator_state, sat_problem, last_call=False):
+        return sat_problem._native.reinforce_predict(decimator_state[1].contiguous()), None

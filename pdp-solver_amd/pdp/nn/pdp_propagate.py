@@ -1,0 +1,53 @@
+"""Propagators of the PDP framework (reference: src/pdp/nn/pdp_propagate.py).
+
+``SurveyPropagator`` keeps the reference's constructor and ``forward(init_state, decimator_state, sat_problem,
+is_training, active_mask)`` signature (pdp_propagate.py:114-237); the sweep itself is the HIP kernel behind
+``pdp_sp_propagate`` (csrc/pdp_ops.hip) instead of ten sparse products.
+"""
+
+import torch
+import torch.nn as nn
+
+from pdp import native
+
+
+class SurveyPropagator(nn.Module):
+    "Survey Propagation in the log domain (reference: pdp_propagate.py:114-221), adaptors not supported natively."
+
+    def __init__(self, device, decimator_dimension, include_adaptors=False, pi=0.0):
+        super(SurveyPropagator, self).__init__()
+        if include_adaptors:
+            raise native.NativeError("SurveyPropagator(include_adaptors=True) (model type p-nd-np) is not runnable in the "
+                                     "reference either (SURVEY.md App. B-5) and has no native kernel")
+        self._device = device
+        self._function_message_dim = 3
+        self._variable_message_dim = 2
+        self._include_adaptors = False
+        self._pi = float(pi)
+
+    def forward(self, init_state, decimator_state, sat_problem, is_training, active_mask=None):
+        if len(decimator_state) == 3:
+            dec_q, dec_fs, edge_mask = decimator_state
+        else:
+            dec_q, dec_fs = decimator_state
+            edge_mask = None
+        init_q, init_fs = init_state
+        am = None if active_mask is None else active_mask.reshape(-1).contiguous()
+        return sat_problem._native.sp_propagate(dec_q.contiguous(), dec_fs.contiguous(),
+                                                None if edge_mask is None else edge_mask.reshape(-1).contiguous(),
+                                                am, init_q.contiguous(), init_fs.contiguous(), self._pi)
+
+    def get_init_state(self, graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, randomized, batch_replication):
+        "reference: pdp_propagate.py:223-237 (random draws come from the torch CPU generator, like the reference on CPU)"
+        edge_num = graph_map.size(1) * batch_replication
+        dev = self._device
+        if randomized:
+            variable_state = torch.rand(edge_num, self._function_message_dim, dtype=torch.float32)
+            variable_state = variable_state / torch.sum(variable_state, 1).unsqueeze(1)
+            function_state = torch.rand(edge_num, self._variable_message_dim, dtype=torch.float32)
+            function_state[:, 1] = 0
+            return (variable_state.to(dev), function_state.to(dev))
+        variable_state = torch.ones(edge_num, self._function_message_dim, dtype=torch.float32, device=dev) / self._function_message_dim
+        function_state = 0.5 * torch.ones(edge_num, self._variable_message_dim, dtype=torch.float32, device=dev)
+        function_state[:, 1] = 0
+        return (variable_state, function_state)

@@ -1,0 +1,361 @@
+"""The PDP solver framework on the MI355X-native library.
+
+Keeps the reference's class names, constructor arguments and ``forward`` / ``get_init_state`` signatures
+(reference: src/pdp/nn/solver.py) so that ``trainer`` / ``satyr.py`` and third-party plug-ins keep working:
+
+* ``SATProblem`` (solver.py:19-285) -- batch container.  The reference materialises 24 sparse COO masks; here the
+  batch lives in an instance-local CSR layout in HBM (csrc/pdp_problem.hip) and the reference's mask tuples are
+  only built lazily for plug-ins that still want them.
+* ``PropagatorDecimatorSolverBase`` (solver.py:293-511) -- the PDP loop.  When the (propagator, decimator,
+  predictor, termination check) quadruple is the native classical one, the whole ``_forward_core`` loop runs as ONE
+  persistent kernel (csrc/pdp_solve.hip); otherwise the generic step-wise loop below calls the plug-ins exactly like
+  the reference does.  Results are identical either way (tests/test_api_forward.py).
+"""
+
+import os
+
+import torch
+import torch.nn as nn
+
+from pdp import native
+from pdp.nn import pdp_propagate, pdp_decimate, pdp_predict, util
+
+
+###############################################################
+### The Problem Class
+###############################################################
+
+class SATProblem(object):
+    "A batch of CNF instances resident in HBM (reference: solver.py:19-285)."
+
+    def __init__(self, data_batch, device, batch_replication=1):
+        self._device = device
+        self._batch_replication = batch_replication
+        graph_map, batch_variable_map, batch_function_map, edge_feature, meta_data, _ = data_batch
+        if meta_data is not None:
+            raise native.NativeError("meta_data (graph features) is not supported by the native path "
+                                     "(has_meta_data is False in every reference config)")
+        self._orig = (graph_map, batch_variable_map, batch_function_map, edge_feature)
+        self._native = native.Problem(graph_map, batch_variable_map, batch_function_map, edge_feature,
+                                      replication=batch_replication)
+        self._native1 = None
+        self._meta_data = None
+        self._variable_num = self._native.V
+        self._function_num = self._native.F
+        self._edge_num = self._native.E
+        self._batch_size = self._native.B
+        if batch_replication > 1:
+            self._graph_map, self._batch_variable_map, self._batch_function_map, self._edge_feature = self._native.export_graph()
+        else:
+            self._graph_map, self._batch_variable_map, self._batch_function_map = graph_map, batch_variable_map, batch_function_map
+            self._edge_feature = edge_feature.reshape(-1, 1)
+        # state tensors are owned here and mutated in place by the kernels (solver.py:49-54)
+        self._active_variables = self._native.active_variables
+        self._active_functions = self._native.active_functions
+        self._solution = self._native.solution
+        self._is_sat = self._native.is_sat
+        self._edge_mask = None
+        self._masks = {}
+
+    def _native_unreplicated(self):
+        "handle on the original (non-replicated) batch, used by evaluators that look at de-duplicated predictions"
+        if self._native1 is None:
+            gm, bvm, bfm, ef = self._orig
+            self._native1 = native.Problem(gm, bvm, bfm, ef, replication=1)
+        return self._native1
+
+    # ---- K7 / K8 -------------------------------------------------------------------------------------------
+    def simplify(self):
+        "unit propagation + pure-literal elimination to a fix-point (solver.py:281-285)"
+        self._native.simplify()
+
+    def set_variables(self, assignment):
+        "fix variables ({-1,0,+1} per variable) and simplify (solver.py:275-279); ``assignment`` is masked in place"
+        self._native.set_variables(assignment.reshape(-1))
+
+    def refresh_edge_mask(self):
+        "solver.py:370-371; returns True when every edge is still active"
+        all_active = self._native.refresh_edge_mask(True)
+        self._edge_mask = self._native.edge_mask
+        return all_active
+
+    # ---- lazily materialised reference masks (only for third-party plug-ins) --------------------------------
+    def _sparse(self, rows, cols, vals, shape):
+        return torch.sparse_coo_tensor(torch.stack([rows.long(), cols.long()]), vals, shape, device=self._device)
+
+    def _mask_tuple(self, kind):
+        if kind in self._masks:
+            return self._masks[kind]
+        gm, E, V, F, B = self._graph_map, self._edge_num, self._variable_num, self._function_num, self._batch_size
+        er = torch.arange(E, device=self._device)
+        ef = self._edge_feature.reshape(-1)
+        if kind == 'graph' or kind in ('pos', 'neg', 'signed'):
+            vals = {'graph': torch.ones(E, device=self._device), 'pos': (ef == 1).float(), 'neg': (ef == -1).float(),
+                    'signed': ef}[kind]
+            vm = self._sparse(gm[0], er, vals, (V, E)); fm = self._sparse(gm[1], er, vals, (F, E))
+            out = (vm, vm.transpose(0, 1), fm, fm.transpose(0, 1))
+        elif kind == 'batch':
+            vm = self._sparse(torch.arange(V, device=self._device), self._batch_variable_map, torch.ones(V, device=self._device), (V, B))
+            fm = self._sparse(torch.arange(F, device=self._device), self._batch_function_map, torch.ones(F, device=self._device), (F, B))
+            out = (vm, vm.transpose(0, 1), fm, fm.transpose(0, 1))
+        elif kind == 'vf':
+            m = self._sparse(gm[0], gm[1], torch.ones(E, device=self._device), (V, F))
+            sm = self._sparse(gm[0], gm[1], ef, (V, F))
+            out = (m, m.transpose(0, 1), sm, sm.transpose(0, 1))
+        else:
+            raise KeyError(kind)
+        self._masks[kind] = out
+        return out
+
+    _graph_mask_tuple = property(lambda self: self._mask_tuple('graph'))
+    _pos_mask_tuple = property(lambda self: self._mask_tuple('pos'))
+    _neg_mask_tuple = property(lambda self: self._mask_tuple('neg'))
+    _signed_mask_tuple = property(lambda self: self._mask_tuple('signed'))
+    _batch_mask_tuple = property(lambda self: self._mask_tuple('batch'))
+    _vf_mask_tuple = property(lambda self: self._mask_tuple('vf'))
+
+
+###############################################################
+### The Solver Classes
+###############################################################
+
+def _is_standard_termination(check_termination):
+    "the trainer's CNF-check callback (trainer.py:150-162) is implemented inside the persistent kernel"
+    return check_termination is not None and getattr(check_termination, '_pdp_standard_termination', False)
+
+
+class PropagatorDecimatorSolverBase(nn.Module):
+    "The base class for all PDP SAT solvers (reference: solver.py:293-511)."
+
+    def __init__(self, device, name, propagator, decimator, predictor, local_search_iterations=0, epsilon=0.05,
+                 rng='torch', seed=0, persistent=True):
+        super(PropagatorDecimatorSolverBase, self).__init__()
+        self._device = device
+        self._module_list = nn.ModuleList()
+        self._propagator = propagator
+        self._decimator = decimator
+        self._predictor = predictor
+        self._module_list.append(self._propagator)
+        self._module_list.append(self._decimator)
+        self._module_list.append(self._predictor)
+        self._global_step = nn.Parameter(torch.tensor([0], dtype=torch.float, device=self._device), requires_grad=False)
+        self._name = name
+        self._local_search_iterations = local_search_iterations
+        self._epsilon = epsilon
+        self._rng = rng                  # 'torch': reference-compatible CPU generator stream, 'philox': on device
+        self._seed = seed
+        self._persistent = persistent    # allow the one-launch persistent loop when the plug-ins permit it
+        self.last_run = {}               # diagnostics of the most recent forward (iterations, path taken ...)
+
+    def parameter_count(self):
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)
+
+    def save(self, export_path_base):
+        torch.save(self.state_dict(), os.path.join(export_path_base, self._name))
+
+    def load(self, import_path_base):
+        self.load_state_dict(torch.load(os.path.join(import_path_base, self._name), map_location=self._device))
+
+    # -----------------------------------------------------------------------------------------------------------
+    def forward(self, init_state, graph_map, batch_variable_map, batch_function_map, edge_feature,
+                meta_data, is_training=True, iteration_num=1, check_termination=None, simplify=True, batch_replication=1):
+        native.require_gpu()
+        init_propagator_state, init_decimator_state = init_state
+        batch_replication = 1 if is_training else batch_replication
+        sat_problem = SATProblem((graph_map, batch_variable_map, batch_function_map, edge_feature, meta_data, None),
+                                 self._device, batch_replication)
+        self.last_run = dict(path='none', iterations=0, walksat_steps=0)
+
+        if simplify and not is_training:
+            sat_problem.simplify()
+
+        if self._propagator is not None and self._decimator is not None:
+            propagator_state, decimator_state = self._forward_core(init_propagator_state, init_decimator_state,
+                                                                   sat_problem, iteration_num, is_training, check_termination)
+        else:
+            decimator_state = None
+            propagator_state = None
+
+        prediction = self._predictor(decimator_state, sat_problem, True)
+
+        if not is_training:
+            prediction = self._local_search(prediction, sat_problem, batch_replication)
+
+        prediction = self._update_solution(prediction, sat_problem)
+
+        if batch_replication > 1:
+            prediction, propagator_state, decimator_state = self._deduplicate(prediction, propagator_state, decimator_state, sat_problem)
+
+        self._last_problem = sat_problem
+        return (prediction, (propagator_state, decimator_state))
+
+    # -----------------------------------------------------------------------------------------------------------
+    def _can_run_persistent(self, sat_problem, is_training, check_termination):
+        return (self._persistent and not is_training and sat_problem._batch_replication == 1
+                and type(self._propagator) is pdp_propagate.SurveyPropagator
+                and type(self._decimator) is pdp_decimate.SequentialDecimator
+                and type(self._decimator._scorer) is pdp_predict.SurveyScorer
+                and type(self._predictor) is pdp_predict.IdentityPredictor
+                and self._propagator._pi == self._decimator._scorer._pi
+                and _is_standard_termination(check_termination))
+
+    def _forward_core(self, init_propagator_state, init_decimator_state, sat_problem, iteration_num, is_training, check_termination):
+        if self._can_run_persistent(sat_problem, is_training, check_termination):
+            out = self._forward_core_persistent(init_propagator_state, sat_problem, iteration_num, check_termination)
+            if out is not None:
+                return out
+        return self._forward_core_stepwise(init_propagator_state, init_decimator_state, sat_problem, iteration_num,
+                                           is_training, check_termination)
+
+    def _forward_core_persistent(self, init_propagator_state, sat_problem, iteration_num, check_termination):
+        "the whole loop of solver.py:355-386 in one kernel launch; None if the speculation failed"
+        nat = sat_problem._native
+        q = init_propagator_state[0].clone().contiguous()
+        fs = init_propagator_state[1].clone().contiguous()
+        active_mask = torch.ones(sat_problem._batch_size, dtype=torch.uint8, device=self._device)
+        snapshot = [t.clone() for t in (nat.active_variables, nat.active_functions, nat.solution, nat.is_sat, nat.edge_mask)]
+        handle = self._decimator.native_handle(sat_problem)
+        try:
+            iters, used_lds = nat.sp_solve(q, fs, active_mask, handle, int(iteration_num), self._decimator._tolerance,
+                                           self._decimator._t_max, self._propagator._pi,
+                                           check_termination=check_termination is not None)
+        except native.SpeculationFailed:
+            for dst, src in zip((nat.active_variables, nat.active_functions, nat.solution, nat.is_sat, nat.edge_mask), snapshot):
+                dst.copy_(src)
+            self._decimator._handle = None
+            return None
+        self.last_run.update(path='persistent-lds' if used_lds else 'persistent-hbm', iterations=iters)
+        sat_problem._edge_mask = nat.edge_mask
+        state = (q, fs)
+        dec_state = state
+        if iters > 0 and not bool((nat.edge_mask == 1).all().item()):
+            dec_state = state + (nat.edge_mask,)
+        self._active_mask = active_mask.unsqueeze(1)
+        return state, dec_state
+
+    def _forward_core_stepwise(self, init_propagator_state, init_decimator_state, sat_problem, iteration_num, is_training, check_termination):
+        "generic plug-in loop, statement for statement the reference's (solver.py:355-386)"
+        propagator_state = init_propagator_state
+        decimator_state = init_decimator_state
+        if check_termination is None:
+            active_mask = None
+        else:
+            active_mask = torch.ones(sat_problem._batch_size, 1, dtype=torch.uint8, device=self._device)
+        iters = 0
+        for _ in range(int(iteration_num)):
+            propagator_state = self._propagator(propagator_state, decimator_state, sat_problem, is_training, active_mask)
+            decimator_state = self._decimator(decimator_state, propagator_state, sat_problem, is_training, active_mask)
+            all_active = sat_problem.refresh_edge_mask()
+            if not all_active:
+                decimator_state = tuple(decimator_state[:2]) + (sat_problem._edge_mask,)
+            iters += 1
+            if check_termination is not None:
+                prediction = self._predictor(decimator_state, sat_problem)
+                prediction = self._update_solution(prediction, sat_problem)
+                check_termination(active_mask, prediction, sat_problem)
+                if int(active_mask.sum().item()) <= 0:
+                    break
+        self.last_run.update(path='stepwise', iterations=iters)
+        self._active_mask = active_mask
+        return propagator_state, decimator_state
+
+    # -----------------------------------------------------------------------------------------------------------
+    def _update_solution(self, prediction, sat_problem):
+        "solver.py:388-399"
+        if prediction[0] is not None:
+            variable_solution = sat_problem._native.update_solution(prediction[0].reshape(-1).contiguous())
+        else:
+            variable_solution = None
+        return variable_solution, prediction[1]
+
+    def _deduplicate(self, prediction, propagator_state, decimator_state, sat_problem):
+        "min-energy replica per original instance (solver.py:401-431 with the integer-division fix)"
+        if sat_problem._batch_replication <= 1:
+            return None, None, None
+        R = sat_problem._batch_replication
+        variable_prediction, chosen = sat_problem._native.deduplicate(prediction[0].reshape(-1).contiguous())
+        e0 = sat_problem._edge_num // R
+        b0 = sat_problem._batch_size // R
+        # per-edge replica choice: instance of each original edge
+        inst_of_edge = sat_problem._orig[1][sat_problem._orig[0][0].long()].long()
+        pick = chosen.long()[inst_of_edge]                       # [E0]
+        idx = pick * e0 + torch.arange(e0, device=self._device)
+        sel = lambda states: None if states is None else tuple(x[idx] for x in states)
+        return (variable_prediction, None), sel(propagator_state), sel(decimator_state)
+
+    def _local_search(self, prediction, sat_problem, batch_replication):
+        "Walk-SAT post-processing (solver.py:433-467)"
+        pred = prediction[0].reshape(-1).contiguous()
+        w = int(self._local_search_iterations)
+        nat = sat_problem._native
+        if self._rng == 'torch' and w > 0:
+            V, B = sat_problem._variable_num, sat_problem._batch_size
+            state = torch.get_rng_state()
+            draws = torch.rand(w * (V + B)).view(w, V + B)
+            var_rand = draws[:, :V].contiguous().to(self._device)
+            coin = draws[:, V:].contiguous().to(self._device)
+            out, steps = nat.local_search(pred, w, self._epsilon, var_rand, coin)
+            torch.set_rng_state(state)
+            if steps > 0:
+                torch.rand(steps * (V + B))            # consume exactly what the reference consumes
+        else:
+            out, steps = nat.local_search(pred, w, self._epsilon, seed=self._seed)
+        sat_problem._edge_mask = nat.edge_mask
+        self.last_run['walksat_steps'] = steps
+        return out, prediction[1]
+
+    def get_init_state(self, graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, randomized, batch_replication=1):
+        "solver.py:498-511"
+        if self._propagator is None:
+            init_propagator_state = None
+        else:
+            init_propagator_state = self._propagator.get_init_state(graph_map, batch_variable_map, batch_function_map,
+                                                                    edge_feature, graph_feat, randomized, batch_replication)
+        if self._decimator is None:
+            init_decimator_state = None
+        else:
+            init_decimator_state = self._decimator.get_init_state(graph_map, batch_variable_map, batch_function_map,
+                                                                  edge_feature, graph_feat, randomized, batch_replication)
+        return init_propagator_state, init_decimator_state
+
+
+###############################################################
+
+
+class SurveyPropagatorSolver(PropagatorDecimatorSolverBase):
+    "Classical SP-guided decimation via the PDP framework (reference: solver.py:567-578)."
+
+    def __init__(self, device, name, tolerance, t_max, local_search_iterations=0, epsilon=0.05, rng='torch', seed=0, persistent=True):
+        super(SurveyPropagatorSolver, self).__init__(
+            device=device, name=name,
+            propagator=pdp_propagate.SurveyPropagator(device, decimator_dimension=1, include_adaptors=False),
+            decimator=pdp_decimate.SequentialDecimator(
+                device, message_dimension=(3, 1),
+                scorer=pdp_predict.SurveyScorer(device, message_dimension=1, include_adaptors=False),
+                tolerance=tolerance, t_max=t_max),
+            predictor=pdp_predict.IdentityPredictor(device=device, random_fill=True, rng=rng, seed=seed),
+            local_search_iterations=local_search_iterations, epsilon=epsilon, rng=rng, seed=seed, persistent=persistent)
+
+
+class WalkSATSolver(PropagatorDecimatorSolverBase):
+    "Classical Walk-SAT via the PDP framework (reference: solver.py:584-592)."
+
+    def __init__(self, device, name, iteration_num, epsilon=0.05, rng='torch', seed=0):
+        super(WalkSATSolver, self).__init__(
+            device=device, name=name, propagator=None, decimator=None,
+            predictor=pdp_predict.IdentityPredictor(device=device, random_fill=True, rng=rng, seed=seed),
+            local_search_iterations=iteration_num, epsilon=epsilon, rng=rng, seed=seed)
+
+
+class ReinforceSurveyPropagatorSolver(PropagatorDecimatorSolverBase):
+    "Classical Reinforce via the PDP framework (reference: solver.py:598-610)."
+
+    def __init__(self, device, name, pi=0.1, decimation_probability=0.5, local_search_iterations=0, epsilon=0.05, rng='torch', seed=0):
+        super(ReinforceSurveyPropagatorSolver, self).__init__(
+            device=device, name=name,
+            propagator=pdp_propagate.SurveyPropagator(device, decimator_dimension=1, include_adaptors=False, pi=pi),
+            decimator=pdp_decimate.ReinforceDecimator(
+                device, scorer=pdp_predict.SurveyScorer(device, message_dimension=1, include_adaptors=False, pi=pi),
+                decimation_probability=decimation_probability),
+            predictor=pdp_predict.ReinforcePredictor(device=device),
+            local_search_iterations=local_search_iterations, epsilon=epsilon, rng=rng, seed=seed)

@@ -1,0 +1,64 @@
+"""Primitives of the PDP framework on the native library.
+
+Mirrors the public names of the reference's util module for the inference path (reference:
+src/pdp/nn/util.py): ``SatCNFEvaluator`` (:203-236), ``sparse_smooth_max`` / ``sparse_max`` /
+``sparse_argmax`` (:257-286), ``MessageAggregator`` (:11-77), ``PerceptronTanh`` (:242-251).  The
+reference evaluates these with torch sparse COO products and a dense [V x B] matrix; here each is one
+kernel launch over the batch's instance-local CSR layout (see csrc/pdp_ops.hip).
+``SatLossEvaluator`` / ``MultiLayerPerceptron`` are training-only and out of scope.
+"""
+
+import torch
+import torch.nn as nn
+
+from pdp import native
+
+
+class SatCNFEvaluator(nn.Module):
+    """Clause-satisfaction check: returns (solved [B,1], unsat_clauses [B,1])  (reference: util.py:203-236).
+
+    The reference rebuilds four sparse masks from ``graph_map`` on every call; the native check runs on the
+    problem's resident layout, so callers that own a ``SATProblem`` should pass it as ``sat_problem``."""
+
+    def __init__(self, device):
+        super(SatCNFEvaluator, self).__init__()
+        self._device = device
+
+    def forward(self, variable_prediction, graph_map, batch_variable_map, batch_function_map, edge_feature, meta_data,
+                sat_problem=None):
+        if sat_problem is None:
+            from pdp.nn.solver import SATProblem
+            sat_problem = SATProblem((graph_map, batch_variable_map, batch_function_map, edge_feature, meta_data, None),
+                                     self._device, 1)
+        handle = sat_problem._native if sat_problem._batch_replication == 1 else sat_problem._native_unreplicated()
+        return handle.cnf_eval(variable_prediction.reshape(-1).contiguous())
+
+
+class PerceptronTanh(nn.Module):
+    "1-hidden-layer perceptron with tanh output (reference: util.py:242-251)."
+
+    def __init__(self, input_dimension, hidden_dimension, output_dimension):
+        super(PerceptronTanh, self).__init__()
+        self._layer1 = nn.Linear(input_dimension, hidden_dimension)
+        self._layer2 = nn.Linear(hidden_dimension, output_dimension, bias=False)
+
+    def forward(self, inp):
+        return torch.tanh(self._layer2(torch.relu(self._layer1(inp))))
+
+
+def sparse_smooth_max(x, sat_problem, device=None, alpha=30):
+    """Per-variable smooth max of an edge vector ``x [E,1]`` (reference: util.py:282-286).  The reference takes
+    the sparse variable mask; the native form takes the problem that owns it."""
+    if alpha != 30:
+        raise native.NativeError("sparse_smooth_max: the native kernel implements alpha = 30 (the only value the reference uses)")
+    return sat_problem._native.smooth_max(x.reshape(-1).contiguous())
+
+
+def sparse_max(x, sat_problem, device=None):
+    "Exact per-instance max of a variable vector ``x [V]`` incl. the reference's x - min + 1 rounding (util.py:267-275)."
+    return sat_problem._native.instance_max(x.reshape(-1).contiguous())
+
+
+def sparse_argmax(x, sat_problem, device=None):
+    "Per-instance arg-max (global variable index, first index wins ties) of ``x [V]`` (util.py:257-265)."
+    return sat_problem._native.instance_argmax(x.reshape(-1).contiguous())

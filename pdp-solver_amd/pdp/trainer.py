@@ -1,0 +1,92 @@
+"""Model factory + prediction post-processing for PDP SAT solvers (reference: src/pdp/trainer.py).
+
+Only the inference side of ``SatFactorGraphTrainer`` is in scope: ``_build_graph``
+(model_type -> solver class, trainer.py:48-99), ``_check_recurrence_termination`` (:150-162) and
+``_post_process_predictions`` (:125-148).  Loss / metric computation is training-only.
+"""
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from pdp.factorgraph.base import FactorGraphTrainerBase
+from pdp.nn import solver, util
+
+
+class Perceptron(nn.Module):
+    "1-hidden-layer perceptron with sigmoid output (reference: trainer.py:20-29); classifier head of the neural predictor."
+
+    def __init__(self, input_dimension, hidden_dimension, output_dimension):
+        super(Perceptron, self).__init__()
+        self._layer1 = nn.Linear(input_dimension, hidden_dimension)
+        self._layer2 = nn.Linear(hidden_dimension, output_dimension, bias=False)
+
+    def forward(self, inp):
+        return torch.sigmoid(self._layer2(torch.relu(self._layer1(inp))))
+
+
+class SatFactorGraphTrainer(FactorGraphTrainerBase):
+    "Builds a PDP SAT solver from a config dict and runs prediction (reference: trainer.py:34-162)."
+
+    def __init__(self, config, use_cuda, logger):
+        super(SatFactorGraphTrainer, self).__init__(config=config, has_meta_data=False, error_dim=config.get('error_dim', 1),
+                                                    loss=None, evaluator=nn.L1Loss(), use_cuda=use_cuda, logger=logger)
+        self._cnf_evaluator = util.SatCNFEvaluator(device=self._device)
+        self._counter = 0
+
+    def _build_graph(self, config):
+        rng = config.get('rng', 'torch')
+        seed = int(config.get('random_seed', 0) or 0)
+        t = config['model_type']
+        common = dict(local_search_iterations=config['local_search_iteration'], epsilon=config['epsilon'], rng=rng, seed=seed)
+        if t == 'p-d-p':
+            model = solver.SurveyPropagatorSolver(device=self._device, name=config['model_name'], tolerance=config['tolerance'],
+                                                  t_max=config['t_max'], persistent=config.get('persistent', True), **common)
+        elif t == 'walk-sat':
+            model = solver.WalkSATSolver(device=self._device, name=config['model_name'],
+                                         iteration_num=config['local_search_iteration'], epsilon=config['epsilon'], rng=rng, seed=seed)
+        elif t == 'reinforce':
+            model = solver.ReinforceSurveyPropagatorSolver(device=self._device, name=config['model_name'], pi=config['pi'],
+                                                           decimation_probability=config['decimation_probability'], **common)
+        elif t in ('np-nd-np', 'np-d-np'):
+            model = solver.build_neural_solver(self._device, config, Perceptron, common)
+        elif t == 'p-nd-np':
+            raise NotImplementedError("model_type 'p-nd-np' cannot run in the reference either (input-size mismatch, "
+                                      "SURVEY.md App. B-5); it has no native implementation")
+        else:
+            raise KeyError("unknown model_type %r" % (t,))
+        if config.get('verbose'):
+            self._logger.info("The model parameter count is %d." % model.parameter_count())
+        return [model]
+
+    def _post_process_predictions(self, model, prediction, graph_map, batch_variable_map, batch_function_map,
+                                  edge_feature, graph_feat, label, misc_data):
+        """JSON result rows (reference: trainer.py:125-148).  The reference scans ``batch_variable_map == i`` for every
+        instance (O(B*V)); instance slices come from one prefix sum here."""
+        sat_problem = getattr(model, '_last_problem', None)
+        solved, unsat = self._cnf_evaluator(prediction[0], graph_map, batch_variable_map, batch_function_map, edge_feature,
+                                            graph_feat, sat_problem=sat_problem)
+        output = solved.detach().cpu().numpy()
+        unsat_clause_num = unsat.detach().cpu().numpy()
+        labs = label.detach().cpu().numpy()
+        bits = (prediction[0].detach().reshape(-1) > 0.5).to(torch.uint8).cpu().numpy()
+        counts = np.bincount(batch_variable_map.detach().cpu().numpy().astype(np.int64), minlength=output.shape[0])
+        offs = np.concatenate(([0], np.cumsum(counts)))
+        rows = []
+        for i in range(output.shape[0]):
+            instance = {
+                'ID': misc_data[i][0] if len(misc_data[i]) > 0 else "",
+                'label': int(labs[i, 0]),
+                'solved': int(output[i].flatten()[0] == 1),
+                'unsat_clauses': int(unsat_clause_num[i].flatten()[0]),
+                'solution': bits[offs[i]:offs[i + 1]].astype(int).tolist()
+            }
+            rows.append(str(instance).replace("'", '"') + "\n")
+            self._counter += 1
+        return "".join(rows)
+
+    def _check_recurrence_termination(self, active, prediction, sat_problem):
+        "De-activates the instances the model has already solved (reference: trainer.py:150-162)."
+        sat_problem._native.check_termination(active.reshape(-1), prediction[0].reshape(-1).contiguous())
+
+    _check_recurrence_termination._pdp_standard_termination = True

@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Run a PDP solver against a test set on the MI355X (drop-in for the reference's src/satyr.py).
+
+Same positionals, flags, YAML keys and output format as the reference CLI (reference: satyr.py:45-109).
+Additions: ``--rng {torch,philox}`` (torch = the reference's CPU random stream, bit-compatible results for the
+same ``-s`` seed; philox = on-device counters, fastest) and ``--stepwise`` (disable the one-launch persistent loop).
+``-c/--cpu_mode`` is rejected: the hot path has no CPU fallback.
+"""
+
+import argparse
+import logging
+import os
+import sys
+from datetime import datetime
+
+import numpy as np
+import torch
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+
+import dimacs2json  # noqa: E402
+from pdp.trainer import SatFactorGraphTrainer  # noqa: E402
+
+
+def run(config, logger, output):
+    "Runs the prediction engine (reference: satyr.py:21-42)."
+    np.random.seed(config['random_seed'])
+    torch.manual_seed(config['random_seed'])
+    if config['verbose']:
+        logger.info("Building the computational graph...")
+    predicter = SatFactorGraphTrainer(config=config, use_cuda=not config['cpu_mode'], logger=logger)
+    if config['verbose']:
+        logger.info("Starting the prediction phase...")
+    predicter._counter = 0
+    if output == '':
+        predicter.predict(test_list=config['test_path'], out_file=sys.stdout, import_path_base=config['model_path'],
+                          post_processor=predicter._post_process_predictions, batch_replication=config['batch_replication'])
+    else:
+        with open(output, 'w') as file:
+            predicter.predict(test_list=config['test_path'], out_file=file, import_path_base=config['model_path'],
+                              post_processor=predicter._post_process_predictions, batch_replication=config['batch_replication'])
+    return predicter
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument('model_config', help='The model configuration yaml file')
+    parser.add_argument('test_path', help='The input test path')
+    parser.add_argument('test_recurrence_num', help='The number of iterations for the PDP', type=int)
+    parser.add_argument('-b', '--batch_replication', help='Batch replication factor', type=int, default=1)
+    parser.add_argument('-z', '--batch_size', help='Batch size', type=int, default=5000)
+    parser.add_argument('-m', '--max_cache_size', help='Maximum cache size', type=int, default=100000)
+    parser.add_argument('-l', '--test_batch_limit', help='Memory limit for mini-batches', type=int, default=40000000)
+    parser.add_argument('-w', '--local_search_iteration', help='Number of iterations for post-processing local search', type=int, default=100)
+    parser.add_argument('-e', '--epsilon', help='Epsilon probablity for post-processing local search', type=float, default=0.5)
+    parser.add_argument('-v', '--verbose', help='Verbose', action='store_true')
+    parser.add_argument('-c', '--cpu_mode', help='Run on CPU (not available in the MI355X build)', action='store_true')
+    parser.add_argument('-d', '--dimacs', help='The input folder contains DIMACS files', action='store_true')
+    parser.add_argument('-s', '--random_seed', help='Random seed', type=int, default=int(datetime.now().microsecond))
+    parser.add_argument('-o', '--output', help='The JSON output file', default='')
+    parser.add_argument('--rng', help='Random source for random fill / Walk-SAT', choices=['torch', 'philox'], default='torch')
+    parser.add_argument('--stepwise', help='Disable the persistent one-launch PDP loop', action='store_true')
+    args = vars(parser.parse_args(argv))
+
+    with open(args['model_config'], 'r') as f:
+        model_config = yaml.safe_load(f)
+
+    fmt = '[%(levelname)s] %(asctime)s - %(name)s: %(message)s'
+    logging.basicConfig(level=logging.DEBUG, format=fmt)
+    logger = logging.getLogger(model_config['model_name'])
+
+    temp_file_name = None
+    if args['dimacs']:
+        if args['verbose']:
+            logger.info("Converting DIMACS files into JSON...")
+        temp_file_name = 'temp_problem_file.json'
+        if os.path.isfile(args['test_path']):
+            head, _ = os.path.split(args['test_path'])
+            temp_file_name = os.path.join(head, temp_file_name)
+            dimacs2json.convert_file(args['test_path'], temp_file_name, False)
+        else:
+            temp_file_name = os.path.join(args['test_path'], temp_file_name)
+            dimacs2json.convert_directory(args['test_path'], temp_file_name, False)
+        args['test_path'] = temp_file_name
+
+    config = {**model_config, **args}
+    if config['model_type'] in ('p-d-p', 'walk-sat', 'reinforce'):
+        config['model_path'] = None
+        config['hidden_dim'] = 3
+    if config['model_type'] == 'walk-sat':
+        config['local_search_iteration'] = config['test_recurrence_num']
+    config['dropout'] = 0
+    config['error_dim'] = 1
+    config['exploration'] = 0
+    config['persistent'] = not config['stepwise']
+
+    try:
+        run(config, logger, config['output'])
+    finally:
+        if temp_file_name is not None and os.path.exists(temp_file_name):
+            os.remove(temp_file_name)
+    print('')
+
+
+if __name__ == '__main__':
+    main()

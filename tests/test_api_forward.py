@@ -1,0 +1,115 @@
+"""GPU end-to-end tests through the reference-shaped Python API (pdp.trainer / pdp.nn.solver) and the satyr CLI.
+
+With ``rng='torch'`` the native path consumes the global torch CPU generator exactly like the reference's
+--cpu_mode run, so for the same seed the FINAL ASSIGNMENTS must equal the reference's golden outputs bit for bit
+(captured by tests/golden/generate_golden.py), on both the persistent one-launch loop and the step-wise loop."""
+import io
+import logging
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, REPO
+
+pytestmark = pytest.mark.gpu
+LOG = logging.getLogger('test')
+
+
+def cfg(model_type, **kw):
+    c = dict(model_type=model_type, model_name='t-' + model_type, verbose=False, local_search_iteration=0, epsilon=0.5,
+             tolerance=0.02, t_max=100, pi=0.01, decimation_probability=0.5, rng='torch', random_seed=0, hidden_dim=3,
+             test_batch_limit=40000000, batch_size=5000, test_recurrence_num=1)
+    c.update(kw)
+    return c
+
+
+def run_golden(name, model_type, persistent=True, **kw):
+    from pdp.trainer import SatFactorGraphTrainer
+    d = load_golden(name)
+    T, w, seed, R = [int(x) for x in d['meta']]
+    tr = SatFactorGraphTrainer(cfg(model_type, local_search_iteration=w, persistent=persistent, **kw), use_cuda=True, logger=LOG)
+    m = tr._model_list[0]
+    dev = torch.device('cuda:0')
+    gm = torch.from_numpy(d['graph_map']).to(dev); bvm = torch.from_numpy(d['batch_variable_map']).to(dev)
+    bfm = torch.from_numpy(d['batch_function_map']).to(dev); ef = torch.from_numpy(d['edge_feature']).to(dev)
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        st = m.get_init_state(gm, bvm, bfm, ef, None, randomized=False, batch_replication=R)
+        pred, states = m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef,
+                         meta_data=None, is_training=False, iteration_num=T, check_termination=tr._check_recurrence_termination,
+                         batch_replication=R)
+    return d, tr, m, pred, states, (gm, bvm, bfm, ef)
+
+
+CASES = [('trace_pdp_n50', 'p-d-p', dict(tolerance=0.02, t_max=100)),
+         ('trace_pdp_easy_ws', 'p-d-p', dict(tolerance=0.05, t_max=10)),
+         ('trace_pdp_mixed', 'p-d-p', dict(tolerance=0.05, t_max=8)),
+         ('trace_walksat_easy', 'walk-sat', {}),
+         ('trace_pdp_rep3', 'p-d-p', dict(tolerance=0.05, t_max=6)),
+         ('trace_reinforce_easy', 'reinforce', dict(pi=0.01, decimation_probability=0.5))]
+
+
+@pytest.mark.parametrize('name,model_type,kw', CASES)
+@pytest.mark.parametrize('persistent', [True, False])
+def test_forward_equals_reference_golden(name, model_type, kw, persistent):
+    d, tr, m, pred, states, batch = run_golden(name, model_type, persistent=persistent, **kw)
+    np.testing.assert_array_equal(pred[0].cpu().numpy()[:, 0], d['final_prediction'])
+    if model_type == 'p-d-p' and int(d['meta'][3]) == 1:
+        assert m.last_run['iterations'] == int(d['iterations_run'][0])
+        assert m.last_run['path'] == ('persistent-lds' if persistent else 'stepwise')
+        np.testing.assert_allclose(states[0][0].cpu().numpy(), d['final_prop_0'], rtol=5e-4, atol=5e-6)
+    if 'final_solved' in d.files:
+        solved, unsat = tr._cnf_evaluator(pred[0], *batch, None, sat_problem=m._last_problem)
+        np.testing.assert_array_equal(solved.cpu().numpy()[:, 0], d['final_solved'])
+        np.testing.assert_array_equal(unsat.cpu().numpy()[:, 0], d['final_unsat'])
+    # the global generator must have advanced exactly as far as the reference's
+    torch.manual_seed(int(d['meta'][2]))
+    torch.rand(int(d['rand_sizes'].sum()))
+    expected_next = torch.rand(4)
+    # replay our run's consumption
+    d2, tr2, m2, pred2, _, _ = run_golden(name, model_type, persistent=persistent, **kw)
+    np.testing.assert_array_equal(torch.rand(4).numpy(), expected_next.numpy())
+
+
+def test_post_processing_rows():
+    d, tr, m, pred, states, (gm, bvm, bfm, ef) = run_golden('trace_pdp_easy_ws', 'p-d-p', tolerance=0.05, t_max=10)
+    B = int(bvm.max()) + 1
+    label = torch.zeros(B, 1, device=gm.device)
+    msg = tr._post_process_predictions(m, pred, gm, bvm, bfm, ef, None, label, [["f%d" % i] for i in range(B)])
+    rows = [r for r in msg.split('\n') if r]
+    assert len(rows) == B
+    import json
+    for i, r in enumerate(rows):
+        j = json.loads(r)
+        assert j['ID'] == 'f%d' % i and j['solved'] == int(d['final_solved'][i]) and j['unsat_clauses'] == int(d['final_unsat'][i])
+        sl = d['final_prediction'][d['batch_variable_map'] == i]
+        assert j['solution'] == (sl > 0.5).astype(int).tolist()
+
+
+def test_cli_matches_reference_output(tmp_path):
+    """satyr.py on the JSON the reference converter produced (same instance order) must print the reference's rows."""
+    import satyr
+    out = tmp_path / 'out.jsonl'
+    satyr.main([os.path.join(REPO, 'config', 'Predict', 'PDP-p-d-p-sp-pytorch.yaml'),
+                os.path.join(REPO, 'tests', 'golden', 'cli_dimacs20.converted.jsonl'), '50',
+                '-z', '8', '-s', '7', '-w', '40', '-o', str(out)])
+    got = [l for l in out.read_text().split('\n') if l.strip()]
+    ref = [l for l in open(os.path.join(REPO, 'tests', 'golden', 'cli_pdp_dimacs20.out.jsonl')).read().split('\n') if l.strip()]
+    assert got == ref
+
+
+def test_cli_dimacs_mode_runs(tmp_path):
+    import json
+    import shutil
+    import satyr
+    ddir = tmp_path / 'cnf'
+    shutil.copytree(os.path.join(REPO, 'tests', 'golden', 'dimacs20'), str(ddir))
+    out = tmp_path / 'out.jsonl'
+    satyr.main([os.path.join(REPO, 'config', 'Predict', 'PDP-p-d-p-walksat-pytorch.yaml'), str(ddir), '30', '-d',
+                '-z', '100', '-s', '1', '--rng', 'philox', '-o', str(out)])
+    rows = [json.loads(l) for l in out.read_text().split('\n') if l.strip()]
+    assert len(rows) == 20 and not os.path.exists(str(ddir / 'temp_problem_file.json'))
+    assert all(set(r) == {'ID', 'label', 'solved', 'unsat_clauses', 'solution'} for r in rows)
+    assert sum(r['solved'] for r in rows) >= 1
