@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Benchmark of the PDP hot path on MI355X.
+
+Metric (BASELINE.json): PDP message-passing iterations/sec on random 3-SAT n=200 m=840 batch=5000 ('p-d-p' survey
+propagation + sequential decimation, T=100, configs[1]).  One "step" = one pass of the hot path over one resident
+batch: reset of the solver state, SATProblem.simplify, and the T-iteration propagate/decimate/predict/terminate
+loop (reference: src/pdp/nn/solver.py:332-337,355-386) -- the loop runs as ONE persistent kernel launch.
+value = executed PDP iterations per second, aggregated over all ranks (each rank owns its own batch of 5000
+instances: weak scaling, no collective on the data path; one RCCL all-reduce of the solved counters at the end).
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches one rank per GPU through
+torch.distributed.run.  Rank 0 prints ONE JSON line.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, 'pdp-solver_amd'))
+
+from pdp import native  # noqa: E402
+from pdp.factorgraph import dataset  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_iteration(E, V, F):
+    "SURVEY.md section 8(d): streaming model of one SP iteration, 41 B/edge + 36 B/variable + 8 B/clause"
+    return 41 * E + 36 * V + 8 * F
+
+
+def cpu_baseline(args):
+    """CPU restatement (oracle, single thread) timed on a bounded sample of the same workload."""
+    sys.path.insert(0, REPO)
+    from oracle import binding
+    binding.build()
+    bs, ts = args.cpu_sample_batch, args.cpu_sample_iters
+    items = dataset.random_ksat_items(bs, args.n, 3, seed=777)
+    b = dataset.collate_segment(items)
+    p = binding.Problem(b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'])
+    t0 = time.perf_counter()
+    res = p.forward('p-d-p', ts, local_search_iterations=0, tolerance=args.tolerance, t_max=args.t_max, seed=1)
+    dt = time.perf_counter() - t0
+    inst_iters = bs * res['iterations_run'] / dt
+    return dict(value=inst_iters / args.batch, unit='iterations/s (batch of %d instances)' % args.batch, cores=1, kind='port',
+                sample='%d instances x %d iterations of the same n=%d m=%d 3-SAT family in %.1f s (%.0f instance-iterations/s), '
+                       'scaled linearly to the batch' % (bs, res['iterations_run'], args.n, int(round(4.2 * args.n)), dt, inst_iters))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=5000)
+    ap.add_argument('--n', type=int, default=200)
+    ap.add_argument('--iters', type=int, default=100)
+    ap.add_argument('--tolerance', type=float, default=0.02)
+    ap.add_argument('--t_max', type=float, default=100)
+    ap.add_argument('--walksat', type=int, default=100, help='Walk-SAT steps of the (untimed) solved-fraction pass')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-batch', type=int, default=64)
+    ap.add_argument('--cpu-sample-iters', type=int, default=40)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    native.require_gpu()
+    dev = torch.device('cuda', local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    # ---- synthetic batch, resident in HBM before the timed region ---------------------------------------------
+    m = int(round(4.2 * args.n))
+    items = dataset.random_ksat_items(args.batch, args.n, 3, m=m, seed=1000003 * rank)
+    b = dataset.to_torch(dataset.collate_segment(items), dev)
+    prob = native.Problem(b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'], batch_size=args.batch)
+    E, V, F, B = prob.E, prob.V, prob.F, prob.B
+    q = torch.empty(E, 3, device=dev); fs = torch.empty(E, 2, device=dev)
+    am = torch.empty(B, dtype=torch.uint8, device=dev)
+    dec = native.Decimator(prob)
+    L = native.lib()
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    kernel_ms, iters_done, paths = [], [], []
+
+    def step(record):
+        # state reset = get_init_state(randomized=False) + a fresh SATProblem (solver.py:49-54, pdp_propagate.py:233-235)
+        native.check(L.pdp_problem_bind_state(prob._h, native.ptr(prob.active_variables), native.ptr(prob.active_functions),
+                                              native.ptr(prob.solution), native.ptr(prob.is_sat), native.ptr(prob.edge_mask),
+                                              native._stream()))
+        q.fill_(1.0); q.div_(3.0); fs.zero_(); fs[:, 0] = 0.5; am.fill_(1); dec.reset()
+        prob.simplify()
+        ev0.record()
+        try:
+            it, lds = prob.sp_solve(q, fs, am, dec, args.iters, args.tolerance, args.t_max)
+            path = 'persistent-lds' if lds else 'persistent-hbm'
+        except native.SpeculationFailed:
+            raise SystemExit("bench: speculation failed on the benchmark batch (unexpected)")
+        ev1.record()
+        if record:
+            torch.cuda.synchronize()
+            kernel_ms.append(ev0.elapsed_time(ev1)); iters_done.append(it); paths.append(path)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize(); barrier()
+    elapsed = time.perf_counter() - t0
+    total_iters = float(sum(iters_done))
+
+    # ---- untimed: finish the forward pass once (random fill + Walk-SAT) for the solved fraction ------------------
+    prob.random_fill(seed=12345 + rank)
+    out, ws_steps = prob.local_search(prob.solution.clone(), args.walksat, 0.5, seed=999 + rank)
+    pred = prob.update_solution(out.reshape(-1).contiguous())
+    solved, unsat = prob.cnf_eval(pred.reshape(-1).contiguous())
+    stats = torch.tensor([float(B), float(solved.sum().item()), float(unsat.sum().item()), elapsed, total_iters],
+                         dtype=torch.float64, device=dev)
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)       # the only collective of the path: a 40-byte sum over xGMI
+    n_inst, n_solved, n_unsat, _, iters_all = [float(x) for x in stats.tolist()]
+
+    if rank == 0:
+        value = iters_all / elapsed
+        kms = float(np.mean(kernel_ms))
+        it_mean = float(np.mean(iters_done))
+        bytes_launch = algorithmic_bytes_per_iteration(E, V, F) * it_mean
+        achieved = bytes_launch / (kms * 1e-3) / 1e9
+        # measured HBM traffic per launch (rocprofv3 PMC passes, corrected as MI355X_MICROARCH.md prescribes), if profiled
+        traffic = None
+        pmc = os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get('k_sp_solve_bytes_per_launch')
+            except Exception:
+                traffic = None
+        line = {
+            'metric': 'pdp_iterations_per_sec', 'value': value,
+            'unit': 'iterations/s (each iteration sweeps a batch of %d instances)' % args.batch,
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': "configs[1]: 'p-d-p' survey propagation, random 3-SAT n=%d m=%d batch=%d T=%d per GPU" % (args.n, m, args.batch, args.iters),
+                       'E': E, 'V': V, 'F': F, 'iterations_per_step': it_mean, 'path': paths[0] if paths else None,
+                       'instance_iterations_per_sec': value * args.batch, 'edge_updates_per_sec': value * 2 * E,
+                       'kernel_ms_per_launch': kms, 'solved_fraction': n_solved / n_inst, 'unsat_clauses_total': n_unsat,
+                       'walksat_steps': ws_steps, 'tolerance': args.tolerance, 't_max': args.t_max, 'parallelism': 'instances sharded, dp%d' % world},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': traffic, 'kernel': 'k_sp_solve<uint16_t,true>',
+                         'note': 'achieved = streaming-model algorithmic bytes (41E+36V+8F per iteration) x iterations per launch / '
+                                 'launch duration; the instance state is LDS-resident so this may exceed the HBM peak'},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args)
+        else:
+            line['cpu_baseline'] = None
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

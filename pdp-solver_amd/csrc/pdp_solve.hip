@@ -44,6 +44,8 @@ struct SolveParams {
     int has_prev;
     int check_termination;
     int has_edge_mask;          // problem->has_edge_mask at entry
+    int poison_from;            // first iteration at which the batch is NaN-poisoned (INT_MAX: never); pass 2 only
+    uint32_t *nan_iter;         // device word: min over instances of the first iteration whose surveys contain a NaN
     uint32_t *spec_zero;        // [T] bits: site0 (survey max), site1 (diff max), site2 (coeff argmax): some instance had an exact 0
     uint32_t *spec_used;        // [T] bits: some instance evaluated the site
     // HBM-mode scratch
@@ -147,6 +149,15 @@ __global__ void __launch_bounds__(LDS ? 512 : 256) k_sp_solve(PView pv, SolvePar
 
     for (int t = 0; t < sp.T; ++t) {
         if (!active) break;
+        // pass 1 only: once some instance is known to poison the batch before t, this pass will be replayed anyway
+        if (sp.poison_from == 0x7fffffff) {
+            if (tid == 0) sh_flag[0] = (__hip_atomic_load(sp.nan_iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)t) ? 1 : 0;
+            __syncthreads();
+            const int abort_now = sh_flag[0];
+            __syncthreads();
+            if (abort_now) break;
+        }
+        const bool poisoned = t >= sp.poison_from;
         iters = t + 1;
         // ---- P1: per-edge logs (pdp_propagate.py:166-169,185-188)
         for (int e = tid; e < ne; e += nt) {
@@ -186,7 +197,9 @@ __global__ void __launch_bounds__(LDS ? 512 : 256) k_sp_solve(PView pv, SolvePar
             const SpOut o = d_sp_edge(s, I.P[v], I.N[v], I.s1[e], force, sp.pi);
             const float qu_old = I.qu[e * I.qstride];
             const float qu_new = 1.0f * o.qu + (1.0f - 1.0f) * qu_old;
-            if (qu_new != qu_new || eta_new != eta_new || o.qs != o.qs || o.dc != o.dc) nan_seen = 1;
+            // only a NaN SURVEY poisons the batch-global reductions of this iteration; a NaN in q (0/0) reaches the
+            // surveys one iteration later (x = log(max(NaN, eps)) = NaN)
+            if (eta_new != eta_new) nan_seen = 1;
             float d = 0.0f;
             if (has_prev) {
                 const float pe = prev_from_global ? sp.prev[G.e0 + e] : eta_old;
@@ -229,12 +242,22 @@ __global__ void __launch_bounds__(LDS ? 512 : 256) k_sp_solve(PView pv, SolvePar
         float dmax = 0.0f;
         if (has_prev) dmax = d_instance_max(I, I.xv2, 0.0f, other_rows, redf);
         z1 = __syncthreads_or(z1); z2 = __syncthreads_or(z2); nan_seen = __syncthreads_or(nan_seen);
-        if (nan_seen) violation = 1;
+        // A NaN survey (0/0 in pdp_propagate.py:215-216) makes every batch-global min/max of the reference NaN from
+        // this iteration on.  Pass 1 records the first such iteration, pass 2 replays with it.
+        if (nan_seen && !poisoned) {
+            if (tid == 0) atomicMin(sp.nan_iter, (uint32_t)t);
+            if (sp.poison_from != 0x7fffffff) violation = 1;      // pass 2 must not find an earlier NaN
+        }
         int conv = 0;
-        if (g <= 1e-10f) active = 0;                          // trivial surveys: leave the instance to Walk-SAT
-        if (has_prev) {
-            if (dmax < sp.tol) cnt = 0.0f;
-            conv = (dmax < sp.tol) ? 1 : 0;
+        if (!poisoned) {
+            if (g <= 1e-10f) active = 0;                      // trivial surveys: leave the instance to Walk-SAT
+            if (has_prev) {
+                if (dmax < sp.tol) cnt = 0.0f;
+                conv = (dmax < sp.tol) ? 1 : 0;
+                if (cnt >= sp.t_max) { conv = 1; cnt = 0.0f; }
+            }
+        } else if (has_prev) {
+            // all maxima are NaN: comparisons are False, only the counter overflow still "converges" an instance
             if (cnt >= sp.t_max) { conv = 1; cnt = 0.0f; }
         }
         uint32_t used = 1u | (has_prev ? 2u : 0u);
@@ -243,7 +266,7 @@ __global__ void __launch_bounds__(LDS ? 512 : 256) k_sp_solve(PView pv, SolvePar
         if (has_prev && !conv && n > 0) zero |= 4u;
         // ---- P6: decimation (pdp_decimate.py:152-171)
         int decimated = 0;
-        if (has_prev && conv) {
+        if (has_prev && conv && !poisoned && !nan_seen) {
             // scorer (pdp_predict.py:155-192)
             for (int e = tid; e < ne; e += nt)
                 I.s3[e] = pdp_safe_log(1.0f - I.eta[e * I.estride], PDP_SCORER_EPS) * (0.0f + I.af[I.e_fn[e]]);
@@ -269,7 +292,7 @@ __global__ void __launch_bounds__(LDS ? 512 : 256) k_sp_solve(PView pv, SolvePar
             }
             __syncthreads();
             z3 = __syncthreads_or(z3); anynz = __syncthreads_or(anynz); cn = __syncthreads_or(cn);
-            if (cn) violation = 1;
+            if (cn) violation = 1;                                // cannot happen without a NaN survey
             used |= 4u; if (z3) zero |= 4u;
             const int li = d_instance_argmax(I, I.coeff, 0.0f, redf, redi);
             if (active && anynz && !cn && li >= 0) {
@@ -283,7 +306,7 @@ __global__ void __launch_bounds__(LDS ? 512 : 256) k_sp_solve(PView pv, SolvePar
             }
         }
         if (has_prev) cnt = cnt + 1.0f;
-        if (tid == 0) { atomicOr(&sp.spec_used[t], used); if (zero) atomicOr(&sp.spec_zero[t], zero); }
+        if (tid == 0 && !poisoned) { atomicOr(&sp.spec_used[t], used); if (zero) atomicOr(&sp.spec_zero[t], zero); }
         // ---- P7: edge mask refresh (solver.py:370-371); values only change after a decimation
         if (decimated || !use_em) {
             for (int e = tid; e < ne; e += nt) {
@@ -333,6 +356,25 @@ __global__ void __launch_bounds__(LDS ? 512 : 256) k_sp_solve(PView pv, SolvePar
     (void)sh_flag;
 }
 
+// ---- host side ---------------------------------------------------------------------------------------------------
+struct SolveSnapshot {
+    float *q, *fs, *av, *af, *sol, *sat, *emask, *prev, *cnt; uint8_t *amask;
+};
+
+static int snapshot_copy(pdp_problem *p, pdp_solve_args *a, SolveSnapshot &s, bool save, hipStream_t st)
+{
+    const size_t E = p->E, V = p->V, F = p->F, B = p->B;
+    struct { void *live; void *snap; size_t bytes; } items[] = {
+        {a->q, s.q, 3 * E * 4}, {a->fs, s.fs, 2 * E * 4}, {p->av, s.av, V * 4}, {p->af, s.af, F * 4}, {p->sol, s.sol, V * 4},
+        {p->is_sat, s.sat, B * 4}, {p->emask, s.emask, E * 4}, {a->decimator->prev, s.prev, E * 4},
+        {a->decimator->counters, s.cnt, B * 4}, {a->active_mask, s.amask, B}};
+    for (auto &it : items) {
+        if (save) PDP_HIP_CHECK(hipMemcpyAsync(it.snap, it.live, it.bytes, hipMemcpyDeviceToDevice, st));
+        else PDP_HIP_CHECK(hipMemcpyAsync(it.live, it.snap, it.bytes, hipMemcpyDeviceToDevice, st));
+    }
+    return PDP_OK;
+}
+
 extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
 {
     PDP_REQUIRE(p && a && p->av, "NULL argument / state not bound");
@@ -343,62 +385,99 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
     const int T = a->iterations;
     a->iterations_run_host = 0; a->used_lds_host = 0;
     if (T <= 0) return PDP_OK;
+    const size_t E = p->E, V = p->V, F = p->F, B = p->B;
 
-    uint32_t *spec = nullptr;
-    PDP_HIP_CHECK(hipMalloc((void **)&spec, sizeof(uint32_t) * 2 * (size_t)T));
-    PDP_HIP_CHECK(hipMemsetAsync(spec, 0, sizeof(uint32_t) * 2 * (size_t)T, st));
-    PDP_HIP_CHECK(hipMemsetAsync(p->flags + FL_SPEC_VIOLATION, 0, sizeof(uint32_t) * 2, st));   // violation + iters_run
-    PDP_HIP_CHECK(hipMemsetAsync(p->flags + FL_PERM_ZERO, 0xff, sizeof(uint32_t), st));
+    // one allocation: speculation record [2T] + nan word + snapshot of everything the loop mutates
+    const size_t words = 2 * (size_t)T + 4;
+    const size_t snap_floats = 3 * E + 2 * E + V + F + V + B + E + E + B;
+    char *blob = nullptr;
+    PDP_HIP_CHECK(hipMalloc((void **)&blob, words * 4 + snap_floats * 4 + B + 64));
+    uint32_t *spec = (uint32_t *)blob;
+    uint32_t *nan_iter = spec + 2 * (size_t)T;
+    float *f = (float *)(blob + words * 4);
+    SolveSnapshot snap;
+    snap.q = f; f += 3 * E; snap.fs = f; f += 2 * E; snap.av = f; f += V; snap.af = f; f += F; snap.sol = f; f += V;
+    snap.sat = f; f += B; snap.emask = f; f += E; snap.prev = f; f += E; snap.cnt = f; f += B; snap.amask = (uint8_t *)f;
+    const int had_prev = a->decimator->has_prev, had_emask = p->has_edge_mask;
+    int status = snapshot_copy(p, a, snap, true, st);
+    if (status != PDP_OK) { (void)hipFree(blob); return status; }
 
     SolveParams sp;
     memset(&sp, 0, sizeof(sp));
     sp.T = T; sp.tol = a->tolerance; sp.t_max = a->t_max; sp.pi = a->pi;
     sp.q = a->q; sp.fs = a->fs; sp.amask = a->active_mask;
-    sp.prev = a->decimator->prev; sp.counters = a->decimator->counters; sp.has_prev = a->decimator->has_prev;
-    sp.check_termination = a->check_termination; sp.has_edge_mask = p->has_edge_mask;
-    sp.spec_used = spec; sp.spec_zero = spec + T;
+    sp.prev = a->decimator->prev; sp.counters = a->decimator->counters; sp.has_prev = had_prev;
+    sp.check_termination = a->check_termination; sp.has_edge_mask = had_emask;
+    sp.spec_used = spec; sp.spec_zero = spec + T; sp.nan_iter = nan_iter;
 
     const size_t lds = lds_bytes_for(p->max_n, p->max_m, p->max_e);
     const bool fits = lds <= 160 * 1024 - 2048 && p->max_e < 65535 && p->max_n < 65535 && p->max_m < 65535;
     float *extra_v = nullptr;
     if (fits) {
         PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sp_solve<uint16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_sp_solve<uint16_t, true>), dim3(p->B), dim3(512), lds, st, make_view(p), sp);
         a->used_lds_host = 1;
     } else {
         for (int i = 0; i < 4; ++i) sp.ws_e[i] = p->ws_e[i];
         sp.ws_f = p->ws_f[0];
         for (int i = 0; i < 6; ++i) sp.ws_v[i] = p->ws_v[i];
-        PDP_HIP_CHECK(hipMalloc((void **)&extra_v, sizeof(float) * (size_t)p->V));
+        PDP_HIP_CHECK(hipMalloc((void **)&extra_v, sizeof(float) * V));
         sp.ws_v[6] = extra_v;
         for (int i = 0; i < 3; ++i) sp.ws_vi[i] = p->ws_vi[i];
         sp.ws_fu[0] = p->ws_fu[0]; sp.ws_fu[1] = p->ws_fu[1];
-        hipLaunchKernelGGL((k_sp_solve<int32_t, false>), dim3(p->B), dim3(256), 0, st, make_view(p), sp);
     }
-    PDP_LAUNCH_CHECK();
-    // verify the speculation record
-    uint32_t *host = (uint32_t *)malloc(sizeof(uint32_t) * 2 * (size_t)T);
-    PDP_HIP_CHECK(hipMemcpyAsync(host, spec, sizeof(uint32_t) * 2 * (size_t)T, hipMemcpyDeviceToHost, st));
-    PDP_HIP_CHECK(hipMemcpyAsync(p->flags_host, p->flags, FL_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    PDP_HIP_CHECK(hipStreamSynchronize(st));
-    bool ok = p->flags_host[FL_SPEC_VIOLATION] == 0u;
-    const uint32_t perm_from = p->flags_host[FL_PERM_ZERO];
-    for (int t = 0; t < T && ok; ++t) if ((uint32_t)t < perm_from && (host[t] & ~host[T + t]) != 0u) ok = false;
-    if (getenv("PDP_DEBUG")) {
-        fprintf(stderr, "[pdp_sp_solve] violation=%u iters=%u perm_from=%u lds=%zu\n", p->flags_host[FL_SPEC_VIOLATION],
-                p->flags_host[FL_ITERS_RUN], perm_from, lds);
-        for (int t = 0; t < T; ++t) if (t < 3 || (host[t] & ~host[T + t])) fprintf(stderr, "  t=%d used=%u zero=%u\n", t, host[t], host[T + t]);
+    uint32_t *host = (uint32_t *)malloc(words * 4);
+    bool ok = true;
+    int poison_from = 0x7fffffff;
+    int passes = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        passes = pass + 1;
+        sp.poison_from = poison_from;
+        PDP_HIP_CHECK(hipMemsetAsync(spec, 0, sizeof(uint32_t) * 2 * (size_t)T, st));
+        PDP_HIP_CHECK(hipMemsetAsync(nan_iter, 0xff, sizeof(uint32_t), st));
+        PDP_HIP_CHECK(hipMemsetAsync(p->flags + FL_SPEC_VIOLATION, 0, sizeof(uint32_t) * 2, st));   // violation + iters_run
+        PDP_HIP_CHECK(hipMemsetAsync(p->flags + FL_PERM_ZERO, 0xff, sizeof(uint32_t), st));
+        if (fits) hipLaunchKernelGGL((k_sp_solve<uint16_t, true>), dim3(p->B), dim3(512), lds, st, make_view(p), sp);
+        else hipLaunchKernelGGL((k_sp_solve<int32_t, false>), dim3(p->B), dim3(256), 0, st, make_view(p), sp);
+        PDP_LAUNCH_CHECK();
+        PDP_HIP_CHECK(hipMemcpyAsync(host, spec, words * 4, hipMemcpyDeviceToHost, st));
+        PDP_HIP_CHECK(hipMemcpyAsync(p->flags_host, p->flags, FL_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        PDP_HIP_CHECK(hipStreamSynchronize(st));
+        const uint32_t t_nan = host[2 * (size_t)T];
+        if (pass == 0 && t_nan < (uint32_t)T) {
+            // some instance poisons the batch from iteration t_nan on: restore and replay with the poison applied
+            poison_from = (int)t_nan;
+            status = snapshot_copy(p, a, snap, false, st);
+            if (status != PDP_OK) break;
+            continue;
+        }
+        ok = p->flags_host[FL_SPEC_VIOLATION] == 0u;
+        const uint32_t perm_from = p->flags_host[FL_PERM_ZERO];
+        for (int t = 0; t < T && t < poison_from && ok; ++t)
+            if ((uint32_t)t < perm_from && (host[t] & ~host[T + t]) != 0u) ok = false;
+        if (getenv("PDP_DEBUG")) {
+            fprintf(stderr, "[pdp_sp_solve] pass=%d violation=%u iters=%u perm_from=%u poison_from=%d lds=%zu ok=%d\n", pass,
+                    p->flags_host[FL_SPEC_VIOLATION], p->flags_host[FL_ITERS_RUN], perm_from, poison_from, lds, (int)ok);
+            for (int t = 0; t < T; ++t) if (t < 2 || (host[t] & ~host[T + t])) fprintf(stderr, "  t=%d used=%u zero=%u\n", t, host[t], host[T + t]);
+        }
+        break;
+    }
+    a->iterations_run_host = (int32_t)p->flags_host[FL_ITERS_RUN];
+    if (status == PDP_OK && !ok) {
+        // leave the caller's state exactly as it was so that it can rerun the batch step-wise
+        status = snapshot_copy(p, a, snap, false, st);
+        if (status == PDP_OK) status = hipStreamSynchronize(st) == hipSuccess ? PDP_OK : PDP_ERR_HIP;
     }
     free(host);
-    (void)hipFree(spec);
+    (void)hipFree(blob);
     if (extra_v) (void)hipFree(extra_v);
-    a->iterations_run_host = (int32_t)p->flags_host[FL_ITERS_RUN];
-    a->decimator->has_prev = 1;
-    p->has_edge_mask = 1;
+    if (status != PDP_OK) return status;
+    (void)passes;
     if (!ok) {
-        pdp_set_error("persistent solve: a cross-instance coupling of the reference became active (batch-global min != 0 or NaN); "
-                      "state is not reference-exact, rerun the batch step-wise");
+        pdp_set_error("persistent solve: a cross-instance coupling of the reference became active (batch-global min != 0); "
+                      "state restored, rerun the batch step-wise");
         return PDP_ERR_SPECULATION;
     }
+    a->decimator->has_prev = 1;
+    p->has_edge_mask = 1;
     return PDP_OK;
 }

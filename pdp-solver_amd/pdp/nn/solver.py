@@ -213,17 +213,13 @@ class PropagatorDecimatorSolverBase(nn.Module):
         q = init_propagator_state[0].clone().contiguous()
         fs = init_propagator_state[1].clone().contiguous()
         active_mask = torch.ones(sat_problem._batch_size, dtype=torch.uint8, device=self._device)
-        snapshot = [t.clone() for t in (nat.active_variables, nat.active_functions, nat.solution, nat.is_sat, nat.edge_mask)]
         handle = self._decimator.native_handle(sat_problem)
         try:
             iters, used_lds = nat.sp_solve(q, fs, active_mask, handle, int(iteration_num), self._decimator._tolerance,
                                            self._decimator._t_max, self._propagator._pi,
                                            check_termination=check_termination is not None)
         except native.SpeculationFailed:
-            for dst, src in zip((nat.active_variables, nat.active_functions, nat.solution, nat.is_sat, nat.edge_mask), snapshot):
-                dst.copy_(src)
-            self._decimator._handle = None
-            return None
+            return None            # the library restored every array it touched; fall back to the strict step-wise loop
         self.last_run.update(path='persistent-lds' if used_lds else 'persistent-hbm', iterations=iters)
         sat_problem._edge_mask = nat.edge_mask
         state = (q, fs)
