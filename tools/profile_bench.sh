@@ -1,0 +1,22 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence for bench.py on the GPU box: kernel-trace stats, then separate PMC passes
+# (counters are never combined with tracing domains other than --kernel-trace).
+# usage (through gpurun): bash tools/profile_bench.sh <tag> [bench args...]
+set -u
+TAG=${1:-r01}; shift || true
+cd "$(dirname "$0")/.."
+ROOT=$PWD
+export TMPDIR=/tmp
+OUT=$ROOT/gpurun_out/prof_$TAG; rm -rf "$OUT"
+mkdir -p "$OUT"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline $*"
+cd /tmp
+rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/trace" -o trace -- python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_trace.log" 2>&1
+rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY -d "$OUT/pmc1" -o pmc -- python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_pmc1.log" 2>&1
+rocprofv3 --output-format csv --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY -d "$OUT/pmc2" -o pmc -- python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_pmc2.log" 2>&1
+rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc3" -o pmc -- python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_pmc3.log" 2>&1
+rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc4" -o pmc -- python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_pmc4.log" 2>&1
+cd "$ROOT"
+python3 tools/summarize_profile.py "$OUT" > "$OUT/summary.txt" 2>&1
+cat "$OUT/summary.txt"
+tail -2 "$OUT/bench_trace.log"

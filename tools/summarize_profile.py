@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 output directories (kernel stats + PMC csv files) into a small text summary."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+
+
+def find(pattern):
+    return sorted(glob.glob(os.path.join(root, '**', pattern), recursive=True))
+
+
+print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
+for f in find('*kernel_stats.csv'):
+    if '/trace/' not in f:
+        continue
+    with open(f) as fh:
+        rows = list(csv.DictReader(fh))
+    for r in rows[:12]:
+        print("%-70s calls=%s total_ns=%s avg_ns=%s pct=%s" % (r.get('Name', '')[:70], r.get('Calls'), r.get('TotalDurationNs'),
+                                                                r.get('AverageNs'), r.get('Percentage')))
+print()
+print("== PMC counters per kernel (sum over dispatches / dispatches) ==")
+for d in ('pmc1', 'pmc2', 'pmc3', 'pmc4'):
+    for f in find('*counter_collection.csv'):
+        if '/%s/' % d not in f:
+            continue
+        acc = defaultdict(lambda: defaultdict(float))
+        cnt = defaultdict(set)
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                k = r.get('Kernel_Name', '')[:60]
+                acc[k][r.get('Counter_Name')] += float(r.get('Counter_Value', 0) or 0)
+                cnt[k].add(r.get('Dispatch_Id'))
+        for k in sorted(acc, key=lambda x: -sum(acc[x].values()))[:4]:
+            n = max(1, len(cnt[k]))
+            print("[%s] %-60s dispatches=%d" % (d, k, n))
+            for c, v in sorted(acc[k].items()):
+                print("      %-28s %.4g per dispatch" % (c, v / n))
