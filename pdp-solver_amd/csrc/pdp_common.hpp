@@ -92,6 +92,10 @@ struct pdp_problem {
     uint32_t *flags;            // [FL_COUNT] device
     uint32_t *flags_host;       // pinned host mirror
     void *cub_tmp; size_t cub_tmp_bytes;
+    // persistent-solver scratch, allocated on first use and kept (hipMalloc/hipFree of ~0.5 GB cost milliseconds)
+    char *solve_blob; size_t solve_blob_bytes;
+    uint32_t *solve_host; size_t solve_host_words;   // pinned
+    float *solve_extra_v;
 };
 
 struct pdp_decimator {

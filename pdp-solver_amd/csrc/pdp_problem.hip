@@ -179,6 +179,9 @@ extern "C" int pdp_problem_destroy(pdp_problem *p)
                     p->ws_vi[0], p->ws_vi[1], p->ws_vi[2], p->ws_fu[0], p->ws_fu[1], p->flags, p->cub_tmp};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     if (p->flags_host) (void)hipHostFree(p->flags_host);
+    if (p->solve_blob) (void)hipFree(p->solve_blob);
+    if (p->solve_host) (void)hipHostFree(p->solve_host);
+    if (p->solve_extra_v) (void)hipFree(p->solve_extra_v);
     delete p;
     return PDP_OK;
 }

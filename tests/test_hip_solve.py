@@ -92,3 +92,23 @@ def test_speculation_detects_coupling(oracle):
     am = torch.ones(hp.B, dtype=torch.uint8, device='cuda:0')
     with pytest.raises(native.SpeculationFailed):
         hp.sp_solve(q, fs, am, native.Decimator(hp), 5, 0.02, 100)
+
+
+@pytest.mark.parametrize('spec,T,tol,t_max', [(dict(batch=400, n=60, k=3, seed=7000), 120, 0.05, 8),
+                                              (dict(batch=200, n=100, k=3, seed=5000), 150, 0.05, 10)])
+def test_persistent_solve_reproduces_nan_poisoning(oracle, spec, T, tol, t_max):
+    """At the SAT threshold some instance produces 0/0 in the survey normalisation; in the reference the NaN then
+    disables gating / convergence / decimation for the WHOLE batch.  The persistent solver must
+    reproduce that exactly (pass 1 finds the poison iteration, the affected instances are replayed)."""
+    b = random_batch(**spec)
+    hp, res, q, fs, am, iters, used_lds, spec_ok = run_pair(oracle, b, T, tol, t_max)
+    assert np.isnan(res['fs']).any(), "test batch no longer produces a NaN: pick another seed"
+    assert spec_ok and used_lds
+    it = res['iterations_run']
+    assert iters == it
+    np.testing.assert_array_equal(npy(am), res['trace_active_mask'][it - 1])
+    np.testing.assert_array_equal(npy(hp.active_variables)[:, 0], res['trace_active_var'][it - 1])
+    np.testing.assert_array_equal(npy(hp.active_functions)[:, 0], res['trace_active_fn'][it - 1])
+    np.testing.assert_array_equal(npy(hp.solution), res['trace_solution'][it - 1])
+    np.testing.assert_array_equal(npy(q), res['q'])
+    np.testing.assert_array_equal(npy(fs), res['fs'])
