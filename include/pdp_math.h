@@ -47,15 +47,17 @@ PDP_HD float pdp_abs(float x) { return pdp_bits2f(pdp_f2bits(x) & 0x7fffffffu); 
 /* 2^n for -126 <= n <= 127 */
 PDP_HD float pdp_pow2i(int n) { return pdp_bits2f((uint32_t)(n + 127) << 23); }
 
-/* e^x.  Result is correctly scaled into the denormal range (single final rounding). */
+/* e^x.  Result is correctly scaled into the denormal range (single final rounding).
+ * Written branch-free (selects only): on gfx950 early returns would become divergent exec-mask branches. */
 PDP_HD float pdp_expf(float x)
 {
-    if (x != x) return x;
-    if (x > 88.7228394f) return PDP_INF;
-    if (x < -104.0f) return 0.0f;
-    const float t = x * 1.44269504088896341f;
+    const int is_nan = (x != x);
+    float xc = is_nan ? 0.0f : x;
+    xc = (xc > 89.0f) ? 89.0f : xc;
+    xc = (xc < -104.5f) ? -104.5f : xc;
+    const float t = xc * 1.44269504088896341f;
     const float nf = (t + 12582912.0f) - 12582912.0f;     /* round-to-nearest-even integer */
-    float r = fmaf(nf, -0.693359375f, x);                  /* x - n*ln2 (hi, exact product) */
+    float r = fmaf(nf, -0.693359375f, xc);                 /* x - n*ln2 (hi, exact product) */
     r = fmaf(nf, 2.12194440e-4f, r);                       /*           (lo)                */
     const float z = r * r;
     float p = 1.9875691500e-4f;
@@ -66,10 +68,13 @@ PDP_HD float pdp_expf(float x)
     p = fmaf(p, r, 5.0000001201e-1f);
     p = fmaf(p, z, r);
     p = p + 1.0f;
-    const int n = (int)nf;                                 /* |n| <= 151: safe conversion */
-    const int n1 = n / 2;
-    const int n2 = n - n1;
-    return (p * pdp_pow2i(n1)) * pdp_pow2i(n2);            /* first product exact, second rounds once */
+    const int n = (int)nf;                                 /* |n| <= 151 after the clamp */
+    const int n1 = n >> 1;                                 /* any split with both halves in the normal range works: */
+    const int n2 = n - n1;                                 /* the first product is exact, the second rounds once     */
+    float res = (p * pdp_pow2i(n1)) * pdp_pow2i(n2);
+    res = (x > 88.7228394f) ? PDP_INF : res;
+    res = (x < -104.0f) ? 0.0f : res;
+    return is_nan ? x : res;
 }
 
 /* e^x - 1, accurate near 0 (used by tanh) */
@@ -89,18 +94,22 @@ PDP_HD float pdp_expm1f(float x)
     return pdp_expf(x) - 1.0f;
 }
 
-/* natural log, x > 0 expected (denormals fine); x == 0 -> -inf, x < 0 -> NaN */
+/* natural log, x > 0 expected (denormals fine); x == 0 -> -inf, x < 0 -> NaN.  Branch-free like pdp_expf. */
 PDP_HD float pdp_logf(float x)
 {
-    if (x != x) return x;
-    if (x <= 0.0f) return (x == 0.0f) ? -PDP_INF : PDP_NAN;
-    uint32_t u = pdp_f2bits(x);
-    if (u == 0x7f800000u) return x;
-    int e = 0;
-    if (u < 0x00800000u) { x = x * 8388608.0f; e = -23; u = pdp_f2bits(x); }
-    e += (int)(u >> 23) - 126;                             /* x = m * 2^e, m in [0.5, 1) */
+    const int is_nan = (x != x);
+    const uint32_t u0 = pdp_f2bits(x);
+    const int is_inf = (u0 == 0x7f800000u);
+    const int not_pos = !(x > 0.0f);                       /* x <= 0 or NaN */
+    const float xs = (not_pos || is_inf) ? 1.0f : x;      /* keep the main path on sane input */
+    const int den = pdp_f2bits(xs) < 0x00800000u;
+    const float xn = xs * (den ? 8388608.0f : 1.0f);
+    const uint32_t u = pdp_f2bits(xn);
+    int e = (den ? -23 : 0) + (int)(u >> 23) - 126;        /* x = m * 2^e, m in [0.5, 1) */
     float m = pdp_bits2f((u & 0x007fffffu) | 0x3f000000u);
-    if (m < 0.707106781186547524f) { e -= 1; m = (m + m) - 1.0f; } else { m = m - 1.0f; }
+    const int lt = m < 0.707106781186547524f;
+    e = e - lt;
+    m = (lt ? (m + m) : m) - 1.0f;
     const float z = m * m;
     float y = 7.0376836292e-2f;
     y = fmaf(y, m, -1.1514610310e-1f);
@@ -117,7 +126,10 @@ PDP_HD float pdp_logf(float x)
     y = fmaf(-0.5f, z, y);
     float r = m + y;
     r = fmaf(fe, 0.693359375f, r);
-    return r;
+    r = is_inf ? x : r;
+    r = (x == 0.0f) ? -PDP_INF : r;
+    r = (x < 0.0f) ? PDP_NAN : r;
+    return is_nan ? x : r;
 }
 
 /* log(1 + t) for t >= 0 (compensated) */

@@ -397,58 +397,135 @@ static size_t lds2_bytes_for(int n, int m, int e, bool force)
     return s;
 }
 
+// every LDS array of the v2 kernel, derived from (base, n, m, e): cold code re-derives them instead of keeping ~25
+// pointers alive across the hot loop (they would spill out of the SGPR file)
+struct LdsArrays {
+    float *QU, *EA, *EB, *X, *Y, *FRC;
+    uint16_t *pvv, *pcc, *e2p, *v_ptr, *f_ptr;
+    float *S, *af, *av, *sol, *Pv, *Nv, *xv1, *xv2, *coeff;
+    uint8_t *flag_v;
+};
+__device__ __forceinline__ LdsArrays carve_all(unsigned char *cp, int n, int m, int ne, bool force)
+{
+    LdsArrays L;
+    L.QU = carve<float>(cp, ne); L.EA = carve<float>(cp, ne); L.EB = carve<float>(cp, ne); L.X = carve<float>(cp, ne); L.Y = carve<float>(cp, ne);
+    L.FRC = force ? carve<float>(cp, ne) : nullptr;
+    L.pvv = carve<uint16_t>(cp, ne); L.pcc = carve<uint16_t>(cp, ne); L.e2p = carve<uint16_t>(cp, ne);
+    L.v_ptr = carve<uint16_t>(cp, n + 1); L.f_ptr = carve<uint16_t>(cp, m + 1);
+    L.S = carve<float>(cp, m + 8); L.af = carve<float>(cp, m);
+    L.av = carve<float>(cp, n); L.sol = carve<float>(cp, n); L.Pv = carve<float>(cp, n); L.Nv = carve<float>(cp, n);
+    L.xv1 = carve<float>(cp, n); L.xv2 = carve<float>(cp, n); L.coeff = carve<float>(cp, n);
+    L.flag_v = carve<uint8_t>(cp, n);
+    return L;
+}
+__device__ __forceinline__ LView make_lview(const LdsArrays &L, int b, int n, int m, int ne)
+{
+    LView I;
+    I.b = b; I.n = n; I.m = m; I.e = ne;
+    I.e_var.pv = L.pvv; I.e_fn.pc = L.pcc; I.sgn.pv = L.pvv; I.f_edges = L.e2p; I.v_ptr = L.v_ptr; I.f_ptr = L.f_ptr;
+    I.av = L.av; I.af = L.af; I.sol = L.sol;
+    return I;
+}
+#define UNI(x) __builtin_amdgcn_readfirstlane(x)
+__device__ __forceinline__ float uni_f(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+
+// P6, cold: SurveyScorer + arg-max + set_variables (pdp_decimate.py:152-171).  Returns 1 if a variable was fixed;
+// *spec gets bit 0 "coeff has an exact zero", bit 1 "NaN coefficient".
+template <bool FORCE>
+__device__ __noinline__ int lds_decimate(unsigned char *smem, int b, int n, int m, int ne, int cur, int active, float pi,
+                                         float *is_sat_b, int *spec)
+{
+    __shared__ float redf2[PDP_RED_SCRATCH];
+    __shared__ int redi2[PDP_RED_SCRATCH];
+    const LdsArrays L = carve_all(smem, n, m, ne, FORCE);
+    const LView I = make_lview(L, b, n, m, ne);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    float *Enew = cur ? L.EA : L.EB;
+    float *score = L.xv2, *assign = L.coeff;
+    for (int p = tid; p < ne; p += nt)
+        L.Y[p] = pdp_safe_log(1.0f - Enew[p], PDP_SCORER_EPS) * (0.0f + L.af[L.pcc[p] & 0x3fff]);
+    __syncthreads();
+    int z3 = 0, anynz = 0, cn = 0;
+    for (int v = tid; v < n; v += nt) {
+        float ext = 0.0f, pos = 0.0f, neg = 0.0f, all = 0.0f;
+        for (int p = L.v_ptr[v]; p < L.v_ptr[v + 1]; ++p) {
+            const float f = L.Y[p];
+            const bool ng = (L.pvv[p] & 0x8000) != 0;
+            ext = ext + (FORCE ? L.FRC[p] : 0.0f);
+            pos = pos + (ng ? 0.0f : 1.0f) * f;
+            neg = neg + (ng ? 1.0f : 0.0f) * f;
+            all = all + f;
+        }
+        const float sc = d_score_from_sums(pos, neg, all, ext, pi);
+        const float co = (pdp_abs(sc) * L.av[v]) * 1.0f;
+        score[v] = sc; L.coeff[v] = co;
+        if (co == 0.0f) z3 = 1;
+        if (co != 0.0f) anynz = 1;
+        if (co != co) cn = 1;
+    }
+    __syncthreads();
+    z3 = __syncthreads_or(z3); anynz = __syncthreads_or(anynz); cn = __syncthreads_or(cn);
+    *spec = (z3 ? 1 : 0) | (cn ? 2 : 0);
+    const int li = d_instance_argmax(I, L.coeff, 0.0f, redf2, redi2);
+    if (!(active && anynz && !cn && li >= 0)) return 0;
+    const float sgn_li = pdp_sign(score[li]);
+    __syncthreads();
+    for (int v = tid; v < n; v += nt) assign[v] = 0.0f;
+    __syncthreads();
+    if (tid == 0) assign[li] = sgn_li;
+    __syncthreads();
+    SimplifyScratch ss;
+    ss.assign = assign; ss.deg = reinterpret_cast<int32_t *>(L.xv1); ss.sdeg = reinterpret_cast<int32_t *>(L.xv2);
+    ss.flag_v = L.flag_v; ss.flag_f = reinterpret_cast<uint8_t *>(L.S); ss.flag_f2 = ss.flag_f + ((m + 15) & ~15); ss.red = redi2;
+    d_set_variable_core(I, ss);
+    d_simplify(I, ss, is_sat_b);
+    return 1;
+}
+
+template <bool FORCE>
+__device__ __noinline__ int lds_cnf_count(unsigned char *smem, int b, int n, int m, int ne)
+{
+    __shared__ int redi3[PDP_RED_SCRATCH];
+    const LdsArrays L = carve_all(smem, n, m, ne, FORCE);
+    const LView I = make_lview(L, b, n, m, ne);
+    return d_cnf_sat_count(I, L.sol, redi3);
+}
+
 template <bool FORCE>
 __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float redf[PDP_RED_SCRATCH];
     __shared__ int redi[PDP_RED_SCRATCH];
+
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
     const Inst G = load_inst(pv_, sp.inst_list ? sp.inst_list[blockIdx.x] : (int)blockIdx.x);
-    const float *sq = sp.src_q + 3 * (size_t)G.e0, *sfs = sp.src_fs + 2 * (size_t)G.e0;
     const int n = G.n, m = G.m, ne = G.e;
-    float *gq = sp.q + 3 * (size_t)G.e0;
-    float *gfs = sp.fs + 2 * (size_t)G.e0;
-
-    unsigned char *cp = smem;
-    float *QU = carve<float>(cp, ne), *EA = carve<float>(cp, ne), *EB = carve<float>(cp, ne), *X = carve<float>(cp, ne), *Y = carve<float>(cp, ne);
-    float *FRC = FORCE ? carve<float>(cp, ne) : nullptr;
-    uint16_t *pvv = carve<uint16_t>(cp, ne), *pcc = carve<uint16_t>(cp, ne), *e2p = carve<uint16_t>(cp, ne);
-    uint16_t *v_ptr = carve<uint16_t>(cp, n + 1), *f_ptr = carve<uint16_t>(cp, m + 1);
-    float *S = carve<float>(cp, m + 8), *af = carve<float>(cp, m);
-    float *av = carve<float>(cp, n), *sol = carve<float>(cp, n), *Pv = carve<float>(cp, n), *Nv = carve<float>(cp, n);
-    float *xv1 = carve<float>(cp, n), *xv2 = carve<float>(cp, n), *coeff = carve<float>(cp, n);
-    uint8_t *flag_v = carve<uint8_t>(cp, n);
-    float *score = xv2;                                   // xv2 is dead once the maxima are reduced
-    float *assign = coeff;                                // coeff is dead once the arg-max is known
-    uint8_t *flag_f = reinterpret_cast<uint8_t *>(S), *flag_f2 = flag_f + ((m + 15) & ~15);   // S is dead during decimation
+    const LdsArrays L = carve_all(smem, n, m, ne, FORCE);
+    float *const QU = L.QU, *const X = L.X, *const Y = L.Y;
+    uint16_t *const pvv = L.pvv, *const pcc = L.pcc;
 
     // ---- load ---------------------------------------------------------------------------------------------------------
-    for (int p = tid; p < ne; p += nt) {
-        const int e = G.v_edges[p];
-        const int sg = G.sgn[e];
-        pvv[p] = (uint16_t)(G.e_var[e] | (sg < 0 ? 0x8000 : 0));
-        const bool em = sp.src_emask[G.e0 + e] == 1.0f;
-        pcc[p] = (uint16_t)(G.e_fn[e] | (em ? (PC_EM | PC_EM_USED) : 0));
-        e2p[e] = (uint16_t)p;
-        QU[p] = sq[3 * e]; EA[p] = sfs[2 * e];
-        if constexpr (FORCE) FRC[p] = sfs[2 * e + 1];
+    {
+        const float *sq = sp.src_q + 3 * (size_t)G.e0, *sfs = sp.src_fs + 2 * (size_t)G.e0;
+        for (int p = tid; p < ne; p += nt) {
+            const int e = G.v_edges[p];
+            const int sg = G.sgn[e];
+            pvv[p] = (uint16_t)(G.e_var[e] | (sg < 0 ? 0x8000 : 0));
+            const bool em = sp.src_emask[G.e0 + e] == 1.0f;
+            pcc[p] = (uint16_t)(G.e_fn[e] | (em ? (PC_EM | PC_EM_USED) : 0));
+            L.e2p[e] = (uint16_t)p;
+            QU[p] = sq[3 * e]; L.EA[p] = sfs[2 * e];
+            if constexpr (FORCE) L.FRC[p] = sfs[2 * e + 1];
+        }
+        for (int v = tid; v <= n; v += nt) L.v_ptr[v] = (uint16_t)G.v_ptr[v];
+        for (int c = tid; c <= m; c += nt) L.f_ptr[c] = (uint16_t)G.f_ptr[c];
+        for (int v = tid; v < n; v += nt) { L.av[v] = sp.src_av[G.v0 + v]; L.sol[v] = sp.src_sol[G.v0 + v]; }
+        for (int c = tid; c < m; c += nt) L.af[c] = sp.src_af[G.f0 + c];
+        if (tid == 0 && sp.inst_list) pv_.is_sat[G.b] = sp.src_sat[G.b];
     }
-    for (int v = tid; v <= n; v += nt) v_ptr[v] = (uint16_t)G.v_ptr[v];
-    for (int c = tid; c <= m; c += nt) f_ptr[c] = (uint16_t)G.f_ptr[c];
-    for (int v = tid; v < n; v += nt) { av[v] = sp.src_av[G.v0 + v]; sol[v] = sp.src_sol[G.v0 + v]; }
-    for (int c = tid; c < m; c += nt) af[c] = sp.src_af[G.f0 + c];
-    if (tid == 0 && sp.inst_list) pv_.is_sat[G.b] = sp.src_sat[G.b];
     __syncthreads();
-
-    LView I;
-    I.b = G.b; I.n = n; I.m = m; I.e = ne;
-    I.e_var.pv = pvv; I.e_fn.pc = pcc; I.sgn.pv = pvv; I.f_edges = e2p; I.v_ptr = v_ptr; I.f_ptr = f_ptr;
-    I.av = av; I.af = af; I.sol = sol;
-    SimplifyScratch ss;
-    ss.assign = assign; ss.deg = reinterpret_cast<int32_t *>(xv1); ss.sdeg = reinterpret_cast<int32_t *>(xv2);
-    ss.flag_v = flag_v; ss.flag_f = flag_f; ss.flag_f2 = flag_f2; ss.red = redi;
 
     int active = sp.src_amask[G.b] ? 1 : 0;
     int has_prev = sp.has_prev;
@@ -458,14 +535,16 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
     float cnt = sp.src_cnt[G.b];
     int iters = 0, did_prop = 0, nsat = -1, violation = 0, cur = 0;
     const bool other_rows = n < pv_.V;
+    const float pi = sp.pi, tol = sp.tol, t_max = sp.t_max;
+    const int T = sp.T, poison_from = sp.poison_from;
     // log(max(1 - pi * [force == +-s], eps)): two possible values per kernel (pdp_propagate.py:197,201)
-    const float L0 = pdp_safe_log(1.0f - sp.pi * 0.0f, PDP_SP_EPS), L1 = pdp_safe_log(1.0f - sp.pi * 1.0f, PDP_SP_EPS);
+    const float L0 = pdp_safe_log(1.0f - pi * 0.0f, PDP_SP_EPS), L1 = pdp_safe_log(1.0f - pi * 1.0f, PDP_SP_EPS);
 
-    for (int t = 0; t < sp.T; ++t) {
+    for (int t = 0; t < T; ++t) {
         if (!active) break;
-        const bool poisoned = t >= sp.poison_from;
+        const bool poisoned = t >= poison_from;
         iters = t + 1;
-        float *Eold = cur ? EB : EA, *Enew = cur ? EA : EB;
+        float *const Eold = cur ? L.EB : L.EA, *const Enew = cur ? L.EA : L.EB;
         // ---- E1: per-slot logs -------------------------------------------------------------------------------------
         for (int p = tid; p < ne; p += nt) {
             float x = pdp_safe_log(QU[p], PDP_SP_EPS);
@@ -481,69 +560,75 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
         last_use_em = use_em; em_dirty = 0;
         __syncthreads();
         // ---- R1: per-clause sums (through e2p) and per-variable sums (contiguous), ascending edge id ------------
-        for (int r = tid; r < m + n; r += nt) {
-            if (r < m) {
-                float acc = 0.0f;
-                const int a = f_ptr[r], bnd = f_ptr[r + 1];
-                int k = a;
-                for (; k + 2 < bnd; k += 3) {
-                    const float x0 = X[e2p[k]], x1 = X[e2p[k + 1]], x2 = X[e2p[k + 2]];
-                    acc = acc + x0; acc = acc + x1; acc = acc + x2;
+        {
+            const uint16_t *const e2p = L.e2p, *const f_ptr = L.f_ptr, *const v_ptr = L.v_ptr;
+            float *const S = L.S, *const Pv = L.Pv, *const Nv = L.Nv;
+            for (int r = tid; r < m + n; r += nt) {
+                if (r < m) {
+                    float acc = 0.0f;
+                    const int a = f_ptr[r], bnd = f_ptr[r + 1];
+                    int k = a;
+                    for (; k + 2 < bnd; k += 3) {
+                        const float x0 = X[e2p[k]], x1 = X[e2p[k + 1]], x2 = X[e2p[k + 2]];
+                        acc = acc + x0; acc = acc + x1; acc = acc + x2;
+                    }
+                    for (; k < bnd; ++k) acc = acc + X[e2p[k]];
+                    S[r] = acc;
+                } else {
+                    const int v = r - m;
+                    float P = 0.0f, N = 0.0f;
+                    const int a = v_ptr[v], bnd = v_ptr[v + 1];
+                    int p = a;
+                    for (; p + 3 < bnd; p += 4) {
+                        const float y0 = Y[p], y1 = Y[p + 1], y2 = Y[p + 2], y3 = Y[p + 3];
+                        const uint16_t s0 = pvv[p], s1 = pvv[p + 1], s2 = pvv[p + 2], s3 = pvv[p + 3];
+                        P = P + ((s0 & 0x8000) ? 0.0f : 1.0f) * y0; N = N + ((s0 & 0x8000) ? 1.0f : 0.0f) * y0;
+                        P = P + ((s1 & 0x8000) ? 0.0f : 1.0f) * y1; N = N + ((s1 & 0x8000) ? 1.0f : 0.0f) * y1;
+                        P = P + ((s2 & 0x8000) ? 0.0f : 1.0f) * y2; N = N + ((s2 & 0x8000) ? 1.0f : 0.0f) * y2;
+                        P = P + ((s3 & 0x8000) ? 0.0f : 1.0f) * y3; N = N + ((s3 & 0x8000) ? 1.0f : 0.0f) * y3;
+                    }
+                    for (; p < bnd; ++p) {
+                        const float y0 = Y[p]; const uint16_t s0 = pvv[p];
+                        P = P + ((s0 & 0x8000) ? 0.0f : 1.0f) * y0; N = N + ((s0 & 0x8000) ? 1.0f : 0.0f) * y0;
+                    }
+                    Pv[v] = P; Nv[v] = N;
                 }
-                for (; k < bnd; ++k) acc = acc + X[e2p[k]];
-                S[r] = acc;
-            } else {
-                const int v = r - m;
-                float P = 0.0f, N = 0.0f;
-                const int a = v_ptr[v], bnd = v_ptr[v + 1];
-                int p = a;
-                for (; p + 3 < bnd; p += 4) {
-                    const float y0 = Y[p], y1 = Y[p + 1], y2 = Y[p + 2], y3 = Y[p + 3];
-                    const uint16_t s0 = pvv[p], s1 = pvv[p + 1], s2 = pvv[p + 2], s3 = pvv[p + 3];
-                    P = P + ((s0 & 0x8000) ? 0.0f : 1.0f) * y0; N = N + ((s0 & 0x8000) ? 1.0f : 0.0f) * y0;
-                    P = P + ((s1 & 0x8000) ? 0.0f : 1.0f) * y1; N = N + ((s1 & 0x8000) ? 1.0f : 0.0f) * y1;
-                    P = P + ((s2 & 0x8000) ? 0.0f : 1.0f) * y2; N = N + ((s2 & 0x8000) ? 1.0f : 0.0f) * y2;
-                    P = P + ((s3 & 0x8000) ? 0.0f : 1.0f) * y3; N = N + ((s3 & 0x8000) ? 1.0f : 0.0f) * y3;
-                }
-                for (; p < bnd; ++p) {
-                    const float y0 = Y[p]; const uint16_t s0 = pvv[p];
-                    P = P + ((s0 & 0x8000) ? 0.0f : 1.0f) * y0; N = N + ((s0 & 0x8000) ? 1.0f : 0.0f) * y0;
-                }
-                Pv[v] = P; Nv[v] = N;
             }
         }
         __syncthreads();
         // ---- E2: new survey, new q_u, smooth-max weights -----------------------------------------------------------
         int nan_seen = 0;
-        for (int p = tid; p < ne; p += nt) {
-            const uint16_t pw = pvv[p], cw = pcc[p];
-            const int v = pw & 0x3fff, c = cw & 0x3fff;
-            const float s = (pw & 0x8000) ? -1.0f : 1.0f;
-            const float eta_old = Eold[p];
-            const float agg = (0.0f + S[c]) - X[p];
-            const float eta_new = 1.0f * pdp_safe_exp(agg) + (1.0f - 1.0f) * eta_old;
-            // d_sp_edge with the two log terms taken from {L0, L1}
-            const float force = FORCE ? FRC[p] : 0.0f;
-            const float pos = 0.0f + Pv[v], neg = 0.0f + Nv[v];
-            float same = (0.5f * (1.0f + s)) * pos + (0.5f * (1.0f - s)) * neg;
-            same = same - Y[p];
-            same = same + ((force == s) ? L1 : L0);
-            float opp = (0.5f * (1.0f - s)) * pos + (0.5f * (1.0f + s)) * neg;
-            opp = opp + ((force == -s) ? L1 : L0);
-            const float dc = pdp_safe_exp(same + opp);
-            const float A = pdp_safe_exp(same), Bv = pdp_safe_exp(opp);
-            const float qu = A * (1.0f - Bv), qs = Bv * (1.0f - A);
-            const float total = (qu + qs) + dc;
-            const float qu_new = 1.0f * (qu / total) + (1.0f - 1.0f) * QU[p];
-            if (eta_new != eta_new) nan_seen = 1;
-            QU[p] = qu_new;
-            Enew[p] = eta_new;
-            X[p] = pdp_safe_exp(30.0f * eta_new);
-            if (has_prev) {
-                const float pe = prev_from_global ? sp.src_prev[G.e0 + G.v_edges[p]] : eta_old;
-                float d = pdp_abs(pe - eta_new);
-                if (use_em) d = d * ((cw & PC_EM) ? 1.0f : 0.0f);
-                Y[p] = pdp_safe_exp(30.0f * d);
+        {
+            const float *const S = L.S, *const Pv = L.Pv, *const Nv = L.Nv;
+            for (int p = tid; p < ne; p += nt) {
+                const uint16_t pw = pvv[p], cw = pcc[p];
+                const int v = pw & 0x3fff, c = cw & 0x3fff;
+                const float s = (pw & 0x8000) ? -1.0f : 1.0f;
+                const float eta_old = Eold[p];
+                const float agg = (0.0f + S[c]) - X[p];
+                const float eta_new = 1.0f * pdp_safe_exp(agg) + (1.0f - 1.0f) * eta_old;
+                const float force = FORCE ? L.FRC[p] : 0.0f;
+                const float pos = 0.0f + Pv[v], neg = 0.0f + Nv[v];
+                float same = (0.5f * (1.0f + s)) * pos + (0.5f * (1.0f - s)) * neg;
+                same = same - Y[p];
+                same = same + ((force == s) ? L1 : L0);
+                float opp = (0.5f * (1.0f - s)) * pos + (0.5f * (1.0f + s)) * neg;
+                opp = opp + ((force == -s) ? L1 : L0);
+                const float dc = pdp_safe_exp(same + opp);
+                const float A = pdp_safe_exp(same), Bv = pdp_safe_exp(opp);
+                const float qu = A * (1.0f - Bv), qs = Bv * (1.0f - A);
+                const float total = (qu + qs) + dc;
+                const float qu_new = 1.0f * (qu / total) + (1.0f - 1.0f) * QU[p];
+                if (eta_new != eta_new) nan_seen = 1;
+                QU[p] = qu_new;
+                Enew[p] = eta_new;
+                X[p] = pdp_safe_exp(30.0f * eta_new);
+                if (has_prev) {
+                    const float pe = prev_from_global ? sp.src_prev[G.e0 + G.v_edges[p]] : eta_old;
+                    float d = pdp_abs(pe - eta_new);
+                    if (use_em) d = d * ((cw & PC_EM) ? 1.0f : 0.0f);
+                    Y[p] = pdp_safe_exp(30.0f * d);
+                }
             }
         }
         did_prop = 1;
@@ -551,30 +636,53 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
         // ---- P4: per-variable smooth maxima, partial reductions in registers --------------------------------------------
         float m1 = -PDP_INF, m2 = -PDP_INF;
         int bits = nan_seen ? 4 : 0;                       // bit0: xv1 has an exact 0, bit1: xv2 has one, bit2: NaN
-        for (int v = tid; v < n; v += nt) {
-            float num1 = 0.0f, den1 = 0.0f, num2 = 0.0f, den2 = 0.0f;
-            const int a = v_ptr[v], bnd = v_ptr[v + 1];
-            for (int p = a; p < bnd; ++p) {
-                const float c1 = X[p], et = Enew[p];
-                num1 = num1 + et * c1; den1 = den1 + c1;
-                if (has_prev) {
-                    const float pe = prev_from_global ? sp.src_prev[G.e0 + G.v_edges[p]] : Eold[p];
-                    float d = pdp_abs(pe - et);
-                    if (use_em) d = d * ((pcc[p] & PC_EM) ? 1.0f : 0.0f);
-                    const float c2 = Y[p];
-                    num2 = num2 + d * c2; den2 = den2 + c2;
+        {
+            const uint16_t *const v_ptr = L.v_ptr;
+            const float *const av = L.av;
+            for (int v = tid; v < n; v += nt) {
+                float num1 = 0.0f, den1 = 0.0f, num2 = 0.0f, den2 = 0.0f;
+                const int a = v_ptr[v], bnd = v_ptr[v + 1];
+                if (has_prev && !prev_from_global) {
+                    int p = a;
+                    for (; p + 1 < bnd; p += 2) {
+                        const float c10 = X[p], c11 = X[p + 1], e0 = Enew[p], e1 = Enew[p + 1], o0 = Eold[p], o1 = Eold[p + 1];
+                        const float c20 = Y[p], c21 = Y[p + 1];
+                        const uint16_t w0 = pcc[p], w1 = pcc[p + 1];
+                        float d0 = pdp_abs(o0 - e0), d1 = pdp_abs(o1 - e1);
+                        if (use_em) { d0 = d0 * ((w0 & PC_EM) ? 1.0f : 0.0f); d1 = d1 * ((w1 & PC_EM) ? 1.0f : 0.0f); }
+                        num1 = num1 + e0 * c10; den1 = den1 + c10; num2 = num2 + d0 * c20; den2 = den2 + c20;
+                        num1 = num1 + e1 * c11; den1 = den1 + c11; num2 = num2 + d1 * c21; den2 = den2 + c21;
+                    }
+                    for (; p < bnd; ++p) {
+                        const float c1 = X[p], et = Enew[p];
+                        float d = pdp_abs(Eold[p] - et);
+                        if (use_em) d = d * ((pcc[p] & PC_EM) ? 1.0f : 0.0f);
+                        const float c2 = Y[p];
+                        num1 = num1 + et * c1; den1 = den1 + c1; num2 = num2 + d * c2; den2 = den2 + c2;
+                    }
+                } else {
+                    for (int p = a; p < bnd; ++p) {
+                        const float c1 = X[p], et = Enew[p];
+                        num1 = num1 + et * c1; den1 = den1 + c1;
+                        if (has_prev) {
+                            float d = pdp_abs(sp.src_prev[G.e0 + G.v_edges[p]] - et);
+                            if (use_em) d = d * ((pcc[p] & PC_EM) ? 1.0f : 0.0f);
+                            const float c2 = Y[p];
+                            num2 = num2 + d * c2; den2 = den2 + c2;
+                        }
+                    }
                 }
-            }
-            const float a_v = av[v];
-            const float r1 = (num1 / pdp_max(den1, 1.0f)) * a_v;
-            if (r1 == 0.0f) bits |= 1;
-            if (r1 != r1) bits |= 4;
-            m1 = pdp_max(m1, (r1 - 0.0f) + 1.0f);
-            if (has_prev) {
-                const float r2 = (num2 / pdp_max(den2, 1.0f)) * a_v;
-                if (r2 == 0.0f) bits |= 2;
-                if (r2 != r2) bits |= 4;
-                m2 = pdp_max(m2, (r2 - 0.0f) + 1.0f);
+                const float a_v = av[v];
+                const float r1 = (num1 / pdp_max(den1, 1.0f)) * a_v;
+                if (r1 == 0.0f) bits |= 1;
+                if (r1 != r1) bits |= 4;
+                m1 = pdp_max(m1, (r1 - 0.0f) + 1.0f);
+                if (has_prev) {
+                    const float r2 = (num2 / pdp_max(den2, 1.0f)) * a_v;
+                    if (r2 == 0.0f) bits |= 2;
+                    if (r2 != r2) bits |= 4;
+                    m2 = pdp_max(m2, (r2 - 0.0f) + 1.0f);
+                }
             }
         }
         // ---- P5: one fused workgroup reduction (two NaN-propagating maxima + flag bits) -----------------------------------
@@ -589,13 +697,14 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
         m1 = -PDP_INF; m2 = -PDP_INF; bits = 0;
         for (int i = 0; i < nw; ++i) { m1 = pdp_max(m1, redf[i]); m2 = pdp_max(m2, redf[16 + i]); bits |= redi[i]; }
         __syncthreads();
+        m1 = uni_f(m1); m2 = uni_f(m2); bits = UNI(bits);          // workgroup-uniform: keep the control flow scalar
         if (other_rows) { m1 = pdp_max(m1, 0.0f); m2 = pdp_max(m2, 0.0f); }
         const float g = (m1 + 0.0f) - 1.0f, dmax = (m2 + 0.0f) - 1.0f;
         const int z1 = bits & 1, z2 = (bits >> 1) & 1;
         nan_seen = (bits >> 2) & 1;
         if (nan_seen && !poisoned) {
             if (tid == 0) atomicMin(sp.nan_iter, (uint32_t)t);
-            if (sp.poison_from != 0x7fffffff) violation = 1;
+            if (poison_from != 0x7fffffff) violation = 1;
         }
         int conv = 0;
         if (!poisoned) {
@@ -603,62 +712,32 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
             // instances with an event at or after the poison iteration have to be replayed
             if (g <= 1e-10f) { active = 0; last_event = t; }
             if (has_prev) {
-                if (dmax < sp.tol) { cnt = 0.0f; last_event = t; }
-                conv = (dmax < sp.tol) ? 1 : 0;
-                if (cnt >= sp.t_max) { conv = 1; cnt = 0.0f; }
+                if (dmax < tol) { cnt = 0.0f; last_event = t; }
+                conv = (dmax < tol) ? 1 : 0;
+                if (cnt >= t_max) { conv = 1; cnt = 0.0f; }
                 if (conv) last_event = t;
             }
         } else if (has_prev) {
-            if (cnt >= sp.t_max) { conv = 1; cnt = 0.0f; }
+            if (cnt >= t_max) { conv = 1; cnt = 0.0f; }
         }
         uint32_t used = 1u | (has_prev ? 2u : 0u);
         uint32_t zero = (z1 ? 1u : 0u) | ((has_prev && z2) ? 2u : 0u);
         if (has_prev && !conv && n > 0) zero |= 4u;
-        // ---- P6: decimation (rare) -------------------------------------------------------------------------------------------
+        // ---- P6: decimation (rare, out of line) ------------------------------------------------------------------------------
         int decimated = 0;
         if (has_prev && conv && !poisoned && !nan_seen) {
-            for (int p = tid; p < ne; p += nt)
-                Y[p] = pdp_safe_log(1.0f - Enew[p], PDP_SCORER_EPS) * (0.0f + af[pcc[p] & 0x3fff]);
-            __syncthreads();
-            int z3 = 0, anynz = 0, cn = 0;
-            for (int v = tid; v < n; v += nt) {
-                float ext = 0.0f, pos = 0.0f, neg = 0.0f, all = 0.0f;
-                for (int p = v_ptr[v]; p < v_ptr[v + 1]; ++p) {
-                    const float f = Y[p];
-                    const bool ng = (pvv[p] & 0x8000) != 0;
-                    ext = ext + (FORCE ? FRC[p] : 0.0f);
-                    pos = pos + (ng ? 0.0f : 1.0f) * f;
-                    neg = neg + (ng ? 1.0f : 0.0f) * f;
-                    all = all + f;
-                }
-                const float sc = d_score_from_sums(pos, neg, all, ext, sp.pi);
-                const float co = (pdp_abs(sc) * av[v]) * 1.0f;
-                score[v] = sc; coeff[v] = co;
-                if (co == 0.0f) z3 = 1;
-                if (co != 0.0f) anynz = 1;
-                if (co != co) cn = 1;
-            }
-            __syncthreads();
-            z3 = __syncthreads_or(z3); anynz = __syncthreads_or(anynz); cn = __syncthreads_or(cn);
-            if (cn) violation = 1;
-            used |= 4u; if (z3) zero |= 4u;
-            const int li = d_instance_argmax(I, coeff, 0.0f, redf, redi);
-            if (active && anynz && !cn && li >= 0) {
-                const float sgn_li = pdp_sign(score[li]);
-                __syncthreads();
-                for (int v = tid; v < n; v += nt) assign[v] = 0.0f;
-                __syncthreads();
-                if (tid == 0) assign[li] = sgn_li;
-                __syncthreads();
-                d_set_variable_core(I, ss);
-                d_simplify(I, ss, pv_.is_sat + G.b);
-                decimated = 1;
-            }
+            int spec_bits = 0;
+            decimated = UNI(lds_decimate<FORCE>(smem, G.b, n, m, ne, cur, active, pi, pv_.is_sat + G.b, &spec_bits));
+            spec_bits = UNI(spec_bits);
+            used |= 4u;
+            if (spec_bits & 1) zero |= 4u;
+            if (spec_bits & 2) violation = 1;
         }
         if (has_prev) cnt = cnt + 1.0f;
         if (tid == 0 && !poisoned) { atomicOr(&sp.spec_used[t], used); if (zero) atomicOr(&sp.spec_zero[t], zero); }
         // ---- P7: edge-mask refresh (only changes after a decimation) ------------------------------------------------------
         if (decimated || !use_em) {
+            const float *const av = L.av, *const af = L.af;
             for (int p = tid; p < ne; p += nt) {
                 const uint16_t cw = pcc[p];
                 const float a = 0.0f + av[pvv[p] & 0x3fff];
@@ -671,7 +750,7 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
         }
         // ---- P8: termination check ---------------------------------------------------------------------------------------------
         if (sp.check_termination) {
-            if (decimated || nsat < 0) nsat = d_cnf_sat_count(I, sol, redi);
+            if (decimated || nsat < 0) nsat = UNI(lds_cnf_count<FORCE>(smem, G.b, n, m, ne));
             if (active && nsat == m) active = 0;
         }
         has_prev = 1; prev_from_global = 0; cur ^= 1;
@@ -679,7 +758,10 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
 
     // ---- write back ------------------------------------------------------------------------------------------------------------
     {
-        float *Efin = cur ? EB : EA, *Eprev = cur ? EA : EB;       // after the toggle: final surveys / the ones the last sweep read
+        float *gq = sp.q + 3 * (size_t)G.e0;
+        float *gfs = sp.fs + 2 * (size_t)G.e0;
+        const float *sq = sp.src_q + 3 * (size_t)G.e0, *sfs = sp.src_fs + 2 * (size_t)G.e0;
+        float *Efin = cur ? L.EB : L.EA, *Eprev = cur ? L.EA : L.EB;       // after the toggle: final surveys / the ones the last sweep read
         for (int p = tid; p < ne; p += nt) {
             const int e = G.v_edges[p];
             const uint16_t pw = pvv[p], cw = pcc[p];
@@ -688,8 +770,8 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
                 const float s = (pw & 0x8000) ? -1.0f : 1.0f;
                 float y = pdp_safe_log(1.0f - Eprev[p], PDP_SP_EPS);
                 if (last_use_em) y = y * ((cw & PC_EM_USED) ? 1.0f : 0.0f);
-                const float force = FORCE ? FRC[p] : 0.0f;
-                const float pos = 0.0f + Pv[v], neg = 0.0f + Nv[v];
+                const float force = FORCE ? L.FRC[p] : 0.0f;
+                const float pos = 0.0f + L.Pv[v], neg = 0.0f + L.Nv[v];
                 float same = (0.5f * (1.0f + s)) * pos + (0.5f * (1.0f - s)) * neg;
                 same = same - y;
                 same = same + ((force == s) ? L1 : L0);
@@ -714,10 +796,10 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
             if (use_em || sp.inst_list) G.emask[e] = (cw & PC_EM) ? 1.0f : 0.0f;
         }
     }
-    for (int v = tid; v < n; v += nt) { G.av[v] = av[v]; G.sol[v] = sol[v]; }
-    for (int c = tid; c < m; c += nt) G.af[c] = af[c];
+    for (int v = tid; v < n; v += nt) { G.av[v] = L.av[v]; G.sol[v] = L.sol[v]; }
+    for (int c = tid; c < m; c += nt) G.af[c] = L.af[c];
     int any_inactive = 0;
-    for (int v = tid; v < n; v += nt) any_inactive |= (av[v] == 0.0f) ? 1 : 0;
+    for (int v = tid; v < n; v += nt) any_inactive |= (L.av[v] == 0.0f) ? 1 : 0;
     any_inactive = __syncthreads_or(any_inactive);
     if (tid == 0) {
         if (any_inactive) atomicMin(&pv_.flags[FL_PERM_ZERO], (uint32_t)iters);
