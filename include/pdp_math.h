@@ -165,6 +165,81 @@ PDP_HD float pdp_tanhf(float x)
     return x < 0.0f ? -r : r;
 }
 
+/* ---- lean variants for hot loops --------------------------------------------------------------
+ * Same results as the general functions on their stated domain (checked bit for bit by the tests);
+ * they only drop selects for inputs the caller rules out. */
+/* torch.max(a, c) / torch.min(a, c) for a constant c that is not NaN: NaN in a propagates */
+PDP_HD float pdp_max_c(float a, float c) { return (a < c) ? c : a; }
+PDP_HD float pdp_min_c(float a, float c) { return (a > c) ? c : a; }
+
+/* p * 2^n, correctly rounded also into the denormal range (|n| <= 160) */
+PDP_HD float pdp_scale2(float p, int n)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_ldexpf(p, n);                          /* v_ldexp_f32: one correctly rounded instruction */
+#else
+    const int n1 = n >> 1, n2 = n - n1;
+    return (p * pdp_pow2i(n1)) * pdp_pow2i(n2);
+#endif
+}
+
+/* e^x for x <= 30 or NaN (the argument of safe_exp after its clamp) */
+PDP_HD float pdp_expf_le30(float x)
+{
+    const float xc = (x < -104.5f) ? -104.5f : x;          /* NaN stays NaN and is returned unchanged below */
+    const float t = xc * 1.44269504088896341f;
+    const float nf = (t + 12582912.0f) - 12582912.0f;
+    float r = fmaf(nf, -0.693359375f, xc);
+    r = fmaf(nf, 2.12194440e-4f, r);
+    const float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    p = fmaf(p, z, r);
+    p = p + 1.0f;
+    float res = pdp_scale2(p, (x != x) ? 0 : (int)nf);
+    res = (x < -104.0f) ? 0.0f : res;
+    return (x != x) ? x : res;
+}
+
+/* log(x) for finite x > 0 (denormals included) or NaN */
+PDP_HD float pdp_logf_pos(float x)
+{
+    const uint32_t u0 = pdp_f2bits(x);
+    const int den = u0 < 0x00800000u;
+    const float xn = x * (den ? 8388608.0f : 1.0f);
+    const uint32_t u = pdp_f2bits(xn);
+    int e = (den ? -23 : 0) + (int)(u >> 23) - 126;
+    float m = pdp_bits2f((u & 0x007fffffu) | 0x3f000000u);
+    const int lt = m < 0.707106781186547524f;
+    e = e - lt;
+    m = (lt ? (m + m) : m) - 1.0f;
+    const float z = m * m;
+    float y = 7.0376836292e-2f;
+    y = fmaf(y, m, -1.1514610310e-1f);
+    y = fmaf(y, m, 1.1676998740e-1f);
+    y = fmaf(y, m, -1.2420140846e-1f);
+    y = fmaf(y, m, 1.4249322787e-1f);
+    y = fmaf(y, m, -1.6668057665e-1f);
+    y = fmaf(y, m, 2.0000714765e-1f);
+    y = fmaf(y, m, -2.4999993993e-1f);
+    y = fmaf(y, m, 3.3333331174e-1f);
+    y = (y * m) * z;
+    const float fe = (float)e;
+    y = fmaf(fe, -2.12194440e-4f, y);
+    y = fmaf(-0.5f, z, y);
+    float r = m + y;
+    r = fmaf(fe, 0.693359375f, r);
+    return (x != x) ? x : r;
+}
+/* safe_log for a finite-or-NaN argument (eps > 0 makes the log argument positive) */
+PDP_HD float pdp_safe_log_fin(float x, float eps) { return pdp_logf_pos(pdp_max_c(x, eps)); }
+/* safe_exp with the lean pieces (valid for every input: the clamp bounds the argument) */
+PDP_HD float pdp_safe_exp_fast(float x) { return pdp_expf_le30(pdp_min_c(x, 30.0f)); }
+
 /* ---- the reference's clamped forms ------------------------------------------------------- */
 /* safe_log(x) = log(max(x, eps))  (reference: pdp_propagate.py:133-134, pdp_predict.py:149-150) */
 PDP_HD float pdp_safe_log(float x, float eps) { return pdp_logf(pdp_max(x, eps)); }

@@ -972,6 +972,9 @@ ORC_API void orc_math_apply(int fn, const float *x, float *y, int64_t n)
         case 6: y[i] = pdp_safe_log(x[i], PDP_SP_EPS); break;
         case 7: y[i] = pdp_philox_uniform(0x1234abcdULL, 2u, 7u, (uint32_t)i); break;
         case 8: y[i] = 1.0f / x[i]; break;
+        case 9: y[i] = pdp_safe_exp_fast(x[i]); break;
+        case 10: y[i] = pdp_safe_log_fin(x[i], PDP_SP_EPS); break;
+        case 11: y[i] = pdp_safe_log_fin(x[i], PDP_SCORER_EPS); break;
         default: y[i] = x[i];
         }
     }

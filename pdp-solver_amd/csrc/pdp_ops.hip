@@ -658,6 +658,9 @@ __global__ void k_math_apply(int fn, const float *x, float *y, int64_t n)
         case 6: r = pdp_safe_log(x[i], PDP_SP_EPS); break;
         case 7: r = pdp_philox_uniform(0x1234abcdULL, 2u, 7u, (uint32_t)i); break;
         case 8: r = 1.0f / x[i]; break;
+        case 9: r = pdp_safe_exp_fast(x[i]); break;
+        case 10: r = pdp_safe_log_fin(x[i], PDP_SP_EPS); break;
+        case 11: r = pdp_safe_log_fin(x[i], PDP_SCORER_EPS); break;
         default: r = x[i];
         }
         y[i] = r;

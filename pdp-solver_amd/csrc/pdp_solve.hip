@@ -44,6 +44,7 @@ struct SolveParams {
     int has_prev;
     int check_termination;
     int has_edge_mask;          // problem->has_edge_mask at entry
+    int final_chunk;            // this launch ends the loop: rebuild q_s / q_dc for instances that are still active
     int poison_from;            // first iteration at which the batch is NaN-poisoned (INT_MAX: never); pass 2 only
     const int32_t *inst_list;   // replay pass: instances to run (grid = list length); NULL: instance = blockIdx.x
     int32_t *last_event;        // [B] pass 1: last iteration with a gate / convergence event (-1: none)
@@ -427,6 +428,20 @@ __device__ __forceinline__ LView make_lview(const LdsArrays &L, int b, int n, in
     return I;
 }
 #define UNI(x) __builtin_amdgcn_readfirstlane(x)
+#ifdef PDP_PHASE_PROF
+__device__ unsigned long long g_phase_cycles[16];
+#define PROF_DECL unsigned long long _t0 = __builtin_readcyclecounter(), _t1;
+#define PROF_MARK(i) do { _t1 = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_phase_cycles[i], _t1 - _t0); _t0 = _t1; } while (0)
+extern "C" int pdp_debug_phase_cycles(unsigned long long *out_host, int reset)
+{
+    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#else
+#define PROF_DECL
+#define PROF_MARK(i)
+#endif
 __device__ __forceinline__ float uni_f(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
 
 // P6, cold: SurveyScorer + arg-max + set_variables (pdp_decimate.py:152-171).  Returns 1 if a variable was fixed;
@@ -540,6 +555,8 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
     // log(max(1 - pi * [force == +-s], eps)): two possible values per kernel (pdp_propagate.py:197,201)
     const float L0 = pdp_safe_log(1.0f - pi * 0.0f, PDP_SP_EPS), L1 = pdp_safe_log(1.0f - pi * 1.0f, PDP_SP_EPS);
 
+    PROF_DECL
+    PROF_MARK(0);                                            // load
     for (int t = 0; t < T; ++t) {
         if (!active) break;
         const bool poisoned = t >= poison_from;
@@ -547,8 +564,8 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
         float *const Eold = cur ? L.EB : L.EA, *const Enew = cur ? L.EA : L.EB;
         // ---- E1: per-slot logs -------------------------------------------------------------------------------------
         for (int p = tid; p < ne; p += nt) {
-            float x = pdp_safe_log(QU[p], PDP_SP_EPS);
-            float y = pdp_safe_log(1.0f - Eold[p], PDP_SP_EPS);
+            float x = pdp_safe_log_fin(QU[p], PDP_SP_EPS);
+            float y = pdp_safe_log_fin(1.0f - Eold[p], PDP_SP_EPS);
             if (use_em) {
                 uint16_t c = pcc[p];
                 const float em = (c & PC_EM) ? 1.0f : 0.0f;
@@ -559,6 +576,7 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
         }
         last_use_em = use_em; em_dirty = 0;
         __syncthreads();
+        PROF_MARK(1);                                        // E1
         // ---- R1: per-clause sums (through e2p) and per-variable sums (contiguous), ascending edge id ------------
         {
             const uint16_t *const e2p = L.e2p, *const f_ptr = L.f_ptr, *const v_ptr = L.v_ptr;
@@ -596,6 +614,7 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
             }
         }
         __syncthreads();
+        PROF_MARK(2);                                        // R1
         // ---- E2: new survey, new q_u, smooth-max weights -----------------------------------------------------------
         int nan_seen = 0;
         {
@@ -606,7 +625,7 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
                 const float s = (pw & 0x8000) ? -1.0f : 1.0f;
                 const float eta_old = Eold[p];
                 const float agg = (0.0f + S[c]) - X[p];
-                const float eta_new = 1.0f * pdp_safe_exp(agg) + (1.0f - 1.0f) * eta_old;
+                const float eta_new = 1.0f * pdp_safe_exp_fast(agg) + (1.0f - 1.0f) * eta_old;
                 const float force = FORCE ? L.FRC[p] : 0.0f;
                 const float pos = 0.0f + Pv[v], neg = 0.0f + Nv[v];
                 float same = (0.5f * (1.0f + s)) * pos + (0.5f * (1.0f - s)) * neg;
@@ -614,77 +633,77 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
                 same = same + ((force == s) ? L1 : L0);
                 float opp = (0.5f * (1.0f - s)) * pos + (0.5f * (1.0f + s)) * neg;
                 opp = opp + ((force == -s) ? L1 : L0);
-                const float dc = pdp_safe_exp(same + opp);
-                const float A = pdp_safe_exp(same), Bv = pdp_safe_exp(opp);
+                const float dc = pdp_safe_exp_fast(same + opp);
+                const float A = pdp_safe_exp_fast(same), Bv = pdp_safe_exp_fast(opp);
                 const float qu = A * (1.0f - Bv), qs = Bv * (1.0f - A);
                 const float total = (qu + qs) + dc;
                 const float qu_new = 1.0f * (qu / total) + (1.0f - 1.0f) * QU[p];
                 if (eta_new != eta_new) nan_seen = 1;
                 QU[p] = qu_new;
                 Enew[p] = eta_new;
-                X[p] = pdp_safe_exp(30.0f * eta_new);
+                X[p] = pdp_safe_exp_fast(30.0f * eta_new);
                 if (has_prev) {
                     const float pe = prev_from_global ? sp.src_prev[G.e0 + G.v_edges[p]] : eta_old;
                     float d = pdp_abs(pe - eta_new);
                     if (use_em) d = d * ((cw & PC_EM) ? 1.0f : 0.0f);
-                    Y[p] = pdp_safe_exp(30.0f * d);
+                    Y[p] = pdp_safe_exp_fast(30.0f * d);
                 }
             }
         }
         did_prop = 1;
         __syncthreads();
-        // ---- P4: per-variable smooth maxima, partial reductions in registers --------------------------------------------
+        PROF_MARK(3);                                        // E2
+        // ---- P4: per-variable smooth maxima (two rows per variable: survey / difference), partial reductions in registers
         float m1 = -PDP_INF, m2 = -PDP_INF;
         int bits = nan_seen ? 4 : 0;                       // bit0: xv1 has an exact 0, bit1: xv2 has one, bit2: NaN
         {
             const uint16_t *const v_ptr = L.v_ptr;
             const float *const av = L.av;
-            for (int v = tid; v < n; v += nt) {
-                float num1 = 0.0f, den1 = 0.0f, num2 = 0.0f, den2 = 0.0f;
+            const int rows = has_prev ? 2 * n : n;
+            for (int r = tid; r < rows; r += nt) {
+                const bool second = r >= n;
+                const int v = second ? r - n : r;
+                float num = 0.0f, den = 0.0f;
                 const int a = v_ptr[v], bnd = v_ptr[v + 1];
-                if (has_prev && !prev_from_global) {
+                if (!second) {
+                    int p = a;
+                    for (; p + 3 < bnd; p += 4) {
+                        const float c0 = X[p], c1 = X[p + 1], c2 = X[p + 2], c3 = X[p + 3];
+                        const float e0 = Enew[p], e1 = Enew[p + 1], e2 = Enew[p + 2], e3 = Enew[p + 3];
+                        num = num + e0 * c0; den = den + c0; num = num + e1 * c1; den = den + c1;
+                        num = num + e2 * c2; den = den + c2; num = num + e3 * c3; den = den + c3;
+                    }
+                    for (; p < bnd; ++p) { const float c0 = X[p]; num = num + Enew[p] * c0; den = den + c0; }
+                } else if (!prev_from_global) {
                     int p = a;
                     for (; p + 1 < bnd; p += 2) {
-                        const float c10 = X[p], c11 = X[p + 1], e0 = Enew[p], e1 = Enew[p + 1], o0 = Eold[p], o1 = Eold[p + 1];
-                        const float c20 = Y[p], c21 = Y[p + 1];
-                        const uint16_t w0 = pcc[p], w1 = pcc[p + 1];
-                        float d0 = pdp_abs(o0 - e0), d1 = pdp_abs(o1 - e1);
-                        if (use_em) { d0 = d0 * ((w0 & PC_EM) ? 1.0f : 0.0f); d1 = d1 * ((w1 & PC_EM) ? 1.0f : 0.0f); }
-                        num1 = num1 + e0 * c10; den1 = den1 + c10; num2 = num2 + d0 * c20; den2 = den2 + c20;
-                        num1 = num1 + e1 * c11; den1 = den1 + c11; num2 = num2 + d1 * c21; den2 = den2 + c21;
+                        const float c0 = Y[p], c1 = Y[p + 1];
+                        float d0 = pdp_abs(Eold[p] - Enew[p]), d1 = pdp_abs(Eold[p + 1] - Enew[p + 1]);
+                        if (use_em) { d0 = d0 * ((pcc[p] & PC_EM) ? 1.0f : 0.0f); d1 = d1 * ((pcc[p + 1] & PC_EM) ? 1.0f : 0.0f); }
+                        num = num + d0 * c0; den = den + c0; num = num + d1 * c1; den = den + c1;
                     }
                     for (; p < bnd; ++p) {
-                        const float c1 = X[p], et = Enew[p];
-                        float d = pdp_abs(Eold[p] - et);
+                        float d = pdp_abs(Eold[p] - Enew[p]);
                         if (use_em) d = d * ((pcc[p] & PC_EM) ? 1.0f : 0.0f);
-                        const float c2 = Y[p];
-                        num1 = num1 + et * c1; den1 = den1 + c1; num2 = num2 + d * c2; den2 = den2 + c2;
+                        const float c0 = Y[p];
+                        num = num + d * c0; den = den + c0;
                     }
                 } else {
                     for (int p = a; p < bnd; ++p) {
-                        const float c1 = X[p], et = Enew[p];
-                        num1 = num1 + et * c1; den1 = den1 + c1;
-                        if (has_prev) {
-                            float d = pdp_abs(sp.src_prev[G.e0 + G.v_edges[p]] - et);
-                            if (use_em) d = d * ((pcc[p] & PC_EM) ? 1.0f : 0.0f);
-                            const float c2 = Y[p];
-                            num2 = num2 + d * c2; den2 = den2 + c2;
-                        }
+                        float d = pdp_abs(sp.src_prev[G.e0 + G.v_edges[p]] - Enew[p]);
+                        if (use_em) d = d * ((pcc[p] & PC_EM) ? 1.0f : 0.0f);
+                        const float c0 = Y[p];
+                        num = num + d * c0; den = den + c0;
                     }
                 }
-                const float a_v = av[v];
-                const float r1 = (num1 / pdp_max(den1, 1.0f)) * a_v;
-                if (r1 == 0.0f) bits |= 1;
-                if (r1 != r1) bits |= 4;
-                m1 = pdp_max(m1, (r1 - 0.0f) + 1.0f);
-                if (has_prev) {
-                    const float r2 = (num2 / pdp_max(den2, 1.0f)) * a_v;
-                    if (r2 == 0.0f) bits |= 2;
-                    if (r2 != r2) bits |= 4;
-                    m2 = pdp_max(m2, (r2 - 0.0f) + 1.0f);
-                }
+                const float rr = (num / pdp_max_c(den, 1.0f)) * av[v];
+                const float tt = (rr - 0.0f) + 1.0f;
+                if (rr != rr) bits |= 4;
+                if (!second) { if (rr == 0.0f) bits |= 1; m1 = pdp_max(m1, tt); }
+                else { if (rr == 0.0f) bits |= 2; m2 = pdp_max(m2, tt); }
             }
         }
+        PROF_MARK(4);                                        // P4
         // ---- P5: one fused workgroup reduction (two NaN-propagating maxima + flag bits) -----------------------------------
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -698,6 +717,7 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
         for (int i = 0; i < nw; ++i) { m1 = pdp_max(m1, redf[i]); m2 = pdp_max(m2, redf[16 + i]); bits |= redi[i]; }
         __syncthreads();
         m1 = uni_f(m1); m2 = uni_f(m2); bits = UNI(bits);          // workgroup-uniform: keep the control flow scalar
+        PROF_MARK(5);                                        // P5
         if (other_rows) { m1 = pdp_max(m1, 0.0f); m2 = pdp_max(m2, 0.0f); }
         const float g = (m1 + 0.0f) - 1.0f, dmax = (m2 + 0.0f) - 1.0f;
         const int z1 = bits & 1, z2 = (bits >> 1) & 1;
@@ -733,6 +753,7 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
             if (spec_bits & 1) zero |= 4u;
             if (spec_bits & 2) violation = 1;
         }
+        PROF_MARK(6);                                        // P6 decimation
         if (has_prev) cnt = cnt + 1.0f;
         if (tid == 0 && !poisoned) { atomicOr(&sp.spec_used[t], used); if (zero) atomicOr(&sp.spec_zero[t], zero); }
         // ---- P7: edge-mask refresh (only changes after a decimation) ------------------------------------------------------
@@ -754,6 +775,7 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
             if (active && nsat == m) active = 0;
         }
         has_prev = 1; prev_from_global = 0; cur ^= 1;
+        PROF_MARK(7);                                        // P7 + P8
     }
 
     // ---- write back ------------------------------------------------------------------------------------------------------------
@@ -765,10 +787,10 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
         for (int p = tid; p < ne; p += nt) {
             const int e = G.v_edges[p];
             const uint16_t pw = pvv[p], cw = pcc[p];
-            if (did_prop) {
+            if (did_prop && (sp.final_chunk || !active)) {
                 const int v = pw & 0x3fff;
                 const float s = (pw & 0x8000) ? -1.0f : 1.0f;
-                float y = pdp_safe_log(1.0f - Eprev[p], PDP_SP_EPS);
+                float y = pdp_safe_log_fin(1.0f - Eprev[p], PDP_SP_EPS);
                 if (last_use_em) y = y * ((cw & PC_EM_USED) ? 1.0f : 0.0f);
                 const float force = FORCE ? L.FRC[p] : 0.0f;
                 const float pos = 0.0f + L.Pv[v], neg = 0.0f + L.Nv[v];
@@ -777,8 +799,8 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
                 same = same + ((force == s) ? L1 : L0);
                 float opp = (0.5f * (1.0f - s)) * pos + (0.5f * (1.0f + s)) * neg;
                 opp = opp + ((force == -s) ? L1 : L0);
-                const float dc = pdp_safe_exp(same + opp);
-                const float A = pdp_safe_exp(same), Bv = pdp_safe_exp(opp);
+                const float dc = pdp_safe_exp_fast(same + opp);
+                const float A = pdp_safe_exp_fast(same), Bv = pdp_safe_exp_fast(opp);
                 const float qu = A * (1.0f - Bv), qs = Bv * (1.0f - A);
                 const float total = (qu + qs) + dc;
                 // (1 - mask) * old keeps a NaN forever; the three columns of q turn NaN together, so q_u carries the stickiness
@@ -788,6 +810,9 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
                 gq[3 * e + 2] = 1.0f * (dc / total) + (1.0f - 1.0f) * sticky;
                 gfs[2 * e] = Efin[p];
                 sp.prev[G.e0 + e] = Efin[p];
+            }
+            else if (did_prop) {              // the loop continues in the next chunk: q_s / q_dc are rebuilt by the last one
+                gq[3 * e] = QU[p]; gfs[2 * e] = Efin[p]; sp.prev[G.e0 + e] = Efin[p];
             }
             else if (sp.inst_list) {          // replayed instance that did not run: restore its pre-pass-1 messages
                 gq[3 * e] = sq[3 * e]; gq[3 * e + 1] = sq[3 * e + 1]; gq[3 * e + 2] = sq[3 * e + 2];
@@ -801,6 +826,7 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
     int any_inactive = 0;
     for (int v = tid; v < n; v += nt) any_inactive |= (L.av[v] == 0.0f) ? 1 : 0;
     any_inactive = __syncthreads_or(any_inactive);
+    PROF_MARK(8);                                            // write back
     if (tid == 0) {
         if (any_inactive) atomicMin(&pv_.flags[FL_PERM_ZERO], (uint32_t)iters);
         sp.amask[G.b] = (uint8_t)active;
@@ -953,6 +979,7 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
     while (status == PDP_OK && ok && done < T) {
         const int c = (T - done) < C ? (T - done) : C;
         sp.T = c; sp.has_prev = a->decimator->has_prev; sp.has_edge_mask = p->has_edge_mask;
+        sp.final_chunk = (done + c >= T) ? 1 : 0;
         set_src_live();
         int poison_from = poisoned_all ? 0 : 0x7fffffff;
         uint32_t n_replayed = 0;

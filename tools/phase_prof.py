@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Debug helper: per-phase shader-cycle sums of the persistent solver (needs a -DPDP_PHASE_PROF build)."""
+import ctypes as C, os, sys, subprocess
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, 'pdp-solver_amd'))
+import torch
+from pdp import native
+from pdp.factorgraph import dataset
+B, n, T = int(sys.argv[1]) if len(sys.argv) > 1 else 5000, 200, 100
+dev = torch.device('cuda:0')
+b = dataset.to_torch(dataset.collate_segment(dataset.random_ksat_items(B, n, 3, seed=0)), dev)
+prob = native.Problem(b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'])
+L = native.lib()
+out = (C.c_ulonglong * 16)()
+for rep in range(2):
+    native.check(L.pdp_problem_bind_state(prob._h, native.ptr(prob.active_variables), native.ptr(prob.active_functions), native.ptr(prob.solution), native.ptr(prob.is_sat), native.ptr(prob.edge_mask), native._stream()))
+    q = torch.full((prob.E, 3), 1.0, device=dev) / 3.0; fs = torch.zeros(prob.E, 2, device=dev); fs[:, 0] = 0.5
+    am = torch.ones(prob.B, dtype=torch.uint8, device=dev); dec = native.Decimator(prob)
+    prob.simplify(); torch.cuda.synchronize()
+    L.pdp_debug_phase_cycles(out, 1)
+    it, lds = prob.sp_solve(q, fs, am, dec, T, 0.02, 100)
+    torch.cuda.synchronize()
+    L.pdp_debug_phase_cycles(out, 0)
+names = ['load', 'E1 logs', 'R1 row sums', 'E2 exps/div', 'P4 smooth max', 'P5 reduce', 'P6 decimate', 'P7+P8', 'write back']
+tot = sum(out[i] for i in range(9))
+for i, nm in enumerate(names):
+    print("%-16s %14d cycles  %5.1f%%" % (nm, out[i], 100.0 * out[i] / tot))
+print("total WG-cycles %d" % tot)
