@@ -1,0 +1,79 @@
+"""Instance-sharded data parallelism: one process per GPU, no collective on the data path.
+
+The reference has no working multi-GPU path (``nn.DataParallel`` would scatter ``graph_map`` along dim 0, SURVEY.md
+App. B-13).  Every PDP computation is local to one CNF instance, so a batch shards by instances: each rank solves a
+contiguous range of instances (balanced by edge count) completely on its own GPU and the ranks meet exactly once, in
+an all-reduce(sum) of ``[instances, solved, unsat clauses]`` (RCCL over xGMI on a node: ``backend='nccl'``; the tests use
+``gloo`` on CPU).  Result rows are gathered in rank order by the caller if it wants them.
+"""
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(edge_counts, world_size):
+    """Contiguous instance ranges [lo, hi) per rank, balanced by the cumulative edge count.
+
+    Every rank gets at least one instance while instances remain; ranges are contiguous so replicas / result
+    order stay rank-major."""
+    edge_counts = np.asarray(edge_counts, dtype=np.int64)
+    n = int(edge_counts.size)
+    world_size = int(world_size)
+    if n == 0:
+        return [(0, 0)] * world_size
+    csum = np.cumsum(edge_counts)
+    total = int(csum[-1])
+    bounds, lo = [], 0
+    for r in range(world_size):
+        if r == world_size - 1:
+            hi = n
+        else:
+            target = total * (r + 1) / float(world_size)
+            hi = int(np.searchsorted(csum, target, side='left')) + 1
+            hi = max(hi, lo + (1 if lo < n else 0))
+            hi = min(hi, n - min(n - hi, world_size - 1 - r) if n - hi < world_size - 1 - r else hi)
+            hi = min(hi, n)
+        bounds.append((lo, hi))
+        lo = hi
+    return bounds
+
+
+def shard_items(items, rank, world_size):
+    "the loader items (dataset.parse_line tuples) this rank owns"
+    lo, hi = shard_bounds([it[2].shape[1] for it in items], world_size)[rank]
+    return items[lo:hi], lo
+
+
+def reduce_stats(n_instances, n_solved, n_unsat_clauses, device=None, group=None):
+    """The single collective of the path: all-reduce(sum) of three counters.  Works without an initialised process
+    group (world size 1)."""
+    t = torch.tensor([float(n_instances), float(n_solved), float(n_unsat_clauses)], dtype=torch.float64,
+                     device=device if device is not None else 'cpu')
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    n, s, u = [float(x) for x in t.tolist()]
+    return dict(instances=int(n), solved=int(s), unsat_clauses=int(u), solved_fraction=(s / n if n else 0.0))
+
+
+def gather_rows(rows, group=None):
+    "rank-ordered list of every rank's result rows (python objects; host side only)"
+    if not (dist.is_available() and dist.is_initialized()):
+        return list(rows)
+    world = dist.get_world_size(group)
+    out = [None] * world
+    dist.all_gather_object(out, list(rows), group=group)
+    return [r for part in out for r in part]
+
+
+def solve_sharded(items, solve_fn, rank=None, world_size=None, device=None):
+    """Run ``solve_fn(list_of_items) -> (solved [b] array-like, unsat [b] array-like, rows list)`` on this rank's shard and
+    reduce the counters.  ``solve_fn`` is the native forward in production and the CPU oracle in the gloo tests."""
+    if world_size is None:
+        world_size = dist.get_world_size() if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    mine, offset = shard_items(items, rank, world_size)
+    solved, unsat, rows = solve_fn(mine) if len(mine) else ([], [], [])
+    stats = reduce_stats(len(mine), float(np.sum(solved)), float(np.sum(unsat)), device=device)
+    return stats, gather_rows(rows), offset

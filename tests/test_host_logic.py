@@ -1,0 +1,106 @@
+"""CPU tests (no GPU): loader layout vs the reference's golden tensors, DIMACS converter vs the reference's output,
+dynamic batch divider, C-ABI library loads and exports every declared symbol, product code never touches oracle/."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import REPO, load_golden
+from pdp import generator
+from pdp.factorgraph import dataset
+
+
+@pytest.mark.parametrize('jsonl,npz', [('mixed_batch.jsonl', 'problem_simplify'), ('sat50_batch.jsonl', 'trace_pdp_n50'),
+                                       ('neural_batch.jsonl', 'trace_neural_h32')])
+def test_collate_equals_reference_loader(jsonl, npz):
+    """dataset.parse_line + collate_segment must produce exactly the tensors the reference loader produced
+    (captured in the golden files by running FactorGraphDataset._convert_line / dag_collate_fn)."""
+    lines = [l for l in open(os.path.join(REPO, 'tests', 'golden', jsonl)).read().split('\n') if l.strip()]
+    b = dataset.collate_segment([dataset.parse_line(l) for l in lines])
+    d = load_golden(npz)
+    np.testing.assert_array_equal(b['graph_map'], d['graph_map'])
+    np.testing.assert_array_equal(b['batch_variable_map'], d['batch_variable_map'])
+    np.testing.assert_array_equal(b['batch_function_map'], d['batch_function_map'])
+    np.testing.assert_array_equal(b['edge_feature'], d['edge_feature'])
+    assert b['graph_map'].dtype == np.int32 and b['edge_feature'].dtype == np.float32 and b['edge_feature'].shape[1] == 1
+
+
+def test_dimacs_converter_equals_reference(tmp_path):
+    import dimacs2json
+    out = tmp_path / 'conv.jsonl'
+    dimacs2json.convert_directory(os.path.join(REPO, 'tests', 'golden', 'dimacs20'), str(out))
+    got = sorted(l for l in out.read_text().split('\n') if l)
+    ref = sorted(l for l in open(os.path.join(REPO, 'tests', 'golden', 'cli_dimacs20.converted.jsonl')).read().split('\n') if l)
+    assert got == ref
+    # file mode: label from the 8th character from the end (reference: dimacs2json.py:118-122)
+    src = os.path.join(REPO, 'tests', 'golden', 'dimacs20', 'uf_03_1.cnf')
+    dimacs2json.convert_file(src, str(out))
+    row = json.loads(out.read_text())
+    assert row[4] == ['uf_03_1.cnf'] and row[3] == 0.0      # '...uf_03_1.cnf'[-8] == '0'
+
+
+def test_converter_edge_cases(tmp_path):
+    """duplicate literal (last sign wins), empty clause dropped, unused variables compacted, comment / blank lines"""
+    import dimacs2json
+    p = tmp_path / 'x_1.cnf'
+    p.write_text("c comment\np cnf 6 5\n1 -1 3 0\n\n0\n5 -6 0\n-3 0\nc trailing\n3 5 6 0\n")
+    out = tmp_path / 'o.jsonl'
+    dimacs2json.convert_directory(str(tmp_path), str(out))
+    row = json.loads(out.read_text().strip())
+    assert row[0] == [4, 4]                      # variables {1,3,5,6} -> 1..4, the empty clause is gone
+    assert row[1] == [-1, 2, 3, -4, -2, 2, 3, 4] and row[2] == [1, 1, 2, 2, 3, 4, 4, 4]
+    assert row[3] == 1.0 and row[4] == ['x_1.cnf']
+
+
+def test_generator_compaction_consistency():
+    rng = np.random.RandomState(3)
+    variables, signs = generator.uniform_ksat_arrays(30, 100, 3, rng)
+    vn, fn, gm, ef = generator.compact_arrays(30, variables, signs)
+    clauses = [[int((v + 1) * s) for v, s in zip(vs, ss)] for vs, ss in zip(variables, signs)]
+    it = dataset.instance_from_clauses(30, clauses)
+    assert (vn, fn) == (it[0], it[1])
+    np.testing.assert_array_equal(gm, it[2]); np.testing.assert_array_equal(ef, it[3])
+
+
+def test_dynamic_batch_divider():
+    edges = [30, 10, 50, 20, 40]
+    assert dataset.divide(edges, limit=10 ** 9, hidden_dim=3) == [[0, 1, 2, 3, 4]]
+    segs = dataset.divide(edges, limit=300, hidden_dim=3)      # 300 // (50*3) = 2 per segment for the largest
+    assert segs[0] == [2, 4] and sorted(sum(segs, [])) == [0, 1, 2, 3, 4]
+    assert dataset.divide([1000], limit=10, hidden_dim=3) == [[0]]   # larger than the limit: own segment, no infinite loop
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    """include/pdp_hip.h is the boundary: every function it declares must be exported by libpdp_hip.so."""
+    from pdp import native
+    header = open(os.path.join(REPO, 'include', 'pdp_hip.h')).read()
+    declared = set(re.findall(r'\b(pdp_[a-z0-9_]+)\s*\(', header))
+    declared -= {'pdp_solve_args'}
+    lib = native.lib()
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert set(native.EXPORTED_SYMBOLS) == declared
+    assert lib.pdp_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    from pdp import native
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(native.NativeError):
+        native.Problem(torch.zeros(2, 3, dtype=torch.int32), torch.zeros(3, dtype=torch.int32), torch.zeros(1, dtype=torch.int32),
+                       torch.ones(3, 1))
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for root, _, files in os.walk(os.path.join(REPO, 'pdp-solver_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.hpp', '.h', '.c', '.cpp')) or f == 'Makefile':
+                txt = open(os.path.join(root, f), errors='replace').read()
+                if re.search(r'(^|\s)(from|import)\s+oracle\b', txt) or 'oracle/' in txt.replace('under oracle/', ''):
+                    bad.append(os.path.join(root, f))
+    assert not bad, bad
