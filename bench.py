@@ -83,15 +83,18 @@ def main():
     # ---- synthetic batch, resident in HBM before the timed region ---------------------------------------------
     m = int(round(4.2 * args.n))
     items = dataset.random_ksat_items(args.batch, args.n, 3, m=m, seed=1000003 * rank)
-    b = dataset.to_torch(dataset.collate_segment(items), dev)
+    host_batch = dataset.collate_segment(items)
+    torch.cuda.synchronize(); t_setup = time.perf_counter()
+    b = dataset.to_torch(host_batch, dev)                      # PCIe upload of the loader tensors
     prob = native.Problem(b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'], batch_size=args.batch)
+    torch.cuda.synchronize(); setup_ms = 1e3 * (time.perf_counter() - t_setup)   # reported, never part of `value`
     E, V, F, B = prob.E, prob.V, prob.F, prob.B
     q = torch.empty(E, 3, device=dev); fs = torch.empty(E, 2, device=dev)
     am = torch.empty(B, dtype=torch.uint8, device=dev)
     dec = native.Decimator(prob)
     L = native.lib()
     ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
-    kernel_ms, iters_done, paths = [], [], []
+    kernel_ms, iters_done, paths, launches = [], [], [], []
 
     def step(record):
         # state reset = get_init_state(randomized=False) + a fresh SATProblem (solver.py:49-54, pdp_propagate.py:233-235)
@@ -109,7 +112,7 @@ def main():
         ev1.record()
         if record:
             torch.cuda.synchronize()
-            kernel_ms.append(ev0.elapsed_time(ev1)); iters_done.append(it); paths.append(path)
+            kernel_ms.append(ev0.elapsed_time(ev1)); iters_done.append(it); paths.append(path); launches.append(prob.last_solve_launches)
 
     def barrier():
         if world > 1:
@@ -143,16 +146,19 @@ def main():
 
     if rank == 0:
         value = iters_all / elapsed
-        kms = float(np.mean(kernel_ms))
+        kms = float(np.mean(kernel_ms))                 # HIP-event time of one pdp_sp_solve call (all its launches)
         it_mean = float(np.mean(iters_done))
-        bytes_launch = algorithmic_bytes_per_iteration(E, V, F) * it_mean
-        achieved = bytes_launch / (kms * 1e-3) / 1e9
+        n_launch = float(np.mean(launches))
+        # per kernel launch: algorithmic bytes = bytes/iteration x iterations per launch; duration = call time / launches
+        bytes_launch = algorithmic_bytes_per_iteration(E, V, F) * it_mean / n_launch
+        launch_ms = kms / n_launch
+        achieved = bytes_launch / (launch_ms * 1e-3) / 1e9
         # measured HBM traffic per launch (rocprofv3 PMC passes, corrected as MI355X_MICROARCH.md prescribes), if profiled
         traffic = None
-        pmc = os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')
+        pmc = os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')   # written by tools/summarize_profile.py
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get('k_sp_solve_bytes_per_launch')
+                traffic = json.load(open(pmc)).get('k_sp_solve_lds_bytes_per_launch')
             except Exception:
                 traffic = None
         line = {
@@ -163,10 +169,11 @@ def main():
             'config': {'workload': "configs[1]: 'p-d-p' survey propagation, random 3-SAT n=%d m=%d batch=%d T=%d per GPU" % (args.n, m, args.batch, args.iters),
                        'E': E, 'V': V, 'F': F, 'iterations_per_step': it_mean, 'path': paths[0] if paths else None,
                        'instance_iterations_per_sec': value * args.batch, 'edge_updates_per_sec': value * 2 * E,
-                       'kernel_ms_per_launch': kms, 'solved_fraction': n_solved / n_inst, 'unsat_clauses_total': n_unsat,
+                       'solve_call_ms': kms, 'kernel_launches_per_call': n_launch, 'kernel_ms_per_launch': launch_ms,
+                       'algorithmic_bytes_per_launch': bytes_launch, 'setup_ms_upload_and_layout': setup_ms, 'solved_fraction': n_solved / n_inst, 'unsat_clauses_total': n_unsat,
                        'walksat_steps': ws_steps, 'tolerance': args.tolerance, 't_max': args.t_max, 'parallelism': 'instances sharded, dp%d' % world},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'kernel': 'k_sp_solve<uint16_t,true>',
+                         'traffic': traffic, 'kernel': 'k_sp_solve_lds<false>',
                          'note': 'achieved = streaming-model algorithmic bytes (41E+36V+8F per iteration) x iterations per launch / '
                                  'launch duration; the instance state is LDS-resident so this may exceed the HBM peak'},
         }

@@ -157,6 +157,7 @@ typedef struct pdp_solve_args {
     int32_t check_termination;    /* 1: per-iteration CNF check de-activates solved instances */
     int32_t iterations_run_host;  /* out: executed iterations (max over instances) */
     int32_t used_lds_host;        /* out: 1 if the LDS-resident variant ran */
+    int32_t kernel_launches_host; /* out: solver kernel launches issued (chunks + poison replays) */
 } pdp_solve_args;
 int pdp_sp_solve(pdp_problem *p, pdp_solve_args *args, void *stream);
 

@@ -884,7 +884,7 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
     PDP_REQUIRE(p->R == 1, "persistent solve needs replication == 1 (replicas couple through the termination check)");
     hipStream_t st = ST(stream);
     const int T = a->iterations;
-    a->iterations_run_host = 0; a->used_lds_host = 0;
+    a->iterations_run_host = 0; a->used_lds_host = 0; a->kernel_launches_host = 0;
     if (T <= 0) return PDP_OK;
     const size_t E = p->E, V = p->V, F = p->F, B = p->B;
     // The loop runs in chunks of C iterations (one launch each; the kernel resumes from the HBM state).  Chunking bounds
@@ -996,6 +996,7 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
             PDP_HIP_CHECK(hipMemsetAsync(p->flags + FL_SPEC_VIOLATION, 0, sizeof(uint32_t) * (sp.inst_list ? 1 : 2), st));
             launch(sp.inst_list ? (int)n_replayed : p->B);
             PDP_LAUNCH_CHECK();
+            a->kernel_launches_host++;
             PDP_HIP_CHECK(hipMemcpyAsync(host, spec, words * 4, hipMemcpyDeviceToHost, st));
             PDP_HIP_CHECK(hipMemcpyAsync(p->flags_host, p->flags, FL_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             PDP_HIP_CHECK(hipStreamSynchronize(st));

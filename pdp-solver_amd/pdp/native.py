@@ -95,7 +95,7 @@ class SolveArgs(C.Structure):
                 ('pi', C.c_float), ('decimation_probability', C.c_float), ('seed', C.c_uint64),
                 ('coins', C.c_void_p), ('q', C.c_void_p), ('fs', C.c_void_p), ('active_mask', C.c_void_p),
                 ('decimator', C.c_void_p), ('check_termination', C.c_int32), ('iterations_run_host', C.c_int32),
-                ('used_lds_host', C.c_int32)]
+                ('used_lds_host', C.c_int32), ('kernel_launches_host', C.c_int32)]
 
 
 class Decimator(object):
@@ -298,6 +298,7 @@ class Problem(object):
         a.decimator = dec._h.value
         a.check_termination = 1 if check_termination else 0
         check(lib().pdp_sp_solve(self._h, C.byref(a), _stream()))
+        self.last_solve_launches = int(a.kernel_launches_host)
         return int(a.iterations_run_host), bool(a.used_lds_host)
 
 
