@@ -161,6 +161,35 @@ typedef struct pdp_solve_args {
 } pdp_solve_args;
 int pdp_sp_solve(pdp_problem *p, pdp_solve_args *args, void *stream);
 
+/* ---- neural plug-ins: per-edge MLP / GRU layers on the fp32 matrix cores ---------------------------------
+ * Weights are handed over PRE-TRANSPOSED and ZERO PADDED by the host: a layer y = act(W x + b) with nn.Linear weight
+ * W [N, K] is passed as Wt [Kp, Np] row-major with Wt[k, j] = W[j, k], Kp = K rounded up to even, Np = N rounded up
+ * to a multiple of 32, biases padded to Np with zeros.  Products are k-ordered fp32 fma chains starting at the bias. */
+typedef struct pdp_agg_desc {      /* MessageAggregator (reference: src/pdp/nn/util.py:11-77) */
+    const float *Wt1m, *b1m, *Wt2m, *Wt1a, *b1a, *Wt2a;   /* W1_m (+bias), W2_m, W1_a (+bias), W2_a */
+    int32_t din;                    /* input width = state width + 1 (edge sign is appended by the kernel) */
+    int32_t m1, a, g, out;          /* mem_hidden, mem_agg_hidden, agg_hidden, output widths */
+    int32_t fd;                     /* 1: edge sign appended after aggregation (include_self_message=False), else 0 */
+} pdp_agg_desc;
+typedef struct pdp_gru_desc {      /* nn.GRUCell: Wt_ih [Kp(dx+1), 3*Hp], Wt_hh [Kp(H), 3*Hp], gate g at columns g*Hp.. */
+    const float *Wt_ih, *Wt_hh, *b_ih, *b_hh;
+    int32_t dx, H;
+} pdp_gru_desc;
+typedef struct pdp_head_desc {     /* Perceptron / PerceptronTanh head: Wt1 [Kp(H), Np(C)], b1 [Np], w2 [C] */
+    const float *Wt1, *b1, *w2;
+    int32_t H, C, out_act;         /* out_act: 3 sigmoid (trainer.py:28-29), 4 tanh (util.py:250-251) */
+} pdp_head_desc;
+/* replaces: one MessageAggregator call of NeuralMessagePasser.forward (pdp_propagate.py:77-78 by_variable=1, :88-89
+ * by_variable=0): out [E,out] = mask * Agg([state ‖ sign]) + (1 - mask) * old, mask from active_mask (NULL: ones) */
+int pdp_neural_aggregate_edges(pdp_problem *p, const pdp_agg_desc *d, int by_variable, const float *state,
+                               const float *edge_mask, const uint8_t *active_mask, const float *old, float *out, void *stream);
+/* replaces: one GRU direction of NeuralDecimator.forward (pdp_decimate.py:70-75, 78-83): out [E,H] (must not alias h) */
+int pdp_neural_gru(pdp_problem *p, const pdp_gru_desc *d, const float *state, const float *h, const uint8_t *active_mask,
+                   float *out, void *stream);
+/* replaces: NeuralPredictor.forward variable branch (pdp_predict.py:67-77): state [E,H] -> pred [V] */
+int pdp_neural_predict(pdp_problem *p, const pdp_agg_desc *d, const pdp_head_desc *head, const float *state,
+                       const float *edge_mask, float *pred, void *stream);
+
 /* ---- math probes (tests: device exp/log must equal the host header bit for bit) ---------------------- */
 int pdp_math_apply(int fn, const float *x, float *y, int64_t n, void *stream);
 

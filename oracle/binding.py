@@ -258,3 +258,121 @@ def math_apply(fn, x):
     y = np.zeros_like(x)
     lib().orc_math_apply(C.c_int(names[fn]), _p(x), _p(y), C.c_int64(x.size))
     return y
+
+
+# ---- neural operators (oracle/pdp_oracle_neural.c) -----------------------------------------------------------------------
+class AggWeights(C.Structure):
+    _fields_ = [('din', C.c_int), ('m1', C.c_int), ('a', C.c_int), ('fd', C.c_int), ('g', C.c_int), ('out', C.c_int),
+                ('W1m', C.c_void_p), ('b1m', C.c_void_p), ('W2m', C.c_void_p), ('W1a', C.c_void_p), ('b1a', C.c_void_p),
+                ('W2a', C.c_void_p)]
+
+
+ACTS = {'none': 0, 'logsigmoid': 1, 'relu': 2, 'sigmoid': 3, 'tanh': 4}
+
+
+def linear(x, W, b=None, act='none'):
+    x = _f(x); W = _f(W); b = _f(b)
+    R, K = x.shape
+    y = np.zeros((R, W.shape[0]), np.float32)
+    lib().orc_linear(_p(x), C.c_int64(R), C.c_int(K), C.c_int64(K), _p(W), _p(b), C.c_int(W.shape[0]), C.c_int(ACTS[act]), _p(y), C.c_int64(W.shape[0]))
+    return y
+
+
+def csr_rows(row_of_edge, n_rows):
+    "ascending-edge-id CSR of a row index vector (helper for the neural aggregator)"
+    row_of_edge = np.asarray(row_of_edge, dtype=np.int64)
+    order = np.argsort(row_of_edge, kind='stable').astype(np.int32)
+    ptr = np.zeros(n_rows + 1, np.int32)
+    np.cumsum(np.bincount(row_of_edge, minlength=n_rows), out=ptr[1:])
+    return ptr, order
+
+
+def aggregator(edge_row, n_rows, state, edge_sign, edge_mask, include_self, w):
+    """w: dict with W1m,b1m,W2m,W1a,b1a,W2a (numpy).  Returns [E,out] (or [n_rows,out] when include_self)."""
+    state = _f(state); edge_sign = _f(edge_sign); em = _f(edge_mask)
+    E = state.shape[0]
+    ptr, order = csr_rows(edge_row, n_rows)
+    er = np.ascontiguousarray(edge_row, dtype=np.int32)
+    keep = [_f(w[k]) for k in ('W1m', 'b1m', 'W2m', 'W1a', 'b1a', 'W2a')]
+    aw = AggWeights()
+    aw.din = keep[0].shape[1]; aw.m1 = keep[0].shape[0]; aw.a = keep[2].shape[0]; aw.g = keep[3].shape[0]; aw.out = keep[5].shape[0]
+    aw.fd = keep[3].shape[1] - aw.a
+    for name, arr in zip(('W1m', 'b1m', 'W2m', 'W1a', 'b1a', 'W2a'), keep):
+        setattr(aw, name, arr.ctypes.data)
+    out = np.zeros((n_rows if include_self else E, aw.out), np.float32)
+    lib().orc_aggregator(C.c_int(E), C.c_int(n_rows), _p(ptr), _p(order), _p(er), _p(state), _p(edge_sign), _p(em),
+                         C.c_int(1 if include_self else 0), C.byref(aw), _p(out))
+    return out
+
+
+def gru(state, edge_sign, h, W_ih, W_hh, b_ih, b_hh, mask=None):
+    state = _f(state); h = _f(h)
+    E, H = h.shape
+    out = np.zeros((E, H), np.float32)
+    lib().orc_gru(C.c_int(E), C.c_int(H), C.c_int(state.shape[1]), _p(state), _p(_f(edge_sign)), _p(h), _p(_f(W_ih)), _p(_f(W_hh)),
+                  _p(_f(b_ih)), _p(_f(b_hh)), _p(_f(mask)), _p(out))
+    return out
+
+
+def perceptron(x, W1, b1, W2, out_act='sigmoid'):
+    x = _f(x)
+    y = np.zeros((x.shape[0], 1), np.float32)
+    lib().orc_perceptron(C.c_int(x.shape[0]), C.c_int(x.shape[1]), C.c_int(_f(W1).shape[0]), _p(x), _p(_f(W1)), _p(_f(b1)), _p(_f(W2)),
+                         C.c_int(ACTS[out_act]), _p(y))
+    return y
+
+
+def neural_weights(d, prefix='w__'):
+    "golden .npz (flattened state-dict keys) -> nested dict of the np-nd-np model's tensors"
+    g = lambda k: d[prefix + k]
+    def agg(base):
+        return dict(W1m=g(base + '___W1_m__weight'), b1m=g(base + '___W1_m__bias'), W2m=g(base + '___W2_m__weight'),
+                    W1a=g(base + '___W1_a__weight'), b1a=g(base + '___W1_a__bias'), W2a=g(base + '___W2_a__weight'))
+    def cell(base):
+        return dict(W_ih=g(base + '__weight_ih'), W_hh=g(base + '__weight_hh'), b_ih=g(base + '__bias_ih'), b_hh=g(base + '__bias_hh'))
+    return dict(prop_v=agg('_propagator___variable_aggregator'), prop_f=agg('_propagator___function_aggregator'),
+                gru_v=cell('_decimator___variable_rnn_cell'), gru_f=cell('_decimator___function_rnn_cell'),
+                pred=agg('_predictor___variable_aggregator'),
+                head=dict(W1=g('_predictor___variable_classifier___layer1__weight'), b1=g('_predictor___variable_classifier___layer1__bias'),
+                          W2=g('_predictor___variable_classifier___layer2__weight')))
+
+
+def neural_forward(problem, weights, init, T, trace=None):
+    """np-nd-np forward loop (solver.py:355-386 with the neural plug-ins) composed from the oracle's operators.
+    problem: binding.Problem (already simplified); init = (prop_v, prop_f, dec_v, dec_f) numpy [E,H].
+    Returns (final prediction [V] after _local_search(0 steps) + _update_solution, states dict)."""
+    ev, ec, es, vi, fi = problem.graph()
+    E, V, F, B = problem.E, problem.V, problem.F, problem.B
+    pv, pf, dv, df = [np.ascontiguousarray(x, dtype=np.float32) for x in init]
+    am = np.ones(B, np.uint8)
+    em = None
+    iters = 0
+    pred = None
+    for t in range(T):
+        mask = am[vi[ev]].astype(np.float32)
+        fstate = aggregator(ev, V, dv, es, em, False, weights['prop_v'])
+        pf = (mask[:, None] * fstate + (1.0 - mask[:, None]) * pf).astype(np.float32)
+        vstate = aggregator(ec, F, df, es, em, False, weights['prop_f'])
+        pv = (mask[:, None] * vstate + (1.0 - mask[:, None]) * pv).astype(np.float32)
+        dv = gru(pv, es, dv, mask=mask, **weights['gru_v'])
+        df = gru(pf, es, df, mask=mask, **weights['gru_f'])
+        m, s = problem.refresh_edge_mask()
+        if s < E:
+            em = m
+        agg = aggregator(ev, V, dv, es, em, True, weights['pred'])
+        p = perceptron(agg, weights['head']['W1'], weights['head']['b1'], weights['head']['W2'])[:, 0]
+        pred = problem.update_solution(p)
+        if trace is not None:
+            trace.append(dict(prop_v=pv.copy(), prop_f=pf.copy(), dec_v=dv.copy(), dec_f=df.copy(), pred=pred.copy()))
+        am = problem.check_termination(am, pred)
+        if trace is not None:
+            trace[-1]['active_mask'] = am.copy()
+        iters = t + 1
+        if am.sum() <= 0:
+            break
+    # final predictor call + local search with 0 steps + update_solution (solver.py:342-348)
+    agg = aggregator(ev, V, dv, es, em, True, weights['pred'])
+    p = perceptron(agg, weights['head']['W1'], weights['head']['b1'], weights['head']['W2'])[:, 0]
+    ls, _, _ = problem.local_search(p, 0, 0.5, seed=0)
+    final = problem.update_solution(ls)
+    return final, dict(prop_v=pv, prop_f=pf, dec_v=dv, dec_f=df, iterations=iters, active_mask=am)

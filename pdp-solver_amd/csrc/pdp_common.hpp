@@ -78,6 +78,8 @@ struct pdp_problem {
     int32_t *inst_v0, *inst_f0, *inst_e0;   // [B+1]
     int32_t *v_ptr, *v_edges;   // [V+B] local CSR offsets (instance b at v0+b, n+1 entries), [E] local edge ids
     int32_t *f_ptr, *f_edges;   // [F+B], [E]
+    int32_t *nv_ptr, *nv_edges; // [V+1], [E] by-variable CSR with GLOBAL edge ids (neural row sums)
+    int32_t *nf_ptr, *nf_edges; // [F+1], [E] by-clause
     // bound state (caller owned)
     float *av, *af, *sol, *is_sat, *emask;
     int has_edge_mask;          // refresh_edge_mask was called (sat_problem._edge_mask is not None)
@@ -96,6 +98,7 @@ struct pdp_problem {
     char *solve_blob; size_t solve_blob_bytes;
     uint32_t *solve_host; size_t solve_host_words;   // pinned
     float *solve_extra_v;
+    float *nws[4]; size_t nws_floats[4];             // neural workspaces (grow on demand)
 };
 
 struct pdp_decimator {

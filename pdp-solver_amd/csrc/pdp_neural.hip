@@ -1,0 +1,376 @@
+// pdp_neural.hip -- the neural PDP operators on the fp32 matrix cores of gfx950.
+// replaces: MessageAggregator.forward (reference: src/pdp/nn/util.py:51-77), NeuralMessagePasser.forward
+// (src/pdp/nn/pdp_propagate.py:47-95), NeuralDecimator.forward / nn.GRUCell (src/pdp/nn/pdp_decimate.py:51-87),
+// NeuralPredictor.forward + Perceptron head (src/pdp/nn/pdp_predict.py:49-91, src/pdp/trainer.py:20-29).
+//
+// Every per-edge MLP / GRU layer is a [64-edge tile] x [K] x [N] product on v_mfma_f32_32x32x2_f32.  That instruction
+// is a k-ordered fp32 fmaf chain (MI355X_MICROARCH.md), so the results equal the CPU oracle's
+// `acc = bias; acc = fmaf(x[k], w[k], acc)` loops bit for bit; zero padding of K adds fmaf(0,0,acc) = acc.
+// A workgroup (8 waves) keeps the tile's activations in LDS between layers (row stride odd -> conflict-free column
+// reads for the A operand), weights arrive pre-transposed / zero padded as Wt[Kp][Np] so the B operand is a coalesced
+// 128-byte row segment per half-wave; the activation (exact logsigmoid / sigmoid / tanh from pdp_math.h) is applied on
+// the accumulator registers.  Row sums between the two halves of an aggregator are sequential in ascending edge id.
+#include "pdp_common.hpp"
+
+#define ST(s) ((hipStream_t)(s))
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define TM 64             // edges (rows) per tile
+#define NWAVES 8
+#define NTN (NWAVES * 64)
+
+enum { ACT_NONE = 0, ACT_LOGSIGMOID = 1, ACT_RELU = 2, ACT_SIGMOID = 3, ACT_TANH = 4 };
+
+__device__ __forceinline__ float act_apply(float v, int act)
+{
+    switch (act) {
+    case ACT_LOGSIGMOID: return pdp_logsigmoidf(v);
+    case ACT_RELU: return v > 0.0f ? v : ((v != v) ? v : 0.0f);
+    case ACT_SIGMOID: return pdp_sigmoidf(v);
+    case ACT_TANH: return pdp_tanhf(v);
+    default: return v;
+    }
+}
+
+// one 32x32 output block: acc[r] = bias[col]; acc += A[32*mb + i][k] * Wt[k][32*nb + j], k ascending
+__device__ __forceinline__ f32x16 mfma_block(const float *A, int lda, int Kp, const float *__restrict__ Wt, int Np, int nb, int mb,
+                                             const float *__restrict__ bias)
+{
+    const int l = threadIdx.x & 63, i = l & 31, kh = l >> 5;
+    const float b0 = bias ? bias[32 * nb + i] : 0.0f;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = b0;
+    const float *a_ptr = A + (32 * mb + i) * lda + kh;
+    const float *b_ptr = Wt + (size_t)kh * Np + 32 * nb + i;
+#pragma unroll 8
+    for (int k0 = 0; k0 < Kp; k0 += 2) {
+        const float a = a_ptr[k0];
+        const float b = b_ptr[(size_t)k0 * Np];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// C/D layout of the 32x32 MFMA: reg r of lane l holds row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31
+__device__ __forceinline__ int acc_row(int r, int l) { return (r & 3) + 8 * (r >> 2) + 4 * (l >> 5); }
+
+// layer on an LDS tile: out[row][col] = act(bias + in[row][:] . Wt[:, col]); columns >= n_valid are written as 0
+__device__ __forceinline__ void lds_layer(const float *in, int ldi, int Kp, const float *Wt, int Np, const float *bias, int n_valid, int act,
+                                          float *out, int ldo)
+{
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int nblocks = (Np / 32) * (TM / 32);
+    for (int blk = wave; blk < nblocks; blk += NWAVES) {
+        const int nb = blk / (TM / 32), mb = blk % (TM / 32);
+        const f32x16 acc = mfma_block(in, ldi, Kp, Wt, Np, nb, mb, bias);
+        const int col = 32 * nb + (l & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * mb + acc_row(r, l);
+            out[row * ldo + col] = (col < n_valid) ? act_apply(acc[r], act) : 0.0f;
+        }
+    }
+}
+
+// ---- model description handed over by the host (all weights pre-transposed and zero padded: Wt[Kp][Np]) ------------
+struct AggW {      // MessageAggregator
+    const float *Wt1m, *b1m, *Wt2m, *Wt1a, *b1a, *Wt2a;
+    int din;       // state width + 1 (edge sign)            -> Kp1 = even(din)
+    int m1, a, g, out;            // valid widths
+    int Kp1, Np1, Kp2, Np2, Kp3, Np3, Kp4, Np4;
+    int fd;        // 1: edge sign appended to the aggregated vector (include_self = False), 0: not
+};
+struct GruW {
+    const float *Wt_ih, *Wt_hh, *b_ih, *b_hh;     // Wt_ih [Kpx][3*Hp], Wt_hh [Kph][3*Hp], biases [3*Hp]
+    int dx, H, Kpx, Kph, Hp;
+};
+struct HeadW { const float *Wt1, *b1, *w2; int H, C, Kp, Np, out_act; };   // Perceptron: Wt1 [Kp][Np], w2 [C]
+
+static inline int even_up(int x) { return (x + 1) & ~1; }
+static inline int pad32(int x) { return (x + 31) & ~31; }
+
+// ---- kernel 1: aggregator pre-transform on edge tiles:  h2 = logsig(W2m logsig(W1m [state ‖ s] + b1m)) * edge_mask ------
+__global__ void __launch_bounds__(NTN) k_agg_pre(int E, const float *__restrict__ state, int sd, const float *__restrict__ sign,
+                                                 const float *__restrict__ emask, AggW w, float *__restrict__ h2out)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int ld0 = w.Kp1 + 1, ld1 = w.Np1 + 1;
+    float *X = sm, *H1 = sm + TM * ld0;
+    const int e0 = blockIdx.x * TM;
+    for (int idx = threadIdx.x; idx < TM * w.Kp1; idx += NTN) {
+        const int r = idx / w.Kp1, c = idx % w.Kp1;
+        const int e = e0 + r;
+        float v = 0.0f;
+        if (e < E) v = (c < sd) ? state[(size_t)e * sd + c] : (c == sd ? sign[e] : 0.0f);
+        X[r * ld0 + c] = v;
+    }
+    __syncthreads();
+    lds_layer(X, ld0, w.Kp1, w.Wt1m, w.Np1, w.b1m, w.m1, ACT_LOGSIGMOID, H1, ld1);
+    __syncthreads();
+    // second layer straight to HBM (compact [E, a]), masked by the edge mask (util.py:57-58)
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int nblocks = (w.Np2 / 32) * (TM / 32);
+    for (int blk = wave; blk < nblocks; blk += NWAVES) {
+        const int nb = blk / (TM / 32), mb = blk % (TM / 32);
+        const f32x16 acc = mfma_block(H1, ld1, w.Kp2, w.Wt2m, w.Np2, nb, mb, nullptr);
+        const int col = 32 * nb + (l & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int e = e0 + 32 * mb + acc_row(r, l);
+            if (e < E && col < w.a) {
+                float v = pdp_logsigmoidf(acc[r]);
+                if (emask) v = v * emask[e];
+                h2out[(size_t)e * w.a + col] = v;
+            }
+        }
+    }
+}
+
+// ---- kernel 2: row sums (per variable / clause), sequential in ascending edge id ------------------------------------------
+__global__ void k_row_sum(int R, int A, const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ row_edges,
+                          const float *__restrict__ h2, float *__restrict__ agg)
+{
+    const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)R * A) return;
+    const int r = (int)(idx / A), c = (int)(idx % A);
+    float acc = 0.0f;
+    for (int k = row_ptr[r]; k < row_ptr[r + 1]; ++k) acc = acc + h2[(size_t)row_edges[k] * A + c];
+    agg[idx] = acc;
+}
+
+// ---- kernel 3: aggregator post-transform on edge tiles (include_self = False) ------------------------------------------------
+// r = agg[row(e)] - h2[e] * edge_mask ; [r ‖ s] -> logsig(W2a logsig(W1a . + b1a)) ; out = mask * new + (1 - mask) * old
+__global__ void __launch_bounds__(NTN) k_agg_post(int E, const float *__restrict__ agg, const int32_t *__restrict__ edge_row,
+                                                  const float *__restrict__ h2, const float *__restrict__ sign,
+                                                  const float *__restrict__ emask, const float *__restrict__ rowmask /*[E] or NULL*/,
+                                                  const float *__restrict__ old, AggW w, float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int ld0 = w.Kp3 + 1, ld1 = w.Np3 + 1;
+    float *Rt = sm, *G1 = sm + TM * ld0;
+    const int e0 = blockIdx.x * TM;
+    for (int idx = threadIdx.x; idx < TM * w.Kp3; idx += NTN) {
+        const int r = idx / w.Kp3, c = idx % w.Kp3;
+        const int e = e0 + r;
+        float v = 0.0f;
+        if (e < E) {
+            if (c < w.a) {
+                const float own = emask ? h2[(size_t)e * w.a + c] * emask[e] : h2[(size_t)e * w.a + c];
+                v = (0.0f + agg[(size_t)edge_row[e] * w.a + c]) - own;
+            } else if (c == w.a && w.fd) v = sign[e];
+        }
+        Rt[r * ld0 + c] = v;
+    }
+    __syncthreads();
+    lds_layer(Rt, ld0, w.Kp3, w.Wt1a, w.Np3, w.b1a, w.g, ACT_LOGSIGMOID, G1, ld1);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int nblocks = (w.Np4 / 32) * (TM / 32);
+    for (int blk = wave; blk < nblocks; blk += NWAVES) {
+        const int nb = blk / (TM / 32), mb = blk % (TM / 32);
+        const f32x16 acc = mfma_block(G1, ld1, w.Kp4, w.Wt2a, w.Np4, nb, mb, nullptr);
+        const int col = 32 * nb + (l & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int e = e0 + 32 * mb + acc_row(r, l);
+            if (e < E && col < w.out) {
+                const float nv = pdp_logsigmoidf(acc[r]);
+                const float mk = rowmask ? rowmask[e] : 1.0f;
+                out[(size_t)e * w.out + col] = mk * nv + (1.0f - mk) * old[(size_t)e * w.out + col];
+            }
+        }
+    }
+}
+
+// ---- kernel 4: predictor tail on variable tiles (include_self = True) + Perceptron head --------------------------------------------
+__global__ void __launch_bounds__(NTN) k_predict_rows(int V, const float *__restrict__ agg, AggW w, HeadW hd, float *__restrict__ pred)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int ld0 = w.Kp3 + 1, ld1 = w.Np3 + 1, ld2 = w.Np4 + 1, ld3 = hd.Np + 1;
+    float *Rt = sm, *G1 = Rt + TM * ld0, *O = G1 + TM * ld1, *C1 = O + TM * ld2;
+    const int v0 = blockIdx.x * TM;
+    for (int idx = threadIdx.x; idx < TM * w.Kp3; idx += NTN) {
+        const int r = idx / w.Kp3, c = idx % w.Kp3;
+        Rt[r * ld0 + c] = (v0 + r < V && c < w.a) ? agg[(size_t)(v0 + r) * w.a + c] : 0.0f;
+    }
+    __syncthreads();
+    lds_layer(Rt, ld0, w.Kp3, w.Wt1a, w.Np3, w.b1a, w.g, ACT_LOGSIGMOID, G1, ld1);
+    __syncthreads();
+    lds_layer(G1, ld1, w.Kp4, w.Wt2a, w.Np4, nullptr, w.out, ACT_LOGSIGMOID, O, ld2);
+    __syncthreads();
+    lds_layer(O, ld2, hd.Kp, hd.Wt1, hd.Np, hd.b1, hd.C, ACT_RELU, C1, ld3);
+    __syncthreads();
+    if (threadIdx.x < TM && v0 + threadIdx.x < V) {
+        float acc = 0.0f;
+        for (int k = 0; k < hd.C; ++k) acc = fmaf(C1[threadIdx.x * ld3 + k], hd.w2[k], acc);
+        pred[v0 + threadIdx.x] = act_apply(acc, hd.out_act);
+    }
+}
+
+// ---- kernel 5: GRU cell on edge tiles ----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NTN) k_gru(int E, const float *__restrict__ state, const float *__restrict__ sign,
+                                             const float *__restrict__ hprev, const float *__restrict__ rowmask, GruW g, float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int ldx = g.Kpx + 1, ldh = g.Kph + 1;
+    float *X = sm, *Hs = sm + TM * ldx;
+    const int e0 = blockIdx.x * TM;
+    for (int idx = threadIdx.x; idx < TM * g.Kpx; idx += NTN) {
+        const int r = idx / g.Kpx, c = idx % g.Kpx;
+        const int e = e0 + r;
+        float v = 0.0f;
+        if (e < E) v = (c < g.dx) ? state[(size_t)e * g.dx + c] : (c == g.dx ? sign[e] : 0.0f);
+        X[r * ldx + c] = v;
+    }
+    for (int idx = threadIdx.x; idx < TM * g.Kph; idx += NTN) {
+        const int r = idx / g.Kph, c = idx % g.Kph;
+        const int e = e0 + r;
+        Hs[r * ldh + c] = (e < E && c < g.H) ? hprev[(size_t)e * g.H + c] : 0.0f;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int hb = g.Hp / 32;
+    const int nblocks = hb * (TM / 32);
+    const int N3 = 3 * g.Hp;
+    for (int blk = wave; blk < nblocks; blk += NWAVES) {
+        const int nb = blk / (TM / 32), mb = blk % (TM / 32);
+        // gate order r, z, n (torch.nn.GRUCell); input and hidden products stay separate sums
+        const f32x16 ir = mfma_block(X, ldx, g.Kpx, g.Wt_ih, N3, nb, mb, g.b_ih);
+        const f32x16 hr = mfma_block(Hs, ldh, g.Kph, g.Wt_hh, N3, nb, mb, g.b_hh);
+        const f32x16 iz = mfma_block(X, ldx, g.Kpx, g.Wt_ih, N3, hb + nb, mb, g.b_ih);
+        const f32x16 hz = mfma_block(Hs, ldh, g.Kph, g.Wt_hh, N3, hb + nb, mb, g.b_hh);
+        const f32x16 in_ = mfma_block(X, ldx, g.Kpx, g.Wt_ih, N3, 2 * hb + nb, mb, g.b_ih);
+        const f32x16 hn = mfma_block(Hs, ldh, g.Kph, g.Wt_hh, N3, 2 * hb + nb, mb, g.b_hh);
+        const int col = 32 * nb + (l & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * mb + acc_row(r, l);
+            const int e = e0 + row;
+            if (e < E && col < g.H) {
+                const float rg = pdp_sigmoidf(hr[r] + ir[r]);
+                const float zg = pdp_sigmoidf(hz[r] + iz[r]);
+                const float ng = pdp_tanhf(in_[r] + hn[r] * rg);
+                const float hp = Hs[row * ldh + col];
+                const float hnew = (hp - ng) * zg + ng;
+                const float mk = rowmask ? rowmask[e] : 1.0f;
+                out[(size_t)e * g.H + col] = mk * hnew + (1.0f - mk) * hp;
+            }
+        }
+    }
+}
+
+// mask per edge from the per-instance active mask (K1: two chained sparse products in the reference)
+__global__ void k_edge_active(int E, const int32_t *__restrict__ gm, const int32_t *__restrict__ var_inst, const uint8_t *__restrict__ amask,
+                              float *__restrict__ out)
+{
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x)
+        out[e] = amask ? (0.0f + (0.0f + (float)amask[var_inst[gm[e]]])) : 1.0f;
+}
+
+// ---- C ABI ----------------------------------------------------------------------------------------------------------------------------
+static AggW make_agg(const pdp_agg_desc *d)
+{
+    AggW w;
+    w.Wt1m = d->Wt1m; w.b1m = d->b1m; w.Wt2m = d->Wt2m; w.Wt1a = d->Wt1a; w.b1a = d->b1a; w.Wt2a = d->Wt2a;
+    w.din = d->din; w.m1 = d->m1; w.a = d->a; w.g = d->g; w.out = d->out; w.fd = d->fd;
+    w.Kp1 = even_up(d->din); w.Np1 = pad32(d->m1);
+    w.Kp2 = even_up(d->m1); w.Np2 = pad32(d->a);
+    w.Kp3 = even_up(d->a + d->fd); w.Np3 = pad32(d->g);
+    w.Kp4 = even_up(d->g); w.Np4 = pad32(d->out);
+    return w;
+}
+
+static int set_lds(const void *fn, size_t bytes)
+{
+    if (bytes > 160 * 1024 - 512) { pdp_set_error("neural kernel tile needs %zu bytes of LDS", bytes); return PDP_ERR_UNSUPPORTED; }
+    PDP_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return PDP_OK;
+}
+
+static float *neural_ws(pdp_problem *p, int slot, size_t floats);
+
+// replaces: MessageAggregator.forward with include_self_message=False as used by NeuralMessagePasser
+// (pdp_propagate.py:77-78,88-89): by_variable != 0 aggregates over the variable of each edge, else over its clause.
+// state [E, din-1]; edge_mask [E] or NULL; active_mask uint8 [B] or NULL; old [E, out] = state blended in where inactive.
+extern "C" int pdp_neural_aggregate_edges(pdp_problem *p, const pdp_agg_desc *d, int by_variable, const float *state,
+                                          const float *edge_mask, const uint8_t *active_mask, const float *old, float *out, void *stream)
+{
+    PDP_REQUIRE(p && d && state && old && out, "NULL argument");
+    hipStream_t st = ST(stream);
+    const AggW w = make_agg(d);
+    const int E = p->E, R = by_variable ? p->V : p->F;
+    float *h2 = neural_ws(p, 0, (size_t)E * w.a), *agg = neural_ws(p, 1, (size_t)R * w.a), *rowmask = neural_ws(p, 2, (size_t)E);
+    if (!h2 || !agg || !rowmask) return PDP_ERR_HIP;
+    const int tiles = (E + TM - 1) / TM;
+    const size_t lds1 = sizeof(float) * (size_t)TM * ((w.Kp1 + 1) + (w.Np1 + 1));
+    const size_t lds3 = sizeof(float) * (size_t)TM * ((w.Kp3 + 1) + (w.Np3 + 1));
+    int s = set_lds((const void *)k_agg_pre, lds1); if (s != PDP_OK) return s;
+    s = set_lds((const void *)k_agg_post, lds3); if (s != PDP_OK) return s;
+    hipLaunchKernelGGL(k_edge_active, dim3(1024), dim3(256), 0, st, E, p->graph_map, p->var_inst, active_mask, rowmask);
+    hipLaunchKernelGGL(k_agg_pre, dim3(tiles), dim3(NTN), lds1, st, E, state, w.din - 1, p->edge_sign, edge_mask, w, h2);
+    // global CSR rows in ascending edge id: the sorted edge lists of the problem (global ids)
+    const int32_t *row_ptr = by_variable ? p->nv_ptr : p->nf_ptr;
+    const int32_t *row_edges = by_variable ? p->nv_edges : p->nf_edges;
+    hipLaunchKernelGGL(k_row_sum, dim3((unsigned)(((int64_t)R * w.a + 255) / 256)), dim3(256), 0, st, R, w.a, row_ptr, row_edges, h2, agg);
+    const int32_t *edge_row = by_variable ? p->graph_map : p->graph_map + E;
+    hipLaunchKernelGGL(k_agg_post, dim3(tiles), dim3(NTN), lds3, st, E, agg, edge_row, h2, p->edge_sign, edge_mask, rowmask, old, w, out);
+    PDP_LAUNCH_CHECK();
+    return PDP_OK;
+}
+
+// replaces: NeuralDecimator.forward, one direction (pdp_decimate.py:70-75 / 78-83): h' = mask * GRU([state ‖ s], h) + (1 - mask) * h
+extern "C" int pdp_neural_gru(pdp_problem *p, const pdp_gru_desc *d, const float *state, const float *h, const uint8_t *active_mask,
+                              float *out, void *stream)
+{
+    PDP_REQUIRE(p && d && state && h && out, "NULL argument");
+    PDP_REQUIRE(out != h, "output must not alias the hidden state");
+    hipStream_t st = ST(stream);
+    GruW g;
+    g.Wt_ih = d->Wt_ih; g.Wt_hh = d->Wt_hh; g.b_ih = d->b_ih; g.b_hh = d->b_hh; g.dx = d->dx; g.H = d->H;
+    g.Kpx = even_up(d->dx + 1); g.Kph = even_up(d->H); g.Hp = pad32(d->H);
+    const int E = p->E;
+    float *rowmask = neural_ws(p, 2, (size_t)E);
+    if (!rowmask) return PDP_ERR_HIP;
+    const size_t lds = sizeof(float) * (size_t)TM * ((g.Kpx + 1) + (g.Kph + 1));
+    int s = set_lds((const void *)k_gru, lds); if (s != PDP_OK) return s;
+    hipLaunchKernelGGL(k_edge_active, dim3(1024), dim3(256), 0, st, E, p->graph_map, p->var_inst, active_mask, rowmask);
+    hipLaunchKernelGGL(k_gru, dim3((E + TM - 1) / TM), dim3(NTN), lds, st, E, state, p->edge_sign, h, rowmask, g, out);
+    PDP_LAUNCH_CHECK();
+    return PDP_OK;
+}
+
+// replaces: NeuralPredictor.forward (pdp_predict.py:67-77): variable aggregator with include_self_message=True + classifier head
+extern "C" int pdp_neural_predict(pdp_problem *p, const pdp_agg_desc *d, const pdp_head_desc *hd, const float *state, const float *edge_mask,
+                                  float *pred, void *stream)
+{
+    PDP_REQUIRE(p && d && hd && state && pred, "NULL argument");
+    hipStream_t st = ST(stream);
+    const AggW w = make_agg(d);
+    HeadW h;
+    h.Wt1 = hd->Wt1; h.b1 = hd->b1; h.w2 = hd->w2; h.H = hd->H; h.C = hd->C; h.out_act = hd->out_act;
+    h.Kp = even_up(hd->H); h.Np = pad32(hd->C);
+    const int E = p->E, V = p->V;
+    float *h2 = neural_ws(p, 0, (size_t)E * w.a), *agg = neural_ws(p, 1, (size_t)V * w.a);
+    if (!h2 || !agg) return PDP_ERR_HIP;
+    const size_t lds1 = sizeof(float) * (size_t)TM * ((w.Kp1 + 1) + (w.Np1 + 1));
+    const size_t lds4 = sizeof(float) * (size_t)TM * ((w.Kp3 + 1) + (w.Np3 + 1) + (w.Np4 + 1) + (h.Np + 1));
+    int s = set_lds((const void *)k_agg_pre, lds1); if (s != PDP_OK) return s;
+    s = set_lds((const void *)k_predict_rows, lds4); if (s != PDP_OK) return s;
+    hipLaunchKernelGGL(k_agg_pre, dim3((E + TM - 1) / TM), dim3(NTN), lds1, st, E, state, w.din - 1, p->edge_sign, edge_mask, w, h2);
+    hipLaunchKernelGGL(k_row_sum, dim3((unsigned)(((int64_t)V * w.a + 255) / 256)), dim3(256), 0, st, V, w.a, p->nv_ptr, p->nv_edges, h2, agg);
+    hipLaunchKernelGGL(k_predict_rows, dim3((V + TM - 1) / TM), dim3(NTN), lds4, st, V, agg, w, h, pred);
+    PDP_LAUNCH_CHECK();
+    return PDP_OK;
+}
+
+static float *neural_ws(pdp_problem *p, int slot, size_t floats)
+{
+    if (p->nws_floats[slot] < floats) {
+        if (p->nws[slot]) (void)hipFree(p->nws[slot]);
+        p->nws[slot] = nullptr; p->nws_floats[slot] = 0;
+        if (hipMalloc((void **)&p->nws[slot], floats * sizeof(float)) != hipSuccess) { pdp_set_error("hipMalloc of a neural workspace failed"); return nullptr; }
+        p->nws_floats[slot] = floats;
+    }
+    return p->nws[slot];
+}

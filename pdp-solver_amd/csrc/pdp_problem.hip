@@ -143,6 +143,13 @@ __global__ void k_csr_finish(int E, int N, int B, const int32_t *sorted_keys, co
     }
 }
 
+// global-id CSR offsets: ptr[i] = first sorted position with key >= i, i in [0, N]
+__global__ void k_global_ptr(int E, int N, const int32_t *sorted_keys, int32_t *ptr)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= N) ptr[i] = lower_bound_i32(sorted_keys, E, i);
+}
+
 __global__ void k_max_dims(int B, const int32_t *v0, const int32_t *f0, const int32_t *e0, uint32_t *out /*[3]*/)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -182,6 +189,11 @@ extern "C" int pdp_problem_destroy(pdp_problem *p)
     if (p->solve_blob) (void)hipFree(p->solve_blob);
     if (p->solve_host) (void)hipHostFree(p->solve_host);
     if (p->solve_extra_v) (void)hipFree(p->solve_extra_v);
+    for (int i = 0; i < 4; ++i) if (p->nws[i]) (void)hipFree(p->nws[i]);
+    if (p->nv_ptr) (void)hipFree(p->nv_ptr);
+    if (p->nv_edges) (void)hipFree(p->nv_edges);
+    if (p->nf_ptr) (void)hipFree(p->nf_ptr);
+    if (p->nf_edges) (void)hipFree(p->nf_edges);
     delete p;
     return PDP_OK;
 }
@@ -254,11 +266,17 @@ static int build_problem(pdp_problem *p, const int32_t *graph_map, const int32_t
     hipLaunchKernelGGL(k_csr_finish, dim3(grid_for((int64_t)V + B + E)), dim3(256), 0, st, E, V, B, keys_out, vals_out,
                        p->var_inst, p->inst_v0, p->inst_e0, p->v_ptr, p->v_edges, (uint32_t *)nullptr);
     PDP_LAUNCH_CHECK();
+    PDP_TRY(dmalloc(&p->nv_ptr, (size_t)V + 1)); PDP_TRY(dmalloc(&p->nv_edges, (size_t)E));
+    hipLaunchKernelGGL(k_global_ptr, dim3((V + 1 + 255) / 256), dim3(256), 0, st, E, V, keys_out, p->nv_ptr);
+    PDP_HIP_CHECK(hipMemcpyAsync(p->nv_edges, vals_out, sizeof(int32_t) * (size_t)E, hipMemcpyDeviceToDevice, st));
     // by clause
     PDP_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(p->cub_tmp, tmp_bytes, p->graph_map + E, keys_out, iota_e, vals_out, E, 0, bits, st));
     hipLaunchKernelGGL(k_csr_finish, dim3(grid_for((int64_t)F + B + E)), dim3(256), 0, st, E, F, B, keys_out, vals_out,
                        p->fn_inst, p->inst_f0, p->inst_e0, p->f_ptr, p->f_edges, p->flags + FL_GMIN0);
     PDP_LAUNCH_CHECK();
+    PDP_TRY(dmalloc(&p->nf_ptr, (size_t)F + 1)); PDP_TRY(dmalloc(&p->nf_edges, (size_t)E));
+    hipLaunchKernelGGL(k_global_ptr, dim3((F + 1 + 255) / 256), dim3(256), 0, st, E, F, keys_out, p->nf_ptr);
+    PDP_HIP_CHECK(hipMemcpyAsync(p->nf_edges, vals_out, sizeof(int32_t) * (size_t)E, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(k_max_dims, dim3((B + 255) / 256), dim3(256), 0, st, B, p->inst_v0, p->inst_f0, p->inst_e0,
                        p->flags + FL_GMIN1);
     PDP_LAUNCH_CHECK();

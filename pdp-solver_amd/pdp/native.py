@@ -26,6 +26,7 @@ EXPORTED_SYMBOLS = [
     'pdp_decimator_destroy', 'pdp_decimator_reset', 'pdp_sequential_decimate', 'pdp_sequential_decimate_gate',
     'pdp_sequential_decimate_apply', 'pdp_reinforce_decimate', 'pdp_reinforce_predict', 'pdp_energy',
     'pdp_energy_diff', 'pdp_random_fill', 'pdp_local_search', 'pdp_deduplicate', 'pdp_sp_solve', 'pdp_math_apply',
+    'pdp_neural_aggregate_edges', 'pdp_neural_gru', 'pdp_neural_predict',
 ]
 
 
@@ -96,6 +97,77 @@ class SolveArgs(C.Structure):
                 ('coins', C.c_void_p), ('q', C.c_void_p), ('fs', C.c_void_p), ('active_mask', C.c_void_p),
                 ('decimator', C.c_void_p), ('check_termination', C.c_int32), ('iterations_run_host', C.c_int32),
                 ('used_lds_host', C.c_int32), ('kernel_launches_host', C.c_int32)]
+
+
+class AggDesc(C.Structure):
+    _fields_ = [('Wt1m', C.c_void_p), ('b1m', C.c_void_p), ('Wt2m', C.c_void_p), ('Wt1a', C.c_void_p), ('b1a', C.c_void_p),
+                ('Wt2a', C.c_void_p), ('din', C.c_int32), ('m1', C.c_int32), ('a', C.c_int32), ('g', C.c_int32),
+                ('out', C.c_int32), ('fd', C.c_int32)]
+
+
+class GruDesc(C.Structure):
+    _fields_ = [('Wt_ih', C.c_void_p), ('Wt_hh', C.c_void_p), ('b_ih', C.c_void_p), ('b_hh', C.c_void_p), ('dx', C.c_int32), ('H', C.c_int32)]
+
+
+class HeadDesc(C.Structure):
+    _fields_ = [('Wt1', C.c_void_p), ('b1', C.c_void_p), ('w2', C.c_void_p), ('H', C.c_int32), ('C', C.c_int32), ('out_act', C.c_int32)]
+
+
+def _pad_linear(weight, bias):
+    "nn.Linear weight [N,K] (+bias) -> (Wt [Kp,Np] zero padded, bias [Np]) in the layout include/pdp_hip.h documents"
+    N, K = weight.shape
+    Kp, Np = K + (K & 1), (N + 31) // 32 * 32
+    Wt = torch.zeros(Kp, Np, dtype=torch.float32, device=weight.device)
+    Wt[:K, :N] = weight.detach().t()
+    bp = torch.zeros(Np, dtype=torch.float32, device=weight.device)
+    if bias is not None:
+        bp[:N] = bias.detach()
+    return Wt.contiguous(), bp
+
+
+class AggregatorWeights(object):
+    "device-side, padded copy of a MessageAggregator's four layers (keeps the tensors alive for the descriptor)"
+
+    def __init__(self, W1m, b1m, W2m, W1a, b1a, W2a, feature_dim):
+        self.t = []
+        Wt1m, bb1m = _pad_linear(W1m, b1m); Wt2m, _ = _pad_linear(W2m, None)
+        Wt1a, bb1a = _pad_linear(W1a, b1a); Wt2a, _ = _pad_linear(W2a, None)
+        self.t = [Wt1m, bb1m, Wt2m, Wt1a, bb1a, Wt2a]
+        d = AggDesc()
+        d.Wt1m, d.b1m, d.Wt2m, d.Wt1a, d.b1a, d.Wt2a = [x.data_ptr() for x in self.t]
+        d.din = W1m.shape[1]; d.m1 = W1m.shape[0]; d.a = W2m.shape[0]; d.g = W1a.shape[0]; d.out = W2a.shape[0]; d.fd = feature_dim
+        assert W1a.shape[1] == d.a + feature_dim
+        self.desc = d
+
+
+class GruWeights(object):
+    def __init__(self, W_ih, W_hh, b_ih, b_hh):
+        H = W_hh.shape[1]; dx1 = W_ih.shape[1]
+        Hp = (H + 31) // 32 * 32
+        Kpx, Kph = dx1 + (dx1 & 1), H + (H & 1)
+        dev = W_ih.device
+        Wt_ih = torch.zeros(Kpx, 3 * Hp, dtype=torch.float32, device=dev); Wt_hh = torch.zeros(Kph, 3 * Hp, dtype=torch.float32, device=dev)
+        bi = torch.zeros(3 * Hp, dtype=torch.float32, device=dev); bh = torch.zeros(3 * Hp, dtype=torch.float32, device=dev)
+        for g in range(3):
+            Wt_ih[:dx1, g * Hp:g * Hp + H] = W_ih.detach()[g * H:(g + 1) * H].t()
+            Wt_hh[:H, g * Hp:g * Hp + H] = W_hh.detach()[g * H:(g + 1) * H].t()
+            bi[g * Hp:g * Hp + H] = b_ih.detach()[g * H:(g + 1) * H]; bh[g * Hp:g * Hp + H] = b_hh.detach()[g * H:(g + 1) * H]
+        self.t = [Wt_ih.contiguous(), Wt_hh.contiguous(), bi, bh]
+        d = GruDesc()
+        d.Wt_ih, d.Wt_hh, d.b_ih, d.b_hh = [x.data_ptr() for x in self.t]
+        d.dx = dx1 - 1; d.H = H
+        self.desc = d
+
+
+class HeadWeights(object):
+    def __init__(self, W1, b1, W2, out_act):
+        Wt1, bb1 = _pad_linear(W1, b1)
+        w2 = W2.detach().reshape(-1).to(torch.float32).contiguous()
+        self.t = [Wt1, bb1, w2]
+        d = HeadDesc()
+        d.Wt1, d.b1, d.w2 = [x.data_ptr() for x in self.t]
+        d.H = W1.shape[1]; d.C = W1.shape[0]; d.out_act = {'sigmoid': 3, 'tanh': 4}[out_act]
+        self.desc = d
 
 
 class Decimator(object):
@@ -285,6 +357,28 @@ class Problem(object):
         chosen = torch.empty(self.B // self.R, dtype=torch.int32, device=self.device)
         check(lib().pdp_deduplicate(self._h, ptr(pred, torch.float32, self.V), ptr(out), ptr(chosen), _stream()))
         return out, chosen
+
+    # -- neural plug-ins -------------------------------------------------------------------------------------------------
+    def neural_aggregate_edges(self, agg_w, by_variable, state, edge_mask, active_mask, old):
+        out = torch.empty(self.E, agg_w.desc.out, dtype=torch.float32, device=self.device)
+        check(lib().pdp_neural_aggregate_edges(self._h, C.byref(agg_w.desc), C.c_int(1 if by_variable else 0),
+                                               ptr(state, torch.float32, self.E * (agg_w.desc.din - 1), 'state'),
+                                               ptr(edge_mask, torch.float32, self.E, 'edge_mask'), ptr(active_mask, torch.uint8, self.B, 'active_mask'),
+                                               ptr(old, torch.float32, self.E * agg_w.desc.out, 'init_state'), ptr(out), _stream()))
+        return out
+
+    def neural_gru(self, gru_w, state, h, active_mask):
+        out = torch.empty(self.E, gru_w.desc.H, dtype=torch.float32, device=self.device)
+        check(lib().pdp_neural_gru(self._h, C.byref(gru_w.desc), ptr(state, torch.float32, self.E * gru_w.desc.dx, 'message_state'),
+                                   ptr(h, torch.float32, self.E * gru_w.desc.H, 'init_state'), ptr(active_mask, torch.uint8, self.B, 'active_mask'),
+                                   ptr(out), _stream()))
+        return out
+
+    def neural_predict(self, agg_w, head_w, state, edge_mask):
+        out = torch.empty(self.V, 1, dtype=torch.float32, device=self.device)
+        check(lib().pdp_neural_predict(self._h, C.byref(agg_w.desc), C.byref(head_w.desc), ptr(state, torch.float32, self.E * (agg_w.desc.din - 1), 'state'),
+                                       ptr(edge_mask, torch.float32, self.E, 'edge_mask'), ptr(out), _stream()))
+        return out
 
     # -- persistent solve -----------------------------------------------------------------------------------------
     def sp_solve(self, q, fs, active_mask, dec, iterations, tolerance, t_max, pi=0.0, model=MODEL_SP,

@@ -1,0 +1,58 @@
+"""GPU parity tests of the neural operators (fp32 MFMA kernels in csrc/pdp_neural.hip) against the CPU oracle: the
+matrix-core products are k-ordered fmaf chains, the oracle computes the same chains, so results must be bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import random_batch, load_golden
+from test_hip_ops import t, npy, make_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_agg(rng, din, m1, a, g, out, fd):
+    s = lambda *sh: (rng.randn(*sh) * 0.3).astype(np.float32)
+    return dict(W1m=s(m1, din), b1m=s(m1), W2m=s(a, m1), W1a=s(g, a + fd), b1a=s(g), W2a=s(out, g))
+
+
+def dev_agg(w, fd):
+    from pdp import native
+    return native.AggregatorWeights(t(w['W1m']), t(w['b1m']), t(w['W2m']), t(w['W1a']), t(w['b1a']), t(w['W2a']), fd)
+
+
+@pytest.mark.parametrize('H,m1,a,g', [(32, 100, 50, 100), (128, 100, 50, 100), (20, 36, 17, 40)])
+def test_aggregator_gru_predict_bit_exact(oracle, H, m1, a, g):
+    from pdp import native
+    b = random_batch(batch=9, n=25, mixed=True, seed=77)
+    hp, op = make_pair(oracle, b)
+    hp.simplify(); op.simplify()
+    rng = np.random.RandomState(H)
+    assign = np.zeros(op.V, np.float32); pick = rng.choice(op.V, size=op.V // 6, replace=False); assign[pick] = rng.randint(0, 2, len(pick)) * 2 - 1
+    hp.set_variables(t(assign)); op.set_variables(assign)
+    hp.refresh_edge_mask(); em, _ = op.refresh_edge_mask()
+    ev, ec, es, vi, fi = op.graph()
+    E, V, F, B = op.E, op.V, op.F, op.B
+    state = (rng.randn(E, H) * 0.5).astype(np.float32); old = (rng.randn(E, H) * 0.5).astype(np.float32)
+    am = (rng.rand(B) > 0.3).astype(np.uint8)
+    mask = am[vi[ev]].astype(np.float32)
+    w = rand_agg(rng, H + 1, m1, a, g, H, 1)
+    for by_var, rows, nrows in ((True, ev, V), (False, ec, F)):
+        for use_em in (True, False):
+            ref = oracle.aggregator(rows, nrows, state, es, em if use_em else None, False, w)
+            ref = mask[:, None] * ref + (1.0 - mask[:, None]) * old
+            got = hp.neural_aggregate_edges(dev_agg(w, 1), by_var, t(state), hp.edge_mask if use_em else None, t(am), t(old))
+            np.testing.assert_array_equal(npy(got), ref.astype(np.float32), err_msg='agg by_var=%s em=%s' % (by_var, use_em))
+    # GRU
+    s = lambda *sh: (rng.randn(*sh) * 0.2).astype(np.float32)
+    gw = dict(W_ih=s(3 * H, H + 1), W_hh=s(3 * H, H), b_ih=s(3 * H), b_hh=s(3 * H))
+    hprev = (rng.randn(E, H) * 0.5).astype(np.float32)
+    ref = oracle.gru(state, es, hprev, mask=mask, **gw)
+    got = hp.neural_gru(native.GruWeights(t(gw['W_ih']), t(gw['W_hh']), t(gw['b_ih']), t(gw['b_hh'])), t(state), t(hprev), t(am))
+    np.testing.assert_array_equal(npy(got), ref)
+    # predictor (include_self aggregator + perceptron head)
+    wp = rand_agg(rng, H + 1, m1, a, g, H, 0)
+    hw = dict(W1=s(50, H), b1=s(50), W2=s(1, 50))
+    agg = oracle.aggregator(ev, V, state, es, em, True, wp)
+    ref = oracle.perceptron(agg, hw['W1'], hw['b1'], hw['W2'])
+    got = hp.neural_predict(dev_agg(wp, 0), native.HeadWeights(t(hw['W1']), t(hw['b1']), t(hw['W2']), 'sigmoid'), t(state), hp.edge_mask)
+    np.testing.assert_array_equal(npy(got), ref)
