@@ -7,6 +7,60 @@ from pdp import native
 from pdp.nn import pdp_predict
 
 
+class NeuralDecimator(nn.Module):
+    """Two GRU cells on the edges (reference: pdp_decimate.py:21-100); nn.GRUCell parameters keep their names so that
+    reference checkpoints load, the cell itself runs on the matrix cores."""
+
+    def __init__(self, device, message_dimension, meta_data_dimension, hidden_dimension, mem_hidden_dimension,
+                 mem_agg_hidden_dimension, agg_hidden_dimension, edge_dimension, dropout):
+        super(NeuralDecimator, self).__init__()
+        if edge_dimension != 1 or meta_data_dimension != 0:
+            raise native.NativeError("NeuralDecimator: native kernels need edge_feature_dim = 1 and meta_feature_dim = 0")
+        self._device = device
+        self._module_list = nn.ModuleList()
+        self._drop_out = dropout
+        if isinstance(message_dimension, tuple):
+            variable_message_dim, function_message_dim = message_dimension
+        else:
+            variable_message_dim = function_message_dim = message_dimension
+        self._variable_rnn_cell = nn.GRUCell(variable_message_dim + edge_dimension + meta_data_dimension, hidden_dimension, bias=True)
+        self._function_rnn_cell = nn.GRUCell(function_message_dim + edge_dimension + meta_data_dimension, hidden_dimension, bias=True)
+        self._module_list.append(self._variable_rnn_cell)
+        self._module_list.append(self._function_rnn_cell)
+        self._hidden_dimension = hidden_dimension
+        self._mem_hidden_dimension = mem_hidden_dimension
+        self._agg_hidden_dimension = agg_hidden_dimension
+        self._mem_agg_hidden_dimension = mem_agg_hidden_dimension
+        self._native = {}
+
+    def _weights(self, name, cell):
+        params = (cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh)
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if name not in self._native or self._native[name][0] != key:
+            self._native[name] = (key, native.GruWeights(*[p.data for p in params]))
+        return self._native[name][1]
+
+    def forward(self, init_state, message_state, sat_problem, is_training, active_mask=None):
+        variable_state, function_state = message_state
+        am = None if active_mask is None else active_mask.reshape(-1).contiguous()
+        nat = sat_problem._native
+        new_variable_state = nat.neural_gru(self._weights('v', self._variable_rnn_cell), variable_state.contiguous(),
+                                            init_state[0].contiguous(), am)
+        new_function_state = nat.neural_gru(self._weights('f', self._function_rnn_cell), function_state.contiguous(),
+                                            init_state[1].contiguous(), am)
+        return new_variable_state, new_function_state
+
+    def get_init_state(self, graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, randomized, batch_replication):
+        "reference: pdp_decimate.py:89-100"
+        edge_num = graph_map.size(1) * batch_replication
+        if randomized:
+            variable_state = 2.0 * torch.rand(edge_num, self._hidden_dimension, dtype=torch.float32) - 1.0
+            function_state = 2.0 * torch.rand(edge_num, self._hidden_dimension, dtype=torch.float32) - 1.0
+            return (variable_state.to(self._device), function_state.to(self._device))
+        return (torch.zeros(edge_num, self._hidden_dimension, dtype=torch.float32, device=self._device),
+                torch.zeros(edge_num, self._hidden_dimension, dtype=torch.float32, device=self._device))
+
+
 class SequentialDecimator(nn.Module):
     """Convergence-gated greedy decimation, one variable per converged instance and call
     (reference: pdp_decimate.py:106-183).  The stateful parts of the reference (``_previous_function_state``,

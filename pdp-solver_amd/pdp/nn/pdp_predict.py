@@ -19,6 +19,63 @@ def _init_sp_state(device, edge_num, randomized):
     return (variable_state, function_state)
 
 
+class NeuralPredictor(nn.Module):
+    """Aggregates the edge states at the variable nodes (deep set with self message) and classifies them
+    (reference: pdp_predict.py:18-104).  Only the variable branch exists natively (function_classifier is None in every
+    reference solver)."""
+
+    def __init__(self, device, decimator_dimension, prediction_dimension, edge_dimension, meta_data_dimension, mem_hidden_dimension,
+                 agg_hidden_dimension, mem_agg_hidden_dimension, variable_classifier=None, function_classifier=None):
+        super(NeuralPredictor, self).__init__()
+        if function_classifier is not None or variable_classifier is None:
+            raise native.NativeError("NeuralPredictor: the native path implements the variable classifier branch only")
+        if edge_dimension != 1 or meta_data_dimension != 0 or prediction_dimension != 1:
+            raise native.NativeError("NeuralPredictor: native kernels need edge_feature_dim = 1, meta_feature_dim = 0, prediction_dim = 1")
+        from pdp.nn import util
+        self._device = device
+        self._module_list = nn.ModuleList()
+        self._variable_classifier = variable_classifier
+        self._function_classifier = None
+        self._hidden_dimension = decimator_dimension
+        self._variable_aggregator = util.MessageAggregator(device, decimator_dimension + edge_dimension + meta_data_dimension,
+                                                           decimator_dimension, mem_hidden_dimension, mem_agg_hidden_dimension,
+                                                           agg_hidden_dimension, 0, include_self_message=True)
+        self._module_list.append(self._variable_aggregator)
+        self._module_list.append(self._variable_classifier)
+        self._head = None
+        self._head_key = None
+
+    def _head_weights(self):
+        c = self._variable_classifier
+        params = (c._layer1.weight, c._layer1.bias, c._layer2.weight)
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._head is None or key != self._head_key:
+            act = 'tanh' if type(c).__name__ == 'PerceptronTanh' else 'sigmoid'
+            self._head = native.HeadWeights(*[p.data for p in params], out_act=act)
+            self._head_key = key
+        return self._head
+
+    def forward(self, decimator_state, sat_problem, last_call=False):
+        if len(decimator_state) == 3:
+            decimator_variable_state, _, edge_mask = decimator_state
+            edge_mask = edge_mask.reshape(-1).contiguous()
+        else:
+            decimator_variable_state, _ = decimator_state
+            edge_mask = None
+        pred = sat_problem._native.neural_predict(self._variable_aggregator.native_weights(), self._head_weights(),
+                                                  decimator_variable_state.contiguous(), edge_mask)
+        return pred, None
+
+    def get_init_state(self, graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, randomized, batch_replication):
+        edge_num = graph_map.size(1) * batch_replication
+        if randomized:
+            variable_state = 2.0 * torch.rand(edge_num, self._hidden_dimension, dtype=torch.float32) - 1.0
+            function_state = 2.0 * torch.rand(edge_num, self._hidden_dimension, dtype=torch.float32) - 1.0
+            return (variable_state.to(self._device), function_state.to(self._device))
+        return (torch.zeros(edge_num, self._hidden_dimension, dtype=torch.float32, device=self._device),
+                torch.zeros(edge_num, self._hidden_dimension, dtype=torch.float32, device=self._device))
+
+
 class IdentityPredictor(nn.Module):
     """Prediction = the problem's current solution; on the last call the still-undecided variables are filled
     with uniform random numbers (reference: pdp_predict.py:110-128).  ``rng`` selects where those numbers come

@@ -9,6 +9,63 @@ import torch
 import torch.nn as nn
 
 from pdp import native
+from pdp.nn import util
+
+
+class NeuralMessagePasser(nn.Module):
+    """The neural propagator: two deep-set aggregators, variables->functions and functions->variables
+    (reference: pdp_propagate.py:21-108).  Each direction is one call into the matrix-core kernels."""
+
+    def __init__(self, device, edge_dimension, decimator_dimension, meta_data_dimension, hidden_dimension, mem_hidden_dimension,
+                 mem_agg_hidden_dimension, agg_hidden_dimension, dropout):
+        super(NeuralMessagePasser, self).__init__()
+        if edge_dimension != 1 or meta_data_dimension != 0:
+            raise native.NativeError("NeuralMessagePasser: native kernels need edge_feature_dim = 1 and meta_feature_dim = 0")
+        self._device = device
+        self._module_list = nn.ModuleList()
+        self._drop_out = dropout
+        self._variable_aggregator = util.MessageAggregator(device, decimator_dimension + edge_dimension + meta_data_dimension,
+                                                           hidden_dimension, mem_hidden_dimension, mem_agg_hidden_dimension,
+                                                           agg_hidden_dimension, edge_dimension, include_self_message=False)
+        self._function_aggregator = util.MessageAggregator(device, decimator_dimension + edge_dimension + meta_data_dimension,
+                                                           hidden_dimension, mem_hidden_dimension, mem_agg_hidden_dimension,
+                                                           agg_hidden_dimension, edge_dimension, include_self_message=False)
+        self._module_list.append(self._variable_aggregator)
+        self._module_list.append(self._function_aggregator)
+        self._hidden_dimension = hidden_dimension
+        self._mem_hidden_dimension = mem_hidden_dimension
+        self._agg_hidden_dimension = agg_hidden_dimension
+        self._mem_agg_hidden_dimension = mem_agg_hidden_dimension
+
+    def forward(self, init_state, decimator_state, sat_problem, is_training, active_mask=None):
+        if is_training and self._drop_out > 0:
+            raise native.NativeError("training (dropout) is out of scope of the native inference path")
+        if len(decimator_state) == 3:
+            decimator_variable_state, decimator_function_state, edge_mask = decimator_state
+            edge_mask = edge_mask.reshape(-1).contiguous()
+        else:
+            decimator_variable_state, decimator_function_state = decimator_state
+            edge_mask = None
+        variable_state, function_state = init_state
+        am = None if active_mask is None else active_mask.reshape(-1).contiguous()
+        nat = sat_problem._native
+        # variables --> functions (pdp_propagate.py:72-78)
+        function_state = nat.neural_aggregate_edges(self._variable_aggregator.native_weights(), True,
+                                                    decimator_variable_state.contiguous(), edge_mask, am, function_state.contiguous())
+        # functions --> variables (pdp_propagate.py:83-89)
+        variable_state = nat.neural_aggregate_edges(self._function_aggregator.native_weights(), False,
+                                                    decimator_function_state.contiguous(), edge_mask, am, variable_state.contiguous())
+        return variable_state, function_state
+
+    def get_init_state(self, graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, randomized, batch_replication):
+        "reference: pdp_propagate.py:97-108"
+        edge_num = graph_map.size(1) * batch_replication
+        if randomized:
+            variable_state = 2.0 * torch.rand(edge_num, self._hidden_dimension, dtype=torch.float32) - 1.0
+            function_state = 2.0 * torch.rand(edge_num, self._hidden_dimension, dtype=torch.float32) - 1.0
+            return (variable_state.to(self._device), function_state.to(self._device))
+        return (torch.zeros(edge_num, self._hidden_dimension, dtype=torch.float32, device=self._device),
+                torch.zeros(edge_num, self._hidden_dimension, dtype=torch.float32, device=self._device))
 
 
 class SurveyPropagator(nn.Module):

@@ -318,6 +318,42 @@ class PropagatorDecimatorSolverBase(nn.Module):
 ###############################################################
 
 
+class NeuralPropagatorDecimatorSolver(PropagatorDecimatorSolverBase):
+    "Fully neural PDP solver: neural propagator + neural (GRU) decimator + neural predictor (reference: solver.py:517-537)."
+
+    def __init__(self, device, name, edge_dimension, meta_data_dimension, propagator_dimension, decimator_dimension,
+                 mem_hidden_dimension, agg_hidden_dimension, mem_agg_hidden_dimension, prediction_dimension,
+                 variable_classifier=None, function_classifier=None, dropout=0, local_search_iterations=0, epsilon=0.05,
+                 rng='torch', seed=0):
+        super(NeuralPropagatorDecimatorSolver, self).__init__(
+            device=device, name=name,
+            propagator=pdp_propagate.NeuralMessagePasser(device, edge_dimension, decimator_dimension, meta_data_dimension,
+                                                         propagator_dimension, mem_hidden_dimension, mem_agg_hidden_dimension,
+                                                         agg_hidden_dimension, dropout),
+            decimator=pdp_decimate.NeuralDecimator(device, propagator_dimension, meta_data_dimension, decimator_dimension,
+                                                   mem_hidden_dimension, mem_agg_hidden_dimension, agg_hidden_dimension,
+                                                   edge_dimension, dropout),
+            predictor=pdp_predict.NeuralPredictor(device, decimator_dimension, prediction_dimension, edge_dimension,
+                                                  meta_data_dimension, mem_hidden_dimension, agg_hidden_dimension,
+                                                  mem_agg_hidden_dimension, variable_classifier, function_classifier),
+            local_search_iterations=local_search_iterations, epsilon=epsilon, rng=rng, seed=seed)
+
+
+def build_neural_solver(device, config, perceptron_cls, common):
+    "model_type np-nd-np (reference: trainer.py:51-60); np-d-np needs a strided survey view that is not built yet"
+    if config['model_type'] != 'np-nd-np':
+        raise NotImplementedError("model_type %r has no native implementation yet (np-nd-np, p-d-p, walk-sat, reinforce are available)"
+                                  % (config['model_type'],))
+    return NeuralPropagatorDecimatorSolver(
+        device=device, name=config['model_name'], edge_dimension=config['edge_feature_dim'],
+        meta_data_dimension=config['meta_feature_dim'], propagator_dimension=config['hidden_dim'],
+        decimator_dimension=config['hidden_dim'], mem_hidden_dimension=config['mem_hidden_dim'],
+        agg_hidden_dimension=config['agg_hidden_dim'], mem_agg_hidden_dimension=config['mem_agg_hidden_dim'],
+        prediction_dimension=config['prediction_dim'],
+        variable_classifier=perceptron_cls(config['hidden_dim'], config['classifier_dim'], config['prediction_dim']),
+        function_classifier=None, dropout=config.get('dropout', 0), **common)
+
+
 class SurveyPropagatorSolver(PropagatorDecimatorSolverBase):
     "Classical SP-guided decimation via the PDP framework (reference: solver.py:567-578)."
 

@@ -34,6 +34,47 @@ class SatCNFEvaluator(nn.Module):
         return handle.cnf_eval(variable_prediction.reshape(-1).contiguous())
 
 
+class MessageAggregator(nn.Module):
+    """Deep-set message aggregation at variable / function nodes (reference: util.py:11-77).
+
+    Same parameters and state-dict keys as the reference (``_W1_m``, ``_W2_m``, ``_W1_a``, ``_W2_a`` plus their aliases in
+    ``_module_list``), so reference checkpoints load unchanged.  The computation runs on the fp32 matrix cores
+    (csrc/pdp_neural.hip); the module only keeps padded, transposed copies of its weights for the kernels."""
+
+    def __init__(self, device, input_dimension, output_dimension, mem_hidden_dimension,
+                 mem_agg_hidden_dimension, agg_hidden_dimension, feature_dimension, include_self_message):
+        super(MessageAggregator, self).__init__()
+        if not (mem_hidden_dimension > 0 and mem_agg_hidden_dimension > 0 and agg_hidden_dimension > 0):
+            raise native.NativeError("MessageAggregator: the native kernels implement the full 4-layer form "
+                                     "(mem_hidden_dim, mem_agg_hidden_dim, agg_hidden_dim > 0) used by every reference config")
+        self._device = device
+        self._include_self_message = include_self_message
+        self._module_list = nn.ModuleList()
+        self._W1_m = nn.Linear(input_dimension, mem_hidden_dimension, bias=True)
+        self._W2_m = nn.Linear(mem_hidden_dimension, mem_agg_hidden_dimension, bias=False)
+        self._module_list.append(self._W1_m)
+        self._module_list.append(self._W2_m)
+        self._W1_a = nn.Linear(mem_agg_hidden_dimension + feature_dimension, agg_hidden_dimension, bias=True)
+        self._W2_a = nn.Linear(agg_hidden_dimension, output_dimension, bias=False)
+        self._module_list.append(self._W1_a)
+        self._module_list.append(self._W2_a)
+        self._agg_hidden_dimension = agg_hidden_dimension
+        self._mem_hidden_dimension = mem_hidden_dimension
+        self._mem_agg_hidden_dimension = mem_agg_hidden_dimension
+        self._feature_dimension = feature_dimension
+        self._native = None
+        self._native_key = None
+
+    def native_weights(self):
+        "padded / transposed device copies, rebuilt whenever a parameter was modified in place or replaced"
+        params = (self._W1_m.weight, self._W1_m.bias, self._W2_m.weight, self._W1_a.weight, self._W1_a.bias, self._W2_a.weight)
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._native is None or key != self._native_key:
+            self._native = native.AggregatorWeights(*[p.data for p in params], feature_dim=self._feature_dimension)
+            self._native_key = key
+        return self._native
+
+
 class PerceptronTanh(nn.Module):
     "1-hidden-layer perceptron with tanh output (reference: util.py:242-251)."
 

@@ -113,3 +113,52 @@ def test_cli_dimacs_mode_runs(tmp_path):
     assert len(rows) == 20 and not os.path.exists(str(ddir / 'temp_problem_file.json'))
     assert all(set(r) == {'ID', 'label', 'solved', 'unsat_clauses', 'solution'} for r in rows)
     assert sum(r['solved'] for r in rows) >= 1
+
+
+# ---- neural solver through the API ----------------------------------------------------------------------------------------------
+def _neural_model(d, H):
+    from pdp.trainer import SatFactorGraphTrainer
+    tr = SatFactorGraphTrainer(cfg('np-nd-np', hidden_dim=H, edge_feature_dim=1, meta_feature_dim=0, prediction_dim=1, mem_hidden_dim=100,
+                                   agg_hidden_dim=100, mem_agg_hidden_dim=50, classifier_dim=50, local_search_iteration=0), use_cuda=True, logger=LOG)
+    m = tr._model_list[0]
+    # load the reference's seeded random weights (canonical keys of the golden file -> state dict, aliases included)
+    import json
+    alias = json.load(open(os.path.join(REPO, 'tests', 'golden', 'state_dict_alias_map.json')))
+    sd = {}
+    for key, canon in alias.items():
+        k = 'w__' + canon.replace('.', '__')
+        if key == '_global_step':
+            sd[key] = torch.zeros(1)
+        elif k in d.files:
+            sd[key] = torch.from_numpy(d[k])
+    missing, unexpected = m.load_state_dict(sd, strict=True), None
+    return tr, m
+
+
+@pytest.mark.parametrize('name', ['trace_neural_h32', 'trace_neural_h128'])
+def test_neural_forward_equals_reference_golden(name):
+    """np-nd-np with the reference's (seeded random) weights loaded from the aliased state dict: per-iteration
+    predictions and states within fp tolerance of the reference trace, thresholded final assignment identical."""
+    d = load_golden(name)
+    T, H = [int(x) for x in d['meta']]
+    tr, m = _neural_model(d, H)
+    dev = torch.device('cuda:0')
+    gm = torch.from_numpy(d['graph_map']).to(dev); bvm = torch.from_numpy(d['batch_variable_map']).to(dev)
+    bfm = torch.from_numpy(d['batch_function_map']).to(dev); ef = torch.from_numpy(d['edge_feature']).to(dev)
+    st = ((torch.from_numpy(d['init_prop_v']).to(dev), torch.from_numpy(d['init_prop_f']).to(dev)),
+          (torch.from_numpy(d['init_dec_v']).to(dev), torch.from_numpy(d['init_dec_f']).to(dev)))
+    rec = []
+
+    def check(active, prediction, sp):
+        rec.append(prediction[0].reshape(-1).cpu().numpy().copy())
+        tr._check_recurrence_termination(active, prediction, sp)
+
+    with torch.no_grad():
+        pred, (ps, ds) = m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None,
+                           is_training=False, iteration_num=T, check_termination=check, batch_replication=1)
+    assert m.last_run['path'] == 'stepwise' and m.last_run['iterations'] == T
+    for i, p in enumerate(rec):
+        np.testing.assert_allclose(p, d['pred_%d' % i], rtol=3e-4, atol=3e-5, err_msg='pred %d' % i)
+    np.testing.assert_allclose(ps[0].cpu().numpy(), d['prop_v_%d' % (T - 1)], rtol=3e-4, atol=3e-5)
+    np.testing.assert_allclose(ds[1].cpu().numpy(), d['dec_f_%d' % (T - 1)], rtol=3e-4, atol=3e-5)
+    np.testing.assert_array_equal(pred[0].cpu().numpy()[:, 0], d['final_prediction'])
