@@ -53,6 +53,81 @@ def cpu_baseline(args):
                        'scaled linearly to the batch' % (bs, res['iterations_run'], args.n, int(round(4.2 * args.n)), dt, inst_iters))
 
 
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 vector peak
+
+
+def bench_neural(args, dev, rank, world):
+    """configs[2]: fully neural PDP (np-nd-np, hidden_dim 128, layer widths 100/100/50/50) on random 3-SAT n=200.
+    A step = T iterations of propagate (2 deep-set aggregators) / decimate (2 GRU cells) / predict / terminate on a resident
+    batch with seeded random-init weights (the reference ships none).  SURVEY.md 8(d): 573 752 flop per edge and
+    48 500 per variable and iteration, all in fp32 MFMA."""
+    import logging
+    from pdp.trainer import SatFactorGraphTrainer
+    T = args.iters
+    m_cl = int(round(4.2 * args.n))
+    items = dataset.random_ksat_items(args.batch, args.n, 3, m=m_cl, seed=1000003 * rank)
+    b = dataset.to_torch(dataset.collate_segment(items), dev)
+    cfg = dict(model_type='np-nd-np', model_name='bench-np-nd-np', verbose=False, local_search_iteration=0, epsilon=0.5, rng='philox',
+               random_seed=1, hidden_dim=args.hidden, edge_feature_dim=1, meta_feature_dim=0, prediction_dim=1, mem_hidden_dim=100,
+               agg_hidden_dim=100, mem_agg_hidden_dim=50, classifier_dim=50, test_batch_limit=1 << 62, batch_size=args.batch,
+               test_recurrence_num=T)
+    torch.manual_seed(1234)
+    tr = SatFactorGraphTrainer(cfg, use_cuda=True, logger=logging.getLogger('bench'))
+    model = tr._model_list[0]
+    gm, bvm, bfm, ef = b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature']
+    E, V, F = gm.size(1), bvm.numel(), bfm.numel()
+    iters_done, step_ms = [], []
+
+    def step(record):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        with torch.no_grad():
+            st = model.get_init_state(gm, bvm, bfm, ef, None, randomized=False, batch_replication=1)
+            model(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None,
+                  is_training=False, iteration_num=T, check_termination=tr._check_recurrence_termination, batch_replication=1)
+        torch.cuda.synchronize()
+        if record:
+            step_ms.append(1e3 * (time.perf_counter() - t0)); iters_done.append(model.last_run['iterations'])
+
+    for _ in range(args.warmup):
+        step(False)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    tot = torch.tensor([float(sum(iters_done)), elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        iters_all = float(tot[0].item())
+        value = iters_all / elapsed
+        flops_iter = 573752.0 * E + 48500.0 * V
+        achieved = flops_iter * float(np.mean(iters_done)) / (float(np.mean(step_ms)) * 1e-3) / 1e12
+        print(json.dumps({
+            'metric': 'pdp_iterations_per_sec', 'value': value,
+            'unit': 'iterations/s (each iteration sweeps a batch of %d instances)' % args.batch, 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': "configs[2]: 'np-nd-np' hidden_dim=%d (100/100/50/50), random 3-SAT n=%d m=%d batch=%d T=%d per GPU, "
+                                   "seeded random-init weights" % (args.hidden, args.n, m_cl, args.batch, T),
+                       'E': E, 'V': V, 'F': F, 'iterations_per_step': float(np.mean(iters_done)), 'path': model.last_run['path'],
+                       'instance_iterations_per_sec': value * args.batch, 'parallelism': 'instances sharded, dp%d' % world},
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / MFMA_F32_PEAK_TFLOPS,
+                         'traffic': None, 'kernel': 'k_gru / k_agg_pre / k_agg_post (v_mfma_f32_32x32x2_f32)',
+                         'note': 'achieved = (573752 E + 48500 V) flop per iteration x iterations / step time (whole step, all kernels)'},
+            'cpu_baseline': None}))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -64,6 +139,9 @@ def main():
     ap.add_argument('--tolerance', type=float, default=0.02)
     ap.add_argument('--t_max', type=float, default=100)
     ap.add_argument('--walksat', type=int, default=100, help='Walk-SAT steps of the (untimed) solved-fraction pass')
+    ap.add_argument('--workload', choices=['sp', 'neural'], default='sp',
+                    help="sp: configs[1] (headline metric); neural: configs[2] 'np-nd-np' hidden_dim=128 on the same graph (fp32 MFMA)")
+    ap.add_argument('--hidden', type=int, default=128)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-batch', type=int, default=64)
     ap.add_argument('--cpu-sample-iters', type=int, default=40)
@@ -79,6 +157,8 @@ def main():
     native.require_gpu()
     dev = torch.device('cuda', local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
+    if args.workload == 'neural':
+        return bench_neural(args, dev, rank, world)
 
     # ---- synthetic batch, resident in HBM before the timed region ---------------------------------------------
     m = int(round(4.2 * args.n))

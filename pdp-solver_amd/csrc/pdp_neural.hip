@@ -32,7 +32,67 @@ __device__ __forceinline__ float act_apply(float v, int act)
     }
 }
 
-// one 32x32 output block: acc[r] = bias[col]; acc += A[32*mb + i][k] * Wt[k][32*nb + j], k ascending
+// Two 32x32 output blocks (both 32-row halves of the tile, same 32 columns):
+//   acc[mb][r] = bias[col];  acc[mb] += A[32*mb + i][k] * Wt[k][32*nb + j],  k ascending.
+// The B fragment (one float per lane and k-step, a coalesced 128-byte row segment per half-wave) is shared by the two
+// row blocks and prefetched into registers one 16-step chunk ahead (double buffered), so the L2 latency of the weight
+// stream is covered by 32 MFMAs (2048 cycles) instead of stalling every k-step.
+template <int MB, int BCH>
+__device__ __forceinline__ void mfma_chain(const float *A, int lda, int Kp, const float *__restrict__ Wt, int Np, int nb, int mb0,
+                                           const float *__restrict__ bias, f32x16 (&acc)[MB])
+{
+    const int l = threadIdx.x & 63, i = l & 31, kh = l >> 5;
+    const float b0 = bias ? bias[32 * nb + i] : 0.0f;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = b0;
+    const float *ap = A + (32 * mb0 + i) * lda + kh;
+    const float *bp = Wt + (size_t)kh * Np + 32 * nb + i;
+    const int steps = Kp >> 1;
+    const size_t bstride = (size_t)2 * Np;
+    float bufA[BCH], bufB[BCH];
+    int s0 = 0;
+    if (steps >= BCH) {
+#pragma unroll
+        for (int s = 0; s < BCH; ++s) bufA[s] = bp[(size_t)s * bstride];
+    }
+    while (s0 + BCH <= steps) {
+        const bool more1 = s0 + 2 * BCH <= steps;
+        if (more1) {
+#pragma unroll
+            for (int s = 0; s < BCH; ++s) bufB[s] = bp[(size_t)(s0 + BCH + s) * bstride];
+        }
+#pragma unroll
+        for (int s = 0; s < BCH; ++s) {
+            const int k0 = 2 * (s0 + s);
+#pragma unroll
+            for (int m = 0; m < MB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[32 * m * lda + k0], bufA[s], acc[m], 0, 0, 0);
+        }
+        s0 += BCH;
+        if (!more1) break;
+        const bool more2 = s0 + 2 * BCH <= steps;
+        if (more2) {
+#pragma unroll
+            for (int s = 0; s < BCH; ++s) bufA[s] = bp[(size_t)(s0 + BCH + s) * bstride];
+        }
+#pragma unroll
+        for (int s = 0; s < BCH; ++s) {
+            const int k0 = 2 * (s0 + s);
+#pragma unroll
+            for (int m = 0; m < MB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[32 * m * lda + k0], bufB[s], acc[m], 0, 0, 0);
+        }
+        s0 += BCH;
+        if (!more2) break;
+    }
+    for (int s = s0; s < steps; ++s) {
+        const float bv = bp[(size_t)s * bstride];
+#pragma unroll
+        for (int m = 0; m < MB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[32 * m * lda + 2 * s], bv, acc[m], 0, 0, 0);
+    }
+}
+// plain variant for the VALU-heavy aggregator layers: few registers (two workgroups per CU hide the weight-stream
+// latency better there than a deep register prefetch does; measured 17.4 vs 21.4 ms for k_agg_pre at config 3)
 __device__ __forceinline__ f32x16 mfma_block(const float *A, int lda, int Kp, const float *__restrict__ Wt, int Np, int nb, int mb,
                                              const float *__restrict__ bias)
 {
@@ -44,12 +104,15 @@ __device__ __forceinline__ f32x16 mfma_block(const float *A, int lda, int Kp, co
     const float *a_ptr = A + (32 * mb + i) * lda + kh;
     const float *b_ptr = Wt + (size_t)kh * Np + 32 * nb + i;
 #pragma unroll 8
-    for (int k0 = 0; k0 < Kp; k0 += 2) {
-        const float a = a_ptr[k0];
-        const float b = b_ptr[(size_t)k0 * Np];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-    }
+    for (int k0 = 0; k0 < Kp; k0 += 2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ptr[k0], b_ptr[(size_t)k0 * Np], acc, 0, 0, 0);
     return acc;
+}
+__device__ __forceinline__ void mfma_pair(const float *A, int lda, int Kp, const float *__restrict__ Wt, int Np, int nb,
+                                          const float *__restrict__ bias, f32x16 &acc0, f32x16 &acc1)
+{
+    acc0 = mfma_block(A, lda, Kp, Wt, Np, nb, 0, bias);
+    acc1 = mfma_block(A, lda, Kp, Wt, Np, nb, 1, bias);
 }
 
 // C/D layout of the 32x32 MFMA: reg r of lane l holds row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31
@@ -231,28 +294,30 @@ __global__ void __launch_bounds__(NTN) k_gru(int E, const float *__restrict__ st
     __syncthreads();
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int hb = g.Hp / 32;
-    const int nblocks = hb * (TM / 32);
     const int N3 = 3 * g.Hp;
-    for (int blk = wave; blk < nblocks; blk += NWAVES) {
-        const int nb = blk / (TM / 32), mb = blk % (TM / 32);
-        // gate order r, z, n (torch.nn.GRUCell); input and hidden products stay separate sums
-        const f32x16 ir = mfma_block(X, ldx, g.Kpx, g.Wt_ih, N3, nb, mb, g.b_ih);
-        const f32x16 hr = mfma_block(Hs, ldh, g.Kph, g.Wt_hh, N3, nb, mb, g.b_hh);
-        const f32x16 iz = mfma_block(X, ldx, g.Kpx, g.Wt_ih, N3, hb + nb, mb, g.b_ih);
-        const f32x16 hz = mfma_block(Hs, ldh, g.Kph, g.Wt_hh, N3, hb + nb, mb, g.b_hh);
-        const f32x16 in_ = mfma_block(X, ldx, g.Kpx, g.Wt_ih, N3, 2 * hb + nb, mb, g.b_ih);
-        const f32x16 hn = mfma_block(Hs, ldh, g.Kph, g.Wt_hh, N3, 2 * hb + nb, mb, g.b_hh);
+    for (int blk = wave; blk < hb * 2; blk += NWAVES) {
+        const int nb = blk >> 1, mb = blk & 1;
         const int col = 32 * nb + (l & 31);
+        // gate order r, z, n (torch.nn.GRUCell); input and hidden products stay separate sums (hgates + igates)
+        f32x16 ia[1], ha[1], rg, zg;
+        mfma_chain<1, 8>(X, ldx, g.Kpx, g.Wt_ih, N3, nb, mb, g.b_ih, ia);
+        mfma_chain<1, 8>(Hs, ldh, g.Kph, g.Wt_hh, N3, nb, mb, g.b_hh, ha);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rg[r] = pdp_sigmoidf(ha[0][r] + ia[0][r]);
+        mfma_chain<1, 8>(X, ldx, g.Kpx, g.Wt_ih, N3, hb + nb, mb, g.b_ih, ia);
+        mfma_chain<1, 8>(Hs, ldh, g.Kph, g.Wt_hh, N3, hb + nb, mb, g.b_hh, ha);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zg[r] = pdp_sigmoidf(ha[0][r] + ia[0][r]);
+        mfma_chain<1, 8>(X, ldx, g.Kpx, g.Wt_ih, N3, 2 * hb + nb, mb, g.b_ih, ia);
+        mfma_chain<1, 8>(Hs, ldh, g.Kph, g.Wt_hh, N3, 2 * hb + nb, mb, g.b_hh, ha);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = 32 * mb + acc_row(r, l);
             const int e = e0 + row;
             if (e < E && col < g.H) {
-                const float rg = pdp_sigmoidf(hr[r] + ir[r]);
-                const float zg = pdp_sigmoidf(hz[r] + iz[r]);
-                const float ng = pdp_tanhf(in_[r] + hn[r] * rg);
+                const float ng = pdp_tanhf(ia[0][r] + ha[0][r] * rg[r]);
                 const float hp = Hs[row * ldh + col];
-                const float hnew = (hp - ng) * zg + ng;
+                const float hnew = (hp - ng) * zg[r] + ng;
                 const float mk = rowmask ? rowmask[e] : 1.0f;
                 out[(size_t)e * g.H + col] = mk * hnew + (1.0f - mk) * hp;
             }
