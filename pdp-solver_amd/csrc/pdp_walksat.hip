@@ -6,6 +6,7 @@
 #include "pdp_device.hpp"
 
 #include <hipcub/hipcub.hpp>
+#include <stdlib.h>
 
 #define ST(s) ((hipStream_t)(s))
 #define DECL_RED __shared__ float redf[PDP_RED_SCRATCH]; __shared__ int redi[PDP_RED_SCRATCH];
@@ -221,6 +222,200 @@ __global__ void __launch_bounds__(PDP_NT) k_edge_mask2(PView pv)
     }
 }
 
+// ---- Walk-SAT, persistent form: all steps of one instance in one workgroup, state in LDS -----------------------------
+// Same arithmetic as the step-wise kernels above.  The only batch-global quantity of a step is the min of the random
+// candidate vector (util.sparse_argmax's x - x.min() + 1); the kernel assumes it is 0 (true whenever ANY variable of the
+// batch is inactive, outside every unsat clause, or belongs to a finished instance) and records per step whether an
+// exact zero existed; pdp_local_search falls back to the strict loop if the record has a hole.
+struct WsParams {
+    const float *pred; float *out;
+    int steps_cap; float epsilon; int rng_mode; const float *var_rand, *coin_rand; uint64_t seed;
+    int32_t *first_sat;        // [B] step at which the instance had no unsat clause (steps_cap if never)
+    uint32_t *spec_used, *spec_zero;   // [steps] any unsat instance evaluated the arg-max / an exact zero existed
+    const int32_t *inst_list;  // replay subset or NULL
+    const int32_t *cap_b;      // per-instance step cap (replication replay) or NULL
+};
+
+static size_t ws_lds_bytes(int n, int m, int e)
+{
+    auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    return 3 * a16((size_t)e * 2) + a16((size_t)(n + 1) * 2) + a16((size_t)(m + 1) * 2) + 4 * a16((size_t)n * 4) + 3 * a16((size_t)m * 4) + a16((size_t)m);
+}
+
+template <class T> __device__ __forceinline__ T *ws_carve(unsigned char *&p, size_t count)
+{
+    T *r = reinterpret_cast<T *>(p);
+    p += (count * sizeof(T) + 15) & ~(size_t)15;
+    return r;
+}
+
+__global__ void __launch_bounds__(256) k_walksat_lds(PView pv, WsParams wp)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    DECL_RED
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const Inst G = load_inst(pv, wp.inst_list ? wp.inst_list[blockIdx.x] : (int)blockIdx.x);
+    const int n = G.n, m = G.m, ne = G.e;
+    unsigned char *cp = smem;
+    uint16_t *pvv = ws_carve<uint16_t>(cp, ne), *pcc = ws_carve<uint16_t>(cp, ne), *e2p = ws_carve<uint16_t>(cp, ne);
+    uint16_t *v_ptr = ws_carve<uint16_t>(cp, n + 1), *f_ptr = ws_carve<uint16_t>(cp, m + 1);
+    float *av = ws_carve<float>(cp, n), *a = ws_carve<float>(cp, n), *negd = ws_carve<float>(cp, n), *uv = ws_carve<float>(cp, n);
+    float *af = ws_carve<float>(cp, m), *aggc = ws_carve<float>(cp, m), *degc = ws_carve<float>(cp, m);
+    uint8_t *unsat = ws_carve<uint8_t>(cp, m);
+    for (int p = tid; p < ne; p += nt) {
+        const int e = G.v_edges[p];
+        pvv[p] = (uint16_t)(G.e_var[e] | (G.sgn[e] < 0 ? 0x8000 : 0));
+        pcc[p] = (uint16_t)(G.e_fn[e] | ((G.emask[e] == 1.0f) ? 0x8000 : 0));
+        e2p[e] = (uint16_t)p;
+    }
+    for (int v = tid; v <= n; v += nt) v_ptr[v] = (uint16_t)G.v_ptr[v];
+    for (int c = tid; c <= m; c += nt) f_ptr[c] = (uint16_t)G.f_ptr[c];
+    for (int v = tid; v < n; v += nt) {
+        av[v] = G.av[v];
+        const float bit = (wp.pred[G.v0 + v] > 0.5f) ? 1.0f : 0.0f;
+        a[v] = G.av[v] * (2.0f * bit - 1.0f);
+    }
+    for (int c = tid; c < m; c += nt) af[c] = G.af[c];
+    __syncthreads();
+    for (int c = tid; c < m; c += nt) {          // number of active variables per clause: constant during the search
+        float deg = 0.0f;
+        for (int k = f_ptr[c]; k < f_ptr[c + 1]; ++k) deg = deg + (0.0f + av[pvv[e2p[k]] & 0x3fff]);
+        degc[c] = deg;
+    }
+    const int cap = wp.cap_b ? wp.cap_b[G.b] : wp.steps_cap;
+    int first_sat = cap;
+    for (int it = 0; it < cap; ++it) {
+        int cnt = 0;
+        for (int c = tid; c < m; c += nt) {
+            float agg = 0.0f;
+            for (int k = f_ptr[c]; k < f_ptr[c + 1]; ++k) {
+                const uint16_t pw = pvv[e2p[k]];
+                const int v = pw & 0x3fff;
+                agg = agg + (0.0f + ((pw & 0x8000) ? -1.0f : 1.0f) * (a[v] * av[v]));
+            }
+            aggc[c] = agg;
+            const float u = ((agg == -degc[c]) ? 1.0f : 0.0f) * af[c];
+            unsat[c] = (u == 1.0f) ? 1 : 0;
+            cnt += unsat[c];
+        }
+        cnt = block_reduce(cnt, OpAddI(), 0, redi);
+        cnt = __builtin_amdgcn_readfirstlane(cnt);
+        if (cnt == 0) { first_sat = it; break; }
+        int has_zero = 0;
+        for (int v = tid; v < n; v += nt) {
+            const float dist_v = a[v] * av[v];
+            float delta = 0.0f, acc = 0.0f;
+            for (int p = v_ptr[v]; p < v_ptr[v + 1]; ++p) {
+                const uint16_t cw = pcc[p];
+                const int c = cw & 0x3fff;
+                const float dist = 0.0f + ((pvv[p] & 0x8000) ? -1.0f : 1.0f) * dist_v;
+                const float others = (0.0f + aggc[c]) - dist;
+                const float critical = ((others == (1.0f - (0.0f + degc[c]))) ? 1.0f : 0.0f) * ((cw & 0x8000) ? 1.0f : 0.0f);
+                delta = delta + critical * dist;
+                acc = acc + (float)unsat[c];
+            }
+            acc = acc * av[v];
+            const float u = (wp.rng_mode == PDP_RNG_STREAM) ? wp.var_rand[(size_t)it * pv.V + G.v0 + v]
+                                                             : pdp_philox_uniform(wp.seed, PDP_RNG_STREAM_WSVAR, (uint32_t)it, (uint32_t)(G.v0 + v));
+            const float r = ((acc > 0.0f) ? 1.0f : 0.0f) * u;
+            negd[v] = -delta; uv[v] = r;
+            if (r == 0.0f) has_zero = 1;
+        }
+        __syncthreads();
+        has_zero = __syncthreads_or(has_zero);
+        Inst L = G;                                  // arg-max helpers only need n and the thread layout
+        const int greedy = d_instance_argmax(L, negd, 0.0f, redf, redi);
+        const int randi = d_instance_argmax(L, uv, 0.0f, redf, redi);
+        if (tid == 0) {
+            atomicOr(&wp.spec_used[it], 1u);
+            if (has_zero) atomicOr(&wp.spec_zero[it], 1u);
+            const float u = (wp.rng_mode == PDP_RNG_STREAM) ? wp.coin_rand[(size_t)it * pv.B + G.b]
+                                                             : pdp_philox_uniform(wp.seed, PDP_RNG_STREAM_WSCOIN, (uint32_t)it, (uint32_t)G.b);
+            const int ind = (u > wp.epsilon) ? greedy : randi;
+            if (ind >= 0) a[ind] = -a[ind];
+        }
+        __syncthreads();
+    }
+    for (int v = tid; v < n; v += nt) wp.out[G.v0 + v] = (a[v] + 1.0f) / 2.0f;
+    if (tid == 0) wp.first_sat[G.b] = first_sat;
+}
+
+__global__ void k_ws_group_stop(int B0, int R, int cap, const int32_t *first_sat, uint32_t *stop /*max over originals of min over replicas*/)
+{
+    const int b0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b0 >= B0) return;
+    int mn = cap;
+    for (int r = 0; r < R; ++r) { const int f = first_sat[b0 + r * B0]; mn = f < mn ? f : mn; }
+    atomicMax(stop, (uint32_t)mn);
+}
+__global__ void k_ws_replay_list(int B, int stop, const int32_t *first_sat, int32_t *cap_b, int32_t *list, uint32_t *count)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    cap_b[b] = stop;
+    if (first_sat[b] > stop) list[atomicAdd(count, 1u)] = b;     // ran past the global stop in pass 1: redo with the cap
+}
+
+// returns PDP_OK and *done = 1 if the persistent search produced the reference result, *done = 0 if the caller must run the strict loop
+static int local_search_persistent(pdp_problem *p, const float *pred, int iterations, float epsilon, int rng_mode, const float *var_rand,
+                                   const float *coin_rand, uint64_t seed, float *out, int32_t *steps_host, hipStream_t st, int *done)
+{
+    *done = 0;
+    const size_t lds = ws_lds_bytes(p->max_n, p->max_m, p->max_e);
+    if (!p->fn_edges_identity || lds > 64 * 1024 || p->max_n >= 16384 || p->max_m >= 16384 || p->max_e >= 65535 || iterations <= 0) return PDP_OK;
+    const size_t words = 2 * (size_t)iterations + 4;
+    uint32_t *spec = nullptr;
+    PDP_HIP_CHECK(hipMalloc((void **)&spec, words * 4 + (size_t)p->B * 4 * 3));
+    int32_t *first_sat = (int32_t *)(spec + words), *cap_b = first_sat + p->B, *list = cap_b + p->B;
+    PDP_HIP_CHECK(hipMemsetAsync(spec, 0, words * 4, st));
+    PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_walksat_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_edge_mask2, dim3(p->B), dim3(PDP_NT), 0, st, make_view(p));       // solver.py:439-440
+    p->has_edge_mask = 1;
+    WsParams wp;
+    wp.pred = pred; wp.out = out; wp.steps_cap = iterations; wp.epsilon = epsilon; wp.rng_mode = rng_mode; wp.var_rand = var_rand;
+    wp.coin_rand = coin_rand; wp.seed = seed; wp.first_sat = first_sat; wp.spec_used = spec; wp.spec_zero = spec + iterations;
+    wp.inst_list = nullptr; wp.cap_b = nullptr;
+    hipLaunchKernelGGL(k_walksat_lds, dim3(p->B), dim3(256), lds, st, make_view(p), wp);
+    PDP_LAUNCH_CHECK();
+    uint32_t *ctl = spec + 2 * (size_t)iterations;       // [0] global stop step, [1] replay count
+    hipLaunchKernelGGL(k_ws_group_stop, dim3((p->B0 + 255) / 256), dim3(256), 0, st, p->B0, p->R, iterations, first_sat, ctl);
+    uint32_t *host = (uint32_t *)malloc(words * 4);
+    PDP_HIP_CHECK(hipMemcpyAsync(host, spec, words * 4, hipMemcpyDeviceToHost, st));
+    PDP_HIP_CHECK(hipStreamSynchronize(st));
+    const int stop = (int)host[2 * (size_t)iterations];
+    int status = PDP_OK;
+    if (p->R > 1 && stop < iterations) {
+        // replicas that were still searching at the global stop step must be truncated there (solver.py:446-449)
+        hipLaunchKernelGGL(k_ws_replay_list, dim3((p->B + 255) / 256), dim3(256), 0, st, p->B, stop, first_sat, cap_b, list, ctl + 1);
+        uint32_t cnt = 0;
+        PDP_HIP_CHECK(hipMemcpyAsync(&cnt, ctl + 1, 4, hipMemcpyDeviceToHost, st));
+        PDP_HIP_CHECK(hipStreamSynchronize(st));
+        if (cnt) {
+            wp.inst_list = list; wp.cap_b = cap_b;
+            hipLaunchKernelGGL(k_walksat_lds, dim3(cnt), dim3(256), lds, st, make_view(p), wp);
+            PDP_HIP_CHECK(hipStreamSynchronize(st));
+        }
+    }
+    // speculation record: every step < stop in which some instance searched needs an exact zero somewhere.  An instance that
+    // finished at step f supplies zeros for every later step (its candidates are all 0), so only steps before the first finish count.
+    bool ok = true;
+    int first_finish = iterations;
+    {
+        int32_t *fs_host = (int32_t *)malloc(sizeof(int32_t) * (size_t)p->B);
+        if (hipMemcpy(fs_host, first_sat, sizeof(int32_t) * (size_t)p->B, hipMemcpyDeviceToHost) != hipSuccess) status = PDP_ERR_HIP;
+        for (int b = 0; b < p->B; ++b) first_finish = fs_host[b] < first_finish ? fs_host[b] : first_finish;
+        free(fs_host);
+    }
+    for (int t = 0; t < stop && t < first_finish && ok; ++t) if (host[t] && !host[iterations + t]) ok = false;
+    free(host);
+    (void)hipFree(spec);
+    if (status != PDP_OK) return status;
+    if (!ok) return PDP_OK;          // caller runs the strict loop on the untouched inputs
+    if (steps_host) *steps_host = stop;
+    *done = 1;
+    return PDP_OK;
+}
+
 extern "C" int pdp_local_search(pdp_problem *p, const float *pred, int iterations, float epsilon, int rng_mode,
                                 const float *var_rand, const float *coin_rand, uint64_t seed, float *out,
                                 int32_t *steps_host, void *stream)
@@ -228,6 +423,12 @@ extern "C" int pdp_local_search(pdp_problem *p, const float *pred, int iteration
     PDP_REQUIRE(p && p->av && pred && out, "NULL argument / state not bound");
     PDP_REQUIRE(rng_mode == PDP_RNG_PHILOX || iterations == 0 || (var_rand && coin_rand), "stream mode needs the drawn values");
     hipStream_t st = ST(stream);
+    if (!getenv("PDP_WALKSAT_STRICT")) {
+        int done = 0;
+        const int rc = local_search_persistent(p, pred, iterations, epsilon, rng_mode, var_rand, coin_rand, seed, out, steps_host, st, &done);
+        if (rc != PDP_OK) return rc;
+        if (done) return PDP_OK;
+    }
     const PView pv = make_view(p);
     float *a = p->ws_v[0], *negdelta = p->ws_v[1], *uv = p->ws_v[2], *unsat_b = p->ws_b[0];
     hipLaunchKernelGGL(k_ws_init, dim3(grid_for(p->V)), dim3(256), 0, st, p->V, p->av, pred, a);
