@@ -562,17 +562,24 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
         const bool poisoned = t >= poison_from;
         iters = t + 1;
         float *const Eold = cur ? L.EB : L.EA, *const Enew = cur ? L.EA : L.EB;
-        // ---- E1: per-slot logs -------------------------------------------------------------------------------------
-        for (int p = tid; p < ne; p += nt) {
-            float x = pdp_safe_log_fin(QU[p], PDP_SP_EPS);
-            float y = pdp_safe_log_fin(1.0f - Eold[p], PDP_SP_EPS);
+        // ---- E1: per-slot logs, two slots per trip (independent chains for the scheduler / packed fp32 ops) -------------
+        for (int p0 = tid; p0 < ne; p0 += 2 * nt) {
+            const int p1 = p0 + nt;
+            const bool has1 = p1 < ne;
+            const int q1 = has1 ? p1 : p0;
+            float x0 = pdp_safe_log_fin(QU[p0], PDP_SP_EPS), x1 = pdp_safe_log_fin(QU[q1], PDP_SP_EPS);
+            float y0 = pdp_safe_log_fin(1.0f - Eold[p0], PDP_SP_EPS), y1 = pdp_safe_log_fin(1.0f - Eold[q1], PDP_SP_EPS);
             if (use_em) {
-                uint16_t c = pcc[p];
-                const float em = (c & PC_EM) ? 1.0f : 0.0f;
-                x = x * em; y = y * em;
-                if (em_dirty) { c = (uint16_t)((c & ~PC_EM_USED) | ((c & PC_EM) ? PC_EM_USED : 0)); pcc[p] = c; }
+                uint16_t c0 = pcc[p0], c1 = pcc[q1];
+                const float em0 = (c0 & PC_EM) ? 1.0f : 0.0f, em1 = (c1 & PC_EM) ? 1.0f : 0.0f;
+                x0 = x0 * em0; y0 = y0 * em0; x1 = x1 * em1; y1 = y1 * em1;
+                if (em_dirty) {
+                    pcc[p0] = (uint16_t)((c0 & ~PC_EM_USED) | ((c0 & PC_EM) ? PC_EM_USED : 0));
+                    if (has1) pcc[p1] = (uint16_t)((c1 & ~PC_EM_USED) | ((c1 & PC_EM) ? PC_EM_USED : 0));
+                }
             }
-            X[p] = x; Y[p] = y;
+            X[p0] = x0; Y[p0] = y0;
+            if (has1) { X[p1] = x1; Y[p1] = y1; }
         }
         last_use_em = use_em; em_dirty = 0;
         __syncthreads();
@@ -641,7 +648,6 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
                 if (eta_new != eta_new) nan_seen = 1;
                 QU[p] = qu_new;
                 Enew[p] = eta_new;
-                X[p] = pdp_safe_exp_fast(30.0f * eta_new);
                 if (has_prev) {
                     const float pe = prev_from_global ? sp.src_prev[G.e0 + G.v_edges[p]] : eta_old;
                     float d = pdp_abs(pe - eta_new);
@@ -653,9 +659,12 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
         did_prop = 1;
         __syncthreads();
         PROF_MARK(3);                                        // E2
-        // ---- P4: per-variable smooth maxima (two rows per variable: survey / difference), partial reductions in registers
+        // ---- P4: per-variable smooth maxima.  Site 0 (survey gate `max <= 1e-10`, pdp_decimate.py:127-133) is decided lazily:
+        // smooth_max_v >= eta_max_v / deg_v (the largest survey carries the largest weight), so one active variable with
+        // eta_max_v >= 2^-21 * deg_v proves (x + 1) - 1 >= 2^-23 > 1e-10 and no exp is needed; an exact zero of the operand
+        // exists iff some variable is inactive or has only zero surveys.  Otherwise the exact weights are computed below.
         float m1 = -PDP_INF, m2 = -PDP_INF;
-        int bits = nan_seen ? 4 : 0;                       // bit0: xv1 has an exact 0, bit1: xv2 has one, bit2: NaN
+        int bits = nan_seen ? 4 : 0;                       // bit0: xv1 has an exact 0, bit1: xv2 has one, bit2: NaN, bit3: gate certified open
         {
             const uint16_t *const v_ptr = L.v_ptr;
             const float *const av = L.av;
@@ -663,18 +672,22 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
             for (int r = tid; r < rows; r += nt) {
                 const bool second = r >= n;
                 const int v = second ? r - n : r;
-                float num = 0.0f, den = 0.0f;
                 const int a = v_ptr[v], bnd = v_ptr[v + 1];
                 if (!second) {
+                    float emax = 0.0f;
                     int p = a;
                     for (; p + 3 < bnd; p += 4) {
-                        const float c0 = X[p], c1 = X[p + 1], c2 = X[p + 2], c3 = X[p + 3];
                         const float e0 = Enew[p], e1 = Enew[p + 1], e2 = Enew[p + 2], e3 = Enew[p + 3];
-                        num = num + e0 * c0; den = den + c0; num = num + e1 * c1; den = den + c1;
-                        num = num + e2 * c2; den = den + c2; num = num + e3 * c3; den = den + c3;
+                        emax = fmaxf(fmaxf(emax, e0), fmaxf(e1, fmaxf(e2, e3)));      // NaN surveys are flagged in E2 already
                     }
-                    for (; p < bnd; ++p) { const float c0 = X[p]; num = num + Enew[p] * c0; den = den + c0; }
-                } else if (!prev_from_global) {
+                    for (; p < bnd; ++p) emax = fmaxf(emax, Enew[p]);
+                    const float a_v = av[v];
+                    if (a_v == 0.0f || !(emax > 0.0f)) bits |= 1;
+                    if (a_v == 1.0f && emax >= 4.76837158203125e-7f * (float)(bnd - a)) bits |= 8;
+                    continue;
+                }
+                float num = 0.0f, den = 0.0f;
+                if (!prev_from_global) {
                     int p = a;
                     for (; p + 1 < bnd; p += 2) {
                         const float c0 = Y[p], c1 = Y[p + 1];
@@ -697,10 +710,9 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
                     }
                 }
                 const float rr = (num / pdp_max_c(den, 1.0f)) * av[v];
-                const float tt = (rr - 0.0f) + 1.0f;
                 if (rr != rr) bits |= 4;
-                if (!second) { if (rr == 0.0f) bits |= 1; m1 = pdp_max(m1, tt); }
-                else { if (rr == 0.0f) bits |= 2; m2 = pdp_max(m2, tt); }
+                if (rr == 0.0f) bits |= 2;
+                m2 = pdp_max(m2, (rr - 0.0f) + 1.0f);
             }
         }
         PROF_MARK(4);                                        // P4
@@ -718,8 +730,27 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
         __syncthreads();
         m1 = uni_f(m1); m2 = uni_f(m2); bits = UNI(bits);          // workgroup-uniform: keep the control flow scalar
         PROF_MARK(5);                                        // P5
-        if (other_rows) { m1 = pdp_max(m1, 0.0f); m2 = pdp_max(m2, 0.0f); }
-        const float g = (m1 + 0.0f) - 1.0f, dmax = (m2 + 0.0f) - 1.0f;
+        float g;
+        if (bits & 8) {
+            g = 1.0f;                                       // certified: the gate stays open, its exact value is never used
+        } else {
+            // exact path (rare: every active variable has only vanishing surveys): util.py:282-286 + :267-275
+            for (int p = tid; p < ne; p += nt) X[p] = pdp_safe_exp_fast(30.0f * Enew[p]);
+            __syncthreads();
+            float mm = -PDP_INF;
+            for (int v = tid; v < n; v += nt) {
+                float num = 0.0f, den = 0.0f;
+                for (int p = L.v_ptr[v]; p < L.v_ptr[v + 1]; ++p) { const float c0 = X[p]; num = num + Enew[p] * c0; den = den + c0; }
+                const float rr = (num / pdp_max_c(den, 1.0f)) * L.av[v];
+                mm = pdp_max(mm, (rr - 0.0f) + 1.0f);
+            }
+            mm = block_reduce(mm, OpMaxNan(), -PDP_INF, redf);
+            mm = uni_f(mm);
+            if (other_rows) mm = pdp_max(mm, 0.0f);
+            g = (mm + 0.0f) - 1.0f;
+        }
+        if (other_rows) m2 = pdp_max(m2, 0.0f);
+        const float dmax = (m2 + 0.0f) - 1.0f;
         const int z1 = bits & 1, z2 = (bits >> 1) & 1;
         nan_seen = (bits >> 2) & 1;
         if (nan_seen && !poisoned) {
