@@ -235,8 +235,78 @@ PDP_HD float pdp_logf_pos(float x)
     r = fmaf(fe, 0.693359375f, r);
     return (x != x) ? x : r;
 }
-/* safe_log for a finite-or-NaN argument (eps > 0 makes the log argument positive) */
-PDP_HD float pdp_safe_log_fin(float x, float eps) { return pdp_logf_pos(pdp_max_c(x, eps)); }
+/* ---- select-free forms for the hot loops --------------------------------------------------------
+ * On gfx950 a v_cmp + v_cndmask pair costs about four FMAs (the compare result travels through an SGPR pair), so the
+ * per-edge code avoids selects: clamps are v_max_f32, mantissa / exponent come from v_frexp_*, the "m < sqrt(1/2)"
+ * decision is integer arithmetic on the bit pattern, and a NaN argument is re-injected at the end as x - x (exactly 0
+ * for finite x).  Same results as the general functions on the stated domains (tests/test_hip_ops.py,
+ * tests/test_oracle_golden.py). */
+PDP_HD float pdp_fmaxf(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fmaxf(a, b);                           /* v_max_f32: the non-NaN operand wins */
+#else
+    return (a != a) ? b : ((b != b) ? a : ((a < b) ? b : a));
+#endif
+}
+
+/* log(max(x, eps)) for a finite-or-NaN x and eps > 0 (the reference's safe_log on everything the SP update feeds it) */
+PDP_HD float pdp_safe_log_fin(float x, float eps)
+{
+    const float xm = pdp_fmaxf(x, eps);                     /* NaN -> eps here, NaN again through the last line */
+#if defined(__HIP_DEVICE_COMPILE__)
+    float m = __builtin_amdgcn_frexp_mantf(xm);             /* xm = m * 2^e, m in [0.5, 1), exact, denormals included */
+    int e = __builtin_amdgcn_frexp_expf(xm);
+#else
+    const uint32_t u0 = pdp_f2bits(xm);
+    const int den = u0 < 0x00800000u;
+    const float xn = xm * (den ? 8388608.0f : 1.0f);
+    const uint32_t u = pdp_f2bits(xn);
+    int e = (den ? -23 : 0) + (int)(u >> 23) - 126;
+    float m = pdp_bits2f((u & 0x007fffffu) | 0x3f000000u);
+#endif
+    const uint32_t lt = (pdp_f2bits(m) - 0x3f3504f3u) >> 31;   /* m < 0.70710677f: positive floats order like their bit patterns */
+    e = e - (int)lt;
+    m = pdp_scale2(m, (int)lt) - 1.0f;                       /* (lt ? m + m : m) - 1 */
+    const float z = m * m;
+    float y = 7.0376836292e-2f;
+    y = fmaf(y, m, -1.1514610310e-1f);
+    y = fmaf(y, m, 1.1676998740e-1f);
+    y = fmaf(y, m, -1.2420140846e-1f);
+    y = fmaf(y, m, 1.4249322787e-1f);
+    y = fmaf(y, m, -1.6668057665e-1f);
+    y = fmaf(y, m, 2.0000714765e-1f);
+    y = fmaf(y, m, -2.4999993993e-1f);
+    y = fmaf(y, m, 3.3333331174e-1f);
+    y = (y * m) * z;
+    const float fe = (float)e;
+    y = fmaf(fe, -2.12194440e-4f, y);
+    y = fmaf(-0.5f, z, y);
+    float r = m + y;
+    r = fmaf(fe, 0.693359375f, r);
+    return r + (x - x);
+}
+
+/* e^x for a finite x <= 30 or NaN (the reference's safe_exp wherever its argument is a finite sum of logs).
+ * No "x < -104 -> 0" select: p * 2^n rounds to zero by itself there (e^-104 = 0.486 * 2^-149). */
+PDP_HD float pdp_expf_fin_le30(float x)
+{
+    const float xc = pdp_fmaxf(x, -104.5f);
+    const float t = xc * 1.44269504088896341f;
+    const float nf = (t + 12582912.0f) - 12582912.0f;
+    float r = fmaf(nf, -0.693359375f, xc);
+    r = fmaf(nf, 2.12194440e-4f, r);
+    const float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    p = fmaf(p, z, r);
+    p = p + 1.0f;
+    return pdp_scale2(p, (int)nf) + (x - x);
+}
 /* safe_exp with the lean pieces (valid for every input: the clamp bounds the argument) */
 PDP_HD float pdp_safe_exp_fast(float x) { return pdp_expf_le30(pdp_min_c(x, 30.0f)); }
 

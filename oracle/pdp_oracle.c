@@ -975,6 +975,7 @@ ORC_API void orc_math_apply(int fn, const float *x, float *y, int64_t n)
         case 9: y[i] = pdp_safe_exp_fast(x[i]); break;
         case 10: y[i] = pdp_safe_log_fin(x[i], PDP_SP_EPS); break;
         case 11: y[i] = pdp_safe_log_fin(x[i], PDP_SCORER_EPS); break;
+        case 12: y[i] = pdp_expf_fin_le30(x[i]); break;
         default: y[i] = x[i];
         }
     }

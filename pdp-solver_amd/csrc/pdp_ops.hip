@@ -661,6 +661,7 @@ __global__ void k_math_apply(int fn, const float *x, float *y, int64_t n)
         case 9: r = pdp_safe_exp_fast(x[i]); break;
         case 10: r = pdp_safe_log_fin(x[i], PDP_SP_EPS); break;
         case 11: r = pdp_safe_log_fin(x[i], PDP_SCORER_EPS); break;
+        case 12: r = pdp_expf_fin_le30(x[i]); break;
         default: r = x[i];
         }
         y[i] = r;

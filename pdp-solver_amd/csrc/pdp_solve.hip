@@ -438,17 +438,83 @@ extern "C" int pdp_debug_phase_cycles(unsigned long long *out_host, int reset)
     if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)) != hipSuccess) return 1; }
     return 0;
 }
+#define PROF_COUNT(i) do { if (threadIdx.x == 0) atomicAdd(&g_phase_cycles[i], 1ull); } while (0)
 #else
 #define PROF_DECL
 #define PROF_MARK(i)
+#define PROF_COUNT(i)
 #endif
+// Four independent evaluations side by side.  A dependent chain of VALU ops issues one instruction per ~4.3 cycles on
+// gfx950, two or more independent chains in the same wave reach ~2.2 (tools/micro/pk_rate.hip), so the transcendental
+// polynomials of one slot (four exps) or two slots (four logs) are evaluated as 4-vectors: every step is the same IEEE
+// operation per element as the scalar pdp_expf_fin_le30 / pdp_safe_log_fin of include/pdp_math.h.
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef int i4v __attribute__((ext_vector_type(4)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4v vfma(f4v a, f4v b, f4v c) { return __builtin_elementwise_fma(a, b, c); }
+
+__device__ __forceinline__ f4v exp4_fin_le30(f4v x)
+{
+    const f4v xc = __builtin_elementwise_max(x, (f4v)(-104.5f));
+    const f4v t = xc * 1.44269504088896341f;
+    const f4v nf = (t + 12582912.0f) - 12582912.0f;
+    f4v r = vfma(nf, (f4v)(-0.693359375f), xc);
+    r = vfma(nf, (f4v)(2.12194440e-4f), r);
+    const f4v z = r * r;
+    f4v p = (f4v)(1.9875691500e-4f);
+    p = vfma(p, r, (f4v)(1.3981999507e-3f));
+    p = vfma(p, r, (f4v)(8.3334519073e-3f));
+    p = vfma(p, r, (f4v)(4.1665795894e-2f));
+    p = vfma(p, r, (f4v)(1.6666665459e-1f));
+    p = vfma(p, r, (f4v)(5.0000001201e-1f));
+    p = vfma(p, z, r);
+    p = p + 1.0f;
+    const i4v n = __builtin_convertvector(nf, i4v);
+    f4v res;
+    res.x = __builtin_ldexpf(p.x, n.x); res.y = __builtin_ldexpf(p.y, n.y); res.z = __builtin_ldexpf(p.z, n.z); res.w = __builtin_ldexpf(p.w, n.w);
+    return res + (x - x);
+}
+
+__device__ __forceinline__ f4v log4_fin(f4v x, float eps)
+{
+    const f4v xm = __builtin_elementwise_max(x, (f4v)(eps));
+    f4v m; i4v e;
+    m.x = __builtin_amdgcn_frexp_mantf(xm.x); m.y = __builtin_amdgcn_frexp_mantf(xm.y); m.z = __builtin_amdgcn_frexp_mantf(xm.z); m.w = __builtin_amdgcn_frexp_mantf(xm.w);
+    e.x = __builtin_amdgcn_frexp_expf(xm.x); e.y = __builtin_amdgcn_frexp_expf(xm.y); e.z = __builtin_amdgcn_frexp_expf(xm.z); e.w = __builtin_amdgcn_frexp_expf(xm.w);
+    const u4v lt = (__builtin_bit_cast(u4v, m) - 0x3f3504f3u) >> 31;
+    e = e - __builtin_bit_cast(i4v, lt);
+    const i4v lti = __builtin_bit_cast(i4v, lt);
+    m.x = __builtin_ldexpf(m.x, lti.x); m.y = __builtin_ldexpf(m.y, lti.y); m.z = __builtin_ldexpf(m.z, lti.z); m.w = __builtin_ldexpf(m.w, lti.w);
+    m = m - 1.0f;
+    const f4v z = m * m;
+    f4v y = (f4v)(7.0376836292e-2f);
+    y = vfma(y, m, (f4v)(-1.1514610310e-1f));
+    y = vfma(y, m, (f4v)(1.1676998740e-1f));
+    y = vfma(y, m, (f4v)(-1.2420140846e-1f));
+    y = vfma(y, m, (f4v)(1.4249322787e-1f));
+    y = vfma(y, m, (f4v)(-1.6668057665e-1f));
+    y = vfma(y, m, (f4v)(2.0000714765e-1f));
+    y = vfma(y, m, (f4v)(-2.4999993993e-1f));
+    y = vfma(y, m, (f4v)(3.3333331174e-1f));
+    y = (y * m) * z;
+    const f4v fe = __builtin_convertvector(e, f4v);
+    y = vfma(fe, (f4v)(-2.12194440e-4f), y);
+    y = vfma((f4v)(-0.5f), z, y);
+    f4v r = m + y;
+    r = vfma(fe, (f4v)(0.693359375f), r);
+    return r + (x - x);
+}
+
+// select-free decoding of the packed slot words (a v_cmp + v_cndmask pair costs ~4 FMAs on gfx950)
+__device__ __forceinline__ float slot_sign(uint16_t pw) { return __uint_as_float(0x3f800000u | ((uint32_t)(pw & 0x8000u) << 16)); }      // bit 15 set: -1, else +1
+__device__ __forceinline__ float bit15_to_float(uint16_t w) { return __uint_as_float((uint32_t)((int32_t)((uint32_t)w << 16) >> 31) & 0x3f800000u); }   // bit 15 set: 1, else 0
 __device__ __forceinline__ float uni_f(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
 
 // P6, cold: SurveyScorer + arg-max + set_variables (pdp_decimate.py:152-171).  Returns 1 if a variable was fixed;
 // *spec gets bit 0 "coeff has an exact zero", bit 1 "NaN coefficient".
 template <bool FORCE>
 __device__ __noinline__ int lds_decimate(unsigned char *smem, int b, int n, int m, int ne, int cur, int active, float pi,
-                                         float *is_sat_b, int *spec)
+                                         float *is_sat_b, int *spec, int *verified)
 {
     __shared__ float redf2[PDP_RED_SCRATCH];
     __shared__ int redi2[PDP_RED_SCRATCH];
@@ -485,13 +551,101 @@ __device__ __noinline__ int lds_decimate(unsigned char *smem, int b, int n, int 
     if (!(active && anynz && !cn && li >= 0)) return 0;
     const float sgn_li = pdp_sign(score[li]);
     __syncthreads();
+    SimplifyScratch ss;
+    ss.assign = assign; ss.deg = reinterpret_cast<int32_t *>(L.xv1); ss.sdeg = reinterpret_cast<int32_t *>(L.xv2);
+    ss.flag_v = L.flag_v; ss.flag_f = reinterpret_cast<uint8_t *>(L.S); ss.flag_f2 = ss.flag_f + ((m + 15) & ~15); ss.red = redi2;
+
+    // ---- fast path ------------------------------------------------------------------------------------------------
+    // A problem that went through simplify() has no active unit clause and no active pure variable (both loops of
+    // solver.py:228-273 / :180-203 run to a fix-point, and peeling never shrinks a clause that stays active).  Under that
+    // invariant fixing ONE variable can only create unit clauses among its own clauses and pure variables among the
+    // variables of the clauses it satisfied, so the full-instance sweeps of the reference shrink to the neighbourhood of
+    // the variable.  The invariant is checked once per launch (the state may have been written from outside); anything
+    // the neighbourhood scan finds is handed to the general routines, which redo the reference's sweeps.
+    if (*verified == 0) {
+        int bad = 0;
+        for (int c = tid; c < m; c += nt) {
+            if (L.af[c] == 1.0f) {
+                float deg = 0.0f;
+                for (int k = L.f_ptr[c]; k < L.f_ptr[c + 1]; ++k) deg = deg + L.av[L.pvv[L.e2p[k]] & 0x3fff];
+                if (deg == 1.0f) bad = 1;
+            }
+        }
+        for (int v = tid; v < n; v += nt) {
+            if (L.av[v] == 1.0f) {
+                int d = 0, sd = 0;
+                int p = L.v_ptr[v];
+                const int bnd = L.v_ptr[v + 1];
+                for (; p + 3 < bnd; p += 4) {
+                    const uint16_t c0 = L.pcc[p], c1 = L.pcc[p + 1], c2 = L.pcc[p + 2], c3 = L.pcc[p + 3];
+                    const int a0 = L.af[c0 & 0x3fff] == 1.0f, a1 = L.af[c1 & 0x3fff] == 1.0f, a2 = L.af[c2 & 0x3fff] == 1.0f, a3 = L.af[c3 & 0x3fff] == 1.0f;
+                    d += a0 + a1 + a2 + a3;
+                    sd += ((L.pvv[p] & 0x8000) ? -a0 : a0) + ((L.pvv[p + 1] & 0x8000) ? -a1 : a1) + ((L.pvv[p + 2] & 0x8000) ? -a2 : a2) + ((L.pvv[p + 3] & 0x8000) ? -a3 : a3);
+                }
+                for (; p < bnd; ++p) { const int a0 = L.af[L.pcc[p] & 0x3fff] == 1.0f; d += a0; sd += (L.pvv[p] & 0x8000) ? -a0 : a0; }
+                if (d == (sd < 0 ? -sd : sd)) bad = 1;
+            }
+        }
+        *verified = __syncthreads_or(bad) ? 2 : 1;
+    }
+    if (*verified == 1) {
+        const int a = L.v_ptr[li], deg_li = L.v_ptr[li + 1] - a;
+        const bool neg_li = sgn_li < 0.0f;
+        for (int v = tid; v < n; v += nt) L.flag_v[v] = 0;
+        __syncthreads();
+        // _set_variable_core for a one-hot assignment: a clause is switched off iff one of its literals of `li` is satisfied
+        for (int j = tid; j < deg_li; j += nt) {
+            const int p = a + j;
+            const int c = L.pcc[p] & 0x3fff;
+            const bool satisfied = ((L.pvv[p] & 0x8000) != 0) == neg_li;
+            if (satisfied && L.af[c] == 1.0f) {
+                L.af[c] = 0.0f;
+                for (int k = L.f_ptr[c]; k < L.f_ptr[c + 1]; ++k) {
+                    const int u = L.pvv[L.e2p[k]] & 0x3fff;
+                    if (u != li && L.av[u] == 1.0f) L.flag_v[u] = 1;      // lost a clause: may have become pure
+                }
+            }
+        }
+        if (tid == 0) { L.av[li] = 0.0f; L.sol[li] = (sgn_li + 1.0f) / 2.0f; }
+        __syncthreads();
+        int single = 0;
+        for (int j = tid; j < deg_li; j += nt) {
+            const int c = L.pcc[a + j] & 0x3fff;
+            if (L.af[c] == 1.0f) {
+                float deg = 0.0f;
+                for (int k = L.f_ptr[c]; k < L.f_ptr[c + 1]; ++k) deg = deg + L.av[L.pvv[L.e2p[k]] & 0x3fff];
+                if (deg == 1.0f) single = 1;
+            }
+        }
+        if (__syncthreads_or(single)) {
+            d_simplify(I, ss, is_sat_b);
+            return 1;
+        }
+        int pure = 0;
+        for (int v = tid; v < n; v += nt) {
+            if (L.flag_v[v]) {
+                int d = 0, sd = 0;
+                int p = L.v_ptr[v];
+                const int bnd = L.v_ptr[v + 1];
+                for (; p + 3 < bnd; p += 4) {
+                    const uint16_t c0 = L.pcc[p], c1 = L.pcc[p + 1], c2 = L.pcc[p + 2], c3 = L.pcc[p + 3];
+                    const int a0 = L.af[c0 & 0x3fff] == 1.0f, a1 = L.af[c1 & 0x3fff] == 1.0f, a2 = L.af[c2 & 0x3fff] == 1.0f, a3 = L.af[c3 & 0x3fff] == 1.0f;
+                    d += a0 + a1 + a2 + a3;
+                    sd += ((L.pvv[p] & 0x8000) ? -a0 : a0) + ((L.pvv[p + 1] & 0x8000) ? -a1 : a1) + ((L.pvv[p + 2] & 0x8000) ? -a2 : a2) + ((L.pvv[p + 3] & 0x8000) ? -a3 : a3);
+                }
+                for (; p < bnd; ++p) { const int a0 = L.af[L.pcc[p] & 0x3fff] == 1.0f; d += a0; sd += (L.pvv[p] & 0x8000) ? -a0 : a0; }
+                if (d == (sd < 0 ? -sd : sd)) pure = 1;
+            }
+        }
+        if (__syncthreads_or(pure)) d_peel(I, ss);
+        return 1;
+    }
+
+    // ---- general path: the reference's sweeps over the whole instance -------------------------------------------------
     for (int v = tid; v < n; v += nt) assign[v] = 0.0f;
     __syncthreads();
     if (tid == 0) assign[li] = sgn_li;
     __syncthreads();
-    SimplifyScratch ss;
-    ss.assign = assign; ss.deg = reinterpret_cast<int32_t *>(L.xv1); ss.sdeg = reinterpret_cast<int32_t *>(L.xv2);
-    ss.flag_v = L.flag_v; ss.flag_f = reinterpret_cast<uint8_t *>(L.S); ss.flag_f2 = ss.flag_f + ((m + 15) & ~15); ss.red = redi2;
     d_set_variable_core(I, ss);
     d_simplify(I, ss, is_sat_b);
     return 1;
@@ -507,7 +661,7 @@ __device__ __noinline__ int lds_cnf_count(unsigned char *smem, int b, int n, int
 }
 
 template <bool FORCE>
-__global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
+__global__ void __launch_bounds__(512, 4) k_sp_solve_lds(PView pv_, SolveParams sp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float redf[PDP_RED_SCRATCH];
@@ -549,6 +703,7 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
     int use_em = sp.has_edge_mask, last_use_em = 0, em_dirty = 0;
     float cnt = sp.src_cnt[G.b];
     int iters = 0, did_prop = 0, nsat = -1, violation = 0, cur = 0;
+    int simplified = 0;                  // 0: unknown, 1: the entry state is a simplify() fix-point (checked at the first decimation), 2: it is not
     const bool other_rows = n < pv_.V;
     const float pi = sp.pi, tol = sp.tol, t_max = sp.t_max;
     const int T = sp.T, poison_from = sp.poison_from;
@@ -567,11 +722,11 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
             const int p1 = p0 + nt;
             const bool has1 = p1 < ne;
             const int q1 = has1 ? p1 : p0;
-            float x0 = pdp_safe_log_fin(QU[p0], PDP_SP_EPS), x1 = pdp_safe_log_fin(QU[q1], PDP_SP_EPS);
-            float y0 = pdp_safe_log_fin(1.0f - Eold[p0], PDP_SP_EPS), y1 = pdp_safe_log_fin(1.0f - Eold[q1], PDP_SP_EPS);
+            const f4v lg = log4_fin((f4v){QU[p0], QU[q1], 1.0f - Eold[p0], 1.0f - Eold[q1]}, PDP_SP_EPS);
+            float x0 = lg.x, x1 = lg.y, y0 = lg.z, y1 = lg.w;
             if (use_em) {
                 uint16_t c0 = pcc[p0], c1 = pcc[q1];
-                const float em0 = (c0 & PC_EM) ? 1.0f : 0.0f, em1 = (c1 & PC_EM) ? 1.0f : 0.0f;
+                const float em0 = bit15_to_float(c0), em1 = bit15_to_float(c1);
                 x0 = x0 * em0; y0 = y0 * em0; x1 = x1 * em1; y1 = y1 * em1;
                 if (em_dirty) {
                     pcc[p0] = (uint16_t)((c0 & ~PC_EM_USED) | ((c0 & PC_EM) ? PC_EM_USED : 0));
@@ -607,14 +762,16 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
                     for (; p + 3 < bnd; p += 4) {
                         const float y0 = Y[p], y1 = Y[p + 1], y2 = Y[p + 2], y3 = Y[p + 3];
                         const uint16_t s0 = pvv[p], s1 = pvv[p + 1], s2 = pvv[p + 2], s3 = pvv[p + 3];
-                        P = P + ((s0 & 0x8000) ? 0.0f : 1.0f) * y0; N = N + ((s0 & 0x8000) ? 1.0f : 0.0f) * y0;
-                        P = P + ((s1 & 0x8000) ? 0.0f : 1.0f) * y1; N = N + ((s1 & 0x8000) ? 1.0f : 0.0f) * y1;
-                        P = P + ((s2 & 0x8000) ? 0.0f : 1.0f) * y2; N = N + ((s2 & 0x8000) ? 1.0f : 0.0f) * y2;
-                        P = P + ((s3 & 0x8000) ? 0.0f : 1.0f) * y3; N = N + ((s3 & 0x8000) ? 1.0f : 0.0f) * y3;
+                        const float n0 = bit15_to_float(s0), n1 = bit15_to_float(s1), n2 = bit15_to_float(s2), n3 = bit15_to_float(s3);
+                        P = P + (1.0f - n0) * y0; N = N + n0 * y0;
+                        P = P + (1.0f - n1) * y1; N = N + n1 * y1;
+                        P = P + (1.0f - n2) * y2; N = N + n2 * y2;
+                        P = P + (1.0f - n3) * y3; N = N + n3 * y3;
                     }
                     for (; p < bnd; ++p) {
                         const float y0 = Y[p]; const uint16_t s0 = pvv[p];
-                        P = P + ((s0 & 0x8000) ? 0.0f : 1.0f) * y0; N = N + ((s0 & 0x8000) ? 1.0f : 0.0f) * y0;
+                        const float n0 = bit15_to_float(s0);
+                        P = P + (1.0f - n0) * y0; N = N + n0 * y0;
                     }
                     Pv[v] = P; Nv[v] = N;
                 }
@@ -623,16 +780,15 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
         __syncthreads();
         PROF_MARK(2);                                        // R1
         // ---- E2: new survey, new q_u, smooth-max weights -----------------------------------------------------------
-        int nan_seen = 0;
+        float nan_acc = 0.0f;
         {
             const float *const S = L.S, *const Pv = L.Pv, *const Nv = L.Nv;
             for (int p = tid; p < ne; p += nt) {
                 const uint16_t pw = pvv[p], cw = pcc[p];
                 const int v = pw & 0x3fff, c = cw & 0x3fff;
-                const float s = (pw & 0x8000) ? -1.0f : 1.0f;
+                const float s = slot_sign(pw);
                 const float eta_old = Eold[p];
                 const float agg = (0.0f + S[c]) - X[p];
-                const float eta_new = 1.0f * pdp_safe_exp_fast(agg) + (1.0f - 1.0f) * eta_old;
                 const float force = FORCE ? L.FRC[p] : 0.0f;
                 const float pos = 0.0f + Pv[v], neg = 0.0f + Nv[v];
                 float same = (0.5f * (1.0f + s)) * pos + (0.5f * (1.0f - s)) * neg;
@@ -640,35 +796,45 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
                 same = same + ((force == s) ? L1 : L0);
                 float opp = (0.5f * (1.0f - s)) * pos + (0.5f * (1.0f + s)) * neg;
                 opp = opp + ((force == -s) ? L1 : L0);
-                const float dc = pdp_safe_exp_fast(same + opp);
-                const float A = pdp_safe_exp_fast(same), Bv = pdp_safe_exp_fast(opp);
+                const f4v ex = exp4_fin_le30((f4v){agg, same + opp, same, opp});
+                const float eta_new = 1.0f * ex.x + (1.0f - 1.0f) * eta_old;
+                const float dc = ex.y;
+                const float A = ex.z, Bv = ex.w;
                 const float qu = A * (1.0f - Bv), qs = Bv * (1.0f - A);
                 const float total = (qu + qs) + dc;
                 const float qu_new = 1.0f * (qu / total) + (1.0f - 1.0f) * QU[p];
-                if (eta_new != eta_new) nan_seen = 1;
+                nan_acc = nan_acc + (eta_new - eta_new);     // stays 0 unless a survey is NaN (surveys are <= 1)
                 QU[p] = qu_new;
                 Enew[p] = eta_new;
                 if (has_prev) {
                     const float pe = prev_from_global ? sp.src_prev[G.e0 + G.v_edges[p]] : eta_old;
                     float d = pdp_abs(pe - eta_new);
-                    if (use_em) d = d * ((cw & PC_EM) ? 1.0f : 0.0f);
-                    Y[p] = pdp_safe_exp_fast(30.0f * d);
+                    if (use_em) d = d * bit15_to_float(cw);
+                    Y[p] = d;                               // the smooth-max weights exp(30 d) are only built when P4 cannot decide without them
                 }
             }
         }
+        int nan_seen = (nan_acc != nan_acc) ? 1 : 0;
         did_prop = 1;
         __syncthreads();
         PROF_MARK(3);                                        // E2
-        // ---- P4: per-variable smooth maxima.  Site 0 (survey gate `max <= 1e-10`, pdp_decimate.py:127-133) is decided lazily:
-        // smooth_max_v >= eta_max_v / deg_v (the largest survey carries the largest weight), so one active variable with
-        // eta_max_v >= 2^-21 * deg_v proves (x + 1) - 1 >= 2^-23 > 1e-10 and no exp is needed; an exact zero of the operand
-        // exists iff some variable is inactive or has only zero surveys.  Otherwise the exact weights are computed below.
-        float m1 = -PDP_INF, m2 = -PDP_INF;
-        int bits = nan_seen ? 4 : 0;                       // bit0: xv1 has an exact 0, bit1: xv2 has one, bit2: NaN, bit3: gate certified open
+        // ---- P4: per-variable smooth maxima, decided lazily.  The two batch-visible facts per instance are booleans:
+        // site 0 (survey gate `max <= 1e-10`, pdp_decimate.py:127-133) and site 1 (`max |delta eta| < tolerance`, :135-146).
+        // Site 0: smooth_max_v >= eta_max_v / deg_v (the largest survey carries the largest weight), so one active variable
+        // with eta_max_v >= 2^-21 * deg_v proves (x + 1) - 1 >= 2^-23 > 1e-10; an exact zero of the operand exists iff some
+        // variable is inactive or has only zero surveys.
+        // Site 1: with d in [0, D], W = exp(30 D), S1 = sum d, S2 = sum d^2 the chord / tangent of exp give
+        //   (D W + (S1 - D) + 30 (S2 - D^2)) / (deg + S1 (W - 1) / D)  <=  smooth_max_v  <=  min(D, (S1 + S2 (W - 1) / D) / (deg + 30 S1)),
+        // one exp per VARIABLE instead of one per edge.  A variable whose bounds straddle the tolerance (or whose D is so small
+        // that the quotient may round to zero) is marked and evaluated exactly in P5b, in the reference's summation order.
+        int bits = nan_seen ? 4 : 0;       // 1: site-0 operand has an exact 0, 2: site-1 operand has one, 4: NaN, 8: gate certified open,
+                                           // 16: some variable proves "not converged", 32: undecided variables, 64: tiny-D variables
         {
             const uint16_t *const v_ptr = L.v_ptr;
             const float *const av = L.av;
+            float *const amb = L.xv1;
             const int rows = has_prev ? 2 * n : n;
+            const float tol_lo = tol - (2e-6f + 1e-4f * pdp_abs(tol)), tol_hi = tol + (2e-6f + 1e-4f * pdp_abs(tol));
             for (int r = tid; r < rows; r += nt) {
                 const bool second = r >= n;
                 const int v = second ? r - n : r;
@@ -686,56 +852,82 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
                     if (a_v == 1.0f && emax >= 4.76837158203125e-7f * (float)(bnd - a)) bits |= 8;
                     continue;
                 }
-                float num = 0.0f, den = 0.0f;
-                if (!prev_from_global) {
+                float S1 = 0.0f, S2 = 0.0f, D = 0.0f;        // order-free statistics (they only feed the certificates)
+                {
+                    float s1b = 0.0f, s2b = 0.0f, Db = 0.0f;
                     int p = a;
-                    for (; p + 1 < bnd; p += 2) {
-                        const float c0 = Y[p], c1 = Y[p + 1];
-                        float d0 = pdp_abs(Eold[p] - Enew[p]), d1 = pdp_abs(Eold[p + 1] - Enew[p + 1]);
-                        if (use_em) { d0 = d0 * ((pcc[p] & PC_EM) ? 1.0f : 0.0f); d1 = d1 * ((pcc[p + 1] & PC_EM) ? 1.0f : 0.0f); }
-                        num = num + d0 * c0; den = den + c0; num = num + d1 * c1; den = den + c1;
+                    for (; p + 3 < bnd; p += 4) {
+                        const float d0 = Y[p], d1 = Y[p + 1], d2 = Y[p + 2], d3 = Y[p + 3];
+                        S1 += d0 + d1; s1b += d2 + d3;
+                        S2 = fmaf(d0, d0, fmaf(d1, d1, S2)); s2b = fmaf(d2, d2, fmaf(d3, d3, s2b));
+                        D = fmaxf(D, fmaxf(d0, d1)); Db = fmaxf(Db, fmaxf(d2, d3));
                     }
-                    for (; p < bnd; ++p) {
-                        float d = pdp_abs(Eold[p] - Enew[p]);
-                        if (use_em) d = d * ((pcc[p] & PC_EM) ? 1.0f : 0.0f);
-                        const float c0 = Y[p];
-                        num = num + d * c0; den = den + c0;
-                    }
-                } else {
-                    for (int p = a; p < bnd; ++p) {
-                        float d = pdp_abs(sp.src_prev[G.e0 + G.v_edges[p]] - Enew[p]);
-                        if (use_em) d = d * ((pcc[p] & PC_EM) ? 1.0f : 0.0f);
-                        const float c0 = Y[p];
-                        num = num + d * c0; den = den + c0;
-                    }
+                    for (; p < bnd; ++p) { const float d0 = Y[p]; S1 += d0; S2 = fmaf(d0, d0, S2); D = fmaxf(D, d0); }
+                    S1 += s1b; S2 += s2b; D = fmaxf(D, Db);
                 }
-                const float rr = (num / pdp_max_c(den, 1.0f)) * av[v];
-                if (rr != rr) bits |= 4;
-                if (rr == 0.0f) bits |= 2;
-                m2 = pdp_max(m2, (rr - 0.0f) + 1.0f);
+                const float a_v = av[v];
+                float code = 0.0f;
+                if (S1 != S1) bits |= 4;                    // a NaN survey difference
+                else if (a_v == 0.0f || D == 0.0f) bits |= (0.0f < tol) ? 2 : (2 | 16);   // smooth max * active == 0 exactly
+                else if (!(D >= 1e-30f)) { bits |= 64; code = 2.0f; }
+                else {
+                    const float deg = (float)(bnd - a);
+                    const float W = pdp_expf_fin_le30(30.0f * D);
+                    const float kk = (W - 1.0f) / D;
+                    const float ub = fminf(D, fmaf(S2, kk, S1) / fmaf(30.0f, S1, deg));
+                    const float lb = (fmaf(D, W, S1 - D) + 30.0f * (S2 - D * D)) / fmaf(S1, kk, deg);
+                    if (lb * 0.9999f >= tol_hi) bits |= 16;
+                    else if (!(ub * 1.0001f < tol_lo)) { bits |= 32; code = 1.0f; }
+                }
+                amb[v] = code;
             }
         }
         PROF_MARK(4);                                        // P4
-        // ---- P5: one fused workgroup reduction (two NaN-propagating maxima + flag bits) -----------------------------------
+        // ---- P5: one fused workgroup reduction of the flag bits ------------------------------------------------------------
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            m1 = pdp_max(m1, __shfl_down(m1, off, 64));
-            m2 = pdp_max(m2, __shfl_down(m2, off, 64));
-            bits |= __shfl_down(bits, off, 64);
+        for (int off = 32; off > 0; off >>= 1) bits |= __shfl_down(bits, off, 64);
+        if (lane == 0) redi[wid] = bits;
+        __syncthreads();
+        bits = 0;
+        for (int i = 0; i < nw; ++i) bits |= redi[i];
+        __syncthreads();
+        bits = UNI(bits);                                    // workgroup-uniform: keep the control flow scalar
+        // ---- P5b (rare): exact smooth max of the marked variables (util.py:282-286 + :267-275 with the global min at 0)
+        if ((bits & 64) || ((bits & 32) && !(bits & 16))) {
+            PROF_COUNT(9);
+            int b2 = 0;
+            const float *const amb = L.xv1;
+            const bool need_decision = !(bits & 16);
+            for (int v = tid; v < n; v += nt) {
+                const float code = amb[v];
+                if (code == 2.0f || (code == 1.0f && need_decision)) {
+                    float num = 0.0f, den = 0.0f;
+                    for (int p = L.v_ptr[v]; p < L.v_ptr[v + 1]; ++p) {
+                        const float d = Y[p];
+                        const float c0 = pdp_expf_fin_le30(30.0f * d);
+                        num = num + d * c0; den = den + c0;
+                    }
+                    const float rr = (num / pdp_max_c(den, 1.0f)) * L.av[v];
+                    if (rr == 0.0f) b2 |= 2;
+                    if (!((((rr - 0.0f) + 1.0f) + 0.0f) - 1.0f < tol)) b2 |= 16;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) b2 |= __shfl_down(b2, off, 64);
+            if (lane == 0) redi[wid] = b2;
+            __syncthreads();
+            b2 = 0;
+            for (int i = 0; i < nw; ++i) b2 |= redi[i];
+            __syncthreads();
+            bits |= UNI(b2);
         }
-        if (lane == 0) { redf[wid] = m1; redf[16 + wid] = m2; redi[wid] = bits; }
-        __syncthreads();
-        m1 = -PDP_INF; m2 = -PDP_INF; bits = 0;
-        for (int i = 0; i < nw; ++i) { m1 = pdp_max(m1, redf[i]); m2 = pdp_max(m2, redf[16 + i]); bits |= redi[i]; }
-        __syncthreads();
-        m1 = uni_f(m1); m2 = uni_f(m2); bits = UNI(bits);          // workgroup-uniform: keep the control flow scalar
         PROF_MARK(5);                                        // P5
         float g;
         if (bits & 8) {
             g = 1.0f;                                       // certified: the gate stays open, its exact value is never used
         } else {
             // exact path (rare: every active variable has only vanishing surveys): util.py:282-286 + :267-275
-            for (int p = tid; p < ne; p += nt) X[p] = pdp_safe_exp_fast(30.0f * Enew[p]);
+            for (int p = tid; p < ne; p += nt) X[p] = pdp_expf_fin_le30(30.0f * Enew[p]);
             __syncthreads();
             float mm = -PDP_INF;
             for (int v = tid; v < n; v += nt) {
@@ -749,8 +941,9 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
             if (other_rows) mm = pdp_max(mm, 0.0f);
             g = (mm + 0.0f) - 1.0f;
         }
-        if (other_rows) m2 = pdp_max(m2, 0.0f);
-        const float dmax = (m2 + 0.0f) - 1.0f;
+        // site 1: (max_v (rr_v + 1)) - 1 < tol  <=>  every variable passes the same test on its own (both maps are monotone);
+        // a NaN anywhere makes the reference's maximum NaN and the comparison false
+        const bool below_tol = (n > 0) ? (!(bits & 16) && !(bits & 4)) : ((other_rows ? -1.0f : -PDP_INF) < tol);
         const int z1 = bits & 1, z2 = (bits >> 1) & 1;
         nan_seen = (bits >> 2) & 1;
         if (nan_seen && !poisoned) {
@@ -763,8 +956,8 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
             // instances with an event at or after the poison iteration have to be replayed
             if (g <= 1e-10f) { active = 0; last_event = t; }
             if (has_prev) {
-                if (dmax < tol) { cnt = 0.0f; last_event = t; }
-                conv = (dmax < tol) ? 1 : 0;
+                if (below_tol) { cnt = 0.0f; last_event = t; }
+                conv = below_tol ? 1 : 0;
                 if (cnt >= t_max) { conv = 1; cnt = 0.0f; }
                 if (conv) last_event = t;
             }
@@ -778,12 +971,14 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
         int decimated = 0;
         if (has_prev && conv && !poisoned && !nan_seen) {
             int spec_bits = 0;
-            decimated = UNI(lds_decimate<FORCE>(smem, G.b, n, m, ne, cur, active, pi, pv_.is_sat + G.b, &spec_bits));
-            spec_bits = UNI(spec_bits);
+            decimated = UNI(lds_decimate<FORCE>(smem, G.b, n, m, ne, cur, active, pi, pv_.is_sat + G.b, &spec_bits, &simplified));
+            spec_bits = UNI(spec_bits); simplified = UNI(simplified);
             used |= 4u;
             if (spec_bits & 1) zero |= 4u;
             if (spec_bits & 2) violation = 1;
         }
+        if (decimated) { if (simplified == 1) PROF_COUNT(10); else PROF_COUNT(11); }
+        PROF_COUNT(12);
         PROF_MARK(6);                                        // P6 decimation
         if (has_prev) cnt = cnt + 1.0f;
         if (tid == 0 && !poisoned) { atomicOr(&sp.spec_used[t], used); if (zero) atomicOr(&sp.spec_zero[t], zero); }
@@ -820,7 +1015,7 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
             const uint16_t pw = pvv[p], cw = pcc[p];
             if (did_prop && (sp.final_chunk || !active)) {
                 const int v = pw & 0x3fff;
-                const float s = (pw & 0x8000) ? -1.0f : 1.0f;
+                const float s = slot_sign(pw);
                 float y = pdp_safe_log_fin(1.0f - Eprev[p], PDP_SP_EPS);
                 if (last_use_em) y = y * ((cw & PC_EM_USED) ? 1.0f : 0.0f);
                 const float force = FORCE ? L.FRC[p] : 0.0f;
@@ -830,8 +1025,8 @@ __global__ void __launch_bounds__(512) k_sp_solve_lds(PView pv_, SolveParams sp)
                 same = same + ((force == s) ? L1 : L0);
                 float opp = (0.5f * (1.0f - s)) * pos + (0.5f * (1.0f + s)) * neg;
                 opp = opp + ((force == -s) ? L1 : L0);
-                const float dc = pdp_safe_exp_fast(same + opp);
-                const float A = pdp_safe_exp_fast(same), Bv = pdp_safe_exp_fast(opp);
+                const float dc = pdp_expf_fin_le30(same + opp);
+                const float A = pdp_expf_fin_le30(same), Bv = pdp_expf_fin_le30(opp);
                 const float qu = A * (1.0f - Bv), qs = Bv * (1.0f - A);
                 const float total = (qu + qs) + dc;
                 // (1 - mask) * old keeps a NaN forever; the three columns of q turn NaN together, so q_u carries the stickiness

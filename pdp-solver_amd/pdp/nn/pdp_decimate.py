@@ -85,7 +85,12 @@ class SequentialDecimator(nn.Module):
 
     def forward(self, init_state, message_state, sat_problem, is_training, active_mask=None):
         handle = self.native_handle(sat_problem)
-        fs = message_state[1].contiguous()
+        fs = message_state[1]
+        if fs.size(1) != 2:
+            # neural propagator (model type np-d-np): the gate reads column 0 of an [E, H] state (pdp_decimate.py:128,
+            # 137); the native gate / apply kernels take the [E, 2] survey layout, column 1 is unused with a foreign scorer
+            fs = torch.stack((fs[:, 0], torch.zeros_like(fs[:, 0])), dim=1)
+        fs = fs.contiguous()
         am = None if active_mask is None else active_mask.reshape(-1)
         if isinstance(self._scorer, pdp_predict.SurveyScorer):
             sat_problem._native.sequential_decimate(handle, fs, am, self._tolerance, self._t_max, self._scorer._pi)

@@ -339,10 +339,43 @@ class NeuralPropagatorDecimatorSolver(PropagatorDecimatorSolverBase):
             local_search_iterations=local_search_iterations, epsilon=epsilon, rng=rng, seed=seed)
 
 
+class NeuralSequentialDecimatorSolver(PropagatorDecimatorSolverBase):
+    """Neural propagator + the sequential decimator scored by a neural predictor + identity predictor
+    (reference: solver.py:616-637, model type np-d-np).  The decimator's survey gate reads column 0 of the neural
+    function state, a logsigmoid output, so under ``check_termination`` the reference switches every instance off after
+    the first iteration; that behaviour is reproduced, not repaired."""
+
+    def __init__(self, device, name, edge_dimension, meta_data_dimension, propagator_dimension, decimator_dimension,
+                 mem_hidden_dimension, agg_hidden_dimension, mem_agg_hidden_dimension, classifier_dimension, dropout,
+                 tolerance, t_max, local_search_iterations=0, epsilon=0.05, rng='torch', seed=0):
+        super(NeuralSequentialDecimatorSolver, self).__init__(
+            device=device, name=name,
+            propagator=pdp_propagate.NeuralMessagePasser(device, edge_dimension, decimator_dimension, meta_data_dimension,
+                                                         propagator_dimension, mem_hidden_dimension, mem_agg_hidden_dimension,
+                                                         agg_hidden_dimension, dropout),
+            decimator=pdp_decimate.SequentialDecimator(
+                device, message_dimension=(3, 1),
+                scorer=pdp_predict.NeuralPredictor(device, decimator_dimension, 1, edge_dimension, meta_data_dimension,
+                                                   mem_hidden_dimension, agg_hidden_dimension, mem_agg_hidden_dimension,
+                                                   variable_classifier=util.PerceptronTanh(decimator_dimension, classifier_dimension, 1),
+                                                   function_classifier=None),
+                tolerance=tolerance, t_max=t_max),
+            predictor=pdp_predict.IdentityPredictor(device=device, random_fill=True, rng=rng, seed=seed),
+            local_search_iterations=local_search_iterations, epsilon=epsilon, rng=rng, seed=seed)
+
+
 def build_neural_solver(device, config, perceptron_cls, common):
-    "model_type np-nd-np (reference: trainer.py:51-60); np-d-np needs a strided survey view that is not built yet"
+    "model types np-nd-np and np-d-np (reference: trainer.py:51-60, 73-81)"
+    if config['model_type'] == 'np-d-np':
+        return NeuralSequentialDecimatorSolver(
+            device=device, name=config['model_name'], edge_dimension=config['edge_feature_dim'],
+            meta_data_dimension=config['meta_feature_dim'], propagator_dimension=config['hidden_dim'],
+            decimator_dimension=config['hidden_dim'], mem_hidden_dimension=config['mem_hidden_dim'],
+            agg_hidden_dimension=config['agg_hidden_dim'], mem_agg_hidden_dimension=config['mem_agg_hidden_dim'],
+            classifier_dimension=config['classifier_dim'], dropout=config.get('dropout', 0),
+            tolerance=config['tolerance'], t_max=config['t_max'], **common)
     if config['model_type'] != 'np-nd-np':
-        raise NotImplementedError("model_type %r has no native implementation yet (np-nd-np, p-d-p, walk-sat, reinforce are available)"
+        raise NotImplementedError("model_type %r has no native implementation (np-nd-np, np-d-np, p-d-p, walk-sat, reinforce are available)"
                                   % (config['model_type'],))
     return NeuralPropagatorDecimatorSolver(
         device=device, name=config['model_name'], edge_dimension=config['edge_feature_dim'],

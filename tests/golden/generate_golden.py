@@ -458,6 +458,49 @@ def gen_neural():
         save('trace_neural_' + tag, **out)
 
 
+def gen_np_d_np():
+    "model type np-d-np: neural propagator + sequential decimator scored by a neural predictor (solver.py:616-637)"
+    lines = make_lines([(16, 52, (3,))] * 6, seed0=2100)
+    with open(os.path.join(HERE, 'npdnp_batch.jsonl'), 'w') as f:
+        f.write("\n".join(lines) + "\n")
+    gm, bvm, bfm, ef, lab, misc = batch_tensors(lines)
+    H, T, w = 24, 14, 8
+    cfg = base_cfg('np-d-np', hidden_dim=H, local_search_iteration=w, tolerance=0.2, t_max=3)
+    tr, m = build(cfg, seed=4321)
+    out = problem_arrays(gm, bvm, bfm, ef)
+    for k, v in m.state_dict().items():
+        if k.startswith(('_propagator.', '_decimator.', '_predictor.')) and '_module_list' not in k:
+            out['w__' + k.replace('.', '__')] = np_(v)
+    with open(os.path.join(HERE, 'state_dict_alias_map_npdnp.json'), 'w') as f:
+        json.dump(alias_map(m), f, indent=0, sort_keys=True)
+    ints = {k: [] for k in ('active_variables', 'solution', 'active_mask')}
+    orig_check = tr._check_recurrence_termination
+
+    def check(active, prediction, sp):
+        orig_check(active, prediction, sp)
+        ints['active_variables'].append(np_(sp._active_variables[:, 0])); ints['solution'].append(np_(sp._solution))
+        ints['active_mask'].append(np_(active[:, 0]))
+
+    torch.manual_seed(9)
+    del RAND_LOG[:]
+    torch.rand = _rec_rand
+    try:
+        with torch.no_grad():
+            st = m.get_init_state(gm, bvm, bfm, ef, None, randomized=True, batch_replication=1)
+            out['init_prop_v'] = np_(st[0][0]); out['init_prop_f'] = np_(st[0][1])
+            pred, (ps, ds) = m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef,
+                               meta_data=None, is_training=False, iteration_num=T, check_termination=check, batch_replication=1)
+    finally:
+        torch.rand = _real_rand
+    for k, v in ints.items():
+        out['trace_' + k] = np.stack(v)
+    out['final_prediction'] = np_(pred[0][:, 0])
+    out['final_prop_0'] = np_(ps[0]); out['final_prop_1'] = np_(ps[1])
+    out['rand_sizes'] = np.array([len(r) for r in RAND_LOG], dtype=np.int64)
+    out['meta'] = np.array([T, H, w, 9], dtype=np.int64)
+    save('trace_np_d_np', **out)
+
+
 # ---- E. CLI -------------------------------------------------------------------------------------
 
 def gen_cli():
@@ -492,7 +535,7 @@ def gen_cli():
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['problem', 'ops', 'traces', 'neural', 'cli']
+    what = sys.argv[1:] or ['problem', 'ops', 'traces', 'neural', 'npdnp', 'cli']
     lines = None
     if 'problem' in what or 'ops' in what:
         lines = gen_loader_and_simplify()
@@ -502,5 +545,7 @@ if __name__ == '__main__':
         gen_traces()
     if 'neural' in what:
         gen_neural()
+    if 'npdnp' in what:
+        gen_np_d_np()
     if 'cli' in what:
         gen_cli()

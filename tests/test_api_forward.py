@@ -162,3 +162,49 @@ def test_neural_forward_equals_reference_golden(name):
     np.testing.assert_allclose(ps[0].cpu().numpy(), d['prop_v_%d' % (T - 1)], rtol=3e-4, atol=3e-5)
     np.testing.assert_allclose(ds[1].cpu().numpy(), d['dec_f_%d' % (T - 1)], rtol=3e-4, atol=3e-5)
     np.testing.assert_array_equal(pred[0].cpu().numpy()[:, 0], d['final_prediction'])
+
+
+def test_np_d_np_equals_reference_golden():
+    """model type np-d-np (neural propagator, sequential decimator scored by a neural predictor): same random stream as
+    the reference run => identical per-iteration problem state and identical final assignment after Walk-SAT; the neural
+    states within fp tolerance.  (The survey gate reads a logsigmoid output, so the reference stops after one iteration.)"""
+    import json
+    from pdp.trainer import SatFactorGraphTrainer
+    d = load_golden('trace_np_d_np')
+    T, H, w, seed = [int(x) for x in d['meta']]
+    tr = SatFactorGraphTrainer(cfg('np-d-np', hidden_dim=H, edge_feature_dim=1, meta_feature_dim=0, prediction_dim=1, mem_hidden_dim=100,
+                                   agg_hidden_dim=100, mem_agg_hidden_dim=50, classifier_dim=50, local_search_iteration=w,
+                                   tolerance=0.2, t_max=3), use_cuda=True, logger=LOG)
+    m = tr._model_list[0]
+    alias = json.load(open(os.path.join(REPO, 'tests', 'golden', 'state_dict_alias_map_npdnp.json')))
+    sd = {}
+    for key, canon in alias.items():
+        k = 'w__' + canon.replace('.', '__')
+        if key == '_global_step':
+            sd[key] = torch.zeros(1)
+        elif k in d.files:
+            sd[key] = torch.from_numpy(d[k])
+    m.load_state_dict(sd, strict=True)
+    dev = torch.device('cuda:0')
+    gm = torch.from_numpy(d['graph_map']).to(dev); bvm = torch.from_numpy(d['batch_variable_map']).to(dev)
+    bfm = torch.from_numpy(d['batch_function_map']).to(dev); ef = torch.from_numpy(d['edge_feature']).to(dev)
+    rec = {'av': [], 'sol': [], 'am': []}
+
+    def check(active, prediction, sp):
+        tr._check_recurrence_termination(active, prediction, sp)
+        rec['av'].append(sp._active_variables[:, 0].cpu().numpy().copy()); rec['sol'].append(sp._solution.cpu().numpy().copy())
+        rec['am'].append(active[:, 0].cpu().numpy().copy())
+
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        st = m.get_init_state(gm, bvm, bfm, ef, None, randomized=True, batch_replication=1)
+        np.testing.assert_array_equal(st[0][0].cpu().numpy(), d['init_prop_v'])
+        pred, (ps, ds) = m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None,
+                           is_training=False, iteration_num=T, check_termination=check, batch_replication=1)
+    assert len(rec['av']) == d['trace_active_variables'].shape[0]
+    np.testing.assert_array_equal(np.stack(rec['av']), d['trace_active_variables'])
+    np.testing.assert_array_equal(np.stack(rec['sol']), d['trace_solution'])
+    np.testing.assert_array_equal(np.stack(rec['am']).astype(np.int64), d['trace_active_mask'].astype(np.int64))
+    np.testing.assert_allclose(ps[0].cpu().numpy(), d['final_prop_0'], rtol=3e-4, atol=3e-5)
+    np.testing.assert_allclose(ps[1].cpu().numpy(), d['final_prop_1'], rtol=3e-4, atol=3e-5)
+    np.testing.assert_array_equal(pred[0].cpu().numpy()[:, 0], d['final_prediction'])

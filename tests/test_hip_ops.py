@@ -56,6 +56,12 @@ def test_device_math_bit_exact(oracle):
     xl = np.concatenate([np.exp(rng.uniform(-100, 10, 300000)), rng.uniform(0, 2, 100000), [1e-40, 1e-45, 0.0, -1.0, np.nan, np.inf]]).astype(np.float32)
     for fn in ('log', 'safe_log', 'safe_log_fin', 'safe_log_fin_scorer', 'rcp'):
         np.testing.assert_array_equal(npy(native.math_apply(fn, t(xl))), oracle.math_apply(fn, xl), err_msg=fn)
+    # the select-free hot-loop forms against the GENERAL functions of the oracle on their domain (finite or NaN)
+    xe = np.concatenate([x[np.isfinite(x) & (x <= 30)], np.arange(np.float32(-100).view(np.uint32), np.float32(-110).view(np.uint32), 7, dtype=np.uint32).view(np.float32),
+                         [np.nan]]).astype(np.float32)
+    np.testing.assert_array_equal(npy(native.math_apply('exp_fin', t(xe))), oracle.math_apply('safe_exp', xe))
+    xf = np.concatenate([xl[np.isfinite(xl)], np.arange(0, 0x00800000, 5, dtype=np.uint32).view(np.float32), [np.nan, -3.0, -1e-30]]).astype(np.float32)
+    np.testing.assert_array_equal(npy(native.math_apply('safe_log_fin', t(xf))), oracle.math_apply('safe_log', xf))
 
 
 @pytest.mark.parametrize('spec', BATCHES)

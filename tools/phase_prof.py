@@ -5,6 +5,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, 'pdp-solver_amd'))
 import torch
 from pdp import native
+if os.path.exists(native.LIB_PATH.replace('.so', '_prof.so')):
+    native.LIB_PATH = native.LIB_PATH.replace('.so', '_prof.so')      # built with EXTRA=-DPDP_PHASE_PROF next to the product library
 from pdp.factorgraph import dataset
 B, n, T = int(sys.argv[1]) if len(sys.argv) > 1 else 5000, 200, 100
 dev = torch.device('cuda:0')
@@ -26,3 +28,4 @@ tot = sum(out[i] for i in range(9))
 for i, nm in enumerate(names):
     print("%-16s %14d cycles  %5.1f%%" % (nm, out[i], 100.0 * out[i] / tot))
 print("total WG-cycles %d" % tot)
+print("instance-iterations %d, exact smooth-max passes %d, decimations on the neighbourhood path %d, on the general path %d" % (out[12], out[9], out[10], out[11]))
