@@ -98,6 +98,12 @@ struct pdp_problem {
     char *solve_blob; size_t solve_blob_bytes;
     uint32_t *solve_host; size_t solve_host_words;   // pinned
     float *solve_extra_v;
+    // LDS-resident solver: private instance records (pdp_solve.hip, BlobLayout) and device-side control blocks
+    int64_t *res_stat_off;                           // [2B] static | dynamic record offsets
+    char *res_stat; size_t res_stat_bytes; int res_static_built;
+    char *res_dyn[2]; size_t res_dyn_bytes;
+    float *res_prev_slots;
+    char *res_ctl; size_t res_ctl_bytes;
     float *nws[4]; size_t nws_floats[4];             // neural workspaces (grow on demand)
 };
 

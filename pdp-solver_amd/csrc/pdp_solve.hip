@@ -14,6 +14,7 @@
 // through the strict step-wise entry points (pdp_ops.hip), so results always equal the reference semantics.
 #include "pdp_device.hpp"
 #include <stdlib.h>
+#include <vector>
 
 #define ST(s) ((hipStream_t)(s))
 
@@ -56,7 +57,57 @@ struct SolveParams {
     uint32_t *spec_used;        // [T] bits: some instance evaluated the site
     // HBM-mode scratch
     float *ws_e[4]; float *ws_f; float *ws_v[7]; int32_t *ws_vi[3]; uint8_t *ws_fu[2];
+    // LDS-resident kernel: private instance records (see BlobLayout) and device-side control
+    int pass;                   // 0: every instance, 1: replay of ctl->replay_count listed instances
+    int chunk_start;            // iterations completed before this launch
+    struct SolveCtl *ctl;       // this chunk's control block
+    struct SolveCall *call;     // the call's control block
+    const char *stat;           // static (topology) records
+    const char *dyn_in;         // dynamic records this launch resumes from
+    char *dyn_out;              // dynamic records this launch leaves behind
+    const int64_t *stat_off, *dyn_off;   // [B] byte offsets of the instance records
+    const float *prev_slots;    // [E] slot-major copy of the decimator's previous surveys (first launch of a call only)
 };
+
+// Device-side control of the chunked persistent solve: the host enqueues every launch of a call up front and reads
+// one SolveCall back at the end.
+struct SolveCtl {               // one per chunk
+    uint32_t nan_iter;          // min over instances of the first chunk-relative iteration with a NaN survey (0xffffffff: none)
+    uint32_t perm_zero;         // first iteration from which an exited instance guarantees exact zeros (0xffffffff: none)
+    uint32_t violation;         // a speculation the kernel itself can see failed
+    uint32_t iters_run;         // max over instances of the iterations run in this chunk
+    uint32_t replay_count;      // instances listed for the poison replay
+    uint32_t do_replay;
+    int32_t poison_from;        // replay pass: first poisoned (chunk-relative) iteration
+    uint32_t pad;
+};
+struct SolveCall {
+    uint32_t poisoned_all;      // a NaN poisoned the batch in an earlier chunk: later chunks run poisoned from their first iteration
+    uint32_t stop;              // every instance went inactive (solver.py:383): the remaining launches return immediately
+    uint32_t fail;              // a cross-instance coupling became active: the caller must rerun step-wise
+    uint32_t total_iters;
+    uint32_t pad[4];
+};
+
+// Private instance records of the LDS-resident solver.  Between two launches of a call an instance lives in HBM as the
+// verbatim image of its LDS arrays (slot-major, 16-byte aligned pieces): resuming is a coalesced copy instead of a
+// gather through the CSR, and the record a launch resumed from stays intact, which is the snapshot the poison replay needs.
+//   static  (per problem): pvv | e2p | v_ptr | f_ptr
+//   dynamic (two copies, ping-pong): header | QU | E | pcc | af | av | sol
+struct DynHeader { uint32_t active, done, perm_zero, pad0; float cnt, is_sat, pad1, pad2; };
+struct BlobLayout { size_t pvv, e2p, vptr, fptr, stat_bytes, hdr, QU, E, pcc, af, av, sol, dyn_bytes; };
+__host__ __device__ inline BlobLayout blob_layout(int n, int m, int ne)
+{
+    auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    BlobLayout b; size_t o = 0;
+    b.pvv = o; o += a16((size_t)ne * 2); b.e2p = o; o += a16((size_t)ne * 2);
+    b.vptr = o; o += a16((size_t)(n + 1) * 2); b.fptr = o; o += a16((size_t)(m + 1) * 2); b.stat_bytes = o;
+    o = 0;
+    b.hdr = o; o += a16(sizeof(DynHeader));
+    b.QU = o; o += a16((size_t)ne * 4); b.E = o; o += a16((size_t)ne * 4); b.pcc = o; o += a16((size_t)ne * 2);
+    b.af = o; o += a16((size_t)m * 4); b.av = o; o += a16((size_t)n * 4); b.sol = o; o += a16((size_t)n * 4); b.dyn_bytes = o;
+    return b;
+}
 
 __device__ __forceinline__ size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
@@ -669,44 +720,61 @@ __global__ void __launch_bounds__(512, 4) k_sp_solve_lds(PView pv_, SolveParams 
 
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
-    const Inst G = load_inst(pv_, sp.inst_list ? sp.inst_list[blockIdx.x] : (int)blockIdx.x);
+    SolveCtl *const ctl = sp.ctl;
+    if (sp.call->stop) return;                                                 // every instance went inactive in an earlier chunk
+    if (sp.pass == 1 && (!ctl->do_replay || blockIdx.x >= ctl->replay_count)) return;
+    const Inst G = load_inst(pv_, sp.pass == 1 ? sp.inst_list[blockIdx.x] : (int)blockIdx.x);
     const int n = G.n, m = G.m, ne = G.e;
     const LdsArrays L = carve_all(smem, n, m, ne, FORCE);
     float *const QU = L.QU, *const X = L.X, *const Y = L.Y;
     uint16_t *const pvv = L.pvv, *const pcc = L.pcc;
-
-    // ---- load ---------------------------------------------------------------------------------------------------------
-    {
-        const float *sq = sp.src_q + 3 * (size_t)G.e0, *sfs = sp.src_fs + 2 * (size_t)G.e0;
-        for (int p = tid; p < ne; p += nt) {
-            const int e = G.v_edges[p];
-            const int sg = G.sgn[e];
-            pvv[p] = (uint16_t)(G.e_var[e] | (sg < 0 ? 0x8000 : 0));
-            const bool em = sp.src_emask[G.e0 + e] == 1.0f;
-            pcc[p] = (uint16_t)(G.e_fn[e] | (em ? (PC_EM | PC_EM_USED) : 0));
-            L.e2p[e] = (uint16_t)p;
-            QU[p] = sq[3 * e]; L.EA[p] = sfs[2 * e];
-            if constexpr (FORCE) L.FRC[p] = sfs[2 * e + 1];
+    const BlobLayout BL = blob_layout(n, m, ne);
+    const char *const din = sp.dyn_in + sp.dyn_off[G.b];
+    char *const dout = sp.dyn_out + sp.dyn_off[G.b];
+    const DynHeader hdr = *reinterpret_cast<const DynHeader *>(din + BL.hdr);
+    if (hdr.done) {
+        // finished in an earlier launch (its outputs are in the caller's arrays already): carry the record forward
+        if (tid == 0) {
+            *reinterpret_cast<DynHeader *>(dout + BL.hdr) = hdr;
+            if (hdr.perm_zero) atomicMin(&ctl->perm_zero, 0u);
+            if (sp.pass == 0) sp.last_event[G.b] = -1;
         }
-        for (int v = tid; v <= n; v += nt) L.v_ptr[v] = (uint16_t)G.v_ptr[v];
-        for (int c = tid; c <= m; c += nt) L.f_ptr[c] = (uint16_t)G.f_ptr[c];
-        for (int v = tid; v < n; v += nt) { L.av[v] = sp.src_av[G.v0 + v]; L.sol[v] = sp.src_sol[G.v0 + v]; }
-        for (int c = tid; c < m; c += nt) L.af[c] = sp.src_af[G.f0 + c];
-        if (tid == 0 && sp.inst_list) pv_.is_sat[G.b] = sp.src_sat[G.b];
+        return;
     }
+
+    // ---- load: coalesced 16-byte copies of the instance record --------------------------------------------------------------
+    {
+        const char *const stt = sp.stat + sp.stat_off[G.b];
+        auto copy16 = [&](void *dst, const char *src, size_t bytes) {
+            uint4 *d = reinterpret_cast<uint4 *>(dst);
+            const uint4 *g = reinterpret_cast<const uint4 *>(src);
+            for (int i = tid; i < (int)((bytes + 15) >> 4); i += nt) d[i] = g[i];
+        };
+        copy16(pvv, stt + BL.pvv, (size_t)ne * 2); copy16(L.e2p, stt + BL.e2p, (size_t)ne * 2);
+        copy16(L.v_ptr, stt + BL.vptr, (size_t)(n + 1) * 2); copy16(L.f_ptr, stt + BL.fptr, (size_t)(m + 1) * 2);
+        copy16(QU, din + BL.QU, (size_t)ne * 4); copy16(L.EA, din + BL.E, (size_t)ne * 4); copy16(pcc, din + BL.pcc, (size_t)ne * 2);
+        copy16(L.af, din + BL.af, (size_t)m * 4); copy16(L.av, din + BL.av, (size_t)n * 4); copy16(L.sol, din + BL.sol, (size_t)n * 4);
+        if constexpr (FORCE) {
+            const float *sfs = sp.src_fs + 2 * (size_t)G.e0;                   // the external-force column is an input only
+            for (int p = tid; p < ne; p += nt) L.FRC[p] = sfs[2 * G.v_edges[p] + 1];
+        }
+    }
+    __shared__ float s_is_sat;
+    if (tid == 0) s_is_sat = hdr.is_sat;
     __syncthreads();
 
-    int active = sp.src_amask[G.b] ? 1 : 0;
+    int active = hdr.active ? 1 : 0;
     int has_prev = sp.has_prev;
     int last_event = -1;
-    int prev_from_global = sp.has_prev;
+    int prev_from_global = (sp.has_prev && sp.prev_slots) ? 1 : 0;     // later launches: the previous surveys are the loaded ones
     int use_em = sp.has_edge_mask, last_use_em = 0, em_dirty = 0;
-    float cnt = sp.src_cnt[G.b];
+    float cnt = hdr.cnt;
     int iters = 0, did_prop = 0, nsat = -1, violation = 0, cur = 0;
     int simplified = 0;                  // 0: unknown, 1: the entry state is a simplify() fix-point (checked at the first decimation), 2: it is not
     const bool other_rows = n < pv_.V;
     const float pi = sp.pi, tol = sp.tol, t_max = sp.t_max;
-    const int T = sp.T, poison_from = sp.poison_from;
+    const int T = sp.T;
+    const int poison_from = sp.pass == 1 ? ctl->poison_from : (sp.call->poisoned_all ? 0 : 0x7fffffff);
     // log(max(1 - pi * [force == +-s], eps)): two possible values per kernel (pdp_propagate.py:197,201)
     const float L0 = pdp_safe_log(1.0f - pi * 0.0f, PDP_SP_EPS), L1 = pdp_safe_log(1.0f - pi * 1.0f, PDP_SP_EPS);
 
@@ -807,7 +875,7 @@ __global__ void __launch_bounds__(512, 4) k_sp_solve_lds(PView pv_, SolveParams 
                 QU[p] = qu_new;
                 Enew[p] = eta_new;
                 if (has_prev) {
-                    const float pe = prev_from_global ? sp.src_prev[G.e0 + G.v_edges[p]] : eta_old;
+                    const float pe = prev_from_global ? sp.prev_slots[G.e0 + p] : eta_old;
                     float d = pdp_abs(pe - eta_new);
                     if (use_em) d = d * bit15_to_float(cw);
                     Y[p] = d;                               // the smooth-max weights exp(30 d) are only built when P4 cannot decide without them
@@ -825,60 +893,55 @@ __global__ void __launch_bounds__(512, 4) k_sp_solve_lds(PView pv_, SolveParams 
         // variable is inactive or has only zero surveys.
         // Site 1: with d in [0, D], W = exp(30 D), S1 = sum d, S2 = sum d^2 the chord / tangent of exp give
         //   (D W + (S1 - D) + 30 (S2 - D^2)) / (deg + S1 (W - 1) / D)  <=  smooth_max_v  <=  min(D, (S1 + S2 (W - 1) / D) / (deg + 30 S1)),
-        // one exp per VARIABLE instead of one per edge.  A variable whose bounds straddle the tolerance (or whose D is so small
+        // at most one exp per VARIABLE instead of one per edge (none when D itself is below the tolerance).  A variable whose bounds straddle the tolerance (or whose D is so small
         // that the quotient may round to zero) is marked and evaluated exactly in P5b, in the reference's summation order.
         int bits = nan_seen ? 4 : 0;       // 1: site-0 operand has an exact 0, 2: site-1 operand has one, 4: NaN, 8: gate certified open,
                                            // 16: some variable proves "not converged", 32: undecided variables, 64: tiny-D variables
         {
+            // two lanes per variable, each scans half of the variable's slots; every statistic here is order-free (maxima, and
+            // sums that only feed certificates with a safety margin), so the halves combine through one lane exchange
             const uint16_t *const v_ptr = L.v_ptr;
             const float *const av = L.av;
             float *const amb = L.xv1;
-            const int rows = has_prev ? 2 * n : n;
             const float tol_lo = tol - (2e-6f + 1e-4f * pdp_abs(tol)), tol_hi = tol + (2e-6f + 1e-4f * pdp_abs(tol));
-            for (int r = tid; r < rows; r += nt) {
-                const bool second = r >= n;
-                const int v = second ? r - n : r;
+            for (int r = tid; r < 2 * n; r += nt) {
+                const int v = r >> 1, h = r & 1;
                 const int a = v_ptr[v], bnd = v_ptr[v + 1];
-                if (!second) {
-                    float emax = 0.0f;
-                    int p = a;
-                    for (; p + 3 < bnd; p += 4) {
-                        const float e0 = Enew[p], e1 = Enew[p + 1], e2 = Enew[p + 2], e3 = Enew[p + 3];
-                        emax = fmaxf(fmaxf(emax, e0), fmaxf(e1, fmaxf(e2, e3)));      // NaN surveys are flagged in E2 already
+                const int half = (bnd - a + 1) >> 1;
+                const int lo = a + h * half, hi = h ? bnd : a + half;
+                float emax = 0.0f, S1 = 0.0f, S2 = 0.0f, D = 0.0f;
+                if (has_prev) {
+                    int p = lo;
+                    for (; p + 1 < hi; p += 2) {
+                        const float e0 = Enew[p], e1 = Enew[p + 1], d0 = Y[p], d1 = Y[p + 1];
+                        emax = fmaxf(emax, fmaxf(e0, e1));           // NaN surveys are flagged in E2 already
+                        S1 += d0 + d1; S2 = fmaf(d0, d0, fmaf(d1, d1, S2)); D = fmaxf(D, fmaxf(d0, d1));
                     }
-                    for (; p < bnd; ++p) emax = fmaxf(emax, Enew[p]);
-                    const float a_v = av[v];
-                    if (a_v == 0.0f || !(emax > 0.0f)) bits |= 1;
-                    if (a_v == 1.0f && emax >= 4.76837158203125e-7f * (float)(bnd - a)) bits |= 8;
-                    continue;
+                    if (p < hi) { const float e0 = Enew[p], d0 = Y[p]; emax = fmaxf(emax, e0); S1 += d0; S2 = fmaf(d0, d0, S2); D = fmaxf(D, d0); }
+                } else {
+                    for (int p = lo; p < hi; ++p) emax = fmaxf(emax, Enew[p]);
                 }
-                float S1 = 0.0f, S2 = 0.0f, D = 0.0f;        // order-free statistics (they only feed the certificates)
-                {
-                    float s1b = 0.0f, s2b = 0.0f, Db = 0.0f;
-                    int p = a;
-                    for (; p + 3 < bnd; p += 4) {
-                        const float d0 = Y[p], d1 = Y[p + 1], d2 = Y[p + 2], d3 = Y[p + 3];
-                        S1 += d0 + d1; s1b += d2 + d3;
-                        S2 = fmaf(d0, d0, fmaf(d1, d1, S2)); s2b = fmaf(d2, d2, fmaf(d3, d3, s2b));
-                        D = fmaxf(D, fmaxf(d0, d1)); Db = fmaxf(Db, fmaxf(d2, d3));
-                    }
-                    for (; p < bnd; ++p) { const float d0 = Y[p]; S1 += d0; S2 = fmaf(d0, d0, S2); D = fmaxf(D, d0); }
-                    S1 += s1b; S2 += s2b; D = fmaxf(D, Db);
-                }
+                emax = fmaxf(emax, __shfl_xor(emax, 1, 64));
+                S1 += __shfl_xor(S1, 1, 64); S2 += __shfl_xor(S2, 1, 64); D = fmaxf(D, __shfl_xor(D, 1, 64));
                 const float a_v = av[v];
+                const float deg = (float)(bnd - a);
+                if (a_v == 0.0f || !(emax > 0.0f)) bits |= 1;
+                if (a_v == 1.0f && emax >= 4.76837158203125e-7f * deg) bits |= 8;
+                if (!has_prev) continue;
                 float code = 0.0f;
                 if (S1 != S1) bits |= 4;                    // a NaN survey difference
                 else if (a_v == 0.0f || D == 0.0f) bits |= (0.0f < tol) ? 2 : (2 | 16);   // smooth max * active == 0 exactly
-                else if (!(D >= 1e-30f)) { bits |= 64; code = 2.0f; }
-                else {
-                    const float deg = (float)(bnd - a);
-                    const float W = pdp_expf_fin_le30(30.0f * D);
-                    const float kk = (W - 1.0f) / D;
-                    const float ub = fminf(D, fmaf(S2, kk, S1) / fmaf(30.0f, S1, deg));
-                    const float lb = (fmaf(D, W, S1 - D) + 30.0f * (S2 - D * D)) / fmaf(S1, kk, deg);
-                    if (lb * 0.9999f >= tol_hi) bits |= 16;
-                    else if (!(ub * 1.0001f < tol_lo)) { bits |= 32; code = 1.0f; }
+                else if (!(D >= 1e-30f)) { bits |= 64; code = 2.0f; }                      // the quotient may round to zero: exact
+                else if (D * 1.0001f < tol_lo) { }                                        // smooth max <= D: below the tolerance
+                else if (D >= 1e-15f) {
+                    // the bounds above, cross-multiplied by D so that no division is needed
+                    const float W = pdp_expf_fin_le30(30.0f * D), Wm1 = W - 1.0f;
+                    const float ubn = fmaf(S2, Wm1, S1 * D), ubd = D * fmaf(30.0f, S1, deg);
+                    const float lbn = D * (fmaf(D, W, S1 - D) + 30.0f * (S2 - D * D)), lbd = fmaf(S1, Wm1, D * deg);
+                    if (lbn * 0.9999f >= tol_hi * lbd) bits |= 16;
+                    else if (!(ubn * 1.0001f < tol_lo * ubd)) { bits |= 32; code = 1.0f; }
                 }
+                else { bits |= 32; code = 1.0f; }
                 amb[v] = code;
             }
         }
@@ -947,7 +1010,7 @@ __global__ void __launch_bounds__(512, 4) k_sp_solve_lds(PView pv_, SolveParams 
         const int z1 = bits & 1, z2 = (bits >> 1) & 1;
         nan_seen = (bits >> 2) & 1;
         if (nan_seen && !poisoned) {
-            if (tid == 0) atomicMin(sp.nan_iter, (uint32_t)t);
+            if (tid == 0) atomicMin(&ctl->nan_iter, (uint32_t)t);
             if (poison_from != 0x7fffffff) violation = 1;
         }
         int conv = 0;
@@ -971,7 +1034,7 @@ __global__ void __launch_bounds__(512, 4) k_sp_solve_lds(PView pv_, SolveParams 
         int decimated = 0;
         if (has_prev && conv && !poisoned && !nan_seen) {
             int spec_bits = 0;
-            decimated = UNI(lds_decimate<FORCE>(smem, G.b, n, m, ne, cur, active, pi, pv_.is_sat + G.b, &spec_bits, &simplified));
+            decimated = UNI(lds_decimate<FORCE>(smem, G.b, n, m, ne, cur, active, pi, &s_is_sat, &spec_bits, &simplified));
             spec_bits = UNI(spec_bits); simplified = UNI(simplified);
             used |= 4u;
             if (spec_bits & 1) zero |= 4u;
@@ -1004,70 +1067,146 @@ __global__ void __launch_bounds__(512, 4) k_sp_solve_lds(PView pv_, SolveParams 
         PROF_MARK(7);                                        // P7 + P8
     }
 
-    // ---- write back ------------------------------------------------------------------------------------------------------------
-    {
-        float *gq = sp.q + 3 * (size_t)G.e0;
-        float *gfs = sp.fs + 2 * (size_t)G.e0;
-        const float *sq = sp.src_q + 3 * (size_t)G.e0, *sfs = sp.src_fs + 2 * (size_t)G.e0;
-        float *Efin = cur ? L.EB : L.EA, *Eprev = cur ? L.EA : L.EB;       // after the toggle: final surveys / the ones the last sweep read
-        for (int p = tid; p < ne; p += nt) {
-            const int e = G.v_edges[p];
-            const uint16_t pw = pvv[p], cw = pcc[p];
-            if (did_prop && (sp.final_chunk || !active)) {
-                const int v = pw & 0x3fff;
-                const float s = slot_sign(pw);
-                float y = pdp_safe_log_fin(1.0f - Eprev[p], PDP_SP_EPS);
-                if (last_use_em) y = y * ((cw & PC_EM_USED) ? 1.0f : 0.0f);
-                const float force = FORCE ? L.FRC[p] : 0.0f;
-                const float pos = 0.0f + L.Pv[v], neg = 0.0f + L.Nv[v];
-                float same = (0.5f * (1.0f + s)) * pos + (0.5f * (1.0f - s)) * neg;
-                same = same - y;
-                same = same + ((force == s) ? L1 : L0);
-                float opp = (0.5f * (1.0f - s)) * pos + (0.5f * (1.0f + s)) * neg;
-                opp = opp + ((force == -s) ? L1 : L0);
-                const float dc = pdp_expf_fin_le30(same + opp);
-                const float A = pdp_expf_fin_le30(same), Bv = pdp_expf_fin_le30(opp);
-                const float qu = A * (1.0f - Bv), qs = Bv * (1.0f - A);
-                const float total = (qu + qs) + dc;
-                // (1 - mask) * old keeps a NaN forever; the three columns of q turn NaN together, so q_u carries the stickiness
-                const float sticky = QU[p];
-                gq[3 * e] = QU[p];
-                gq[3 * e + 1] = 1.0f * (qs / total) + (1.0f - 1.0f) * sticky;
-                gq[3 * e + 2] = 1.0f * (dc / total) + (1.0f - 1.0f) * sticky;
-                gfs[2 * e] = Efin[p];
-                sp.prev[G.e0 + e] = Efin[p];
-            }
-            else if (did_prop) {              // the loop continues in the next chunk: q_s / q_dc are rebuilt by the last one
-                gq[3 * e] = QU[p]; gfs[2 * e] = Efin[p]; sp.prev[G.e0 + e] = Efin[p];
-            }
-            else if (sp.inst_list) {          // replayed instance that did not run: restore its pre-pass-1 messages
-                gq[3 * e] = sq[3 * e]; gq[3 * e + 1] = sq[3 * e + 1]; gq[3 * e + 2] = sq[3 * e + 2];
-                gfs[2 * e] = sfs[2 * e]; sp.prev[G.e0 + e] = sp.src_prev[G.e0 + e];
-            }
-            if (use_em || sp.inst_list) G.emask[e] = (cw & PC_EM) ? 1.0f : 0.0f;
-        }
-    }
-    for (int v = tid; v < n; v += nt) { G.av[v] = L.av[v]; G.sol[v] = L.sol[v]; }
-    for (int c = tid; c < m; c += nt) G.af[c] = L.af[c];
+    // ---- leave: either the instance is finished (inactive, or the loop ends here) and its results go to the caller's arrays,
+    // or it continues in the next launch and its LDS image goes to the next dynamic record -----------------------------------
     int any_inactive = 0;
     for (int v = tid; v < n; v += nt) any_inactive |= (L.av[v] == 0.0f) ? 1 : 0;
     any_inactive = __syncthreads_or(any_inactive);
+    const bool finishing = did_prop && (sp.final_chunk || !active);
+    float *const Efin = cur ? L.EB : L.EA, *const Eprev = cur ? L.EA : L.EB;   // after the toggle: final surveys / the ones the last sweep read
+    if (finishing) {
+        float *gq = sp.q + 3 * (size_t)G.e0;
+        float *gfs = sp.fs + 2 * (size_t)G.e0;
+        for (int p = tid; p < ne; p += nt) {
+            const int e = G.v_edges[p];
+            const uint16_t pw = pvv[p], cw = pcc[p];
+            const int v = pw & 0x3fff;
+            const float s = slot_sign(pw);
+            float y = pdp_safe_log_fin(1.0f - Eprev[p], PDP_SP_EPS);
+            if (last_use_em) y = y * ((cw & PC_EM_USED) ? 1.0f : 0.0f);
+            const float force = FORCE ? L.FRC[p] : 0.0f;
+            const float pos = 0.0f + L.Pv[v], neg = 0.0f + L.Nv[v];
+            float same = (0.5f * (1.0f + s)) * pos + (0.5f * (1.0f - s)) * neg;
+            same = same - y;
+            same = same + ((force == s) ? L1 : L0);
+            float opp = (0.5f * (1.0f - s)) * pos + (0.5f * (1.0f + s)) * neg;
+            opp = opp + ((force == -s) ? L1 : L0);
+            const float dc = pdp_expf_fin_le30(same + opp);
+            const float A = pdp_expf_fin_le30(same), Bv = pdp_expf_fin_le30(opp);
+            const float qu = A * (1.0f - Bv), qs = Bv * (1.0f - A);
+            const float total = (qu + qs) + dc;
+            // (1 - mask) * old keeps a NaN forever; the three columns of q turn NaN together, so q_u carries the stickiness
+            const float sticky = QU[p];
+            gq[3 * e] = QU[p];
+            gq[3 * e + 1] = 1.0f * (qs / total) + (1.0f - 1.0f) * sticky;
+            gq[3 * e + 2] = 1.0f * (dc / total) + (1.0f - 1.0f) * sticky;
+            gfs[2 * e] = Efin[p];
+            sp.prev[G.e0 + e] = Efin[p];
+            G.emask[e] = (cw & PC_EM) ? 1.0f : 0.0f;
+        }
+        for (int v = tid; v < n; v += nt) { G.av[v] = L.av[v]; G.sol[v] = L.sol[v]; }
+        for (int c = tid; c < m; c += nt) G.af[c] = L.af[c];
+    } else {
+        auto dump16 = [&](size_t off, const void *src, size_t bytes) {
+            uint4 *g = reinterpret_cast<uint4 *>(dout + off);
+            const uint4 *d = reinterpret_cast<const uint4 *>(src);
+            for (int i = tid; i < (int)((bytes + 15) >> 4); i += nt) g[i] = d[i];
+        };
+        dump16(BL.QU, QU, (size_t)ne * 4); dump16(BL.E, Efin, (size_t)ne * 4);
+        dump16(BL.af, L.af, (size_t)m * 4); dump16(BL.av, L.av, (size_t)n * 4); dump16(BL.sol, L.sol, (size_t)n * 4);
+        // the next launch starts with "the mask the last propagate used" == the current mask
+        uint16_t *gpc = reinterpret_cast<uint16_t *>(dout + BL.pcc);
+        for (int p = tid; p < ne; p += nt) { const uint16_t cw = pcc[p]; gpc[p] = (uint16_t)((cw & ~PC_EM_USED) | ((cw & PC_EM) ? PC_EM_USED : 0)); }
+    }
     PROF_MARK(8);                                            // write back
     if (tid == 0) {
-        if (any_inactive) atomicMin(&pv_.flags[FL_PERM_ZERO], (uint32_t)iters);
-        sp.amask[G.b] = (uint8_t)active;
-        sp.counters[G.b] = cnt;
-        if (!sp.inst_list) sp.last_event[G.b] = last_event;
-        atomicMax(&pv_.flags[FL_ITERS_RUN], (uint32_t)iters);
-        if (violation) atomicOr(&pv_.flags[FL_SPEC_VIOLATION], 1u);
+        DynHeader h;
+        h.active = (uint32_t)active; h.done = finishing ? 1u : 0u; h.perm_zero = (finishing && any_inactive) ? 1u : 0u; h.pad0 = 0;
+        h.cnt = cnt; h.is_sat = s_is_sat; h.pad1 = 0.0f; h.pad2 = 0.0f;
+        *reinterpret_cast<DynHeader *>(dout + BL.hdr) = h;
+        if (finishing) { sp.amask[G.b] = (uint8_t)active; sp.counters[G.b] = cnt; pv_.is_sat[G.b] = s_is_sat; }
+        if (any_inactive) atomicMin(&ctl->perm_zero, (uint32_t)iters);
+        if (sp.pass == 0) sp.last_event[G.b] = last_event;
+        atomicMax(&ctl->iters_run, (uint32_t)iters);
+        if (violation) atomicOr(&ctl->violation, 1u);
     }
 }
 
-__global__ void k_replay_list(int B, const int32_t *last_event, int t_star, int32_t *list, uint32_t *count)
+// canonical arrays -> static + first dynamic record (once per call; the static part once per problem)
+__global__ void __launch_bounds__(256) k_solve_import(PView pv, const float *q, const float *fs, const uint8_t *amask, const float *prev, const float *counters,
+                                                      int has_prev, int build_static, char *stat, char *dyn, const int64_t *stat_off, const int64_t *dyn_off, float *prev_slots)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B && last_event[b] >= t_star) list[atomicAdd(count, 1u)] = b;
+    const Inst G = load_inst(pv, blockIdx.x);
+    const int n = G.n, m = G.m, ne = G.e, tid = threadIdx.x, nt = blockDim.x;
+    const BlobLayout BL = blob_layout(n, m, ne);
+    char *st = stat + stat_off[G.b], *dy = dyn + dyn_off[G.b];
+    uint16_t *pvv = reinterpret_cast<uint16_t *>(st + BL.pvv), *e2p = reinterpret_cast<uint16_t *>(st + BL.e2p);
+    float *QU = reinterpret_cast<float *>(dy + BL.QU), *Ecur = reinterpret_cast<float *>(dy + BL.E);
+    uint16_t *pcc = reinterpret_cast<uint16_t *>(dy + BL.pcc);
+    const float *sq = q + 3 * (size_t)G.e0, *sfs = fs + 2 * (size_t)G.e0;
+    for (int p = tid; p < ne; p += nt) {
+        const int e = G.v_edges[p];
+        if (build_static) { pvv[p] = (uint16_t)(G.e_var[e] | (G.sgn[e] < 0 ? 0x8000 : 0)); e2p[e] = (uint16_t)p; }
+        const bool em = G.emask[e] == 1.0f;
+        pcc[p] = (uint16_t)(G.e_fn[e] | (em ? (PC_EM | PC_EM_USED) : 0));
+        QU[p] = sq[3 * e]; Ecur[p] = sfs[2 * e];
+        if (has_prev) prev_slots[G.e0 + p] = prev[G.e0 + e];
+    }
+    if (build_static) {
+        uint16_t *vp = reinterpret_cast<uint16_t *>(st + BL.vptr), *fp = reinterpret_cast<uint16_t *>(st + BL.fptr);
+        for (int v = tid; v <= n; v += nt) vp[v] = (uint16_t)G.v_ptr[v];
+        for (int c = tid; c <= m; c += nt) fp[c] = (uint16_t)G.f_ptr[c];
+    }
+    float *av = reinterpret_cast<float *>(dy + BL.av), *sol = reinterpret_cast<float *>(dy + BL.sol), *af = reinterpret_cast<float *>(dy + BL.af);
+    int any_inactive = 0;
+    for (int v = tid; v < n; v += nt) { const float a = G.av[v]; av[v] = a; sol[v] = G.sol[v]; any_inactive |= (a == 0.0f) ? 1 : 0; }
+    for (int c = tid; c < m; c += nt) af[c] = G.af[c];
+    any_inactive = __syncthreads_or(any_inactive);
+    if (tid == 0) {
+        DynHeader h;
+        h.active = amask[G.b] ? 1u : 0u; h.done = h.active ? 0u : 1u;      // an instance that enters inactive never runs: nothing to write back
+        h.perm_zero = (h.done && any_inactive) ? 1u : 0u; h.pad0 = 0;
+        h.cnt = counters[G.b]; h.is_sat = pv.is_sat[G.b]; h.pad1 = 0.0f; h.pad2 = 0.0f;
+        *reinterpret_cast<DynHeader *>(dy + BL.hdr) = h;
+    }
 }
+
+// after pass 1 of a chunk: does a NaN poison the batch from this chunk on?  
+__global__ void k_solve_post(SolveCtl *ctl, SolveCall *call, int c)
+{
+    if (call->stop) return;
+    ctl->do_replay = 0; ctl->replay_count = 0;
+    if (!call->poisoned_all && ctl->nan_iter < (uint32_t)c) {
+        ctl->poison_from = (int32_t)ctl->nan_iter;
+        call->poisoned_all = 1;
+        if (ctl->violation) call->fail = 1;
+        ctl->do_replay = 1;
+    }
+}
+
+// only instances with a gate / convergence event at or after the poison iteration behave differently under the poison
+__global__ void k_replay_list(int B, const int32_t *last_event, SolveCtl *ctl, const SolveCall *call, int32_t *list)
+{
+    if (call->stop || !ctl->do_replay) return;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && last_event[b] >= ctl->poison_from) list[atomicAdd(&ctl->replay_count, 1u)] = b;
+}
+
+// after the (possible) replay: speculation check of the chunk and loop control
+__global__ void k_solve_finish(SolveCtl *ctl, SolveCall *call, const uint32_t *spec_used, const uint32_t *spec_zero, int c, int chunk_start)
+{
+    if (call->stop) return;
+    if (ctl->violation) call->fail = 1;
+    // iterations at or after the poison point are not speculated on (the reference's reductions are NaN there), and the
+    // kernel records nothing in a poisoned iteration
+    const int poison_from = ctl->do_replay ? ctl->poison_from : 0x7fffffff;
+    for (int t = 0; t < c && t < poison_from; ++t)
+        if ((uint32_t)t < ctl->perm_zero && (spec_used[t] & ~spec_zero[t]) != 0u) call->fail = 1;
+    const uint32_t it = ctl->iters_run;
+    call->total_iters = (uint32_t)chunk_start + it;
+    if (it < (uint32_t)c) call->stop = 1;          // every instance went inactive inside this chunk (global early exit, solver.py:383)
+}
+
 
 __global__ void k_any_force(const float *fs, int64_t E, uint32_t *flag)
 {
@@ -1102,6 +1241,155 @@ __global__ void k_max_i32(int B, const int32_t *x, uint32_t *out)
     atomicMax(out, (uint32_t)m);
 }
 
+__global__ void k_solve_ctl_init(SolveCtl *ctl, int nchunks, SolveCall *call)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nchunks) { SolveCtl c; memset(&c, 0, sizeof(c)); c.nan_iter = 0xffffffffu; c.perm_zero = 0xffffffffu; c.poison_from = 0x7fffffff; ctl[i] = c; }
+    if (i == 0) { SolveCall z; memset(&z, 0, sizeof(z)); *call = z; }
+}
+
+static int ensure_bytes(char **ptr, size_t *have, size_t need)
+{
+    if (*have >= need) return PDP_OK;
+    if (*ptr) (void)hipFree(*ptr);
+    *ptr = nullptr; *have = 0;
+    PDP_HIP_CHECK(hipMalloc((void **)ptr, need));
+    *have = need;
+    return PDP_OK;
+}
+
+// LDS-resident path: every launch of the call is enqueued up front (import, then per chunk: pass 1, poison decision, replay
+// list, replay, speculation check); the host reads one control block at the end.
+static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, bool force, size_t lds, int nt_lds, int C)
+{
+    const int T = a->iterations;
+    const size_t E = p->E, V = p->V, F = p->F, B = p->B;
+    const int nchunks = (T + C - 1) / C;
+    // ---- instance record offsets + static records: once per problem --------------------------------------------------------
+    if (!p->res_stat_off) {
+        std::vector<int32_t> v0(B + 1), f0(B + 1), e0(B + 1);
+        PDP_HIP_CHECK(hipMemcpy(v0.data(), p->inst_v0, (B + 1) * 4, hipMemcpyDeviceToHost));
+        PDP_HIP_CHECK(hipMemcpy(f0.data(), p->inst_f0, (B + 1) * 4, hipMemcpyDeviceToHost));
+        PDP_HIP_CHECK(hipMemcpy(e0.data(), p->inst_e0, (B + 1) * 4, hipMemcpyDeviceToHost));
+        std::vector<int64_t> off(2 * B);
+        size_t so = 0, dy = 0;
+        for (size_t b = 0; b < B; ++b) {
+            const BlobLayout bl = blob_layout(v0[b + 1] - v0[b], f0[b + 1] - f0[b], e0[b + 1] - e0[b]);
+            off[b] = (int64_t)so; off[B + b] = (int64_t)dy;
+            so += bl.stat_bytes; dy += bl.dyn_bytes;
+        }
+        PDP_HIP_CHECK(hipMalloc((void **)&p->res_stat_off, 2 * B * sizeof(int64_t)));
+        PDP_HIP_CHECK(hipMemcpy(p->res_stat_off, off.data(), 2 * B * sizeof(int64_t), hipMemcpyHostToDevice));
+        p->res_stat_bytes = so + 16; p->res_dyn_bytes = dy + 16;
+        PDP_HIP_CHECK(hipMalloc((void **)&p->res_stat, p->res_stat_bytes));
+        PDP_HIP_CHECK(hipMalloc((void **)&p->res_dyn[0], p->res_dyn_bytes));
+        PDP_HIP_CHECK(hipMalloc((void **)&p->res_dyn[1], p->res_dyn_bytes));
+        PDP_HIP_CHECK(hipMalloc((void **)&p->res_prev_slots, (E + 4) * sizeof(float)));
+        p->res_static_built = 0;
+    }
+    const int64_t *stat_off = p->res_stat_off, *dyn_off = p->res_stat_off + B;
+    // ---- control blocks, speculation record, replay list; call-entry snapshot for the failure path ---------------------------
+    const size_t ctl_bytes = (size_t)nchunks * sizeof(SolveCtl) + sizeof(SolveCall) + 2 * (size_t)T * 4 + 2 * B * 4 + 64;
+    int status = ensure_bytes(&p->res_ctl, &p->res_ctl_bytes, ctl_bytes);
+    if (status != PDP_OK) return status;
+    SolveCtl *ctl = (SolveCtl *)p->res_ctl;
+    SolveCall *call = (SolveCall *)(ctl + nchunks);
+    uint32_t *spec = (uint32_t *)(call + 1);                 // [T] used | [T] zero
+    int32_t *last_event = (int32_t *)(spec + 2 * (size_t)T);
+    int32_t *replay_list = last_event + B;
+    const size_t snap_floats = 3 * E + 2 * E + V + F + V + B + E + E + B;
+    const size_t snap_bytes = snap_floats * 4 + ((B + 63) & ~(size_t)63);
+    status = ensure_bytes(&p->solve_blob, &p->solve_blob_bytes, snap_bytes + 64);
+    if (status != PDP_OK) return status;
+    const size_t host_words = ((size_t)nchunks * sizeof(SolveCtl) + sizeof(SolveCall)) / 4;
+    if (p->solve_host_words < host_words) {
+        if (p->solve_host) (void)hipHostFree(p->solve_host);
+        p->solve_host = nullptr; p->solve_host_words = 0;
+        PDP_HIP_CHECK(hipHostMalloc((void **)&p->solve_host, host_words * 4));
+        p->solve_host_words = host_words;
+    }
+    SolveSnapshot snap0;
+    {
+        float *f = (float *)p->solve_blob;
+        snap0.q = f; f += 3 * E; snap0.fs = f; f += 2 * E; snap0.av = f; f += V; snap0.af = f; f += F; snap0.sol = f; f += V;
+        snap0.sat = f; f += B; snap0.emask = f; f += E; snap0.prev = f; f += E; snap0.cnt = f; f += B; snap0.amask = (uint8_t *)f;
+    }
+    const int had_prev0 = a->decimator->has_prev, had_emask0 = p->has_edge_mask;
+    status = snapshot_copy(p, a, snap0, true, st);
+    if (status != PDP_OK) return status;
+
+    if (force) PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sp_solve_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    else PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sp_solve_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    a->used_lds_host = 1;
+
+    hipLaunchKernelGGL(k_solve_ctl_init, dim3((nchunks + 255) / 256), dim3(256), 0, st, ctl, nchunks, call);
+    PDP_HIP_CHECK(hipMemsetAsync(spec, 0, 2 * (size_t)T * 4, st));
+    hipLaunchKernelGGL(k_solve_import, dim3(p->B), dim3(256), 0, st, make_view(p), (const float *)a->q, (const float *)a->fs, (const uint8_t *)a->active_mask,
+                       (const float *)a->decimator->prev, (const float *)a->decimator->counters, a->decimator->has_prev, p->res_static_built ? 0 : 1,
+                       p->res_stat, p->res_dyn[0], stat_off, dyn_off, p->res_prev_slots);
+    PDP_LAUNCH_CHECK();
+    p->res_static_built = 1;
+
+    SolveParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.tol = a->tolerance; sp.t_max = a->t_max; sp.pi = a->pi;
+    sp.q = a->q; sp.fs = a->fs; sp.amask = a->active_mask; sp.src_fs = a->fs;
+    sp.prev = a->decimator->prev; sp.counters = a->decimator->counters;
+    sp.check_termination = a->check_termination;
+    sp.last_event = last_event; sp.inst_list = replay_list;
+    sp.call = call; sp.stat = p->res_stat; sp.stat_off = stat_off; sp.dyn_off = dyn_off;
+    int done = 0;
+    for (int k = 0; k < nchunks; ++k) {
+        const int c = (T - done) < C ? (T - done) : C;
+        sp.T = c; sp.chunk_start = done; sp.final_chunk = (done + c >= T) ? 1 : 0;
+        sp.has_prev = (k == 0) ? a->decimator->has_prev : 1;
+        sp.has_edge_mask = (k == 0) ? p->has_edge_mask : 1;
+        sp.prev_slots = (k == 0 && a->decimator->has_prev) ? p->res_prev_slots : nullptr;
+        sp.ctl = ctl + k; sp.spec_used = spec + done; sp.spec_zero = spec + T + done;
+        sp.dyn_in = p->res_dyn[k & 1]; sp.dyn_out = p->res_dyn[(k + 1) & 1];
+        for (int pass = 0; pass < 2; ++pass) {
+            sp.pass = pass;
+            if (force) hipLaunchKernelGGL((k_sp_solve_lds<true>), dim3(p->B), dim3(nt_lds), lds, st, make_view(p), sp);
+            else hipLaunchKernelGGL((k_sp_solve_lds<false>), dim3(p->B), dim3(nt_lds), lds, st, make_view(p), sp);
+            if (pass == 0) {
+                hipLaunchKernelGGL(k_solve_post, dim3(1), dim3(1), 0, st, ctl + k, call, c);
+                hipLaunchKernelGGL(k_replay_list, dim3((p->B + 255) / 256), dim3(256), 0, st, p->B, (const int32_t *)last_event, ctl + k, (const SolveCall *)call, replay_list);
+            }
+        }
+        hipLaunchKernelGGL(k_solve_finish, dim3(1), dim3(1), 0, st, ctl + k, call, (const uint32_t *)sp.spec_used, (const uint32_t *)sp.spec_zero, c, done);
+        PDP_LAUNCH_CHECK();
+        done += c;
+    }
+    PDP_HIP_CHECK(hipMemcpyAsync(p->solve_host, ctl, host_words * 4, hipMemcpyDeviceToHost, st));
+    PDP_HIP_CHECK(hipStreamSynchronize(st));
+    const SolveCtl *hctl = (const SolveCtl *)p->solve_host;
+    const SolveCall *hcall = (const SolveCall *)(hctl + nchunks);
+    const bool debug = getenv("PDP_DEBUG") != nullptr;
+    int launches = 0;
+    for (int k = 0; k < nchunks; ++k) {
+        if (hctl[k].iters_run == 0 && k * C >= (int)hcall->total_iters && k > 0) break;     // launches after the global early exit return at once
+        launches += 1 + (hctl[k].do_replay && hctl[k].replay_count ? 1 : 0);
+        if (debug)
+            fprintf(stderr, "[pdp_sp_solve] chunk@%d violation=%u perm_from=%u nan_iter=%u poison_from=%d replayed=%u iters=%u lds=%zu\n", k * C,
+                    hctl[k].violation, hctl[k].perm_zero, hctl[k].nan_iter, hctl[k].poison_from, hctl[k].do_replay ? hctl[k].replay_count : 0u, hctl[k].iters_run, lds);
+    }
+    a->kernel_launches_host = launches;
+    if (hcall->fail) {
+        // leave the caller's state exactly as it was at call entry so that it can rerun the batch step-wise
+        status = snapshot_copy(p, a, snap0, false, st);
+        if (status == PDP_OK) status = hipStreamSynchronize(st) == hipSuccess ? PDP_OK : PDP_ERR_HIP;
+        a->decimator->has_prev = had_prev0; p->has_edge_mask = had_emask0;
+        if (status != PDP_OK) return status;
+        pdp_set_error("persistent solve: a cross-instance coupling of the reference became active (batch-global min != 0); "
+                      "state restored, rerun the batch step-wise");
+        return PDP_ERR_SPECULATION;
+    }
+    a->decimator->has_prev = 1;
+    p->has_edge_mask = 1;
+    a->iterations_run_host = (int)hcall->total_iters;
+    return PDP_OK;
+}
+
 extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
 {
     PDP_REQUIRE(p && a && p->av, "NULL argument / state not bound");
@@ -1116,9 +1404,24 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
     // The loop runs in chunks of C iterations (one launch each; the kernel resumes from the HBM state).  Chunking bounds
     // the cost of reproducing the reference's NaN poisoning: only the chunk in which the first NaN appears is partially
     // replayed, and every later chunk runs "poisoned from its first iteration" without any snapshot.
-    int C = 16;   // measured on MI355X (n=200, batch=5000, T=100): 8 -> 3342, 16 -> 3668, 32 -> 3642, 100 -> 3063 iterations/s
+    // chunk length, measured on MI355X (n=200, batch=5000, T=100, one NaN poison at iteration 81): 8 -> 6593, 12 -> 6837,
+    // 16 -> 6638, 25 -> 6415 iterations/s.  Short chunks bound the poison replay, long ones amortise the record copies.
+    int C = 12;
     if (const char *env = getenv("PDP_SOLVE_CHUNK")) { const int v = atoi(env); if (v > 0) C = v; }
     if (C > T) C = T;
+    {
+        // does the external-force column hold anything but zeros?  (it does not for the p-d-p solver)
+        PDP_HIP_CHECK(hipMemsetAsync(p->flags + FL_N_SEL, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k_any_force, dim3(1024), dim3(256), 0, st, a->fs, (int64_t)E, p->flags + FL_N_SEL);
+        uint32_t force_flag = 0;
+        PDP_HIP_CHECK(hipMemcpyAsync(&force_flag, p->flags + FL_N_SEL, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        PDP_HIP_CHECK(hipStreamSynchronize(st));
+        const bool force_r = force_flag != 0;
+        const size_t lds_r = lds2_bytes_for(p->max_n, p->max_m, p->max_e, force_r);
+        const bool fits_r = p->fn_edges_identity && lds_r <= 160 * 1024 - 1024 && p->max_e < 65535 && p->max_n < 16384 && p->max_m < 16384;
+        if (fits_r) return sp_solve_resident(p, a, st, force_r, lds_r, p->max_e <= 1024 ? 256 : 512, C);
+    }
+    // ---- instances too large for the LDS: HBM-resident kernel, host-driven chunk loop -----------------------------------
 
     // one allocation: speculation record [2C] + control words + per-instance records + two snapshots (call entry, chunk entry)
     const size_t words = 2 * (size_t)C + 8;
@@ -1163,22 +1466,11 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
     sp.spec_used = spec; sp.spec_zero = spec + C; sp.nan_iter = ctl;
     sp.last_event = last_event;
 
-    // does the external-force column hold anything but zeros?  (it does not for the p-d-p solver)
     PDP_HIP_CHECK(hipMemsetAsync(ctl, 0, sizeof(uint32_t) * 8, st));
-    hipLaunchKernelGGL(k_any_force, dim3(1024), dim3(256), 0, st, a->fs, (int64_t)E, ctl + 1);
-    uint32_t force_flag = 0;
-    PDP_HIP_CHECK(hipMemcpyAsync(&force_flag, ctl + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    PDP_HIP_CHECK(hipStreamSynchronize(st));
-    const bool force = force_flag != 0;
-    const size_t lds = lds2_bytes_for(p->max_n, p->max_m, p->max_e, force);
-    const bool fits = p->fn_edges_identity && lds <= 160 * 1024 - 1024 && p->max_e < 65535 && p->max_n < 16384 && p->max_m < 16384;
-    const int nt_lds = p->max_e <= 1024 ? 256 : 512;
+    const bool fits = false;
+    const size_t lds = 0;
     float *extra_v = nullptr;
-    if (fits) {
-        if (force) PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sp_solve_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        else PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sp_solve_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        a->used_lds_host = 1;
-    } else {
+    {
         for (int i = 0; i < 4; ++i) sp.ws_e[i] = p->ws_e[i];
         sp.ws_f = p->ws_f[0];
         for (int i = 0; i < 6; ++i) sp.ws_v[i] = p->ws_v[i];
@@ -1188,11 +1480,7 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
         for (int i = 0; i < 3; ++i) sp.ws_vi[i] = p->ws_vi[i];
         sp.ws_fu[0] = p->ws_fu[0]; sp.ws_fu[1] = p->ws_fu[1];
     }
-    auto launch = [&](int grid) {
-        if (fits && force) hipLaunchKernelGGL((k_sp_solve_lds<true>), dim3(grid), dim3(nt_lds), lds, st, make_view(p), sp);
-        else if (fits) hipLaunchKernelGGL((k_sp_solve_lds<false>), dim3(grid), dim3(nt_lds), lds, st, make_view(p), sp);
-        else hipLaunchKernelGGL((k_sp_solve<int32_t, false>), dim3(grid), dim3(256), 0, st, make_view(p), sp);
-    };
+    auto launch = [&](int grid) { hipLaunchKernelGGL((k_sp_solve<int32_t, false>), dim3(grid), dim3(256), 0, st, make_view(p), sp); };
     auto set_src_live = [&]() {
         sp.inst_list = nullptr;
         sp.src_q = a->q; sp.src_fs = a->fs; sp.src_av = p->av; sp.src_af = p->af; sp.src_sol = p->sol; sp.src_sat = p->is_sat;
@@ -1232,17 +1520,7 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
                 poison_from = (int)t_nan;
                 poisoned_all = true;
                 if (p->flags_host[FL_SPEC_VIOLATION]) { ok = false; break; }
-                if (fits) {
-                    // only instances with a gate / convergence event at or after t_nan behave differently under the
-                    // poison: replay exactly those from the chunk-entry snapshot
-                    hipLaunchKernelGGL(k_replay_list, dim3((p->B + 255) / 256), dim3(256), 0, st, p->B, last_event, poison_from, replay_list, ctl + 2);
-                    PDP_HIP_CHECK(hipMemcpyAsync(&n_replayed, ctl + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-                    PDP_HIP_CHECK(hipStreamSynchronize(st));
-                    if (n_replayed == 0) break;
-                    sp.inst_list = replay_list;
-                    sp.src_q = snap.q; sp.src_fs = snap.fs; sp.src_av = snap.av; sp.src_af = snap.af; sp.src_sol = snap.sol;
-                    sp.src_sat = snap.sat; sp.src_emask = snap.emask; sp.src_prev = snap.prev; sp.src_cnt = snap.cnt; sp.src_amask = snap.amask;
-                } else {
+                {
                     status = snapshot_copy(p, a, snap, false, st);       // HBM kernel works in place: full replay of the chunk
                     if (status != PDP_OK) break;
                 }
