@@ -67,6 +67,7 @@ struct SolveParams {
     char *dyn_out;              // dynamic records this launch leaves behind
     const int64_t *stat_off, *dyn_off;   // [B] byte offsets of the instance records
     const float *prev_slots;    // [E] slot-major copy of the decimator's previous surveys (first launch of a call only)
+    int debug_skip;             // -DPDP_PHASE_PROF builds: bit mask of phases to skip (timing experiments, results are wrong)
 };
 
 // Device-side control of the chunked persistent solve: the host enqueues every launch of a call up front and reads
@@ -94,7 +95,7 @@ struct SolveCall {
 // gather through the CSR, and the record a launch resumed from stays intact, which is the snapshot the poison replay needs.
 //   static  (per problem): pvv | e2p | v_ptr | f_ptr
 //   dynamic (two copies, ping-pong): header | QU | E | pcc | af | av | sol
-struct DynHeader { uint32_t active, done, perm_zero, pad0; float cnt, is_sat, pad1, pad2; };
+struct DynHeader { uint32_t active, done, perm_zero, simplified; float cnt, is_sat, pad1, pad2; };   // simplified: 0 unknown, 1 the state is a simplify() fix-point, 2 it is not
 struct BlobLayout { size_t pvv, e2p, vptr, fptr, stat_bytes, hdr, QU, E, pcc, af, av, sol, dyn_bytes; };
 __host__ __device__ inline BlobLayout blob_layout(int n, int m, int ne)
 {
@@ -481,19 +482,25 @@ __device__ __forceinline__ LView make_lview(const LdsArrays &L, int b, int n, in
 #define UNI(x) __builtin_amdgcn_readfirstlane(x)
 #ifdef PDP_PHASE_PROF
 __device__ unsigned long long g_phase_cycles[16];
-#define PROF_DECL unsigned long long _t0 = __builtin_readcyclecounter(), _t1;
-#define PROF_MARK(i) do { _t1 = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_phase_cycles[i], _t1 - _t0); _t0 = _t1; } while (0)
+// per-phase sums stay in registers and are flushed once per launch: one atomic per phase and iteration from 5000 workgroups
+// onto the same 16 words more than doubled the kernel time
+#define PROF_DECL unsigned long long _t0 = __builtin_readcyclecounter(), _t1; uint32_t _acc[13] = {0};
+#define PROF_MARK(i) do { _t1 = __builtin_readcyclecounter(); _acc[i] += (uint32_t)(_t1 - _t0); _t0 = _t1; } while (0)
+#define PROF_FLUSH() do { if (threadIdx.x == 0) { _Pragma("unroll") for (int _i = 0; _i < 13; ++_i) if (_acc[_i]) atomicAdd(&g_phase_cycles[_i], (unsigned long long)_acc[_i]); } } while (0)
 extern "C" int pdp_debug_phase_cycles(unsigned long long *out_host, int reset)
 {
     if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
     if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)) != hipSuccess) return 1; }
     return 0;
 }
-#define PROF_COUNT(i) do { if (threadIdx.x == 0) atomicAdd(&g_phase_cycles[i], 1ull); } while (0)
+#define PROF_COUNT(i) do { _acc[i] += 1u; } while (0)
+#define PROF_SKIP(bit) (sp.debug_skip & (bit))
 #else
 #define PROF_DECL
 #define PROF_MARK(i)
 #define PROF_COUNT(i)
+#define PROF_FLUSH()
+#define PROF_SKIP(bit) false
 #endif
 // Four independent evaluations side by side.  A dependent chain of VALU ops issues one instruction per ~4.3 cycles on
 // gfx950, two or more independent chains in the same wave reach ~2.2 (tools/micro/pk_rate.hip), so the transcendental
@@ -556,9 +563,48 @@ __device__ __forceinline__ f4v log4_fin(f4v x, float eps)
     return r + (x - x);
 }
 
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef int i2v __attribute__((ext_vector_type(2)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2v log2_fin(f2v x, float eps)             // two-wide twin of log4_fin for the ragged last trip
+{
+    const f2v xm = __builtin_elementwise_max(x, (f2v)(eps));
+    f2v m; i2v e;
+    m.x = __builtin_amdgcn_frexp_mantf(xm.x); m.y = __builtin_amdgcn_frexp_mantf(xm.y);
+    e.x = __builtin_amdgcn_frexp_expf(xm.x); e.y = __builtin_amdgcn_frexp_expf(xm.y);
+    const u2v lt = (__builtin_bit_cast(u2v, m) - 0x3f3504f3u) >> 31;
+    const i2v lti = __builtin_bit_cast(i2v, lt);
+    e = e - lti;
+    m.x = __builtin_ldexpf(m.x, lti.x); m.y = __builtin_ldexpf(m.y, lti.y);
+    m = m - 1.0f;
+    const f2v z = m * m;
+    f2v y = (f2v)(7.0376836292e-2f);
+    y = __builtin_elementwise_fma(y, m, (f2v)(-1.1514610310e-1f));
+    y = __builtin_elementwise_fma(y, m, (f2v)(1.1676998740e-1f));
+    y = __builtin_elementwise_fma(y, m, (f2v)(-1.2420140846e-1f));
+    y = __builtin_elementwise_fma(y, m, (f2v)(1.4249322787e-1f));
+    y = __builtin_elementwise_fma(y, m, (f2v)(-1.6668057665e-1f));
+    y = __builtin_elementwise_fma(y, m, (f2v)(2.0000714765e-1f));
+    y = __builtin_elementwise_fma(y, m, (f2v)(-2.4999993993e-1f));
+    y = __builtin_elementwise_fma(y, m, (f2v)(3.3333331174e-1f));
+    y = (y * m) * z;
+    const f2v fe = __builtin_convertvector(e, f2v);
+    y = __builtin_elementwise_fma(fe, (f2v)(-2.12194440e-4f), y);
+    y = __builtin_elementwise_fma((f2v)(-0.5f), z, y);
+    f2v r = m + y;
+    r = __builtin_elementwise_fma(fe, (f2v)(0.693359375f), r);
+    return r + (x - x);
+}
+
 // select-free decoding of the packed slot words (a v_cmp + v_cndmask pair costs ~4 FMAs on gfx950)
 __device__ __forceinline__ float slot_sign(uint16_t pw) { return __uint_as_float(0x3f800000u | ((uint32_t)(pw & 0x8000u) << 16)); }      // bit 15 set: -1, else +1
-__device__ __forceinline__ float bit15_to_float(uint16_t w) { return __uint_as_float((uint32_t)((int32_t)((uint32_t)w << 16) >> 31) & 0x3f800000u); }   // bit 15 set: 1, else 0
+__device__ __forceinline__ float bit15_to_float(uint16_t w)          // bit 15 set: 1, else 0
+{
+    const int32_t ext = (int32_t)((uint32_t)w << 16) >> 31;
+    uint32_t r;
+    asm("v_and_b32 %0, 0x3f800000, %1" : "=v"(r) : "v"(ext));     // kept opaque: the optimiser would turn the mask back into a compare + select
+    return __uint_as_float(r);
+}
 __device__ __forceinline__ float uni_f(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
 
 // P6, cold: SurveyScorer + arg-max + set_variables (pdp_decimate.py:152-171).  Returns 1 if a variable was fixed;
@@ -575,7 +621,7 @@ __device__ __noinline__ int lds_decimate(unsigned char *smem, int b, int n, int 
     float *Enew = cur ? L.EA : L.EB;
     float *score = L.xv2, *assign = L.coeff;
     for (int p = tid; p < ne; p += nt)
-        L.Y[p] = pdp_safe_log(1.0f - Enew[p], PDP_SCORER_EPS) * (0.0f + L.af[L.pcc[p] & 0x3fff]);
+        L.Y[p] = pdp_safe_log_fin(1.0f - Enew[p], PDP_SCORER_EPS) * (0.0f + L.af[L.pcc[p] & 0x3fff]);   // surveys are finite or NaN
     __syncthreads();
     int z3 = 0, anynz = 0, cn = 0;
     for (int v = tid; v < n; v += nt) {
@@ -770,7 +816,7 @@ __global__ void __launch_bounds__(512, 4) k_sp_solve_lds(PView pv_, SolveParams 
     int use_em = sp.has_edge_mask, last_use_em = 0, em_dirty = 0;
     float cnt = hdr.cnt;
     int iters = 0, did_prop = 0, nsat = -1, violation = 0, cur = 0;
-    int simplified = 0;                  // 0: unknown, 1: the entry state is a simplify() fix-point (checked at the first decimation), 2: it is not
+    int simplified = (int)hdr.simplified;   // 0: unknown, 1: the state is a simplify() fix-point (checked at the first decimation of a call), 2: it is not
     const bool other_rows = n < pv_.V;
     const float pi = sp.pi, tol = sp.tol, t_max = sp.t_max;
     const int T = sp.T;
@@ -786,12 +832,19 @@ __global__ void __launch_bounds__(512, 4) k_sp_solve_lds(PView pv_, SolveParams 
         iters = t + 1;
         float *const Eold = cur ? L.EB : L.EA, *const Enew = cur ? L.EA : L.EB;
         // ---- E1: per-slot logs, two slots per trip (independent chains for the scheduler / packed fp32 ops) -------------
+        if (!PROF_SKIP(1))
         for (int p0 = tid; p0 < ne; p0 += 2 * nt) {
             const int p1 = p0 + nt;
             const bool has1 = p1 < ne;
             const int q1 = has1 ? p1 : p0;
-            const f4v lg = log4_fin((f4v){QU[p0], QU[q1], 1.0f - Eold[p0], 1.0f - Eold[q1]}, PDP_SP_EPS);
-            float x0 = lg.x, x1 = lg.y, y0 = lg.z, y1 = lg.w;
+            float x0, x1, y0, y1;
+            if (__builtin_amdgcn_ballot_w64(has1) != 0) {
+                const f4v lg = log4_fin((f4v){QU[p0], QU[q1], 1.0f - Eold[p0], 1.0f - Eold[q1]}, PDP_SP_EPS);
+                x0 = lg.x; x1 = lg.y; y0 = lg.z; y1 = lg.w;
+            } else {                                        // ragged last trip: one slot per lane
+                const f2v lg = log2_fin((f2v){QU[p0], 1.0f - Eold[p0]}, PDP_SP_EPS);
+                x0 = lg.x; y0 = lg.y; x1 = x0; y1 = y0;
+            }
             if (use_em) {
                 uint16_t c0 = pcc[p0], c1 = pcc[q1];
                 const float em0 = bit15_to_float(c0), em1 = bit15_to_float(c1);
@@ -811,38 +864,59 @@ __global__ void __launch_bounds__(512, 4) k_sp_solve_lds(PView pv_, SolveParams 
         {
             const uint16_t *const e2p = L.e2p, *const f_ptr = L.f_ptr, *const v_ptr = L.v_ptr;
             float *const S = L.S, *const Pv = L.Pv, *const Nv = L.Nv;
-            for (int r = tid; r < m + n; r += nt) {
-                if (r < m) {
-                    float acc = 0.0f;
-                    const int a = f_ptr[r], bnd = f_ptr[r + 1];
-                    int k = a;
-                    for (; k + 2 < bnd; k += 3) {
-                        const float x0 = X[e2p[k]], x1 = X[e2p[k + 1]], x2 = X[e2p[k + 2]];
-                        acc = acc + x0; acc = acc + x1; acc = acc + x2;
-                    }
-                    for (; k < bnd; ++k) acc = acc + X[e2p[k]];
-                    S[r] = acc;
-                } else {
-                    const int v = r - m;
-                    float P = 0.0f, N = 0.0f;
-                    const int a = v_ptr[v], bnd = v_ptr[v + 1];
-                    int p = a;
-                    for (; p + 3 < bnd; p += 4) {
-                        const float y0 = Y[p], y1 = Y[p + 1], y2 = Y[p + 2], y3 = Y[p + 3];
-                        const uint16_t s0 = pvv[p], s1 = pvv[p + 1], s2 = pvv[p + 2], s3 = pvv[p + 3];
-                        const float n0 = bit15_to_float(s0), n1 = bit15_to_float(s1), n2 = bit15_to_float(s2), n3 = bit15_to_float(s3);
-                        P = P + (1.0f - n0) * y0; N = N + n0 * y0;
-                        P = P + (1.0f - n1) * y1; N = N + n1 * y1;
-                        P = P + (1.0f - n2) * y2; N = N + n2 * y2;
-                        P = P + (1.0f - n3) * y3; N = N + n3 * y3;
-                    }
-                    for (; p < bnd; ++p) {
-                        const float y0 = Y[p]; const uint16_t s0 = pvv[p];
-                        const float n0 = bit15_to_float(s0);
-                        P = P + (1.0f - n0) * y0; N = N + n0 * y0;
-                    }
-                    Pv[v] = P; Nv[v] = N;
+            // Work is handed out per wave in items of 64 rows.  A variable row is a sequential sum over ~|E|/n terms and costs
+            // about two clause rows, so the waves that take a variable item skip the first two rounds of clause items.
+            const int nvi = (n + 63) >> 6, nci = (m + 63) >> 6;
+            auto var_rows = [&](int item) {
+                const int v = (item << 6) + lane;
+                if (v >= n) return;
+                float P = 0.0f, N = 0.0f;
+                const int a = v_ptr[v], bnd = v_ptr[v + 1];
+                int p = a;
+                for (; p + 7 < bnd; p += 8) {                   // eight loads in flight per LDS round trip, then the ordered adds
+                    float y[8]; uint16_t sg[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { y[j] = Y[p + j]; sg[j] = pvv[p + j]; }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float nj = bit15_to_float(sg[j]); P = P + (1.0f - nj) * y[j]; N = N + nj * y[j]; }
                 }
+                for (; p + 3 < bnd; p += 4) {
+                    float y[4]; uint16_t sg[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { y[j] = Y[p + j]; sg[j] = pvv[p + j]; }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const float nj = bit15_to_float(sg[j]); P = P + (1.0f - nj) * y[j]; N = N + nj * y[j]; }
+                }
+                {
+                    float y[3]; uint16_t sg[3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { const int q = (p + j < bnd) ? p + j : a; y[j] = Y[q]; sg[j] = pvv[q]; }
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        if (p + j < bnd) { const float nj = bit15_to_float(sg[j]); P = P + (1.0f - nj) * y[j]; N = N + nj * y[j]; }
+                }
+                Pv[v] = P; Nv[v] = N;
+            };
+            auto clause_rows = [&](int item) {
+                const int r = (item << 6) + lane;
+                if (r >= m) return;
+                float acc = 0.0f;
+                const int a = f_ptr[r], bnd = f_ptr[r + 1];
+                int k = a;
+                for (; k + 2 < bnd; k += 3) {
+                    const float x0 = X[e2p[k]], x1 = X[e2p[k + 1]], x2 = X[e2p[k + 2]];
+                    acc = acc + x0; acc = acc + x1; acc = acc + x2;
+                }
+                for (; k < bnd; ++k) acc = acc + X[e2p[k]];
+                S[r] = acc;
+            };
+            if (!PROF_SKIP(2)) {
+                for (int i = wid; i < nvi; i += nw) var_rows(i);
+                const int first = (nvi < nw) ? nvi : nw;          // waves [first, nw) have no variable item
+                const int base = 2 * (nw - first);
+                if (wid >= first)
+                    for (int rd = 0; rd < 2; ++rd) { const int j = (wid - first) + rd * (nw - first); if (j < nci) clause_rows(j); }
+                for (int j = base + wid; j < nci; j += nw) clause_rows(j);
             }
         }
         __syncthreads();
@@ -851,6 +925,7 @@ __global__ void __launch_bounds__(512, 4) k_sp_solve_lds(PView pv_, SolveParams 
         float nan_acc = 0.0f;
         {
             const float *const S = L.S, *const Pv = L.Pv, *const Nv = L.Nv;
+            if (!PROF_SKIP(4))
             for (int p = tid; p < ne; p += nt) {
                 const uint16_t pw = pvv[p], cw = pcc[p];
                 const int v = pw & 0x3fff, c = cw & 0x3fff;
@@ -904,6 +979,7 @@ __global__ void __launch_bounds__(512, 4) k_sp_solve_lds(PView pv_, SolveParams 
             const float *const av = L.av;
             float *const amb = L.xv1;
             const float tol_lo = tol - (2e-6f + 1e-4f * pdp_abs(tol)), tol_hi = tol + (2e-6f + 1e-4f * pdp_abs(tol));
+            if (!PROF_SKIP(8))
             for (int r = tid; r < 2 * n; r += nt) {
                 const int v = r >> 1, h = r & 1;
                 const int a = v_ptr[v], bnd = v_ptr[v + 1];
@@ -1032,7 +1108,7 @@ __global__ void __launch_bounds__(512, 4) k_sp_solve_lds(PView pv_, SolveParams 
         if (has_prev && !conv && n > 0) zero |= 4u;
         // ---- P6: decimation (rare, out of line) ------------------------------------------------------------------------------
         int decimated = 0;
-        if (has_prev && conv && !poisoned && !nan_seen) {
+        if (has_prev && conv && !poisoned && !nan_seen && !PROF_SKIP(16)) {
             int spec_bits = 0;
             decimated = UNI(lds_decimate<FORCE>(smem, G.b, n, m, ne, cur, active, pi, &s_is_sat, &spec_bits, &simplified));
             spec_bits = UNI(spec_bits); simplified = UNI(simplified);
@@ -1119,9 +1195,10 @@ __global__ void __launch_bounds__(512, 4) k_sp_solve_lds(PView pv_, SolveParams 
         for (int p = tid; p < ne; p += nt) { const uint16_t cw = pcc[p]; gpc[p] = (uint16_t)((cw & ~PC_EM_USED) | ((cw & PC_EM) ? PC_EM_USED : 0)); }
     }
     PROF_MARK(8);                                            // write back
+    PROF_FLUSH();
     if (tid == 0) {
         DynHeader h;
-        h.active = (uint32_t)active; h.done = finishing ? 1u : 0u; h.perm_zero = (finishing && any_inactive) ? 1u : 0u; h.pad0 = 0;
+        h.active = (uint32_t)active; h.done = finishing ? 1u : 0u; h.perm_zero = (finishing && any_inactive) ? 1u : 0u; h.simplified = (uint32_t)simplified;
         h.cnt = cnt; h.is_sat = s_is_sat; h.pad1 = 0.0f; h.pad2 = 0.0f;
         *reinterpret_cast<DynHeader *>(dout + BL.hdr) = h;
         if (finishing) { sp.amask[G.b] = (uint8_t)active; sp.counters[G.b] = cnt; pv_.is_sat[G.b] = s_is_sat; }
@@ -1165,7 +1242,7 @@ __global__ void __launch_bounds__(256) k_solve_import(PView pv, const float *q, 
     if (tid == 0) {
         DynHeader h;
         h.active = amask[G.b] ? 1u : 0u; h.done = h.active ? 0u : 1u;      // an instance that enters inactive never runs: nothing to write back
-        h.perm_zero = (h.done && any_inactive) ? 1u : 0u; h.pad0 = 0;
+        h.perm_zero = (h.done && any_inactive) ? 1u : 0u; h.simplified = 0;
         h.cnt = counters[G.b]; h.is_sat = pv.is_sat[G.b]; h.pad1 = 0.0f; h.pad2 = 0.0f;
         *reinterpret_cast<DynHeader *>(dy + BL.hdr) = h;
     }
@@ -1338,6 +1415,7 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     sp.check_termination = a->check_termination;
     sp.last_event = last_event; sp.inst_list = replay_list;
     sp.call = call; sp.stat = p->res_stat; sp.stat_off = stat_off; sp.dyn_off = dyn_off;
+    if (const char *env = getenv("PDP_DEBUG_SKIP")) sp.debug_skip = atoi(env);
     int done = 0;
     for (int k = 0; k < nchunks; ++k) {
         const int c = (T - done) < C ? (T - done) : C;

@@ -20,12 +20,14 @@ for rep in range(2):
     am = torch.ones(prob.B, dtype=torch.uint8, device=dev); dec = native.Decimator(prob)
     prob.simplify(); torch.cuda.synchronize()
     L.pdp_debug_phase_cycles(out, 1)
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True); t0.record()
     it, lds = prob.sp_solve(q, fs, am, dec, T, 0.02, 100)
-    torch.cuda.synchronize()
+    t1.record(); torch.cuda.synchronize()
+    wall_ms = t0.elapsed_time(t1)
     L.pdp_debug_phase_cycles(out, 0)
 names = ['load', 'E1 logs', 'R1 row sums', 'E2 exps/div', 'P4 smooth max', 'P5 reduce', 'P6 decimate', 'P7+P8', 'write back']
 tot = sum(out[i] for i in range(9))
 for i, nm in enumerate(names):
     print("%-16s %14d cycles  %5.1f%%" % (nm, out[i], 100.0 * out[i] / tot))
-print("total WG-cycles %d" % tot)
+print("total WG-cycles %d, solve call %.2f ms (PDP_DEBUG_SKIP=%s)" % (tot, wall_ms, os.environ.get("PDP_DEBUG_SKIP", "0")))
 print("instance-iterations %d, exact smooth-max passes %d, decimations on the neighbourhood path %d, on the general path %d" % (out[12], out[9], out[10], out[11]))
