@@ -143,8 +143,8 @@ def main():
                     help="sp: configs[1] (headline metric); neural: configs[2] 'np-nd-np' hidden_dim=128 on the same graph (fp32 MFMA)")
     ap.add_argument('--hidden', type=int, default=128)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-batch', type=int, default=64)
-    ap.add_argument('--cpu-sample-iters', type=int, default=40)
+    ap.add_argument('--cpu-sample-batch', type=int, default=1000)
+    ap.add_argument('--cpu-sample-iters', type=int, default=100)
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -185,14 +185,14 @@ def main():
         prob.simplify()
         ev0.record()
         try:
-            it, lds = prob.sp_solve(q, fs, am, dec, args.iters, args.tolerance, args.t_max)
+            it, lds = prob.sp_solve(q, fs, am, dec, args.iters, args.tolerance, args.t_max, time_kernels=True)
             path = 'persistent-lds' if lds else 'persistent-hbm'
         except native.SpeculationFailed:
             raise SystemExit("bench: speculation failed on the benchmark batch (unexpected)")
         ev1.record()
         if record:
             torch.cuda.synchronize()
-            kernel_ms.append(ev0.elapsed_time(ev1)); iters_done.append(it); paths.append(path); launches.append(prob.last_solve_launches)
+            kernel_ms.append(ev0.elapsed_time(ev1)); iters_done.append(it); paths.append(path); launches.append(dict(prob.last_solve_stats))
 
     def barrier():
         if world > 1:
@@ -228,10 +228,13 @@ def main():
         value = iters_all / elapsed
         kms = float(np.mean(kernel_ms))                 # HIP-event time of one pdp_sp_solve call (all its launches)
         it_mean = float(np.mean(iters_done))
-        n_launch = float(np.mean(launches))
-        # per kernel launch: algorithmic bytes = bytes/iteration x iterations per launch; duration = call time / launches
+        n_launch = float(np.mean([l['launches'] for l in launches]))
+        n_replay = float(np.mean([l['replays'] for l in launches]))
+        # dominant kernel k_sp_solve_lds<false, false> (one launch per chunk of iterations): HIP events recorded by the library
+        # on the launch stream around every launch; algorithmic bytes = bytes/iteration x iterations per launch
+        launch_ms = float(np.mean([l['solve_kernel_ms'] for l in launches])) / n_launch
+        replay_ms = float(np.mean([l['replay_kernel_ms'] for l in launches]))
         bytes_launch = algorithmic_bytes_per_iteration(E, V, F) * it_mean / n_launch
-        launch_ms = kms / n_launch
         achieved = bytes_launch / (launch_ms * 1e-3) / 1e9
         # measured HBM traffic per launch (rocprofv3 PMC passes, corrected as MI355X_MICROARCH.md prescribes), if profiled
         traffic = None
@@ -250,12 +253,14 @@ def main():
                        'E': E, 'V': V, 'F': F, 'iterations_per_step': it_mean, 'path': paths[0] if paths else None,
                        'instance_iterations_per_sec': value * args.batch, 'edge_updates_per_sec': value * 2 * E,
                        'solve_call_ms': kms, 'kernel_launches_per_call': n_launch, 'kernel_ms_per_launch': launch_ms,
+                       'poison_replay_launches_per_call': n_replay, 'poison_replay_ms_per_call': replay_ms,
                        'algorithmic_bytes_per_launch': bytes_launch, 'setup_ms_upload_and_layout': setup_ms, 'solved_fraction': n_solved / n_inst, 'unsat_clauses_total': n_unsat,
                        'walksat_steps': ws_steps, 'tolerance': args.tolerance, 't_max': args.t_max, 'parallelism': 'instances sharded, dp%d' % world},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'kernel': 'k_sp_solve_lds<false>',
+                         'traffic': traffic, 'kernel': 'k_sp_solve_lds<false, false>',
                          'note': 'achieved = streaming-model algorithmic bytes (41E+36V+8F per iteration) x iterations per launch / '
-                                 'launch duration; the instance state is LDS-resident so this may exceed the HBM peak'},
+                                 'average launch duration (HIP events on the launch stream); the instance state is LDS-resident, '
+                                 'so the kernel is bound by VALU issue, not by HBM (DESIGN.md section 4)'},
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args)

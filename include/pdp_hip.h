@@ -157,7 +157,11 @@ typedef struct pdp_solve_args {
     int32_t check_termination;    /* 1: per-iteration CNF check de-activates solved instances */
     int32_t iterations_run_host;  /* out: executed iterations (max over instances) */
     int32_t used_lds_host;        /* out: 1 if the LDS-resident variant ran */
-    int32_t kernel_launches_host; /* out: solver kernel launches issued (chunks + poison replays) */
+    int32_t kernel_launches_host; /* out: launches of the solver kernel that did work (one per chunk of iterations) */
+    int32_t replay_launches_host; /* out: poison-replay launches that did work */
+    int32_t time_kernels;         /* in: 1 = bracket every solver launch with HIP events and report the sums below */
+    float solve_kernel_ms_host;   /* out: device time of the chunk launches (time_kernels == 1) */
+    float replay_kernel_ms_host;  /* out: device time of the replay launches (time_kernels == 1) */
 } pdp_solve_args;
 int pdp_sp_solve(pdp_problem *p, pdp_solve_args *args, void *stream);
 

@@ -104,6 +104,7 @@ struct pdp_problem {
     char *res_dyn[2]; size_t res_dyn_bytes;
     float *res_prev_slots;
     char *res_ctl; size_t res_ctl_bytes;
+    hipEvent_t *res_events; int res_events_n;       // 4 per chunk, created on demand (pdp_solve_args.time_kernels)
     float *nws[4]; size_t nws_floats[4];             // neural workspaces (grow on demand)
 };
 

@@ -191,6 +191,8 @@ extern "C" int pdp_problem_destroy(pdp_problem *p)
     if (p->solve_extra_v) (void)hipFree(p->solve_extra_v);
     void *res[] = {p->res_stat_off, p->res_stat, p->res_dyn[0], p->res_dyn[1], p->res_prev_slots, p->res_ctl};
     for (void *q : res) if (q) (void)hipFree(q);
+    for (int i = 0; i < p->res_events_n; ++i) (void)hipEventDestroy(p->res_events[i]);
+    free(p->res_events);
     for (int i = 0; i < 4; ++i) if (p->nws[i]) (void)hipFree(p->nws[i]);
     if (p->nv_ptr) (void)hipFree(p->nv_ptr);
     if (p->nv_edges) (void)hipFree(p->nv_edges);

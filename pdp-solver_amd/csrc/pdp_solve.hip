@@ -58,7 +58,6 @@ struct SolveParams {
     // HBM-mode scratch
     float *ws_e[4]; float *ws_f; float *ws_v[7]; int32_t *ws_vi[3]; uint8_t *ws_fu[2];
     // LDS-resident kernel: private instance records (see BlobLayout) and device-side control
-    int pass;                   // 0: every instance, 1: replay of ctl->replay_count listed instances
     int chunk_start;            // iterations completed before this launch
     struct SolveCtl *ctl;       // this chunk's control block
     struct SolveCall *call;     // the call's control block
@@ -757,7 +756,9 @@ __device__ __noinline__ int lds_cnf_count(unsigned char *smem, int b, int n, int
     return d_cnf_sat_count(I, L.sol, redi3);
 }
 
-template <bool FORCE>
+// REPLAY: the poison-replay pass over ctl->replay_count listed instances (a separate instantiation, so that profilers list
+// the two passes under different names)
+template <bool FORCE, bool REPLAY>
 __global__ void __launch_bounds__(512, 4) k_sp_solve_lds(PView pv_, SolveParams sp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -768,8 +769,8 @@ __global__ void __launch_bounds__(512, 4) k_sp_solve_lds(PView pv_, SolveParams 
     const int lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
     SolveCtl *const ctl = sp.ctl;
     if (sp.call->stop) return;                                                 // every instance went inactive in an earlier chunk
-    if (sp.pass == 1 && (!ctl->do_replay || blockIdx.x >= ctl->replay_count)) return;
-    const Inst G = load_inst(pv_, sp.pass == 1 ? sp.inst_list[blockIdx.x] : (int)blockIdx.x);
+    if (REPLAY && (!ctl->do_replay || blockIdx.x >= ctl->replay_count)) return;
+    const Inst G = load_inst(pv_, REPLAY ? sp.inst_list[blockIdx.x] : (int)blockIdx.x);
     const int n = G.n, m = G.m, ne = G.e;
     const LdsArrays L = carve_all(smem, n, m, ne, FORCE);
     float *const QU = L.QU, *const X = L.X, *const Y = L.Y;
@@ -783,7 +784,7 @@ __global__ void __launch_bounds__(512, 4) k_sp_solve_lds(PView pv_, SolveParams 
         if (tid == 0) {
             *reinterpret_cast<DynHeader *>(dout + BL.hdr) = hdr;
             if (hdr.perm_zero) atomicMin(&ctl->perm_zero, 0u);
-            if (sp.pass == 0) sp.last_event[G.b] = -1;
+            if (!REPLAY) sp.last_event[G.b] = -1;
         }
         return;
     }
@@ -820,7 +821,7 @@ __global__ void __launch_bounds__(512, 4) k_sp_solve_lds(PView pv_, SolveParams 
     const bool other_rows = n < pv_.V;
     const float pi = sp.pi, tol = sp.tol, t_max = sp.t_max;
     const int T = sp.T;
-    const int poison_from = sp.pass == 1 ? ctl->poison_from : (sp.call->poisoned_all ? 0 : 0x7fffffff);
+    const int poison_from = REPLAY ? ctl->poison_from : (sp.call->poisoned_all ? 0 : 0x7fffffff);
     // log(max(1 - pi * [force == +-s], eps)): two possible values per kernel (pdp_propagate.py:197,201)
     const float L0 = pdp_safe_log(1.0f - pi * 0.0f, PDP_SP_EPS), L1 = pdp_safe_log(1.0f - pi * 1.0f, PDP_SP_EPS);
 
@@ -1203,7 +1204,7 @@ __global__ void __launch_bounds__(512, 4) k_sp_solve_lds(PView pv_, SolveParams 
         *reinterpret_cast<DynHeader *>(dout + BL.hdr) = h;
         if (finishing) { sp.amask[G.b] = (uint8_t)active; sp.counters[G.b] = cnt; pv_.is_sat[G.b] = s_is_sat; }
         if (any_inactive) atomicMin(&ctl->perm_zero, (uint32_t)iters);
-        if (sp.pass == 0) sp.last_event[G.b] = last_event;
+        if (!REPLAY) sp.last_event[G.b] = last_event;
         atomicMax(&ctl->iters_run, (uint32_t)iters);
         if (violation) atomicOr(&ctl->violation, 1u);
     }
@@ -1395,9 +1396,22 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     status = snapshot_copy(p, a, snap0, true, st);
     if (status != PDP_OK) return status;
 
-    if (force) PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sp_solve_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    else PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sp_solve_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (force) {
+        PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sp_solve_lds<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sp_solve_lds<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    } else {
+        PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sp_solve_lds<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sp_solve_lds<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     a->used_lds_host = 1;
+    // optional: HIP events around every solver launch (the caller asks for kernel times, e.g. the benchmark's roofline line)
+    const bool timed = a->time_kernels != 0;
+    if (timed && p->res_events_n < 4 * nchunks) {
+        hipEvent_t *ev = (hipEvent_t *)realloc(p->res_events, sizeof(hipEvent_t) * 4 * (size_t)nchunks);
+        PDP_REQUIRE(ev, "out of host memory");
+        p->res_events = ev;
+        for (; p->res_events_n < 4 * nchunks; ++p->res_events_n) PDP_HIP_CHECK(hipEventCreate(&p->res_events[p->res_events_n]));
+    }
 
     hipLaunchKernelGGL(k_solve_ctl_init, dim3((nchunks + 255) / 256), dim3(256), 0, st, ctl, nchunks, call);
     PDP_HIP_CHECK(hipMemsetAsync(spec, 0, 2 * (size_t)T * 4, st));
@@ -1426,9 +1440,12 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
         sp.ctl = ctl + k; sp.spec_used = spec + done; sp.spec_zero = spec + T + done;
         sp.dyn_in = p->res_dyn[k & 1]; sp.dyn_out = p->res_dyn[(k + 1) & 1];
         for (int pass = 0; pass < 2; ++pass) {
-            sp.pass = pass;
-            if (force) hipLaunchKernelGGL((k_sp_solve_lds<true>), dim3(p->B), dim3(nt_lds), lds, st, make_view(p), sp);
-            else hipLaunchKernelGGL((k_sp_solve_lds<false>), dim3(p->B), dim3(nt_lds), lds, st, make_view(p), sp);
+            if (timed) PDP_HIP_CHECK(hipEventRecord(p->res_events[4 * k + 2 * pass], st));
+            if (force && pass == 0) hipLaunchKernelGGL((k_sp_solve_lds<true, false>), dim3(p->B), dim3(nt_lds), lds, st, make_view(p), sp);
+            else if (force) hipLaunchKernelGGL((k_sp_solve_lds<true, true>), dim3(p->B), dim3(nt_lds), lds, st, make_view(p), sp);
+            else if (pass == 0) hipLaunchKernelGGL((k_sp_solve_lds<false, false>), dim3(p->B), dim3(nt_lds), lds, st, make_view(p), sp);
+            else hipLaunchKernelGGL((k_sp_solve_lds<false, true>), dim3(p->B), dim3(nt_lds), lds, st, make_view(p), sp);
+            if (timed) PDP_HIP_CHECK(hipEventRecord(p->res_events[4 * k + 2 * pass + 1], st));
             if (pass == 0) {
                 hipLaunchKernelGGL(k_solve_post, dim3(1), dim3(1), 0, st, ctl + k, call, c);
                 hipLaunchKernelGGL(k_replay_list, dim3((p->B + 255) / 256), dim3(256), 0, st, p->B, (const int32_t *)last_event, ctl + k, (const SolveCall *)call, replay_list);
@@ -1443,15 +1460,23 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     const SolveCtl *hctl = (const SolveCtl *)p->solve_host;
     const SolveCall *hcall = (const SolveCall *)(hctl + nchunks);
     const bool debug = getenv("PDP_DEBUG") != nullptr;
-    int launches = 0;
+    int launches = 0, replays = 0;
+    float solve_ms = 0.0f, replay_ms = 0.0f;
     for (int k = 0; k < nchunks; ++k) {
         if (hctl[k].iters_run == 0 && k * C >= (int)hcall->total_iters && k > 0) break;     // launches after the global early exit return at once
-        launches += 1 + (hctl[k].do_replay && hctl[k].replay_count ? 1 : 0);
+        const bool replayed = hctl[k].do_replay && hctl[k].replay_count;
+        launches += 1; replays += replayed ? 1 : 0;
+        if (timed) {
+            float ms = 0.0f;
+            PDP_HIP_CHECK(hipEventElapsedTime(&ms, p->res_events[4 * k], p->res_events[4 * k + 1])); solve_ms += ms;
+            if (replayed) { PDP_HIP_CHECK(hipEventElapsedTime(&ms, p->res_events[4 * k + 2], p->res_events[4 * k + 3])); replay_ms += ms; }
+        }
         if (debug)
             fprintf(stderr, "[pdp_sp_solve] chunk@%d violation=%u perm_from=%u nan_iter=%u poison_from=%d replayed=%u iters=%u lds=%zu\n", k * C,
                     hctl[k].violation, hctl[k].perm_zero, hctl[k].nan_iter, hctl[k].poison_from, hctl[k].do_replay ? hctl[k].replay_count : 0u, hctl[k].iters_run, lds);
     }
-    a->kernel_launches_host = launches;
+    a->kernel_launches_host = launches; a->replay_launches_host = replays;
+    a->solve_kernel_ms_host = solve_ms; a->replay_kernel_ms_host = replay_ms;
     if (hcall->fail) {
         // leave the caller's state exactly as it was at call entry so that it can rerun the batch step-wise
         status = snapshot_copy(p, a, snap0, false, st);
@@ -1476,7 +1501,8 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
     PDP_REQUIRE(p->R == 1, "persistent solve needs replication == 1 (replicas couple through the termination check)");
     hipStream_t st = ST(stream);
     const int T = a->iterations;
-    a->iterations_run_host = 0; a->used_lds_host = 0; a->kernel_launches_host = 0;
+    a->iterations_run_host = 0; a->used_lds_host = 0; a->kernel_launches_host = 0; a->replay_launches_host = 0;
+    a->solve_kernel_ms_host = 0.0f; a->replay_kernel_ms_host = 0.0f;
     if (T <= 0) return PDP_OK;
     const size_t E = p->E, V = p->V, F = p->F, B = p->B;
     // The loop runs in chunks of C iterations (one launch each; the kernel resumes from the HBM state).  Chunking bounds

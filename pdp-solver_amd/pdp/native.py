@@ -96,7 +96,8 @@ class SolveArgs(C.Structure):
                 ('pi', C.c_float), ('decimation_probability', C.c_float), ('seed', C.c_uint64),
                 ('coins', C.c_void_p), ('q', C.c_void_p), ('fs', C.c_void_p), ('active_mask', C.c_void_p),
                 ('decimator', C.c_void_p), ('check_termination', C.c_int32), ('iterations_run_host', C.c_int32),
-                ('used_lds_host', C.c_int32), ('kernel_launches_host', C.c_int32)]
+                ('used_lds_host', C.c_int32), ('kernel_launches_host', C.c_int32), ('replay_launches_host', C.c_int32),
+                ('time_kernels', C.c_int32), ('solve_kernel_ms_host', C.c_float), ('replay_kernel_ms_host', C.c_float)]
 
 
 class AggDesc(C.Structure):
@@ -382,8 +383,9 @@ class Problem(object):
 
     # -- persistent solve -----------------------------------------------------------------------------------------
     def sp_solve(self, q, fs, active_mask, dec, iterations, tolerance, t_max, pi=0.0, model=MODEL_SP,
-                 decimation_probability=0.5, seed=0, coins=None, check_termination=True):
+                 decimation_probability=0.5, seed=0, coins=None, check_termination=True, time_kernels=False):
         a = SolveArgs()
+        a.time_kernels = 1 if time_kernels else 0
         a.model = model; a.iterations = iterations; a.tolerance = tolerance; a.t_max = t_max; a.pi = pi
         a.decimation_probability = decimation_probability; a.seed = seed
         a.coins = ptr(coins, torch.float32).value if coins is not None else None
@@ -393,6 +395,8 @@ class Problem(object):
         a.check_termination = 1 if check_termination else 0
         check(lib().pdp_sp_solve(self._h, C.byref(a), _stream()))
         self.last_solve_launches = int(a.kernel_launches_host)
+        self.last_solve_stats = dict(launches=int(a.kernel_launches_host), replays=int(a.replay_launches_host),
+                                     solve_kernel_ms=float(a.solve_kernel_ms_host), replay_kernel_ms=float(a.replay_kernel_ms_host))
         return int(a.iterations_run_host), bool(a.used_lds_host)
 
 
