@@ -165,6 +165,18 @@ typedef struct pdp_solve_args {
 } pdp_solve_args;
 int pdp_sp_solve(pdp_problem *p, pdp_solve_args *args, void *stream);
 
+/* ---- DIMACS ingestion (host code, no GPU needed) -----------------------------------------------------------
+ * Native twin of the reference's converter front end (reference: src/dimacs2json.py:22-51 parsing, :43-51,85-91
+ * compaction; consumed by src/pdp/factorgraph/dataset.py:120-136).  pdp_dimacs_open parses one file in a single pass and
+ * reports the sizes of the COMPACT instance (unused variables dropped, empty clauses dropped, last occurrence of a
+ * variable inside a clause wins); pdp_dimacs_read copies the edge list: signed_vars[e] = +-(1-based compact variable id),
+ * clause_ids[e] = 1-based clause id, clause-major with ascending variable index -- the second and third list of the
+ * reference's JSON line.  Malformed input -> PDP_ERR_INVALID with file:line in pdp_last_error(). */
+typedef struct pdp_dimacs pdp_dimacs;
+int pdp_dimacs_open(const char *path, pdp_dimacs **out, int32_t *n_vars, int32_t *n_clauses, int64_t *n_edges);
+int pdp_dimacs_read(const pdp_dimacs *d, int32_t *signed_vars /*[n_edges]*/, int32_t *clause_ids /*[n_edges]*/);
+int pdp_dimacs_close(pdp_dimacs *d);
+
 /* ---- neural plug-ins: per-edge MLP / GRU layers on the fp32 matrix cores ---------------------------------
  * Weights are handed over PRE-TRANSPOSED and ZERO PADDED by the host: a layer y = act(W x + b) with nn.Linear weight
  * W [N, K] is passed as Wt [Kp, Np] row-major with Wt[k, j] = W[j, k], Kp = K rounded up to even, Np = N rounded up

@@ -6,7 +6,8 @@ Output lines are byte-identical to the reference's for valid input (``[[n, m], [
 variable inside a clause wins, empty clauses and unused variables are dropped, literals are clause-major with
 ascending variable index, the label is the last digit of the file stem (directory mode, :105) or the character
 8 from the end of the path (file mode, :118-122).  The parser streams clauses into sparse rows instead of the
-reference's dense [clauses x variables] matrix, so big instances do not need O(n*m) memory; the O(m^2)
+reference's dense [clauses x variables] matrix (native single-pass parser, csrc/pdp_dimacs.hip), so big instances do
+not need O(n*m) memory; the O(m^2)
 subsumption option ``-s`` is out of scope.
 """
 
@@ -22,7 +23,8 @@ from pdp import generator  # noqa: E402
 
 
 def parse_dimacs(path):
-    """Returns (declared variable count, list of clauses as lists of signed ints)."""
+    """Pure-Python statement of the parsing rules: (declared variable count, list of clauses as lists of signed ints).
+    The converter itself uses the native parser; the tests check the two against each other."""
     n = 0
     clauses = []
     with open(path, 'r') as f:
@@ -44,8 +46,10 @@ def parse_dimacs(path):
 
 
 def json_line(path, label):
-    n, clauses = parse_dimacs(path)
-    return generator.json_line(n, clauses, label=label, name=os.path.split(path)[1])
+    "One output line; the text is read by the native parser of libpdp_hip.so (pdp_dimacs_open, include/pdp_hip.h)."
+    from pdp import native
+    var_num, clause_num, signed_vars, clause_ids = native.dimacs_parse(path)
+    return generator.format_json_line(var_num, clause_num, signed_vars, clause_ids, label=label, name=os.path.split(path)[1])
 
 
 def convert_directory(dimacs_dir, output_file, propagate=False, only_positive=False):

@@ -105,10 +105,15 @@ def json_line(n, clauses, label=-1, name=""):
     """One line of the compact JSON dataset format (reference: src/dimacs2json.py:85-91,
     src/pdp/factorgraph/dataset.py:120-136)."""
     var_num, clause_num, sv, ci = compact_instance(n, clauses)
+    return format_json_line(var_num, clause_num, sv, ci, label, name)
+
+
+def format_json_line(var_num, clause_num, signed_vars, clause_ids, label=-1, name=""):
+    "The JSON text of one compact instance (same byte layout as json.dumps of the reference's list, dimacs2json.py:85-91)."
     label_txt = repr(float(label)) if isinstance(label, float) else str(label)
     return "[[%d, %d], [%s], [%s], %s, [\"%s\"]]" % (
-        var_num, clause_num, ", ".join(str(int(x)) for x in sv), ", ".join(str(int(x)) for x in ci),
-        label_txt, name)
+        var_num, clause_num, ", ".join(map(str, np.asarray(signed_vars).tolist())),
+        ", ".join(map(str, np.asarray(clause_ids).tolist())), label_txt, name)
 
 
 def generate_batch(batch, n, k=3, m=None, seed=0):

@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     'pdp_decimator_destroy', 'pdp_decimator_reset', 'pdp_sequential_decimate', 'pdp_sequential_decimate_gate',
     'pdp_sequential_decimate_apply', 'pdp_reinforce_decimate', 'pdp_reinforce_predict', 'pdp_energy',
     'pdp_energy_diff', 'pdp_random_fill', 'pdp_local_search', 'pdp_deduplicate', 'pdp_sp_solve', 'pdp_math_apply',
-    'pdp_neural_aggregate_edges', 'pdp_neural_gru', 'pdp_neural_predict',
+    'pdp_neural_aggregate_edges', 'pdp_neural_gru', 'pdp_neural_predict', 'pdp_dimacs_open', 'pdp_dimacs_read', 'pdp_dimacs_close',
 ]
 
 
@@ -398,6 +398,21 @@ class Problem(object):
         self.last_solve_stats = dict(launches=int(a.kernel_launches_host), replays=int(a.replay_launches_host),
                                      solve_kernel_ms=float(a.solve_kernel_ms_host), replay_kernel_ms=float(a.replay_kernel_ms_host))
         return int(a.iterations_run_host), bool(a.used_lds_host)
+
+
+def dimacs_parse(path):
+    """One DIMACS file -> (var_num, clause_num, signed_vars int32 [E], clause_ids int32 [E]) in the compact conventions of the
+    reference's converter (include/pdp_hip.h, pdp_dimacs_open).  Host code only: works without a GPU."""
+    import numpy as np
+    h = C.c_void_p()
+    nv, nc, ne = C.c_int32(), C.c_int32(), C.c_int64()
+    check(lib().pdp_dimacs_open(os.fsencode(path), C.byref(h), C.byref(nv), C.byref(nc), C.byref(ne)))
+    try:
+        sv = np.empty(ne.value, np.int32); ci = np.empty(ne.value, np.int32)
+        check(lib().pdp_dimacs_read(h, sv.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p)))
+    finally:
+        lib().pdp_dimacs_close(h)
+    return int(nv.value), int(nc.value), sv, ci
 
 
 def math_apply(fn, x):

@@ -104,3 +104,65 @@ def test_product_never_imports_the_oracle():
                 if re.search(r'(^|\s)(from|import)\s+oracle\b', txt) or 'oracle/' in txt.replace('under oracle/', ''):
                     bad.append(os.path.join(root, f))
     assert not bad, bad
+
+
+# ---- native DIMACS reader (host code of libpdp_hip.so; no GPU needed) ---------------------------------------------------------------
+def _py_compact(path):
+    import dimacs2json
+    from pdp import generator
+    n, clauses = dimacs2json.parse_dimacs(path)
+    return generator.compact_instance(n, clauses)
+
+
+def test_native_dimacs_reader_matches_python_rules(tmp_path):
+    from pdp import native
+    gdir = os.path.join(REPO, 'tests', 'golden', 'dimacs20')
+    files = sorted(os.listdir(gdir))
+    assert len(files) == 20
+    for f in files:
+        vn, cn, sv, ci = native.dimacs_parse(os.path.join(gdir, f))
+        pvn, pcn, psv, pci = _py_compact(os.path.join(gdir, f))
+        assert (vn, cn) == (pvn, pcn)
+        np.testing.assert_array_equal(sv, psv); np.testing.assert_array_equal(ci, pci)
+    # the conventions, one by one: comments, '%' lines, duplicate literal, x and -x in one clause (last wins), empty clause,
+    # unused variables, a clause without its terminating 0, text after the 0, CRLF and tabs, a sign prefix
+    txt = ("c a comment\r\n"
+           "p cnf 9 7\r\n"
+           "3 -5 3 0\r\n"
+           "% not a clause\n"
+           "7 -7 2 0\n"
+           "0\n"
+           "\t-9\t2 0 4 5\n"
+           "+3 5\n"
+           "\n"
+           "-2 -2 -2 0\n")
+    p = tmp_path / 'edge.cnf'
+    p.write_bytes(txt.encode())
+    vn, cn, sv, ci = native.dimacs_parse(str(p))
+    pvn, pcn, psv, pci = _py_compact(str(p))
+    assert (vn, cn) == (pvn, pcn) == (5, 5)          # variables 2 3 5 7 9 -> 1..5; the "0" line is an empty clause
+    np.testing.assert_array_equal(sv, psv); np.testing.assert_array_equal(ci, pci)
+    np.testing.assert_array_equal(sv, [2, -3, 1, -4, 1, -5, 2, 3, -1])
+    np.testing.assert_array_equal(ci, [1, 1, 2, 2, 3, 3, 4, 4, 5])
+    # malformed input is an error with file:line, like the reference's int() failure
+    bad = tmp_path / 'bad.cnf'
+    bad.write_text("p cnf 2 1\n1 x2 0\n")
+    with pytest.raises(native.NativeError, match='bad.cnf:2'):
+        native.dimacs_parse(str(bad))
+    with pytest.raises(native.NativeError):
+        native.dimacs_parse(str(tmp_path / 'missing.cnf'))
+    empty = tmp_path / 'empty.cnf'
+    empty.write_text("c nothing\np cnf 0 0\n")
+    assert native.dimacs_parse(str(empty))[:2] == (0, 0)
+
+
+def test_dimacs2json_lines_equal_reference_golden(tmp_path):
+    "directory conversion through the native reader reproduces the reference converter's lines byte for byte"
+    import dimacs2json
+    out = tmp_path / 'conv.jsonl'
+    dimacs2json.convert_directory(os.path.join(REPO, 'tests', 'golden', 'dimacs20'), str(out))
+    got = {json.loads(l)[4][0]: l for l in out.read_text().split('\n') if l.strip()}
+    ref = {json.loads(l)[4][0]: l for l in open(os.path.join(REPO, 'tests', 'golden', 'cli_dimacs20.converted.jsonl')).read().split('\n') if l.strip()}
+    assert got.keys() == ref.keys() and len(got) == 20
+    for k in ref:
+        assert got[k] == ref[k], k
