@@ -92,16 +92,17 @@ struct SolveCall {
 // Private instance records of the LDS-resident solver.  Between two launches of a call an instance lives in HBM as the
 // verbatim image of its LDS arrays (slot-major, 16-byte aligned pieces): resuming is a coalesced copy instead of a
 // gather through the CSR, and the record a launch resumed from stays intact, which is the snapshot the poison replay needs.
-//   static  (per problem): pvv | e2p | v_ptr | f_ptr
+//   static  (per problem): pvv | e2p | v_ptr | f_ptr | vord (variables by descending degree)
 //   dynamic (two copies, ping-pong): header | QU | E | pcc | af | av | sol
 struct DynHeader { uint32_t active, done, perm_zero, simplified; float cnt, is_sat, pad1, pad2; };   // simplified: 0 unknown, 1 the state is a simplify() fix-point, 2 it is not
-struct BlobLayout { size_t pvv, e2p, vptr, fptr, stat_bytes, hdr, QU, E, pcc, af, av, sol, dyn_bytes; };
+struct BlobLayout { size_t pvv, e2p, vptr, fptr, vord, stat_bytes, hdr, QU, E, pcc, af, av, sol, dyn_bytes; };
 __host__ __device__ inline BlobLayout blob_layout(int n, int m, int ne)
 {
     auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     BlobLayout b; size_t o = 0;
     b.pvv = o; o += a16((size_t)ne * 2); b.e2p = o; o += a16((size_t)ne * 2);
-    b.vptr = o; o += a16((size_t)(n + 1) * 2); b.fptr = o; o += a16((size_t)(m + 1) * 2); b.stat_bytes = o;
+    b.vptr = o; o += a16((size_t)(n + 1) * 2); b.fptr = o; o += a16((size_t)(m + 1) * 2);
+    b.vord = o; o += a16((size_t)n * 2); b.stat_bytes = o;
     o = 0;
     b.hdr = o; o += a16(sizeof(DynHeader));
     b.QU = o; o += a16((size_t)ne * 4); b.E = o; o += a16((size_t)ne * 4); b.pcc = o; o += a16((size_t)ne * 2);
@@ -433,6 +434,7 @@ struct LView {   // what the shared simplification routines see: "edge id" == sl
     float *av, *af, *sol;
 };
 
+#define PDP_RED_SMALL 16    /* per-wave reduction slots of the LDS solver (<= 16 waves per workgroup) */
 #define PC_EM 0x8000u      /* current edge mask bit */
 #define PC_EM_USED 0x4000u /* edge mask bit the last propagate used (needed to rebuild q_s / q_dc at exit) */
 
@@ -446,6 +448,7 @@ static size_t lds2_bytes_for(int n, int m, int e, bool force)
     s += a16((size_t)(m + 8) * 4) + a16((size_t)m * 4);        // S (aliases flag_f/flag_f2), af
     s += 7 * a16((size_t)n * 4);                               // av, sol, P, N, xv1(deg), xv2(sdeg,score), coeff(assign)
     s += a16((size_t)n);                                       // flag_v
+    s += a16((size_t)n * 2);                                   // vord
     return s;
 }
 
@@ -456,6 +459,7 @@ struct LdsArrays {
     uint16_t *pvv, *pcc, *e2p, *v_ptr, *f_ptr;
     float *S, *af, *av, *sol, *Pv, *Nv, *xv1, *xv2, *coeff;
     uint8_t *flag_v;
+    uint16_t *vord;      // variables in order of descending degree: a wave of 64 consecutive entries runs loops of similar length
 };
 __device__ __forceinline__ LdsArrays carve_all(unsigned char *cp, int n, int m, int ne, bool force)
 {
@@ -468,6 +472,7 @@ __device__ __forceinline__ LdsArrays carve_all(unsigned char *cp, int n, int m, 
     L.av = carve<float>(cp, n); L.sol = carve<float>(cp, n); L.Pv = carve<float>(cp, n); L.Nv = carve<float>(cp, n);
     L.xv1 = carve<float>(cp, n); L.xv2 = carve<float>(cp, n); L.coeff = carve<float>(cp, n);
     L.flag_v = carve<uint8_t>(cp, n);
+    L.vord = carve<uint16_t>(cp, n);
     return L;
 }
 __device__ __forceinline__ LView make_lview(const LdsArrays &L, int b, int n, int m, int ne)
@@ -612,8 +617,8 @@ template <bool FORCE>
 __device__ __noinline__ int lds_decimate(unsigned char *smem, int b, int n, int m, int ne, int cur, int active, float pi,
                                          float *is_sat_b, int *spec, int *verified)
 {
-    __shared__ float redf2[PDP_RED_SCRATCH];
-    __shared__ int redi2[PDP_RED_SCRATCH];
+    __shared__ float redf2[PDP_RED_SMALL];
+    __shared__ int redi2[PDP_RED_SMALL];
     const LdsArrays L = carve_all(smem, n, m, ne, FORCE);
     const LView I = make_lview(L, b, n, m, ne);
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -750,7 +755,7 @@ __device__ __noinline__ int lds_decimate(unsigned char *smem, int b, int n, int 
 template <bool FORCE>
 __device__ __noinline__ int lds_cnf_count(unsigned char *smem, int b, int n, int m, int ne)
 {
-    __shared__ int redi3[PDP_RED_SCRATCH];
+    __shared__ int redi3[PDP_RED_SMALL];
     const LdsArrays L = carve_all(smem, n, m, ne, FORCE);
     const LView I = make_lview(L, b, n, m, ne);
     return d_cnf_sat_count(I, L.sol, redi3);
@@ -762,8 +767,8 @@ template <bool FORCE, bool REPLAY>
 __global__ void __launch_bounds__(512, 4) k_sp_solve_lds(PView pv_, SolveParams sp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ float redf[PDP_RED_SCRATCH];
-    __shared__ int redi[PDP_RED_SCRATCH];
+    __shared__ float redf[PDP_RED_SMALL];
+    __shared__ int redi[PDP_RED_SMALL];
 
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
@@ -799,6 +804,7 @@ __global__ void __launch_bounds__(512, 4) k_sp_solve_lds(PView pv_, SolveParams 
         };
         copy16(pvv, stt + BL.pvv, (size_t)ne * 2); copy16(L.e2p, stt + BL.e2p, (size_t)ne * 2);
         copy16(L.v_ptr, stt + BL.vptr, (size_t)(n + 1) * 2); copy16(L.f_ptr, stt + BL.fptr, (size_t)(m + 1) * 2);
+        copy16(L.vord, stt + BL.vord, (size_t)n * 2);
         copy16(QU, din + BL.QU, (size_t)ne * 4); copy16(L.EA, din + BL.E, (size_t)ne * 4); copy16(pcc, din + BL.pcc, (size_t)ne * 2);
         copy16(L.af, din + BL.af, (size_t)m * 4); copy16(L.av, din + BL.av, (size_t)n * 4); copy16(L.sol, din + BL.sol, (size_t)n * 4);
         if constexpr (FORCE) {
@@ -868,56 +874,93 @@ __global__ void __launch_bounds__(512, 4) k_sp_solve_lds(PView pv_, SolveParams 
             // Work is handed out per wave in items of 64 rows.  A variable row is a sequential sum over ~|E|/n terms and costs
             // about two clause rows, so the waves that take a variable item skip the first two rounds of clause items.
             const int nvi = (n + 63) >> 6, nci = (m + 63) >> 6;
+            // P / N: ordered sums of y over the positive / negative edges.  The reference adds (mask * y) for every edge; a masked-out
+            // term is +-0 and never changes the running sum (which starts at +0 and therefore is never -0), so the terms of the
+            // other sign are cleared with a bit mask instead of multiplied; a NaN y must reach both sums and is re-injected at the end.
+            const uint16_t *const vord = L.vord;
             auto var_rows = [&](int item) {
-                const int v = (item << 6) + lane;
-                if (v >= n) return;
+                const int i = (item << 6) + lane;
+                if (i >= n) return;
+                const int v = vord[i];
                 float P = 0.0f, N = 0.0f;
                 const int a = v_ptr[v], bnd = v_ptr[v + 1];
+                auto acc = [&](float y, uint16_t sg) {
+                    const uint32_t neg = (uint32_t)((int32_t)((uint32_t)sg << 16) >> 31);       // all ones for a negative literal
+                    P = P + __uint_as_float(__float_as_uint(y) & ~neg);
+                    N = N + __uint_as_float(__float_as_uint(y) & neg);
+                };
                 int p = a;
-                for (; p + 7 < bnd; p += 8) {                   // eight loads in flight per LDS round trip, then the ordered adds
+                for (; p + 15 < bnd; p += 16) {                 // as many loads in flight per LDS round trip as the degree allows, then the ordered adds
+                    float y[16]; uint16_t sg[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) { y[j] = Y[p + j]; sg[j] = pvv[p + j]; }
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) acc(y[j], sg[j]);
+                }
+                for (; p + 7 < bnd; p += 8) {
                     float y[8]; uint16_t sg[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) { y[j] = Y[p + j]; sg[j] = pvv[p + j]; }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { const float nj = bit15_to_float(sg[j]); P = P + (1.0f - nj) * y[j]; N = N + nj * y[j]; }
+                    for (int j = 0; j < 8; ++j) acc(y[j], sg[j]);
                 }
                 for (; p + 3 < bnd; p += 4) {
                     float y[4]; uint16_t sg[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { y[j] = Y[p + j]; sg[j] = pvv[p + j]; }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { const float nj = bit15_to_float(sg[j]); P = P + (1.0f - nj) * y[j]; N = N + nj * y[j]; }
+                    for (int j = 0; j < 4; ++j) acc(y[j], sg[j]);
                 }
                 {
                     float y[3]; uint16_t sg[3];
 #pragma unroll
                     for (int j = 0; j < 3; ++j) { const int q = (p + j < bnd) ? p + j : a; y[j] = Y[q]; sg[j] = pvv[q]; }
 #pragma unroll
-                    for (int j = 0; j < 3; ++j)
-                        if (p + j < bnd) { const float nj = bit15_to_float(sg[j]); P = P + (1.0f - nj) * y[j]; N = N + nj * y[j]; }
+                    for (int j = 0; j < 3; ++j) if (p + j < bnd) acc(y[j], sg[j]);
                 }
-                Pv[v] = P; Nv[v] = N;
+                Pv[v] = P + 0.0f * N; Nv[v] = N + 0.0f * P;
             };
-            auto clause_rows = [&](int item) {
-                const int r = (item << 6) + lane;
-                if (r >= m) return;
+            // Clause rows are a three-level dependent LDS chain (f_ptr -> e2p -> X): a lane takes up to four rows at once so that the
+            // chain is paid once per group, not once per row; the straight-line form needs 3-literal clauses in all of the lane's rows.
+            auto clause_row = [&](int r) {
                 float acc = 0.0f;
                 const int a = f_ptr[r], bnd = f_ptr[r + 1];
-                int k = a;
-                for (; k + 2 < bnd; k += 3) {
-                    const float x0 = X[e2p[k]], x1 = X[e2p[k + 1]], x2 = X[e2p[k + 2]];
-                    acc = acc + x0; acc = acc + x1; acc = acc + x2;
-                }
-                for (; k < bnd; ++k) acc = acc + X[e2p[k]];
+                for (int k = a; k < bnd; ++k) acc = acc + X[e2p[k]];
                 S[r] = acc;
             };
+            auto clause_group = [&](int j0, int cnt) {
+                int r[4], a[4]; bool ok[4]; bool all3 = true;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    r[i] = ((j0 + i) << 6) + lane; ok[i] = i < cnt && r[i] < m; a[i] = 0;
+                    if (ok[i]) { a[i] = f_ptr[r[i]]; all3 = all3 && (f_ptr[r[i] + 1] - a[i] == 3); }
+                }
+                if (__builtin_amdgcn_ballot_w64(!all3) == 0) {
+                    uint16_t e[4][3]; float x[4][3];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (ok[i]) { e[i][0] = e2p[a[i]]; e[i][1] = e2p[a[i] + 1]; e[i][2] = e2p[a[i] + 2]; }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (ok[i]) { x[i][0] = X[e[i][0]]; x[i][1] = X[e[i][1]]; x[i][2] = X[e[i][2]]; }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (ok[i]) { float acc = 0.0f; acc = acc + x[i][0]; acc = acc + x[i][1]; acc = acc + x[i][2]; S[r[i]] = acc; }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (ok[i]) clause_row(r[i]);
+                }
+            };
             if (!PROF_SKIP(2)) {
-                for (int i = wid; i < nvi; i += nw) var_rows(i);
-                const int first = (nvi < nw) ? nvi : nw;          // waves [first, nw) have no variable item
-                const int base = 2 * (nw - first);
-                if (wid >= first)
-                    for (int rd = 0; rd < 2; ++rd) { const int j = (wid - first) + rd * (nw - first); if (j < nci) clause_rows(j); }
-                for (int j = base + wid; j < nci; j += nw) clause_rows(j);
+                if (!PROF_SKIP(32)) for (int i = wid; i < nvi; i += nw) var_rows(i);
+                // clause items go to the waves without a variable item (a variable row is several times longer), in contiguous chunks
+                const int first = (nvi < nw) ? nvi : nw;
+                const int helpers = nw - first;
+                int j_begin, j_end, j_step;
+                if (helpers > 0) { const int chunk = (nci + helpers - 1) / helpers; j_begin = (wid - first) * chunk; j_end = j_begin + chunk; j_step = 0; if (wid < first) j_end = j_begin = 0; }
+                else { j_begin = wid * 4; j_end = nci; j_step = nw * 4; }
+                if (j_end > nci) j_end = nci;
+                if (!PROF_SKIP(64)) {
+                    if (j_step == 0) { for (int j = j_begin; j < j_end; j += 4) clause_group(j, (j_end - j) < 4 ? (j_end - j) : 4); }
+                    else { for (int j = j_begin; j < j_end; j += j_step) clause_group(j, (nci - j) < 4 ? (nci - j) : 4); }
+                }
             }
         }
         __syncthreads();
@@ -982,7 +1025,7 @@ __global__ void __launch_bounds__(512, 4) k_sp_solve_lds(PView pv_, SolveParams 
             const float tol_lo = tol - (2e-6f + 1e-4f * pdp_abs(tol)), tol_hi = tol + (2e-6f + 1e-4f * pdp_abs(tol));
             if (!PROF_SKIP(8))
             for (int r = tid; r < 2 * n; r += nt) {
-                const int v = r >> 1, h = r & 1;
+                const int v = L.vord[r >> 1], h = r & 1;
                 const int a = v_ptr[v], bnd = v_ptr[v + 1];
                 const int half = (bnd - a + 1) >> 1;
                 const int lo = a + h * half, hi = h ? bnd : a + half;
@@ -1234,6 +1277,16 @@ __global__ void __launch_bounds__(256) k_solve_import(PView pv, const float *q, 
         uint16_t *vp = reinterpret_cast<uint16_t *>(st + BL.vptr), *fp = reinterpret_cast<uint16_t *>(st + BL.fptr);
         for (int v = tid; v <= n; v += nt) vp[v] = (uint16_t)G.v_ptr[v];
         for (int c = tid; c <= m; c += nt) fp[c] = (uint16_t)G.f_ptr[c];
+        // counting sort of the variables by descending degree (capped at 255); the order inside a bucket is irrelevant
+        __shared__ int hist[256];
+        uint16_t *vord = reinterpret_cast<uint16_t *>(st + BL.vord);
+        for (int i = tid; i < 256; i += nt) hist[i] = 0;
+        __syncthreads();
+        for (int v = tid; v < n; v += nt) { const int d = G.v_ptr[v + 1] - G.v_ptr[v]; atomicAdd(&hist[255 - (d < 255 ? d : 255)], 1); }
+        __syncthreads();
+        if (tid == 0) { int run = 0; for (int i = 0; i < 256; ++i) { const int c = hist[i]; hist[i] = run; run += c; } }
+        __syncthreads();
+        for (int v = tid; v < n; v += nt) { const int d = G.v_ptr[v + 1] - G.v_ptr[v]; vord[atomicAdd(&hist[255 - (d < 255 ? d : 255)], 1)] = (uint16_t)v; }
     }
     float *av = reinterpret_cast<float *>(dy + BL.av), *sol = reinterpret_cast<float *>(dy + BL.sol), *af = reinterpret_cast<float *>(dy + BL.af);
     int any_inactive = 0;

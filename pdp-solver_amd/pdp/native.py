@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libpdp_hip.so')
+LIB_PATH = os.environ.get('PDP_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'csrc', 'libpdp_hip.so')   # PDP_HIP_LIB: A/B builds
 
 PDP_OK = 0
 PDP_ERR_SPECULATION = 5
