@@ -77,23 +77,6 @@ PDP_HD float pdp_expf(float x)
     return is_nan ? x : res;
 }
 
-/* e^x - 1, accurate near 0 (used by tanh) */
-PDP_HD float pdp_expm1f(float x)
-{
-    if (x != x) return x;
-    if (pdp_abs(x) < 0.34657359f) {
-        const float z = x * x;
-        float p = 1.9875691500e-4f;
-        p = fmaf(p, x, 1.3981999507e-3f);
-        p = fmaf(p, x, 8.3334519073e-3f);
-        p = fmaf(p, x, 4.1665795894e-2f);
-        p = fmaf(p, x, 1.6666665459e-1f);
-        p = fmaf(p, x, 5.0000001201e-1f);
-        return fmaf(p, z, x);
-    }
-    return pdp_expf(x) - 1.0f;
-}
-
 /* natural log, x > 0 expected (denormals fine); x == 0 -> -inf, x < 0 -> NaN.  Branch-free like pdp_expf. */
 PDP_HD float pdp_logf(float x)
 {
@@ -130,39 +113,6 @@ PDP_HD float pdp_logf(float x)
     r = (x == 0.0f) ? -PDP_INF : r;
     r = (x < 0.0f) ? PDP_NAN : r;
     return is_nan ? x : r;
-}
-
-/* log(1 + t) for t >= 0 (compensated) */
-PDP_HD float pdp_log1pf(float t)
-{
-    const float u = 1.0f + t;
-    if (u == 1.0f) return t;
-    if (u != u || u == PDP_INF) return u;
-    return pdp_logf(u) - ((u - 1.0f) - t) / u;
-}
-
-/* torch F.logsigmoid: min(x, 0) - log1p(exp(-|x|)) */
-PDP_HD float pdp_logsigmoidf(float x)
-{
-    if (x != x) return x;
-    const float mn = x < 0.0f ? x : 0.0f;
-    return mn - pdp_log1pf(pdp_expf(-pdp_abs(x)));
-}
-
-PDP_HD float pdp_sigmoidf(float x) { return 1.0f / (1.0f + pdp_expf(-x)); }
-
-PDP_HD float pdp_tanhf(float x)
-{
-    if (x != x) return x;
-    const float a = pdp_abs(x);
-    float r;
-    if (a > 10.0f) {
-        r = 1.0f;
-    } else {
-        const float em = pdp_expm1f(a + a);
-        r = em / (em + 2.0f);
-    }
-    return x < 0.0f ? -r : r;
 }
 
 /* ---- lean variants for hot loops --------------------------------------------------------------
@@ -309,6 +259,75 @@ PDP_HD float pdp_expf_fin_le30(float x)
 }
 /* safe_exp with the lean pieces (valid for every input: the clamp bounds the argument) */
 PDP_HD float pdp_safe_exp_fast(float x) { return pdp_expf_le30(pdp_min_c(x, 30.0f)); }
+
+/* ---- activation functions of the neural plug-ins (finite or NaN arguments; select-free like the forms above) ------------ */
+PDP_HD float pdp_fminf(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fminf(a, b);                           /* v_min_f32: the non-NaN operand wins */
+#else
+    return (a != a) ? b : ((b != b) ? a : ((a > b) ? b : a));
+#endif
+}
+
+/* e^x for any finite x or NaN: underflows to 0, overflows to +inf (p * 2^128) like expf */
+PDP_HD float pdp_expf_fin(float x)
+{
+    const float xc = pdp_fminf(pdp_fmaxf(x, -104.5f), 89.0f);
+    const float t = xc * 1.44269504088896341f;
+    const float nf = (t + 12582912.0f) - 12582912.0f;
+    float r = fmaf(nf, -0.693359375f, xc);
+    r = fmaf(nf, 2.12194440e-4f, r);
+    const float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    p = fmaf(p, z, r);
+    p = p + 1.0f;
+    return pdp_scale2(p, (int)nf) + (x - x);
+}
+
+/* torch F.logsigmoid(x) = min(x, 0) - log1p(exp(-|x|)).  With t = e^-|x| in (0, 1] and u = fl(1 + t):
+ * log1p(t) = log(u) + (t - (u - 1)); the second term is the rounding error of u (dividing it by u, as the textbook form does,
+ * changes the result by less than 2^-25 t), and for u == 1 the sum is t itself. */
+PDP_HD float pdp_logsigmoidf(float x)
+{
+    const float t = pdp_expf_fin_le30(-pdp_abs(x));
+    const float u = 1.0f + t;
+    const float l1p = pdp_safe_log_fin(u, 1.0f) + (t - (u - 1.0f));
+    return pdp_fminf(x, 0.0f) - l1p;                        /* a NaN x is dropped by the min and carried by l1p */
+}
+
+/* torch.sigmoid(x) = 1 / (1 + exp(-x)); exp(-x) = +inf for x < -88.7 gives 0 like torch */
+PDP_HD float pdp_sigmoidf(float x) { return 1.0f / (1.0f + pdp_expf_fin(-x)); }
+
+/* tanh(x) = em / (em + 2), em = e^{2|x|} - 1 without cancellation: with 2|x| = n ln2 + r the polynomial part q = e^r - 1 is
+ * the exact answer for n == 0.  |x| is clamped at 10 (tanh(10) rounds to 1). */
+PDP_HD float pdp_tanhf(float x)
+{
+    const float a = pdp_fminf(pdp_abs(x), 10.0f);
+    const float y = a + a;
+    const float t = y * 1.44269504088896341f;
+    const float nf = (t + 12582912.0f) - 12582912.0f;
+    float r = fmaf(nf, -0.693359375f, y);
+    r = fmaf(nf, 2.12194440e-4f, r);
+    const float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    const float q = fmaf(p, z, r);                          /* e^r - 1 */
+    const int n = (int)nf;
+    const float big = pdp_scale2(q + 1.0f, n) - 1.0f;
+    const float em = (n == 0) ? q : big;
+    const float v = em / (em + 2.0f);
+    return pdp_bits2f(pdp_f2bits(v) | (pdp_f2bits(x) & 0x80000000u)) + (x - x);
+}
 
 /* ---- the reference's clamped forms ------------------------------------------------------- */
 /* safe_log(x) = log(max(x, eps))  (reference: pdp_propagate.py:133-134, pdp_predict.py:149-150) */
