@@ -108,6 +108,52 @@ __device__ __forceinline__ f32x16 mfma_block(const float *A, int lda, int Kp, co
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ptr[k0], b_ptr[(size_t)k0 * Np], acc, 0, 0, 0);
     return acc;
 }
+// both operands in LDS (resident weights): batches of U k-steps, the operands of the next batch are read while the MFMAs of the
+// current one run (an MFMA chain is serial: 64 cycles per step, far longer than an LDS round trip per batch)
+template <int U>
+__device__ __forceinline__ f32x16 mfma_block_lds(const float *A, int lda, int Kp, const float *W, int Np, int nb, int mb, const float *__restrict__ bias)
+{
+    const int l = threadIdx.x & 63, i = l & 31, kh = l >> 5;
+    const float b0 = bias ? bias[32 * nb + i] : 0.0f;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = b0;
+    const float *ap = A + (32 * mb + i) * lda + kh;
+    const float *bp = W + kh * Np + 32 * nb + i;
+    const int steps = Kp >> 1, full = steps / U;
+    float a0[U], w0[U], a1[U], w1[U];
+    if (full > 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) { a0[u] = ap[2 * u]; w0[u] = bp[2 * u * Np]; }
+    }
+    int g = 0;
+    for (; g + 1 < full; g += 2) {
+        const int k1 = 2 * U * (g + 1);
+#pragma unroll
+        for (int u = 0; u < U; ++u) { a1[u] = ap[k1 + 2 * u]; w1[u] = bp[(k1 + 2 * u) * Np]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], w0[u], acc, 0, 0, 0);
+        if (g + 2 < full) {
+            const int k2 = 2 * U * (g + 2);
+#pragma unroll
+            for (int u = 0; u < U; ++u) { a0[u] = ap[k2 + 2 * u]; w0[u] = bp[(k2 + 2 * u) * Np]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], w1[u], acc, 0, 0, 0);
+    }
+    if (g < full) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], w0[u], acc, 0, 0, 0);
+    }
+    for (int s2 = full * U; s2 < steps; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s2], bp[2 * s2 * Np], acc, 0, 0, 0);
+    return acc;
+}
+
+// lds_layer with LDS-resident weights
+__device__ __forceinline__ int acc_row(int r, int l);
+__device__ __forceinline__ void lds_layer_res(const float *in, int ldi, int Kp, const float *W, int Np, const float *bias, int n_valid, int act,
+                                              float *out, int ldo);
+
 __device__ __forceinline__ void mfma_pair(const float *A, int lda, int Kp, const float *__restrict__ Wt, int Np, int nb,
                                           const float *__restrict__ bias, f32x16 &acc0, f32x16 &acc1)
 {
@@ -127,6 +173,23 @@ __device__ __forceinline__ void lds_layer(const float *in, int ldi, int Kp, cons
     for (int blk = wave; blk < nblocks; blk += NWAVES) {
         const int nb = blk / (TM / 32), mb = blk % (TM / 32);
         const f32x16 acc = mfma_block(in, ldi, Kp, Wt, Np, nb, mb, bias);
+        const int col = 32 * nb + (l & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * mb + acc_row(r, l);
+            out[row * ldo + col] = (col < n_valid) ? act_apply(acc[r], act) : 0.0f;
+        }
+    }
+}
+
+__device__ __forceinline__ void lds_layer_res(const float *in, int ldi, int Kp, const float *W, int Np, const float *bias, int n_valid, int act,
+                                              float *out, int ldo)
+{
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int nblocks = (Np / 32) * (TM / 32);
+    for (int blk = wave; blk < nblocks; blk += NWAVES) {
+        const int nb = blk / (TM / 32), mb = blk % (TM / 32);
+        const f32x16 acc = mfma_block_lds<8>(in, ldi, Kp, W, Np, nb, mb, bias);
         const int col = 32 * nb + (l & 31);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -246,6 +309,142 @@ __global__ void __launch_bounds__(NTN) k_agg_post(int E, const float *__restrict
     }
 }
 
+// ---- resident-weight forms of kernels 1 and 3 --------------------------------------------------------------------------------------------
+// The weight matrices of an aggregator half are small (W1m + W2m = 92 KB at hidden 128): fetching the B operand from L2 inside the
+// MFMA chain left the matrix cores idle for most of the time (one k-step per L2 round trip).  Here a workgroup copies both
+// matrices into LDS once and then walks over many edge tiles (persistent grid, one workgroup per CU); the next tile's input
+// rows are fetched into registers while the current tile runs, and dropped into the X buffer once layer 1 no longer needs it.
+#define PRE_R (TM / NWAVES)    /* rows of a tile per wave */
+#define PRE_C 3                /* 64-column passes per row (input width <= 192) */
+
+__device__ __forceinline__ void copy_to_lds(float *dst, const float *__restrict__ src, int n)
+{
+    for (int i = threadIdx.x; i < n; i += NTN) dst[i] = src[i];
+}
+
+__global__ void __launch_bounds__(NTN) k_agg_pre_res(int E, const float *__restrict__ state, int sd, const float *__restrict__ sign,
+                                                     const float *__restrict__ emask, AggW w, float *__restrict__ h2out, int ntiles)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int ld0 = w.Kp1 + 1, ld1 = w.Np1 + 1;
+    float *W1 = sm, *W2 = W1 + w.Kp1 * w.Np1, *X = W2 + w.Kp2 * w.Np2, *H1 = X + TM * ld0;
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    copy_to_lds(W1, w.Wt1m, w.Kp1 * w.Np1);
+    copy_to_lds(W2, w.Wt2m, w.Kp2 * w.Np2);
+    float pre[PRE_R][PRE_C];
+    auto fetch = [&](int tile) {
+        const int e0 = tile * TM;
+#pragma unroll
+        for (int jr = 0; jr < PRE_R; ++jr) {
+            const int e = e0 + wave + NWAVES * jr;
+#pragma unroll
+            for (int jc = 0; jc < PRE_C; ++jc) {
+                const int c = l + 64 * jc;
+                float v = 0.0f;
+                if (e < E && c < w.Kp1) v = (c < sd) ? state[(size_t)e * sd + c] : (c == sd ? sign[e] : 0.0f);
+                pre[jr][jc] = v;
+            }
+        }
+    };
+    auto deposit = [&]() {
+#pragma unroll
+        for (int jr = 0; jr < PRE_R; ++jr)
+#pragma unroll
+            for (int jc = 0; jc < PRE_C; ++jc) { const int c = l + 64 * jc; if (c < w.Kp1) X[(wave + NWAVES * jr) * ld0 + c] = pre[jr][jc]; }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) { fetch(tile); deposit(); }
+    for (; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();                                   // X (and, the first time, the weights) are in place
+        const int next = tile + gridDim.x;
+        if (next < ntiles) fetch(next);                   // in flight during layer 1
+        lds_layer_res(X, ld0, w.Kp1, W1, w.Np1, w.b1m, w.m1, ACT_LOGSIGMOID, H1, ld1);
+        __syncthreads();                                   // H1 complete, X free
+        if (next < ntiles) deposit();
+        const int e0 = tile * TM;
+        const int nblocks = (w.Np2 / 32) * (TM / 32);
+        for (int blk = wave; blk < nblocks; blk += NWAVES) {
+            const int nb = blk / (TM / 32), mb = blk % (TM / 32);
+            const f32x16 acc = mfma_block_lds<8>(H1, ld1, w.Kp2, W2, w.Np2, nb, mb, nullptr);
+            const int col = 32 * nb + (l & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int e = e0 + 32 * mb + acc_row(r, l);
+                if (e < E && col < w.a) {
+                    float v = pdp_logsigmoidf(acc[r]);
+                    if (emask) v = v * emask[e];
+                    h2out[(size_t)e * w.a + col] = v;
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(NTN) k_agg_post_res(int E, const float *__restrict__ agg, const int32_t *__restrict__ edge_row,
+                                                      const float *__restrict__ h2, const float *__restrict__ sign,
+                                                      const float *__restrict__ emask, const float *__restrict__ rowmask,
+                                                      const float *__restrict__ old, AggW w, float *__restrict__ out, int ntiles)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int ld0 = w.Kp3 + 1, ld1 = w.Np3 + 1;
+    float *W3 = sm, *W4 = W3 + w.Kp3 * w.Np3, *Rt = W4 + w.Kp4 * w.Np4, *G1 = Rt + TM * ld0;
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    copy_to_lds(W3, w.Wt1a, w.Kp3 * w.Np3);
+    copy_to_lds(W4, w.Wt2a, w.Kp4 * w.Np4);
+    float pre[PRE_R][PRE_C];
+    auto fetch = [&](int tile) {
+        const int e0 = tile * TM;
+#pragma unroll
+        for (int jr = 0; jr < PRE_R; ++jr) {
+            const int e = e0 + wave + NWAVES * jr;
+#pragma unroll
+            for (int jc = 0; jc < PRE_C; ++jc) {
+                const int c = l + 64 * jc;
+                float v = 0.0f;
+                if (e < E && c < w.Kp3) {
+                    if (c < w.a) {
+                        const float own = emask ? h2[(size_t)e * w.a + c] * emask[e] : h2[(size_t)e * w.a + c];
+                        v = (0.0f + agg[(size_t)edge_row[e] * w.a + c]) - own;
+                    } else if (c == w.a && w.fd) v = sign[e];
+                }
+                pre[jr][jc] = v;
+            }
+        }
+    };
+    auto deposit = [&]() {
+#pragma unroll
+        for (int jr = 0; jr < PRE_R; ++jr)
+#pragma unroll
+            for (int jc = 0; jc < PRE_C; ++jc) { const int c = l + 64 * jc; if (c < w.Kp3) Rt[(wave + NWAVES * jr) * ld0 + c] = pre[jr][jc]; }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) { fetch(tile); deposit(); }
+    for (; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();
+        const int next = tile + gridDim.x;
+        if (next < ntiles) fetch(next);
+        lds_layer_res(Rt, ld0, w.Kp3, W3, w.Np3, w.b1a, w.g, ACT_LOGSIGMOID, G1, ld1);
+        __syncthreads();
+        if (next < ntiles) deposit();
+        const int e0 = tile * TM;
+        const int nblocks = (w.Np4 / 32) * (TM / 32);
+        for (int blk = wave; blk < nblocks; blk += NWAVES) {
+            const int nb = blk / (TM / 32), mb = blk % (TM / 32);
+            const f32x16 acc = mfma_block_lds<8>(G1, ld1, w.Kp4, W4, w.Np4, nb, mb, nullptr);
+            const int col = 32 * nb + (l & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int e = e0 + 32 * mb + acc_row(r, l);
+                if (e < E && col < w.out) {
+                    const float nv = pdp_logsigmoidf(acc[r]);
+                    const float mk = rowmask ? rowmask[e] : 1.0f;
+                    out[(size_t)e * w.out + col] = mk * nv + (1.0f - mk) * old[(size_t)e * w.out + col];
+                }
+            }
+        }
+    }
+}
+
 // ---- kernel 4: predictor tail on variable tiles (include_self = True) + Perceptron head --------------------------------------------
 __global__ void __launch_bounds__(NTN) k_predict_rows(int V, const float *__restrict__ agg, AggW w, HeadW hd, float *__restrict__ pred)
 {
@@ -273,55 +472,81 @@ __global__ void __launch_bounds__(NTN) k_predict_rows(int V, const float *__rest
 
 // ---- kernel 5: GRU cell on edge tiles ----------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(NTN) k_gru(int E, const float *__restrict__ state, const float *__restrict__ sign,
-                                             const float *__restrict__ hprev, const float *__restrict__ rowmask, GruW g, float *__restrict__ out)
+                                             const float *__restrict__ hprev, const float *__restrict__ rowmask, GruW g, float *__restrict__ out, int ntiles)
 {
+    // Persistent over edge tiles: the rows of the next tile are fetched into registers (8 rows per wave, all loads in flight at once)
+    // while the six MFMA chains of the current tile run, and dropped into LDS between the two barriers that separate tiles.
+    // (Staging the weights through LDS in k-chunks shared by all waves was tried and is slower here: 37 vs 35 ms at config 3 --
+    // the kernel is limited by the serial MFMA -> epilogue sequence of each wave at two waves per SIMD, not by the weight stream.)
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int ldx = g.Kpx + 1, ldh = g.Kph + 1;
     float *X = sm, *Hs = sm + TM * ldx;
-    const int e0 = blockIdx.x * TM;
-    for (int idx = threadIdx.x; idx < TM * g.Kpx; idx += NTN) {
-        const int r = idx / g.Kpx, c = idx % g.Kpx;
-        const int e = e0 + r;
-        float v = 0.0f;
-        if (e < E) v = (c < g.dx) ? state[(size_t)e * g.dx + c] : (c == g.dx ? sign[e] : 0.0f);
-        X[r * ldx + c] = v;
-    }
-    for (int idx = threadIdx.x; idx < TM * g.Kph; idx += NTN) {
-        const int r = idx / g.Kph, c = idx % g.Kph;
-        const int e = e0 + r;
-        Hs[r * ldh + c] = (e < E && c < g.H) ? hprev[(size_t)e * g.H + c] : 0.0f;
-    }
-    __syncthreads();
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int hb = g.Hp / 32;
-    const int N3 = 3 * g.Hp;
-    for (int blk = wave; blk < hb * 2; blk += NWAVES) {
-        const int nb = blk >> 1, mb = blk & 1;
-        const int col = 32 * nb + (l & 31);
-        // gate order r, z, n (torch.nn.GRUCell); input and hidden products stay separate sums (hgates + igates)
-        f32x16 ia[1], ha[1], rg, zg;
-        mfma_chain<1, 8>(X, ldx, g.Kpx, g.Wt_ih, N3, nb, mb, g.b_ih, ia);
-        mfma_chain<1, 8>(Hs, ldh, g.Kph, g.Wt_hh, N3, nb, mb, g.b_hh, ha);
+    float px[PRE_R][PRE_C], ph[PRE_R][PRE_C];
+    auto fetch = [&](int tile) {
+        const int e0 = tile * TM;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) rg[r] = pdp_sigmoidf(ha[0][r] + ia[0][r]);
-        mfma_chain<1, 8>(X, ldx, g.Kpx, g.Wt_ih, N3, hb + nb, mb, g.b_ih, ia);
-        mfma_chain<1, 8>(Hs, ldh, g.Kph, g.Wt_hh, N3, hb + nb, mb, g.b_hh, ha);
+        for (int jr = 0; jr < PRE_R; ++jr) {
+            const int e = e0 + wave + NWAVES * jr;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) zg[r] = pdp_sigmoidf(ha[0][r] + ia[0][r]);
-        mfma_chain<1, 8>(X, ldx, g.Kpx, g.Wt_ih, N3, 2 * hb + nb, mb, g.b_ih, ia);
-        mfma_chain<1, 8>(Hs, ldh, g.Kph, g.Wt_hh, N3, 2 * hb + nb, mb, g.b_hh, ha);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = 32 * mb + acc_row(r, l);
-            const int e = e0 + row;
-            if (e < E && col < g.H) {
-                const float ng = pdp_tanhf(ia[0][r] + ha[0][r] * rg[r]);
-                const float hp = Hs[row * ldh + col];
-                const float hnew = (hp - ng) * zg[r] + ng;
-                const float mk = rowmask ? rowmask[e] : 1.0f;
-                out[(size_t)e * g.H + col] = mk * hnew + (1.0f - mk) * hp;
+            for (int jc = 0; jc < PRE_C; ++jc) {
+                const int c = l + 64 * jc;
+                float v = 0.0f, hv = 0.0f;
+                if (e < E && c < g.Kpx) v = (c < g.dx) ? state[(size_t)e * g.dx + c] : (c == g.dx ? sign[e] : 0.0f);
+                if (e < E && c < g.H) hv = hprev[(size_t)e * g.H + c];
+                px[jr][jc] = v; ph[jr][jc] = hv;
             }
         }
+    };
+    auto deposit = [&]() {
+#pragma unroll
+        for (int jr = 0; jr < PRE_R; ++jr)
+#pragma unroll
+            for (int jc = 0; jc < PRE_C; ++jc) {
+                const int c = l + 64 * jc, r = wave + NWAVES * jr;
+                if (c < g.Kpx) X[r * ldx + c] = px[jr][jc];
+                if (c < g.Kph) Hs[r * ldh + c] = ph[jr][jc];
+            }
+    };
+    const int hb = g.Hp / 32;
+    const int N3 = 3 * g.Hp;
+    int tile = blockIdx.x;
+    if (tile < ntiles) { fetch(tile); deposit(); }
+    for (; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();
+        const int next = tile + gridDim.x;
+        if (next < ntiles) fetch(next);
+        const int e0 = tile * TM;
+        for (int blk = wave; blk < hb * 2; blk += NWAVES) {
+            const int nb = blk >> 1, mb = blk & 1;
+            const int col = 32 * nb + (l & 31);
+            // gate order r, z, n (torch.nn.GRUCell); input and hidden products stay separate sums (hgates + igates)
+            f32x16 ia[1], ha[1], rg, zg;
+            mfma_chain<1, 8>(X, ldx, g.Kpx, g.Wt_ih, N3, nb, mb, g.b_ih, ia);
+            mfma_chain<1, 8>(Hs, ldh, g.Kph, g.Wt_hh, N3, nb, mb, g.b_hh, ha);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rg[r] = pdp_sigmoidf(ha[0][r] + ia[0][r]);
+            mfma_chain<1, 8>(X, ldx, g.Kpx, g.Wt_ih, N3, hb + nb, mb, g.b_ih, ia);
+            mfma_chain<1, 8>(Hs, ldh, g.Kph, g.Wt_hh, N3, hb + nb, mb, g.b_hh, ha);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zg[r] = pdp_sigmoidf(ha[0][r] + ia[0][r]);
+            mfma_chain<1, 8>(X, ldx, g.Kpx, g.Wt_ih, N3, 2 * hb + nb, mb, g.b_ih, ia);
+            mfma_chain<1, 8>(Hs, ldh, g.Kph, g.Wt_hh, N3, 2 * hb + nb, mb, g.b_hh, ha);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * mb + acc_row(r, l);
+                const int e = e0 + row;
+                if (e < E && col < g.H) {
+                    const float ng = pdp_tanhf(ia[0][r] + ha[0][r] * rg[r]);
+                    const float hp = Hs[row * ldh + col];
+                    const float hnew = (hp - ng) * zg[r] + ng;
+                    const float mk = rowmask ? rowmask[e] : 1.0f;
+                    out[(size_t)e * g.H + col] = mk * hnew + (1.0f - mk) * hp;
+                }
+            }
+        }
+        __syncthreads();                                   // every wave is done with X / Hs
+        if (next < ntiles) deposit();
     }
 }
 
@@ -355,6 +580,31 @@ static int set_lds(const void *fn, size_t bytes)
 
 static float *neural_ws(pdp_problem *p, int slot, size_t floats);
 
+#define LDS_RES_LIMIT (160 * 1024 - 512)
+static int persistent_grid()
+{
+    static int cus = 0;
+    if (!cus) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount; if (cus <= 0) cus = 256; }
+    return cus;
+}
+
+// aggregator pre-transform: resident-weight persistent form when both matrices and the tile fit the LDS, tile-per-workgroup form otherwise
+static int launch_agg_pre(int E, const float *state, const float *sign, const float *edge_mask, const AggW &w, float *h2, hipStream_t st)
+{
+    const int tiles = (E + TM - 1) / TM;
+    const size_t lds1 = sizeof(float) * (size_t)TM * ((w.Kp1 + 1) + (w.Np1 + 1));
+    const size_t res1 = sizeof(float) * ((size_t)w.Kp1 * w.Np1 + (size_t)w.Kp2 * w.Np2) + lds1;
+    if (res1 <= LDS_RES_LIMIT && w.Kp1 <= 64 * PRE_C) {
+        int s = set_lds((const void *)k_agg_pre_res, res1); if (s != PDP_OK) return s;
+        const int grid = tiles < persistent_grid() ? tiles : persistent_grid();
+        hipLaunchKernelGGL(k_agg_pre_res, dim3(grid), dim3(NTN), res1, st, E, state, w.din - 1, sign, edge_mask, w, h2, tiles);
+    } else {
+        int s = set_lds((const void *)k_agg_pre, lds1); if (s != PDP_OK) return s;
+        hipLaunchKernelGGL(k_agg_pre, dim3(tiles), dim3(NTN), lds1, st, E, state, w.din - 1, sign, edge_mask, w, h2);
+    }
+    return PDP_OK;
+}
+
 // replaces: MessageAggregator.forward with include_self_message=False as used by NeuralMessagePasser
 // (pdp_propagate.py:77-78,88-89): by_variable != 0 aggregates over the variable of each edge, else over its clause.
 // state [E, din-1]; edge_mask [E] or NULL; active_mask uint8 [B] or NULL; old [E, out] = state blended in where inactive.
@@ -373,13 +623,23 @@ extern "C" int pdp_neural_aggregate_edges(pdp_problem *p, const pdp_agg_desc *d,
     int s = set_lds((const void *)k_agg_pre, lds1); if (s != PDP_OK) return s;
     s = set_lds((const void *)k_agg_post, lds3); if (s != PDP_OK) return s;
     hipLaunchKernelGGL(k_edge_active, dim3(1024), dim3(256), 0, st, E, p->graph_map, p->var_inst, active_mask, rowmask);
-    hipLaunchKernelGGL(k_agg_pre, dim3(tiles), dim3(NTN), lds1, st, E, state, w.din - 1, p->edge_sign, edge_mask, w, h2);
+    s = launch_agg_pre(E, state, p->edge_sign, edge_mask, w, h2, st); if (s != PDP_OK) return s;
     // global CSR rows in ascending edge id: the sorted edge lists of the problem (global ids)
     const int32_t *row_ptr = by_variable ? p->nv_ptr : p->nf_ptr;
     const int32_t *row_edges = by_variable ? p->nv_edges : p->nf_edges;
     hipLaunchKernelGGL(k_row_sum, dim3((unsigned)(((int64_t)R * w.a + 255) / 256)), dim3(256), 0, st, R, w.a, row_ptr, row_edges, h2, agg);
     const int32_t *edge_row = by_variable ? p->graph_map : p->graph_map + E;
-    hipLaunchKernelGGL(k_agg_post, dim3(tiles), dim3(NTN), lds3, st, E, agg, edge_row, h2, p->edge_sign, edge_mask, rowmask, old, w, out);
+    const size_t res3 = sizeof(float) * ((size_t)w.Kp3 * w.Np3 + (size_t)w.Kp4 * w.Np4) + lds3;
+    // the post-transform has little MFMA work per tile and a gather-heavy tile load: three small workgroups per CU (tile-per-workgroup
+    // form) overlap better than one resident one (12.8 vs 18.3 ms at config 3), so the resident form is opt-in
+    static const bool post_res = getenv("PDP_NEURAL_POST_RESIDENT") != nullptr;
+    if (post_res && res3 <= LDS_RES_LIMIT && w.Kp3 <= 64 * PRE_C) {
+        s = set_lds((const void *)k_agg_post_res, res3); if (s != PDP_OK) return s;
+        const int grid = tiles < persistent_grid() ? tiles : persistent_grid();
+        hipLaunchKernelGGL(k_agg_post_res, dim3(grid), dim3(NTN), res3, st, E, agg, edge_row, h2, p->edge_sign, edge_mask, rowmask, old, w, out, tiles);
+    } else {
+        hipLaunchKernelGGL(k_agg_post, dim3(tiles), dim3(NTN), lds3, st, E, agg, edge_row, h2, p->edge_sign, edge_mask, rowmask, old, w, out);
+    }
     PDP_LAUNCH_CHECK();
     return PDP_OK;
 }
@@ -398,9 +658,14 @@ extern "C" int pdp_neural_gru(pdp_problem *p, const pdp_gru_desc *d, const float
     float *rowmask = neural_ws(p, 2, (size_t)E);
     if (!rowmask) return PDP_ERR_HIP;
     const size_t lds = sizeof(float) * (size_t)TM * ((g.Kpx + 1) + (g.Kph + 1));
+    PDP_REQUIRE(g.Kpx <= 64 * PRE_C && g.Kph <= 64 * PRE_C, "GRU wider than 192 inputs is not supported by the tile prefetch");
     int s = set_lds((const void *)k_gru, lds); if (s != PDP_OK) return s;
     hipLaunchKernelGGL(k_edge_active, dim3(1024), dim3(256), 0, st, E, p->graph_map, p->var_inst, active_mask, rowmask);
-    hipLaunchKernelGGL(k_gru, dim3((E + TM - 1) / TM), dim3(NTN), lds, st, E, state, p->edge_sign, h, rowmask, g, out);
+    const int tiles = (E + TM - 1) / TM;
+    int per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_gru, NTN, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    const int grid = tiles < per_cu * persistent_grid() ? tiles : per_cu * persistent_grid();
+    hipLaunchKernelGGL(k_gru, dim3(grid), dim3(NTN), lds, st, E, state, p->edge_sign, h, rowmask, g, out, tiles);
     PDP_LAUNCH_CHECK();
     return PDP_OK;
 }
@@ -422,7 +687,7 @@ extern "C" int pdp_neural_predict(pdp_problem *p, const pdp_agg_desc *d, const p
     const size_t lds4 = sizeof(float) * (size_t)TM * ((w.Kp3 + 1) + (w.Np3 + 1) + (w.Np4 + 1) + (h.Np + 1));
     int s = set_lds((const void *)k_agg_pre, lds1); if (s != PDP_OK) return s;
     s = set_lds((const void *)k_predict_rows, lds4); if (s != PDP_OK) return s;
-    hipLaunchKernelGGL(k_agg_pre, dim3((E + TM - 1) / TM), dim3(NTN), lds1, st, E, state, w.din - 1, p->edge_sign, edge_mask, w, h2);
+    s = launch_agg_pre(E, state, p->edge_sign, edge_mask, w, h2, st); if (s != PDP_OK) return s;
     hipLaunchKernelGGL(k_row_sum, dim3((unsigned)(((int64_t)V * w.a + 255) / 256)), dim3(256), 0, st, V, w.a, p->nv_ptr, p->nv_edges, h2, agg);
     hipLaunchKernelGGL(k_predict_rows, dim3((V + TM - 1) / TM), dim3(NTN), lds4, st, V, agg, w, h, pred);
     PDP_LAUNCH_CHECK();
