@@ -112,3 +112,29 @@ def test_persistent_solve_reproduces_nan_poisoning(oracle, spec, T, tol, t_max):
     np.testing.assert_array_equal(npy(hp.solution), res['trace_solution'][it - 1])
     np.testing.assert_array_equal(npy(q), res['q'])
     np.testing.assert_array_equal(npy(fs), res['fs'])
+
+
+@pytest.mark.parametrize('chunk', [None, '5'])
+def test_persistent_solve_resumes_across_calls(oracle, monkeypatch, chunk):
+    """Two consecutive calls (the second one enters with decimator state: previous surveys, counters, edge mask) end exactly
+    where one call of the total length ends -- also with a chunk length that does not divide either call."""
+    from pdp import native
+    if chunk:
+        monkeypatch.setenv('PDP_SOLVE_CHUNK', chunk)
+    b = random_batch(batch=40, n=40, k=3, m=140, seed=900)
+    T1, T2, tol, t_max = 23, 37, 0.05, 10
+    hp, res, q, fs, am, iters, used_lds, spec_ok = run_pair(oracle, b, T1 + T2, tol, t_max)
+    assert spec_ok and used_lds
+    hp2, op2 = make_pair(oracle, b)
+    hp2.simplify()
+    q2 = torch.full((hp2.E, 3), 1.0, device='cuda:0') / 3.0
+    fs2 = torch.zeros(hp2.E, 2, device='cuda:0'); fs2[:, 0] = 0.5
+    am2 = torch.ones(hp2.B, dtype=torch.uint8, device='cuda:0')
+    dec2 = native.Decimator(hp2)
+    it1, _ = hp2.sp_solve(q2, fs2, am2, dec2, T1, tol, t_max)
+    it2, _ = hp2.sp_solve(q2, fs2, am2, dec2, T2, tol, t_max)
+    assert it1 == T1 and it1 + it2 == iters == res['iterations_run']
+    for a, c in ((q, q2), (fs, fs2), (am, am2), (hp.active_variables, hp2.active_variables), (hp.active_functions, hp2.active_functions),
+                 (hp.solution, hp2.solution)):
+        np.testing.assert_array_equal(npy(a), npy(c))
+    np.testing.assert_array_equal(npy(q2), res['q'])
