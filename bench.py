@@ -143,6 +143,7 @@ def main():
                     help="sp: configs[1] (headline metric); neural: configs[2] 'np-nd-np' hidden_dim=128 on the same graph (fp32 MFMA)")
     ap.add_argument('--hidden', type=int, default=128)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--seed-rank', type=int, default=None, help='generate the batch another rank would get (checks of the sharded run on one GPU)')
     ap.add_argument('--cpu-sample-batch', type=int, default=1000)
     ap.add_argument('--cpu-sample-iters', type=int, default=100)
     args = ap.parse_args()
@@ -162,7 +163,7 @@ def main():
 
     # ---- synthetic batch, resident in HBM before the timed region ---------------------------------------------
     m = int(round(4.2 * args.n))
-    items = dataset.random_ksat_items(args.batch, args.n, 3, m=m, seed=1000003 * rank)
+    items = dataset.random_ksat_items(args.batch, args.n, 3, m=m, seed=1000003 * (rank if args.seed_rank is None else args.seed_rank))
     host_batch = dataset.collate_segment(items)
     torch.cuda.synchronize(); t_setup = time.perf_counter()
     b = dataset.to_torch(host_batch, dev)                      # PCIe upload of the loader tensors
