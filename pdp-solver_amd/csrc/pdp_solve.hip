@@ -1575,7 +1575,8 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
         PDP_HIP_CHECK(hipStreamSynchronize(st));
         const bool force_r = force_flag != 0;
         const size_t lds_r = lds2_bytes_for(p->max_n, p->max_m, p->max_e, force_r);
-        const bool fits_r = p->fn_edges_identity && lds_r <= 160 * 1024 - 1024 && p->max_e < 65535 && p->max_n < 16384 && p->max_m < 16384;
+        const bool fits_r = p->fn_edges_identity && lds_r <= 160 * 1024 - 1024 && p->max_e < 65535 && p->max_n < 16384 && p->max_m < 16384 &&
+                            getenv("PDP_SOLVE_FORCE_HBM") == nullptr;          // the switch lets the tests reach the HBM-resident kernel with small instances
         if (fits_r) return sp_solve_resident(p, a, st, force_r, lds_r, p->max_e <= 1024 ? 256 : 512, C);
     }
     // ---- instances too large for the LDS: HBM-resident kernel, host-driven chunk loop -----------------------------------

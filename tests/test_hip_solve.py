@@ -138,3 +138,22 @@ def test_persistent_solve_resumes_across_calls(oracle, monkeypatch, chunk):
                  (hp.solution, hp2.solution)):
         np.testing.assert_array_equal(npy(a), npy(c))
     np.testing.assert_array_equal(npy(q2), res['q'])
+
+
+@pytest.mark.parametrize('spec,T,tol,t_max', [SPECS[1], SPECS[3], (dict(batch=400, n=60, k=3, seed=7000), 120, 0.05, 8)])
+def test_hbm_resident_kernel_matches_oracle_loop(oracle, monkeypatch, spec, T, tol, t_max):
+    """Instances that do not fit the LDS run the same algorithm on HBM-resident arrays (host-driven chunk loop with snapshots);
+    forced here for small instances, including a batch that is NaN-poisoned."""
+    monkeypatch.setenv('PDP_SOLVE_FORCE_HBM', '1')
+    b = random_batch(**spec)
+    hp, res, q, fs, am, iters, used_lds, spec_ok = run_pair(oracle, b, T, tol, t_max)
+    if not spec_ok:
+        pytest.skip("speculation failed on this batch (the caller would rerun step-wise)")
+    assert not used_lds
+    it = res['iterations_run']
+    assert iters == it
+    np.testing.assert_array_equal(npy(am), res['trace_active_mask'][it - 1])
+    np.testing.assert_array_equal(npy(hp.active_variables)[:, 0], res['trace_active_var'][it - 1])
+    np.testing.assert_array_equal(npy(hp.solution), res['trace_solution'][it - 1])
+    np.testing.assert_array_equal(npy(q), res['q'])
+    np.testing.assert_array_equal(npy(fs), res['fs'])
