@@ -1265,13 +1265,25 @@ __global__ void __launch_bounds__(256) k_solve_import(PView pv, const float *q, 
     float *QU = reinterpret_cast<float *>(dy + BL.QU), *Ecur = reinterpret_cast<float *>(dy + BL.E);
     uint16_t *pcc = reinterpret_cast<uint16_t *>(dy + BL.pcc);
     const float *sq = q + 3 * (size_t)G.e0, *sfs = fs + 2 * (size_t)G.e0;
-    for (int p = tid; p < ne; p += nt) {
-        const int e = G.v_edges[p];
-        if (build_static) { pvv[p] = (uint16_t)(G.e_var[e] | (G.sgn[e] < 0 ? 0x8000 : 0)); e2p[e] = (uint16_t)p; }
-        const bool em = G.emask[e] == 1.0f;
-        pcc[p] = (uint16_t)(G.e_fn[e] | (em ? (PC_EM | PC_EM_USED) : 0));
-        QU[p] = sq[3 * e]; Ecur[p] = sfs[2 * e];
-        if (has_prev) prev_slots[G.e0 + p] = prev[G.e0 + e];
+    // four slots per trip: the gathers through v_edges are dependent loads, keep several of them in flight
+    for (int p0 = tid; p0 < ne; p0 += 4 * nt) {
+        int e[4]; float qv[4], ev[4], mv[4], pv[4] = {0.0f, 0.0f, 0.0f, 0.0f}; int fn[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int p = p0 + j * nt; e[j] = G.v_edges[p < ne ? p : p0]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            qv[j] = sq[3 * e[j]]; ev[j] = sfs[2 * e[j]]; mv[j] = G.emask[e[j]]; fn[j] = G.e_fn[e[j]];
+            if (has_prev) pv[j] = prev[G.e0 + e[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = p0 + j * nt;
+            if (p >= ne) continue;
+            if (build_static) { pvv[p] = (uint16_t)(G.e_var[e[j]] | (G.sgn[e[j]] < 0 ? 0x8000 : 0)); e2p[e[j]] = (uint16_t)p; }
+            pcc[p] = (uint16_t)(fn[j] | ((mv[j] == 1.0f) ? (PC_EM | PC_EM_USED) : 0));
+            QU[p] = qv[j]; Ecur[p] = ev[j];
+            if (has_prev) prev_slots[G.e0 + p] = pv[j];
+        }
     }
     if (build_static) {
         uint16_t *vp = reinterpret_cast<uint16_t *>(st + BL.vptr), *fp = reinterpret_cast<uint16_t *>(st + BL.fptr);
