@@ -980,9 +980,10 @@ __global__ void __launch_bounds__(512, 4) k_sp_solve_lds(PView pv_, SolveParams 
                 const float pos = 0.0f + Pv[v], neg = 0.0f + Nv[v];
                 float same = (0.5f * (1.0f + s)) * pos + (0.5f * (1.0f - s)) * neg;
                 same = same - Y[p];
-                same = same + ((force == s) ? L1 : L0);
+                // without an external force both log terms are log(1) = +0: adding it can only turn a -0 into +0, which exp ignores
+                if constexpr (FORCE) same = same + ((force == s) ? L1 : L0);
                 float opp = (0.5f * (1.0f - s)) * pos + (0.5f * (1.0f + s)) * neg;
-                opp = opp + ((force == -s) ? L1 : L0);
+                if constexpr (FORCE) opp = opp + ((force == -s) ? L1 : L0);
                 const f4v ex = exp4_fin_le30((f4v){agg, same + opp, same, opp});
                 const float eta_new = 1.0f * ex.x + (1.0f - 1.0f) * eta_old;
                 const float dc = ex.y;
