@@ -975,9 +975,9 @@ __global__ void __launch_bounds__(512, 4) k_sp_solve_lds(PView pv_, SolveParams 
                 const int v = pw & 0x3fff, c = cw & 0x3fff;
                 const float s = slot_sign(pw);
                 const float eta_old = Eold[p];
-                const float agg = (0.0f + S[c]) - X[p];
+                const float agg = S[c] - X[p];                  // the reference's 0 + S is a no-op: a sum that starts at +0 is never -0
                 const float force = FORCE ? L.FRC[p] : 0.0f;
-                const float pos = 0.0f + Pv[v], neg = 0.0f + Nv[v];
+                const float pos = Pv[v], neg = Nv[v];
                 float same = (0.5f * (1.0f + s)) * pos + (0.5f * (1.0f - s)) * neg;
                 same = same - Y[p];
                 // without an external force both log terms are log(1) = +0: adding it can only turn a -0 into +0, which exp ignores
