@@ -157,3 +157,48 @@ def test_hbm_resident_kernel_matches_oracle_loop(oracle, monkeypatch, spec, T, t
     np.testing.assert_array_equal(npy(hp.solution), res['trace_solution'][it - 1])
     np.testing.assert_array_equal(npy(q), res['q'])
     np.testing.assert_array_equal(npy(fs), res['fs'])
+
+
+def _tiny_batch(clause_lists):
+    from pdp.factorgraph import dataset
+    items = [dataset.instance_from_clauses(max(abs(l) for c in cl for l in c), cl, label=-1, name="t%d" % i) for i, cl in enumerate(clause_lists)]
+    return dataset.collate_segment(items)
+
+
+@pytest.mark.parametrize('T', [1, 7])
+def test_persistent_solve_degenerate_instances(oracle, T):
+    """Edge cases next to ordinary instances in one batch: an instance that simplify() solves completely (unit propagation), a
+    contradictory one (x and not x: conflict, solver.py:248-262), a single clause, one long clause, one variable in 30 clauses."""
+    from pdp import generator
+    rng = np.random.RandomState(4)
+    ordinary = generator.uniform_ksat(30, 100, 3, rng)
+    b = _tiny_batch([[[1], [-1, 2], [-2, 3]],
+                     [[1], [-1]],
+                     [[1, -2, 3]],
+                     [[i + 1 for i in range(40)]],
+                     [[1, (i % 6) + 2, -((i % 5) + 8)] for i in range(30)],
+                     ordinary])
+    hp, res, q, fs, am, iters, used_lds, spec_ok = run_pair(oracle, b, T, 0.05, 10)
+    assert spec_ok and used_lds
+    it = res['iterations_run']
+    assert iters == it
+    np.testing.assert_array_equal(npy(am), res['trace_active_mask'][it - 1])
+    np.testing.assert_array_equal(npy(hp.active_variables)[:, 0], res['trace_active_var'][it - 1])
+    np.testing.assert_array_equal(npy(hp.active_functions)[:, 0], res['trace_active_fn'][it - 1])
+    np.testing.assert_array_equal(npy(hp.solution), res['trace_solution'][it - 1])
+    np.testing.assert_array_equal(npy(q), res['q'])
+    np.testing.assert_array_equal(npy(fs), res['fs'])
+
+
+def test_persistent_solve_with_nothing_to_do(oracle):
+    "every instance enters inactive: no iteration runs and no array changes"
+    from pdp import native
+    b = random_batch(batch=5, n=30, k=3, seed=77)
+    hp, op = make_pair(oracle, b)
+    hp.simplify()
+    q = torch.rand(hp.E, 3, device='cuda:0'); fs = torch.rand(hp.E, 2, device='cuda:0')
+    q0, fs0, av0 = q.clone(), fs.clone(), hp.active_variables.clone()
+    am = torch.zeros(hp.B, dtype=torch.uint8, device='cuda:0')
+    iters, _ = hp.sp_solve(q, fs, am, native.Decimator(hp), 9, 0.02, 100)
+    assert iters == 0 and int(am.sum()) == 0
+    assert torch.equal(q, q0) and torch.equal(fs, fs0) and torch.equal(hp.active_variables, av0)
