@@ -107,13 +107,47 @@ def to_torch(batch, device):
         misc_data=batch['misc_data'], batch_size=batch['batch_size'])
 
 
+def dimacs_file_list(path):
+    """The DIMACS inputs of a run in the converter's order with the converter's labels (reference: src/dimacs2json.py:98-125):
+    a directory contributes its *.cnf / *.dimacs files in os.listdir order, label = last digit of the file stem; a single
+    file gets the character 8 from the end of its path as label; -1 when that is not a digit."""
+    import os
+    if os.path.isfile(path):
+        c = path[-8] if len(path) >= 8 else ''
+        return [(path, float(c) if c.isdigit() else -1)]
+    out = []
+    for f in os.listdir(path):
+        full = os.path.join(path, f)
+        stem, ext = os.path.splitext(full)
+        if os.path.isfile(full) and ext.lower() in ('.dimacs', '.cnf'):
+            out.append((full, float(stem[-1]) if stem[-1].isdigit() else -1))
+    return out
+
+
+def dimacs_item(path, label):
+    "One DIMACS file -> loader item, through the native reader (no JSON round trip); same tuple as parse_line of the converted line."
+    import os
+    from pdp import native
+    var_num, clause_num, signed_vars, clause_ids = native.dimacs_parse(path)
+    graph_map = np.stack((np.abs(signed_vars) - 1, clause_ids - 1)).astype(np.int32)
+    return var_num, clause_num, graph_map, np.sign(signed_vars).astype(np.float32), float(label), [os.path.split(path)[1]]
+
+
 class FactorGraphDataset(object):
-    """JSON-lines dataset with the reference's iteration order (shuffle=False)."""
+    """JSON-lines dataset with the reference's iteration order (shuffle=False).  ``input_file`` may also be a DIMACS file or a
+    directory of DIMACS files: the instances are then read directly by the native parser, in the order and with the labels the
+    converter (dimacs2json.py) would have produced."""
 
     def __init__(self, input_file, limit, hidden_dim, max_cache_size=100000, batch_replication=1):
+        import os
         self._input_file = input_file
-        with open(input_file, 'r') as f:
-            self._lines = [l for l in f.read().split('\n') if l.strip()]
+        self._dimacs = None
+        if os.path.isdir(input_file) or os.path.splitext(input_file)[1].lower() in ('.cnf', '.dimacs'):
+            self._dimacs = dimacs_file_list(input_file)
+            self._lines = self._dimacs
+        else:
+            with open(input_file, 'r') as f:
+                self._lines = [l for l in f.read().split('\n') if l.strip()]
         self._limit = limit
         self._hidden_dim = hidden_dim
         self._batch_replication = batch_replication
@@ -126,7 +160,7 @@ class FactorGraphDataset(object):
     def __getitem__(self, idx):
         if idx in self._cache:
             return self._cache[idx]
-        item = parse_line(self._lines[idx])
+        item = dimacs_item(*self._dimacs[idx]) if self._dimacs is not None else parse_line(self._lines[idx])
         if len(self._cache) < self._max_cache_size:
             self._cache[idx] = item
         return item

@@ -72,19 +72,11 @@ def main(argv=None):
     logging.basicConfig(level=logging.DEBUG, format=fmt)
     logger = logging.getLogger(model_config['model_name'])
 
+    # -d: the reference converts the DIMACS input into a temporary JSON file first (satyr.py:66-80); here the loader reads the
+    # DIMACS files directly through the native parser (same instances, same order, same labels -- dataset.dimacs_file_list)
     temp_file_name = None
-    if args['dimacs']:
-        if args['verbose']:
-            logger.info("Converting DIMACS files into JSON...")
-        temp_file_name = 'temp_problem_file.json'
-        if os.path.isfile(args['test_path']):
-            head, _ = os.path.split(args['test_path'])
-            temp_file_name = os.path.join(head, temp_file_name)
-            dimacs2json.convert_file(args['test_path'], temp_file_name, False)
-        else:
-            temp_file_name = os.path.join(args['test_path'], temp_file_name)
-            dimacs2json.convert_directory(args['test_path'], temp_file_name, False)
-        args['test_path'] = temp_file_name
+    if args['dimacs'] and args['verbose']:
+        logger.info("Reading DIMACS files...")
 
     config = {**model_config, **args}
     if config['model_type'] in ('p-d-p', 'walk-sat', 'reinforce'):

@@ -166,3 +166,24 @@ def test_dimacs2json_lines_equal_reference_golden(tmp_path):
     assert got.keys() == ref.keys() and len(got) == 20
     for k in ref:
         assert got[k] == ref[k], k
+
+
+def test_loader_reads_dimacs_directly():
+    "a DIMACS directory handed to the loader yields exactly the items of the converter's JSON lines (no temp file, no JSON)"
+    gdir = os.path.join(REPO, 'tests', 'golden', 'dimacs20')
+    ds = dataset.FactorGraphDataset(gdir, 40000000, 3)
+    ref = {}
+    for l in open(os.path.join(REPO, 'tests', 'golden', 'cli_dimacs20.converted.jsonl')).read().split('\n'):
+        if l.strip():
+            it = dataset.parse_line(l)
+            ref[it[5][0]] = it
+    assert len(ds) == 20 == len(ref)
+    for i in range(len(ds)):
+        vn, fn, gm, ef, label, misc = ds[i]
+        r = ref[misc[0]]
+        assert (vn, fn, label) == (r[0], r[1], r[4])
+        np.testing.assert_array_equal(gm, r[2]); np.testing.assert_array_equal(ef, r[3])
+        assert gm.dtype == r[2].dtype and ef.dtype == r[3].dtype
+    single = os.path.join(gdir, sorted(os.listdir(gdir))[0])
+    one = dataset.FactorGraphDataset(single, 40000000, 3)
+    assert len(one) == 1 and one[0][5] == [os.path.split(single)[1]]
