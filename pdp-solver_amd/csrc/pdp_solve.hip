@@ -764,7 +764,7 @@ __device__ __noinline__ int lds_cnf_count(unsigned char *smem, int b, int n, int
 // REPLAY: the poison-replay pass over ctl->replay_count listed instances (a separate instantiation, so that profilers list
 // the two passes under different names)
 template <bool FORCE, bool REPLAY>
-__global__ void __launch_bounds__(512, 4) k_sp_solve_lds(PView pv_, SolveParams sp)
+__global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams sp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float redf[PDP_RED_SMALL];
@@ -1590,7 +1590,10 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
         const size_t lds_r = lds2_bytes_for(p->max_n, p->max_m, p->max_e, force_r);
         const bool fits_r = p->fn_edges_identity && lds_r <= 160 * 1024 - 1024 && p->max_e < 65535 && p->max_n < 16384 && p->max_m < 16384 &&
                             getenv("PDP_SOLVE_FORCE_HBM") == nullptr;          // the switch lets the tests reach the HBM-resident kernel with small instances
-        if (fits_r) return sp_solve_resident(p, a, st, force_r, lds_r, p->max_e <= 1024 ? 256 : 512, C);
+        // threads per instance: 256 for tiny instances, 512 while two workgroups share a CU, 1024 when the instance's LDS image allows
+        // only one workgroup per CU (the same 16 waves per CU either way)
+        const int nt_r = p->max_e <= 1024 ? 256 : (lds_r > 80 * 1024 ? 1024 : 512);
+        if (fits_r) return sp_solve_resident(p, a, st, force_r, lds_r, nt_r, C);
     }
     // ---- instances too large for the LDS: HBM-resident kernel, host-driven chunk loop -----------------------------------
 
