@@ -1,11 +1,13 @@
-// pdp_solve.hip -- persistent solver: the whole PDP iteration loop in ONE launch.
+// pdp_solve.hip -- persistent solver: the PDP iteration loop without a host round trip per iteration.
 // replaces: PropagatorDecimatorSolverBase._forward_core (reference: src/pdp/nn/solver.py:355-386) for the
 // classical triple SurveyPropagator + SequentialDecimator(SurveyScorer) + IdentityPredictor together with the
 // per-iteration termination check (src/pdp/trainer.py:150-162).
 //
-// One workgroup owns one CNF instance for all T iterations.  When the instance fits (the common case: the
-// BASELINE configs have <= ~5k edges per instance) its topology and its whole message state live in LDS and HBM
-// is touched twice: load at entry, store at exit.  Larger instances run the same code on HBM-resident arrays.
+// One workgroup owns one CNF instance.  When the instance fits (the common case: the BASELINE configs have <= ~5k
+// edges per instance) its topology and its whole message state live in LDS for a chunk of iterations per launch
+// (k_sp_solve_lds); between launches it lives in a private slot-major record in HBM, and all launches of a call plus the
+// device-side decisions between them are enqueued up front (sp_solve_resident).  Larger instances run the same algorithm
+// on HBM-resident arrays (k_sp_solve, host-driven chunk loop).  DESIGN.md section 4.2 is the narrative.
 //
 // Cross-instance couplings of the reference cannot be honoured inside independent
 // workgroups, so the kernel SPECULATES that they are inert -- batch-global min of each arg-max/max operand is 0
@@ -118,22 +120,6 @@ __device__ __forceinline__ T *carve(unsigned char *&p, size_t count)
     T *r = reinterpret_cast<T *>(p);
     p += align16(count * sizeof(T));
     return r;
-}
-
-// LDS bytes needed for an instance of (n, m, e): must mirror the carve sequence in the kernel
-static size_t lds_bytes_for(int n, int m, int e)
-{
-    auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    size_t s = 0;
-    s += 4 * a16((size_t)e * 2);          // e_var, e_fn, v_edges, f_edges (u16)
-    s += a16((size_t)(n + 1) * 2) + a16((size_t)(m + 1) * 2);
-    s += a16((size_t)e);                  // sgn
-    s += 8 * a16((size_t)e * 4);          // emask, qu, eta, force, s0..s3
-    s += a16((size_t)m * 4) * 2;          // af, S
-    s += a16((size_t)n * 4) * 9;          // av, sol, P, N, xv1, xv2, score, coeff, assign
-    s += a16((size_t)n * 4) * 2;          // deg, sdeg
-    s += a16((size_t)n) + 2 * a16((size_t)m);
-    return s;
 }
 
 template <class IT, bool LDS>
@@ -1598,6 +1584,7 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
     // ---- instances too large for the LDS: HBM-resident kernel, host-driven chunk loop -----------------------------------
 
     // one allocation: speculation record [2C] + control words + per-instance records + two snapshots (call entry, chunk entry)
+    // (HBM-resident kernel only; the LDS path keeps its state in the instance records and needs the call-entry snapshot alone)
     const size_t words = 2 * (size_t)C + 8;
     const size_t snap_floats = 3 * E + 2 * E + V + F + V + B + E + E + B;
     const size_t snap_bytes = snap_floats * 4 + ((B + 63) & ~(size_t)63);
