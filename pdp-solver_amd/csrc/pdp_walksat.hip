@@ -231,9 +231,10 @@ struct WsParams {
     const float *pred; float *out;
     int steps_cap; float epsilon; int rng_mode; const float *var_rand, *coin_rand; uint64_t seed;
     int32_t *first_sat;        // [B] step at which the instance had no unsat clause (steps_cap if never)
-    uint32_t *spec_used, *spec_zero;   // [steps] any unsat instance evaluated the arg-max / an exact zero existed
+    uint32_t *spec_used, *spec_zero;   // bit maps [(steps + 31) / 32]: any unsat instance evaluated the arg-max / an exact zero existed
     const int32_t *inst_list;  // replay subset or NULL
     const int32_t *cap_b;      // per-instance step cap (replication replay) or NULL
+    int debug_skip;            // timing experiments only (PDP_WS_DEBUG_SKIP): 1 skip the update pass, 2 constant random numbers, 4 skip the arg-max scan
 };
 
 static size_t ws_lds_bytes(int n, int m, int e)
@@ -249,17 +250,79 @@ template <class T> __device__ __forceinline__ T *ws_carve(unsigned char *&p, siz
     return r;
 }
 
+// Incremental form.  The reference re-evaluates every clause and every variable in each step (solver.py:469-496); all of those
+// quantities are small integers, so they can be carried from step to step exactly: flipping variable f changes
+//   aggc[c]  (signed literal sum)            only for the clauses c of f,
+//   unsat[c], the per-instance unsat count   only for those clauses,
+//   delta[u] (energy change if u flips)      only for the variables u of those clauses: minus the old, plus the new contribution
+//                                            of clause c (integer LDS atomics),
+//   nuns[u]  (# unsat clauses containing u)  only where unsat[c] changed.
+// A step is then: one scan over the variables feeding two 64-bit LDS max-atomics (value | inverted index: larger value wins,
+// first index wins ties -- util.sparse_argmax), the flip, and one pass over the ~deg(f) clauses of f.
+// arg-max of (value, index) pairs as the maximum of 64-bit keys: order-preserving bits of the (non-NaN) value on top, inverted
+// index below, so the larger value wins and the first index wins ties (util.sparse_argmax); 0 = "no candidate".
+__device__ __forceinline__ unsigned long long ws_key(float t, int v)
+{
+    const uint32_t b = __float_as_uint(t);
+    const uint32_t ord = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    return ((unsigned long long)ord << 32) | (uint32_t)(0xffffffffu - (uint32_t)v);
+}
+__device__ __forceinline__ int ws_key_index(unsigned long long k) { return k ? (int)(0xffffffffu - (uint32_t)k) : -1; }
+
+// wave-level maximum with DPP moves (a __shfl_down is an LDS round trip of ~100 cycles, a DPP move a few): Hillis-Steele steps
+// inside the 16-lane rows, then lane 15 / lane 31 broadcasts; the result is in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long ws_dpp_max(unsigned long long k)
+{
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(k >> 32), CTRL, ROW_MASK, 0xf, false);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)k, CTRL, ROW_MASK, 0xf, false);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;      // lanes without a source see 0
+    return o > k ? o : k;
+}
+__device__ __forceinline__ unsigned long long ws_wave_max(unsigned long long k)
+{
+    k = ws_dpp_max<0x111, 0xf>(k);      // row_shr:1
+    k = ws_dpp_max<0x112, 0xf>(k);      // row_shr:2
+    k = ws_dpp_max<0x114, 0xf>(k);      // row_shr:4
+    k = ws_dpp_max<0x118, 0xf>(k);      // row_shr:8   -> lane 15 of every row holds its row's maximum
+    k = ws_dpp_max<0x142, 0xa>(k);      // row_bcast:15 into rows 1 and 3
+    k = ws_dpp_max<0x143, 0xc>(k);      // row_bcast:31 into rows 2 and 3 -> lane 63
+    return k;
+}
+
+#ifdef PDP_PHASE_PROF
+__device__ unsigned long long g_ws_cycles[8];
+extern "C" int pdp_debug_ws_cycles(unsigned long long *out_host, int reset)
+{
+    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_ws_cycles), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_ws_cycles), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#define WS_PROF_DECL unsigned long long _t0 = __builtin_readcyclecounter(), _t1; uint32_t _acc[8] = {0};
+#define WS_PROF_MARK(i) do { _t1 = __builtin_readcyclecounter(); _acc[i] += (uint32_t)(_t1 - _t0); _t0 = _t1; } while (0)
+#define WS_PROF_FLUSH() do { if (threadIdx.x == 0) { _Pragma("unroll") for (int _i = 0; _i < 8; ++_i) if (_acc[_i]) atomicAdd(&g_ws_cycles[_i], (unsigned long long)_acc[_i]); } } while (0)
+#else
+#define WS_PROF_DECL
+#define WS_PROF_MARK(i)
+#define WS_PROF_FLUSH()
+#endif
+
 __global__ void __launch_bounds__(256) k_walksat_lds(PView pv, WsParams wp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DECL_RED
+    __shared__ int s_cnt, s_pick;
+    __shared__ float s_coin;
+    __shared__ unsigned long long s_keys[8];         // per-wave maxima of the two arg-max keys (at most 4 waves)
     const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
     const Inst G = load_inst(pv, wp.inst_list ? wp.inst_list[blockIdx.x] : (int)blockIdx.x);
     const int n = G.n, m = G.m, ne = G.e;
     unsigned char *cp = smem;
     uint16_t *pvv = ws_carve<uint16_t>(cp, ne), *pcc = ws_carve<uint16_t>(cp, ne), *e2p = ws_carve<uint16_t>(cp, ne);
     uint16_t *v_ptr = ws_carve<uint16_t>(cp, n + 1), *f_ptr = ws_carve<uint16_t>(cp, m + 1);
-    float *av = ws_carve<float>(cp, n), *a = ws_carve<float>(cp, n), *negd = ws_carve<float>(cp, n), *uv = ws_carve<float>(cp, n);
+    float *av = ws_carve<float>(cp, n), *a = ws_carve<float>(cp, n);
+    int *delta = ws_carve<int>(cp, n), *nuns = ws_carve<int>(cp, n);
     float *af = ws_carve<float>(cp, m), *aggc = ws_carve<float>(cp, m), *degc = ws_carve<float>(cp, m);
     uint8_t *unsat = ws_carve<uint8_t>(cp, m);
     for (int p = tid; p < ne; p += nt) {
@@ -276,68 +339,155 @@ __global__ void __launch_bounds__(256) k_walksat_lds(PView pv, WsParams wp)
         a[v] = G.av[v] * (2.0f * bit - 1.0f);
     }
     for (int c = tid; c < m; c += nt) af[c] = G.af[c];
+    if (tid == 0) s_cnt = 0;
     __syncthreads();
-    for (int c = tid; c < m; c += nt) {          // number of active variables per clause: constant during the search
-        float deg = 0.0f;
-        for (int k = f_ptr[c]; k < f_ptr[c + 1]; ++k) deg = deg + (0.0f + av[pvv[e2p[k]] & 0x3fff]);
-        degc[c] = deg;
-    }
-    const int cap = wp.cap_b ? wp.cap_b[G.b] : wp.steps_cap;
-    int first_sat = cap;
-    for (int it = 0; it < cap; ++it) {
+    // ---- full evaluation once (the reference's per-step formulas) --------------------------------------------------------
+    int dup_any = 0;                                  // some variable occurs twice in one clause (not in loader output; handled anyway)
+    {
         int cnt = 0;
         for (int c = tid; c < m; c += nt) {
-            float agg = 0.0f;
+            float deg = 0.0f, agg = 0.0f;
             for (int k = f_ptr[c]; k < f_ptr[c + 1]; ++k) {
                 const uint16_t pw = pvv[e2p[k]];
                 const int v = pw & 0x3fff;
+                deg = deg + (0.0f + av[v]);
                 agg = agg + (0.0f + ((pw & 0x8000) ? -1.0f : 1.0f) * (a[v] * av[v]));
+                for (int k2 = f_ptr[c]; k2 < k; ++k2) if ((pvv[e2p[k2]] & 0x3fff) == v) dup_any = 1;
             }
-            aggc[c] = agg;
-            const float u = ((agg == -degc[c]) ? 1.0f : 0.0f) * af[c];
+            degc[c] = deg; aggc[c] = agg;
+            const float u = ((agg == -deg) ? 1.0f : 0.0f) * af[c];
             unsat[c] = (u == 1.0f) ? 1 : 0;
             cnt += unsat[c];
         }
         cnt = block_reduce(cnt, OpAddI(), 0, redi);
-        cnt = __builtin_amdgcn_readfirstlane(cnt);
-        if (cnt == 0) { first_sat = it; break; }
-        int has_zero = 0;
+        dup_any = __syncthreads_or(dup_any);
+        if (tid == 0) s_cnt = cnt;
         for (int v = tid; v < n; v += nt) {
             const float dist_v = a[v] * av[v];
-            float delta = 0.0f, acc = 0.0f;
+            float d = 0.0f, acc = 0.0f;
             for (int p = v_ptr[v]; p < v_ptr[v + 1]; ++p) {
                 const uint16_t cw = pcc[p];
                 const int c = cw & 0x3fff;
                 const float dist = 0.0f + ((pvv[p] & 0x8000) ? -1.0f : 1.0f) * dist_v;
                 const float others = (0.0f + aggc[c]) - dist;
                 const float critical = ((others == (1.0f - (0.0f + degc[c]))) ? 1.0f : 0.0f) * ((cw & 0x8000) ? 1.0f : 0.0f);
-                delta = delta + critical * dist;
+                d = d + critical * dist;
                 acc = acc + (float)unsat[c];
             }
-            acc = acc * av[v];
-            const float u = (wp.rng_mode == PDP_RNG_STREAM) ? wp.var_rand[(size_t)it * pv.V + G.v0 + v]
-                                                             : pdp_philox_uniform(wp.seed, PDP_RNG_STREAM_WSVAR, (uint32_t)it, (uint32_t)(G.v0 + v));
-            const float r = ((acc > 0.0f) ? 1.0f : 0.0f) * u;
-            negd[v] = -delta; uv[v] = r;
-            if (r == 0.0f) has_zero = 1;
-        }
-        __syncthreads();
-        has_zero = __syncthreads_or(has_zero);
-        Inst L = G;                                  // arg-max helpers only need n and the thread layout
-        const int greedy = d_instance_argmax(L, negd, 0.0f, redf, redi);
-        const int randi = d_instance_argmax(L, uv, 0.0f, redf, redi);
-        if (tid == 0) {
-            atomicOr(&wp.spec_used[it], 1u);
-            if (has_zero) atomicOr(&wp.spec_zero[it], 1u);
-            const float u = (wp.rng_mode == PDP_RNG_STREAM) ? wp.coin_rand[(size_t)it * pv.B + G.b]
-                                                             : pdp_philox_uniform(wp.seed, PDP_RNG_STREAM_WSCOIN, (uint32_t)it, (uint32_t)G.b);
-            const int ind = (u > wp.epsilon) ? greedy : randi;
-            if (ind >= 0) a[ind] = -a[ind];
+            delta[v] = (int)d; nuns[v] = (int)acc;           // exact: sums of at most deg(v) terms in {-1, 0, 1}
         }
         __syncthreads();
     }
+    const int cap = wp.cap_b ? wp.cap_b[G.b] : wp.steps_cap;
+    int first_sat = cap;
+    uint32_t used32 = 0, zero32 = 0;                            // thread 0: speculation bits of the current block of 32 steps
+    int it = 0;
+    WS_PROF_DECL
+    WS_PROF_MARK(0);
+    for (; it < cap; ++it) {
+        if (s_cnt == 0) { first_sat = it; break; }              // uniform: s_cnt is only written before a barrier
+        // ---- the two arg-maxes of the step (solver.py:452-458): one scan, DPP reductions per wave, thread 0 joins the waves ----
+        unsigned long long kg = 0ull, kr = 0ull; int has_zero = 0;
+        if (tid == nt - 1)                                       // the coin of the step, by a lane that is idle (or nearly so) in the scan
+            s_coin = (wp.rng_mode == PDP_RNG_STREAM) ? wp.coin_rand[(size_t)it * pv.B + G.b]
+                                                      : pdp_philox_uniform(wp.seed, PDP_RNG_STREAM_WSCOIN, (uint32_t)it, (uint32_t)G.b);
+        if (!(wp.debug_skip & 4))
+        for (int v = tid; v < n; v += nt) {
+            const float acc = (float)nuns[v] * av[v];
+            const float u = (wp.debug_skip & 2) ? 0.25f : ((wp.rng_mode == PDP_RNG_STREAM) ? wp.var_rand[(size_t)it * pv.V + G.v0 + v]
+                                                             : pdp_philox_uniform(wp.seed, PDP_RNG_STREAM_WSVAR, (uint32_t)it, (uint32_t)(G.v0 + v)));
+            const float r = ((acc > 0.0f) ? 1.0f : 0.0f) * u;
+            if (r == 0.0f) has_zero = 1;
+            const float tg = ((-(float)delta[v]) - 0.0f) + 1.0f, tr = (r - 0.0f) + 1.0f;      // util.sparse_argmax's x - min + 1 with min == 0
+            const unsigned long long k0 = ws_key(tg, v), k1 = ws_key(tr, v);
+            kg = k0 > kg ? k0 : kg; kr = k1 > kr ? k1 : kr;
+        }
+        WS_PROF_MARK(1);                                        // scan
+        kg = ws_wave_max(kg);
+        kr = ws_wave_max(kr);
+        has_zero = __builtin_amdgcn_ballot_w64(has_zero != 0) != 0 ? 1 : 0;
+        if (lane == 63) { s_keys[wid] = kg; s_keys[4 + wid] = kr; redi[wid] = has_zero; }
+        __syncthreads();
+        WS_PROF_MARK(2);                                        // wave reductions + barrier
+        if (tid == 0) {
+            unsigned long long bg = s_keys[0], br = s_keys[4]; has_zero = redi[0];
+            for (int k = 1; k < nw; ++k) { bg = s_keys[k] > bg ? s_keys[k] : bg; br = s_keys[4 + k] > br ? s_keys[4 + k] : br; has_zero |= redi[k]; }
+            const int bgi = ws_key_index(bg), bri = ws_key_index(br);
+            // one global atomic per step and workgroup on the same word serialises the whole batch: collect 32 steps per flush
+            used32 |= 1u << (it & 31);
+            if (has_zero) zero32 |= 1u << (it & 31);
+            if ((it & 31) == 31) {
+                atomicOr(&wp.spec_used[it >> 5], used32);
+                if (zero32) atomicOr(&wp.spec_zero[it >> 5], zero32);
+                used32 = 0; zero32 = 0;
+            }
+            const int ind = (s_coin > wp.epsilon) ? bgi : bri;
+            s_pick = ind;
+            if (ind >= 0) a[ind] = -a[ind];
+        }
+        __syncthreads();
+        WS_PROF_MARK(3);                                        // thread 0: join, coin, flip + barrier
+        // ---- carry the flip through the clauses of the picked variable ----------------------------------------------------------
+        const int f = s_pick;
+        if (f >= 0 && !(wp.debug_skip & 1)) {
+            const int pa = v_ptr[f], deg_f = v_ptr[f + 1] - pa;
+            const float a_new = a[f] * av[f];                 // 0 for an inactive variable: nothing changes then
+            for (int j = tid; j < deg_f; j += nt) {
+                const int p = pa + j;
+                const int c = pcc[p] & 0x3fff;
+                float sum_s = (pvv[p] & 0x8000) ? -1.0f : 1.0f; bool first = true;
+                if (dup_any) {                                   // f may occur more than once in a clause: handle the clause once
+                    sum_s = 0.0f;
+                    for (int p2 = pa; p2 < pa + deg_f; ++p2)
+                        if ((pcc[p2] & 0x3fff) == c) { if (p2 < p) first = false; sum_s += (pvv[p2] & 0x8000) ? -1.0f : 1.0f; }
+                }
+                if (!first || a_new == 0.0f) continue;
+                const float old_agg = aggc[c], new_agg = old_agg + 2.0f * sum_s * a_new;
+                const float target = 1.0f - (0.0f + degc[c]);
+                const int u_new = (((new_agg == -degc[c]) ? 1.0f : 0.0f) * af[c] == 1.0f) ? 1 : 0;
+                const int du = u_new - (int)unsat[c];
+                auto touch = [&](uint16_t pw, uint16_t cw, float au) {      // one literal of clause c: unsat count and contribution change
+                    const int u = pw & 0x3fff;
+                    if (du) atomicAdd(&nuns[u], du);
+                    if (!(cw & 0x8000)) return;                  // masked edge: contributes 0 before and after
+                    const float sg = (pw & 0x8000) ? -1.0f : 1.0f;
+                    const float dist_new = sg * au;
+                    const float dist_old = (u == f) ? -dist_new : dist_new;
+                    const float c_old = ((old_agg - dist_old) == target) ? dist_old : 0.0f;
+                    const float c_new = ((new_agg - dist_new) == target) ? dist_new : 0.0f;
+                    const int dd = (int)(c_new - c_old);
+                    if (dd) atomicAdd(&delta[u], dd);
+                };
+                const int k0 = f_ptr[c], klen = f_ptr[c + 1] - k0;
+                if (klen == 3) {                                 // the common case as straight-line code: three LDS levels instead of nine
+                    const int q0 = e2p[k0], q1 = e2p[k0 + 1], q2 = e2p[k0 + 2];
+                    const uint16_t w0 = pvv[q0], w1 = pvv[q1], w2 = pvv[q2], c0 = pcc[q0], c1 = pcc[q1], c2 = pcc[q2];
+                    const float a0 = a[w0 & 0x3fff] * av[w0 & 0x3fff], a1 = a[w1 & 0x3fff] * av[w1 & 0x3fff], a2 = a[w2 & 0x3fff] * av[w2 & 0x3fff];
+                    touch(w0, c0, a0); touch(w1, c1, a1); touch(w2, c2, a2);
+                } else {
+                    for (int k = k0; k < k0 + klen; ++k) {
+                        const int q = e2p[k];
+                        const uint16_t pw = pvv[q];
+                        touch(pw, pcc[q], a[pw & 0x3fff] * av[pw & 0x3fff]);
+                    }
+                }
+                aggc[c] = new_agg;
+                if (du) { unsat[c] = (uint8_t)u_new; atomicAdd(&s_cnt, du); }
+            }
+        }
+        __syncthreads();
+        WS_PROF_MARK(4);                                        // update pass + barrier
+    }
+    WS_PROF_FLUSH();
     for (int v = tid; v < n; v += nt) wp.out[G.v0 + v] = (a[v] + 1.0f) / 2.0f;
-    if (tid == 0) wp.first_sat[G.b] = first_sat;
+    if (tid == 0) {
+        wp.first_sat[G.b] = first_sat;
+        if (used32) {                                            // the steps of the last, partial block end at it - 1
+            const int w = (it - 1) >> 5;
+            atomicOr(&wp.spec_used[w], used32);
+            if (zero32) atomicOr(&wp.spec_zero[w], zero32);
+        }
+    }
 }
 
 __global__ void k_ws_group_stop(int B0, int R, int cap, const int32_t *first_sat, uint32_t *stop /*max over originals of min over replicas*/)
@@ -363,7 +513,8 @@ static int local_search_persistent(pdp_problem *p, const float *pred, int iterat
     *done = 0;
     const size_t lds = ws_lds_bytes(p->max_n, p->max_m, p->max_e);
     if (!p->fn_edges_identity || lds > 64 * 1024 || p->max_n >= 16384 || p->max_m >= 16384 || p->max_e >= 65535 || iterations <= 0) return PDP_OK;
-    const size_t words = 2 * (size_t)iterations + 4;
+    const size_t bw = ((size_t)iterations + 31) / 32;               // words per bit map
+    const size_t words = 2 * bw + 4;
     uint32_t *spec = nullptr;
     PDP_HIP_CHECK(hipMalloc((void **)&spec, words * 4 + (size_t)p->B * 4 * 3));
     int32_t *first_sat = (int32_t *)(spec + words), *cap_b = first_sat + p->B, *list = cap_b + p->B;
@@ -373,16 +524,19 @@ static int local_search_persistent(pdp_problem *p, const float *pred, int iterat
     p->has_edge_mask = 1;
     WsParams wp;
     wp.pred = pred; wp.out = out; wp.steps_cap = iterations; wp.epsilon = epsilon; wp.rng_mode = rng_mode; wp.var_rand = var_rand;
-    wp.coin_rand = coin_rand; wp.seed = seed; wp.first_sat = first_sat; wp.spec_used = spec; wp.spec_zero = spec + iterations;
+    wp.coin_rand = coin_rand; wp.seed = seed; wp.first_sat = first_sat; wp.spec_used = spec; wp.spec_zero = spec + bw;
     wp.inst_list = nullptr; wp.cap_b = nullptr;
-    hipLaunchKernelGGL(k_walksat_lds, dim3(p->B), dim3(256), lds, st, make_view(p), wp);
+    wp.debug_skip = getenv("PDP_WS_DEBUG_SKIP") ? atoi(getenv("PDP_WS_DEBUG_SKIP")) : 0;
+    int ws_nt = 256;
+    if (const char *env = getenv("PDP_WALKSAT_THREADS")) { const int v = atoi(env); if (v == 64 || v == 128 || v == 256) ws_nt = v; }
+    hipLaunchKernelGGL(k_walksat_lds, dim3(p->B), dim3(ws_nt), lds, st, make_view(p), wp);
     PDP_LAUNCH_CHECK();
-    uint32_t *ctl = spec + 2 * (size_t)iterations;       // [0] global stop step, [1] replay count
+    uint32_t *ctl = spec + 2 * bw;                       // [0] global stop step, [1] replay count
     hipLaunchKernelGGL(k_ws_group_stop, dim3((p->B0 + 255) / 256), dim3(256), 0, st, p->B0, p->R, iterations, first_sat, ctl);
     uint32_t *host = (uint32_t *)malloc(words * 4);
     PDP_HIP_CHECK(hipMemcpyAsync(host, spec, words * 4, hipMemcpyDeviceToHost, st));
     PDP_HIP_CHECK(hipStreamSynchronize(st));
-    const int stop = (int)host[2 * (size_t)iterations];
+    const int stop = (int)host[2 * bw];
     int status = PDP_OK;
     if (p->R > 1 && stop < iterations) {
         // replicas that were still searching at the global stop step must be truncated there (solver.py:446-449)
@@ -392,7 +546,7 @@ static int local_search_persistent(pdp_problem *p, const float *pred, int iterat
         PDP_HIP_CHECK(hipStreamSynchronize(st));
         if (cnt) {
             wp.inst_list = list; wp.cap_b = cap_b;
-            hipLaunchKernelGGL(k_walksat_lds, dim3(cnt), dim3(256), lds, st, make_view(p), wp);
+            hipLaunchKernelGGL(k_walksat_lds, dim3(cnt), dim3(ws_nt), lds, st, make_view(p), wp);
             PDP_HIP_CHECK(hipStreamSynchronize(st));
         }
     }
@@ -406,7 +560,8 @@ static int local_search_persistent(pdp_problem *p, const float *pred, int iterat
         for (int b = 0; b < p->B; ++b) first_finish = fs_host[b] < first_finish ? fs_host[b] : first_finish;
         free(fs_host);
     }
-    for (int t = 0; t < stop && t < first_finish && ok; ++t) if (host[t] && !host[iterations + t]) ok = false;
+    for (int t = 0; t < stop && t < first_finish && ok; ++t)
+        if (((host[t >> 5] >> (t & 31)) & 1u) && !((host[bw + (t >> 5)] >> (t & 31)) & 1u)) ok = false;
     free(host);
     (void)hipFree(spec);
     if (status != PDP_OK) return status;
