@@ -234,7 +234,6 @@ struct WsParams {
     uint32_t *spec_used, *spec_zero;   // bit maps [(steps + 31) / 32]: any unsat instance evaluated the arg-max / an exact zero existed
     const int32_t *inst_list;  // replay subset or NULL
     const int32_t *cap_b;      // per-instance step cap (replication replay) or NULL
-    int debug_skip;            // timing experiments only (PDP_WS_DEBUG_SKIP): 1 skip the update pass, 2 constant random numbers, 4 skip the arg-max scan
 };
 
 static size_t ws_lds_bytes(int n, int m, int e)
@@ -311,7 +310,7 @@ __global__ void __launch_bounds__(256) k_walksat_lds(PView pv, WsParams wp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DECL_RED
-    __shared__ int s_cnt, s_pick;
+    __shared__ int s_cnt;
     __shared__ float s_coin;
     __shared__ unsigned long long s_keys[8];         // per-wave maxima of the two arg-max keys (at most 4 waves)
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -319,7 +318,8 @@ __global__ void __launch_bounds__(256) k_walksat_lds(PView pv, WsParams wp)
     const Inst G = load_inst(pv, wp.inst_list ? wp.inst_list[blockIdx.x] : (int)blockIdx.x);
     const int n = G.n, m = G.m, ne = G.e;
     unsigned char *cp = smem;
-    uint16_t *pvv = ws_carve<uint16_t>(cp, ne), *pcc = ws_carve<uint16_t>(cp, ne), *e2p = ws_carve<uint16_t>(cp, ne);
+    // by-variable slots: pvv = variable | sign << 15, pcc = clause | edge mask << 15;  by-clause edges: cl = variable | mask << 14 | sign << 15
+    uint16_t *pvv = ws_carve<uint16_t>(cp, ne), *pcc = ws_carve<uint16_t>(cp, ne), *cl = ws_carve<uint16_t>(cp, ne);
     uint16_t *v_ptr = ws_carve<uint16_t>(cp, n + 1), *f_ptr = ws_carve<uint16_t>(cp, m + 1);
     float *av = ws_carve<float>(cp, n), *a = ws_carve<float>(cp, n);
     int *delta = ws_carve<int>(cp, n), *nuns = ws_carve<int>(cp, n);
@@ -327,9 +327,10 @@ __global__ void __launch_bounds__(256) k_walksat_lds(PView pv, WsParams wp)
     uint8_t *unsat = ws_carve<uint8_t>(cp, m);
     for (int p = tid; p < ne; p += nt) {
         const int e = G.v_edges[p];
-        pvv[p] = (uint16_t)(G.e_var[e] | (G.sgn[e] < 0 ? 0x8000 : 0));
-        pcc[p] = (uint16_t)(G.e_fn[e] | ((G.emask[e] == 1.0f) ? 0x8000 : 0));
-        e2p[e] = (uint16_t)p;
+        const bool em = G.emask[e] == 1.0f, neg = G.sgn[e] < 0;
+        pvv[p] = (uint16_t)(G.e_var[e] | (neg ? 0x8000 : 0));
+        pcc[p] = (uint16_t)(G.e_fn[e] | (em ? 0x8000 : 0));
+        cl[e] = (uint16_t)(G.e_var[e] | (em ? 0x4000 : 0) | (neg ? 0x8000 : 0));      // edges are clause-major: edge id == position in the clause list
     }
     for (int v = tid; v <= n; v += nt) v_ptr[v] = (uint16_t)G.v_ptr[v];
     for (int c = tid; c <= m; c += nt) f_ptr[c] = (uint16_t)G.f_ptr[c];
@@ -348,11 +349,11 @@ __global__ void __launch_bounds__(256) k_walksat_lds(PView pv, WsParams wp)
         for (int c = tid; c < m; c += nt) {
             float deg = 0.0f, agg = 0.0f;
             for (int k = f_ptr[c]; k < f_ptr[c + 1]; ++k) {
-                const uint16_t pw = pvv[e2p[k]];
-                const int v = pw & 0x3fff;
+                const uint16_t w = cl[k];
+                const int v = w & 0x3fff;
                 deg = deg + (0.0f + av[v]);
-                agg = agg + (0.0f + ((pw & 0x8000) ? -1.0f : 1.0f) * (a[v] * av[v]));
-                for (int k2 = f_ptr[c]; k2 < k; ++k2) if ((pvv[e2p[k2]] & 0x3fff) == v) dup_any = 1;
+                agg = agg + (0.0f + ((w & 0x8000) ? -1.0f : 1.0f) * (a[v] * av[v]));
+                for (int k2 = f_ptr[c]; k2 < k; ++k2) if ((cl[k2] & 0x3fff) == v) dup_any = 1;
             }
             degc[c] = deg; aggc[c] = agg;
             const float u = ((agg == -deg) ? 1.0f : 0.0f) * af[c];
@@ -379,23 +380,33 @@ __global__ void __launch_bounds__(256) k_walksat_lds(PView pv, WsParams wp)
         __syncthreads();
     }
     const int cap = wp.cap_b ? wp.cap_b[G.b] : wp.steps_cap;
+    auto var_rand = [&](int step, int v) -> float {
+        return (wp.rng_mode == PDP_RNG_STREAM) ? wp.var_rand[(size_t)step * pv.V + G.v0 + v]
+                                               : pdp_philox_uniform(wp.seed, PDP_RNG_STREAM_WSVAR, (uint32_t)step, (uint32_t)(G.v0 + v));
+    };
+    auto coin_rand = [&](int step) -> float {
+        return (wp.rng_mode == PDP_RNG_STREAM) ? wp.coin_rand[(size_t)step * pv.B + G.b]
+                                               : pdp_philox_uniform(wp.seed, PDP_RNG_STREAM_WSCOIN, (uint32_t)step, (uint32_t)G.b);
+    };
     int first_sat = cap;
     uint32_t used32 = 0, zero32 = 0;                            // thread 0: speculation bits of the current block of 32 steps
+    // the random numbers of a step are fetched one step ahead (first variable of every thread, and the coin by the last thread)
+    float u_pref = (tid < n && cap > 0) ? var_rand(0, tid) : 0.0f;
+    float coin_pref = (tid == nt - 1 && cap > 0) ? coin_rand(0) : 0.0f;
     int it = 0;
     WS_PROF_DECL
     WS_PROF_MARK(0);
+    int pending = -1;                                           // variable picked in the previous step whose a[] entry is not flipped yet
     for (; it < cap; ++it) {
         if (s_cnt == 0) { first_sat = it; break; }              // uniform: s_cnt is only written before a barrier
-        // ---- the two arg-maxes of the step (solver.py:452-458): one scan, DPP reductions per wave, thread 0 joins the waves ----
+        if (tid == 0 && pending >= 0) a[pending] = -a[pending];
+        pending = -1;
+        // ---- the two arg-maxes of the step (solver.py:452-458): one scan, DPP maxima per wave, every lane joins the waves ------
         unsigned long long kg = 0ull, kr = 0ull; int has_zero = 0;
-        if (tid == nt - 1)                                       // the coin of the step, by a lane that is idle (or nearly so) in the scan
-            s_coin = (wp.rng_mode == PDP_RNG_STREAM) ? wp.coin_rand[(size_t)it * pv.B + G.b]
-                                                      : pdp_philox_uniform(wp.seed, PDP_RNG_STREAM_WSCOIN, (uint32_t)it, (uint32_t)G.b);
-        if (!(wp.debug_skip & 4))
+        if (tid == nt - 1) s_coin = coin_pref;
         for (int v = tid; v < n; v += nt) {
             const float acc = (float)nuns[v] * av[v];
-            const float u = (wp.debug_skip & 2) ? 0.25f : ((wp.rng_mode == PDP_RNG_STREAM) ? wp.var_rand[(size_t)it * pv.V + G.v0 + v]
-                                                             : pdp_philox_uniform(wp.seed, PDP_RNG_STREAM_WSVAR, (uint32_t)it, (uint32_t)(G.v0 + v)));
+            const float u = (v == tid) ? u_pref : var_rand(it, v);
             const float r = ((acc > 0.0f) ? 1.0f : 0.0f) * u;
             if (r == 0.0f) has_zero = 1;
             const float tg = ((-(float)delta[v]) - 0.0f) + 1.0f, tr = (r - 0.0f) + 1.0f;      // util.sparse_argmax's x - min + 1 with min == 0
@@ -408,11 +419,11 @@ __global__ void __launch_bounds__(256) k_walksat_lds(PView pv, WsParams wp)
         has_zero = __builtin_amdgcn_ballot_w64(has_zero != 0) != 0 ? 1 : 0;
         if (lane == 63) { s_keys[wid] = kg; s_keys[4 + wid] = kr; redi[wid] = has_zero; }
         __syncthreads();
-        WS_PROF_MARK(2);                                        // wave reductions + barrier
+        WS_PROF_MARK(2);                                        // wave maxima + barrier
+        unsigned long long bg = s_keys[0], br = s_keys[4]; has_zero = redi[0];
+        for (int k = 1; k < nw; ++k) { bg = s_keys[k] > bg ? s_keys[k] : bg; br = s_keys[4 + k] > br ? s_keys[4 + k] : br; has_zero |= redi[k]; }
+        const int f = (s_coin > wp.epsilon) ? ws_key_index(bg) : ws_key_index(br);        // identical on every lane
         if (tid == 0) {
-            unsigned long long bg = s_keys[0], br = s_keys[4]; has_zero = redi[0];
-            for (int k = 1; k < nw; ++k) { bg = s_keys[k] > bg ? s_keys[k] : bg; br = s_keys[4 + k] > br ? s_keys[4 + k] : br; has_zero |= redi[k]; }
-            const int bgi = ws_key_index(bg), bri = ws_key_index(br);
             // one global atomic per step and workgroup on the same word serialises the whole batch: collect 32 steps per flush
             used32 |= 1u << (it & 31);
             if (has_zero) zero32 |= 1u << (it & 31);
@@ -421,17 +432,16 @@ __global__ void __launch_bounds__(256) k_walksat_lds(PView pv, WsParams wp)
                 if (zero32) atomicOr(&wp.spec_zero[it >> 5], zero32);
                 used32 = 0; zero32 = 0;
             }
-            const int ind = (s_coin > wp.epsilon) ? bgi : bri;
-            s_pick = ind;
-            if (ind >= 0) a[ind] = -a[ind];
         }
-        __syncthreads();
-        WS_PROF_MARK(3);                                        // thread 0: join, coin, flip + barrier
-        // ---- carry the flip through the clauses of the picked variable ----------------------------------------------------------
-        const int f = s_pick;
-        if (f >= 0 && !(wp.debug_skip & 1)) {
+        if (it + 1 < cap) {                                     // next step's random numbers: in flight during the update pass
+            if (tid < n) u_pref = var_rand(it + 1, tid);
+            if (tid == nt - 1) coin_pref = coin_rand(it + 1);
+        }
+        WS_PROF_MARK(3);                                        // join + prefetch
+        // ---- flip f and carry the change through its clauses ---------------------------------------------------------------------
+        if (f >= 0) {
             const int pa = v_ptr[f], deg_f = v_ptr[f + 1] - pa;
-            const float a_new = a[f] * av[f];                 // 0 for an inactive variable: nothing changes then
+            const float a_new = -a[f] * av[f];                // 0 for an inactive variable: nothing changes then
             for (int j = tid; j < deg_f; j += nt) {
                 const int p = pa + j;
                 const int c = pcc[p] & 0x3fff;
@@ -446,12 +456,12 @@ __global__ void __launch_bounds__(256) k_walksat_lds(PView pv, WsParams wp)
                 const float target = 1.0f - (0.0f + degc[c]);
                 const int u_new = (((new_agg == -degc[c]) ? 1.0f : 0.0f) * af[c] == 1.0f) ? 1 : 0;
                 const int du = u_new - (int)unsat[c];
-                auto touch = [&](uint16_t pw, uint16_t cw, float au) {      // one literal of clause c: unsat count and contribution change
-                    const int u = pw & 0x3fff;
+                auto touch = [&](uint16_t w) {                   // one literal of clause c: unsat count and contribution change
+                    const int u = w & 0x3fff;
                     if (du) atomicAdd(&nuns[u], du);
-                    if (!(cw & 0x8000)) return;                  // masked edge: contributes 0 before and after
-                    const float sg = (pw & 0x8000) ? -1.0f : 1.0f;
-                    const float dist_new = sg * au;
+                    if (!(w & 0x4000)) return;                   // masked edge: contributes 0 before and after
+                    const float sg = (w & 0x8000) ? -1.0f : 1.0f;
+                    const float dist_new = sg * ((u == f) ? a_new : a[u] * av[u]);      // a[f] itself is written at the end of the pass
                     const float dist_old = (u == f) ? -dist_new : dist_new;
                     const float c_old = ((old_agg - dist_old) == target) ? dist_old : 0.0f;
                     const float c_new = ((new_agg - dist_new) == target) ? dist_new : 0.0f;
@@ -459,26 +469,19 @@ __global__ void __launch_bounds__(256) k_walksat_lds(PView pv, WsParams wp)
                     if (dd) atomicAdd(&delta[u], dd);
                 };
                 const int k0 = f_ptr[c], klen = f_ptr[c + 1] - k0;
-                if (klen == 3) {                                 // the common case as straight-line code: three LDS levels instead of nine
-                    const int q0 = e2p[k0], q1 = e2p[k0 + 1], q2 = e2p[k0 + 2];
-                    const uint16_t w0 = pvv[q0], w1 = pvv[q1], w2 = pvv[q2], c0 = pcc[q0], c1 = pcc[q1], c2 = pcc[q2];
-                    const float a0 = a[w0 & 0x3fff] * av[w0 & 0x3fff], a1 = a[w1 & 0x3fff] * av[w1 & 0x3fff], a2 = a[w2 & 0x3fff] * av[w2 & 0x3fff];
-                    touch(w0, c0, a0); touch(w1, c1, a1); touch(w2, c2, a2);
-                } else {
-                    for (int k = k0; k < k0 + klen; ++k) {
-                        const int q = e2p[k];
-                        const uint16_t pw = pvv[q];
-                        touch(pw, pcc[q], a[pw & 0x3fff] * av[pw & 0x3fff]);
-                    }
-                }
+                if (klen == 3) { const uint16_t w0 = cl[k0], w1 = cl[k0 + 1], w2 = cl[k0 + 2]; touch(w0); touch(w1); touch(w2); }
+                else for (int k = k0; k < k0 + klen; ++k) touch(cl[k]);
                 aggc[c] = new_agg;
                 if (du) { unsat[c] = (uint8_t)u_new; atomicAdd(&s_cnt, du); }
             }
         }
+        pending = f;                                            // a[f] itself is flipped after the barrier: nobody reads `a` before the next one
         __syncthreads();
         WS_PROF_MARK(4);                                        // update pass + barrier
     }
     WS_PROF_FLUSH();
+    if (tid == 0 && pending >= 0) a[pending] = -a[pending];
+    __syncthreads();
     for (int v = tid; v < n; v += nt) wp.out[G.v0 + v] = (a[v] + 1.0f) / 2.0f;
     if (tid == 0) {
         wp.first_sat[G.b] = first_sat;
@@ -526,7 +529,6 @@ static int local_search_persistent(pdp_problem *p, const float *pred, int iterat
     wp.pred = pred; wp.out = out; wp.steps_cap = iterations; wp.epsilon = epsilon; wp.rng_mode = rng_mode; wp.var_rand = var_rand;
     wp.coin_rand = coin_rand; wp.seed = seed; wp.first_sat = first_sat; wp.spec_used = spec; wp.spec_zero = spec + bw;
     wp.inst_list = nullptr; wp.cap_b = nullptr;
-    wp.debug_skip = getenv("PDP_WS_DEBUG_SKIP") ? atoi(getenv("PDP_WS_DEBUG_SKIP")) : 0;
     int ws_nt = 256;
     if (const char *env = getenv("PDP_WALKSAT_THREADS")) { const int v = atoi(env); if (v == 64 || v == 128 || v == 256) ws_nt = v; }
     hipLaunchKernelGGL(k_walksat_lds, dim3(p->B), dim3(ws_nt), lds, st, make_view(p), wp);

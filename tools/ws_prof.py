@@ -19,7 +19,7 @@ for rep in range(2):
     res, st = prob.local_search(prob.solution.clone(), steps, 0.5, seed=999)
     t1.record(); torch.cuda.synchronize()
     L.pdp_debug_ws_cycles(out, 0)
-names = ['setup', 'scan', 'wave reduce + barrier', 'thread-0 join/coin/flip + barrier', 'update pass + barrier']
+names = ['setup', 'scan', 'wave maxima + barrier', 'join + random-number prefetch', 'update pass + barrier']
 tot = sum(out[i] for i in range(5))
 for i, nm in enumerate(names):
     print("%-36s %14d cycles %5.1f%%  (%.0f per instance-step)" % (nm, out[i], 100.0 * out[i] / tot, out[i] / (B * st)))
