@@ -586,6 +586,20 @@ __device__ __forceinline__ f2v log2_fin(f2v x, float eps)             // two-wid
     return r + (x - x);
 }
 
+// cross-lane helpers without the LDS crossbar (a __shfl is a ds_bpermute round trip of ~100 cycles):
+// OR of a 7-bit flag set over the wave, one ballot per bit; exchange with lane ^ 1 through a DPP quad permute.
+__device__ __forceinline__ int wave_or_bits7(int bits)
+{
+    int r = 0;
+#pragma unroll
+    for (int b = 0; b < 7; ++b) r |= (__builtin_amdgcn_ballot_w64((bits >> b) & 1) != 0ull) ? (1 << b) : 0;
+    return r;
+}
+__device__ __forceinline__ float lane_xor1(float x)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, true));
+}
+
 // select-free decoding of the packed slot words (a v_cmp + v_cndmask pair costs ~4 FMAs on gfx950)
 __device__ __forceinline__ float slot_sign(uint16_t pw) { return __uint_as_float(0x3f800000u | ((uint32_t)(pw & 0x8000u) << 16)); }      // bit 15 set: -1, else +1
 __device__ __forceinline__ float bit15_to_float(uint16_t w)          // bit 15 set: 1, else 0
@@ -1028,8 +1042,8 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
                 } else {
                     for (int p = lo; p < hi; ++p) emax = fmaxf(emax, Enew[p]);
                 }
-                emax = fmaxf(emax, __shfl_xor(emax, 1, 64));
-                S1 += __shfl_xor(S1, 1, 64); S2 += __shfl_xor(S2, 1, 64); D = fmaxf(D, __shfl_xor(D, 1, 64));
+                emax = fmaxf(emax, lane_xor1(emax));
+                S1 += lane_xor1(S1); S2 += lane_xor1(S2); D = fmaxf(D, lane_xor1(D));
                 const float a_v = av[v];
                 const float deg = (float)(bnd - a);
                 if (a_v == 0.0f || !(emax > 0.0f)) bits |= 1;
@@ -1054,8 +1068,7 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
         }
         PROF_MARK(4);                                        // P4
         // ---- P5: one fused workgroup reduction of the flag bits ------------------------------------------------------------
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) bits |= __shfl_down(bits, off, 64);
+        bits = wave_or_bits7(bits);
         if (lane == 0) redi[wid] = bits;
         __syncthreads();
         bits = 0;
@@ -1082,8 +1095,7 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
                     if (!((((rr - 0.0f) + 1.0f) + 0.0f) - 1.0f < tol)) b2 |= 16;
                 }
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) b2 |= __shfl_down(b2, off, 64);
+            b2 = wave_or_bits7(b2);
             if (lane == 0) redi[wid] = b2;
             __syncthreads();
             b2 = 0;
