@@ -177,11 +177,28 @@ __host__ __device__ __forceinline__ float pdp_dec_ordered(uint32_t k)
 // All take a small LDS scratch array (>= 2 * nwaves entries of the payload type) and must be called by
 // every thread of the workgroup.  They end with a barrier, so the scratch can be reused immediately.
 
-template <typename T, typename Op>
-__device__ __forceinline__ T wave_reduce(T v, Op op)
+// Wave-level reduction with DPP moves (a __shfl_down is a ds_bpermute: an LDS round trip per step): Hillis-Steele steps inside the
+// 16-lane rows, then the lane-15 / lane-31 broadcasts.  The total ends up in LANE 63.  T is a 32-bit type.
+template <int CTRL, int ROW_MASK, typename T, typename Op>
+__device__ __forceinline__ T wave_dpp_step(T v, Op op, T identity)
 {
-#pragma unroll
-    for (int off = PDP_WAVE / 2; off > 0; off >>= 1) v = op(v, __shfl_down(v, off, PDP_WAVE));
+    static_assert(sizeof(T) == 4, "32-bit types only");
+    int vi, idi;
+    __builtin_memcpy(&vi, &v, 4); __builtin_memcpy(&idi, &identity, 4);
+    const int oi = __builtin_amdgcn_update_dpp(idi, vi, CTRL, ROW_MASK, 0xf, false);      // lanes without a source see the identity
+    T o;
+    __builtin_memcpy(&o, &oi, 4);
+    return op(v, o);
+}
+template <typename T, typename Op>
+__device__ __forceinline__ T wave_reduce(T v, Op op, T identity)
+{
+    v = wave_dpp_step<0x111, 0xf>(v, op, identity);      // row_shr:1
+    v = wave_dpp_step<0x112, 0xf>(v, op, identity);      // row_shr:2
+    v = wave_dpp_step<0x114, 0xf>(v, op, identity);      // row_shr:4
+    v = wave_dpp_step<0x118, 0xf>(v, op, identity);      // row_shr:8
+    v = wave_dpp_step<0x142, 0xa>(v, op, identity);      // row_bcast:15
+    v = wave_dpp_step<0x143, 0xc>(v, op, identity);      // row_bcast:31
     return v;
 }
 
@@ -190,8 +207,8 @@ __device__ __forceinline__ T block_reduce(T v, Op op, T identity, T *scratch)
 {
     const int lane = threadIdx.x & (PDP_WAVE - 1), wid = threadIdx.x / PDP_WAVE;
     const int nw = (blockDim.x + PDP_WAVE - 1) / PDP_WAVE;
-    v = wave_reduce(v, op);
-    if (lane == 0) scratch[wid] = v;
+    v = wave_reduce(v, op, identity);
+    if (lane == PDP_WAVE - 1) scratch[wid] = v;
     __syncthreads();
     T r = identity;
     for (int i = 0; i < nw; ++i) r = op(r, scratch[i]);
@@ -216,17 +233,20 @@ __device__ __forceinline__ bool arg_better(float av, int ai, float bv, int bi)
     if (av < bv) return false;
     return ai < bi;
 }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void argmax_dpp_step(float &v, int &i)
+{
+    const int ov = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    const int oi = __builtin_amdgcn_update_dpp(-1, i, CTRL, ROW_MASK, 0xf, false);          // lanes without a source see index -1: never better
+    if (arg_better(__int_as_float(ov), oi, v, i)) { v = __int_as_float(ov); i = oi; }
+}
 __device__ __forceinline__ ArgPair block_argmax(float v, int i, float *sv, int *si)
 {
     const int lane = threadIdx.x & (PDP_WAVE - 1), wid = threadIdx.x / PDP_WAVE;
     const int nw = (blockDim.x + PDP_WAVE - 1) / PDP_WAVE;
-#pragma unroll
-    for (int off = PDP_WAVE / 2; off > 0; off >>= 1) {
-        const float ov = __shfl_down(v, off, PDP_WAVE);
-        const int oi = __shfl_down(i, off, PDP_WAVE);
-        if (arg_better(ov, oi, v, i)) { v = ov; i = oi; }
-    }
-    if (lane == 0) { sv[wid] = v; si[wid] = i; }
+    argmax_dpp_step<0x111, 0xf>(v, i); argmax_dpp_step<0x112, 0xf>(v, i); argmax_dpp_step<0x114, 0xf>(v, i);
+    argmax_dpp_step<0x118, 0xf>(v, i); argmax_dpp_step<0x142, 0xa>(v, i); argmax_dpp_step<0x143, 0xc>(v, i);     // total in lane 63
+    if (lane == PDP_WAVE - 1) { sv[wid] = v; si[wid] = i; }
     __syncthreads();
     ArgPair r; r.v = sv[0]; r.i = si[0];
     for (int k = 1; k < nw; ++k) if (arg_better(sv[k], si[k], r.v, r.i)) { r.v = sv[k]; r.i = si[k]; }
