@@ -627,26 +627,63 @@ __device__ __noinline__ int lds_decimate(unsigned char *smem, int b, int n, int 
     for (int p = tid; p < ne; p += nt)
         L.Y[p] = pdp_safe_log_fin(1.0f - Enew[p], PDP_SCORER_EPS) * (0.0f + L.af[L.pcc[p] & 0x3fff]);   // surveys are finite or NaN
     __syncthreads();
-    int z3 = 0, anynz = 0, cn = 0;
-    for (int v = tid; v < n; v += nt) {
+    // SurveyScorer tail (pdp_predict.py:174-192) with the select-free math forms: same values as d_score_from_sums (every argument
+    // here is finite or NaN); the three log terms of the external force take two possible values
+    const float Lpi = pdp_safe_log(1.0f - pi, PDP_SCORER_EPS), L0 = pdp_safe_log(1.0f - pi * 0.0f, PDP_SCORER_EPS);
+    auto score_of = [&](float pos, float neg, float all, float ext_sum) {
+        const float ef = pdp_sign(ext_sum);
+        float ps = pos + ((ef == 1.0f) ? Lpi : L0);
+        float ng = neg + ((ef == -1.0f) ? Lpi : L0);
+        float pns = ps + ng;
+        float dc = all + Lpi;
+        const float bias = (2.0f * pns + dc) / 4.0f;
+        ps = ps - bias; ng = ng - bias; pns = pns - bias;
+        const f4v ex = exp4_fin_le30((f4v){pdp_min_c(dc - bias, 30.0f), pdp_min_c(ps, 30.0f), pdp_min_c(ng, 30.0f), pdp_min_c(pns, 30.0f)});
+        dc = ex.x;
+        const float q0 = ex.y - ex.w;
+        const float q1 = ex.z - ex.w;
+        const float total = pdp_safe_log_fin((q0 + q1) + dc, PDP_SCORER_EPS);
+        const float l1 = pdp_safe_log_fin(q1, PDP_SCORER_EPS), l0 = pdp_safe_log_fin(q0, PDP_SCORER_EPS);
+        return pdp_expf_fin_le30(pdp_min_c(l1 - total, 30.0f)) - pdp_expf_fin_le30(pdp_min_c(l0 - total, 30.0f));
+    };
+    int flags = 0;                                   // 1: a coefficient is exactly 0, 2: some coefficient is non-zero, 4: NaN coefficient
+    for (int i = tid; i < n; i += nt) {
+        const int v = L.vord[i];                     // degree-sorted: the lanes of a wave run loops of similar length
         float ext = 0.0f, pos = 0.0f, neg = 0.0f, all = 0.0f;
-        for (int p = L.v_ptr[v]; p < L.v_ptr[v + 1]; ++p) {
-            const float f = L.Y[p];
-            const bool ng = (L.pvv[p] & 0x8000) != 0;
-            ext = ext + (FORCE ? L.FRC[p] : 0.0f);
+        auto acc = [&](float f, uint16_t pw, float frc) {
+            const bool ng = (pw & 0x8000) != 0;
+            ext = ext + frc;
             pos = pos + (ng ? 0.0f : 1.0f) * f;
             neg = neg + (ng ? 1.0f : 0.0f) * f;
             all = all + f;
+        };
+        int p = L.v_ptr[v];
+        const int bnd = L.v_ptr[v + 1];
+        for (; p + 7 < bnd; p += 8) {                // all loads of a batch first: one LDS round trip per eight edges
+            float f[8], fr[8]; uint16_t pw[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { f[j] = L.Y[p + j]; pw[j] = L.pvv[p + j]; fr[j] = FORCE ? L.FRC[p + j] : 0.0f; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc(f[j], pw[j], fr[j]);
         }
-        const float sc = d_score_from_sums(pos, neg, all, ext, pi);
+        for (; p + 3 < bnd; p += 4) {
+            float f[4], fr[4]; uint16_t pw[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { f[j] = L.Y[p + j]; pw[j] = L.pvv[p + j]; fr[j] = FORCE ? L.FRC[p + j] : 0.0f; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc(f[j], pw[j], fr[j]);
+        }
+        for (; p < bnd; ++p) acc(L.Y[p], L.pvv[p], FORCE ? L.FRC[p] : 0.0f);
+        const float sc = score_of(pos, neg, all, ext);
         const float co = (pdp_abs(sc) * L.av[v]) * 1.0f;
         score[v] = sc; L.coeff[v] = co;
-        if (co == 0.0f) z3 = 1;
-        if (co != 0.0f) anynz = 1;
-        if (co != co) cn = 1;
+        L.flag_v[v] = 0;                             // candidate marks of the neighbourhood path below
+        if (co == 0.0f) flags |= 1;
+        if (co != 0.0f) flags |= 2;
+        if (co != co) flags |= 4;
     }
-    __syncthreads();
-    z3 = __syncthreads_or(z3); anynz = __syncthreads_or(anynz); cn = __syncthreads_or(cn);
+    flags = block_reduce(flags, OpOrI(), 0, redi2);    // (its barriers also publish score / coeff)
+    const int z3 = flags & 1, anynz = (flags >> 1) & 1, cn = (flags >> 2) & 1;
     *spec = (z3 ? 1 : 0) | (cn ? 2 : 0);
     const int li = d_instance_argmax(I, L.coeff, 0.0f, redf2, redi2);
     if (!(active && anynz && !cn && li >= 0)) return 0;
@@ -692,8 +729,6 @@ __device__ __noinline__ int lds_decimate(unsigned char *smem, int b, int n, int 
     if (*verified == 1) {
         const int a = L.v_ptr[li], deg_li = L.v_ptr[li + 1] - a;
         const bool neg_li = sgn_li < 0.0f;
-        for (int v = tid; v < n; v += nt) L.flag_v[v] = 0;
-        __syncthreads();
         // _set_variable_core for a one-hot assignment: a clause is switched off iff one of its literals of `li` is satisfied
         for (int j = tid; j < deg_li; j += nt) {
             const int p = a + j;
@@ -718,11 +753,7 @@ __device__ __noinline__ int lds_decimate(unsigned char *smem, int b, int n, int 
                 if (deg == 1.0f) single = 1;
             }
         }
-        if (__syncthreads_or(single)) {
-            d_simplify(I, ss, is_sat_b);
-            return 1;
-        }
-        int pure = 0;
+        int pure = 0;                                       // (both scans only read the state step 1 left: one reduction for the two)
         for (int v = tid; v < n; v += nt) {
             if (L.flag_v[v]) {
                 int d = 0, sd = 0;
@@ -738,7 +769,9 @@ __device__ __noinline__ int lds_decimate(unsigned char *smem, int b, int n, int 
                 if (d == (sd < 0 ? -sd : sd)) pure = 1;
             }
         }
-        if (__syncthreads_or(pure)) d_peel(I, ss);
+        const int found = block_reduce((single ? 1 : 0) | (pure ? 2 : 0), OpOrI(), 0, redi2);
+        if (found & 1) d_simplify(I, ss, is_sat_b);         // a unit clause: the general routines redo the reference's sweeps
+        else if (found & 2) d_peel(I, ss);
         return 1;
     }
 
