@@ -254,5 +254,51 @@ __device__ __forceinline__ ArgPair block_argmax(float v, int i, float *sv, int *
     return r;
 }
 
+// arg-max of (value, index) pairs as the maximum of 64-bit keys: order-preserving bits of the (non-NaN) value on top, inverted
+// index below, so the larger value wins and the first index wins ties (util.sparse_argmax); 0 = "no candidate".
+__device__ __forceinline__ unsigned long long argkey(float t, int v)
+{
+    const uint32_t b = __float_as_uint(t);
+    const uint32_t ord = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    return ((unsigned long long)ord << 32) | (uint32_t)(0xffffffffu - (uint32_t)v);
+}
+__device__ __forceinline__ int argkey_index(unsigned long long k) { return k ? (int)(0xffffffffu - (uint32_t)k) : -1; }
+
+// wave-level maximum with DPP moves (a __shfl_down is an LDS round trip of ~100 cycles, a DPP move a few): Hillis-Steele steps
+// inside the 16-lane rows, then lane 15 / lane 31 broadcasts; the result is in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long k)
+{
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(k >> 32), CTRL, ROW_MASK, 0xf, false);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)k, CTRL, ROW_MASK, 0xf, false);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;      // lanes without a source see 0
+    return o > k ? o : k;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
+{
+    k = dpp_max_u64<0x111, 0xf>(k);      // row_shr:1
+    k = dpp_max_u64<0x112, 0xf>(k);      // row_shr:2
+    k = dpp_max_u64<0x114, 0xf>(k);      // row_shr:4
+    k = dpp_max_u64<0x118, 0xf>(k);      // row_shr:8   -> lane 15 of every row holds its row's maximum
+    k = dpp_max_u64<0x142, 0xa>(k);      // row_bcast:15 into rows 1 and 3
+    k = dpp_max_u64<0x143, 0xc>(k);      // row_bcast:31 into rows 2 and 3 -> lane 63
+    return k;
+}
+
+
+// block-wide arg-max through keys (values must not be NaN): every thread gets the winning key
+__device__ __forceinline__ unsigned long long block_max_u64(unsigned long long k, unsigned long long *scratch /*[>= waves]*/)
+{
+    const int lane = threadIdx.x & (PDP_WAVE - 1), wid = threadIdx.x / PDP_WAVE;
+    const int nw = (blockDim.x + PDP_WAVE - 1) / PDP_WAVE;
+    k = wave_max_u64(k);
+    if (lane == PDP_WAVE - 1) scratch[wid] = k;
+    __syncthreads();
+    unsigned long long r = scratch[0];
+    for (int i = 1; i < nw; ++i) r = scratch[i] > r ? scratch[i] : r;
+    __syncthreads();
+    return r;
+}
+
 // number of LDS scratch floats the primitives need
 #define PDP_RED_SCRATCH 64

@@ -471,7 +471,7 @@ __device__ __forceinline__ LView make_lview(const LdsArrays &L, int b, int n, in
 }
 #define UNI(x) __builtin_amdgcn_readfirstlane(x)
 #ifdef PDP_PHASE_PROF
-__device__ unsigned long long g_phase_cycles[16];
+__device__ unsigned long long g_phase_cycles[24];
 // per-phase sums stay in registers and are flushed once per launch: one atomic per phase and iteration from 5000 workgroups
 // onto the same 16 words more than doubled the kernel time
 #define PROF_DECL unsigned long long _t0 = __builtin_readcyclecounter(), _t1; uint32_t _acc[13] = {0};
@@ -479,18 +479,22 @@ __device__ unsigned long long g_phase_cycles[16];
 #define PROF_FLUSH() do { if (threadIdx.x == 0) { _Pragma("unroll") for (int _i = 0; _i < 13; ++_i) if (_acc[_i]) atomicAdd(&g_phase_cycles[_i], (unsigned long long)_acc[_i]); } } while (0)
 extern "C" int pdp_debug_phase_cycles(unsigned long long *out_host, int reset)
 {
-    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)) != hipSuccess) return 1; }
+    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 24) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[24] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)) != hipSuccess) return 1; }
     return 0;
 }
 #define PROF_COUNT(i) do { _acc[i] += 1u; } while (0)
 #define PROF_SKIP(bit) (sp.debug_skip & (bit))
+#define DEC_PROF_DECL unsigned long long _d0 = __builtin_readcyclecounter(), _d1;
+#define DEC_PROF_MARK(i) do { _d1 = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_phase_cycles[i], _d1 - _d0); _d0 = _d1; } while (0)
 #else
 #define PROF_DECL
 #define PROF_MARK(i)
 #define PROF_COUNT(i)
 #define PROF_FLUSH()
 #define PROF_SKIP(bit) false
+#define DEC_PROF_DECL
+#define DEC_PROF_MARK(i)
 #endif
 // Four independent evaluations side by side.  A dependent chain of VALU ops issues one instruction per ~4.3 cycles on
 // gfx950, two or more independent chains in the same wave reach ~2.2 (tools/micro/pk_rate.hip), so the transcendental
@@ -624,9 +628,11 @@ __device__ __noinline__ int lds_decimate(unsigned char *smem, int b, int n, int 
     const int tid = threadIdx.x, nt = blockDim.x;
     float *Enew = cur ? L.EA : L.EB;
     float *score = L.xv2, *assign = L.coeff;
+    DEC_PROF_DECL
     for (int p = tid; p < ne; p += nt)
         L.Y[p] = pdp_safe_log_fin(1.0f - Enew[p], PDP_SCORER_EPS) * (0.0f + L.af[L.pcc[p] & 0x3fff]);   // surveys are finite or NaN
     __syncthreads();
+    DEC_PROF_MARK(16);                                // scorer: edge logs
     // SurveyScorer tail (pdp_predict.py:174-192) with the select-free math forms: same values as d_score_from_sums (every argument
     // here is finite or NaN); the three log terms of the external force take two possible values
     const float Lpi = pdp_safe_log(1.0f - pi, PDP_SCORER_EPS), L0 = pdp_safe_log(1.0f - pi * 0.0f, PDP_SCORER_EPS);
@@ -685,10 +691,20 @@ __device__ __noinline__ int lds_decimate(unsigned char *smem, int b, int n, int 
     flags = block_reduce(flags, OpOrI(), 0, redi2);    // (its barriers also publish score / coeff)
     const int z3 = flags & 1, anynz = (flags >> 1) & 1, cn = (flags >> 2) & 1;
     *spec = (z3 ? 1 : 0) | (cn ? 2 : 0);
-    const int li = d_instance_argmax(I, L.coeff, 0.0f, redf2, redi2);
+    DEC_PROF_MARK(17);                                // scorer: per-variable sums + score + flag reduction
+    // util.sparse_argmax on (coeff - 0) + 1: larger value wins, first index wins ties.  Keys need NaN-free values: with a NaN
+    // coefficient (cn) the result is not used
+    int li;
+    {
+        __shared__ unsigned long long keys2[PDP_RED_SMALL];
+        unsigned long long k = 0ull;
+        for (int v = tid; v < n; v += nt) { const unsigned long long kv = argkey((L.coeff[v] - 0.0f) + 1.0f, v); k = kv > k ? kv : k; }
+        li = argkey_index(block_max_u64(k, keys2));
+    }
     if (!(active && anynz && !cn && li >= 0)) return 0;
     const float sgn_li = pdp_sign(score[li]);
     __syncthreads();
+    DEC_PROF_MARK(18);                                // arg-max
     SimplifyScratch ss;
     ss.assign = assign; ss.deg = reinterpret_cast<int32_t *>(L.xv1); ss.sdeg = reinterpret_cast<int32_t *>(L.xv2);
     ss.flag_v = L.flag_v; ss.flag_f = reinterpret_cast<uint8_t *>(L.S); ss.flag_f2 = ss.flag_f + ((m + 15) & ~15); ss.red = redi2;
@@ -725,6 +741,7 @@ __device__ __noinline__ int lds_decimate(unsigned char *smem, int b, int n, int 
             }
         }
         *verified = __syncthreads_or(bad) ? 2 : 1;
+        DEC_PROF_MARK(19);                            // fix-point verification (once per call)
     }
     if (*verified == 1) {
         const int a = L.v_ptr[li], deg_li = L.v_ptr[li + 1] - a;
@@ -744,6 +761,7 @@ __device__ __noinline__ int lds_decimate(unsigned char *smem, int b, int n, int 
         }
         if (tid == 0) { L.av[li] = 0.0f; L.sol[li] = (sgn_li + 1.0f) / 2.0f; }
         __syncthreads();
+        DEC_PROF_MARK(20);                            // set the variable, switch its satisfied clauses off
         int single = 0;
         for (int j = tid; j < deg_li; j += nt) {
             const int c = L.pcc[a + j] & 0x3fff;
@@ -770,6 +788,10 @@ __device__ __noinline__ int lds_decimate(unsigned char *smem, int b, int n, int 
             }
         }
         const int found = block_reduce((single ? 1 : 0) | (pure ? 2 : 0), OpOrI(), 0, redi2);
+        DEC_PROF_MARK(21);                            // unit-clause / pure-variable scans
+#ifdef PDP_PHASE_PROF
+        if (threadIdx.x == 0) { if (found & 1) atomicAdd(&g_phase_cycles[22], 1ull); else if (found & 2) atomicAdd(&g_phase_cycles[23], 1ull); }
+#endif
         if (found & 1) d_simplify(I, ss, is_sat_b);         // a unit clause: the general routines redo the reference's sweeps
         else if (found & 2) d_peel(I, ss);
         return 1;
@@ -846,6 +868,9 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
         }
     }
     __shared__ float s_is_sat;
+    constexpr int SPEC_LOCAL = 64;
+    __shared__ uint8_t s_spec_used[SPEC_LOCAL], s_spec_zero[SPEC_LOCAL];
+    if (tid < SPEC_LOCAL) { s_spec_used[tid] = 0; s_spec_zero[tid] = 0; }
     if (tid == 0) s_is_sat = hdr.is_sat;
     __syncthreads();
 
@@ -1196,7 +1221,12 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
         PROF_COUNT(12);
         PROF_MARK(6);                                        // P6 decimation
         if (has_prev) cnt = cnt + 1.0f;
-        if (tid == 0 && !poisoned) { atomicOr(&sp.spec_used[t], used); if (zero) atomicOr(&sp.spec_zero[t], zero); }
+        // the speculation record of this iteration: kept in LDS and flushed once at the end of the launch (a global atomic here would
+        // make thread 0's wave wait for an L2 round trip at the next barrier, in every iteration)
+        if (tid == 0 && !poisoned) {
+            if (t < SPEC_LOCAL) { s_spec_used[t] = (uint8_t)used; s_spec_zero[t] = (uint8_t)zero; }
+            else { atomicOr(&sp.spec_used[t], used); if (zero) atomicOr(&sp.spec_zero[t], zero); }
+        }
         // ---- P7: edge-mask refresh (only changes after a decimation) ------------------------------------------------------
         if (decimated || !use_em) {
             const float *const av = L.av, *const af = L.af;
@@ -1269,6 +1299,10 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
         // the next launch starts with "the mask the last propagate used" == the current mask
         uint16_t *gpc = reinterpret_cast<uint16_t *>(dout + BL.pcc);
         for (int p = tid; p < ne; p += nt) { const uint16_t cw = pcc[p]; gpc[p] = (uint16_t)((cw & ~PC_EM_USED) | ((cw & PC_EM) ? PC_EM_USED : 0)); }
+    }
+    if (tid < SPEC_LOCAL && tid < T) {
+        if (s_spec_used[tid]) atomicOr(&sp.spec_used[tid], (uint32_t)s_spec_used[tid]);
+        if (s_spec_zero[tid]) atomicOr(&sp.spec_zero[tid], (uint32_t)s_spec_zero[tid]);
     }
     PROF_MARK(8);                                            // write back
     PROF_FLUSH();

@@ -258,37 +258,6 @@ template <class T> __device__ __forceinline__ T *ws_carve(unsigned char *&p, siz
 //   nuns[u]  (# unsat clauses containing u)  only where unsat[c] changed.
 // A step is then: one scan over the variables feeding two 64-bit LDS max-atomics (value | inverted index: larger value wins,
 // first index wins ties -- util.sparse_argmax), the flip, and one pass over the ~deg(f) clauses of f.
-// arg-max of (value, index) pairs as the maximum of 64-bit keys: order-preserving bits of the (non-NaN) value on top, inverted
-// index below, so the larger value wins and the first index wins ties (util.sparse_argmax); 0 = "no candidate".
-__device__ __forceinline__ unsigned long long ws_key(float t, int v)
-{
-    const uint32_t b = __float_as_uint(t);
-    const uint32_t ord = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-    return ((unsigned long long)ord << 32) | (uint32_t)(0xffffffffu - (uint32_t)v);
-}
-__device__ __forceinline__ int ws_key_index(unsigned long long k) { return k ? (int)(0xffffffffu - (uint32_t)k) : -1; }
-
-// wave-level maximum with DPP moves (a __shfl_down is an LDS round trip of ~100 cycles, a DPP move a few): Hillis-Steele steps
-// inside the 16-lane rows, then lane 15 / lane 31 broadcasts; the result is in lane 63.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned long long ws_dpp_max(unsigned long long k)
-{
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(k >> 32), CTRL, ROW_MASK, 0xf, false);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)k, CTRL, ROW_MASK, 0xf, false);
-    const unsigned long long o = ((unsigned long long)hi << 32) | lo;      // lanes without a source see 0
-    return o > k ? o : k;
-}
-__device__ __forceinline__ unsigned long long ws_wave_max(unsigned long long k)
-{
-    k = ws_dpp_max<0x111, 0xf>(k);      // row_shr:1
-    k = ws_dpp_max<0x112, 0xf>(k);      // row_shr:2
-    k = ws_dpp_max<0x114, 0xf>(k);      // row_shr:4
-    k = ws_dpp_max<0x118, 0xf>(k);      // row_shr:8   -> lane 15 of every row holds its row's maximum
-    k = ws_dpp_max<0x142, 0xa>(k);      // row_bcast:15 into rows 1 and 3
-    k = ws_dpp_max<0x143, 0xc>(k);      // row_bcast:31 into rows 2 and 3 -> lane 63
-    return k;
-}
-
 #ifdef PDP_PHASE_PROF
 __device__ unsigned long long g_ws_cycles[8];
 extern "C" int pdp_debug_ws_cycles(unsigned long long *out_host, int reset)
@@ -410,19 +379,19 @@ __global__ void __launch_bounds__(256) k_walksat_lds(PView pv, WsParams wp)
             const float r = ((acc > 0.0f) ? 1.0f : 0.0f) * u;
             if (r == 0.0f) has_zero = 1;
             const float tg = ((-(float)delta[v]) - 0.0f) + 1.0f, tr = (r - 0.0f) + 1.0f;      // util.sparse_argmax's x - min + 1 with min == 0
-            const unsigned long long k0 = ws_key(tg, v), k1 = ws_key(tr, v);
+            const unsigned long long k0 = argkey(tg, v), k1 = argkey(tr, v);
             kg = k0 > kg ? k0 : kg; kr = k1 > kr ? k1 : kr;
         }
         WS_PROF_MARK(1);                                        // scan
-        kg = ws_wave_max(kg);
-        kr = ws_wave_max(kr);
+        kg = wave_max_u64(kg);
+        kr = wave_max_u64(kr);
         has_zero = __builtin_amdgcn_ballot_w64(has_zero != 0) != 0 ? 1 : 0;
         if (lane == 63) { s_keys[wid] = kg; s_keys[4 + wid] = kr; redi[wid] = has_zero; }
         __syncthreads();
         WS_PROF_MARK(2);                                        // wave maxima + barrier
         unsigned long long bg = s_keys[0], br = s_keys[4]; has_zero = redi[0];
         for (int k = 1; k < nw; ++k) { bg = s_keys[k] > bg ? s_keys[k] : bg; br = s_keys[4 + k] > br ? s_keys[4 + k] : br; has_zero |= redi[k]; }
-        const int f = (s_coin > wp.epsilon) ? ws_key_index(bg) : ws_key_index(br);        // identical on every lane
+        const int f = (s_coin > wp.epsilon) ? argkey_index(bg) : argkey_index(br);        // identical on every lane
         if (tid == 0) {
             // one global atomic per step and workgroup on the same word serialises the whole batch: collect 32 steps per flush
             used32 |= 1u << (it & 31);
