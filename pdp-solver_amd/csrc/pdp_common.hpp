@@ -20,6 +20,12 @@
 // ---- error plumbing -------------------------------------------------------------------------
 void pdp_set_error(const char *fmt, ...);
 
+// ---- device memory: a small cache in front of hipMalloc / hipFree (pdp_problem.hip) --------------------------------------
+// A batch costs ~60 allocations and as many frees; hipFree of a large block synchronises the device (7.5 ms per destroyed
+// config-2 problem).  Freed blocks are kept (up to PDP_POOL_LIMIT_BYTES) and handed out again for requests of a similar size.
+int pdp_dev_alloc(void **out, size_t bytes);
+void pdp_dev_free(void *ptr);
+
 #define PDP_HIP_CHECK(expr)                                                                      \
     do {                                                                                         \
         hipError_t _e = (expr);                                                                  \

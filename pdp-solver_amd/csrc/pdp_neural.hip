@@ -697,9 +697,9 @@ extern "C" int pdp_neural_predict(pdp_problem *p, const pdp_agg_desc *d, const p
 static float *neural_ws(pdp_problem *p, int slot, size_t floats)
 {
     if (p->nws_floats[slot] < floats) {
-        if (p->nws[slot]) (void)hipFree(p->nws[slot]);
+        if (p->nws[slot]) pdp_dev_free(p->nws[slot]);
         p->nws[slot] = nullptr; p->nws_floats[slot] = 0;
-        if (hipMalloc((void **)&p->nws[slot], floats * sizeof(float)) != hipSuccess) { pdp_set_error("hipMalloc of a neural workspace failed"); return nullptr; }
+        if (pdp_dev_alloc((void **)&p->nws[slot], floats * sizeof(float)) != PDP_OK) return nullptr;
         p->nws_floats[slot] = floats;
     }
     return p->nws[slot];

@@ -351,8 +351,8 @@ extern "C" int pdp_decimator_create(pdp_decimator **out, pdp_problem *p)
     PDP_REQUIRE(out && p, "NULL argument");
     pdp_decimator *d = new pdp_decimator();
     d->p = p; d->has_prev = 0; d->prev = nullptr; d->counters = nullptr;
-    PDP_HIP_CHECK(hipMalloc((void **)&d->prev, sizeof(float) * (size_t)p->E));
-    PDP_HIP_CHECK(hipMalloc((void **)&d->counters, sizeof(float) * (size_t)p->B));
+    { int st_ = pdp_dev_alloc((void **)&d->prev, sizeof(float) * (size_t)p->E); if (st_ != PDP_OK) return st_; }
+    { int st_ = pdp_dev_alloc((void **)&d->counters, sizeof(float) * (size_t)p->B); if (st_ != PDP_OK) return st_; }
     PDP_HIP_CHECK(hipMemset(d->counters, 0, sizeof(float) * (size_t)p->B));
     PDP_HIP_CHECK(hipMemset(d->prev, 0, sizeof(float) * (size_t)p->E));
     *out = d;
@@ -361,8 +361,8 @@ extern "C" int pdp_decimator_create(pdp_decimator **out, pdp_problem *p)
 extern "C" int pdp_decimator_destroy(pdp_decimator *d)
 {
     if (!d) return PDP_OK;
-    if (d->prev) (void)hipFree(d->prev);
-    if (d->counters) (void)hipFree(d->counters);
+    if (d->prev) pdp_dev_free(d->prev);
+    if (d->counters) pdp_dev_free(d->counters);
     delete d;
     return PDP_OK;
 }

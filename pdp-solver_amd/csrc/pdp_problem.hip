@@ -10,6 +10,9 @@
 // Rows keep ascending edge id, which pins the fp32 summation order to the reference's
 // (torch.mm(sparse, dense) on CPU accumulates in storage order).
 #include "pdp_common.hpp"
+#include <mutex>
+#include <unordered_map>
+#include <vector>
 
 #include <hipcub/hipcub.hpp>
 #include <stdarg.h>
@@ -166,12 +169,79 @@ __global__ void k_fill(float *p, int64_t n, float v)
 
 static inline int grid_for(int64_t n, int nt = 256) { int64_t g = (n + nt - 1) / nt; if (g < 1) g = 1; if (g > 8192) g = 8192; return (int)g; }
 
+// ---- cached device allocator ---------------------------------------------------------------------------------------------------
+#define PDP_POOL_LIMIT_BYTES ((size_t)16 << 30)     /* cached (free) bytes kept at most; the card has 288 GB */
+namespace {
+struct PoolBlock { void *p; size_t bytes; };
+std::mutex g_pool_mu;
+std::vector<PoolBlock> g_pool_free;
+std::unordered_map<void *, size_t> g_pool_live;
+size_t g_pool_cached = 0;
+}
+
+int pdp_dev_alloc(void **out, size_t bytes)
+{
+    *out = nullptr;
+    const size_t need = ((bytes ? bytes : 1) + 4095) & ~(size_t)4095;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        size_t best = g_pool_free.size();
+        for (size_t i = 0; i < g_pool_free.size(); ++i)             // smallest cached block of at least the size, at most 25 % larger
+            if (g_pool_free[i].bytes >= need && g_pool_free[i].bytes <= need + need / 4 &&
+                (best == g_pool_free.size() || g_pool_free[i].bytes < g_pool_free[best].bytes)) best = i;
+        if (best != g_pool_free.size()) {
+            const PoolBlock b = g_pool_free[best];
+            g_pool_free[best] = g_pool_free.back(); g_pool_free.pop_back();
+            g_pool_cached -= b.bytes;
+            g_pool_live[b.p] = b.bytes;
+            *out = b.p;
+            return PDP_OK;
+        }
+    }
+    void *ptr = nullptr;
+    hipError_t e = hipMalloc(&ptr, need);
+    if (e != hipSuccess) {
+        // out of memory with blocks in the cache: give them back and retry once
+        {
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            for (const PoolBlock &b : g_pool_free) (void)hipFree(b.p);
+            g_pool_free.clear(); g_pool_cached = 0;
+        }
+        (void)hipGetLastError();
+        e = hipMalloc(&ptr, need);
+    }
+    if (e != hipSuccess) { pdp_set_error("hipMalloc(%zu bytes) failed: %s", need, hipGetErrorString(e)); return PDP_ERR_HIP; }
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool_live[ptr] = need;
+    *out = ptr;
+    return PDP_OK;
+}
+
+void pdp_dev_free(void *ptr)
+{
+    if (!ptr) return;
+    std::vector<void *> evict;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto it = g_pool_live.find(ptr);
+        if (it == g_pool_live.end()) { evict.push_back(ptr); }          // not ours (should not happen): plain free
+        else {
+            g_pool_free.push_back(PoolBlock{ptr, it->second});
+            g_pool_cached += it->second;
+            g_pool_live.erase(it);
+            while (g_pool_cached > PDP_POOL_LIMIT_BYTES && !g_pool_free.empty()) {      // oldest first
+                evict.push_back(g_pool_free.front().p); g_pool_cached -= g_pool_free.front().bytes;
+                g_pool_free.erase(g_pool_free.begin());
+            }
+        }
+    }
+    for (void *q : evict) (void)hipFree(q);
+}
+
 template <typename T>
 static int dmalloc(T **p, size_t n)
 {
-    *p = nullptr;
-    PDP_HIP_CHECK(hipMalloc((void **)p, (n ? n : 1) * sizeof(T)));
-    return PDP_OK;
+    return pdp_dev_alloc((void **)p, (n ? n : 1) * sizeof(T));
 }
 
 #define PDP_TRY(x) do { int _s = (x); if (_s != PDP_OK) return _s; } while (0)
@@ -184,20 +254,20 @@ extern "C" int pdp_problem_destroy(pdp_problem *p)
                     p->ws_e[2], p->ws_e[3], p->ws_v[0], p->ws_v[1], p->ws_v[2], p->ws_v[3], p->ws_v[4], p->ws_v[5],
                     p->ws_f[0], p->ws_f[1], p->ws_b[0], p->ws_b[1], p->ws_b[2], p->ws_b[3], p->ws_bi[0], p->ws_bi[1],
                     p->ws_vi[0], p->ws_vi[1], p->ws_vi[2], p->ws_fu[0], p->ws_fu[1], p->flags, p->cub_tmp};
-    for (void *q : ptrs) if (q) (void)hipFree(q);
+    for (void *q : ptrs) if (q) pdp_dev_free(q);
     if (p->flags_host) (void)hipHostFree(p->flags_host);
-    if (p->solve_blob) (void)hipFree(p->solve_blob);
+    if (p->solve_blob) pdp_dev_free(p->solve_blob);
     if (p->solve_host) (void)hipHostFree(p->solve_host);
-    if (p->solve_extra_v) (void)hipFree(p->solve_extra_v);
+    if (p->solve_extra_v) pdp_dev_free(p->solve_extra_v);
     void *res[] = {p->res_stat_off, p->res_stat, p->res_dyn[0], p->res_dyn[1], p->res_prev_slots, p->res_ctl};
-    for (void *q : res) if (q) (void)hipFree(q);
+    for (void *q : res) if (q) pdp_dev_free(q);
     for (int i = 0; i < p->res_events_n; ++i) (void)hipEventDestroy(p->res_events[i]);
     free(p->res_events);
-    for (int i = 0; i < 4; ++i) if (p->nws[i]) (void)hipFree(p->nws[i]);
-    if (p->nv_ptr) (void)hipFree(p->nv_ptr);
-    if (p->nv_edges) (void)hipFree(p->nv_edges);
-    if (p->nf_ptr) (void)hipFree(p->nf_ptr);
-    if (p->nf_edges) (void)hipFree(p->nf_edges);
+    for (int i = 0; i < 4; ++i) if (p->nws[i]) pdp_dev_free(p->nws[i]);
+    if (p->nv_ptr) pdp_dev_free(p->nv_ptr);
+    if (p->nv_edges) pdp_dev_free(p->nv_edges);
+    if (p->nf_ptr) pdp_dev_free(p->nf_ptr);
+    if (p->nf_edges) pdp_dev_free(p->nf_edges);
     delete p;
     return PDP_OK;
 }
@@ -291,7 +361,7 @@ static int build_problem(pdp_problem *p, const int32_t *graph_map, const int32_t
     p->max_m = (int)p->flags_host[FL_GMIN1 + 1];
     p->max_e = (int)p->flags_host[FL_GMIN1 + 2];
     PDP_HIP_CHECK(hipMemsetAsync(p->flags, 0, FL_COUNT * sizeof(uint32_t), st));
-    (void)hipFree(keys_out); (void)hipFree(vals_out); (void)hipFree(iota_e);
+    pdp_dev_free(keys_out); pdp_dev_free(vals_out); pdp_dev_free(iota_e);
     return PDP_OK;
 }
 

@@ -1460,9 +1460,9 @@ __global__ void k_solve_ctl_init(SolveCtl *ctl, int nchunks, SolveCall *call)
 static int ensure_bytes(char **ptr, size_t *have, size_t need)
 {
     if (*have >= need) return PDP_OK;
-    if (*ptr) (void)hipFree(*ptr);
+    if (*ptr) pdp_dev_free(*ptr);
     *ptr = nullptr; *have = 0;
-    PDP_HIP_CHECK(hipMalloc((void **)ptr, need));
+    { int st_ = pdp_dev_alloc((void **)ptr, need); if (st_ != PDP_OK) return st_; }
     *have = need;
     return PDP_OK;
 }
@@ -1487,13 +1487,13 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
             off[b] = (int64_t)so; off[B + b] = (int64_t)dy;
             so += bl.stat_bytes; dy += bl.dyn_bytes;
         }
-        PDP_HIP_CHECK(hipMalloc((void **)&p->res_stat_off, 2 * B * sizeof(int64_t)));
+        { int st_ = pdp_dev_alloc((void **)&p->res_stat_off, 2 * B * sizeof(int64_t)); if (st_ != PDP_OK) return st_; }
         PDP_HIP_CHECK(hipMemcpy(p->res_stat_off, off.data(), 2 * B * sizeof(int64_t), hipMemcpyHostToDevice));
         p->res_stat_bytes = so + 16; p->res_dyn_bytes = dy + 16;
-        PDP_HIP_CHECK(hipMalloc((void **)&p->res_stat, p->res_stat_bytes));
-        PDP_HIP_CHECK(hipMalloc((void **)&p->res_dyn[0], p->res_dyn_bytes));
-        PDP_HIP_CHECK(hipMalloc((void **)&p->res_dyn[1], p->res_dyn_bytes));
-        PDP_HIP_CHECK(hipMalloc((void **)&p->res_prev_slots, (E + 4) * sizeof(float)));
+        { int st_ = pdp_dev_alloc((void **)&p->res_stat, p->res_stat_bytes); if (st_ != PDP_OK) return st_; }
+        { int st_ = pdp_dev_alloc((void **)&p->res_dyn[0], p->res_dyn_bytes); if (st_ != PDP_OK) return st_; }
+        { int st_ = pdp_dev_alloc((void **)&p->res_dyn[1], p->res_dyn_bytes); if (st_ != PDP_OK) return st_; }
+        { int st_ = pdp_dev_alloc((void **)&p->res_prev_slots, (E + 4) * sizeof(float)); if (st_ != PDP_OK) return st_; }
         p->res_static_built = 0;
     }
     const int64_t *stat_off = p->res_stat_off, *dyn_off = p->res_stat_off + B;
@@ -1669,9 +1669,9 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
     const size_t snap_bytes = snap_floats * 4 + ((B + 63) & ~(size_t)63);
     const size_t blob_bytes = words * 4 + 2 * B * 4 + 2 * snap_bytes + 64;
     if (p->solve_blob_bytes < blob_bytes) {
-        if (p->solve_blob) (void)hipFree(p->solve_blob);
+        if (p->solve_blob) pdp_dev_free(p->solve_blob);
         p->solve_blob = nullptr; p->solve_blob_bytes = 0;
-        PDP_HIP_CHECK(hipMalloc((void **)&p->solve_blob, blob_bytes));
+        { int st_ = pdp_dev_alloc((void **)&p->solve_blob, blob_bytes); if (st_ != PDP_OK) return st_; }
         p->solve_blob_bytes = blob_bytes;
     }
     if (p->solve_host_words < words) {
@@ -1714,7 +1714,7 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
         for (int i = 0; i < 4; ++i) sp.ws_e[i] = p->ws_e[i];
         sp.ws_f = p->ws_f[0];
         for (int i = 0; i < 6; ++i) sp.ws_v[i] = p->ws_v[i];
-        if (!p->solve_extra_v) PDP_HIP_CHECK(hipMalloc((void **)&p->solve_extra_v, sizeof(float) * V));
+        if (!p->solve_extra_v) { int st_ = pdp_dev_alloc((void **)&p->solve_extra_v, sizeof(float) * V); if (st_ != PDP_OK) return st_; }
         extra_v = p->solve_extra_v;
         sp.ws_v[6] = extra_v;
         for (int i = 0; i < 3; ++i) sp.ws_vi[i] = p->ws_vi[i];

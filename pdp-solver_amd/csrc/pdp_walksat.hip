@@ -119,8 +119,8 @@ extern "C" int pdp_random_fill(pdp_problem *p, int rng_mode, const float *values
         size_t need = 0;
         PDP_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, p->ws_vi[0], p->ws_vi[1], p->V, st));
         if (need > p->cub_tmp_bytes) {
-            if (p->cub_tmp) (void)hipFree(p->cub_tmp);
-            PDP_HIP_CHECK(hipMalloc(&p->cub_tmp, need));
+            if (p->cub_tmp) pdp_dev_free(p->cub_tmp);
+            { int st_ = pdp_dev_alloc(&p->cub_tmp, need); if (st_ != PDP_OK) return st_; }
             p->cub_tmp_bytes = need;
         }
         PDP_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(p->cub_tmp, need, p->ws_vi[0], p->ws_vi[1], p->V, st));
@@ -488,7 +488,7 @@ static int local_search_persistent(pdp_problem *p, const float *pred, int iterat
     const size_t bw = ((size_t)iterations + 31) / 32;               // words per bit map
     const size_t words = 2 * bw + 4;
     uint32_t *spec = nullptr;
-    PDP_HIP_CHECK(hipMalloc((void **)&spec, words * 4 + (size_t)p->B * 4 * 3));
+    { int st_ = pdp_dev_alloc((void **)&spec, words * 4 + (size_t)p->B * 4 * 3); if (st_ != PDP_OK) return st_; }
     int32_t *first_sat = (int32_t *)(spec + words), *cap_b = first_sat + p->B, *list = cap_b + p->B;
     PDP_HIP_CHECK(hipMemsetAsync(spec, 0, words * 4, st));
     PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_walksat_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -534,7 +534,7 @@ static int local_search_persistent(pdp_problem *p, const float *pred, int iterat
     for (int t = 0; t < stop && t < first_finish && ok; ++t)
         if (((host[t >> 5] >> (t & 31)) & 1u) && !((host[bw + (t >> 5)] >> (t & 31)) & 1u)) ok = false;
     free(host);
-    (void)hipFree(spec);
+    pdp_dev_free(spec);
     if (status != PDP_OK) return status;
     if (!ok) return PDP_OK;          // caller runs the strict loop on the untouched inputs
     if (steps_host) *steps_host = stop;
