@@ -176,6 +176,10 @@ typedef struct pdp_dimacs pdp_dimacs;
 int pdp_dimacs_open(const char *path, pdp_dimacs **out, int32_t *n_vars, int32_t *n_clauses, int64_t *n_edges);
 int pdp_dimacs_read(const pdp_dimacs *d, int32_t *signed_vars /*[n_edges]*/, int32_t *clause_ids /*[n_edges]*/);
 int pdp_dimacs_close(pdp_dimacs *d);
+/* count files parsed by `threads` host threads; out / n_vars / n_clauses / n_edges are arrays of `count` entries.  On a failure every
+ * handle is released and the first error is reported. */
+int pdp_dimacs_open_many(const char *const *paths, int32_t count, int32_t threads, pdp_dimacs **out, int32_t *n_vars,
+                         int32_t *n_clauses, int64_t *n_edges);
 
 /* ---- neural plug-ins: per-edge MLP / GRU layers on the fp32 matrix cores ---------------------------------
  * Weights are handed over PRE-TRANSPOSED and ZERO PADDED by the host: a layer y = act(W x + b) with nn.Linear weight

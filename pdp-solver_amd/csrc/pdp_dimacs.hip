@@ -14,6 +14,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <thread>
+#include <atomic>
+#include <string>
 
 struct pdp_dimacs {
     int32_t n_vars = 0, n_clauses = 0;
@@ -137,5 +140,39 @@ extern "C" int pdp_dimacs_read(const pdp_dimacs *d, int32_t *signed_vars, int32_
 extern "C" int pdp_dimacs_close(pdp_dimacs *d)
 {
     delete d;
+    return PDP_OK;
+}
+
+// Many files at once, parsed by a few host threads (the loader's DIMACS mode: thousands of small files per batch).
+// out[i] receives the handle of paths[i] (NULL for a file that failed; the first failure's message is kept), sizes as in pdp_dimacs_open.
+extern "C" int pdp_dimacs_open_many(const char *const *paths, int32_t count, int32_t threads, pdp_dimacs **out, int32_t *n_vars,
+                                    int32_t *n_clauses, int64_t *n_edges)
+{
+    PDP_REQUIRE(count >= 0 && (count == 0 || (paths && out && n_vars && n_clauses && n_edges)), "NULL argument");
+    if (threads < 1) threads = 1;
+    if (threads > count) threads = count > 0 ? count : 1;
+    std::atomic<int32_t> next(0), failed(-1);
+    std::vector<std::string> messages((size_t)threads);
+    auto work = [&](int tid) {
+        for (;;) {
+            const int32_t i = next.fetch_add(1);
+            if (i >= count) break;
+            out[i] = nullptr;
+            const int st = pdp_dimacs_open(paths[i], &out[i], &n_vars[i], &n_clauses[i], &n_edges[i]);
+            if (st != PDP_OK) {
+                int32_t expect = -1;
+                if (failed.compare_exchange_strong(expect, i)) messages[(size_t)tid] = pdp_last_error();
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (std::thread &t : pool) t.join();
+    if (failed.load() >= 0) {
+        for (const std::string &m : messages) if (!m.empty()) { pdp_set_error("%s", m.c_str()); break; }
+        for (int32_t i = 0; i < count; ++i) if (out[i]) { delete out[i]; out[i] = nullptr; }
+        return PDP_ERR_INVALID;
+    }
     return PDP_OK;
 }

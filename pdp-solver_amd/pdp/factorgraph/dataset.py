@@ -168,7 +168,24 @@ class FactorGraphDataset(object):
     def batches(self, batch_size):
         """Yields lists of segment batches, ``batch_size`` instances per loader batch."""
         for start in range(0, len(self), batch_size):
-            items = [self[i] for i in range(start, min(start + batch_size, len(self)))]
+            idx = range(start, min(start + batch_size, len(self)))
+            if self._dimacs is not None and len(idx) > 1:
+                # DIMACS files: one call parses the batch's files with a few host threads inside the native library
+                import os
+                from pdp import native
+                todo = [i for i in idx if i not in self._cache]
+                parsed = native.dimacs_parse_many([self._dimacs[i][0] for i in todo], threads=min(8, os.cpu_count() or 1))
+                for i, (vn, cn, sv, ci) in zip(todo, parsed):
+                    path, label = self._dimacs[i]
+                    item = (vn, cn, np.stack((np.abs(sv) - 1, ci - 1)).astype(np.int32), np.sign(sv).astype(np.float32), float(label), [os.path.split(path)[1]])
+                    if len(self._cache) < self._max_cache_size:
+                        self._cache[i] = item
+                    else:
+                        self._cache.setdefault('_tmp', {})[i] = item
+                tmp = self._cache.pop('_tmp', {})
+                items = [self._cache[i] if i in self._cache else tmp[i] for i in idx]
+            else:
+                items = [self[i] for i in idx]
             yield collate(items, self._limit, self._hidden_dim, self._batch_replication)
 
     @staticmethod

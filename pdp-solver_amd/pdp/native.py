@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     'pdp_decimator_destroy', 'pdp_decimator_reset', 'pdp_sequential_decimate', 'pdp_sequential_decimate_gate',
     'pdp_sequential_decimate_apply', 'pdp_reinforce_decimate', 'pdp_reinforce_predict', 'pdp_energy',
     'pdp_energy_diff', 'pdp_random_fill', 'pdp_local_search', 'pdp_deduplicate', 'pdp_sp_solve', 'pdp_math_apply',
-    'pdp_neural_aggregate_edges', 'pdp_neural_gru', 'pdp_neural_predict', 'pdp_dimacs_open', 'pdp_dimacs_read', 'pdp_dimacs_close',
+    'pdp_neural_aggregate_edges', 'pdp_neural_gru', 'pdp_neural_predict', 'pdp_dimacs_open', 'pdp_dimacs_read', 'pdp_dimacs_close', 'pdp_dimacs_open_many',
 ]
 
 
@@ -413,6 +413,29 @@ def dimacs_parse(path):
     finally:
         lib().pdp_dimacs_close(h)
     return int(nv.value), int(nc.value), sv, ci
+
+
+def dimacs_parse_many(paths, threads=8):
+    """Several DIMACS files at once (parsed by host threads inside the library): list of dimacs_parse tuples in input order."""
+    import numpy as np
+    n = len(paths)
+    if n == 0:
+        return []
+    arr = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    handles = (C.c_void_p * n)()
+    nv = (C.c_int32 * n)(); nc = (C.c_int32 * n)(); ne = (C.c_int64 * n)()
+    check(lib().pdp_dimacs_open_many(arr, C.c_int32(n), C.c_int32(threads), handles, nv, nc, ne))
+    out = []
+    try:
+        for i in range(n):
+            sv = np.empty(ne[i], np.int32); ci = np.empty(ne[i], np.int32)
+            check(lib().pdp_dimacs_read(C.c_void_p(handles[i]), sv.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p)))
+            out.append((int(nv[i]), int(nc[i]), sv, ci))
+    finally:
+        for i in range(n):
+            if handles[i]:
+                lib().pdp_dimacs_close(C.c_void_p(handles[i]))
+    return out
 
 
 def math_apply(fn, x):

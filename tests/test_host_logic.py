@@ -187,3 +187,21 @@ def test_loader_reads_dimacs_directly():
     single = os.path.join(gdir, sorted(os.listdir(gdir))[0])
     one = dataset.FactorGraphDataset(single, 40000000, 3)
     assert len(one) == 1 and one[0][5] == [os.path.split(single)[1]]
+
+
+def test_native_dimacs_batch_reader(tmp_path):
+    "pdp_dimacs_open_many (host threads inside the library) returns what the one-file call returns, in input order; errors propagate"
+    from pdp import native
+    gdir = os.path.join(REPO, 'tests', 'golden', 'dimacs20')
+    paths = [os.path.join(gdir, f) for f in sorted(os.listdir(gdir))]
+    many = native.dimacs_parse_many(paths * 3, threads=4)
+    assert len(many) == 60
+    for path, got in zip(paths * 3, many):
+        one = native.dimacs_parse(path)
+        assert got[:2] == one[:2]
+        np.testing.assert_array_equal(got[2], one[2]); np.testing.assert_array_equal(got[3], one[3])
+    assert native.dimacs_parse_many([]) == []
+    bad = tmp_path / 'bad.cnf'
+    bad.write_text("p cnf 2 1\n1 x2 0\n")
+    with pytest.raises(native.NativeError, match='bad.cnf:2'):
+        native.dimacs_parse_many(paths[:5] + [str(bad)] + paths[5:9], threads=3)
