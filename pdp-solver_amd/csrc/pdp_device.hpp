@@ -257,14 +257,15 @@ __device__ __forceinline__ float d_score_from_sums(float pos, float neg, float a
 
 // SurveyPropagator per-edge update (pdp_propagate.py:195-218) from the per-variable sums
 struct SpOut { float qu, qs, dc; };
-__device__ __forceinline__ SpOut d_sp_edge(float s, float P, float N, float y, float force, float pi)
+// L0 / L1: the two values log(max(1 - pi * [force == +-s], eps)) can take (pdp_propagate.py:197,201), computed once by the caller
+__device__ __forceinline__ SpOut d_sp_edge(float s, float P, float N, float y, float force, float L0, float L1)
 {
     const float pos = 0.0f + P, neg = 0.0f + N;
     float same = (0.5f * (1.0f + s)) * pos + (0.5f * (1.0f - s)) * neg;
     same = same - y;
-    same = same + pdp_safe_log(1.0f - pi * ((force == s) ? 1.0f : 0.0f), PDP_SP_EPS);
+    same = same + ((force == s) ? L1 : L0);
     float opp = (0.5f * (1.0f - s)) * pos + (0.5f * (1.0f + s)) * neg;
-    opp = opp + pdp_safe_log(1.0f - pi * ((force == -s) ? 1.0f : 0.0f), PDP_SP_EPS);
+    opp = opp + ((force == -s) ? L1 : L0);
     float dc = same + opp;
     dc = pdp_safe_exp(dc);
     const float A = pdp_safe_exp(same), Bv = pdp_safe_exp(opp);

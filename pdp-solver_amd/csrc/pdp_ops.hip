@@ -194,6 +194,7 @@ __global__ void __launch_bounds__(PDP_NT) k_sp_propagate(PView pv, const float *
     xs += I.e0; ys += I.e0; Sw += I.f0; Pw += I.v0; Nw += I.v0;
     const float *em = emask ? emask + I.e0 : nullptr;
     const float mask = amask ? (0.0f + (0.0f + (float)amask[I.b])) : 1.0f;
+    const float L0 = pdp_safe_log(1.0f - pi * 0.0f, PDP_SP_EPS), L1 = pdp_safe_log(1.0f - pi * 1.0f, PDP_SP_EPS);
     for (int e = tid; e < I.e; e += nt) {
         float x = pdp_safe_log(dq[3 * e], PDP_SP_EPS);
         float y = pdp_safe_log(1.0f - dfs[2 * e], PDP_SP_EPS);
@@ -224,7 +225,7 @@ __global__ void __launch_bounds__(PDP_NT) k_sp_propagate(PView pv, const float *
         const float agg = (0.0f + Sw[c]) - xs[e];
         const float eta = mask * pdp_safe_exp(agg) + (1.0f - mask) * ifs[2 * e];
         const float force = dfs[2 * e + 1];
-        const SpOut o = d_sp_edge(s, Pw[v], Nw[v], ys[e], force, pi);
+        const SpOut o = d_sp_edge(s, Pw[v], Nw[v], ys[e], force, L0, L1);
         oq[3 * e + 0] = mask * o.qu + (1.0f - mask) * iq[3 * e + 0];
         oq[3 * e + 1] = mask * o.qs + (1.0f - mask) * iq[3 * e + 1];
         oq[3 * e + 2] = mask * o.dc + (1.0f - mask) * iq[3 * e + 2];

@@ -135,6 +135,7 @@ __global__ void __launch_bounds__(LDS ? 512 : 256) k_sp_solve(PView pv, SolvePar
     const int n = G.n, m = G.m, ne = G.e;
     float *gq = sp.q + 3 * (size_t)G.e0;
     float *gfs = sp.fs + 2 * (size_t)G.e0;
+    const float L0h = pdp_safe_log(1.0f - sp.pi * 0.0f, PDP_SP_EPS), L1h = pdp_safe_log(1.0f - sp.pi * 1.0f, PDP_SP_EPS);
 
     SView<IT> I;
     I.b = G.b; I.n = n; I.m = m; I.e = ne;
@@ -238,7 +239,7 @@ __global__ void __launch_bounds__(LDS ? 512 : 256) k_sp_solve(PView pv, SolvePar
             const float agg = (0.0f + I.S[c]) - I.s0[e];
             const float eta_new = 1.0f * pdp_safe_exp(agg) + (1.0f - 1.0f) * eta_old;
             const float force = I.force[e * I.fstride];
-            const SpOut o = d_sp_edge(s, I.P[v], I.N[v], I.s1[e], force, sp.pi);
+            const SpOut o = d_sp_edge(s, I.P[v], I.N[v], I.s1[e], force, L0h, L1h);
             const float qu_old = I.qu[e * I.qstride];
             const float qu_new = 1.0f * o.qu + (1.0f - 1.0f) * qu_old;
             // only a NaN SURVEY poisons the batch-global reductions of this iteration; a NaN in q (0/0) reaches the
@@ -373,7 +374,7 @@ __global__ void __launch_bounds__(LDS ? 512 : 256) k_sp_solve(PView pv, SolvePar
     if (did_prop) {
         // q_s / q_dc of the last sweep are recomputed from the per-variable sums that are still resident
         for (int e = tid; e < ne; e += nt) {
-            const SpOut o = d_sp_edge((float)I.sgn[e], I.P[I.e_var[e]], I.N[I.e_var[e]], I.s1[e], I.force[e * I.fstride], sp.pi);
+            const SpOut o = d_sp_edge((float)I.sgn[e], I.P[I.e_var[e]], I.N[I.e_var[e]], I.s1[e], I.force[e * I.fstride], L0h, L1h);
             // (1 - mask) * old keeps a NaN forever; the three columns of q turn NaN together, so q_u carries the stickiness
             const float sticky = I.qu[e * I.qstride];
             gq[3 * e + 1] = 1.0f * o.qs + (1.0f - 1.0f) * sticky;
