@@ -550,6 +550,161 @@ __global__ void __launch_bounds__(NTN) k_gru(int E, const float *__restrict__ st
     }
 }
 
+// ---- kernel 5b: the same cell, software pipelined inside each wave (hidden width 128) -------------------------------------------------
+// In k_gru the two waves of a SIMD run in lock step (two barriers per tile): both issue their MFMA chains, then both run their
+// activation epilogues, so the matrix pipe idles during every epilogue (rocprofv3: MFMA pipe 46 % busy).  Here every gate is one
+// straight-line block in which the k-steps of the *next* gate's two chains alternate with slices of the *previous* gate's
+// activations (one accumulator register = one slice per 1/16 of the k-steps):
+//     r chains  ||  tanh + blend + store of the previous tile      (carried across the tile boundary in registers)
+//     z chains  ||  sigmoid of the r gate
+//     n chains  ||  sigmoid of the z gate
+// The arithmetic per element is unchanged (same chains, same activation functions), so the result is bit-identical to k_gru.
+template <int SX, int SH, int NV, class Epi>
+__device__ __forceinline__ void gru_phase(const float *xa, const float *ha, __amdgpu_buffer_rsrc_t wi, __amdgpu_buffer_rsrc_t wh,
+                                          int voff /* byte offset of this lane's column in a weight row pair */, int wstride /* bytes per k-step */,
+                                          float bi, float bh, f32x16 &ai, f32x16 &ah, Epi &&epi)
+{
+    // weight rows through buffer loads: lane offset in a VGPR, k-step offset as a scalar -- no per-step 64-bit address registers
+    auto wload = [&](int s2) -> float {
+        return (s2 < SX) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wi, voff, s2 * wstride, 0))
+                         : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wh, voff, (s2 - SX) * wstride, 0));
+    };
+    auto aload = [&](int s2) -> float { return (s2 < SX) ? xa[2 * s2] : ha[2 * (s2 - SX)]; };
+    constexpr int S = SX + SH, CH = (S + 15) / 16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ai[r] = bi; ah[r] = bh; }
+    float bb[2][CH], aa[2][CH];                            // both operands of a chunk are fetched while the previous chunk runs
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+        if (j < (S / 16)) { bb[0][j] = wload(j); aa[0][j] = aload(j); }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int lo = c * S / 16, hi = (c + 1) * S / 16, hi2 = (c + 2) * S / 16;
+        if (c < 15) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int s = hi + j;
+                if (s < hi2) { bb[(c + 1) & 1][j] = wload(s); aa[(c + 1) & 1][j] = aload(s); }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int s = lo + j;
+            if (s < hi) {
+                if (s < SX) ai = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[c & 1][j], bb[c & 1][j], ai, 0, 0, 0);
+                else ah = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[c & 1][j], bb[c & 1][j], ah, 0, 0, 0);
+            }
+        }
+        epi(c);
+        // (pure arithmetic is not ordered against the scheduling barriers by itself: the empty asm statements here and in the
+        //  activation slices tie the chunk's results to this point of the instruction stream)
+        asm volatile("" : "+v"(ai), "+v"(ah));
+        // issue order inside the chunk: one MFMA (64 cycles on the matrix pipe), NV VALU instructions of the activation slice in its shadow
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+            if (lo + j < hi) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, NV, 0); }
+        __builtin_amdgcn_sched_barrier(0);                 // and nothing moves across chunks (keeps the loads of later chunks from piling up)
+    }
+}
+
+template <int SX, bool MASK>
+__global__ void __launch_bounds__(NTN) k_gru_pipe(int E, const float *__restrict__ state, const float *__restrict__ sign,
+                                                  const float *__restrict__ hprev, const float *__restrict__ rowmask, GruW g,
+                                                  float *__restrict__ out, int ntiles /* full tiles only */)
+{
+    constexpr int SH = 64, H = 128;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int ldx = 2 * SX + 1, ldh = 2 * SH + 1;
+    float *X = sm, *Hs = sm + TM * ldx, *Mk = Hs + TM * ldh;     // Mk [2][TM]: row masks of the current and the previous tile
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    static_assert(2 * SX - 2 == H, "input = [message of width H, edge sign, zero pad]");
+    // tile rows: 512 bytes of message and 512 bytes of hidden state per edge = one dwordx2 per lane and row; the sign column by wave 0
+    float2 px[PRE_R], ph[PRE_R];
+    float psg = 0.0f;                                     // wave 0: edge sign, wave 1: row mask
+    auto fetch = [&](int tile) {
+        const int e0 = tile * TM;
+#pragma unroll
+        for (int jr = 0; jr < PRE_R; ++jr) {
+            const size_t e = (size_t)(e0 + wave + NWAVES * jr);
+            px[jr] = reinterpret_cast<const float2 *>(state + e * H)[l];
+            ph[jr] = reinterpret_cast<const float2 *>(hprev + e * H)[l];
+        }
+        if (wave == 0) psg = sign[e0 + l];
+        if (wave == 1) psg = MASK ? rowmask[e0 + l] : 1.0f;
+    };
+    auto deposit = [&](int par) {
+#pragma unroll
+        for (int jr = 0; jr < PRE_R; ++jr) {
+            const int r = wave + NWAVES * jr;
+            X[r * ldx + 2 * l] = px[jr].x; X[r * ldx + 2 * l + 1] = px[jr].y;
+            Hs[r * ldh + 2 * l] = ph[jr].x; Hs[r * ldh + 2 * l + 1] = ph[jr].y;
+        }
+        if (wave == 0) X[l * ldx + H] = psg;
+        if (wave == 1) Mk[par * TM + l] = psg;
+    };
+    if (threadIdx.x < TM) { X[threadIdx.x * ldx + H + 1] = 0.0f; Mk[threadIdx.x] = 0.0f; Mk[TM + threadIdx.x] = 0.0f; }   // zero pad column (never overwritten)
+    const int nb = wave >> 1, mb = wave & 1, i = l & 31, kh = l >> 5;
+    const int col = 32 * nb + i;
+    const int N3 = 3 * H;
+    const int ws = 2 * N3 * (int)sizeof(float);
+    const float *xa = X + (32 * mb + i) * ldx + kh, *ha = Hs + (32 * mb + i) * ldh + kh;
+    const __amdgpu_buffer_rsrc_t wi = __builtin_amdgcn_make_buffer_rsrc((void *)g.Wt_ih, 0, 2 * SX * N3 * (int)sizeof(float), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wh = __builtin_amdgcn_make_buffer_rsrc((void *)g.Wt_hh, 0, 2 * SH * N3 * (int)sizeof(float), 0x00020000);
+    const int voff = (kh * N3 + col) * (int)sizeof(float);
+    const int ooff = ((32 * mb + 4 * kh) * H + col) * (int)sizeof(float);
+    const float bir = g.b_ih[col], biz = g.b_ih[H + col], bin = g.b_ih[2 * H + col];
+    const float bhr = g.b_hh[col], bhz = g.b_hh[H + col], bhn = g.b_hh[2 * H + col];
+    const int row0 = 32 * mb + 4 * kh;                    // acc_row(r, l) = row0 - 32 mb + (r & 3) + 8 (r >> 2)
+    f32x16 tq, zg, hq;                                    // carried: tanh argument, update gate, previous hidden value
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { tq[r] = 0.0f; zg[r] = 0.0f; hq[r] = 0.0f; }
+    int tile = blockIdx.x;
+    if (tile < ntiles) { fetch(tile); deposit(0); }
+    int e_prev = tile * TM;                               // first pass: the slices store zeros where this lane stores its results later
+    int par = 0;                                          // Mk[par] = masks of the current tile, Mk[par ^ 1] = of the previous one
+    for (; tile < ntiles; tile += gridDim.x, par ^= 1) {
+        __syncthreads();
+        const int next = tile + gridDim.x;
+        if (next < ntiles) fetch(next);
+        f32x16 ai, ah, rg;
+        const __amdgpu_buffer_rsrc_t ob = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)e_prev * H), 0, TM * H * (int)sizeof(float), 0x00020000);
+        const float *mp = Mk + (par ^ 1) * TM + row0;
+        gru_phase<SX, SH, 8>(xa, ha, wi, wh, voff, ws, bir, bhr, ai, ah, [&](int c) {
+            const int ro = (c & 3) + 8 * (c >> 2);
+            const float ng = pdp_tanhf(tq[c]);
+            const float hnew = (hq[c] - ng) * zg[c] + ng;
+            const float mk = mp[ro];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mk * hnew + (1.0f - mk) * hq[c]), ob, ooff, ro * H * (int)sizeof(float), 0);
+        });
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rg[r] = ah[r] + ai[r];
+        gru_phase<SX, SH, 6>(xa, ha, wi, wh, voff + H * (int)sizeof(float), ws, biz, bhz, ai, ah, [&](int c) { float v = pdp_sigmoidf(rg[c]); asm volatile("" : "+v"(v)); rg[c] = v; });
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zg[r] = ah[r] + ai[r];
+        gru_phase<SX, SH, 6>(xa, ha, wi, wh, voff + 2 * H * (int)sizeof(float), ws, bin, bhn, ai, ah, [&](int c) { float v = pdp_sigmoidf(zg[c]); asm volatile("" : "+v"(v)); zg[c] = v; });
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            tq[r] = ai[r] + ah[r] * rg[r];
+            hq[r] = Hs[(row0 + (r & 3) + 8 * (r >> 2)) * ldh + col];
+        }
+        e_prev = tile * TM;
+        __syncthreads();                                   // every wave is done with X / Hs
+        if (next < ntiles) deposit(par ^ 1);
+    }
+    if (blockIdx.x < ntiles) {
+        const __amdgpu_buffer_rsrc_t ob = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)e_prev * H), 0, TM * H * (int)sizeof(float), 0x00020000);
+        const float *mp = Mk + (par ^ 1) * TM + row0;       // par was flipped once more when the loop ended
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int ro = (c & 3) + 8 * (c >> 2);
+            const float ng = pdp_tanhf(tq[c]);
+            const float hnew = (hq[c] - ng) * zg[c] + ng;
+            const float mk = mp[ro];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mk * hnew + (1.0f - mk) * hq[c]), ob, ooff, ro * H * (int)sizeof(float), 0);
+        }
+    }
+}
+
 // mask per edge from the per-instance active mask (K1: two chained sparse products in the reference)
 __global__ void k_edge_active(int E, const int32_t *__restrict__ gm, const int32_t *__restrict__ var_inst, const uint8_t *__restrict__ amask,
                               float *__restrict__ out)
@@ -583,6 +738,7 @@ static float *neural_ws(pdp_problem *p, int slot, size_t floats);
 #define LDS_RES_LIMIT (160 * 1024 - 512)
 static int persistent_grid()
 {
+    if (const char *e = getenv("PDP_NEURAL_GRID")) { const int v = atoi(e); if (v > 0) return v; }   // tests: many tiles per workgroup on small inputs
     static int cus = 0;
     if (!cus) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount; if (cus <= 0) cus = 256; }
     return cus;
@@ -661,6 +817,24 @@ extern "C" int pdp_neural_gru(pdp_problem *p, const pdp_gru_desc *d, const float
     PDP_REQUIRE(g.Kpx <= 64 * PRE_C && g.Kph <= 64 * PRE_C, "GRU wider than 192 inputs is not supported by the tile prefetch");
     int s = set_lds((const void *)k_gru, lds); if (s != PDP_OK) return s;
     hipLaunchKernelGGL(k_edge_active, dim3(1024), dim3(256), 0, st, E, p->graph_map, p->var_inst, active_mask, rowmask);
+    static const bool plain = getenv("PDP_NEURAL_GRU_PLAIN") != nullptr;
+    if (!plain && d->H == 128 && g.Kpx == 130) {
+        // hidden width 128 with a 129-wide input (config 3): pipelined kernel on the full tiles, the plain one on the ragged tail
+        const int full = E / TM, tail = E - full * TM;
+        if (full > 0) {
+            const size_t ldsp = lds + sizeof(float) * 2 * TM;
+            s = set_lds((const void *)k_gru_pipe<65, true>, ldsp); if (s != PDP_OK) return s;
+            const int grid = full < persistent_grid() ? full : persistent_grid();
+            hipLaunchKernelGGL((k_gru_pipe<65, true>), dim3(grid), dim3(NTN), ldsp, st, E, state, p->edge_sign, h, rowmask, g, out, full);
+        }
+        if (tail > 0) {
+            const size_t o = (size_t)full * TM;
+            hipLaunchKernelGGL(k_gru, dim3(1), dim3(NTN), lds, st, tail, state + o * g.dx, p->edge_sign + o, h + o * g.H, rowmask + o, g,
+                               out + o * g.H, 1);
+        }
+        PDP_LAUNCH_CHECK();
+        return PDP_OK;
+    }
     const int tiles = (E + TM - 1) / TM;
     int per_cu = 1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_gru, NTN, lds) != hipSuccess || per_cu < 1) per_cu = 1;

@@ -20,9 +20,12 @@ def dev_agg(w, fd):
     return native.AggregatorWeights(t(w['W1m']), t(w['b1m']), t(w['W2m']), t(w['W1a']), t(w['b1a']), t(w['W2a']), fd)
 
 
-@pytest.mark.parametrize('H,m1,a,g', [(32, 100, 50, 100), (128, 100, 50, 100), (20, 36, 17, 40)])
-def test_aggregator_gru_predict_bit_exact(oracle, H, m1, a, g):
+@pytest.mark.parametrize('H,m1,a,g,grid', [(32, 100, 50, 100, None), (128, 100, 50, 100, None), (20, 36, 17, 40, None),
+                                           (128, 100, 50, 100, 3), (32, 100, 50, 100, 2)])
+def test_aggregator_gru_predict_bit_exact(oracle, monkeypatch, H, m1, a, g, grid):
     from pdp import native
+    if grid:          # persistent kernels: many tiles per workgroup (cross-tile prefetch and the pipelined GRU's carried epilogue)
+        monkeypatch.setenv('PDP_NEURAL_GRID', str(grid))
     b = random_batch(batch=9, n=25, mixed=True, seed=77)
     hp, op = make_pair(oracle, b)
     hp.simplify(); op.simplify()
