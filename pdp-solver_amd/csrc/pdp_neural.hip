@@ -445,6 +445,130 @@ __global__ void __launch_bounds__(NTN) k_agg_post_res(int E, const float *__rest
     }
 }
 
+// ---- wave-private form of kernel 1 ---------------------------------------------------------------------------------------------------------
+// In the workgroup-tile kernels above the MFMA chains fetch their LDS operands just in time and the 64-column second layer occupies only
+// half of the waves between two barriers.  Here a wave owns a 32-edge tile from the input rows to the stored result: its input block and
+// (over the same LDS bytes) the hidden layer live in a private LDS region, each layer is one straight-line MFMA sequence with both
+// operands prefetched, and there is no workgroup barrier at all.  Measured on config 3 (tools/neural_ops_time.py): 10.4 -> 8.2 ms; the
+// pieces are additive (chains 3.2 ms + activations 2.1 ms + rest 3.1 ms): f32 MFMA and VALU work of the two waves of a SIMD do not
+// overlap, so what is left is instruction count.  The same form of the post-transform was built and measured: 12.8 ms against 12.5 ms for
+// k_agg_post (its gather / previous-state / store streams do not hide behind 2 waves per SIMD), so that kernel stays as it is.
+// Per element the arithmetic is the same chain and the same activation, so results are unchanged.
+#define WT 32              /* edges per wave tile */
+
+// NB column blocks of one layer as one straight-line sequence of NB * STEPS MFMAs (block after block, each block one k-ordered chain):
+// the A operands (LDS) are read one 8-step chunk ahead, the weight fragments (L2, buffer loads: lane offset in a VGPR, k-step offset as a
+// scalar) two chunks ahead, so no MFMA waits for an operand and the prefetch runs on across the block boundaries.
+template <int STEPS, int NB, int NP>
+__device__ __forceinline__ void wave_chains(const float *a /* LDS: row (lane & 31) of the block, column lane >> 5 */, __amdgpu_buffer_rsrc_t wr,
+                                            const float *__restrict__ bias, f32x16 (&acc)[NB])
+{
+    constexpr int T = STEPS * NB, CH = 8, NC = (T + CH - 1) / CH;
+    const int l = threadIdx.x & 63, i = l & 31, kh = l >> 5;
+    const int voff = (kh * NP + i) * (int)sizeof(float);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const float b0 = bias ? bias[32 * nb + i] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = b0;
+    }
+    auto wl = [&](int t) -> float {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wr, voff + (t / STEPS) * 32 * (int)sizeof(float),
+                                                                             (t % STEPS) * 2 * NP * (int)sizeof(float), 0));
+    };
+    float aa[2][CH], bb[3][CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        if (j < T) { bb[0][j] = wl(j); aa[0][j] = a[2 * (j % STEPS)]; }
+        if (CH + j < T) bb[1][j] = wl(CH + j);
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int t2 = (c + 2) * CH + j, t1 = (c + 1) * CH + j;
+            if (t2 < T) bb[(c + 2) % 3][j] = wl(t2);
+            if (t1 < T) aa[(c + 1) & 1][j] = a[2 * (t1 % STEPS)];
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int t = c * CH + j;
+            if (t < T) acc[t / STEPS] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[c & 1][j], bb[c % 3][j], acc[t / STEPS], 0, 0, 0);
+        }
+        // pure arithmetic is not ordered against scheduling barriers by itself: tie the chunk's accumulators to this point
+        asm volatile("" : "+v"(acc[(c * CH) / STEPS]));
+        if ((c * CH + CH - 1) / STEPS != (c * CH) / STEPS && (c * CH + CH - 1) / STEPS < NB) asm volatile("" : "+v"(acc[(c * CH + CH - 1) / STEPS]));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Specialised on the layer shapes (S = k-steps, NB = 32-column blocks); other shapes use the workgroup-tile kernels above.
+// k_agg_pre_wave: the input row is [128 message floats, edge sign, zero pad]: one dwordx2 per lane and row, and the whole next tile is
+// fetched into registers right after the current one has been dropped into LDS, so its HBM latency hides behind both layers.
+template <int S1, int NB1, int S2, int NB2>
+__global__ void __launch_bounds__(NTN) k_agg_pre_wave(int E, const float *__restrict__ state, const float *__restrict__ sign,
+                                                      const float *__restrict__ emask, AggW w, float *__restrict__ h2out, int ntiles)
+{
+    static_assert(2 * S1 == 130, "input row = 128 floats + sign + pad");
+    constexpr int ld = (2 * S1 > 32 * NB1 ? 2 * S1 : 32 * NB1) | 1;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, i = l & 31, kh = l >> 5;
+    float *X = sm + wave * WT * ld;                        // this wave's region: input block, then the hidden layer
+    const __amdgpu_buffer_rsrc_t w1 = __builtin_amdgcn_make_buffer_rsrc((void *)w.Wt1m, 0, 2 * S1 * 32 * NB1 * (int)sizeof(float), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w2 = __builtin_amdgcn_make_buffer_rsrc((void *)w.Wt2m, 0, 2 * S2 * 32 * NB2 * (int)sizeof(float), 0x00020000);
+    float2 pv[WT];
+    float psg = 0.0f;
+    auto fetch = [&](int tile) {
+        const int e0 = tile * WT;
+#pragma unroll
+        for (int r = 0; r < WT; ++r) {
+            const int e = e0 + r;
+            pv[r] = (e < E) ? reinterpret_cast<const float2 *>(state + (size_t)e * 128)[l] : make_float2(0.0f, 0.0f);
+        }
+        psg = (l < WT && e0 + l < E) ? sign[e0 + l] : 0.0f;
+    };
+    const int stride = gridDim.x * NWAVES;
+    int tile = blockIdx.x * NWAVES + wave;
+    if (tile < ntiles) fetch(tile);
+    for (; tile < ntiles; tile += stride) {
+        const int e0 = tile * WT;
+#pragma unroll
+        for (int r = 0; r < WT; ++r) { X[r * ld + 2 * l] = pv[r].x; X[r * ld + 2 * l + 1] = pv[r].y; }
+        if (l < WT) { X[l * ld + 128] = psg; X[l * ld + 129] = 0.0f; }
+        f32x16 acc[NB1];
+        wave_chains<S1, NB1, 32 * NB1>(X + i * ld + kh, w1, w.b1m, acc);
+        // HBM requests go out here, in front of the long activation phase: vector-memory results return in issue order, so a weight load of
+        // the next chain issued behind them would otherwise wait for a full HBM round trip
+        if (tile + stride < ntiles) fetch(tile + stride);
+        float em[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const int e = e0 + acc_row(r, l); em[r] = (emask && e < E) ? emask[e] : 1.0f; }
+        // every chain has consumed its operands (LDS operations of a wave complete in order): the hidden layer replaces the input block
+#pragma unroll
+        for (int nb = 0; nb < NB1; ++nb) {
+            const int col = 32 * nb + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) X[acc_row(r, l) * ld + col] = (col < w.m1) ? pdp_logsigmoidf(acc[nb][r]) : 0.0f;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x16 ac2[NB2];
+        wave_chains<S2, NB2, 32 * NB2>(X + i * ld + kh, w2, nullptr, ac2);
+#pragma unroll
+        for (int nb = 0; nb < NB2; ++nb) {
+            const int col = 32 * nb + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int e = e0 + acc_row(r, l);
+                if (e < E && col < w.a) {
+                    float v = pdp_logsigmoidf(ac2[nb][r]);
+                    if (emask) v = v * em[r];
+                    h2out[(size_t)e * w.a + col] = v;
+                }
+            }
+        }
+    }
+}
+
 // ---- kernel 4: predictor tail on variable tiles (include_self = True) + Perceptron head --------------------------------------------
 __global__ void __launch_bounds__(NTN) k_predict_rows(int V, const float *__restrict__ agg, AggW w, HeadW hd, float *__restrict__ pred)
 {
@@ -744,13 +868,21 @@ static int persistent_grid()
     return cus;
 }
 
-// aggregator pre-transform: resident-weight persistent form when both matrices and the tile fit the LDS, tile-per-workgroup form otherwise
+// aggregator pre-transform: wave-private form (default); resident-weight persistent form when both matrices and the tile fit the LDS, tile-per-workgroup form otherwise
 static int launch_agg_pre(int E, const float *state, const float *sign, const float *edge_mask, const AggW &w, float *h2, hipStream_t st)
 {
     const int tiles = (E + TM - 1) / TM;
     const size_t lds1 = sizeof(float) * (size_t)TM * ((w.Kp1 + 1) + (w.Np1 + 1));
     const size_t res1 = sizeof(float) * ((size_t)w.Kp1 * w.Np1 + (size_t)w.Kp2 * w.Np2) + lds1;
-    if (res1 <= LDS_RES_LIMIT && w.Kp1 <= 64 * PRE_C) {
+    static const bool tile_form = getenv("PDP_NEURAL_AGG_TILE") != nullptr;
+    if (!tile_form && w.din - 1 == 128 && w.Kp1 == 130 && w.Np1 == 128 && w.Kp2 == 100 && w.Np2 == 64) {       // config 3's shapes
+        constexpr int ldw = 131;
+        const size_t ldsw = sizeof(float) * (size_t)NWAVES * WT * ldw;
+        int s = set_lds((const void *)k_agg_pre_wave<65, 4, 50, 2>, ldsw); if (s != PDP_OK) return s;
+        const int wt = (E + WT - 1) / WT, need = (wt + NWAVES - 1) / NWAVES;
+        const int grid = need < persistent_grid() ? need : persistent_grid();
+        hipLaunchKernelGGL((k_agg_pre_wave<65, 4, 50, 2>), dim3(grid), dim3(NTN), ldsw, st, E, state, sign, edge_mask, w, h2, wt);
+    } else if (res1 <= LDS_RES_LIMIT && w.Kp1 <= 64 * PRE_C) {
         int s = set_lds((const void *)k_agg_pre_res, res1); if (s != PDP_OK) return s;
         const int grid = tiles < persistent_grid() ? tiles : persistent_grid();
         hipLaunchKernelGGL(k_agg_pre_res, dim3(grid), dim3(NTN), res1, st, E, state, w.din - 1, sign, edge_mask, w, h2, tiles);
