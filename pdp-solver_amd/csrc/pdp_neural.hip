@@ -569,6 +569,57 @@ __global__ void __launch_bounds__(NTN) k_agg_pre_wave(int E, const float *__rest
     }
 }
 
+// ---- kernel 3 with prefetched chains (config 3's shapes) ---------------------------------------------------------------------------------
+// Same workgroup-tile structure as k_agg_post (three workgroups per CU hide its gather / previous-state / store streams), but every wave's
+// block is a straight-line wave_chains sequence: both operands prefetched instead of fetched just in time.
+template <int S3, int NB3, int S4, int NB4>
+__global__ void __launch_bounds__(NTN, 6) k_agg_post_pf(int E, const float *__restrict__ agg, const int32_t *__restrict__ edge_row,
+                                                        const float *__restrict__ h2, const float *__restrict__ sign,
+                                                        const float *__restrict__ emask, const float *__restrict__ rowmask,
+                                                        const float *__restrict__ old, AggW w, float *__restrict__ out)
+{
+    static_assert(NB3 * 2 == NWAVES && NB4 * 2 == NWAVES, "one 32x32 block per wave and layer");
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int ld0 = 2 * S3 + 1, ld1 = 32 * NB3 + 1;
+    float *Rt = sm, *G1 = sm + TM * ld0;
+    const int e0 = blockIdx.x * TM;
+    for (int idx = threadIdx.x; idx < TM * 2 * S3; idx += NTN) {
+        const int r = idx / (2 * S3), c = idx % (2 * S3);
+        const int e = e0 + r;
+        float v = 0.0f;
+        if (e < E) {
+            if (c < w.a) {
+                const float own = emask ? h2[(size_t)e * w.a + c] * emask[e] : h2[(size_t)e * w.a + c];
+                v = (0.0f + agg[(size_t)edge_row[e] * w.a + c]) - own;
+            } else if (c == w.a && w.fd) v = sign[e];
+        }
+        Rt[r * ld0 + c] = v;
+    }
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, i = l & 31, kh = l >> 5;
+    const int nb = wave >> 1, mb = wave & 1, col = 32 * nb + i;
+    const __amdgpu_buffer_rsrc_t w3 = __builtin_amdgcn_make_buffer_rsrc((void *)(w.Wt1a + 32 * nb), 0, (2 * S3 * 32 * NB3 - 32 * nb) * (int)sizeof(float), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w4 = __builtin_amdgcn_make_buffer_rsrc((void *)(w.Wt2a + 32 * nb), 0, (2 * S4 * 32 * NB4 - 32 * nb) * (int)sizeof(float), 0x00020000);
+    __syncthreads();
+    {
+        f32x16 acc[1];
+        wave_chains<S3, 1, 32 * NB3>(Rt + (32 * mb + i) * ld0 + kh, w3, w.b1a + 32 * nb, acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) G1[(32 * mb + acc_row(r, l)) * ld1 + col] = (col < w.g) ? pdp_logsigmoidf(acc[0][r]) : 0.0f;
+    }
+    __syncthreads();
+    f32x16 acc[1];
+    wave_chains<S4, 1, 32 * NB4>(G1 + (32 * mb + i) * ld1 + kh, w4, nullptr, acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int e = e0 + 32 * mb + acc_row(r, l);
+        if (e < E && col < w.out) {
+            const float nv = pdp_logsigmoidf(acc[0][r]);
+            const float mk = rowmask ? rowmask[e] : 1.0f;
+            out[(size_t)e * w.out + col] = mk * nv + (1.0f - mk) * old[(size_t)e * w.out + col];
+        }
+    }
+}
+
 // ---- kernel 4: predictor tail on variable tiles (include_self = True) + Perceptron head --------------------------------------------
 __global__ void __launch_bounds__(NTN) k_predict_rows(int V, const float *__restrict__ agg, AggW w, HeadW hd, float *__restrict__ pred)
 {
@@ -921,7 +972,12 @@ extern "C" int pdp_neural_aggregate_edges(pdp_problem *p, const pdp_agg_desc *d,
     // the post-transform has little MFMA work per tile and a gather-heavy tile load: three small workgroups per CU (tile-per-workgroup
     // form) overlap better than one resident one (12.8 vs 18.3 ms at config 3), so the resident form is opt-in
     static const bool post_res = getenv("PDP_NEURAL_POST_RESIDENT") != nullptr;
-    if (post_res && res3 <= LDS_RES_LIMIT && w.Kp3 <= 64 * PRE_C) {
+    static const bool post_plain = getenv("PDP_NEURAL_POST_PLAIN") != nullptr;
+    if (!post_res && !post_plain && w.Kp3 == 52 && w.Np3 == 128 && w.Kp4 == 100 && w.Np4 == 128) {                   // config 3's shapes
+        const size_t ldsp = sizeof(float) * (size_t)TM * (53 + 129);
+        s = set_lds((const void *)k_agg_post_pf<26, 4, 50, 4>, ldsp); if (s != PDP_OK) return s;
+        hipLaunchKernelGGL((k_agg_post_pf<26, 4, 50, 4>), dim3(tiles), dim3(NTN), ldsp, st, E, agg, edge_row, h2, p->edge_sign, edge_mask, rowmask, old, w, out);
+    } else if (post_res && res3 <= LDS_RES_LIMIT && w.Kp3 <= 64 * PRE_C) {
         s = set_lds((const void *)k_agg_post_res, res3); if (s != PDP_OK) return s;
         const int grid = tiles < persistent_grid() ? tiles : persistent_grid();
         hipLaunchKernelGGL(k_agg_post_res, dim3(grid), dim3(NTN), res3, st, E, agg, edge_row, h2, p->edge_sign, edge_mask, rowmask, old, w, out, tiles);
