@@ -56,6 +56,34 @@ def cpu_baseline(args):
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 vector peak
 
 
+def cpu_baseline_neural(args):
+    """The oracle's operators of one np-nd-np iteration (2 edge aggregators, 2 GRU cells, predictor aggregator + head), single thread,
+    on a few instances of the same family with random weights of the same shapes; scaled linearly to the batch."""
+    sys.path.insert(0, REPO)
+    from oracle import binding
+    binding.build()
+    bs, H = 60, args.hidden
+    b = dataset.collate_segment(dataset.random_ksat_items(bs, args.n, 3, m=int(round(4.2 * args.n)), seed=777))
+    gm = np.asarray(b['graph_map']); ev, ec = gm[0].astype(np.int32), gm[1].astype(np.int32)
+    es = np.asarray(b['edge_feature'], dtype=np.float32).reshape(-1)
+    E, V, F = ev.size, int(np.asarray(b['batch_variable_map']).size), int(np.asarray(b['batch_function_map']).size)
+    rng = np.random.RandomState(1)
+    r = lambda *sh: (rng.randn(*sh) * 0.2).astype(np.float32)
+    agg = lambda fd: dict(W1m=r(100, H + 1), b1m=r(100), W2m=r(50, 100), W1a=r(100, 50 + fd), b1a=r(100), W2a=r(H, 100))
+    wv, wf, wp = agg(1), agg(1), agg(0)
+    gv = dict(W_ih=r(3 * H, H + 1), W_hh=r(3 * H, H), b_ih=r(3 * H), b_hh=r(3 * H)); gf = dict(gv)
+    head = (r(50, H), r(50), r(1, 50))
+    dv, df, pv, pf = r(E, H), r(E, H), r(E, H), r(E, H)
+    t0 = time.perf_counter()
+    pf2 = binding.aggregator(ev, V, dv, es, None, False, wv); pv2 = binding.aggregator(ec, F, df, es, None, False, wf)
+    dv2 = binding.gru(pv2, es, dv, **gv); df2 = binding.gru(pf2, es, df, **gf)
+    binding.perceptron(binding.aggregator(ev, V, dv2, es, None, True, wp), *head)
+    dt = time.perf_counter() - t0
+    return dict(value=bs / dt / args.batch, unit='iterations/s (batch of %d instances)' % args.batch, cores=1, kind='port',
+                sample='one np-nd-np iteration (2 aggregators, 2 GRU cells, predictor) of %d instances of the same n=%d family, hidden %d, '
+                       'in %.1f s, scaled linearly to the batch' % (bs, args.n, H, dt))
+
+
 def bench_neural(args, dev, rank, world):
     """configs[2]: fully neural PDP (np-nd-np, hidden_dim 128, layer widths 100/100/50/50) on random 3-SAT n=200.
     A step = T iterations of propagate (2 deep-set aggregators) / decimate (2 GRU cells) / predict / terminate on a resident
@@ -108,6 +136,7 @@ def bench_neural(args, dev, rank, world):
     if rank == 0:
         iters_all = float(tot[0].item())
         value = iters_all / elapsed
+        cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline_neural(args)
         flops_iter = 573752.0 * E + 48500.0 * V
         achieved = flops_iter * float(np.mean(iters_done)) / (float(np.mean(step_ms)) * 1e-3) / 1e12
         print(json.dumps({
@@ -120,9 +149,9 @@ def bench_neural(args, dev, rank, world):
                        'E': E, 'V': V, 'F': F, 'iterations_per_step': float(np.mean(iters_done)), 'path': model.last_run['path'],
                        'instance_iterations_per_sec': value * args.batch, 'parallelism': 'instances sharded, dp%d' % world},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / MFMA_F32_PEAK_TFLOPS,
-                         'traffic': None, 'kernel': 'k_gru / k_agg_pre / k_agg_post (v_mfma_f32_32x32x2_f32)',
+                         'traffic': None, 'kernel': 'k_gru_pipe / k_agg_pre_wave / k_agg_post_pf (v_mfma_f32_32x32x2_f32)',
                          'note': 'achieved = (573752 E + 48500 V) flop per iteration x iterations / step time (whole step, all kernels)'},
-            'cpu_baseline': None}))
+            'cpu_baseline': cpu}))
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
