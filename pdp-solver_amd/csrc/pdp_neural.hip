@@ -925,7 +925,7 @@ static int launch_agg_pre(int E, const float *state, const float *sign, const fl
     const int tiles = (E + TM - 1) / TM;
     const size_t lds1 = sizeof(float) * (size_t)TM * ((w.Kp1 + 1) + (w.Np1 + 1));
     const size_t res1 = sizeof(float) * ((size_t)w.Kp1 * w.Np1 + (size_t)w.Kp2 * w.Np2) + lds1;
-    static const bool tile_form = getenv("PDP_NEURAL_AGG_TILE") != nullptr;
+    const bool tile_form = getenv("PDP_NEURAL_AGG_TILE") != nullptr;
     if (!tile_form && w.din - 1 == 128 && w.Kp1 == 130 && w.Np1 == 128 && w.Kp2 == 100 && w.Np2 == 64) {       // config 3's shapes
         constexpr int ldw = 131;
         const size_t ldsw = sizeof(float) * (size_t)NWAVES * WT * ldw;
@@ -971,8 +971,8 @@ extern "C" int pdp_neural_aggregate_edges(pdp_problem *p, const pdp_agg_desc *d,
     const size_t res3 = sizeof(float) * ((size_t)w.Kp3 * w.Np3 + (size_t)w.Kp4 * w.Np4) + lds3;
     // the post-transform has little MFMA work per tile and a gather-heavy tile load: three small workgroups per CU (tile-per-workgroup
     // form) overlap better than one resident one (12.8 vs 18.3 ms at config 3), so the resident form is opt-in
-    static const bool post_res = getenv("PDP_NEURAL_POST_RESIDENT") != nullptr;
-    static const bool post_plain = getenv("PDP_NEURAL_POST_PLAIN") != nullptr;
+    const bool post_res = getenv("PDP_NEURAL_POST_RESIDENT") != nullptr;
+    const bool post_plain = getenv("PDP_NEURAL_POST_PLAIN") != nullptr;
     if (!post_res && !post_plain && w.Kp3 == 52 && w.Np3 == 128 && w.Kp4 == 100 && w.Np4 == 128) {                   // config 3's shapes
         const size_t ldsp = sizeof(float) * (size_t)TM * (53 + 129);
         s = set_lds((const void *)k_agg_post_pf<26, 4, 50, 4>, ldsp); if (s != PDP_OK) return s;
@@ -1005,7 +1005,7 @@ extern "C" int pdp_neural_gru(pdp_problem *p, const pdp_gru_desc *d, const float
     PDP_REQUIRE(g.Kpx <= 64 * PRE_C && g.Kph <= 64 * PRE_C, "GRU wider than 192 inputs is not supported by the tile prefetch");
     int s = set_lds((const void *)k_gru, lds); if (s != PDP_OK) return s;
     hipLaunchKernelGGL(k_edge_active, dim3(1024), dim3(256), 0, st, E, p->graph_map, p->var_inst, active_mask, rowmask);
-    static const bool plain = getenv("PDP_NEURAL_GRU_PLAIN") != nullptr;
+    const bool plain = getenv("PDP_NEURAL_GRU_PLAIN") != nullptr;
     if (!plain && d->H == 128 && g.Kpx == 130) {
         // hidden width 128 with a 129-wide input (config 3): pipelined kernel on the full tiles, the plain one on the ragged tail
         const int full = E / TM, tail = E - full * TM;

@@ -112,3 +112,40 @@ def test_clause_counts_rederived_and_deterministic(big):
     assert iters2 == iters
     for a, b in ((q, q2), (fs, fs2), (hp.active_variables, hp2.active_variables), (am, am2)):
         np.testing.assert_array_equal(npy(a), npy(b))
+
+
+def test_neural_operator_forms_agree_at_full_size(big, oracle, monkeypatch):
+    """configs[2] shapes (hidden 128, 12.6 M edges): the specialised kernels (in-wave pipelined GRU, wave-private / prefetched aggregator
+    halves, many tiles per persistent workgroup) give bit for bit what the plain tile kernels give, an active mask with holes included;
+    a sample of GRU rows is checked against the oracle (the cell is row-wise, so a sample of rows is an exact check)."""
+    from pdp import native
+    _, host, tb = big
+    dev = torch.device('cuda:0')
+    p = native.Problem(tb['graph_map'], tb['batch_variable_map'], tb['batch_function_map'], tb['edge_feature'])
+    E, H = p.E, 128
+    g = torch.Generator(device='cpu'); g.manual_seed(5)
+    r = lambda *s: (torch.randn(*s, generator=g) * 0.2).to(dev)
+    gw_host = [r(3 * H, H + 1), r(3 * H, H), r(3 * H), r(3 * H)]
+    gw = native.GruWeights(*gw_host)
+    aw = native.AggregatorWeights(r(100, H + 1), r(100), r(50, 100), r(100, 51), r(100), r(H, 100), 1)
+    state = torch.randn(E, H, device=dev) * 0.5
+    h = torch.randn(E, H, device=dev) * 0.5
+    am = (torch.rand(p.B, device=dev) > 0.2).to(torch.uint8)
+    new_gru = p.neural_gru(gw, state, h, am)
+    new_agg = [p.neural_aggregate_edges(aw, bv, state, None, am, h) for bv in (True, False)]
+    for k in ('PDP_NEURAL_GRU_PLAIN', 'PDP_NEURAL_AGG_TILE', 'PDP_NEURAL_POST_PLAIN'):
+        monkeypatch.setenv(k, '1')
+    old_gru = p.neural_gru(gw, state, h, am)
+    assert torch.equal(new_gru, old_gru)
+    del old_gru
+    for bv, new in zip((True, False), new_agg):
+        assert torch.equal(new, p.neural_aggregate_edges(aw, bv, state, None, am, h))
+    # oracle on a sample of edges
+    rng = np.random.RandomState(3)
+    idx = np.sort(rng.choice(E, 4096, replace=False))
+    ti = torch.from_numpy(idx).to(dev)
+    gm = npy(tb['graph_map']); vi = npy(tb['batch_variable_map'])
+    mask = npy(am)[vi[gm[0][idx]]].astype(np.float32)
+    es = npy(tb['edge_feature']).reshape(-1)[idx]
+    ref = oracle.gru(npy(state[ti]), es, npy(h[ti]), *[npy(w) for w in gw_host], mask=mask)
+    np.testing.assert_array_equal(npy(new_gru[ti]), ref)
