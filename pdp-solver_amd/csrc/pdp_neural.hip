@@ -774,7 +774,8 @@ __device__ __forceinline__ void gru_phase(const float *xa, const float *ha, __am
         // (pure arithmetic is not ordered against the scheduling barriers by itself: the empty asm statements here and in the
         //  activation slices tie the chunk's results to this point of the instruction stream)
         asm volatile("" : "+v"(ai), "+v"(ah));
-        // issue order inside the chunk: one MFMA (64 cycles on the matrix pipe), NV VALU instructions of the activation slice in its shadow
+        // issue order inside the chunk: one MFMA, NV VALU instructions of the activation slice, ... (measured: few long VALU runs beat many
+        // short ones -- NV = 4/3: 26.5 ms, 8/6: 24.8 ms, 26/16: 24.0 ms per call; every VALU run between two dependent MFMAs costs a fixed delay)
 #pragma unroll
         for (int j = 0; j < CH; ++j)
             if (lo + j < hi) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, NV, 0); }
@@ -844,7 +845,7 @@ __global__ void __launch_bounds__(NTN) k_gru_pipe(int E, const float *__restrict
         f32x16 ai, ah, rg;
         const __amdgpu_buffer_rsrc_t ob = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)e_prev * H), 0, TM * H * (int)sizeof(float), 0x00020000);
         const float *mp = Mk + (par ^ 1) * TM + row0;
-        gru_phase<SX, SH, 8>(xa, ha, wi, wh, voff, ws, bir, bhr, ai, ah, [&](int c) {
+        gru_phase<SX, SH, 26>(xa, ha, wi, wh, voff, ws, bir, bhr, ai, ah, [&](int c) {
             const int ro = (c & 3) + 8 * (c >> 2);
             const float ng = pdp_tanhf(tq[c]);
             const float hnew = (hq[c] - ng) * zg[c] + ng;
@@ -853,10 +854,10 @@ __global__ void __launch_bounds__(NTN) k_gru_pipe(int E, const float *__restrict
         });
 #pragma unroll
         for (int r = 0; r < 16; ++r) rg[r] = ah[r] + ai[r];
-        gru_phase<SX, SH, 6>(xa, ha, wi, wh, voff + H * (int)sizeof(float), ws, biz, bhz, ai, ah, [&](int c) { float v = pdp_sigmoidf(rg[c]); asm volatile("" : "+v"(v)); rg[c] = v; });
+        gru_phase<SX, SH, 16>(xa, ha, wi, wh, voff + H * (int)sizeof(float), ws, biz, bhz, ai, ah, [&](int c) { float v = pdp_sigmoidf(rg[c]); asm volatile("" : "+v"(v)); rg[c] = v; });
 #pragma unroll
         for (int r = 0; r < 16; ++r) zg[r] = ah[r] + ai[r];
-        gru_phase<SX, SH, 6>(xa, ha, wi, wh, voff + 2 * H * (int)sizeof(float), ws, bin, bhn, ai, ah, [&](int c) { float v = pdp_sigmoidf(zg[c]); asm volatile("" : "+v"(v)); zg[c] = v; });
+        gru_phase<SX, SH, 16>(xa, ha, wi, wh, voff + 2 * H * (int)sizeof(float), ws, bin, bhn, ai, ah, [&](int c) { float v = pdp_sigmoidf(zg[c]); asm volatile("" : "+v"(v)); zg[c] = v; });
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             tq[r] = ai[r] + ah[r] * rg[r];
