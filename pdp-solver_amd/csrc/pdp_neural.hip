@@ -583,19 +583,26 @@ __global__ void __launch_bounds__(NTN, 6) k_agg_post_pf(int E, const float *__re
     constexpr int ld0 = 2 * S3 + 1, ld1 = 32 * NB3 + 1;
     float *Rt = sm, *G1 = sm + TM * ld0;
     const int e0 = blockIdx.x * TM;
-    for (int idx = threadIdx.x; idx < TM * 2 * S3; idx += NTN) {
-        const int r = idx / (2 * S3), c = idx % (2 * S3);
-        const int e = e0 + r;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, i = l & 31, kh = l >> 5;
+    // tile rows: a wave takes 8 rows, lane c holds column c (2 S3 <= 64); the row's indices are wave-uniform (scalar loads, scalar address
+    // arithmetic) -- the element-indexed loop of k_agg_post spends ~1000 VALU instructions per wave and tile on divisions and 64-bit
+    // addresses, and VALU time adds to MFMA time on this chip
+    static_assert(2 * S3 <= 64, "one lane per input column");
+#pragma unroll
+    for (int jr = 0; jr < TM / NWAVES; ++jr) {
+        const int r = wave + NWAVES * jr, e = e0 + r;
         float v = 0.0f;
         if (e < E) {
-            if (c < w.a) {
-                const float own = emask ? h2[(size_t)e * w.a + c] * emask[e] : h2[(size_t)e * w.a + c];
-                v = (0.0f + agg[(size_t)edge_row[e] * w.a + c]) - own;
-            } else if (c == w.a && w.fd) v = sign[e];
+            const int row = edge_row[e];
+            const float sg = sign[e];
+            if (l < w.a) {
+                const float hv = h2[(size_t)e * w.a + l];
+                const float own = emask ? hv * emask[e] : hv;
+                v = (0.0f + agg[(size_t)row * w.a + l]) - own;
+            } else if (l == w.a && w.fd) v = sg;
         }
-        Rt[r * ld0 + c] = v;
+        if (l < 2 * S3) Rt[r * ld0 + l] = v;
     }
-    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, i = l & 31, kh = l >> 5;
     const int nb = wave >> 1, mb = wave & 1, col = 32 * nb + i;
     const __amdgpu_buffer_rsrc_t w3 = __builtin_amdgcn_make_buffer_rsrc((void *)(w.Wt1a + 32 * nb), 0, (2 * S3 * 32 * NB3 - 32 * nb) * (int)sizeof(float), 0x00020000);
     const __amdgpu_buffer_rsrc_t w4 = __builtin_amdgcn_make_buffer_rsrc((void *)(w.Wt2a + 32 * nb), 0, (2 * S4 * 32 * NB4 - 32 * nb) * (int)sizeof(float), 0x00020000);
@@ -607,16 +614,26 @@ __global__ void __launch_bounds__(NTN, 6) k_agg_post_pf(int E, const float *__re
         for (int r = 0; r < 16; ++r) G1[(32 * mb + acc_row(r, l)) * ld1 + col] = (col < w.g) ? pdp_logsigmoidf(acc[0][r]) : 0.0f;
     }
     __syncthreads();
+    // blend operands and result through buffer accesses with a per-tile base (lane offset in a VGPR, row offset as a scalar, rows past E
+    // clipped by the descriptor); the previous state is requested before the last layer's chain
+    constexpr int ROWB = 32 * NB4 * (int)sizeof(float);
+    const int rows = E - e0 < TM ? E - e0 : TM;
+    const __amdgpu_buffer_rsrc_t ob = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)e0 * 32 * NB4), 0, rows * ROWB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t pb = __builtin_amdgcn_make_buffer_rsrc((void *)(old + (size_t)e0 * 32 * NB4), 0, rows * ROWB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mb_ = __builtin_amdgcn_make_buffer_rsrc((void *)(rowmask ? rowmask + e0 : old), 0, rows * (int)sizeof(float), 0x00020000);
+    const int lo = (32 * mb + 4 * kh) * ROWB + col * (int)sizeof(float), lm = (32 * mb + 4 * kh) * (int)sizeof(float);
+    float po[16], mk[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) po[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pb, lo, ((r & 3) + 8 * (r >> 2)) * ROWB, 0));
     f32x16 acc[1];
     wave_chains<S4, 1, 32 * NB4>(G1 + (32 * mb + i) * ld1 + kh, w4, nullptr, acc);
 #pragma unroll
+    for (int r = 0; r < 16; ++r)
+        mk[r] = rowmask ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mb_, lm, ((r & 3) + 8 * (r >> 2)) * (int)sizeof(float), 0)) : 1.0f;
+#pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int e = e0 + 32 * mb + acc_row(r, l);
-        if (e < E && col < w.out) {
-            const float nv = pdp_logsigmoidf(acc[0][r]);
-            const float mk = rowmask ? rowmask[e] : 1.0f;
-            out[(size_t)e * w.out + col] = mk * nv + (1.0f - mk) * old[(size_t)e * w.out + col];
-        }
+        const float nv = pdp_logsigmoidf(acc[0][r]);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mk[r] * nv + (1.0f - mk[r]) * po[r]), ob, lo, ((r & 3) + 8 * (r >> 2)) * ROWB, 0);
     }
 }
 
@@ -974,7 +991,7 @@ extern "C" int pdp_neural_aggregate_edges(pdp_problem *p, const pdp_agg_desc *d,
     // form) overlap better than one resident one (12.8 vs 18.3 ms at config 3), so the resident form is opt-in
     const bool post_res = getenv("PDP_NEURAL_POST_RESIDENT") != nullptr;
     const bool post_plain = getenv("PDP_NEURAL_POST_PLAIN") != nullptr;
-    if (!post_res && !post_plain && w.Kp3 == 52 && w.Np3 == 128 && w.Kp4 == 100 && w.Np4 == 128) {                   // config 3's shapes
+    if (!post_res && !post_plain && w.Kp3 == 52 && w.Np3 == 128 && w.Kp4 == 100 && w.Np4 == 128 && w.out == 128) {                   // config 3's shapes
         const size_t ldsp = sizeof(float) * (size_t)TM * (53 + 129);
         s = set_lds((const void *)k_agg_post_pf<26, 4, 50, 4>, ldsp); if (s != PDP_OK) return s;
         hipLaunchKernelGGL((k_agg_post_pf<26, 4, 50, 4>), dim3(tiles), dim3(NTN), ldsp, st, E, agg, edge_row, h2, p->edge_sign, edge_mask, rowmask, old, w, out);
