@@ -503,7 +503,7 @@ __device__ __forceinline__ void wave_chains(const float *a /* LDS: row (lane & 3
 }
 
 // Specialised on the layer shapes (S = k-steps, NB = 32-column blocks); other shapes use the workgroup-tile kernels above.
-// k_agg_pre_wave: the input row is [128 message floats, edge sign, zero pad]: one dwordx2 per lane and row, and the whole next tile is
+// k_agg_pre_wave: the input row is [128 message floats, edge sign, zero pad]: two dwords per lane and row, and the whole next tile is
 // fetched into registers right after the current one has been dropped into LDS, so its HBM latency hides behind both layers.
 template <int S1, int NB1, int S2, int NB2>
 __global__ void __launch_bounds__(NTN) k_agg_pre_wave(int E, const float *__restrict__ state, const float *__restrict__ sign,
@@ -512,20 +512,30 @@ __global__ void __launch_bounds__(NTN) k_agg_pre_wave(int E, const float *__rest
     static_assert(2 * S1 == 130, "input row = 128 floats + sign + pad");
     constexpr int ld = (2 * S1 > 32 * NB1 ? 2 * S1 : 32 * NB1) | 1;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, i = l & 31, kh = l >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, i = l & 31, kh = l >> 5;
     float *X = sm + wave * WT * ld;                        // this wave's region: input block, then the hidden layer
     const __amdgpu_buffer_rsrc_t w1 = __builtin_amdgcn_make_buffer_rsrc((void *)w.Wt1m, 0, 2 * S1 * 32 * NB1 * (int)sizeof(float), 0x00020000);
     const __amdgpu_buffer_rsrc_t w2 = __builtin_amdgcn_make_buffer_rsrc((void *)w.Wt2m, 0, 2 * S2 * 32 * NB2 * (int)sizeof(float), 0x00020000);
+    // All tile traffic goes through buffer accesses with a per-tile base (scalar arithmetic), the lane offset in one VGPR and the row offset
+    // as a scalar; rows past E are clipped by the descriptor (loads return 0, stores are dropped) -- no per-element 64-bit addresses or
+    // bounds tests in the vector ALU, whose time adds to the MFMA time.
+    auto tile_rsrc = [&](const float *base, int e0, int row_bytes) {
+        const int rows = E - e0 < WT ? E - e0 : WT;
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(base + (size_t)e0 * (row_bytes / (int)sizeof(float))), 0, rows * row_bytes, 0x00020000);
+    };
     float2 pv[WT];
     float psg = 0.0f;
     auto fetch = [&](int tile) {
         const int e0 = tile * WT;
+        const __amdgpu_buffer_rsrc_t sb = tile_rsrc(state, e0, 128 * (int)sizeof(float)), gb = tile_rsrc(sign, e0, (int)sizeof(float));
 #pragma unroll
         for (int r = 0; r < WT; ++r) {
-            const int e = e0 + r;
-            pv[r] = (e < E) ? reinterpret_cast<const float2 *>(state + (size_t)e * 128)[l] : make_float2(0.0f, 0.0f);
+            // (two dword loads, columns l and 64 + l: the b64 / b128 forms of the raw buffer load builtin come out of this hipcc as ONE
+            //  buffer_load_dword -- checked in the ISA)
+            pv[r].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sb, l * 4, r * 128 * (int)sizeof(float), 0));
+            pv[r].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sb, l * 4 + 256, r * 128 * (int)sizeof(float), 0));
         }
-        psg = (l < WT && e0 + l < E) ? sign[e0 + l] : 0.0f;
+        psg = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gb, l * 4, 0, 0));       // lanes >= 32 read past the tile: 0
     };
     const int stride = gridDim.x * NWAVES;
     int tile = blockIdx.x * NWAVES + wave;
@@ -533,7 +543,7 @@ __global__ void __launch_bounds__(NTN) k_agg_pre_wave(int E, const float *__rest
     for (; tile < ntiles; tile += stride) {
         const int e0 = tile * WT;
 #pragma unroll
-        for (int r = 0; r < WT; ++r) { X[r * ld + 2 * l] = pv[r].x; X[r * ld + 2 * l + 1] = pv[r].y; }
+        for (int r = 0; r < WT; ++r) { X[r * ld + l] = pv[r].x; X[r * ld + 64 + l] = pv[r].y; }
         if (l < WT) { X[l * ld + 128] = psg; X[l * ld + 129] = 0.0f; }
         f32x16 acc[NB1];
         wave_chains<S1, NB1, 32 * NB1>(X + i * ld + kh, w1, w.b1m, acc);
@@ -541,8 +551,11 @@ __global__ void __launch_bounds__(NTN) k_agg_pre_wave(int E, const float *__rest
         // the next chain issued behind them would otherwise wait for a full HBM round trip
         if (tile + stride < ntiles) fetch(tile + stride);
         float em[16];
+        if (emask) {
+            const __amdgpu_buffer_rsrc_t eb = tile_rsrc(emask, e0, (int)sizeof(float));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { const int e = e0 + acc_row(r, l); em[r] = (emask && e < E) ? emask[e] : 1.0f; }
+            for (int r = 0; r < 16; ++r) em[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(eb, 16 * kh, ((r & 3) + 8 * (r >> 2)) * 4, 0));
+        }
         // every chain has consumed its operands (LDS operations of a wave complete in order): the hidden layer replaces the input block
 #pragma unroll
         for (int nb = 0; nb < NB1; ++nb) {
@@ -553,16 +566,17 @@ __global__ void __launch_bounds__(NTN) k_agg_pre_wave(int E, const float *__rest
         }
         f32x16 ac2[NB2];
         wave_chains<S2, NB2, 32 * NB2>(X + i * ld + kh, w2, nullptr, ac2);
+        const int rowb = w.a * (int)sizeof(float);                           // h2 rows are a floats wide
+        const __amdgpu_buffer_rsrc_t hb = tile_rsrc(h2out, e0, rowb);
+        const int lo = 4 * kh * rowb + i * (int)sizeof(float);
 #pragma unroll
         for (int nb = 0; nb < NB2; ++nb) {
-            const int col = 32 * nb + i;
+            if (32 * nb + i < w.a) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int e = e0 + acc_row(r, l);
-                if (e < E && col < w.a) {
+                for (int r = 0; r < 16; ++r) {
                     float v = pdp_logsigmoidf(ac2[nb][r]);
                     if (emask) v = v * em[r];
-                    h2out[(size_t)e * w.a + col] = v;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), hb, lo + nb * 128, ((r & 3) + 8 * (r >> 2)) * rowb, 0);
                 }
             }
         }
