@@ -62,7 +62,7 @@ def cpu_baseline_neural(args):
     sys.path.insert(0, REPO)
     from oracle import binding
     binding.build()
-    bs, H = 60, args.hidden
+    bs, H = 400, args.hidden
     b = dataset.collate_segment(dataset.random_ksat_items(bs, args.n, 3, m=int(round(4.2 * args.n)), seed=777))
     gm = np.asarray(b['graph_map']); ev, ec = gm[0].astype(np.int32), gm[1].astype(np.int32)
     es = np.asarray(b['edge_feature'], dtype=np.float32).reshape(-1)
