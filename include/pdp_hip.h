@@ -87,6 +87,18 @@ int pdp_instance_argmax(pdp_problem *p, const float *x, int64_t *out, void *stre
 int pdp_sp_propagate(pdp_problem *p, const float *dec_q, const float *dec_fs, const float *edge_mask,
                      const uint8_t *active_mask, const float *init_q, const float *init_fs, float pi,
                      float *out_q, float *out_fs, void *stream);
+
+/* ---- adaptor form of the propagator (model type p-nd-np) ------------------------------------------
+ * replaces: the include_adaptors=True branches of SurveyPropagator.forward (pdp_propagate.py:166-167, 179-182).
+ * dec_v / dec_f [E,H] = neural decimator state; w_f [H] = _function_input_projector.weight, W_v [2,H] =
+ * _variable_input_projector.weight; outputs xlog [E] = logsigmoid(w_f . dec_v) and fs2 [E,2] =
+ * (sigmoid(W_v[0] . dec_f), sign(W_v[1] . dec_f)). */
+int pdp_sp_adaptors(pdp_problem *p, int H, const float *dec_v, const float *dec_f, const float *w_f, const float *W_v,
+                    float *xlog, float *fs2, void *stream);
+/* pdp_sp_propagate with the clause-to-variable input already in the log domain (xlog [E] from pdp_sp_adaptors) */
+int pdp_sp_propagate_adapted(pdp_problem *p, const float *xlog, const float *dec_fs, const float *edge_mask,
+                             const uint8_t *active_mask, const float *init_q, const float *init_fs, float pi,
+                             float *out_q, float *out_fs, void *stream);
 /* K6 replaces: SurveyScorer.forward (pdp_predict.py:155-192): fs [E,2] -> score [V] */
 int pdp_survey_score(pdp_problem *p, const float *fs, float pi, float *score, void *stream);
 

@@ -144,6 +144,13 @@ class Problem(object):
                                _p(_f(init_q)), _p(_f(init_fs)), C.c_float(pi), _p(oq), _p(ofs))
         return oq, ofs
 
+    def sp_propagate_adapted(self, xlog, dec_fs, edge_mask, active_mask, init_q, init_fs, pi=0.0):
+        oq = np.zeros((self.E, 3), np.float32); ofs = np.zeros((self.E, 2), np.float32)
+        am = None if active_mask is None else np.ascontiguousarray(active_mask, dtype=np.uint8)
+        lib().orc_sp_propagate_adapted(self._h, _p(_f(xlog)), _p(_f(dec_fs)), _p(_f(edge_mask)), _p(am),
+                                       _p(_f(init_q)), _p(_f(init_fs)), C.c_float(pi), _p(oq), _p(ofs))
+        return oq, ofs
+
     def survey_score(self, fs, pi=0.0):
         out = np.zeros(self.V, np.float32)
         lib().orc_survey_score(self._h, _p(_f(fs)), C.c_float(pi), _p(out))
@@ -376,3 +383,66 @@ def neural_forward(problem, weights, init, T, trace=None):
     ls, _, _ = problem.local_search(p, 0, 0.5, seed=0)
     final = problem.update_solution(ls)
     return final, dict(prop_v=pv, prop_f=pf, dec_v=dv, dec_f=df, iterations=iters, active_mask=am)
+
+
+def pnd_weights(d, prefix='w__'):
+    "golden .npz -> tensors of the p-nd-np model (adaptor projections, two GRU cells, predictor)"
+    g = lambda k: d[prefix + k]
+    nw = dict(w_f=g('_propagator___function_input_projector__weight'), W_v=g('_propagator___variable_input_projector__weight'))
+    def agg(base):
+        return dict(W1m=g(base + '___W1_m__weight'), b1m=g(base + '___W1_m__bias'), W2m=g(base + '___W2_m__weight'),
+                    W1a=g(base + '___W1_a__weight'), b1a=g(base + '___W1_a__bias'), W2a=g(base + '___W2_a__weight'))
+    def cell(base):
+        return dict(W_ih=g(base + '__weight_ih'), W_hh=g(base + '__weight_hh'), b_ih=g(base + '__bias_ih'), b_hh=g(base + '__bias_hh'))
+    nw.update(gru_v=cell('_decimator___variable_rnn_cell'), gru_f=cell('_decimator___function_rnn_cell'),
+              pred=agg('_predictor___variable_aggregator'),
+              head=dict(W1=g('_predictor___variable_classifier___layer1__weight'), b1=g('_predictor___variable_classifier___layer1__bias'),
+                        W2=g('_predictor___variable_classifier___layer2__weight')))
+    return nw
+
+
+def sp_adaptors(dec_v, dec_f, w_f, W_v):
+    """include_adaptors=True inputs of the SP propagator (pdp_propagate.py:166-167, 179-182): k-ascending fmaf dot products,
+    xlog = logsigmoid(w_f . dec_v), eta = sigmoid(W_v[0] . dec_f), force = sign(W_v[1] . dec_f)"""
+    xlog = linear(dec_v, np.reshape(w_f, (1, -1)), None, 'logsigmoid')[:, 0]
+    b = linear(dec_f, W_v, None, 'none')
+    eta = math_apply('sigmoid', b[:, 0])
+    force = np.sign(b[:, 1]).astype(np.float32)
+    force[np.isnan(b[:, 1])] = 0.0                        # pdp_sign: (x > 0) - (x < 0)
+    return np.ascontiguousarray(xlog, dtype=np.float32), np.ascontiguousarray(np.stack((eta, force), 1), dtype=np.float32)
+
+
+def pnd_forward(problem, weights, init, T, trace=None):
+    """p-nd-np forward loop (solver.py:355-386: SP propagator with adaptors, neural decimator, neural predictor).
+    init = (q [E,3], fs [E,2], dec_v [E,H], dec_f [E,H])."""
+    ev, ec, es, vi, fi = problem.graph()
+    E, V, B = problem.E, problem.V, problem.B
+    q, fs, dv, df = [np.ascontiguousarray(x, dtype=np.float32) for x in init]
+    am = np.ones(B, np.uint8)
+    em = None
+    iters = 0
+    for t in range(T):
+        mask = am[vi[ev]].astype(np.float32)
+        xlog, fs2 = sp_adaptors(dv, df, weights['w_f'], weights['W_v'])
+        q, fs = problem.sp_propagate_adapted(xlog, fs2, em, am, q, fs, 0.0)
+        dv = gru(q, es, dv, mask=mask, **weights['gru_v'])
+        df = gru(fs, es, df, mask=mask, **weights['gru_f'])
+        m, s = problem.refresh_edge_mask()
+        if s < E:
+            em = m
+        agg = aggregator(ev, V, dv, es, em, True, weights['pred'])
+        p = perceptron(agg, weights['head']['W1'], weights['head']['b1'], weights['head']['W2'])[:, 0]
+        pred = problem.update_solution(p)
+        if trace is not None:
+            trace.append(dict(prop_q=q.copy(), prop_fs=fs.copy(), dec_v=dv.copy(), dec_f=df.copy(), pred=pred.copy()))
+        am = problem.check_termination(am, pred)
+        if trace is not None:
+            trace[-1]['active_mask'] = am.copy()
+        iters = t + 1
+        if am.sum() <= 0:
+            break
+    agg = aggregator(ev, V, dv, es, em, True, weights['pred'])
+    p = perceptron(agg, weights['head']['W1'], weights['head']['b1'], weights['head']['W2'])[:, 0]
+    ls, _, _ = problem.local_search(p, 0, 0.5, seed=0)
+    final = problem.update_solution(ls)
+    return final, dict(q=q, fs=fs, dec_v=dv, dec_f=df, iterations=iters, active_mask=am)

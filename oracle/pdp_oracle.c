@@ -383,9 +383,27 @@ ORC_API void orc_instance_argmax(const orc_problem *p, const float *x /*[V]*/, i
  * (include_adaptors = False).  q_* are [E,3] row-major, fs_* are [E,2] row-major.
  * `dec_q`/`dec_fs` = decimator_state, `init_q`/`init_fs` = init_state (previous propagator state).
  * ------------------------------------------------------------------------------------------ */
+static void sp_propagate_impl(const orc_problem *p, int x_is_log, const float *dec_q, const float *dec_fs, const float *edge_mask,
+                              const uint8_t *active_mask, const float *init_q, const float *init_fs, float pi, float *out_q, float *out_fs);
+
 ORC_API void orc_sp_propagate(const orc_problem *p, const float *dec_q, const float *dec_fs, const float *edge_mask /*or NULL*/,
                               const uint8_t *active_mask /*[B] or NULL*/, const float *init_q, const float *init_fs,
                               float pi, float *out_q, float *out_fs)
+{
+    sp_propagate_impl(p, 0, dec_q, dec_fs, edge_mask, active_mask, init_q, init_fs, pi, out_q, out_fs);
+}
+
+/* the include_adaptors=True form (pdp_propagate.py:166-167): xlog [E] = logsigmoid(projection) is already in the log domain */
+ORC_API void orc_sp_propagate_adapted(const orc_problem *p, const float *xlog, const float *dec_fs, const float *edge_mask,
+                                      const uint8_t *active_mask, const float *init_q, const float *init_fs,
+                                      float pi, float *out_q, float *out_fs)
+{
+    sp_propagate_impl(p, 1, xlog, dec_fs, edge_mask, active_mask, init_q, init_fs, pi, out_q, out_fs);
+}
+
+/* SurveyPropagator.forward (pdp_propagate.py:139-221) */
+static void sp_propagate_impl(const orc_problem *p, int x_is_log, const float *dec_q, const float *dec_fs, const float *edge_mask,
+                              const uint8_t *active_mask, const float *init_q, const float *init_fs, float pi, float *out_q, float *out_fs)
 {
     const int E = p->E, V = p->V, F = p->F;
     float *x = (float *)xcalloc((size_t)E, sizeof(float));
@@ -394,7 +412,7 @@ ORC_API void orc_sp_propagate(const orc_problem *p, const float *dec_q, const fl
     float *P = (float *)xcalloc((size_t)V, sizeof(float));
     float *N = (float *)xcalloc((size_t)V, sizeof(float));
     for (int e = 0; e < E; ++e) {
-        x[e] = pdp_safe_log(dec_q[3 * e + 0], PDP_SP_EPS);
+        x[e] = x_is_log ? dec_q[e] : pdp_safe_log(dec_q[3 * e + 0], PDP_SP_EPS);
         y[e] = pdp_safe_log(1.0f - dec_fs[2 * e + 0], PDP_SP_EPS);
         if (edge_mask) { x[e] = x[e] * edge_mask[e]; y[e] = y[e] * edge_mask[e]; }
     }

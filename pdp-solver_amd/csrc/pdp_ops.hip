@@ -183,20 +183,23 @@ extern "C" int pdp_instance_argmax(pdp_problem *p, const float *x, int64_t *out,
 }
 
 // ---- K1-K3 ------------------------------------------------------------------------------------------------------
+// LOGX: dq is [E] and already holds the log-domain clause message (the adaptor form of the propagator, model type p-nd-np:
+// logsigmoid of a learned projection, pdp_propagate.py:166-167) instead of [E,3] surveys whose first column goes through safe_log
+template <bool LOGX>
 __global__ void __launch_bounds__(PDP_NT) k_sp_propagate(PView pv, const float *dq, const float *dfs, const float *emask,
                                                          const uint8_t *amask, const float *iq, const float *ifs, float pi,
                                                          float *oq, float *ofs, float *xs, float *ys, float *Sw, float *Pw, float *Nw)
 {
     const Inst I = load_inst(pv, blockIdx.x);
     const int tid = threadIdx.x, nt = blockDim.x;
-    dq += 3 * (size_t)I.e0; dfs += 2 * (size_t)I.e0; iq += 3 * (size_t)I.e0; ifs += 2 * (size_t)I.e0;
+    dq += (LOGX ? 1 : 3) * (size_t)I.e0; dfs += 2 * (size_t)I.e0; iq += 3 * (size_t)I.e0; ifs += 2 * (size_t)I.e0;
     oq += 3 * (size_t)I.e0; ofs += 2 * (size_t)I.e0;
     xs += I.e0; ys += I.e0; Sw += I.f0; Pw += I.v0; Nw += I.v0;
     const float *em = emask ? emask + I.e0 : nullptr;
     const float mask = amask ? (0.0f + (0.0f + (float)amask[I.b])) : 1.0f;
     const float L0 = pdp_safe_log(1.0f - pi * 0.0f, PDP_SP_EPS), L1 = pdp_safe_log(1.0f - pi * 1.0f, PDP_SP_EPS);
     for (int e = tid; e < I.e; e += nt) {
-        float x = pdp_safe_log(dq[3 * e], PDP_SP_EPS);
+        float x = LOGX ? dq[e] : pdp_safe_log(dq[3 * e], PDP_SP_EPS);
         float y = pdp_safe_log(1.0f - dfs[2 * e], PDP_SP_EPS);
         if (em) { x = x * em[e]; y = y * em[e]; }
         xs[e] = x; ys[e] = y;
@@ -240,7 +243,64 @@ extern "C" int pdp_sp_propagate(pdp_problem *p, const float *dec_q, const float 
 {
     PDP_REQUIRE(p && dec_q && dec_fs && init_q && init_fs && out_q && out_fs, "NULL argument");
     PDP_REQUIRE(out_q != dec_q && out_q != init_q && out_fs != dec_fs && out_fs != init_fs, "outputs must not alias inputs");
-    hipLaunchKernelGGL(k_sp_propagate, dim3(p->B), dim3(PDP_NT), 0, ST(stream), make_view(p), dec_q, dec_fs, edge_mask,
+    hipLaunchKernelGGL(k_sp_propagate<false>, dim3(p->B), dim3(PDP_NT), 0, ST(stream), make_view(p), dec_q, dec_fs, edge_mask,
+                       active_mask, init_q, init_fs, pi, out_q, out_fs, p->ws_e[0], p->ws_e[1], p->ws_f[0], p->ws_v[0], p->ws_v[1]);
+    PDP_LAUNCH_CHECK();
+    return PDP_OK;
+}
+
+// ---- adaptor form of the propagator (model type p-nd-np) -----------------------------------------------------------------------
+// replaces: the include_adaptors=True branches of SurveyPropagator.forward (pdp_propagate.py:166-167, 179-182): per edge
+//   xlog = logsigmoid(w_f . dec_v[e]),  eta = sigmoid(W_v[0] . dec_f[e]),  force = sign(W_v[1] . dec_f[e])
+// with every dot product the k-ascending fmaf chain from 0 that the oracle computes.  A wave takes 64 edges: their rows go through LDS
+// (coalesced 256-byte row segments in, one lane per edge out), 64 columns at a time.
+__global__ void __launch_bounds__(256) k_sp_adaptors(int E, int H, const float *__restrict__ dv, const float *__restrict__ df,
+                                                     const float *__restrict__ wf, const float *__restrict__ Wv,
+                                                     float *__restrict__ xlog, float *__restrict__ fs2)
+{
+    __shared__ float tile[4][64 * 65];
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    float *T = tile[wave];
+    for (int64_t e0 = ((int64_t)blockIdx.x * 4 + wave) * 64; e0 < E; e0 += (int64_t)gridDim.x * 256) {
+        const int64_t e = e0 + l;
+        float a = 0.0f, b0 = 0.0f, b1 = 0.0f;
+        for (int pass = 0; pass < 2; ++pass) {
+            const float *src = pass == 0 ? dv : df;
+            for (int c0 = 0; c0 < H; c0 += 64) {
+                const int nc = H - c0 < 64 ? H - c0 : 64;
+                for (int r = 0; r < 64; ++r) {
+                    const int64_t er = e0 + r;
+                    T[r * 65 + l] = (er < E && l < nc) ? src[er * H + c0 + l] : 0.0f;
+                }
+                if (pass == 0) { for (int k = 0; k < nc; ++k) a = fmaf(T[l * 65 + k], wf[c0 + k], a); }
+                else { for (int k = 0; k < nc; ++k) { const float v = T[l * 65 + k]; b0 = fmaf(v, Wv[c0 + k], b0); b1 = fmaf(v, Wv[H + c0 + k], b1); } }
+            }
+        }
+        if (e < E) {
+            xlog[e] = pdp_logsigmoidf(a);
+            fs2[2 * e + 0] = pdp_sigmoidf(b0);
+            fs2[2 * e + 1] = pdp_sign(b1);
+        }
+    }
+}
+
+extern "C" int pdp_sp_adaptors(pdp_problem *p, int H, const float *dec_v, const float *dec_f, const float *w_f, const float *W_v,
+                               float *xlog, float *fs2, void *stream)
+{
+    PDP_REQUIRE(p && dec_v && dec_f && w_f && W_v && xlog && fs2 && H > 0, "NULL argument");
+    const int64_t groups = ((int64_t)p->E + 255) / 256;
+    hipLaunchKernelGGL(k_sp_adaptors, dim3((unsigned)(groups < 4096 ? (groups < 1 ? 1 : groups) : 4096)), dim3(256), 0, ST(stream), p->E, H, dec_v, dec_f, w_f, W_v, xlog, fs2);
+    PDP_LAUNCH_CHECK();
+    return PDP_OK;
+}
+
+extern "C" int pdp_sp_propagate_adapted(pdp_problem *p, const float *xlog, const float *dec_fs, const float *edge_mask,
+                                        const uint8_t *active_mask, const float *init_q, const float *init_fs, float pi,
+                                        float *out_q, float *out_fs, void *stream)
+{
+    PDP_REQUIRE(p && xlog && dec_fs && init_q && init_fs && out_q && out_fs, "NULL argument");
+    PDP_REQUIRE(out_q != init_q && out_fs != dec_fs && out_fs != init_fs, "outputs must not alias inputs");
+    hipLaunchKernelGGL(k_sp_propagate<true>, dim3(p->B), dim3(PDP_NT), 0, ST(stream), make_view(p), xlog, dec_fs, edge_mask,
                        active_mask, init_q, init_fs, pi, out_q, out_fs, p->ws_e[0], p->ws_e[1], p->ws_f[0], p->ws_v[0], p->ws_v[1]);
     PDP_LAUNCH_CHECK();
     return PDP_OK;

@@ -21,7 +21,7 @@ MODEL_SP, MODEL_WALKSAT, MODEL_REINFORCE = 0, 1, 2
 EXPORTED_SYMBOLS = [
     'pdp_abi_version', 'pdp_last_error', 'pdp_device_count', 'pdp_problem_create', 'pdp_problem_destroy',
     'pdp_problem_dims', 'pdp_problem_export_graph', 'pdp_problem_bind_state', 'pdp_simplify', 'pdp_set_variables',
-    'pdp_refresh_edge_mask', 'pdp_smooth_max', 'pdp_instance_max', 'pdp_instance_argmax', 'pdp_sp_propagate',
+    'pdp_refresh_edge_mask', 'pdp_smooth_max', 'pdp_instance_max', 'pdp_instance_argmax', 'pdp_sp_propagate', 'pdp_sp_adaptors', 'pdp_sp_propagate_adapted',
     'pdp_survey_score', 'pdp_cnf_eval', 'pdp_update_solution', 'pdp_check_termination', 'pdp_decimator_create',
     'pdp_decimator_destroy', 'pdp_decimator_reset', 'pdp_sequential_decimate', 'pdp_sequential_decimate_gate',
     'pdp_sequential_decimate_apply', 'pdp_reinforce_decimate', 'pdp_reinforce_predict', 'pdp_energy',
@@ -280,6 +280,25 @@ class Problem(object):
                                      ptr(init_q, torch.float32, 3 * self.E, 'init_state[0]'),
                                      ptr(init_fs, torch.float32, 2 * self.E, 'init_state[1]'),
                                      C.c_float(pi), ptr(out_q), ptr(out_fs), _stream()))
+        return out_q, out_fs
+
+    def sp_adaptors(self, dec_v, dec_f, w_f, W_v):
+        "adaptor form of the propagator inputs (p-nd-np): [E,H] decimator states -> xlog [E], fs2 [E,2]"
+        H = dec_v.shape[1]
+        xlog = torch.empty(self.E, dtype=torch.float32, device=self.device)
+        fs2 = torch.empty(self.E, 2, dtype=torch.float32, device=self.device)
+        check(lib().pdp_sp_adaptors(self._h, C.c_int(H), ptr(dec_v, torch.float32, self.E * H, 'decimator_state[0]'),
+                                    ptr(dec_f, torch.float32, self.E * H, 'decimator_state[1]'), ptr(w_f, torch.float32, H, 'w_f'),
+                                    ptr(W_v, torch.float32, 2 * H, 'W_v'), ptr(xlog), ptr(fs2), _stream()))
+        return xlog, fs2
+
+    def sp_propagate_adapted(self, xlog, dec_fs, edge_mask, active_mask, init_q, init_fs, pi=0.0):
+        out_q = torch.empty(self.E, 3, dtype=torch.float32, device=self.device)
+        out_fs = torch.empty(self.E, 2, dtype=torch.float32, device=self.device)
+        check(lib().pdp_sp_propagate_adapted(self._h, ptr(xlog, torch.float32, self.E, 'xlog'), ptr(dec_fs, torch.float32, 2 * self.E, 'fs2'),
+                                             ptr(edge_mask, torch.float32, self.E, 'edge_mask'), ptr(active_mask, torch.uint8, self.B, 'active_mask'),
+                                             ptr(init_q, torch.float32, 3 * self.E, 'init_state[0]'), ptr(init_fs, torch.float32, 2 * self.E, 'init_state[1]'),
+                                             C.c_float(pi), ptr(out_q), ptr(out_fs), _stream()))
         return out_q, out_fs
 
     def survey_score(self, fs, pi=0.0):

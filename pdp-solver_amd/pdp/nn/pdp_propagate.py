@@ -69,18 +69,21 @@ class NeuralMessagePasser(nn.Module):
 
 
 class SurveyPropagator(nn.Module):
-    "Survey Propagation in the log domain (reference: pdp_propagate.py:114-221), adaptors not supported natively."
+    """Survey Propagation in the log domain (reference: pdp_propagate.py:114-221).  With ``include_adaptors`` (model type
+    p-nd-np) two bias-free linear maps turn the neural decimator's [E, H] states into the propagator's inputs
+    (pdp_propagate.py:128-131, 166-167, 179-182); the parameter names are the reference's, so its checkpoints load."""
 
     def __init__(self, device, decimator_dimension, include_adaptors=False, pi=0.0):
         super(SurveyPropagator, self).__init__()
-        if include_adaptors:
-            raise native.NativeError("SurveyPropagator(include_adaptors=True) (model type p-nd-np) is not runnable in the "
-                                     "reference either (SURVEY.md App. B-5) and has no native kernel")
         self._device = device
         self._function_message_dim = 3
         self._variable_message_dim = 2
-        self._include_adaptors = False
+        self._include_adaptors = include_adaptors
         self._pi = float(pi)
+        if include_adaptors:
+            self._variable_input_projector = nn.Linear(decimator_dimension, self._variable_message_dim, bias=False)
+            self._function_input_projector = nn.Linear(decimator_dimension, 1, bias=False)
+            self._module_list = nn.ModuleList([self._variable_input_projector, self._function_input_projector])
 
     def forward(self, init_state, decimator_state, sat_problem, is_training, active_mask=None):
         if len(decimator_state) == 3:
@@ -90,9 +93,14 @@ class SurveyPropagator(nn.Module):
             edge_mask = None
         init_q, init_fs = init_state
         am = None if active_mask is None else active_mask.reshape(-1).contiguous()
-        return sat_problem._native.sp_propagate(dec_q.contiguous(), dec_fs.contiguous(),
-                                                None if edge_mask is None else edge_mask.reshape(-1).contiguous(),
-                                                am, init_q.contiguous(), init_fs.contiguous(), self._pi)
+        em = None if edge_mask is None else edge_mask.reshape(-1).contiguous()
+        nat = sat_problem._native
+        if self._include_adaptors:
+            xlog, fs2 = nat.sp_adaptors(dec_q.contiguous(), dec_fs.contiguous(),
+                                        self._function_input_projector.weight.data.reshape(-1).contiguous(),
+                                        self._variable_input_projector.weight.data.contiguous())
+            return nat.sp_propagate_adapted(xlog, fs2, em, am, init_q.contiguous(), init_fs.contiguous(), self._pi)
+        return nat.sp_propagate(dec_q.contiguous(), dec_fs.contiguous(), em, am, init_q.contiguous(), init_fs.contiguous(), self._pi)
 
     def get_init_state(self, graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, randomized, batch_replication):
         "reference: pdp_propagate.py:223-237 (random draws come from the torch CPU generator, like the reference on CPU)"

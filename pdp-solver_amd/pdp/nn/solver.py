@@ -339,6 +339,26 @@ class NeuralPropagatorDecimatorSolver(PropagatorDecimatorSolverBase):
             local_search_iterations=local_search_iterations, epsilon=epsilon, rng=rng, seed=seed)
 
 
+class NeuralSurveyPropagatorSolver(PropagatorDecimatorSolverBase):
+    """SP propagator with learned adaptors + neural decimator + neural predictor (reference: solver.py:543-561, model type p-nd-np).
+    The reference builds its decimator with a function-message width of 1 against a propagator that emits [eta, force], and fails in
+    the first GRU call; here the width is the 2 the propagator has -- the golden trace this model is pinned to
+    (tests/golden/trace_p_nd_np.npz) comes from the reference with exactly that one-word change."""
+
+    def __init__(self, device, name, edge_dimension, meta_data_dimension, decimator_dimension, mem_hidden_dimension,
+                 agg_hidden_dimension, mem_agg_hidden_dimension, prediction_dimension, variable_classifier=None,
+                 function_classifier=None, dropout=0, local_search_iterations=0, epsilon=0.05, rng='torch', seed=0):
+        super(NeuralSurveyPropagatorSolver, self).__init__(
+            device=device, name=name,
+            propagator=pdp_propagate.SurveyPropagator(device, decimator_dimension, include_adaptors=True),
+            decimator=pdp_decimate.NeuralDecimator(device, (3, 2), meta_data_dimension, decimator_dimension, mem_hidden_dimension,
+                                                   mem_agg_hidden_dimension, agg_hidden_dimension, edge_dimension, dropout),
+            predictor=pdp_predict.NeuralPredictor(device, decimator_dimension, prediction_dimension, edge_dimension,
+                                                  meta_data_dimension, mem_hidden_dimension, agg_hidden_dimension,
+                                                  mem_agg_hidden_dimension, variable_classifier, function_classifier),
+            local_search_iterations=local_search_iterations, epsilon=epsilon, rng=rng, seed=seed)
+
+
 class NeuralSequentialDecimatorSolver(PropagatorDecimatorSolverBase):
     """Neural propagator + the sequential decimator scored by a neural predictor + identity predictor
     (reference: solver.py:616-637, model type np-d-np).  The decimator's survey gate reads column 0 of the neural
@@ -365,7 +385,7 @@ class NeuralSequentialDecimatorSolver(PropagatorDecimatorSolverBase):
 
 
 def build_neural_solver(device, config, perceptron_cls, common):
-    "model types np-nd-np and np-d-np (reference: trainer.py:51-60, 73-81)"
+    "model types np-nd-np, p-nd-np and np-d-np (reference: trainer.py:51-81)"
     if config['model_type'] == 'np-d-np':
         return NeuralSequentialDecimatorSolver(
             device=device, name=config['model_name'], edge_dimension=config['edge_feature_dim'],
@@ -374,8 +394,16 @@ def build_neural_solver(device, config, perceptron_cls, common):
             agg_hidden_dimension=config['agg_hidden_dim'], mem_agg_hidden_dimension=config['mem_agg_hidden_dim'],
             classifier_dimension=config['classifier_dim'], dropout=config.get('dropout', 0),
             tolerance=config['tolerance'], t_max=config['t_max'], **common)
+    if config['model_type'] == 'p-nd-np':
+        return NeuralSurveyPropagatorSolver(
+            device=device, name=config['model_name'], edge_dimension=config['edge_feature_dim'],
+            meta_data_dimension=config['meta_feature_dim'], decimator_dimension=config['hidden_dim'],
+            mem_hidden_dimension=config['mem_hidden_dim'], agg_hidden_dimension=config['agg_hidden_dim'],
+            mem_agg_hidden_dimension=config['mem_agg_hidden_dim'], prediction_dimension=config['prediction_dim'],
+            variable_classifier=perceptron_cls(config['hidden_dim'], config['classifier_dim'], config['prediction_dim']),
+            function_classifier=None, dropout=config.get('dropout', 0), **common)
     if config['model_type'] != 'np-nd-np':
-        raise NotImplementedError("model_type %r has no native implementation (np-nd-np, np-d-np, p-d-p, walk-sat, reinforce are available)"
+        raise NotImplementedError("model_type %r has no native implementation (np-nd-np, np-d-np, p-nd-np, p-d-p, walk-sat, reinforce are available)"
                                   % (config['model_type'],))
     return NeuralPropagatorDecimatorSolver(
         device=device, name=config['model_name'], edge_dimension=config['edge_feature_dim'],

@@ -48,11 +48,8 @@ class SatFactorGraphTrainer(FactorGraphTrainerBase):
         elif t == 'reinforce':
             model = solver.ReinforceSurveyPropagatorSolver(device=self._device, name=config['model_name'], pi=config['pi'],
                                                            decimation_probability=config['decimation_probability'], **common)
-        elif t in ('np-nd-np', 'np-d-np'):
+        elif t in ('np-nd-np', 'np-d-np', 'p-nd-np'):
             model = solver.build_neural_solver(self._device, config, Perceptron, common)
-        elif t == 'p-nd-np':
-            raise NotImplementedError("model_type 'p-nd-np' cannot run in the reference either (input-size mismatch, "
-                                      "SURVEY.md App. B-5); it has no native implementation")
         else:
             raise KeyError("unknown model_type %r" % (t,))
         if config.get('verbose'):

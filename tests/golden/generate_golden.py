@@ -501,6 +501,67 @@ def gen_np_d_np():
     save('trace_np_d_np', **out)
 
 
+
+def gen_p_nd_np():
+    """model type p-nd-np: SP propagator with learned adaptors + neural decimator + neural predictor (solver.py:543-561).
+    The reference cannot construct a runnable model (NeuralDecimator((3, 1), ...) against a propagator that emits
+    [eta, force]); the one-word shim below gives the decimator the function-message width 2 the propagator really has.  Everything
+    else is the unmodified reference."""
+    import pdp.nn.pdp_decimate as ref_dec
+    orig_init = ref_dec.NeuralDecimator.__init__
+
+    def shim_init(self, device, message_dimension, *a, **k):                  # B-5
+        orig_init(self, device, (3, 2) if message_dimension == (3, 1) else message_dimension, *a, **k)
+
+    lines = make_lines([(18, 60, (3,))] * 4 + [(14, 40, (2, 3, 4))] * 2, seed0=3100)
+    with open(os.path.join(HERE, 'pndnp_batch.jsonl'), 'w') as f:
+        f.write("\n".join(lines) + "\n")
+    gm, bvm, bfm, ef, lab, misc = batch_tensors(lines)
+    H, T = 32, 6
+    cfg = base_cfg('p-nd-np', hidden_dim=H, local_search_iteration=0)
+    ref_dec.NeuralDecimator.__init__ = shim_init
+    try:
+        tr, m = build(cfg, seed=2468)
+    finally:
+        ref_dec.NeuralDecimator.__init__ = orig_init
+    out = problem_arrays(gm, bvm, bfm, ef)
+    out.update(flat_state_dict(m))
+    with open(os.path.join(HERE, 'state_dict_alias_map_pndnp.json'), 'w') as f:
+        json.dump(alias_map(m), f, indent=0, sort_keys=True)
+    it = {'i': 0}
+    rec = {}
+    orig_check = tr._check_recurrence_termination
+
+    def check(active, prediction, sp):
+        i = it['i']
+        rec['pred_%d' % i] = np_(prediction[0][:, 0])
+        orig_check(active, prediction, sp)
+        rec['active_mask_%d' % i] = np_(active[:, 0])
+        it['i'] += 1
+
+    def prop_hook(mod, inp, outp):
+        rec['prop_q_%d' % it['i']] = np_(outp[0]); rec['prop_fs_%d' % it['i']] = np_(outp[1])
+
+    def dec_hook(mod, inp, outp):
+        rec['dec_v_%d' % it['i']] = np_(outp[0]); rec['dec_f_%d' % it['i']] = np_(outp[1])
+
+    h1 = m._propagator.register_forward_hook(prop_hook)
+    h2 = m._decimator.register_forward_hook(dec_hook)
+    torch.manual_seed(5)
+    with torch.no_grad():
+        st = m.get_init_state(gm, bvm, bfm, ef, None, randomized=True, batch_replication=1)
+        out['init_prop_q'] = np_(st[0][0]); out['init_prop_fs'] = np_(st[0][1])
+        out['init_dec_v'] = np_(st[1][0]); out['init_dec_f'] = np_(st[1][1])
+        pred, _ = m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm,
+                    edge_feature=ef, meta_data=None, is_training=False, iteration_num=T,
+                    check_termination=check, batch_replication=1)
+    h1.remove(); h2.remove()
+    out.update(rec)
+    out['final_prediction'] = np_(pred[0][:, 0])
+    out['meta'] = np.array([T, H, it['i']], dtype=np.int64)
+    save('trace_p_nd_np', **out)
+
+
 # ---- E. CLI -------------------------------------------------------------------------------------
 
 def gen_cli():
@@ -547,5 +608,7 @@ if __name__ == '__main__':
         gen_neural()
     if 'npdnp' in what:
         gen_np_d_np()
+    if 'pndnp' in what:
+        gen_p_nd_np()
     if 'cli' in what:
         gen_cli()

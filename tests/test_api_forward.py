@@ -208,3 +208,48 @@ def test_np_d_np_equals_reference_golden():
     np.testing.assert_allclose(ps[0].cpu().numpy(), d['final_prop_0'], rtol=3e-4, atol=3e-5)
     np.testing.assert_allclose(ps[1].cpu().numpy(), d['final_prop_1'], rtol=3e-4, atol=3e-5)
     np.testing.assert_array_equal(pred[0].cpu().numpy()[:, 0], d['final_prediction'])
+
+
+def test_p_nd_np_equals_reference_golden():
+    """model type p-nd-np (SP propagator with learned adaptors + neural decimator + neural predictor; BASELINE configs[4]) with the
+    reference's seeded random weights loaded through the aliased state dict (strict: same parameter names): per-iteration
+    predictions and states within fp tolerance of the reference trace (reference + the one-word App. B-5 shim, see
+    tests/golden/generate_golden.py::gen_p_nd_np), thresholded final assignment identical."""
+    import json
+    from pdp.trainer import SatFactorGraphTrainer
+    d = load_golden('trace_p_nd_np')
+    T, H, iters = [int(x) for x in d['meta']]
+    tr = SatFactorGraphTrainer(cfg('p-nd-np', hidden_dim=H, edge_feature_dim=1, meta_feature_dim=0, prediction_dim=1, mem_hidden_dim=100,
+                                   agg_hidden_dim=100, mem_agg_hidden_dim=50, classifier_dim=50, local_search_iteration=0), use_cuda=True, logger=LOG)
+    m = tr._model_list[0]
+    alias = json.load(open(os.path.join(REPO, 'tests', 'golden', 'state_dict_alias_map_pndnp.json')))
+    sd = {}
+    for key, canon in alias.items():
+        k = 'w__' + canon.replace('.', '__')
+        if key == '_global_step':
+            sd[key] = torch.zeros(1)
+        elif k in d.files:
+            sd[key] = torch.from_numpy(d[k])
+    m.load_state_dict(sd, strict=True)
+    dev = torch.device('cuda:0')
+    gm = torch.from_numpy(d['graph_map']).to(dev); bvm = torch.from_numpy(d['batch_variable_map']).to(dev)
+    bfm = torch.from_numpy(d['batch_function_map']).to(dev); ef = torch.from_numpy(d['edge_feature']).to(dev)
+    st = ((torch.from_numpy(d['init_prop_q']).to(dev), torch.from_numpy(d['init_prop_fs']).to(dev)),
+          (torch.from_numpy(d['init_dec_v']).to(dev), torch.from_numpy(d['init_dec_f']).to(dev)))
+    rec = []
+
+    def check(active, prediction, sp):
+        rec.append(prediction[0].reshape(-1).cpu().numpy().copy())
+        tr._check_recurrence_termination(active, prediction, sp)
+
+    with torch.no_grad():
+        pred, (ps, ds) = m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None,
+                           is_training=False, iteration_num=T, check_termination=check, batch_replication=1)
+    assert m.last_run['path'] == 'stepwise' and m.last_run['iterations'] == iters
+    for i, p in enumerate(rec):
+        np.testing.assert_allclose(p, d['pred_%d' % i], rtol=3e-4, atol=3e-5, err_msg='pred %d' % i)
+    np.testing.assert_allclose(ps[0].cpu().numpy(), d['prop_q_%d' % (iters - 1)], rtol=3e-4, atol=3e-5)
+    np.testing.assert_allclose(ps[1].cpu().numpy(), d['prop_fs_%d' % (iters - 1)], rtol=3e-4, atol=3e-5)
+    np.testing.assert_allclose(ds[0].cpu().numpy(), d['dec_v_%d' % (iters - 1)], rtol=3e-4, atol=3e-5)
+    np.testing.assert_allclose(ds[1].cpu().numpy(), d['dec_f_%d' % (iters - 1)], rtol=3e-4, atol=3e-5)
+    np.testing.assert_array_equal(pred[0].cpu().numpy()[:, 0], d['final_prediction'])

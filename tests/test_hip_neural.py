@@ -59,3 +59,39 @@ def test_aggregator_gru_predict_bit_exact(oracle, monkeypatch, H, m1, a, g, grid
     ref = oracle.perceptron(agg, hw['W1'], hw['b1'], hw['W2'])
     got = hp.neural_predict(dev_agg(wp, 0), native.HeadWeights(t(hw['W1']), t(hw['b1']), t(hw['W2']), 'sigmoid'), t(state), hp.edge_mask)
     np.testing.assert_array_equal(npy(got), ref)
+
+
+@pytest.mark.parametrize('H', [32, 128, 20])
+def test_sp_adaptors_and_adapted_propagate_bit_exact(oracle, H):
+    """adaptor form of the SP propagator (model type p-nd-np): the projections are k-ascending fmaf chains on both sides, so the
+    log-domain inputs and the propagated surveys equal the oracle's bit for bit; small-GRU shapes (3 + 1 and 2 + 1 inputs) too."""
+    from pdp import native
+    b = random_batch(batch=7, n=22, mixed=True, seed=91)
+    hp, op = make_pair(oracle, b)
+    hp.simplify(); op.simplify()
+    rng = np.random.RandomState(H + 5)
+    assign = np.zeros(op.V, np.float32); pick = rng.choice(op.V, size=op.V // 7, replace=False); assign[pick] = rng.randint(0, 2, len(pick)) * 2 - 1
+    hp.set_variables(t(assign)); op.set_variables(assign)
+    hp.refresh_edge_mask(); em, _ = op.refresh_edge_mask()
+    ev, ec, es, vi, fi = op.graph()
+    E, B = op.E, op.B
+    dv = (rng.randn(E, H) * 0.7).astype(np.float32); df = (rng.randn(E, H) * 0.7).astype(np.float32)
+    w_f = (rng.randn(1, H) * 0.4).astype(np.float32); W_v = (rng.randn(2, H) * 0.4).astype(np.float32)
+    xlog_ref, fs2_ref = oracle.sp_adaptors(dv, df, w_f, W_v)
+    xlog, fs2 = hp.sp_adaptors(t(dv), t(df), t(w_f.reshape(-1)), t(W_v))
+    np.testing.assert_array_equal(npy(xlog), xlog_ref)
+    np.testing.assert_array_equal(npy(fs2), fs2_ref)
+    am = (rng.rand(B) > 0.3).astype(np.uint8)
+    iq = rng.rand(E, 3).astype(np.float32); ifs = rng.rand(E, 2).astype(np.float32)
+    for use_em in (True, False):
+        q_ref, fs_ref = op.sp_propagate_adapted(xlog_ref, fs2_ref, em if use_em else None, am, iq, ifs, 0.0)
+        q, fs = hp.sp_propagate_adapted(xlog, fs2, hp.edge_mask if use_em else None, t(am), t(iq), t(ifs), 0.0)
+        np.testing.assert_array_equal(npy(q), q_ref); np.testing.assert_array_equal(npy(fs), fs_ref)
+    # the decimator's two GRU cells of this model type: [E,3] + sign and [E,2] + sign inputs
+    mask = am[vi[ev]].astype(np.float32)
+    s = lambda *sh: (rng.randn(*sh) * 0.3).astype(np.float32)
+    for width, inp in ((3, q_ref), (2, fs_ref)):
+        gw = dict(W_ih=s(3 * H, width + 1), W_hh=s(3 * H, H), b_ih=s(3 * H), b_hh=s(3 * H))
+        ref = oracle.gru(inp, es, dv, mask=mask, **gw)
+        got = hp.neural_gru(native.GruWeights(t(gw['W_ih']), t(gw['W_hh']), t(gw['b_ih']), t(gw['b_hh'])), t(inp), t(dv), t(am))
+        np.testing.assert_array_equal(npy(got), ref)

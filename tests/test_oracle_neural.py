@@ -27,3 +27,23 @@ def test_neural_forward_matches_reference(oracle, name):
             if key in d.files:
                 np.testing.assert_allclose(tr[k], d[key], rtol=RTOL, atol=ATOL, err_msg=key)
     np.testing.assert_array_equal(final, d['final_prediction'])
+
+
+def test_p_nd_np_forward_matches_reference(oracle):
+    """model type p-nd-np (SP propagator with adaptors + neural decimator + neural predictor).  The reference cannot construct this
+    model as written; the golden trace comes from the reference with the one-word shim in
+    tests/golden/generate_golden.py::gen_p_nd_np (function-message width 2), everything else unmodified."""
+    d = load_golden('trace_p_nd_np')
+    T, H, iters = [int(x) for x in d['meta']]
+    p = oracle.Problem(d['graph_map'], d['batch_variable_map'], d['batch_function_map'], d['edge_feature'])
+    p.simplify()
+    w = oracle.pnd_weights(d)
+    trace = []
+    final, st = oracle.pnd_forward(p, w, (d['init_prop_q'], d['init_prop_fs'], d['init_dec_v'], d['init_dec_f']), T, trace=trace)
+    assert st['iterations'] == iters
+    for i, tr in enumerate(trace):
+        np.testing.assert_allclose(tr['pred'], d['pred_%d' % i], rtol=RTOL, atol=ATOL, err_msg='pred %d' % i)
+        np.testing.assert_array_equal(tr['active_mask'], d['active_mask_%d' % i])
+        for k in ('prop_q', 'prop_fs', 'dec_v', 'dec_f'):
+            np.testing.assert_allclose(tr[k], d['%s_%d' % (k, i)], rtol=RTOL, atol=ATOL, err_msg='%s %d' % (k, i))
+    np.testing.assert_array_equal(final, d['final_prediction'])
