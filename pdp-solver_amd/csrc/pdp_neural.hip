@@ -836,32 +836,40 @@ __global__ void __launch_bounds__(NTN) k_gru_pipe(int E, const float *__restrict
     constexpr int ldx = 2 * SX + 1, ldh = 2 * SH + 1;
     float *X = sm, *Hs = sm + TM * ldx, *Mk = Hs + TM * ldh;     // Mk [2][TM]: row masks of the current and the previous tile
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-    static_assert(2 * SX - 2 == H, "input = [message of width H, edge sign, zero pad]");
-    // tile rows: 512 bytes of message and 512 bytes of hidden state per edge = one dwordx2 per lane and row; the sign column by wave 0
+    // input row = [message, edge sign, zero pad] of 2 SX floats.  WIDE (np-nd-np): the message is H = 128 floats, 512 bytes per edge = one
+    // dwordx2 per lane and row, the sign column by wave 0.  Narrow (p-nd-np: 3 or 2 survey columns): lane c loads column c of the row.
+    constexpr bool WIDE = 2 * SX - 2 == H;
+    static_assert(WIDE || 2 * SX <= 64, "narrow input rows: one lane per column");
+    const int dx = g.dx;
     float2 px[PRE_R], ph[PRE_R];
-    float psg = 0.0f;                                     // wave 0: edge sign, wave 1: row mask
+    float psg = 0.0f;                                     // wave 0: edge sign (WIDE), wave 1: row mask
     auto fetch = [&](int tile) {
         const int e0 = tile * TM;
 #pragma unroll
         for (int jr = 0; jr < PRE_R; ++jr) {
             const size_t e = (size_t)(e0 + wave + NWAVES * jr);
-            px[jr] = reinterpret_cast<const float2 *>(state + e * H)[l];
+            if constexpr (WIDE) px[jr] = reinterpret_cast<const float2 *>(state + e * H)[l];
+            else px[jr].x = (l < dx) ? state[e * dx + l] : (l == dx ? sign[e] : 0.0f);
             ph[jr] = reinterpret_cast<const float2 *>(hprev + e * H)[l];
         }
-        if (wave == 0) psg = sign[e0 + l];
+        if (WIDE && wave == 0) psg = sign[e0 + l];
         if (wave == 1) psg = MASK ? rowmask[e0 + l] : 1.0f;
     };
     auto deposit = [&](int par) {
 #pragma unroll
         for (int jr = 0; jr < PRE_R; ++jr) {
             const int r = wave + NWAVES * jr;
-            X[r * ldx + 2 * l] = px[jr].x; X[r * ldx + 2 * l + 1] = px[jr].y;
+            if constexpr (WIDE) { X[r * ldx + 2 * l] = px[jr].x; X[r * ldx + 2 * l + 1] = px[jr].y; }
+            else { if (l < 2 * SX) X[r * ldx + l] = px[jr].x; }
             Hs[r * ldh + 2 * l] = ph[jr].x; Hs[r * ldh + 2 * l + 1] = ph[jr].y;
         }
-        if (wave == 0) X[l * ldx + H] = psg;
+        if (WIDE && wave == 0) X[l * ldx + H] = psg;
         if (wave == 1) Mk[par * TM + l] = psg;
     };
-    if (threadIdx.x < TM) { X[threadIdx.x * ldx + H + 1] = 0.0f; Mk[threadIdx.x] = 0.0f; Mk[TM + threadIdx.x] = 0.0f; }   // zero pad column (never overwritten)
+    if (threadIdx.x < TM) {
+        if (WIDE) X[threadIdx.x * ldx + H + 1] = 0.0f;    // zero pad column (never overwritten)
+        Mk[threadIdx.x] = 0.0f; Mk[TM + threadIdx.x] = 0.0f;
+    }
     const int nb = wave >> 1, mb = wave & 1, i = l & 31, kh = l >> 5;
     const int col = 32 * nb + i;
     const int N3 = 3 * H;
@@ -1050,14 +1058,20 @@ extern "C" int pdp_neural_gru(pdp_problem *p, const pdp_gru_desc *d, const float
     int s = set_lds((const void *)k_gru, lds); if (s != PDP_OK) return s;
     hipLaunchKernelGGL(k_edge_active, dim3(1024), dim3(256), 0, st, E, p->graph_map, p->var_inst, active_mask, rowmask);
     const bool plain = getenv("PDP_NEURAL_GRU_PLAIN") != nullptr;
-    if (!plain && d->H == 128 && g.Kpx == 130) {
-        // hidden width 128 with a 129-wide input (config 3): pipelined kernel on the full tiles, the plain one on the ragged tail
+    if (!plain && d->H == 128 && (g.Kpx == 130 || g.Kpx == 4)) {
+        // hidden width 128 with a 129-wide input (np-nd-np, config 3) or a 4- / 3-wide one (p-nd-np: surveys + sign): pipelined kernel on
+        // the full tiles, the plain one on the ragged tail
         const int full = E / TM, tail = E - full * TM;
         if (full > 0) {
             const size_t ldsp = lds + sizeof(float) * 2 * TM;
-            s = set_lds((const void *)k_gru_pipe<65, true>, ldsp); if (s != PDP_OK) return s;
             const int grid = full < persistent_grid() ? full : persistent_grid();
-            hipLaunchKernelGGL((k_gru_pipe<65, true>), dim3(grid), dim3(NTN), ldsp, st, E, state, p->edge_sign, h, rowmask, g, out, full);
+            if (g.Kpx == 130) {
+                s = set_lds((const void *)k_gru_pipe<65, true>, ldsp); if (s != PDP_OK) return s;
+                hipLaunchKernelGGL((k_gru_pipe<65, true>), dim3(grid), dim3(NTN), ldsp, st, E, state, p->edge_sign, h, rowmask, g, out, full);
+            } else {
+                s = set_lds((const void *)k_gru_pipe<2, true>, ldsp); if (s != PDP_OK) return s;
+                hipLaunchKernelGGL((k_gru_pipe<2, true>), dim3(grid), dim3(NTN), ldsp, st, E, state, p->edge_sign, h, rowmask, g, out, full);
+            }
         }
         if (tail > 0) {
             const size_t o = (size_t)full * TM;

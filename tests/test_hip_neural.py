@@ -61,11 +61,13 @@ def test_aggregator_gru_predict_bit_exact(oracle, monkeypatch, H, m1, a, g, grid
     np.testing.assert_array_equal(npy(got), ref)
 
 
-@pytest.mark.parametrize('H', [32, 128, 20])
-def test_sp_adaptors_and_adapted_propagate_bit_exact(oracle, H):
+@pytest.mark.parametrize('H,grid', [(32, None), (128, None), (20, None), (128, 2)])
+def test_sp_adaptors_and_adapted_propagate_bit_exact(oracle, monkeypatch, H, grid):
     """adaptor form of the SP propagator (model type p-nd-np): the projections are k-ascending fmaf chains on both sides, so the
     log-domain inputs and the propagated surveys equal the oracle's bit for bit; small-GRU shapes (3 + 1 and 2 + 1 inputs) too."""
     from pdp import native
+    if grid:
+        monkeypatch.setenv('PDP_NEURAL_GRID', str(grid))
     b = random_batch(batch=7, n=22, mixed=True, seed=91)
     hp, op = make_pair(oracle, b)
     hp.simplify(); op.simplify()

@@ -1,6 +1,6 @@
 """configs[4]-shaped run on one GPU: mixed random k-SAT (k in {3,4,5}, n in [100,500]), batch_replication 4, dynamic batching, np-nd-np
 (hidden 128, seeded random weights) + Walk-SAT.  Prints segment sizes, time per iteration and the result-row statistics.
-Usage: python tools/mixed_neural_check.py [instances] [iterations]"""
+Usage: python tools/mixed_neural_check.py [instances] [iterations] [model_type: np-nd-np | p-nd-np]"""
 import sys, time, logging, io, json
 import numpy as np, torch
 sys.path.insert(0, '/root/repo/pdp-solver_amd')
@@ -8,6 +8,7 @@ from pdp.factorgraph import dataset
 from pdp.trainer import SatFactorGraphTrainer
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+MODEL = sys.argv[3] if len(sys.argv) > 3 else 'np-nd-np'
 rng = np.random.RandomState(0)
 alpha = {3: 0.9 * 4.27, 4: 0.9 * 9.93, 5: 0.9 * 21.12}
 items = []
@@ -16,7 +17,7 @@ for i in range(B):
     items += dataset.random_ksat_items(1, n, k, m=int(round(alpha[k] * n)), seed=1000 + i)
 edges = [it[2].shape[1] for it in items]
 print('instances %d, edges %d (min %d max %d per instance)' % (B, sum(edges), min(edges), max(edges)))
-cfg = dict(model_type='np-nd-np', model_name='mixed', verbose=False, local_search_iteration=100, epsilon=0.5, rng='philox', random_seed=1,
+cfg = dict(model_type=MODEL, model_name='mixed', verbose=False, local_search_iteration=100, epsilon=0.5, rng='philox', random_seed=1,
            hidden_dim=128, edge_feature_dim=1, meta_feature_dim=0, prediction_dim=1, mem_hidden_dim=100, agg_hidden_dim=100,
            mem_agg_hidden_dim=50, classifier_dim=50, test_batch_limit=int(4e9), batch_size=B, test_recurrence_num=T)
 torch.manual_seed(1234)
