@@ -253,27 +253,30 @@ extern "C" int pdp_sp_propagate(pdp_problem *p, const float *dec_q, const float 
 // replaces: the include_adaptors=True branches of SurveyPropagator.forward (pdp_propagate.py:166-167, 179-182): per edge
 //   xlog = logsigmoid(w_f . dec_v[e]),  eta = sigmoid(W_v[0] . dec_f[e]),  force = sign(W_v[1] . dec_f[e])
 // with every dot product the k-ascending fmaf chain from 0 that the oracle computes.  A wave takes 64 edges: their rows go through LDS
-// (coalesced 256-byte row segments in, one lane per edge out), 64 columns at a time.
-__global__ void __launch_bounds__(256) k_sp_adaptors(int E, int H, const float *__restrict__ dv, const float *__restrict__ df,
-                                                     const float *__restrict__ wf, const float *__restrict__ Wv,
-                                                     float *__restrict__ xlog, float *__restrict__ fs2)
+// (coalesced 128-byte row segments in, one lane per edge out), 32 columns at a time.
+__global__ void __launch_bounds__(64) k_sp_adaptors(int E, int H, const float *__restrict__ dv, const float *__restrict__ df,
+                                                    const float *__restrict__ wf, const float *__restrict__ Wv,
+                                                    float *__restrict__ xlog, float *__restrict__ fs2)
 {
-    __shared__ float tile[4][64 * 65];
-    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-    float *T = tile[wave];
-    for (int64_t e0 = ((int64_t)blockIdx.x * 4 + wave) * 64; e0 < E; e0 += (int64_t)gridDim.x * 256) {
+    __shared__ float T[64 * 33];                           // 64 edges x 32 columns (8.4 KB: many single-wave workgroups per CU)
+    const int l = threadIdx.x, half = l >> 5, c = l & 31;
+    for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < E; e0 += (int64_t)gridDim.x * 64) {
         const int64_t e = e0 + l;
         float a = 0.0f, b0 = 0.0f, b1 = 0.0f;
         for (int pass = 0; pass < 2; ++pass) {
             const float *src = pass == 0 ? dv : df;
-            for (int c0 = 0; c0 < H; c0 += 64) {
-                const int nc = H - c0 < 64 ? H - c0 : 64;
-                for (int r = 0; r < 64; ++r) {
-                    const int64_t er = e0 + r;
-                    T[r * 65 + l] = (er < E && l < nc) ? src[er * H + c0 + l] : 0.0f;
+            for (int c0 = 0; c0 < H; c0 += 32) {
+                const int nc = H - c0 < 32 ? H - c0 : 32;
+                float v[32];
+#pragma unroll
+                for (int j = 0; j < 32; ++j) {             // rows 2j and 2j + 1: two 128-byte row segments per load instruction
+                    const int64_t er = e0 + 2 * j + half;
+                    v[j] = (er < E && c < nc) ? src[er * H + c0 + c] : 0.0f;
                 }
-                if (pass == 0) { for (int k = 0; k < nc; ++k) a = fmaf(T[l * 65 + k], wf[c0 + k], a); }
-                else { for (int k = 0; k < nc; ++k) { const float v = T[l * 65 + k]; b0 = fmaf(v, Wv[c0 + k], b0); b1 = fmaf(v, Wv[H + c0 + k], b1); } }
+#pragma unroll
+                for (int j = 0; j < 32; ++j) T[(2 * j + half) * 33 + c] = v[j];
+                if (pass == 0) { for (int k = 0; k < nc; ++k) a = fmaf(T[l * 33 + k], wf[c0 + k], a); }
+                else { for (int k = 0; k < nc; ++k) { const float x = T[l * 33 + k]; b0 = fmaf(x, Wv[c0 + k], b0); b1 = fmaf(x, Wv[H + c0 + k], b1); } }
             }
         }
         if (e < E) {
@@ -288,8 +291,8 @@ extern "C" int pdp_sp_adaptors(pdp_problem *p, int H, const float *dec_v, const 
                                float *xlog, float *fs2, void *stream)
 {
     PDP_REQUIRE(p && dec_v && dec_f && w_f && W_v && xlog && fs2 && H > 0, "NULL argument");
-    const int64_t groups = ((int64_t)p->E + 255) / 256;
-    hipLaunchKernelGGL(k_sp_adaptors, dim3((unsigned)(groups < 4096 ? (groups < 1 ? 1 : groups) : 4096)), dim3(256), 0, ST(stream), p->E, H, dec_v, dec_f, w_f, W_v, xlog, fs2);
+    const int64_t groups = ((int64_t)p->E + 63) / 64;
+    hipLaunchKernelGGL(k_sp_adaptors, dim3((unsigned)(groups < 16384 ? (groups < 1 ? 1 : groups) : 16384)), dim3(64), 0, ST(stream), p->E, H, dec_v, dec_f, w_f, W_v, xlog, fs2);
     PDP_LAUNCH_CHECK();
     return PDP_OK;
 }
