@@ -105,6 +105,11 @@ int pdp_survey_score(pdp_problem *p, const float *fs, float pi, float *score, vo
 /* ---- K9 / K13 -------------------------------------------------------------------------------------
  * replaces: SatCNFEvaluator.forward (util.py:210-236): pred [V] -> solved [B], unsat_clauses [B] */
 int pdp_cnf_eval(pdp_problem *p, const float *pred, float *solved, float *unsat, void *stream);
+
+/* replaces: SatLossEvaluator.forward (util.py:178-197), the energy loss of a prediction reported by the test mode
+ * (trainer.py:108-123, base.py:223-250).  pred [V]; coeff = min(global_step^exploration, max_coeff) (host); loss_sharpness a
+ * positive integer; loss: device float [1] = mean over the clauses of the batch. */
+int pdp_sat_loss(pdp_problem *p, const float *pred, float coeff, float eps, int sharpness, float *loss, void *stream);
 /* replaces: PropagatorDecimatorSolverBase._update_solution (solver.py:388-399): out [V] */
 int pdp_update_solution(pdp_problem *p, const float *pred, float *out, void *stream);
 /* replaces: SatFactorGraphTrainer._check_recurrence_termination (trainer.py:150-162), replication aware */

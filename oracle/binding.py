@@ -162,6 +162,10 @@ class Problem(object):
         lib().orc_cnf_eval(self._h, _p(_f(pred)), _p(s), _p(u))
         return s, u
 
+    def sat_loss(self, pred, coeff, eps, sharpness):
+        lib().orc_sat_loss.restype = C.c_float
+        return float(lib().orc_sat_loss(self._h, _p(_f(pred)), C.c_float(coeff), C.c_float(eps), C.c_int(int(sharpness))))
+
     def update_solution(self, pred):
         out = np.zeros(self.V, np.float32)
         lib().orc_update_solution(self._h, _p(_f(pred)), _p(out))

@@ -512,6 +512,32 @@ ORC_API void orc_cnf_eval(const orc_problem *p, const float *pred /*[V]*/, float
     free(max_sat); free(batch_values);
 }
 
+/* Energy loss of a prediction.  reference: SatLossEvaluator.forward util.py:178-197 (test mode, trainer.py:108-123).
+ * The mean over the clauses is taken per instance (ascending clause id) and then over the instances (ascending id). */
+ORC_API float orc_sat_loss(const orc_problem *p, const float *pred /*[V]*/, float coeff, float eps, int sharpness)
+{
+    const int F = p->F, B = p->B;
+    float *inst_sum = (float *)xcalloc((size_t)B, sizeof(float));
+    for (int c = 0; c < F; ++c) {
+        float nom = 0.0f, den = 0.0f;
+        for (int k = p->fn_ptr[c]; k < p->fn_ptr[c + 1]; ++k) {
+            const int e = p->fn_edges[k];
+            const float s = p->edge_sign[e];
+            const float ev = s * pred[p->edge_var[e]] + (1.0f - s) / 2.0f;
+            const float w = pdp_expf(coeff * ev);
+            nom = nom + w * ev; den = den + w;
+        }
+        const float d = den / pdp_max_c(nom, eps) - 1.0f;
+        float pw = d;
+        for (int j = 1; j < sharpness; ++j) pw = pw * d;
+        inst_sum[p->fn_inst[c]] = inst_sum[p->fn_inst[c]] + pdp_safe_log(1.0f + pw, eps);
+    }
+    float acc = 0.0f;
+    for (int b = 0; b < B; ++b) acc = acc + inst_sum[b];
+    free(inst_sum);
+    return acc / (float)F;
+}
+
 /* K13. reference: PropagatorDecimatorSolverBase._update_solution solver.py:388-399 */
 ORC_API void orc_update_solution(orc_problem *p, const float *pred /*[V]*/, float *out /*[V]*/)
 {

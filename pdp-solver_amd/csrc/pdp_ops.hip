@@ -369,6 +369,54 @@ extern "C" int pdp_cnf_eval(pdp_problem *p, const float *pred, float *solved, fl
     return PDP_OK;
 }
 
+// ---- energy loss of a prediction (test mode: SatLossEvaluator.forward, util.py:178-197) ----------------------------------------
+// per edge   ev = s x_v + (1 - s) / 2,  w = exp(coeff ev);  per clause (edges in ascending id)  nom = sum w ev,  den = sum w,
+// cv = 1 + (den / max(nom, eps) - 1)^sharpness,  term = log(max(cv, eps));  loss = mean over all clauses of the batch.
+// The mean is taken in a fixed order (clauses of an instance in ascending id by one thread, then the instances in ascending id) so that
+// the CPU oracle reproduces it bit for bit; the reference's torch.mean uses another order (compared with a tolerance).
+__global__ void __launch_bounds__(PDP_NT) k_sat_loss(PView pv, const float *pred, float coeff, float eps, int sharpness, float *term, float *inst_sum)
+{
+    const Inst I = load_inst(pv, blockIdx.x);
+    pred += I.v0; term += I.f0;
+    for (int c = threadIdx.x; c < I.m; c += blockDim.x) {
+        float nom = 0.0f, den = 0.0f;
+        for (int k = I.f_ptr[c]; k < I.f_ptr[c + 1]; ++k) {
+            const int e = I.f_edges[k];
+            const float s = (float)I.sgn[e];
+            const float ev = s * pred[I.e_var[e]] + (1.0f - s) / 2.0f;
+            const float w = pdp_expf(coeff * ev);
+            nom = nom + w * ev; den = den + w;
+        }
+        const float d = den / pdp_max_c(nom, eps) - 1.0f;
+        float pw = d;
+        for (int j = 1; j < sharpness; ++j) pw = pw * d;
+        term[c] = pdp_safe_log(1.0f + pw, eps);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float acc = 0.0f;
+        for (int c = 0; c < I.m; ++c) acc = acc + term[c];
+        inst_sum[I.b] = acc;
+    }
+}
+
+__global__ void k_sat_loss_finish(int B, int F, const float *inst_sum, float *loss)
+{
+    float acc = 0.0f;
+    for (int b = 0; b < B; ++b) acc = acc + inst_sum[b];
+    loss[0] = acc / (float)F;
+}
+
+extern "C" int pdp_sat_loss(pdp_problem *p, const float *pred, float coeff, float eps, int sharpness, float *loss, void *stream)
+{
+    PDP_REQUIRE(p && pred && loss, "NULL argument");
+    PDP_REQUIRE(sharpness >= 1, "loss_sharpness must be a positive integer");
+    hipLaunchKernelGGL(k_sat_loss, dim3(p->B), dim3(PDP_NT), 0, ST(stream), make_view(p), pred, coeff, eps, sharpness, p->ws_f[0], p->ws_b[0]);
+    hipLaunchKernelGGL(k_sat_loss_finish, dim3(1), dim3(1), 0, ST(stream), p->B, p->F, p->ws_b[0], loss);
+    PDP_LAUNCH_CHECK();
+    return PDP_OK;
+}
+
 __global__ void k_update_solution(int V, const float *av, float *sol, const float *pred, float *out)
 {
     for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < V; v += (int64_t)gridDim.x * blockDim.x) {

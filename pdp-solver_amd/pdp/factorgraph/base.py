@@ -1,12 +1,14 @@
-"""Predict driver (reference: src/pdp/factorgraph/base.py, predict path :252-305,451-472).
+"""Predict and test drivers (reference: src/pdp/factorgraph/base.py, predict path :252-305,451-472, test path :183-250,406-449).
 
-The train / test loops of the reference's ``FactorGraphTrainerBase`` are out of scope;
-``predict`` keeps its signature.  There is no ``nn.DataParallel`` wrap (it mis-scatters ``graph_map``, SURVEY.md
+The training loop of the reference's ``FactorGraphTrainerBase`` is out of scope; ``predict`` and
+``test`` keep their signatures.  There is no ``nn.DataParallel`` wrap (it mis-scatters ``graph_map``, SURVEY.md
 App. B-13): multi-GPU runs shard instances across ranks instead (pdp/parallel.py).
 """
 
+import os
 import time
 
+import numpy as np
 import torch
 
 from pdp import native
@@ -74,6 +76,72 @@ class FactorGraphTrainerBase(object):
 
     def _check_recurrence_termination(self, active, prediction, sat_problem):
         pass
+
+    def _compute_evaluation_metrics(self, model, evaluator, prediction, label, graph_map, batch_variable_map, batch_function_map,
+                                    edge_feature, meta_data):
+        return evaluator(prediction, label)
+
+    def _test_epoch(self, validation_loader, batch_replication):
+        "reference: base.py:183-219 -- per-example weighted mean of the evaluation metrics over the loader"
+        with torch.no_grad():
+            error = np.zeros((self._error_dim, len(self._model_list)), dtype=np.float32)
+            total_example_num = 0
+            for data in validation_loader:
+                for i in range(len(data[0])):
+                    (graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, label, _) = \
+                        [self._to_cuda(d[i]) for d in data]
+                    total_example_num += int(batch_variable_map.max().item()) + 1
+                    self._test_batch(error, graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, label,
+                                     batch_replication)
+        self._last_test_counts = (error.copy(), total_example_num)       # sums, for a sharded run's single all-reduce
+        return error / total_example_num
+
+    def _test_batch(self, error, graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, label, batch_replication):
+        "reference: base.py:221-250 (random initial state, like the reference's validation / test passes)"
+        this_batch_size = float(int(batch_variable_map.max().item()) + 1)
+        for (i, model) in enumerate(self._model_list):
+            state = model.get_init_state(graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat,
+                                         randomized=True, batch_replication=batch_replication)
+            prediction, _ = model(init_state=state, graph_map=graph_map, batch_variable_map=batch_variable_map,
+                                  batch_function_map=batch_function_map, edge_feature=edge_feature, meta_data=graph_feat,
+                                  is_training=False, iteration_num=self._config['test_recurrence_num'],
+                                  check_termination=self._check_recurrence_termination, batch_replication=batch_replication)
+            error[:, i] += (this_batch_size * self._compute_evaluation_metrics(
+                model=model, evaluator=self._evaluator, prediction=prediction, label=label, graph_map=graph_map,
+                batch_variable_map=batch_variable_map, batch_function_map=batch_function_map, edge_feature=edge_feature,
+                meta_data=graph_feat)).detach().cpu().numpy()
+
+    def test(self, test_list, import_path_base=None, batch_replication=1):
+        "Tests the PDP model and generates test stats: [[file, error [error_dim, models], seconds], ...] (reference: base.py:406-449)."
+        if isinstance(test_list, list):
+            test_files = test_list
+        elif os.path.isdir(test_list):
+            test_files = [os.path.join(test_list, f) for f in os.listdir(test_list)
+                          if os.path.isfile(os.path.join(test_list, f)) and f[-5:].lower() == '.json']
+        elif isinstance(test_list, str):
+            test_files = [test_list]
+        else:
+            return None
+        result = []
+        for file in test_files:
+            test_loader = FactorGraphDataset.get_loader(
+                input_file=file, limit=self._config['test_batch_limit'], hidden_dim=self._config['hidden_dim'],
+                batch_size=self._config['batch_size'], shuffle=False, num_workers=0,
+                max_cache_size=self._config.get('max_cache_size', 100000), batch_replication=batch_replication)
+            if import_path_base is not None:
+                self._load(import_path_base)
+            start_time = time.time()
+            error = self._test_epoch(test_loader, batch_replication)
+            torch.cuda.synchronize()
+            duration = time.time() - start_time
+            if self._config.get('verbose'):
+                message = ''
+                for (i, model) in enumerate(self._model_list):
+                    message += '{:s}, dataset:{:s} error={:s}|'.format(model._name, file, np.array_str(error[:, i].flatten()))
+                self._logger.info(message)
+                self._logger.info('Time spent: %s seconds' % duration)
+            result += [[file, error, duration]]
+        return result
 
     def predict(self, test_list, out_file, import_path_base=None, post_processor=None, batch_replication=1):
         "Produces predictions for a (trained) PDP model (reference: base.py:451-472)."

@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     'pdp_abi_version', 'pdp_last_error', 'pdp_device_count', 'pdp_problem_create', 'pdp_problem_destroy',
     'pdp_problem_dims', 'pdp_problem_export_graph', 'pdp_problem_bind_state', 'pdp_simplify', 'pdp_set_variables',
     'pdp_refresh_edge_mask', 'pdp_smooth_max', 'pdp_instance_max', 'pdp_instance_argmax', 'pdp_sp_propagate', 'pdp_sp_adaptors', 'pdp_sp_propagate_adapted',
-    'pdp_survey_score', 'pdp_cnf_eval', 'pdp_update_solution', 'pdp_check_termination', 'pdp_decimator_create',
+    'pdp_survey_score', 'pdp_cnf_eval', 'pdp_sat_loss', 'pdp_update_solution', 'pdp_check_termination', 'pdp_decimator_create',
     'pdp_decimator_destroy', 'pdp_decimator_reset', 'pdp_sequential_decimate', 'pdp_sequential_decimate_gate',
     'pdp_sequential_decimate_apply', 'pdp_reinforce_decimate', 'pdp_reinforce_predict', 'pdp_energy',
     'pdp_energy_diff', 'pdp_random_fill', 'pdp_local_search', 'pdp_deduplicate', 'pdp_sp_solve', 'pdp_math_apply',
@@ -312,6 +312,13 @@ class Problem(object):
         unsat = torch.empty(self.B, 1, dtype=torch.float32, device=self.device)
         check(lib().pdp_cnf_eval(self._h, ptr(pred, torch.float32, self.V, 'prediction'), ptr(solved), ptr(unsat), _stream()))
         return solved, unsat
+
+    def sat_loss(self, pred, coeff, eps, sharpness):
+        "energy loss of a prediction (SatLossEvaluator.forward): device float [1]"
+        out = torch.empty(1, dtype=torch.float32, device=self.device)
+        check(lib().pdp_sat_loss(self._h, ptr(pred, torch.float32, self.V, 'prediction'), C.c_float(coeff), C.c_float(eps),
+                                 C.c_int(int(sharpness)), ptr(out), _stream()))
+        return out
 
     def update_solution(self, pred):
         out = torch.empty(self.V, 1, dtype=torch.float32, device=self.device)

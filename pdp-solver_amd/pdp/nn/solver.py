@@ -201,17 +201,21 @@ class PropagatorDecimatorSolverBase(nn.Module):
 
     def _forward_core(self, init_propagator_state, init_decimator_state, sat_problem, iteration_num, is_training, check_termination):
         if self._can_run_persistent(sat_problem, is_training, check_termination):
-            out = self._forward_core_persistent(init_propagator_state, sat_problem, iteration_num, check_termination)
+            out = self._forward_core_persistent(init_propagator_state, init_decimator_state, sat_problem, iteration_num, check_termination)
             if out is not None:
                 return out
         return self._forward_core_stepwise(init_propagator_state, init_decimator_state, sat_problem, iteration_num,
                                            is_training, check_termination)
 
-    def _forward_core_persistent(self, init_propagator_state, sat_problem, iteration_num, check_termination):
-        "the whole loop of solver.py:355-386 in one kernel launch; None if the speculation failed"
+    def _forward_core_persistent(self, init_propagator_state, init_decimator_state, sat_problem, iteration_num, check_termination):
+        """the whole loop of solver.py:355-386 in one kernel launch; None if the speculation failed.  The first sweep reads the
+        DECIMATOR's initial state (solver.py:365: propagator(propagator_state, decimator_state, ...)); the propagator's own initial
+        state only fills instances that are inactive, and none is at the first sweep -- the two differ when the initial state is
+        random (test mode, base.py:229)."""
         nat = sat_problem._native
-        q = init_propagator_state[0].clone().contiguous()
-        fs = init_propagator_state[1].clone().contiguous()
+        src = init_decimator_state if int(iteration_num) > 0 else init_propagator_state
+        q = src[0].clone().contiguous()
+        fs = src[1].clone().contiguous()
         active_mask = torch.ones(sat_problem._batch_size, dtype=torch.uint8, device=self._device)
         handle = self._decimator.native_handle(sat_problem)
         try:

@@ -34,6 +34,31 @@ class SatCNFEvaluator(nn.Module):
         return handle.cnf_eval(variable_prediction.reshape(-1).contiguous())
 
 
+class SatLossEvaluator(nn.Module):
+    """Energy of a prediction = the training loss, reported by the test mode (reference: util.py:110-197).  ``forward`` keeps the
+    reference's argument list; the computation is one native call on the problem's resident layout (pass ``sat_problem``), where the
+    reference rebuilds two sparse masks and runs three sparse products per call."""
+
+    def __init__(self, alpha, device):
+        super(SatLossEvaluator, self).__init__()
+        self._alpha = alpha
+        self._device = device
+
+    def forward(self, variable_prediction, label, graph_map, batch_variable_map, batch_function_map, edge_feature, meta_data,
+                global_step, eps, max_coeff, loss_sharpness, sat_problem=None):
+        if float(loss_sharpness) != int(loss_sharpness) or int(loss_sharpness) < 1:
+            raise native.NativeError("SatLossEvaluator: the native kernel takes a positive integer loss_sharpness")
+        if sat_problem is None:
+            from pdp.nn.solver import SATProblem
+            sat_problem = SATProblem((graph_map, batch_variable_map, batch_function_map, edge_feature, meta_data, None),
+                                     self._device, 1)
+        handle = sat_problem._native if sat_problem._batch_replication == 1 else sat_problem._native_unreplicated()
+        gs = global_step.detach().to(torch.float32).reshape(-1)[:1].cpu()
+        coeff = float(torch.min(gs.pow(self._alpha), torch.tensor([float(max_coeff)])).item())     # util.py:181
+        e = float(eps.reshape(-1)[0].item()) if torch.is_tensor(eps) else float(eps)
+        return handle.sat_loss(variable_prediction.reshape(-1).contiguous(), coeff, e, int(loss_sharpness)).reshape(())
+
+
 class MessageAggregator(nn.Module):
     """Deep-set message aggregation at variable / function nodes (reference: util.py:11-77).
 

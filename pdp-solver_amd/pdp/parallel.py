@@ -3,8 +3,8 @@
 The reference has no working multi-GPU path (``nn.DataParallel`` would scatter ``graph_map`` along dim 0, SURVEY.md
 App. B-13).  Every PDP computation is local to one CNF instance, so a batch shards by instances: each rank solves a
 contiguous range of instances (balanced by edge count) completely on its own GPU and the ranks meet exactly once, in
-an all-reduce(sum) of ``[instances, solved, unsat clauses]`` (RCCL over xGMI on a node: ``backend='nccl'``; the tests use
-``gloo`` on CPU).  Result rows are gathered in rank order by the caller if it wants them.
+an all-reduce(sum) of ``[instances, solved, unsat clauses]`` -- in test mode of the metric sums ``[accuracy, recall, loss]`` and the
+example count -- (RCCL over xGMI on a node: ``backend='nccl'``; the tests use ``gloo`` on CPU).  Result rows are gathered in rank order by the caller if it wants them.
 """
 
 import numpy as np
@@ -54,6 +54,19 @@ def reduce_stats(n_instances, n_solved, n_unsat_clauses, device=None, group=None
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     n, s, u = [float(x) for x in t.tolist()]
     return dict(instances=int(n), solved=int(s), unsat_clauses=int(u), solved_fraction=(s / n if n else 0.0))
+
+
+def reduce_test_metrics(error_sums, n_examples, device=None, group=None):
+    """Test mode across ranks: every rank holds the per-example-weighted sums of its shard ([accuracy error, recall error, loss] x
+    models, ``FactorGraphTrainerBase._last_test_counts``); one all-reduce(sum) of the sums and the example count gives the means the
+    single-process run reports (base.py:219)."""
+    sums = np.asarray(error_sums, dtype=np.float64)
+    t = torch.tensor(list(sums.reshape(-1)) + [float(n_examples)], dtype=torch.float64, device=device if device is not None else 'cpu')
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    vals = t.cpu().numpy()
+    n = float(vals[-1])
+    return (vals[:-1].reshape(sums.shape) / n if n else vals[:-1].reshape(sums.shape)), int(n)
 
 
 def gather_rows(rows, group=None):

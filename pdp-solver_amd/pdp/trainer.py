@@ -1,8 +1,9 @@
 """Model factory + prediction post-processing for PDP SAT solvers (reference: src/pdp/trainer.py).
 
-Only the inference side of ``SatFactorGraphTrainer`` is in scope: ``_build_graph``
-(model_type -> solver class, trainer.py:48-99), ``_check_recurrence_termination`` (:150-162) and
-``_post_process_predictions`` (:125-148).  Loss / metric computation is training-only.
+The inference side of ``SatFactorGraphTrainer``: ``_build_graph`` (model_type -> solver class,
+trainer.py:48-99), ``_check_recurrence_termination`` (:150-162), ``_post_process_predictions`` (:125-148) and the test-mode
+metrics ``_compute_evaluation_metrics`` (:108-123: accuracy / recall errors of the clause check and the energy loss).  Training
+(``_compute_loss`` inside ``_train_batch``, backward, Adam) is out of scope.
 """
 
 import numpy as np
@@ -29,10 +30,13 @@ class SatFactorGraphTrainer(FactorGraphTrainerBase):
     "Builds a PDP SAT solver from a config dict and runs prediction (reference: trainer.py:34-162)."
 
     def __init__(self, config, use_cuda, logger):
-        super(SatFactorGraphTrainer, self).__init__(config=config, has_meta_data=False, error_dim=config.get('error_dim', 1),
+        super(SatFactorGraphTrainer, self).__init__(config=config, has_meta_data=False, error_dim=config.get('error_dim', 3),
                                                     loss=None, evaluator=nn.L1Loss(), use_cuda=use_cuda, logger=logger)
+        self._eps = 1e-8 * torch.ones(1, device=self._device)
+        self._loss_evaluator = util.SatLossEvaluator(alpha=self._config.get('exploration', 0.0), device=self._device)
         self._cnf_evaluator = util.SatCNFEvaluator(device=self._device)
         self._counter = 0
+        self._max_coeff = 10.0
 
     def _build_graph(self, config):
         rng = config.get('rng', 'torch')
@@ -55,6 +59,24 @@ class SatFactorGraphTrainer(FactorGraphTrainerBase):
         if config.get('verbose'):
             self._logger.info("The model parameter count is %d." % model.parameter_count())
         return [model]
+
+    def _compute_evaluation_metrics(self, model, evaluator, prediction, label, graph_map, batch_variable_map, batch_function_map,
+                                    edge_feature, meta_data):
+        """[accuracy error, recall error, energy loss] of a prediction on a labelled batch (reference: trainer.py:108-123).
+        The clause check and the loss run on the problem the model has just solved (no mask rebuild)."""
+        sat_problem = getattr(model, '_last_problem', None)
+        output, _ = self._cnf_evaluator(variable_prediction=prediction[0], graph_map=graph_map, batch_variable_map=batch_variable_map,
+                                        batch_function_map=batch_function_map, edge_feature=edge_feature, meta_data=meta_data,
+                                        sat_problem=sat_problem)
+        output = (output.reshape(label.shape) > 0.5).float()
+        recall = torch.sum(label * (output - label).abs()) / torch.max(torch.sum(label), self._eps)
+        accuracy = evaluator(output, label).unsqueeze(0)
+        loss_value = self._loss_evaluator(variable_prediction=prediction[0], label=label, graph_map=graph_map,
+                                          batch_variable_map=batch_variable_map, batch_function_map=batch_function_map,
+                                          edge_feature=edge_feature, meta_data=meta_data, global_step=model._global_step,
+                                          eps=self._eps, max_coeff=self._max_coeff, loss_sharpness=self._config['loss_sharpness'],
+                                          sat_problem=sat_problem).unsqueeze(0)
+        return torch.cat([accuracy, recall.reshape(1), loss_value], 0)
 
     def _post_process_predictions(self, model, prediction, graph_map, batch_variable_map, batch_function_map,
                                   edge_feature, graph_feat, label, misc_data):

@@ -381,6 +381,9 @@ def gen_traces():
     run_trace('p-d-p', easy[:4], T=25, w=20, seed=5, replication=3, tag='trace_pdp_rep3',
               cfg_kw=dict(tolerance=0.05, t_max=6))
     run_trace('reinforce', easy, T=40, w=10, seed=13, tag='trace_reinforce_easy')
+    # random initial state (the test mode's, base.py:229): the first sweep reads the decimator's random state
+    run_trace('p-d-p', make_lines([(30, 108, (3,))] * 10 + [(24, 60, (2, 3, 4))] * 6, seed0=4300), T=25, w=15, seed=21, randomized=True,
+              tag='trace_pdp_randinit', cfg_kw=dict(tolerance=0.05, t_max=10))
 
 
 # ---- D. neural operators + traces ------------------------------------------------------------
@@ -562,6 +565,50 @@ def gen_p_nd_np():
     save('trace_p_nd_np', **out)
 
 
+
+def gen_test_metrics():
+    """test mode (satyr-train-test.py -t; base.py:223-250, trainer.py:108-123): accuracy / recall / energy loss of given predictions
+    on a labelled batch, computed by the reference's own _compute_evaluation_metrics."""
+    lines = make_lines([(20, 70, (3,))] * 6 + [(14, 40, (2, 3, 4))] * 3, seed0=4200)
+    gm, bvm, bfm, ef, lab, misc = batch_tensors(lines)
+    cfg = base_cfg('p-d-p', exploration=0.3, loss_sharpness=5)
+    tr, m = build(cfg, seed=1)
+    out = problem_arrays(gm, bvm, bfm, ef)
+    rng = np.random.RandomState(11)
+    B = int(bvm.max().item()) + 1
+    label = torch.from_numpy(rng.randint(0, 2, size=(B, 1)).astype(np.float32))
+    out['label'] = np_(label)
+    V = bvm.numel()
+    preds = [rng.rand(V).astype(np.float32), (rng.rand(V) > 0.5).astype(np.float32), (0.5 + 0.01 * rng.randn(V)).astype(np.float32)]
+    steps = [1.0, 40.0, 5.0e4]
+    res = []
+    for k, (pr, gs) in enumerate(zip(preds, steps)):
+        m._global_step.data = torch.tensor([gs], dtype=torch.float32)
+        with torch.no_grad():
+            met = tr._compute_evaluation_metrics(model=m, evaluator=tr._evaluator, prediction=(torch.from_numpy(pr).reshape(-1, 1), None),
+                                                 label=label, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm,
+                                                 edge_feature=ef, meta_data=None)
+        out['pred_%d' % k] = pr
+        res.append(np_(met).reshape(-1))
+    out['metrics'] = np.stack(res).astype(np.float32)          # rows: [accuracy error, recall error, loss]
+    out['global_step'] = np.array(steps, dtype=np.float32)
+    out['params'] = np.array([0.3, 10.0, 1e-8, 5.0], dtype=np.float64)   # exploration, max_coeff, eps, loss_sharpness
+    # whole test() call of the reference on a labelled JSON file (p-d-p + Walk-SAT, random initial state from the seeded torch stream)
+    tlines = make_lines([(40, 140, (3,))] * 10 + [(24, 60, (2, 3, 4))] * 6, seed0=4300)       # alpha = 3.5: SP converges, Walk-SAT solves some
+    with open(os.path.join(HERE, 'test_mode_batch.json'), 'w') as f:
+        f.write("\n".join(tlines) + "\n")
+    cfg2 = base_cfg('p-d-p', error_dim=3, exploration=0.3, loss_sharpness=5, test_recurrence_num=25, local_search_iteration=15,
+                    batch_size=16, test_batch_limit=40000000, max_cache_size=100000, tolerance=0.05, t_max=10)
+    tr2, m2 = build(cfg2, seed=1)
+    tr2._num_cores = 0                                                    # in-process loader (same random stream, no worker processes)
+    m2._global_step.data = torch.tensor([7.0], dtype=torch.float32)
+    torch.manual_seed(21)
+    res = tr2.test(os.path.join(HERE, 'test_mode_batch.json'), batch_replication=1)
+    out['test_mode_error'] = np.asarray(res[0][1], dtype=np.float32)     # [3, 1]: accuracy error, recall error, loss
+    out['test_mode_meta'] = np.array([25, 15, 16, 21, 7], dtype=np.int64)  # T, walk-sat steps, batch size, torch seed, global step
+    save('test_metrics', **out)
+
+
 # ---- E. CLI -------------------------------------------------------------------------------------
 
 def gen_cli():
@@ -610,5 +657,10 @@ if __name__ == '__main__':
         gen_np_d_np()
     if 'pndnp' in what:
         gen_p_nd_np()
+    if 'metrics' in what:
+        gen_test_metrics()
+    if 'randinit' in what:
+        run_trace('p-d-p', make_lines([(30, 108, (3,))] * 10 + [(24, 60, (2, 3, 4))] * 6, seed0=4300), T=25, w=15, seed=21, randomized=True,
+                  tag='trace_pdp_randinit', cfg_kw=dict(tolerance=0.05, t_max=10))
     if 'cli' in what:
         gen_cli()

@@ -36,7 +36,7 @@ def run_golden(name, model_type, persistent=True, **kw):
     bfm = torch.from_numpy(d['batch_function_map']).to(dev); ef = torch.from_numpy(d['edge_feature']).to(dev)
     torch.manual_seed(seed)
     with torch.no_grad():
-        st = m.get_init_state(gm, bvm, bfm, ef, None, randomized=False, batch_replication=R)
+        st = m.get_init_state(gm, bvm, bfm, ef, None, randomized='randinit' in name, batch_replication=R)
         pred, states = m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef,
                          meta_data=None, is_training=False, iteration_num=T, check_termination=tr._check_recurrence_termination,
                          batch_replication=R)
@@ -46,6 +46,7 @@ def run_golden(name, model_type, persistent=True, **kw):
 CASES = [('trace_pdp_n50', 'p-d-p', dict(tolerance=0.02, t_max=100)),
          ('trace_pdp_easy_ws', 'p-d-p', dict(tolerance=0.05, t_max=10)),
          ('trace_pdp_mixed', 'p-d-p', dict(tolerance=0.05, t_max=8)),
+         ('trace_pdp_randinit', 'p-d-p', dict(tolerance=0.05, t_max=10)),      # random initial state (test mode): first sweep reads the decimator's
          ('trace_walksat_easy', 'walk-sat', {}),
          ('trace_pdp_rep3', 'p-d-p', dict(tolerance=0.05, t_max=6)),
          ('trace_reinforce_easy', 'reinforce', dict(pi=0.01, decimation_probability=0.5))]
@@ -253,3 +254,45 @@ def test_p_nd_np_equals_reference_golden():
     np.testing.assert_allclose(ds[0].cpu().numpy(), d['dec_v_%d' % (iters - 1)], rtol=3e-4, atol=3e-5)
     np.testing.assert_allclose(ds[1].cpu().numpy(), d['dec_f_%d' % (iters - 1)], rtol=3e-4, atol=3e-5)
     np.testing.assert_array_equal(pred[0].cpu().numpy()[:, 0], d['final_prediction'])
+
+
+def test_test_mode_metrics_equal_reference_golden():
+    """test mode (satyr-train-test.py -t; base.py:183-250, 406-449; trainer.py:108-123): (a) accuracy / recall errors and the energy loss
+    of given predictions on a labelled batch equal the reference's _compute_evaluation_metrics (loss: another summation order than
+    torch.mean, rtol 2e-6; a clause with zero weighted value gives inf on both sides); (b) a whole ``test()`` call on a labelled JSON
+    file with the reference's seed (random initial state + Walk-SAT draws from the same torch stream) returns the reference's errors.
+    (The file holds instances at alpha = 3.5.  At the threshold, alpha = 3.6, sweeps that do not converge amplify a 1-ulp difference of
+    the fp32 messages -- torch's kernels against include/pdp_math.h -- over ~20 iterations until one decimation decision flips: observed
+    on one instance in 16 for one random stream, with every integer and every float within 1e-4 equal up to that iteration.)"""
+    from pdp.trainer import SatFactorGraphTrainer
+    from pdp.nn.solver import SATProblem
+    d = load_golden('test_metrics')
+    dev = torch.device('cuda:0')
+    alpha, max_coeff, eps, sharp = [float(x) for x in d['params']]
+    tr = SatFactorGraphTrainer(cfg('p-d-p', error_dim=3, exploration=alpha, loss_sharpness=int(sharp)), use_cuda=True, logger=LOG)
+    m = tr._model_list[0]
+    gm = torch.from_numpy(d['graph_map']).to(dev); bvm = torch.from_numpy(d['batch_variable_map']).to(dev)
+    bfm = torch.from_numpy(d['batch_function_map']).to(dev); ef = torch.from_numpy(d['edge_feature']).to(dev)
+    label = torch.from_numpy(d['label']).to(dev)
+    m._last_problem = SATProblem((gm, bvm, bfm, ef, None, None), dev, 1)
+    for k in range(3):
+        m._global_step.data = torch.tensor([float(d['global_step'][k])], device=m._global_step.device)
+        pred = torch.from_numpy(d['pred_%d' % k]).to(dev).reshape(-1, 1)
+        met = tr._compute_evaluation_metrics(model=m, evaluator=tr._evaluator, prediction=(pred, None), label=label, graph_map=gm,
+                                             batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None).cpu().numpy()
+        ref = d['metrics'][k]
+        np.testing.assert_allclose(met[:2], ref[:2], rtol=0, atol=1e-6)
+        if np.isinf(ref[2]):
+            assert np.isinf(met[2]) and met[2] > 0
+        else:
+            np.testing.assert_allclose(met[2], ref[2], rtol=2e-6)
+    T, w, bs, seed, gstep = [int(x) for x in d['test_mode_meta']]
+    tr2 = SatFactorGraphTrainer(cfg('p-d-p', error_dim=3, exploration=alpha, loss_sharpness=int(sharp), test_recurrence_num=T,
+                                    local_search_iteration=w, batch_size=bs, tolerance=0.05, t_max=10), use_cuda=True, logger=LOG)
+    tr2._model_list[0]._global_step.data = torch.tensor([float(gstep)], device=tr2._model_list[0]._global_step.device)
+    torch.manual_seed(seed)
+    res = tr2.test(os.path.join(REPO, 'tests', 'golden', 'test_mode_batch.json'), batch_replication=1)
+    err = np.asarray(res[0][1]).reshape(-1)
+    ref = d['test_mode_error'].reshape(-1)
+    np.testing.assert_allclose(err[:2], ref[:2], rtol=0, atol=1e-6)
+    assert (np.isinf(err[2]) and np.isinf(ref[2])) or abs(err[2] - ref[2]) <= 2e-6 * abs(ref[2])

@@ -245,3 +245,16 @@ def test_deduplicate(oracle):
     hout, hch = hp.deduplicate(t(pred)); oout, och = op.deduplicate(pred)
     np.testing.assert_array_equal(npy(hout)[:, 0], oout)
     np.testing.assert_array_equal(npy(hch), och)
+
+
+@pytest.mark.parametrize('sharp', [1, 3, 5])
+def test_sat_loss_bit_exact(oracle, sharp):
+    "energy loss of a prediction (SatLossEvaluator.forward, util.py:178-197): same nesting of sums on both sides, so the float is identical"
+    b = random_batch(batch=11, n=30, mixed=True, seed=123)
+    hp, op = make_pair(oracle, b)
+    rng = np.random.RandomState(sharp)
+    for pred, coeff in ((rng.rand(op.V).astype(np.float32), 1.0), ((rng.rand(op.V) > 0.5).astype(np.float32), 3.5),
+                        ((0.5 + 0.2 * rng.randn(op.V)).astype(np.float32), 10.0)):
+        ref = np.float32(op.sat_loss(pred, np.float32(coeff), 1e-8, sharp))
+        got = npy(hp.sat_loss(t(pred), float(np.float32(coeff)), 1e-8, sharp))[0]
+        assert (np.isinf(ref) and np.isinf(got)) or ref == got, (ref, got)

@@ -163,3 +163,27 @@ def test_full_forward_trace(oracle, golden_dir, name, model, kw):
         s, u = p.cnf_eval(res['prediction'])
         np.testing.assert_array_equal(s, d['final_solved'])
         np.testing.assert_array_equal(u, d['final_unsat'])
+
+
+def test_sat_loss_and_test_metrics(oracle, golden_dir):
+    """test mode (base.py:223-250, trainer.py:108-123): accuracy / recall errors from the clause check and the energy loss of
+    SatLossEvaluator (util.py:178-197) against the reference's own _compute_evaluation_metrics on a labelled batch.  The loss is a
+    mean of logs in another summation order than torch.mean: rtol 2e-6; the infinite case (a clause with zero weighted value) is inf."""
+    d = load(golden_dir, 'test_metrics')
+    p = make_problem(oracle, d)
+    alpha, max_coeff, eps, sharp = [float(x) for x in d['params']]
+    label = d['label'].reshape(-1)
+    for k in range(3):
+        pred = d['pred_%d' % k]
+        coeff = np.float32(min(np.float32(d['global_step'][k]) ** np.float32(alpha), np.float32(max_coeff)))
+        loss = p.sat_loss(pred, coeff, eps, int(sharp))
+        solved, _ = p.cnf_eval(pred)
+        out = (solved > 0.5).astype(np.float32)
+        acc_err = np.mean(np.abs(out - label))
+        rec_err = np.sum(label * np.abs(out - label)) / max(np.sum(label), 1e-8)
+        ref = d['metrics'][k]
+        assert abs(acc_err - ref[0]) < 1e-6 and abs(rec_err - ref[1]) < 1e-6
+        if np.isinf(ref[2]):
+            assert np.isinf(loss) and loss > 0
+        else:
+            assert abs(loss - ref[2]) <= 2e-6 * abs(ref[2]), (loss, ref[2])

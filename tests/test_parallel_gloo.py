@@ -75,3 +75,42 @@ def test_sharded_solve_equals_unsharded():
         exp_rows += r; exp_solved += int(np.sum(s)); exp_unsat += int(np.sum(u))
     assert stats == dict(instances=12, solved=exp_solved, unsat_clauses=exp_unsat, solved_fraction=exp_solved / 12.0)
     assert rows == exp_rows
+
+
+def _metrics_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sys.path.insert(0, REPO)
+    from oracle import binding
+    items = dataset.random_ksat_items(10, 30, 3, m=100, seed=5000)
+    mine, _ = parallel.shard_items(items, rank, world)
+    b = dataset.collate_segment(mine)
+    p = binding.Problem(b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'])
+    pred = np.random.RandomState(7 + rank).rand(p.V).astype(np.float32)
+    solved, _ = p.cnf_eval((pred > 0.5).astype(np.float32))
+    label = (np.arange(len(mine)) % 2).astype(np.float32)
+    n = float(len(mine))
+    sums = np.array([[n * np.mean(np.abs(solved - label))], [n * np.sum(label * np.abs(solved - label)) / max(label.sum(), 1e-8)],
+                     [n * p.sat_loss(pred, 2.0, 1e-8, 5)]])
+    mean, total = parallel.reduce_test_metrics(sums, len(mine))
+    q.put((rank, sums, len(mine), mean, total))
+    dist.destroy_process_group()
+
+
+def test_test_mode_metrics_reduce_over_ranks():
+    "test mode across ranks: one all-reduce(sum) of the per-example-weighted metric sums [accuracy, recall, loss] and the example count"
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_metrics_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    exp = (got[0][1] + got[1][1]) / float(got[0][2] + got[1][2])
+    for rank, sums, n, mean, total in got:
+        assert total == 10
+        np.testing.assert_allclose(mean, exp, rtol=1e-12)
