@@ -144,15 +144,36 @@ class FactorGraphTrainerBase(object):
         return result
 
     def predict(self, test_list, out_file, import_path_base=None, post_processor=None, batch_replication=1):
-        "Produces predictions for a (trained) PDP model (reference: base.py:451-472)."
+        """Produces predictions for a (trained) PDP model (reference: base.py:451-472).
+
+        Under ``torch.distributed`` (one process per GPU, ``python -m torch.distributed.run --nproc-per-node N satyr.py ...``) every rank
+        solves a contiguous shard of the instances on its own GPU -- no collective on the data path -- and the ranks meet once: an
+        all-reduce(sum) of [instances, solved, unsat clauses] and a rank-ordered gather of the result rows, which rank 0 writes.  Each
+        shard is solved as a single-process run of that shard with the same seed would solve it."""
+        import io
+        from pdp import parallel
+        world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
+        rank = torch.distributed.get_rank() if world > 1 else 0
         test_loader = FactorGraphDataset.get_loader(
             input_file=test_list, limit=self._config['test_batch_limit'], hidden_dim=self._config['hidden_dim'],
             batch_size=self._config['batch_size'], shuffle=False, num_workers=0,
-            max_cache_size=self._config.get('max_cache_size', 100000), batch_replication=batch_replication)
+            max_cache_size=self._config.get('max_cache_size', 100000), batch_replication=batch_replication,
+            shard=(rank, world) if world > 1 else None)
         if import_path_base is not None:
             self._load(import_path_base)
         start_time = time.time()
-        self._predict_epoch(test_loader, post_processor, batch_replication, out_file)
+        self._run_stats = [0, 0, 0]                       # instances, solved, unsatisfied clauses (filled by the post-processor)
+        sink = io.StringIO() if world > 1 else out_file
+        self._predict_epoch(test_loader, post_processor, batch_replication, sink)
         torch.cuda.synchronize()
+        if world > 1:
+            on_gpu = torch.distributed.get_backend() == 'nccl'
+            self.last_stats = parallel.reduce_stats(*self._run_stats, device=self._device if on_gpu else None)
+            parts = parallel.gather_rows([sink.getvalue()])
+            if rank == 0:
+                out_file.write("".join(parts))
+        else:
+            self.last_stats = parallel.reduce_stats(*self._run_stats)
         if self._config.get('verbose'):
             self._logger.info('Time spent: %s seconds' % (time.time() - start_time))
+            self._logger.info('instances %(instances)d, solved %(solved)d, unsatisfied clauses %(unsat_clauses)d' % self.last_stats)

@@ -138,7 +138,7 @@ class FactorGraphDataset(object):
     directory of DIMACS files: the instances are then read directly by the native parser, in the order and with the labels the
     converter (dimacs2json.py) would have produced."""
 
-    def __init__(self, input_file, limit, hidden_dim, max_cache_size=100000, batch_replication=1):
+    def __init__(self, input_file, limit, hidden_dim, max_cache_size=100000, batch_replication=1, shard=None):
         import os
         self._input_file = input_file
         self._dimacs = None
@@ -148,6 +148,18 @@ class FactorGraphDataset(object):
         else:
             with open(input_file, 'r') as f:
                 self._lines = [l for l in f.read().split('\n') if l.strip()]
+        self.shard_offset = 0
+        if shard is not None and shard[1] > 1:
+            # one process per GPU: this rank keeps a contiguous range of the instances, balanced by input size (file size / line
+            # length as the proxy of the edge count -- no rank parses the others' instances)
+            from pdp import parallel
+            rank, world = shard
+            weights = [os.path.getsize(pth) for pth, _ in self._dimacs] if self._dimacs is not None else [len(l) for l in self._lines]
+            lo, hi = parallel.shard_bounds(weights, world)[rank]
+            self._lines = self._lines[lo:hi]
+            if self._dimacs is not None:
+                self._dimacs = self._lines
+            self.shard_offset = lo
         self._limit = limit
         self._hidden_dim = hidden_dim
         self._batch_replication = batch_replication
@@ -190,10 +202,10 @@ class FactorGraphDataset(object):
 
     @staticmethod
     def get_loader(input_file, limit, hidden_dim, batch_size, shuffle=False, num_workers=0, max_cache_size=100000,
-                   use_cuda=True, generator=None, epoch_size=0, batch_replication=1):
+                   use_cuda=True, generator=None, epoch_size=0, batch_replication=1, shard=None):
         """Signature-compatible constructor (reference: dataset.py:189-211); returns an iterable of
         reference-shaped 7-tuples of per-segment lists."""
-        ds = FactorGraphDataset(input_file, limit, hidden_dim, max_cache_size, batch_replication)
+        ds = FactorGraphDataset(input_file, limit, hidden_dim, max_cache_size, batch_replication, shard=shard)
 
         class _Loader(object):
             dataset = ds

@@ -102,6 +102,9 @@ class SatFactorGraphTrainer(FactorGraphTrainerBase):
             }
             rows.append(str(instance).replace("'", '"') + "\n")
             self._counter += 1
+        if hasattr(self, '_run_stats'):
+            self._run_stats[0] += int(output.shape[0]); self._run_stats[1] += int((output.reshape(output.shape[0], -1)[:, 0] == 1).sum())
+            self._run_stats[2] += int(unsat_clause_num.sum())
         return "".join(rows)
 
     def _check_recurrence_termination(self, active, prediction, sat_problem):

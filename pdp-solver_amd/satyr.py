@@ -4,7 +4,8 @@
 Same positionals, flags, YAML keys and output format as the reference CLI (reference: satyr.py:45-109).
 Additions: ``--rng {torch,philox}`` (torch = the reference's CPU random stream, bit-compatible results for the
 same ``-s`` seed; philox = on-device counters, fastest) and ``--stepwise`` (disable the one-launch persistent loop).
-``-c/--cpu_mode`` is rejected: the hot path has no CPU fallback.
+``-c/--cpu_mode`` is rejected: the hot path has no CPU fallback.  Launched through ``python -m torch.distributed.run --nproc-per-node N``
+it runs one process per GPU on a shard of the input each and reduces the result once over RCCL.
 """
 
 import argparse
@@ -35,6 +36,8 @@ def run(config, logger, output):
     if config['verbose']:
         logger.info("Starting the prediction phase...")
     predicter._counter = 0
+    if int(os.environ.get('RANK', '0')) != 0:
+        output = os.devnull                                # sharded run: rank 0 writes the gathered rows
     if output == '':
         predicter.predict(test_list=config['test_path'], out_file=sys.stdout, import_path_base=config['model_path'],
                           post_processor=predicter._post_process_predictions, batch_replication=config['batch_replication'])
@@ -89,12 +92,23 @@ def main(argv=None):
     config['exploration'] = 0
     config['persistent'] = not config['stepwise']
 
+    # one process per GPU under torch.distributed.run: instances are sharded across the ranks (pdp/factorgraph/base.py::predict)
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1:
+        import torch.distributed as dist
+        # PDP_DIST_BACKEND=gloo lets several ranks share one GPU (checks of the sharded path on a single-GPU box); RCCL needs one GPU each
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % max(1, torch.cuda.device_count()))
+        dist.init_process_group(backend=os.environ.get('PDP_DIST_BACKEND', 'nccl'))
     try:
         run(config, logger, config['output'])
     finally:
         if temp_file_name is not None and os.path.exists(temp_file_name):
             os.remove(temp_file_name)
-    print('')
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+    if world == 1 or int(os.environ.get('RANK', '0')) == 0:
+        print('')
 
 
 if __name__ == '__main__':

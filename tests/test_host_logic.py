@@ -205,3 +205,26 @@ def test_native_dimacs_batch_reader(tmp_path):
     bad.write_text("p cnf 2 1\n1 x2 0\n")
     with pytest.raises(native.NativeError, match='bad.cnf:2'):
         native.dimacs_parse_many(paths[:5] + [str(bad)] + paths[5:9], threads=3)
+
+
+def test_dataset_shards_cover_the_input_in_order(tmp_path):
+    "one process per GPU: every rank's loader keeps a contiguous range of the instances; together they cover the input once, in order"
+    from pdp.factorgraph import dataset
+    from pdp import generator
+    lines = []
+    for i in range(23):
+        n = 10 + 3 * (i % 5)
+        cl = generator.uniform_ksat(n, 3 * n, 3, np.random.RandomState(i))
+        lines.append(generator.json_line(n, cl, label=i % 2, name='x%d' % i))
+    path = tmp_path / 'in.json'
+    path.write_text("\n".join(lines) + "\n")
+    whole = dataset.FactorGraphDataset(str(path), 10 ** 9, 3)
+    for world in (2, 3, 8):
+        got, offs = [], []
+        for rank in range(world):
+            ds = dataset.FactorGraphDataset(str(path), 10 ** 9, 3, shard=(rank, world))
+            offs.append(ds.shard_offset)
+            got += [ds[i][5][0] for i in range(len(ds))]
+            assert len(ds) >= 1
+        assert got == [whole[i][5][0] for i in range(len(whole))]
+        assert offs == sorted(offs) and offs[0] == 0
