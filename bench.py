@@ -126,11 +126,11 @@ def bench_neural(args, dev, rank, world):
         step(True)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    tot = torch.tensor([float(sum(iters_done)), elapsed], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(sum(iters_done)), elapsed], dtype=torch.float64, device=args.coll_dev)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=args.coll_dev); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     if rank == 0:
@@ -180,12 +180,18 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    backend = os.environ.get('PDP_DIST_BACKEND', 'nccl')    # gloo: several ranks on one GPU (checks of the N > 1 code on a single-GPU box)
     if world > 1:
         import torch.distributed as dist
+        local_rank = local_rank % max(1, torch.cuda.device_count()) if backend != 'nccl' else local_rank
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
     native.require_gpu()
     dev = torch.device('cuda', local_rank if world > 1 else 0)
+    args.coll_dev = dev if backend == 'nccl' else torch.device('cpu')
     torch.cuda.set_device(dev)
     if args.workload == 'neural':
         return bench_neural(args, dev, rank, world)
@@ -245,10 +251,10 @@ def main():
     pred = prob.update_solution(out.reshape(-1).contiguous())
     solved, unsat = prob.cnf_eval(pred.reshape(-1).contiguous())
     stats = torch.tensor([float(B), float(solved.sum().item()), float(unsat.sum().item()), elapsed, total_iters],
-                         dtype=torch.float64, device=dev)
+                         dtype=torch.float64, device=args.coll_dev)
     if world > 1:
         import torch.distributed as dist
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=args.coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)       # the only collective of the path: a 40-byte sum over xGMI
