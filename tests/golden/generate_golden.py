@@ -609,6 +609,50 @@ def gen_test_metrics():
     save('test_metrics', **out)
 
 
+
+def gen_headline_poison():
+    """BASELINE configs[1]'s instance family at a batch the reference can run: uniform 3-SAT n=200 m=840, B=50, T=100, p-d-p.
+    At the SAT threshold a 0/0 in the SP update (pdp_propagate.py:215-216) turns every batch-global reduction into NaN:
+    from that sweep on no instance of the batch is gated or decimated.  The instances are regenerated from seeds by the build's own
+    generator (the same generator bench.py uses), so only the outcome is stored."""
+    # instances of bench.py's rank-0 batch (instance i = RandomState(i)); 2499, 2776, 3533 and 4730 are the ones whose surveys become NaN
+    # within 100 sweeps on the MI355X run of the full 5 000-instance batch (the first at sweep 81)
+    seeds = [2499, 2776, 3533, 4730] + list(range(100, 146))
+    lines = []
+    for sd in seeds:
+        variables, signs = gen.uniform_ksat_arrays(200, 840, 3, np.random.RandomState(sd))
+        vn, fn, gmap, efeat = gen.compact_arrays(200, variables, signs)
+        lines.append(gen.format_json_line(vn, fn, ((gmap[0] + 1) * efeat).astype(np.int64), gmap[1] + 1, -1, "h%d" % sd))
+    cfg = base_cfg('p-d-p', local_search_iteration=0, tolerance=0.02, t_max=100)
+    tr, m = build(cfg)
+    gm, bvm, bfm, ef, lab, misc = batch_tensors(lines)
+    T = 100
+    counts, nan_iter = [], []
+    orig_check = tr._check_recurrence_termination
+
+    def check(active, prediction, sp):
+        orig_check(active, prediction, sp)
+        counts.append(int(sp._active_variables.sum().item()))
+
+    def prop_hook(mod, inp, outp):
+        if not nan_iter and bool(torch.isnan(outp[0]).any()):
+            nan_iter.append(len(counts))
+
+    h = m._propagator.register_forward_hook(prop_hook)
+    torch.manual_seed(7)
+    with torch.no_grad():
+        st = m.get_init_state(gm, bvm, bfm, ef, None, randomized=False, batch_replication=1)
+        pred, (ps, ds) = m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None,
+                           is_training=False, iteration_num=T, check_termination=check, batch_replication=1)
+    h.remove()
+    ev = RU.SatCNFEvaluator(torch.device('cpu'))
+    solved, unsat = ev(pred[0], gm, bvm, bfm, ef, None)
+    save('headline_n200_poison', seeds=np.array(seeds, dtype=np.int64), meta=np.array([200, 840, T, 7, len(counts)], dtype=np.int64),
+         active_variable_count=np.array(counts, dtype=np.int64), first_nan_sweep=np.array(nan_iter or [-1], dtype=np.int64),
+         final_bits=np.packbits((np_(pred[0][:, 0]) > 0.5).astype(np.uint8)), variable_num=np.array([int(bvm.numel())], dtype=np.int64),
+         final_solved=np_(solved[:, 0]), final_unsat=np_(unsat[:, 0]))
+
+
 # ---- E. CLI -------------------------------------------------------------------------------------
 
 def gen_cli():
@@ -659,6 +703,8 @@ if __name__ == '__main__':
         gen_p_nd_np()
     if 'metrics' in what:
         gen_test_metrics()
+    if 'headline' in what:
+        gen_headline_poison()
     if 'randinit' in what:
         run_trace('p-d-p', make_lines([(30, 108, (3,))] * 10 + [(24, 60, (2, 3, 4))] * 6, seed0=4300), T=25, w=15, seed=21, randomized=True,
                   tag='trace_pdp_randinit', cfg_kw=dict(tolerance=0.05, t_max=10))

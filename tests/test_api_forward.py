@@ -296,3 +296,46 @@ def test_test_mode_metrics_equal_reference_golden():
     ref = d['test_mode_error'].reshape(-1)
     np.testing.assert_allclose(err[:2], ref[:2], rtol=0, atol=1e-6)
     assert (np.isinf(err[2]) and np.isinf(ref[2])) or abs(err[2] - ref[2]) <= 2e-6 * abs(ref[2])
+
+
+@pytest.mark.parametrize('persistent', [True, False])
+def test_headline_family_with_nan_poison_equals_reference(persistent):
+    """BASELINE configs[1]'s instance family (uniform 3-SAT n=200 m=840) at a batch the reference can run: 50 instances of bench.py's
+    rank-0 batch, among them the four whose surveys become NaN (0/0 in the SP update, pdp_propagate.py:215-216).  In the reference the
+    first NaN appears at sweep 81 and from then on no instance of the batch is decimated (batch-global reductions turn NaN, SURVEY App.
+    B-6).  The persistent solver (speculation + device-side poison replay) and the step-wise loop must both end in the reference's final
+    assignment bit for bit, with its per-instance clause counts -- and the step-wise loop with its decimation trajectory."""
+    from pdp.trainer import SatFactorGraphTrainer
+    from pdp.factorgraph import dataset
+    d = load_golden('headline_n200_poison')
+    n, mcl, T, seed, sweeps = [int(x) for x in d['meta']]
+    items = []
+    for sd in d['seeds']:
+        items += dataset.random_ksat_items(1, n, 3, m=mcl, seed=int(sd))
+    dev = torch.device('cuda:0')
+    b = dataset.to_torch(dataset.collate_segment(items), dev)
+    gm, bvm, bfm, ef = b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature']
+    assert bvm.numel() == int(d['variable_num'][0])
+    tr = SatFactorGraphTrainer(cfg('p-d-p', local_search_iteration=0, persistent=persistent, tolerance=0.02, t_max=100), use_cuda=True, logger=LOG)
+    m = tr._model_list[0]
+    counts = []
+
+    def check(active, prediction, sp):
+        tr._check_recurrence_termination(active, prediction, sp)
+        counts.append(int(sp._active_variables.sum().item()))
+
+    check._pdp_standard_termination = persistent          # the persistent loop implements the standard callback itself
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        st = m.get_init_state(gm, bvm, bfm, ef, None, randomized=False, batch_replication=1)
+        pred, _ = m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None,
+                    is_training=False, iteration_num=T, check_termination=check, batch_replication=1)
+    assert m.last_run['iterations'] == sweeps and m.last_run['path'] == ('persistent-lds' if persistent else 'stepwise')
+    bits = np.packbits((pred[0].cpu().numpy()[:, 0] > 0.5).astype(np.uint8))
+    np.testing.assert_array_equal(bits, d['final_bits'])
+    solved, unsat = tr._cnf_evaluator(pred[0], gm, bvm, bfm, ef, None, sat_problem=m._last_problem)
+    np.testing.assert_array_equal(solved.cpu().numpy()[:, 0], d['final_solved'])
+    np.testing.assert_array_equal(unsat.cpu().numpy()[:, 0], d['final_unsat'])
+    if not persistent:
+        np.testing.assert_array_equal(np.array(counts), d['active_variable_count'])
+        assert counts[int(d['first_nan_sweep'][0])] == counts[-1]          # nothing is decimated once the batch is poisoned
