@@ -653,6 +653,42 @@ def gen_headline_poison():
          final_solved=np_(solved[:, 0]), final_unsat=np_(unsat[:, 0]))
 
 
+
+def gen_headline_neural():
+    """np-nd-np, hidden 128 (configs[2]) on 6 instances of bench.py's family (n=200 m=840): per-sweep predictions of the reference with the
+    seeded weights of gen_neural's h128 model (same constructor seed, so trace_neural_h128.npz holds these tensors)."""
+    seeds = list(range(100, 106))
+    lines = []
+    for sd in seeds:
+        variables, signs = gen.uniform_ksat_arrays(200, 840, 3, np.random.RandomState(sd))
+        vn, fn, gmap, efeat = gen.compact_arrays(200, variables, signs)
+        lines.append(gen.format_json_line(vn, fn, ((gmap[0] + 1) * efeat).astype(np.int64), gmap[1] + 1, -1, "h%d" % sd))
+    gm, bvm, bfm, ef, lab, misc = batch_tensors(lines)
+    H, T = 128, 4
+    cfg = base_cfg('np-nd-np', hidden_dim=H, local_search_iteration=0)
+    tr, m = build(cfg, seed=1234)
+    ref_w = np.load(os.path.join(HERE, 'trace_neural_h128.npz'))
+    for k, v in flat_state_dict(m).items():
+        assert np.array_equal(ref_w[k], v), k
+    rec = {}
+    it = {'i': 0}
+    orig_check = tr._check_recurrence_termination
+
+    def check(active, prediction, sp):
+        rec['pred_%d' % it['i']] = np_(prediction[0][:, 0])
+        orig_check(active, prediction, sp)
+        it['i'] += 1
+
+    torch.manual_seed(3)
+    with torch.no_grad():
+        st = m.get_init_state(gm, bvm, bfm, ef, None, randomized=False, batch_replication=1)      # the predict path's initial state (zeros)
+        pred, (ps, ds) = m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None,
+                           is_training=False, iteration_num=T, check_termination=check, batch_replication=1)
+    rec['final_prediction'] = np_(pred[0][:, 0])
+    rec['final_dec_f_sample'] = np_(ds[1][::97])
+    save('headline_n200_neural', seeds=np.array(seeds, dtype=np.int64), meta=np.array([200, 840, T, H, it['i']], dtype=np.int64), **rec)
+
+
 # ---- E. CLI -------------------------------------------------------------------------------------
 
 def gen_cli():
@@ -705,6 +741,8 @@ if __name__ == '__main__':
         gen_test_metrics()
     if 'headline' in what:
         gen_headline_poison()
+    if 'headline_neural' in what:
+        gen_headline_neural()
     if 'randinit' in what:
         run_trace('p-d-p', make_lines([(30, 108, (3,))] * 10 + [(24, 60, (2, 3, 4))] * 6, seed0=4300), T=25, w=15, seed=21, randomized=True,
                   tag='trace_pdp_randinit', cfg_kw=dict(tolerance=0.05, t_max=10))

@@ -339,3 +339,34 @@ def test_headline_family_with_nan_poison_equals_reference(persistent):
     if not persistent:
         np.testing.assert_array_equal(np.array(counts), d['active_variable_count'])
         assert counts[int(d['first_nan_sweep'][0])] == counts[-1]          # nothing is decimated once the batch is poisoned
+
+
+def test_headline_family_neural_equals_reference():
+    """np-nd-np, hidden 128 (configs[2]) on six instances of bench.py's family (n=200 m=840, 15 120 edges = 236 edge tiles, so the
+    pipelined GRU, the wave-private and the prefetched aggregator kernels all run many tiles): per-sweep predictions and a sample of the
+    final decimator state within fp tolerance of the reference run with the same seeded weights, thresholded final assignment identical."""
+    from pdp.factorgraph import dataset
+    d = load_golden('headline_n200_neural')
+    n, mcl, T, H, sweeps = [int(x) for x in d['meta']]
+    tr, m = _neural_model(load_golden('trace_neural_h128'), H)
+    items = []
+    for sd in d['seeds']:
+        items += dataset.random_ksat_items(1, n, 3, m=mcl, seed=int(sd))
+    dev = torch.device('cuda:0')
+    b = dataset.to_torch(dataset.collate_segment(items), dev)
+    gm, bvm, bfm, ef = b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature']
+    rec = []
+
+    def check(active, prediction, sp):
+        rec.append(prediction[0].reshape(-1).cpu().numpy().copy())
+        tr._check_recurrence_termination(active, prediction, sp)
+
+    with torch.no_grad():
+        st = m.get_init_state(gm, bvm, bfm, ef, None, randomized=False, batch_replication=1)
+        pred, (ps, ds) = m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None,
+                           is_training=False, iteration_num=T, check_termination=check, batch_replication=1)
+    assert len(rec) == sweeps
+    for i, p in enumerate(rec):
+        np.testing.assert_allclose(p, d['pred_%d' % i], rtol=3e-4, atol=3e-5, err_msg='pred %d' % i)
+    np.testing.assert_allclose(ds[1].cpu().numpy()[::97], d['final_dec_f_sample'], rtol=3e-4, atol=3e-5)
+    np.testing.assert_array_equal(pred[0].cpu().numpy()[:, 0], d['final_prediction'])
