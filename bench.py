@@ -273,13 +273,20 @@ def main():
         bytes_launch = algorithmic_bytes_per_iteration(E, V, F) * it_mean / n_launch
         achieved = bytes_launch / (launch_ms * 1e-3) / 1e9
         # measured HBM traffic per launch (rocprofv3 PMC passes, corrected as MI355X_MICROARCH.md prescribes), if profiled
-        traffic = None
+        traffic, valu = None, None
         pmc = os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')   # written by tools/summarize_profile.py
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get('k_sp_solve_lds_bytes_per_launch')
+                pj = json.load(open(pmc))
+                traffic = pj.get('k_sp_solve_lds_bytes_per_launch')
+                if pj.get('SQ_INSTS_VALU_per_launch') and args.batch == 5000 and args.n == 200:
+                    # what actually binds the LDS-resident kernel: wave-level VALU instructions x 4 cycles (one wave64 instruction per SIMD
+                    # every 4 cycles) against the 1024 SIMDs x 2.4 GHz of the chip over the measured launch time
+                    insts = float(pj['SQ_INSTS_VALU_per_launch'])
+                    valu = {'insts_per_launch': insts, 'issue_frac': insts * 4.0 / (1024 * 2.4e9 * launch_ms * 1e-3),
+                            'note': 'SQ_INSTS_VALU (rocprofv3 PMC pass of the same kernel) x 4 cycles / (1024 SIMDs x 2.4 GHz x launch time)'}
             except Exception:
-                traffic = None
+                traffic, valu = None, None
         line = {
             'metric': 'pdp_iterations_per_sec', 'value': value,
             'unit': 'iterations/s (each iteration sweeps a batch of %d instances)' % args.batch,
@@ -293,7 +300,7 @@ def main():
                        'algorithmic_bytes_per_launch': bytes_launch, 'setup_ms_upload_and_layout': setup_ms, 'solved_fraction': n_solved / n_inst, 'unsat_clauses_total': n_unsat,
                        'walksat_steps': ws_steps, 'tolerance': args.tolerance, 't_max': args.t_max, 'parallelism': 'instances sharded, dp%d' % world},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'kernel': 'k_sp_solve_lds<false, false>',
+                         'traffic': traffic, 'valu_issue': valu, 'kernel': 'k_sp_solve_lds<false, false>',
                          'note': 'achieved = streaming-model algorithmic bytes (41E+36V+8F per iteration) x iterations per launch / '
                                  'average launch duration (HIP events on the launch stream); the instance state is LDS-resident, '
                                  'so the kernel is bound by VALU issue, not by HBM (DESIGN.md section 4)'},
