@@ -51,36 +51,48 @@ __device__ __forceinline__ void mfma_chain(const float *A, int lda, int Kp, cons
     const float *bp = Wt + (size_t)kh * Np + 32 * nb + i;
     const int steps = Kp >> 1;
     const size_t bstride = (size_t)2 * Np;
-    float bufA[BCH], bufB[BCH];
+    // both operands of a chunk of BCH k-steps sit in registers before its MFMAs issue: the weight fragments (L2) and the LDS operands of
+    // the next chunk are requested while the current chunk runs (double buffered)
+    float bufA[BCH], bufB[BCH], aA[MB][BCH], aB[MB][BCH];
     int s0 = 0;
     if (steps >= BCH) {
 #pragma unroll
-        for (int s = 0; s < BCH; ++s) bufA[s] = bp[(size_t)s * bstride];
+        for (int s = 0; s < BCH; ++s) {
+            bufA[s] = bp[(size_t)s * bstride];
+#pragma unroll
+            for (int m = 0; m < MB; ++m) aA[m][s] = ap[32 * m * lda + 2 * s];
+        }
     }
     while (s0 + BCH <= steps) {
         const bool more1 = s0 + 2 * BCH <= steps;
         if (more1) {
 #pragma unroll
-            for (int s = 0; s < BCH; ++s) bufB[s] = bp[(size_t)(s0 + BCH + s) * bstride];
+            for (int s = 0; s < BCH; ++s) {
+                bufB[s] = bp[(size_t)(s0 + BCH + s) * bstride];
+#pragma unroll
+                for (int m = 0; m < MB; ++m) aB[m][s] = ap[32 * m * lda + 2 * (s0 + BCH + s)];
+            }
         }
 #pragma unroll
         for (int s = 0; s < BCH; ++s) {
-            const int k0 = 2 * (s0 + s);
 #pragma unroll
-            for (int m = 0; m < MB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[32 * m * lda + k0], bufA[s], acc[m], 0, 0, 0);
+            for (int m = 0; m < MB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(aA[m][s], bufA[s], acc[m], 0, 0, 0);
         }
         s0 += BCH;
         if (!more1) break;
         const bool more2 = s0 + 2 * BCH <= steps;
         if (more2) {
 #pragma unroll
-            for (int s = 0; s < BCH; ++s) bufA[s] = bp[(size_t)(s0 + BCH + s) * bstride];
+            for (int s = 0; s < BCH; ++s) {
+                bufA[s] = bp[(size_t)(s0 + BCH + s) * bstride];
+#pragma unroll
+                for (int m = 0; m < MB; ++m) aA[m][s] = ap[32 * m * lda + 2 * (s0 + BCH + s)];
+            }
         }
 #pragma unroll
         for (int s = 0; s < BCH; ++s) {
-            const int k0 = 2 * (s0 + s);
 #pragma unroll
-            for (int m = 0; m < MB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[32 * m * lda + k0], bufB[s], acc[m], 0, 0, 0);
+            for (int m = 0; m < MB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(aB[m][s], bufB[s], acc[m], 0, 0, 0);
         }
         s0 += BCH;
         if (!more2) break;
@@ -91,22 +103,13 @@ __device__ __forceinline__ void mfma_chain(const float *A, int lda, int Kp, cons
         for (int m = 0; m < MB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[32 * m * lda + 2 * s], bv, acc[m], 0, 0, 0);
     }
 }
-// plain variant for the VALU-heavy aggregator layers: few registers (two workgroups per CU hide the weight-stream
-// latency better there than a deep register prefetch does; measured 17.4 vs 21.4 ms for k_agg_pre at config 3)
+// one 32x32 block of a layer on an LDS tile with the weights streamed from L2 (generic shapes)
 __device__ __forceinline__ f32x16 mfma_block(const float *A, int lda, int Kp, const float *__restrict__ Wt, int Np, int nb, int mb,
                                              const float *__restrict__ bias)
 {
-    const int l = threadIdx.x & 63, i = l & 31, kh = l >> 5;
-    const float b0 = bias ? bias[32 * nb + i] : 0.0f;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = b0;
-    const float *a_ptr = A + (32 * mb + i) * lda + kh;
-    const float *b_ptr = Wt + (size_t)kh * Np + 32 * nb + i;
-#pragma unroll 8
-    for (int k0 = 0; k0 < Kp; k0 += 2)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ptr[k0], b_ptr[(size_t)k0 * Np], acc, 0, 0, 0);
-    return acc;
+    f32x16 acc[1];
+    mfma_chain<1, 8>(A, lda, Kp, Wt, Np, nb, mb, bias, acc);
+    return acc[0];
 }
 // both operands in LDS (resident weights): batches of U k-steps, the operands of the next batch are read while the MFMAs of the
 // current one run (an MFMA chain is serial: 64 cycles per step, far longer than an LDS round trip per batch)
