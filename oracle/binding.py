@@ -411,8 +411,7 @@ def sp_adaptors(dec_v, dec_f, w_f, W_v):
     xlog = linear(dec_v, np.reshape(w_f, (1, -1)), None, 'logsigmoid')[:, 0]
     b = linear(dec_f, W_v, None, 'none')
     eta = math_apply('sigmoid', b[:, 0])
-    force = np.sign(b[:, 1]).astype(np.float32)
-    force[np.isnan(b[:, 1])] = 0.0                        # pdp_sign: (x > 0) - (x < 0)
+    force = np.sign(b[:, 1]).astype(np.float32)           # NaN stays NaN, like torch.sign
     return np.ascontiguousarray(xlog, dtype=np.float32), np.ascontiguousarray(np.stack((eta, force), 1), dtype=np.float32)
 
 

@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(64) k_sp_adaptors(int E, int H, const float *_
         if (e < E) {
             xlog[e] = pdp_logsigmoidf(a);
             fs2[2 * e + 0] = pdp_sigmoidf(b0);
-            fs2[2 * e + 1] = pdp_sign(b1);
+            fs2[2 * e + 1] = (b1 != b1) ? b1 : pdp_sign(b1);                 // torch.sign(NaN) = NaN
         }
     }
 }

@@ -78,6 +78,7 @@ def test_sp_adaptors_and_adapted_propagate_bit_exact(oracle, monkeypatch, H, gri
     ev, ec, es, vi, fi = op.graph()
     E, B = op.E, op.B
     dv = (rng.randn(E, H) * 0.7).astype(np.float32); df = (rng.randn(E, H) * 0.7).astype(np.float32)
+    dv[3, 1] = np.nan; df[5, H - 1] = np.nan; df[7, 0] = np.inf          # NaN / inf propagate like torch (sign(NaN) = NaN)
     w_f = (rng.randn(1, H) * 0.4).astype(np.float32); W_v = (rng.randn(2, H) * 0.4).astype(np.float32)
     xlog_ref, fs2_ref = oracle.sp_adaptors(dv, df, w_f, W_v)
     xlog, fs2 = hp.sp_adaptors(t(dv), t(df), t(w_f.reshape(-1)), t(W_v))
