@@ -518,13 +518,14 @@ __device__ __forceinline__ void wave_chains(const float *a /* LDS: row (lane & 3
 }
 
 // Specialised on the layer shapes (S = k-steps, NB = 32-column blocks); other shapes use the workgroup-tile kernels above.
-// k_agg_pre_wave: the input row is [128 message floats, edge sign, zero pad]: two dwords per lane and row, and the whole next tile is
+// k_agg_pre_wave: the input row is [128 or 150 message floats, edge sign, zero pad]: two or three dwords per lane and row, and the whole next tile is
 // fetched into registers right after the current one has been dropped into LDS, so its HBM latency hides behind both layers.
 template <int S1, int NB1, int S2, int NB2>
 __global__ void __launch_bounds__(NTN) k_agg_pre_wave(int E, const float *__restrict__ state, const float *__restrict__ sign,
                                                       const float *__restrict__ emask, AggW w, float *__restrict__ h2out, int ntiles)
 {
-    static_assert(2 * S1 == 130, "input row = 128 floats + sign + pad");
+    constexpr int SD = 2 * S1 - 2, CG = (SD + 63) / 64;    // message width (input row = SD floats + sign + pad), 64-column groups of a row
+    static_assert(CG <= 3, "input rows of at most 192 floats");
     constexpr int ld = (2 * S1 > 32 * NB1 ? 2 * S1 : 32 * NB1) | 1;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, i = l & 31, kh = l >> 5;
@@ -538,17 +539,18 @@ __global__ void __launch_bounds__(NTN) k_agg_pre_wave(int E, const float *__rest
         const int rows = E - e0 < WT ? E - e0 : WT;
         return __builtin_amdgcn_make_buffer_rsrc((void *)(base + (size_t)e0 * (row_bytes / (int)sizeof(float))), 0, rows * row_bytes, 0x00020000);
     };
-    float2 pv[WT];
+    float pv[WT][CG];
     float psg = 0.0f;
     auto fetch = [&](int tile) {
         const int e0 = tile * WT;
-        const __amdgpu_buffer_rsrc_t sb = tile_rsrc(state, e0, 128 * (int)sizeof(float)), gb = tile_rsrc(sign, e0, (int)sizeof(float));
+        const __amdgpu_buffer_rsrc_t sb = tile_rsrc(state, e0, SD * (int)sizeof(float)), gb = tile_rsrc(sign, e0, (int)sizeof(float));
 #pragma unroll
         for (int r = 0; r < WT; ++r) {
-            // (two dword loads, columns l and 64 + l: the b64 / b128 forms of the raw buffer load builtin come out of this hipcc as ONE
-            //  buffer_load_dword -- checked in the ISA)
-            pv[r].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sb, l * 4, r * 128 * (int)sizeof(float), 0));
-            pv[r].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sb, l * 4 + 256, r * 128 * (int)sizeof(float), 0));
+            // (dword loads, columns l, 64 + l, ...: the b64 / b128 forms of the raw buffer load builtin come out of this hipcc as ONE
+            //  buffer_load_dword -- checked in the ISA; a column past the row reads the next row's start and is not deposited)
+#pragma unroll
+            for (int j = 0; j < CG; ++j)
+                pv[r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sb, l * 4 + 256 * j, r * SD * (int)sizeof(float), 0));
         }
         psg = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gb, l * 4, 0, 0));       // lanes >= 32 read past the tile: 0
     };
@@ -558,8 +560,11 @@ __global__ void __launch_bounds__(NTN) k_agg_pre_wave(int E, const float *__rest
     for (; tile < ntiles; tile += stride) {
         const int e0 = tile * WT;
 #pragma unroll
-        for (int r = 0; r < WT; ++r) { X[r * ld + l] = pv[r].x; X[r * ld + 64 + l] = pv[r].y; }
-        if (l < WT) { X[l * ld + 128] = psg; X[l * ld + 129] = 0.0f; }
+        for (int r = 0; r < WT; ++r)
+#pragma unroll
+            for (int j = 0; j < CG; ++j)
+                if (64 * j + l < SD) X[r * ld + 64 * j + l] = pv[r][j];
+        if (l < WT) { X[l * ld + SD] = psg; X[l * ld + SD + 1] = 0.0f; }
         f32x16 acc[NB1];
         wave_chains<S1, NB1, 32 * NB1>(X + i * ld + kh, w1, w.b1m, acc);
         // HBM requests go out here, in front of the long activation phase: vector-memory results return in issue order, so a weight load of
@@ -607,7 +612,7 @@ __global__ void __launch_bounds__(NTN, 6) k_agg_post_pf(int E, const float *__re
                                                         const float *__restrict__ emask, const float *__restrict__ rowmask,
                                                         const float *__restrict__ old, AggW w, float *__restrict__ out)
 {
-    static_assert(NB3 * 2 == NWAVES && NB4 * 2 == NWAVES, "one 32x32 block per wave and layer");
+    static_assert(NB3 * 2 == NWAVES && NB4 * 2 >= NWAVES, "one 32x32 block per wave in the hidden layer, one or two in the output layer");
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int ld0 = 2 * S3 + 1, ld1 = 32 * NB3 + 1;
     float *Rt = sm, *G1 = sm + TM * ld0;
@@ -634,7 +639,6 @@ __global__ void __launch_bounds__(NTN, 6) k_agg_post_pf(int E, const float *__re
     }
     const int nb = wave >> 1, mb = wave & 1, col = 32 * nb + i;
     const __amdgpu_buffer_rsrc_t w3 = __builtin_amdgcn_make_buffer_rsrc((void *)(w.Wt1a + 32 * nb), 0, (2 * S3 * 32 * NB3 - 32 * nb) * (int)sizeof(float), 0x00020000);
-    const __amdgpu_buffer_rsrc_t w4 = __builtin_amdgcn_make_buffer_rsrc((void *)(w.Wt2a + 32 * nb), 0, (2 * S4 * 32 * NB4 - 32 * nb) * (int)sizeof(float), 0x00020000);
     __syncthreads();
     {
         f32x16 acc[1];
@@ -644,25 +648,33 @@ __global__ void __launch_bounds__(NTN, 6) k_agg_post_pf(int E, const float *__re
     }
     __syncthreads();
     // blend operands and result through buffer accesses with a per-tile base (lane offset in a VGPR, row offset as a scalar, rows past E
-    // clipped by the descriptor); the previous state is requested before the last layer's chain
-    constexpr int ROWB = 32 * NB4 * (int)sizeof(float);
+    // clipped by the descriptor); the previous state is requested before the last layer's chain.  The output is w.out = 128 or 150 floats
+    // wide: with 5 column blocks (150) the 10 blocks of the tile go round the 8 waves twice.
+    const int ROWB = w.out * (int)sizeof(float);
     const int rows = E - e0 < TM ? E - e0 : TM;
-    const __amdgpu_buffer_rsrc_t ob = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)e0 * 32 * NB4), 0, rows * ROWB, 0x00020000);
-    const __amdgpu_buffer_rsrc_t pb = __builtin_amdgcn_make_buffer_rsrc((void *)(old + (size_t)e0 * 32 * NB4), 0, rows * ROWB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ob = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)e0 * w.out), 0, rows * ROWB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t pb = __builtin_amdgcn_make_buffer_rsrc((void *)(old + (size_t)e0 * w.out), 0, rows * ROWB, 0x00020000);
     const __amdgpu_buffer_rsrc_t mb_ = __builtin_amdgcn_make_buffer_rsrc((void *)(rowmask ? rowmask + e0 : old), 0, rows * (int)sizeof(float), 0x00020000);
-    const int lo = (32 * mb + 4 * kh) * ROWB + col * (int)sizeof(float), lm = (32 * mb + 4 * kh) * (int)sizeof(float);
-    float po[16], mk[16];
+    for (int blk = wave; blk < 2 * NB4; blk += NWAVES) {
+        const int nb4 = blk >> 1, mb4 = blk & 1, col4 = 32 * nb4 + i;
+        const bool live = col4 < w.out;                   // the last block of a 150-wide output has 22 live columns
+        const __amdgpu_buffer_rsrc_t w4 = __builtin_amdgcn_make_buffer_rsrc((void *)(w.Wt2a + 32 * nb4), 0, (2 * S4 * 32 * NB4 - 32 * nb4) * (int)sizeof(float), 0x00020000);
+        const int lo = (32 * mb4 + 4 * kh) * ROWB + col4 * (int)sizeof(float), lm = (32 * mb4 + 4 * kh) * (int)sizeof(float);
+        float po[16], mk[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) po[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pb, lo, ((r & 3) + 8 * (r >> 2)) * ROWB, 0));
-    f32x16 acc[1];
-    wave_chains<S4, 1, 32 * NB4>(G1 + (32 * mb + i) * ld1 + kh, w4, nullptr, acc);
+        for (int r = 0; r < 16; ++r) po[r] = live ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pb, lo, ((r & 3) + 8 * (r >> 2)) * ROWB, 0)) : 0.0f;
+        f32x16 acc[1];
+        wave_chains<S4, 1, 32 * NB4>(G1 + (32 * mb4 + i) * ld1 + kh, w4, nullptr, acc);
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-        mk[r] = rowmask ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mb_, lm, ((r & 3) + 8 * (r >> 2)) * (int)sizeof(float), 0)) : 1.0f;
+        for (int r = 0; r < 16; ++r)
+            mk[r] = rowmask ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mb_, lm, ((r & 3) + 8 * (r >> 2)) * (int)sizeof(float), 0)) : 1.0f;
+        if (live) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float nv = pdp_logsigmoidf(acc[0][r]);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mk[r] * nv + (1.0f - mk[r]) * po[r]), ob, lo, ((r & 3) + 8 * (r >> 2)) * ROWB, 0);
+            for (int r = 0; r < 16; ++r) {
+                const float nv = pdp_logsigmoidf(acc[0][r]);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mk[r] * nv + (1.0f - mk[r]) * po[r]), ob, lo, ((r & 3) + 8 * (r >> 2)) * ROWB, 0);
+            }
+        }
     }
 }
 
@@ -981,13 +993,17 @@ static int launch_agg_pre(int E, const float *state, const float *sign, const fl
     const size_t lds1 = sizeof(float) * (size_t)TM * ((w.Kp1 + 1) + (w.Np1 + 1));
     const size_t res1 = sizeof(float) * ((size_t)w.Kp1 * w.Np1 + (size_t)w.Kp2 * w.Np2) + lds1;
     const bool tile_form = getenv("PDP_NEURAL_AGG_TILE") != nullptr;
-    if (!tile_form && w.din - 1 == 128 && w.Kp1 == 130 && w.Np1 == 128 && w.Kp2 == 100 && w.Np2 == 64) {       // config 3's shapes
-        constexpr int ldw = 131;
+    const bool shape128 = w.din - 1 == 128 && w.Kp1 == 130, shape150 = w.din - 1 == 150 && w.Kp1 == 152;
+    if (!tile_form && (shape128 || shape150) && w.Np1 == 128 && w.Kp2 == 100 && w.Np2 == 64) {
+        // hidden 128 (BASELINE configs) or 150 (the reference's shipped predict config) with the 100 / 50 inner widths
+        const int ldw = shape128 ? 131 : 153;
         const size_t ldsw = sizeof(float) * (size_t)NWAVES * WT * ldw;
-        int s = set_lds((const void *)k_agg_pre_wave<65, 4, 50, 2>, ldsw); if (s != PDP_OK) return s;
+        const void *fn = shape128 ? (const void *)k_agg_pre_wave<65, 4, 50, 2> : (const void *)k_agg_pre_wave<76, 4, 50, 2>;
+        int s = set_lds(fn, ldsw); if (s != PDP_OK) return s;
         const int wt = (E + WT - 1) / WT, need = (wt + NWAVES - 1) / NWAVES;
         const int grid = need < persistent_grid() ? need : persistent_grid();
-        hipLaunchKernelGGL((k_agg_pre_wave<65, 4, 50, 2>), dim3(grid), dim3(NTN), ldsw, st, E, state, sign, edge_mask, w, h2, wt);
+        if (shape128) hipLaunchKernelGGL((k_agg_pre_wave<65, 4, 50, 2>), dim3(grid), dim3(NTN), ldsw, st, E, state, sign, edge_mask, w, h2, wt);
+        else hipLaunchKernelGGL((k_agg_pre_wave<76, 4, 50, 2>), dim3(grid), dim3(NTN), ldsw, st, E, state, sign, edge_mask, w, h2, wt);
     } else if (res1 <= LDS_RES_LIMIT && w.Kp1 <= 64 * PRE_C) {
         int s = set_lds((const void *)k_agg_pre_res, res1); if (s != PDP_OK) return s;
         const int grid = tiles < persistent_grid() ? tiles : persistent_grid();
@@ -1028,10 +1044,16 @@ extern "C" int pdp_neural_aggregate_edges(pdp_problem *p, const pdp_agg_desc *d,
     // form) overlap better than one resident one (12.8 vs 18.3 ms at config 3), so the resident form is opt-in
     const bool post_res = getenv("PDP_NEURAL_POST_RESIDENT") != nullptr;
     const bool post_plain = getenv("PDP_NEURAL_POST_PLAIN") != nullptr;
-    if (!post_res && !post_plain && w.Kp3 == 52 && w.Np3 == 128 && w.Kp4 == 100 && w.Np4 == 128 && w.out == 128) {                   // config 3's shapes
+    if (!post_res && !post_plain && w.Kp3 == 52 && w.Np3 == 128 && w.Kp4 == 100 && ((w.Np4 == 128 && w.out == 128) || (w.Np4 == 160 && w.out == 150))) {
+        // hidden 128 (BASELINE configs) or 150 (the reference's shipped predict config) with the 100 / 50 inner widths
         const size_t ldsp = sizeof(float) * (size_t)TM * (53 + 129);
-        s = set_lds((const void *)k_agg_post_pf<26, 4, 50, 4>, ldsp); if (s != PDP_OK) return s;
-        hipLaunchKernelGGL((k_agg_post_pf<26, 4, 50, 4>), dim3(tiles), dim3(NTN), ldsp, st, E, agg, edge_row, h2, p->edge_sign, edge_mask, rowmask, old, w, out);
+        if (w.Np4 == 128) {
+            s = set_lds((const void *)k_agg_post_pf<26, 4, 50, 4>, ldsp); if (s != PDP_OK) return s;
+            hipLaunchKernelGGL((k_agg_post_pf<26, 4, 50, 4>), dim3(tiles), dim3(NTN), ldsp, st, E, agg, edge_row, h2, p->edge_sign, edge_mask, rowmask, old, w, out);
+        } else {
+            s = set_lds((const void *)k_agg_post_pf<26, 4, 50, 5>, ldsp); if (s != PDP_OK) return s;
+            hipLaunchKernelGGL((k_agg_post_pf<26, 4, 50, 5>), dim3(tiles), dim3(NTN), ldsp, st, E, agg, edge_row, h2, p->edge_sign, edge_mask, rowmask, old, w, out);
+        }
     } else if (post_res && res3 <= LDS_RES_LIMIT && w.Kp3 <= 64 * PRE_C) {
         s = set_lds((const void *)k_agg_post_res, res3); if (s != PDP_OK) return s;
         const int grid = tiles < persistent_grid() ? tiles : persistent_grid();

@@ -21,7 +21,7 @@ def dev_agg(w, fd):
 
 
 @pytest.mark.parametrize('H,m1,a,g,grid', [(32, 100, 50, 100, None), (128, 100, 50, 100, None), (20, 36, 17, 40, None),
-                                           (128, 100, 50, 100, 3), (32, 100, 50, 100, 2)])
+                                           (128, 100, 50, 100, 3), (32, 100, 50, 100, 2), (150, 100, 50, 100, None), (150, 100, 50, 100, 2)])
 def test_aggregator_gru_predict_bit_exact(oracle, monkeypatch, H, m1, a, g, grid):
     from pdp import native
     if grid:          # persistent kernels: many tiles per workgroup (cross-tile prefetch and the pipelined GRU's carried epilogue)
