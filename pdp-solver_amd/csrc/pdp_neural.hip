@@ -783,6 +783,69 @@ __global__ void __launch_bounds__(NTN) k_gru(int E, const float *__restrict__ st
     }
 }
 
+// ---- kernel 5a: k_gru on a 128-edge LDS window -------------------------------------------------------------------------------------------
+// For hidden widths whose column blocks do not divide the 8 waves (150 -> 5 blocks: the 10 blocks of a 64-edge tile take two rounds, the
+// second with 2 waves busy) a 128-edge window gives 20 blocks = 2.5 rounds.  The window fills the LDS (155 KB at hidden 150), so the rows go
+// straight from HBM to LDS at the start of a tile instead of through a register prefetch.
+template <int TMV>
+__global__ void __launch_bounds__(NTN) k_gru_window(int E, const float *__restrict__ state, const float *__restrict__ sign,
+                                                    const float *__restrict__ hprev, const float *__restrict__ rowmask, GruW g,
+                                                    float *__restrict__ out, int ntiles)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int RB = TMV / 32;
+    const int ldx = g.Kpx + 1, ldh = g.Kph + 1;
+    float *X = sm, *Hs = sm + TMV * ldx;
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int hb = g.Hp / 32;
+    const int N3 = 3 * g.Hp;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int e0 = tile * TMV;
+        __syncthreads();                                   // every wave is done with the previous window
+#pragma unroll 4
+        for (int r = wave; r < TMV; r += NWAVES) {
+            const int e = e0 + r;
+#pragma unroll
+            for (int jc = 0; jc < PRE_C; ++jc) {
+                const int c = l + 64 * jc;
+                float v = 0.0f, hv = 0.0f;
+                if (e < E && c < g.Kpx) v = (c < g.dx) ? state[(size_t)e * g.dx + c] : (c == g.dx ? sign[e] : 0.0f);
+                if (e < E && c < g.H) hv = hprev[(size_t)e * g.H + c];
+                if (c < g.Kpx) X[r * ldx + c] = v;
+                if (c < g.Kph) Hs[r * ldh + c] = hv;
+            }
+        }
+        __syncthreads();
+        for (int blk = wave; blk < hb * RB; blk += NWAVES) {
+            const int nb = blk / RB, mb = blk % RB;
+            const int col = 32 * nb + (l & 31);
+            f32x16 ia[1], ha[1], rg, zg;
+            mfma_chain<1, 8>(X, ldx, g.Kpx, g.Wt_ih, N3, nb, mb, g.b_ih, ia);
+            mfma_chain<1, 8>(Hs, ldh, g.Kph, g.Wt_hh, N3, nb, mb, g.b_hh, ha);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rg[r] = pdp_sigmoidf(ha[0][r] + ia[0][r]);
+            mfma_chain<1, 8>(X, ldx, g.Kpx, g.Wt_ih, N3, hb + nb, mb, g.b_ih, ia);
+            mfma_chain<1, 8>(Hs, ldh, g.Kph, g.Wt_hh, N3, hb + nb, mb, g.b_hh, ha);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zg[r] = pdp_sigmoidf(ha[0][r] + ia[0][r]);
+            mfma_chain<1, 8>(X, ldx, g.Kpx, g.Wt_ih, N3, 2 * hb + nb, mb, g.b_ih, ia);
+            mfma_chain<1, 8>(Hs, ldh, g.Kph, g.Wt_hh, N3, 2 * hb + nb, mb, g.b_hh, ha);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * mb + acc_row(r, l);
+                const int e = e0 + row;
+                if (e < E && col < g.H) {
+                    const float ng = pdp_tanhf(ia[0][r] + ha[0][r] * rg[r]);
+                    const float hp = Hs[row * ldh + col];
+                    const float hnew = (hp - ng) * zg[r] + ng;
+                    const float mk = rowmask ? rowmask[e] : 1.0f;
+                    out[(size_t)e * g.H + col] = mk * hnew + (1.0f - mk) * hp;
+                }
+            }
+        }
+    }
+}
+
 // ---- kernel 5b: the same cell, software pipelined inside each wave (hidden width 128) -------------------------------------------------
 // In k_gru the two waves of a SIMD run in lock step (two barriers per tile): both issue their MFMA chains, then both run their
 // activation epilogues, so the matrix pipe idles during every epilogue (rocprofv3: MFMA pipe 46 % busy).  Here every gate is one
@@ -1103,6 +1166,16 @@ extern "C" int pdp_neural_gru(pdp_problem *p, const pdp_gru_desc *d, const float
             hipLaunchKernelGGL(k_gru, dim3(1), dim3(NTN), lds, st, tail, state + o * g.dx, p->edge_sign + o, h + o * g.H, rowmask + o, g,
                                out + o * g.H, 1);
         }
+        PDP_LAUNCH_CHECK();
+        return PDP_OK;
+    }
+    const size_t lds_w = sizeof(float) * (size_t)128 * ((g.Kpx + 1) + (g.Kph + 1));
+    if (!plain && ((g.Hp / 32) * 2) % NWAVES != 0 && lds_w <= LDS_RES_LIMIT) {
+        // column blocks that do not divide the waves (hidden 150): 128-edge window, 2.5 rounds instead of 2 x 2 per 128 edges
+        s = set_lds((const void *)k_gru_window<128>, lds_w); if (s != PDP_OK) return s;
+        const int tw = (E + 127) / 128;
+        const int gridw = tw < persistent_grid() ? tw : persistent_grid();
+        hipLaunchKernelGGL((k_gru_window<128>), dim3(gridw), dim3(NTN), lds_w, st, E, state, p->edge_sign, h, rowmask, g, out, tw);
         PDP_LAUNCH_CHECK();
         return PDP_OK;
     }
