@@ -370,3 +370,41 @@ def test_headline_family_neural_equals_reference():
         np.testing.assert_allclose(p, d['pred_%d' % i], rtol=3e-4, atol=3e-5, err_msg='pred %d' % i)
     np.testing.assert_allclose(ds[1].cpu().numpy()[::97], d['final_dec_f_sample'], rtol=3e-4, atol=3e-5)
     np.testing.assert_array_equal(pred[0].cpu().numpy()[:, 0], d['final_prediction'])
+
+
+def test_test_mode_script(tmp_path):
+    "satyr-train-test.py -t on a Train-style YAML (the reference's keys): same errors as the reference's test() call; training is rejected"
+    import importlib.util
+    import yaml
+    d = load_golden('test_metrics')
+    T, w, bs, seed, gstep = [int(x) for x in d['test_mode_meta']]
+    cfg_path = tmp_path / 'train_style.yaml'
+    cfg_path.write_text(yaml.safe_dump(dict(
+        model_name='t-sp', model_type='p-d-p', version='2.0', has_meta_data=False, train_path=[], validation_path=[],
+        test_path=[os.path.join(REPO, 'tests', 'golden', 'test_mode_batch.json')], model_path=str(tmp_path), repetition_num=1,
+        label_dim=1, edge_feature_dim=1, meta_feature_dim=0, error_dim=3, metric_index=0, prediction_dim=1, hidden_dim=3,
+        mem_hidden_dim=50, agg_hidden_dim=50, mem_agg_hidden_dim=50, classifier_dim=50, batch_size=bs, exploration=0.3, verbose=False,
+        test_recurrence_num=T, max_cache_size=100000, dropout=0, loss_sharpness=5, test_batch_limit=40000000,
+        local_search_iteration=w, epsilon=0.5, tolerance=0.05, t_max=10)))
+    spec = importlib.util.spec_from_file_location('satyr_train_test', os.path.join(REPO, 'pdp-solver_amd', 'satyr-train-test.py'))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    with pytest.raises(SystemExit):
+        mod.run(0, str(cfg_path), True, None, False, False, False, 1)
+    # run() seeds with its first argument; the golden call used seed 21 and global step 7 -- patch the step through the trainer class
+    from pdp.trainer import SatFactorGraphTrainer
+    orig = SatFactorGraphTrainer._build_graph
+
+    def build_with_step(self, config):
+        ms = orig(self, config)
+        ms[0]._global_step.data = torch.tensor([float(gstep)])
+        return ms
+
+    SatFactorGraphTrainer._build_graph = build_with_step
+    try:
+        res = mod.run(seed, str(cfg_path), False, None, False, False, False, 1)
+    finally:
+        SatFactorGraphTrainer._build_graph = orig
+    err = np.asarray(res[0][1]).reshape(-1)
+    ref = d['test_mode_error'].reshape(-1)
+    np.testing.assert_allclose(err[:2], ref[:2], rtol=0, atol=1e-6)
+    assert np.isinf(err[2]) == np.isinf(ref[2])
