@@ -19,7 +19,7 @@ edges = [it[2].shape[1] for it in items]
 print('instances %d, edges %d (min %d max %d per instance)' % (B, sum(edges), min(edges), max(edges)))
 cfg = dict(model_type=MODEL, model_name='mixed', verbose=False, local_search_iteration=100, epsilon=0.5, rng='philox', random_seed=1,
            hidden_dim=128, edge_feature_dim=1, meta_feature_dim=0, prediction_dim=1, mem_hidden_dim=100, agg_hidden_dim=100,
-           mem_agg_hidden_dim=50, classifier_dim=50, test_batch_limit=int(4e9), batch_size=B, test_recurrence_num=T)
+           mem_agg_hidden_dim=50, classifier_dim=50, test_batch_limit=int(4e9), batch_size=B, test_recurrence_num=T, tolerance=0.02, t_max=100)
 torch.manual_seed(1234)
 tr = SatFactorGraphTrainer(cfg, use_cuda=True, logger=logging.getLogger('t'))
 segs = dataset.divide(edges, cfg['test_batch_limit'] // 4, 128)
