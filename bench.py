@@ -269,6 +269,8 @@ def main():
         # dominant kernel k_sp_solve_lds<false, false> (one launch per chunk of iterations): HIP events recorded by the library
         # on the launch stream around every launch; algorithmic bytes = bytes/iteration x iterations per launch
         launch_ms = float(np.mean([l['solve_kernel_ms'] for l in launches])) / n_launch
+        if launch_ms <= 0.0:                            # HBM-resident fallback kernel (instances too large for the LDS): no per-launch events,
+            launch_ms = kms / max(n_launch, 1.0)        # the events around the whole call divided by its launches
         replay_ms = float(np.mean([l['replay_kernel_ms'] for l in launches]))
         bytes_launch = algorithmic_bytes_per_iteration(E, V, F) * it_mean / n_launch
         achieved = bytes_launch / (launch_ms * 1e-3) / 1e9
