@@ -131,3 +131,11 @@ def write_dimacs_directory(directory, instances, stem="inst"):
         write_dimacs(p, n, clauses)
         paths.append(p)
     return paths
+
+
+# the generator classes of the reference's pdp.generator module (uniform and the two Community Attachment variants)
+try:
+    from pdp.cnf_generators import (CNFGeneratorBase, UniformCNFGenerator, ModularCNFGenerator,  # noqa: E402,F401
+                                    VariableModularCNFGenerator, is_sat)
+except ImportError:      # this file loaded on its own next to another `pdp` package (tests/golden/generate_golden.py does that)
+    pass

@@ -689,6 +689,31 @@ def gen_headline_neural():
     save('headline_n200_neural', seeds=np.array(seeds, dtype=np.int64), meta=np.array([200, 840, T, H, it['i']], dtype=np.int64), **rec)
 
 
+
+def gen_generators():
+    """The reference's CNF generators (src/pdp/generator.py) under fixed numpy seeds: uniform, modular and variable-modular,
+    generate() and generate_complete() (the variable-modular generate_complete cannot run in the reference, App. B-11)."""
+    import pdp.generator as RG
+    out = {}
+    specs = [('uniform', lambda: RG.UniformCNFGenerator(20, 40, 2, 5, 2.0, 5.0, 5)),
+             ('modular', lambda: RG.ModularCNFGenerator(3, 30, 60, 0.3, 0.9, 3, 8, 2.0, 5.0, 5)),
+             ('vmodular', lambda: RG.VariableModularCNFGenerator(2, 5, 30, 60, 0.3, 0.9, 3, 8, 2.0, 5.0, 5))]
+    for name, make in specs:
+        for method in ('generate', 'generate_complete'):
+            if name == 'vmodular' and method == 'generate_complete':
+                continue
+            for seed in (1, 2, 3):
+                np.random.seed(seed)
+                g = make()
+                for draw in range(2):
+                    n, m, gm, ef, _, label, clauses = getattr(g, method)()
+                    key = '%s_%s_s%d_d%d' % (name, method, seed, draw)
+                    out[key + '_nm'] = np.array([n, m], dtype=np.int64)
+                    out[key + '_gm'] = np.asarray(gm, dtype=np.int32)
+                    out[key + '_ef'] = np.asarray(ef, dtype=np.float32)
+    save('generators', **out)
+
+
 # ---- E. CLI -------------------------------------------------------------------------------------
 
 def gen_cli():
@@ -741,6 +766,8 @@ if __name__ == '__main__':
         gen_test_metrics()
     if 'headline' in what:
         gen_headline_poison()
+    if 'generators' in what:
+        gen_generators()
     if 'headline_neural' in what:
         gen_headline_neural()
     if 'randinit' in what:

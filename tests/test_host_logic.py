@@ -228,3 +228,53 @@ def test_dataset_shards_cover_the_input_in_order(tmp_path):
             assert len(ds) >= 1
         assert got == [whole[i][5][0] for i in range(len(whole))]
         assert offs == sorted(offs) and offs[0] == 0
+
+
+def test_cnf_generators_reproduce_the_reference_for_a_seed():
+    """uniform / modular / variable-modular generators (reference: src/pdp/generator.py:98-321): same numpy seed, same instance --
+    sizes, edge list and signs of two consecutive draws, for generate() and generate_complete()"""
+    from pdp import generator as G
+    from helpers import load_golden
+    d = load_golden('generators')
+    specs = [('uniform', lambda: G.UniformCNFGenerator(20, 40, 2, 5, 2.0, 5.0, 5)),
+             ('modular', lambda: G.ModularCNFGenerator(3, 30, 60, 0.3, 0.9, 3, 8, 2.0, 5.0, 5)),
+             ('vmodular', lambda: G.VariableModularCNFGenerator(2, 5, 30, 60, 0.3, 0.9, 3, 8, 2.0, 5.0, 5))]
+    checked = 0
+    for name, make in specs:
+        for method in ('generate', 'generate_complete'):
+            if name == 'vmodular' and method == 'generate_complete':
+                with pytest.raises(NotImplementedError):
+                    make().generate_complete()
+                continue
+            for seed in (1, 2, 3):
+                np.random.seed(seed)
+                g = make()
+                for draw in range(2):
+                    n, m, gm, ef, _, label, clauses = getattr(g, method)()
+                    key = '%s_%s_s%d_d%d' % (name, method, seed, draw)
+                    assert [n, m] == d[key + '_nm'].tolist(), key
+                    np.testing.assert_array_equal(np.asarray(gm, dtype=np.int32), d[key + '_gm'], err_msg=key)
+                    np.testing.assert_array_equal(np.asarray(ef, dtype=np.float32), d[key + '_ef'], err_msg=key)
+                    if method == 'generate_complete':
+                        assert len(clauses) == m
+                    checked += 1
+    assert checked == 30
+
+
+def test_generate_dataset_writes_loadable_files(tmp_path):
+    "generate_dataset: JSON lines the loader parses and DIMACS files the native reader parses to the same instance"
+    from pdp import generator as G, native
+    from pdp.factorgraph import dataset
+    np.random.seed(5)
+    g = G.ModularCNFGenerator(3, 20, 30, 0.3, 0.9, 3, 6, 2.0, 4.0, alpha_resolution=2)
+    g.generate_dataset(3, str(tmp_path / 'dimacs'), str(tmp_path / 'json'), 'mod', sat_only=False)
+    jsons = sorted(os.listdir(str(tmp_path / 'json')))
+    assert len(jsons) == 2
+    lines = [l for l in open(os.path.join(str(tmp_path / 'json'), jsons[0])).read().split('\n') if l.strip()]
+    assert len(lines) == 3
+    item = dataset.parse_line(lines[0])
+    ddir = os.path.join(str(tmp_path / 'dimacs'), jsons[0][:-5])
+    files = sorted(os.listdir(ddir))
+    assert len(files) == 3
+    vn, cn, sv, ci = native.dimacs_parse(os.path.join(ddir, 'dimacs_0_sat=False.DIMACS'))
+    assert cn == item[1] and vn == item[0]
