@@ -337,6 +337,18 @@ PDP_HD float pdp_tanhf(float x)
     return pdp_bits2f(pdp_f2bits(v) | (pdp_f2bits(x) & 0x80000000u)) + (x - x);
 }
 
+/* GRU candidate gate: tanh(x) = sign(x) (1 - 2 / (e^{2|x|} + 1)), |x| clamped at 10 (tanh(10) rounds to 1).  Absolute error < 1.2e-7 (half an ulp of 1 from the
+ * division and from the subtraction each, plus a quarter of the exponential's relative error); near 0 the RELATIVE error is not that of a
+ * cancellation-free form, which the GRU does not need: the value only enters h' = (h - n) z + n.  32 instead of 45 VALU instructions on gfx950
+ * (no expm1 reconstruction, no n == 0 select). */
+PDP_HD float pdp_tanhf_abs(float x)
+{
+    const float a = pdp_fminf(pdp_abs(x), 10.0f);
+    const float t = pdp_expf_fin(a + a);
+    const float v = 1.0f - 2.0f / (t + 1.0f);
+    return pdp_bits2f(pdp_f2bits(v) | (pdp_f2bits(x) & 0x80000000u)) + (x - x);
+}
+
 /* ---- the reference's clamped forms ------------------------------------------------------- */
 /* safe_log(x) = log(max(x, eps))  (reference: pdp_propagate.py:133-134, pdp_predict.py:149-150) */
 PDP_HD float pdp_safe_log(float x, float eps) { return pdp_logf(pdp_max(x, eps)); }

@@ -134,7 +134,7 @@ ORC_API void orc_gru(int E, int H, int dx /*state width, input = dx + 1*/, const
             }
             const float r = pdp_sigmoidf(hg[0] + ig[0]);
             const float z = pdp_sigmoidf(hg[1] + ig[1]);
-            const float n = pdp_tanhf(ig[2] + hg[2] * r);
+            const float n = pdp_tanhf_abs(ig[2] + hg[2] * r);
             const float hn = (he[j] - n) * z + n;
             out[e * H + j] = mk * hn + (1.0f - mk) * he[j];
         }

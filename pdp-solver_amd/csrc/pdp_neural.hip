@@ -770,7 +770,7 @@ __global__ void __launch_bounds__(NTN) k_gru(int E, const float *__restrict__ st
                 const int row = 32 * mb + acc_row(r, l);
                 const int e = e0 + row;
                 if (e < E && col < g.H) {
-                    const float ng = pdp_tanhf(ia[0][r] + ha[0][r] * rg[r]);
+                    const float ng = pdp_tanhf_abs(ia[0][r] + ha[0][r] * rg[r]);
                     const float hp = Hs[row * ldh + col];
                     const float hnew = (hp - ng) * zg[r] + ng;
                     const float mk = rowmask ? rowmask[e] : 1.0f;
@@ -835,7 +835,7 @@ __global__ void __launch_bounds__(NTN) k_gru_window(int E, const float *__restri
                 const int row = 32 * mb + acc_row(r, l);
                 const int e = e0 + row;
                 if (e < E && col < g.H) {
-                    const float ng = pdp_tanhf(ia[0][r] + ha[0][r] * rg[r]);
+                    const float ng = pdp_tanhf_abs(ia[0][r] + ha[0][r] * rg[r]);
                     const float hp = Hs[row * ldh + col];
                     const float hnew = (hp - ng) * zg[r] + ng;
                     const float mk = rowmask ? rowmask[e] : 1.0f;
@@ -976,7 +976,7 @@ __global__ void __launch_bounds__(NTN) k_gru_pipe(int E, const float *__restrict
         const float *mp = Mk + (par ^ 1) * TM + row0;
         gru_phase<SX, SH, 26>(xa, ha, wi, wh, voff, ws, bir, bhr, ai, ah, [&](int c) {
             const int ro = (c & 3) + 8 * (c >> 2);
-            const float ng = pdp_tanhf(tq[c]);
+            const float ng = pdp_tanhf_abs(tq[c]);
             const float hnew = (hq[c] - ng) * zg[c] + ng;
             const float mk = mp[ro];
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mk * hnew + (1.0f - mk) * hq[c]), ob, ooff, ro * H * (int)sizeof(float), 0);
@@ -1002,7 +1002,7 @@ __global__ void __launch_bounds__(NTN) k_gru_pipe(int E, const float *__restrict
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             const int ro = (c & 3) + 8 * (c >> 2);
-            const float ng = pdp_tanhf(tq[c]);
+            const float ng = pdp_tanhf_abs(tq[c]);
             const float hnew = (hq[c] - ng) * zg[c] + ng;
             const float mk = mp[ro];
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mk * hnew + (1.0f - mk) * hq[c]), ob, ooff, ro * H * (int)sizeof(float), 0);

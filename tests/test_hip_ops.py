@@ -51,7 +51,7 @@ def test_device_math_bit_exact(oracle):
     from pdp import native
     rng = np.random.RandomState(0)
     x = np.concatenate([rng.uniform(-110, 35, 300000), rng.uniform(-1, 1, 100000), [-92.1034, 0.0, 30.0, np.nan, np.inf, -np.inf]]).astype(np.float32)
-    for fn in ('exp', 'safe_exp', 'safe_exp_fast', 'logsigmoid', 'sigmoid', 'tanh', 'philox'):
+    for fn in ('exp', 'safe_exp', 'safe_exp_fast', 'logsigmoid', 'sigmoid', 'tanh', 'tanh_abs', 'philox'):
         np.testing.assert_array_equal(npy(native.math_apply(fn, t(x))), oracle.math_apply(fn, x), err_msg=fn)
     xl = np.concatenate([np.exp(rng.uniform(-100, 10, 300000)), rng.uniform(0, 2, 100000), [1e-40, 1e-45, 0.0, -1.0, np.nan, np.inf]]).astype(np.float32)
     for fn in ('log', 'safe_log', 'safe_log_fin', 'safe_log_fin_scorer', 'rcp'):

@@ -40,6 +40,9 @@ def test_math_accuracy(oracle):
     assert np.max(np.abs(ls - refs) / np.maximum(np.abs(refs), 1e-30)) < 4e-7
     th = oracle.math_apply('tanh', xs / 4)
     assert np.max(np.abs(th - np.tanh(xs.astype(np.float64) / 4))) < 2e-7
+    tha = oracle.math_apply('tanh_abs', xs / 4)           # the GRU's candidate gate: absolute accuracy only
+    assert np.max(np.abs(tha - np.tanh(xs.astype(np.float64) / 4))) < 1.5e-7
+    assert np.all(np.sign(tha) * np.sign(xs) >= 0) and np.all(np.abs(tha) <= 1.0)
     sg = oracle.math_apply('sigmoid', xs)
     assert np.max(np.abs(sg - 1 / (1 + np.exp(-xs.astype(np.float64))))) < 1.5e-7
     u = oracle.math_apply('philox', np.zeros(100000))
