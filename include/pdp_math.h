@@ -270,10 +270,10 @@ PDP_HD float pdp_fminf(float a, float b)
 #endif
 }
 
-/* e^x for any finite x or NaN: underflows to 0, overflows to +inf (p * 2^128) like expf */
-PDP_HD float pdp_expf_fin(float x)
+/* e^min(x, hi) for any finite x or NaN: underflows to 0; with hi = 89 it overflows to +inf (p * 2^128) like expf */
+PDP_HD float pdp_expf_fin_hi(float x, float hi)
 {
-    const float xc = pdp_fminf(pdp_fmaxf(x, -104.5f), 89.0f);
+    const float xc = pdp_fminf(pdp_fmaxf(x, -104.5f), hi);
     const float t = xc * 1.44269504088896341f;
     const float nf = (t + 12582912.0f) - 12582912.0f;
     float r = fmaf(nf, -0.693359375f, xc);
@@ -289,6 +289,7 @@ PDP_HD float pdp_expf_fin(float x)
     p = p + 1.0f;
     return pdp_scale2(p, (int)nf) + (x - x);
 }
+PDP_HD float pdp_expf_fin(float x) { return pdp_expf_fin_hi(x, 89.0f); }
 
 /* torch F.logsigmoid(x) = min(x, 0) - log1p(exp(-|x|)).  With t = e^-|x| in (0, 1]: log1p(t) = t * P(t), P the degree-8 polynomial
  * fitted to log1p(t) / t at Chebyshev nodes of [0, 1] (truncation 3e-8 relative; with fp32 Horner rounding < 3 ulp over the whole range,
@@ -309,8 +310,29 @@ PDP_HD float pdp_logsigmoidf(float x)
     return pdp_fminf(x, 0.0f) - p * t;                      /* a NaN x is dropped by the min and carried by t */
 }
 
-/* torch.sigmoid(x) = 1 / (1 + exp(-x)); exp(-x) = +inf for x < -88.7 gives 0 like torch */
-PDP_HD float pdp_sigmoidf(float x) { return 1.0f / (1.0f + pdp_expf_fin(-x)); }
+/* 1 / d for 1 <= d <= 2^126 (or NaN).  On the device: v_rcp_f32 (1 ulp) + one Newton step + the residual correction of the compiler's own
+ * division sequence, without its scaling / fix-up instructions, which only matter outside this range -- 8 instead of 12 instructions.  The
+ * result is the correctly rounded quotient for EVERY float of the range: tests/test_hip_ops.py::test_reciprocal_exhaustive compares all
+ * 1.06e9 of them with the IEEE division, which is what the host side (the oracle) computes here. */
+PDP_HD float pdp_rcp_ge1(float d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e = fmaf(-d, r, 1.0f);
+    r = fmaf(e, r, r);
+    const float rem = fmaf(-d, r, 1.0f);
+    float q = fmaf(rem, r, r);
+    const float rem2 = fmaf(-d, q, 1.0f);
+    q = fmaf(rem2, r, q);
+    return q;
+#else
+    return 1.0f / d;
+#endif
+}
+
+/* torch.sigmoid(x) = 1 / (1 + exp(-x)).  The exponent is clamped at 87 so that the denominator stays in the range of pdp_rcp_ge1: for
+ * x < -87 the result is 1.6e-38 where torch's decays on to 0 through the denormals -- a difference of at most 1.6e-38. */
+PDP_HD float pdp_sigmoidf(float x) { return pdp_rcp_ge1(1.0f + pdp_expf_fin_hi(-x, 87.0f)); }
 
 /* tanh(x) = em / (em + 2), em = e^{2|x|} - 1 without cancellation: with 2|x| = n ln2 + r the polynomial part q = e^r - 1 is
  * the exact answer for n == 0.  |x| is clamped at 10 (tanh(10) rounds to 1). */
@@ -345,7 +367,8 @@ PDP_HD float pdp_tanhf_abs(float x)
 {
     const float a = pdp_fminf(pdp_abs(x), 10.0f);
     const float t = pdp_expf_fin(a + a);
-    const float v = 1.0f - 2.0f / (t + 1.0f);
+    const float r = pdp_rcp_ge1(t + 1.0f);                  /* t + 1 in [2, e^20 + 1] */
+    const float v = 1.0f - (r + r);
     return pdp_bits2f(pdp_f2bits(v) | (pdp_f2bits(x) & 0x80000000u)) + (x - x);
 }
 

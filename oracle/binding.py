@@ -264,7 +264,7 @@ class Problem(object):
 
 def math_apply(fn, x):
     names = {'exp': 0, 'log': 1, 'logsigmoid': 2, 'sigmoid': 3, 'tanh': 4, 'safe_exp': 5, 'safe_log': 6,
-             'philox': 7, 'rcp': 8, 'safe_exp_fast': 9, 'safe_log_fin': 10, 'safe_log_fin_scorer': 11, 'exp_fin': 12, 'tanh_abs': 13}
+             'philox': 7, 'rcp': 8, 'safe_exp_fast': 9, 'safe_log_fin': 10, 'safe_log_fin_scorer': 11, 'exp_fin': 12, 'tanh_abs': 13, 'rcp_ge1': 14}
     x = _f(x)
     y = np.zeros_like(x)
     lib().orc_math_apply(C.c_int(names[fn]), _p(x), _p(y), C.c_int64(x.size))

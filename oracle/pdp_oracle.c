@@ -1013,6 +1013,7 @@ ORC_API void orc_math_apply(int fn, const float *x, float *y, int64_t n)
         case 3: y[i] = pdp_sigmoidf(x[i]); break;
         case 4: y[i] = pdp_tanhf(x[i]); break;
         case 13: y[i] = pdp_tanhf_abs(x[i]); break;
+        case 14: y[i] = pdp_rcp_ge1(x[i]); break;
         case 5: y[i] = pdp_safe_exp(x[i]); break;
         case 6: y[i] = pdp_safe_log(x[i], PDP_SP_EPS); break;
         case 7: y[i] = pdp_philox_uniform(0x1234abcdULL, 2u, 7u, (uint32_t)i); break;

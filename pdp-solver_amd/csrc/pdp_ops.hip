@@ -767,6 +767,7 @@ __global__ void k_math_apply(int fn, const float *x, float *y, int64_t n)
         case 3: r = pdp_sigmoidf(x[i]); break;
         case 4: r = pdp_tanhf(x[i]); break;
         case 13: r = pdp_tanhf_abs(x[i]); break;
+        case 14: r = pdp_rcp_ge1(x[i]); break;
         case 5: r = pdp_safe_exp(x[i]); break;
         case 6: r = pdp_safe_log(x[i], PDP_SP_EPS); break;
         case 7: r = pdp_philox_uniform(0x1234abcdULL, 2u, 7u, (uint32_t)i); break;

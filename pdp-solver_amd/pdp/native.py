@@ -465,7 +465,7 @@ def dimacs_parse_many(paths, threads=8):
 
 
 def math_apply(fn, x):
-    names = {'exp': 0, 'log': 1, 'logsigmoid': 2, 'sigmoid': 3, 'tanh': 4, 'safe_exp': 5, 'safe_log': 6, 'philox': 7, 'rcp': 8, 'safe_exp_fast': 9, 'safe_log_fin': 10, 'safe_log_fin_scorer': 11, 'exp_fin': 12, 'tanh_abs': 13}
+    names = {'exp': 0, 'log': 1, 'logsigmoid': 2, 'sigmoid': 3, 'tanh': 4, 'safe_exp': 5, 'safe_log': 6, 'philox': 7, 'rcp': 8, 'safe_exp_fast': 9, 'safe_log_fin': 10, 'safe_log_fin_scorer': 11, 'exp_fin': 12, 'tanh_abs': 13, 'rcp_ge1': 14}
     require_gpu()
     y = torch.empty_like(x)
     check(lib().pdp_math_apply(C.c_int(names[fn]), ptr(x, torch.float32), ptr(y), C.c_int64(x.numel()), _stream()))

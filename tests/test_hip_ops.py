@@ -258,3 +258,21 @@ def test_sat_loss_bit_exact(oracle, sharp):
         ref = np.float32(op.sat_loss(pred, np.float32(coeff), 1e-8, sharp))
         got = npy(hp.sat_loss(t(pred), float(np.float32(coeff)), 1e-8, sharp))[0]
         assert (np.isinf(ref) and np.isinf(got)) or ref == got, (ref, got)
+
+
+def test_reciprocal_exhaustive():
+    """pdp_rcp_ge1 (v_rcp_f32 + Newton step + residual correction, no scaling / fix-up instructions) against the IEEE division for EVERY
+    float in [1, 2^126]: the range of the denominators 1 + e^-x and e^2|x| + 1 of the GRU gates.  Compared on the device with the
+    compiler's own correctly rounded `1.0f / x` (math probe 'rcp', itself checked against the CPU in test_math_functions_bit_exact)."""
+    from pdp import native
+    lo, hi = 0x3f800000, 0x7e800000                      # bit patterns of 1.0f and 2^126
+    step = 1 << 26
+    bad = 0
+    for start in range(lo, hi + 1, step):
+        n = min(step, hi + 1 - start)
+        bits = torch.arange(start, start + n, dtype=torch.int64, device='cuda:0').to(torch.int32)
+        x = bits.view(torch.float32)
+        a = native.math_apply('rcp_ge1', x)
+        b = native.math_apply('rcp', x)
+        bad += int((a.view(torch.int32) != b.view(torch.int32)).sum().item())
+    assert bad == 0
