@@ -7,8 +7,8 @@ variable inside a clause wins, empty clauses and unused variables are dropped, l
 ascending variable index, the label is the last digit of the file stem (directory mode, :105) or the character
 8 from the end of the path (file mode, :118-122).  The parser streams clauses into sparse rows instead of the
 reference's dense [clauses x variables] matrix (native single-pass parser, csrc/pdp_dimacs.hip), so big instances do
-not need O(n*m) memory; the O(m^2)
-subsumption option ``-s`` is out of scope.
+not need O(n*m) memory.  ``-s`` removes subsumed clauses in the reference's two passes (dimacs2json.py:60-83) through an inverted
+literal index instead of its dense [clauses x clauses] product.
 """
 
 import argparse
@@ -45,16 +45,59 @@ def parse_dimacs(path):
     return n, clauses
 
 
-def json_line(path, label):
+def remove_subsumed(signed_vars, clause_ids):
+    """The reference's ``_propagate_constraints`` (dimacs2json.py:60-83) on the compact edge list: pass 1 drops every clause that contains
+    all literals of a LATER clause (equal clauses: the earlier one goes), pass 2 drops, among the survivors, every clause that contains
+    all literals of an EARLIER one.  Variables keep their numbers (the reference compacts them before this step only).  Returns
+    (signed_vars, clause_ids) with the surviving clauses renumbered 1..m' in order."""
+    import numpy as np
+    sv = np.asarray(signed_vars, dtype=np.int64); ci = np.asarray(clause_ids, dtype=np.int64)
+    m = int(ci.max()) if ci.size else 0
+    bounds = np.searchsorted(ci, np.arange(1, m + 2))
+    clauses = [sv[bounds[i]:bounds[i + 1]].tolist() for i in range(m)]
+
+    def survivors(cls, drop_superset_of_later):
+        index = {}
+        for i, c in enumerate(cls):
+            for lit in c:
+                index.setdefault(lit, []).append(i)
+        keep = [True] * len(cls)
+        for i, c in enumerate(cls):                        # clause i as the (candidate) subset
+            if not c:
+                continue
+            lists = sorted((index[lit] for lit in c), key=len)
+            common = set(lists[0])
+            for lst in lists[1:]:
+                common.intersection_update(lst)
+                if not common:
+                    break
+            for j in common:                               # clause j contains every literal of clause i
+                if drop_superset_of_later and j < i:
+                    keep[j] = False
+                if not drop_superset_of_later and j > i:
+                    keep[j] = False
+        return [c for c, k in zip(cls, keep) if k]
+
+    if len(clauses) >= 2:
+        clauses = survivors(clauses, True)
+    if len(clauses) >= 2:
+        clauses = survivors(clauses, False)
+    out_sv = [lit for c in clauses for lit in c]
+    out_ci = [i + 1 for i, c in enumerate(clauses) for _ in c]
+    return np.asarray(out_sv, dtype=np.int32), np.asarray(out_ci, dtype=np.int32)
+
+
+def json_line(path, label, propagate=False):
     "One output line; the text is read by the native parser of libpdp_hip.so (pdp_dimacs_open, include/pdp_hip.h)."
     from pdp import native
     var_num, clause_num, signed_vars, clause_ids = native.dimacs_parse(path)
+    if propagate:
+        signed_vars, clause_ids = remove_subsumed(signed_vars, clause_ids)
+        clause_num = int(clause_ids.max()) if clause_ids.size else 0
     return generator.format_json_line(var_num, clause_num, signed_vars, clause_ids, label=label, name=os.path.split(path)[1])
 
 
 def convert_directory(dimacs_dir, output_file, propagate=False, only_positive=False):
-    if propagate:
-        raise NotImplementedError("-s/--simplify (clause subsumption) is out of scope for the native port")
     file_list = [os.path.join(dimacs_dir, f) for f in os.listdir(dimacs_dir) if os.path.isfile(os.path.join(dimacs_dir, f))]
     with open(output_file, 'w') as f:
         for path in file_list:
@@ -64,19 +107,17 @@ def convert_directory(dimacs_dir, output_file, propagate=False, only_positive=Fa
             label = float(name[-1]) if name[-1].isdigit() else -1
             if only_positive and label == 0:
                 continue
-            f.write(json_line(path, label) + '\n')
+            f.write(json_line(path, label, propagate) + '\n')
 
 
 def convert_file(file_name, output_file, propagate=False):
-    if propagate:
-        raise NotImplementedError("-s/--simplify (clause subsumption) is out of scope for the native port")
     if len(file_name) < 8:
         label = -1
     else:
         c = file_name[-8]
         label = float(c) if c.isdigit() else -1
     with open(output_file, 'w') as f:
-        f.write(json_line(file_name, label) + '\n')
+        f.write(json_line(file_name, label, propagate) + '\n')
 
 
 if __name__ == '__main__':

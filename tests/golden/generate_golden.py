@@ -714,6 +714,27 @@ def gen_generators():
     save('generators', **out)
 
 
+
+def gen_subsumption():
+    "dimacs2json -s (clause subsumption, dimacs2json.py:60-83) on files with duplicate, subsumed and opposite-sign clauses"
+    import dimacs2json as RDJ
+    ddir = os.path.join(HERE, 'dimacs_subsume')
+    os.makedirs(ddir, exist_ok=True)
+    rng = np.random.RandomState(77)
+    for i in range(4):
+        n = 12 + 2 * i
+        clauses = gen.uniform_ksat(n, 30, 3, rng)
+        extra = []
+        for c in clauses[:10]:
+            extra.append(c[:2])                                   # subsumes its parent (later in the file)
+            extra.append(c + [int(((abs(c[0]) % n) + 1) * (1 if i % 2 else -1))] if abs(c[0]) % n + 1 not in [abs(x) for x in c] else c)
+            extra.append([-c[0]] + c[1:])                         # opposite sign: no subsumption
+        clauses = clauses[:5] + extra[:12] + clauses[5:] + extra[12:] + [clauses[3], clauses[7][:1]]
+        gen.write_dimacs(os.path.join(ddir, 'sub_%d_%d.cnf' % (i, i % 2)), n, clauses)
+    RDJ.convert_directory(ddir, os.path.join(HERE, 'dimacs_subsume.converted.jsonl'), True)
+    RDJ.convert_directory(ddir, os.path.join(HERE, 'dimacs_subsume.plain.jsonl'), False)
+
+
 # ---- E. CLI -------------------------------------------------------------------------------------
 
 def gen_cli():
@@ -768,6 +789,8 @@ if __name__ == '__main__':
         gen_headline_poison()
     if 'generators' in what:
         gen_generators()
+    if 'subsume' in what:
+        gen_subsumption()
     if 'headline_neural' in what:
         gen_headline_neural()
     if 'randinit' in what:

@@ -278,3 +278,16 @@ def test_generate_dataset_writes_loadable_files(tmp_path):
     assert len(files) == 3
     vn, cn, sv, ci = native.dimacs_parse(os.path.join(ddir, 'dimacs_0_sat=False.DIMACS'))
     assert cn == item[1] and vn == item[0]
+
+
+def test_converter_subsumption_equals_reference(tmp_path):
+    "dimacs2json -s: the two subsumption passes of the reference (dimacs2json.py:60-83), byte-identical lines"
+    import dimacs2json
+    ddir = os.path.join(REPO, 'tests', 'golden', 'dimacs_subsume')
+    out = tmp_path / 's.jsonl'
+    dimacs2json.convert_directory(ddir, str(out), True)
+    got = {json.loads(l)[4][0]: l for l in out.read_text().split('\n') if l.strip()}
+    ref = {json.loads(l)[4][0]: l for l in open(os.path.join(REPO, 'tests', 'golden', 'dimacs_subsume.converted.jsonl')).read().split('\n') if l.strip()}
+    plain = {json.loads(l)[4][0]: l for l in open(os.path.join(REPO, 'tests', 'golden', 'dimacs_subsume.plain.jsonl')).read().split('\n') if l.strip()}
+    assert got == ref and len(ref) == 4
+    assert all(json.loads(ref[k])[0][1] < json.loads(plain[k])[0][1] for k in ref)       # every file really lost clauses
