@@ -912,7 +912,10 @@ __global__ void __launch_bounds__(NTN) k_gru_pipe(int E, const float *__restrict
     constexpr int SH = 64, H = 128;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int ldx = 2 * SX + 1, ldh = 2 * SH + 1;
-    float *X = sm, *Hs = sm + TM * ldx, *Mk = Hs + TM * ldh;     // Mk [2][TM]: row masks of the current and the previous tile
+    // two tile buffers (X, Hs), used alternately: the next tile's rows are dropped into the other buffer as soon as they have arrived, while
+    // this tile still computes -- one barrier per tile, and the deposit is off the critical path
+    constexpr int TB = TM * (ldx + ldh);
+    float *X = sm, *Hs = sm + TM * ldx, *Mk = sm + 2 * TB;        // Mk [3][TM]: row masks of the previous, the current and the next tile
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
     // input row = [message, edge sign, zero pad] of 2 SX floats.  WIDE (np-nd-np): the message is H = 128 floats, 512 bytes per edge = one
     // dwordx2 per lane and row, the sign column by wave 0.  Narrow (p-nd-np: 3 or 2 survey columns): lane c loads column c of the row.
@@ -933,20 +936,21 @@ __global__ void __launch_bounds__(NTN) k_gru_pipe(int E, const float *__restrict
         if (WIDE && wave == 0) psg = sign[e0 + l];
         if (wave == 1) psg = MASK ? rowmask[e0 + l] : 1.0f;
     };
-    auto deposit = [&](int par) {
+    auto deposit = [&](int par, int mslot) {
+        float *Xb = X + par * TB, *Hb = Hs + par * TB;
 #pragma unroll
         for (int jr = 0; jr < PRE_R; ++jr) {
             const int r = wave + NWAVES * jr;
-            if constexpr (WIDE) { X[r * ldx + 2 * l] = px[jr].x; X[r * ldx + 2 * l + 1] = px[jr].y; }
-            else { if (l < 2 * SX) X[r * ldx + l] = px[jr].x; }
-            Hs[r * ldh + 2 * l] = ph[jr].x; Hs[r * ldh + 2 * l + 1] = ph[jr].y;
+            if constexpr (WIDE) { Xb[r * ldx + 2 * l] = px[jr].x; Xb[r * ldx + 2 * l + 1] = px[jr].y; }
+            else { if (l < 2 * SX) Xb[r * ldx + l] = px[jr].x; }
+            Hb[r * ldh + 2 * l] = ph[jr].x; Hb[r * ldh + 2 * l + 1] = ph[jr].y;
         }
-        if (WIDE && wave == 0) X[l * ldx + H] = psg;
-        if (wave == 1) Mk[par * TM + l] = psg;
+        if (WIDE && wave == 0) Xb[l * ldx + H] = psg;
+        if (wave == 1) Mk[mslot * TM + l] = psg;
     };
     if (threadIdx.x < TM) {
-        if (WIDE) X[threadIdx.x * ldx + H + 1] = 0.0f;    // zero pad column (never overwritten)
-        Mk[threadIdx.x] = 0.0f; Mk[TM + threadIdx.x] = 0.0f;
+        if (WIDE) { X[threadIdx.x * ldx + H + 1] = 0.0f; X[TB + threadIdx.x * ldx + H + 1] = 0.0f; }   // zero pad column (never overwritten)
+        Mk[2 * TM + threadIdx.x] = 0.0f;                    // the "previous tile" row of the first pass (rows 0 and 1 are deposited before they are read)
     }
     const int nb = wave >> 1, mb = wave & 1, i = l & 31, kh = l >> 5;
     const int col = 32 * nb + i;
@@ -964,17 +968,18 @@ __global__ void __launch_bounds__(NTN) k_gru_pipe(int E, const float *__restrict
 #pragma unroll
     for (int r = 0; r < 16; ++r) { tq[r] = 0.0f; zg[r] = 0.0f; hq[r] = 0.0f; }
     int tile = blockIdx.x;
-    if (tile < ntiles) { fetch(tile); deposit(0); }
+    if (tile < ntiles) { fetch(tile); deposit(0, 0); }
     int e_prev = tile * TM;                               // first pass: the slices store zeros where this lane stores its results later
-    int par = 0;                                          // Mk[par] = masks of the current tile, Mk[par ^ 1] = of the previous one
-    for (; tile < ntiles; tile += gridDim.x, par ^= 1) {
+    int par = 0, ms = 0;                                  // tile buffer of the current tile; Mk[ms] = its masks, Mk[(ms + 2) % 3] = the previous tile's
+    for (; tile < ntiles; tile += gridDim.x, par ^= 1, ms = (ms + 1) % 3) {
         __syncthreads();
         const int next = tile + gridDim.x;
         if (next < ntiles) fetch(next);
+        const float *xa_b = xa + par * TB, *ha_b = ha + par * TB;
         f32x16 ai, ah, rg;
         const __amdgpu_buffer_rsrc_t ob = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)e_prev * H), 0, TM * H * (int)sizeof(float), 0x00020000);
-        const float *mp = Mk + (par ^ 1) * TM + row0;
-        gru_phase<SX, SH, 26>(xa, ha, wi, wh, voff, ws, bir, bhr, ai, ah, [&](int c) {
+        const float *mp = Mk + ((ms + 2) % 3) * TM + row0;
+        gru_phase<SX, SH, 26>(xa_b, ha_b, wi, wh, voff, ws, bir, bhr, ai, ah, [&](int c) {
             const int ro = (c & 3) + 8 * (c >> 2);
             const float ng = pdp_tanhf_abs(tq[c]);
             const float hnew = (hq[c] - ng) * zg[c] + ng;
@@ -983,22 +988,21 @@ __global__ void __launch_bounds__(NTN) k_gru_pipe(int E, const float *__restrict
         });
 #pragma unroll
         for (int r = 0; r < 16; ++r) rg[r] = ah[r] + ai[r];
-        gru_phase<SX, SH, 16>(xa, ha, wi, wh, voff + H * (int)sizeof(float), ws, biz, bhz, ai, ah, [&](int c) { float v = pdp_sigmoidf(rg[c]); asm volatile("" : "+v"(v)); rg[c] = v; });
+        if (next < ntiles) deposit(par ^ 1, (ms + 1) % 3);   // nobody reads the other buffer (or that mask row) during this tile
+        gru_phase<SX, SH, 16>(xa_b, ha_b, wi, wh, voff + H * (int)sizeof(float), ws, biz, bhz, ai, ah, [&](int c) { float v = pdp_sigmoidf(rg[c]); asm volatile("" : "+v"(v)); rg[c] = v; });
 #pragma unroll
         for (int r = 0; r < 16; ++r) zg[r] = ah[r] + ai[r];
-        gru_phase<SX, SH, 16>(xa, ha, wi, wh, voff + 2 * H * (int)sizeof(float), ws, bin, bhn, ai, ah, [&](int c) { float v = pdp_sigmoidf(zg[c]); asm volatile("" : "+v"(v)); zg[c] = v; });
+        gru_phase<SX, SH, 16>(xa_b, ha_b, wi, wh, voff + 2 * H * (int)sizeof(float), ws, bin, bhn, ai, ah, [&](int c) { float v = pdp_sigmoidf(zg[c]); asm volatile("" : "+v"(v)); zg[c] = v; });
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             tq[r] = ai[r] + ah[r] * rg[r];
-            hq[r] = Hs[(row0 + (r & 3) + 8 * (r >> 2)) * ldh + col];
+            hq[r] = Hs[par * TB + (row0 + (r & 3) + 8 * (r >> 2)) * ldh + col];
         }
         e_prev = tile * TM;
-        __syncthreads();                                   // every wave is done with X / Hs
-        if (next < ntiles) deposit(par ^ 1);
     }
     if (blockIdx.x < ntiles) {
         const __amdgpu_buffer_rsrc_t ob = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)e_prev * H), 0, TM * H * (int)sizeof(float), 0x00020000);
-        const float *mp = Mk + (par ^ 1) * TM + row0;       // par was flipped once more when the loop ended
+        const float *mp = Mk + ((ms + 2) % 3) * TM + row0;   // ms was advanced once more when the loop ended
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             const int ro = (c & 3) + 8 * (c >> 2);
@@ -1151,7 +1155,7 @@ extern "C" int pdp_neural_gru(pdp_problem *p, const pdp_gru_desc *d, const float
         // the full tiles, the plain one on the ragged tail
         const int full = E / TM, tail = E - full * TM;
         if (full > 0) {
-            const size_t ldsp = lds + sizeof(float) * 2 * TM;
+            const size_t ldsp = 2 * lds + sizeof(float) * 3 * TM;        // two tile buffers + three mask rows
             const int grid = full < persistent_grid() ? full : persistent_grid();
             if (g.Kpx == 130) {
                 s = set_lds((const void *)k_gru_pipe<65, true>, ldsp); if (s != PDP_OK) return s;
