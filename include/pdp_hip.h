@@ -179,6 +179,9 @@ typedef struct pdp_solve_args {
     int32_t time_kernels;         /* in: 1 = bracket every solver launch with HIP events and report the sums below */
     float solve_kernel_ms_host;   /* out: device time of the chunk launches (time_kernels == 1) */
     float replay_kernel_ms_host;  /* out: device time of the replay launches (time_kernels == 1) */
+    int32_t replicas_identical;   /* in: 1 = the R replicas of every instance (batch replication, solver.py:56-82) start from identical state,
+                                   * so their trajectories coincide and the replica-aware termination rule (trainer.py:157-160) equals the
+                                   * per-replica one; required when the problem was created with replication > 1 */
 } pdp_solve_args;
 int pdp_sp_solve(pdp_problem *p, pdp_solve_args *args, void *stream);
 

@@ -1630,7 +1630,7 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
     PDP_REQUIRE(p && a && p->av, "NULL argument / state not bound");
     PDP_REQUIRE(a->model == PDP_MODEL_SP, "persistent solve: only the SP triple is implemented (use the step-wise path)");
     PDP_REQUIRE(a->q && a->fs && a->active_mask && a->decimator, "NULL state array");
-    PDP_REQUIRE(p->R == 1, "persistent solve needs replication == 1 (replicas couple through the termination check)");
+    PDP_REQUIRE(p->R == 1 || a->replicas_identical, "persistent solve with batch replication needs identical replicas (replicas couple through the termination check)");
     hipStream_t st = ST(stream);
     const int T = a->iterations;
     a->iterations_run_host = 0; a->used_lds_host = 0; a->kernel_launches_host = 0; a->replay_launches_host = 0;

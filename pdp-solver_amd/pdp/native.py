@@ -97,7 +97,8 @@ class SolveArgs(C.Structure):
                 ('coins', C.c_void_p), ('q', C.c_void_p), ('fs', C.c_void_p), ('active_mask', C.c_void_p),
                 ('decimator', C.c_void_p), ('check_termination', C.c_int32), ('iterations_run_host', C.c_int32),
                 ('used_lds_host', C.c_int32), ('kernel_launches_host', C.c_int32), ('replay_launches_host', C.c_int32),
-                ('time_kernels', C.c_int32), ('solve_kernel_ms_host', C.c_float), ('replay_kernel_ms_host', C.c_float)]
+                ('time_kernels', C.c_int32), ('solve_kernel_ms_host', C.c_float), ('replay_kernel_ms_host', C.c_float),
+                ('replicas_identical', C.c_int32)]
 
 
 class AggDesc(C.Structure):
@@ -409,9 +410,10 @@ class Problem(object):
 
     # -- persistent solve -----------------------------------------------------------------------------------------
     def sp_solve(self, q, fs, active_mask, dec, iterations, tolerance, t_max, pi=0.0, model=MODEL_SP,
-                 decimation_probability=0.5, seed=0, coins=None, check_termination=True, time_kernels=False):
+                 decimation_probability=0.5, seed=0, coins=None, check_termination=True, time_kernels=False, replicas_identical=False):
         a = SolveArgs()
         a.time_kernels = 1 if time_kernels else 0
+        a.replicas_identical = 1 if replicas_identical else 0
         a.model = model; a.iterations = iterations; a.tolerance = tolerance; a.t_max = t_max; a.pi = pi
         a.decimation_probability = decimation_probability; a.seed = seed
         a.coins = ptr(coins, torch.float32).value if coins is not None else None

@@ -190,8 +190,21 @@ class PropagatorDecimatorSolverBase(nn.Module):
         return (prediction, (propagator_state, decimator_state))
 
     # -----------------------------------------------------------------------------------------------------------
-    def _can_run_persistent(self, sat_problem, is_training, check_termination):
-        return (self._persistent and not is_training and sat_problem._batch_replication == 1
+    @staticmethod
+    def _replicas_identical(sat_problem, states):
+        """Batch replication with a deterministic initial state (the predict path, base.py:288): every replica of an instance starts from
+        the same messages, so the R copies run through identical sweeps and the replica-aware termination rule (trainer.py:157-160: all
+        copies stop when one is solved) coincides with the per-copy rule the persistent kernel implements."""
+        R = sat_problem._batch_replication
+        for x in states:
+            v = x.reshape(R, -1)
+            if not bool((v == v[0:1]).all().item()):
+                return False
+        return True
+
+    def _can_run_persistent(self, sat_problem, is_training, check_termination, states=()):
+        return (self._persistent and not is_training
+                and (sat_problem._batch_replication == 1 or self._replicas_identical(sat_problem, states))
                 and type(self._propagator) is pdp_propagate.SurveyPropagator
                 and type(self._decimator) is pdp_decimate.SequentialDecimator
                 and type(self._decimator._scorer) is pdp_predict.SurveyScorer
@@ -200,7 +213,7 @@ class PropagatorDecimatorSolverBase(nn.Module):
                 and _is_standard_termination(check_termination))
 
     def _forward_core(self, init_propagator_state, init_decimator_state, sat_problem, iteration_num, is_training, check_termination):
-        if self._can_run_persistent(sat_problem, is_training, check_termination):
+        if self._can_run_persistent(sat_problem, is_training, check_termination, tuple(init_propagator_state[:2]) + tuple(init_decimator_state[:2])):
             out = self._forward_core_persistent(init_propagator_state, init_decimator_state, sat_problem, iteration_num, check_termination)
             if out is not None:
                 return out
@@ -221,7 +234,8 @@ class PropagatorDecimatorSolverBase(nn.Module):
         try:
             iters, used_lds = nat.sp_solve(q, fs, active_mask, handle, int(iteration_num), self._decimator._tolerance,
                                            self._decimator._t_max, self._propagator._pi,
-                                           check_termination=check_termination is not None)
+                                           check_termination=check_termination is not None,
+                                           replicas_identical=sat_problem._batch_replication > 1)
         except native.SpeculationFailed:
             return None            # the library restored every array it touched; fall back to the strict step-wise loop
         self.last_run.update(path='persistent-lds' if used_lds else 'persistent-hbm', iterations=iters)

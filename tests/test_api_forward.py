@@ -57,6 +57,9 @@ CASES = [('trace_pdp_n50', 'p-d-p', dict(tolerance=0.02, t_max=100)),
 def test_forward_equals_reference_golden(name, model_type, kw, persistent):
     d, tr, m, pred, states, batch = run_golden(name, model_type, persistent=persistent, **kw)
     np.testing.assert_array_equal(pred[0].cpu().numpy()[:, 0], d['final_prediction'])
+    if model_type == 'p-d-p' and int(d['meta'][3]) > 1:
+        # batch replication with the deterministic initial state: identical replicas, so the persistent loop is allowed
+        assert m.last_run['path'] == ('persistent-lds' if persistent else 'stepwise')
     if model_type == 'p-d-p' and int(d['meta'][3]) == 1:
         assert m.last_run['iterations'] == int(d['iterations_run'][0])
         assert m.last_run['path'] == ('persistent-lds' if persistent else 'stepwise')
