@@ -172,6 +172,8 @@ def main():
                     help="sp: configs[1] (headline metric); neural: configs[2] 'np-nd-np' hidden_dim=128 on the same graph (fp32 MFMA)")
     ap.add_argument('--hidden', type=int, default=128)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--isolated', action='store_true', help="sp workload: every instance solved on its own (no batch-wide couplings of the "
+                    "reference, hence no NaN-poison replay); the default is the reference's strict semantics")
     ap.add_argument('--seed-rank', type=int, default=None, help='generate the batch another rank would get (checks of the sharded run on one GPU)')
     ap.add_argument('--cpu-sample-batch', type=int, default=1000)
     ap.add_argument('--cpu-sample-iters', type=int, default=100)
@@ -221,7 +223,7 @@ def main():
         prob.simplify()
         ev0.record()
         try:
-            it, lds = prob.sp_solve(q, fs, am, dec, args.iters, args.tolerance, args.t_max, time_kernels=True)
+            it, lds = prob.sp_solve(q, fs, am, dec, args.iters, args.tolerance, args.t_max, time_kernels=True, isolate_instances=args.isolated)
             path = 'persistent-lds' if lds else 'persistent-hbm'
         except native.SpeculationFailed:
             raise SystemExit("bench: speculation failed on the benchmark batch (unexpected)")
@@ -300,7 +302,8 @@ def main():
                        'solve_call_ms': kms, 'kernel_launches_per_call': n_launch, 'kernel_ms_per_launch': launch_ms,
                        'poison_replay_launches_per_call': n_replay, 'poison_replay_ms_per_call': replay_ms,
                        'algorithmic_bytes_per_launch': bytes_launch, 'setup_ms_upload_and_layout': setup_ms, 'solved_fraction': n_solved / n_inst, 'unsat_clauses_total': n_unsat,
-                       'walksat_steps': ws_steps, 'tolerance': args.tolerance, 't_max': args.t_max, 'parallelism': 'instances sharded, dp%d' % world},
+                       'walksat_steps': ws_steps, 'tolerance': args.tolerance, 't_max': args.t_max, 'parallelism': 'instances sharded, dp%d' % world,
+                       'semantics': 'isolated instances' if args.isolated else "reference (batch-wide couplings reproduced)"},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'valu_issue': valu, 'kernel': 'k_sp_solve_lds<false, false>',
                          'note': 'achieved = streaming-model algorithmic bytes (41E+36V+8F per iteration) x iterations per launch / '

@@ -182,6 +182,10 @@ typedef struct pdp_solve_args {
     int32_t replicas_identical;   /* in: 1 = the R replicas of every instance (batch replication, solver.py:56-82) start from identical state,
                                    * so their trajectories coincide and the replica-aware termination rule (trainer.py:157-160) equals the
                                    * per-replica one; required when the problem was created with replication > 1 */
+    int32_t isolate_instances;    /* in: 1 = "fixed" semantics instead of the reference's: every instance is solved on its own -- the
+                                   * batch-global minimum of sparse_max / sparse_argmax is taken as 0 and a NaN survey stops the decimation
+                                   * of its own instance only (in the reference it stops the whole batch).  Never
+                                   * returns PDP_ERR_SPECULATION.  LDS-resident solver only. */
 } pdp_solve_args;
 int pdp_sp_solve(pdp_problem *p, pdp_solve_args *args, void *stream);
 

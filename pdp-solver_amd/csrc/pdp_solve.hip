@@ -1382,10 +1382,11 @@ __global__ void __launch_bounds__(256) k_solve_import(PView pv, const float *q, 
 }
 
 // after pass 1 of a chunk: does a NaN poison the batch from this chunk on?  
-__global__ void k_solve_post(SolveCtl *ctl, SolveCall *call, int c)
+__global__ void k_solve_post(SolveCtl *ctl, SolveCall *call, int c, int isolate)
 {
     if (call->stop) return;
     ctl->do_replay = 0; ctl->replay_count = 0;
+    if (isolate) return;                            // isolated instances: a NaN stays inside its instance, nothing is replayed
     if (!call->poisoned_all && ctl->nan_iter < (uint32_t)c) {
         ctl->poison_from = (int32_t)ctl->nan_iter;
         call->poisoned_all = 1;
@@ -1403,15 +1404,15 @@ __global__ void k_replay_list(int B, const int32_t *last_event, SolveCtl *ctl, c
 }
 
 // after the (possible) replay: speculation check of the chunk and loop control
-__global__ void k_solve_finish(SolveCtl *ctl, SolveCall *call, const uint32_t *spec_used, const uint32_t *spec_zero, int c, int chunk_start)
+__global__ void k_solve_finish(SolveCtl *ctl, SolveCall *call, const uint32_t *spec_used, const uint32_t *spec_zero, int c, int chunk_start, int isolate)
 {
     if (call->stop) return;
-    if (ctl->violation) call->fail = 1;
+    if (ctl->violation && !isolate) call->fail = 1;
     // iterations at or after the poison point are not speculated on (the reference's reductions are NaN there), and the
     // kernel records nothing in a poisoned iteration
     const int poison_from = ctl->do_replay ? ctl->poison_from : 0x7fffffff;
     for (int t = 0; t < c && t < poison_from; ++t)
-        if ((uint32_t)t < ctl->perm_zero && (spec_used[t] & ~spec_zero[t]) != 0u) call->fail = 1;
+        if (!isolate && (uint32_t)t < ctl->perm_zero && (spec_used[t] & ~spec_zero[t]) != 0u) call->fail = 1;
     const uint32_t it = ctl->iters_run;
     call->total_iters = (uint32_t)chunk_start + it;
     if (it < (uint32_t)c) call->stop = 1;          // every instance went inactive inside this chunk (global early exit, solver.py:383)
@@ -1579,11 +1580,11 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
             else hipLaunchKernelGGL((k_sp_solve_lds<false, true>), dim3(p->B), dim3(nt_lds), lds, st, make_view(p), sp);
             if (timed) PDP_HIP_CHECK(hipEventRecord(p->res_events[4 * k + 2 * pass + 1], st));
             if (pass == 0) {
-                hipLaunchKernelGGL(k_solve_post, dim3(1), dim3(1), 0, st, ctl + k, call, c);
+                hipLaunchKernelGGL(k_solve_post, dim3(1), dim3(1), 0, st, ctl + k, call, c, (int)a->isolate_instances);
                 hipLaunchKernelGGL(k_replay_list, dim3((p->B + 255) / 256), dim3(256), 0, st, p->B, (const int32_t *)last_event, ctl + k, (const SolveCall *)call, replay_list);
             }
         }
-        hipLaunchKernelGGL(k_solve_finish, dim3(1), dim3(1), 0, st, ctl + k, call, (const uint32_t *)sp.spec_used, (const uint32_t *)sp.spec_zero, c, done);
+        hipLaunchKernelGGL(k_solve_finish, dim3(1), dim3(1), 0, st, ctl + k, call, (const uint32_t *)sp.spec_used, (const uint32_t *)sp.spec_zero, c, done, (int)a->isolate_instances);
         PDP_LAUNCH_CHECK();
         done += c;
     }
@@ -1660,6 +1661,7 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
         // only one workgroup per CU (the same 16 waves per CU either way)
         const int nt_r = p->max_e <= 1024 ? 256 : (lds_r > 80 * 1024 ? 1024 : 512);
         if (fits_r) return sp_solve_resident(p, a, st, force_r, lds_r, nt_r, C);
+        PDP_REQUIRE(!a->isolate_instances, "isolated-instance mode needs instances that fit the LDS-resident solver");
     }
     // ---- instances too large for the LDS: HBM-resident kernel, host-driven chunk loop -----------------------------------
 

@@ -145,6 +145,7 @@ class PropagatorDecimatorSolverBase(nn.Module):
         self._rng = rng                  # 'torch': reference-compatible CPU generator stream, 'philox': on device
         self._seed = seed
         self._persistent = persistent    # allow the one-launch persistent loop when the plug-ins permit it
+        self._isolated = False           # True: "fixed" semantics -- instances solved on their own, no batch-wide couplings (persistent loop only)
         self.last_run = {}               # diagnostics of the most recent forward (iterations, path taken ...)
 
     def parameter_count(self):
@@ -213,7 +214,10 @@ class PropagatorDecimatorSolverBase(nn.Module):
                 and _is_standard_termination(check_termination))
 
     def _forward_core(self, init_propagator_state, init_decimator_state, sat_problem, iteration_num, is_training, check_termination):
-        if self._can_run_persistent(sat_problem, is_training, check_termination, tuple(init_propagator_state[:2]) + tuple(init_decimator_state[:2])):
+        can = self._can_run_persistent(sat_problem, is_training, check_termination, tuple(init_propagator_state[:2]) + tuple(init_decimator_state[:2]))
+        if self._isolated and not can:
+            raise native.NativeError("isolated-instance mode runs on the persistent SP loop only (p-d-p, standard termination check)")
+        if can:
             out = self._forward_core_persistent(init_propagator_state, init_decimator_state, sat_problem, iteration_num, check_termination)
             if out is not None:
                 return out
@@ -235,7 +239,7 @@ class PropagatorDecimatorSolverBase(nn.Module):
             iters, used_lds = nat.sp_solve(q, fs, active_mask, handle, int(iteration_num), self._decimator._tolerance,
                                            self._decimator._t_max, self._propagator._pi,
                                            check_termination=check_termination is not None,
-                                           replicas_identical=sat_problem._batch_replication > 1)
+                                           replicas_identical=sat_problem._batch_replication > 1, isolate_instances=self._isolated)
         except native.SpeculationFailed:
             return None            # the library restored every array it touched; fall back to the strict step-wise loop
         self.last_run.update(path='persistent-lds' if used_lds else 'persistent-hbm', iterations=iters)

@@ -46,6 +46,7 @@ class SatFactorGraphTrainer(FactorGraphTrainerBase):
         if t == 'p-d-p':
             model = solver.SurveyPropagatorSolver(device=self._device, name=config['model_name'], tolerance=config['tolerance'],
                                                   t_max=config['t_max'], persistent=config.get('persistent', True), **common)
+            model._isolated = bool(config.get('isolated', False))
         elif t == 'walk-sat':
             model = solver.WalkSATSolver(device=self._device, name=config['model_name'],
                                          iteration_num=config['local_search_iteration'], epsilon=config['epsilon'], rng=rng, seed=seed)

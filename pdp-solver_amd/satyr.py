@@ -3,7 +3,8 @@
 
 Same positionals, flags, YAML keys and output format as the reference CLI (reference: satyr.py:45-109).
 Additions: ``--rng {torch,philox}`` (torch = the reference's CPU random stream, bit-compatible results for the
-same ``-s`` seed; philox = on-device counters, fastest) and ``--stepwise`` (disable the one-launch persistent loop).
+same ``-s`` seed; philox = on-device counters, fastest), ``--stepwise`` (disable the one-launch persistent loop) and ``--isolated``
+(every instance on its own instead of the reference's batch-wide couplings).
 ``-c/--cpu_mode`` is rejected: the hot path has no CPU fallback.  Launched through ``python -m torch.distributed.run --nproc-per-node N``
 it runs one process per GPU on a shard of the input each and reduces the result once over RCCL.
 """
@@ -66,6 +67,9 @@ def main(argv=None):
     parser.add_argument('-o', '--output', help='The JSON output file', default='')
     parser.add_argument('--rng', help='Random source for random fill / Walk-SAT', choices=['torch', 'philox'], default='torch')
     parser.add_argument('--stepwise', help='Disable the persistent one-launch PDP loop', action='store_true')
+    parser.add_argument('--isolated', help='Solve every instance on its own: none of the batch-wide couplings of the reference '
+                        '(global minima, NaN poisoning of the whole batch); p-d-p only, results differ from the reference where those couplings act',
+                        action='store_true')
     args = vars(parser.parse_args(argv))
 
     with open(args['model_config'], 'r') as f:

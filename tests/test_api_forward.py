@@ -411,3 +411,46 @@ def test_test_mode_script(tmp_path):
     ref = d['test_mode_error'].reshape(-1)
     np.testing.assert_allclose(err[:2], ref[:2], rtol=0, atol=1e-6)
     assert np.isinf(err[2]) == np.isinf(ref[2])
+
+
+def test_isolated_mode_properties():
+    """'isolated' mode of the persistent solver (a "fixed" mode next to the strict one): every instance is solved on its
+    own.  (a) Where the reference's couplings are inert, it equals the strict mode bit for bit (46 instances of the bench family without a
+    NaN instance).  (b) In the batch that also holds the four NaN-producing instances, those 46 keep exactly their results of (a) -- the
+    strict mode stops their decimation at sweep 81 -- and the run needs no replay and cannot fail the speculation."""
+    from pdp.trainer import SatFactorGraphTrainer
+    from pdp.factorgraph import dataset
+    d = load_golden('headline_n200_poison')
+    n, mcl, T, seed, sweeps = [int(x) for x in d['meta']]
+    dev = torch.device('cuda:0')
+
+    def run(seeds, isolated):
+        items = []
+        for sd in seeds:
+            items += dataset.random_ksat_items(1, n, 3, m=mcl, seed=int(sd))
+        b = dataset.to_torch(dataset.collate_segment(items), dev)
+        tr = SatFactorGraphTrainer(cfg('p-d-p', local_search_iteration=0, tolerance=0.02, t_max=100, isolated=isolated), use_cuda=True, logger=LOG)
+        m = tr._model_list[0]
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            st = m.get_init_state(b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'], None, randomized=False, batch_replication=1)
+            m(init_state=st, graph_map=b['graph_map'], batch_variable_map=b['batch_variable_map'], batch_function_map=b['batch_function_map'],
+              edge_feature=b['edge_feature'], meta_data=None, is_training=False, iteration_num=T, check_termination=tr._check_recurrence_termination,
+              batch_replication=1)
+        assert m.last_run['path'] == 'persistent-lds'
+        sp = m._last_problem
+        return sp._active_variables.reshape(-1).cpu().numpy().copy(), sp._solution.reshape(-1).cpu().numpy().copy(), b['batch_variable_map'].cpu().numpy()
+
+    clean = [int(s_) for s_ in d['seeds'][4:]]
+    av_s, sol_s, _ = run(clean, False)
+    av_i, sol_i, _ = run(clean, True)
+    np.testing.assert_array_equal(av_i, av_s); np.testing.assert_array_equal(sol_i, sol_s)       # same batch, same stream: everything equal
+    av_all, sol_all, bvm = run([int(s_) for s_ in d['seeds']], True)
+    keep = bvm >= 4                                         # the 46 clean instances follow the four NaN instances in the batch
+    assert np.array_equal(np.bincount(bvm[keep] - 4, weights=av_all[keep]), np.bincount(bvm[keep] - 4, weights=av_i)), 'per-instance counts'
+    np.testing.assert_array_equal(av_all[keep], av_i)
+    fixed = av_i == 0                                        # still-active variables got their random fill from different stream positions
+    np.testing.assert_array_equal(sol_all[keep][fixed], sol_i[fixed])
+    av_strict, _, _ = run([int(s_) for s_ in d['seeds']], False)
+    assert int(av_strict.sum()) == int(d['active_variable_count'][-1])          # the reference's (poisoned) count
+    assert int(av_all.sum()) < int(av_strict.sum())                             # isolated: decimation went on after sweep 81
