@@ -10,6 +10,13 @@
 // reads for the A operand), weights arrive pre-transposed / zero padded as Wt[Kp][Np] so the B operand is a coalesced
 // 128-byte row segment per half-wave; the activation (exact logsigmoid / sigmoid / tanh from pdp_math.h) is applied on
 // the accumulator registers.  Row sums between the two halves of an aggregator are sequential in ascending edge id.
+//
+// Kernel map (DESIGN.md section 4.4 has the measurements behind each choice):
+//   generic shapes      k_agg_pre / k_agg_pre_res, k_row_sum, k_agg_post (/ k_agg_post_res), k_predict_rows, k_gru, k_gru_window
+//   hidden 128 and 150  k_agg_pre_wave (a wave owns a 32-edge tile through both layers), k_agg_post_pf (prefetched chains)
+//   hidden 128          k_gru_pipe (in-wave pipelined MFMA chains and activation slices; also the 4- / 3-input cells of p-nd-np)
+// What bounds them: on gfx950 the f32 MFMA and the VALU share issue time on a SIMD -- their times add up whichever wave issues them --
+// so beyond keeping every MFMA's operands in registers ahead of time, instruction count is what counts.
 #include "pdp_common.hpp"
 
 #define ST(s) ((hipStream_t)(s))
