@@ -149,3 +149,50 @@ def test_neural_operator_forms_agree_at_full_size(big, oracle, monkeypatch):
     es = npy(tb['edge_feature']).reshape(-1)[idx]
     ref = oracle.gru(npy(state[ti]), es, npy(h[ti]), *[npy(w) for w in gw_host], mask=mask)
     np.testing.assert_array_equal(npy(new_gru[ti]), ref)
+
+
+def test_neural_operators_past_2G_elements():
+    """configs[3]'s per-GPU shape (5 000 x n=400 m=1680: 25.2 M edges, [E, 128] states of 3.2e9 elements = 12.9 GB -- past 32-bit element
+    and byte offsets).  Instances are independent, so the whole batch must give, bit for bit, what its two halves (1.6e9 elements each,
+    the range the other full-size test pins against the plain kernels and the oracle) give when they are run as batches of their own."""
+    from pdp.factorgraph import dataset
+    from pdp import native
+    dev = torch.device('cuda:0')
+    Bq, Nq, Mq, H = 5000, 400, 1680, 128
+    items = dataset.random_ksat_items(Bq, Nq, 3, m=Mq, seed=11)
+    mk = lambda its: dataset.to_torch(dataset.collate_segment(its), dev)
+    prob = lambda tb: native.Problem(tb['graph_map'], tb['batch_variable_map'], tb['batch_function_map'], tb['edge_feature'])
+    g = torch.Generator(device='cpu'); g.manual_seed(9)
+    r = lambda *s: (torch.randn(*s, generator=g) * 0.2).to(dev)
+    gw = native.GruWeights(r(3 * H, H + 1), r(3 * H, H), r(3 * H), r(3 * H))
+    aw = native.AggregatorWeights(r(100, H + 1), r(100), r(50, 100), r(100, 51), r(100), r(H, 100), 1)
+    pw = native.AggregatorWeights(r(100, H + 1), r(100), r(50, 100), r(100, 50), r(100), r(H, 100), 0)
+    hw = native.HeadWeights(r(50, H), r(50), r(1, 50), 'sigmoid')
+    tb = mk(items)
+    p = prob(tb)
+    E, V = p.E, p.V
+    assert E * H > 2 ** 31 and E == Bq * Mq * 3
+    gs = torch.Generator(device=dev); gs.manual_seed(4)
+    state = torch.randn(E, H, device=dev, generator=gs) * 0.5
+    h = torch.randn(E, H, device=dev, generator=gs) * 0.5
+    am = (torch.rand(Bq, device=dev, generator=gs) > 0.2).to(torch.uint8)
+    whole = dict(gru=p.neural_gru(gw, state, h, am),
+                 agg_v=p.neural_aggregate_edges(aw, True, state, None, am, h),
+                 agg_f=p.neural_aggregate_edges(aw, False, state, None, am, h),
+                 pred=p.neural_predict(pw, hw, state, None))
+    torch.cuda.synchronize()
+    del p
+    half = Bq // 2
+    e0 = v0 = 0
+    for k in range(2):
+        tbh = mk(items[k * half:(k + 1) * half])
+        ph = prob(tbh)
+        e1, v1 = e0 + ph.E, v0 + ph.V                      # instance-major ids: a half is a contiguous range of edges and variables
+        s, hh, a = state[e0:e1].contiguous(), h[e0:e1].contiguous(), am[k * half:(k + 1) * half].contiguous()
+        assert torch.equal(whole['gru'][e0:e1], ph.neural_gru(gw, s, hh, a))
+        assert torch.equal(whole['agg_v'][e0:e1], ph.neural_aggregate_edges(aw, True, s, None, a, hh))
+        assert torch.equal(whole['agg_f'][e0:e1], ph.neural_aggregate_edges(aw, False, s, None, a, hh))
+        assert torch.equal(whole['pred'][v0:v1], ph.neural_predict(pw, hw, s, None))
+        del ph, s, hh, a
+        e0, v0 = e1, v1
+    assert e0 == E and v0 == V

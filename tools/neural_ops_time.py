@@ -1,12 +1,13 @@
 """Times the neural operator entry points alone (GRU cell, edge aggregator) on config 3's graph (5 000 x n=200 m=840, hidden 128).
-Usage: python tools/neural_ops_time.py [reps]; PDP_HIP_LIB selects another build of the library for same-box A/B runs."""
+Usage: python tools/neural_ops_time.py [reps [n]] (m = 4.2 n); PDP_HIP_LIB selects another build of the library for same-box A/B runs."""
 import sys, torch
 sys.path.insert(0, '/root/repo/pdp-solver_amd')
 from pdp.factorgraph import dataset
 from pdp import native
 dev = torch.device('cuda:0')
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-tb = dataset.to_torch(dataset.collate_segment(dataset.random_ksat_items(5000, 200, 3, m=840, seed=0)), dev)
+nv = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+tb = dataset.to_torch(dataset.collate_segment(dataset.random_ksat_items(5000, nv, 3, m=int(round(4.2 * nv)), seed=0)), dev)
 p = native.Problem(tb['graph_map'], tb['batch_variable_map'], tb['batch_function_map'], tb['edge_feature'])
 E, H = p.E, 128
 g = torch.Generator(device='cpu'); g.manual_seed(1)
