@@ -165,8 +165,9 @@ typedef struct pdp_solve_args {
     int32_t model;                /* PDP_MODEL_SP or PDP_MODEL_REINFORCE */
     int32_t iterations;           /* T */
     float tolerance, t_max, pi, decimation_probability;
-    uint64_t seed;                /* Reinforce coin (Philox) */
-    const float *coins;           /* Reinforce: [T] host-drawn coins or NULL for Philox */
+    uint64_t seed;                /* reserved */
+    const float *coins;           /* PDP_MODEL_REINFORCE: device array [iterations], the shared coin torch.rand(1) of every iteration
+                                   * (pdp_decimate.py:218) drawn by the caller in order; iterations_run_host says how many were consumed */
     float *q;                     /* [E,3] in: init propagator state[0], out: final */
     float *fs;                    /* [E,2] in/out */
     uint8_t *active_mask;         /* [B] in/out */

@@ -69,6 +69,10 @@ struct SolveParams {
     const int64_t *stat_off, *dyn_off;   // [B] byte offsets of the instance records
     const float *prev_slots;    // [E] slot-major copy of the decimator's previous surveys (first launch of a call only)
     int debug_skip;             // -DPDP_PHASE_PROF builds: bit mask of phases to skip (timing experiments, results are wrong)
+    const float *frc_in;        // Reinforce: [E] slot-major force column this launch resumes from (double-buffered like the dynamic records:
+    float *frc_out;             //            a poison replay must not see what pass 1 left behind)
+    const float *coins;         // Reinforce: [T of the call] the shared coin of every iteration (pdp_decimate.py:218), drawn by the caller
+    float dprob;                // Reinforce: decimation probability
 };
 
 // Device-side control of the chunked persistent solve: the host enqueues every launch of a call up front and reads
@@ -616,13 +620,32 @@ __device__ __forceinline__ float bit15_to_float(uint16_t w)          // bit 15 s
 }
 __device__ __forceinline__ float uni_f(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
 
+// SurveyScorer tail (pdp_predict.py:174-192) with the select-free math forms: same values as d_score_from_sums (every argument
+// here is finite or NaN); the three log terms of the external force take two possible values
+__device__ __forceinline__ float lds_score_of(float pos, float neg, float all, float ext_sum, float Lpi, float L0)
+{
+    const float ef = pdp_sign(ext_sum);
+    float ps = pos + ((ef == 1.0f) ? Lpi : L0);
+    float ng = neg + ((ef == -1.0f) ? Lpi : L0);
+    float pns = ps + ng;
+    float dc = all + Lpi;
+    const float bias = (2.0f * pns + dc) / 4.0f;
+    ps = ps - bias; ng = ng - bias; pns = pns - bias;
+    const f4v ex = exp4_fin_le30((f4v){pdp_min_c(dc - bias, 30.0f), pdp_min_c(ps, 30.0f), pdp_min_c(ng, 30.0f), pdp_min_c(pns, 30.0f)});
+    dc = ex.x;
+    const float q0 = ex.y - ex.w;
+    const float q1 = ex.z - ex.w;
+    const float total = pdp_safe_log_fin((q0 + q1) + dc, PDP_SCORER_EPS);
+    const float l1 = pdp_safe_log_fin(q1, PDP_SCORER_EPS), l0 = pdp_safe_log_fin(q0, PDP_SCORER_EPS);
+    return pdp_expf_fin_le30(pdp_min_c(l1 - total, 30.0f)) - pdp_expf_fin_le30(pdp_min_c(l0 - total, 30.0f));
+}
+
 // P6, cold: SurveyScorer + arg-max + set_variables (pdp_decimate.py:152-171).  Returns 1 if a variable was fixed;
 // *spec gets bit 0 "coeff has an exact zero", bit 1 "NaN coefficient".
 template <bool FORCE>
 __device__ __noinline__ int lds_decimate(unsigned char *smem, int b, int n, int m, int ne, int cur, int active, float pi,
                                          float *is_sat_b, int *spec, int *verified)
 {
-    __shared__ float redf2[PDP_RED_SMALL];
     __shared__ int redi2[PDP_RED_SMALL];
     const LdsArrays L = carve_all(smem, n, m, ne, FORCE);
     const LView I = make_lview(L, b, n, m, ne);
@@ -634,25 +657,7 @@ __device__ __noinline__ int lds_decimate(unsigned char *smem, int b, int n, int 
         L.Y[p] = pdp_safe_log_fin(1.0f - Enew[p], PDP_SCORER_EPS) * (0.0f + L.af[L.pcc[p] & 0x3fff]);   // surveys are finite or NaN
     __syncthreads();
     DEC_PROF_MARK(16);                                // scorer: edge logs
-    // SurveyScorer tail (pdp_predict.py:174-192) with the select-free math forms: same values as d_score_from_sums (every argument
-    // here is finite or NaN); the three log terms of the external force take two possible values
     const float Lpi = pdp_safe_log(1.0f - pi, PDP_SCORER_EPS), L0 = pdp_safe_log(1.0f - pi * 0.0f, PDP_SCORER_EPS);
-    auto score_of = [&](float pos, float neg, float all, float ext_sum) {
-        const float ef = pdp_sign(ext_sum);
-        float ps = pos + ((ef == 1.0f) ? Lpi : L0);
-        float ng = neg + ((ef == -1.0f) ? Lpi : L0);
-        float pns = ps + ng;
-        float dc = all + Lpi;
-        const float bias = (2.0f * pns + dc) / 4.0f;
-        ps = ps - bias; ng = ng - bias; pns = pns - bias;
-        const f4v ex = exp4_fin_le30((f4v){pdp_min_c(dc - bias, 30.0f), pdp_min_c(ps, 30.0f), pdp_min_c(ng, 30.0f), pdp_min_c(pns, 30.0f)});
-        dc = ex.x;
-        const float q0 = ex.y - ex.w;
-        const float q1 = ex.z - ex.w;
-        const float total = pdp_safe_log_fin((q0 + q1) + dc, PDP_SCORER_EPS);
-        const float l1 = pdp_safe_log_fin(q1, PDP_SCORER_EPS), l0 = pdp_safe_log_fin(q0, PDP_SCORER_EPS);
-        return pdp_expf_fin_le30(pdp_min_c(l1 - total, 30.0f)) - pdp_expf_fin_le30(pdp_min_c(l0 - total, 30.0f));
-    };
     int flags = 0;                                   // 1: a coefficient is exactly 0, 2: some coefficient is non-zero, 4: NaN coefficient
     for (int i = tid; i < n; i += nt) {
         const int v = L.vord[i];                     // degree-sorted: the lanes of a wave run loops of similar length
@@ -681,7 +686,7 @@ __device__ __noinline__ int lds_decimate(unsigned char *smem, int b, int n, int 
             for (int j = 0; j < 4; ++j) acc(f[j], pw[j], fr[j]);
         }
         for (; p < bnd; ++p) acc(L.Y[p], L.pvv[p], FORCE ? L.FRC[p] : 0.0f);
-        const float sc = score_of(pos, neg, all, ext);
+        const float sc = lds_score_of(pos, neg, all, ext, Lpi, L0);
         const float co = (pdp_abs(sc) * L.av[v]) * 1.0f;
         score[v] = sc; L.coeff[v] = co;
         L.flag_v[v] = 0;                             // candidate marks of the neighbourhood path below
@@ -808,6 +813,51 @@ __device__ __noinline__ int lds_decimate(unsigned char *smem, int b, int n, int 
     return 1;
 }
 
+// Reinforce triple, cold: the force update of ReinforceDecimator.forward (pdp_decimate.py:218-232: SurveyScorer on the new surveys and
+// the OLD force, force <- sign(score) on every edge of the instance) when `do_force`, then ReinforcePredictor (pdp_predict.py:221-226:
+// sum of the force over the variable's edges > 0) and _update_solution (solver.py:388-399).  A variable's slots are contiguous and
+// read by its own thread only, so the new force is written in the same pass; the old force goes to X (free between E2 and the next E1):
+// the write-back rebuilds q_s / q_dc of the last sweep, which read the old force.  Returns 1 if a score was NaN.
+__device__ __noinline__ int lds_reinforce_step(unsigned char *smem, int n, int m, int ne, int cur, float pi, int do_force)
+{
+    const LdsArrays L = carve_all(smem, n, m, ne, true);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    int bad = 0;
+    if (do_force) {
+        const float *Enew = cur ? L.EA : L.EB;
+        for (int p = tid; p < ne; p += nt)
+            L.Y[p] = pdp_safe_log_fin(1.0f - Enew[p], PDP_SCORER_EPS) * (0.0f + L.af[L.pcc[p] & 0x3fff]);
+        __syncthreads();
+    }
+    const float Lpi = pdp_safe_log(1.0f - pi, PDP_SCORER_EPS), L0 = pdp_safe_log(1.0f - pi * 0.0f, PDP_SCORER_EPS);
+    for (int i = tid; i < n; i += nt) {
+        const int v = L.vord[i];
+        const int a = L.v_ptr[v], bnd = L.v_ptr[v + 1];
+        float ext = 0.0f;
+        if (do_force) {
+            float pos = 0.0f, neg = 0.0f, all = 0.0f;
+            for (int p = a; p < bnd; ++p) {
+                const float f = L.Y[p];
+                const bool ng = (L.pvv[p] & 0x8000) != 0;
+                ext = ext + L.FRC[p];
+                pos = pos + (ng ? 0.0f : 1.0f) * f;
+                neg = neg + (ng ? 1.0f : 0.0f) * f;
+                all = all + f;
+            }
+            const float sc = lds_score_of(pos, neg, all, ext, Lpi, L0);
+            if (sc != sc) bad = 1;
+            const float sg = 0.0f + pdp_sign_nan(sc);
+            for (int p = a; p < bnd; ++p) { L.X[p] = L.FRC[p]; L.FRC[p] = sg; }   // mask * sign + (1 - mask) * old with mask == 1 (old is finite here); X keeps the force the last sweep read
+        }
+        ext = 0.0f;
+        for (int p = a; p < bnd; ++p) ext = ext + L.FRC[p];
+        const float pred = (ext > 0.0f) ? 1.0f : 0.0f;
+        const float av = L.av[v];
+        if (av == 1.0f) L.sol[v] = av * pred + (1.0f - av) * L.sol[v];      // only active variables take the prediction (solver.py:395-397)
+    }
+    return __syncthreads_or(bad);
+}
+
 template <bool FORCE>
 __device__ __noinline__ int lds_cnf_count(unsigned char *smem, int b, int n, int m, int ne)
 {
@@ -819,7 +869,10 @@ __device__ __noinline__ int lds_cnf_count(unsigned char *smem, int b, int n, int
 
 // REPLAY: the poison-replay pass over ctl->replay_count listed instances (a separate instantiation, so that profilers list
 // the two passes under different names)
-template <bool FORCE, bool REPLAY>
+// RF: the Reinforce triple (ReinforceDecimator + ReinforcePredictor, pdp_decimate.py:202-234) instead of the sequential decimator: no
+// survey gate, no counters, no decimation; convergence (`max <= 0.01`) de-activates the instance, a shared coin per iteration decides
+// whether the force is renewed.  Under the NaN poison the gate's batch-wide maximum is NaN: nobody leaves through the gate.
+template <bool FORCE, bool REPLAY, bool RF = false>
 __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams sp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -863,7 +916,9 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
         copy16(L.vord, stt + BL.vord, (size_t)n * 2);
         copy16(QU, din + BL.QU, (size_t)ne * 4); copy16(L.EA, din + BL.E, (size_t)ne * 4); copy16(pcc, din + BL.pcc, (size_t)ne * 2);
         copy16(L.af, din + BL.af, (size_t)m * 4); copy16(L.av, din + BL.av, (size_t)n * 4); copy16(L.sol, din + BL.sol, (size_t)n * 4);
-        if constexpr (FORCE) {
+        if constexpr (RF) {
+            for (int p = tid; p < ne; p += nt) L.FRC[p] = sp.frc_in[G.e0 + p];
+        } else if constexpr (FORCE) {
             const float *sfs = sp.src_fs + 2 * (size_t)G.e0;                   // the external-force column is an input only
             for (int p = tid; p < ne; p += nt) L.FRC[p] = sfs[2 * G.v_edges[p] + 1];
         }
@@ -882,6 +937,7 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
     int use_em = sp.has_edge_mask, last_use_em = 0, em_dirty = 0;
     float cnt = hdr.cnt;
     int iters = 0, did_prop = 0, nsat = -1, violation = 0, cur = 0;
+    int rf_last_flip = 0;                    // Reinforce: the force was renewed after the last sweep (X holds the one that sweep read)
     int simplified = (int)hdr.simplified;   // 0: unknown, 1: the state is a simplify() fix-point (checked at the first decimation of a call), 2: it is not
     const bool other_rows = n < pv_.V;
     const float pi = sp.pi, tol = sp.tol, t_max = sp.t_max;
@@ -1151,7 +1207,8 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
                     }
                     const float rr = (num / pdp_max_c(den, 1.0f)) * L.av[v];
                     if (rr == 0.0f) b2 |= 2;
-                    if (!((((rr - 0.0f) + 1.0f) + 0.0f) - 1.0f < tol)) b2 |= 16;
+                    const float mv = (((rr - 0.0f) + 1.0f) + 0.0f) - 1.0f;
+                    if (RF ? !(mv <= tol) : !(mv < tol)) b2 |= 16;
                 }
             }
             b2 = wave_or_bits7(b2);
@@ -1164,8 +1221,8 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
         }
         PROF_MARK(5);                                        // P5
         float g;
-        if (bits & 8) {
-            g = 1.0f;                                       // certified: the gate stays open, its exact value is never used
+        if (RF || (bits & 8)) {
+            g = 1.0f;                                       // certified: the gate stays open, its exact value is never used (Reinforce has no survey gate)
         } else {
             // exact path (rare: every active variable has only vanishing surveys): util.py:282-286 + :267-275
             for (int p = tid; p < ne; p += nt) X[p] = pdp_expf_fin_le30(30.0f * Enew[p]);
@@ -1184,7 +1241,7 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
         }
         // site 1: (max_v (rr_v + 1)) - 1 < tol  <=>  every variable passes the same test on its own (both maps are monotone);
         // a NaN anywhere makes the reference's maximum NaN and the comparison false
-        const bool below_tol = (n > 0) ? (!(bits & 16) && !(bits & 4)) : ((other_rows ? -1.0f : -PDP_INF) < tol);
+        const bool below_tol = (n > 0) ? (!(bits & 16) && !(bits & 4)) : (RF ? ((other_rows ? -1.0f : -PDP_INF) <= tol) : ((other_rows ? -1.0f : -PDP_INF) < tol));
         const int z1 = bits & 1, z2 = (bits >> 1) & 1;
         nan_seen = (bits >> 2) & 1;
         if (nan_seen && !poisoned) {
@@ -1192,6 +1249,11 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
             if (poison_from != 0x7fffffff) violation = 1;
         }
         int conv = 0;
+        int rf_changed = 0;
+        if constexpr (RF) {
+            // active_mask[sum_diff <= 0.01] = 0 (pdp_decimate.py:205-215); under the poison the batch-wide maximum is NaN and nobody leaves
+            if (!poisoned && has_prev && below_tol) { active = 0; last_event = t; }
+        } else
         if (!poisoned) {
             // an "event" is anything a NaN-poisoned batch would NOT do: pass 1 remembers the last one so that only the
             // instances with an event at or after the poison iteration have to be replayed
@@ -1205,12 +1267,22 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
         } else if (has_prev) {
             if (cnt >= t_max) { conv = 1; cnt = 0.0f; }
         }
-        uint32_t used = 1u | (has_prev ? 2u : 0u);
-        uint32_t zero = (z1 ? 1u : 0u) | ((has_prev && z2) ? 2u : 0u);
-        if (has_prev && !conv && n > 0) zero |= 4u;
+        uint32_t used = (RF ? 0u : 1u) | (has_prev ? 2u : 0u);
+        uint32_t zero = ((!RF && z1) ? 1u : 0u) | ((has_prev && z2) ? 2u : 0u);
+        if (!RF && has_prev && !conv && n > 0) zero |= 4u;
+        if constexpr (RF) {
+            // the shared coin of this iteration (pdp_decimate.py:218); instances that are still active after the gate renew their force.
+            // Predictor + _update_solution run in every iteration of the reference; their result only changes with the force.
+            const int flip = (sp.coins[sp.chunk_start + t] < sp.dprob) && active;
+            rf_last_flip = flip;
+            if (flip || nsat < 0) {
+                if (UNI(lds_reinforce_step(smem, n, m, ne, cur, pi, flip)) && !nan_seen) violation = 1;    // a NaN score without a NaN survey: not expected
+                rf_changed = 1;
+            }
+        }
         // ---- P6: decimation (rare, out of line) ------------------------------------------------------------------------------
         int decimated = 0;
-        if (has_prev && conv && !poisoned && !nan_seen && !PROF_SKIP(16)) {
+        if (!RF && has_prev && conv && !poisoned && !nan_seen && !PROF_SKIP(16)) {
             int spec_bits = 0;
             decimated = UNI(lds_decimate<FORCE>(smem, G.b, n, m, ne, cur, active, pi, &s_is_sat, &spec_bits, &simplified));
             spec_bits = UNI(spec_bits); simplified = UNI(simplified);
@@ -1243,7 +1315,7 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
         }
         // ---- P8: termination check ---------------------------------------------------------------------------------------------
         if (sp.check_termination) {
-            if (decimated || nsat < 0) nsat = UNI(lds_cnf_count<FORCE>(smem, G.b, n, m, ne));
+            if (decimated || rf_changed || nsat < 0) nsat = UNI(lds_cnf_count<FORCE>(smem, G.b, n, m, ne));
             if (active && nsat == m) active = 0;
         }
         has_prev = 1; prev_from_global = 0; cur ^= 1;
@@ -1267,7 +1339,7 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
             const float s = slot_sign(pw);
             float y = pdp_safe_log_fin(1.0f - Eprev[p], PDP_SP_EPS);
             if (last_use_em) y = y * ((cw & PC_EM_USED) ? 1.0f : 0.0f);
-            const float force = FORCE ? L.FRC[p] : 0.0f;
+            const float force = FORCE ? ((RF && rf_last_flip) ? X[p] : L.FRC[p]) : 0.0f;
             const float pos = 0.0f + L.Pv[v], neg = 0.0f + L.Nv[v];
             float same = (0.5f * (1.0f + s)) * pos + (0.5f * (1.0f - s)) * neg;
             same = same - y;
@@ -1284,6 +1356,7 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
             gq[3 * e + 1] = 1.0f * (qs / total) + (1.0f - 1.0f) * sticky;
             gq[3 * e + 2] = 1.0f * (dc / total) + (1.0f - 1.0f) * sticky;
             gfs[2 * e] = Efin[p];
+            if constexpr (RF) gfs[2 * e + 1] = L.FRC[p];
             sp.prev[G.e0 + e] = Efin[p];
             G.emask[e] = (cw & PC_EM) ? 1.0f : 0.0f;
         }
@@ -1299,7 +1372,7 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
         dump16(BL.af, L.af, (size_t)m * 4); dump16(BL.av, L.av, (size_t)n * 4); dump16(BL.sol, L.sol, (size_t)n * 4);
         // the next launch starts with "the mask the last propagate used" == the current mask
         uint16_t *gpc = reinterpret_cast<uint16_t *>(dout + BL.pcc);
-        for (int p = tid; p < ne; p += nt) { const uint16_t cw = pcc[p]; gpc[p] = (uint16_t)((cw & ~PC_EM_USED) | ((cw & PC_EM) ? PC_EM_USED : 0)); }
+        for (int p = tid; p < ne; p += nt) { const uint16_t cw = pcc[p]; gpc[p] = (uint16_t)((cw & ~PC_EM_USED) | ((cw & PC_EM) ? PC_EM_USED : 0)); }        if constexpr (RF) { for (int p = tid; p < ne; p += nt) sp.frc_out[G.e0 + p] = L.FRC[p]; }
     }
     if (tid < SPEC_LOCAL && tid < T) {
         if (s_spec_used[tid]) atomicOr(&sp.spec_used[tid], (uint32_t)s_spec_used[tid]);
@@ -1379,6 +1452,14 @@ __global__ void __launch_bounds__(256) k_solve_import(PView pv, const float *q, 
         h.cnt = counters[G.b]; h.is_sat = pv.is_sat[G.b]; h.pad1 = 0.0f; h.pad2 = 0.0f;
         *reinterpret_cast<DynHeader *>(dy + BL.hdr) = h;
     }
+}
+
+// Reinforce: the force column of the caller's [E,2] state in slot order
+__global__ void __launch_bounds__(256) k_force_import(PView pv, const float *fs, float *frc)
+{
+    const Inst G = load_inst(pv, blockIdx.x);
+    const float *sfs = fs + 2 * (size_t)G.e0;
+    for (int p = threadIdx.x; p < G.e; p += blockDim.x) frc[G.e0 + p] = sfs[2 * G.v_edges[p] + 1];
 }
 
 // after pass 1 of a chunk: does a NaN poison the batch from this chunk on?  
@@ -1473,6 +1554,7 @@ static int ensure_bytes(char **ptr, size_t *have, size_t need)
 // list, replay, speculation check); the host reads one control block at the end.
 static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, bool force, size_t lds, int nt_lds, int C)
 {
+    const bool rf = a->model == PDP_MODEL_REINFORCE;
     const int T = a->iterations;
     const size_t E = p->E, V = p->V, F = p->F, B = p->B;
     const int nchunks = (T + C - 1) / C;
@@ -1500,7 +1582,8 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     }
     const int64_t *stat_off = p->res_stat_off, *dyn_off = p->res_stat_off + B;
     // ---- control blocks, speculation record, replay list; call-entry snapshot for the failure path ---------------------------
-    const size_t ctl_bytes = (size_t)nchunks * sizeof(SolveCtl) + sizeof(SolveCall) + 2 * (size_t)T * 4 + 2 * B * 4 + 64;
+    const size_t ctl_bytes = (size_t)nchunks * sizeof(SolveCtl) + sizeof(SolveCall) + 2 * (size_t)T * 4 + 2 * B * 4 + 64 +
+                             (rf ? 2 * (E + 4) * sizeof(float) : 0);            // Reinforce: two slot-major force columns
     int status = ensure_bytes(&p->res_ctl, &p->res_ctl_bytes, ctl_bytes);
     if (status != PDP_OK) return status;
     SolveCtl *ctl = (SolveCtl *)p->res_ctl;
@@ -1529,7 +1612,10 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     status = snapshot_copy(p, a, snap0, true, st);
     if (status != PDP_OK) return status;
 
-    if (force) {
+    if (rf) {
+        PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sp_solve_lds<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sp_solve_lds<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    } else if (force) {
         PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sp_solve_lds<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sp_solve_lds<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     } else {
@@ -1560,6 +1646,12 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     sp.q = a->q; sp.fs = a->fs; sp.amask = a->active_mask; sp.src_fs = a->fs;
     sp.prev = a->decimator->prev; sp.counters = a->decimator->counters;
     sp.check_termination = a->check_termination;
+    sp.coins = a->coins; sp.dprob = a->decimation_probability;
+    float *frc_buf[2] = {nullptr, nullptr};
+    if (rf) {
+        frc_buf[0] = (float *)(((uintptr_t)(replay_list + B) + 15) & ~(uintptr_t)15); frc_buf[1] = frc_buf[0] + E + 4;
+        hipLaunchKernelGGL(k_force_import, dim3(p->B), dim3(256), 0, st, make_view(p), (const float *)a->fs, frc_buf[0]);
+    }
     sp.last_event = last_event; sp.inst_list = replay_list;
     sp.call = call; sp.stat = p->res_stat; sp.stat_off = stat_off; sp.dyn_off = dyn_off;
     if (const char *env = getenv("PDP_DEBUG_SKIP")) sp.debug_skip = atoi(env);
@@ -1572,9 +1664,12 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
         sp.prev_slots = (k == 0 && a->decimator->has_prev) ? p->res_prev_slots : nullptr;
         sp.ctl = ctl + k; sp.spec_used = spec + done; sp.spec_zero = spec + T + done;
         sp.dyn_in = p->res_dyn[k & 1]; sp.dyn_out = p->res_dyn[(k + 1) & 1];
+        sp.frc_in = frc_buf[k & 1]; sp.frc_out = frc_buf[(k + 1) & 1];
         for (int pass = 0; pass < 2; ++pass) {
             if (timed) PDP_HIP_CHECK(hipEventRecord(p->res_events[4 * k + 2 * pass], st));
-            if (force && pass == 0) hipLaunchKernelGGL((k_sp_solve_lds<true, false>), dim3(p->B), dim3(nt_lds), lds, st, make_view(p), sp);
+            if (rf && pass == 0) hipLaunchKernelGGL((k_sp_solve_lds<true, false, true>), dim3(p->B), dim3(nt_lds), lds, st, make_view(p), sp);
+            else if (rf) hipLaunchKernelGGL((k_sp_solve_lds<true, true, true>), dim3(p->B), dim3(nt_lds), lds, st, make_view(p), sp);
+            else if (force && pass == 0) hipLaunchKernelGGL((k_sp_solve_lds<true, false>), dim3(p->B), dim3(nt_lds), lds, st, make_view(p), sp);
             else if (force) hipLaunchKernelGGL((k_sp_solve_lds<true, true>), dim3(p->B), dim3(nt_lds), lds, st, make_view(p), sp);
             else if (pass == 0) hipLaunchKernelGGL((k_sp_solve_lds<false, false>), dim3(p->B), dim3(nt_lds), lds, st, make_view(p), sp);
             else hipLaunchKernelGGL((k_sp_solve_lds<false, true>), dim3(p->B), dim3(nt_lds), lds, st, make_view(p), sp);
@@ -1629,7 +1724,10 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
 extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
 {
     PDP_REQUIRE(p && a && p->av, "NULL argument / state not bound");
-    PDP_REQUIRE(a->model == PDP_MODEL_SP, "persistent solve: only the SP triple is implemented (use the step-wise path)");
+    PDP_REQUIRE(a->model == PDP_MODEL_SP || a->model == PDP_MODEL_REINFORCE, "persistent solve: SP and Reinforce triples only");
+    const bool rf_model = a->model == PDP_MODEL_REINFORCE;
+    PDP_REQUIRE(!rf_model || a->coins, "persistent Reinforce needs the per-iteration coins (device array [iterations])");
+    PDP_REQUIRE(!rf_model || !a->isolate_instances, "isolated-instance mode is implemented for the SP triple only");
     PDP_REQUIRE(a->q && a->fs && a->active_mask && a->decimator, "NULL state array");
     PDP_REQUIRE(p->R == 1 || a->replicas_identical, "persistent solve with batch replication needs identical replicas (replicas couple through the termination check)");
     hipStream_t st = ST(stream);
@@ -1653,7 +1751,7 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
         uint32_t force_flag = 0;
         PDP_HIP_CHECK(hipMemcpyAsync(&force_flag, p->flags + FL_N_SEL, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         PDP_HIP_CHECK(hipStreamSynchronize(st));
-        const bool force_r = force_flag != 0;
+        const bool force_r = force_flag != 0 || rf_model;
         const size_t lds_r = lds2_bytes_for(p->max_n, p->max_m, p->max_e, force_r);
         const bool fits_r = p->fn_edges_identity && lds_r <= 160 * 1024 - 1024 && p->max_e < 65535 && p->max_n < 16384 && p->max_m < 16384 &&
                             getenv("PDP_SOLVE_FORCE_HBM") == nullptr;          // the switch lets the tests reach the HBM-resident kernel with small instances
@@ -1662,6 +1760,10 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
         const int nt_r = p->max_e <= 1024 ? 256 : (lds_r > 80 * 1024 ? 1024 : 512);
         if (fits_r) return sp_solve_resident(p, a, st, force_r, lds_r, nt_r, C);
         PDP_REQUIRE(!a->isolate_instances, "isolated-instance mode needs instances that fit the LDS-resident solver");
+        if (rf_model) {          // nothing was touched: the caller runs the step-wise loop
+            pdp_set_error("persistent Reinforce: an instance does not fit the LDS-resident solver; run the batch step-wise");
+            return PDP_ERR_SPECULATION;
+        }
     }
     // ---- instances too large for the LDS: HBM-resident kernel, host-driven chunk loop -----------------------------------
 

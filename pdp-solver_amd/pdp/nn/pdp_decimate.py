@@ -122,10 +122,14 @@ class ReinforceDecimator(nn.Module):
         self._handle = None
         self._handle_problem = None
 
-    def forward(self, init_state, message_state, sat_problem, is_training, active_mask=None):
+    def native_handle(self, sat_problem):
         if self._handle is None or self._handle_problem is not sat_problem._native:
             self._handle = native.Decimator(sat_problem._native)
             self._handle_problem = sat_problem._native
+        return self._handle
+
+    def forward(self, init_state, message_state, sat_problem, is_training, active_mask=None):
+        self.native_handle(sat_problem)
         variable_state, function_state = message_state
         coin = float(torch.rand(1).item())          # one shared coin per batch (pdp_decimate.py:218)
         am = None if active_mask is None else active_mask.reshape(-1)

@@ -203,15 +203,28 @@ class PropagatorDecimatorSolverBase(nn.Module):
                 return False
         return True
 
+    def _persistent_model(self):
+        "which triple of the persistent kernel this solver is: MODEL_SP, MODEL_REINFORCE or None (plug-ins of other types: generic loop)"
+        if (type(self._propagator) is not pdp_propagate.SurveyPropagator or self._propagator._include_adaptors
+                or type(getattr(self._decimator, '_scorer', None)) is not pdp_predict.SurveyScorer
+                or self._propagator._pi != self._decimator._scorer._pi):
+            return None
+        if type(self._decimator) is pdp_decimate.SequentialDecimator and type(self._predictor) is pdp_predict.IdentityPredictor:
+            return native.MODEL_SP
+        if type(self._decimator) is pdp_decimate.ReinforceDecimator and type(self._predictor) is pdp_predict.ReinforcePredictor:
+            return native.MODEL_REINFORCE
+        return None
+
     def _can_run_persistent(self, sat_problem, is_training, check_termination, states=()):
-        return (self._persistent and not is_training
-                and (sat_problem._batch_replication == 1 or self._replicas_identical(sat_problem, states))
-                and type(self._propagator) is pdp_propagate.SurveyPropagator
-                and type(self._decimator) is pdp_decimate.SequentialDecimator
-                and type(self._decimator._scorer) is pdp_predict.SurveyScorer
-                and type(self._predictor) is pdp_predict.IdentityPredictor
-                and self._propagator._pi == self._decimator._scorer._pi
-                and _is_standard_termination(check_termination))
+        model = self._persistent_model()
+        if model is None or not self._persistent or is_training or not _is_standard_termination(check_termination):
+            return False
+        if model == native.MODEL_REINFORCE:
+            # the Reinforce gate exists only with a termination callback (active_mask is None otherwise, pdp_decimate.py:205) and while
+            # the batch has an active variable (a batch-wide condition that the loop cannot change: nothing is decimated)
+            if check_termination is None or self._isolated or not bool((sat_problem._active_variables > 0).any().item()):
+                return False
+        return sat_problem._batch_replication == 1 or self._replicas_identical(sat_problem, states)
 
     def _forward_core(self, init_propagator_state, init_decimator_state, sat_problem, iteration_num, is_training, check_termination):
         can = self._can_run_persistent(sat_problem, is_training, check_termination, tuple(init_propagator_state[:2]) + tuple(init_decimator_state[:2]))
@@ -235,13 +248,28 @@ class PropagatorDecimatorSolverBase(nn.Module):
         fs = src[1].clone().contiguous()
         active_mask = torch.ones(sat_problem._batch_size, dtype=torch.uint8, device=self._device)
         handle = self._decimator.native_handle(sat_problem)
+        model = self._persistent_model()
+        extra = {}
+        if model == native.MODEL_REINFORCE:
+            # one torch.rand(1) per executed iteration (pdp_decimate.py:218): draw them all, rewind, consume what the loop used
+            rng_state = torch.get_rng_state()
+            coins = torch.cat([torch.rand(1) for _ in range(int(iteration_num))]) if int(iteration_num) > 0 else torch.zeros(0)
+            extra = dict(model=model, coins=coins.to(self._device), decimation_probability=self._decimator._decimation_probability)
+            tolerance, t_max = 0.01, 0.0                   # the gate's constant (pdp_decimate.py:215); no counters
+        else:
+            tolerance, t_max = self._decimator._tolerance, self._decimator._t_max
         try:
-            iters, used_lds = nat.sp_solve(q, fs, active_mask, handle, int(iteration_num), self._decimator._tolerance,
-                                           self._decimator._t_max, self._propagator._pi,
+            iters, used_lds = nat.sp_solve(q, fs, active_mask, handle, int(iteration_num), tolerance, t_max, self._propagator._pi,
                                            check_termination=check_termination is not None,
-                                           replicas_identical=sat_problem._batch_replication > 1, isolate_instances=self._isolated)
+                                           replicas_identical=sat_problem._batch_replication > 1, isolate_instances=self._isolated, **extra)
         except native.SpeculationFailed:
+            if model == native.MODEL_REINFORCE:
+                torch.set_rng_state(rng_state)
             return None            # the library restored every array it touched; fall back to the strict step-wise loop
+        if model == native.MODEL_REINFORCE:
+            torch.set_rng_state(rng_state)
+            for _ in range(iters):
+                torch.rand(1)
         self.last_run.update(path='persistent-lds' if used_lds else 'persistent-hbm', iterations=iters)
         sat_problem._edge_mask = nat.edge_mask
         state = (q, fs)
@@ -465,7 +493,8 @@ class WalkSATSolver(PropagatorDecimatorSolverBase):
 class ReinforceSurveyPropagatorSolver(PropagatorDecimatorSolverBase):
     "Classical Reinforce via the PDP framework (reference: solver.py:598-610)."
 
-    def __init__(self, device, name, pi=0.1, decimation_probability=0.5, local_search_iterations=0, epsilon=0.05, rng='torch', seed=0):
+    def __init__(self, device, name, pi=0.1, decimation_probability=0.5, local_search_iterations=0, epsilon=0.05, rng='torch', seed=0,
+                 persistent=True):
         super(ReinforceSurveyPropagatorSolver, self).__init__(
             device=device, name=name,
             propagator=pdp_propagate.SurveyPropagator(device, decimator_dimension=1, include_adaptors=False, pi=pi),
@@ -473,4 +502,4 @@ class ReinforceSurveyPropagatorSolver(PropagatorDecimatorSolverBase):
                 device, scorer=pdp_predict.SurveyScorer(device, message_dimension=1, include_adaptors=False, pi=pi),
                 decimation_probability=decimation_probability),
             predictor=pdp_predict.ReinforcePredictor(device=device),
-            local_search_iterations=local_search_iterations, epsilon=epsilon, rng=rng, seed=seed)
+            local_search_iterations=local_search_iterations, epsilon=epsilon, rng=rng, seed=seed, persistent=persistent)

@@ -52,7 +52,8 @@ class SatFactorGraphTrainer(FactorGraphTrainerBase):
                                          iteration_num=config['local_search_iteration'], epsilon=config['epsilon'], rng=rng, seed=seed)
         elif t == 'reinforce':
             model = solver.ReinforceSurveyPropagatorSolver(device=self._device, name=config['model_name'], pi=config['pi'],
-                                                           decimation_probability=config['decimation_probability'], **common)
+                                                           decimation_probability=config['decimation_probability'],
+                                                           persistent=config.get('persistent', True), **common)
         elif t in ('np-nd-np', 'np-d-np', 'p-nd-np'):
             model = solver.build_neural_solver(self._device, config, Perceptron, common)
         else:

@@ -60,6 +60,8 @@ def test_forward_equals_reference_golden(name, model_type, kw, persistent):
     if model_type == 'p-d-p' and int(d['meta'][3]) > 1:
         # batch replication with the deterministic initial state: identical replicas, so the persistent loop is allowed
         assert m.last_run['path'] == ('persistent-lds' if persistent else 'stepwise')
+    if model_type == 'reinforce':
+        assert m.last_run['path'] == ('persistent-lds' if persistent else 'stepwise')
     if model_type == 'p-d-p' and int(d['meta'][3]) == 1:
         assert m.last_run['iterations'] == int(d['iterations_run'][0])
         assert m.last_run['path'] == ('persistent-lds' if persistent else 'stepwise')
@@ -454,3 +456,42 @@ def test_isolated_mode_properties():
     av_strict, _, _ = run([int(s_) for s_ in d['seeds']], False)
     assert int(av_strict.sum()) == int(d['active_variable_count'][-1])          # the reference's (poisoned) count
     assert int(av_all.sum()) < int(av_strict.sum())                             # isolated: decimation went on after sweep 81
+
+
+@pytest.mark.parametrize('alpha,n,B,T,w,has_nan', [(3.6, 120, 96, 80, 0, False), (4.2, 200, 64, 45, 25, False), (2.5, 60, 40, 50, 0, False),
+                                                  (4.2, 200, 64, 60, 25, True), (4.2, 200, 1500, 100, 0, True)])
+def test_reinforce_persistent_equals_stepwise(alpha, n, B, T, w, has_nan):
+    """The Reinforce triple (model type `reinforce`) on the one-launch persistent loop and on the step-wise plug-in loop (the form the
+    golden trace pins against the reference): same prediction, same final messages and force column bit for bit, same executed iterations,
+    same active mask, same consumption of the global generator (one coin per executed iteration, then Walk-SAT's draws).  In the last
+    two cases surveys turn NaN (after sweep 48 in the first): from then on the gate's batch-wide maximum is NaN in the reference and no
+    instance leaves through the gate any more -- the persistent loop reproduces that with its poison replay, the NaN instance keeps a NaN
+    force (torch.sign(NaN))."""
+    from pdp.trainer import SatFactorGraphTrainer
+    from pdp.factorgraph import dataset
+    dev = torch.device('cuda:0')
+    items = dataset.random_ksat_items(B, n, 3, m=int(round(alpha * n)), seed=400 + n)
+    b = dataset.to_torch(dataset.collate_segment(items), dev)
+    gm, bvm, bfm, ef = b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature']
+    out = {}
+    for persistent in (True, False):
+        tr = SatFactorGraphTrainer(cfg('reinforce', local_search_iteration=w, persistent=persistent, pi=0.1, decimation_probability=0.4),
+                                   use_cuda=True, logger=LOG)
+        m = tr._model_list[0]
+        torch.manual_seed(21)
+        with torch.no_grad():
+            st = m.get_init_state(gm, bvm, bfm, ef, None, randomized=False, batch_replication=1)
+            pred, states = m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None,
+                             is_training=False, iteration_num=T, check_termination=tr._check_recurrence_termination, batch_replication=1)
+        assert m.last_run['path'] == ('persistent-lds' if persistent else 'stepwise')
+        out[persistent] = (pred[0].clone(), [x.clone() for x in states[0][:2]], [x.clone() for x in states[1][:2]], m.last_run['iterations'],
+                           m._active_mask.reshape(-1).clone(), m._last_problem._solution.clone(), torch.rand(3))
+    a, c = out[True], out[False]
+    assert a[3] == c[3] and a[3] > 1
+    assert torch.equal(a[0], c[0]) and torch.equal(a[4].to(torch.uint8), c[4].to(torch.uint8)) and torch.equal(a[5], c[5])
+    for x, y in zip(a[1] + a[2], c[1] + c[2]):
+        assert torch.equal(x.nan_to_num(nan=-7.0), y.nan_to_num(nan=-7.0))
+        assert has_nan or not bool(torch.isnan(x).any())
+    assert bool(torch.isnan(a[2][1]).any()) == has_nan
+    assert torch.equal(a[6], c[6])
+    assert float(a[2][1][:, 1].nan_to_num(nan=0.0).abs().sum()) > 0            # the force column was renewed at all
