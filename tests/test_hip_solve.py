@@ -202,3 +202,34 @@ def test_persistent_solve_with_nothing_to_do(oracle):
     iters, _ = hp.sp_solve(q, fs, am, native.Decimator(hp), 9, 0.02, 100)
     assert iters == 0 and int(am.sum()) == 0
     assert torch.equal(q, q0) and torch.equal(fs, fs0) and torch.equal(hp.active_variables, av0)
+
+
+@pytest.mark.parametrize('spec,T,pi,dprob', [(dict(batch=32, n=50, k=3, seed=70), 40, 0.1, 0.5),
+                                             (dict(batch=64, n=40, mixed=True, seed=170), 30, 0.01, 0.3),
+                                             (dict(batch=100, n=30, k=3, m=100, seed=310), 50, 0.2, 0.7),
+                                             (dict(batch=6, n=200, k=3, seed=19), 30, 0.1, 1.0)])
+@pytest.mark.parametrize('chunk', [None, '7'])
+def test_persistent_reinforce_matches_oracle_loop(oracle, monkeypatch, spec, T, pi, dprob, chunk):
+    """The Reinforce triple (pdp_decimate.py:202-234, pdp_predict.py:221-226) in one persistent call against the oracle's iteration loop
+    with the same recorded coins: messages and the force column bit for bit, same active mask, solution and executed iterations."""
+    from pdp import native
+    if chunk:
+        monkeypatch.setenv('PDP_SOLVE_CHUNK', chunk)
+    b = random_batch(**spec)
+    hp, op = make_pair(oracle, b)
+    coins = np.random.RandomState(spec['seed']).rand(T).astype(np.float32)
+    res = op.forward('reinforce', T, local_search_iterations=0, pi=pi, decimation_probability=dprob, stream=coins, trace=True)
+    hp.simplify()
+    E, B = hp.E, hp.B
+    q = torch.full((E, 3), 1.0, device='cuda:0') / 3.0
+    fs = torch.zeros(E, 2, device='cuda:0'); fs[:, 0] = 0.5
+    am = torch.ones(B, dtype=torch.uint8, device='cuda:0')
+    dec = native.Decimator(hp)
+    iters, used_lds = hp.sp_solve(q, fs, am, dec, T, 0.01, 0.0, pi=pi, model=native.MODEL_REINFORCE, coins=t(coins), decimation_probability=dprob)
+    it = res['iterations_run']
+    assert used_lds and iters == it and res['rand_consumed'] == it
+    np.testing.assert_array_equal(npy(am), res['trace_active_mask'][it - 1])
+    np.testing.assert_array_equal(npy(hp.solution), res['trace_solution'][it - 1])
+    np.testing.assert_array_equal(npy(q), res['q'])
+    np.testing.assert_array_equal(npy(fs), res['fs'])
+    assert np.abs(res['fs'][:, 1]).sum() > 0
