@@ -268,7 +268,7 @@ def main():
         it_mean = float(np.mean(iters_done))
         n_launch = float(np.mean([l['launches'] for l in launches]))
         n_replay = float(np.mean([l['replays'] for l in launches]))
-        # dominant kernel k_sp_solve_lds<false, false> (one launch per chunk of iterations): HIP events recorded by the library
+        # dominant kernel k_sp_solve_lds<false, false, false> (one launch per chunk of iterations): HIP events recorded by the library
         # on the launch stream around every launch; algorithmic bytes = bytes/iteration x iterations per launch
         launch_ms = float(np.mean([l['solve_kernel_ms'] for l in launches])) / n_launch
         if launch_ms <= 0.0:                            # HBM-resident fallback kernel (instances too large for the LDS): no per-launch events,
@@ -305,7 +305,7 @@ def main():
                        'walksat_steps': ws_steps, 'tolerance': args.tolerance, 't_max': args.t_max, 'parallelism': 'instances sharded, dp%d' % world,
                        'semantics': 'isolated instances' if args.isolated else "reference (batch-wide couplings reproduced)"},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'valu_issue': valu, 'kernel': 'k_sp_solve_lds<false, false>',
+                         'traffic': traffic, 'valu_issue': valu, 'kernel': 'k_sp_solve_lds<false, false, false>',
                          'note': 'achieved = streaming-model algorithmic bytes (41E+36V+8F per iteration) x iterations per launch / '
                                  'average launch duration (HIP events on the launch stream); the instance state is LDS-resident, '
                                  'so the kernel is bound by VALU issue, not by HBM (DESIGN.md section 4)'},

@@ -52,14 +52,14 @@ for d, name in (('pmc3', 'FETCH_SIZE'), ('pmc4', 'WRITE_SIZE')):
         tot, disp = 0.0, set()
         with open(f) as fh:
             for r in csv.DictReader(fh):
-                if 'k_sp_solve_lds<false, false>' in r.get('Kernel_Name', '') and r.get('Counter_Name') == name:
+                if 'k_sp_solve_lds<false, false' in r.get('Kernel_Name', '') and r.get('Counter_Name') == name:
                     tot += float(r.get('Counter_Value', 0) or 0); disp.add(r.get('Dispatch_Id'))
         if disp:
             vals[name] = tot / len(disp)
 if 'FETCH_SIZE' in vals and 'WRITE_SIZE' in vals:
     out = dict(FETCH_SIZE_KiB_per_launch=vals['FETCH_SIZE'], WRITE_SIZE_KiB_per_launch=vals['WRITE_SIZE'],
                k_sp_solve_lds_bytes_per_launch=(2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0,
-               note='2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes; average over the launches of k_sp_solve_lds<false, false> (one per chunk of 12 iterations; the poison replay is k_sp_solve_lds<false, true>)')
+               note='2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes; average over the launches of k_sp_solve_lds<false, false, false> (one per chunk of 12 iterations; the poison replay is k_sp_solve_lds<false, true, false>)')
     json.dump(out, open(os.path.join(root, 'pmc_traffic.json'), 'w'), indent=1)
     print()
     print('== HBM traffic of k_sp_solve_lds per launch:', json.dumps(out))
