@@ -458,15 +458,15 @@ def test_isolated_mode_properties():
     assert int(av_all.sum()) < int(av_strict.sum())                             # isolated: decimation went on after sweep 81
 
 
-@pytest.mark.parametrize('alpha,n,B,T,w,has_nan', [(3.6, 120, 96, 80, 0, False), (4.2, 200, 64, 45, 25, False), (2.5, 60, 40, 50, 0, False),
-                                                  (4.2, 200, 64, 60, 25, True), (4.2, 200, 1500, 100, 0, True)])
-def test_reinforce_persistent_equals_stepwise(alpha, n, B, T, w, has_nan):
+@pytest.mark.parametrize('alpha,n,B,T,w,has_nan,R', [(3.6, 120, 96, 80, 0, False, 1), (4.2, 200, 64, 45, 25, False, 1), (2.5, 60, 40, 50, 0, False, 1),
+                                                    (4.2, 200, 64, 60, 25, True, 1), (4.2, 200, 1500, 100, 0, True, 1), (3.8, 80, 30, 40, 20, False, 3)])
+def test_reinforce_persistent_equals_stepwise(alpha, n, B, T, w, has_nan, R):
     """The Reinforce triple (model type `reinforce`) on the one-launch persistent loop and on the step-wise plug-in loop (the form the
     golden trace pins against the reference): same prediction, same final messages and force column bit for bit, same executed iterations,
     same active mask, same consumption of the global generator (one coin per executed iteration, then Walk-SAT's draws).  In the last
     two cases surveys turn NaN (after sweep 48 in the first): from then on the gate's batch-wide maximum is NaN in the reference and no
     instance leaves through the gate any more -- the persistent loop reproduces that with its poison replay, the NaN instance keeps a NaN
-    force (torch.sign(NaN))."""
+    force (torch.sign(NaN)).  The last case runs with batch replication 3 (identical replicas: deterministic initial state, shared coin)."""
     from pdp.trainer import SatFactorGraphTrainer
     from pdp.factorgraph import dataset
     dev = torch.device('cuda:0')
@@ -480,9 +480,9 @@ def test_reinforce_persistent_equals_stepwise(alpha, n, B, T, w, has_nan):
         m = tr._model_list[0]
         torch.manual_seed(21)
         with torch.no_grad():
-            st = m.get_init_state(gm, bvm, bfm, ef, None, randomized=False, batch_replication=1)
+            st = m.get_init_state(gm, bvm, bfm, ef, None, randomized=False, batch_replication=R)
             pred, states = m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None,
-                             is_training=False, iteration_num=T, check_termination=tr._check_recurrence_termination, batch_replication=1)
+                             is_training=False, iteration_num=T, check_termination=tr._check_recurrence_termination, batch_replication=R)
         assert m.last_run['path'] == ('persistent-lds' if persistent else 'stepwise')
         out[persistent] = (pred[0].clone(), [x.clone() for x in states[0][:2]], [x.clone() for x in states[1][:2]], m.last_run['iterations'],
                            m._active_mask.reshape(-1).clone(), m._last_problem._solution.clone(), torch.rand(3))
