@@ -212,12 +212,16 @@ def test_persistent_solve_with_nothing_to_do(oracle):
 def test_persistent_reinforce_matches_oracle_loop(oracle, monkeypatch, spec, T, pi, dprob, chunk):
     """The Reinforce triple (pdp_decimate.py:202-234, pdp_predict.py:221-226) in one persistent call against the oracle's iteration loop
     with the same recorded coins: messages and the force column bit for bit, same active mask, solution and executed iterations."""
-    from pdp import native
     if chunk:
         monkeypatch.setenv('PDP_SOLVE_CHUNK', chunk)
-    b = random_batch(**spec)
+    res = _reinforce_pair(oracle, random_batch(**spec), T, pi, dprob, spec['seed'])
+    assert np.abs(res['fs'][:, 1]).sum() > 0
+
+
+def _reinforce_pair(oracle, b, T, pi, dprob, seed):
+    from pdp import native
     hp, op = make_pair(oracle, b)
-    coins = np.random.RandomState(spec['seed']).rand(T).astype(np.float32)
+    coins = np.random.RandomState(seed).rand(T).astype(np.float32)
     res = op.forward('reinforce', T, local_search_iterations=0, pi=pi, decimation_probability=dprob, stream=coins, trace=True)
     hp.simplify()
     E, B = hp.E, hp.B
@@ -232,4 +236,19 @@ def test_persistent_reinforce_matches_oracle_loop(oracle, monkeypatch, spec, T, 
     np.testing.assert_array_equal(npy(hp.solution), res['trace_solution'][it - 1])
     np.testing.assert_array_equal(npy(q), res['q'])
     np.testing.assert_array_equal(npy(fs), res['fs'])
-    assert np.abs(res['fs'][:, 1]).sum() > 0
+    return res
+
+
+@pytest.mark.parametrize('T', [1, 2, 9])
+def test_persistent_reinforce_degenerate_instances(oracle, T):
+    "the edge-case batch of test_persistent_solve_degenerate_instances under the Reinforce triple"
+    from pdp import generator
+    rng = np.random.RandomState(4)
+    ordinary = generator.uniform_ksat(30, 100, 3, rng)
+    b = _tiny_batch([[[1], [-1, 2], [-2, 3]],
+                     [[1], [-1]],
+                     [[1, -2, 3]],
+                     [[i + 1 for i in range(40)]],
+                     [[1, (i % 6) + 2, -((i % 5) + 8)] for i in range(30)],
+                     ordinary])
+    _reinforce_pair(oracle, b, T, 0.1, 0.6, 3)
