@@ -1,5 +1,5 @@
 """Times the neural operator entry points alone (GRU cell, edge aggregator) on config 3's graph (5 000 x n=200 m=840, hidden 128).
-Usage: python tools/neural_ops_time.py [reps [n]] (m = 4.2 n); PDP_HIP_LIB selects another build of the library for same-box A/B runs."""
+Usage: python tools/neural_ops_time.py [reps [n [hidden]]] (m = 4.2 n); PDP_HIP_LIB selects another build of the library for same-box A/B runs."""
 import sys, torch
 sys.path.insert(0, '/root/repo/pdp-solver_amd')
 from pdp.factorgraph import dataset
@@ -9,7 +9,7 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 nv = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 tb = dataset.to_torch(dataset.collate_segment(dataset.random_ksat_items(5000, nv, 3, m=int(round(4.2 * nv)), seed=0)), dev)
 p = native.Problem(tb['graph_map'], tb['batch_variable_map'], tb['batch_function_map'], tb['edge_feature'])
-E, H = p.E, 128
+E, H = p.E, (int(sys.argv[3]) if len(sys.argv) > 3 else 128)
 g = torch.Generator(device='cpu'); g.manual_seed(1)
 r = lambda *s: (torch.randn(*s, generator=g) * 0.2).to(dev)
 gw = native.GruWeights(r(3 * H, H + 1), r(3 * H, H), r(3 * H), r(3 * H))
