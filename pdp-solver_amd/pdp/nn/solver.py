@@ -335,15 +335,26 @@ class PropagatorDecimatorSolverBase(nn.Module):
         w = int(self._local_search_iterations)
         nat = sat_problem._native
         if self._rng == 'torch' and w > 0:
+            # The reference draws rand(V, 1) and rand(B) from the global CPU generator in every step it executes (solver.py:457,460).
+            # The stream is drawn in pieces of whole steps (bounded host / device memory, nothing drawn past an early stop by more than
+            # one piece): a piece is one call of the native search, which resumes from the assignment the previous piece left -- the
+            # search state IS the assignment ((a + 1) / 2 maps back to a for active variables, inactive ones stay 0).
             V, B = sat_problem._variable_num, sat_problem._batch_size
-            state = torch.get_rng_state()
-            draws = torch.rand(w * (V + B)).view(w, V + B)
-            var_rand = draws[:, :V].contiguous().to(self._device)
-            coin = draws[:, V:].contiguous().to(self._device)
-            out, steps = nat.local_search(pred, w, self._epsilon, var_rand, coin)
-            torch.set_rng_state(state)
-            if steps > 0:
-                torch.rand(steps * (V + B))            # consume exactly what the reference consumes
+            per_piece = max(1, int(os.environ.get('PDP_WALKSAT_RNG_CHUNK', str(1 << 26))) // (V + B))
+            out, steps = pred, 0
+            while steps < w:
+                c = min(per_piece, w - steps)
+                state = torch.get_rng_state()
+                draws = torch.rand(c * (V + B)).view(c, V + B)
+                var_rand = draws[:, :V].contiguous().to(self._device)
+                coin = draws[:, V:].contiguous().to(self._device)
+                out, done = nat.local_search(out.reshape(-1).contiguous(), c, self._epsilon, var_rand, coin)
+                steps += done
+                if done < c:
+                    torch.set_rng_state(state)
+                    if done > 0:
+                        torch.rand(done * (V + B))     # consume exactly what the reference consumes
+                    break
         else:
             out, steps = nat.local_search(pred, w, self._epsilon, seed=self._seed)
         sat_problem._edge_mask = nat.edge_mask

@@ -510,3 +510,12 @@ def test_reinforce_steps_when_the_resident_solver_is_unavailable(monkeypatch):
     expected_next = torch.rand(4)
     run_golden('trace_reinforce_easy', 'reinforce', persistent=True, pi=0.01, decimation_probability=0.5)
     np.testing.assert_array_equal(torch.rand(4).numpy(), expected_next.numpy())
+
+
+@pytest.mark.parametrize('name,model_type,kw', [c for c in CASES if c[0] in ('trace_pdp_easy_ws', 'trace_walksat_easy', 'trace_pdp_rep3', 'trace_pdp_mixed')])
+@pytest.mark.parametrize('chunk', ['1', '5000'])
+def test_walksat_random_stream_in_pieces(monkeypatch, name, model_type, kw, chunk):
+    """rng='torch' draws the Walk-SAT numbers of the reference's CPU stream in pieces of whole steps and resumes the native search from the
+    assignment of the previous piece: with one step (or a few) per piece the golden outputs and the generator position must not change."""
+    monkeypatch.setenv('PDP_WALKSAT_RNG_CHUNK', chunk)
+    test_forward_equals_reference_golden(name, model_type, kw, True)
