@@ -415,9 +415,11 @@ def sp_adaptors(dec_v, dec_f, w_f, W_v):
     return np.ascontiguousarray(xlog, dtype=np.float32), np.ascontiguousarray(np.stack((eta, force), 1), dtype=np.float32)
 
 
-def pnd_forward(problem, weights, init, T, trace=None):
+def pnd_forward(problem, weights, init, T, trace=None, walksat=None):
     """p-nd-np forward loop (solver.py:355-386: SP propagator with adaptors, neural decimator, neural predictor).
-    init = (q [E,3], fs [E,2], dec_v [E,H], dec_f [E,H])."""
+    init = (q [E,3], fs [E,2], dec_v [E,H], dec_f [E,H]).  walksat = dict(steps, epsilon, stream, cursor): the post-processing
+    local search of solver.py:433-467 on the recorded random stream (cursor is updated in place); with batch replication the
+    result is de-duplicated (solver.py:401-431)."""
     ev, ec, es, vi, fi = problem.graph()
     E, V, B = problem.E, problem.V, problem.B
     q, fs, dv, df = [np.ascontiguousarray(x, dtype=np.float32) for x in init]
@@ -446,6 +448,12 @@ def pnd_forward(problem, weights, init, T, trace=None):
             break
     agg = aggregator(ev, V, dv, es, em, True, weights['pred'])
     p = perceptron(agg, weights['head']['W1'], weights['head']['b1'], weights['head']['W2'])[:, 0]
-    ls, _, _ = problem.local_search(p, 0, 0.5, seed=0)
+    steps = 0
+    if walksat is None:
+        ls, _, _ = problem.local_search(p, 0, 0.5, seed=0)
+    else:
+        ls, steps, walksat['cursor'] = problem.local_search(p, walksat['steps'], walksat['epsilon'], stream=walksat['stream'], cursor=walksat['cursor'])
     final = problem.update_solution(ls)
-    return final, dict(q=q, fs=fs, dec_v=dv, dec_f=df, iterations=iters, active_mask=am)
+    if problem.R > 1:
+        final, _ = problem.deduplicate(final)
+    return final, dict(q=q, fs=fs, dec_v=dv, dec_f=df, iterations=iters, active_mask=am, walksat_steps=steps)

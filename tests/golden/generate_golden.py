@@ -690,6 +690,174 @@ def gen_headline_neural():
 
 
 
+# ---- F. BASELINE configs[0] / configs[4] / long neural pins ---------------------------------------------------------------
+
+def gen_config0_cli():
+    """BASELINE configs[0]: 'p-d-p' on 100 random 3-SAT DIMACS files n=50 m=210, --cpu_mode, batch_size=100, T=50, through the reference's
+    own CLI (satyr.py -d -c -z 100).  The files are regenerated from seeds by the test (generator.write_dimacs, instance i =
+    RandomState(9000 + i)); stored: the reference's output rows, whose ID column also is the converter's os.listdir order."""
+    import runpy
+    import shutil
+    ddir = tempfile.mkdtemp(prefix='cfg0_')
+    try:
+        for i in range(100):
+            gen.write_dimacs(os.path.join(ddir, 'c0_%03d_%d.cnf' % (i, i % 2)), 50, gen.uniform_ksat(50, 210, 3, np.random.RandomState(9000 + i)))
+        out_path = os.path.join(HERE, 'cli_config0.out.jsonl')
+        argv = ['satyr.py', '/root/reference/config/Predict/PDP-p-d-p-sp-pytorch.yaml', ddir, '50', '-d', '-c', '-z', '100', '-s', '7', '-o', out_path]
+        old_argv, old_cwd = sys.argv, os.getcwd()
+        sys.argv = argv
+        try:
+            runpy.run_path(os.path.join(REF, 'satyr.py'), run_name='__main__')
+        finally:
+            sys.argv = old_argv
+            os.chdir(old_cwd)
+    finally:
+        shutil.rmtree(ddir, ignore_errors=True)
+    print('wrote', out_path)
+
+
+def mixed_k_lines(count, n_lo, n_hi, seed0, alpha_scale=0.9):
+    "configs[4]'s family at test size: k drawn per instance from {3,4,5}, n ~ U{n_lo..n_hi}, m = round(0.9 * alpha_k * n) (SURVEY.md 8(d))"
+    alpha = {3: 4.27, 4: 9.93, 5: 21.12}
+    lines, meta = [], []
+    for i in range(count):
+        rng = np.random.RandomState(seed0 + i)
+        k = int(rng.choice([3, 4, 5])); n = int(rng.randint(n_lo, n_hi + 1))
+        m = int(round(alpha_scale * alpha[k] * n))
+        lines.append(gen.json_line(n, gen.uniform_ksat(n, m, k, rng), label=i % 2, name="mk%d" % i))
+        meta.append((k, n, m))
+    return lines, meta
+
+
+def _with_b5_shim(fn):
+    import pdp.nn.pdp_decimate as ref_dec
+    orig_init = ref_dec.NeuralDecimator.__init__
+
+    def shim_init(self, device, message_dimension, *a, **k):                  # B-5
+        orig_init(self, device, (3, 2) if message_dimension == (3, 1) else message_dimension, *a, **k)
+
+    ref_dec.NeuralDecimator.__init__ = shim_init
+    try:
+        return fn()
+    finally:
+        ref_dec.NeuralDecimator.__init__ = orig_init
+
+
+def gen_config4_mixed():
+    """BASELINE configs[4] at a size the reference runs in seconds: 'p-nd-np' (reference + the App. B-4 / B-5 shims) on mixed random k-SAT,
+    k in {3,4,5}, n in [20,60], batch_replication 4, a test_batch_limit that cuts the loader batch into several dynamic segments, Walk-SAT
+    with the torch random stream -- through the reference's own predict() (loader, DynamicBatchDivider, _predict_batch, _deduplicate,
+    post-processor).  Stored: weights, the JSON input, per-segment per-sweep predictions, and the output rows."""
+    H, T, w, R, seed = 32, 8, 25, 4, 17
+    lines, meta = mixed_k_lines(14, 20, 60, seed0=8800)
+    with open(os.path.join(HERE, 'config4_mixed.json'), 'w') as f:
+        f.write("\n".join(lines) + "\n")
+    edges = [len(json.loads(l)[1]) for l in lines]
+    limit = 4 * H * (sum(edges) // 3)                 # limit // R // (max_edges * H) < batch: three or four segments, largest instances first
+    cfg = base_cfg('p-nd-np', hidden_dim=H, local_search_iteration=w, test_recurrence_num=T, batch_size=14, test_batch_limit=limit,
+                   max_cache_size=100000)
+    tr, m = _with_b5_shim(lambda: build(cfg, seed=97531))
+    tr._num_cores = 0
+    out = flat_state_dict(m)
+    with open(os.path.join(HERE, 'state_dict_alias_map_config4.json'), 'w') as f:
+        json.dump(alias_map(m), f, indent=0, sort_keys=True)
+    rec, seg = {}, {'i': -1, 'sweep': 0, 'sizes': []}
+    orig_check = tr._check_recurrence_termination
+    orig_batch = tr._predict_batch
+
+    def check(active, prediction, sp):
+        rec['seg%d_pred_%d' % (seg['i'], seg['sweep'])] = np_(prediction[0][:, 0])
+        orig_check(active, prediction, sp)
+        rec['seg%d_active_%d' % (seg['i'], seg['sweep'])] = np_(active[:, 0])
+        seg['sweep'] += 1
+
+    def predict_batch(graph_map, *a, **k):
+        seg['i'] += 1; seg['sweep'] = 0
+        seg['sizes'].append(int(graph_map.size(1)))
+        return orig_batch(graph_map, *a, **k)
+
+    tr._check_recurrence_termination = check
+    tr._predict_batch = predict_batch
+    torch.manual_seed(seed); np.random.seed(seed)
+    del RAND_LOG[:]
+    torch.rand = _rec_rand
+    buf = io.StringIO()
+    try:
+        tr.predict(os.path.join(HERE, 'config4_mixed.json'), buf, import_path_base=None, post_processor=tr._post_process_predictions,
+                   batch_replication=R)
+    finally:
+        torch.rand = _real_rand
+    rows = [l for l in buf.getvalue().split('\n') if l.strip()]
+    with open(os.path.join(HERE, 'config4_mixed.out.jsonl'), 'w') as f:
+        f.write("\n".join(rows) + "\n")
+    out.update(rec)
+    out['meta'] = np.array([T, H, w, R, seed, limit, len(seg['sizes'])], dtype=np.int64)
+    out['segment_edges'] = np.array(seg['sizes'], dtype=np.int64)
+    out['instance_knm'] = np.array(meta, dtype=np.int64)
+    out['rand_sizes'] = np.array([len(r) for r in RAND_LOG], dtype=np.int64)
+    save('config4_mixed', **out)
+    print('config4: %d segments (edges %s), %d rows, solved %d' % (len(seg['sizes']), seg['sizes'], len(rows),
+                                                                  sum(json.loads(r)['solved'] for r in rows)))
+
+
+def _headline_lines(seeds):
+    lines = []
+    for sd in seeds:
+        variables, signs = gen.uniform_ksat_arrays(200, 840, 3, np.random.RandomState(sd))
+        vn, fn, gmap, efeat = gen.compact_arrays(200, variables, signs)
+        lines.append(gen.format_json_line(vn, fn, ((gmap[0] + 1) * efeat).astype(np.int64), gmap[1] + 1, -1, "h%d" % sd))
+    return lines
+
+
+def gen_neural_long():
+    """Longer reference pins of the neural model types at configs[2]'s width: hidden 128, 8 instances of bench.py's family (n=200 m=840),
+    T = 24 sweeps from the test mode's random initial state (torch seed 3).  np-nd-np uses the seeded weights of trace_neural_h128.npz (same constructor seed);
+    p-nd-np (reference + App. B-5 shim) stores its own.  Stored per sweep: the prediction (all variables), the active mask, a sample of the
+    decimator state; at the end the final prediction."""
+    seeds = list(range(200, 208))
+    lines = _headline_lines(seeds)
+    gm, bvm, bfm, ef, lab, misc = batch_tensors(lines)
+    H, T = 128, 24
+    for mt in ('np-nd-np', 'p-nd-np'):
+        cfg = base_cfg(mt, hidden_dim=H, local_search_iteration=0)
+        if mt == 'np-nd-np':
+            tr, m = build(cfg, seed=1234)
+            ref_w = np.load(os.path.join(HERE, 'trace_neural_h128.npz'))
+            for k, v in flat_state_dict(m).items():
+                assert np.array_equal(ref_w[k], v), k
+            rec = {}
+        else:
+            tr, m = _with_b5_shim(lambda: build(cfg, seed=2468))
+            rec = flat_state_dict(m)
+            with open(os.path.join(HERE, 'state_dict_alias_map_pndnp_h128.json'), 'w') as f:
+                json.dump(alias_map(m), f, indent=0, sort_keys=True)
+        it = {'i': 0}
+        orig_check = tr._check_recurrence_termination
+
+        def check(active, prediction, sp):
+            rec['pred_%d' % it['i']] = np_(prediction[0][:, 0])
+            orig_check(active, prediction, sp)
+            rec['active_mask_%d' % it['i']] = np_(active[:, 0])
+            it['i'] += 1
+
+        def dec_hook(mod, inp, outp):
+            rec['dec_v_sample_%d' % it['i']] = np_(outp[0][::997]); rec['dec_f_sample_%d' % it['i']] = np_(outp[1][::997])
+
+        h2 = m._decimator.register_forward_hook(dec_hook)
+        torch.manual_seed(3)
+        with torch.no_grad():
+            # the test mode's random initial state (base.py:229): regenerated by the build from the same torch seed, a sample is stored
+            st = m.get_init_state(gm, bvm, bfm, ef, None, randomized=True, batch_replication=1)
+            for a_, nm in ((st[0][0], 'init_prop_0'), (st[0][1], 'init_prop_1'), (st[1][0], 'init_dec_0'), (st[1][1], 'init_dec_1')):
+                rec[nm + '_sample'] = np_(a_[::997])
+            pred, (ps, ds) = m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None,
+                               is_training=False, iteration_num=T, check_termination=check, batch_replication=1)
+        h2.remove()
+        rec['final_prediction'] = np_(pred[0][:, 0])
+        save('neural_long_' + mt.replace('-', '_'), seeds=np.array(seeds, dtype=np.int64), meta=np.array([200, 840, T, H, it['i']], dtype=np.int64), **rec)
+
+
+
 def gen_generators():
     """The reference's CNF generators (src/pdp/generator.py) under fixed numpy seeds: uniform, modular and variable-modular,
     generate() and generate_complete() (the variable-modular generate_complete cannot run in the reference, App. B-11)."""
@@ -798,3 +966,9 @@ if __name__ == '__main__':
                   tag='trace_pdp_randinit', cfg_kw=dict(tolerance=0.05, t_max=10))
     if 'cli' in what:
         gen_cli()
+    if 'config0' in what:
+        gen_config0_cli()
+    if 'config4' in what:
+        gen_config4_mixed()
+    if 'neural_long' in what:
+        gen_neural_long()

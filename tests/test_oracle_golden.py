@@ -190,3 +190,37 @@ def test_sat_loss_and_test_metrics(oracle, golden_dir):
             assert np.isinf(loss) and loss > 0
         else:
             assert abs(loss - ref[2]) <= 2e-6 * abs(ref[2]), (loss, ref[2])
+
+
+def config0_items(golden_dir):
+    "BASELINE configs[0]'s 100 instances (n=50 m=210, instance i = RandomState(9000 + i)) in the order of the reference CLI's rows"
+    import json
+    from pdp import generator
+    from pdp.factorgraph import dataset
+    rows = [json.loads(l) for l in open(os.path.join(golden_dir, 'cli_config0.out.jsonl')) if l.strip()]
+    items = []
+    for r in rows:
+        i = int(r['ID'].split('_')[1])
+        items.append(dataset.instance_from_clauses(50, generator.uniform_ksat(50, 210, 3, np.random.RandomState(9000 + i)), label=i % 2, name=r['ID']))
+    return rows, items
+
+
+def test_config0_cli_rows(oracle, golden_dir):
+    """BASELINE configs[0] ('p-d-p' on 100 random 3-SAT DIMACS n=50, --cpu_mode, batch_size=100, T=50): the oracle, fed with the torch CPU
+    stream the reference CLI consumes for `-s 7` (DataLoader base seed, random fill, 100 Walk-SAT steps), reproduces every row the
+    reference wrote: solved flag, unsatisfied-clause count and the whole assignment of all 100 instances."""
+    import torch
+    from pdp.factorgraph import dataset
+    rows, items = config0_items(golden_dir)
+    b = dataset.collate_segment(items)
+    p = oracle.Problem(b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'])
+    torch.manual_seed(7)
+    torch.empty((), dtype=torch.int64).random_()
+    stream = torch.rand(p.V + 100 * (p.V + p.B)).numpy()
+    res = p.forward('p-d-p', 50, local_search_iterations=100, epsilon=0.5, tolerance=0.02, t_max=100, stream=stream)
+    solved, unsat = p.cnf_eval(res['prediction'])
+    off = np.concatenate(([0], np.cumsum([it[0] for it in items])))
+    for i, r in enumerate(rows):
+        assert r['solved'] == int(solved[i]) and r['unsat_clauses'] == int(unsat[i]), r['ID']
+        assert r['solution'] == (res['prediction'][off[i]:off[i + 1]] > 0.5).astype(int).tolist(), r['ID']
+    assert sum(r['solved'] for r in rows) == 13
