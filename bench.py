@@ -4,13 +4,18 @@
 Metric (BASELINE.json): PDP message-passing iterations/sec on random 3-SAT n=200 m=840 batch=5000 ('p-d-p' survey
 propagation + sequential decimation, T=100, configs[1]).  One "step" = one pass of the hot path over one resident
 batch: reset of the solver state, SATProblem.simplify, and the T-iteration propagate/decimate/predict/terminate
-loop (reference: src/pdp/nn/solver.py:332-337,355-386) -- the loop runs as ONE persistent kernel launch.
+loop (reference: src/pdp/nn/solver.py:332-337,355-386) -- the loop runs as ONE persistent kernel launch per chunk of iterations.
 value = executed PDP iterations per second, aggregated over all ranks (each rank owns its own batch of 5000
 instances: weak scaling, no collective on the data path; one RCCL all-reduce of the solved counters at the end).
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches one rank per GPU through
-torch.distributed.run.  Rank 0 prints ONE JSON line.
-"""
+Contract: `python bench.py --gpus N --steps K --warmup W`.  With N > 1 and no WORLD_SIZE in the environment this process is only a
+launcher: it starts N ranks (one per GPU) through `python -m torch.distributed.run` BEFORE touching the GPU itself, forwards the single
+JSON line rank 0 prints, and exits non-zero if any rank fails.  Under torch.distributed.run (what the driver uses for N > 1) it is a
+rank and WORLD_SIZE must equal --gpus.  Rank 0 prints ONE JSON line.
+
+At N = 1 the line also carries, outside the headline's timed loop: `cpu_baseline` (the C oracle over all host cores at the full batch;
+`cpu_baseline_torch_sparse`: the PyTorch-CPU restatement of the reference's sparse-mm formulation) and `config.secondary`
+(configs[2]'s neural kernels with per-kernel rooflines, Walk-SAT, the Reinforce solver)."""
 
 import argparse
 import json
@@ -19,15 +24,13 @@ import sys
 import time
 
 import numpy as np
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(REPO, 'pdp-solver_amd'))
 
-from pdp import native  # noqa: E402
-from pdp.factorgraph import dataset  # noqa: E402
-
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 vector peak
+N_SIMD, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, 2.4 GHz
 
 
 def algorithmic_bytes_per_iteration(E, V, F):
@@ -35,25 +38,193 @@ def algorithmic_bytes_per_iteration(E, V, F):
     return 41 * E + 36 * V + 8 * F
 
 
-def cpu_baseline(args):
-    """CPU restatement (oracle, single thread) timed on a bounded sample of the same workload."""
+# =====================================================================================================================
+# launcher: `python bench.py --gpus N` with N > 1 outside torch.distributed.run
+# =====================================================================================================================
+def launch_ranks(n, argv):
+    """Start n ranks of this script (one per GPU) and forward rank 0's JSON line.  Nothing here touches the GPU: a process that has
+    initialised HIP must not fork / exec ranks, so the launch happens before any device call."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=env)
+    lines = [l for l in proc.stdout.split('\n') if l.startswith('{') and '"metric"' in l]
+    if proc.returncode != 0 or not lines:
+        sys.stderr.write(proc.stdout[-4000:] + '\n' + proc.stderr[-8000:] + '\n')
+        sys.stderr.write("bench.py: the %d-rank run failed (exit code %d)\n" % (n, proc.returncode))
+        return proc.returncode or 1
+    line = json.loads(lines[-1])
+    if line.get('rccl_ranks') != n or line.get('n_gpus') != n:
+        sys.stderr.write("bench.py: asked for %d ranks, the line reports %r\n" % (n, (line.get('n_gpus'), line.get('rccl_ranks'))))
+        return 1
+    print(lines[-1])
+    return 0
+
+
+def init_ranks(args):
+    """(world, rank, local_rank, backend) of this process; initialises torch.distributed when world > 1.  backend 'nccl' is RCCL (one GPU
+    per rank); PDP_DIST_BACKEND=gloo lets several ranks share one GPU (checks of the N > 1 code on a single-GPU box / on CPU)."""
+    import torch
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    backend = os.environ.get('PDP_DIST_BACKEND', 'nccl')
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d ranks were started" % (args.gpus, world))
+    if world > 1:
+        import torch.distributed as dist
+        if args.selftest_collective:
+            dist.init_process_group(backend if backend != 'nccl' or torch.cuda.is_available() else 'gloo')
+        elif backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            local_rank = local_rank % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: process group of %d ranks for --gpus %d" % (dist.get_world_size(), args.gpus))
+    return world, rank, local_rank, backend
+
+
+def selftest_collective(args):
+    """The N-rank plumbing without any GPU work (tests/test_parallel_gloo.py runs it with gloo on CPU): rendezvous, barrier, MAX of the
+    per-rank times, SUM of the per-rank counters, rank 0's single line, non-zero exit when a rank fails."""
+    import torch
+    import torch.distributed as dist
+    world, rank, _, _ = init_ranks(args)
+    if os.environ.get('PDP_BENCH_FAIL_RANK') == str(rank):
+        raise SystemExit("bench.py selftest: rank %d fails on request" % rank)
+    elapsed = 0.010 * (rank + 1)
+    stats = torch.tensor([1000.0, float(rank + 1), 100.0 * args.steps], dtype=torch.float64)
+    ranks = 1
+    if world > 1:
+        dist.barrier()
+        tmax = torch.tensor([elapsed], dtype=torch.float64); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); elapsed = float(tmax.item())
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        ranks = dist.get_world_size()
+    if rank == 0:
+        print(json.dumps({'metric': 'pdp_iterations_per_sec', 'selftest': True, 'value': float(stats[2].item()) / elapsed, 'n_gpus': world,
+                          'rccl_ranks': ranks, 'steps': args.steps, 'warmup': args.warmup, 'instances': float(stats[0].item()),
+                          'rank_sum': float(stats[1].item()), 'max_elapsed_s': elapsed}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+# =====================================================================================================================
+# CPU baselines (rank 0, N = 1; run BEFORE the GPU is touched: the oracle workers are forked)
+# =====================================================================================================================
+_CPU_ITEMS = None
+
+
+def _oracle_worker(job):
+    lo, hi, iters, tol, t_max = job
+    from oracle import binding
+    from pdp.factorgraph import dataset
+    b = dataset.collate_segment(_CPU_ITEMS[lo:hi])
+    p = binding.Problem(b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'])
+    res = p.forward('p-d-p', iters, local_search_iterations=0, tolerance=tol, t_max=t_max, seed=1)
+    return (hi - lo) * res['iterations_run']
+
+
+def cpu_model_name():
+    try:
+        for l in open('/proc/cpuinfo'):
+            if l.startswith('model name'):
+                return l.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline_all_cores(args, items):
+    """The C oracle (single-threaded restatement of the reference's algorithm, oracle/pdp_oracle.c) on EVERY host core: the full batch of
+    the headline workload cut into one contiguous sub-batch per worker process, every sub-batch run for the full T iterations.  (Each
+    sub-batch is a batch of its own for the reference's batch-wide couplings; this is a throughput baseline.)"""
+    import multiprocessing as mp
+    global _CPU_ITEMS
     sys.path.insert(0, REPO)
     from oracle import binding
     binding.build()
-    bs, ts = args.cpu_sample_batch, args.cpu_sample_iters
-    items = dataset.random_ksat_items(bs, args.n, 3, seed=777)
-    b = dataset.collate_segment(items)
-    p = binding.Problem(b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'])
-    t0 = time.perf_counter()
-    res = p.forward('p-d-p', ts, local_search_iterations=0, tolerance=args.tolerance, t_max=args.t_max, seed=1)
-    dt = time.perf_counter() - t0
-    inst_iters = bs * res['iterations_run'] / dt
-    return dict(value=inst_iters / args.batch, unit='iterations/s (batch of %d instances)' % args.batch, cores=1, kind='port',
-                sample='%d instances x %d iterations of the same n=%d m=%d 3-SAT family in %.1f s (%.0f instance-iterations/s), '
-                       'scaled linearly to the batch' % (bs, res['iterations_run'], args.n, int(round(4.2 * args.n)), dt, inst_iters))
+    cores = os.cpu_count() or 1
+    if args.cpu_cores:
+        cores = min(cores, args.cpu_cores)
+    B = len(items) if args.cpu_full_batch else min(len(items), args.cpu_sample_batch)
+    _CPU_ITEMS = items[:B]
+    workers = min(cores, B)
+    bounds = [(B * w) // workers for w in range(workers + 1)]
+    jobs = [(bounds[w], bounds[w + 1], args.iters, args.tolerance, args.t_max) for w in range(workers)]
+    ctx = mp.get_context('fork')
+    with ctx.Pool(workers) as pool:
+        pool.map(_oracle_worker, [(0, 1, 1, args.tolerance, args.t_max)] * workers)       # start the workers, load the library
+        t0 = time.perf_counter()
+        done = pool.map(_oracle_worker, jobs, chunksize=1)
+        dt = time.perf_counter() - t0
+    _CPU_ITEMS = None
+    inst_iters = float(sum(done)) / dt
+    return dict(value=inst_iters / args.batch, unit='iterations/s (batch of %d instances)' % args.batch, cores=workers, kind='port',
+                cpu_model=cpu_model_name(),
+                sample='the oracle on %d worker processes (one per host core), %d instances x %d iterations of the headline batch in %.2f s '
+                       '(%.0f instance-iterations/s)%s' % (workers, B, args.iters, dt, inst_iters,
+                                                           '' if B == args.batch else ', scaled linearly to the batch'))
 
 
-MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 vector peak
+def cpu_baseline_torch_sparse(args, items):
+    """The reference's own formulation on the CPU: sparse COO masks + torch.mm + the dense [V x B] matrices of sparse_max / sparse_argmax
+    (oracle/torch_sparse_port.py, an own restatement of the op sequence; the reference itself cannot travel to this box), with
+    torch.set_num_threads(all cores) as src/pdp/factorgraph/base.py:43-50 does.  B = 500 for 3 iterations, then the full batch: its cost is
+    quadratic in B (20 GB dense matrix per reduction at B = 5000), so the full batch runs 2 iterations and the second one -- the first with
+    a convergence test -- is the per-iteration figure."""
+    import torch
+    sys.path.insert(0, REPO)
+    from oracle import torch_sparse_port as port
+    from pdp.factorgraph import dataset
+    cores = os.cpu_count() or 1
+    if args.cpu_cores:
+        cores = min(cores, args.cpu_cores)
+    torch.set_num_threads(cores)
+    out = dict(unit='iterations/s (batch of B instances)', cores=cores, kind='port', cpu_model=cpu_model_name(), runs=[])
+    def mem_available_gb():
+        try:
+            for l in open('/proc/meminfo'):
+                if l.startswith('MemAvailable'):
+                    return float(l.split()[1]) / 1e6
+        except OSError:
+            pass
+        return 0.0
+
+    for B, T in ((500, 3), (args.batch, 2)):
+        if B > len(items) or (B > 500 and not args.cpu_full_batch):
+            continue
+        need_gb = 3.0 * 4e-9 * B * (B * args.n)                     # three live dense [V x B] fp32 matrices at the worst point
+        if B > 500 and mem_available_gb() < need_gb + 16.0:
+            out['skipped'] = 'B=%d needs ~%.0f GB of host memory for the dense [V x B] matrices (%.0f GB available)' % (B, need_gb, mem_available_gb())
+            continue
+        b = dataset.collate_segment(items[:B])
+        t0 = time.perf_counter()
+        P = port.SparseBatch(b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'])
+        with torch.no_grad():
+            P.simplify()
+            setup = time.perf_counter() - t0
+            times = []
+            port.forward_loop(P, T, tolerance=args.tolerance, t_max=args.t_max, simplify=False, times=times)
+        steady = times[1:] if len(times) > 1 else times
+        per_iter = float(np.mean(steady))
+        out['runs'].append(dict(B=B, iterations=len(times), seconds_per_iteration=per_iter, first_iteration_s=times[0], setup_s=setup,
+                                iterations_per_s=1.0 / per_iter, instance_iterations_per_s=B / per_iter))
+        del P
+    if out['runs']:
+        last = out['runs'][-1]
+        out['value'] = last['iterations_per_s'] * last['B'] / float(args.batch) if last['B'] != args.batch else last['iterations_per_s']
+        out['sample'] = 'torch sparse-mm restatement, %d threads: ' % cores + '; '.join(
+            'B=%d: %.2f s per iteration (%d iterations run)' % (r['B'], r['seconds_per_iteration'], r['iterations']) for r in out['runs'])
+    return out
 
 
 def cpu_baseline_neural(args):
@@ -61,6 +232,7 @@ def cpu_baseline_neural(args):
     on a few instances of the same family with random weights of the same shapes; scaled linearly to the batch."""
     sys.path.insert(0, REPO)
     from oracle import binding
+    from pdp.factorgraph import dataset
     binding.build()
     bs, H = 400, args.hidden
     b = dataset.collate_segment(dataset.random_ksat_items(bs, args.n, 3, m=int(round(4.2 * args.n)), seed=777))
@@ -84,55 +256,108 @@ def cpu_baseline_neural(args):
                        'in %.1f s, scaled linearly to the batch' % (bs, args.n, H, dt))
 
 
-def bench_neural(args, dev, rank, world):
-    """configs[2]: fully neural PDP (np-nd-np, hidden_dim 128, layer widths 100/100/50/50) on random 3-SAT n=200.
-    A step = T iterations of propagate (2 deep-set aggregators) / decimate (2 GRU cells) / predict / terminate on a resident
-    batch with seeded random-init weights (the reference ships none).  SURVEY.md 8(d): 573 752 flop per edge and
-    48 500 per variable and iteration, all in fp32 MFMA."""
+# =====================================================================================================================
+# configs[2]: the neural workload (standalone with --workload neural, and as a short secondary measurement of the default run)
+# =====================================================================================================================
+# MACs per edge / per variable of the kernels of one np-nd-np iteration at hidden H, inner widths 100 / 50 / 100
+def neural_flops(H):
+    return dict(agg_pre=2.0 * ((H + 1) * 100 + 100 * 50),          # per edge and aggregator call: W1_m, W2_m
+                agg_post=2.0 * (51 * 100 + 100 * H),               # per edge: W1_a, W2_a
+                gru=2.0 * (3 * H * (H + 1) + 3 * H * H),           # per edge: W_ih, W_hh
+                predict_head=2.0 * (50 * 100 + 100 * H + H * 50 + 50))    # per VARIABLE: predictor's W1_a, W2_a + perceptron head
+
+
+def make_neural_model(args, T):
     import logging
+    import torch
     from pdp.trainer import SatFactorGraphTrainer
-    T = args.iters
-    m_cl = int(round(4.2 * args.n))
-    items = dataset.random_ksat_items(args.batch, args.n, 3, m=m_cl, seed=1000003 * rank)
-    b = dataset.to_torch(dataset.collate_segment(items), dev)
     cfg = dict(model_type='np-nd-np', model_name='bench-np-nd-np', verbose=False, local_search_iteration=0, epsilon=0.5, rng='philox',
                random_seed=1, hidden_dim=args.hidden, edge_feature_dim=1, meta_feature_dim=0, prediction_dim=1, mem_hidden_dim=100,
                agg_hidden_dim=100, mem_agg_hidden_dim=50, classifier_dim=50, test_batch_limit=1 << 62, batch_size=args.batch,
                test_recurrence_num=T)
     torch.manual_seed(1234)
     tr = SatFactorGraphTrainer(cfg, use_cuda=True, logger=logging.getLogger('bench'))
-    model = tr._model_list[0]
+    return tr, tr._model_list[0]
+
+
+def neural_step(tr, model, b, T):
+    import torch
     gm, bvm, bfm, ef = b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature']
-    E, V, F = gm.size(1), bvm.numel(), bfm.numel()
+    with torch.no_grad():
+        st = model.get_init_state(gm, bvm, bfm, ef, None, randomized=False, batch_replication=1)
+        model(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None,
+              is_training=False, iteration_num=T, check_termination=tr._check_recurrence_termination, batch_replication=1)
+    return model.last_run['iterations']
+
+
+def neural_kernel_rooflines(native, timing, E, V, H):
+    "per-kernel lines from the library's HIP events: ms per launch, algorithmic flop per launch, TFLOP/s, fraction of the fp32 MFMA peak"
+    fl = neural_flops(H)
+    out = {}
+    for key, kernels in (('agg_pre', 'k_agg_pre_wave'), ('agg_post', 'k_agg_post_pf'), ('gru', 'k_gru_pipe'), ('predict_head', 'k_predict_rows'),
+                         ('row_sum', 'k_row_sum')):
+        ms, n = timing[key]
+        if n == 0:
+            continue
+        per = ms / n
+        row = dict(kernel=kernels, launches=n, ms_per_launch=per)
+        if key in fl:
+            flop = fl[key] * (V if key == 'predict_head' else E)
+            tf = flop / (per * 1e-3) / 1e12
+            row.update(flop_per_launch=flop, tflops=tf, frac_of_mfma_f32_peak=tf / MFMA_F32_PEAK_TFLOPS)
+        out[key] = row
+    if 'agg_pre' in out and 'agg_post' in out:
+        # one MessageAggregator call of the propagator = pre + row sum + post (the pre launches also serve the predictor: per launch figures)
+        ms = out['agg_pre']['ms_per_launch'] + out['agg_post']['ms_per_launch'] + out.get('row_sum', {}).get('ms_per_launch', 0.0)
+        tf = (fl['agg_pre'] + fl['agg_post']) * E / (ms * 1e-3) / 1e12
+        out['aggregator_call'] = dict(ms=ms, tflops=tf, frac_of_mfma_f32_peak=tf / MFMA_F32_PEAK_TFLOPS)
+    return out
+
+
+def bench_neural(args, dev, rank, world):
+    """configs[2]: fully neural PDP (np-nd-np, hidden_dim 128, layer widths 100/100/50/50) on random 3-SAT n=200.
+    A step = T iterations of propagate (2 deep-set aggregators) / decimate (2 GRU cells) / predict / terminate on a resident
+    batch with seeded random-init weights (the reference ships none).  SURVEY.md 8(d): 573 752 flop per edge and
+    48 500 per variable and iteration, all in fp32 MFMA."""
+    import torch
+    from pdp import native
+    from pdp.factorgraph import dataset
+    T = args.iters
+    m_cl = int(round(4.2 * args.n))
+    items = dataset.random_ksat_items(args.batch, args.n, 3, m=m_cl, seed=1000003 * rank)
+    b = dataset.to_torch(dataset.collate_segment(items), dev)
+    tr, model = make_neural_model(args, T)
+    E, V, F = b['graph_map'].size(1), b['batch_variable_map'].numel(), b['batch_function_map'].numel()
     iters_done, step_ms = [], []
 
     def step(record):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        with torch.no_grad():
-            st = model.get_init_state(gm, bvm, bfm, ef, None, randomized=False, batch_replication=1)
-            model(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None,
-                  is_training=False, iteration_num=T, check_termination=tr._check_recurrence_termination, batch_replication=1)
+        it = neural_step(tr, model, b, T)
         torch.cuda.synchronize()
         if record:
-            step_ms.append(1e3 * (time.perf_counter() - t0)); iters_done.append(model.last_run['iterations'])
+            step_ms.append(1e3 * (time.perf_counter() - t0)); iters_done.append(it)
 
     for _ in range(args.warmup):
         step(False)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
+    native.kernel_timing(True)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    timing = native.kernel_timing_read(); native.kernel_timing(False)
     tot = torch.tensor([float(sum(iters_done)), elapsed], dtype=torch.float64, device=args.coll_dev)
+    ranks = 1
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=args.coll_dev); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        ranks = dist.get_world_size()
     if rank == 0:
         iters_all = float(tot[0].item())
         value = iters_all / elapsed
@@ -141,7 +366,7 @@ def bench_neural(args, dev, rank, world):
         achieved = flops_iter * float(np.mean(iters_done)) / (float(np.mean(step_ms)) * 1e-3) / 1e12
         print(json.dumps({
             'metric': 'pdp_iterations_per_sec', 'value': value,
-            'unit': 'iterations/s (each iteration sweeps a batch of %d instances)' % args.batch, 'n_gpus': world, 'steps': args.steps,
+            'unit': 'iterations/s (each iteration sweeps a batch of %d instances)' % args.batch, 'n_gpus': world, 'rccl_ranks': ranks, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': "configs[2]: 'np-nd-np' hidden_dim=%d (100/100/50/50), random 3-SAT n=%d m=%d batch=%d T=%d per GPU, "
@@ -150,11 +375,137 @@ def bench_neural(args, dev, rank, world):
                        'instance_iterations_per_sec': value * args.batch, 'parallelism': 'instances sharded, dp%d' % world},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / MFMA_F32_PEAK_TFLOPS,
                          'traffic': None, 'kernel': 'k_gru_pipe / k_agg_pre_wave / k_agg_post_pf (v_mfma_f32_32x32x2_f32)',
-                         'note': 'achieved = (573752 E + 48500 V) flop per iteration x iterations / step time (whole step, all kernels)'},
+                         'kernels': neural_kernel_rooflines(native, timing, E, V, args.hidden),
+                         'note': 'achieved = (573752 E + 48500 V) flop per iteration x iterations / step time (whole step, all kernels); '
+                                 'kernels: HIP events of the library around every launch, flop = the MACs of that kernel x 2'},
             'cpu_baseline': cpu}))
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def secondary_measurements(args, dev, b, prob, native):
+    """Outside the headline's timed loop (rank 0, N = 1): the other hot kernels on the same resident batch, each with the numbers its
+    roofline fraction is computed from -- configs[2]'s neural iteration (3 sweeps), 1 000 Walk-SAT steps, the Reinforce solver's forward."""
+    import torch
+    E, V, F, B = prob.E, prob.V, prob.F, prob.B
+    out = {}
+    # ---- neural: np-nd-np hidden 128, T = 3 on the same graph -------------------------------------------------------------------------
+    try:
+        T = args.secondary_neural_iters
+        saved_hidden = args.hidden
+        tr, model = make_neural_model(args, T)
+        neural_step(tr, model, b, T)                                 # warm-up (workspaces, caching allocator)
+        torch.cuda.synchronize()
+        native.kernel_timing(True)
+        t0 = time.perf_counter()
+        it = neural_step(tr, model, b, T)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        timing = native.kernel_timing_read(); native.kernel_timing(False)
+        flops_iter = 573752.0 * E + 48500.0 * V
+        tf = flops_iter * it / dt / 1e12
+        out['neural'] = dict(workload="configs[2]: 'np-nd-np' hidden_dim=%d on the same batch, T=%d, seeded random-init weights" % (saved_hidden, T),
+                             iterations=it, seconds=dt, iterations_per_sec=it / dt, flop_per_iteration=flops_iter,
+                             roofline=dict(bound='mfma', achieved=tf, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s', frac=tf / MFMA_F32_PEAK_TFLOPS),
+                             kernels=neural_kernel_rooflines(native, timing, E, V, saved_hidden),
+                             note='per-kernel ms: HIP events recorded by the library on the launch stream around every launch (pdp_kernel_timing); '
+                                  'flop per launch = MACs of that kernel (SURVEY.md 8(d)) x 2; peak = fp32-input MFMA')
+        del tr, model
+        torch.cuda.empty_cache()
+    except Exception as ex:                                            # a secondary measurement never costs the headline line
+        out['neural'] = dict(error=repr(ex))
+    # ---- Walk-SAT: 1 000 steps, Philox numbers on the device ----------------------------------------------------------------------------
+    try:
+        steps_req = args.secondary_walksat_steps
+        prob.random_fill(seed=4321)
+        start = prob.solution.clone()
+        prob.local_search(start, 10, 0.5, seed=5)                     # warm-up
+        torch.cuda.synchronize()
+        native.kernel_timing(True)
+        t0 = time.perf_counter()
+        res, steps = prob.local_search(start, steps_req, 0.5, seed=999)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        timing = native.kernel_timing_read(); native.kernel_timing(False)
+        kms, kn = timing['walksat']
+        pred = prob.update_solution(res.reshape(-1).contiguous())
+        solved, unsat = prob.cnf_eval(pred.reshape(-1).contiguous())
+        bytes_step = 13.0 * E + 8.0 * V                                # SURVEY.md 8(d): one full re-evaluation step of the non-incremental form
+        ach = bytes_step * steps / (kms * 1e-3) / 1e9 if kms > 0 else None
+        out['walksat'] = dict(workload='%d Walk-SAT steps (epsilon 0.5, Philox) on the headline batch from the random fill' % steps_req,
+                              steps=steps, call_seconds=dt, kernel='k_walksat_lds', kernel_ms=kms, kernel_launches=kn,
+                              steps_per_sec=steps / dt, instance_steps_per_sec=steps * B / dt,
+                              solved_fraction=float(solved.sum().item()) / B, unsat_clauses_total=float(unsat.sum().item()),
+                              roofline=dict(bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s', frac=(ach / HBM_PEAK_GBS) if ach else None,
+                                            note='streaming model 13 E + 8 V bytes per step x steps / kernel time; the kernel is LDS-resident '
+                                                 'and incremental (it touches O(degree) words per flip), so this is the fraction of what a '
+                                                 'perfect full-re-evaluation implementation could do, like the headline kernel\'s'))
+    except Exception as ex:
+        out['walksat'] = dict(error=repr(ex))
+    # ---- Reinforce solver: the persistent kernel's other instantiation --------------------------------------------------------------------
+    try:
+        T = args.iters
+        L = native.lib()
+        q = torch.empty(E, 3, device=dev); fs = torch.empty(E, 2, device=dev)
+        am = torch.empty(B, dtype=torch.uint8, device=dev)
+        dec = native.Decimator(prob)
+        g = torch.Generator(device='cpu'); g.manual_seed(77)
+        coins = torch.rand(T, generator=g).to(dev)
+        runs = []
+        for rep in range(3):
+            native.check(L.pdp_problem_bind_state(prob._h, native.ptr(prob.active_variables), native.ptr(prob.active_functions),
+                                                  native.ptr(prob.solution), native.ptr(prob.is_sat), native.ptr(prob.edge_mask), native._stream()))
+            q.fill_(1.0); q.div_(3.0); fs.zero_(); fs[:, 0] = 0.5; am.fill_(1); dec.reset()
+            prob.simplify()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            it, lds = prob.sp_solve(q, fs, am, dec, T, 0.01, 0.0, pi=0.1, model=native.MODEL_REINFORCE, coins=coins, decimation_probability=0.5,
+                                    time_kernels=True)
+            torch.cuda.synchronize()
+            runs.append((time.perf_counter() - t0, it, lds, dict(prob.last_solve_stats)))
+        dt, it, lds, st = runs[-1]
+        per_launch = st['solve_kernel_ms'] / max(1, st['launches'])
+        bytes_launch = algorithmic_bytes_per_iteration(E, V, F) * it / max(1, st['launches'])
+        ach = bytes_launch / (per_launch * 1e-3) / 1e9
+        out['reinforce'] = dict(workload="'reinforce' (pi 0.1, decimation probability 0.5) on the headline batch, T=%d, the persistent loop" % T,
+                                iterations=it, call_seconds=dt, iterations_per_sec=it / dt, path='persistent-lds' if lds else 'persistent-hbm',
+                                kernel='k_sp_solve_lds<true, false, true>', kernel_launches=st['launches'], kernel_ms_per_launch=per_launch,
+                                replay_launches=st['replays'], replay_ms=st['replay_kernel_ms'],
+                                roofline=dict(bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS,
+                                              note='streaming-model bytes (41E+36V+8F per iteration) x iterations per launch / launch time'))
+    except native.SpeculationFailed as ex:
+        out['reinforce'] = dict(error='speculation failed: %s' % ex)
+    except Exception as ex:
+        out['reinforce'] = dict(error=repr(ex))
+    return out
+
+
+def solved_fractions(args, dev, b, native, rank):
+    """The metric's "(and solved %)": the whole forward (simplify, T sweeps, random fill, w Walk-SAT steps, Philox numbers) at the headline
+    setting and at a longer one, with the reference's batch-wide semantics and with isolated instances.  Untimed."""
+    import logging
+    import torch
+    from pdp.trainer import SatFactorGraphTrainer
+    out = {}
+    gm, bvm, bfm, ef = b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature']
+    for name, T, w, iso in (('T%d_w%d_reference_semantics' % (args.iters, args.walksat), args.iters, args.walksat, False),
+                            ('T1000_w1000_reference_semantics', 1000, 1000, False), ('T1000_w1000_isolated_instances', 1000, 1000, True)):
+        try:
+            tr = SatFactorGraphTrainer(dict(model_type='p-d-p', model_name='bench', verbose=False, local_search_iteration=w, epsilon=0.5,
+                                            tolerance=args.tolerance, t_max=args.t_max, rng='philox', random_seed=12345 + rank, hidden_dim=3,
+                                            isolated=iso, test_batch_limit=1 << 62, batch_size=args.batch, test_recurrence_num=T),
+                                       use_cuda=True, logger=logging.getLogger('bench'))
+            m = tr._model_list[0]
+            with torch.no_grad():
+                st = m.get_init_state(gm, bvm, bfm, ef, None, randomized=False, batch_replication=1)
+                pred, _ = m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None,
+                            is_training=False, iteration_num=T, check_termination=tr._check_recurrence_termination, batch_replication=1)
+                solved, unsat = tr._cnf_evaluator(pred[0], gm, bvm, bfm, ef, None, sat_problem=m._last_problem)
+            out[name] = dict(solved=int(solved.sum().item()), instances=int(solved.numel()), solved_fraction=float(solved.mean().item()),
+                             unsat_clauses_total=float(unsat.sum().item()), iterations=m.last_run['iterations'], path=m.last_run['path'])
+        except Exception as ex:
+            out[name] = dict(error=repr(ex))
+    return out
 
 
 def main():
@@ -172,25 +523,38 @@ def main():
                     help="sp: configs[1] (headline metric); neural: configs[2] 'np-nd-np' hidden_dim=128 on the same graph (fp32 MFMA)")
     ap.add_argument('--hidden', type=int, default=128)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip config.secondary (neural / Walk-SAT / Reinforce) and the long solved-fraction runs')
     ap.add_argument('--isolated', action='store_true', help="sp workload: every instance solved on its own (no batch-wide couplings of the "
                     "reference, hence no NaN-poison replay); the default is the reference's strict semantics")
     ap.add_argument('--seed-rank', type=int, default=None, help='generate the batch another rank would get (checks of the sharded run on one GPU)')
-    ap.add_argument('--cpu-sample-batch', type=int, default=1000)
-    ap.add_argument('--cpu-sample-iters', type=int, default=100)
+    ap.add_argument('--cpu-sample-batch', type=int, default=1000, help='CPU baseline without --cpu-full-batch: instances of the sample')
+    ap.add_argument('--cpu-cores', type=int, default=0, help='cap the CPU baselines at this many cores (0: all)')
+    ap.add_argument('--cpu-partial-batch', dest='cpu_full_batch', action='store_false', help='CPU baselines on --cpu-sample-batch instances only')
+    ap.add_argument('--secondary-neural-iters', type=int, default=3)
+    ap.add_argument('--secondary-walksat-steps', type=int, default=1000)
+    ap.add_argument('--selftest-collective', action='store_true', help='the N-rank plumbing only (no GPU work); used by the gloo test')
     args = ap.parse_args()
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    backend = os.environ.get('PDP_DIST_BACKEND', 'nccl')    # gloo: several ranks on one GPU (checks of the N > 1 code on a single-GPU box)
-    if world > 1:
-        import torch.distributed as dist
-        local_rank = local_rank % max(1, torch.cuda.device_count()) if backend != 'nccl' else local_rank
-        torch.cuda.set_device(local_rank)
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-        else:
-            dist.init_process_group(backend)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.selftest_collective:
+        return selftest_collective(args)
+
+    world_env, rank_env = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    m = int(round(4.2 * args.n))
+    from pdp.factorgraph import dataset
+    items = None
+    cpu, cpu_ts = None, None
+    if args.workload == 'sp':
+        items = dataset.random_ksat_items(args.batch, args.n, 3, m=m, seed=1000003 * (rank_env if args.seed_rank is None else args.seed_rank))
+        if world_env == 1 and not args.no_cpu_baseline:
+            # before anything initialises the GPU in this process: the oracle workers are forked
+            cpu = cpu_baseline_all_cores(args, items)
+            cpu_ts = cpu_baseline_torch_sparse(args, items)
+
+    import torch
+    from pdp import native
+    world, rank, local_rank, backend = init_ranks(args)
     native.require_gpu()
     dev = torch.device('cuda', local_rank if world > 1 else 0)
     args.coll_dev = dev if backend == 'nccl' else torch.device('cpu')
@@ -199,8 +563,6 @@ def main():
         return bench_neural(args, dev, rank, world)
 
     # ---- synthetic batch, resident in HBM before the timed region ---------------------------------------------
-    m = int(round(4.2 * args.n))
-    items = dataset.random_ksat_items(args.batch, args.n, 3, m=m, seed=1000003 * (rank if args.seed_rank is None else args.seed_rank))
     host_batch = dataset.collate_segment(items)
     torch.cuda.synchronize(); t_setup = time.perf_counter()
     b = dataset.to_torch(host_batch, dev)                      # PCIe upload of the loader tensors
@@ -254,12 +616,14 @@ def main():
     solved, unsat = prob.cnf_eval(pred.reshape(-1).contiguous())
     stats = torch.tensor([float(B), float(solved.sum().item()), float(unsat.sum().item()), elapsed, total_iters],
                          dtype=torch.float64, device=args.coll_dev)
+    ranks = 1
     if world > 1:
         import torch.distributed as dist
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=args.coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)       # the only collective of the path: a 40-byte sum over xGMI
+        ranks = dist.get_world_size()
     n_inst, n_solved, n_unsat, _, iters_all = [float(x) for x in stats.tolist()]
 
     if rank == 0:
@@ -276,44 +640,52 @@ def main():
         replay_ms = float(np.mean([l['replay_kernel_ms'] for l in launches]))
         bytes_launch = algorithmic_bytes_per_iteration(E, V, F) * it_mean / n_launch
         achieved = bytes_launch / (launch_ms * 1e-3) / 1e9
-        # measured HBM traffic per launch (rocprofv3 PMC passes, corrected as MI355X_MICROARCH.md prescribes), if profiled
-        traffic, valu = None, None
-        pmc = os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')   # written by tools/summarize_profile.py
-        if os.path.exists(pmc):
+        # measured HBM traffic and VALU instruction count per launch: NOT measured in this run -- read from the committed rocprofv3 PMC
+        # summary of the same kernel and labelled with their source
+        traffic, valu, src = None, None, None
+        pmcs = sorted(f for f in os.listdir(os.path.join(REPO, 'profiles')) if f.endswith('_pmc_traffic.json')) if os.path.isdir(os.path.join(REPO, 'profiles')) else []
+        if pmcs and args.batch == 5000 and args.n == 200:
             try:
-                pj = json.load(open(pmc))
+                src = 'profiles/' + pmcs[-1]
+                pj = json.load(open(os.path.join(REPO, src)))
                 traffic = pj.get('k_sp_solve_lds_bytes_per_launch')
-                if pj.get('SQ_INSTS_VALU_per_launch') and args.batch == 5000 and args.n == 200:
-                    # what actually binds the LDS-resident kernel: wave-level VALU instructions x 4 cycles (one wave64 instruction per SIMD
-                    # every 4 cycles) against the 1024 SIMDs x 2.4 GHz of the chip over the measured launch time
+                if pj.get('SQ_INSTS_VALU_per_launch'):
+                    # what binds the LDS-resident kernel: wave-level VALU instructions against the issue slots of 1024 SIMDs over the measured
+                    # launch time.  A wave64 fp32 instruction occupies its SIMD for 2 cycles when the same wave has an independent instruction
+                    # next and ~4 in a dependent chain (tools/micro/pk_rate.hip: 2.2 / 4.3 measured; MI355X_MICROARCH.md: 2 cycles) -- both given
                     insts = float(pj['SQ_INSTS_VALU_per_launch'])
-                    valu = {'insts_per_launch': insts, 'issue_frac': insts * 4.0 / (1024 * 2.4e9 * launch_ms * 1e-3),
-                            'note': 'SQ_INSTS_VALU (rocprofv3 PMC pass of the same kernel) x 4 cycles / (1024 SIMDs x 2.4 GHz x launch time)'}
+                    cyc = N_SIMD * CLOCK_HZ * launch_ms * 1e-3
+                    valu = {'insts_per_launch': insts, 'cycles_per_inst_per_simd': cyc / insts, 'issue_frac_at_2_cycles': insts * 2.0 / cyc,
+                            'issue_frac_at_4_cycles_dependent_chain': insts * 4.0 / cyc, 'source': src,
+                            'note': 'SQ_INSTS_VALU of a rocprofv3 PMC pass of the same kernel (committed summary, not this run) / (1024 SIMDs x 2.4 GHz x '
+                                    'this run\'s launch time)'}
             except Exception:
                 traffic, valu = None, None
+        config = {'workload': "configs[1]: 'p-d-p' survey propagation, random 3-SAT n=%d m=%d batch=%d T=%d per GPU" % (args.n, m, args.batch, args.iters),
+                  'E': E, 'V': V, 'F': F, 'iterations_per_step': it_mean, 'path': paths[0] if paths else None,
+                  'instance_iterations_per_sec': value * args.batch, 'edge_updates_per_sec': value * 2 * E,
+                  'solve_call_ms': kms, 'kernel_launches_per_call': n_launch, 'kernel_ms_per_launch': launch_ms,
+                  'poison_replay_launches_per_call': n_replay, 'poison_replay_ms_per_call': replay_ms,
+                  'algorithmic_bytes_per_launch': bytes_launch, 'setup_ms_upload_and_layout': setup_ms, 'solved_fraction': n_solved / n_inst, 'unsat_clauses_total': n_unsat,
+                  'walksat_steps': ws_steps, 'tolerance': args.tolerance, 't_max': args.t_max, 'parallelism': 'instances sharded, dp%d' % world,
+                  'semantics': 'isolated instances' if args.isolated else "reference (batch-wide couplings reproduced)"}
+        if world == 1 and not args.no_secondary:
+            config['solved'] = solved_fractions(args, dev, b, native, rank)
+            config['secondary'] = secondary_measurements(args, dev, b, prob, native)
         line = {
             'metric': 'pdp_iterations_per_sec', 'value': value,
             'unit': 'iterations/s (each iteration sweeps a batch of %d instances)' % args.batch,
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'n_gpus': world, 'rccl_ranks': ranks, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': "configs[1]: 'p-d-p' survey propagation, random 3-SAT n=%d m=%d batch=%d T=%d per GPU" % (args.n, m, args.batch, args.iters),
-                       'E': E, 'V': V, 'F': F, 'iterations_per_step': it_mean, 'path': paths[0] if paths else None,
-                       'instance_iterations_per_sec': value * args.batch, 'edge_updates_per_sec': value * 2 * E,
-                       'solve_call_ms': kms, 'kernel_launches_per_call': n_launch, 'kernel_ms_per_launch': launch_ms,
-                       'poison_replay_launches_per_call': n_replay, 'poison_replay_ms_per_call': replay_ms,
-                       'algorithmic_bytes_per_launch': bytes_launch, 'setup_ms_upload_and_layout': setup_ms, 'solved_fraction': n_solved / n_inst, 'unsat_clauses_total': n_unsat,
-                       'walksat_steps': ws_steps, 'tolerance': args.tolerance, 't_max': args.t_max, 'parallelism': 'instances sharded, dp%d' % world,
-                       'semantics': 'isolated instances' if args.isolated else "reference (batch-wide couplings reproduced)"},
+            'config': config,
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'valu_issue': valu, 'kernel': 'k_sp_solve_lds<false, false, false>',
+                         'traffic': traffic, 'traffic_source': src, 'valu_issue': valu, 'kernel': 'k_sp_solve_lds<false, false, false>',
                          'note': 'achieved = streaming-model algorithmic bytes (41E+36V+8F per iteration) x iterations per launch / '
-                                 'average launch duration (HIP events on the launch stream); the instance state is LDS-resident, '
-                                 'so the kernel is bound by VALU issue, not by HBM (DESIGN.md section 4)'},
+                                 'average launch duration (HIP events on the launch stream, this run); the instance state is LDS-resident, '
+                                 'so the kernel is bound by VALU issue, not by HBM (DESIGN.md section 4); traffic / valu_issue come from the '
+                                 'committed PMC summary named in their source fields, not from this run'},
+            'cpu_baseline': cpu, 'cpu_baseline_torch_sparse': cpu_ts,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(args)
-        else:
-            line['cpu_baseline'] = None
         print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist

@@ -235,6 +235,20 @@ int pdp_neural_gru(pdp_problem *p, const pdp_gru_desc *d, const float *state, co
 int pdp_neural_predict(pdp_problem *p, const pdp_agg_desc *d, const pdp_head_desc *head, const float *state,
                        const float *edge_mask, float *pred, void *stream);
 
+/* ---- kernel timing (measurement only: bench.py's per-kernel roofline lines) ------------------------------
+ * When enabled, the library brackets the kernels named below with HIP events ON THEIR LAUNCH STREAM (the stream handed to the entry
+ * point); pdp_kernel_timing_read synchronises on the recorded events and returns, per key, the summed device time in ms and the number
+ * of launches since the last read.  No effect on results; off by default. */
+enum { PDP_TK_AGG_PRE = 0,      /* k_agg_pre_wave / k_agg_pre_res / k_agg_pre: first half of a MessageAggregator (two layers per edge) */
+       PDP_TK_ROW_SUM = 1,      /* k_row_sum: per-row sum of the pre-transformed edges */
+       PDP_TK_AGG_POST = 2,     /* k_agg_post_pf / k_agg_post_res / k_agg_post: second half (two layers per edge, masked blend) */
+       PDP_TK_GRU = 3,          /* k_gru_pipe / k_gru_window / k_gru */
+       PDP_TK_PREDICT_HEAD = 4, /* k_predict_rows: per-variable layers + perceptron head of NeuralPredictor */
+       PDP_TK_WALKSAT = 5,      /* k_walksat_lds: the persistent Walk-SAT launch(es) of pdp_local_search */
+       PDP_TK_COUNT = 6 };
+int pdp_kernel_timing(int enable);
+int pdp_kernel_timing_read(float *ms_host /*[PDP_TK_COUNT]*/, int32_t *launches_host /*[PDP_TK_COUNT]*/);
+
 /* ---- math probes (tests: device exp/log must equal the host header bit for bit) ---------------------- */
 int pdp_math_apply(int fn, const float *x, float *y, int64_t n, void *stream);
 

@@ -26,6 +26,15 @@ void pdp_set_error(const char *fmt, ...);
 int pdp_dev_alloc(void **out, size_t bytes);
 void pdp_dev_free(void *ptr);
 
+// ---- optional kernel timing (pdp_kernel_timing, pdp_problem.hip): events on the launch stream around a scope ------------------------
+void pdp_timing_mark(int key, hipStream_t st, bool begin);
+extern int g_pdp_timing_on;
+struct pdp_timed_scope {
+    int key; hipStream_t st;
+    pdp_timed_scope(int k, hipStream_t s) : key(k), st(s) { if (g_pdp_timing_on) pdp_timing_mark(key, st, true); }
+    ~pdp_timed_scope() { if (g_pdp_timing_on) pdp_timing_mark(key, st, false); }
+};
+
 #define PDP_HIP_CHECK(expr)                                                                      \
     do {                                                                                         \
         hipError_t _e = (expr);                                                                  \

@@ -1065,6 +1065,7 @@ static int persistent_grid()
 // aggregator pre-transform: wave-private form (default); resident-weight persistent form when both matrices and the tile fit the LDS, tile-per-workgroup form otherwise
 static int launch_agg_pre(int E, const float *state, const float *sign, const float *edge_mask, const AggW &w, float *h2, hipStream_t st)
 {
+    pdp_timed_scope timed(PDP_TK_AGG_PRE, st);
     const int tiles = (E + TM - 1) / TM;
     const size_t lds1 = sizeof(float) * (size_t)TM * ((w.Kp1 + 1) + (w.Np1 + 1));
     const size_t res1 = sizeof(float) * ((size_t)w.Kp1 * w.Np1 + (size_t)w.Kp2 * w.Np2) + lds1;
@@ -1113,13 +1114,15 @@ extern "C" int pdp_neural_aggregate_edges(pdp_problem *p, const pdp_agg_desc *d,
     // global CSR rows in ascending edge id: the sorted edge lists of the problem (global ids)
     const int32_t *row_ptr = by_variable ? p->nv_ptr : p->nf_ptr;
     const int32_t *row_edges = by_variable ? p->nv_edges : p->nf_edges;
-    hipLaunchKernelGGL(k_row_sum, dim3((unsigned)(((int64_t)R * w.a + 255) / 256)), dim3(256), 0, st, R, w.a, row_ptr, row_edges, h2, agg);
+    { pdp_timed_scope timed(PDP_TK_ROW_SUM, st);
+      hipLaunchKernelGGL(k_row_sum, dim3((unsigned)(((int64_t)R * w.a + 255) / 256)), dim3(256), 0, st, R, w.a, row_ptr, row_edges, h2, agg); }
     const int32_t *edge_row = by_variable ? p->graph_map : p->graph_map + E;
     const size_t res3 = sizeof(float) * ((size_t)w.Kp3 * w.Np3 + (size_t)w.Kp4 * w.Np4) + lds3;
     // the post-transform has little MFMA work per tile and a gather-heavy tile load: three small workgroups per CU (tile-per-workgroup
     // form) overlap better than one resident one (12.8 vs 18.3 ms at config 3), so the resident form is opt-in
     const bool post_res = getenv("PDP_NEURAL_POST_RESIDENT") != nullptr;
     const bool post_plain = getenv("PDP_NEURAL_POST_PLAIN") != nullptr;
+    pdp_timed_scope timed_post(PDP_TK_AGG_POST, st);
     if (!post_res && !post_plain && w.Kp3 == 52 && w.Np3 == 128 && w.Kp4 == 100 && ((w.Np4 == 128 && w.out == 128) || (w.Np4 == 160 && w.out == 150))) {
         // hidden 128 (BASELINE configs) or 150 (the reference's shipped predict config) with the 100 / 50 inner widths
         const size_t ldsp = sizeof(float) * (size_t)TM * (53 + 129);
@@ -1158,6 +1161,7 @@ extern "C" int pdp_neural_gru(pdp_problem *p, const pdp_gru_desc *d, const float
     PDP_REQUIRE(g.Kpx <= 64 * PRE_C && g.Kph <= 64 * PRE_C, "GRU wider than 192 inputs is not supported by the tile prefetch");
     int s = set_lds((const void *)k_gru, lds); if (s != PDP_OK) return s;
     hipLaunchKernelGGL(k_edge_active, dim3(1024), dim3(256), 0, st, E, p->graph_map, p->var_inst, active_mask, rowmask);
+    pdp_timed_scope timed(PDP_TK_GRU, st);
     const bool plain = getenv("PDP_NEURAL_GRU_PLAIN") != nullptr;
     if (!plain && d->H == 128 && (g.Kpx == 130 || g.Kpx == 4)) {
         // hidden width 128 with a 129-wide input (np-nd-np, config 3) or a 4- / 3-wide one (p-nd-np: surveys + sign): pipelined kernel on
@@ -1219,8 +1223,10 @@ extern "C" int pdp_neural_predict(pdp_problem *p, const pdp_agg_desc *d, const p
     int s = set_lds((const void *)k_agg_pre, lds1); if (s != PDP_OK) return s;
     s = set_lds((const void *)k_predict_rows, lds4); if (s != PDP_OK) return s;
     s = launch_agg_pre(E, state, p->edge_sign, edge_mask, w, h2, st); if (s != PDP_OK) return s;
-    hipLaunchKernelGGL(k_row_sum, dim3((unsigned)(((int64_t)V * w.a + 255) / 256)), dim3(256), 0, st, V, w.a, p->nv_ptr, p->nv_edges, h2, agg);
-    hipLaunchKernelGGL(k_predict_rows, dim3((V + TM - 1) / TM), dim3(NTN), lds4, st, V, agg, w, h, pred);
+    { pdp_timed_scope timed(PDP_TK_ROW_SUM, st);
+      hipLaunchKernelGGL(k_row_sum, dim3((unsigned)(((int64_t)V * w.a + 255) / 256)), dim3(256), 0, st, V, w.a, p->nv_ptr, p->nv_edges, h2, agg); }
+    { pdp_timed_scope timed(PDP_TK_PREDICT_HEAD, st);
+      hipLaunchKernelGGL(k_predict_rows, dim3((V + TM - 1) / TM), dim3(NTN), lds4, st, V, agg, w, h, pred); }
     PDP_LAUNCH_CHECK();
     return PDP_OK;
 }

@@ -36,6 +36,60 @@ extern "C" int pdp_device_count(void)
     return n;
 }
 
+// ---- kernel timing (measurement only) -------------------------------------------------------------------------------------
+int g_pdp_timing_on = 0;
+namespace {
+struct TimedSpan { int key; hipEvent_t e0, e1; bool closed; };
+std::mutex g_timing_mu;
+std::vector<TimedSpan> g_spans;
+std::vector<hipEvent_t> g_event_pool;
+hipEvent_t timing_event()
+{
+    if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+}
+void pdp_timing_mark(int key, hipStream_t st, bool begin)
+{
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    if (begin) {
+        TimedSpan s; s.key = key; s.e0 = timing_event(); s.e1 = timing_event(); s.closed = false;
+        if (!s.e0 || !s.e1) return;
+        (void)hipEventRecord(s.e0, st);
+        g_spans.push_back(s);
+    } else {
+        for (size_t i = g_spans.size(); i-- > 0;)
+            if (g_spans[i].key == key && !g_spans[i].closed) { (void)hipEventRecord(g_spans[i].e1, st); g_spans[i].closed = true; break; }
+    }
+}
+extern "C" int pdp_kernel_timing(int enable)
+{
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    for (auto &s : g_spans) { g_event_pool.push_back(s.e0); g_event_pool.push_back(s.e1); }
+    g_spans.clear();
+    g_pdp_timing_on = enable ? 1 : 0;
+    return PDP_OK;
+}
+extern "C" int pdp_kernel_timing_read(float *ms_host, int32_t *launches_host)
+{
+    PDP_REQUIRE(ms_host && launches_host, "NULL argument");
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    for (int k = 0; k < PDP_TK_COUNT; ++k) { ms_host[k] = 0.0f; launches_host[k] = 0; }
+    for (auto &s : g_spans) {
+        if (s.closed && s.key >= 0 && s.key < PDP_TK_COUNT) {
+            PDP_HIP_CHECK(hipEventSynchronize(s.e1));
+            float ms = 0.0f;
+            PDP_HIP_CHECK(hipEventElapsedTime(&ms, s.e0, s.e1));
+            ms_host[s.key] += ms; launches_host[s.key] += 1;
+        }
+        g_event_pool.push_back(s.e0); g_event_pool.push_back(s.e1);
+    }
+    g_spans.clear();
+    return PDP_OK;
+}
+
 // ---- kernels -----------------------------------------------------------------------------------------
 __global__ void k_replicate(int E0, int V0, int F0, int B0, int R, const int32_t *gm, const int32_t *bvm,
                             const int32_t *bfm, const float *ef, int32_t *ogm, int32_t *ovi, int32_t *ofi,

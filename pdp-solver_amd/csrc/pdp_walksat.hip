@@ -500,7 +500,8 @@ static int local_search_persistent(pdp_problem *p, const float *pred, int iterat
     wp.inst_list = nullptr; wp.cap_b = nullptr;
     int ws_nt = 256;
     if (const char *env = getenv("PDP_WALKSAT_THREADS")) { const int v = atoi(env); if (v == 64 || v == 128 || v == 256) ws_nt = v; }
-    hipLaunchKernelGGL(k_walksat_lds, dim3(p->B), dim3(ws_nt), lds, st, make_view(p), wp);
+    { pdp_timed_scope timed(PDP_TK_WALKSAT, st);
+      hipLaunchKernelGGL(k_walksat_lds, dim3(p->B), dim3(ws_nt), lds, st, make_view(p), wp); }
     PDP_LAUNCH_CHECK();
     uint32_t *ctl = spec + 2 * bw;                       // [0] global stop step, [1] replay count
     hipLaunchKernelGGL(k_ws_group_stop, dim3((p->B0 + 255) / 256), dim3(256), 0, st, p->B0, p->R, iterations, first_sat, ctl);

@@ -27,6 +27,7 @@ EXPORTED_SYMBOLS = [
     'pdp_sequential_decimate_apply', 'pdp_reinforce_decimate', 'pdp_reinforce_predict', 'pdp_energy',
     'pdp_energy_diff', 'pdp_random_fill', 'pdp_local_search', 'pdp_deduplicate', 'pdp_sp_solve', 'pdp_math_apply',
     'pdp_neural_aggregate_edges', 'pdp_neural_gru', 'pdp_neural_predict', 'pdp_dimacs_open', 'pdp_dimacs_read', 'pdp_dimacs_close', 'pdp_dimacs_open_many',
+    'pdp_kernel_timing', 'pdp_kernel_timing_read',
 ]
 
 
@@ -465,6 +466,21 @@ def dimacs_parse_many(paths, threads=8):
             if handles[i]:
                 lib().pdp_dimacs_close(C.c_void_p(handles[i]))
     return out
+
+
+TIMING_KEYS = ('agg_pre', 'row_sum', 'agg_post', 'gru', 'predict_head', 'walksat')       # include/pdp_hip.h: PDP_TK_*
+
+
+def kernel_timing(enable):
+    "bracket the library's neural / Walk-SAT kernels with HIP events on their launch stream (measurement only)"
+    check(lib().pdp_kernel_timing(C.c_int(1 if enable else 0)))
+
+
+def kernel_timing_read():
+    "{key: (summed device ms, launches)} since the last read; synchronises on the recorded events"
+    ms = (C.c_float * len(TIMING_KEYS))(); n = (C.c_int32 * len(TIMING_KEYS))()
+    check(lib().pdp_kernel_timing_read(ms, n))
+    return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(TIMING_KEYS)}
 
 
 def math_apply(fn, x):

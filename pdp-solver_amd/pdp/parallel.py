@@ -26,14 +26,15 @@ def shard_bounds(edge_counts, world_size):
     total = int(csum[-1])
     bounds, lo = [], 0
     for r in range(world_size):
-        if r == world_size - 1:
+        later_ranks = world_size - 1 - r
+        if later_ranks == 0:
             hi = n
         else:
-            target = total * (r + 1) / float(world_size)
-            hi = int(np.searchsorted(csum, target, side='left')) + 1
-            hi = max(hi, lo + (1 if lo < n else 0))
-            hi = min(hi, n - min(n - hi, world_size - 1 - r) if n - hi < world_size - 1 - r else hi)
-            hi = min(hi, n)
+            # smallest prefix whose edge count reaches this rank's share of the total ...
+            hi = int(np.searchsorted(csum, total * (r + 1) / float(world_size), side='left')) + 1
+            # ... but at least one instance while instances remain, and one left over for each later rank when there are enough
+            hi = max(hi, lo + 1)
+            hi = min(hi, max(lo + 1, n - later_ranks), n)
         bounds.append((lo, hi))
         lo = hi
     return bounds

@@ -1,0 +1,59 @@
+"""bench.py on the GPU box: the line's contract fields at N = 1 (with the secondary measurements and both CPU baselines on a small
+workload) and the launcher at N = 2 (two gloo ranks sharing the box's single GPU: RCCL wants one GPU per rank)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from helpers import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def _bench(env_extra, *argv):
+    env = dict(os.environ); env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py')] + list(argv), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       universal_newlines=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.split('\n') if l.startswith('{')]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_bench_line_small_workload():
+    line = _bench({}, '--steps', '2', '--warmup', '1', '--batch', '600', '--iters', '40', '--cpu-cores', '8', '--secondary-walksat-steps', '200')
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'rccl_ranks', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+              'data', 'config', 'roofline', 'cpu_baseline', 'cpu_baseline_torch_sparse'):
+        assert k in line, k
+    assert line['n_gpus'] == 1 and line['rccl_ranks'] == 1 and line['steps'] == 2 and line['vs_baseline'] is None and line['dtype'] == 'f32'
+    assert line['config']['path'] == 'persistent-lds' and line['config']['iterations_per_step'] == 40
+    rf = line['roofline']
+    assert rf['bound'] == 'hbm' and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-12 and rf['peak'] == 8000.0
+    assert abs(rf['achieved'] - line['config']['algorithmic_bytes_per_launch'] / (line['config']['kernel_ms_per_launch'] * 1e-3) / 1e9) < 1e-6 * rf['achieved']
+    cpu = line['cpu_baseline']
+    assert cpu['kind'] == 'port' and cpu['cores'] == 8 and cpu['value'] > 0 and 'cpu_model' in cpu
+    ts = line['cpu_baseline_torch_sparse']
+    assert ts['runs'] and ts['runs'][0]['B'] == 500 and ts['runs'][0]['seconds_per_iteration'] > 0
+    sec = line['config']['secondary']
+    for name in ('neural', 'walksat', 'reinforce'):
+        assert 'error' not in sec[name], sec[name]
+    nk = sec['neural']['kernels']
+    for key in ('agg_pre', 'agg_post', 'gru', 'predict_head', 'aggregator_call'):
+        assert nk[key].get('ms_per_launch', nk[key].get('ms')) > 0 and 0 < nk[key]['frac_of_mfma_f32_peak'] < 1.0
+    assert nk['gru']['launches'] == 2 * sec['neural']['iterations'] and nk['agg_post']['launches'] == 2 * sec['neural']['iterations']
+    assert sec['walksat']['steps'] > 0 and sec['walksat']['kernel_launches'] >= 1
+    assert sec['reinforce']['path'] == 'persistent-lds' and sec['reinforce']['kernel_ms_per_launch'] > 0
+    for name, row in line['config']['solved'].items():
+        assert 'error' not in row, row
+        assert 0 <= row['solved'] <= row['instances'] == 600
+
+
+def test_bench_launcher_two_ranks_on_one_gpu():
+    line = _bench({'PDP_DIST_BACKEND': 'gloo'}, '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '500', '--iters', '30')
+    assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['scaling'] == 'weak'
+    assert line['cpu_baseline'] is None and 'secondary' not in line['config']
+    one = _bench({}, '--steps', '2', '--warmup', '1', '--batch', '500', '--iters', '30', '--no-cpu-baseline', '--no-secondary')
+    assert one['n_gpus'] == 1 and one['config']['E'] == line['config']['E']          # per-rank batch is fixed: weak scaling
+    assert line['config']['iterations_per_step'] == one['config']['iterations_per_step']

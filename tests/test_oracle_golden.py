@@ -224,3 +224,31 @@ def test_config0_cli_rows(oracle, golden_dir):
         assert r['solved'] == int(solved[i]) and r['unsat_clauses'] == int(unsat[i]), r['ID']
         assert r['solution'] == (res['prediction'][off[i]:off[i + 1]] > 0.5).astype(int).tolist(), r['ID']
     assert sum(r['solved'] for r in rows) == 13
+
+
+def test_torch_sparse_port_equals_oracle(oracle):
+    """bench.py's second CPU baseline -- the PyTorch-CPU restatement of the reference's sparse-mm formulation (oracle/torch_sparse_port.py,
+    SURVEY.md 8(d)(2)) -- runs the same algorithm as the C oracle: identical integer trajectory (active flags, solution, active mask per
+    sweep, decimations included) and messages within the tolerance that separates torch's exp / log from include/pdp_math.h."""
+    import torch
+    from oracle import torch_sparse_port as port
+    from pdp.factorgraph import dataset
+    items = dataset.random_ksat_items(12, 40, 3, m=140, seed=900) + dataset.random_ksat_items(6, 30, 3, m=126, seed=950)
+    b = dataset.collate_segment(items)
+    T = 40
+    p = oracle.Problem(b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'])
+    res = p.forward('p-d-p', T, local_search_iterations=0, tolerance=0.05, t_max=10, seed=1, trace=True, trace_float=True)
+    P = port.SparseBatch(b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'])
+    trace = []
+    with torch.no_grad():
+        q, fs, done = port.forward_loop(P, T, tolerance=0.05, t_max=10, trace=trace)
+    assert done == res['iterations_run'] and done > 10
+    decimated = 0
+    for i, tr in enumerate(trace):
+        np.testing.assert_array_equal(tr['active_var'], res['trace_active_var'][i], err_msg='sweep %d' % i)
+        np.testing.assert_array_equal(tr['active_fn'], res['trace_active_fn'][i])
+        np.testing.assert_array_equal(tr['solution'], res['trace_solution'][i])
+        np.testing.assert_array_equal(tr['active_mask'], res['trace_active_mask'][i])
+        np.testing.assert_allclose(tr['q'], res['trace_q'][i], rtol=5e-4, atol=5e-6)
+        decimated += int(i > 0 and (tr['active_var'] != trace[i - 1]['active_var']).any())
+    assert decimated >= 3                       # the comparison covered decimation events (scorer, arg-max, set_variables, simplify)

@@ -114,3 +114,38 @@ def test_test_mode_metrics_reduce_over_ranks():
     for rank, sums, n, mean, total in got:
         assert total == 10
         np.testing.assert_allclose(mean, exp, rtol=1e-12)
+
+
+def test_shard_bounds_small_inputs():
+    assert parallel.shard_bounds([5, 5], 3) == [(0, 1), (1, 2), (2, 2)]           # fewer instances than ranks: the first ranks get one each
+    assert parallel.shard_bounds([], 2) == [(0, 0), (0, 0)]
+    assert parallel.shard_bounds([1, 1, 1, 100], 2) == [(0, 3), (3, 4)]             # one heavy instance at the end still leaves the last rank one
+    assert parallel.shard_bounds([100, 1, 1, 1], 2) == [(0, 1), (1, 4)]
+    assert parallel.shard_bounds([10] * 8, 8) == [(i, i + 1) for i in range(8)]
+
+
+def _run_bench(extra_env, *argv):
+    import subprocess
+    env = dict(os.environ); env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(REPO, 'bench.py')] + list(argv), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          universal_newlines=True, env=env, timeout=600)
+
+
+def test_bench_launcher_starts_the_ranks_it_is_asked_for():
+    """`python bench.py --gpus 2` outside torch.distributed.run is a launcher: it starts 2 ranks through torch.distributed.run (gloo here:
+    no GPU in the CPU suite, --selftest-collective skips the device work but runs the rendezvous, the barrier, the MAX / SUM reductions
+    and rank 0's single line), forwards one JSON line with n_gpus == rccl_ranks == 2, and fails when a rank fails."""
+    import json
+    r = _run_bench({'PDP_DIST_BACKEND': 'gloo'}, '--gpus', '2', '--steps', '4', '--warmup', '1', '--selftest-collective')
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.split('\n') if l.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['steps'] == 4 and line['warmup'] == 1
+    assert line['instances'] == 2000.0 and line['rank_sum'] == 3.0 and abs(line['max_elapsed_s'] - 0.02) < 1e-12     # SUM over ranks, MAX of the times
+    assert abs(line['value'] - 2 * 400.0 / 0.02) < 1e-6                                                                # whole-job aggregate / max time
+    bad = _run_bench({'PDP_DIST_BACKEND': 'gloo', 'PDP_BENCH_FAIL_RANK': '1'}, '--gpus', '2', '--selftest-collective')
+    assert bad.returncode != 0 and not [l for l in bad.stdout.split('\n') if l.startswith('{')]
+    # a rank count that does not match --gpus is refused, not silently run as one rank
+    mism = _run_bench({'WORLD_SIZE': '1', 'RANK': '0'}, '--gpus', '2', '--selftest-collective')
+    assert mism.returncode != 0 and 'WORLD_SIZE' in (mism.stderr + mism.stdout)
