@@ -133,6 +133,32 @@ def _oracle_worker(job):
     return (hi - lo) * res['iterations_run']
 
 
+def effective_cores():
+    """host cores this process may really use: min(os.cpu_count(), the scheduler affinity mask, the cgroup CPU quota).  On the GPU boxes of
+    this pool os.cpu_count() reports every hardware thread of the host (256) while the container's quota is far smaller; worker pools and
+    torch thread counts sized by cpu_count() then oversubscribe and run many times slower than one thread per usable core."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]                      # cgroup v2
+        if q != 'max':
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read()); per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota + 0.5)))
+    return max(1, n)
+
+
 def cpu_model_name():
     try:
         for l in open('/proc/cpuinfo'):
@@ -152,7 +178,7 @@ def cpu_baseline_all_cores(args, items):
     sys.path.insert(0, REPO)
     from oracle import binding
     binding.build()
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     if args.cpu_cores:
         cores = min(cores, args.cpu_cores)
     B = len(items) if args.cpu_full_batch else min(len(items), args.cpu_sample_batch)
@@ -169,10 +195,10 @@ def cpu_baseline_all_cores(args, items):
     _CPU_ITEMS = None
     inst_iters = float(sum(done)) / dt
     return dict(value=inst_iters / args.batch, unit='iterations/s (batch of %d instances)' % args.batch, cores=workers, kind='port',
-                cpu_model=cpu_model_name(),
-                sample='the oracle on %d worker processes (one per host core), %d instances x %d iterations of the headline batch in %.2f s '
-                       '(%.0f instance-iterations/s)%s' % (workers, B, args.iters, dt, inst_iters,
-                                                           '' if B == args.batch else ', scaled linearly to the batch'))
+                cpu_model=cpu_model_name(), host_hardware_threads=os.cpu_count(),
+                sample='the oracle on %d worker processes (one per usable host core: min of cpu_count %d, affinity, cgroup quota), %d instances x '
+                       '%d iterations of the headline batch in %.2f s (%.0f instance-iterations/s)%s'
+                       % (workers, os.cpu_count() or 1, B, args.iters, dt, inst_iters, '' if B == args.batch else ', scaled linearly to the batch'))
 
 
 def cpu_baseline_torch_sparse(args, items):
@@ -185,7 +211,7 @@ def cpu_baseline_torch_sparse(args, items):
     sys.path.insert(0, REPO)
     from oracle import torch_sparse_port as port
     from pdp.factorgraph import dataset
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     if args.cpu_cores:
         cores = min(cores, args.cpu_cores)
     torch.set_num_threads(cores)
@@ -213,7 +239,10 @@ def cpu_baseline_torch_sparse(args, items):
             P.simplify()
             setup = time.perf_counter() - t0
             times = []
-            port.forward_loop(P, T, tolerance=args.tolerance, t_max=args.t_max, simplify=False, times=times)
+            # the full batch stops after the first iteration when set-up + that iteration exceed the budget of the default run (the
+            # steady-state iterations add the convergence test: two more dense [V x B] reductions each)
+            port.forward_loop(P, T, tolerance=args.tolerance, t_max=args.t_max, simplify=False, times=times,
+                              max_seconds=None if B <= 500 else max(0.0, args.cpu_torch_budget_s - setup))
         steady = times[1:] if len(times) > 1 else times
         per_iter = float(np.mean(steady))
         out['runs'].append(dict(B=B, iterations=len(times), seconds_per_iteration=per_iter, first_iteration_s=times[0], setup_s=setup,
@@ -530,6 +559,8 @@ def main():
     ap.add_argument('--cpu-sample-batch', type=int, default=1000, help='CPU baseline without --cpu-full-batch: instances of the sample')
     ap.add_argument('--cpu-cores', type=int, default=0, help='cap the CPU baselines at this many cores (0: all)')
     ap.add_argument('--cpu-partial-batch', dest='cpu_full_batch', action='store_false', help='CPU baselines on --cpu-sample-batch instances only')
+    ap.add_argument('--cpu-torch-budget-s', type=float, default=25.0, help='torch sparse-mm baseline at the full batch: run the steady-state '
+                    'iterations only if set-up + first iteration took less than this many seconds')
     ap.add_argument('--secondary-neural-iters', type=int, default=3)
     ap.add_argument('--secondary-walksat-steps', type=int, default=1000)
     ap.add_argument('--selftest-collective', action='store_true', help='the N-rank plumbing only (no GPU work); used by the gloo test')

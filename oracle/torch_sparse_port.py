@@ -221,9 +221,10 @@ def cnf_solved(P, pred):
     return (total == got).float(), total - got
 
 
-def forward_loop(P, T, tolerance=0.02, t_max=100, simplify=True, trace=None, times=None):
+def forward_loop(P, T, tolerance=0.02, t_max=100, simplify=True, trace=None, times=None, max_seconds=None):
     """p-d-p: simplify + T iterations of propagate / decimate / refresh / predict / terminate from the deterministic initial state.
-    `times` (a list) receives the wall seconds of every iteration (the first one has no previous survey: no convergence test)."""
+    `times` (a list) receives the wall seconds of every iteration (the first one has no previous survey: no convergence test);
+    with `max_seconds` the loop stops once the iterations run so far took longer than that (bounded CPU baseline)."""
     import time
     if simplify:
         P.simplify()
@@ -253,5 +254,7 @@ def forward_loop(P, T, tolerance=0.02, t_max=100, simplify=True, trace=None, tim
             trace.append(dict(active_var=P.active_var[:, 0].clone().numpy(), active_fn=P.active_fn[:, 0].clone().numpy(),
                               solution=P.solution.clone().numpy(), active_mask=active[:, 0].clone().numpy(), q=q.clone().numpy()))
         if active.sum() <= 0:
+            break
+        if max_seconds is not None and times is not None and sum(times) > max_seconds:
             break
     return q, fs, done

@@ -24,7 +24,7 @@ for f in find('*kernel_stats.csv'):
                                                                 r.get('AverageNs'), r.get('Percentage')))
 print()
 print("== PMC counters per kernel (sum over dispatches / dispatches) ==")
-for d in ('pmc1', 'pmc2', 'pmc3', 'pmc4'):
+for d in ('pmc1', 'pmc2', 'pmc5', 'pmc6', 'pmc7', 'pmc3', 'pmc4'):
     for f in find('*counter_collection.csv'):
         if '/%s/' % d not in f:
             continue
