@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(LDS ? 512 : 256) k_sp_solve(PView pv, SolvePar
 // =====================================================================================================================
 struct LView {   // what the shared simplification routines see: "edge id" == slot
     int b, n, m, e;
-    struct EVar { const uint16_t *pv; __device__ __forceinline__ int operator[](int p) const { return pv[p] & 0x3fff; } } e_var;
+    struct EVar { const uint16_t *pv; int mask; __device__ __forceinline__ int operator[](int p) const { return pv[p] & mask; } } e_var;   // mask 0x3fff; 0x1fff when bits 13-14 hold the Reinforce force
     struct EFn { const uint16_t *pc; __device__ __forceinline__ int operator[](int p) const { return pc[p] & 0x3fff; } } e_fn;
     struct Sgn { const uint16_t *pv; __device__ __forceinline__ int operator[](int p) const { return (pv[p] & 0x8000) ? -1 : 1; } } sgn;
     struct Iden { __device__ __forceinline__ int operator[](int k) const { return k; } } v_edges;
@@ -426,6 +426,15 @@ struct LView {   // what the shared simplification routines see: "edge id" == sl
 };
 
 #define PDP_RED_SMALL 16    /* per-wave reduction slots of the LDS solver (<= 16 waves per workgroup) */
+/* Reinforce triple: the external force of a slot is one of {0, +1, -1, NaN} (initial state 0, then torch.sign of a score) and lives in bits
+ * 13-14 of the slot's variable word, so the instance image stays at five floats per slot and two workgroups still share a CU; the variable
+ * id then has 13 bits (instances of < 8192 variables) */
+#define PV_FRC_SHIFT 13
+#define PV_FRC_MASK 0x6000u
+#define PV_VMASK_RF 0x1fff
+__host__ __device__ __forceinline__ uint32_t frc_enc(float f) { return (f != f) ? 3u : ((f == 1.0f) ? 1u : ((f == -1.0f) ? 2u : 0u)); }
+__device__ __forceinline__ float frc_dec(uint32_t c) { return __uint_as_float((c == 0u) ? 0u : ((c == 1u) ? 0x3f800000u : ((c == 2u) ? 0xbf800000u : 0x7fc00000u))); }
+__device__ __forceinline__ float frc_of(uint16_t pw) { return frc_dec(((uint32_t)pw & PV_FRC_MASK) >> PV_FRC_SHIFT); }
 #define PC_EM 0x8000u      /* current edge mask bit */
 #define PC_EM_USED 0x4000u /* edge mask bit the last propagate used (needed to rebuild q_s / q_dc at exit) */
 
@@ -466,11 +475,11 @@ __device__ __forceinline__ LdsArrays carve_all(unsigned char *cp, int n, int m, 
     L.vord = carve<uint16_t>(cp, n);
     return L;
 }
-__device__ __forceinline__ LView make_lview(const LdsArrays &L, int b, int n, int m, int ne)
+__device__ __forceinline__ LView make_lview(const LdsArrays &L, int b, int n, int m, int ne, int vmask = 0x3fff)
 {
     LView I;
     I.b = b; I.n = n; I.m = m; I.e = ne;
-    I.e_var.pv = L.pvv; I.e_fn.pc = L.pcc; I.sgn.pv = L.pvv; I.f_edges = L.e2p; I.v_ptr = L.v_ptr; I.f_ptr = L.f_ptr;
+    I.e_var.pv = L.pvv; I.e_var.mask = vmask; I.e_fn.pc = L.pcc; I.sgn.pv = L.pvv; I.f_edges = L.e2p; I.v_ptr = L.v_ptr; I.f_ptr = L.f_ptr;
     I.av = L.av; I.af = L.af; I.sol = L.sol;
     return I;
 }
@@ -820,7 +829,7 @@ __device__ __noinline__ int lds_decimate(unsigned char *smem, int b, int n, int 
 // the write-back rebuilds q_s / q_dc of the last sweep, which read the old force.  Returns 1 if a score was NaN.
 __device__ __noinline__ int lds_reinforce_step(unsigned char *smem, int n, int m, int ne, int cur, float pi, int do_force)
 {
-    const LdsArrays L = carve_all(smem, n, m, ne, true);
+    const LdsArrays L = carve_all(smem, n, m, ne, false);
     const int tid = threadIdx.x, nt = blockDim.x;
     int bad = 0;
     if (do_force) {
@@ -838,8 +847,9 @@ __device__ __noinline__ int lds_reinforce_step(unsigned char *smem, int n, int m
             float pos = 0.0f, neg = 0.0f, all = 0.0f;
             for (int p = a; p < bnd; ++p) {
                 const float f = L.Y[p];
-                const bool ng = (L.pvv[p] & 0x8000) != 0;
-                ext = ext + L.FRC[p];
+                const uint16_t pw = L.pvv[p];
+                const bool ng = (pw & 0x8000) != 0;
+                ext = ext + frc_of(pw);
                 pos = pos + (ng ? 0.0f : 1.0f) * f;
                 neg = neg + (ng ? 1.0f : 0.0f) * f;
                 all = all + f;
@@ -847,10 +857,12 @@ __device__ __noinline__ int lds_reinforce_step(unsigned char *smem, int n, int m
             const float sc = lds_score_of(pos, neg, all, ext, Lpi, L0);
             if (sc != sc) bad = 1;
             const float sg = 0.0f + pdp_sign_nan(sc);
-            for (int p = a; p < bnd; ++p) { L.X[p] = L.FRC[p]; L.FRC[p] = sg; }   // mask * sign + (1 - mask) * old with mask == 1 (old is finite here); X keeps the force the last sweep read
+            const uint16_t code = (uint16_t)(frc_enc(sg) << PV_FRC_SHIFT);
+            // mask * sign + (1 - mask) * old with mask == 1 (old is finite here); X keeps the force the last sweep read
+            for (int p = a; p < bnd; ++p) { const uint16_t pw = L.pvv[p]; L.X[p] = frc_of(pw); L.pvv[p] = (uint16_t)((pw & ~PV_FRC_MASK) | code); }
         }
         ext = 0.0f;
-        for (int p = a; p < bnd; ++p) ext = ext + L.FRC[p];
+        for (int p = a; p < bnd; ++p) ext = ext + frc_of(L.pvv[p]);
         const float pred = (ext > 0.0f) ? 1.0f : 0.0f;
         const float av = L.av[v];
         if (av == 1.0f) L.sol[v] = av * pred + (1.0f - av) * L.sol[v];      // only active variables take the prediction (solver.py:395-397)
@@ -858,12 +870,12 @@ __device__ __noinline__ int lds_reinforce_step(unsigned char *smem, int n, int m
     return __syncthreads_or(bad);
 }
 
-template <bool FORCE>
+template <bool FORCE, bool RF = false>
 __device__ __noinline__ int lds_cnf_count(unsigned char *smem, int b, int n, int m, int ne)
 {
     __shared__ int redi3[PDP_RED_SMALL];
-    const LdsArrays L = carve_all(smem, n, m, ne, FORCE);
-    const LView I = make_lview(L, b, n, m, ne);
+    const LdsArrays L = carve_all(smem, n, m, ne, FORCE && !RF);
+    const LView I = make_lview(L, b, n, m, ne, RF ? PV_VMASK_RF : 0x3fff);
     return d_cnf_sat_count(I, L.sol, redi3);
 }
 
@@ -886,7 +898,8 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
     if (REPLAY && (!ctl->do_replay || blockIdx.x >= ctl->replay_count)) return;
     const Inst G = load_inst(pv_, REPLAY ? sp.inst_list[blockIdx.x] : (int)blockIdx.x);
     const int n = G.n, m = G.m, ne = G.e;
-    const LdsArrays L = carve_all(smem, n, m, ne, FORCE);
+    const LdsArrays L = carve_all(smem, n, m, ne, FORCE && !RF);
+    constexpr int VM = RF ? PV_VMASK_RF : 0x3fff;           // variable id of a slot word
     float *const QU = L.QU, *const X = L.X, *const Y = L.Y;
     uint16_t *const pvv = L.pvv, *const pcc = L.pcc;
     const BlobLayout BL = blob_layout(n, m, ne);
@@ -911,14 +924,16 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
             const uint4 *g = reinterpret_cast<const uint4 *>(src);
             for (int i = tid; i < (int)((bytes + 15) >> 4); i += nt) d[i] = g[i];
         };
-        copy16(pvv, stt + BL.pvv, (size_t)ne * 2); copy16(L.e2p, stt + BL.e2p, (size_t)ne * 2);
+        if constexpr (RF) {                                                    // variable word | force code of the slot
+            const uint16_t *spv = reinterpret_cast<const uint16_t *>(stt + BL.pvv);
+            for (int p = tid; p < ne; p += nt) pvv[p] = (uint16_t)(spv[p] | (frc_enc(sp.frc_in[G.e0 + p]) << PV_FRC_SHIFT));
+        } else copy16(pvv, stt + BL.pvv, (size_t)ne * 2);
+        copy16(L.e2p, stt + BL.e2p, (size_t)ne * 2);
         copy16(L.v_ptr, stt + BL.vptr, (size_t)(n + 1) * 2); copy16(L.f_ptr, stt + BL.fptr, (size_t)(m + 1) * 2);
         copy16(L.vord, stt + BL.vord, (size_t)n * 2);
         copy16(QU, din + BL.QU, (size_t)ne * 4); copy16(L.EA, din + BL.E, (size_t)ne * 4); copy16(pcc, din + BL.pcc, (size_t)ne * 2);
         copy16(L.af, din + BL.af, (size_t)m * 4); copy16(L.av, din + BL.av, (size_t)n * 4); copy16(L.sol, din + BL.sol, (size_t)n * 4);
-        if constexpr (RF) {
-            for (int p = tid; p < ne; p += nt) L.FRC[p] = sp.frc_in[G.e0 + p];
-        } else if constexpr (FORCE) {
+        if constexpr (FORCE && !RF) {
             const float *sfs = sp.src_fs + 2 * (size_t)G.e0;                   // the external-force column is an input only
             for (int p = tid; p < ne; p += nt) L.FRC[p] = sfs[2 * G.v_edges[p] + 1];
         }
@@ -1087,11 +1102,11 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
             if (!PROF_SKIP(4))
             for (int p = tid; p < ne; p += nt) {
                 const uint16_t pw = pvv[p], cw = pcc[p];
-                const int v = pw & 0x3fff, c = cw & 0x3fff;
+                const int v = pw & VM, c = cw & 0x3fff;
                 const float s = slot_sign(pw);
                 const float eta_old = Eold[p];
                 const float agg = S[c] - X[p];                  // the reference's 0 + S is a no-op: a sum that starts at +0 is never -0
-                const float force = FORCE ? L.FRC[p] : 0.0f;
+                const float force = RF ? frc_of(pw) : (FORCE ? L.FRC[p] : 0.0f);
                 const float pos = Pv[v], neg = Nv[v];
                 float same = (0.5f * (1.0f + s)) * pos + (0.5f * (1.0f - s)) * neg;
                 same = same - Y[p];
@@ -1305,7 +1320,7 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
             const float *const av = L.av, *const af = L.af;
             for (int p = tid; p < ne; p += nt) {
                 const uint16_t cw = pcc[p];
-                const float a = 0.0f + av[pvv[p] & 0x3fff];
+                const float a = 0.0f + av[pvv[p] & VM];
                 const float b = 0.0f + af[cw & 0x3fff];
                 const bool em = (a * b) == 1.0f;
                 pcc[p] = (uint16_t)((cw & ~PC_EM) | (em ? PC_EM : 0));
@@ -1315,7 +1330,7 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
         }
         // ---- P8: termination check ---------------------------------------------------------------------------------------------
         if (sp.check_termination) {
-            if (decimated || rf_changed || nsat < 0) nsat = UNI(lds_cnf_count<FORCE>(smem, G.b, n, m, ne));
+            if (decimated || rf_changed || nsat < 0) nsat = UNI((lds_cnf_count<FORCE, RF>(smem, G.b, n, m, ne)));
             if (active && nsat == m) active = 0;
         }
         has_prev = 1; prev_from_global = 0; cur ^= 1;
@@ -1335,11 +1350,11 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
         for (int p = tid; p < ne; p += nt) {
             const int e = G.v_edges[p];
             const uint16_t pw = pvv[p], cw = pcc[p];
-            const int v = pw & 0x3fff;
+            const int v = pw & VM;
             const float s = slot_sign(pw);
             float y = pdp_safe_log_fin(1.0f - Eprev[p], PDP_SP_EPS);
             if (last_use_em) y = y * ((cw & PC_EM_USED) ? 1.0f : 0.0f);
-            const float force = FORCE ? ((RF && rf_last_flip) ? X[p] : L.FRC[p]) : 0.0f;
+            const float force = RF ? (rf_last_flip ? X[p] : frc_of(pw)) : (FORCE ? L.FRC[p] : 0.0f);
             const float pos = 0.0f + L.Pv[v], neg = 0.0f + L.Nv[v];
             float same = (0.5f * (1.0f + s)) * pos + (0.5f * (1.0f - s)) * neg;
             same = same - y;
@@ -1356,7 +1371,7 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
             gq[3 * e + 1] = 1.0f * (qs / total) + (1.0f - 1.0f) * sticky;
             gq[3 * e + 2] = 1.0f * (dc / total) + (1.0f - 1.0f) * sticky;
             gfs[2 * e] = Efin[p];
-            if constexpr (RF) gfs[2 * e + 1] = L.FRC[p];
+            if constexpr (RF) gfs[2 * e + 1] = frc_of(pw);
             sp.prev[G.e0 + e] = Efin[p];
             G.emask[e] = (cw & PC_EM) ? 1.0f : 0.0f;
         }
@@ -1372,7 +1387,8 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
         dump16(BL.af, L.af, (size_t)m * 4); dump16(BL.av, L.av, (size_t)n * 4); dump16(BL.sol, L.sol, (size_t)n * 4);
         // the next launch starts with "the mask the last propagate used" == the current mask
         uint16_t *gpc = reinterpret_cast<uint16_t *>(dout + BL.pcc);
-        for (int p = tid; p < ne; p += nt) { const uint16_t cw = pcc[p]; gpc[p] = (uint16_t)((cw & ~PC_EM_USED) | ((cw & PC_EM) ? PC_EM_USED : 0)); }        if constexpr (RF) { for (int p = tid; p < ne; p += nt) sp.frc_out[G.e0 + p] = L.FRC[p]; }
+        for (int p = tid; p < ne; p += nt) { const uint16_t cw = pcc[p]; gpc[p] = (uint16_t)((cw & ~PC_EM_USED) | ((cw & PC_EM) ? PC_EM_USED : 0)); }
+        if constexpr (RF) { for (int p = tid; p < ne; p += nt) sp.frc_out[G.e0 + p] = frc_of(pvv[p]); }
     }
     if (tid < SPEC_LOCAL && tid < T) {
         if (s_spec_used[tid]) atomicOr(&sp.spec_used[tid], (uint32_t)s_spec_used[tid]);
@@ -1455,11 +1471,17 @@ __global__ void __launch_bounds__(256) k_solve_import(PView pv, const float *q, 
 }
 
 // Reinforce: the force column of the caller's [E,2] state in slot order
-__global__ void __launch_bounds__(256) k_force_import(PView pv, const float *fs, float *frc)
+__global__ void __launch_bounds__(256) k_force_import(PView pv, const float *fs, float *frc, SolveCtl *ctl0)
 {
     const Inst G = load_inst(pv, blockIdx.x);
     const float *sfs = fs + 2 * (size_t)G.e0;
-    for (int p = threadIdx.x; p < G.e; p += blockDim.x) frc[G.e0 + p] = sfs[2 * G.v_edges[p] + 1];
+    int odd = 0;
+    for (int p = threadIdx.x; p < G.e; p += blockDim.x) {
+        const float f = sfs[2 * G.v_edges[p] + 1];
+        frc[G.e0 + p] = f;
+        odd |= (f == f && f != 0.0f && f != 1.0f && f != -1.0f) ? 1 : 0;     // the resident kernel keeps the force as a 2-bit code
+    }
+    if (__syncthreads_or(odd) && threadIdx.x == 0) atomicOr(&ctl0->violation, 1u);   // the call fails over to the step-wise loop
 }
 
 // after pass 1 of a chunk: does a NaN poison the batch from this chunk on?  
@@ -1650,7 +1672,7 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     float *frc_buf[2] = {nullptr, nullptr};
     if (rf) {
         frc_buf[0] = (float *)(((uintptr_t)(replay_list + B) + 15) & ~(uintptr_t)15); frc_buf[1] = frc_buf[0] + E + 4;
-        hipLaunchKernelGGL(k_force_import, dim3(p->B), dim3(256), 0, st, make_view(p), (const float *)a->fs, frc_buf[0]);
+        hipLaunchKernelGGL(k_force_import, dim3(p->B), dim3(256), 0, st, make_view(p), (const float *)a->fs, frc_buf[0], ctl);
     }
     sp.last_event = last_event; sp.inst_list = replay_list;
     sp.call = call; sp.stat = p->res_stat; sp.stat_off = stat_off; sp.dyn_off = dyn_off;
@@ -1752,8 +1774,8 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
         PDP_HIP_CHECK(hipMemcpyAsync(&force_flag, p->flags + FL_N_SEL, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         PDP_HIP_CHECK(hipStreamSynchronize(st));
         const bool force_r = force_flag != 0 || rf_model;
-        const size_t lds_r = lds2_bytes_for(p->max_n, p->max_m, p->max_e, force_r);
-        const bool fits_r = p->fn_edges_identity && lds_r <= 160 * 1024 - 1024 && p->max_e < 65535 && p->max_n < 16384 && p->max_m < 16384 &&
+        const size_t lds_r = lds2_bytes_for(p->max_n, p->max_m, p->max_e, force_r && !rf_model);   // Reinforce: the force is a 2-bit code in the slot word
+        const bool fits_r = p->fn_edges_identity && lds_r <= 160 * 1024 - 1024 && p->max_e < 65535 && p->max_n < (rf_model ? 8192 : 16384) && p->max_m < 16384 &&
                             getenv("PDP_SOLVE_FORCE_HBM") == nullptr;          // the switch lets the tests reach the HBM-resident kernel with small instances
         // threads per instance: 256 for tiny instances, 512 while two workgroups share a CU, 1024 when the instance's LDS image allows
         // only one workgroup per CU (the same 16 waves per CU either way)
