@@ -235,6 +235,32 @@ int pdp_neural_gru(pdp_problem *p, const pdp_gru_desc *d, const float *state, co
 int pdp_neural_predict(pdp_problem *p, const pdp_agg_desc *d, const pdp_head_desc *head, const float *state,
                        const float *edge_mask, float *pred, void *stream);
 
+/* ---- training path (the gradients loss.backward() needs in FactorGraphTrainerBase._train_batch, src/pdp/factorgraph/base.py:149-182) ------------
+ * The reference differentiates its torch operators with autograd.  Each differentiable building block of the np-nd-np solver has a
+ * forward and an adjoint entry point here; the host wraps a pair in an autograd node (pdp/nn/train_ops.py) and keeps the graph bookkeeping,
+ * gradient clipping and the caller's optimizer.  Activations are identified like pdp_head_desc.out_act: 0 none, 1 logsigmoid, 2 relu,
+ * 3 sigmoid, 4 tanh; activation derivatives are taken from the saved OUTPUT.  All matrices row-major fp32. */
+/* replaces: nn.Linear + activation (util.py:56,74 MessageAggregator layers; trainer.py:28-29 Perceptron): Y [R,N] = act(X [R,K] W^T + b), W [N,K] */
+int pdp_train_linear(const float *X, int64_t R, int K, int64_t ldx, const float *W, const float *b, int N, int act, float *Y, void *stream);
+/* adjoint: dZ = dY * act'(Y) (dZ [R,N]: scratch, may alias dY); dX [R,K] = dZ W (NULL: skipped); dW [N,K] = dZ^T X; db [N] = column sums (NULL: no bias) */
+int pdp_train_linear_backward(const float *dY, const float *Y, const float *X, int64_t R, int K, int64_t ldx, const float *W, int N, int act,
+                              float *dZ, float *dX, int64_t lddx, float *dW, float *db, void *stream);
+/* replaces: torch.mm(mask, state) of MessageAggregator.forward (util.py:60): x [E,A] -> out [rows,A], ordered sum over the edges of every
+ * variable (by_variable != 0) or clause */
+int pdp_train_row_sum(pdp_problem *p, int by_variable, const float *x, int A, float *out, void *stream);
+/* replaces: torch.mm(mask_transpose, aggregated) - state (util.py:63-69): rows [rows,A] -> out [E,A] = rows[row(e)] - x[e] (x NULL: gather only).
+ * The adjoint of the exclude-self aggregation is the same pair of calls on the gradient; of the plain row sum, the gather. */
+int pdp_train_row_spread(pdp_problem *p, int by_variable, const float *rows, const float *x, int A, float *out, void *stream);
+/* replaces: nn.GRUCell forward (pdp_decimate.py:38-41,70-83): x [R,Kx], h [R,H], W_ih [3H,Kx], W_hh [3H,H] -> hnew [R,H];
+ * saved [R,4H] = r | z | n | W_hn h + b_hn for the adjoint; scratch [R,6H] */
+int pdp_train_gru(const float *x, const float *h, const float *W_ih, const float *W_hh, const float *b_ih, const float *b_hh, int64_t R, int Kx, int H,
+                  float *hnew, float *saved, float *scratch, void *stream);
+/* adjoint: dhnew [R,H] -> dx [R,Kx], dh [R,H], dW_ih, dW_hh, db_ih [3H], db_hh [3H]; scratch [R,7H] */
+int pdp_train_gru_backward(const float *dhnew, const float *saved, const float *x, const float *h, const float *W_ih, const float *W_hh, int64_t R, int Kx,
+                           int H, float *dx, float *dh, float *dW_ih, float *dW_hh, float *db_ih, float *db_hh, float *scratch, void *stream);
+/* adjoint of pdp_sat_loss (SatLossEvaluator.forward, util.py:178-197) with respect to the prediction: dpred [V] = upstream * d loss / d pred */
+int pdp_sat_loss_grad(pdp_problem *p, const float *pred, float coeff, float eps, int sharpness, float upstream, float *dpred, void *stream);
+
 /* ---- kernel timing (measurement only: bench.py's per-kernel roofline lines) ------------------------------
  * When enabled, the library brackets the kernels named below with HIP events ON THEIR LAUNCH STREAM (the stream handed to the entry
  * point); pdp_kernel_timing_read synchronises on the recorded events and returns, per key, the summed device time in ms and the number

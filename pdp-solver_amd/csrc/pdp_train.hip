@@ -1,0 +1,380 @@
+// pdp_train.hip -- training path of the neural PDP solver: forward-with-saved-activations and backward of
+// the building blocks of NeuralMessagePasser / MessageAggregator (reference: src/pdp/nn/pdp_propagate.py:47-95, src/pdp/nn/util.py:51-77),
+// NeuralDecimator's GRU cells (src/pdp/nn/pdp_decimate.py:51-87, torch.nn.GRUCell), NeuralPredictor + Perceptron
+// (src/pdp/nn/pdp_predict.py:49-91, src/pdp/trainer.py:20-29) and the energy loss (src/pdp/nn/util.py:178-197), i.e. what
+// loss.backward() in FactorGraphTrainerBase._train_batch (src/pdp/factorgraph/base.py:149-182) runs through.
+//
+// The reference gets its backward pass from torch autograd over sparse-mm / addmm / gru_cell.  Here every differentiable step has a
+// forward and a backward entry point; pdp/nn/train_ops.py wraps each pair in a torch.autograd.Function, so the graph bookkeeping
+// (which tensors are alive, gradient accumulation into the nn.Parameters, clip_grad_norm_, the optimizer the caller hands to train())
+// stays with PyTorch while all arithmetic of the path is native:
+//   * dense layers on the fp32 matrix cores: one generic tiled GEMM kernel (v_mfma_f32_32x32x2_f32, 64 x 64 tiles through LDS, any
+//     transposition, split-K with a deterministic second pass for the weight gradients, whose reduction runs over all edges)
+//   * per-row sums over the by-variable / by-clause CSR of the problem (ordered, no atomics) and their adjoints
+//   * the GRU gate arithmetic and its derivative, activation derivatives from the saved OUTPUTS (logsigmoid' = 1 - exp(y), sigmoid' =
+//     y (1 - y), tanh' = 1 - y^2, relu' = [y > 0]), the loss gradient with respect to the prediction.
+// Inference keeps its fused, bit-exact kernels (pdp_neural.hip); training results are compared with the reference's autograd within a
+// tolerance (another summation order than MKL's sgemm), tests/test_train_gpu.py.
+#include "pdp_common.hpp"
+
+#define ST(s) ((hipStream_t)(s))
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { TACT_NONE = 0, TACT_LOGSIGMOID = 1, TACT_RELU = 2, TACT_SIGMOID = 3, TACT_TANH = 4 };
+
+__device__ __forceinline__ float tact(float v, int act)
+{
+    switch (act) {
+    case TACT_LOGSIGMOID: return pdp_logsigmoidf(v);
+    case TACT_RELU: return v > 0.0f ? v : ((v != v) ? v : 0.0f);
+    case TACT_SIGMOID: return pdp_sigmoidf(v);
+    case TACT_TANH: return pdp_tanhf(v);
+    default: return v;
+    }
+}
+// derivative of the activation with respect to its argument, from the activation's OUTPUT y
+__device__ __forceinline__ float tact_grad(float y, int act)
+{
+    switch (act) {
+    case TACT_LOGSIGMOID: return 1.0f - pdp_expf(y);            // d/dz log sigma(z) = 1 - sigma(z),  sigma(z) = exp(y)
+    case TACT_RELU: return y > 0.0f ? 1.0f : 0.0f;
+    case TACT_SIGMOID: return y * (1.0f - y);
+    case TACT_TANH: return 1.0f - y * y;
+    default: return 1.0f;
+    }
+}
+
+// ---- generic GEMM on the fp32 matrix cores ---------------------------------------------------------------------------------------------
+// C[M,N] = sum_k A(m,k) B(k,n);  A is stored [M,K] (TA = false, leading dimension lda) or [K,M] (TA = true);  B is stored [K,N]
+// (TB = false) or [N,K] (TB = true).  64 x 64 output tile per 256-thread workgroup, four waves with one 32 x 32 accumulator block each,
+// K in slabs of 16 through LDS.  gridDim.z > 1: split-K, slab range z of the K dimension goes to partial[z] (summed by k_splitk_reduce).
+// Epilogue (gridDim.z == 1): + bias[n], activation, optional element-wise factor (dropout mask, or the incoming gradient's act').
+#define GB 64
+#define GK 16
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(256) k_gemm(int M, int N, int64_t K, const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb,
+                                              float *__restrict__ C, int64_t ldc, const float *__restrict__ bias, int act, float *__restrict__ partial)
+{
+    __shared__ float As[GB][GK + 1];
+    __shared__ float Bs[GK][GB + 1];
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int m0 = blockIdx.y * GB, n0 = blockIdx.x * GB;
+    const int mb = w & 1, nb = w >> 1;
+    const int i = l & 31, kh = l >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int64_t slabs = (K + GK - 1) / GK;
+    const int64_t per = (slabs + gridDim.z - 1) / gridDim.z;
+    const int64_t s_begin = per * blockIdx.z, s_end = (s_begin + per < slabs) ? s_begin + per : slabs;
+    for (int64_t sl = s_begin; sl < s_end; ++sl) {
+        const int64_t k0 = sl * GK;
+        // A tile: 64 rows x 16 k
+        for (int t = tid; t < GB * GK; t += 256) {
+            int r, kk;
+            if (TA) { r = t % GB; kk = t / GB; } else { kk = t % GK; r = t / GK; }          // the fastest index follows the storage order
+            const int m = m0 + r; const int64_t k = k0 + kk;
+            float v = 0.0f;
+            if (m < M && k < K) v = TA ? A[k * lda + m] : A[(int64_t)m * lda + k];
+            As[r][kk] = v;
+        }
+        for (int t = tid; t < GK * GB; t += 256) {
+            int c, kk;
+            if (TB) { kk = t % GK; c = t / GK; } else { c = t % GB; kk = t / GB; }
+            const int n = n0 + c; const int64_t k = k0 + kk;
+            float v = 0.0f;
+            if (n < N && k < K) v = TB ? B[(int64_t)n * ldb + k] : B[k * ldb + n];
+            Bs[kk][c] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < GK / 2; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[32 * mb + i][2 * s + kh], Bs[2 * s + kh][32 * nb + i], acc, 0, 0, 0);
+        __syncthreads();
+    }
+    const int col = n0 + 32 * nb + i;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row < M && col < N) {
+            if (gridDim.z > 1) partial[((int64_t)blockIdx.z * M + row) * N + col] = acc[r];
+            else {
+                float v = acc[r] + (bias ? bias[col] : 0.0f);
+                C[(int64_t)row * ldc + col] = tact(v, act);
+            }
+        }
+    }
+}
+
+__global__ void k_splitk_reduce(int64_t MN, int splits, const float *__restrict__ partial, float *__restrict__ C)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < MN; i += (int64_t)gridDim.x * blockDim.x) {
+        float acc = 0.0f;
+        for (int z = 0; z < splits; ++z) acc = acc + partial[(int64_t)z * MN + i];
+        C[i] = acc;
+    }
+}
+
+// column sums of Z [R,N] in two deterministic passes: partial[s][n] over a slice of rows, then their sum
+__global__ void __launch_bounds__(256) k_colsum_partial(int64_t R, int N, const float *__restrict__ Z, int slices, float *__restrict__ partial)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int64_t per = (R + slices - 1) / slices, r0 = per * blockIdx.y, r1 = (r0 + per < R) ? r0 + per : R;
+    float acc = 0.0f;
+    for (int64_t r = r0; r < r1; ++r) acc = acc + Z[r * N + n];
+    partial[(int64_t)blockIdx.y * N + n] = acc;
+}
+
+// dZ = dY * act'(Y) (element-wise), in place into out
+__global__ void k_act_backward(int64_t n, const float *__restrict__ dY, const float *__restrict__ Y, int act, float *__restrict__ out)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = dY[i] * tact_grad(Y[i], act);
+}
+
+static int grid1d(int64_t n) { int64_t g = (n + 255) / 256; if (g > 16384) g = 16384; return (int)(g < 1 ? 1 : g); }
+
+template <bool TA, bool TB>
+static int gemm(int M, int N, int64_t K, const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, const float *bias, int act,
+                int splits, float *partial, hipStream_t st)
+{
+    dim3 grid((N + GB - 1) / GB, (M + GB - 1) / GB, splits > 1 ? splits : 1);
+    hipLaunchKernelGGL((k_gemm<TA, TB>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, bias, act, partial);
+    if (splits > 1) hipLaunchKernelGGL(k_splitk_reduce, dim3(grid1d((int64_t)M * N)), dim3(256), 0, st, (int64_t)M * N, splits, (const float *)partial, C);
+    PDP_LAUNCH_CHECK();
+    return PDP_OK;
+}
+
+static int pick_splits(int64_t R) { int64_t s = (R + 4095) / 4096; if (s > 128) s = 128; return (int)(s < 1 ? 1 : s); }
+
+// scratch for split-K partials and column sums: grown on demand, kept (per process; training drives one stream)
+static float *g_train_scratch = nullptr; static size_t g_train_scratch_floats = 0;
+static float *train_scratch(size_t floats)
+{
+    if (g_train_scratch_floats < floats) {
+        if (g_train_scratch) pdp_dev_free(g_train_scratch);
+        g_train_scratch = nullptr; g_train_scratch_floats = 0;
+        if (pdp_dev_alloc((void **)&g_train_scratch, floats * sizeof(float)) != PDP_OK) return nullptr;
+        g_train_scratch_floats = floats;
+    }
+    return g_train_scratch;
+}
+
+// replaces: nn.Linear + activation as used by MessageAggregator / Perceptron (util.py:56,74; trainer.py:28-29): Y = act(X W^T + b)
+extern "C" int pdp_train_linear(const float *X, int64_t R, int K, int64_t ldx, const float *W, const float *b, int N, int act, float *Y, void *stream)
+{
+    PDP_REQUIRE(X && W && Y && R >= 0 && K > 0 && N > 0 && R < (int64_t)1 << 31, "bad argument");
+    if (R == 0) return PDP_OK;
+    return gemm<false, true>((int)R, N, K, X, ldx, W, K, Y, N, b, act, 1, nullptr, ST(stream));
+}
+
+// its adjoint: dZ = dY * act'(Y);  dX = dZ W  (NULL: not needed);  dW = dZ^T X;  db = column sums of dZ (NULL: no bias).
+// dZ [R,N] is caller-provided scratch (may alias dY).
+extern "C" int pdp_train_linear_backward(const float *dY, const float *Y, const float *X, int64_t R, int K, int64_t ldx, const float *W, int N, int act,
+                                         float *dZ, float *dX, int64_t lddx, float *dW, float *db, void *stream)
+{
+    PDP_REQUIRE(dY && Y && X && W && dZ && dW && R >= 0 && R < (int64_t)1 << 31, "bad argument");
+    hipStream_t st = ST(stream);
+    if (R == 0) {
+        PDP_HIP_CHECK(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)N * K, st));
+        if (db) PDP_HIP_CHECK(hipMemsetAsync(db, 0, sizeof(float) * (size_t)N, st));
+        return PDP_OK;
+    }
+    hipLaunchKernelGGL(k_act_backward, dim3(grid1d(R * N)), dim3(256), 0, st, R * N, dY, Y, act, dZ);
+    int s;
+    if (dX) { s = gemm<false, false>((int)R, K, N, dZ, N, W, K, dX, lddx, nullptr, TACT_NONE, 1, nullptr, st); if (s != PDP_OK) return s; }
+    const int splits = pick_splits(R);
+    float *scr = train_scratch((size_t)splits * ((size_t)N * K + N) + 16);
+    if (!scr) return PDP_ERR_HIP;
+    s = gemm<true, false>(N, K, R, dZ, N, X, ldx, dW, K, nullptr, TACT_NONE, splits, scr, st);
+    if (s != PDP_OK) return s;
+    if (db) {
+        float *part = scr + (size_t)splits * N * K;
+        hipLaunchKernelGGL(k_colsum_partial, dim3((N + 255) / 256, splits), dim3(256), 0, st, R, N, (const float *)dZ, splits, part);
+        hipLaunchKernelGGL(k_splitk_reduce, dim3(grid1d(N)), dim3(256), 0, st, (int64_t)N, splits, (const float *)part, db);
+    }
+    PDP_LAUNCH_CHECK();
+    return PDP_OK;
+}
+
+// ---- per-row sums over the problem's CSR and their adjoints (MessageAggregator's torch.mm(mask, state), util.py:60-69) ------------------
+__global__ void k_trow_sum(int64_t R, int A, const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ row_edges, const float *__restrict__ x,
+                           float *__restrict__ out)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < R * A; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / A; const int c = (int)(i % A);
+        float acc = 0.0f;
+        for (int k = row_ptr[r]; k < row_ptr[r + 1]; ++k) acc = acc + x[(int64_t)row_edges[k] * A + c];       // ascending edge id
+        out[i] = acc;
+    }
+}
+// out[e] = rows[row(e)] - (x ? x[e] : 0)
+__global__ void k_trow_spread(int64_t E, int A, const int32_t *__restrict__ edge_row, const float *__restrict__ rows, const float *__restrict__ x,
+                              float *__restrict__ out)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < E * A; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = i / A; const int c = (int)(i % A);
+        const float v = rows[(int64_t)edge_row[e] * A + c];
+        out[i] = x ? v - x[i] : v;
+    }
+}
+
+// x [E,A] -> out [rows,A]: the ordered sum over the edges of every variable (by_variable != 0) or clause.  Forward of the
+// include_self_message=True aggregator; first half of the exclude-self one and of both adjoints.
+extern "C" int pdp_train_row_sum(pdp_problem *p, int by_variable, const float *x, int A, float *out, void *stream)
+{
+    PDP_REQUIRE(p && x && out && A > 0, "bad argument");
+    const int64_t R = by_variable ? p->V : p->F;
+    hipLaunchKernelGGL(k_trow_sum, dim3(grid1d(R * A)), dim3(256), 0, ST(stream), R, A, by_variable ? p->nv_ptr : p->nf_ptr,
+                       by_variable ? p->nv_edges : p->nf_edges, x, out);
+    PDP_LAUNCH_CHECK();
+    return PDP_OK;
+}
+// rows [rows,A] -> out [E,A]: out[e] = rows[row(e)] - x[e] (x NULL: plain gather).  With x = the summed edge values this completes the
+// exclude-self aggregation (util.py:63-69); with x = the incoming gradient, its adjoint; with x NULL the adjoint of the plain row sum.
+extern "C" int pdp_train_row_spread(pdp_problem *p, int by_variable, const float *rows, const float *x, int A, float *out, void *stream)
+{
+    PDP_REQUIRE(p && rows && out && A > 0, "bad argument");
+    const int32_t *edge_row = by_variable ? p->graph_map : p->graph_map + p->E;
+    hipLaunchKernelGGL(k_trow_spread, dim3(grid1d((int64_t)p->E * A)), dim3(256), 0, ST(stream), (int64_t)p->E, A, edge_row, rows, x, out);
+    PDP_LAUNCH_CHECK();
+    return PDP_OK;
+}
+
+// ---- GRU cell (torch.nn.GRUCell as used by NeuralDecimator, pdp_decimate.py:38-41,70-83) ---------------------------------------------------
+// gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh (gate order r, z, n);  r = sigma(gi_r + gh_r), z = sigma(gi_z + gh_z),
+// n = tanh(gi_n + r gh_n),  h' = (1 - z) n + z h.  saved [R,4H] = r | z | n | gh_n.
+__global__ void k_gru_point(int64_t R, int H, const float *__restrict__ gi, const float *__restrict__ gh, const float *__restrict__ h,
+                            float *__restrict__ hnew, float *__restrict__ saved)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < R * H; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = i / H; const int c = (int)(i % H);
+        const float *a = gi + e * 3 * H, *b = gh + e * 3 * H;
+        const float r = pdp_sigmoidf(a[c] + b[c]);
+        const float z = pdp_sigmoidf(a[H + c] + b[H + c]);
+        const float ghn = b[2 * H + c];
+        const float n = pdp_tanhf(a[2 * H + c] + r * ghn);
+        hnew[i] = (1.0f - z) * n + z * h[i];
+        float *sv = saved + e * 4 * H;
+        sv[c] = r; sv[H + c] = z; sv[2 * H + c] = n; sv[3 * H + c] = ghn;
+    }
+}
+__global__ void k_gru_point_backward(int64_t R, int H, const float *__restrict__ dhn, const float *__restrict__ saved, const float *__restrict__ h,
+                                     float *__restrict__ dgi, float *__restrict__ dgh, float *__restrict__ dh)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < R * H; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = i / H; const int c = (int)(i % H);
+        const float *sv = saved + e * 4 * H;
+        const float r = sv[c], z = sv[H + c], n = sv[2 * H + c], ghn = sv[3 * H + c];
+        const float g = dhn[i];
+        const float dn_pre = g * (1.0f - z) * (1.0f - n * n);
+        const float dz_pre = g * (h[i] - n) * z * (1.0f - z);
+        const float dr_pre = dn_pre * ghn * r * (1.0f - r);
+        float *a = dgi + e * 3 * H, *b = dgh + e * 3 * H;
+        a[c] = dr_pre; b[c] = dr_pre;
+        a[H + c] = dz_pre; b[H + c] = dz_pre;
+        a[2 * H + c] = dn_pre; b[2 * H + c] = dn_pre * r;
+        dh[i] = g * z;                                   // the direct path; the W_hh path is added by the caller's GEMM (beta = 1 below)
+    }
+}
+__global__ void k_add_inplace(int64_t n, float *__restrict__ y, const float *__restrict__ x)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = y[i] + x[i];
+}
+
+// scratch [R, 6H]: gi | gh
+extern "C" int pdp_train_gru(const float *x, const float *h, const float *W_ih, const float *W_hh, const float *b_ih, const float *b_hh, int64_t R, int Kx, int H,
+                             float *hnew, float *saved, float *scratch, void *stream)
+{
+    PDP_REQUIRE(x && h && W_ih && W_hh && b_ih && b_hh && hnew && saved && scratch && R < (int64_t)1 << 31, "bad argument");
+    if (R == 0) return PDP_OK;
+    hipStream_t st = ST(stream);
+    float *gi = scratch, *gh = scratch + (size_t)R * 3 * H;
+    int s = gemm<false, true>((int)R, 3 * H, Kx, x, Kx, W_ih, Kx, gi, 3 * H, b_ih, TACT_NONE, 1, nullptr, st); if (s != PDP_OK) return s;
+    s = gemm<false, true>((int)R, 3 * H, H, h, H, W_hh, H, gh, 3 * H, b_hh, TACT_NONE, 1, nullptr, st); if (s != PDP_OK) return s;
+    hipLaunchKernelGGL(k_gru_point, dim3(grid1d(R * H)), dim3(256), 0, st, R, H, (const float *)gi, (const float *)gh, h, hnew, saved);
+    PDP_LAUNCH_CHECK();
+    return PDP_OK;
+}
+// scratch [R, 6H + H]: dgi | dgh | W_hh path of dh
+extern "C" int pdp_train_gru_backward(const float *dhnew, const float *saved, const float *x, const float *h, const float *W_ih, const float *W_hh, int64_t R,
+                                      int Kx, int H, float *dx, float *dh, float *dW_ih, float *dW_hh, float *db_ih, float *db_hh, float *scratch, void *stream)
+{
+    PDP_REQUIRE(dhnew && saved && x && h && W_ih && W_hh && dx && dh && dW_ih && dW_hh && db_ih && db_hh && scratch && R < (int64_t)1 << 31, "bad argument");
+    hipStream_t st = ST(stream);
+    if (R == 0) {
+        PDP_HIP_CHECK(hipMemsetAsync(dW_ih, 0, sizeof(float) * 3 * (size_t)H * Kx, st)); PDP_HIP_CHECK(hipMemsetAsync(dW_hh, 0, sizeof(float) * 3 * (size_t)H * H, st));
+        PDP_HIP_CHECK(hipMemsetAsync(db_ih, 0, sizeof(float) * 3 * (size_t)H, st)); PDP_HIP_CHECK(hipMemsetAsync(db_hh, 0, sizeof(float) * 3 * (size_t)H, st));
+        return PDP_OK;
+    }
+    float *dgi = scratch, *dgh = scratch + (size_t)R * 3 * H, *dh2 = dgh + (size_t)R * 3 * H;
+    hipLaunchKernelGGL(k_gru_point_backward, dim3(grid1d(R * H)), dim3(256), 0, st, R, H, dhnew, saved, h, dgi, dgh, dh);
+    int s = gemm<false, false>((int)R, Kx, 3 * H, dgi, 3 * H, W_ih, Kx, dx, Kx, nullptr, TACT_NONE, 1, nullptr, st); if (s != PDP_OK) return s;
+    s = gemm<false, false>((int)R, H, 3 * H, dgh, 3 * H, W_hh, H, dh2, H, nullptr, TACT_NONE, 1, nullptr, st); if (s != PDP_OK) return s;
+    hipLaunchKernelGGL(k_add_inplace, dim3(grid1d(R * H)), dim3(256), 0, st, R * H, dh, (const float *)dh2);
+    const int splits = pick_splits(R);
+    const size_t wmax = (size_t)3 * H * (Kx > H ? Kx : H);
+    float *scr = train_scratch((size_t)splits * (wmax + 3 * H) + 16);
+    if (!scr) return PDP_ERR_HIP;
+    float *part = scr + (size_t)splits * wmax;
+    s = gemm<true, false>(3 * H, Kx, R, dgi, 3 * H, x, Kx, dW_ih, Kx, nullptr, TACT_NONE, splits, scr, st); if (s != PDP_OK) return s;
+    hipLaunchKernelGGL(k_colsum_partial, dim3((3 * H + 255) / 256, splits), dim3(256), 0, st, R, 3 * H, (const float *)dgi, splits, part);
+    hipLaunchKernelGGL(k_splitk_reduce, dim3(grid1d(3 * H)), dim3(256), 0, st, (int64_t)3 * H, splits, (const float *)part, db_ih);
+    s = gemm<true, false>(3 * H, H, R, dgh, 3 * H, h, H, dW_hh, H, nullptr, TACT_NONE, splits, scr, st); if (s != PDP_OK) return s;
+    hipLaunchKernelGGL(k_colsum_partial, dim3((3 * H + 255) / 256, splits), dim3(256), 0, st, R, 3 * H, (const float *)dgh, splits, part);
+    hipLaunchKernelGGL(k_splitk_reduce, dim3(grid1d(3 * H)), dim3(256), 0, st, (int64_t)3 * H, splits, (const float *)part, db_hh);
+    PDP_LAUNCH_CHECK();
+    return PDP_OK;
+}
+
+// ---- gradient of the energy loss with respect to the prediction (SatLossEvaluator.forward, util.py:178-197; forward: pdp_sat_loss) -------------
+// ev = s x_v + (1 - s) / 2, w = exp(coeff ev); per clause nom = sum w ev, den = sum w, d = den / max(nom, eps) - 1, cv = 1 + d^k,
+// term = log(max(cv, eps)), loss = mean of the terms.  torch.max(a, eps) passes the gradient to a where a > eps.
+__global__ void __launch_bounds__(PDP_NT) k_sat_loss_grad(PView pv, const float *pred, float coeff, float eps, int sharpness, float upstream_over_F,
+                                                        float *gnom, float *gden, float *dpred)
+{
+    const Inst I = load_inst(pv, blockIdx.x);
+    pred += I.v0; gnom += I.f0; gden += I.f0; dpred += I.v0;
+    for (int c = threadIdx.x; c < I.m; c += blockDim.x) {
+        float nom = 0.0f, den = 0.0f;
+        for (int k = I.f_ptr[c]; k < I.f_ptr[c + 1]; ++k) {
+            const int e = I.f_edges[k];
+            const float s = (float)I.sgn[e];
+            const float ev = s * pred[I.e_var[e]] + (1.0f - s) / 2.0f;
+            const float w = pdp_expf(coeff * ev);
+            nom = nom + w * ev; den = den + w;
+        }
+        const float nm = pdp_max_c(nom, eps);
+        const float d = den / nm - 1.0f;
+        float pw1 = 1.0f;                                 // d^(k-1)
+        for (int j = 1; j < sharpness; ++j) pw1 = pw1 * d;
+        const float cv = 1.0f + pw1 * d;
+        const float dterm = (cv > eps) ? upstream_over_F / cv : 0.0f;
+        const float dd = dterm * (float)sharpness * pw1;
+        gden[c] = dd / nm;
+        gnom[c] = (nom > eps) ? -dd * den / (nm * nm) : 0.0f;
+    }
+    __syncthreads();
+    for (int v = threadIdx.x; v < I.n; v += blockDim.x) {
+        float acc = 0.0f;
+        for (int k = I.v_ptr[v]; k < I.v_ptr[v + 1]; ++k) {
+            const int e = I.v_edges[k];
+            const int c = I.e_fn[e];
+            const float s = (float)I.sgn[e];
+            const float ev = s * pred[v] + (1.0f - s) / 2.0f;
+            const float w = pdp_expf(coeff * ev);
+            const float dev = gnom[c] * (w + coeff * w * ev) + gden[c] * (coeff * w);
+            acc = acc + s * dev;
+        }
+        dpred[v] = acc;
+    }
+}
+extern "C" int pdp_sat_loss_grad(pdp_problem *p, const float *pred, float coeff, float eps, int sharpness, float upstream, float *dpred, void *stream)
+{
+    PDP_REQUIRE(p && pred && dpred, "NULL argument");
+    PDP_REQUIRE(sharpness >= 1, "loss_sharpness must be a positive integer");
+    hipLaunchKernelGGL(k_sat_loss_grad, dim3(p->B), dim3(PDP_NT), 0, ST(stream), make_view(p), pred, coeff, eps, sharpness, upstream / (float)p->F, p->ws_f[0],
+                       p->ws_f[1], dpred);
+    PDP_LAUNCH_CHECK();
+    return PDP_OK;
+}

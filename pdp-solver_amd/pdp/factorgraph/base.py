@@ -1,6 +1,7 @@
 """Predict and test drivers (reference: src/pdp/factorgraph/base.py, predict path :252-305,451-472, test path :183-250,406-449).
 
-The training loop of the reference's ``FactorGraphTrainerBase`` is out of scope; ``predict`` and
+``train`` / ``_train_epoch`` / ``_train_batch`` (reference: base.py:113-182, 311-404) run the neural solver's differentiable path
+(pdp/nn/train_ops.py: native forward / adjoint pairs under torch autograd) with the optimizer the caller provides; ``predict`` and
 ``test`` keep their signatures.  There is no ``nn.DataParallel`` wrap (it mis-scatters ``graph_map``, SURVEY.md
 App. B-13): multi-GPU runs shard instances across ranks instead (pdp/parallel.py).
 """
@@ -49,6 +50,105 @@ class FactorGraphTrainerBase(object):
         if isinstance(data, list) or data is None:
             return data
         return data.to(self._device, non_blocking=True)
+
+    # ---- training (reference: base.py:108-182, 311-404) -------------------------------------------------------------------------
+    def get_parameter_list(self):
+        "list of dictionaries with the models' trainable parameters, for the optimizer's constructor (base.py:108-111)"
+        return [{'params': [p for p in model.parameters() if p.requires_grad]} for model in self._model_list]
+
+    def _reset_global_step(self):
+        for model in self._model_list:
+            model._global_step.data.zero_()
+
+    def _compute_loss(self, model, loss, prediction, label, graph_map, batch_variable_map, batch_function_map, edge_feature, meta_data):
+        return loss(prediction, label)
+
+    def _train_batch(self, total_loss, optimizer, graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, label):
+        """One optimizer step on one (segment of a) batch (reference: base.py:149-182): train_outer_recurrence_num calls of the model, the state
+        carried from call to call, loss = sum_t lambda^(T - t - 1) loss_t, back-propagation through all of them, gradient clipping per model."""
+        import torch.nn as nn
+        optimizer.zero_grad()
+        T = int(self._config['train_outer_recurrence_num'])
+        lam = float(self._config['lambda'])
+        for (i, model) in enumerate(self._model_list):
+            state = model.get_init_state(graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, self._config['randomized'])
+            loss = torch.zeros(1, device=self._device)
+            for t in range(T):
+                prediction, state = model(init_state=state, graph_map=graph_map, batch_variable_map=batch_variable_map,
+                                          batch_function_map=batch_function_map, edge_feature=edge_feature, meta_data=graph_feat,
+                                          is_training=True, iteration_num=self._config['train_inner_recurrence_num'])
+                loss = loss + self._compute_loss(model=model, loss=self._loss, prediction=prediction, label=label, graph_map=graph_map,
+                                                 batch_variable_map=batch_variable_map, batch_function_map=batch_function_map,
+                                                 edge_feature=edge_feature, meta_data=graph_feat) * (lam ** (T - t - 1))
+            loss.backward()
+            nn.utils.clip_grad_norm_(model.parameters(), self._config['clip_norm'])
+            total_loss[i] += float(loss.detach().cpu().numpy().reshape(-1)[0])
+        optimizer.step()
+
+    def _train_epoch(self, train_loader, optimizer):
+        "reference: base.py:113-147 -- the models' global step advances once per loader batch; returns the loss per example"
+        total_loss = np.zeros(len(self._model_list), dtype=np.float32)
+        total_example_num = 0
+        for data in train_loader:
+            for i in range(len(data[0])):
+                (graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, label, _) = [self._to_cuda(d[i]) for d in data]
+                total_example_num += int(batch_variable_map.max().item()) + 1
+                self._train_batch(total_loss, optimizer, graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, label)
+            for model in self._model_list:
+                model._global_step.data += 1
+        return total_loss / max(1, total_example_num)
+
+    def train(self, train_list, validation_list, optimizer, last_export_path_base=None, best_export_path_base=None, metric_index=0,
+              load_model=None, reset_step=False, generator=None, train_epoch_size=0):
+        """Trains the PDP model (reference: base.py:311-404): per epoch one pass over the (shuffled, or generated) training set and a
+        validation pass with the test-mode metrics; the last model and the best one by ``metric_index`` are checkpointed.
+        Returns (model list, errors [error_dim, models, epochs, repetitions], losses [models, epochs, repetitions])."""
+        train_loader = FactorGraphDataset.get_loader(
+            input_file=train_list[0], limit=self._config['train_batch_limit'], hidden_dim=self._config['hidden_dim'],
+            batch_size=self._config['batch_size'], shuffle=True, num_workers=0, max_cache_size=self._config.get('max_cache_size', 100000),
+            generator=generator, epoch_size=train_epoch_size)
+        validation_loader = FactorGraphDataset.get_loader(
+            input_file=validation_list[0], limit=self._config['test_batch_limit'], hidden_dim=self._config['hidden_dim'],
+            batch_size=self._config['batch_size'], shuffle=False, num_workers=0, max_cache_size=self._config.get('max_cache_size', 100000))
+        model_num = len(self._model_list)
+        errors = np.zeros((self._error_dim, model_num, self._config['epoch_num'], self._config['repetition_num']), dtype=np.float32)
+        losses = np.zeros((model_num, self._config['epoch_num'], self._config['repetition_num']), dtype=np.float32)
+        best_errors = np.repeat(np.inf, model_num)
+        for rep in range(self._config['repetition_num']):
+            if load_model == "best" and best_export_path_base is not None:
+                self._load(best_export_path_base)
+            elif load_model == "last" and last_export_path_base is not None:
+                self._load(last_export_path_base)
+            if reset_step:
+                self._reset_global_step()
+            for epoch in range(self._config['epoch_num']):
+                start_time = time.time()
+                losses[:, epoch, rep] = self._train_epoch(train_loader, optimizer)
+                errors[:, :, epoch, rep] = self._test_epoch(validation_loader, 1)
+                torch.cuda.synchronize()
+                duration = time.time() - start_time
+                if last_export_path_base is not None:
+                    for model in self._model_list:
+                        model.save(last_export_path_base)
+                if best_export_path_base is not None:
+                    for (i, model) in enumerate(self._model_list):
+                        if errors[metric_index, i, epoch, rep] < best_errors[i]:
+                            best_errors[i] = errors[metric_index, i, epoch, rep]
+                            model.save(best_export_path_base)
+                if self._config.get('verbose'):
+                    message = ''
+                    for (i, model) in enumerate(self._model_list):
+                        message += 'Step {:d}: {:s} error={:s}, {:s} loss={:5.5f} |'.format(
+                            int(model._global_step.int()[0]), model._name, np.array_str(errors[:, i, epoch, rep].flatten()), model._name,
+                            losses[i, epoch, rep])
+                    self._logger.info('Rep {:2d}, Epoch {:2d}: {:s}'.format(rep + 1, epoch + 1, message))
+                    self._logger.info('Time spent: %s seconds' % duration)
+        if best_export_path_base is not None:
+            base = os.path.relpath(best_export_path_base)
+            np.save(os.path.join(base, "losses"), losses, allow_pickle=False)
+            np.save(os.path.join(base, "errors"), errors, allow_pickle=False)
+            self._save(best_export_path_base)
+        return self._model_list, errors, losses
 
     def _predict_epoch(self, validation_loader, post_processor, batch_replication, file):
         with torch.no_grad():

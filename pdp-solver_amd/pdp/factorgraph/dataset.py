@@ -134,22 +134,27 @@ def dimacs_item(path, label):
 
 
 class FactorGraphDataset(object):
-    """JSON-lines dataset with the reference's iteration order (shuffle=False).  ``input_file`` may also be a DIMACS file or a
+    """JSON-lines dataset with the reference's iteration order.  ``input_file`` may also be a DIMACS file or a
     directory of DIMACS files: the instances are then read directly by the native parser, in the order and with the labels the
-    converter (dimacs2json.py) would have produced."""
+    converter (dimacs2json.py) would have produced.  With a ``generator`` (training, dataset.py:84-104) every item is a fresh
+    ``generator.generate()`` instance and the data set has ``epoch_size`` items."""
 
-    def __init__(self, input_file, limit, hidden_dim, max_cache_size=100000, batch_replication=1, shard=None):
+    def __init__(self, input_file, limit, hidden_dim, max_cache_size=100000, batch_replication=1, shard=None, generator=None, epoch_size=0):
         import os
         self._input_file = input_file
         self._dimacs = None
-        if os.path.isdir(input_file) or os.path.splitext(input_file)[1].lower() in ('.cnf', '.dimacs'):
+        self._generator = generator
+        self._epoch_size = int(epoch_size)
+        if generator is not None:
+            self._lines = []
+        elif os.path.isdir(input_file) or os.path.splitext(input_file)[1].lower() in ('.cnf', '.dimacs'):
             self._dimacs = dimacs_file_list(input_file)
             self._lines = self._dimacs
         else:
             with open(input_file, 'r') as f:
                 self._lines = [l for l in f.read().split('\n') if l.strip()]
         self.shard_offset = 0
-        if shard is not None and shard[1] > 1:
+        if shard is not None and shard[1] > 1 and generator is None:
             # one process per GPU: this rank keeps a contiguous range of the instances, balanced by input size (file size / line
             # length as the proxy of the edge count -- no rank parses the others' instances)
             from pdp import parallel
@@ -167,9 +172,12 @@ class FactorGraphDataset(object):
         self._max_cache_size = max_cache_size
 
     def __len__(self):
-        return len(self._lines)
+        return self._epoch_size if self._generator is not None else len(self._lines)
 
     def __getitem__(self, idx):
+        if self._generator is not None:
+            n, m, graph_map, edge_feature, _, label, _ = self._generator.generate()
+            return int(n), int(m), np.asarray(graph_map, dtype=np.int32), np.asarray(edge_feature, dtype=np.float32), float(label), []
         if idx in self._cache:
             return self._cache[idx]
         item = dimacs_item(*self._dimacs[idx]) if self._dimacs is not None else parse_line(self._lines[idx])
@@ -177,10 +185,11 @@ class FactorGraphDataset(object):
             self._cache[idx] = item
         return item
 
-    def batches(self, batch_size):
-        """Yields lists of segment batches, ``batch_size`` instances per loader batch."""
-        for start in range(0, len(self), batch_size):
-            idx = range(start, min(start + batch_size, len(self)))
+    def batches(self, batch_size, order=None):
+        """Yields lists of segment batches, ``batch_size`` instances per loader batch (``order``: the sampler's permutation)."""
+        order = list(range(len(self))) if order is None else list(order)
+        for start in range(0, len(order), batch_size):
+            idx = order[start:start + batch_size]
             if self._dimacs is not None and len(idx) > 1:
                 # DIMACS files: one call parses the batch's files with a few host threads inside the native library
                 import os
@@ -205,7 +214,7 @@ class FactorGraphDataset(object):
                    use_cuda=True, generator=None, epoch_size=0, batch_replication=1, shard=None):
         """Signature-compatible constructor (reference: dataset.py:189-211); returns an iterable of
         reference-shaped 7-tuples of per-segment lists."""
-        ds = FactorGraphDataset(input_file, limit, hidden_dim, max_cache_size, batch_replication, shard=shard)
+        ds = FactorGraphDataset(input_file, limit, hidden_dim, max_cache_size, batch_replication, shard=shard, generator=generator, epoch_size=epoch_size)
 
         class _Loader(object):
             dataset = ds
@@ -215,7 +224,13 @@ class FactorGraphDataset(object):
                 # created (reference: base.py:258 enumerates the loader once per predict call).  Consume the
                 # same draw so that later torch.rand calls see the reference's random stream.
                 torch.empty((), dtype=torch.int64).random_()
-                for segs in ds.batches(batch_size):
+                order = None
+                if shuffle:
+                    # torch.utils.data.RandomSampler: a seed from the global generator, then randperm from a generator of its own
+                    seed = int(torch.empty((), dtype=torch.int64).random_().item())
+                    g = torch.Generator(); g.manual_seed(seed)
+                    order = torch.randperm(len(ds), generator=g).tolist()
+                for segs in ds.batches(batch_size, order):
                     yield ([torch.from_numpy(s['graph_map']) for s in segs],
                            [torch.from_numpy(s['batch_variable_map']) for s in segs],
                            [torch.from_numpy(s['batch_function_map']) for s in segs],

@@ -42,6 +42,17 @@ class NeuralDecimator(nn.Module):
 
     def forward(self, init_state, message_state, sat_problem, is_training, active_mask=None):
         variable_state, function_state = message_state
+        if is_training and torch.is_grad_enabled():
+            # the differentiable cells of the training path (pdp_decimate.py:51-87)
+            from pdp.nn import train_ops as T
+            sign = sat_problem._edge_feature
+            cv, cf = self._variable_rnn_cell, self._function_rnn_cell
+            nv = T.GruCell.apply(torch.cat((variable_state, sign), 1), init_state[0], cv.weight_ih, cv.weight_hh, cv.bias_ih, cv.bias_hh)
+            nf = T.GruCell.apply(torch.cat((function_state, sign), 1), init_state[1], cf.weight_ih, cf.weight_hh, cf.bias_ih, cf.bias_hh)
+            if active_mask is not None:
+                mask = active_mask.reshape(-1).float()[sat_problem._batch_variable_map.long()][sat_problem._graph_map[0].long()].unsqueeze(1)
+                nv = mask * nv + (1 - mask) * init_state[0]; nf = mask * nf + (1 - mask) * init_state[1]
+            return nv, nf
         am = None if active_mask is None else active_mask.reshape(-1).contiguous()
         nat = sat_problem._native
         new_variable_state = nat.neural_gru(self._weights('v', self._variable_rnn_cell), variable_state.contiguous(),

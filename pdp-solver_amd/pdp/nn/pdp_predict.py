@@ -56,6 +56,15 @@ class NeuralPredictor(nn.Module):
         return self._head
 
     def forward(self, decimator_state, sat_problem, last_call=False):
+        if torch.is_grad_enabled() and decimator_state[0].requires_grad:
+            # the differentiable form of the training path (pdp_predict.py:49-91; trainer.py:28-29 for the head)
+            from pdp.nn import train_ops as T
+            em = decimator_state[2] if len(decimator_state) == 3 else None
+            agg = self._variable_aggregator.forward_train(torch.cat((decimator_state[0], sat_problem._edge_feature), 1), None, sat_problem, True, em)
+            c = self._variable_classifier
+            hid = T.LinearAct.apply(agg, c._layer1.weight, c._layer1.bias, 'relu')
+            out_act = 'tanh' if type(c).__name__ == 'PerceptronTanh' else 'sigmoid'
+            return T.LinearAct.apply(hid, c._layer2.weight, None, out_act), None
         if len(decimator_state) == 3:
             decimator_variable_state, _, edge_mask = decimator_state
             edge_mask = edge_mask.reshape(-1).contiguous()

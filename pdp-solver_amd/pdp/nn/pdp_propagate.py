@@ -38,8 +38,10 @@ class NeuralMessagePasser(nn.Module):
         self._mem_agg_hidden_dimension = mem_agg_hidden_dimension
 
     def forward(self, init_state, decimator_state, sat_problem, is_training, active_mask=None):
+        if is_training and torch.is_grad_enabled():
+            return self._forward_train(init_state, decimator_state, sat_problem, active_mask)
         if is_training and self._drop_out > 0:
-            raise native.NativeError("training (dropout) is out of scope of the native inference path")
+            raise native.NativeError("is_training with dropout needs gradients enabled (the differentiable training path)")
         if len(decimator_state) == 3:
             decimator_variable_state, decimator_function_state, edge_mask = decimator_state
             edge_mask = edge_mask.reshape(-1).contiguous()
@@ -56,6 +58,28 @@ class NeuralMessagePasser(nn.Module):
         variable_state = nat.neural_aggregate_edges(self._function_aggregator.native_weights(), False,
                                                     decimator_function_state.contiguous(), edge_mask, am, variable_state.contiguous())
         return variable_state, function_state
+
+    def _forward_train(self, init_state, decimator_state, sat_problem, active_mask):
+        "the differentiable sweep of the training path (pdp_propagate.py:47-95 with is_training=True): aggregators + dropout"
+        from pdp.nn import train_ops as T
+        if len(decimator_state) == 3:
+            dec_v, dec_f, edge_mask = decimator_state
+        else:
+            dec_v, dec_f = decimator_state
+            edge_mask = None
+        variable_state, function_state = init_state
+        sign = sat_problem._edge_feature
+        if active_mask is not None:
+            mask = active_mask.reshape(-1).float()[sat_problem._batch_variable_map.long()][sat_problem._graph_map[0].long()].unsqueeze(1)
+        fs = self._variable_aggregator.forward_train(torch.cat((dec_v, sign), 1), sign, sat_problem, True, edge_mask)
+        if active_mask is not None:
+            fs = mask * fs + (1 - mask) * function_state
+        fs = T.dropout(fs, self._drop_out, getattr(self, '_rng', 'torch'))
+        vs = self._function_aggregator.forward_train(torch.cat((dec_f, sign), 1), sign, sat_problem, False, edge_mask)
+        if active_mask is not None:
+            vs = mask * vs + (1 - mask) * variable_state
+        vs = T.dropout(vs, self._drop_out, getattr(self, '_rng', 'torch'))
+        return vs, fs
 
     def get_init_state(self, graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, randomized, batch_replication):
         "reference: pdp_propagate.py:97-108"

@@ -308,6 +308,11 @@ class PropagatorDecimatorSolverBase(nn.Module):
     # -----------------------------------------------------------------------------------------------------------
     def _update_solution(self, prediction, sat_problem):
         "solver.py:388-399"
+        if prediction[0] is not None and torch.is_grad_enabled() and prediction[0].requires_grad:
+            # training: the blend stays on the autograd graph (every variable is active there: no simplification, solver.py:332)
+            av = sat_problem._active_variables
+            variable_solution = av * prediction[0] + (1.0 - av) * sat_problem._solution.unsqueeze(1)
+            return variable_solution, prediction[1]
         if prediction[0] is not None:
             variable_solution = sat_problem._native.update_solution(prediction[0].reshape(-1).contiguous())
         else:

@@ -1,0 +1,149 @@
+"""Differentiable building blocks of the neural PDP solver for the training path (reference: what torch autograd derives for
+src/pdp/nn/util.py:51-77, src/pdp/nn/pdp_decimate.py:70-83, src/pdp/trainer.py:28-29 and src/pdp/nn/util.py:178-197 when
+``FactorGraphTrainerBase._train_batch`` calls ``loss.backward()``, src/pdp/factorgraph/base.py:149-182).
+
+Each ``torch.autograd.Function`` below pairs a forward entry point of libpdp_hip.so with its adjoint (csrc/pdp_train.hip).  PyTorch keeps
+the graph, accumulates the parameter gradients and runs the optimizer the caller hands to ``train()``; the arithmetic is native.
+"""
+
+import ctypes as C
+
+import torch
+
+from pdp import native
+
+ACT = {'none': 0, 'logsigmoid': 1, 'relu': 2, 'sigmoid': 3, 'tanh': 4}
+
+
+def _f(t):
+    return t.contiguous() if t is not None else None
+
+
+class LinearAct(torch.autograd.Function):
+    "y = act(x W^T + b): nn.Linear followed by an activation, on the fp32 matrix cores"
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        x, weight = _f(x), _f(weight)
+        R, K = x.shape
+        N = weight.shape[0]
+        y = torch.empty(R, N, dtype=torch.float32, device=x.device)
+        native.check(native.lib().pdp_train_linear(native.ptr(x, torch.float32), C.c_int64(R), C.c_int(K), C.c_int64(K), native.ptr(weight, torch.float32),
+                                                   native.ptr(_f(bias), torch.float32), C.c_int(N), C.c_int(ACT[act]), native.ptr(y), native._stream()))
+        ctx.save_for_backward(x, weight, y)
+        ctx.act, ctx.has_bias = act, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        dy = _f(dy)
+        R, K = x.shape
+        N = weight.shape[0]
+        dz = torch.empty_like(dy)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(weight)
+        db = torch.empty(N, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        native.check(native.lib().pdp_train_linear_backward(native.ptr(dy, torch.float32), native.ptr(y), native.ptr(x), C.c_int64(R), C.c_int(K), C.c_int64(K),
+                                                            native.ptr(weight), C.c_int(N), C.c_int(ACT[ctx.act]), native.ptr(dz), native.ptr(dx), C.c_int64(K),
+                                                            native.ptr(dw), native.ptr(db), native._stream()))
+        return dx, dw, db, None
+
+
+class RowAggregate(torch.autograd.Function):
+    """Deep-set aggregation over the rows of the factor graph (util.py:60-69): the ordered sum of the edge values of every variable
+    (by_variable) or clause; with include_self False every edge gets its row's sum minus its own value ([E, A]), else the rows ([rows, A])."""
+
+    @staticmethod
+    def forward(ctx, s, problem, by_variable, include_self):
+        s = _f(s)
+        A = s.shape[1]
+        L = native.lib()
+        rows = torch.empty(problem.V if by_variable else problem.F, A, dtype=torch.float32, device=s.device)
+        native.check(L.pdp_train_row_sum(problem._h, C.c_int(1 if by_variable else 0), native.ptr(s, torch.float32), C.c_int(A), native.ptr(rows), native._stream()))
+        ctx.problem, ctx.by_variable, ctx.include_self = problem, by_variable, include_self
+        if include_self:
+            return rows
+        out = torch.empty_like(s)
+        native.check(L.pdp_train_row_spread(problem._h, C.c_int(1 if by_variable else 0), native.ptr(rows), native.ptr(s), C.c_int(A), native.ptr(out), native._stream()))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = _f(dout)
+        p, bv = ctx.problem, C.c_int(1 if ctx.by_variable else 0)
+        A = dout.shape[1]
+        L = native.lib()
+        ds = torch.empty(p.E, A, dtype=torch.float32, device=dout.device)
+        if ctx.include_self:
+            native.check(L.pdp_train_row_spread(p._h, bv, native.ptr(dout, torch.float32), None, C.c_int(A), native.ptr(ds), native._stream()))
+        else:
+            rows = torch.empty(p.V if ctx.by_variable else p.F, A, dtype=torch.float32, device=dout.device)
+            native.check(L.pdp_train_row_sum(p._h, bv, native.ptr(dout, torch.float32), C.c_int(A), native.ptr(rows), native._stream()))
+            native.check(L.pdp_train_row_spread(p._h, bv, native.ptr(rows), native.ptr(dout), C.c_int(A), native.ptr(ds), native._stream()))
+        return ds, None, None, None
+
+
+class GruCell(torch.autograd.Function):
+    "torch.nn.GRUCell (gate order r, z, n) on the fp32 matrix cores"
+
+    @staticmethod
+    def forward(ctx, x, h, w_ih, w_hh, b_ih, b_hh):
+        x, h, w_ih, w_hh, b_ih, b_hh = [_f(t) for t in (x, h, w_ih, w_hh, b_ih, b_hh)]
+        R, Kx = x.shape
+        H = h.shape[1]
+        hnew = torch.empty_like(h)
+        saved = torch.empty(R, 4 * H, dtype=torch.float32, device=x.device)
+        scratch = torch.empty(R, 6 * H, dtype=torch.float32, device=x.device)
+        native.check(native.lib().pdp_train_gru(native.ptr(x, torch.float32), native.ptr(h, torch.float32), native.ptr(w_ih), native.ptr(w_hh), native.ptr(b_ih),
+                                                native.ptr(b_hh), C.c_int64(R), C.c_int(Kx), C.c_int(H), native.ptr(hnew), native.ptr(saved), native.ptr(scratch),
+                                                native._stream()))
+        ctx.save_for_backward(x, h, w_ih, w_hh, saved)
+        return hnew
+
+    @staticmethod
+    def backward(ctx, dhnew):
+        x, h, w_ih, w_hh, saved = ctx.saved_tensors
+        dhnew = _f(dhnew)
+        R, Kx = x.shape
+        H = h.shape[1]
+        dx, dh = torch.empty_like(x), torch.empty_like(h)
+        dw_ih, dw_hh = torch.empty_like(w_ih), torch.empty_like(w_hh)
+        db_ih = torch.empty(3 * H, dtype=torch.float32, device=x.device); db_hh = torch.empty_like(db_ih)
+        scratch = torch.empty(R, 7 * H, dtype=torch.float32, device=x.device)
+        native.check(native.lib().pdp_train_gru_backward(native.ptr(dhnew, torch.float32), native.ptr(saved), native.ptr(x), native.ptr(h), native.ptr(w_ih),
+                                                         native.ptr(w_hh), C.c_int64(R), C.c_int(Kx), C.c_int(H), native.ptr(dx), native.ptr(dh), native.ptr(dw_ih),
+                                                         native.ptr(dw_hh), native.ptr(db_ih), native.ptr(db_hh), native.ptr(scratch), native._stream()))
+        return dx, dh, dw_ih, dw_hh, db_ih, db_hh
+
+
+class SatLoss(torch.autograd.Function):
+    "energy loss of a prediction (SatLossEvaluator.forward, util.py:178-197) and its gradient with respect to the prediction"
+
+    @staticmethod
+    def forward(ctx, pred, problem, coeff, eps, sharpness):
+        p = _f(pred.reshape(-1))
+        out = problem.sat_loss(p, coeff, eps, sharpness)
+        ctx.save_for_backward(p)
+        ctx.problem, ctx.args, ctx.shape = problem, (coeff, eps, sharpness), pred.shape
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (p,) = ctx.saved_tensors
+        coeff, eps, sharpness = ctx.args
+        d = torch.empty_like(p)
+        native.check(native.lib().pdp_sat_loss_grad(ctx.problem._h, native.ptr(p, torch.float32), C.c_float(coeff), C.c_float(eps), C.c_int(int(sharpness)),
+                                                    C.c_float(1.0), native.ptr(d), native._stream()))
+        return (d * g).reshape(ctx.shape), None, None, None, None
+
+
+def dropout(x, p, rng):
+    """F.dropout(x, p, training=True) (pdp_propagate.py:80,91).  rng 'torch': the mask comes from the global CPU generator exactly as the
+    reference's --cpu_mode run draws it (the draw depends on the shape and p only); otherwise torch's device generator."""
+    if p <= 0:
+        return x
+    if rng == 'torch':
+        mask = torch.nn.functional.dropout(torch.ones(x.shape, dtype=torch.float32), p=p, training=True).to(x.device)
+        return x * mask
+    return torch.nn.functional.dropout(x, p=p, training=True)

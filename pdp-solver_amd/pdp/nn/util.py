@@ -5,7 +5,8 @@ src/pdp/nn/util.py): ``SatCNFEvaluator`` (:203-236), ``sparse_smooth_max`` / ``s
 ``sparse_argmax`` (:257-286), ``MessageAggregator`` (:11-77), ``PerceptronTanh`` (:242-251).  The
 reference evaluates these with torch sparse COO products and a dense [V x B] matrix; here each is one
 kernel launch over the batch's instance-local CSR layout (see csrc/pdp_ops.hip).
-``SatLossEvaluator`` / ``MultiLayerPerceptron`` are training-only and out of scope.
+``SatLossEvaluator.forward`` is differentiable with respect to the prediction (pdp/nn/train_ops.py::SatLoss); ``MultiLayerPerceptron``
+is not used by any solver of the reference and is not built.
 """
 
 import torch
@@ -56,6 +57,9 @@ class SatLossEvaluator(nn.Module):
         gs = global_step.detach().to(torch.float32).reshape(-1)[:1].cpu()
         coeff = float(torch.min(gs.pow(self._alpha), torch.tensor([float(max_coeff)])).item())     # util.py:181
         e = float(eps.reshape(-1)[0].item()) if torch.is_tensor(eps) else float(eps)
+        if torch.is_grad_enabled() and variable_prediction.requires_grad:
+            from pdp.nn import train_ops as T
+            return T.SatLoss.apply(variable_prediction, handle, coeff, e, int(loss_sharpness))
         return handle.sat_loss(variable_prediction.reshape(-1).contiguous(), coeff, e, int(loss_sharpness)).reshape(())
 
 
@@ -98,6 +102,22 @@ class MessageAggregator(nn.Module):
             self._native = native.AggregatorWeights(*[p.data for p in params], feature_dim=self._feature_dimension)
             self._native_key = key
         return self._native
+
+
+    def forward_train(self, state, feature, sat_problem, by_variable, edge_mask=None):
+        """The differentiable form (training; reference: util.py:51-77): ``state`` [E, input_dimension] already carries the appended edge
+        feature, ``feature`` [E, feature_dimension] (or None) is appended after the aggregation.  Every layer and the row aggregation is a
+        native forward / adjoint pair (pdp/nn/train_ops.py)."""
+        from pdp.nn import train_ops as T
+        s = T.LinearAct.apply(state, self._W1_m.weight, self._W1_m.bias, 'logsigmoid')
+        s = T.LinearAct.apply(s, self._W2_m.weight, None, 'logsigmoid')
+        if edge_mask is not None:
+            s = s * edge_mask
+        agg = T.RowAggregate.apply(s, sat_problem._native, by_variable, self._include_self_message)
+        if feature is not None:
+            agg = torch.cat((agg, feature), 1)
+        g = T.LinearAct.apply(agg, self._W1_a.weight, self._W1_a.bias, 'logsigmoid')
+        return T.LinearAct.apply(g, self._W2_a.weight, None, 'logsigmoid')
 
 
 class PerceptronTanh(nn.Module):

@@ -2,8 +2,8 @@
 
 The inference side of ``SatFactorGraphTrainer``: ``_build_graph`` (model_type -> solver class,
 trainer.py:48-99), ``_check_recurrence_termination`` (:150-162), ``_post_process_predictions`` (:125-148) and the test-mode
-metrics ``_compute_evaluation_metrics`` (:108-123: accuracy / recall errors of the clause check and the energy loss).  Training
-(``_compute_loss`` inside ``_train_batch``, backward, Adam) is out of scope.
+metrics ``_compute_evaluation_metrics`` (:108-123: accuracy / recall errors of the clause check and the energy loss), and the training
+loss ``_compute_loss`` (:100-106) used by ``FactorGraphTrainerBase._train_batch``.
 """
 
 import numpy as np
@@ -56,11 +56,20 @@ class SatFactorGraphTrainer(FactorGraphTrainerBase):
                                                            persistent=config.get('persistent', True), **common)
         elif t in ('np-nd-np', 'np-d-np', 'p-nd-np'):
             model = solver.build_neural_solver(self._device, config, Perceptron, common)
+            if hasattr(model._propagator, '_drop_out'):
+                model._propagator._rng = rng                   # where the training path's dropout masks come from
         else:
             raise KeyError("unknown model_type %r" % (t,))
         if config.get('verbose'):
             self._logger.info("The model parameter count is %d." % model.parameter_count())
         return [model]
+
+    def _compute_loss(self, model, loss, prediction, label, graph_map, batch_variable_map, batch_function_map, edge_feature, meta_data):
+        "the energy of the prediction (reference: trainer.py:100-106); differentiable with respect to the prediction"
+        return self._loss_evaluator(variable_prediction=prediction[0], label=label, graph_map=graph_map, batch_variable_map=batch_variable_map,
+                                    batch_function_map=batch_function_map, edge_feature=edge_feature, meta_data=meta_data,
+                                    global_step=model._global_step, eps=self._eps, max_coeff=self._max_coeff,
+                                    loss_sharpness=self._config['loss_sharpness'], sat_problem=getattr(model, '_last_problem', None))
 
     def _compute_evaluation_metrics(self, model, evaluator, prediction, label, graph_map, batch_variable_map, batch_function_map,
                                     edge_feature, meta_data):

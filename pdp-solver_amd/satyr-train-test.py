@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Test mode of the PDP trainer/tester (reference: src/satyr-train-test.py with ``-t``).
+"""The PDP trainer / tester (reference: src/satyr-train-test.py).
 
-``python satyr-train-test.py <config.yaml> -t [-l best|last] [-b R]`` evaluates the configured solver on the labelled JSON datasets of
-``test_path`` and prints accuracy / recall per dataset (plus the two result CSV files next to a dataset directory), like the
-reference.  Training (the mode without ``-t``) is out of scope of this build and is rejected; ``-c`` (CPU mode) too -- the hot path
-runs on the MI355X only.
+``python satyr-train-test.py <config.yaml> [-t] [-l best|last] [-r] [-g] [-b R]``: without ``-t`` the configured neural solver
+(model_type np-nd-np) is trained -- Adam on the energy loss, from the JSON training set or, with ``-g``, from the configured CNF
+generator -- with a validation pass per epoch and best / last checkpoints under ``model_path``; then (and with ``-t`` only) the solver
+is evaluated on the labelled JSON datasets of ``test_path``: accuracy / recall per dataset plus the two result CSV files next to a
+dataset directory, like the reference.  ``-c`` (CPU mode) is rejected: the hot path runs on the MI355X only.
 """
 
 import argparse
@@ -30,17 +31,47 @@ def write_results(result_list, file_path, column):
             writer.writerow([row[0], row[1][1, 0] if column == 1 else row[2]])
 
 
+def make_generator(config):
+    "the CNF generator a training run draws its examples from (reference: satyr-train-test.py:85-95)"
+    from pdp import cnf_generators as G
+    if config['generator'] == 'modular':
+        return G.ModularCNFGenerator(config['min_k'], config['min_n'], config['max_n'], config['min_q'], config['max_q'], config['min_c'],
+                                     config['max_c'], config['min_alpha'], config['max_alpha'])
+    if config['generator'] == 'v-modular':
+        return G.VariableModularCNFGenerator(config['min_k'], config['max_k'], config['min_n'], config['max_n'], config['min_q'], config['max_q'],
+                                             config['min_c'], config['max_c'], config['min_alpha'], config['max_alpha'])
+    return G.UniformCNFGenerator(config['min_n'], config['max_n'], config['min_k'], config['max_k'], config['min_alpha'], config['max_alpha'])
+
+
 def run(random_seed, config_file, is_training, load_model, cpu, reset_step, use_generator, batch_replication):
-    if is_training:
-        raise SystemExit("satyr-train-test.py: training is out of scope of this build (SURVEY.md section 8 f3); use -t for the test mode")
-    np.random.seed(random_seed)
-    torch.manual_seed(random_seed)
+    if not use_generator:
+        np.random.seed(random_seed)
+        torch.manual_seed(random_seed)
     with open(config_file, 'r') as f:
         config = yaml.safe_load(f)
     logging.basicConfig(level=logging.DEBUG, format='[%(levelname)s] %(asctime)s - %(name)s: %(message)s')
     logger = logging.getLogger(config['model_name'] + ' (' + str(config['version']) + ')')
-    trainer = SatFactorGraphTrainer(config=config, use_cuda=not cpu, logger=logger)
+    for key in ('train_path', 'validation_path'):
+        if is_training and not isinstance(config.get(key), list):
+            config[key] = [os.path.join(config[key], f) for f in os.listdir(config[key])
+                           if os.path.isfile(os.path.join(config[key], f)) and f.endswith('.json')]
     base = os.path.join(os.path.relpath(config['model_path']), config['model_name'], str(config['version']))
+    best_base, last_base = os.path.join(base, 'best'), os.path.join(base, 'last')
+    trainer = SatFactorGraphTrainer(config=config, use_cuda=not cpu, logger=logger)
+    if is_training:
+        if config['model_type'] != 'np-nd-np':
+            raise SystemExit("satyr-train-test.py: training is built for model_type np-nd-np (the differentiable path of the fully neural "
+                             "solver); %r has no trainable native path" % (config['model_type'],))
+        import torch.optim as optim
+        for d in (best_base, last_base):
+            os.makedirs(d, exist_ok=True)
+        if config['verbose']:
+            logger.info("Starting the training phase...")
+        trainer.train(train_list=config['train_path'], validation_list=config['validation_path'],
+                      optimizer=optim.Adam(trainer.get_parameter_list(), lr=config['learning_rate'], weight_decay=config['weight_decay']),
+                      last_export_path_base=last_base, best_export_path_base=best_base, metric_index=config['metric_index'],
+                      load_model=load_model, reset_step=reset_step, generator=make_generator(config) if use_generator else None,
+                      train_epoch_size=config.get('train_epoch_size', 0))
     import_path_base = os.path.join(base, load_model) if load_model in ('last', 'best') else None
     if config['verbose']:
         logger.info("Starting the test phase...")

@@ -858,6 +858,92 @@ def gen_neural_long():
 
 
 
+# ---- G. training path (f3) ---------------------------------------------------------------------------------------------------------
+
+def train_cfg(**kw):
+    cfg = base_cfg('np-nd-np', hidden_dim=32, error_dim=3, exploration=0.1, loss_sharpness=5, dropout=0.0, randomized=True,
+                   train_inner_recurrence_num=1, train_outer_recurrence_num=3, clip_norm=0.65, batch_size=6, epoch_num=2, repetition_num=1,
+                   train_batch_limit=4000000, test_batch_limit=40000000, max_cache_size=100000, test_recurrence_num=5, local_search_iteration=0)
+    cfg['lambda'] = 0.9
+    cfg.update(kw)
+    return cfg
+
+
+def gen_train():
+    """The training path of the reference (FactorGraphTrainerBase._train_batch / train, base.py:149-182, 311-404) on np-nd-np, hidden 32:
+    (a) one batch: the loss, the gradient of every parameter after loss.backward() (before clipping), and the parameters after the
+    clipped Adam step; (b) a two-epoch train() call with dropout 0.2 on a 12-instance file (shuffled loader, validation pass):
+    losses and validation errors per epoch and the final parameters."""
+    import torch.optim as optim
+    lines = make_lines([(18, 60, (3,))] * 4 + [(14, 40, (2, 3, 4))] * 2, seed0=6100)
+    gm, bvm, bfm, ef, lab, misc = batch_tensors(lines)
+    cfg = train_cfg()
+    tr, m = build(cfg, seed=777)
+    m._global_step.data = torch.tensor([3.0])
+    out = problem_arrays(gm, bvm, bfm, ef)
+    out['label'] = np_(lab)
+    for k, v in flat_state_dict(m).items():
+        out[k] = v
+    with open(os.path.join(HERE, 'state_dict_alias_map_train.json'), 'w') as f:
+        json.dump(alias_map(m), f, indent=0, sort_keys=True)
+    # manual backward (same statements as _train_batch) for the raw gradients
+    torch.manual_seed(31)
+    lam = torch.tensor([cfg['lambda']], dtype=torch.float32)
+    state = m.get_init_state(gm, bvm, bfm, ef, None, cfg['randomized'])
+    loss = torch.zeros(1)
+    step_losses = []
+    for t in range(cfg['train_outer_recurrence_num']):
+        prediction, state = m(init_state=state, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None,
+                              is_training=True, iteration_num=cfg['train_inner_recurrence_num'])
+        lt = tr._compute_loss(model=m, loss=tr._loss, prediction=prediction, label=lab, graph_map=gm, batch_variable_map=bvm,
+                              batch_function_map=bfm, edge_feature=ef, meta_data=None)
+        step_losses.append(float(lt))
+        if t == 0:
+            out['first_prediction'] = np_(prediction[0][:, 0])
+        loss = loss + lt * lam.pow(float(cfg['train_outer_recurrence_num'] - t - 1))
+    loss.backward()
+    out['loss'] = np.array([float(loss)], dtype=np.float32)
+    out['step_losses'] = np.array(step_losses, dtype=np.float32)
+    for name, prm in m.named_parameters(remove_duplicate=False):          # every alias is listed: keep the canonical names
+        if prm.grad is not None and '_module_list' not in name and name.startswith(('_propagator.', '_decimator.', '_predictor.')):
+            out['g__' + name.replace('.', '__')] = np_(prm.grad)
+    # the real _train_batch on a fresh copy of the same model: parameters after the clipped Adam step
+    tr2, m2 = build(cfg, seed=777)
+    m2._global_step.data = torch.tensor([3.0])
+    opt = optim.Adam(tr2.get_parameter_list(), lr=1e-3, weight_decay=1e-10)
+    total = np.zeros(1, dtype=np.float32)
+    torch.manual_seed(31)
+    tr2._train_batch(total, opt, gm, bvm, bfm, ef, None, lab)
+    out['train_batch_total_loss'] = total.copy()
+    for k, v in flat_state_dict(m2).items():
+        out['after__' + k] = v
+    save('train_batch', **out)
+
+    # (b) train(): two epochs, dropout, shuffled loader
+    tl = make_lines([(16, 50, (3,))] * 8 + [(12, 30, (2, 3, 4))] * 4, seed0=6200)
+    with open(os.path.join(HERE, 'train_small.json'), 'w') as f:
+        f.write("\n".join(tl) + "\n")
+    cfg3 = train_cfg(dropout=0.2, max_cache_size=1)      # the reference's collate adds the batch offsets INTO the cached item arrays (dataset.py:172-173):
+                                                         # a cached item is wrong from its second use on; a one-item cache never serves a stale one here
+    tr3, m3 = build(cfg3, seed=778)
+    tr3._num_cores = 0
+    opt3 = optim.Adam(tr3.get_parameter_list(), lr=1e-3, weight_decay=1e-10)
+    torch.manual_seed(41); np.random.seed(41)
+    path = os.path.join(HERE, 'train_small.json')
+    res = {}
+    for k, v in flat_state_dict(m3).items():
+        res[k] = v
+    _, errors, losses = tr3.train([path], [path], opt3, last_export_path_base=None, best_export_path_base=None, metric_index=0)
+    res['errors'] = errors; res['losses'] = losses
+    res['global_step'] = np_(m3._global_step)
+    for k, v in flat_state_dict(m3).items():
+        res['after__' + k] = v
+    res['next_rand'] = torch.rand(4).numpy()
+    save('train_run', **res)
+    print('train_batch loss', float(loss), 'step losses', step_losses, '| train(): losses', losses.reshape(-1), 'errors', errors[:, 0, :, 0])
+
+
+
 def gen_generators():
     """The reference's CNF generators (src/pdp/generator.py) under fixed numpy seeds: uniform, modular and variable-modular,
     generate() and generate_complete() (the variable-modular generate_complete cannot run in the reference, App. B-11)."""
@@ -972,3 +1058,5 @@ if __name__ == '__main__':
         gen_config4_mixed()
     if 'neural_long' in what:
         gen_neural_long()
+    if 'train' in what:
+        gen_train()

@@ -291,3 +291,50 @@ def test_converter_subsumption_equals_reference(tmp_path):
     plain = {json.loads(l)[4][0]: l for l in open(os.path.join(REPO, 'tests', 'golden', 'dimacs_subsume.plain.jsonl')).read().split('\n') if l.strip()}
     assert got == ref and len(ref) == 4
     assert all(json.loads(ref[k])[0][1] < json.loads(plain[k])[0][1] for k in ref)       # every file really lost clauses
+
+
+def test_training_loader_follows_torch_dataloader_draws(tmp_path):
+    """The training loader (shuffle=True) consumes the global torch CPU generator like torch's DataLoader + RandomSampler do (one base
+    seed per iterator, then the sampler's seed for a generator of its own) and visits the items in the sampler's order; with a CNF
+    generator every item is a fresh generate() instance and the data set has epoch_size items (reference: dataset.py:84-104, 189-211)."""
+    import torch
+    import torch.utils.data as tud
+    from pdp import generator as gen
+    from pdp import cnf_generators
+    from pdp.factorgraph.dataset import FactorGraphDataset
+    lines = []
+    for i in range(11):
+        lines.append(gen.json_line(12, gen.uniform_ksat(12, 30, 3, np.random.RandomState(50 + i)), label=i % 2, name='i%d' % i))
+    path = tmp_path / 'train.json'
+    path.write_text("\n".join(lines) + "\n")
+
+    class Idx(tud.Dataset):
+        def __len__(self): return 11
+        def __getitem__(self, i): return i
+
+    for epoch_pair in range(2):
+        torch.manual_seed(123 + epoch_pair)
+        ref_order = []
+        for _ in range(2):                                   # two epochs = two iterators over the same DataLoader
+            ref_order += [int(x) for batch in tud.DataLoader(Idx(), batch_size=4, shuffle=True, num_workers=0) for x in batch]
+        ref_next = torch.rand(3)
+        torch.manual_seed(123 + epoch_pair)
+        loader = FactorGraphDataset.get_loader(str(path), limit=10 ** 9, hidden_dim=3, batch_size=4, shuffle=True)
+        got = []
+        for _ in range(2):
+            for data in loader:
+                got += [int(md[0][1:]) for seg in data[6] for md in seg]
+        assert got == ref_order
+        assert torch.equal(torch.rand(3), ref_next)
+    np.random.seed(5)
+    g = cnf_generators.UniformCNFGenerator(6, 12, 2, 4, 2.0, 4.0)
+    loader = FactorGraphDataset.get_loader('', limit=10 ** 9, hidden_dim=3, batch_size=4, shuffle=True, generator=g, epoch_size=10)
+    sizes = [len(seg) for data in loader for seg in data[6]]
+    assert sum(sizes) == 10 and len(loader.dataset) == 10
+    np.random.seed(5)
+    g2 = cnf_generators.UniformCNFGenerator(6, 12, 2, 4, 2.0, 4.0)
+    first = g2.generate()
+    np.random.seed(5)
+    g3 = cnf_generators.UniformCNFGenerator(6, 12, 2, 4, 2.0, 4.0)
+    data = next(iter(FactorGraphDataset.get_loader('', limit=10 ** 9, hidden_dim=3, batch_size=1, shuffle=False, generator=g3, epoch_size=1)))
+    assert data[0][0].shape[1] == np.asarray(first[2]).shape[1] and int(data[1][0].numel()) == int(first[0])
