@@ -187,6 +187,8 @@ typedef struct pdp_solve_args {
                                    * batch-global minimum of sparse_max / sparse_argmax is taken as 0 and a NaN survey stops the decimation
                                    * of its own instance only (in the reference it stops the whole batch).  Never
                                    * returns PDP_ERR_SPECULATION.  LDS-resident solver only. */
+    int32_t hbm_instances_host;   /* out: instances of the batch that did not fit the LDS and ran on the HBM-resident kernel inside the same chunk
+                                   * loop (per-instance routing; 0 when every instance fits, the batch size when none does) */
 } pdp_solve_args;
 int pdp_sp_solve(pdp_problem *p, pdp_solve_args *args, void *stream);
 

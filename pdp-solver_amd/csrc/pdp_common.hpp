@@ -120,6 +120,13 @@ struct pdp_problem {
     float *res_prev_slots;
     char *res_ctl; size_t res_ctl_bytes;
     hipEvent_t *res_events; int res_events_n;       // 4 per chunk, created on demand (pdp_solve_args.time_kernels)
+    // per-instance routing of the persistent solver: instances whose image fits the LDS / the others (HBM-resident kernel, same chunk loop)
+    int32_t *res_fit_list, *res_big_list;            // device, [res_nfit] / [res_nbig] instance ids in ascending order
+    uint8_t *res_is_big;                             // device, [B]
+    int res_nfit, res_nbig, res_fit_n, res_fit_m, res_fit_e;   // counts; largest fitting instance
+    char *res_big_snap; size_t res_big_snap_bytes;   // chunk-entry state of the big instances (the NaN-poison replay restarts them from it)
+    uint32_t *team_ws;          // barrier counters and reduction mailboxes of the workgroup teams (k_sp_solve<NT, true>)
+    hipStream_t res_side_stream; hipEvent_t res_side_ev[2];   // the big instances' launches overlap the LDS-resident kernel on a stream of their own
     float *nws[4]; size_t nws_floats[4];             // neural workspaces (grow on demand)
 };
 
@@ -235,6 +242,8 @@ struct OpMaxNan { __device__ float operator()(float a, float b) const { return p
 struct OpMinNan { __device__ float operator()(float a, float b) const { return pdp_min(a, b); } };
 struct OpAddI { __device__ int operator()(int a, int b) const { return a + b; } };
 struct OpOrI { __device__ int operator()(int a, int b) const { return a | b; } };
+struct OpMinI { __device__ int operator()(int a, int b) const { return a < b ? a : b; } };
+struct OpMaxI { __device__ int operator()(int a, int b) const { return a > b ? a : b; } };
 
 // arg-max with torch.argmax semantics: larger value wins, NaN is maximal, first index wins ties.
 struct ArgPair { float v; int i; };
@@ -317,3 +326,16 @@ __device__ __forceinline__ unsigned long long block_max_u64(unsigned long long k
 
 // number of LDS scratch floats the primitives need
 #define PDP_RED_SCRATCH 64
+
+// ---- execution team of a per-instance routine ---------------------------------------------------------------------
+// The per-instance device routines (pdp_device.hpp) are written against these six calls.  For every instance view but
+// TeamView the team IS the workgroup and they are the plain block primitives; a TeamView (pdp_solve.hip) spreads one big
+// instance over several workgroups and overloads them with device-scope versions.
+template <class I> __device__ __forceinline__ int team_tid(const I &) { return threadIdx.x; }
+template <class I> __device__ __forceinline__ int team_nt(const I &) { return blockDim.x; }
+template <class I> __device__ __forceinline__ void team_sync(const I &) { __syncthreads(); }
+template <class I> __device__ __forceinline__ int team_any(const I &, int x) { return __syncthreads_or(x); }
+template <class I, typename T, typename Op>
+__device__ __forceinline__ T team_reduce(const I &, T v, Op op, T identity, T *scratch) { return block_reduce(v, op, identity, scratch); }
+template <class I>
+__device__ __forceinline__ ArgPair team_argmax(const I &, float v, int i, float *sv, int *si) { return block_argmax(v, i, sv, si); }

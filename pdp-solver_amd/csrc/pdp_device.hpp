@@ -1,7 +1,8 @@
 // pdp_device.hpp -- per-instance device routines, executed cooperatively by one workgroup.
 // They are templated on the instance view `I` (field names of struct Inst) so the same code runs on an
-// HBM-resident view (int32 ids, step-wise kernels) and on an LDS-resident view (u16 ids, persistent
-// solver).  Every routine must be called by all threads of the workgroup and leaves it synchronised.
+// HBM-resident view (int32 ids, step-wise kernels), on an LDS-resident view (u16 ids, persistent solver) and on a
+// TeamView (one big instance spread over several workgroups).  Thread ids, barriers and reductions go through the
+// team_* calls of pdp_common.hpp; every routine must be called by all threads of the team and leaves it synchronised.
 //
 // Arithmetic mirrors the reference statement by statement; all quantities here are small integers
 // held in fp32 by the reference, so int32 arithmetic is exact and order-independent.
@@ -45,9 +46,9 @@ struct SimplifyScratch {
 template <class I>
 __device__ void d_set_variable_core(const I &in, const SimplifyScratch &s)
 {
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = team_tid(in), nt = team_nt(in);
     for (int v = tid; v < in.n; v += nt) s.assign[v] = s.assign[v] * in.av[v];
-    __syncthreads();
+    team_sync(in);
     for (int c = tid; c < in.m; c += nt) {
         float input_num = 0.0f, function_eval = 0.0f;
         for (int k = in.f_ptr[c]; k < in.f_ptr[c + 1]; ++k) {
@@ -59,20 +60,20 @@ __device__ void d_set_variable_core(const I &in, const SimplifyScratch &s)
         const float deact = ((function_eval > -input_num) ? 1.0f : 0.0f) * in.af[c];
         s.flag_f2[c] = (deact == 1.0f) ? 1 : 0;
     }
-    __syncthreads();
+    team_sync(in);
     for (int v = tid; v < in.n; v += nt) {
         const float a = s.assign[v];
         if (pdp_abs(a) == 1.0f) { in.av[v] = 0.0f; in.sol[v] = (a + 1.0f) / 2.0f; }
     }
     for (int c = tid; c < in.m; c += nt) if (s.flag_f2[c]) in.af[c] = 0.0f;
-    __syncthreads();
+    team_sync(in);
 }
 
 // reference: SATProblem._propagate_single_clauses (solver.py:228-273)
 template <class I>
 __device__ void d_unit_propagate(const I &in, const SimplifyScratch &s, float *is_sat_b)
 {
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = team_tid(in), nt = team_nt(in);
     for (;;) {
         int any = 0;
         for (int c = tid; c < in.m; c += nt) {
@@ -82,7 +83,7 @@ __device__ void d_unit_propagate(const I &in, const SimplifyScratch &s, float *i
             s.flag_f[c] = (single == 1.0f) ? 1 : 0;
             any |= s.flag_f[c];
         }
-        any = __syncthreads_or(any);
+        any = team_any(in, any);
         if (!any) break;
         int nconf = 0;
         for (int v = tid; v < in.n; v += nt) {
@@ -97,7 +98,7 @@ __device__ void d_unit_propagate(const I &in, const SimplifyScratch &s, float *i
             const int aev = ev < 0 ? -ev : ev;
             if (aev != inum && in.av[v] == 1.0f) nconf++;
         }
-        nconf = block_reduce(nconf, OpAddI(), 0, s.red);
+        nconf = team_reduce(in, nconf, OpAddI(), 0, s.red);
         if (nconf >= 1) {
             if (tid == 0) *is_sat_b = 0.0f;
             // the reference compares (count * active) with == 1 (solver.py:257,261)
@@ -105,7 +106,7 @@ __device__ void d_unit_propagate(const I &in, const SimplifyScratch &s, float *i
                 for (int c = tid; c < in.m; c += nt) if (in.af[c] == 1.0f) in.af[c] = 0.0f;
                 for (int v = tid; v < in.n; v += nt) if (in.av[v] == 1.0f) in.av[v] = 0.0f;
             }
-            __syncthreads();
+            team_sync(in);
         }
         for (int v = tid; v < in.n; v += nt) {
             const int inum = s.deg[v], ev = s.sdeg[v];
@@ -114,7 +115,7 @@ __device__ void d_unit_propagate(const I &in, const SimplifyScratch &s, float *i
             s.assign[v] = (float)((ev > 0) - (ev < 0)) * assigned;
         }
         for (int c = tid; c < in.m; c += nt) if (s.flag_f[c]) in.af[c] = 0.0f;
-        __syncthreads();
+        team_sync(in);
         d_set_variable_core(in, s);
     }
 }
@@ -123,7 +124,7 @@ __device__ void d_unit_propagate(const I &in, const SimplifyScratch &s, float *i
 template <class I>
 __device__ void d_peel(const I &in, const SimplifyScratch &s)
 {
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = team_tid(in), nt = team_nt(in);
     for (int v = tid; v < in.n; v += nt) {
         int d = 0, sd = 0;
         for (int k = in.v_ptr[v]; k < in.v_ptr[v + 1]; ++k) {
@@ -133,7 +134,7 @@ __device__ void d_peel(const I &in, const SimplifyScratch &s)
         }
         s.deg[v] = d; s.sdeg[v] = sd;
     }
-    __syncthreads();
+    team_sync(in);
     for (;;) {
         int any = 0;
         for (int v = tid; v < in.n; v += nt) {
@@ -142,14 +143,14 @@ __device__ void d_peel(const I &in, const SimplifyScratch &s)
             s.flag_v[v] = single ? 1 : 0;
             any |= single;
         }
-        any = __syncthreads_or(any);
+        any = team_any(in, any);
         if (!any) break;
         for (int c = tid; c < in.m; c += nt) {
             int acc = 0;
             for (int k = in.f_ptr[c]; k < in.f_ptr[c + 1]; ++k) acc += s.flag_v[in.e_var[in.f_edges[k]]];
             s.flag_f[c] = (acc > 0 && in.af[c] == 1.0f) ? 1 : 0;
         }
-        __syncthreads();
+        team_sync(in);
         for (int v = tid; v < in.n; v += nt) {
             int dd = 0, sd = 0;
             for (int k = in.v_ptr[v]; k < in.v_ptr[v + 1]; ++k) {
@@ -165,10 +166,10 @@ __device__ void d_peel(const I &in, const SimplifyScratch &s)
             }
             s.deg[v] -= dd; s.sdeg[v] -= sd;
         }
-        __syncthreads();
+        team_sync(in);
         for (int v = tid; v < in.n; v += nt) if (s.flag_v[v]) in.av[v] = 0.0f;
         for (int c = tid; c < in.m; c += nt) if (s.flag_f[c]) in.af[c] = 0.0f;
-        __syncthreads();
+        team_sync(in);
     }
 }
 
@@ -186,7 +187,7 @@ template <class I>
 __device__ int d_cnf_sat_count(const I &in, const float *pred /*[n]*/, int *red)
 {
     int cnt = 0;
-    for (int c = threadIdx.x; c < in.m; c += blockDim.x) {
+    for (int c = team_tid(in); c < in.m; c += team_nt(in)) {
         float clause = 0.0f;
         for (int k = in.f_ptr[c]; k < in.f_ptr[c + 1]; ++k) {
             const int e = in.f_edges[k];
@@ -197,7 +198,7 @@ __device__ int d_cnf_sat_count(const I &in, const float *pred /*[n]*/, int *red)
         }
         cnt += (clause > 0.0f) ? 1 : 0;
     }
-    return block_reduce(cnt, OpAddI(), 0, red);
+    return team_reduce(in, cnt, OpAddI(), 0, red);
 }
 
 // per-instance part of util.sparse_max (util.py:267-275): max over the dense column of
@@ -206,8 +207,8 @@ template <class I>
 __device__ float d_instance_max(const I &in, const float *x /*[n]*/, float gmin, bool other_rows, float *red)
 {
     float t = -PDP_INF;
-    for (int v = threadIdx.x; v < in.n; v += blockDim.x) t = pdp_max(t, (x[v] - gmin) + 1.0f);
-    t = block_reduce(t, OpMaxNan(), -PDP_INF, red);
+    for (int v = team_tid(in); v < in.n; v += team_nt(in)) t = pdp_max(t, (x[v] - gmin) + 1.0f);
+    t = team_reduce(in, t, OpMaxNan(), -PDP_INF, red);
     if (other_rows) t = pdp_max(t, 0.0f);
     return (t + gmin) - 1.0f;
 }
@@ -217,11 +218,11 @@ template <class I>
 __device__ int d_instance_argmax(const I &in, const float *x /*[n]*/, float gmin, float *redf, int *redi)
 {
     float bv = 0.0f; int bi = -1;
-    for (int v = threadIdx.x; v < in.n; v += blockDim.x) {
+    for (int v = team_tid(in); v < in.n; v += team_nt(in)) {
         const float t = (x[v] - gmin) + 1.0f;
         if (arg_better(t, v, bv, bi)) { bv = t; bi = v; }
     }
-    return block_argmax(bv, bi, redf, redi).i;
+    return team_argmax(in, bv, bi, redf, redi).i;
 }
 
 // per-variable smooth max (util.sparse_smooth_max util.py:282-286) of an edge vector

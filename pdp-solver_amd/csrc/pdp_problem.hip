@@ -313,8 +313,10 @@ extern "C" int pdp_problem_destroy(pdp_problem *p)
     if (p->solve_blob) pdp_dev_free(p->solve_blob);
     if (p->solve_host) (void)hipHostFree(p->solve_host);
     if (p->solve_extra_v) pdp_dev_free(p->solve_extra_v);
-    void *res[] = {p->res_stat_off, p->res_stat, p->res_dyn[0], p->res_dyn[1], p->res_prev_slots, p->res_ctl};
+    void *res[] = {p->res_stat_off, p->res_stat, p->res_dyn[0], p->res_dyn[1], p->res_prev_slots, p->res_ctl, p->res_fit_list, p->res_big_list, p->res_is_big, p->res_big_snap};
     for (void *q : res) if (q) pdp_dev_free(q);
+    if (p->team_ws) pdp_dev_free(p->team_ws);
+    if (p->res_side_stream) { (void)hipStreamDestroy(p->res_side_stream); for (int i = 0; i < 2; ++i) (void)hipEventDestroy(p->res_side_ev[i]); }
     for (int i = 0; i < p->res_events_n; ++i) (void)hipEventDestroy(p->res_events[i]);
     free(p->res_events);
     for (int i = 0; i < 4; ++i) if (p->nws[i]) pdp_dev_free(p->nws[i]);

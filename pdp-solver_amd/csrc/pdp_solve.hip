@@ -17,6 +17,7 @@
 #include "pdp_device.hpp"
 #include <stdlib.h>
 #include <vector>
+#include <type_traits>
 
 #define ST(s) ((hipStream_t)(s))
 
@@ -73,6 +74,17 @@ struct SolveParams {
     float *frc_out;             //            a poison replay must not see what pass 1 left behind)
     const float *coins;         // Reinforce: [T of the call] the shared coin of every iteration (pdp_decimate.py:218), drawn by the caller
     float dprob;                // Reinforce: decimation probability
+    // per-instance routing (mixed batches): the LDS-resident kernel runs the instances of fit_list, the HBM-resident kernel those of
+    // big_list, both under the device-side control blocks of the chunk
+    const int32_t *fit_list;    // NULL: instance = blockIdx.x
+    const int32_t *big_list;    // HBM-resident kernel: NULL: instance = blockIdx.x
+    int hbm_device_ctl;         // HBM-resident kernel: 1 = stop / poison / replay decisions come from ctl / call (else from the host: poison_from)
+    int hbm_replay;             // HBM-resident kernel under device control: this launch is the replay pass
+    uint32_t *w_perm_zero, *w_iters_run, *w_violation;   // HBM-resident kernel: where its control words go (pv.flags slots, or the chunk's SolveCtl)
+    // teams (k_sp_solve<NT, true>): team_size workgroups per instance, team_count instances, numbered slot-minor over team_slots
+    int team_size, team_count, team_slots;
+    int team_no_xcd;            // debugging: always take the agent-scope barrier
+    uint32_t *team_ws;          // [team_count][PDP_TEAM_WORDS], zeroed before every launch
 };
 
 // Device-side control of the chunked persistent solve: the host enqueues every launch of a call up front and reads
@@ -126,62 +138,185 @@ __device__ __forceinline__ T *carve(unsigned char *&p, size_t count)
     return r;
 }
 
-template <class IT, bool LDS>
-__global__ void __launch_bounds__(LDS ? 512 : 256) k_sp_solve(PView pv, SolveParams sp)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ float redf[PDP_RED_SCRATCH];
-    __shared__ int redi[PDP_RED_SCRATCH];
-    __shared__ int sh_flag[4];
+// One big instance spread over `size` workgroups (the team): thread ids run over the whole team, barriers and reductions
+// are device-scope.  Everything a team barrier orders lives in HBM (the HBM-resident view keeps no instance state in LDS).
+struct TeamView : SView<int32_t> {
+    int rank, size;             // this workgroup's place in the team
+    int same_xcd;               // every workgroup of the team reported the same XCC id (checked at kernel start)
+    uint32_t *bar;              // arrival counter, zeroed before the launch; it only grows: barrier k is complete at k * size arrivals
+    uint32_t *box;              // [2][size][4] reduction mailboxes, alternating with the parity of the barrier they ride on
+    mutable uint32_t epoch;     // team barriers passed (identical on every thread of the team)
+    uint32_t *lds;              // [PDP_TEAM_MAX * 4] LDS words the mailbox reads are staged in
+};
+#define PDP_TEAM_MAX 32
+#define PDP_TEAM_WORDS (32 + 2 * PDP_TEAM_MAX * 4)      // words of team workspace per instance: the counter on a 128 B line of its own, then the mailboxes
 
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const Inst G = load_inst(pv, blockIdx.x);
+__device__ __forceinline__ int team_tid(const TeamView &t) { return t.rank * (int)blockDim.x + (int)threadIdx.x; }
+__device__ __forceinline__ int team_nt(const TeamView &t) { return t.size * (int)blockDim.x; }
+// Team barrier.  Workgroups on DIFFERENT XCDs only see each other's stores through agent-scope release / acquire fences, which
+// write back and invalidate the XCD's whole L2 -- tens of microseconds next to a kernel that streams instance records.  The
+// launch numbers the workgroups so that a team lands on ONE XCD (k_sp_solve), every team verifies that at its first barrier,
+// and then the shared L2 is the point of coherence: a store is visible once it left the write-through vector cache
+// (s_waitcnt vmcnt(0)), and a reader only has to drop its CU's vector cache (buffer_inv).
+__device__ __forceinline__ void team_sync(const TeamView &t)
+{
+    if (t.size == 1) { __syncthreads(); return; }
+    if (t.same_xcd) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    t.epoch += 1;
+    if (threadIdx.x < PDP_WAVE) {
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(t.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t target = t.epoch * (uint32_t)t.size;
+            while (__hip_atomic_load(t.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        }
+        // the vector cache belongs to the CU, i.e. to the whole workgroup: one wave drops it for everybody (sixteen waves doing it
+        // cost ~7 us per barrier)
+        if (t.same_xcd) asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (!t.same_xcd) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+// A mailbox written for the barrier of epoch e is read right after that barrier; the next writer of the same half has passed
+// barrier e + 1, which every workgroup only reaches after its reads.
+__device__ __forceinline__ uint32_t *team_box(const TeamView &t) { return t.box + (size_t)(t.epoch & 1u) * t.size * 4; }
+__device__ __forceinline__ void box_put(uint32_t *w, uint32_t v) { __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t box_get(const uint32_t *w) { return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// every thread gets the `words` mailbox words of every rank: lane r of the first wave fetches rank r's (all fetches in flight
+// together -- one after the other they cost a memory round trip each), the workgroup reads them back from LDS
+__device__ __forceinline__ const uint32_t *team_collect(const TeamView &t, const uint32_t *box, int words, uint32_t *lds /*[size * 4]*/)
+{
+    if ((int)threadIdx.x < t.size) for (int w = 0; w < words; ++w) lds[4 * threadIdx.x + w] = box_get(&box[4 * threadIdx.x + w]);
+    __syncthreads();
+    return lds;
+}
+template <typename T, typename Op>
+__device__ __forceinline__ T team_reduce(const TeamView &t, T v, Op op, T identity, T *scratch)
+{
+    static_assert(sizeof(T) == 4, "mailboxes hold 32-bit values");
+    v = block_reduce(v, op, identity, scratch);
+    if (t.size == 1) return v;
+    uint32_t *box = team_box(t);
+    if (threadIdx.x == 0) box_put(&box[4 * t.rank], __builtin_bit_cast(uint32_t, v));
+    team_sync(t);
+    const uint32_t *got = team_collect(t, box, 1, t.lds);
+    T r = identity;
+    for (int i = 0; i < t.size; ++i) r = op(r, __builtin_bit_cast(T, got[4 * i]));
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ int team_any(const TeamView &t, int x)      // like __syncthreads_or: is x non-zero anywhere (NOT the bitwise or)
+{
+    x = __syncthreads_or(x);
+    if (t.size == 1) return x;
+    uint32_t *box = team_box(t);
+    if (threadIdx.x == 0) box_put(&box[4 * t.rank], (uint32_t)x);
+    team_sync(t);
+    const uint32_t *got = team_collect(t, box, 1, t.lds);
+    uint32_t r = 0;
+    for (int i = 0; i < t.size; ++i) r |= got[4 * i];
+    __syncthreads();
+    return (int)r;
+}
+__device__ __forceinline__ ArgPair team_argmax(const TeamView &t, float v, int i, float *sv, int *si)
+{
+    ArgPair r = block_argmax(v, i, sv, si);
+    if (t.size == 1) return r;
+    uint32_t *box = team_box(t);
+    if (threadIdx.x == 0) { box_put(&box[4 * t.rank], __float_as_uint(r.v)); box_put(&box[4 * t.rank + 1], (uint32_t)r.i); }
+    team_sync(t);
+    const uint32_t *got = team_collect(t, box, 2, t.lds);
+    r.v = 0.0f; r.i = -1;
+    for (int k = 0; k < t.size; ++k) {
+        const float ov = __uint_as_float(got[4 * k]);
+        const int oi = (int)got[4 * k + 1];
+        if (arg_better(ov, oi, r.v, r.i)) { r.v = ov; r.i = oi; }
+    }
+    __syncthreads();
+    return r;
+}
+// the three reductions that close an iteration of the sweep -- two maxima (NaN is maximal) and a bit mask -- on one barrier
+struct IterRed { float a, b; int bits; };
+template <class IT>
+__device__ __forceinline__ IterRed team_iter_reduce(const SView<IT> &, IterRed x, float *redf, int *redi)
+{
+    x.a = block_reduce(x.a, OpMaxNan(), -PDP_INF, redf);
+    x.b = block_reduce(x.b, OpMaxNan(), -PDP_INF, redf);
+    x.bits = block_reduce(x.bits, OpOrI(), 0, redi);
+    return x;
+}
+__device__ __forceinline__ IterRed team_iter_reduce(const TeamView &t, IterRed x, float *redf, int *redi)
+{
+    x = team_iter_reduce(static_cast<const SView<int32_t> &>(t), x, redf, redi);
+    if (t.size == 1) return x;
+    uint32_t *box = team_box(t);
+    if (threadIdx.x == 0) { box_put(&box[4 * t.rank], __float_as_uint(x.a)); box_put(&box[4 * t.rank + 1], __float_as_uint(x.b)); box_put(&box[4 * t.rank + 2], (uint32_t)x.bits); }
+    team_sync(t);
+    const uint32_t *got = team_collect(t, box, 3, t.lds);
+    IterRed r; r.a = -PDP_INF; r.b = -PDP_INF; r.bits = 0;
+    for (int k = 0; k < t.size; ++k) {
+        r.a = pdp_max(r.a, __uint_as_float(got[4 * k]));
+        r.b = pdp_max(r.b, __uint_as_float(got[4 * k + 1]));
+        r.bits |= (int)got[4 * k + 2];
+    }
+    __syncthreads();
+    return r;
+}
+
+// HBM-resident form of the solver: the instance's arrays stay where the problem keeps them, one workgroup (TEAM = false) or a
+// team of workgroups (TEAM = true, few big instances) walks them.
+template <int NT, bool TEAM>
+__global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
+{
+    // little static LDS on purpose: two workgroups of the LDS-resident kernel leave ~1.4 KB of a CU's LDS, and a team workgroup that
+    // fits next to them does not cost the mixed batch one of those two
+    __shared__ float redf[NT / PDP_WAVE];
+    __shared__ int redi[NT / PDP_WAVE];
+    __shared__ uint32_t team_lds[TEAM ? PDP_TEAM_MAX * 4 : 1];
+
+    if (sp.hbm_device_ctl) {
+        if (sp.call->stop) return;                                           // every instance went inactive in an earlier chunk
+        if (sp.hbm_replay && !sp.ctl->do_replay) return;                     // no NaN poisoned the batch in this chunk
+    }
+    const int poison_from = sp.hbm_device_ctl ? (sp.hbm_replay ? sp.ctl->poison_from : (sp.call->poisoned_all ? 0 : 0x7fffffff)) : sp.poison_from;
+    std::conditional_t<TEAM, TeamView, SView<int32_t>> I;
+    int slot = (int)blockIdx.x;          // which of the launch's instances
+    if constexpr (TEAM) {
+        // slot-minor numbering with the slot count padded to the XCD count: workgroups go to the XCDs round-robin, so the
+        // workgroups of one team share an XCD (and its L2); the padding workgroups leave at once
+        slot = (int)blockIdx.x % sp.team_slots;
+        if (slot >= sp.team_count) return;
+        I.rank = (int)blockIdx.x / sp.team_slots; I.size = sp.team_size; I.epoch = 0;
+        I.bar = sp.team_ws + (size_t)slot * PDP_TEAM_WORDS; I.box = I.bar + 32;
+        // first barrier, with full agent-scope fences: does the whole team sit on one XCD?  (HW_REG_XCC_ID = 20, bits 3:0)
+        // the team is the long pole of a mixed batch and shares its CUs with the LDS-resident kernel's waves: let the scheduler prefer it
+        __builtin_amdgcn_s_setprio(3);
+        I.same_xcd = 0; I.lds = team_lds;
+        const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf);
+        const int seen = team_reduce(I, 1 << xcc, OpOrI(), 0, redi);
+        I.same_xcd = ((seen & (seen - 1)) == 0 && !sp.team_no_xcd) ? 1 : 0;
+    }
+    const Inst G = load_inst(pv, sp.big_list ? sp.big_list[slot] : slot);
+    const int tid = team_tid(I), nt = team_nt(I);
+    constexpr int ROWL = TEAM ? 8 : (NT >= 1024 ? 4 : 1);      // lanes per variable row: the fewer threads an instance has, the more rows each must walk anyway
+    const int rl = tid & (ROWL - 1);
     const int n = G.n, m = G.m, ne = G.e;
     float *gq = sp.q + 3 * (size_t)G.e0;
     float *gfs = sp.fs + 2 * (size_t)G.e0;
     const float L0h = pdp_safe_log(1.0f - sp.pi * 0.0f, PDP_SP_EPS), L1h = pdp_safe_log(1.0f - sp.pi * 1.0f, PDP_SP_EPS);
 
-    SView<IT> I;
     I.b = G.b; I.n = n; I.m = m; I.e = ne;
-    if constexpr (LDS) {
-        unsigned char *p = smem;
-        IT *e_var = carve<IT>(p, ne), *e_fn = carve<IT>(p, ne), *v_edges = carve<IT>(p, ne), *f_edges = carve<IT>(p, ne);
-        IT *v_ptr = carve<IT>(p, n + 1), *f_ptr = carve<IT>(p, m + 1);
-        int8_t *sgn = carve<int8_t>(p, ne);
-        I.emask = carve<float>(p, ne); I.qu = carve<float>(p, ne); I.eta = carve<float>(p, ne);
-        float *force = carve<float>(p, ne);
-        I.s0 = carve<float>(p, ne); I.s1 = carve<float>(p, ne); I.s2 = carve<float>(p, ne); I.s3 = carve<float>(p, ne);
-        I.af = carve<float>(p, m); I.S = carve<float>(p, m);
-        I.av = carve<float>(p, n); I.sol = carve<float>(p, n); I.P = carve<float>(p, n); I.N = carve<float>(p, n);
-        I.xv1 = carve<float>(p, n); I.xv2 = carve<float>(p, n); I.score = carve<float>(p, n); I.coeff = carve<float>(p, n);
-        I.assign = carve<float>(p, n);
-        I.deg = carve<int32_t>(p, n); I.sdeg = carve<int32_t>(p, n);
-        I.flag_v = carve<uint8_t>(p, n); I.flag_f = carve<uint8_t>(p, m); I.flag_f2 = carve<uint8_t>(p, m);
-        for (int e = tid; e < ne; e += nt) {
-            e_var[e] = (IT)G.e_var[e]; e_fn[e] = (IT)G.e_fn[e]; v_edges[e] = (IT)G.v_edges[e]; f_edges[e] = (IT)G.f_edges[e];
-            sgn[e] = G.sgn[e];
-            I.emask[e] = G.emask[e];
-            I.qu[e] = gq[3 * e]; I.eta[e] = gfs[2 * e]; force[e] = gfs[2 * e + 1];
-        }
-        for (int v = tid; v <= n; v += nt) v_ptr[v] = (IT)G.v_ptr[v];
-        for (int c = tid; c <= m; c += nt) f_ptr[c] = (IT)G.f_ptr[c];
-        for (int v = tid; v < n; v += nt) { I.av[v] = G.av[v]; I.sol[v] = G.sol[v]; }
-        for (int c = tid; c < m; c += nt) I.af[c] = G.af[c];
-        I.e_var = e_var; I.e_fn = e_fn; I.v_edges = v_edges; I.f_edges = f_edges; I.v_ptr = v_ptr; I.f_ptr = f_ptr; I.sgn = sgn;
-        I.force = force; I.qstride = 1; I.estride = 1; I.fstride = 1;
-    } else {
-        I.e_var = G.e_var; I.e_fn = G.e_fn; I.v_edges = G.v_edges; I.f_edges = G.f_edges; I.v_ptr = G.v_ptr; I.f_ptr = G.f_ptr;
-        I.sgn = G.sgn; I.av = G.av; I.af = G.af; I.sol = G.sol; I.emask = G.emask;
-        I.qu = gq; I.qstride = 3; I.eta = gfs; I.estride = 2; I.force = gfs + 1; I.fstride = 2;
-        I.s0 = sp.ws_e[0] + G.e0; I.s1 = sp.ws_e[1] + G.e0; I.s2 = sp.ws_e[2] + G.e0; I.s3 = sp.ws_e[3] + G.e0;
-        I.S = sp.ws_f + G.f0;
-        I.P = sp.ws_v[0] + G.v0; I.N = sp.ws_v[1] + G.v0; I.xv1 = sp.ws_v[2] + G.v0; I.xv2 = sp.ws_v[3] + G.v0;
-        I.score = sp.ws_v[4] + G.v0; I.coeff = sp.ws_v[5] + G.v0; I.assign = sp.ws_v[6] + G.v0;
-        I.deg = sp.ws_vi[0] + G.v0; I.sdeg = sp.ws_vi[1] + G.v0;
-        I.flag_v = reinterpret_cast<uint8_t *>(sp.ws_vi[2]) + G.v0;
-        I.flag_f = sp.ws_fu[0] + G.f0; I.flag_f2 = sp.ws_fu[1] + G.f0;
-    }
-    __syncthreads();
+    I.e_var = G.e_var; I.e_fn = G.e_fn; I.v_edges = G.v_edges; I.f_edges = G.f_edges; I.v_ptr = G.v_ptr; I.f_ptr = G.f_ptr;
+    I.sgn = G.sgn; I.av = G.av; I.af = G.af; I.sol = G.sol; I.emask = G.emask;
+    I.qu = gq; I.qstride = 3; I.eta = gfs; I.estride = 2; I.force = gfs + 1; I.fstride = 2;
+    I.s0 = sp.ws_e[0] + G.e0; I.s1 = sp.ws_e[1] + G.e0; I.s2 = sp.ws_e[2] + G.e0; I.s3 = sp.ws_e[3] + G.e0;
+    I.S = sp.ws_f + G.f0;
+    I.P = sp.ws_v[0] + G.v0; I.N = sp.ws_v[1] + G.v0; I.xv1 = sp.ws_v[2] + G.v0; I.xv2 = sp.ws_v[3] + G.v0;
+    I.score = sp.ws_v[4] + G.v0; I.coeff = sp.ws_v[5] + G.v0; I.assign = sp.ws_v[6] + G.v0;
+    I.deg = sp.ws_vi[0] + G.v0; I.sdeg = sp.ws_vi[1] + G.v0;
+    I.flag_v = reinterpret_cast<uint8_t *>(sp.ws_vi[2]) + G.v0;
+    I.flag_f = sp.ws_fu[0] + G.f0; I.flag_f2 = sp.ws_fu[1] + G.f0;
 
     SimplifyScratch ss;
     ss.assign = I.assign; ss.deg = I.deg; ss.sdeg = I.sdeg; ss.flag_v = I.flag_v; ss.flag_f = I.flag_f; ss.flag_f2 = I.flag_f2; ss.red = redi;
@@ -196,44 +331,69 @@ __global__ void __launch_bounds__(LDS ? 512 : 256) k_sp_solve(PView pv, SolvePar
     int violation = 0;
     const bool other_rows = n < pv.V;
 
+    int abort_next = 0;
+#ifdef PDP_PHASE_PROF
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = wall_clock64();
+#define TP(i) { const long long now_ = wall_clock64(); tacc[i] += now_ - tlast; tlast = now_; }
+#else
+#define TP(i)
+#endif
     for (int t = 0; t < sp.T; ++t) {
         if (!active) break;
-        // pass 1 only: once some instance is known to poison the batch before t, this pass will be replayed anyway
-        if (sp.poison_from == 0x7fffffff) {
-            if (tid == 0) sh_flag[0] = (__hip_atomic_load(sp.nan_iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)t) ? 1 : 0;
-            __syncthreads();
-            const int abort_now = sh_flag[0];
-            __syncthreads();
-            if (abort_now) break;
-        }
-        const bool poisoned = t >= sp.poison_from;
+        if (abort_next) break;                // pass 1 only: some instance poisons the batch before t, this pass will be replayed anyway
+        const bool poisoned = t >= poison_from;
         iters = t + 1;
-        // ---- P1: per-edge logs (pdp_propagate.py:166-169,185-188)
-        for (int e = tid; e < ne; e += nt) {
-            float x = pdp_safe_log(I.qu[e * I.qstride], PDP_SP_EPS);
-            float y = pdp_safe_log(1.0f - I.eta[e * I.estride], PDP_SP_EPS);
-            if (use_em) { const float em = I.emask[e]; x = x * em; y = y * em; }
-            I.s0[e] = x; I.s1[e] = y;
-        }
-        __syncthreads();
-        // ---- P2: per-clause and per-variable sums (ascending edge id)
+        // ---- P1 + P2: per-edge logs (pdp_propagate.py:166-169,185-188) and their per-clause / per-variable sums in ascending
+        // edge order; every edge sits in exactly one clause row and one variable row, which computes and leaves its log for P3
+        // (memory latency is what this kernel waits for: rows are walked in batches whose loads are all in flight together, and
+        // the sums then take the batch's values in entry order -- the reference's summation order)
         for (int c = tid; c < m; c += nt) {
+            const int beg = I.f_ptr[c], end = I.f_ptr[c + 1];
             float acc = 0.0f;
-            for (int k = I.f_ptr[c]; k < I.f_ptr[c + 1]; ++k) acc = acc + I.s0[I.f_edges[k]];
+            for (int k0 = beg; k0 < end; k0 += 4) {
+                int ee[4]; float xx[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ee[j] = I.f_edges[(k0 + j < end) ? k0 + j : end - 1];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    xx[j] = pdp_safe_log(I.qu[ee[j] * I.qstride], PDP_SP_EPS);
+                    if (use_em) xx[j] = xx[j] * I.emask[ee[j]];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (k0 + j < end) { I.s0[ee[j]] = xx[j]; acc = acc + xx[j]; }
+            }
             I.S[c] = acc;
         }
-        for (int v = tid; v < n; v += nt) {
+        // a variable row belongs to ROWL adjacent lanes: each gathers one entry, every lane of the group adds them in entry order
+        for (int v = tid / ROWL; v < n; v += nt / ROWL) {
+            const int beg = I.v_ptr[v], end = I.v_ptr[v + 1];
             float P = 0.0f, N = 0.0f;
-            for (int k = I.v_ptr[v]; k < I.v_ptr[v + 1]; ++k) {
-                const int e = I.v_edges[k];
-                const float y = I.s1[e];
-                const int sg = I.sgn[e];
-                P = P + ((sg == 1) ? 1.0f : 0.0f) * y;
-                N = N + ((sg == -1) ? 1.0f : 0.0f) * y;
+            for (int k0 = beg; k0 < end; k0 += ROWL) {
+                const int k = k0 + rl;
+                float y = 0.0f; int sg = 0;
+                if (k < end) {
+                    const int e = I.v_edges[k];
+                    y = pdp_safe_log(1.0f - I.eta[e * I.estride], PDP_SP_EPS);
+                    if (use_em) y = y * I.emask[e];
+                    I.s1[e] = y;
+                    sg = I.sgn[e];
+                }
+                const int cntk = end - k0;
+#pragma unroll
+                for (int j = 0; j < ROWL; ++j) {
+                    const float yj = __shfl(y, j, ROWL);
+                    const int sj = __shfl(sg, j, ROWL);
+                    if (j < cntk) {
+                        P = P + ((sj == 1) ? 1.0f : 0.0f) * yj;
+                        N = N + ((sj == -1) ? 1.0f : 0.0f) * yj;
+                    }
+                }
             }
-            I.P[v] = P; I.N[v] = N;
+            if (rl == 0) { I.P[v] = P; I.N[v] = N; }
         }
-        __syncthreads();
+        TP(0)
+        team_sync(I);
+        TP(1)
         // ---- P3: new surveys + new q_u, and the decimator's per-edge terms (pdp_decimate.py:128-141)
         int nan_seen = 0;
         for (int e = tid; e < ne; e += nt) {
@@ -262,40 +422,69 @@ __global__ void __launch_bounds__(LDS ? 512 : 256) k_sp_solve(PView pv, SolvePar
             I.s3[e] = pdp_safe_exp(30.0f * d);            // smooth-max weight of the difference
         }
         did_prop = 1;
-        __syncthreads();
-        // ---- P4: per-variable smooth maxima (util.py:282-286) times the active flag
+        TP(2)
+        team_sync(I);
+        TP(3)
+        // ---- P4 + P5: per-variable smooth maxima (util.py:282-286) times the active flag, and their per-instance maxima with
+        // the reference's (x - min + 1) rounding (util.sparse_max, util.py:267-275), speculating min == 0
         int z1 = 0, z2 = 0;
-        for (int v = tid; v < n; v += nt) {
+        IterRed red; red.a = -PDP_INF; red.b = -PDP_INF;
+        for (int v = tid / ROWL; v < n; v += nt / ROWL) {
+            const int beg = I.v_ptr[v], end = I.v_ptr[v + 1];
             float num1 = 0.0f, den1 = 0.0f, num2 = 0.0f, den2 = 0.0f;
-            for (int k = I.v_ptr[v]; k < I.v_ptr[v + 1]; ++k) {
-                const int e = I.v_edges[k];
-                const float c1 = I.s0[e], et = I.eta[e * I.estride];
-                num1 = num1 + et * c1; den1 = den1 + c1;
-                if (has_prev) { const float c2 = I.s3[e], d = I.s2[e]; num2 = num2 + d * c2; den2 = den2 + c2; }
+            for (int k0 = beg; k0 < end; k0 += ROWL) {
+                const int k = k0 + rl;
+                float c1 = 0.0f, p1 = 0.0f, c2 = 0.0f, p2 = 0.0f;
+                if (k < end) {
+                    const int e = I.v_edges[k];
+                    c1 = I.s0[e]; p1 = I.eta[e * I.estride] * c1;
+                    if (has_prev) { c2 = I.s3[e]; p2 = I.s2[e] * c2; }
+                }
+                const int cntk = end - k0;
+#pragma unroll
+                for (int j = 0; j < ROWL; ++j) {
+                    const float c1j = __shfl(c1, j, ROWL), p1j = __shfl(p1, j, ROWL);
+                    if (j < cntk) { num1 = num1 + p1j; den1 = den1 + c1j; }
+                    if (has_prev) {
+                        const float c2j = __shfl(c2, j, ROWL), p2j = __shfl(p2, j, ROWL);
+                        if (j < cntk) { num2 = num2 + p2j; den2 = den2 + c2j; }
+                    }
+                }
             }
             const float a = I.av[v];
             const float r1 = (num1 / pdp_max(den1, 1.0f)) * a;
-            I.xv1[v] = r1;
+            red.a = pdp_max(red.a, (r1 - 0.0f) + 1.0f);
             if (r1 == 0.0f) z1 = 1;
             if (r1 != r1) nan_seen = 1;
             if (has_prev) {
                 const float r2 = (num2 / pdp_max(den2, 1.0f)) * a;
-                I.xv2[v] = r2;
+                red.b = pdp_max(red.b, (r2 - 0.0f) + 1.0f);
                 if (r2 == 0.0f) z2 = 1;
                 if (r2 != r2) nan_seen = 1;
             }
         }
-        __syncthreads();
-        // ---- P5: per-instance maxima with the reference's (x - min + 1) rounding, speculating min == 0
-        const float g = d_instance_max(I, I.xv1, 0.0f, other_rows, redf);
-        float dmax = 0.0f;
-        if (has_prev) dmax = d_instance_max(I, I.xv2, 0.0f, other_rows, redf);
-        z1 = __syncthreads_or(z1); z2 = __syncthreads_or(z2); nan_seen = __syncthreads_or(nan_seen);
+        TP(4)
+        // the same barrier carries pass 1's look at the batch's first NaN iteration for the next trip of the loop
+        const int nan_before_next = (poison_from == 0x7fffffff && tid == 0 &&
+                                     __hip_atomic_load(sp.nan_iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)(t + 1)) ? 1 : 0;
+        red.bits = (z1 ? 1 : 0) | (z2 ? 2 : 0) | (nan_seen ? 4 : 0) | (nan_before_next ? 8 : 0);
+        red = team_iter_reduce(I, red, redf, redi);
+        TP(5)
+        z1 = red.bits & 1; z2 = red.bits & 2; nan_seen = red.bits & 4; abort_next = red.bits & 8;
+        float g = red.a, dmax = 0.0f;
+        if (other_rows) g = pdp_max(g, 0.0f);
+        g = (g + 0.0f) - 1.0f;
+        if (has_prev) {
+            dmax = red.b;
+            if (other_rows) dmax = pdp_max(dmax, 0.0f);
+            dmax = (dmax + 0.0f) - 1.0f;
+        }
         // A NaN survey (0/0 in pdp_propagate.py:215-216) makes every batch-global min/max of the reference NaN from
         // this iteration on.  Pass 1 records the first such iteration, pass 2 replays with it.
         if (nan_seen && !poisoned) {
             if (tid == 0) atomicMin(sp.nan_iter, (uint32_t)t);
-            if (sp.poison_from != 0x7fffffff) violation = 1;      // pass 2 must not find an earlier NaN
+            if (poison_from != 0x7fffffff) violation = 1;      // pass 2 must not find an earlier NaN
+            else abort_next = 1;
         }
         int conv = 0;
         if (!poisoned) {
@@ -319,7 +508,7 @@ __global__ void __launch_bounds__(LDS ? 512 : 256) k_sp_solve(PView pv, SolvePar
             // scorer (pdp_predict.py:155-192)
             for (int e = tid; e < ne; e += nt)
                 I.s3[e] = pdp_safe_log(1.0f - I.eta[e * I.estride], PDP_SCORER_EPS) * (0.0f + I.af[I.e_fn[e]]);
-            __syncthreads();
+            team_sync(I);
             int z3 = 0, anynz = 0, cn = 0;
             for (int v = tid; v < n; v += nt) {
                 float ext = 0.0f, pos = 0.0f, neg = 0.0f, all = 0.0f;
@@ -339,16 +528,18 @@ __global__ void __launch_bounds__(LDS ? 512 : 256) k_sp_solve(PView pv, SolvePar
                 if (co != 0.0f) anynz = 1;
                 if (co != co) cn = 1;
             }
-            __syncthreads();
-            z3 = __syncthreads_or(z3); anynz = __syncthreads_or(anynz); cn = __syncthreads_or(cn);
+            {
+                const int bits = team_reduce(I, (z3 ? 1 : 0) | (anynz ? 2 : 0) | (cn ? 4 : 0), OpOrI(), 0, redi);     // (its barrier also publishes score / coeff)
+                z3 = bits & 1; anynz = bits & 2; cn = bits & 4;
+            }
             if (cn) violation = 1;                                // cannot happen without a NaN survey
             used |= 4u; if (z3) zero |= 4u;
             const int li = d_instance_argmax(I, I.coeff, 0.0f, redf, redi);
             if (active && anynz && !cn && li >= 0) {
                 for (int v = tid; v < n; v += nt) I.assign[v] = 0.0f;
-                __syncthreads();
+                team_sync(I);
                 if (tid == 0) I.assign[li] = pdp_sign(I.score[li]);
-                __syncthreads();
+                team_sync(I);
                 d_set_variable_core(I, ss);
                 d_simplify(I, ss, pv.is_sat + G.b);
                 decimated = 1;
@@ -364,7 +555,7 @@ __global__ void __launch_bounds__(LDS ? 512 : 256) k_sp_solve(PView pv, SolvePar
                 I.emask[e] = a * b;
             }
             use_em = 1;
-            __syncthreads();
+            team_sync(I);
         }
         // ---- P8: prediction = solution; termination check (trainer.py:150-162, util.py:226-236)
         if (sp.check_termination) {
@@ -372,7 +563,12 @@ __global__ void __launch_bounds__(LDS ? 512 : 256) k_sp_solve(PView pv, SolvePar
             if (active && nsat == m) active = 0;
         }
         has_prev = 1; prev_from_global = 0;
+        TP(6)
     }
+#ifdef PDP_PHASE_PROF
+    if (tid == 0 && TEAM) printf("[team %d x %d] iters %d: rows %lld sync %lld edges %lld sync %lld maxima %lld reduce %lld rest %lld (x10 ns)\n", I.b, nt, iters, tacc[0], tacc[1], tacc[2], tacc[3], tacc[4], tacc[5], tacc[6]);
+#endif
+#undef TP
 
     // ---- write back -------------------------------------------------------------------------------------------
     if (did_prop) {
@@ -383,27 +579,20 @@ __global__ void __launch_bounds__(LDS ? 512 : 256) k_sp_solve(PView pv, SolvePar
             const float sticky = I.qu[e * I.qstride];
             gq[3 * e + 1] = 1.0f * o.qs + (1.0f - 1.0f) * sticky;
             gq[3 * e + 2] = 1.0f * o.dc + (1.0f - 1.0f) * sticky;
-            if constexpr (LDS) { gq[3 * e] = I.qu[e]; gfs[2 * e] = I.eta[e]; }
             sp.prev[G.e0 + e] = I.eta[e * I.estride];
         }
-    }
-    if constexpr (LDS) {
-        for (int e = tid; e < ne; e += nt) G.emask[e] = I.emask[e];
-        for (int v = tid; v < n; v += nt) { G.av[v] = I.av[v]; G.sol[v] = I.sol[v]; }
-        for (int c = tid; c < m; c += nt) G.af[c] = I.af[c];
     }
     // an instance with a de-activated variable contributes an exact 0 to every batch-global min from now on
     int any_inactive = 0;
     for (int v = tid; v < n; v += nt) any_inactive |= (I.av[v] == 0.0f) ? 1 : 0;
-    any_inactive = __syncthreads_or(any_inactive);
+    any_inactive = team_any(I, any_inactive);
     if (tid == 0) {
-        if (any_inactive) atomicMin(&pv.flags[FL_PERM_ZERO], (uint32_t)iters);
+        if (any_inactive) atomicMin(sp.w_perm_zero, (uint32_t)iters);
         sp.amask[G.b] = (uint8_t)active;
         sp.counters[G.b] = cnt;
-        atomicMax(&pv.flags[FL_ITERS_RUN], (uint32_t)iters);
-        if (violation) atomicOr(&pv.flags[FL_SPEC_VIOLATION], 1u);
+        atomicMax(sp.w_iters_run, (uint32_t)iters);
+        if (violation) atomicOr(sp.w_violation, 1u);
     }
-    (void)sh_flag;
 }
 
 
@@ -894,9 +1083,10 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
     SolveCtl *const ctl = sp.ctl;
+    const int index = (int)blockIdx.x;
     if (sp.call->stop) return;                                                 // every instance went inactive in an earlier chunk
-    if (REPLAY && (!ctl->do_replay || blockIdx.x >= ctl->replay_count)) return;
-    const Inst G = load_inst(pv_, REPLAY ? sp.inst_list[blockIdx.x] : (int)blockIdx.x);
+    if (REPLAY && (!ctl->do_replay || (uint32_t)index >= ctl->replay_count)) return;
+    const Inst G = load_inst(pv_, REPLAY ? sp.inst_list[index] : (sp.fit_list ? sp.fit_list[index] : index));
     const int n = G.n, m = G.m, ne = G.e;
     const LdsArrays L = carve_all(smem, n, m, ne, FORCE && !RF);
     constexpr int VM = RF ? PV_VMASK_RF : 0x3fff;           // variable id of a slot word
@@ -1411,9 +1601,10 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
 
 // canonical arrays -> static + first dynamic record (once per call; the static part once per problem)
 __global__ void __launch_bounds__(256) k_solve_import(PView pv, const float *q, const float *fs, const uint8_t *amask, const float *prev, const float *counters,
-                                                      int has_prev, int build_static, char *stat, char *dyn, const int64_t *stat_off, const int64_t *dyn_off, float *prev_slots)
+                                                      int has_prev, int build_static, char *stat, char *dyn, const int64_t *stat_off, const int64_t *dyn_off, float *prev_slots,
+                                                      const int32_t *list)
 {
-    const Inst G = load_inst(pv, blockIdx.x);
+    const Inst G = load_inst(pv, list ? list[blockIdx.x] : (int)blockIdx.x);
     const int n = G.n, m = G.m, ne = G.e, tid = threadIdx.x, nt = blockDim.x;
     const BlobLayout BL = blob_layout(n, m, ne);
     char *st = stat + stat_off[G.b], *dy = dyn + dyn_off[G.b];
@@ -1499,11 +1690,11 @@ __global__ void k_solve_post(SolveCtl *ctl, SolveCall *call, int c, int isolate)
 }
 
 // only instances with a gate / convergence event at or after the poison iteration behave differently under the poison
-__global__ void k_replay_list(int B, const int32_t *last_event, SolveCtl *ctl, const SolveCall *call, int32_t *list)
+__global__ void k_replay_list(int B, const int32_t *last_event, SolveCtl *ctl, const SolveCall *call, int32_t *list, const uint8_t *is_big)
 {
     if (call->stop || !ctl->do_replay) return;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B && last_event[b] >= ctl->poison_from) list[atomicAdd(&ctl->replay_count, 1u)] = b;
+    if (b < B && !(is_big && is_big[b]) && last_event[b] >= ctl->poison_from) list[atomicAdd(&ctl->replay_count, 1u)] = b;   // (big instances: replayed wholesale)
 }
 
 // after the (possible) replay: speculation check of the chunk and loop control
@@ -1521,6 +1712,23 @@ __global__ void k_solve_finish(SolveCtl *ctl, SolveCall *call, const uint32_t *s
     if (it < (uint32_t)c) call->stop = 1;          // every instance went inactive inside this chunk (global early exit, solver.py:383)
 }
 
+
+// chunk-entry state of the big instances (HBM-resident kernel works in place): save before pass 1, restore before the replay pass
+struct BigSnap { float *q, *fs, *av, *af, *sol, *sat, *emask, *prev, *cnt; uint8_t *amask; };
+__global__ void __launch_bounds__(256) k_big_state(PView pv, const int32_t *list, BigSnap live, BigSnap snap, int restore, const SolveCtl *ctl, const SolveCall *call)
+{
+    if (call->stop) return;
+    if (restore && !ctl->do_replay) return;
+    const Inst G = load_inst(pv, list[blockIdx.x]);
+    const BigSnap &src = restore ? snap : live, &dst = restore ? live : snap;
+    const int tid = blockIdx.y * blockDim.x + threadIdx.x, nt = gridDim.y * blockDim.x;
+    for (int64_t i = tid; i < 3 * (int64_t)G.e; i += nt) dst.q[3 * (int64_t)G.e0 + i] = src.q[3 * (int64_t)G.e0 + i];
+    for (int64_t i = tid; i < 2 * (int64_t)G.e; i += nt) dst.fs[2 * (int64_t)G.e0 + i] = src.fs[2 * (int64_t)G.e0 + i];
+    for (int i = tid; i < G.e; i += nt) { dst.emask[G.e0 + i] = src.emask[G.e0 + i]; dst.prev[G.e0 + i] = src.prev[G.e0 + i]; }
+    for (int i = tid; i < G.n; i += nt) { dst.av[G.v0 + i] = src.av[G.v0 + i]; dst.sol[G.v0 + i] = src.sol[G.v0 + i]; }
+    for (int i = tid; i < G.m; i += nt) dst.af[G.f0 + i] = src.af[G.f0 + i];
+    if (tid == 0) { dst.sat[G.b] = src.sat[G.b]; dst.cnt[G.b] = src.cnt[G.b]; dst.amask[G.b] = src.amask[G.b]; }
+}
 
 __global__ void k_any_force(const float *fs, int64_t E, uint32_t *flag)
 {
@@ -1572,6 +1780,85 @@ static int ensure_bytes(char **ptr, size_t *have, size_t need)
     return PDP_OK;
 }
 
+// does this instance's image fit the LDS-resident solver?  (force-less image: the Reinforce force is a 2-bit code, an external-force
+// column of the SP triple is checked by the caller against the largest fitting instance)
+// Launch of the HBM-resident kernel over `count` instances.  Few instances get a TEAM of workgroups each: a team's workgroups wait
+// for each other, so all of them must be resident at once -- the teams of an XCD stay within one workgroup per CU -- and a team is only
+// as large as the instance has work for (>= 2 edges per thread).  PDP_SOLVE_TEAM=<n> caps the team size (1: never a team).
+static int launch_hbm(pdp_problem *p, SolveParams sp, int count, hipStream_t s_)
+{
+    int cap = PDP_TEAM_MAX;
+    sp.team_no_xcd = getenv("PDP_SOLVE_TEAM_AGENT_FENCES") ? 1 : 0;
+    if (const char *env = getenv("PDP_SOLVE_TEAM")) { const int v = atoi(env); if (v >= 1 && v <= PDP_TEAM_MAX) cap = v; }
+    int tnt = 256;              // measured on the mixed headline batch (tools/mixed_batch_time.py): 256 x 32 beats 512 x 32 and 1024 x 16 next to the LDS-resident kernel
+    if (const char *env = getenv("PDP_SOLVE_TEAM_THREADS")) { const int v = atoi(env); if (v == 256 || v == 512 || v == 1024) tnt = v; }
+    int size = 1;
+    const int per_xcd = ((count + 7) & ~7) / 8;          // teams that share an XCD (32 CUs, one workgroup per CU assumed)
+    while (size * 2 <= cap && per_xcd * size * 2 <= 32 && (size_t)p->max_e >= (size_t)size * 2 * tnt * 2) size *= 2;
+    if (size > 1) {
+        if (!p->team_ws) { int st_ = pdp_dev_alloc((void **)&p->team_ws, sizeof(uint32_t) * 256 * PDP_TEAM_WORDS); if (st_ != PDP_OK) return st_; }
+        PDP_HIP_CHECK(hipMemsetAsync(p->team_ws, 0, sizeof(uint32_t) * (size_t)count * PDP_TEAM_WORDS, s_));
+        sp.team_size = size; sp.team_count = count; sp.team_slots = (count + 7) & ~7; sp.team_ws = p->team_ws;
+        if (tnt == 1024) hipLaunchKernelGGL((k_sp_solve<1024, true>), dim3(size * sp.team_slots), dim3(1024), 0, s_, make_view(p), sp);
+        else if (tnt == 512) hipLaunchKernelGGL((k_sp_solve<512, true>), dim3(size * sp.team_slots), dim3(512), 0, s_, make_view(p), sp);
+        else hipLaunchKernelGGL((k_sp_solve<256, true>), dim3(size * sp.team_slots), dim3(256), 0, s_, make_view(p), sp);
+    } else if (count <= 512) {
+        hipLaunchKernelGGL((k_sp_solve<1024, false>), dim3(count), dim3(1024), 0, s_, make_view(p), sp);     // one wave per SIMD waits on L2 most of the time
+    } else {
+        hipLaunchKernelGGL((k_sp_solve<256, false>), dim3(count), dim3(256), 0, s_, make_view(p), sp);
+    }
+    return PDP_OK;
+}
+
+static bool instance_fits_lds(int n, int m, int e)
+{
+    return lds2_bytes_for(n, m, e, false) <= 160 * 1024 - 1024 && e < 65535 && n < 16384 && m < 16384;
+}
+
+// once per problem: which instances fit the LDS (fit_list / big_list), the byte offsets of the fitting instances' records and the records'
+// storage.  Instances that do not fit run on the HBM-resident kernel inside the same chunk loop (per-instance routing).
+static int resident_prepare(pdp_problem *p)
+{
+    if (p->res_stat_off) return PDP_OK;
+    const size_t B = p->B, E = p->E;
+    std::vector<int32_t> v0(B + 1), f0(B + 1), e0(B + 1);
+    PDP_HIP_CHECK(hipMemcpy(v0.data(), p->inst_v0, (B + 1) * 4, hipMemcpyDeviceToHost));
+    PDP_HIP_CHECK(hipMemcpy(f0.data(), p->inst_f0, (B + 1) * 4, hipMemcpyDeviceToHost));
+    PDP_HIP_CHECK(hipMemcpy(e0.data(), p->inst_e0, (B + 1) * 4, hipMemcpyDeviceToHost));
+    std::vector<int64_t> off(2 * B);
+    std::vector<int32_t> fit, big;
+    std::vector<uint8_t> is_big(B, 0);
+    size_t so = 0, dy = 0;
+    p->res_fit_n = p->res_fit_m = p->res_fit_e = 0;
+    for (size_t b = 0; b < B; ++b) {
+        const int n = v0[b + 1] - v0[b], m = f0[b + 1] - f0[b], e = e0[b + 1] - e0[b];
+        off[b] = (int64_t)so; off[B + b] = (int64_t)dy;
+        if (!instance_fits_lds(n, m, e)) { big.push_back((int32_t)b); is_big[b] = 1; continue; }
+        fit.push_back((int32_t)b);
+        if (n > p->res_fit_n) p->res_fit_n = n;
+        if (m > p->res_fit_m) p->res_fit_m = m;
+        if (e > p->res_fit_e) p->res_fit_e = e;
+        const BlobLayout bl = blob_layout(n, m, e);
+        so += bl.stat_bytes; dy += bl.dyn_bytes;
+    }
+    p->res_nfit = (int)fit.size(); p->res_nbig = (int)big.size();
+    { int st_ = pdp_dev_alloc((void **)&p->res_fit_list, (fit.size() + 1) * 4); if (st_ != PDP_OK) return st_; }
+    { int st_ = pdp_dev_alloc((void **)&p->res_big_list, (big.size() + 1) * 4); if (st_ != PDP_OK) return st_; }
+    { int st_ = pdp_dev_alloc((void **)&p->res_is_big, B + 1); if (st_ != PDP_OK) return st_; }
+    if (!fit.empty()) PDP_HIP_CHECK(hipMemcpy(p->res_fit_list, fit.data(), fit.size() * 4, hipMemcpyHostToDevice));
+    if (!big.empty()) PDP_HIP_CHECK(hipMemcpy(p->res_big_list, big.data(), big.size() * 4, hipMemcpyHostToDevice));
+    PDP_HIP_CHECK(hipMemcpy(p->res_is_big, is_big.data(), B, hipMemcpyHostToDevice));
+    p->res_stat_bytes = so + 16; p->res_dyn_bytes = dy + 16;
+    { int st_ = pdp_dev_alloc((void **)&p->res_stat, p->res_stat_bytes); if (st_ != PDP_OK) return st_; }
+    { int st_ = pdp_dev_alloc((void **)&p->res_dyn[0], p->res_dyn_bytes); if (st_ != PDP_OK) return st_; }
+    { int st_ = pdp_dev_alloc((void **)&p->res_dyn[1], p->res_dyn_bytes); if (st_ != PDP_OK) return st_; }
+    { int st_ = pdp_dev_alloc((void **)&p->res_prev_slots, (E + 4) * sizeof(float)); if (st_ != PDP_OK) return st_; }
+    p->res_static_built = 0;
+    { int st_ = pdp_dev_alloc((void **)&p->res_stat_off, 2 * B * sizeof(int64_t)); if (st_ != PDP_OK) return st_; }   // (set last: marks the preparation complete)
+    PDP_HIP_CHECK(hipMemcpy(p->res_stat_off, off.data(), 2 * B * sizeof(int64_t), hipMemcpyHostToDevice));
+    return PDP_OK;
+}
+
 // LDS-resident path: every launch of the call is enqueued up front (import, then per chunk: pass 1, poison decision, replay
 // list, replay, speculation check); the host reads one control block at the end.
 static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, bool force, size_t lds, int nt_lds, int C)
@@ -1580,28 +1867,6 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     const int T = a->iterations;
     const size_t E = p->E, V = p->V, F = p->F, B = p->B;
     const int nchunks = (T + C - 1) / C;
-    // ---- instance record offsets + static records: once per problem --------------------------------------------------------
-    if (!p->res_stat_off) {
-        std::vector<int32_t> v0(B + 1), f0(B + 1), e0(B + 1);
-        PDP_HIP_CHECK(hipMemcpy(v0.data(), p->inst_v0, (B + 1) * 4, hipMemcpyDeviceToHost));
-        PDP_HIP_CHECK(hipMemcpy(f0.data(), p->inst_f0, (B + 1) * 4, hipMemcpyDeviceToHost));
-        PDP_HIP_CHECK(hipMemcpy(e0.data(), p->inst_e0, (B + 1) * 4, hipMemcpyDeviceToHost));
-        std::vector<int64_t> off(2 * B);
-        size_t so = 0, dy = 0;
-        for (size_t b = 0; b < B; ++b) {
-            const BlobLayout bl = blob_layout(v0[b + 1] - v0[b], f0[b + 1] - f0[b], e0[b + 1] - e0[b]);
-            off[b] = (int64_t)so; off[B + b] = (int64_t)dy;
-            so += bl.stat_bytes; dy += bl.dyn_bytes;
-        }
-        { int st_ = pdp_dev_alloc((void **)&p->res_stat_off, 2 * B * sizeof(int64_t)); if (st_ != PDP_OK) return st_; }
-        PDP_HIP_CHECK(hipMemcpy(p->res_stat_off, off.data(), 2 * B * sizeof(int64_t), hipMemcpyHostToDevice));
-        p->res_stat_bytes = so + 16; p->res_dyn_bytes = dy + 16;
-        { int st_ = pdp_dev_alloc((void **)&p->res_stat, p->res_stat_bytes); if (st_ != PDP_OK) return st_; }
-        { int st_ = pdp_dev_alloc((void **)&p->res_dyn[0], p->res_dyn_bytes); if (st_ != PDP_OK) return st_; }
-        { int st_ = pdp_dev_alloc((void **)&p->res_dyn[1], p->res_dyn_bytes); if (st_ != PDP_OK) return st_; }
-        { int st_ = pdp_dev_alloc((void **)&p->res_prev_slots, (E + 4) * sizeof(float)); if (st_ != PDP_OK) return st_; }
-        p->res_static_built = 0;
-    }
     const int64_t *stat_off = p->res_stat_off, *dyn_off = p->res_stat_off + B;
     // ---- control blocks, speculation record, replay list; call-entry snapshot for the failure path ---------------------------
     const size_t ctl_bytes = (size_t)nchunks * sizeof(SolveCtl) + sizeof(SolveCall) + 2 * (size_t)T * 4 + 2 * B * 4 + 64 +
@@ -1656,9 +1921,11 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
 
     hipLaunchKernelGGL(k_solve_ctl_init, dim3((nchunks + 255) / 256), dim3(256), 0, st, ctl, nchunks, call);
     PDP_HIP_CHECK(hipMemsetAsync(spec, 0, 2 * (size_t)T * 4, st));
-    hipLaunchKernelGGL(k_solve_import, dim3(p->B), dim3(256), 0, st, make_view(p), (const float *)a->q, (const float *)a->fs, (const uint8_t *)a->active_mask,
+    const int nfit = p->res_nfit, nbig = p->res_nbig;
+    const int32_t *fit_list = nbig ? p->res_fit_list : nullptr;                 // all instances fit: instance = block index
+    hipLaunchKernelGGL(k_solve_import, dim3(nfit), dim3(256), 0, st, make_view(p), (const float *)a->q, (const float *)a->fs, (const uint8_t *)a->active_mask,
                        (const float *)a->decimator->prev, (const float *)a->decimator->counters, a->decimator->has_prev, p->res_static_built ? 0 : 1,
-                       p->res_stat, p->res_dyn[0], stat_off, dyn_off, p->res_prev_slots);
+                       p->res_stat, p->res_dyn[0], stat_off, dyn_off, p->res_prev_slots, fit_list);
     PDP_LAUNCH_CHECK();
     p->res_static_built = 1;
 
@@ -1676,6 +1943,36 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     }
     sp.last_event = last_event; sp.inst_list = replay_list;
     sp.call = call; sp.stat = p->res_stat; sp.stat_off = stat_off; sp.dyn_off = dyn_off;
+    sp.fit_list = fit_list;
+    // instances that do not fit the LDS: the HBM-resident kernel on their list, under the same device-side control; it works in place, so
+    // the state they enter a chunk with is saved for the NaN-poison replay
+    BigSnap big_live, big_snap;
+    if (nbig) {
+        for (int i = 0; i < 4; ++i) sp.ws_e[i] = p->ws_e[i];
+        sp.ws_f = p->ws_f[0];
+        for (int i = 0; i < 6; ++i) sp.ws_v[i] = p->ws_v[i];
+        if (!p->solve_extra_v) { int st_ = pdp_dev_alloc((void **)&p->solve_extra_v, sizeof(float) * V); if (st_ != PDP_OK) return st_; }
+        sp.ws_v[6] = p->solve_extra_v;
+        for (int i = 0; i < 3; ++i) sp.ws_vi[i] = p->ws_vi[i];
+        sp.ws_fu[0] = p->ws_fu[0]; sp.ws_fu[1] = p->ws_fu[1];
+        sp.big_list = p->res_big_list; sp.hbm_device_ctl = 1;
+        status = ensure_bytes(&p->res_big_snap, &p->res_big_snap_bytes, snap_bytes + 64);
+        if (status != PDP_OK) return status;
+        float *f = (float *)p->res_big_snap;
+        big_snap.q = f; f += 3 * E; big_snap.fs = f; f += 2 * E; big_snap.av = f; f += V; big_snap.af = f; f += F; big_snap.sol = f; f += V;
+        big_snap.sat = f; f += B; big_snap.emask = f; f += E; big_snap.prev = f; f += E; big_snap.cnt = f; f += B; big_snap.amask = (uint8_t *)f;
+        big_live.q = a->q; big_live.fs = a->fs; big_live.av = p->av; big_live.af = p->af; big_live.sol = p->sol; big_live.sat = p->is_sat;
+        big_live.emask = p->emask; big_live.prev = a->decimator->prev; big_live.cnt = a->decimator->counters; big_live.amask = a->active_mask;
+        if (!p->res_side_stream) {
+            int prio_lo = 0, prio_hi = 0;
+            PDP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+            PDP_HIP_CHECK(hipStreamCreateWithPriority(&p->res_side_stream, hipStreamNonBlocking, prio_hi));
+            for (int i = 0; i < 2; ++i) PDP_HIP_CHECK(hipEventCreateWithFlags(&p->res_side_ev[i], hipEventDisableTiming));
+        }
+    }
+    hipStream_t side = p->res_side_stream;
+    auto launch_big = [&](const SolveParams &spx, hipStream_t s_) { return launch_hbm(p, spx, nbig, s_); };
+    const int big_copy_wgs = nbig >= 256 ? 1 : (256 / (nbig > 0 ? nbig : 1) < 32 ? 256 / (nbig > 0 ? nbig : 1) : 32);      // workgroups per instance of the save / restore copies
     if (const char *env = getenv("PDP_DEBUG_SKIP")) sp.debug_skip = atoi(env);
     int done = 0;
     for (int k = 0; k < nchunks; ++k) {
@@ -1687,18 +1984,39 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
         sp.ctl = ctl + k; sp.spec_used = spec + done; sp.spec_zero = spec + T + done;
         sp.dyn_in = p->res_dyn[k & 1]; sp.dyn_out = p->res_dyn[(k + 1) & 1];
         sp.frc_in = frc_buf[k & 1]; sp.frc_out = frc_buf[(k + 1) & 1];
+        if (nbig) {
+            // pass 1 of the big instances goes FIRST, on the side stream: its few workgroups take their CUs before the LDS-resident kernel
+            // fills the chip, and the two kernels overlap (they meet in front of k_solve_post)
+            sp.nan_iter = &ctl[k].nan_iter; sp.w_perm_zero = &ctl[k].perm_zero; sp.w_iters_run = &ctl[k].iters_run; sp.w_violation = &ctl[k].violation;
+            sp.hbm_replay = 0;
+            PDP_HIP_CHECK(hipEventRecord(p->res_side_ev[0], st)); PDP_HIP_CHECK(hipStreamWaitEvent(side, p->res_side_ev[0], 0));
+            hipLaunchKernelGGL(k_big_state, dim3(nbig, big_copy_wgs), dim3(256), 0, side, make_view(p), (const int32_t *)p->res_big_list, big_live, big_snap, 0,
+                               (const SolveCtl *)(ctl + k), (const SolveCall *)call);
+            { const int st_ = launch_big(sp, side); if (st_ != PDP_OK) return st_; }
+        }
         for (int pass = 0; pass < 2; ++pass) {
+            if (nbig && pass == 1) {
+                // replay of the big instances: restored and rerun on the side stream while the selective replay of the small ones runs
+                sp.hbm_replay = 1;
+                PDP_HIP_CHECK(hipEventRecord(p->res_side_ev[0], st)); PDP_HIP_CHECK(hipStreamWaitEvent(side, p->res_side_ev[0], 0));
+                hipLaunchKernelGGL(k_big_state, dim3(nbig, big_copy_wgs), dim3(256), 0, side, make_view(p), (const int32_t *)p->res_big_list, big_live, big_snap, 1,
+                                   (const SolveCtl *)(ctl + k), (const SolveCall *)call);
+                { const int st_ = launch_big(sp, side); if (st_ != PDP_OK) return st_; }
+            }
             if (timed) PDP_HIP_CHECK(hipEventRecord(p->res_events[4 * k + 2 * pass], st));
-            if (rf && pass == 0) hipLaunchKernelGGL((k_sp_solve_lds<true, false, true>), dim3(p->B), dim3(nt_lds), lds, st, make_view(p), sp);
-            else if (rf) hipLaunchKernelGGL((k_sp_solve_lds<true, true, true>), dim3(p->B), dim3(nt_lds), lds, st, make_view(p), sp);
-            else if (force && pass == 0) hipLaunchKernelGGL((k_sp_solve_lds<true, false>), dim3(p->B), dim3(nt_lds), lds, st, make_view(p), sp);
-            else if (force) hipLaunchKernelGGL((k_sp_solve_lds<true, true>), dim3(p->B), dim3(nt_lds), lds, st, make_view(p), sp);
-            else if (pass == 0) hipLaunchKernelGGL((k_sp_solve_lds<false, false>), dim3(p->B), dim3(nt_lds), lds, st, make_view(p), sp);
-            else hipLaunchKernelGGL((k_sp_solve_lds<false, true>), dim3(p->B), dim3(nt_lds), lds, st, make_view(p), sp);
+            if (rf && pass == 0) hipLaunchKernelGGL((k_sp_solve_lds<true, false, true>), dim3(nfit), dim3(nt_lds), lds, st, make_view(p), sp);
+            else if (rf) hipLaunchKernelGGL((k_sp_solve_lds<true, true, true>), dim3(nfit), dim3(nt_lds), lds, st, make_view(p), sp);
+            else if (force && pass == 0) hipLaunchKernelGGL((k_sp_solve_lds<true, false>), dim3(nfit), dim3(nt_lds), lds, st, make_view(p), sp);
+            else if (force) hipLaunchKernelGGL((k_sp_solve_lds<true, true>), dim3(nfit), dim3(nt_lds), lds, st, make_view(p), sp);
+            else if (pass == 0) hipLaunchKernelGGL((k_sp_solve_lds<false, false>), dim3(nfit), dim3(nt_lds), lds, st, make_view(p), sp);
+            else hipLaunchKernelGGL((k_sp_solve_lds<false, true>), dim3(nfit), dim3(nt_lds), lds, st, make_view(p), sp);
             if (timed) PDP_HIP_CHECK(hipEventRecord(p->res_events[4 * k + 2 * pass + 1], st));
+            if (nbig && pass == 1) { PDP_HIP_CHECK(hipEventRecord(p->res_side_ev[1], side)); PDP_HIP_CHECK(hipStreamWaitEvent(st, p->res_side_ev[1], 0)); }
+            if (nbig && pass == 0) { PDP_HIP_CHECK(hipEventRecord(p->res_side_ev[1], side)); PDP_HIP_CHECK(hipStreamWaitEvent(st, p->res_side_ev[1], 0)); }   // join: pass 1 of the big instances
             if (pass == 0) {
                 hipLaunchKernelGGL(k_solve_post, dim3(1), dim3(1), 0, st, ctl + k, call, c, (int)a->isolate_instances);
-                hipLaunchKernelGGL(k_replay_list, dim3((p->B + 255) / 256), dim3(256), 0, st, p->B, (const int32_t *)last_event, ctl + k, (const SolveCall *)call, replay_list);
+                hipLaunchKernelGGL(k_replay_list, dim3((p->B + 255) / 256), dim3(256), 0, st, p->B, (const int32_t *)last_event, ctl + k, (const SolveCall *)call, replay_list,
+                                   (const uint8_t *)(nbig ? p->res_is_big : nullptr));
             }
         }
         hipLaunchKernelGGL(k_solve_finish, dim3(1), dim3(1), 0, st, ctl + k, call, (const uint32_t *)sp.spec_used, (const uint32_t *)sp.spec_zero, c, done, (int)a->isolate_instances);
@@ -1754,7 +2072,7 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
     PDP_REQUIRE(p->R == 1 || a->replicas_identical, "persistent solve with batch replication needs identical replicas (replicas couple through the termination check)");
     hipStream_t st = ST(stream);
     const int T = a->iterations;
-    a->iterations_run_host = 0; a->used_lds_host = 0; a->kernel_launches_host = 0; a->replay_launches_host = 0;
+    a->iterations_run_host = 0; a->used_lds_host = 0; a->kernel_launches_host = 0; a->replay_launches_host = 0; a->hbm_instances_host = 0;
     a->solve_kernel_ms_host = 0.0f; a->replay_kernel_ms_host = 0.0f;
     if (T <= 0) return PDP_OK;
     const size_t E = p->E, V = p->V, F = p->F, B = p->B;
@@ -1774,13 +2092,19 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
         PDP_HIP_CHECK(hipMemcpyAsync(&force_flag, p->flags + FL_N_SEL, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         PDP_HIP_CHECK(hipStreamSynchronize(st));
         const bool force_r = force_flag != 0 || rf_model;
-        const size_t lds_r = lds2_bytes_for(p->max_n, p->max_m, p->max_e, force_r && !rf_model);   // Reinforce: the force is a 2-bit code in the slot word
-        const bool fits_r = p->fn_edges_identity && lds_r <= 160 * 1024 - 1024 && p->max_e < 65535 && p->max_n < (rf_model ? 8192 : 16384) && p->max_m < 16384 &&
-                            getenv("PDP_SOLVE_FORCE_HBM") == nullptr;          // the switch lets the tests reach the HBM-resident kernel with small instances
+        { int st_ = resident_prepare(p); if (st_ != PDP_OK) return st_; }
+        // per-instance routing: the instances whose image fits run LDS-resident, the others on the HBM-resident kernel in the same chunk
+        // loop; the launch is sized by the largest FITTING instance (Reinforce: the force is a 2-bit code in the slot word, no column)
+        const int fn_ = p->res_fit_n, fm_ = p->res_fit_m, fe_ = p->res_fit_e;
+        const size_t lds_r = lds2_bytes_for(fn_, fm_, fe_, force_r && !rf_model);
+        const bool hbm_forced = getenv("PDP_SOLVE_FORCE_HBM") != nullptr;          // the switch lets the tests reach the HBM-resident kernel with small instances
+        const bool mixed_ok = p->res_nbig == 0 || (!rf_model && !a->isolate_instances && getenv("PDP_SOLVE_NO_ROUTING") == nullptr);
+        const bool fits_r = p->fn_edges_identity && p->res_nfit > 0 && lds_r <= 160 * 1024 - 1024 && (!rf_model || fn_ < 8192) && mixed_ok && !hbm_forced;
         // threads per instance: 256 for tiny instances, 512 while two workgroups share a CU, 1024 when the instance's LDS image allows
         // only one workgroup per CU (the same 16 waves per CU either way)
-        const int nt_r = p->max_e <= 1024 ? 256 : (lds_r > 80 * 1024 ? 1024 : 512);
-        if (fits_r) return sp_solve_resident(p, a, st, force_r, lds_r, nt_r, C);
+        const int nt_r = fe_ <= 1024 ? 256 : (lds_r > 80 * 1024 ? 1024 : 512);
+        if (fits_r) { a->hbm_instances_host = p->res_nbig; return sp_solve_resident(p, a, st, force_r, lds_r, nt_r, C); }
+        a->hbm_instances_host = p->B;
         PDP_REQUIRE(!a->isolate_instances, "isolated-instance mode needs instances that fit the LDS-resident solver");
         if (rf_model) {          // nothing was touched: the caller runs the step-wise loop
             pdp_set_error("persistent Reinforce: an instance does not fit the LDS-resident solver; run the batch step-wise");
@@ -1831,6 +2155,7 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
     sp.prev = a->decimator->prev; sp.counters = a->decimator->counters;
     sp.check_termination = a->check_termination;
     sp.spec_used = spec; sp.spec_zero = spec + C; sp.nan_iter = ctl;
+    sp.w_perm_zero = p->flags + FL_PERM_ZERO; sp.w_iters_run = p->flags + FL_ITERS_RUN; sp.w_violation = p->flags + FL_SPEC_VIOLATION;
     sp.last_event = last_event;
 
     PDP_HIP_CHECK(hipMemsetAsync(ctl, 0, sizeof(uint32_t) * 8, st));
@@ -1847,7 +2172,6 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
         for (int i = 0; i < 3; ++i) sp.ws_vi[i] = p->ws_vi[i];
         sp.ws_fu[0] = p->ws_fu[0]; sp.ws_fu[1] = p->ws_fu[1];
     }
-    auto launch = [&](int grid) { hipLaunchKernelGGL((k_sp_solve<int32_t, false>), dim3(grid), dim3(256), 0, st, make_view(p), sp); };
     auto set_src_live = [&]() {
         sp.inst_list = nullptr;
         sp.src_q = a->q; sp.src_fs = a->fs; sp.src_av = p->av; sp.src_af = p->af; sp.src_sol = p->sol; sp.src_sat = p->is_sat;
@@ -1875,7 +2199,8 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
             }
             // violation (+ iters_run, except for the selective replay which extends pass 1's maximum)
             PDP_HIP_CHECK(hipMemsetAsync(p->flags + FL_SPEC_VIOLATION, 0, sizeof(uint32_t) * (sp.inst_list ? 1 : 2), st));
-            launch(sp.inst_list ? (int)n_replayed : p->B);
+            status = launch_hbm(p, sp, p->B, st);
+            if (status != PDP_OK) break;
             PDP_LAUNCH_CHECK();
             a->kernel_launches_host++;
             PDP_HIP_CHECK(hipMemcpyAsync(host, spec, words * 4, hipMemcpyDeviceToHost, st));

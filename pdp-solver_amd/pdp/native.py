@@ -101,7 +101,7 @@ class SolveArgs(C.Structure):
                 ('decimator', C.c_void_p), ('check_termination', C.c_int32), ('iterations_run_host', C.c_int32),
                 ('used_lds_host', C.c_int32), ('kernel_launches_host', C.c_int32), ('replay_launches_host', C.c_int32),
                 ('time_kernels', C.c_int32), ('solve_kernel_ms_host', C.c_float), ('replay_kernel_ms_host', C.c_float),
-                ('replicas_identical', C.c_int32), ('isolate_instances', C.c_int32)]
+                ('replicas_identical', C.c_int32), ('isolate_instances', C.c_int32), ('hbm_instances_host', C.c_int32)]
 
 
 class AggDesc(C.Structure):
@@ -428,7 +428,8 @@ class Problem(object):
         check(lib().pdp_sp_solve(self._h, C.byref(a), _stream()))
         self.last_solve_launches = int(a.kernel_launches_host)
         self.last_solve_stats = dict(launches=int(a.kernel_launches_host), replays=int(a.replay_launches_host),
-                                     solve_kernel_ms=float(a.solve_kernel_ms_host), replay_kernel_ms=float(a.replay_kernel_ms_host))
+                                     solve_kernel_ms=float(a.solve_kernel_ms_host), replay_kernel_ms=float(a.replay_kernel_ms_host),
+                                     hbm_instances=int(a.hbm_instances_host))
         return int(a.iterations_run_host), bool(a.used_lds_host)
 
 

@@ -252,3 +252,88 @@ def test_persistent_reinforce_degenerate_instances(oracle, T):
                      [[1, (i % 6) + 2, -((i % 5) + 8)] for i in range(30)],
                      ordinary])
     _reinforce_pair(oracle, b, T, 0.1, 0.6, 3)
+
+
+@pytest.mark.parametrize('big_n,T,tol,t_max', [(2500, 40, 0.05, 8), (4000, 26, 0.02, 100)])
+def test_mixed_batch_routes_per_instance(oracle, big_n, T, tol, t_max):
+    """Per-instance routing: a batch of small instances plus ONE instance far past the LDS limit (31 500 / 50 400 edges) no longer moves
+    the whole batch to the HBM-resident kernel -- the small ones run LDS-resident, the big one on the HBM-resident kernel inside the same
+    device-driven chunk loop (shared speculation record, NaN-poison decision and replay, early exit).  End state of every instance = the
+    oracle's strict batch semantics, bit for bit."""
+    from pdp import native
+    from pdp.factorgraph import dataset
+    items = dataset.random_ksat_items(20, 60, 3, m=240, seed=300) + dataset.random_ksat_items(1, big_n, 3, m=int(4.2 * big_n), seed=77) + \
+        dataset.random_ksat_items(19, 50, 3, m=200, seed=900)
+    b = dataset.collate_segment(items)
+    hp, res, q, fs, am, iters, used_lds, spec_ok = run_pair(oracle, b, T, tol, t_max)
+    assert spec_ok and used_lds and hp.last_solve_stats['hbm_instances'] == 1
+    it = res['iterations_run']
+    assert iters == it
+    np.testing.assert_array_equal(npy(am), res['trace_active_mask'][it - 1])
+    np.testing.assert_array_equal(npy(hp.active_variables)[:, 0], res['trace_active_var'][it - 1])
+    np.testing.assert_array_equal(npy(hp.active_functions)[:, 0], res['trace_active_fn'][it - 1])
+    np.testing.assert_array_equal(npy(hp.solution), res['trace_solution'][it - 1])
+    np.testing.assert_array_equal(npy(q), res['q'])
+    np.testing.assert_array_equal(npy(fs), res['fs'])
+
+
+@pytest.mark.parametrize('n_big,with_small', [(3, True), (10, True), (3, False)])
+def test_big_instances_run_as_workgroup_teams(oracle, n_big, with_small):
+    """An instance past the LDS limit is spread over a TEAM of workgroups of the HBM-resident kernel (device-scope barriers and
+    reductions, the team on one XCD): several big instances at once (ten = two teams on some XCDs), next to LDS-resident ones in the
+    device-driven loop and alone in the host-driven loop; alpha = 3.5, so the big instances converge and are decimated (scorer,
+    arg-max and simplification run through the team primitives too).  End state = the oracle's, bit for bit."""
+    from pdp.factorgraph import dataset
+    items = []
+    if with_small:
+        items += dataset.random_ksat_items(30, 60, 3, m=240, seed=310)
+    items += [dataset.random_ksat_items(1, 1500 + 100 * i, 3, m=int(3.5 * (1500 + 100 * i)), seed=4100 + i)[0] for i in range(n_big)]
+    if with_small:
+        items += dataset.random_ksat_items(10, 50, 3, m=200, seed=910)
+    b = dataset.collate_segment(items)
+    hp, res, q, fs, am, iters, used_lds, spec_ok = run_pair(oracle, b, 60, 0.05, 8)
+    if not spec_ok:
+        pytest.skip("speculation failed on this batch (the caller would rerun step-wise)")
+    assert used_lds == with_small and hp.last_solve_stats['hbm_instances'] == (n_big if with_small else len(items))
+    it = res['iterations_run']
+    assert iters == it
+    # the big instances did get decimated
+    assert (res['trace_active_var'][it - 1] == 0).sum() > 0
+    np.testing.assert_array_equal(npy(am), res['trace_active_mask'][it - 1])
+    np.testing.assert_array_equal(npy(hp.active_variables)[:, 0], res['trace_active_var'][it - 1])
+    np.testing.assert_array_equal(npy(hp.active_functions)[:, 0], res['trace_active_fn'][it - 1])
+    np.testing.assert_array_equal(npy(hp.solution), res['trace_solution'][it - 1])
+    np.testing.assert_array_equal(npy(q), res['q'])
+    np.testing.assert_array_equal(npy(fs), res['fs'])
+
+
+def test_mixed_batch_routing_under_nan_poison(oracle):
+    """The NaN-poisoned batch of test_persistent_solve_reproduces_nan_poisoning with a 21 000-edge instance added: the big instance runs on
+    the HBM-resident kernel, is saved at chunk entry and replayed from there once some (small) instance poisons the batch; the small
+    instances are replayed selectively as before.  Everything equals the oracle's strict semantics bit for bit -- with decimations of the
+    big instance before the poison and none after it."""
+    from pdp.factorgraph import dataset
+    from helpers import random_batch as rb
+    small = rb(batch=400, n=60, k=3, seed=7000)
+    # rebuild the same small instances as loader items and append the big one
+    from pdp import generator
+    items = []
+    for i in range(400):
+        rng = np.random.RandomState(7000 + i)
+        items.append(dataset.instance_from_clauses(60, generator.uniform_ksat(60, generator.clause_count(60, 3), 3, rng), label=-1, name="u%d" % i))
+    b0 = dataset.collate_segment(items)
+    np.testing.assert_array_equal(b0['graph_map'], small['graph_map'])
+    items.append(dataset.random_ksat_items(1, 2000, 3, m=7000, seed=123)[0])           # alpha = 3.5: converges and gets decimated
+    b = dataset.collate_segment(items)
+    hp, res, q, fs, am, iters, used_lds, spec_ok = run_pair(oracle, b, 120, 0.05, 8)
+    assert np.isnan(res['fs']).any() and spec_ok and used_lds and hp.last_solve_stats['hbm_instances'] == 1 and hp.last_solve_stats['replays'] >= 1
+    it = res['iterations_run']
+    assert iters == it
+    big_v = slice(int(b['batch_variable_map'].size) - 2000, None)
+    assert (res['trace_active_var'][it - 1][big_v] == 0).sum() >= 3                     # the big instance was decimated (before the poison)
+    np.testing.assert_array_equal(npy(am), res['trace_active_mask'][it - 1])
+    np.testing.assert_array_equal(npy(hp.active_variables)[:, 0], res['trace_active_var'][it - 1])
+    np.testing.assert_array_equal(npy(hp.active_functions)[:, 0], res['trace_active_fn'][it - 1])
+    np.testing.assert_array_equal(npy(hp.solution), res['trace_solution'][it - 1])
+    np.testing.assert_array_equal(npy(q), res['q'])
+    np.testing.assert_array_equal(npy(fs), res['fs'])
