@@ -84,6 +84,7 @@ struct SolveParams {
     // teams (k_sp_solve<NT, true>): team_size workgroups per instance, team_count instances, numbered slot-minor over team_slots
     int team_size, team_count, team_slots;
     int team_no_xcd;            // debugging: always take the agent-scope barrier
+    int lds_tickets;            // LDS-resident kernel, pass 1: 0 = instance blockIdx.x, else the number of instances the workgroups draw tickets for
     uint32_t *team_ws;          // [team_count][PDP_TEAM_WORDS], zeroed before every launch
 };
 
@@ -97,7 +98,7 @@ struct SolveCtl {               // one per chunk
     uint32_t replay_count;      // instances listed for the poison replay
     uint32_t do_replay;
     int32_t poison_from;        // replay pass: first poisoned (chunk-relative) iteration
-    uint32_t pad;
+    uint32_t ticket;            // next instance of the LDS-resident pass (launches with sp.lds_tickets)
 };
 struct SolveCall {
     uint32_t poisoned_all;      // a NaN poisoned the batch in an earlier chunk: later chunks run poisoned from their first iteration
@@ -1083,8 +1084,19 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
     SolveCtl *const ctl = sp.ctl;
-    const int index = (int)blockIdx.x;
     if (sp.call->stop) return;                                                 // every instance went inactive in an earlier chunk
+    // Which instance: normally blockIdx.x.  The hardware deals workgroups to the XCDs round-robin, so an XCD that is slower than the
+    // others -- in a mixed batch one of them also hosts the team of a big instance -- makes a static launch wait for its eighth of
+    // the instances.  With sp.lds_tickets every workgroup draws the next instance when it STARTS and the grid is over-provisioned:
+    // the slow XCD simply gets through fewer tickets, and the workgroups left over when they run out leave at once.
+    int index = (int)blockIdx.x;
+    if (!REPLAY && sp.lds_tickets) {
+        __shared__ int s_ticket;
+        if (tid == 0) s_ticket = (int)atomicAdd(&ctl->ticket, 1u);
+        __syncthreads();
+        index = s_ticket;
+        if (index >= sp.lds_tickets) return;
+    }
     if (REPLAY && (!ctl->do_replay || (uint32_t)index >= ctl->replay_count)) return;
     const Inst G = load_inst(pv_, REPLAY ? sp.inst_list[index] : (sp.fit_list ? sp.fit_list[index] : index));
     const int n = G.n, m = G.m, ne = G.e;
@@ -1972,6 +1984,9 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     }
     hipStream_t side = p->res_side_stream;
     auto launch_big = [&](const SolveParams &spx, hipStream_t s_) { return launch_hbm(p, spx, nbig, s_); };
+    // ticketed LDS-resident pass (see k_sp_solve_lds): on for mixed batches; PDP_SOLVE_TICKETS=<percent of over-provisioning>, 0 = off
+    int ticket_extra = nbig > 0 ? 25 : 0;
+    if (const char *env = getenv("PDP_SOLVE_TICKETS")) ticket_extra = atoi(env);
     const int big_copy_wgs = nbig >= 256 ? 1 : (256 / (nbig > 0 ? nbig : 1) < 32 ? 256 / (nbig > 0 ? nbig : 1) : 32);      // workgroups per instance of the save / restore copies
     if (const char *env = getenv("PDP_DEBUG_SKIP")) sp.debug_skip = atoi(env);
     int done = 0;
@@ -2004,11 +2019,13 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
                 { const int st_ = launch_big(sp, side); if (st_ != PDP_OK) return st_; }
             }
             if (timed) PDP_HIP_CHECK(hipEventRecord(p->res_events[4 * k + 2 * pass], st));
-            if (rf && pass == 0) hipLaunchKernelGGL((k_sp_solve_lds<true, false, true>), dim3(nfit), dim3(nt_lds), lds, st, make_view(p), sp);
+            sp.lds_tickets = (pass == 0 && ticket_extra > 0) ? nfit : 0;
+            const int grid_lds = sp.lds_tickets ? nfit + (int)(((int64_t)nfit * ticket_extra + 99) / 100) : nfit;
+            if (rf && pass == 0) hipLaunchKernelGGL((k_sp_solve_lds<true, false, true>), dim3(grid_lds), dim3(nt_lds), lds, st, make_view(p), sp);
             else if (rf) hipLaunchKernelGGL((k_sp_solve_lds<true, true, true>), dim3(nfit), dim3(nt_lds), lds, st, make_view(p), sp);
-            else if (force && pass == 0) hipLaunchKernelGGL((k_sp_solve_lds<true, false>), dim3(nfit), dim3(nt_lds), lds, st, make_view(p), sp);
+            else if (force && pass == 0) hipLaunchKernelGGL((k_sp_solve_lds<true, false>), dim3(grid_lds), dim3(nt_lds), lds, st, make_view(p), sp);
             else if (force) hipLaunchKernelGGL((k_sp_solve_lds<true, true>), dim3(nfit), dim3(nt_lds), lds, st, make_view(p), sp);
-            else if (pass == 0) hipLaunchKernelGGL((k_sp_solve_lds<false, false>), dim3(nfit), dim3(nt_lds), lds, st, make_view(p), sp);
+            else if (pass == 0) hipLaunchKernelGGL((k_sp_solve_lds<false, false>), dim3(grid_lds), dim3(nt_lds), lds, st, make_view(p), sp);
             else hipLaunchKernelGGL((k_sp_solve_lds<false, true>), dim3(nfit), dim3(nt_lds), lds, st, make_view(p), sp);
             if (timed) PDP_HIP_CHECK(hipEventRecord(p->res_events[4 * k + 2 * pass + 1], st));
             if (nbig && pass == 1) { PDP_HIP_CHECK(hipEventRecord(p->res_side_ev[1], side)); PDP_HIP_CHECK(hipStreamWaitEvent(st, p->res_side_ev[1], 0)); }
