@@ -74,16 +74,20 @@ def test_persistent_solve_golden_trace():
 
 
 def test_speculation_detects_coupling(oracle):
-    """A single instance without any inactive variable has batch-global min > 0: the persistent solver must
-    refuse (PDP_ERR_SPECULATION) instead of returning a result that differs from the reference."""
+    """Two instances without any inactive variable: the batch-global min is > 0 and no instance supplies an exact zero, so the
+    persistent solver must refuse (PDP_ERR_SPECULATION) instead of returning a result that differs from the reference.  (A batch of
+    ONE such instance is solved exactly instead: test_single_instance_batches_run_exact.)"""
     from pdp import native
     from pdp.factorgraph import dataset
     n = 12
-    clauses = []
-    for v in range(1, n + 1):
-        a, b2 = (v % n) + 1, ((v + 4) % n) + 1
-        clauses.append([v, -a, b2]); clauses.append([-v, a, -b2]); clauses.append([v, a, -b2]); clauses.append([-v, -a, b2])
-    b = dataset.collate_segment([dataset.instance_from_clauses(n, clauses)])
+    items = []
+    for shift in (4, 5):
+        clauses = []
+        for v in range(1, n + 1):
+            a, b2 = (v % n) + 1, ((v + shift) % n) + 1
+            clauses.append([v, -a, b2]); clauses.append([-v, a, -b2]); clauses.append([v, a, -b2]); clauses.append([-v, -a, b2])
+        items.append(dataset.instance_from_clauses(n, clauses))
+    b = dataset.collate_segment(items)
     hp, op = make_pair(oracle, b)
     hp.simplify(); op.simplify()
     assert op.state()[0].min() == 1.0     # nothing got de-activated: no exact zero in the batch
@@ -305,6 +309,31 @@ def test_big_instances_run_as_workgroup_teams(oracle, n_big, with_small):
     np.testing.assert_array_equal(npy(hp.solution), res['trace_solution'][it - 1])
     np.testing.assert_array_equal(npy(q), res['q'])
     np.testing.assert_array_equal(npy(fs), res['fs'])
+
+
+@pytest.mark.parametrize('n,alpha,T,seeds', [(50, 4.2, 60, range(0, 12)), (200, 4.2, 100, range(20, 26)), (60, 3.5, 120, range(40, 52)), (3000, 3.5, 40, range(60, 62))])
+def test_single_instance_batches_run_exact(oracle, n, alpha, T, seeds):
+    """A batch of ONE instance: nobody else can supply the exact zero the speculation counts on (it fails in the first sweep for most
+    random instances), but the batch-global minima of util.sparse_max / sparse_argmax are then the instance's own.  pdp_sp_solve computes
+    them in the HBM-resident kernel (one launch, a team of workgroups for the n=3000 instance), a NaN survey poisons the instance from
+    that sweep on without a replay, and the call never fails.  End state = the oracle's strict semantics, bit for bit."""
+    from pdp.factorgraph import dataset
+    saw_decimation = False
+    for seed in seeds:
+        items = dataset.random_ksat_items(1, n, 3, m=int(alpha * n), seed=9000 + seed)
+        b = dataset.collate_segment(items)
+        hp, res, q, fs, am, iters, used_lds, spec_ok = run_pair(oracle, b, T, 0.05, 8)
+        assert spec_ok and not used_lds
+        it = res['iterations_run']
+        assert iters == it, seed
+        saw_decimation |= bool((res['trace_active_var'][it - 1] == 0).any())
+        np.testing.assert_array_equal(npy(am), res['trace_active_mask'][it - 1], err_msg=str(seed))
+        np.testing.assert_array_equal(npy(hp.active_variables)[:, 0], res['trace_active_var'][it - 1], err_msg=str(seed))
+        np.testing.assert_array_equal(npy(hp.active_functions)[:, 0], res['trace_active_fn'][it - 1], err_msg=str(seed))
+        np.testing.assert_array_equal(npy(hp.solution), res['trace_solution'][it - 1], err_msg=str(seed))
+        np.testing.assert_array_equal(npy(q), res['q'], err_msg=str(seed))
+        np.testing.assert_array_equal(npy(fs), res['fs'], err_msg=str(seed))
+    assert saw_decimation
 
 
 def test_mixed_batch_routing_under_nan_poison(oracle):

@@ -16,8 +16,11 @@ def run(its, T=50):
     except native.SpeculationFailed:
         return False
 for B, n in [(1, 50), (1, 200), (10, 50), (100, 50), (100, 200), (1000, 50)]:
-    ok = 0; tot = 20
+    ok = 0; tot = 20; first = []
     for s in range(tot):
         its = dataset.random_ksat_items(B, n, 3, m=int(4.2 * n), seed=1000 * s + 7)
-        ok += run(its)
-    print('B=%d n=%d: speculation held in %d of %d batches' % (B, n, ok, tot))
+        held = run(its)
+        ok += held
+        if not held:            # first iteration count at which the call fails = 1 + the failing iteration
+            first.append(next(t for t in range(1, 51) if not run(its, T=t)))
+    print('B=%d n=%d: speculation held in %d of %d batches; failing iteration (1-based) of the others: %s' % (B, n, ok, tot, sorted(first)))
