@@ -27,26 +27,33 @@ import dimacs2json  # noqa: E402
 from pdp.trainer import SatFactorGraphTrainer  # noqa: E402
 
 
-def run(config, logger, output):
-    "Runs the prediction engine (reference: satyr.py:21-42)."
-    np.random.seed(config['random_seed'])
-    torch.manual_seed(config['random_seed'])
-    if config['verbose']:
-        logger.info("Building the computational graph...")
-    predicter = SatFactorGraphTrainer(config=config, use_cuda=not config['cpu_mode'], logger=logger)
-    if config['verbose']:
-        logger.info("Starting the prediction phase...")
-    predicter._counter = 0
+def _open_output(path):
+    "where the result rows go: stdout, a file, or nowhere (ranks other than 0 of a sharded run: rank 0 writes the gathered rows)"
     if int(os.environ.get('RANK', '0')) != 0:
-        output = os.devnull                                # sharded run: rank 0 writes the gathered rows
-    if output == '':
-        predicter.predict(test_list=config['test_path'], out_file=sys.stdout, import_path_base=config['model_path'],
-                          post_processor=predicter._post_process_predictions, batch_replication=config['batch_replication'])
-    else:
-        with open(output, 'w') as file:
-            predicter.predict(test_list=config['test_path'], out_file=file, import_path_base=config['model_path'],
-                              post_processor=predicter._post_process_predictions, batch_replication=config['batch_replication'])
-    return predicter
+        return open(os.devnull, 'w'), True
+    if not path:
+        return sys.stdout, False
+    return open(path, 'w'), True
+
+
+def run(config, logger, output):
+    "Seeds the two random sources, builds the model of config['model_type'] and writes one result row per input instance."
+    seed = config['random_seed']
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    say = logger.info if config['verbose'] else (lambda *a, **k: None)
+    say("Building the computational graph...")
+    solver = SatFactorGraphTrainer(config=config, use_cuda=not config['cpu_mode'], logger=logger)
+    solver._counter = 0
+    say("Starting the prediction phase...")
+    sink, owned = _open_output(output)
+    try:
+        solver.predict(test_list=config['test_path'], out_file=sink, import_path_base=config['model_path'],
+                       post_processor=solver._post_process_predictions, batch_replication=config['batch_replication'])
+    finally:
+        if owned:
+            sink.close()
+    return solver
 
 
 def main(argv=None):
