@@ -85,6 +85,8 @@ struct SolveParams {
     int team_size, team_count, team_slots;
     int team_no_xcd;            // debugging: always take the agent-scope barrier
     int exact;                  // HBM-resident kernel, single-instance batch: the batch-global minima ARE the instance's own, nothing is speculated
+    int rf;                     // HBM-resident kernel: the Reinforce triple (coins, dprob as for the LDS-resident kernel; tol = the gate's 0.01)
+    int isolate;                // HBM-resident kernel: isolated instances (a NaN stays inside its instance, pass 1 is final)
     int lds_tickets;            // LDS-resident kernel, pass 1: 0 = instance blockIdx.x, else the number of instances the workgroups draw tickets for
     uint32_t *team_ws;          // [team_count][PDP_TEAM_WORDS], zeroed before every launch
 };
@@ -278,6 +280,49 @@ __device__ __forceinline__ IterRed team_iter_reduce(const TeamView &t, IterRed x
     return r;
 }
 
+// Reinforce triple on the HBM-resident view (the cold part of an iteration; lds_reinforce_step is the LDS-resident twin): with `do_force`
+// the force update of ReinforceDecimator.forward (pdp_decimate.py:218-232: SurveyScorer on the new surveys and the OLD force, then
+// force <- sign(score) on every edge of the instance), always ReinforcePredictor (pdp_predict.py:221-226) + _update_solution
+// (solver.py:388-399).  The force a sweep read is kept in s2 (free after P4): the write-back rebuilds q_s / q_dc of the last sweep from it.
+// Returns 1 if a score was NaN.
+template <class V>
+__device__ int hbm_reinforce_step(const V &I, float *fs /*[e][2]*/, float pi, int do_force)
+{
+    const int tid = team_tid(I), nt = team_nt(I);
+    if (do_force) {
+        for (int e = tid; e < I.e; e += nt) I.s3[e] = pdp_safe_log(1.0f - I.eta[e * I.estride], PDP_SCORER_EPS) * (0.0f + I.af[I.e_fn[e]]);
+        team_sync(I);
+    }
+    int bad = 0;
+    for (int v = tid; v < I.n; v += nt) {
+        const int a = I.v_ptr[v], bnd = I.v_ptr[v + 1];
+        float ext = 0.0f;
+        if (do_force) {
+            float pos = 0.0f, neg = 0.0f, all = 0.0f;
+            for (int k = a; k < bnd; ++k) {
+                const int e = I.v_edges[k];
+                const float f = I.s3[e];
+                const int sg = I.sgn[e];
+                ext = ext + fs[2 * e + 1];
+                pos = pos + ((sg == 1) ? 1.0f : 0.0f) * f;
+                neg = neg + ((sg == -1) ? 1.0f : 0.0f) * f;
+                all = all + f;
+            }
+            const float sc = d_score_from_sums(pos, neg, all, ext, pi);
+            if (sc != sc) bad = 1;
+            const float sg = 0.0f + pdp_sign_nan(sc);
+            // mask * sign + (1 - mask) * old with mask == 1 (the instance is active, old is finite)
+            for (int k = a; k < bnd; ++k) { const int e = I.v_edges[k]; I.s2[e] = fs[2 * e + 1]; fs[2 * e + 1] = sg; }
+        }
+        ext = 0.0f;
+        for (int k = a; k < bnd; ++k) ext = ext + fs[2 * I.v_edges[k] + 1];
+        const float pred = (ext > 0.0f) ? 1.0f : 0.0f;
+        const float av = I.av[v];
+        if (av == 1.0f) I.sol[v] = av * pred + (1.0f - av) * I.sol[v];      // only active variables take the prediction (solver.py:395-397)
+    }
+    return team_any(I, bad);
+}
+
 // HBM-resident form of the solver: the instance's arrays stay where the problem keeps them, one workgroup (TEAM = false) or a
 // team of workgroups (TEAM = true, few big instances) walks them.
 template <int NT, bool TEAM>
@@ -294,7 +339,8 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
         if (sp.hbm_replay && !sp.ctl->do_replay) return;                     // no NaN poisoned the batch in this chunk
     }
     int poison_from = sp.hbm_device_ctl ? (sp.hbm_replay ? sp.ctl->poison_from : (sp.call->poisoned_all ? 0 : 0x7fffffff)) : sp.poison_from;
-    const bool exact = sp.exact != 0;
+    const bool exact = sp.exact != 0, rf = sp.rf != 0;
+    const bool own_nan = exact || sp.isolate != 0;      // a NaN never leaves the instance: no batch-wide poison record, no replay
     std::conditional_t<TEAM, TeamView, SView<int32_t>> I;
     int slot = (int)blockIdx.x;          // which of the launch's instances
     if constexpr (TEAM) {
@@ -344,6 +390,7 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
     int iters = 0, did_prop = 0;
     int nsat = -1;                            // cached CNF result (solution only changes on decimation)
     int violation = 0;
+    int rf_last_flip = 0;                     // Reinforce: the force was renewed after the last sweep (s2 holds the one that sweep read)
     const bool other_rows = n < pv.V;
 
     int abort_next = 0;
@@ -480,7 +527,7 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
         }
         TP(4)
         // the same barrier carries pass 1's look at the batch's first NaN iteration for the next trip of the loop
-        const int nan_before_next = (!exact && poison_from == 0x7fffffff && tid == 0 &&
+        const int nan_before_next = (!own_nan && poison_from == 0x7fffffff && tid == 0 &&
                                      __hip_atomic_load(sp.nan_iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)(t + 1)) ? 1 : 0;
         red.bits = (z1 ? 1 : 0) | (z2 ? 2 : 0) | (nan_seen ? 4 : 0) | (nan_before_next ? 8 : 0);
         red = team_iter_reduce(I, red, exact, redf, redi);
@@ -502,13 +549,18 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
         if (exact && nan_seen && !poisoned) { poison_from = t; poisoned = true; }
         // A NaN survey (0/0 in pdp_propagate.py:215-216) makes every batch-global min/max of the reference NaN from
         // this iteration on.  Pass 1 records the first such iteration, pass 2 replays with it.
-        if (nan_seen && !poisoned) {
+        if (nan_seen && !poisoned && sp.isolate) {
+            // isolated instance: comparisons with the NaN maxima are false below and `nan_seen` keeps the decimation off, that is all
+        } else if (nan_seen && !poisoned) {
             if (tid == 0) atomicMin(sp.nan_iter, (uint32_t)t);
             if (poison_from != 0x7fffffff) violation = 1;      // pass 2 must not find an earlier NaN
             else abort_next = 1;
         }
-        int conv = 0;
-        if (!poisoned) {
+        int conv = 0, rf_changed = 0;
+        if (rf) {
+            // active_mask[sum_diff <= 0.01] = 0 (pdp_decimate.py:205-215; no survey gate, no counters); under the poison the batch-wide maximum is NaN
+            if (!poisoned && has_prev && dmax <= sp.tol) active = 0;
+        } else if (!poisoned) {
             if (g <= 1e-10f) active = 0;                      // trivial surveys: leave the instance to Walk-SAT
             if (has_prev) {
                 if (dmax < sp.tol) cnt = 0.0f;
@@ -519,13 +571,23 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
             // all maxima are NaN: comparisons are False, only the counter overflow still "converges" an instance
             if (cnt >= sp.t_max) { conv = 1; cnt = 0.0f; }
         }
-        uint32_t used = 1u | (has_prev ? 2u : 0u);
-        uint32_t zero = (z1 ? 1u : 0u) | ((has_prev && z2) ? 2u : 0u);
+        uint32_t used = (rf ? 0u : 1u) | (has_prev ? 2u : 0u);
+        uint32_t zero = ((!rf && z1) ? 1u : 0u) | ((has_prev && z2) ? 2u : 0u);
         // coeff = |score| * active * converged: every variable of a non-converged instance is an exact 0 of site 2
-        if (has_prev && !conv && n > 0) zero |= 4u;
+        if (!rf && has_prev && !conv && n > 0) zero |= 4u;
+        if (rf) {
+            // the shared coin of this iteration (pdp_decimate.py:218); instances that are still active after the gate renew their force.
+            // Predictor + _update_solution run in every iteration of the reference; their result only changes with the force.
+            const int flip = (sp.coins[sp.chunk_start + t] < sp.dprob) && active;
+            rf_last_flip = flip;
+            if (flip || nsat < 0) {
+                if (hbm_reinforce_step(I, gfs, sp.pi, flip) && !nan_seen) violation = 1;    // a NaN score without a NaN survey: not expected
+                rf_changed = 1;
+            }
+        }
         // ---- P6: decimation (pdp_decimate.py:152-171)
         int decimated = 0;
-        if (has_prev && conv && !poisoned && !nan_seen) {
+        if (!rf && has_prev && conv && !poisoned && !nan_seen) {
             // scorer (pdp_predict.py:155-192)
             for (int e = tid; e < ne; e += nt)
                 I.s3[e] = pdp_safe_log(1.0f - I.eta[e * I.estride], PDP_SCORER_EPS) * (0.0f + I.af[I.e_fn[e]]);
@@ -573,7 +635,7 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
             }
         }
         if (has_prev) cnt = cnt + 1.0f;
-        if (tid == 0 && !poisoned && !exact) { atomicOr(&sp.spec_used[t], used); if (zero) atomicOr(&sp.spec_zero[t], zero); }
+        if (tid == 0 && !poisoned && !own_nan) { atomicOr(&sp.spec_used[t], used); if (zero) atomicOr(&sp.spec_zero[t], zero); }
         // ---- P7: edge mask refresh (solver.py:370-371); values only change after a decimation
         if (decimated || !use_em) {
             for (int e = tid; e < ne; e += nt) {
@@ -586,7 +648,7 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
         }
         // ---- P8: prediction = solution; termination check (trainer.py:150-162, util.py:226-236)
         if (sp.check_termination) {
-            if (decimated || nsat < 0) nsat = d_cnf_sat_count(I, I.sol, redi);
+            if (decimated || rf_changed || nsat < 0) nsat = d_cnf_sat_count(I, I.sol, redi);
             if (active && nsat == m) active = 0;
         }
         has_prev = 1; prev_from_global = 0;
@@ -601,7 +663,8 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
     if (did_prop) {
         // q_s / q_dc of the last sweep are recomputed from the per-variable sums that are still resident
         for (int e = tid; e < ne; e += nt) {
-            const SpOut o = d_sp_edge((float)I.sgn[e], I.P[I.e_var[e]], I.N[I.e_var[e]], I.s1[e], I.force[e * I.fstride], L0h, L1h);
+            const float frc = (rf && rf_last_flip) ? I.s2[e] : I.force[e * I.fstride];      // the force the last sweep read
+            const SpOut o = d_sp_edge((float)I.sgn[e], I.P[I.e_var[e]], I.N[I.e_var[e]], I.s1[e], frc, L0h, L1h);
             // (1 - mask) * old keeps a NaN forever; the three columns of q turn NaN together, so q_u carries the stickiness
             const float sticky = I.qu[e * I.qstride];
             gq[3 * e + 1] = 1.0f * o.qs + (1.0f - 1.0f) * sticky;
@@ -1974,6 +2037,7 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     sp.prev = a->decimator->prev; sp.counters = a->decimator->counters;
     sp.check_termination = a->check_termination;
     sp.coins = a->coins; sp.dprob = a->decimation_probability;
+    sp.rf = rf ? 1 : 0; sp.isolate = a->isolate_instances ? 1 : 0;      // (read by the HBM-resident kernel of the big instances)
     float *frc_buf[2] = {nullptr, nullptr};
     if (rf) {
         frc_buf[0] = (float *)(((uintptr_t)(replay_list + B) + 15) & ~(uintptr_t)15); frc_buf[1] = frc_buf[0] + E + 4;
@@ -2127,7 +2191,7 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
     // A batch of ONE instance has nobody to supply the exact zero the speculation counts on (tools/spec_rate.py: it fails in the first
     // iteration for 10-19 of 20 random instances) -- but its batch-global minima are its own: the HBM-resident kernel computes them
     // (sp.exact), nothing is speculated, recorded or replayed, and the whole loop is one launch (a team of workgroups when the instance is big).
-    const bool exact = B == 1 && !rf_model && !a->isolate_instances && getenv("PDP_SOLVE_NO_EXACT") == nullptr;
+    const bool exact = B == 1 && !a->isolate_instances && getenv("PDP_SOLVE_NO_EXACT") == nullptr;
     int C = 12;
     if (const char *env = getenv("PDP_SOLVE_CHUNK")) { const int v = atoi(env); if (v > 0) C = v; }
     if (C > T) C = T;
@@ -2145,18 +2209,13 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
         const int fn_ = p->res_fit_n, fm_ = p->res_fit_m, fe_ = p->res_fit_e;
         const size_t lds_r = lds2_bytes_for(fn_, fm_, fe_, force_r && !rf_model);
         const bool hbm_forced = getenv("PDP_SOLVE_FORCE_HBM") != nullptr;          // the switch lets the tests reach the HBM-resident kernel with small instances
-        const bool mixed_ok = p->res_nbig == 0 || (!rf_model && !a->isolate_instances && getenv("PDP_SOLVE_NO_ROUTING") == nullptr);
+        const bool mixed_ok = p->res_nbig == 0 || getenv("PDP_SOLVE_NO_ROUTING") == nullptr;
         const bool fits_r = p->fn_edges_identity && p->res_nfit > 0 && lds_r <= 160 * 1024 - 1024 && (!rf_model || fn_ < 8192) && mixed_ok && !hbm_forced && !exact;
         // threads per instance: 256 for tiny instances, 512 while two workgroups share a CU, 1024 when the instance's LDS image allows
         // only one workgroup per CU (the same 16 waves per CU either way)
         const int nt_r = fe_ <= 1024 ? 256 : (lds_r > 80 * 1024 ? 1024 : 512);
         if (fits_r) { a->hbm_instances_host = p->res_nbig; return sp_solve_resident(p, a, st, force_r, lds_r, nt_r, C); }
         a->hbm_instances_host = p->B;
-        PDP_REQUIRE(!a->isolate_instances, "isolated-instance mode needs instances that fit the LDS-resident solver");
-        if (rf_model) {          // nothing was touched: the caller runs the step-wise loop
-            pdp_set_error("persistent Reinforce: an instance does not fit the LDS-resident solver; run the batch step-wise");
-            return PDP_ERR_SPECULATION;
-        }
     }
     // ---- instances too large for the LDS: HBM-resident kernel, host-driven chunk loop -----------------------------------
 
@@ -2204,6 +2263,7 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
     sp.spec_used = spec; sp.spec_zero = spec + C; sp.nan_iter = ctl;
     sp.w_perm_zero = p->flags + FL_PERM_ZERO; sp.w_iters_run = p->flags + FL_ITERS_RUN; sp.w_violation = p->flags + FL_SPEC_VIOLATION;
     sp.last_event = last_event;
+    sp.rf = rf_model ? 1 : 0; sp.isolate = a->isolate_instances ? 1 : 0; sp.coins = a->coins; sp.dprob = a->decimation_probability;
 
     PDP_HIP_CHECK(hipMemsetAsync(ctl, 0, sizeof(uint32_t) * 8, st));
     const bool fits = false;
@@ -2245,7 +2305,7 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
     int done = 0, total_iters = 0;
     while (status == PDP_OK && ok && done < T) {
         const int c = (T - done) < C ? (T - done) : C;
-        sp.T = c; sp.has_prev = a->decimator->has_prev; sp.has_edge_mask = p->has_edge_mask;
+        sp.T = c; sp.has_prev = a->decimator->has_prev; sp.has_edge_mask = p->has_edge_mask; sp.chunk_start = done;
         sp.final_chunk = (done + c >= T) ? 1 : 0;
         set_src_live();
         int poison_from = poisoned_all ? 0 : 0x7fffffff;
@@ -2269,7 +2329,7 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
             PDP_HIP_CHECK(hipMemcpyAsync(p->flags_host, p->flags, FL_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             PDP_HIP_CHECK(hipStreamSynchronize(st));
             const uint32_t t_nan = host[2 * (size_t)C];
-            if (pass == 0 && !poisoned_all && t_nan < (uint32_t)c) {
+            if (pass == 0 && !poisoned_all && t_nan < (uint32_t)c && !a->isolate_instances) {
                 // Some instance poisons the batch from (chunk-relative) iteration t_nan on.
                 poison_from = (int)t_nan;
                 poisoned_all = true;
@@ -2285,7 +2345,7 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
         if (status != PDP_OK || !ok) break;
         ok = p->flags_host[FL_SPEC_VIOLATION] == 0u;
         const uint32_t perm_from = p->flags_host[FL_PERM_ZERO];
-        for (int t = 0; t < c && t < poison_from && ok; ++t)
+        for (int t = 0; t < c && t < poison_from && ok && !a->isolate_instances; ++t)
             if ((uint32_t)t < perm_from && (host[t] & ~host[C + t]) != 0u) ok = false;
         if (debug)
             fprintf(stderr, "[pdp_sp_solve] chunk@%d len=%d violation=%u perm_from=%u poison_from=%d replayed=%u iters=%u lds=%zu ok=%d\n", done, c,

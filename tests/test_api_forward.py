@@ -497,13 +497,12 @@ def test_reinforce_persistent_equals_stepwise(alpha, n, B, T, w, has_nan, R):
     assert float(a[2][1][:, 1].nan_to_num(nan=0.0).abs().sum()) > 0            # the force column was renewed at all
 
 
-def test_reinforce_steps_when_the_resident_solver_is_unavailable(monkeypatch):
-    """The Reinforce triple exists on the LDS-resident solver only: when an instance does not fit (forced here by the switch the tests use to
-    reach the HBM-resident SP kernel) the persistent call reports it without touching any state and the solver runs the step-wise loop --
-    same result as the reference, same generator consumption."""
+def test_reinforce_on_the_hbm_resident_kernel_equals_reference(monkeypatch):
+    """The Reinforce triple when the instances do not fit the LDS (forced here by the switch the tests use to reach the HBM-resident
+    kernel): the persistent call runs it on the HBM-resident kernel -- same result as the reference, same generator consumption."""
     monkeypatch.setenv('PDP_SOLVE_FORCE_HBM', '1')
     d, tr, m, pred, states, batch = run_golden('trace_reinforce_easy', 'reinforce', persistent=True, pi=0.01, decimation_probability=0.5)
-    assert m.last_run['path'] == 'stepwise'
+    assert m.last_run['path'] == 'persistent-hbm'
     np.testing.assert_array_equal(pred[0].cpu().numpy()[:, 0], d['final_prediction'])
     torch.manual_seed(int(d['meta'][2]))
     torch.rand(int(d['rand_sizes'].sum()))

@@ -222,7 +222,7 @@ def test_persistent_reinforce_matches_oracle_loop(oracle, monkeypatch, spec, T, 
     assert np.abs(res['fs'][:, 1]).sum() > 0
 
 
-def _reinforce_pair(oracle, b, T, pi, dprob, seed):
+def _reinforce_pair(oracle, b, T, pi, dprob, seed, expect_lds=True):
     from pdp import native
     hp, op = make_pair(oracle, b)
     coins = np.random.RandomState(seed).rand(T).astype(np.float32)
@@ -235,12 +235,61 @@ def _reinforce_pair(oracle, b, T, pi, dprob, seed):
     dec = native.Decimator(hp)
     iters, used_lds = hp.sp_solve(q, fs, am, dec, T, 0.01, 0.0, pi=pi, model=native.MODEL_REINFORCE, coins=t(coins), decimation_probability=dprob)
     it = res['iterations_run']
-    assert used_lds and iters == it and res['rand_consumed'] == it
+    assert (used_lds or not expect_lds) and iters == it and res['rand_consumed'] == it
+    res['hbm_instances'] = hp.last_solve_stats['hbm_instances']
     np.testing.assert_array_equal(npy(am), res['trace_active_mask'][it - 1])
     np.testing.assert_array_equal(npy(hp.solution), res['trace_solution'][it - 1])
     np.testing.assert_array_equal(npy(q), res['q'])
     np.testing.assert_array_equal(npy(fs), res['fs'])
     return res
+
+
+@pytest.mark.parametrize('spec,T,pi,dprob', [(dict(batch=32, n=50, k=3, seed=70), 40, 0.1, 0.5),
+                                             (dict(batch=64, n=40, mixed=True, seed=170), 30, 0.01, 0.3),
+                                             (dict(batch=200, n=100, k=3, seed=5000), 60, 0.1, 0.5)])
+def test_reinforce_on_the_hbm_resident_kernel(oracle, monkeypatch, spec, T, pi, dprob):
+    """The Reinforce triple on the HBM-resident kernel (instances past the LDS limit; forced here for small ones, host-driven chunk loop
+    with snapshots -- the third batch is NaN-poisoned and replayed): same comparison with the oracle's loop, bit for bit."""
+    monkeypatch.setenv('PDP_SOLVE_FORCE_HBM', '1')
+    res = _reinforce_pair(oracle, random_batch(**spec), T, pi, dprob, spec['seed'], expect_lds=False)
+    assert np.nansum(np.abs(res['fs'][:, 1])) > 0 and res['hbm_instances'] == spec['batch']
+
+
+def test_reinforce_mixed_batch_and_single_instance(oracle):
+    """Reinforce with an instance past the LDS limit: (a) next to small ones -- the small ones LDS-resident, the big one as a workgroup team
+    of the HBM-resident kernel in the same chunk loop; (b) alone in its batch: exact mode (its own minimum in the gate, one launch)."""
+    from pdp.factorgraph import dataset
+    big = dataset.random_ksat_items(1, 2500, 3, m=int(4.0 * 2500), seed=78)
+    items = dataset.random_ksat_items(20, 60, 3, m=240, seed=300) + big + dataset.random_ksat_items(19, 50, 3, m=200, seed=900)
+    res = _reinforce_pair(oracle, dataset.collate_segment(items), 40, 0.1, 0.5, 5)
+    assert res['hbm_instances'] == 1 and np.nansum(np.abs(res['fs'][:, 1])) > 0
+    res = _reinforce_pair(oracle, dataset.collate_segment(big), 30, 0.1, 0.5, 6, expect_lds=False)
+    assert res['hbm_instances'] == 1
+    for seed in range(4):
+        res = _reinforce_pair(oracle, dataset.collate_segment(dataset.random_ksat_items(1, 60, 3, m=250, seed=500 + seed)), 40, 0.1, 0.6, seed, expect_lds=False)
+
+
+def test_isolated_mode_on_the_hbm_resident_kernel(monkeypatch):
+    """Isolated instances (no batch-wide couplings, a NaN stays inside its instance) on the HBM-resident kernel: the same end state as the
+    LDS-resident kernel gives for the same batch, bit for bit -- a NaN-poisoned batch, so the two modes differ from the strict one."""
+    from pdp import native
+    b = random_batch(batch=400, n=60, k=3, seed=7000)
+    outs = []
+    for force_hbm in (False, True):
+        if force_hbm:
+            monkeypatch.setenv('PDP_SOLVE_FORCE_HBM', '1')
+        hp = native.Problem(t(b['graph_map']), t(b['batch_variable_map']), t(b['batch_function_map']), t(b['edge_feature']))
+        hp.simplify()
+        q = torch.full((hp.E, 3), 1.0, device='cuda:0') / 3.0
+        fs = torch.zeros(hp.E, 2, device='cuda:0'); fs[:, 0] = 0.5
+        am = torch.ones(hp.B, dtype=torch.uint8, device='cuda:0')
+        iters, used_lds = hp.sp_solve(q, fs, am, native.Decimator(hp), 120, 0.05, 8, isolate_instances=True)
+        assert used_lds != force_hbm
+        outs.append((iters, npy(q), npy(fs), npy(am), npy(hp.active_variables), npy(hp.active_functions), npy(hp.solution)))
+    assert np.isnan(outs[0][2]).any(), "test batch no longer produces a NaN: pick another seed"
+    assert outs[0][0] == outs[1][0]
+    for x, y in zip(outs[0][1:], outs[1][1:]):
+        np.testing.assert_array_equal(x, y)
 
 
 @pytest.mark.parametrize('T', [1, 2, 9])

@@ -8,7 +8,8 @@ from pdp import native
 if os.path.exists(native.LIB_PATH.replace('.so', '_prof.so')):
     native.LIB_PATH = native.LIB_PATH.replace('.so', '_prof.so')      # built with EXTRA=-DPDP_PHASE_PROF next to the product library
 from pdp.factorgraph import dataset
-B, n, T = int(sys.argv[1]) if len(sys.argv) > 1 else 5000, 200, 100
+B, n = int(sys.argv[1]) if len(sys.argv) > 1 else 5000, 200
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 dev = torch.device('cuda:0')
 b = dataset.to_torch(dataset.collate_segment(dataset.random_ksat_items(B, n, 3, seed=0)), dev)
 prob = native.Problem(b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'])
