@@ -509,6 +509,52 @@ def secondary_measurements(args, dev, b, prob, native):
     return out
 
 
+def big_instance_measurements(args, dev, items, headline_value, native):
+    """Instances past the LDS limit: (a) the headline batch plus ONE instance of n = 4 000 (50 400 edges): per-instance
+    routing, the big instance as a workgroup team next to the LDS-resident pass; (b) one instance of n = 100 000 alone in its batch: the
+    exact single-instance mode.  Same tolerance / t_max / T as the headline; best of three calls each."""
+    import torch
+    from pdp.factorgraph import dataset
+    out = {}
+
+    def run(its, reps=3):
+        bb = dataset.to_torch(dataset.collate_segment(its), dev)
+        hp = native.Problem(bb['graph_map'], bb['batch_variable_map'], bb['batch_function_map'], bb['edge_feature'])
+        L = native.lib()
+        q = torch.empty(hp.E, 3, device=dev); fs = torch.empty(hp.E, 2, device=dev); am = torch.empty(hp.B, dtype=torch.uint8, device=dev)
+        dec = native.Decimator(hp)
+        best = None
+        for _ in range(reps):
+            native.check(L.pdp_problem_bind_state(hp._h, native.ptr(hp.active_variables), native.ptr(hp.active_functions), native.ptr(hp.solution),
+                                                  native.ptr(hp.is_sat), native.ptr(hp.edge_mask), native._stream()))
+            q.fill_(1.0); q.div_(3.0); fs.zero_(); fs[:, 0] = 0.5; am.fill_(1); dec.reset(); hp.simplify()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            it, lds = hp.sp_solve(q, fs, am, dec, args.iters, args.tolerance, args.t_max)
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            best = (dt, it, lds) if best is None or dt < best[0] else best
+        return best, dict(hp.last_solve_stats), hp.E
+
+    try:
+        big = dataset.random_ksat_items(1, 4000, 3, m=int(round(4.2 * 4000)), seed=99)
+        (dt0, it0, _), _, _ = run(items)
+        (dt, it, lds), st, E = run(items + big)
+        out['mixed_batch'] = dict(workload='the headline batch + one instance of n=4000 (%d edges): per-instance routing' % big[0][2].shape[1],
+                                  iterations=it, call_seconds=dt, iterations_per_sec=it / dt, plain_batch_iterations_per_sec=it0 / dt0,
+                                  fraction_of_plain_batch=(it / dt) / (it0 / dt0), lds_resident=bool(lds), hbm_instances=st['hbm_instances'])
+    except Exception as ex:
+        out['mixed_batch'] = dict(error=repr(ex))
+    try:
+        n1 = 100000
+        one = dataset.random_ksat_items(1, n1, 3, m=int(round(3.5 * n1)), seed=11)
+        (dt, it, lds), st, E = run(one)
+        out['single_instance'] = dict(workload='one instance of n=%d (%d edges, alpha 3.5) alone in its batch: exact single-instance mode, one launch' % (n1, E),
+                                      iterations=it, call_seconds=dt, iterations_per_sec=it / dt, edge_updates_per_sec=2.0 * E * it / dt,
+                                      lds_resident=bool(lds), hbm_instances=st['hbm_instances'], kernel_launches=st['launches'])
+    except Exception as ex:
+        out['single_instance'] = dict(error=repr(ex))
+    return out
+
+
 def solved_fractions(args, dev, b, native, rank):
     """The metric's "(and solved %)": the whole forward (simplify, T sweeps, random fill, w Walk-SAT steps, Philox numbers) at the headline
     setting and at a longer one, with the reference's batch-wide semantics and with isolated instances.  Untimed."""
@@ -703,6 +749,7 @@ def main():
         if world == 1 and not args.no_secondary:
             config['solved'] = solved_fractions(args, dev, b, native, rank)
             config['secondary'] = secondary_measurements(args, dev, b, prob, native)
+            config['secondary'].update(big_instance_measurements(args, dev, items, value, native))
         line = {
             'metric': 'pdp_iterations_per_sec', 'value': value,
             'unit': 'iterations/s (each iteration sweeps a batch of %d instances)' % args.batch,
