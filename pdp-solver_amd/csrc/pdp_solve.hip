@@ -150,9 +150,8 @@ struct TeamView : SView<int32_t> {
     uint32_t *bar;              // arrival counter, zeroed before the launch; it only grows: barrier k is complete at k * size arrivals
     uint32_t *box;              // [2][size][PDP_BOX_WORDS] reduction mailboxes, alternating with the parity of the barrier they ride on
     mutable uint32_t epoch;     // team barriers passed (identical on every thread of the team)
-    uint32_t *lds;              // [PDP_TEAM_MAX * PDP_BOX_WORDS] LDS words the mailbox reads are staged in
 };
-#define PDP_TEAM_MAX 32
+#define PDP_TEAM_MAX 256                                 // (a workgroup has at least 256 threads: thread r reads rank r's mailbox)
 #define PDP_BOX_WORDS 8                                   // words of one rank's mailbox
 #define PDP_TEAM_WORDS (32 + 2 * PDP_TEAM_MAX * PDP_BOX_WORDS)      // words of team workspace per instance: the counter on a 128 B line of its own, then the mailboxes
 
@@ -166,36 +165,30 @@ __device__ __forceinline__ int team_nt(const TeamView &t) { return t.size * (int
 __device__ __forceinline__ void team_sync(const TeamView &t)
 {
     if (t.size == 1) { __syncthreads(); return; }
-    if (t.same_xcd) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // this wave's stores have left the CU's write-through vector cache
     __syncthreads();
     t.epoch += 1;
     if (threadIdx.x < PDP_WAVE) {
+        // One wave speaks for the workgroup.  Team on several XCDs: the release writes this XCD's L2 back (every wave's stores are in it
+        // by now), the acquire drops the vector cache and the stale L2 lines.  Team on one XCD: the L2 is the point of coherence, only
+        // the CU's vector cache has to go (sixteen waves doing that cost ~7 us per barrier, one wave well under 1).
+        if (!t.same_xcd) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         if (threadIdx.x == 0) {
             __hip_atomic_fetch_add(t.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t target = t.epoch * (uint32_t)t.size;
             while (__hip_atomic_load(t.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
         }
-        // the vector cache belongs to the CU, i.e. to the whole workgroup: one wave drops it for everybody (sixteen waves doing it
-        // cost ~7 us per barrier)
         if (t.same_xcd) asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+        else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
-    if (!t.same_xcd) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 // A mailbox written for the barrier of epoch e is read right after that barrier; the next writer of the same half has passed
-// barrier e + 1, which every workgroup only reaches after its reads.
+// barrier e + 1, which every workgroup only reaches after its reads.  Thread r of every workgroup fetches rank r's mailbox (all
+// fetches in flight together), a block reduction folds them.
 __device__ __forceinline__ uint32_t *team_box(const TeamView &t) { return t.box + (size_t)(t.epoch & 1u) * t.size * PDP_BOX_WORDS; }
 __device__ __forceinline__ void box_put(uint32_t *w, uint32_t v) { __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t box_get(const uint32_t *w) { return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// every thread gets the `words` mailbox words of every rank: lane r of the first wave fetches rank r's (all fetches in flight
-// together -- one after the other they cost a memory round trip each), the workgroup reads them back from LDS
-__device__ __forceinline__ const uint32_t *team_collect(const TeamView &t, const uint32_t *box, int words, uint32_t *lds /*[size * PDP_BOX_WORDS]*/)
-{
-    if ((int)threadIdx.x < t.size) for (int w = 0; w < words; ++w) lds[PDP_BOX_WORDS * threadIdx.x + w] = box_get(&box[PDP_BOX_WORDS * threadIdx.x + w]);
-    __syncthreads();
-    return lds;
-}
 template <typename T, typename Op>
 __device__ __forceinline__ T team_reduce(const TeamView &t, T v, Op op, T identity, T *scratch)
 {
@@ -205,11 +198,8 @@ __device__ __forceinline__ T team_reduce(const TeamView &t, T v, Op op, T identi
     uint32_t *box = team_box(t);
     if (threadIdx.x == 0) box_put(&box[PDP_BOX_WORDS * t.rank], __builtin_bit_cast(uint32_t, v));
     team_sync(t);
-    const uint32_t *got = team_collect(t, box, 1, t.lds);
-    T r = identity;
-    for (int i = 0; i < t.size; ++i) r = op(r, __builtin_bit_cast(T, got[PDP_BOX_WORDS * i]));
-    __syncthreads();
-    return r;
+    const T theirs = ((int)threadIdx.x < t.size) ? __builtin_bit_cast(T, box_get(&box[PDP_BOX_WORDS * threadIdx.x])) : identity;
+    return block_reduce(theirs, op, identity, scratch);
 }
 __device__ __forceinline__ int team_any(const TeamView &t, int x)      // like __syncthreads_or: is x non-zero anywhere (NOT the bitwise or)
 {
@@ -218,11 +208,7 @@ __device__ __forceinline__ int team_any(const TeamView &t, int x)      // like _
     uint32_t *box = team_box(t);
     if (threadIdx.x == 0) box_put(&box[PDP_BOX_WORDS * t.rank], (uint32_t)x);
     team_sync(t);
-    const uint32_t *got = team_collect(t, box, 1, t.lds);
-    uint32_t r = 0;
-    for (int i = 0; i < t.size; ++i) r |= got[PDP_BOX_WORDS * i];
-    __syncthreads();
-    return (int)r;
+    return __syncthreads_or(((int)threadIdx.x < t.size) ? (int)(box_get(&box[PDP_BOX_WORDS * threadIdx.x]) != 0u) : 0);
 }
 __device__ __forceinline__ ArgPair team_argmax(const TeamView &t, float v, int i, float *sv, int *si)
 {
@@ -231,34 +217,38 @@ __device__ __forceinline__ ArgPair team_argmax(const TeamView &t, float v, int i
     uint32_t *box = team_box(t);
     if (threadIdx.x == 0) { box_put(&box[PDP_BOX_WORDS * t.rank], __float_as_uint(r.v)); box_put(&box[PDP_BOX_WORDS * t.rank + 1], (uint32_t)r.i); }
     team_sync(t);
-    const uint32_t *got = team_collect(t, box, 2, t.lds);
-    r.v = 0.0f; r.i = -1;
-    for (int k = 0; k < t.size; ++k) {
-        const float ov = __uint_as_float(got[PDP_BOX_WORDS * k]);
-        const int oi = (int)got[PDP_BOX_WORDS * k + 1];
-        if (arg_better(ov, oi, r.v, r.i)) { r.v = ov; r.i = oi; }
+    float ov = 0.0f; int oi = -1;
+    if ((int)threadIdx.x < t.size) { ov = __uint_as_float(box_get(&box[PDP_BOX_WORDS * threadIdx.x])); oi = (int)box_get(&box[PDP_BOX_WORDS * threadIdx.x + 1]); }
+    return block_argmax(ov, oi, sv, si);
+}
+// the reductions that close an iteration of the sweep -- two maxima (NaN is maximal), a bit mask and, in exact mode, two minima --
+// on one pair of workgroup barriers
+struct IterRed { float a, b, mna, mnb; int bits; };
+struct OpMinLess { __device__ float operator()(float a, float b) const { return b < a ? b : a; } };
+__device__ __forceinline__ IterRed block_iter_reduce(IterRed x, bool with_min, float *s /*[5 * waves]*/)
+{
+    const int lane = threadIdx.x & (PDP_WAVE - 1), wid = threadIdx.x / PDP_WAVE;
+    const int nw = (blockDim.x + PDP_WAVE - 1) / PDP_WAVE;
+    x.a = wave_reduce(x.a, OpMaxNan(), -PDP_INF);
+    x.b = wave_reduce(x.b, OpMaxNan(), -PDP_INF);
+    x.bits = wave_reduce(x.bits, OpOrI(), 0);
+    if (with_min) { x.mna = wave_reduce(x.mna, OpMinLess(), PDP_INF); x.mnb = wave_reduce(x.mnb, OpMinLess(), PDP_INF); }
+    if (lane == PDP_WAVE - 1) { float *w = s + 5 * wid; w[0] = x.a; w[1] = x.b; w[2] = __int_as_float(x.bits); w[3] = x.mna; w[4] = x.mnb; }
+    __syncthreads();
+    IterRed r; r.a = -PDP_INF; r.b = -PDP_INF; r.mna = PDP_INF; r.mnb = PDP_INF; r.bits = 0;
+    for (int i = 0; i < nw; ++i) {
+        const float *w = s + 5 * i;
+        r.a = pdp_max(r.a, w[0]); r.b = pdp_max(r.b, w[1]); r.bits |= __float_as_int(w[2]);
+        if (with_min) { r.mna = OpMinLess()(r.mna, w[3]); r.mnb = OpMinLess()(r.mnb, w[4]); }
     }
     __syncthreads();
     return r;
 }
-// the three reductions that close an iteration of the sweep -- two maxima (NaN is maximal) and a bit mask -- on one barrier
-struct IterRed { float a, b, mna, mnb; int bits; };       // maxima, minima (exact mode only), flag bits
-struct OpMinLess { __device__ float operator()(float a, float b) const { return b < a ? b : a; } };
 template <class IT>
-__device__ __forceinline__ IterRed team_iter_reduce(const SView<IT> &, IterRed x, bool with_min, float *redf, int *redi)
+__device__ __forceinline__ IterRed team_iter_reduce(const SView<IT> &, IterRed x, bool with_min, float *red5) { return block_iter_reduce(x, with_min, red5); }
+__device__ __forceinline__ IterRed team_iter_reduce(const TeamView &t, IterRed x, bool with_min, float *red5)
 {
-    x.a = block_reduce(x.a, OpMaxNan(), -PDP_INF, redf);
-    x.b = block_reduce(x.b, OpMaxNan(), -PDP_INF, redf);
-    if (with_min) {
-        x.mna = block_reduce(x.mna, OpMinLess(), PDP_INF, redf);
-        x.mnb = block_reduce(x.mnb, OpMinLess(), PDP_INF, redf);
-    }
-    x.bits = block_reduce(x.bits, OpOrI(), 0, redi);
-    return x;
-}
-__device__ __forceinline__ IterRed team_iter_reduce(const TeamView &t, IterRed x, bool with_min, float *redf, int *redi)
-{
-    x = team_iter_reduce(static_cast<const SView<int32_t> &>(t), x, with_min, redf, redi);
+    x = block_iter_reduce(x, with_min, red5);
     if (t.size == 1) return x;
     uint32_t *box = team_box(t);
     if (threadIdx.x == 0) {
@@ -267,17 +257,13 @@ __device__ __forceinline__ IterRed team_iter_reduce(const TeamView &t, IterRed x
         if (with_min) { box_put(&mine[3], __float_as_uint(x.mna)); box_put(&mine[4], __float_as_uint(x.mnb)); }
     }
     team_sync(t);
-    const uint32_t *got = team_collect(t, box, with_min ? 5 : 3, t.lds);
-    IterRed r; r.a = -PDP_INF; r.b = -PDP_INF; r.mna = PDP_INF; r.mnb = PDP_INF; r.bits = 0;
-    for (int k = 0; k < t.size; ++k) {
-        const uint32_t *w = &got[PDP_BOX_WORDS * k];
-        r.a = pdp_max(r.a, __uint_as_float(w[0]));
-        r.b = pdp_max(r.b, __uint_as_float(w[1]));
-        r.bits |= (int)w[2];
-        if (with_min) { r.mna = OpMinLess()(r.mna, __uint_as_float(w[3])); r.mnb = OpMinLess()(r.mnb, __uint_as_float(w[4])); }
+    IterRed y; y.a = -PDP_INF; y.b = -PDP_INF; y.mna = PDP_INF; y.mnb = PDP_INF; y.bits = 0;
+    if ((int)threadIdx.x < t.size) {
+        const uint32_t *w = &box[PDP_BOX_WORDS * threadIdx.x];
+        y.a = __uint_as_float(box_get(&w[0])); y.b = __uint_as_float(box_get(&w[1])); y.bits = (int)box_get(&w[2]);
+        if (with_min) { y.mna = __uint_as_float(box_get(&w[3])); y.mnb = __uint_as_float(box_get(&w[4])); }
     }
-    __syncthreads();
-    return r;
+    return block_iter_reduce(y, with_min, red5);
 }
 
 // Reinforce triple on the HBM-resident view (the cold part of an iteration; lds_reinforce_step is the LDS-resident twin): with `do_force`
@@ -332,7 +318,7 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
     // fits next to them does not cost the mixed batch one of those two
     __shared__ float redf[NT / PDP_WAVE];
     __shared__ int redi[NT / PDP_WAVE];
-    __shared__ uint32_t team_lds[TEAM ? PDP_TEAM_MAX * PDP_BOX_WORDS : 1];
+    __shared__ float red5[5 * (NT / PDP_WAVE)];
 
     if (sp.hbm_device_ctl) {
         if (sp.call->stop) return;                                           // every instance went inactive in an earlier chunk
@@ -353,7 +339,7 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
         // first barrier, with full agent-scope fences: does the whole team sit on one XCD?  (HW_REG_XCC_ID = 20, bits 3:0)
         // the team is the long pole of a mixed batch and shares its CUs with the LDS-resident kernel's waves: let the scheduler prefer it
         __builtin_amdgcn_s_setprio(3);
-        I.same_xcd = 0; I.lds = team_lds;
+        I.same_xcd = 0;
         const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf);
         const int seen = team_reduce(I, 1 << xcc, OpOrI(), 0, redi);
         I.same_xcd = ((seen & (seen - 1)) == 0 && !sp.team_no_xcd) ? 1 : 0;
@@ -530,7 +516,7 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
         const int nan_before_next = (!own_nan && poison_from == 0x7fffffff && tid == 0 &&
                                      __hip_atomic_load(sp.nan_iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)(t + 1)) ? 1 : 0;
         red.bits = (z1 ? 1 : 0) | (z2 ? 2 : 0) | (nan_seen ? 4 : 0) | (nan_before_next ? 8 : 0);
-        red = team_iter_reduce(I, red, exact, redf, redi);
+        red = team_iter_reduce(I, red, exact, red5);
         TP(5)
         z1 = red.bits & 1; z2 = red.bits & 2; nan_seen = red.bits & 4; abort_next = red.bits & 8;
         // util.sparse_max (util.py:267-275): max_v((x_v - min) + 1), then + min - 1.  Rounding is monotone, so the maximum of the
@@ -1884,22 +1870,31 @@ static int ensure_bytes(char **ptr, size_t *have, size_t need)
 // does this instance's image fit the LDS-resident solver?  (force-less image: the Reinforce force is a 2-bit code, an external-force
 // column of the SP triple is checked by the caller against the largest fitting instance)
 // Launch of the HBM-resident kernel over `count` instances.  Few instances get a TEAM of workgroups each: a team's workgroups wait
-// for each other, so all of them must be resident at once -- the teams of an XCD stay within one workgroup per CU -- and a team is only
-// as large as the instance has work for (>= 2 edges per thread).  PDP_SOLVE_TEAM=<n> caps the team size (1: never a team).
-static int launch_hbm(pdp_problem *p, SolveParams sp, int count, hipStream_t s_)
+// for each other, so all of them must be resident at once, and a team is only as large as the instance has work for (>= 2 edges per
+// thread).  Normally a team stays on one XCD (<= 32 workgroups, the teams of an XCD within one workgroup per CU): its barriers are
+// cheap there.  `wide`: nothing else runs next to this launch (single-instance batches, batches of big instances only) and an
+// instance is huge -- then a team may span the whole chip (<= 256 workgroups in all, one per CU) with agent-scope barriers, which
+// cost ~10x more each and pay from a few hundred thousand edges on.  PDP_SOLVE_TEAM=<n> caps the team size (1: never a team),
+// PDP_SOLVE_TEAM_WIDE_EDGES=<e> moves the threshold of the wide form (0: never).
+static int launch_hbm(pdp_problem *p, SolveParams sp, int count, hipStream_t s_, bool wide = false)
 {
     int cap = PDP_TEAM_MAX;
     sp.team_no_xcd = getenv("PDP_SOLVE_TEAM_AGENT_FENCES") ? 1 : 0;
     if (const char *env = getenv("PDP_SOLVE_TEAM")) { const int v = atoi(env); if (v >= 1 && v <= PDP_TEAM_MAX) cap = v; }
     int tnt = 256;              // measured on the mixed headline batch (tools/mixed_batch_time.py): 256 x 32 beats 512 x 32 and 1024 x 16 next to the LDS-resident kernel
     if (const char *env = getenv("PDP_SOLVE_TEAM_THREADS")) { const int v = atoi(env); if (v == 256 || v == 512 || v == 1024) tnt = v; }
+    size_t wide_edges = 300000;
+    if (const char *env = getenv("PDP_SOLVE_TEAM_WIDE_EDGES")) wide_edges = (size_t)atoll(env);
+    const bool go_wide = wide && wide_edges > 0 && (size_t)p->max_e >= wide_edges && count <= 128;
     int size = 1;
     const int per_xcd = ((count + 7) & ~7) / 8;          // teams that share an XCD (32 CUs, one workgroup per CU assumed)
-    while (size * 2 <= cap && per_xcd * size * 2 <= 32 && (size_t)p->max_e >= (size_t)size * 2 * tnt * 2) size *= 2;
+    if (go_wide) { while (size * 2 <= cap && (size_t)count * size * 2 <= 256 && (size_t)p->max_e >= (size_t)size * 2 * tnt * 2) size *= 2; }
+    else { while (size * 2 <= cap && size * 2 <= 32 && per_xcd * size * 2 <= 32 && (size_t)p->max_e >= (size_t)size * 2 * tnt * 2) size *= 2; }
     if (size > 1) {
         if (!p->team_ws) { int st_ = pdp_dev_alloc((void **)&p->team_ws, sizeof(uint32_t) * 256 * PDP_TEAM_WORDS); if (st_ != PDP_OK) return st_; }
         PDP_HIP_CHECK(hipMemsetAsync(p->team_ws, 0, sizeof(uint32_t) * (size_t)count * PDP_TEAM_WORDS, s_));
-        sp.team_size = size; sp.team_count = count; sp.team_slots = (count + 7) & ~7; sp.team_ws = p->team_ws;
+        // slot-minor numbering; one-XCD teams pad the slot count to the XCD count so that a team's workgroups share an XCD
+        sp.team_size = size; sp.team_count = count; sp.team_slots = go_wide ? count : ((count + 7) & ~7); sp.team_ws = p->team_ws;
         if (tnt == 1024) hipLaunchKernelGGL((k_sp_solve<1024, true>), dim3(size * sp.team_slots), dim3(1024), 0, s_, make_view(p), sp);
         else if (tnt == 512) hipLaunchKernelGGL((k_sp_solve<512, true>), dim3(size * sp.team_slots), dim3(512), 0, s_, make_view(p), sp);
         else hipLaunchKernelGGL((k_sp_solve<256, true>), dim3(size * sp.team_slots), dim3(256), 0, s_, make_view(p), sp);
@@ -2284,7 +2279,7 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
         PDP_HIP_CHECK(hipMemsetAsync(ctl, 0xff, sizeof(uint32_t), st));
         PDP_HIP_CHECK(hipMemsetAsync(p->flags + FL_PERM_ZERO, 0xff, sizeof(uint32_t), st));
         PDP_HIP_CHECK(hipMemsetAsync(p->flags + FL_SPEC_VIOLATION, 0, sizeof(uint32_t) * 2, st));
-        { const int st_ = launch_hbm(p, sp, 1, st); if (st_ != PDP_OK) return st_; }
+        { const int st_ = launch_hbm(p, sp, 1, st, true); if (st_ != PDP_OK) return st_; }
         PDP_LAUNCH_CHECK();
         PDP_HIP_CHECK(hipMemcpyAsync(p->flags_host, p->flags, FL_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         PDP_HIP_CHECK(hipStreamSynchronize(st));
@@ -2321,7 +2316,7 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
             }
             // violation (+ iters_run, except for the selective replay which extends pass 1's maximum)
             PDP_HIP_CHECK(hipMemsetAsync(p->flags + FL_SPEC_VIOLATION, 0, sizeof(uint32_t) * (sp.inst_list ? 1 : 2), st));
-            status = launch_hbm(p, sp, p->B, st);
+            status = launch_hbm(p, sp, p->B, st, true);
             if (status != PDP_OK) break;
             PDP_LAUNCH_CHECK();
             a->kernel_launches_host++;
