@@ -1885,11 +1885,15 @@ static int launch_hbm(pdp_problem *p, SolveParams sp, int count, hipStream_t s_,
     if (const char *env = getenv("PDP_SOLVE_TEAM_THREADS")) { const int v = atoi(env); if (v == 256 || v == 512 || v == 1024) tnt = v; }
     size_t wide_edges = 300000;
     if (const char *env = getenv("PDP_SOLVE_TEAM_WIDE_EDGES")) wide_edges = (size_t)atoll(env);
-    const bool go_wide = wide && wide_edges > 0 && (size_t)p->max_e >= wide_edges && count <= 128;
+    // workgroups that are certainly resident together: one per CU of the device (a team's workgroups wait for each other)
+    static int cus = 0;
+    if (!cus) { int dev = 0, v = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; else cus = 64; }
+    const int per_xcd_cus = cus / 8 > 0 ? cus / 8 : 1;
+    const bool go_wide = wide && wide_edges > 0 && (size_t)p->max_e >= wide_edges && count * 2 <= cus;
     int size = 1;
     const int per_xcd = ((count + 7) & ~7) / 8;          // teams that share an XCD (32 CUs, one workgroup per CU assumed)
-    if (go_wide) { while (size * 2 <= cap && (size_t)count * size * 2 <= 256 && (size_t)p->max_e >= (size_t)size * 2 * tnt * 2) size *= 2; }
-    else { while (size * 2 <= cap && size * 2 <= 32 && per_xcd * size * 2 <= 32 && (size_t)p->max_e >= (size_t)size * 2 * tnt * 2) size *= 2; }
+    if (go_wide) { while (size * 2 <= cap && (size_t)count * size * 2 <= (size_t)cus && (size_t)p->max_e >= (size_t)size * 2 * tnt * 2) size *= 2; }
+    else { while (size * 2 <= cap && per_xcd * size * 2 <= per_xcd_cus && (size_t)p->max_e >= (size_t)size * 2 * tnt * 2) size *= 2; }
     if (size > 1) {
         if (!p->team_ws) { int st_ = pdp_dev_alloc((void **)&p->team_ws, sizeof(uint32_t) * 256 * PDP_TEAM_WORDS); if (st_ != PDP_OK) return st_; }
         PDP_HIP_CHECK(hipMemsetAsync(p->team_ws, 0, sizeof(uint32_t) * (size_t)count * PDP_TEAM_WORDS, s_));

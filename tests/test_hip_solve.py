@@ -385,6 +385,30 @@ def test_single_instance_batches_run_exact(oracle, n, alpha, T, seeds):
     assert saw_decimation
 
 
+@pytest.mark.parametrize('n_big', [1, 3])
+def test_wide_teams_across_xcds(oracle, monkeypatch, n_big):
+    """Big instances with nothing LDS-resident next to them get chip-wide teams (workgroups on all XCDs, agent-scope barriers issued by
+    one wave per workgroup); the threshold is lowered so that instances the oracle finishes in seconds qualify.  One instance alone (exact
+    mode) and three in a batch (speculative mode, host-driven loop): end state = the oracle's, bit for bit."""
+    from pdp.factorgraph import dataset
+    monkeypatch.setenv('PDP_SOLVE_TEAM_WIDE_EDGES', '10000')
+    items = [dataset.random_ksat_items(1, 2600 + 150 * i, 3, m=int(3.5 * (2600 + 150 * i)), seed=4300 + i)[0] for i in range(n_big)]
+    b = dataset.collate_segment(items)
+    hp, res, q, fs, am, iters, used_lds, spec_ok = run_pair(oracle, b, 60, 0.05, 8)
+    if not spec_ok:
+        pytest.skip("speculation failed on this batch (the caller would rerun step-wise)")
+    assert not used_lds and hp.last_solve_stats['hbm_instances'] == n_big
+    it = res['iterations_run']
+    assert iters == it
+    assert (res['trace_active_var'][it - 1] == 0).sum() > 0
+    np.testing.assert_array_equal(npy(am), res['trace_active_mask'][it - 1])
+    np.testing.assert_array_equal(npy(hp.active_variables)[:, 0], res['trace_active_var'][it - 1])
+    np.testing.assert_array_equal(npy(hp.active_functions)[:, 0], res['trace_active_fn'][it - 1])
+    np.testing.assert_array_equal(npy(hp.solution), res['trace_solution'][it - 1])
+    np.testing.assert_array_equal(npy(q), res['q'])
+    np.testing.assert_array_equal(npy(fs), res['fs'])
+
+
 def test_mixed_batch_routing_under_nan_poison(oracle):
     """The NaN-poisoned batch of test_persistent_solve_reproduces_nan_poisoning with a 21 000-edge instance added: the big instance runs on
     the HBM-resident kernel, is saved at chunk entry and replayed from there once some (small) instance poisons the batch; the small
