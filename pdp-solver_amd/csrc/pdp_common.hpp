@@ -125,6 +125,10 @@ struct pdp_problem {
     uint8_t *res_is_big;                             // device, [B]
     int res_nfit, res_nbig, res_fit_n, res_fit_m, res_fit_e;   // counts; largest fitting instance
     char *res_big_snap; size_t res_big_snap_bytes;   // chunk-entry state of the big instances (the NaN-poison replay restarts them from it)
+    // persistent Walk-SAT, per-instance routing (pdp_walksat.hip::ws_prepare)
+    int ws_route_ready, ws_nfit, ws_nbig, ws_fit_n, ws_fit_m, ws_fit_e;
+    int32_t *ws_fit_list, *ws_big_list; int64_t *ws_big_off; int64_t ws_big_E, ws_big_V, ws_big_F;
+    hipStream_t ws_side_stream; hipEvent_t ws_side_ev[2];
     uint32_t *team_ws;          // barrier counters and reduction mailboxes of the workgroup teams (k_sp_solve<NT, true>)
     hipStream_t res_side_stream; hipEvent_t res_side_ev[2];   // the big instances' launches overlap the LDS-resident kernel on a stream of their own
     float *nws[4]; size_t nws_floats[4];             // neural workspaces (grow on demand)

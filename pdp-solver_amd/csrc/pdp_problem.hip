@@ -316,6 +316,10 @@ extern "C" int pdp_problem_destroy(pdp_problem *p)
     void *res[] = {p->res_stat_off, p->res_stat, p->res_dyn[0], p->res_dyn[1], p->res_prev_slots, p->res_ctl, p->res_fit_list, p->res_big_list, p->res_is_big, p->res_big_snap};
     for (void *q : res) if (q) pdp_dev_free(q);
     if (p->team_ws) pdp_dev_free(p->team_ws);
+    if (p->ws_fit_list) pdp_dev_free(p->ws_fit_list);
+    if (p->ws_big_list) pdp_dev_free(p->ws_big_list);
+    if (p->ws_big_off) pdp_dev_free(p->ws_big_off);
+    if (p->ws_side_stream) { (void)hipStreamDestroy(p->ws_side_stream); for (int i = 0; i < 2; ++i) (void)hipEventDestroy(p->ws_side_ev[i]); }
     if (p->res_side_stream) { (void)hipStreamDestroy(p->res_side_stream); for (int i = 0; i < 2; ++i) (void)hipEventDestroy(p->res_side_ev[i]); }
     for (int i = 0; i < p->res_events_n; ++i) (void)hipEventDestroy(p->res_events[i]);
     free(p->res_events);

@@ -4,9 +4,12 @@
 // (src/pdp/nn/pdp_predict.py:118-128).  One workgroup per instance; all quantities except the
 // uniform draws are small integers.
 #include "pdp_device.hpp"
+#include <type_traits>
+#include <vector>
 
 #include <hipcub/hipcub.hpp>
 #include <stdlib.h>
+#include <string.h>
 
 #define ST(s) ((hipStream_t)(s))
 #define DECL_RED __shared__ float redf[PDP_RED_SCRATCH]; __shared__ int redi[PDP_RED_SCRATCH];
@@ -232,8 +235,15 @@ struct WsParams {
     int steps_cap; float epsilon; int rng_mode; const float *var_rand, *coin_rand; uint64_t seed;
     int32_t *first_sat;        // [B] step at which the instance had no unsat clause (steps_cap if never)
     uint32_t *spec_used, *spec_zero;   // bit maps [(steps + 31) / 32]: any unsat instance evaluated the arg-max / an exact zero existed
-    const int32_t *inst_list;  // replay subset or NULL
+    const int32_t *inst_list;  // the instances of this launch (routing / replay subset) or NULL: instance = blockIdx.x
     const int32_t *cap_b;      // per-instance step cap (replication replay) or NULL
+    // HBM-resident form (instances past the LDS limit): per launch slot the offsets of the instance's pieces in the workspace arrays
+    const int64_t *big_off;    // [slots][3]: edge / variable / clause offset
+    uint32_t *ws_e;            // [3][sum e]: pvv | pcc | cl
+    int32_t *ws_v;             // [3][sum n]: a (float bits) | delta | nuns
+    float *ws_f;               // [2][sum m]: aggc | degc
+    uint8_t *ws_u;             // [sum m]: unsat
+    int64_t ws_E, ws_V, ws_F;  // the sums (strides of the stacked arrays)
 };
 
 static size_t ws_lds_bytes(int n, int m, int e)
@@ -275,40 +285,58 @@ extern "C" int pdp_debug_ws_cycles(unsigned long long *out_host, int reset)
 #define WS_PROF_FLUSH()
 #endif
 
-__global__ void __launch_bounds__(256) k_walksat_lds(PView pv, WsParams wp)
+// W = uint16_t: the LDS-resident form (packed words and offsets in LDS).  W = uint32_t: the HBM-resident form for instances past the LDS
+// limit -- the same statements on words twice as wide, in a per-call workspace; offsets, active flags and clause weights are read where
+// the problem keeps them.  Routed per instance by pdp_local_search.
+template <class W, int NT>
+__global__ void __launch_bounds__(NT) k_walksat(PView pv, WsParams wp)
 {
+    constexpr bool HBM = sizeof(W) == 4;
+    constexpr W SB = (W)((W)1 << (8 * sizeof(W) - 1)), MB = (W)((W)1 << (8 * sizeof(W) - 2)), VM = (W)(MB - 1);    // sign / mask bit, id mask
+    constexpr int NWV = NT / 64;
+    typedef typename std::conditional<HBM, int32_t, uint16_t>::type PT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DECL_RED
     __shared__ int s_cnt;
     __shared__ float s_coin;
-    __shared__ unsigned long long s_keys[8];         // per-wave maxima of the two arg-max keys (at most 4 waves)
+    __shared__ unsigned long long s_keys[2 * NWV];   // per-wave maxima of the two arg-max keys
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
     const Inst G = load_inst(pv, wp.inst_list ? wp.inst_list[blockIdx.x] : (int)blockIdx.x);
     const int n = G.n, m = G.m, ne = G.e;
-    unsigned char *cp = smem;
-    // by-variable slots: pvv = variable | sign << 15, pcc = clause | edge mask << 15;  by-clause edges: cl = variable | mask << 14 | sign << 15
-    uint16_t *pvv = ws_carve<uint16_t>(cp, ne), *pcc = ws_carve<uint16_t>(cp, ne), *cl = ws_carve<uint16_t>(cp, ne);
-    uint16_t *v_ptr = ws_carve<uint16_t>(cp, n + 1), *f_ptr = ws_carve<uint16_t>(cp, m + 1);
-    float *av = ws_carve<float>(cp, n), *a = ws_carve<float>(cp, n);
-    int *delta = ws_carve<int>(cp, n), *nuns = ws_carve<int>(cp, n);
-    float *af = ws_carve<float>(cp, m), *aggc = ws_carve<float>(cp, m), *degc = ws_carve<float>(cp, m);
-    uint8_t *unsat = ws_carve<uint8_t>(cp, m);
+    // by-variable slots: pvv = variable | sign bit, pcc = clause | edge-mask bit (top);  by-clause edges: cl = variable | mask bit | sign bit
+    W *pvv, *pcc, *cl; const PT *v_ptr, *f_ptr; const float *av, *af; float *a, *aggc, *degc; int *delta, *nuns; uint8_t *unsat;
+    if constexpr (HBM) {
+        const int64_t *off = wp.big_off + 3 * (size_t)blockIdx.x;
+        pvv = wp.ws_e + off[0]; pcc = pvv + wp.ws_E; cl = pcc + wp.ws_E;
+        a = reinterpret_cast<float *>(wp.ws_v + off[1]); delta = wp.ws_v + wp.ws_V + off[1]; nuns = delta + wp.ws_V;
+        aggc = wp.ws_f + off[2]; degc = aggc + wp.ws_F; unsat = wp.ws_u + off[2];
+        v_ptr = G.v_ptr; f_ptr = G.f_ptr; av = G.av; af = G.af;
+    } else {
+        unsigned char *cp = smem;
+        pvv = ws_carve<W>(cp, ne); pcc = ws_carve<W>(cp, ne); cl = ws_carve<W>(cp, ne);
+        PT *vp = ws_carve<PT>(cp, n + 1), *fp = ws_carve<PT>(cp, m + 1);
+        float *avl = ws_carve<float>(cp, n); a = ws_carve<float>(cp, n);
+        delta = ws_carve<int>(cp, n); nuns = ws_carve<int>(cp, n);
+        float *afl = ws_carve<float>(cp, m); aggc = ws_carve<float>(cp, m); degc = ws_carve<float>(cp, m);
+        unsat = ws_carve<uint8_t>(cp, m);
+        for (int v = tid; v <= n; v += nt) vp[v] = (PT)G.v_ptr[v];
+        for (int c = tid; c <= m; c += nt) fp[c] = (PT)G.f_ptr[c];
+        for (int v = tid; v < n; v += nt) avl[v] = G.av[v];
+        for (int c = tid; c < m; c += nt) afl[c] = G.af[c];
+        v_ptr = vp; f_ptr = fp; av = avl; af = afl;
+    }
     for (int p = tid; p < ne; p += nt) {
         const int e = G.v_edges[p];
         const bool em = G.emask[e] == 1.0f, neg = G.sgn[e] < 0;
-        pvv[p] = (uint16_t)(G.e_var[e] | (neg ? 0x8000 : 0));
-        pcc[p] = (uint16_t)(G.e_fn[e] | (em ? 0x8000 : 0));
-        cl[e] = (uint16_t)(G.e_var[e] | (em ? 0x4000 : 0) | (neg ? 0x8000 : 0));      // edges are clause-major: edge id == position in the clause list
+        pvv[p] = (W)((W)G.e_var[e] | (neg ? SB : (W)0));
+        pcc[p] = (W)((W)G.e_fn[e] | (em ? SB : (W)0));
+        cl[e] = (W)((W)G.e_var[e] | (em ? MB : (W)0) | (neg ? SB : (W)0));      // edges are clause-major: edge id == position in the clause list
     }
-    for (int v = tid; v <= n; v += nt) v_ptr[v] = (uint16_t)G.v_ptr[v];
-    for (int c = tid; c <= m; c += nt) f_ptr[c] = (uint16_t)G.f_ptr[c];
     for (int v = tid; v < n; v += nt) {
-        av[v] = G.av[v];
         const float bit = (wp.pred[G.v0 + v] > 0.5f) ? 1.0f : 0.0f;
         a[v] = G.av[v] * (2.0f * bit - 1.0f);
     }
-    for (int c = tid; c < m; c += nt) af[c] = G.af[c];
     if (tid == 0) s_cnt = 0;
     __syncthreads();
     // ---- full evaluation once (the reference's per-step formulas) --------------------------------------------------------
@@ -318,11 +346,11 @@ __global__ void __launch_bounds__(256) k_walksat_lds(PView pv, WsParams wp)
         for (int c = tid; c < m; c += nt) {
             float deg = 0.0f, agg = 0.0f;
             for (int k = f_ptr[c]; k < f_ptr[c + 1]; ++k) {
-                const uint16_t w = cl[k];
-                const int v = w & 0x3fff;
+                const W w = cl[k];
+                const int v = (int)(w & VM);
                 deg = deg + (0.0f + av[v]);
-                agg = agg + (0.0f + ((w & 0x8000) ? -1.0f : 1.0f) * (a[v] * av[v]));
-                for (int k2 = f_ptr[c]; k2 < k; ++k2) if ((cl[k2] & 0x3fff) == v) dup_any = 1;
+                agg = agg + (0.0f + ((w & SB) ? -1.0f : 1.0f) * (a[v] * av[v]));
+                for (int k2 = f_ptr[c]; k2 < k; ++k2) if ((int)(cl[k2] & VM) == v) dup_any = 1;
             }
             degc[c] = deg; aggc[c] = agg;
             const float u = ((agg == -deg) ? 1.0f : 0.0f) * af[c];
@@ -336,11 +364,11 @@ __global__ void __launch_bounds__(256) k_walksat_lds(PView pv, WsParams wp)
             const float dist_v = a[v] * av[v];
             float d = 0.0f, acc = 0.0f;
             for (int p = v_ptr[v]; p < v_ptr[v + 1]; ++p) {
-                const uint16_t cw = pcc[p];
-                const int c = cw & 0x3fff;
-                const float dist = 0.0f + ((pvv[p] & 0x8000) ? -1.0f : 1.0f) * dist_v;
+                const W cw = pcc[p];
+                const int c = (int)(cw & (W)~SB);
+                const float dist = 0.0f + ((pvv[p] & SB) ? -1.0f : 1.0f) * dist_v;
                 const float others = (0.0f + aggc[c]) - dist;
-                const float critical = ((others == (1.0f - (0.0f + degc[c]))) ? 1.0f : 0.0f) * ((cw & 0x8000) ? 1.0f : 0.0f);
+                const float critical = ((others == (1.0f - (0.0f + degc[c]))) ? 1.0f : 0.0f) * ((cw & SB) ? 1.0f : 0.0f);
                 d = d + critical * dist;
                 acc = acc + (float)unsat[c];
             }
@@ -386,11 +414,11 @@ __global__ void __launch_bounds__(256) k_walksat_lds(PView pv, WsParams wp)
         kg = wave_max_u64(kg);
         kr = wave_max_u64(kr);
         has_zero = __builtin_amdgcn_ballot_w64(has_zero != 0) != 0 ? 1 : 0;
-        if (lane == 63) { s_keys[wid] = kg; s_keys[4 + wid] = kr; redi[wid] = has_zero; }
+        if (lane == 63) { s_keys[wid] = kg; s_keys[NWV + wid] = kr; redi[wid] = has_zero; }
         __syncthreads();
         WS_PROF_MARK(2);                                        // wave maxima + barrier
-        unsigned long long bg = s_keys[0], br = s_keys[4]; has_zero = redi[0];
-        for (int k = 1; k < nw; ++k) { bg = s_keys[k] > bg ? s_keys[k] : bg; br = s_keys[4 + k] > br ? s_keys[4 + k] : br; has_zero |= redi[k]; }
+        unsigned long long bg = s_keys[0], br = s_keys[NWV]; has_zero = redi[0];
+        for (int k = 1; k < nw; ++k) { bg = s_keys[k] > bg ? s_keys[k] : bg; br = s_keys[NWV + k] > br ? s_keys[NWV + k] : br; has_zero |= redi[k]; }
         const int f = (s_coin > wp.epsilon) ? argkey_index(bg) : argkey_index(br);        // identical on every lane
         if (tid == 0) {
             // one global atomic per step and workgroup on the same word serialises the whole batch: collect 32 steps per flush
@@ -413,23 +441,23 @@ __global__ void __launch_bounds__(256) k_walksat_lds(PView pv, WsParams wp)
             const float a_new = -a[f] * av[f];                // 0 for an inactive variable: nothing changes then
             for (int j = tid; j < deg_f; j += nt) {
                 const int p = pa + j;
-                const int c = pcc[p] & 0x3fff;
-                float sum_s = (pvv[p] & 0x8000) ? -1.0f : 1.0f; bool first = true;
+                const int c = (int)(pcc[p] & (W)~SB);
+                float sum_s = (pvv[p] & SB) ? -1.0f : 1.0f; bool first = true;
                 if (dup_any) {                                   // f may occur more than once in a clause: handle the clause once
                     sum_s = 0.0f;
                     for (int p2 = pa; p2 < pa + deg_f; ++p2)
-                        if ((pcc[p2] & 0x3fff) == c) { if (p2 < p) first = false; sum_s += (pvv[p2] & 0x8000) ? -1.0f : 1.0f; }
+                        if ((int)(pcc[p2] & (W)~SB) == c) { if (p2 < p) first = false; sum_s += (pvv[p2] & SB) ? -1.0f : 1.0f; }
                 }
                 if (!first || a_new == 0.0f) continue;
                 const float old_agg = aggc[c], new_agg = old_agg + 2.0f * sum_s * a_new;
                 const float target = 1.0f - (0.0f + degc[c]);
                 const int u_new = (((new_agg == -degc[c]) ? 1.0f : 0.0f) * af[c] == 1.0f) ? 1 : 0;
                 const int du = u_new - (int)unsat[c];
-                auto touch = [&](uint16_t w) {                   // one literal of clause c: unsat count and contribution change
-                    const int u = w & 0x3fff;
+                auto touch = [&](W w) {                   // one literal of clause c: unsat count and contribution change
+                    const int u = (int)(w & VM);
                     if (du) atomicAdd(&nuns[u], du);
-                    if (!(w & 0x4000)) return;                   // masked edge: contributes 0 before and after
-                    const float sg = (w & 0x8000) ? -1.0f : 1.0f;
+                    if (!(w & MB)) return;                   // masked edge: contributes 0 before and after
+                    const float sg = (w & SB) ? -1.0f : 1.0f;
                     const float dist_new = sg * ((u == f) ? a_new : a[u] * av[u]);      // a[f] itself is written at the end of the pass
                     const float dist_old = (u == f) ? -dist_new : dist_new;
                     const float c_old = ((old_agg - dist_old) == target) ? dist_old : 0.0f;
@@ -438,7 +466,7 @@ __global__ void __launch_bounds__(256) k_walksat_lds(PView pv, WsParams wp)
                     if (dd) atomicAdd(&delta[u], dd);
                 };
                 const int k0 = f_ptr[c], klen = f_ptr[c + 1] - k0;
-                if (klen == 3) { const uint16_t w0 = cl[k0], w1 = cl[k0 + 1], w2 = cl[k0 + 2]; touch(w0); touch(w1); touch(w2); }
+                if (klen == 3) { const W w0 = cl[k0], w1 = cl[k0 + 1], w2 = cl[k0 + 2]; touch(w0); touch(w1); touch(w2); }
                 else for (int k = k0; k < k0 + klen; ++k) touch(cl[k]);
                 aggc[c] = new_agg;
                 if (du) { unsat[c] = (uint8_t)u_new; atomicAdd(&s_cnt, du); }
@@ -478,36 +506,103 @@ __global__ void k_ws_replay_list(int B, int stop, const int32_t *first_sat, int3
     if (first_sat[b] > stop) list[atomicAdd(count, 1u)] = b;     // ran past the global stop in pass 1: redo with the cap
 }
 
+// Per-instance routing of the persistent Walk-SAT: which instances fit the LDS-resident form, which take the HBM-resident one
+// (computed once per problem from the instance sizes).
+static bool ws_fits_lds(int n, int m, int e) { return ws_lds_bytes(n, m, e) <= 64 * 1024 && n < 16384 && m < 16384 && e < 65535; }
+static int ws_prepare(pdp_problem *p)
+{
+    if (p->ws_route_ready) return PDP_OK;
+    const size_t B = p->B;
+    std::vector<int32_t> v0(B + 1), f0(B + 1), e0(B + 1);
+    PDP_HIP_CHECK(hipMemcpy(v0.data(), p->inst_v0, (B + 1) * 4, hipMemcpyDeviceToHost));
+    PDP_HIP_CHECK(hipMemcpy(f0.data(), p->inst_f0, (B + 1) * 4, hipMemcpyDeviceToHost));
+    PDP_HIP_CHECK(hipMemcpy(e0.data(), p->inst_e0, (B + 1) * 4, hipMemcpyDeviceToHost));
+    std::vector<int32_t> fit, big;
+    std::vector<int64_t> off;
+    int64_t se = 0, sv = 0, sf = 0;
+    p->ws_fit_n = p->ws_fit_m = p->ws_fit_e = 0;
+    for (size_t b = 0; b < B; ++b) {
+        const int n = v0[b + 1] - v0[b], m = f0[b + 1] - f0[b], e = e0[b + 1] - e0[b];
+        if (ws_fits_lds(n, m, e)) {
+            fit.push_back((int32_t)b);
+            if (n > p->ws_fit_n) p->ws_fit_n = n;
+            if (m > p->ws_fit_m) p->ws_fit_m = m;
+            if (e > p->ws_fit_e) p->ws_fit_e = e;
+        } else {
+            big.push_back((int32_t)b);
+            off.push_back(se); off.push_back(sv); off.push_back(sf);
+            se += (e + 3) & ~3; sv += (n + 3) & ~3; sf += (m + 3) & ~3;
+        }
+    }
+    p->ws_nfit = (int)fit.size(); p->ws_nbig = (int)big.size();
+    p->ws_big_E = se; p->ws_big_V = sv; p->ws_big_F = sf;
+    { int st_ = pdp_dev_alloc((void **)&p->ws_fit_list, (fit.size() + 1) * 4); if (st_ != PDP_OK) return st_; }
+    { int st_ = pdp_dev_alloc((void **)&p->ws_big_list, (big.size() + 1) * 4); if (st_ != PDP_OK) return st_; }
+    { int st_ = pdp_dev_alloc((void **)&p->ws_big_off, (off.size() + 1) * 8); if (st_ != PDP_OK) return st_; }
+    if (!fit.empty()) PDP_HIP_CHECK(hipMemcpy(p->ws_fit_list, fit.data(), fit.size() * 4, hipMemcpyHostToDevice));
+    if (!big.empty()) PDP_HIP_CHECK(hipMemcpy(p->ws_big_list, big.data(), big.size() * 4, hipMemcpyHostToDevice));
+    if (!off.empty()) PDP_HIP_CHECK(hipMemcpy(p->ws_big_off, off.data(), off.size() * 8, hipMemcpyHostToDevice));
+    p->ws_route_ready = 1;
+    return PDP_OK;
+}
+
 // returns PDP_OK and *done = 1 if the persistent search produced the reference result, *done = 0 if the caller must run the strict loop
 static int local_search_persistent(pdp_problem *p, const float *pred, int iterations, float epsilon, int rng_mode, const float *var_rand,
                                    const float *coin_rand, uint64_t seed, float *out, int32_t *steps_host, hipStream_t st, int *done)
 {
     *done = 0;
-    const size_t lds = ws_lds_bytes(p->max_n, p->max_m, p->max_e);
-    if (!p->fn_edges_identity || lds > 64 * 1024 || p->max_n >= 16384 || p->max_m >= 16384 || p->max_e >= 65535 || iterations <= 0) return PDP_OK;
+    if (!p->fn_edges_identity || iterations <= 0) return PDP_OK;
+    { int st_ = ws_prepare(p); if (st_ != PDP_OK) return st_; }
+    const int nfit = p->ws_nfit, nbig = p->ws_nbig;
+    if (nbig && (p->R > 1 || getenv("PDP_WALKSAT_NO_ROUTING"))) return PDP_OK;      // (replica caps are replayed by the LDS-resident form only)
+    const size_t lds = ws_lds_bytes(p->ws_fit_n, p->ws_fit_m, p->ws_fit_e);
     const size_t bw = ((size_t)iterations + 31) / 32;               // words per bit map
     const size_t words = 2 * bw + 4;
     uint32_t *spec = nullptr;
     { int st_ = pdp_dev_alloc((void **)&spec, words * 4 + (size_t)p->B * 4 * 3); if (st_ != PDP_OK) return st_; }
     int32_t *first_sat = (int32_t *)(spec + words), *cap_b = first_sat + p->B, *list = cap_b + p->B;
     PDP_HIP_CHECK(hipMemsetAsync(spec, 0, words * 4, st));
-    PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_walksat_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_edge_mask2, dim3(p->B), dim3(PDP_NT), 0, st, make_view(p));       // solver.py:439-440
     p->has_edge_mask = 1;
     WsParams wp;
+    memset(&wp, 0, sizeof(wp));
     wp.pred = pred; wp.out = out; wp.steps_cap = iterations; wp.epsilon = epsilon; wp.rng_mode = rng_mode; wp.var_rand = var_rand;
     wp.coin_rand = coin_rand; wp.seed = seed; wp.first_sat = first_sat; wp.spec_used = spec; wp.spec_zero = spec + bw;
     wp.inst_list = nullptr; wp.cap_b = nullptr;
     int ws_nt = 256;
     if (const char *env = getenv("PDP_WALKSAT_THREADS")) { const int v = atoi(env); if (v == 64 || v == 128 || v == 256) ws_nt = v; }
-    { pdp_timed_scope timed(PDP_TK_WALKSAT, st);
-      hipLaunchKernelGGL(k_walksat_lds, dim3(p->B), dim3(ws_nt), lds, st, make_view(p), wp); }
+    char *big_ws = nullptr;
+    if (nbig) {
+        // the instances past the LDS limit: one 1024-thread workgroup each on the HBM-resident form, on a stream of its own next to the
+        // LDS-resident launch (they share nothing but the speculation bit maps)
+        const size_t bytes = (size_t)p->ws_big_E * 12 + (size_t)p->ws_big_V * 12 + (size_t)p->ws_big_F * 9 + 64;
+        { int st_ = pdp_dev_alloc((void **)&big_ws, bytes); if (st_ != PDP_OK) { pdp_dev_free(spec); return st_; } }
+        WsParams wb = wp;
+        wb.inst_list = p->ws_big_list; wb.big_off = p->ws_big_off;
+        wb.ws_E = p->ws_big_E; wb.ws_V = p->ws_big_V; wb.ws_F = p->ws_big_F;
+        wb.ws_e = (uint32_t *)big_ws; wb.ws_v = (int32_t *)(wb.ws_e + 3 * wb.ws_E); wb.ws_f = (float *)(wb.ws_v + 3 * wb.ws_V); wb.ws_u = (uint8_t *)(wb.ws_f + 2 * wb.ws_F);
+        if (!p->ws_side_stream) {
+            PDP_HIP_CHECK(hipStreamCreateWithFlags(&p->ws_side_stream, hipStreamNonBlocking));
+            for (int i = 0; i < 2; ++i) PDP_HIP_CHECK(hipEventCreateWithFlags(&p->ws_side_ev[i], hipEventDisableTiming));
+        }
+        PDP_HIP_CHECK(hipEventRecord(p->ws_side_ev[0], st)); PDP_HIP_CHECK(hipStreamWaitEvent(p->ws_side_stream, p->ws_side_ev[0], 0));
+        hipLaunchKernelGGL((k_walksat<uint32_t, 1024>), dim3(nbig), dim3(1024), 0, p->ws_side_stream, make_view(p), wb);
+        PDP_HIP_CHECK(hipEventRecord(p->ws_side_ev[1], p->ws_side_stream));
+    }
+    if (nfit) {
+        PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_walksat<uint16_t, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        wp.inst_list = nbig ? p->ws_fit_list : nullptr;
+        pdp_timed_scope timed(PDP_TK_WALKSAT, st);
+        hipLaunchKernelGGL((k_walksat<uint16_t, 256>), dim3(nfit), dim3(ws_nt), lds, st, make_view(p), wp);
+    }
+    if (nbig) PDP_HIP_CHECK(hipStreamWaitEvent(st, p->ws_side_ev[1], 0));
     PDP_LAUNCH_CHECK();
     uint32_t *ctl = spec + 2 * bw;                       // [0] global stop step, [1] replay count
     hipLaunchKernelGGL(k_ws_group_stop, dim3((p->B0 + 255) / 256), dim3(256), 0, st, p->B0, p->R, iterations, first_sat, ctl);
     uint32_t *host = (uint32_t *)malloc(words * 4);
     PDP_HIP_CHECK(hipMemcpyAsync(host, spec, words * 4, hipMemcpyDeviceToHost, st));
     PDP_HIP_CHECK(hipStreamSynchronize(st));
+    if (big_ws) pdp_dev_free(big_ws);
     const int stop = (int)host[2 * bw];
     int status = PDP_OK;
     if (p->R > 1 && stop < iterations) {
@@ -518,7 +613,7 @@ static int local_search_persistent(pdp_problem *p, const float *pred, int iterat
         PDP_HIP_CHECK(hipStreamSynchronize(st));
         if (cnt) {
             wp.inst_list = list; wp.cap_b = cap_b;
-            hipLaunchKernelGGL(k_walksat_lds, dim3(cnt), dim3(ws_nt), lds, st, make_view(p), wp);
+            hipLaunchKernelGGL((k_walksat<uint16_t, 256>), dim3(cnt), dim3(ws_nt), lds, st, make_view(p), wp);
             PDP_HIP_CHECK(hipStreamSynchronize(st));
         }
     }

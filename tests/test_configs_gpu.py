@@ -55,6 +55,29 @@ def test_cli_dimacs_directory_equals_reference_rows(tmp_path, monkeypatch):
     assert not os.path.exists(str(ddir / 'temp_problem_file.json'))
 
 
+def test_cli_directory_with_a_big_instance(tmp_path):
+    """`satyr.py -d` on a directory that mixes 30 small files with one instance far past the LDS limit (n = 3000, 10 500 clauses), and on
+    the big file alone: the persistent loop (per-instance routing: the big one as a workgroup team; alone: exact single-instance mode)
+    writes the rows of the strict step-wise loop, Walk-SAT pass included (--rng philox: the same device-side numbers on both)."""
+    import satyr
+    from pdp import generator
+    yaml_ = os.path.join(REPO, 'config', 'Predict', 'PDP-p-d-p-walksat-pytorch.yaml')
+    mixed = tmp_path / 'mixed'; mixed.mkdir()
+    alone = tmp_path / 'alone'; alone.mkdir()
+    for i in range(30):
+        generator.write_dimacs(str(mixed / ('s_%03d.cnf' % i)), 60, generator.uniform_ksat(60, 240, 3, np.random.RandomState(700 + i)))
+    big = generator.uniform_ksat(3000, 10500, 3, np.random.RandomState(31337))
+    generator.write_dimacs(str(mixed / 'big.cnf'), 3000, big)
+    generator.write_dimacs(str(alone / 'big.cnf'), 3000, big)
+    for ddir in (mixed, alone):
+        rows = []
+        for extra in ([], ['--stepwise']):
+            out = tmp_path / ('out_%s_%d.jsonl' % (ddir.name, len(extra)))
+            satyr.main([yaml_, str(ddir), '60', '-d', '-z', '100', '-s', '3', '-w', '50', '--rng', 'philox', '-o', str(out)] + extra)
+            rows.append(_rows(str(out)))
+        assert rows[0] == rows[1] and len(rows[0]) == (31 if ddir is mixed else 1)
+
+
 @pytest.mark.parametrize('extra', [[], ['--stepwise']])
 def test_config0_cli_equals_reference_rows(tmp_path, monkeypatch, extra):
     """BASELINE configs[0]: 'p-d-p' on 100 random 3-SAT DIMACS files n=50 m=210, batch_size=100, T=50 (default -w 100 -e 0.5), the

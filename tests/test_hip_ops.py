@@ -199,6 +199,43 @@ def test_random_fill_and_local_search(oracle, spec, mode):
     np.testing.assert_array_equal(npy(hout)[:, 0], oout)
 
 
+@pytest.mark.parametrize('mode', ['stream', 'philox'])
+@pytest.mark.parametrize('n_big,with_small', [(1, True), (2, True), (2, False)])
+def test_local_search_routes_big_instances(oracle, mode, n_big, with_small):
+    """Persistent Walk-SAT with per-instance routing: instances past the LDS limit (n = 3000 / 3500: ~40 000 edges) run the HBM-resident
+    form of the same kernel next to the LDS-resident launch of the small ones (or alone) -- same assignments and step count as the oracle."""
+    from pdp.factorgraph import dataset
+    items = []
+    if with_small:
+        items += dataset.random_ksat_items(24, 50, 3, m=200, seed=40)
+    items += [dataset.random_ksat_items(1, 3000 + 500 * i, 3, m=int(3.8 * (3000 + 500 * i)), seed=60 + i)[0] for i in range(n_big)]
+    if with_small:
+        items += dataset.random_ksat_items(8, 40, 3, m=150, seed=41)
+    b = dataset.collate_segment(items)
+    hp, op = make_pair(oracle, b)
+    hp.simplify(); op.simplify()
+    w = 60
+    rng = np.random.RandomState(5)
+    n_active = int((op.state()[0] > 0).sum())
+    if mode == 'stream':
+        stream = rng.rand(n_active + w * (op.V + op.B)).astype(np.float32)
+        hp.random_fill(values=t(stream[:n_active]))
+        cur = op.random_fill(stream=stream)
+        rest = stream[n_active:].reshape(w, op.V + op.B)
+        var_rand = np.ascontiguousarray(rest[:, :op.V]); coin = np.ascontiguousarray(rest[:, op.V:])
+        pred = op.state()[2]
+        hout, hsteps = hp.local_search(t(pred), w, 0.5, t(var_rand), t(coin))
+        oout, osteps, _ = op.local_search(pred, w, 0.5, stream=stream, cursor=cur)
+    else:
+        hp.random_fill(seed=1234); op.random_fill(seed=1234)
+        pred = op.state()[2]
+        hout, hsteps = hp.local_search(t(pred), w, 0.5, seed=99)
+        oout, osteps, _ = op.local_search(pred, w, 0.5, seed=99)
+    assert hsteps == osteps
+    assert (oout != pred).any()
+    np.testing.assert_array_equal(npy(hout)[:, 0], oout)
+
+
 @pytest.mark.parametrize('spec', BATCHES[:4])
 def test_sequential_decimator_steps(oracle, spec):
     """Drive propagate + decimate for a number of iterations through the step-wise entry points and compare
