@@ -343,3 +343,107 @@ template <class I, typename T, typename Op>
 __device__ __forceinline__ T team_reduce(const I &, T v, Op op, T identity, T *scratch) { return block_reduce(v, op, identity, scratch); }
 template <class I>
 __device__ __forceinline__ ArgPair team_argmax(const I &, float v, int i, float *sv, int *si) { return block_argmax(v, i, sv, si); }
+
+// One big instance spread over `size` workgroups (the team): thread ids run over the whole team, barriers and reductions
+// are device-scope.  Everything a team barrier orders must live in HBM.  Teamed<V> adds the team's state to an instance view V; the
+// overloads below are more specialised than the generic team_* calls above, so the per-instance routines pick them up.
+template <class Base>
+struct Teamed : Base {
+    int rank, size;             // this workgroup's place in the team
+    int same_xcd;               // every workgroup of the team reported the same XCC id (checked at kernel start)
+    uint32_t *bar;              // arrival counter, zeroed before the launch; it only grows: barrier k is complete at k * size arrivals
+    uint32_t *box;              // [2][size][PDP_BOX_WORDS] reduction mailboxes, alternating with the parity of the barrier they ride on
+    mutable uint32_t epoch;     // team barriers passed (identical on every thread of the team)
+};
+#define PDP_TEAM_MAX 256                                 // (a workgroup has at least 256 threads: thread r reads rank r's mailbox)
+#define PDP_BOX_WORDS 8                                   // words of one rank's mailbox
+#define PDP_TEAM_WORDS (32 + 2 * PDP_TEAM_MAX * PDP_BOX_WORDS)      // words of team workspace per instance: the counter on a 128 B line of its own, then the mailboxes
+
+template <class B> __device__ __forceinline__ int team_tid(const Teamed<B> &t) { return t.rank * (int)blockDim.x + (int)threadIdx.x; }
+template <class B> __device__ __forceinline__ int team_nt(const Teamed<B> &t) { return t.size * (int)blockDim.x; }
+// Team barrier.  Workgroups on DIFFERENT XCDs only see each other's stores through agent-scope release / acquire fences, which
+// write back and invalidate the XCD's whole L2 -- tens of microseconds next to a kernel that streams instance records.  The
+// launch numbers the workgroups so that a team lands on ONE XCD (k_sp_solve), every team verifies that at its first barrier,
+// and then the shared L2 is the point of coherence: a store is visible once it left the write-through vector cache
+// (s_waitcnt vmcnt(0)), and a reader only has to drop its CU's vector cache (buffer_inv).
+template <class B> __device__ __forceinline__ void team_sync(const Teamed<B> &t)
+{
+    if (t.size == 1) { __syncthreads(); return; }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // this wave's stores have left the CU's write-through vector cache
+    __syncthreads();
+    t.epoch += 1;
+    if (threadIdx.x < PDP_WAVE) {
+        // One wave speaks for the workgroup.  Team on several XCDs: the release writes this XCD's L2 back (every wave's stores are in it
+        // by now), the acquire drops the vector cache and the stale L2 lines.  Team on one XCD: the L2 is the point of coherence, only
+        // the CU's vector cache has to go (sixteen waves doing that cost ~7 us per barrier, one wave well under 1).
+        if (!t.same_xcd) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(t.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t target = t.epoch * (uint32_t)t.size;
+            while (__hip_atomic_load(t.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        }
+        if (t.same_xcd) asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+        else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+// A mailbox written for the barrier of epoch e is read right after that barrier; the next writer of the same half has passed
+// barrier e + 1, which every workgroup only reaches after its reads.  Thread r of every workgroup fetches rank r's mailbox (all
+// fetches in flight together), a block reduction folds them.
+template <class B> __device__ __forceinline__ uint32_t *team_box(const Teamed<B> &t) { return t.box + (size_t)(t.epoch & 1u) * t.size * PDP_BOX_WORDS; }
+__device__ __forceinline__ void box_put(uint32_t *w, uint32_t v) { __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t box_get(const uint32_t *w) { return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class B, typename T, typename Op>
+__device__ __forceinline__ T team_reduce(const Teamed<B> &t, T v, Op op, T identity, T *scratch)
+{
+    static_assert(sizeof(T) == 4, "mailboxes hold 32-bit values");
+    v = block_reduce(v, op, identity, scratch);
+    if (t.size == 1) return v;
+    uint32_t *box = team_box(t);
+    if (threadIdx.x == 0) box_put(&box[PDP_BOX_WORDS * t.rank], __builtin_bit_cast(uint32_t, v));
+    team_sync(t);
+    const T theirs = ((int)threadIdx.x < t.size) ? __builtin_bit_cast(T, box_get(&box[PDP_BOX_WORDS * threadIdx.x])) : identity;
+    return block_reduce(theirs, op, identity, scratch);
+}
+template <class B> __device__ __forceinline__ int team_any(const Teamed<B> &t, int x)      // like __syncthreads_or: is x non-zero anywhere (NOT the bitwise or)
+{
+    x = __syncthreads_or(x);
+    if (t.size == 1) return x;
+    uint32_t *box = team_box(t);
+    if (threadIdx.x == 0) box_put(&box[PDP_BOX_WORDS * t.rank], (uint32_t)x);
+    team_sync(t);
+    return __syncthreads_or(((int)threadIdx.x < t.size) ? (int)(box_get(&box[PDP_BOX_WORDS * threadIdx.x]) != 0u) : 0);
+}
+template <class B> __device__ __forceinline__ ArgPair team_argmax(const Teamed<B> &t, float v, int i, float *sv, int *si)
+{
+    ArgPair r = block_argmax(v, i, sv, si);
+    if (t.size == 1) return r;
+    uint32_t *box = team_box(t);
+    if (threadIdx.x == 0) { box_put(&box[PDP_BOX_WORDS * t.rank], __float_as_uint(r.v)); box_put(&box[PDP_BOX_WORDS * t.rank + 1], (uint32_t)r.i); }
+    team_sync(t);
+    float ov = 0.0f; int oi = -1;
+    if ((int)threadIdx.x < t.size) { ov = __uint_as_float(box_get(&box[PDP_BOX_WORDS * threadIdx.x])); oi = (int)box_get(&box[PDP_BOX_WORDS * threadIdx.x + 1]); }
+    return block_argmax(ov, oi, sv, si);
+}
+// Places this workgroup in its team (launch numbering: slot-minor over `slots`) and makes the first barrier: with full agent-scope
+// fences, to find out whether the whole team sits on one XCD (HW_REG_XCC_ID = 20, bits 3:0).  Returns the slot of the launch, or -1 for a
+// padding workgroup (one-XCD teams pad the slot count to the XCD count so that a team's workgroups share an XCD).
+struct TeamLaunch { int size, count, slots, no_xcd; uint32_t *ws; };
+struct pdp_problem;
+int pdp_edge_rows(const pdp_problem *p);     // workgroups per instance of the flat per-edge kernels (gridDim.y): 1 unless an instance is big
+int pdp_team_plan(pdp_problem *p, int count, bool wide, int threads, TeamLaunch *out, hipStream_t st);
+template <class B>
+__device__ __forceinline__ int team_begin(Teamed<B> &t, const TeamLaunch &tl, int *redi)
+{
+    const int slot = (int)blockIdx.x % tl.slots;
+    if (slot >= tl.count) return -1;
+    t.rank = (int)blockIdx.x / tl.slots; t.size = tl.size; t.epoch = 0;
+    t.bar = tl.ws + (size_t)slot * PDP_TEAM_WORDS; t.box = t.bar + 32;
+    t.same_xcd = 0;
+    const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf);
+    const int seen = team_reduce(t, 1 << xcc, OpOrI(), 0, redi);
+    t.same_xcd = ((seen & (seen - 1)) == 0 && !tl.no_xcd) ? 1 : 0;
+    return slot;
+}
+
+

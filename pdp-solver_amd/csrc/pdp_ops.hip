@@ -5,6 +5,7 @@
 // sparse_max/argmax, `.sum() > 0` guards) live in device flag words so that no
 // entry point needs a host round trip unless its signature returns something to the host.
 #include "pdp_device.hpp"
+#include <type_traits>
 
 #define ST(s) ((hipStream_t)(s))
 
@@ -32,24 +33,33 @@ __device__ __forceinline__ SimplifyScratch make_scratch(const Inst &I, float *as
     return s;
 }
 
+// TEAM: a big instance spread over a team of workgroups (pdp_common.hpp: Teamed<>, pdp_team_plan); the routines are the same
+template <bool TEAM>
 __global__ void __launch_bounds__(PDP_NT) k_simplify(PView pv, float *assign_ws, int32_t *deg, int32_t *sdeg, int32_t *fv,
-                                                     uint8_t *ff, uint8_t *ff2)
+                                                     uint8_t *ff, uint8_t *ff2, TeamLaunch tl)
 {
     DECL_RED
     (void)redf;
-    const Inst I = load_inst(pv, blockIdx.x);
+    std::conditional_t<TEAM, Teamed<Inst>, Inst> I;
+    int slot = (int)blockIdx.x;
+    if constexpr (TEAM) { slot = team_begin(I, tl, redi); if (slot < 0) return; }
+    static_cast<Inst &>(I) = load_inst(pv, slot);
     const SimplifyScratch s = make_scratch(I, assign_ws, deg, sdeg, fv, ff, ff2, redi);
     d_simplify(I, s, pv.is_sat + I.b);
 }
 
 // set_variables: assignment lives in caller memory [V]; guard_slot < 0 -> always run
+template <bool TEAM>
 __global__ void __launch_bounds__(PDP_NT) k_set_variables(PView pv, float *assignment, float *assign_ws, int32_t *deg, int32_t *sdeg,
-                                                          int32_t *fv, uint8_t *ff, uint8_t *ff2, int guard_slot)
+                                                          int32_t *fv, uint8_t *ff, uint8_t *ff2, int guard_slot, TeamLaunch tl)
 {
     DECL_RED
     (void)redf;
     if (guard_slot >= 0 && pv.flags[guard_slot] == 0u) return;
-    const Inst I = load_inst(pv, blockIdx.x);
+    std::conditional_t<TEAM, Teamed<Inst>, Inst> I;
+    int slot = (int)blockIdx.x;
+    if constexpr (TEAM) { slot = team_begin(I, tl, redi); if (slot < 0) return; }
+    static_cast<Inst &>(I) = load_inst(pv, slot);
     // the caller's assignment is only masked in place (solver.py:210); simplify works on private scratch
     const SimplifyScratch s0 = make_scratch(I, assignment, deg, sdeg, fv, ff, ff2, redi);
     d_set_variable_core(I, s0);
@@ -57,11 +67,25 @@ __global__ void __launch_bounds__(PDP_NT) k_set_variables(PView pv, float *assig
     d_simplify(I, s, pv.is_sat + I.b);
 }
 
+// few big instances: teams (chip-wide when the instances are huge: nothing else runs next to these launches)
+static int simplify_plan(pdp_problem *p, TeamLaunch *tl, hipStream_t st)
+{
+    tl->size = 1; tl->count = p->B; tl->slots = p->B; tl->no_xcd = 0; tl->ws = nullptr;
+    if (p->max_e < 16384 || p->B > 128) return PDP_OK;
+    return pdp_team_plan(p, p->B, true, PDP_NT, tl, st);
+}
+
 extern "C" int pdp_simplify(pdp_problem *p, void *stream)
 {
     PDP_REQUIRE(p && p->av, "problem state is not bound");
-    hipLaunchKernelGGL(k_simplify, dim3(p->B), dim3(PDP_NT), 0, ST(stream), make_view(p), p->ws_v[5], p->ws_vi[0], p->ws_vi[1],
-                       p->ws_vi[2], p->ws_fu[0], p->ws_fu[1]);
+    TeamLaunch tl;
+    { const int st_ = simplify_plan(p, &tl, ST(stream)); if (st_ != PDP_OK) return st_; }
+    if (tl.size > 1)
+        hipLaunchKernelGGL((k_simplify<true>), dim3(tl.size * tl.slots), dim3(PDP_NT), 0, ST(stream), make_view(p), p->ws_v[5], p->ws_vi[0], p->ws_vi[1],
+                           p->ws_vi[2], p->ws_fu[0], p->ws_fu[1], tl);
+    else
+        hipLaunchKernelGGL((k_simplify<false>), dim3(p->B), dim3(PDP_NT), 0, ST(stream), make_view(p), p->ws_v[5], p->ws_vi[0], p->ws_vi[1],
+                           p->ws_vi[2], p->ws_fu[0], p->ws_fu[1], tl);
     PDP_LAUNCH_CHECK();
     return PDP_OK;
 }
@@ -69,8 +93,14 @@ extern "C" int pdp_simplify(pdp_problem *p, void *stream)
 extern "C" int pdp_set_variables(pdp_problem *p, float *assignment, void *stream)
 {
     PDP_REQUIRE(p && p->av && assignment, "NULL argument / state not bound");
-    hipLaunchKernelGGL(k_set_variables, dim3(p->B), dim3(PDP_NT), 0, ST(stream), make_view(p), assignment, p->ws_v[5], p->ws_vi[0],
-                       p->ws_vi[1], p->ws_vi[2], p->ws_fu[0], p->ws_fu[1], -1);
+    TeamLaunch tl;
+    { const int st_ = simplify_plan(p, &tl, ST(stream)); if (st_ != PDP_OK) return st_; }
+    if (tl.size > 1)
+        hipLaunchKernelGGL((k_set_variables<true>), dim3(tl.size * tl.slots), dim3(PDP_NT), 0, ST(stream), make_view(p), assignment, p->ws_v[5], p->ws_vi[0],
+                           p->ws_vi[1], p->ws_vi[2], p->ws_fu[0], p->ws_fu[1], -1, tl);
+    else
+        hipLaunchKernelGGL((k_set_variables<false>), dim3(p->B), dim3(PDP_NT), 0, ST(stream), make_view(p), assignment, p->ws_v[5], p->ws_vi[0],
+                           p->ws_vi[1], p->ws_vi[2], p->ws_fu[0], p->ws_fu[1], -1, tl);
     PDP_LAUNCH_CHECK();
     return PDP_OK;
 }
@@ -82,7 +112,7 @@ __global__ void __launch_bounds__(PDP_NT) k_edge_mask(PView pv)
     (void)redf;
     const Inst I = load_inst(pv, blockIdx.x);
     int cnt = 0;
-    for (int e = threadIdx.x; e < I.e; e += blockDim.x) {
+    for (int e = blockIdx.y * blockDim.x + threadIdx.x; e < I.e; e += gridDim.y * blockDim.x) {        // (gridDim.y > 1: big instances)
         const float a = 0.0f + I.av[I.e_var[e]];
         const float b = 0.0f + I.af[I.e_fn[e]];
         const float m = a * b;
@@ -104,7 +134,7 @@ extern "C" int pdp_refresh_edge_mask(pdp_problem *p, int32_t *all_active_host, v
 {
     PDP_REQUIRE(p && p->emask, "problem state is not bound");
     reset_flags(p, ST(stream));
-    hipLaunchKernelGGL(k_edge_mask, dim3(p->B), dim3(PDP_NT), 0, ST(stream), make_view(p));
+    hipLaunchKernelGGL(k_edge_mask, dim3(p->B, pdp_edge_rows(p)), dim3(PDP_NT), 0, ST(stream), make_view(p));
     PDP_LAUNCH_CHECK();
     p->has_edge_mask = 1;
     if (all_active_host) {
@@ -637,8 +667,14 @@ static int decimate_apply_chain(pdp_problem *p, pdp_decimator *d, const float *f
     if (d->has_prev) {
         hipLaunchKernelGGL(k_dec_score, dim3(p->B), dim3(PDP_NT), 0, st, pv, fs, pi, ext_score, p->ws_b[2], p->ws_e[2], p->ws_v[2], p->ws_v[3]);
         hipLaunchKernelGGL(k_dec_pick, dim3(p->B), dim3(PDP_NT), 0, st, pv, p->ws_v[2], p->ws_v[3], active_mask, p->ws_v[4]);
-        hipLaunchKernelGGL(k_set_variables, dim3(p->B), dim3(PDP_NT), 0, st, pv, p->ws_v[4], p->ws_v[5], p->ws_vi[0], p->ws_vi[1], p->ws_vi[2],
-                           p->ws_fu[0], p->ws_fu[1], (int)FL_N_SEL);
+        TeamLaunch tl;
+        { const int st_ = simplify_plan(p, &tl, st); if (st_ != PDP_OK) return st_; }
+        if (tl.size > 1)
+            hipLaunchKernelGGL((k_set_variables<true>), dim3(tl.size * tl.slots), dim3(PDP_NT), 0, st, pv, p->ws_v[4], p->ws_v[5], p->ws_vi[0], p->ws_vi[1], p->ws_vi[2],
+                               p->ws_fu[0], p->ws_fu[1], (int)FL_N_SEL, tl);
+        else
+            hipLaunchKernelGGL((k_set_variables<false>), dim3(p->B), dim3(PDP_NT), 0, st, pv, p->ws_v[4], p->ws_v[5], p->ws_vi[0], p->ws_vi[1], p->ws_vi[2],
+                               p->ws_fu[0], p->ws_fu[1], (int)FL_N_SEL, tl);
     }
     hipLaunchKernelGGL(k_dec_finish, dim3(p->B), dim3(PDP_NT), 0, st, pv, fs, d->prev, d->counters, d->has_prev);
     PDP_LAUNCH_CHECK();

@@ -479,3 +479,42 @@ extern "C" int pdp_problem_bind_state(pdp_problem *p, float *av, float *af, floa
     PDP_LAUNCH_CHECK();
     return PDP_OK;
 }
+
+// Team plan of a launch over `count` instances with `threads` per workgroup (see pdp_solve.hip::launch_hbm for the rules): out->size == 1
+// means one workgroup per instance.  Allocates and clears the team workspace on `st`.
+int pdp_team_plan(pdp_problem *p, int count, bool wide, int threads, TeamLaunch *out, hipStream_t st)
+{
+    int cap = PDP_TEAM_MAX;
+    if (const char *env = getenv("PDP_SOLVE_TEAM")) { const int v = atoi(env); if (v >= 1 && v <= PDP_TEAM_MAX) cap = v; }
+    size_t wide_edges = 300000;
+    if (const char *env = getenv("PDP_SOLVE_TEAM_WIDE_EDGES")) wide_edges = (size_t)atoll(env);
+    // workgroups that are certainly resident together: one per CU of the device (a team's workgroups wait for each other)
+    static int cus = 0;
+    if (!cus) { int dev = 0, v = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; else cus = 64; }
+    const int per_xcd_cus = cus / 8 > 0 ? cus / 8 : 1;
+    const bool go_wide = wide && wide_edges > 0 && (size_t)p->max_e >= wide_edges && count * 2 <= cus;
+    int size = 1;
+    const int per_xcd = ((count + 7) & ~7) / 8;          // teams that share an XCD
+    if (go_wide) { while (size * 2 <= cap && (size_t)count * size * 2 <= (size_t)cus && (size_t)p->max_e >= (size_t)size * 2 * threads * 2) size *= 2; }
+    else { while (size * 2 <= cap && per_xcd * size * 2 <= per_xcd_cus && (size_t)p->max_e >= (size_t)size * 2 * threads * 2) size *= 2; }
+    out->size = size; out->count = count; out->no_xcd = getenv("PDP_SOLVE_TEAM_AGENT_FENCES") ? 1 : 0; out->ws = nullptr;
+    // slot-minor numbering; one-XCD teams pad the slot count to the XCD count so that a team's workgroups share an XCD
+    out->slots = go_wide ? count : ((count + 7) & ~7);
+    if (size > 1) {
+        if (!p->team_ws) { int st_ = pdp_dev_alloc((void **)&p->team_ws, sizeof(uint32_t) * 256 * PDP_TEAM_WORDS); if (st_ != PDP_OK) return st_; }
+        PDP_HIP_CHECK(hipMemsetAsync(p->team_ws, 0, sizeof(uint32_t) * (size_t)count * PDP_TEAM_WORDS, st));
+        out->ws = p->team_ws;
+    }
+    return PDP_OK;
+}
+
+int pdp_edge_rows(const pdp_problem *p)
+{
+    if (p->max_e < 16384) return 1;
+    // ~8 edges per thread for the largest instance, within a total of ~64k workgroups
+    long rows = ((long)p->max_e + 8L * PDP_NT - 1) / (8L * PDP_NT);
+    const long cap = 65535L / (p->B > 0 ? p->B : 1);
+    if (rows > cap) rows = cap;
+    if (rows > 1024) rows = 1024;
+    return rows < 1 ? 1 : (int)rows;
+}

@@ -142,85 +142,9 @@ __device__ __forceinline__ T *carve(unsigned char *&p, size_t count)
     return r;
 }
 
-// One big instance spread over `size` workgroups (the team): thread ids run over the whole team, barriers and reductions
-// are device-scope.  Everything a team barrier orders lives in HBM (the HBM-resident view keeps no instance state in LDS).
-struct TeamView : SView<int32_t> {
-    int rank, size;             // this workgroup's place in the team
-    int same_xcd;               // every workgroup of the team reported the same XCC id (checked at kernel start)
-    uint32_t *bar;              // arrival counter, zeroed before the launch; it only grows: barrier k is complete at k * size arrivals
-    uint32_t *box;              // [2][size][PDP_BOX_WORDS] reduction mailboxes, alternating with the parity of the barrier they ride on
-    mutable uint32_t epoch;     // team barriers passed (identical on every thread of the team)
-};
-#define PDP_TEAM_MAX 256                                 // (a workgroup has at least 256 threads: thread r reads rank r's mailbox)
-#define PDP_BOX_WORDS 8                                   // words of one rank's mailbox
-#define PDP_TEAM_WORDS (32 + 2 * PDP_TEAM_MAX * PDP_BOX_WORDS)      // words of team workspace per instance: the counter on a 128 B line of its own, then the mailboxes
+// (TeamView = Teamed<SView<int32_t>>: pdp_common.hpp holds the team machinery -- barrier, mailboxes, reductions)
+typedef Teamed<SView<int32_t>> TeamView;
 
-__device__ __forceinline__ int team_tid(const TeamView &t) { return t.rank * (int)blockDim.x + (int)threadIdx.x; }
-__device__ __forceinline__ int team_nt(const TeamView &t) { return t.size * (int)blockDim.x; }
-// Team barrier.  Workgroups on DIFFERENT XCDs only see each other's stores through agent-scope release / acquire fences, which
-// write back and invalidate the XCD's whole L2 -- tens of microseconds next to a kernel that streams instance records.  The
-// launch numbers the workgroups so that a team lands on ONE XCD (k_sp_solve), every team verifies that at its first barrier,
-// and then the shared L2 is the point of coherence: a store is visible once it left the write-through vector cache
-// (s_waitcnt vmcnt(0)), and a reader only has to drop its CU's vector cache (buffer_inv).
-__device__ __forceinline__ void team_sync(const TeamView &t)
-{
-    if (t.size == 1) { __syncthreads(); return; }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // this wave's stores have left the CU's write-through vector cache
-    __syncthreads();
-    t.epoch += 1;
-    if (threadIdx.x < PDP_WAVE) {
-        // One wave speaks for the workgroup.  Team on several XCDs: the release writes this XCD's L2 back (every wave's stores are in it
-        // by now), the acquire drops the vector cache and the stale L2 lines.  Team on one XCD: the L2 is the point of coherence, only
-        // the CU's vector cache has to go (sixteen waves doing that cost ~7 us per barrier, one wave well under 1).
-        if (!t.same_xcd) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        if (threadIdx.x == 0) {
-            __hip_atomic_fetch_add(t.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t target = t.epoch * (uint32_t)t.size;
-            while (__hip_atomic_load(t.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
-        }
-        if (t.same_xcd) asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
-        else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-}
-// A mailbox written for the barrier of epoch e is read right after that barrier; the next writer of the same half has passed
-// barrier e + 1, which every workgroup only reaches after its reads.  Thread r of every workgroup fetches rank r's mailbox (all
-// fetches in flight together), a block reduction folds them.
-__device__ __forceinline__ uint32_t *team_box(const TeamView &t) { return t.box + (size_t)(t.epoch & 1u) * t.size * PDP_BOX_WORDS; }
-__device__ __forceinline__ void box_put(uint32_t *w, uint32_t v) { __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint32_t box_get(const uint32_t *w) { return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <typename T, typename Op>
-__device__ __forceinline__ T team_reduce(const TeamView &t, T v, Op op, T identity, T *scratch)
-{
-    static_assert(sizeof(T) == 4, "mailboxes hold 32-bit values");
-    v = block_reduce(v, op, identity, scratch);
-    if (t.size == 1) return v;
-    uint32_t *box = team_box(t);
-    if (threadIdx.x == 0) box_put(&box[PDP_BOX_WORDS * t.rank], __builtin_bit_cast(uint32_t, v));
-    team_sync(t);
-    const T theirs = ((int)threadIdx.x < t.size) ? __builtin_bit_cast(T, box_get(&box[PDP_BOX_WORDS * threadIdx.x])) : identity;
-    return block_reduce(theirs, op, identity, scratch);
-}
-__device__ __forceinline__ int team_any(const TeamView &t, int x)      // like __syncthreads_or: is x non-zero anywhere (NOT the bitwise or)
-{
-    x = __syncthreads_or(x);
-    if (t.size == 1) return x;
-    uint32_t *box = team_box(t);
-    if (threadIdx.x == 0) box_put(&box[PDP_BOX_WORDS * t.rank], (uint32_t)x);
-    team_sync(t);
-    return __syncthreads_or(((int)threadIdx.x < t.size) ? (int)(box_get(&box[PDP_BOX_WORDS * threadIdx.x]) != 0u) : 0);
-}
-__device__ __forceinline__ ArgPair team_argmax(const TeamView &t, float v, int i, float *sv, int *si)
-{
-    ArgPair r = block_argmax(v, i, sv, si);
-    if (t.size == 1) return r;
-    uint32_t *box = team_box(t);
-    if (threadIdx.x == 0) { box_put(&box[PDP_BOX_WORDS * t.rank], __float_as_uint(r.v)); box_put(&box[PDP_BOX_WORDS * t.rank + 1], (uint32_t)r.i); }
-    team_sync(t);
-    float ov = 0.0f; int oi = -1;
-    if ((int)threadIdx.x < t.size) { ov = __uint_as_float(box_get(&box[PDP_BOX_WORDS * threadIdx.x])); oi = (int)box_get(&box[PDP_BOX_WORDS * threadIdx.x + 1]); }
-    return block_argmax(ov, oi, sv, si);
-}
 // the reductions that close an iteration of the sweep -- two maxima (NaN is maximal), a bit mask and, in exact mode, two minima --
 // on one pair of workgroup barriers
 struct IterRed { float a, b, mna, mnb; int bits; };
@@ -330,19 +254,11 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
     std::conditional_t<TEAM, TeamView, SView<int32_t>> I;
     int slot = (int)blockIdx.x;          // which of the launch's instances
     if constexpr (TEAM) {
-        // slot-minor numbering with the slot count padded to the XCD count: workgroups go to the XCDs round-robin, so the
-        // workgroups of one team share an XCD (and its L2); the padding workgroups leave at once
-        slot = (int)blockIdx.x % sp.team_slots;
-        if (slot >= sp.team_count) return;
-        I.rank = (int)blockIdx.x / sp.team_slots; I.size = sp.team_size; I.epoch = 0;
-        I.bar = sp.team_ws + (size_t)slot * PDP_TEAM_WORDS; I.box = I.bar + 32;
-        // first barrier, with full agent-scope fences: does the whole team sit on one XCD?  (HW_REG_XCC_ID = 20, bits 3:0)
         // the team is the long pole of a mixed batch and shares its CUs with the LDS-resident kernel's waves: let the scheduler prefer it
         __builtin_amdgcn_s_setprio(3);
-        I.same_xcd = 0;
-        const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf);
-        const int seen = team_reduce(I, 1 << xcc, OpOrI(), 0, redi);
-        I.same_xcd = ((seen & (seen - 1)) == 0 && !sp.team_no_xcd) ? 1 : 0;
+        TeamLaunch tl; tl.size = sp.team_size; tl.count = sp.team_count; tl.slots = sp.team_slots; tl.no_xcd = sp.team_no_xcd; tl.ws = sp.team_ws;
+        slot = team_begin(I, tl, redi);
+        if (slot < 0) return;
     }
     const Inst G = load_inst(pv, sp.big_list ? sp.big_list[slot] : slot);
     const int tid = team_tid(I), nt = team_nt(I);
@@ -1875,33 +1791,18 @@ static int ensure_bytes(char **ptr, size_t *have, size_t need)
 // cheap there.  `wide`: nothing else runs next to this launch (single-instance batches, batches of big instances only) and an
 // instance is huge -- then a team may span the whole chip (<= 256 workgroups in all, one per CU) with agent-scope barriers, which
 // cost ~10x more each and pay from a few hundred thousand edges on.  PDP_SOLVE_TEAM=<n> caps the team size (1: never a team),
-// PDP_SOLVE_TEAM_WIDE_EDGES=<e> moves the threshold of the wide form (0: never).
+// PDP_SOLVE_TEAM_WIDE_EDGES=<e> moves the threshold of the wide form (0: never).  (The plan itself: pdp_team_plan, pdp_problem.hip.)
 static int launch_hbm(pdp_problem *p, SolveParams sp, int count, hipStream_t s_, bool wide = false)
 {
-    int cap = PDP_TEAM_MAX;
-    sp.team_no_xcd = getenv("PDP_SOLVE_TEAM_AGENT_FENCES") ? 1 : 0;
-    if (const char *env = getenv("PDP_SOLVE_TEAM")) { const int v = atoi(env); if (v >= 1 && v <= PDP_TEAM_MAX) cap = v; }
     int tnt = 256;              // measured on the mixed headline batch (tools/mixed_batch_time.py): 256 x 32 beats 512 x 32 and 1024 x 16 next to the LDS-resident kernel
     if (const char *env = getenv("PDP_SOLVE_TEAM_THREADS")) { const int v = atoi(env); if (v == 256 || v == 512 || v == 1024) tnt = v; }
-    size_t wide_edges = 300000;
-    if (const char *env = getenv("PDP_SOLVE_TEAM_WIDE_EDGES")) wide_edges = (size_t)atoll(env);
-    // workgroups that are certainly resident together: one per CU of the device (a team's workgroups wait for each other)
-    static int cus = 0;
-    if (!cus) { int dev = 0, v = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; else cus = 64; }
-    const int per_xcd_cus = cus / 8 > 0 ? cus / 8 : 1;
-    const bool go_wide = wide && wide_edges > 0 && (size_t)p->max_e >= wide_edges && count * 2 <= cus;
-    int size = 1;
-    const int per_xcd = ((count + 7) & ~7) / 8;          // teams that share an XCD (32 CUs, one workgroup per CU assumed)
-    if (go_wide) { while (size * 2 <= cap && (size_t)count * size * 2 <= (size_t)cus && (size_t)p->max_e >= (size_t)size * 2 * tnt * 2) size *= 2; }
-    else { while (size * 2 <= cap && per_xcd * size * 2 <= per_xcd_cus && (size_t)p->max_e >= (size_t)size * 2 * tnt * 2) size *= 2; }
-    if (size > 1) {
-        if (!p->team_ws) { int st_ = pdp_dev_alloc((void **)&p->team_ws, sizeof(uint32_t) * 256 * PDP_TEAM_WORDS); if (st_ != PDP_OK) return st_; }
-        PDP_HIP_CHECK(hipMemsetAsync(p->team_ws, 0, sizeof(uint32_t) * (size_t)count * PDP_TEAM_WORDS, s_));
-        // slot-minor numbering; one-XCD teams pad the slot count to the XCD count so that a team's workgroups share an XCD
-        sp.team_size = size; sp.team_count = count; sp.team_slots = go_wide ? count : ((count + 7) & ~7); sp.team_ws = p->team_ws;
-        if (tnt == 1024) hipLaunchKernelGGL((k_sp_solve<1024, true>), dim3(size * sp.team_slots), dim3(1024), 0, s_, make_view(p), sp);
-        else if (tnt == 512) hipLaunchKernelGGL((k_sp_solve<512, true>), dim3(size * sp.team_slots), dim3(512), 0, s_, make_view(p), sp);
-        else hipLaunchKernelGGL((k_sp_solve<256, true>), dim3(size * sp.team_slots), dim3(256), 0, s_, make_view(p), sp);
+    TeamLaunch tl;
+    { const int st_ = pdp_team_plan(p, count, wide, tnt, &tl, s_); if (st_ != PDP_OK) return st_; }
+    if (tl.size > 1) {
+        sp.team_size = tl.size; sp.team_count = tl.count; sp.team_slots = tl.slots; sp.team_ws = tl.ws; sp.team_no_xcd = tl.no_xcd;
+        if (tnt == 1024) hipLaunchKernelGGL((k_sp_solve<1024, true>), dim3(tl.size * tl.slots), dim3(1024), 0, s_, make_view(p), sp);
+        else if (tnt == 512) hipLaunchKernelGGL((k_sp_solve<512, true>), dim3(tl.size * tl.slots), dim3(512), 0, s_, make_view(p), sp);
+        else hipLaunchKernelGGL((k_sp_solve<256, true>), dim3(tl.size * tl.slots), dim3(256), 0, s_, make_view(p), sp);
     } else if (count <= 512) {
         hipLaunchKernelGGL((k_sp_solve<1024, false>), dim3(count), dim3(1024), 0, s_, make_view(p), sp);     // one wave per SIMD waits on L2 most of the time
     } else {

@@ -218,7 +218,7 @@ __global__ void k_ws_reset(uint32_t *flags)
 __global__ void __launch_bounds__(PDP_NT) k_edge_mask2(PView pv)
 {
     const Inst I = load_inst(pv, blockIdx.x);
-    for (int e = threadIdx.x; e < I.e; e += blockDim.x) {
+    for (int e = blockIdx.y * blockDim.x + threadIdx.x; e < I.e; e += gridDim.y * blockDim.x) {
         const float a = 0.0f + I.av[I.e_var[e]];
         const float b = 0.0f + I.af[I.e_fn[e]];
         I.emask[e] = a * b;
@@ -562,7 +562,7 @@ static int local_search_persistent(pdp_problem *p, const float *pred, int iterat
     { int st_ = pdp_dev_alloc((void **)&spec, words * 4 + (size_t)p->B * 4 * 3); if (st_ != PDP_OK) return st_; }
     int32_t *first_sat = (int32_t *)(spec + words), *cap_b = first_sat + p->B, *list = cap_b + p->B;
     PDP_HIP_CHECK(hipMemsetAsync(spec, 0, words * 4, st));
-    hipLaunchKernelGGL(k_edge_mask2, dim3(p->B), dim3(PDP_NT), 0, st, make_view(p));       // solver.py:439-440
+    hipLaunchKernelGGL(k_edge_mask2, dim3(p->B, pdp_edge_rows(p)), dim3(PDP_NT), 0, st, make_view(p));       // solver.py:439-440
     p->has_edge_mask = 1;
     WsParams wp;
     memset(&wp, 0, sizeof(wp));
@@ -654,7 +654,7 @@ extern "C" int pdp_local_search(pdp_problem *p, const float *pred, int iteration
     const PView pv = make_view(p);
     float *a = p->ws_v[0], *negdelta = p->ws_v[1], *uv = p->ws_v[2], *unsat_b = p->ws_b[0];
     hipLaunchKernelGGL(k_ws_init, dim3(grid_for(p->V)), dim3(256), 0, st, p->V, p->av, pred, a);
-    hipLaunchKernelGGL(k_edge_mask2, dim3(p->B), dim3(PDP_NT), 0, st, pv);       // solver.py:439-440
+    hipLaunchKernelGGL(k_edge_mask2, dim3(p->B, pdp_edge_rows(p)), dim3(PDP_NT), 0, st, pv);       // solver.py:439-440
     p->has_edge_mask = 1;
     int it = 0;
     for (; it < iterations; ++it) {
