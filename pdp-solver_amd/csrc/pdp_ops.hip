@@ -378,25 +378,37 @@ extern "C" int pdp_survey_score(pdp_problem *p, const float *fs, float pi, float
 }
 
 // ---- K9 / K13 -------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(PDP_NT) k_cnf_eval(PView pv, const float *pred, float *solved, float *unsat)
+template <bool TEAM>
+__global__ void __launch_bounds__(PDP_NT) k_cnf_eval(PView pv, const float *pred, float *solved, float *unsat, TeamLaunch tl)
 {
     DECL_RED
     (void)redf;
-    const Inst I = load_inst(pv, blockIdx.x);
+    std::conditional_t<TEAM, Teamed<Inst>, Inst> I;
+    int slot = (int)blockIdx.x;
+    if constexpr (TEAM) { slot = team_begin(I, tl, redi); if (slot < 0) return; }
+    static_cast<Inst &>(I) = load_inst(pv, slot);
     const int nsat = d_cnf_sat_count(I, pred + I.v0, redi);
-    if (threadIdx.x == 0) {
+    if (team_tid(I) == 0) {
         const float max_sat = (float)I.m, bv = (float)nsat;
         solved[I.b] = (max_sat == bv) ? 1.0f : 0.0f;
         unsat[I.b] = max_sat - bv;
     }
 }
 
+static int launch_cnf_eval(pdp_problem *p, const float *pred, float *solved, float *unsat, hipStream_t st)
+{
+    TeamLaunch tl;
+    { const int st_ = simplify_plan(p, &tl, st); if (st_ != PDP_OK) return st_; }          // few big instances: teams
+    if (tl.size > 1) hipLaunchKernelGGL((k_cnf_eval<true>), dim3(tl.size * tl.slots), dim3(PDP_NT), 0, st, make_view(p), pred, solved, unsat, tl);
+    else hipLaunchKernelGGL((k_cnf_eval<false>), dim3(p->B), dim3(PDP_NT), 0, st, make_view(p), pred, solved, unsat, tl);
+    PDP_LAUNCH_CHECK();
+    return PDP_OK;
+}
+
 extern "C" int pdp_cnf_eval(pdp_problem *p, const float *pred, float *solved, float *unsat, void *stream)
 {
     PDP_REQUIRE(p && pred && solved && unsat, "NULL argument");
-    hipLaunchKernelGGL(k_cnf_eval, dim3(p->B), dim3(PDP_NT), 0, ST(stream), make_view(p), pred, solved, unsat);
-    PDP_LAUNCH_CHECK();
-    return PDP_OK;
+    return launch_cnf_eval(p, pred, solved, unsat, ST(stream));
 }
 
 // ---- energy loss of a prediction (test mode: SatLossEvaluator.forward, util.py:178-197) ----------------------------------------
@@ -481,7 +493,7 @@ __global__ void k_termination(int B0, int R, const float *solved, uint8_t *amask
 extern "C" int pdp_check_termination(pdp_problem *p, uint8_t *active_mask, const float *pred, void *stream)
 {
     PDP_REQUIRE(p && active_mask && pred, "NULL argument");
-    hipLaunchKernelGGL(k_cnf_eval, dim3(p->B), dim3(PDP_NT), 0, ST(stream), make_view(p), pred, p->ws_b[0], p->ws_b[1]);
+    { const int st_ = launch_cnf_eval(p, pred, p->ws_b[0], p->ws_b[1], ST(stream)); if (st_ != PDP_OK) return st_; }
     hipLaunchKernelGGL(k_termination, dim3((p->B0 + 255) / 256), dim3(256), 0, ST(stream), p->B0, p->R, p->ws_b[0], active_mask);
     PDP_LAUNCH_CHECK();
     return PDP_OK;
