@@ -238,8 +238,7 @@ __device__ int hbm_reinforce_step(const V &I, float *fs /*[e][2]*/, float pi, in
 template <int NT, bool TEAM>
 __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
 {
-    // little static LDS on purpose: two workgroups of the LDS-resident kernel leave ~1.4 KB of a CU's LDS, and a team workgroup that
-    // fits next to them does not cost the mixed batch one of those two
+    // (only per-wave reduction scratch in LDS: the instance's state is in HBM)
     __shared__ float redf[NT / PDP_WAVE];
     __shared__ int redi[NT / PDP_WAVE];
     __shared__ float red5[5 * (NT / PDP_WAVE)];
