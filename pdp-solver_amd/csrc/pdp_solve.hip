@@ -2090,7 +2090,8 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
     // A batch of ONE instance has nobody to supply the exact zero the speculation counts on (tools/spec_rate.py: it fails in the first
     // iteration for 10-19 of 20 random instances) -- but its batch-global minima are its own: the HBM-resident kernel computes them
     // (sp.exact), nothing is speculated, recorded or replayed, and the whole loop is one launch (a team of workgroups when the instance is big).
-    const bool exact = B == 1 && !a->isolate_instances && getenv("PDP_SOLVE_NO_EXACT") == nullptr;
+    // (the same holds for the R identical replicas of one instance: every replica's own minimum is the batch's)
+    const bool exact = (B == 1 || (p->B0 == 1 && a->replicas_identical)) && !a->isolate_instances && getenv("PDP_SOLVE_NO_EXACT") == nullptr;
     int C = 12;
     if (const char *env = getenv("PDP_SOLVE_CHUNK")) { const int v = atoi(env); if (v > 0) C = v; }
     if (C > T) C = T;
@@ -2183,7 +2184,7 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
         PDP_HIP_CHECK(hipMemsetAsync(ctl, 0xff, sizeof(uint32_t), st));
         PDP_HIP_CHECK(hipMemsetAsync(p->flags + FL_PERM_ZERO, 0xff, sizeof(uint32_t), st));
         PDP_HIP_CHECK(hipMemsetAsync(p->flags + FL_SPEC_VIOLATION, 0, sizeof(uint32_t) * 2, st));
-        { const int st_ = launch_hbm(p, sp, 1, st, true); if (st_ != PDP_OK) return st_; }
+        { const int st_ = launch_hbm(p, sp, p->B, st, true); if (st_ != PDP_OK) return st_; }
         PDP_LAUNCH_CHECK();
         PDP_HIP_CHECK(hipMemcpyAsync(p->flags_host, p->flags, FL_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         PDP_HIP_CHECK(hipStreamSynchronize(st));

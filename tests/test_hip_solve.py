@@ -385,6 +385,29 @@ def test_single_instance_batches_run_exact(oracle, n, alpha, T, seeds):
     assert saw_decimation
 
 
+@pytest.mark.parametrize('n,seed', [(50, 3), (60, 9), (2600, 4)])
+def test_replicas_of_a_single_instance_run_exact(oracle, n, seed):
+    """One instance with batch replication 3 from the deterministic initial state (the predict path with -b 3 on one file): the replicas are
+    identical, so each replica's own minimum is the batch's -- exact mode, no speculation.  Equal to the oracle's replicated batch."""
+    from pdp import native
+    from pdp.factorgraph import dataset
+    b = dataset.collate_segment(dataset.random_ksat_items(1, n, 3, m=int(3.6 * n), seed=9100 + seed))
+    hp, op = make_pair(oracle, b, replication=3)
+    res = op.forward('p-d-p', 50, local_search_iterations=0, tolerance=0.05, t_max=8, seed=5, trace=True)
+    hp.simplify()
+    q = torch.full((hp.E, 3), 1.0, device='cuda:0') / 3.0
+    fs = torch.zeros(hp.E, 2, device='cuda:0'); fs[:, 0] = 0.5
+    am = torch.ones(hp.B, dtype=torch.uint8, device='cuda:0')
+    iters, used_lds = hp.sp_solve(q, fs, am, native.Decimator(hp), 50, 0.05, 8, replicas_identical=True)
+    it = res['iterations_run']
+    assert not used_lds and iters == it and hp.last_solve_stats['hbm_instances'] == 3
+    np.testing.assert_array_equal(npy(am), res['trace_active_mask'][it - 1])
+    np.testing.assert_array_equal(npy(hp.active_variables)[:, 0], res['trace_active_var'][it - 1])
+    np.testing.assert_array_equal(npy(hp.solution), res['trace_solution'][it - 1])
+    np.testing.assert_array_equal(npy(q), res['q'])
+    np.testing.assert_array_equal(npy(fs), res['fs'])
+
+
 @pytest.mark.parametrize('n_big', [1, 3])
 def test_wide_teams_across_xcds(oracle, monkeypatch, n_big):
     """Big instances with nothing LDS-resident next to them get chip-wide teams (workgroups on all XCDs, agent-scope barriers issued by
