@@ -146,7 +146,9 @@ int pdp_energy_diff(pdp_problem *p, const float *assignment, float *delta, void 
 int pdp_random_fill(pdp_problem *p, int rng_mode, const float *values, uint64_t seed, void *stream);
 /* replaces: PropagatorDecimatorSolverBase._local_search (solver.py:433-467).  pred [V] -> out [V].
  * PDP_RNG_STREAM: var_rand [iterations,V] and coin_rand [iterations,B] hold the torch.rand draws of
- * each step.  Synchronises; steps_host receives the number of executed steps (global early exit). */
+ * each step.  Synchronises; steps_host receives the number of executed steps (global early exit).
+ * All steps run in one persistent launch per instance (LDS-resident, or an HBM-resident form for instances past
+ * the LDS limit, routed per instance); the strict three-launches-per-step loop is the fallback. */
 int pdp_local_search(pdp_problem *p, const float *pred, int iterations, float epsilon, int rng_mode,
                      const float *var_rand, const float *coin_rand, uint64_t seed, float *out,
                      int32_t *steps_host, void *stream);
@@ -157,10 +159,15 @@ int pdp_deduplicate(pdp_problem *p, const float *pred, float *out, int32_t *chos
 /* ---- persistent solve: the whole _forward_core loop in one launch ------------------------------------
  * replaces: PropagatorDecimatorSolverBase._forward_core (solver.py:355-386) for the classical
  * triples (SurveyPropagator + SequentialDecimator + IdentityPredictor, or the Reinforce triple),
- * one workgroup per instance with the instance resident in LDS.  The kernel assumes the
- * reference's accidental cross-instance couplings are inert (batch-global min == 0, no NaN); it
- * records violations and the call returns PDP_ERR_SPECULATION, in which case the caller reruns
- * the batch through the step-wise entry points above.  Synchronises. */
+ * one workgroup per instance with the instance resident in LDS; instances past the LDS limit run
+ * on an HBM-resident kernel inside the same call (per-instance routing; a big instance is spread
+ * over a team of workgroups).  The kernels assume the reference's accidental cross-instance
+ * couplings are inert (batch-global min == 0); a NaN survey, which poisons the whole batch in the
+ * reference, is detected and the affected instances are replayed on the device.  If a coupling was
+ * active the call restores every array it touched and returns PDP_ERR_SPECULATION: the caller
+ * reruns the batch through the step-wise entry points above.  A batch of ONE instance (or the
+ * identical replicas of one) is solved exactly instead -- its batch-global minima are its own --
+ * and never fails.  Synchronises. */
 typedef struct pdp_solve_args {
     int32_t model;                /* PDP_MODEL_SP or PDP_MODEL_REINFORCE */
     int32_t iterations;           /* T */
@@ -186,7 +193,7 @@ typedef struct pdp_solve_args {
     int32_t isolate_instances;    /* in: 1 = "fixed" semantics instead of the reference's: every instance is solved on its own -- the
                                    * batch-global minimum of sparse_max / sparse_argmax is taken as 0 and a NaN survey stops the decimation
                                    * of its own instance only (in the reference it stops the whole batch).  Never
-                                   * returns PDP_ERR_SPECULATION.  LDS-resident solver only. */
+                                   * returns PDP_ERR_SPECULATION. */
     int32_t hbm_instances_host;   /* out: instances of the batch that did not fit the LDS and ran on the HBM-resident kernel inside the same chunk
                                    * loop (per-instance routing; 0 when every instance fits, the batch size when none does) */
 } pdp_solve_args;
