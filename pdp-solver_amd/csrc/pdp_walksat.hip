@@ -244,6 +244,7 @@ struct WsParams {
     float *ws_f;               // [2][sum m]: aggc | degc
     uint8_t *ws_u;             // [sum m]: unsat
     int64_t ws_E, ws_V, ws_F;  // the sums (strides of the stacked arrays)
+    int *ws_cnt;               // [slots] team form: unsat clauses of the instance
 };
 
 static size_t ws_lds_bytes(int n, int m, int e)
@@ -490,6 +491,201 @@ __global__ void __launch_bounds__(NT) k_walksat(PView pv, WsParams wp)
     }
 }
 
+// ---- Walk-SAT of a BIG instance as a team of workgroups -------------------------------------------------------------------------------
+// The HBM-resident form above gives a big instance one workgroup, and a step scans all its variables: 0.68 ms per step at n = 300 000.
+// Here the instance's team (pdp_common.hpp: Teamed<>, chip-wide when nothing else runs) shares the scan; a step is the scan, one team
+// exchange of the two arg-max keys (mailboxes, the block maxima of every rank), the flip's O(degree) update by rank 0, one team barrier.
+// Same statements and the same integer state as k_walksat, in the same per-call workspace; the unsat count is a word of that workspace.
+struct WsNone {};
+template <int NT>
+__global__ void __launch_bounds__(NT) k_walksat_team(PView pv, WsParams wp, TeamLaunch tl)
+{
+    typedef uint32_t W;
+    constexpr W SB = 0x80000000u, MB = 0x40000000u, VM = MB - 1u;
+    constexpr int NWV = NT / 64;
+    DECL_RED
+    (void)redf;
+    __shared__ unsigned long long s_keys[2 * NWV];
+    Teamed<WsNone> TT;
+    const int slot = team_begin(TT, tl, redi);
+    if (slot < 0) return;
+    const Inst G = load_inst(pv, wp.inst_list[slot]);
+    const int n = G.n, m = G.m, ne = G.e;
+    const int tid = team_tid(TT), nt = team_nt(TT);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t *off = wp.big_off + 3 * (size_t)slot;
+    W *pvv = wp.ws_e + off[0], *pcc = pvv + wp.ws_E, *cl = pcc + wp.ws_E;
+    float *a = reinterpret_cast<float *>(wp.ws_v + off[1]);
+    int *delta = wp.ws_v + wp.ws_V + off[1], *nuns = delta + wp.ws_V;
+    float *aggc = wp.ws_f + off[2], *degc = aggc + wp.ws_F;
+    uint8_t *unsat = wp.ws_u + off[2];
+    int *gcnt = wp.ws_cnt + slot;                     // unsat clauses of the instance
+    const int32_t *v_ptr = G.v_ptr, *f_ptr = G.f_ptr;
+    const float *av = G.av, *af = G.af;
+    for (int p = tid; p < ne; p += nt) {
+        const int e = G.v_edges[p];
+        const bool em = G.emask[e] == 1.0f, neg = G.sgn[e] < 0;
+        pvv[p] = (W)G.e_var[e] | (neg ? SB : 0u);
+        pcc[p] = (W)G.e_fn[e] | (em ? SB : 0u);
+        cl[e] = (W)G.e_var[e] | (em ? MB : 0u) | (neg ? SB : 0u);
+    }
+    for (int v = tid; v < n; v += nt) {
+        const float bit = (wp.pred[G.v0 + v] > 0.5f) ? 1.0f : 0.0f;
+        a[v] = G.av[v] * (2.0f * bit - 1.0f);
+    }
+    team_sync(TT);
+    // ---- full evaluation once (the reference's per-step formulas) ------------------------------------------------------------------
+    int dup_any = 0;
+    {
+        int cnt = 0;
+        for (int c = tid; c < m; c += nt) {
+            float deg = 0.0f, agg = 0.0f;
+            for (int k = f_ptr[c]; k < f_ptr[c + 1]; ++k) {
+                const W w = cl[k];
+                const int v = (int)(w & VM);
+                deg = deg + (0.0f + av[v]);
+                agg = agg + (0.0f + ((w & SB) ? -1.0f : 1.0f) * (a[v] * av[v]));
+                for (int k2 = f_ptr[c]; k2 < k; ++k2) if ((int)(cl[k2] & VM) == v) dup_any = 1;
+            }
+            degc[c] = deg; aggc[c] = agg;
+            const float u = ((agg == -deg) ? 1.0f : 0.0f) * af[c];
+            unsat[c] = (u == 1.0f) ? 1 : 0;
+            cnt += unsat[c];
+        }
+        cnt = team_reduce(TT, cnt, OpAddI(), 0, redi);           // (its barrier publishes aggc / degc / unsat)
+        dup_any = team_any(TT, dup_any);
+        if (tid == 0) __hip_atomic_store(gcnt, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int v = tid; v < n; v += nt) {
+            const float dist_v = a[v] * av[v];
+            float d = 0.0f, acc = 0.0f;
+            for (int p = v_ptr[v]; p < v_ptr[v + 1]; ++p) {
+                const W cw = pcc[p];
+                const int c = (int)(cw & ~SB);
+                const float dist = 0.0f + ((pvv[p] & SB) ? -1.0f : 1.0f) * dist_v;
+                const float others = (0.0f + aggc[c]) - dist;
+                const float critical = ((others == (1.0f - (0.0f + degc[c]))) ? 1.0f : 0.0f) * ((cw & SB) ? 1.0f : 0.0f);
+                d = d + critical * dist;
+                acc = acc + (float)unsat[c];
+            }
+            delta[v] = (int)d; nuns[v] = (int)acc;
+        }
+        team_sync(TT);
+    }
+    const int cap = wp.steps_cap;
+    auto var_rand = [&](int step, int v) -> float {
+        return (wp.rng_mode == PDP_RNG_STREAM) ? wp.var_rand[(size_t)step * pv.V + G.v0 + v]
+                                               : pdp_philox_uniform(wp.seed, PDP_RNG_STREAM_WSVAR, (uint32_t)step, (uint32_t)(G.v0 + v));
+    };
+    auto coin_rand = [&](int step) -> float {
+        return (wp.rng_mode == PDP_RNG_STREAM) ? wp.coin_rand[(size_t)step * pv.B + G.b]
+                                               : pdp_philox_uniform(wp.seed, PDP_RNG_STREAM_WSCOIN, (uint32_t)step, (uint32_t)G.b);
+    };
+    // block-wide maxima of the two keys and the OR of the flag: every thread gets them
+    auto block_keys = [&](unsigned long long &kg, unsigned long long &kr, int &hz) {
+        kg = wave_max_u64(kg); kr = wave_max_u64(kr);
+        hz = __builtin_amdgcn_ballot_w64(hz != 0) != 0 ? 1 : 0;
+        if (lane == 63) { s_keys[wid] = kg; s_keys[NWV + wid] = kr; redi[wid] = hz; }
+        __syncthreads();
+        kg = s_keys[0]; kr = s_keys[NWV]; hz = redi[0];
+        for (int k = 1; k < NWV; ++k) { kg = s_keys[k] > kg ? s_keys[k] : kg; kr = s_keys[NWV + k] > kr ? s_keys[NWV + k] : kr; hz |= redi[k]; }
+        __syncthreads();
+    };
+    int first_sat = cap;
+    uint32_t used32 = 0, zero32 = 0;
+    int it = 0, pending = -1;
+    for (; it < cap; ++it) {
+        if (__hip_atomic_load(gcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) { first_sat = it; break; }      // uniform: only written before a team barrier
+        if (tid == 0 && pending >= 0) a[pending] = -a[pending];
+        pending = -1;
+        unsigned long long kg = 0ull, kr = 0ull; int has_zero = 0;
+        for (int v = tid; v < n; v += nt) {
+            const float acc = (float)nuns[v] * av[v];
+            const float u = var_rand(it, v);
+            const float r = ((acc > 0.0f) ? 1.0f : 0.0f) * u;
+            if (r == 0.0f) has_zero = 1;
+            const float tg = ((-(float)delta[v]) - 0.0f) + 1.0f, tr = (r - 0.0f) + 1.0f;
+            const unsigned long long k0 = argkey(tg, v), k1 = argkey(tr, v);
+            kg = k0 > kg ? k0 : kg; kr = k1 > kr ? k1 : kr;
+        }
+        block_keys(kg, kr, has_zero);
+        if (TT.size > 1) {
+            uint32_t *box = team_box(TT);
+            if (threadIdx.x == 0) {
+                uint32_t *mine = &box[PDP_BOX_WORDS * TT.rank];
+                box_put(&mine[0], (uint32_t)kg); box_put(&mine[1], (uint32_t)(kg >> 32)); box_put(&mine[2], (uint32_t)kr); box_put(&mine[3], (uint32_t)(kr >> 32));
+                box_put(&mine[4], (uint32_t)has_zero);
+            }
+            team_sync(TT);                                         // (also publishes rank 0's flip of the previous step's variable)
+            kg = 0ull; kr = 0ull; has_zero = 0;
+            if ((int)threadIdx.x < TT.size) {
+                const uint32_t *w = &box[PDP_BOX_WORDS * threadIdx.x];
+                kg = (unsigned long long)box_get(&w[0]) | ((unsigned long long)box_get(&w[1]) << 32);
+                kr = (unsigned long long)box_get(&w[2]) | ((unsigned long long)box_get(&w[3]) << 32);
+                has_zero = (int)box_get(&w[4]);
+            }
+            block_keys(kg, kr, has_zero);
+        }
+        const int f = (coin_rand(it) > wp.epsilon) ? argkey_index(kg) : argkey_index(kr);          // identical on every thread of the team
+        if (tid == 0) {
+            used32 |= 1u << (it & 31);
+            if (has_zero) zero32 |= 1u << (it & 31);
+            if ((it & 31) == 31) {
+                atomicOr(&wp.spec_used[it >> 5], used32);
+                if (zero32) atomicOr(&wp.spec_zero[it >> 5], zero32);
+                used32 = 0; zero32 = 0;
+            }
+        }
+        // ---- flip f and carry the change through its clauses: O(degree), rank 0 ----------------------------------------------------------
+        if (f >= 0 && TT.rank == 0) {
+            const int pa = v_ptr[f], deg_f = v_ptr[f + 1] - pa;
+            const float a_new = -a[f] * av[f];
+            for (int j = threadIdx.x; j < deg_f; j += blockDim.x) {
+                const int p = pa + j;
+                const int c = (int)(pcc[p] & ~SB);
+                float sum_s = (pvv[p] & SB) ? -1.0f : 1.0f; bool first = true;
+                if (dup_any) {
+                    sum_s = 0.0f;
+                    for (int p2 = pa; p2 < pa + deg_f; ++p2)
+                        if ((int)(pcc[p2] & ~SB) == c) { if (p2 < p) first = false; sum_s += (pvv[p2] & SB) ? -1.0f : 1.0f; }
+                }
+                if (!first || a_new == 0.0f) continue;
+                const float old_agg = aggc[c], new_agg = old_agg + 2.0f * sum_s * a_new;
+                const float target = 1.0f - (0.0f + degc[c]);
+                const int u_new = (((new_agg == -degc[c]) ? 1.0f : 0.0f) * af[c] == 1.0f) ? 1 : 0;
+                const int du = u_new - (int)unsat[c];
+                for (int k = f_ptr[c]; k < f_ptr[c + 1]; ++k) {
+                    const W w = cl[k];
+                    const int u = (int)(w & VM);
+                    if (du) atomicAdd(&nuns[u], du);
+                    if (!(w & MB)) continue;
+                    const float sg = (w & SB) ? -1.0f : 1.0f;
+                    const float dist_new = sg * ((u == f) ? a_new : a[u] * av[u]);
+                    const float dist_old = (u == f) ? -dist_new : dist_new;
+                    const float c_old = ((old_agg - dist_old) == target) ? dist_old : 0.0f;
+                    const float c_new = ((new_agg - dist_new) == target) ? dist_new : 0.0f;
+                    const int dd = (int)(c_new - c_old);
+                    if (dd) atomicAdd(&delta[u], dd);
+                }
+                aggc[c] = new_agg;
+                if (du) { unsat[c] = (uint8_t)u_new; atomicAdd(gcnt, du); }
+            }
+        }
+        pending = f;
+        team_sync(TT);
+    }
+    if (tid == 0 && pending >= 0) a[pending] = -a[pending];
+    team_sync(TT);
+    for (int v = tid; v < n; v += nt) wp.out[G.v0 + v] = (a[v] + 1.0f) / 2.0f;
+    if (tid == 0) {
+        wp.first_sat[G.b] = first_sat;
+        if (used32) {
+            const int w = (it - 1) >> 5;
+            atomicOr(&wp.spec_used[w], used32);
+            if (zero32) atomicOr(&wp.spec_zero[w], zero32);
+        }
+    }
+}
+
 __global__ void k_ws_group_stop(int B0, int R, int cap, const int32_t *first_sat, uint32_t *stop /*max over originals of min over replicas*/)
 {
     const int b0 = blockIdx.x * blockDim.x + threadIdx.x;
@@ -575,18 +771,23 @@ static int local_search_persistent(pdp_problem *p, const float *pred, int iterat
     if (nbig) {
         // the instances past the LDS limit: one 1024-thread workgroup each on the HBM-resident form, on a stream of its own next to the
         // LDS-resident launch (they share nothing but the speculation bit maps)
-        const size_t bytes = (size_t)p->ws_big_E * 12 + (size_t)p->ws_big_V * 12 + (size_t)p->ws_big_F * 9 + 64;
+        const size_t bytes = (size_t)p->ws_big_E * 12 + (size_t)p->ws_big_V * 12 + (size_t)p->ws_big_F * 9 + 64 + (size_t)nbig * 4 + 16;
         { int st_ = pdp_dev_alloc((void **)&big_ws, bytes); if (st_ != PDP_OK) { pdp_dev_free(spec); return st_; } }
         WsParams wb = wp;
         wb.inst_list = p->ws_big_list; wb.big_off = p->ws_big_off;
         wb.ws_E = p->ws_big_E; wb.ws_V = p->ws_big_V; wb.ws_F = p->ws_big_F;
         wb.ws_e = (uint32_t *)big_ws; wb.ws_v = (int32_t *)(wb.ws_e + 3 * wb.ws_E); wb.ws_f = (float *)(wb.ws_v + 3 * wb.ws_V); wb.ws_u = (uint8_t *)(wb.ws_f + 2 * wb.ws_F);
+        wb.ws_cnt = (int *)(big_ws + ((bytes - (size_t)nbig * 4 - 16) & ~(size_t)15));
         if (!p->ws_side_stream) {
             PDP_HIP_CHECK(hipStreamCreateWithFlags(&p->ws_side_stream, hipStreamNonBlocking));
             for (int i = 0; i < 2; ++i) PDP_HIP_CHECK(hipEventCreateWithFlags(&p->ws_side_ev[i], hipEventDisableTiming));
         }
         PDP_HIP_CHECK(hipEventRecord(p->ws_side_ev[0], st)); PDP_HIP_CHECK(hipStreamWaitEvent(p->ws_side_stream, p->ws_side_ev[0], 0));
-        hipLaunchKernelGGL((k_walksat<uint32_t, 1024>), dim3(nbig), dim3(1024), 0, p->ws_side_stream, make_view(p), wb);
+        // few big instances: a team of workgroups each (chip-wide when no LDS-resident launch runs next to it)
+        TeamLaunch tl; tl.size = 1;
+        if (!getenv("PDP_WALKSAT_NO_TEAM")) { const int st_ = pdp_team_plan(p, nbig, nfit == 0, 256, &tl, p->ws_side_stream); if (st_ != PDP_OK) { pdp_dev_free(spec); pdp_dev_free(big_ws); return st_; } }
+        if (tl.size > 1) hipLaunchKernelGGL((k_walksat_team<256>), dim3(tl.size * tl.slots), dim3(256), 0, p->ws_side_stream, make_view(p), wb, tl);
+        else hipLaunchKernelGGL((k_walksat<uint32_t, 1024>), dim3(nbig), dim3(1024), 0, p->ws_side_stream, make_view(p), wb);
         PDP_HIP_CHECK(hipEventRecord(p->ws_side_ev[1], p->ws_side_stream));
     }
     if (nfit) {

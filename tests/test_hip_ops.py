@@ -200,11 +200,16 @@ def test_random_fill_and_local_search(oracle, spec, mode):
 
 
 @pytest.mark.parametrize('mode', ['stream', 'philox'])
-@pytest.mark.parametrize('n_big,with_small', [(1, True), (2, True), (2, False)])
-def test_local_search_routes_big_instances(oracle, mode, n_big, with_small):
+@pytest.mark.parametrize('n_big,with_small,form', [(1, True, 'team'), (2, True, 'team'), (2, False, 'team'), (2, False, 'wide'), (1, True, 'one-workgroup')])
+def test_local_search_routes_big_instances(oracle, monkeypatch, mode, n_big, with_small, form):
     """Persistent Walk-SAT with per-instance routing: instances past the LDS limit (n = 3000 / 3500: ~40 000 edges) run the HBM-resident
-    form of the same kernel next to the LDS-resident launch of the small ones (or alone) -- same assignments and step count as the oracle."""
+    form of the same kernel next to the LDS-resident launch of the small ones (or alone) -- as a team of workgroups on one XCD, as a
+    chip-wide team (threshold lowered for the test) or on one workgroup each -- same assignments and step count as the oracle."""
     from pdp.factorgraph import dataset
+    if form == 'wide':
+        monkeypatch.setenv('PDP_SOLVE_TEAM_WIDE_EDGES', '10000')
+    if form == 'one-workgroup':
+        monkeypatch.setenv('PDP_WALKSAT_NO_TEAM', '1')
     items = []
     if with_small:
         items += dataset.random_ksat_items(24, 50, 3, m=200, seed=40)
