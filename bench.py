@@ -263,7 +263,8 @@ def cpu_baseline_neural(args):
     from oracle import binding
     from pdp.factorgraph import dataset
     binding.build()
-    bs, H = 400, args.hidden
+    H = args.hidden
+    bs = max(1, min(400, args.batch, int(400 * 200 / max(1, args.n))))       # ~1 M edges however large the instances are (400 instances at n = 200)
     b = dataset.collate_segment(dataset.random_ksat_items(bs, args.n, 3, m=int(round(4.2 * args.n)), seed=777))
     gm = np.asarray(b['graph_map']); ev, ec = gm[0].astype(np.int32), gm[1].astype(np.int32)
     es = np.asarray(b['edge_feature'], dtype=np.float32).reshape(-1)
