@@ -350,7 +350,7 @@ __device__ __forceinline__ ArgPair team_argmax(const I &, float v, int i, float 
 template <class Base>
 struct Teamed : Base {
     int rank, size;             // this workgroup's place in the team
-    int same_xcd;               // every workgroup of the team reported the same XCC id (checked at kernel start)
+    int same_xcd;               // 1: every workgroup of the team reported the same XCC id (checked at kernel start); 0: agent-scope fences; 2: mailboxes only
     uint32_t *bar;              // arrival counter, zeroed before the launch; it only grows: barrier k is complete at k * size arrivals
     uint32_t *box;              // [2][size][PDP_BOX_WORDS] reduction mailboxes, alternating with the parity of the barrier they ride on
     mutable uint32_t epoch;     // team barriers passed (identical on every thread of the team)
@@ -382,8 +382,9 @@ template <class B> __device__ __forceinline__ void team_sync(const Teamed<B> &t)
             const uint32_t target = t.epoch * (uint32_t)t.size;
             while (__hip_atomic_load(t.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
         }
-        if (t.same_xcd) asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
-        else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (t.same_xcd == 1) asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+        else if (!t.same_xcd) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // (same_xcd == 2: the workgroups exchange mailbox words only -- agent-scope atomics -- and no cache has to be touched)
     }
     __syncthreads();
 }
@@ -430,6 +431,7 @@ template <class B> __device__ __forceinline__ ArgPair team_argmax(const Teamed<B
 // padding workgroup (one-XCD teams pad the slot count to the XCD count so that a team's workgroups share an XCD).
 struct TeamLaunch { int size, count, slots, no_xcd; uint32_t *ws; };
 struct pdp_problem;
+int pdp_device_cus();                         // CUs of the current device (workgroups that are certainly resident together)
 int pdp_edge_rows(const pdp_problem *p);     // workgroups per instance of the flat per-edge kernels (gridDim.y): 1 unless an instance is big
 int pdp_team_plan(pdp_problem *p, int count, bool wide, int threads, TeamLaunch *out, hipStream_t st);
 template <class B>

@@ -489,8 +489,7 @@ int pdp_team_plan(pdp_problem *p, int count, bool wide, int threads, TeamLaunch 
     size_t wide_edges = 300000;
     if (const char *env = getenv("PDP_SOLVE_TEAM_WIDE_EDGES")) wide_edges = (size_t)atoll(env);
     // workgroups that are certainly resident together: one per CU of the device (a team's workgroups wait for each other)
-    static int cus = 0;
-    if (!cus) { int dev = 0, v = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; else cus = 64; }
+    const int cus = pdp_device_cus();
     const int per_xcd_cus = cus / 8 > 0 ? cus / 8 : 1;
     const bool go_wide = wide && wide_edges > 0 && (size_t)p->max_e >= wide_edges && count * 2 <= cus;
     int size = 1;
@@ -517,4 +516,11 @@ int pdp_edge_rows(const pdp_problem *p)
     if (rows > cap) rows = cap;
     if (rows > 1024) rows = 1024;
     return rows < 1 ? 1 : (int)rows;
+}
+
+int pdp_device_cus()
+{
+    static int cus = 0;
+    if (!cus) { int dev = 0, v = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; else cus = 64; }
+    return cus;
 }

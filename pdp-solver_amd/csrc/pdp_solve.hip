@@ -170,7 +170,8 @@ __device__ __forceinline__ IterRed block_iter_reduce(IterRed x, bool with_min, f
 }
 template <class IT>
 __device__ __forceinline__ IterRed team_iter_reduce(const SView<IT> &, IterRed x, bool with_min, float *red5) { return block_iter_reduce(x, with_min, red5); }
-__device__ __forceinline__ IterRed team_iter_reduce(const TeamView &t, IterRed x, bool with_min, float *red5)
+template <class B>
+__device__ __forceinline__ IterRed team_iter_reduce(const Teamed<B> &t, IterRed x, bool with_min, float *red5)
 {
     x = block_iter_reduce(x, with_min, red5);
     if (t.size == 1) return x;
@@ -235,9 +236,17 @@ __device__ int hbm_reinforce_step(const V &I, float *fs /*[e][2]*/, float pi, in
 
 // HBM-resident form of the solver: the instance's arrays stay where the problem keeps them, one workgroup (TEAM = false) or a
 // team of workgroups (TEAM = true, few big instances) walks them.
-template <int NT, bool TEAM>
+// LOCK: the whole (small) batch in lock step -- one workgroup per instance, every workgroup of the launch resident, and three batch-wide
+// mailbox exchanges per iteration carry what the reference couples the instances through: the batch-global minima of the three
+// sparse_max / sparse_argmax sites (pdp_decimate.py:127-160; an INACTIVE instance keeps contributing: its frozen survey maxima, zeros at
+// the difference site, and -- it "converges" in every iteration -- its frozen |score| * active coefficients), a NaN anywhere, the
+// replica-aware termination rule (trainer.py:157-160) and the global early exit.  Nothing is speculated, recorded or replayed.
+struct LockNone {};
+template <int NT, bool TEAM, bool LOCK = false>
 __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
 {
+    static_assert(!(TEAM && LOCK), "lock-step batches give every instance one workgroup");
+    __shared__ uint32_t lock_w[LOCK ? 256 : 1];
     // (only per-wave reduction scratch in LDS: the instance's state is in HBM)
     __shared__ float redf[NT / PDP_WAVE];
     __shared__ int redi[NT / PDP_WAVE];
@@ -249,7 +258,7 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
     }
     int poison_from = sp.hbm_device_ctl ? (sp.hbm_replay ? sp.ctl->poison_from : (sp.call->poisoned_all ? 0 : 0x7fffffff)) : sp.poison_from;
     const bool exact = sp.exact != 0, rf = sp.rf != 0;
-    const bool own_nan = exact || sp.isolate != 0;      // a NaN never leaves the instance: no batch-wide poison record, no replay
+    const bool own_nan = exact || sp.isolate != 0 || LOCK;      // no batch-wide poison record, no replay (LOCK: the NaN is exchanged in the iteration)
     std::conditional_t<TEAM, TeamView, SView<int32_t>> I;
     int slot = (int)blockIdx.x;          // which of the launch's instances
     if constexpr (TEAM) {
@@ -295,6 +304,45 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
     const bool other_rows = n < pv.V;
 
     int abort_next = 0;
+    // ---- LOCK: the batch as a team (mailboxes only: no instance data crosses workgroups), frozen contributions of an inactive instance
+    Teamed<LockNone> BT;
+    float fz_mn0 = PDP_INF, fz_mnc = PDP_INF;
+    int any_active = 1;
+    auto frozen = [&]() {
+        float mn = PDP_INF;
+        for (int v = tid; v < n; v += nt) {
+            float num = 0.0f, den = 0.0f;
+            for (int k = I.v_ptr[v]; k < I.v_ptr[v + 1]; ++k) {
+                const float et = I.eta[I.v_edges[k] * I.estride];
+                const float c1 = pdp_safe_exp(30.0f * et);
+                num = num + et * c1; den = den + c1;
+            }
+            mn = OpMinLess()(mn, (num / pdp_max(den, 1.0f)) * I.av[v]);
+        }
+        fz_mn0 = block_reduce(mn, OpMinLess(), PDP_INF, redf);
+        for (int e = tid; e < ne; e += nt)
+            I.s3[e] = pdp_safe_log(1.0f - I.eta[e * I.estride], PDP_SCORER_EPS) * (0.0f + I.af[I.e_fn[e]]);
+        __syncthreads();
+        mn = PDP_INF;
+        for (int v = tid; v < n; v += nt) {
+            float ext = 0.0f, pos = 0.0f, neg = 0.0f, all = 0.0f;
+            for (int k = I.v_ptr[v]; k < I.v_ptr[v + 1]; ++k) {
+                const int e = I.v_edges[k];
+                const int sg = I.sgn[e];
+                const float f = I.s3[e];
+                ext = ext + I.force[e * I.fstride];
+                pos = pos + ((sg == 1) ? 1.0f : 0.0f) * f;
+                neg = neg + ((sg == -1) ? 1.0f : 0.0f) * f;
+                all = all + f;
+            }
+            mn = OpMinLess()(mn, (pdp_abs(d_score_from_sums(pos, neg, all, ext, sp.pi)) * I.av[v]) * 1.0f);
+        }
+        fz_mnc = block_reduce(mn, OpMinLess(), PDP_INF, redf);
+    };
+    if constexpr (LOCK) {
+        BT.rank = (int)blockIdx.x; BT.size = (int)gridDim.x; BT.epoch = 0; BT.same_xcd = 2; BT.bar = sp.team_ws; BT.box = BT.bar + 32;
+        if (!active) frozen();
+    }
 #ifdef PDP_PHASE_PROF
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = wall_clock64();
 #define TP(i) { const long long now_ = wall_clock64(); tacc[i] += now_ - tlast; tlast = now_; }
@@ -302,10 +350,14 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
 #define TP(i)
 #endif
     for (int t = 0; t < sp.T; ++t) {
-        if (!active) break;
+        if (!LOCK && !active) break;
         if (abort_next) break;                // pass 1 only: some instance poisons the batch before t, this pass will be replayed anyway
         bool poisoned = t >= poison_from;
         iters = t + 1;
+        const int was_active = active;
+        int nan_seen = 0, z1 = 0, z2 = 0;
+        IterRed red; red.a = -PDP_INF; red.b = -PDP_INF; red.mna = PDP_INF; red.mnb = PDP_INF;
+        if (!LOCK || active) {
         // ---- P1 + P2: per-edge logs (pdp_propagate.py:166-169,185-188) and their per-clause / per-variable sums in ascending
         // edge order; every edge sits in exactly one clause row and one variable row, which computes and leaves its log for P3
         // (memory latency is what this kernel waits for: rows are walked in batches whose loads are all in flight together, and
@@ -358,7 +410,6 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
         team_sync(I);
         TP(1)
         // ---- P3: new surveys + new q_u, and the decimator's per-edge terms (pdp_decimate.py:128-141)
-        int nan_seen = 0;
         for (int e = tid; e < ne; e += nt) {
             const int v = I.e_var[e], c = I.e_fn[e];
             const float s = (float)I.sgn[e];
@@ -390,8 +441,6 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
         TP(3)
         // ---- P4 + P5: per-variable smooth maxima (util.py:282-286) times the active flag, and their per-instance maxima with
         // the reference's (x - min + 1) rounding (util.sparse_max, util.py:267-275), speculating min == 0
-        int z1 = 0, z2 = 0;
-        IterRed red; red.a = -PDP_INF; red.b = -PDP_INF; red.mna = PDP_INF; red.mnb = PDP_INF;
         for (int v = tid / ROWL; v < n; v += nt / ROWL) {
             const int beg = I.v_ptr[v], end = I.v_ptr[v + 1];
             float num1 = 0.0f, den1 = 0.0f, num2 = 0.0f, den2 = 0.0f;
@@ -427,17 +476,27 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
             }
         }
         TP(4)
+        } else {
+            // LOCK, inactive instance: its frozen messages still enter the batch-global minima of this iteration
+            if (n > 0) { red.mna = fz_mn0; if (has_prev) red.mnb = 0.0f; }
+        }
         // the same barrier carries pass 1's look at the batch's first NaN iteration for the next trip of the loop
         const int nan_before_next = (!own_nan && poison_from == 0x7fffffff && tid == 0 &&
                                      __hip_atomic_load(sp.nan_iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)(t + 1)) ? 1 : 0;
         red.bits = (z1 ? 1 : 0) | (z2 ? 2 : 0) | (nan_seen ? 4 : 0) | (nan_before_next ? 8 : 0);
-        red = team_iter_reduce(I, red, exact, red5);
+        red = team_iter_reduce(I, red, exact || LOCK, red5);
         TP(5)
         z1 = red.bits & 1; z2 = red.bits & 2; nan_seen = red.bits & 4; abort_next = red.bits & 8;
         // util.sparse_max (util.py:267-275): max_v((x_v - min) + 1), then + min - 1.  Rounding is monotone, so the maximum of the
         // shifted values is the shifted maximum and the raw maximum is all the reduction has to carry.  min: the batch-global one --
         // speculated to be 0, or (single-instance batch) the instance's own.
-        const float gm1 = exact ? red.mna : 0.0f, gm2 = exact ? red.mnb : 0.0f;
+        float gm1 = exact ? red.mna : 0.0f, gm2 = exact ? red.mnb : 0.0f;
+        if constexpr (LOCK) {
+            IterRed ex; ex.a = -PDP_INF; ex.b = -PDP_INF; ex.mna = red.mna; ex.mnb = red.mnb; ex.bits = red.bits & 4;
+            ex = team_iter_reduce(BT, ex, true, red5);
+            gm1 = ex.mna; gm2 = ex.mnb;
+            if ((ex.bits & 4) && !poisoned) { poison_from = t; poisoned = true; }       // a NaN survey anywhere poisons the whole batch from this iteration on
+        }
         float g = (red.a - gm1) + 1.0f, dmax = 0.0f;
         if (other_rows) g = pdp_max(g, 0.0f);
         g = (g + gm1) - 1.0f;
@@ -458,7 +517,9 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
             else abort_next = 1;
         }
         int conv = 0, rf_changed = 0;
-        if (rf) {
+        if (LOCK && !active) {
+            // (an inactive instance takes no decision)
+        } else if (rf) {
             // active_mask[sum_diff <= 0.01] = 0 (pdp_decimate.py:205-215; no survey gate, no counters); under the poison the batch-wide maximum is NaN
             if (!poisoned && has_prev && dmax <= sp.tol) active = 0;
         } else if (!poisoned) {
@@ -488,12 +549,14 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
         }
         // ---- P6: decimation (pdp_decimate.py:152-171)
         int decimated = 0;
-        if (!rf && has_prev && conv && !poisoned && !nan_seen) {
+        const bool will = !rf && has_prev && conv && !poisoned && !nan_seen && (!LOCK || was_active);    // (an instance the gate just closed still enters site 2)
+        int z3 = 0, anynz = 0, cn = 0;
+        float gm3 = 0.0f;
+        if (will) {
             // scorer (pdp_predict.py:155-192)
             for (int e = tid; e < ne; e += nt)
                 I.s3[e] = pdp_safe_log(1.0f - I.eta[e * I.estride], PDP_SCORER_EPS) * (0.0f + I.af[I.e_fn[e]]);
             team_sync(I);
-            int z3 = 0, anynz = 0, cn = 0;
             for (int v = tid; v < n; v += nt) {
                 float ext = 0.0f, pos = 0.0f, neg = 0.0f, all = 0.0f;
                 for (int k = I.v_ptr[v]; k < I.v_ptr[v + 1]; ++k) {
@@ -518,12 +581,18 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
             }
             if (cn) violation = 1;                                // cannot happen without a NaN survey
             used |= 4u; if (z3) zero |= 4u;
-            float gm3 = 0.0f;
-            if (exact) {
+            if (exact || LOCK) {
                 float mn = PDP_INF;
                 for (int v = tid; v < n; v += nt) mn = OpMinLess()(mn, I.coeff[v]);
                 gm3 = team_reduce(I, mn, OpMinLess(), PDP_INF, redf);
             }
+        }
+        if constexpr (LOCK) {
+            // site 2 over the batch: a converged instance's smallest coefficient, 0 for an active one that did not converge (all its
+            // coefficients are 0), the frozen one of an inactive instance
+            if (has_prev) gm3 = team_reduce(BT, will ? gm3 : (was_active ? (n > 0 ? 0.0f : PDP_INF) : fz_mnc), OpMinLess(), PDP_INF, redf);
+        }
+        if (will) {
             const int li = d_instance_argmax(I, I.coeff, gm3, redf, redi);
             if (active && anynz && !cn && li >= 0) {
                 for (int v = tid; v < n; v += nt) I.assign[v] = 0.0f;
@@ -535,7 +604,7 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
                 decimated = 1;
             }
         }
-        if (has_prev) cnt = cnt + 1.0f;
+        if (has_prev && (!LOCK || was_active)) cnt = cnt + 1.0f;
         if (tid == 0 && !poisoned && !own_nan) { atomicOr(&sp.spec_used[t], used); if (zero) atomicOr(&sp.spec_zero[t], zero); }
         // ---- P7: edge mask refresh (solver.py:370-371); values only change after a decimation
         if (decimated || !use_em) {
@@ -552,8 +621,23 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
             if (decimated || rf_changed || nsat < 0) nsat = d_cnf_sat_count(I, I.sol, redi);
             if (active && nsat == m) active = 0;
         }
+        if constexpr (LOCK) {
+            // termination across the batch: replicas of a solved instance stop together (trainer.py:157-160), everybody stops when nobody is left
+            uint32_t *box = team_box(BT);
+            if (threadIdx.x == 0) box_put(&box[PDP_BOX_WORDS * BT.rank], ((sp.check_termination && nsat == m) ? 1u : 0u) | (active ? 2u : 0u));
+            team_sync(BT);
+            if ((int)threadIdx.x < BT.size) lock_w[threadIdx.x] = box_get(&box[PDP_BOX_WORDS * threadIdx.x]);
+            __syncthreads();
+            auto group_solved = [&](int b) { int s_ = 0; for (int r = 0; r < pv.R; ++r) s_ |= (int)(lock_w[b % pv.B0 + r * pv.B0] & 1u); return s_; };
+            if (pv.R > 1 && sp.check_termination && active && group_solved(G.b)) active = 0;
+            int still = 0;
+            if ((int)threadIdx.x < BT.size) still = ((lock_w[threadIdx.x] & 2u) && !(pv.R > 1 && sp.check_termination && group_solved((int)threadIdx.x))) ? 1 : 0;
+            any_active = __syncthreads_or(still);
+            if (was_active && !active) frozen();
+        }
         has_prev = 1; prev_from_global = 0;
         TP(6)
+        if (LOCK && !any_active) break;
     }
 #ifdef PDP_PHASE_PROF
     if (tid == 0 && TEAM) printf("[team %d x %d] iters %d: rows %lld sync %lld edges %lld sync %lld maxima %lld reduce %lld rest %lld (x10 ns)\n", I.b, nt, iters, tacc[0], tacc[1], tacc[2], tacc[3], tacc[4], tacc[5], tacc[6]);
@@ -2067,7 +2151,76 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     return PDP_OK;
 }
 
+// workspaces of the HBM-resident kernel (shared by the host-driven loop, the exact single-instance launch and the lock-step launch)
+static int hbm_workspaces(pdp_problem *p, SolveParams &sp)
+{
+    for (int i = 0; i < 4; ++i) sp.ws_e[i] = p->ws_e[i];
+    sp.ws_f = p->ws_f[0];
+    for (int i = 0; i < 6; ++i) sp.ws_v[i] = p->ws_v[i];
+    if (!p->solve_extra_v) { int st_ = pdp_dev_alloc((void **)&p->solve_extra_v, sizeof(float) * (size_t)p->V); if (st_ != PDP_OK) return st_; }
+    sp.ws_v[6] = p->solve_extra_v;
+    for (int i = 0; i < 3; ++i) sp.ws_vi[i] = p->ws_vi[i];
+    sp.ws_fu[0] = p->ws_fu[0]; sp.ws_fu[1] = p->ws_fu[1];
+    return PDP_OK;
+}
+
+// Lock-step solve of a small batch (k_sp_solve<256, false, true>): exact reference semantics without speculation -- what the batch takes when
+// the speculation failed (no instance supplied the exact zero: batches of a few instances), and what replicated batches with non-identical
+// replicas take (random initial state: the replicas couple through the termination rule).  One launch, no snapshot.
+static bool lockstep_possible(const pdp_problem *p, const pdp_solve_args *a)
+{
+    if (a->model != PDP_MODEL_SP || a->isolate_instances || getenv("PDP_SOLVE_NO_LOCKSTEP")) return false;
+    return p->B <= pdp_device_cus() && p->B <= 256 && p->max_e <= 65536;     // every workgroup resident at once; an instance is one workgroup's work
+}
+static int sp_solve_lockstep(pdp_problem *p, pdp_solve_args *a, hipStream_t st)
+{
+    SolveParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.tol = a->tolerance; sp.t_max = a->t_max; sp.pi = a->pi;
+    sp.q = a->q; sp.fs = a->fs; sp.amask = a->active_mask;
+    sp.prev = a->decimator->prev; sp.counters = a->decimator->counters;
+    sp.check_termination = a->check_termination;
+    sp.w_perm_zero = p->flags + FL_PERM_ZERO; sp.w_iters_run = p->flags + FL_ITERS_RUN; sp.w_violation = p->flags + FL_SPEC_VIOLATION;
+    sp.nan_iter = p->flags + FL_N_SEL; sp.spec_used = nullptr; sp.spec_zero = nullptr;
+    sp.T = a->iterations; sp.has_prev = a->decimator->has_prev; sp.has_edge_mask = p->has_edge_mask; sp.final_chunk = 1; sp.poison_from = 0x7fffffff;
+    { const int st_ = hbm_workspaces(p, sp); if (st_ != PDP_OK) return st_; }
+    if (!p->team_ws) { int st_ = pdp_dev_alloc((void **)&p->team_ws, sizeof(uint32_t) * 256 * PDP_TEAM_WORDS); if (st_ != PDP_OK) return st_; }
+    PDP_HIP_CHECK(hipMemsetAsync(p->team_ws, 0, sizeof(uint32_t) * PDP_TEAM_WORDS, st));
+    sp.team_ws = p->team_ws;
+    PDP_HIP_CHECK(hipMemsetAsync(p->flags + FL_PERM_ZERO, 0xff, sizeof(uint32_t), st));
+    PDP_HIP_CHECK(hipMemsetAsync(p->flags + FL_SPEC_VIOLATION, 0, sizeof(uint32_t) * 2, st));
+    hipLaunchKernelGGL((k_sp_solve<256, false, true>), dim3(p->B), dim3(256), 0, st, make_view(p), sp);
+    PDP_LAUNCH_CHECK();
+    PDP_HIP_CHECK(hipMemcpyAsync(p->flags_host, p->flags, FL_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    PDP_HIP_CHECK(hipStreamSynchronize(st));
+    PDP_REQUIRE(p->flags_host[FL_SPEC_VIOLATION] == 0u, "lock-step solve: inconsistent NaN bookkeeping");
+    a->kernel_launches_host = 1; a->used_lds_host = 0; a->hbm_instances_host = p->B;
+    a->iterations_run_host = (int)p->flags_host[FL_ITERS_RUN];
+    a->decimator->has_prev = 1; p->has_edge_mask = 1;
+    return PDP_OK;
+}
+
+static int sp_solve_speculative(pdp_problem *p, pdp_solve_args *a, void *stream);
 extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
+{
+    PDP_REQUIRE(p && a && p->av, "NULL argument / state not bound");
+    PDP_REQUIRE(a->model == PDP_MODEL_SP || a->model == PDP_MODEL_REINFORCE, "persistent solve: SP and Reinforce triples only");
+    PDP_REQUIRE(a->q && a->fs && a->active_mask && a->decimator, "NULL state array");
+    if (p->R > 1 && !a->replicas_identical) {
+        // replicas that start from different states couple through the termination rule: lock-step, or not at all
+        a->iterations_run_host = 0; a->used_lds_host = 0; a->kernel_launches_host = 0; a->replay_launches_host = 0; a->hbm_instances_host = 0;
+        if (a->iterations <= 0) return PDP_OK;
+        if (lockstep_possible(p, a)) return sp_solve_lockstep(p, a, ST(stream));
+        pdp_set_error("persistent solve with batch replication: the replicas differ (they couple through the termination check) and the batch is too large "
+                      "for the lock-step launch; run the batch step-wise");
+        return PDP_ERR_SPECULATION;
+    }
+    const int rc = sp_solve_speculative(p, a, stream);
+    if (rc == PDP_ERR_SPECULATION && lockstep_possible(p, a)) return sp_solve_lockstep(p, a, ST(stream));      // (every array is back at its call-entry state)
+    return rc;
+}
+
+static int sp_solve_speculative(pdp_problem *p, pdp_solve_args *a, void *stream)
 {
     PDP_REQUIRE(p && a && p->av, "NULL argument / state not bound");
     PDP_REQUIRE(a->model == PDP_MODEL_SP || a->model == PDP_MODEL_REINFORCE, "persistent solve: SP and Reinforce triples only");
@@ -2075,7 +2228,6 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
     PDP_REQUIRE(!rf_model || a->coins, "persistent Reinforce needs the per-iteration coins (device array [iterations])");
     PDP_REQUIRE(!rf_model || !a->isolate_instances, "isolated-instance mode is implemented for the SP triple only");
     PDP_REQUIRE(a->q && a->fs && a->active_mask && a->decimator, "NULL state array");
-    PDP_REQUIRE(p->R == 1 || a->replicas_identical, "persistent solve with batch replication needs identical replicas (replicas couple through the termination check)");
     hipStream_t st = ST(stream);
     const int T = a->iterations;
     a->iterations_run_host = 0; a->used_lds_host = 0; a->kernel_launches_host = 0; a->replay_launches_host = 0; a->hbm_instances_host = 0;

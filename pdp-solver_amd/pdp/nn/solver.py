@@ -224,7 +224,13 @@ class PropagatorDecimatorSolverBase(nn.Module):
             # the batch has an active variable (a batch-wide condition that the loop cannot change: nothing is decimated)
             if check_termination is None or self._isolated or not bool((sat_problem._active_variables > 0).any().item()):
                 return False
-        return sat_problem._batch_replication == 1 or self._replicas_identical(sat_problem, states)
+        if sat_problem._batch_replication == 1:
+            return True
+        # replicated batch: identical replicas (the predict path's deterministic initial state) run like any batch; replicas that differ
+        # (random initial state) couple through the termination rule -- the library has a lock-step launch for small batches of the SP
+        # triple and reports anything else, which sends the batch to the step-wise loop
+        self._replicas_same = self._replicas_identical(sat_problem, states)
+        return self._replicas_same or model == native.MODEL_SP
 
     def _forward_core(self, init_propagator_state, init_decimator_state, sat_problem, iteration_num, is_training, check_termination):
         can = self._can_run_persistent(sat_problem, is_training, check_termination, tuple(init_propagator_state[:2]) + tuple(init_decimator_state[:2]))
@@ -261,7 +267,8 @@ class PropagatorDecimatorSolverBase(nn.Module):
         try:
             iters, used_lds = nat.sp_solve(q, fs, active_mask, handle, int(iteration_num), tolerance, t_max, self._propagator._pi,
                                            check_termination=check_termination is not None,
-                                           replicas_identical=sat_problem._batch_replication > 1, isolate_instances=self._isolated, **extra)
+                                           replicas_identical=sat_problem._batch_replication > 1 and getattr(self, '_replicas_same', True),
+                                           isolate_instances=self._isolated, **extra)
         except native.SpeculationFailed:
             if model == native.MODEL_REINFORCE:
                 torch.set_rng_state(rng_state)

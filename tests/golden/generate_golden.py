@@ -1050,6 +1050,10 @@ if __name__ == '__main__':
     if 'randinit' in what:
         run_trace('p-d-p', make_lines([(30, 108, (3,))] * 10 + [(24, 60, (2, 3, 4))] * 6, seed0=4300), T=25, w=15, seed=21, randomized=True,
                   tag='trace_pdp_randinit', cfg_kw=dict(tolerance=0.05, t_max=10))
+    if 'rep_randinit' in what:
+        # batch replication with a RANDOM initial state: the replicas differ and couple through the termination rule (trainer.py:157-160)
+        run_trace('p-d-p', make_lines([(40, 140, (3,))] * 6, seed0=900), T=30, w=10, seed=29, replication=3, randomized=True,
+                  tag='trace_pdp_rep3_randinit', cfg_kw=dict(tolerance=0.05, t_max=6))
     if 'cli' in what:
         gen_cli()
     if 'config0' in what:

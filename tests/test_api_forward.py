@@ -49,6 +49,7 @@ CASES = [('trace_pdp_n50', 'p-d-p', dict(tolerance=0.02, t_max=100)),
          ('trace_pdp_randinit', 'p-d-p', dict(tolerance=0.05, t_max=10)),      # random initial state (test mode): first sweep reads the decimator's
          ('trace_walksat_easy', 'walk-sat', {}),
          ('trace_pdp_rep3', 'p-d-p', dict(tolerance=0.05, t_max=6)),
+         ('trace_pdp_rep3_randinit', 'p-d-p', dict(tolerance=0.05, t_max=6)),   # replicas that differ: they couple through the termination rule -> lock-step launch
          ('trace_reinforce_easy', 'reinforce', dict(pi=0.01, decimation_probability=0.5))]
 
 
@@ -59,7 +60,7 @@ def test_forward_equals_reference_golden(name, model_type, kw, persistent):
     np.testing.assert_array_equal(pred[0].cpu().numpy()[:, 0], d['final_prediction'])
     if model_type == 'p-d-p' and int(d['meta'][3]) > 1:
         # batch replication with the deterministic initial state: identical replicas, so the persistent loop is allowed
-        assert m.last_run['path'] == ('persistent-lds' if persistent else 'stepwise')
+        assert m.last_run['path'] == (('persistent-hbm' if 'randinit' in name else 'persistent-lds') if persistent else 'stepwise')
     if model_type == 'reinforce':
         assert m.last_run['path'] == ('persistent-lds' if persistent else 'stepwise')
     if model_type == 'p-d-p' and int(d['meta'][3]) == 1:

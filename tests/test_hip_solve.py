@@ -73,7 +73,7 @@ def test_persistent_solve_golden_trace():
     np.testing.assert_allclose(npy(q), d['final_prop_0'], rtol=5e-4, atol=5e-6)
 
 
-def test_speculation_detects_coupling(oracle):
+def test_speculation_detects_coupling(oracle, monkeypatch):
     """Two instances without any inactive variable: the batch-global min is > 0 and no instance supplies an exact zero, so the
     persistent solver must refuse (PDP_ERR_SPECULATION) instead of returning a result that differs from the reference.  (A batch of
     ONE such instance is solved exactly instead: test_single_instance_batches_run_exact.)"""
@@ -94,8 +94,20 @@ def test_speculation_detects_coupling(oracle):
     q = torch.full((hp.E, 3), 1.0, device='cuda:0') / 3.0
     fs = torch.zeros(hp.E, 2, device='cuda:0'); fs[:, 0] = 0.5
     am = torch.ones(hp.B, dtype=torch.uint8, device='cuda:0')
+    monkeypatch.setenv('PDP_SOLVE_NO_LOCKSTEP', '1')
     with pytest.raises(native.SpeculationFailed):
         hp.sp_solve(q, fs, am, native.Decimator(hp), 5, 0.02, 100)
+    # every array is back at its call-entry state; with the lock-step launch (the default for small batches) the same call succeeds
+    # and equals the oracle's strict semantics
+    monkeypatch.delenv('PDP_SOLVE_NO_LOCKSTEP')
+    res = op.forward('p-d-p', 25, local_search_iterations=0, tolerance=0.02, t_max=100, seed=5, trace=True)
+    iters, used_lds = hp.sp_solve(q, fs, am, native.Decimator(hp), 25, 0.02, 100)
+    it = res['iterations_run']
+    assert iters == it and not used_lds
+    np.testing.assert_array_equal(npy(am), res['trace_active_mask'][it - 1])
+    np.testing.assert_array_equal(npy(hp.solution), res['trace_solution'][it - 1])
+    np.testing.assert_array_equal(npy(q), res['q'])
+    np.testing.assert_array_equal(npy(fs), res['fs'])
 
 
 @pytest.mark.parametrize('spec,T,tol,t_max', [(dict(batch=400, n=60, k=3, seed=7000), 120, 0.05, 8),
@@ -406,6 +418,31 @@ def test_replicas_of_a_single_instance_run_exact(oracle, n, seed):
     np.testing.assert_array_equal(npy(hp.solution), res['trace_solution'][it - 1])
     np.testing.assert_array_equal(npy(q), res['q'])
     np.testing.assert_array_equal(npy(fs), res['fs'])
+
+
+@pytest.mark.parametrize('B,n,alpha,T,seeds', [(2, 50, 4.2, 60, range(0, 8)), (10, 50, 4.2, 60, range(0, 20)), (10, 60, 3.5, 100, range(30, 36)), (40, 30, 3.6, 80, range(50, 53))])
+def test_small_batches_fall_back_to_lockstep(oracle, B, n, alpha, T, seeds):
+    """Batches of a few instances: when no instance supplies the exact zero the speculation fails (4 of 20 random batches of 10, most
+    batches of 2) and pdp_sp_solve reruns the batch in ONE lock-step launch -- one workgroup per instance, the batch-global minima, the NaN
+    flag and the termination exchanged through mailboxes in every iteration -- instead of handing it to the step-wise loop.  Either way the
+    end state equals the oracle's strict semantics bit for bit, and the call never fails."""
+    from pdp.factorgraph import dataset
+    lock = 0
+    for seed in seeds:
+        b = dataset.collate_segment(dataset.random_ksat_items(B, n, 3, m=int(alpha * n), seed=1000 * seed + 7))
+        hp, res, q, fs, am, iters, used_lds, spec_ok = run_pair(oracle, b, T, 0.05, 8)
+        assert spec_ok
+        lock += 0 if used_lds else 1
+        it = res['iterations_run']
+        assert iters == it, seed
+        np.testing.assert_array_equal(npy(am), res['trace_active_mask'][it - 1], err_msg=str(seed))
+        np.testing.assert_array_equal(npy(hp.active_variables)[:, 0], res['trace_active_var'][it - 1], err_msg=str(seed))
+        np.testing.assert_array_equal(npy(hp.active_functions)[:, 0], res['trace_active_fn'][it - 1], err_msg=str(seed))
+        np.testing.assert_array_equal(npy(hp.solution), res['trace_solution'][it - 1], err_msg=str(seed))
+        np.testing.assert_array_equal(npy(q), res['q'], err_msg=str(seed))
+        np.testing.assert_array_equal(npy(fs), res['fs'], err_msg=str(seed))
+    if B <= 10 and alpha > 4:
+        assert lock > 0          # some of these batches did take the lock-step launch
 
 
 @pytest.mark.parametrize('n_big', [1, 3])

@@ -1,3 +1,6 @@
+"""How often does pdp_sp_solve succeed by batch size (20 random batches each)?  By default never-failing paths are on: single-instance batches are
+solved exactly and small batches whose speculation failed rerun in the lock-step launch.  PDP_SOLVE_NO_EXACT=1 PDP_SOLVE_NO_LOCKSTEP=1 shows the raw
+speculation: it holds for 20/20 batches at B >= 100, 16/20 at B = 10, 1-10/20 at B = 1, failing in the first iteration."""
 import os, sys
 sys.path.insert(0, '/root/repo/pdp-solver_amd')
 import torch, numpy as np
