@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
         slot = team_begin(I, tl, redi);
         if (slot < 0) return;
     }
-    const Inst G = load_inst(pv, sp.big_list ? sp.big_list[slot] : slot);
+    const Inst G = load_inst(pv, __builtin_amdgcn_readfirstlane(sp.big_list ? sp.big_list[slot] : slot));
     const int tid = team_tid(I), nt = team_nt(I);
     constexpr int ROWL = TEAM ? 8 : (NT >= 1024 ? 4 : 1);      // lanes per variable row: the fewer threads an instance has, the more rows each must walk anyway
     const int rl = tid & (ROWL - 1);
@@ -1148,7 +1148,9 @@ __device__ __noinline__ int lds_cnf_count(unsigned char *smem, int b, int n, int
 // RF: the Reinforce triple (ReinforceDecimator + ReinforcePredictor, pdp_decimate.py:202-234) instead of the sequential decimator: no
 // survey gate, no counters, no decimation; convergence (`max <= 0.01`) de-activates the instance, a shared coin per iteration decides
 // whether the force is renewed.  Under the NaN poison the gate's batch-wide maximum is NaN: nobody leaves through the gate.
-template <bool FORCE, bool REPLAY, bool RF = false>
+// LISTED (pass 1 of mixed batches): the instance comes from sp.fit_list, by ticket -- a separate instantiation, because an instance id that is
+// not blockIdx.x costs a scalar register for the whole kernel and this kernel has none to spare (+3 % VALU instructions from the spill)
+template <bool FORCE, bool REPLAY, bool RF = false, bool LISTED = false>
 __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams sp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1164,15 +1166,21 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
     // the instances.  With sp.lds_tickets every workgroup draws the next instance when it STARTS and the grid is over-provisioned:
     // the slow XCD simply gets through fewer tickets, and the workgroups left over when they run out leave at once.
     int index = (int)blockIdx.x;
-    if (!REPLAY && sp.lds_tickets) {
-        __shared__ int s_ticket;
-        if (tid == 0) s_ticket = (int)atomicAdd(&ctl->ticket, 1u);
-        __syncthreads();
-        index = s_ticket;
-        if (index >= sp.lds_tickets) return;
+    if constexpr (LISTED) {
+        static_assert(!REPLAY, "the replay pass has its own list");
+        if (sp.lds_tickets) {
+            __shared__ int s_ticket;
+            if (tid == 0) s_ticket = (int)atomicAdd(&ctl->ticket, 1u);
+            __syncthreads();
+            index = __builtin_amdgcn_readfirstlane(s_ticket);
+            if (index >= sp.lds_tickets) return;
+        }
+        index = __builtin_amdgcn_readfirstlane(sp.fit_list[index]);
     }
     if (REPLAY && (!ctl->do_replay || (uint32_t)index >= ctl->replay_count)) return;
-    const Inst G = load_inst(pv_, REPLAY ? sp.inst_list[index] : (sp.fit_list ? sp.fit_list[index] : index));
+    const Inst G = load_inst(pv_, REPLAY ? __builtin_amdgcn_readfirstlane(sp.inst_list[index]) : index);
+    __shared__ int s_inst;                                  // listed instance id, parked for the final writes (a scalar register less across the loop)
+    if ((LISTED || REPLAY) && tid == 0) s_inst = G.b;
     const int n = G.n, m = G.m, ne = G.e;
     const LdsArrays L = carve_all(smem, n, m, ne, FORCE && !RF);
     constexpr int VM = RF ? PV_VMASK_RF : 0x3fff;           // variable id of a slot word
@@ -1575,7 +1583,7 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
         int decimated = 0;
         if (!RF && has_prev && conv && !poisoned && !nan_seen && !PROF_SKIP(16)) {
             int spec_bits = 0;
-            decimated = UNI(lds_decimate<FORCE>(smem, G.b, n, m, ne, cur, active, pi, &s_is_sat, &spec_bits, &simplified));
+            decimated = UNI(lds_decimate<FORCE>(smem, 0, n, m, ne, cur, active, pi, &s_is_sat, &spec_bits, &simplified));    // (the view's batch id is unused)
             spec_bits = UNI(spec_bits); simplified = UNI(simplified);
             used |= 4u;
             if (spec_bits & 1) zero |= 4u;
@@ -1606,7 +1614,7 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
         }
         // ---- P8: termination check ---------------------------------------------------------------------------------------------
         if (sp.check_termination) {
-            if (decimated || rf_changed || nsat < 0) nsat = UNI((lds_cnf_count<FORCE, RF>(smem, G.b, n, m, ne)));
+            if (decimated || rf_changed || nsat < 0) nsat = UNI((lds_cnf_count<FORCE, RF>(smem, 0, n, m, ne)));
             if (active && nsat == m) active = 0;
         }
         has_prev = 1; prev_from_global = 0; cur ^= 1;
@@ -1677,9 +1685,10 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
         h.active = (uint32_t)active; h.done = finishing ? 1u : 0u; h.perm_zero = (finishing && any_inactive) ? 1u : 0u; h.simplified = (uint32_t)simplified;
         h.cnt = cnt; h.is_sat = s_is_sat; h.pad1 = 0.0f; h.pad2 = 0.0f;
         *reinterpret_cast<DynHeader *>(dout + BL.hdr) = h;
-        if (finishing) { sp.amask[G.b] = (uint8_t)active; sp.counters[G.b] = cnt; pv_.is_sat[G.b] = s_is_sat; }
+        const int gb = (LISTED || REPLAY) ? *(volatile int *)&s_inst : G.b;
+        if (finishing) { sp.amask[gb] = (uint8_t)active; sp.counters[gb] = cnt; pv_.is_sat[gb] = s_is_sat; }
         if (any_inactive) atomicMin(&ctl->perm_zero, (uint32_t)iters);
-        if (!REPLAY) sp.last_event[G.b] = last_event;
+        if (!REPLAY) sp.last_event[gb] = last_event;
         atomicMax(&ctl->iters_run, (uint32_t)iters);
         if (violation) atomicOr(&ctl->violation, 1u);
     }
@@ -1985,12 +1994,15 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
 
     if (rf) {
         PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sp_solve_lds<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sp_solve_lds<true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sp_solve_lds<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     } else if (force) {
         PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sp_solve_lds<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sp_solve_lds<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sp_solve_lds<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     } else {
         PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sp_solve_lds<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sp_solve_lds<false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sp_solve_lds<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     a->used_lds_host = 1;
@@ -2060,6 +2072,8 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     // ticketed LDS-resident pass (see k_sp_solve_lds): on for mixed batches; PDP_SOLVE_TICKETS=<percent of over-provisioning>, 0 = off
     int ticket_extra = nbig > 0 ? 25 : 0;
     if (const char *env = getenv("PDP_SOLVE_TICKETS")) ticket_extra = atoi(env);
+    if (ticket_extra > 0 && !sp.fit_list) sp.fit_list = p->res_fit_list;        // (tickets index the list; with no big instance it holds every instance)
+    const bool listed = sp.fit_list != nullptr;                                 // pass 1 runs the LISTED instantiation
     const int big_copy_wgs = nbig >= 256 ? 1 : (256 / (nbig > 0 ? nbig : 1) < 32 ? 256 / (nbig > 0 ? nbig : 1) : 32);      // workgroups per instance of the save / restore copies
     if (const char *env = getenv("PDP_DEBUG_SKIP")) sp.debug_skip = atoi(env);
     int done = 0;
@@ -2094,6 +2108,11 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
             if (timed) PDP_HIP_CHECK(hipEventRecord(p->res_events[4 * k + 2 * pass], st));
             sp.lds_tickets = (pass == 0 && ticket_extra > 0) ? nfit : 0;
             const int grid_lds = sp.lds_tickets ? nfit + (int)(((int64_t)nfit * ticket_extra + 99) / 100) : nfit;
+            if (pass == 0 && listed) {
+                if (rf) hipLaunchKernelGGL((k_sp_solve_lds<true, false, true, true>), dim3(grid_lds), dim3(nt_lds), lds, st, make_view(p), sp);
+                else if (force) hipLaunchKernelGGL((k_sp_solve_lds<true, false, false, true>), dim3(grid_lds), dim3(nt_lds), lds, st, make_view(p), sp);
+                else hipLaunchKernelGGL((k_sp_solve_lds<false, false, false, true>), dim3(grid_lds), dim3(nt_lds), lds, st, make_view(p), sp);
+            } else
             if (rf && pass == 0) hipLaunchKernelGGL((k_sp_solve_lds<true, false, true>), dim3(grid_lds), dim3(nt_lds), lds, st, make_view(p), sp);
             else if (rf) hipLaunchKernelGGL((k_sp_solve_lds<true, true, true>), dim3(nfit), dim3(nt_lds), lds, st, make_view(p), sp);
             else if (force && pass == 0) hipLaunchKernelGGL((k_sp_solve_lds<true, false>), dim3(grid_lds), dim3(nt_lds), lds, st, make_view(p), sp);

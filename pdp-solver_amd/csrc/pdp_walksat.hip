@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(NT) k_walksat(PView pv, WsParams wp)
     __shared__ unsigned long long s_keys[2 * NWV];   // per-wave maxima of the two arg-max keys
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
-    const Inst G = load_inst(pv, wp.inst_list ? wp.inst_list[blockIdx.x] : (int)blockIdx.x);
+    const Inst G = load_inst(pv, __builtin_amdgcn_readfirstlane(wp.inst_list ? wp.inst_list[blockIdx.x] : (int)blockIdx.x));
     const int n = G.n, m = G.m, ne = G.e;
     // by-variable slots: pvv = variable | sign bit, pcc = clause | edge-mask bit (top);  by-clause edges: cl = variable | mask bit | sign bit
     W *pvv, *pcc, *cl; const PT *v_ptr, *f_ptr; const float *av, *af; float *a, *aggc, *degc; int *delta, *nuns; uint8_t *unsat;
@@ -509,7 +509,7 @@ __global__ void __launch_bounds__(NT) k_walksat_team(PView pv, WsParams wp, Team
     Teamed<WsNone> TT;
     const int slot = team_begin(TT, tl, redi);
     if (slot < 0) return;
-    const Inst G = load_inst(pv, wp.inst_list[slot]);
+    const Inst G = load_inst(pv, __builtin_amdgcn_readfirstlane(wp.inst_list[slot]));
     const int n = G.n, m = G.m, ne = G.e;
     const int tid = team_tid(TT), nt = team_nt(TT);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
