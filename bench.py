@@ -499,7 +499,7 @@ def secondary_measurements(args, dev, b, prob, native):
         ach = bytes_launch / (per_launch * 1e-3) / 1e9
         out['reinforce'] = dict(workload="'reinforce' (pi 0.1, decimation probability 0.5) on the headline batch, T=%d, the persistent loop" % T,
                                 iterations=it, call_seconds=dt, iterations_per_sec=it / dt, path='persistent-lds' if lds else 'persistent-hbm',
-                                kernel='k_sp_solve_lds<true, false, true>', kernel_launches=st['launches'], kernel_ms_per_launch=per_launch,
+                                kernel='k_sp_solve_lds<true, false, true, false>', kernel_launches=st['launches'], kernel_ms_per_launch=per_launch,
                                 replay_launches=st['replays'], replay_ms=st['replay_kernel_ms'],
                                 roofline=dict(bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS,
                                               note='streaming-model bytes (41E+36V+8F per iteration) x iterations per launch / launch time'))
