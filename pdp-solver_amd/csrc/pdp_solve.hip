@@ -537,7 +537,7 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
         uint32_t zero = ((!rf && z1) ? 1u : 0u) | ((has_prev && z2) ? 2u : 0u);
         // coeff = |score| * active * converged: every variable of a non-converged instance is an exact 0 of site 2
         if (!rf && has_prev && !conv && n > 0) zero |= 4u;
-        if (rf) {
+        if (rf && (!LOCK || was_active)) {
             // the shared coin of this iteration (pdp_decimate.py:218); instances that are still active after the gate renew their force.
             // Predictor + _update_solution run in every iteration of the reference; their result only changes with the force.
             const int flip = (sp.coins[sp.chunk_start + t] < sp.dprob) && active;
@@ -590,7 +590,7 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
         if constexpr (LOCK) {
             // site 2 over the batch: a converged instance's smallest coefficient, 0 for an active one that did not converge (all its
             // coefficients are 0), the frozen one of an inactive instance
-            if (has_prev) gm3 = team_reduce(BT, will ? gm3 : (was_active ? (n > 0 ? 0.0f : PDP_INF) : fz_mnc), OpMinLess(), PDP_INF, redf);
+            if (has_prev && !rf) gm3 = team_reduce(BT, will ? gm3 : (was_active ? (n > 0 ? 0.0f : PDP_INF) : fz_mnc), OpMinLess(), PDP_INF, redf);
         }
         if (will) {
             const int li = d_instance_argmax(I, I.coeff, gm3, redf, redi);
@@ -2188,7 +2188,8 @@ static int hbm_workspaces(pdp_problem *p, SolveParams &sp)
 // replicas take (random initial state: the replicas couple through the termination rule).  One launch, no snapshot.
 static bool lockstep_possible(const pdp_problem *p, const pdp_solve_args *a)
 {
-    if (a->model != PDP_MODEL_SP || a->isolate_instances || getenv("PDP_SOLVE_NO_LOCKSTEP")) return false;
+    if (a->isolate_instances || getenv("PDP_SOLVE_NO_LOCKSTEP")) return false;
+    if (a->model == PDP_MODEL_REINFORCE && p->R > 1) return false;      // (Reinforce with batch replication: step-wise)
     return p->B <= pdp_device_cus() && p->B <= 256 && p->max_e <= 65536;     // every workgroup resident at once; an instance is one workgroup's work
 }
 static int sp_solve_lockstep(pdp_problem *p, pdp_solve_args *a, hipStream_t st)
@@ -2202,6 +2203,7 @@ static int sp_solve_lockstep(pdp_problem *p, pdp_solve_args *a, hipStream_t st)
     sp.w_perm_zero = p->flags + FL_PERM_ZERO; sp.w_iters_run = p->flags + FL_ITERS_RUN; sp.w_violation = p->flags + FL_SPEC_VIOLATION;
     sp.nan_iter = p->flags + FL_N_SEL; sp.spec_used = nullptr; sp.spec_zero = nullptr;
     sp.T = a->iterations; sp.has_prev = a->decimator->has_prev; sp.has_edge_mask = p->has_edge_mask; sp.final_chunk = 1; sp.poison_from = 0x7fffffff;
+    sp.rf = a->model == PDP_MODEL_REINFORCE ? 1 : 0; sp.coins = a->coins; sp.dprob = a->decimation_probability; sp.chunk_start = 0;
     { const int st_ = hbm_workspaces(p, sp); if (st_ != PDP_OK) return st_; }
     if (!p->team_ws) { int st_ = pdp_dev_alloc((void **)&p->team_ws, sizeof(uint32_t) * 256 * PDP_TEAM_WORDS); if (st_ != PDP_OK) return st_; }
     PDP_HIP_CHECK(hipMemsetAsync(p->team_ws, 0, sizeof(uint32_t) * PDP_TEAM_WORDS, st));

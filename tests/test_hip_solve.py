@@ -281,6 +281,19 @@ def test_reinforce_mixed_batch_and_single_instance(oracle):
         res = _reinforce_pair(oracle, dataset.collate_segment(dataset.random_ksat_items(1, 60, 3, m=250, seed=500 + seed)), 40, 0.1, 0.6, seed, expect_lds=False)
 
 
+@pytest.mark.parametrize('B,n,T', [(2, 50, 40), (6, 40, 40), (12, 30, 50)])
+def test_reinforce_small_batches_lockstep(oracle, B, n, T):
+    """Reinforce on batches of a few instances: the gate's batch-global minimum is rarely an exact zero there (nothing is ever decimated), the
+    speculation fails and the call reruns in the lock-step launch -- same comparison with the oracle's loop, for several batches each."""
+    from pdp.factorgraph import dataset
+    lock = 0
+    for seed in range(6):
+        b = dataset.collate_segment(dataset.random_ksat_items(B, n, 3, m=int(4.0 * n), seed=7700 + 10 * seed + B))
+        res = _reinforce_pair(oracle, b, T, 0.1, 0.5, seed, expect_lds=False)
+        lock += 1 if res['hbm_instances'] == B else 0
+    assert lock > 0
+
+
 def test_isolated_mode_on_the_hbm_resident_kernel(monkeypatch):
     """Isolated instances (no batch-wide couplings, a NaN stays inside its instance) on the HBM-resident kernel: the same end state as the
     LDS-resident kernel gives for the same batch, bit for bit -- a NaN-poisoned batch, so the two modes differ from the strict one."""
