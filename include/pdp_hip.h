@@ -164,7 +164,7 @@ int pdp_deduplicate(pdp_problem *p, const float *pred, float *out, int32_t *chos
  * over a team of workgroups).  The kernels assume the reference's accidental cross-instance
  * couplings are inert (batch-global min == 0); a NaN survey, which poisons the whole batch in the
  * reference, is detected and the affected instances are replayed on the device.  If a coupling was
- * active the call restores every array it touched and reruns a batch of up to 256 instances in a
+ * active the call restores every array it touched and reruns a batch of up to 1 024 instances in a
  * lock-step launch that exchanges the couplings exactly; a larger batch returns PDP_ERR_SPECULATION:
  * the caller reruns it through the step-wise entry points above.  A batch of ONE instance (or the
  * identical replicas of one) is solved exactly instead -- its batch-global minima are its own --
@@ -191,7 +191,7 @@ typedef struct pdp_solve_args {
     int32_t replicas_identical;   /* in: 1 = the R replicas of every instance (batch replication, solver.py:56-82) start from identical state,
                                    * so their trajectories coincide and the replica-aware termination rule (trainer.py:157-160) equals the
                                    * per-replica one.  0 with replication > 1 (random initial state): the replicas couple through the
-                                   * termination rule -- batches of up to 256 instances run in the lock-step launch, larger ones return
+                                   * termination rule -- batches of up to 1 024 instances run in the lock-step launch, larger ones return
                                    * PDP_ERR_SPECULATION untouched */
     int32_t isolate_instances;    /* in: 1 = "fixed" semantics instead of the reference's: every instance is solved on its own -- the
                                    * batch-global minimum of sparse_max / sparse_argmax is taken as 0 and a NaN survey stops the decimation

@@ -355,7 +355,8 @@ struct Teamed : Base {
     uint32_t *box;              // [2][size][PDP_BOX_WORDS] reduction mailboxes, alternating with the parity of the barrier they ride on
     mutable uint32_t epoch;     // team barriers passed (identical on every thread of the team)
 };
-#define PDP_TEAM_MAX 256                                 // (a workgroup has at least 256 threads: thread r reads rank r's mailbox)
+#define PDP_TEAM_MAX 256                                 // team size of one instance (mailbox reads: thread r folds ranks r, r + blockDim, ...)
+#define PDP_LOCK_MAX 1024                                // workgroups of a lock-step launch (one instance each)
 #define PDP_BOX_WORDS 8                                   // words of one rank's mailbox
 #define PDP_TEAM_WORDS (32 + 2 * PDP_TEAM_MAX * PDP_BOX_WORDS)      // words of team workspace per instance: the counter on a 128 B line of its own, then the mailboxes
 
@@ -403,7 +404,8 @@ __device__ __forceinline__ T team_reduce(const Teamed<B> &t, T v, Op op, T ident
     uint32_t *box = team_box(t);
     if (threadIdx.x == 0) box_put(&box[PDP_BOX_WORDS * t.rank], __builtin_bit_cast(uint32_t, v));
     team_sync(t);
-    const T theirs = ((int)threadIdx.x < t.size) ? __builtin_bit_cast(T, box_get(&box[PDP_BOX_WORDS * threadIdx.x])) : identity;
+    T theirs = identity;          // thread r folds the mailboxes of ranks r, r + blockDim, ...
+    for (int r = (int)threadIdx.x; r < t.size; r += (int)blockDim.x) theirs = op(theirs, __builtin_bit_cast(T, box_get(&box[PDP_BOX_WORDS * r])));
     return block_reduce(theirs, op, identity, scratch);
 }
 template <class B> __device__ __forceinline__ int team_any(const Teamed<B> &t, int x)      // like __syncthreads_or: is x non-zero anywhere (NOT the bitwise or)
@@ -413,7 +415,9 @@ template <class B> __device__ __forceinline__ int team_any(const Teamed<B> &t, i
     uint32_t *box = team_box(t);
     if (threadIdx.x == 0) box_put(&box[PDP_BOX_WORDS * t.rank], (uint32_t)x);
     team_sync(t);
-    return __syncthreads_or(((int)threadIdx.x < t.size) ? (int)(box_get(&box[PDP_BOX_WORDS * threadIdx.x]) != 0u) : 0);
+    int theirs = 0;
+    for (int r = (int)threadIdx.x; r < t.size; r += (int)blockDim.x) theirs |= (int)(box_get(&box[PDP_BOX_WORDS * r]) != 0u);
+    return __syncthreads_or(theirs);
 }
 template <class B> __device__ __forceinline__ ArgPair team_argmax(const Teamed<B> &t, float v, int i, float *sv, int *si)
 {
@@ -423,7 +427,10 @@ template <class B> __device__ __forceinline__ ArgPair team_argmax(const Teamed<B
     if (threadIdx.x == 0) { box_put(&box[PDP_BOX_WORDS * t.rank], __float_as_uint(r.v)); box_put(&box[PDP_BOX_WORDS * t.rank + 1], (uint32_t)r.i); }
     team_sync(t);
     float ov = 0.0f; int oi = -1;
-    if ((int)threadIdx.x < t.size) { ov = __uint_as_float(box_get(&box[PDP_BOX_WORDS * threadIdx.x])); oi = (int)box_get(&box[PDP_BOX_WORDS * threadIdx.x + 1]); }
+    for (int r = (int)threadIdx.x; r < t.size; r += (int)blockDim.x) {
+        const float rv = __uint_as_float(box_get(&box[PDP_BOX_WORDS * r])); const int ri = (int)box_get(&box[PDP_BOX_WORDS * r + 1]);
+        if (arg_better(rv, ri, ov, oi)) { ov = rv; oi = ri; }
+    }
     return block_argmax(ov, oi, sv, si);
 }
 // Places this workgroup in its team (launch numbering: slot-minor over `slots`) and makes the first barrier: with full agent-scope

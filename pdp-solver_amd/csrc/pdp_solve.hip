@@ -183,10 +183,10 @@ __device__ __forceinline__ IterRed team_iter_reduce(const Teamed<B> &t, IterRed 
     }
     team_sync(t);
     IterRed y; y.a = -PDP_INF; y.b = -PDP_INF; y.mna = PDP_INF; y.mnb = PDP_INF; y.bits = 0;
-    if ((int)threadIdx.x < t.size) {
-        const uint32_t *w = &box[PDP_BOX_WORDS * threadIdx.x];
-        y.a = __uint_as_float(box_get(&w[0])); y.b = __uint_as_float(box_get(&w[1])); y.bits = (int)box_get(&w[2]);
-        if (with_min) { y.mna = __uint_as_float(box_get(&w[3])); y.mnb = __uint_as_float(box_get(&w[4])); }
+    for (int r = (int)threadIdx.x; r < t.size; r += (int)blockDim.x) {
+        const uint32_t *w = &box[PDP_BOX_WORDS * r];
+        y.a = pdp_max(y.a, __uint_as_float(box_get(&w[0]))); y.b = pdp_max(y.b, __uint_as_float(box_get(&w[1]))); y.bits |= (int)box_get(&w[2]);
+        if (with_min) { y.mna = OpMinLess()(y.mna, __uint_as_float(box_get(&w[3]))); y.mnb = OpMinLess()(y.mnb, __uint_as_float(box_get(&w[4]))); }
     }
     return block_iter_reduce(y, with_min, red5);
 }
@@ -246,7 +246,7 @@ template <int NT, bool TEAM, bool LOCK = false>
 __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
 {
     static_assert(!(TEAM && LOCK), "lock-step batches give every instance one workgroup");
-    __shared__ uint32_t lock_w[LOCK ? 256 : 1];
+    __shared__ uint32_t lock_w[LOCK ? PDP_LOCK_MAX : 1];
     // (only per-wave reduction scratch in LDS: the instance's state is in HBM)
     __shared__ float redf[NT / PDP_WAVE];
     __shared__ int redi[NT / PDP_WAVE];
@@ -626,12 +626,12 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
             uint32_t *box = team_box(BT);
             if (threadIdx.x == 0) box_put(&box[PDP_BOX_WORDS * BT.rank], ((sp.check_termination && nsat == m) ? 1u : 0u) | (active ? 2u : 0u));
             team_sync(BT);
-            if ((int)threadIdx.x < BT.size) lock_w[threadIdx.x] = box_get(&box[PDP_BOX_WORDS * threadIdx.x]);
+            for (int r = (int)threadIdx.x; r < BT.size; r += (int)blockDim.x) lock_w[r] = box_get(&box[PDP_BOX_WORDS * r]);
             __syncthreads();
             auto group_solved = [&](int b) { int s_ = 0; for (int r = 0; r < pv.R; ++r) s_ |= (int)(lock_w[b % pv.B0 + r * pv.B0] & 1u); return s_; };
             if (pv.R > 1 && sp.check_termination && active && group_solved(G.b)) active = 0;
             int still = 0;
-            if ((int)threadIdx.x < BT.size) still = ((lock_w[threadIdx.x] & 2u) && !(pv.R > 1 && sp.check_termination && group_solved((int)threadIdx.x))) ? 1 : 0;
+            for (int r = (int)threadIdx.x; r < BT.size; r += (int)blockDim.x) still |= ((lock_w[r] & 2u) && !(pv.R > 1 && sp.check_termination && group_solved(r))) ? 1 : 0;
             any_active = __syncthreads_or(still);
             if (was_active && !active) frozen();
         }
@@ -2183,14 +2183,18 @@ static int hbm_workspaces(pdp_problem *p, SolveParams &sp)
     return PDP_OK;
 }
 
-// Lock-step solve of a small batch (k_sp_solve<256, false, true>): exact reference semantics without speculation -- what the batch takes when
+// Lock-step solve of a small batch -- up to 1 024 instances -- (k_sp_solve<256, false, true>): exact reference semantics without speculation -- what the batch takes when
 // the speculation failed (no instance supplied the exact zero: batches of a few instances), and what replicated batches with non-identical
 // replicas take (random initial state: the replicas couple through the termination rule).  One launch, no snapshot.
 static bool lockstep_possible(const pdp_problem *p, const pdp_solve_args *a)
 {
     if (a->isolate_instances || getenv("PDP_SOLVE_NO_LOCKSTEP")) return false;
     if (a->model == PDP_MODEL_REINFORCE && p->R > 1) return false;      // (Reinforce with batch replication: step-wise)
-    return p->B <= pdp_device_cus() && p->B <= 256 && p->max_e <= 65536;     // every workgroup resident at once; an instance is one workgroup's work
+    // every workgroup must be resident at once (they wait for each other): what the device holds of this kernel, and the mailbox capacity
+    static int per_cu = 0;
+    if (!per_cu) { int v = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, (const void *)k_sp_solve<256, false, true>, 256, 0) == hipSuccess && v > 0) per_cu = v; else per_cu = 1; }
+    const long resident = (long)pdp_device_cus() * (per_cu < 4 ? per_cu : 4);
+    return p->B <= resident && p->B <= PDP_LOCK_MAX && p->max_e <= 65536;     // (an instance is one workgroup's work)
 }
 static int sp_solve_lockstep(pdp_problem *p, pdp_solve_args *a, hipStream_t st)
 {
@@ -2236,6 +2240,7 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
                       "for the lock-step launch; run the batch step-wise");
         return PDP_ERR_SPECULATION;
     }
+    if (getenv("PDP_SOLVE_FORCE_LOCKSTEP") && a->iterations > 0 && lockstep_possible(p, a)) return sp_solve_lockstep(p, a, ST(stream));      // (tests)
     const int rc = sp_solve_speculative(p, a, stream);
     if (rc == PDP_ERR_SPECULATION && lockstep_possible(p, a)) return sp_solve_lockstep(p, a, ST(stream));      // (every array is back at its call-entry state)
     return rc;
