@@ -113,6 +113,7 @@ struct pdp_problem {
     char *solve_blob; size_t solve_blob_bytes;
     uint32_t *solve_host; size_t solve_host_words;   // pinned
     float *solve_extra_v;
+    float *solve_rec;           // [E][4] per-edge records of the HBM-resident solver
     // LDS-resident solver: private instance records (pdp_solve.hip, BlobLayout) and device-side control blocks
     int64_t *res_stat_off;                           // [2B] static | dynamic record offsets
     char *res_stat; size_t res_stat_bytes; int res_static_built;

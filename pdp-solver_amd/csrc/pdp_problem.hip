@@ -313,6 +313,7 @@ extern "C" int pdp_problem_destroy(pdp_problem *p)
     if (p->solve_blob) pdp_dev_free(p->solve_blob);
     if (p->solve_host) (void)hipHostFree(p->solve_host);
     if (p->solve_extra_v) pdp_dev_free(p->solve_extra_v);
+    if (p->solve_rec) pdp_dev_free(p->solve_rec);
     void *res[] = {p->res_stat_off, p->res_stat, p->res_dyn[0], p->res_dyn[1], p->res_prev_slots, p->res_ctl, p->res_fit_list, p->res_big_list, p->res_is_big, p->res_big_snap};
     for (void *q : res) if (q) pdp_dev_free(q);
     if (p->team_ws) pdp_dev_free(p->team_ws);

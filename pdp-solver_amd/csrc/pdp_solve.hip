@@ -60,6 +60,7 @@ struct SolveParams {
     uint32_t *spec_used;        // [T] bits: some instance evaluated the site
     // HBM-mode scratch
     float *ws_e[4]; float *ws_f; float *ws_v[7]; int32_t *ws_vi[3]; uint8_t *ws_fu[2];
+    float *ws_r;                // [E][4] per-edge record of the sweep: survey | exp(30 d) | d | sign * (1: edge mask on, 2: off)
     // LDS-resident kernel: private instance records (see BlobLayout) and device-side control
     int chunk_start;            // iterations completed before this launch
     struct SolveCtl *ctl;       // this chunk's control block
@@ -291,6 +292,13 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
 
     SimplifyScratch ss;
     ss.assign = I.assign; ss.deg = I.deg; ss.sdeg = I.sdeg; ss.flag_v = I.flag_v; ss.flag_f = I.flag_f; ss.flag_f2 = I.flag_f2; ss.red = redi;
+    // Per-edge record.  The variable rows reach their edges through the by-variable CSR -- random 4-byte gathers, a 64-byte line each: eight of
+    // them per edge and sweep were what a huge instance waited for (n = 1 000 000: rows 0.88 + maxima 0.73 of 2.16 ms).  Everything a row needs
+    // from an edge sits in one 16-byte record, written contiguously by the per-edge passes: one gather in P2, one in P4.
+    float4 *const R = reinterpret_cast<float4 *>(sp.ws_r) + G.e0;
+    for (int e = tid; e < ne; e += nt)
+        R[e] = make_float4(gfs[2 * e], 1.0f, 0.0f, (float)G.sgn[e] * ((!sp.has_edge_mask || G.emask[e] == 1.0f) ? 1.0f : 2.0f));
+    team_sync(I);
 
     int active = sp.amask[G.b] ? 1 : 0;
     int has_prev = sp.has_prev;
@@ -387,11 +395,10 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
                 const int k = k0 + rl;
                 float y = 0.0f; int sg = 0;
                 if (k < end) {
-                    const int e = I.v_edges[k];
-                    y = pdp_safe_log(1.0f - I.eta[e * I.estride], PDP_SP_EPS);
-                    if (use_em) y = y * I.emask[e];
-                    I.s1[e] = y;
-                    sg = I.sgn[e];
+                    const float4 r = R[I.v_edges[k]];
+                    y = pdp_safe_log(1.0f - r.x, PDP_SP_EPS);
+                    if (use_em) y = y * ((pdp_abs(r.w) == 1.0f) ? 1.0f : 0.0f);
+                    sg = (r.w > 0.0f) ? 1 : -1;
                 }
                 const int cntk = end - k0;
 #pragma unroll
@@ -417,7 +424,10 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
             const float agg = (0.0f + I.S[c]) - I.s0[e];
             const float eta_new = 1.0f * pdp_safe_exp(agg) + (1.0f - 1.0f) * eta_old;
             const float force = I.force[e * I.fstride];
-            const SpOut o = d_sp_edge(s, I.P[v], I.N[v], I.s1[e], force, L0h, L1h);
+            float y = pdp_safe_log(1.0f - eta_old, PDP_SP_EPS);          // the edge's term of its variable row (P2 computed the same value from the record)
+            if (use_em) y = y * I.emask[e];
+            I.s1[e] = y;                                                  // (the write-back rebuilds q_s / q_dc of the last sweep from it)
+            const SpOut o = d_sp_edge(s, I.P[v], I.N[v], y, force, L0h, L1h);
             const float qu_old = I.qu[e * I.qstride];
             const float qu_new = 1.0f * o.qu + (1.0f - 1.0f) * qu_old;
             // only a NaN SURVEY poisons the batch-global reductions of this iteration; a NaN in q (0/0) reaches the
@@ -431,9 +441,9 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
             }
             I.qu[e * I.qstride] = qu_new;
             I.eta[e * I.estride] = eta_new;
-            I.s0[e] = pdp_safe_exp(30.0f * eta_new);      // smooth-max weight of the survey
-            I.s2[e] = d;
-            I.s3[e] = pdp_safe_exp(30.0f * d);            // smooth-max weight of the difference
+            // (the smooth-max weight of the survey, exp(30 eta), is taken by P4 from the record's survey)
+            float *rec = reinterpret_cast<float *>(&R[e]);
+            rec[0] = eta_new; rec[1] = pdp_safe_exp(30.0f * d); rec[2] = d;      // smooth-max weight of the difference, the difference
         }
         did_prop = 1;
         TP(2)
@@ -448,9 +458,9 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
                 const int k = k0 + rl;
                 float c1 = 0.0f, p1 = 0.0f, c2 = 0.0f, p2 = 0.0f;
                 if (k < end) {
-                    const int e = I.v_edges[k];
-                    c1 = I.s0[e]; p1 = I.eta[e * I.estride] * c1;
-                    if (has_prev) { c2 = I.s3[e]; p2 = I.s2[e] * c2; }
+                    const float4 r = R[I.v_edges[k]];
+                    c1 = pdp_safe_exp(30.0f * r.x); p1 = r.x * c1;
+                    if (has_prev) { c2 = r.y; p2 = r.z * c2; }
                 }
                 const int cntk = end - k0;
 #pragma unroll
@@ -612,6 +622,7 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
                 const float a = 0.0f + I.av[I.e_var[e]];
                 const float b = 0.0f + I.af[I.e_fn[e]];
                 I.emask[e] = a * b;
+                reinterpret_cast<float *>(&R[e])[3] = (float)I.sgn[e] * ((a * b == 1.0f) ? 1.0f : 2.0f);
             }
             use_em = 1;
             team_sync(I);
@@ -1952,6 +1963,21 @@ static int resident_prepare(pdp_problem *p)
     return PDP_OK;
 }
 
+// workspaces of the HBM-resident kernel (shared by the host-driven loop, the exact single-instance launch and the lock-step launch)
+static int hbm_workspaces(pdp_problem *p, SolveParams &sp)
+{
+    for (int i = 0; i < 4; ++i) sp.ws_e[i] = p->ws_e[i];
+    sp.ws_f = p->ws_f[0];
+    for (int i = 0; i < 6; ++i) sp.ws_v[i] = p->ws_v[i];
+    if (!p->solve_extra_v) { int st_ = pdp_dev_alloc((void **)&p->solve_extra_v, sizeof(float) * (size_t)p->V); if (st_ != PDP_OK) return st_; }
+    sp.ws_v[6] = p->solve_extra_v;
+    for (int i = 0; i < 3; ++i) sp.ws_vi[i] = p->ws_vi[i];
+    sp.ws_fu[0] = p->ws_fu[0]; sp.ws_fu[1] = p->ws_fu[1];
+    if (!p->solve_rec) { int st_ = pdp_dev_alloc((void **)&p->solve_rec, sizeof(float) * 4 * ((size_t)p->E + 4)); if (st_ != PDP_OK) return st_; }
+    sp.ws_r = p->solve_rec;
+    return PDP_OK;
+}
+
 // LDS-resident path: every launch of the call is enqueued up front (import, then per chunk: pass 1, poison decision, replay
 // list, replay, speculation check); the host reads one control block at the end.
 static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, bool force, size_t lds, int nt_lds, int C)
@@ -2045,13 +2071,7 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     // the state they enter a chunk with is saved for the NaN-poison replay
     BigSnap big_live, big_snap;
     if (nbig) {
-        for (int i = 0; i < 4; ++i) sp.ws_e[i] = p->ws_e[i];
-        sp.ws_f = p->ws_f[0];
-        for (int i = 0; i < 6; ++i) sp.ws_v[i] = p->ws_v[i];
-        if (!p->solve_extra_v) { int st_ = pdp_dev_alloc((void **)&p->solve_extra_v, sizeof(float) * V); if (st_ != PDP_OK) return st_; }
-        sp.ws_v[6] = p->solve_extra_v;
-        for (int i = 0; i < 3; ++i) sp.ws_vi[i] = p->ws_vi[i];
-        sp.ws_fu[0] = p->ws_fu[0]; sp.ws_fu[1] = p->ws_fu[1];
+        { const int st_ = hbm_workspaces(p, sp); if (st_ != PDP_OK) return st_; }
         sp.big_list = p->res_big_list; sp.hbm_device_ctl = 1;
         status = ensure_bytes(&p->res_big_snap, &p->res_big_snap_bytes, snap_bytes + 64);
         if (status != PDP_OK) return status;
@@ -2167,19 +2187,6 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     a->decimator->has_prev = 1;
     p->has_edge_mask = 1;
     a->iterations_run_host = (int)hcall->total_iters;
-    return PDP_OK;
-}
-
-// workspaces of the HBM-resident kernel (shared by the host-driven loop, the exact single-instance launch and the lock-step launch)
-static int hbm_workspaces(pdp_problem *p, SolveParams &sp)
-{
-    for (int i = 0; i < 4; ++i) sp.ws_e[i] = p->ws_e[i];
-    sp.ws_f = p->ws_f[0];
-    for (int i = 0; i < 6; ++i) sp.ws_v[i] = p->ws_v[i];
-    if (!p->solve_extra_v) { int st_ = pdp_dev_alloc((void **)&p->solve_extra_v, sizeof(float) * (size_t)p->V); if (st_ != PDP_OK) return st_; }
-    sp.ws_v[6] = p->solve_extra_v;
-    for (int i = 0; i < 3; ++i) sp.ws_vi[i] = p->ws_vi[i];
-    sp.ws_fu[0] = p->ws_fu[0]; sp.ws_fu[1] = p->ws_fu[1];
     return PDP_OK;
 }
 
@@ -2347,16 +2354,8 @@ static int sp_solve_speculative(pdp_problem *p, pdp_solve_args *a, void *stream)
     const bool fits = false;
     const size_t lds = 0;
     float *extra_v = nullptr;
-    {
-        for (int i = 0; i < 4; ++i) sp.ws_e[i] = p->ws_e[i];
-        sp.ws_f = p->ws_f[0];
-        for (int i = 0; i < 6; ++i) sp.ws_v[i] = p->ws_v[i];
-        if (!p->solve_extra_v) { int st_ = pdp_dev_alloc((void **)&p->solve_extra_v, sizeof(float) * V); if (st_ != PDP_OK) return st_; }
-        extra_v = p->solve_extra_v;
-        sp.ws_v[6] = extra_v;
-        for (int i = 0; i < 3; ++i) sp.ws_vi[i] = p->ws_vi[i];
-        sp.ws_fu[0] = p->ws_fu[0]; sp.ws_fu[1] = p->ws_fu[1];
-    }
+    { const int st_ = hbm_workspaces(p, sp); if (st_ != PDP_OK) return st_; }
+    extra_v = p->solve_extra_v;
     if (exact) {
         sp.exact = 1; sp.T = T; sp.has_prev = a->decimator->has_prev; sp.has_edge_mask = p->has_edge_mask; sp.final_chunk = 1; sp.poison_from = 0x7fffffff;
         PDP_HIP_CHECK(hipMemsetAsync(ctl, 0xff, sizeof(uint32_t), st));
