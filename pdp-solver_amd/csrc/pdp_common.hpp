@@ -439,6 +439,7 @@ template <class B> __device__ __forceinline__ ArgPair team_argmax(const Teamed<B
 // padding workgroup (one-XCD teams pad the slot count to the XCD count so that a team's workgroups share an XCD).
 struct TeamLaunch { int size, count, slots, no_xcd; uint32_t *ws; };
 struct pdp_problem;
+int pdp_simplify_lds(pdp_problem *p, hipStream_t st);      // pdp_solve.hip: simplify() with the instances in LDS; 0 if the batch does not qualify
 int pdp_device_cus();                         // CUs of the current device (workgroups that are certainly resident together)
 int pdp_edge_rows(const pdp_problem *p);     // workgroups per instance of the flat per-edge kernels (gridDim.y): 1 unless an instance is big
 int pdp_team_plan(pdp_problem *p, int count, bool wide, int threads, TeamLaunch *out, hipStream_t st);

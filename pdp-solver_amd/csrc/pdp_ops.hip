@@ -78,6 +78,7 @@ static int simplify_plan(pdp_problem *p, TeamLaunch *tl, hipStream_t st)
 extern "C" int pdp_simplify(pdp_problem *p, void *stream)
 {
     PDP_REQUIRE(p && p->av, "problem state is not bound");
+    if (pdp_simplify_lds(p, ST(stream))) { PDP_LAUNCH_CHECK(); return PDP_OK; }       // every instance fits the LDS: the same routines, LDS-resident
     TeamLaunch tl;
     { const int st_ = simplify_plan(p, &tl, ST(stream)); if (st_ != PDP_OK) return st_; }
     if (tl.size > 1)

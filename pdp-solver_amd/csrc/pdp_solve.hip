@@ -1843,6 +1843,61 @@ __global__ void k_any_force(const float *fs, int64_t E, uint32_t *flag)
     if (__syncthreads_or(any) && threadIdx.x == 0) atomicOr(flag, 1u);
 }
 
+// ---- simplify() of a batch whose instances fit the LDS ----------------------------------------------------------------------------------
+// pdp_simplify's per-instance kernel walks the HBM-resident arrays: a few latency-bound passes of dependent gathers per instance (252 us
+// on the headline batch, a fiftieth of a 100-sweep solve).  Here the workgroup first copies the instance's topology into LDS in the
+// variable-major slot form of the persistent solver (packed 16-bit words) and runs the SAME routines (d_simplify on an LView) there.
+static size_t simplify_lds_bytes(int n, int m, int e)
+{
+    auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    return 3 * a16((size_t)e * 2) + a16((size_t)(n + 1) * 2) + a16((size_t)(m + 1) * 2) + 3 * a16((size_t)n * 4) + a16((size_t)m * 4) + 2 * a16((size_t)n * 4) +
+           a16((size_t)n) + 2 * a16((size_t)m);
+}
+__global__ void __launch_bounds__(256) k_simplify_lds(PView pv)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int redi[PDP_RED_SMALL];
+    const Inst G = load_inst(pv, blockIdx.x);
+    const int n = G.n, m = G.m, ne = G.e, tid = threadIdx.x, nt = blockDim.x;
+    unsigned char *cp = smem;
+    uint16_t *pvv = carve<uint16_t>(cp, ne), *pcc = carve<uint16_t>(cp, ne), *e2p = carve<uint16_t>(cp, ne);
+    uint16_t *v_ptr = carve<uint16_t>(cp, n + 1), *f_ptr = carve<uint16_t>(cp, m + 1);
+    float *av = carve<float>(cp, n), *sol = carve<float>(cp, n), *assign = carve<float>(cp, n), *af = carve<float>(cp, m);
+    int32_t *deg = carve<int32_t>(cp, n), *sdeg = carve<int32_t>(cp, n);
+    uint8_t *flag_v = carve<uint8_t>(cp, n), *flag_f = carve<uint8_t>(cp, m), *flag_f2 = carve<uint8_t>(cp, m);
+    for (int p = tid; p < ne; p += nt) {
+        const int e = G.v_edges[p];
+        pvv[p] = (uint16_t)(G.e_var[e] | (G.sgn[e] < 0 ? 0x8000 : 0));
+        pcc[p] = (uint16_t)G.e_fn[e];
+        e2p[e] = (uint16_t)p;                           // edges are clause-major: edge id == position in the by-clause list
+    }
+    for (int v = tid; v <= n; v += nt) v_ptr[v] = (uint16_t)G.v_ptr[v];
+    for (int c = tid; c <= m; c += nt) f_ptr[c] = (uint16_t)G.f_ptr[c];
+    for (int v = tid; v < n; v += nt) { av[v] = G.av[v]; sol[v] = G.sol[v]; }
+    for (int c = tid; c < m; c += nt) af[c] = G.af[c];
+    __syncthreads();
+    LView I;
+    I.b = G.b; I.n = n; I.m = m; I.e = ne;
+    I.e_var.pv = pvv; I.e_var.mask = 0x3fff; I.e_fn.pc = pcc; I.sgn.pv = pvv; I.f_edges = e2p; I.v_ptr = v_ptr; I.f_ptr = f_ptr;
+    I.av = av; I.af = af; I.sol = sol;
+    SimplifyScratch ss;
+    ss.assign = assign; ss.deg = deg; ss.sdeg = sdeg; ss.flag_v = flag_v; ss.flag_f = flag_f; ss.flag_f2 = flag_f2; ss.red = redi;
+    d_simplify(I, ss, pv.is_sat + G.b);
+    for (int v = tid; v < n; v += nt) { G.av[v] = av[v]; G.sol[v] = sol[v]; }
+    for (int c = tid; c < m; c += nt) G.af[c] = af[c];
+}
+
+// returns 1 if the LDS-resident form took the batch
+int pdp_simplify_lds(pdp_problem *p, hipStream_t st)
+{
+    if (!p->fn_edges_identity || p->max_n >= 16384 || p->max_m >= 16384 || p->max_e >= 65536 || getenv("PDP_SIMPLIFY_HBM")) return 0;
+    const size_t lds = simplify_lds_bytes(p->max_n, p->max_m, p->max_e);
+    if (lds > 64 * 1024) return 0;
+    if (hipFuncSetAttribute((const void *)k_simplify_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0;
+    hipLaunchKernelGGL(k_simplify_lds, dim3(p->B), dim3(256), lds, st, make_view(p));
+    return 1;
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------
 struct SolveSnapshot {
     float *q, *fs, *av, *af, *sol, *sat, *emask, *prev, *cnt; uint8_t *amask;
