@@ -40,10 +40,8 @@ PDP_HD uint32_t pdp_f2bits(float f) { pdp_f32_bits c; c.f = f; return c.u; }
 /* torch.max / torch.min (elementwise, NaN-propagating) */
 PDP_HD float pdp_max(float a, float b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
 PDP_HD float pdp_min(float a, float b) { return (a != a) ? a : ((b != b) ? b : (a < b ? a : b)); }
-/* torch.sign: sign(NaN) == 0 */
+/* torch.sign: sign(NaN) == 0 (also for the Reinforce force of a NaN score, pdp_decimate.py:230: pinned by trace_reinforce_nan_leak) */
 PDP_HD float pdp_sign(float x) { return (float)((x > 0.0f) - (x < 0.0f)); }
-/* torch.sign keeps a NaN (the Reinforce force of a NaN score, pdp_decimate.py:230) */
-PDP_HD float pdp_sign_nan(float x) { return (x != x) ? x : pdp_sign(x); }
 PDP_HD float pdp_abs(float x) { return pdp_bits2f(pdp_f2bits(x) & 0x7fffffffu); }
 
 /* 2^n for -126 <= n <= 127 */

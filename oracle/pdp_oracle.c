@@ -707,7 +707,7 @@ ORC_API void orc_reinforce_decimate(orc_problem *p, orc_decimator_state *d, floa
         for (int e = 0; e < E; ++e) {
             const int v = p->edge_var[e];
             const float mask = active_mask ? (0.0f + (0.0f + (float)active_mask[p->var_inst[v]])) : 1.0f;
-            const float sc = 0.0f + pdp_sign_nan(score[v]);
+            const float sc = 0.0f + pdp_sign(score[v]);                  /* torch.sign(NaN) is 0 (pinned by trace_reinforce_nan_leak) */
             fs[2 * e + 1] = mask * sc + (1.0f - mask) * fs[2 * e + 1];
         }
         free(score);

@@ -243,6 +243,7 @@ __device__ __forceinline__ T block_reduce(T v, Op op, T identity, T *scratch)
     return r;
 }
 
+__device__ __forceinline__ bool pdp_finite(float x) { return (x - x) == 0.0f; }      // neither NaN nor +-inf
 struct OpMaxNan { __device__ float operator()(float a, float b) const { return pdp_max(a, b); } };
 struct OpMinNan { __device__ float operator()(float a, float b) const { return pdp_min(a, b); } };
 struct OpAddI { __device__ int operator()(int a, int b) const { return a + b; } };

@@ -744,7 +744,7 @@ __global__ void __launch_bounds__(PDP_NT) k_reinforce_force(PView pv, float *fs,
     d_survey_score(I, fs, pi, fm + I.e0, score);
     const float mask = amask ? (0.0f + (0.0f + (float)amask[I.b])) : 1.0f;
     for (int e = threadIdx.x; e < I.e; e += blockDim.x) {
-        const float sc = 0.0f + pdp_sign_nan(score[I.e_var[e]]);
+        const float sc = 0.0f + pdp_sign(score[I.e_var[e]]);       // torch.sign(NaN) is 0
         fs[2 * e + 1] = mask * sc + (1.0f - mask) * fs[2 * e + 1];
     }
 }

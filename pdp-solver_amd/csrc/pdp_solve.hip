@@ -89,6 +89,7 @@ struct SolveParams {
     int rf;                     // HBM-resident kernel: the Reinforce triple (coins, dprob as for the LDS-resident kernel; tol = the gate's 0.01)
     int isolate;                // HBM-resident kernel: isolated instances (a NaN stays inside its instance, pass 1 is final)
     int lds_tickets;            // LDS-resident kernel, pass 1: 0 = instance blockIdx.x, else the number of instances the workgroups draw tickets for
+    uint8_t *ghost_flag;        // LDS-resident kernel: [B] instances that left inactive with iterations to come (checked by k_ghost_check after the call)
     uint32_t *team_ws;          // [team_count][PDP_TEAM_WORDS], zeroed before every launch
 };
 
@@ -222,7 +223,7 @@ __device__ int hbm_reinforce_step(const V &I, float *fs /*[e][2]*/, float pi, in
             }
             const float sc = d_score_from_sums(pos, neg, all, ext, pi);
             if (sc != sc) bad = 1;
-            const float sg = 0.0f + pdp_sign_nan(sc);
+            const float sg = 0.0f + pdp_sign(sc);                   // torch.sign(NaN) is 0
             // mask * sign + (1 - mask) * old with mask == 1 (the instance is active, old is finite)
             for (int k = a; k < bnd; ++k) { const int e = I.v_edges[k]; I.s2[e] = fs[2 * e + 1]; fs[2 * e + 1] = sg; }
         }
@@ -233,6 +234,76 @@ __device__ int hbm_reinforce_step(const V &I, float *fs /*[e][2]*/, float pi, in
         if (av == 1.0f) I.sol[v] = av * pred + (1.0f - av) * I.sol[v];      // only active variables take the prediction (solver.py:395-397)
     }
     return team_any(I, bad);
+}
+
+// Ghost sweep of an inactive instance on an HBM-resident view: would its next sweep, or the scorer on its frozen surveys, produce a
+// non-finite value?  (k_sp_solve explains why that matters.)  Clobbers s0, s3, S, score, coeff.  Team-aware.
+template <class V>
+__device__ int d_ghost_bad(const V &I, float pi, float L0h, float L1h, bool use_em, bool check_score)
+{
+    const int tid = team_tid(I), nt = team_nt(I), n = I.n, m = I.m, ne = I.e;
+        int bad = 0;
+        for (int c = tid; c < m; c += nt) {
+            float acc = 0.0f;
+            for (int k = I.f_ptr[c]; k < I.f_ptr[c + 1]; ++k) {
+                const int e = I.f_edges[k];
+                float x = pdp_safe_log(I.qu[e * I.qstride], PDP_SP_EPS);
+                if (use_em) x = x * I.emask[e];
+                I.s0[e] = x; acc = acc + x;
+            }
+            I.S[c] = acc;
+        }
+        for (int v = tid; v < n; v += nt) {
+            float P = 0.0f, N = 0.0f;
+            for (int k = I.v_ptr[v]; k < I.v_ptr[v + 1]; ++k) {
+                const int e = I.v_edges[k];
+                float y = pdp_safe_log(1.0f - I.eta[e * I.estride], PDP_SP_EPS);
+                if (use_em) y = y * I.emask[e];
+                I.s3[e] = y;
+                const int sg = I.sgn[e];
+                P = P + ((sg == 1) ? 1.0f : 0.0f) * y;
+                N = N + ((sg == -1) ? 1.0f : 0.0f) * y;
+            }
+            I.score[v] = P; I.coeff[v] = N;
+        }
+        team_sync(I);
+        for (int e = tid; e < ne; e += nt) {
+            const float agg = (0.0f + I.S[I.e_fn[e]]) - I.s0[e];
+            const float eta_new = pdp_safe_exp(agg);
+            const int v = I.e_var[e];
+            const SpOut o = d_sp_edge((float)I.sgn[e], I.score[v], I.coeff[v], I.s3[e], I.force[e * I.fstride], L0h, L1h);
+            if (!pdp_finite(eta_new) || !pdp_finite(o.qu) || !pdp_finite(o.qs) || !pdp_finite(o.dc)) {
+                bad = 1;
+#ifdef PDP_PHASE_PROF
+                printf("[ghost] inst %d edge %d: eta_new %g qu %g qs %g dc %g | P %g N %g y %g S %g x %g eta %g q_u %g\n", I.b, e, eta_new, o.qu, o.qs, o.dc, I.score[v], I.coeff[v], I.s3[e],
+                       I.S[I.e_fn[e]], I.s0[e], I.eta[e * I.estride], I.qu[e * I.qstride]);
+#endif
+            }
+        }
+        team_sync(I);
+        for (int e = tid; e < ne; e += nt)
+            I.s3[e] = pdp_safe_log(1.0f - I.eta[e * I.estride], PDP_SCORER_EPS) * (0.0f + I.af[I.e_fn[e]]);
+        team_sync(I);
+        for (int v = tid; v < n; v += nt) {
+            float ext = 0.0f, pos = 0.0f, neg = 0.0f, all = 0.0f;
+            for (int k = I.v_ptr[v]; k < I.v_ptr[v + 1]; ++k) {
+                const int e = I.v_edges[k];
+                const int sg = I.sgn[e];
+                const float f = I.s3[e];
+                ext = ext + I.force[e * I.fstride];
+                pos = pos + ((sg == 1) ? 1.0f : 0.0f) * f;
+                neg = neg + ((sg == -1) ? 1.0f : 0.0f) * f;
+                all = all + f;
+            }
+            const float sc = d_score_from_sums(pos, neg, all, ext, pi);
+            if (check_score && sc != sc) {
+                bad = 1;
+#ifdef PDP_PHASE_PROF
+                printf("[ghost] inst %d var %d: score NaN (pos %g neg %g all %g ext %g)\n", I.b, v, pos, neg, all, ext);
+#endif
+            }
+        }
+        return team_any(I, bad);
 }
 
 // HBM-resident form of the solver: the instance's arrays stay where the problem keeps them, one workgroup (TEAM = false) or a
@@ -347,6 +418,15 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
         }
         fz_mnc = block_reduce(mn, OpMinLess(), PDP_INF, redf);
     };
+    // An INACTIVE instance is not swept here, but the reference still computes its next messages in every iteration and blends them away
+    // with the active mask: mask * new + (1 - mask) * old (pdp_propagate.py:219-221, pdp_decimate.py:230).  0 * new is NaN when `new` is not
+    // finite (0/0 in the normalisation of a saturated instance), so such an instance's messages DO change -- and poison the batch.  The
+    // frozen state is a fixed point of that computation unless its first "ghost" sweep yields a non-finite value, so the instance checks
+    // exactly that once, when it goes inactive with iterations still to come: the would-be next sweep and the scorer (whose NaN reaches the
+    // force column of Reinforce and the coefficient sum of the sequential decimator).  A hit fails the call over to the strict step-wise
+    // loop, which evaluates the blends literally.
+    // (scorer: a NaN score reaches the sequential decimator's coefficient sum; Reinforce takes torch.sign of it, which is 0 for a NaN)
+    auto ghost_bad = [&]() -> int { return d_ghost_bad(I, sp.pi, L0h, L1h, use_em != 0, !rf); };
     if constexpr (LOCK) {
         BT.rank = (int)blockIdx.x; BT.size = (int)gridDim.x; BT.epoch = 0; BT.same_xcd = 2; BT.bar = sp.team_ws; BT.box = BT.bar + 32;
         if (!active) frozen();
@@ -644,7 +724,7 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
             int still = 0;
             for (int r = (int)threadIdx.x; r < BT.size; r += (int)blockDim.x) still |= ((lock_w[r] & 2u) && !(pv.R > 1 && sp.check_termination && group_solved(r))) ? 1 : 0;
             any_active = __syncthreads_or(still);
-            if (was_active && !active) frozen();
+            if (was_active && !active) { frozen(); if (t + 1 < sp.T && any_active && !sp.isolate && ghost_bad()) violation = 1; }
         }
         has_prev = 1; prev_from_global = 0;
         TP(6)
@@ -655,6 +735,7 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
 #endif
 #undef TP
 
+    if (!LOCK && !active && did_prop && !sp.isolate && !(sp.final_chunk && iters >= sp.T)) { if (ghost_bad()) violation = 1; }
     // ---- write back -------------------------------------------------------------------------------------------
     if (did_prop) {
         // q_s / q_dc of the last sweep are recomputed from the per-variable sums that are still resident
@@ -1131,7 +1212,7 @@ __device__ __noinline__ int lds_reinforce_step(unsigned char *smem, int n, int m
             }
             const float sc = lds_score_of(pos, neg, all, ext, Lpi, L0);
             if (sc != sc) bad = 1;
-            const float sg = 0.0f + pdp_sign_nan(sc);
+            const float sg = 0.0f + pdp_sign(sc);                   // torch.sign(NaN) is 0
             const uint16_t code = (uint16_t)(frc_enc(sg) << PV_FRC_SHIFT);
             // mask * sign + (1 - mask) * old with mask == 1 (old is finite here); X keeps the force the last sweep read
             for (int p = a; p < bnd; ++p) { const uint16_t pw = L.pvv[p]; L.X[p] = frc_of(pw); L.pvv[p] = (uint16_t)((pw & ~PV_FRC_MASK) | code); }
@@ -1698,6 +1779,8 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
         *reinterpret_cast<DynHeader *>(dout + BL.hdr) = h;
         const int gb = (LISTED || REPLAY) ? *(volatile int *)&s_inst : G.b;
         if (finishing) { sp.amask[gb] = (uint8_t)active; sp.counters[gb] = cnt; pv_.is_sat[gb] = s_is_sat; }
+        // left inactive with iterations still to come: k_ghost_check looks at its frozen state after the call (see d_ghost_bad)
+        if (finishing && !active && !(sp.final_chunk && iters >= T)) sp.ghost_flag[gb] = 1;
         if (any_inactive) atomicMin(&ctl->perm_zero, (uint32_t)iters);
         if (!REPLAY) sp.last_event[gb] = last_event;
         atomicMax(&ctl->iters_run, (uint32_t)iters);
@@ -1841,6 +1924,26 @@ __global__ void k_any_force(const float *fs, int64_t E, uint32_t *flag)
     int any = 0;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) any |= (fs[2 * e + 1] != 0.0f) ? 1 : 0;
     if (__syncthreads_or(any) && threadIdx.x == 0) atomicOr(flag, 1u);
+}
+
+// After a call of the LDS-resident loop: the instances that left inactive with iterations still to come (ghost_flag) are looked at in the
+// state they wrote back to the caller's arrays -- d_ghost_bad on the HBM-resident view.  A hit fails the call (the host restores the state).
+__global__ void __launch_bounds__(256) k_ghost_check(PView pv, SolveParams sp, const uint8_t *ghost_flag, SolveCall *call)
+{
+    if (!ghost_flag[blockIdx.x]) return;
+    const Inst G = load_inst(pv, blockIdx.x);
+    float *gq = sp.q + 3 * (size_t)G.e0, *gfs = sp.fs + 2 * (size_t)G.e0;
+    SView<int32_t> I;
+    I.b = G.b; I.n = G.n; I.m = G.m; I.e = G.e;
+    I.e_var = G.e_var; I.e_fn = G.e_fn; I.v_edges = G.v_edges; I.f_edges = G.f_edges; I.v_ptr = G.v_ptr; I.f_ptr = G.f_ptr;
+    I.sgn = G.sgn; I.av = G.av; I.af = G.af; I.sol = G.sol; I.emask = G.emask;
+    I.qu = gq; I.qstride = 3; I.eta = gfs; I.estride = 2; I.force = gfs + 1; I.fstride = 2;
+    I.s0 = sp.ws_e[0] + G.e0; I.s1 = sp.ws_e[1] + G.e0; I.s2 = sp.ws_e[2] + G.e0; I.s3 = sp.ws_e[3] + G.e0;
+    I.S = sp.ws_f + G.f0;
+    I.P = sp.ws_v[0] + G.v0; I.N = sp.ws_v[1] + G.v0; I.xv1 = sp.ws_v[2] + G.v0; I.xv2 = sp.ws_v[3] + G.v0;
+    I.score = sp.ws_v[4] + G.v0; I.coeff = sp.ws_v[5] + G.v0; I.assign = sp.ws_v[6] + G.v0;
+    const float L0h = pdp_safe_log(1.0f - sp.pi * 0.0f, PDP_SP_EPS), L1h = pdp_safe_log(1.0f - sp.pi * 1.0f, PDP_SP_EPS);
+    if (d_ghost_bad(I, sp.pi, L0h, L1h, true, !sp.rf) && threadIdx.x == 0) call->fail = 1;
 }
 
 // ---- simplify() of a batch whose instances fit the LDS ----------------------------------------------------------------------------------
@@ -2019,7 +2122,7 @@ static int resident_prepare(pdp_problem *p)
 }
 
 // workspaces of the HBM-resident kernel (shared by the host-driven loop, the exact single-instance launch and the lock-step launch)
-static int hbm_workspaces(pdp_problem *p, SolveParams &sp)
+static int hbm_workspaces(pdp_problem *p, SolveParams &sp, bool records = true)
 {
     for (int i = 0; i < 4; ++i) sp.ws_e[i] = p->ws_e[i];
     sp.ws_f = p->ws_f[0];
@@ -2028,8 +2131,10 @@ static int hbm_workspaces(pdp_problem *p, SolveParams &sp)
     sp.ws_v[6] = p->solve_extra_v;
     for (int i = 0; i < 3; ++i) sp.ws_vi[i] = p->ws_vi[i];
     sp.ws_fu[0] = p->ws_fu[0]; sp.ws_fu[1] = p->ws_fu[1];
-    if (!p->solve_rec) { int st_ = pdp_dev_alloc((void **)&p->solve_rec, sizeof(float) * 4 * ((size_t)p->E + 4)); if (st_ != PDP_OK) return st_; }
-    sp.ws_r = p->solve_rec;
+    if (records) {
+        if (!p->solve_rec) { int st_ = pdp_dev_alloc((void **)&p->solve_rec, sizeof(float) * 4 * ((size_t)p->E + 4)); if (st_ != PDP_OK) return st_; }
+        sp.ws_r = p->solve_rec;
+    }
     return PDP_OK;
 }
 
@@ -2044,7 +2149,8 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     const int64_t *stat_off = p->res_stat_off, *dyn_off = p->res_stat_off + B;
     // ---- control blocks, speculation record, replay list; call-entry snapshot for the failure path ---------------------------
     const size_t ctl_bytes = (size_t)nchunks * sizeof(SolveCtl) + sizeof(SolveCall) + 2 * (size_t)T * 4 + 2 * B * 4 + 64 +
-                             (rf ? 2 * (E + 4) * sizeof(float) : 0);            // Reinforce: two slot-major force columns
+                             (rf ? 2 * (E + 4) * sizeof(float) : 0) +          // Reinforce: two slot-major force columns
+                             ((B + 63) & ~(size_t)63);                          // ghost flags
     int status = ensure_bytes(&p->res_ctl, &p->res_ctl_bytes, ctl_bytes);
     if (status != PDP_OK) return status;
     SolveCtl *ctl = (SolveCtl *)p->res_ctl;
@@ -2119,6 +2225,10 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
         frc_buf[0] = (float *)(((uintptr_t)(replay_list + B) + 15) & ~(uintptr_t)15); frc_buf[1] = frc_buf[0] + E + 4;
         hipLaunchKernelGGL(k_force_import, dim3(p->B), dim3(256), 0, st, make_view(p), (const float *)a->fs, frc_buf[0], ctl);
     }
+    // ghost flags: behind the replay list (and the Reinforce force columns)
+    uint8_t *ghost_flag = rf ? (uint8_t *)(frc_buf[1] + E + 4) : (uint8_t *)(((uintptr_t)(replay_list + B) + 15) & ~(uintptr_t)15);
+    PDP_HIP_CHECK(hipMemsetAsync(ghost_flag, 0, B, st));
+    sp.ghost_flag = ghost_flag;
     sp.last_event = last_event; sp.inst_list = replay_list;
     sp.call = call; sp.stat = p->res_stat; sp.stat_off = stat_off; sp.dyn_off = dyn_off;
     sp.fit_list = fit_list;
@@ -2207,6 +2317,11 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
         PDP_LAUNCH_CHECK();
         done += c;
     }
+    if (!a->isolate_instances) {
+        // instances that left inactive with iterations to come: is their frozen state a fixed point of the reference's masked sweep?
+        if (!nbig) { const int st_ = hbm_workspaces(p, sp, false); if (st_ != PDP_OK) return st_; }
+        hipLaunchKernelGGL(k_ghost_check, dim3(p->B), dim3(256), 0, st, make_view(p), sp, (const uint8_t *)ghost_flag, call);
+    }
     PDP_HIP_CHECK(hipMemcpyAsync(p->solve_host, ctl, host_words * 4, hipMemcpyDeviceToHost, st));
     PDP_HIP_CHECK(hipStreamSynchronize(st));
     const SolveCtl *hctl = (const SolveCtl *)p->solve_host;
@@ -2260,6 +2375,19 @@ static bool lockstep_possible(const pdp_problem *p, const pdp_solve_args *a)
 }
 static int sp_solve_lockstep(pdp_problem *p, pdp_solve_args *a, hipStream_t st)
 {
+    // call-entry snapshot: the one thing the launch cannot do itself is the NaN blend of an inactive instance (ghost_bad in k_sp_solve)
+    const size_t E = p->E, V = p->V, F = p->F, B = p->B;
+    const size_t snap_floats = 3 * E + 2 * E + V + F + V + B + E + E + B;
+    const size_t snap_bytes = snap_floats * 4 + ((B + 63) & ~(size_t)63);
+    { const int st_ = ensure_bytes(&p->solve_blob, &p->solve_blob_bytes, snap_bytes + 64); if (st_ != PDP_OK) return st_; }
+    SolveSnapshot snap0;
+    {
+        float *f = (float *)p->solve_blob;
+        snap0.q = f; f += 3 * E; snap0.fs = f; f += 2 * E; snap0.av = f; f += V; snap0.af = f; f += F; snap0.sol = f; f += V;
+        snap0.sat = f; f += B; snap0.emask = f; f += E; snap0.prev = f; f += E; snap0.cnt = f; f += B; snap0.amask = (uint8_t *)f;
+    }
+    const int had_prev0 = a->decimator->has_prev, had_emask0 = p->has_edge_mask;
+    { const int st_ = snapshot_copy(p, a, snap0, true, st); if (st_ != PDP_OK) return st_; }
     SolveParams sp;
     memset(&sp, 0, sizeof(sp));
     sp.tol = a->tolerance; sp.t_max = a->t_max; sp.pi = a->pi;
@@ -2280,7 +2408,14 @@ static int sp_solve_lockstep(pdp_problem *p, pdp_solve_args *a, hipStream_t st)
     PDP_LAUNCH_CHECK();
     PDP_HIP_CHECK(hipMemcpyAsync(p->flags_host, p->flags, FL_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     PDP_HIP_CHECK(hipStreamSynchronize(st));
-    PDP_REQUIRE(p->flags_host[FL_SPEC_VIOLATION] == 0u, "lock-step solve: inconsistent NaN bookkeeping");
+    if (p->flags_host[FL_SPEC_VIOLATION] != 0u) {
+        int status = snapshot_copy(p, a, snap0, false, st);
+        if (status == PDP_OK) status = hipStreamSynchronize(st) == hipSuccess ? PDP_OK : PDP_ERR_HIP;
+        if (status != PDP_OK) return status;
+        a->decimator->has_prev = had_prev0; p->has_edge_mask = had_emask0;
+        pdp_set_error("persistent solve: an inactive instance's next sweep is not finite (the reference's mask blend makes its messages NaN); state restored, rerun the batch step-wise");
+        return PDP_ERR_SPECULATION;
+    }
     a->kernel_launches_host = 1; a->used_lds_host = 0; a->hbm_instances_host = p->B;
     a->iterations_run_host = (int)p->flags_host[FL_ITERS_RUN];
     a->decimator->has_prev = 1; p->has_edge_mask = 1;
@@ -2391,7 +2526,7 @@ static int sp_solve_speculative(pdp_problem *p, pdp_solve_args *a, void *stream)
     SolveSnapshot snap0 = carve_snap((char *)(replay_list + B));            // state at call entry (speculation failure)
     SolveSnapshot snap = carve_snap((char *)(replay_list + B) + snap_bytes); // state at chunk entry (poison replay)
     const int had_prev0 = a->decimator->has_prev, had_emask0 = p->has_edge_mask;
-    int status = exact ? PDP_OK : snapshot_copy(p, a, snap0, true, st);      // (exact mode cannot fail: no call-entry snapshot)
+    int status = snapshot_copy(p, a, snap0, true, st);
     if (status != PDP_OK) return status;
 
     SolveParams sp;
@@ -2420,7 +2555,15 @@ static int sp_solve_speculative(pdp_problem *p, pdp_solve_args *a, void *stream)
         PDP_LAUNCH_CHECK();
         PDP_HIP_CHECK(hipMemcpyAsync(p->flags_host, p->flags, FL_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         PDP_HIP_CHECK(hipStreamSynchronize(st));
-        PDP_REQUIRE(p->flags_host[FL_SPEC_VIOLATION] == 0u, "persistent solve (single instance): inconsistent NaN bookkeeping");
+        if (p->flags_host[FL_SPEC_VIOLATION] != 0u) {
+            // the instance went inactive in a state whose next sweep is not finite: the reference's mask blend turns that into NaN messages
+            // (see ghost_bad in k_sp_solve); the strict step-wise loop evaluates it literally
+            status = snapshot_copy(p, a, snap0, false, st);
+            if (status == PDP_OK) status = hipStreamSynchronize(st) == hipSuccess ? PDP_OK : PDP_ERR_HIP;
+            if (status != PDP_OK) return status;
+            pdp_set_error("persistent solve: an inactive instance's next sweep is not finite (the reference's mask blend makes its messages NaN); state restored, rerun the batch step-wise");
+            return PDP_ERR_SPECULATION;
+        }
         a->kernel_launches_host = 1;
         a->iterations_run_host = (int)p->flags_host[FL_ITERS_RUN];
         a->decimator->has_prev = 1; p->has_edge_mask = 1;

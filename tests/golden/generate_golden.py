@@ -1054,6 +1054,30 @@ if __name__ == '__main__':
         # batch replication with a RANDOM initial state: the replicas differ and couple through the termination rule (trainer.py:157-160)
         run_trace('p-d-p', make_lines([(40, 140, (3,))] * 6, seed0=900), T=30, w=10, seed=29, replication=3, randomized=True,
                   tag='trace_pdp_rep3_randinit', cfg_kw=dict(tolerance=0.05, t_max=6))
+    if 'rf_leak' in what:
+        # Reinforce on four instances and a coin sequence found by tools/parity_soak.py (rf_leak_instances.jsonl, rf_leak_coins.npy; the
+        # reference's torch.rand(1) calls are fed from that sequence): instance 0 leaves through the gate at sweep 75 while the others go on,
+        # and the next sweep of its frozen state is not finite -- the reference's mask blend (mask * new + (1 - mask) * old,
+        # pdp_propagate.py:219-221) turns messages of the INACTIVE instance into NaN.  Also pins torch.sign(NaN) = 0 for the force column.
+        lines = [l for l in open(os.path.join(HERE, 'rf_leak_instances.jsonl')).read().split('\n') if l.strip()]
+        coins = np.load(os.path.join(HERE, 'rf_leak_coins.npy'))
+        pos = [0]
+        keep = globals()['_real_rand']
+
+        def fed(*a, **k):
+            out = keep(*a, **k)
+            out.fill_(float(coins[pos[0] % len(coins)])); pos[0] += 1
+            return out
+        globals()['_real_rand'] = fed
+        try:
+            run_trace('reinforce', lines, T=100, w=0, seed=0, tag='trace_reinforce_nan_leak', cfg_kw=dict(pi=0.1, decimation_probability=0.6),
+                      float_iters=(0, 1, 74, 75, 76, 77, 80))
+        finally:
+            globals()['_real_rand'] = keep
+        d = np.load(os.path.join(HERE, 'trace_reinforce_nan_leak.npz'))
+        am = d['trace_active_mask']
+        print('rf_leak: iterations', int(d['iterations_run'][0]), 'instance 0 inactive from', int(np.argmax(am[:, 0] == 0)), 'NaN entries in the final state',
+              int(np.isnan(d['final_dec_1']).sum()), int(np.isnan(d['final_dec_0']).sum()), 'at sweep 75/76/77:', [int(np.isnan(d['prop_fs_%d' % t]).sum()) for t in (75, 76, 77)])
     if 'cli' in what:
         gen_cli()
     if 'config0' in what:

@@ -80,6 +80,39 @@ def test_forward_equals_reference_golden(name, model_type, kw, persistent):
     np.testing.assert_array_equal(torch.rand(4).numpy(), expected_next.numpy())
 
 
+@pytest.mark.parametrize('persistent', [True, False])
+def test_nan_leak_into_an_inactive_instance_fails_over_to_the_stepwise_loop(persistent, monkeypatch):
+    """trace_reinforce_nan_leak: the reference's mask blend (mask * new + (1 - mask) * old, pdp_propagate.py:219-221) turns messages of an
+    instance that already LEFT the loop into NaN at sweep 76.  The persistent call sees that its frozen state would not survive another
+    sweep, restores every array and reports; the solver then runs the strict step-wise loop, whose results equal the reference's.
+    The golden was captured with the reference's torch.rand(1) coins FED from a recorded sequence (generate_golden.py rf_leak); the same
+    sequence is fed here, keyed by the generator's position so that the solver's draw / rewind / consume pattern sees the same coin at the
+    same position."""
+    d = load_golden('trace_reinforce_nan_leak')
+    coins = np.load(os.path.join(REPO, 'tests', 'golden', 'rf_leak_coins.npy'))
+    real = torch.rand
+    torch.manual_seed(int(d['meta'][2]))
+    position = {float(real(1).item()): k for k in range(4 * int(d['meta'][0]))}
+
+    def fed(*a, **k):
+        out = real(*a, **k)
+        if out.numel() == 1 and float(out.item()) in position:
+            out.fill_(float(coins[position[float(out.item())] % len(coins)]))
+        return out
+    monkeypatch.setattr(torch, 'rand', fed)
+    d, tr, m, pred, states, batch = run_golden('trace_reinforce_nan_leak', 'reinforce', persistent=persistent, pi=0.1, decimation_probability=0.6)
+    assert m.last_run['path'] == 'stepwise'
+    assert m.last_run['iterations'] == int(d['iterations_run'][0])
+    np.testing.assert_array_equal(pred[0].cpu().numpy()[:, 0], d['final_prediction'])
+    fs = states[0][1].cpu().numpy()
+    np.testing.assert_array_equal(np.isnan(fs), np.isnan(d['final_prop_1']))
+    assert np.isnan(fs[:, 0]).sum() > 0 and not np.isnan(fs[:, 1]).any()        # the surveys of the inactive instance are NaN, the force column is not
+    np.testing.assert_array_equal(fs[:, 1], d['final_prop_1'][:, 1])            # torch.sign(NaN) = 0
+    # the generator stands where the reference's stands: one coin per executed sweep
+    nxt = float(real(1).item())
+    assert position[nxt] == int(d['iterations_run'][0])
+
+
 def test_post_processing_rows():
     d, tr, m, pred, states, (gm, bvm, bfm, ef) = run_golden('trace_pdp_easy_ws', 'p-d-p', tolerance=0.05, t_max=10)
     B = int(bvm.max()) + 1

@@ -281,11 +281,11 @@ def test_reinforce_mixed_batch_and_single_instance(oracle):
         res = _reinforce_pair(oracle, dataset.collate_segment(dataset.random_ksat_items(1, 60, 3, m=250, seed=500 + seed)), 40, 0.1, 0.6, seed, expect_lds=False)
 
 
-@pytest.mark.parametrize('spec,T,tol,t_max', [(dict(batch=700, n=30, k=3, m=100, seed=300), 50, 0.05, 8), (dict(batch=400, n=60, k=3, seed=7000), 120, 0.05, 8),
+@pytest.mark.parametrize('spec,T,tol,t_max', [(dict(batch=500, n=30, k=3, m=100, seed=300), 50, 0.05, 8), (dict(batch=400, n=60, k=3, seed=7000), 120, 0.05, 8),
                                               (dict(batch=64, n=40, mixed=True, seed=100), 30, 0.05, 6)])
 def test_lockstep_launch_on_larger_batches(oracle, monkeypatch, spec, T, tol, t_max):
     """The lock-step launch forced on batches that would normally run speculatively (several workgroups per CU, every one resident; mailbox
-    reads folded over ranks r, r + 256, ...): 700 instances, the NaN-poisoned batch of 400 (the poison is exchanged inline, no replay), a
+    reads folded over ranks r, r + 256, ...): 500 instances, the NaN-poisoned batch of 400 (the poison is exchanged inline, no replay), a
     mixed-k batch -- the oracle's strict semantics bit for bit."""
     monkeypatch.setenv('PDP_SOLVE_FORCE_LOCKSTEP', '1')
     b = random_batch(**spec)
