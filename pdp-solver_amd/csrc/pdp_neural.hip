@@ -908,7 +908,7 @@ __device__ __forceinline__ void gru_phase(const float *xa, const float *ha, __am
         // short ones -- NV = 4/3: 26.5 ms, 8/6: 24.8 ms, 26/16: 24.0 ms per call; every VALU run between two dependent MFMAs costs a fixed delay)
 #pragma unroll
         for (int j = 0; j < CH; ++j)
-            if (lo + j < hi) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); if (c & 1) __builtin_amdgcn_sched_group_barrier(0x002, 2 * NV, 0); }
+            if (lo + j < hi) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); if (NV > 0 && (c & 1)) __builtin_amdgcn_sched_group_barrier(0x002, 2 * NV, 0); }
         __builtin_amdgcn_sched_barrier(0);                 // and nothing moves across chunks (keeps the loads of later chunks from piling up)
     }
 }
@@ -1020,6 +1020,212 @@ __global__ void __launch_bounds__(NTN) k_gru_pipe(int E, const float *__restrict
             const float mk = mp[ro];
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mk * hnew + (1.0f - mk) * hq[c]), ob, ooff, ro * H * (int)sizeof(float), 0);
         }
+    }
+}
+
+// ---- kernel 5c: the pipelined cell with a WAVE as the unit of work (hidden widths whose column blocks do not divide eight waves) --------
+// Hidden 150 (the reference's shipped np-nd-np predict config) has five 32-column blocks: the ten blocks of a 64-edge tile leave two of
+// eight waves busy in a second round, whatever the window.  Here a wave owns a 32-edge tile from its rows to the stored result and walks
+// ALL column blocks itself: four waves per workgroup (one per SIMD, the tile of each is 38 KB of LDS), every SIMD carries the same
+// 3 x NBK chains per tile, nothing is exchanged and there is no workgroup barrier.  With one wave per SIMD nobody covers a wait, so the
+// operand stream never stops: the 3 x NBK phases of a tile are ONE software pipeline -- LDS operands one chunk ahead, weight fragments two
+// chunks ahead, across the phase and block boundaries (the first weights of the next tile are requested in the last chunks of this one) --
+// with the previous gate's activation slices scheduled between the MFMAs as in k_gru_pipe; the result of a block is finished inside the
+// next block's first phase, the last block's while the next tile's rows are in flight.  Same chains, same activation functions per
+// element as k_gru: bit-identical results.
+template <int SX, int SH>
+struct GruStream {
+    static constexpr int S = SX + SH, CH = (S + 15) / 16;
+    float bb[3][CH], aa[2][CH];
+    __amdgpu_buffer_rsrc_t wi, wh;
+    const float *xa, *ha;
+    int ws;
+    __device__ __forceinline__ float wload(int voff, int s2) const {
+        return (s2 < SX) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wi, voff, s2 * ws, 0))
+                         : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wh, voff, (s2 - SX) * ws, 0));
+    }
+    __device__ __forceinline__ float aload(int s2) const { return (s2 < SX) ? xa[2 * s2] : ha[2 * (s2 - SX)]; }
+    // chunk c of a phase = k-steps [c S / 16, (c + 1) S / 16)
+    // (slot and c are constants after unrolling: the arrays live in registers)
+    __device__ __forceinline__ void wchunk(int slot, int voff, int c) {
+        const int lo = c * S / 16, hi = (c + 1) * S / 16;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) if (lo + j < hi) bb[slot][j] = wload(voff, lo + j);
+    }
+    __device__ __forceinline__ void achunk(int slot, int c) {
+        const int lo = c * S / 16, hi = (c + 1) * S / 16;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) if (lo + j < hi) aa[slot][j] = aload(lo + j);
+    }
+};
+
+// one gate of one block: 16 chunks.  BASE = number of the phase's first chunk modulo 3 (the weight slots rotate through the phases).
+// Requests, in chunk c: the LDS operands of chunk c + 1 and the weights of chunk c + 2 -- of this phase, or of the next one (voff_next;
+// a_next: its LDS operands can be read already, i.e. it belongs to the same tile).
+template <int SX, int SH, int NV, int BASE, class Epi>
+__device__ __forceinline__ void gru_phase2(GruStream<SX, SH> &st, int voff, int voff_next, bool a_next, float bi, float bh,
+                                           f32x16 &ai, f32x16 &ah, Epi &&epi)
+{
+    constexpr int S = SX + SH, CH = (S + 15) / 16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ai[r] = bi; ah[r] = bh; }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int lo = c * S / 16, hi = (c + 1) * S / 16;
+        if (c + 2 < 16) st.wchunk((BASE + c + 2) % 3, voff, c + 2);
+        else st.wchunk((BASE + c + 2) % 3, voff_next, c + 2 - 16);
+        if (c + 1 < 16) st.achunk((c + 1) & 1, c + 1);
+        else if (a_next) st.achunk(0, 0);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int s = lo + j;
+            if (s < hi) {
+                const float bv = st.bb[(BASE + c) % 3][j], av = st.aa[c & 1][j];
+                if (s < SX) ai = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, ai, 0, 0, 0);
+                else ah = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, ah, 0, 0, 0);
+            }
+        }
+        if (c & 1) { epi(c - 1); epi(c); }
+        // (with one wave per SIMD the accumulators live in the accumulation registers: the tie must not pull them into VGPRs -- a "+v" here
+        //  costs 64 register moves per chunk, measured 93 instead of 64 cycles per MFMA)
+        asm volatile("" : "+a"(ai), "+a"(ah));
+        // issue order inside the chunk: one MFMA, one weight load and one LDS read of the chunks ahead, then the VALU run of the activation
+        // slice -- the requests go out between the (dependent, 64-cycle) MFMAs instead of in front of them
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+            if (lo + j < hi) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#ifndef GW_NOMIX
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#endif
+                if (NV > 0 && (c & 1)) __builtin_amdgcn_sched_group_barrier(0x002, 2 * NV, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int SX, int SH, int NBK, bool MASK>
+__global__ void __launch_bounds__(256) k_gru_wave(int E, const float *__restrict__ state, const float *__restrict__ sign,
+                                                  const float *__restrict__ hprev, const float *__restrict__ rowmask, GruW g,
+                                                  float *__restrict__ out, int ntiles /* full 32-edge tiles only */)
+{
+    constexpr int H = 2 * SX - 2;                          // input row = [H message floats, edge sign, zero pad]
+    static_assert(2 * SH == H || 2 * SH == H + 1, "hidden rows of H floats (+ one zero when H is odd)");
+    constexpr int HP = 32 * NBK, N3 = 3 * HP, CG = (H + 63) / 64;
+    constexpr int ldx = 2 * SX + 1, ldh = 2 * SH + 1;
+    constexpr int WR = WT * (ldx + ldh) + WT;              // floats per wave: X, Hs, row masks
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, i = l & 31, kh = l >> 5;
+    float *X = sm + wave * WR, *Hs = X + WT * ldx, *Mk = Hs + WT * ldh;
+    constexpr int rowb = H * (int)sizeof(float);
+    GruStream<SX, SH> st;
+    st.wi = __builtin_amdgcn_make_buffer_rsrc((void *)g.Wt_ih, 0, 2 * SX * N3 * (int)sizeof(float), 0x00020000);
+    st.wh = __builtin_amdgcn_make_buffer_rsrc((void *)g.Wt_hh, 0, 2 * SH * N3 * (int)sizeof(float), 0x00020000);
+    st.ws = 2 * N3 * (int)sizeof(float);
+    st.xa = X + i * ldx + kh; st.ha = Hs + i * ldh + kh;
+    auto tile_rsrc = [&](const float *base, int e0, int row_bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(base + (size_t)e0 * (row_bytes / (int)sizeof(float))), 0, WT * row_bytes, 0x00020000);
+    };
+    float px[WT][CG], ph[WT][CG];
+    float psg = 0.0f, pmk = 1.0f;
+    auto fetch = [&](int tile) {
+        const int e0 = tile * WT;
+        const __amdgpu_buffer_rsrc_t sb = tile_rsrc(state, e0, rowb), hb = tile_rsrc(hprev, e0, rowb), gb = tile_rsrc(sign, e0, (int)sizeof(float));
+#pragma unroll
+        for (int r = 0; r < WT; ++r)
+#pragma unroll
+            for (int j = 0; j < CG; ++j) {
+                // (columns l, 64 + l, ...: a column past the row reads the next row's start, or 0 past the tile, and is not deposited)
+                px[r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sb, l * 4 + 256 * j, r * rowb, 0));
+                ph[r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hb, l * 4 + 256 * j, r * rowb, 0));
+            }
+        psg = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gb, l * 4, 0, 0));       // lanes >= 32: past the tile, 0
+        if (MASK) pmk = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(tile_rsrc(rowmask, e0, (int)sizeof(float)), l * 4, 0, 0));
+    };
+    auto deposit = [&]() {
+#pragma unroll
+        for (int r = 0; r < WT; ++r)
+#pragma unroll
+            for (int j = 0; j < CG; ++j)
+                if (64 * j + l < H) { X[r * ldx + 64 * j + l] = px[r][j]; Hs[r * ldh + 64 * j + l] = ph[r][j]; }
+        if (l < WT) {
+            X[l * ldx + H] = psg; X[l * ldx + H + 1] = 0.0f;
+            if (2 * SH > H) Hs[l * ldh + H] = 0.0f;
+            Mk[l] = pmk;
+        }
+    };
+    const int row0 = 4 * kh;                               // acc_row(r, l) = row0 + (r & 3) + 8 (r >> 2)
+    const int voff0 = (kh * N3 + i) * (int)sizeof(float);  // this lane's column of block 0, gate r
+    f32x16 tq, zg, hq;                                     // carried from a block to the next: tanh argument, update gate, previous hidden value
+    const int stride = gridDim.x * 4;
+    int tile = blockIdx.x * 4 + wave;
+    if (tile < ntiles) {
+        fetch(tile);
+        st.wchunk(0, voff0, 0); st.wchunk(1, voff0, 1);
+    }
+    for (; tile < ntiles; tile += stride) {
+        deposit();
+        st.achunk(0, 0);
+        const __amdgpu_buffer_rsrc_t ob = tile_rsrc(out, tile * WT, rowb);
+        int ooff = 0;                                      // where the carried block goes (byte offset of this lane's column in row row0)
+        auto finish = [&](int c) {
+            const int ro = (c & 3) + 8 * (c >> 2);
+            const float ng = pdp_tanhf_abs(tq[c]);
+            const float hnew = (hq[c] - ng) * zg[c] + ng;
+            const float mk = MASK ? Mk[row0 + ro] : 1.0f;
+#if defined(GW_EXP) && (GW_EXP & 1)
+            float sv = mk * hnew + (1.0f - mk) * hq[c]; asm volatile("" :: "v"(sv));
+#else
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mk * hnew + (1.0f - mk) * hq[c]), ob, ooff, ro * rowb, 0);
+#endif
+        };
+        for (int nb = 0; nb < NBK; ++nb) {
+            const int col = 32 * nb + i;
+            const int voff = voff0 + 32 * nb * (int)sizeof(float);
+            const bool last = nb == NBK - 1;
+            const float bir = g.b_ih[col], biz = g.b_ih[HP + col], bin = g.b_ih[2 * HP + col];
+            const float bhr = g.b_hh[col], bhz = g.b_hh[HP + col], bhn = g.b_hh[2 * HP + col];
+            f32x16 ai, ah, rg;
+            if (nb == 0) gru_phase2<SX, SH, 0, 0>(st, voff, voff + HP * (int)sizeof(float), true, bir, bhr, ai, ah, [&](int) {});
+#if defined(GW_EXP) && (GW_EXP & 2)
+            else gru_phase2<SX, SH, 0, 0>(st, voff, voff + HP * (int)sizeof(float), true, bir, bhr, ai, ah, [&](int) {});
+#else
+            else gru_phase2<SX, SH, 26, 0>(st, voff, voff + HP * (int)sizeof(float), true, bir, bhr, ai, ah, finish);
+#endif
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rg[r] = ah[r] + ai[r];
+            gru_phase2<SX, SH, 16, 1>(st, voff + HP * (int)sizeof(float), voff + 2 * HP * (int)sizeof(float), true, biz, bhz, ai, ah,
+#if defined(GW_EXP) && (GW_EXP & 2)
+                                      [&](int c) { });
+#else
+                                      [&](int c) { float v = pdp_sigmoidf(rg[c]); asm volatile("" : "+v"(v)); rg[c] = v; });
+#endif
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zg[r] = ah[r] + ai[r];
+            // the stream runs on into the next block, or (weights only) into block 0 of the next tile
+            gru_phase2<SX, SH, 16, 2>(st, voff + 2 * HP * (int)sizeof(float), last ? voff0 : voff + 32 * (int)sizeof(float), !last, bin, bhn, ai, ah,
+#if defined(GW_EXP) && (GW_EXP & 2)
+                                      [&](int c) { });
+#else
+                                      [&](int c) { float v = pdp_sigmoidf(zg[c]); asm volatile("" : "+v"(v)); zg[c] = v; });
+#endif
+            const int hc = col < H ? col : H - 1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                tq[r] = ai[r] + ah[r] * rg[r];
+                hq[r] = Hs[(row0 + (r & 3) + 8 * (r >> 2)) * ldh + hc];
+            }
+            // a column past H is stored nowhere: an offset past the tile's bytes is dropped by the descriptor
+            ooff = col < H ? (row0 * H + col) * (int)sizeof(float) : 0x40000000;
+        }
+        // the chains of this tile are done with X / Hs (LDS operations of a wave complete in order): request the next tile's rows and
+        // finish the last block while they are in flight
+#if !(defined(GW_EXP) && (GW_EXP & 4))
+        if (tile + stride < ntiles) fetch(tile + stride);
+#endif
+#pragma unroll
+        for (int c = 0; c < 16; ++c) finish(c);
     }
 }
 
@@ -1180,6 +1386,24 @@ extern "C" int pdp_neural_gru(pdp_problem *p, const pdp_gru_desc *d, const float
         }
         if (tail > 0) {
             const size_t o = (size_t)full * TM;
+            hipLaunchKernelGGL(k_gru, dim3(1), dim3(NTN), lds, st, tail, state + o * g.dx, p->edge_sign + o, h + o * g.H, rowmask + o, g,
+                               out + o * g.H, 1);
+        }
+        PDP_LAUNCH_CHECK();
+        return PDP_OK;
+    }
+    if (!plain && !getenv("PDP_NEURAL_GRU_WINDOW") && d->H == 150 && g.Kpx == 152) {
+        // hidden width 150 (five column blocks): a wave per 32-edge tile, four waves per workgroup, one workgroup per CU
+        const int full = E / WT, tail = E - full * WT;
+        if (full > 0) {
+            const size_t ldsw = sizeof(float) * 4 * (size_t)(WT * ((g.Kpx + 1) + (g.Kph + 1)) + WT);
+            const int wgs = (full + 3) / 4;
+            const int grid = wgs < persistent_grid() ? wgs : persistent_grid();
+            s = set_lds((const void *)k_gru_wave<76, 75, 5, true>, ldsw); if (s != PDP_OK) return s;
+            hipLaunchKernelGGL((k_gru_wave<76, 75, 5, true>), dim3(grid), dim3(256), ldsw, st, E, state, p->edge_sign, h, rowmask, g, out, full);
+        }
+        if (tail > 0) {
+            const size_t o = (size_t)full * WT;
             hipLaunchKernelGGL(k_gru, dim3(1), dim3(NTN), lds, st, tail, state + o * g.dx, p->edge_sign + o, h + o * g.H, rowmask + o, g,
                                out + o * g.H, 1);
         }
