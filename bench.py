@@ -324,7 +324,7 @@ def neural_kernel_rooflines(native, timing, E, V, H):
     "per-kernel lines from the library's HIP events: ms per launch, algorithmic flop per launch, TFLOP/s, fraction of the fp32 MFMA peak"
     fl = neural_flops(H)
     out = {}
-    for key, kernels in (('agg_pre', 'k_agg_pre_wave'), ('agg_post', 'k_agg_post_pf'), ('gru', 'k_gru_pipe'), ('predict_head', 'k_predict_rows'),
+    for key, kernels in (('agg_pre', 'k_agg_pre_wave'), ('agg_post', 'k_agg_post_pf'), ('gru', 'k_gru_wave' if H == 150 else 'k_gru_pipe'), ('predict_head', 'k_predict_rows'),
                          ('row_sum', 'k_row_sum')):
         ms, n = timing[key]
         if n == 0:

@@ -15,6 +15,7 @@
 //   generic shapes      k_agg_pre / k_agg_pre_res, k_row_sum, k_agg_post (/ k_agg_post_res), k_predict_rows, k_gru, k_gru_window
 //   hidden 128 and 150  k_agg_pre_wave (a wave owns a 32-edge tile through both layers), k_agg_post_pf (prefetched chains)
 //   hidden 128          k_gru_pipe (in-wave pipelined MFMA chains and activation slices; also the 4- / 3-input cells of p-nd-np)
+//   hidden 150          k_gru_wave (a wave owns a 32-edge tile through all five column blocks: one software pipeline per tile)
 // What bounds them: on gfx950 the f32 MFMA and the VALU share issue time on a SIMD -- their times add up whichever wave issues them --
 // so beyond keeping every MFMA's operands in registers ahead of time, instruction count is what counts.
 #include "pdp_common.hpp"
@@ -1085,6 +1086,7 @@ __device__ __forceinline__ void gru_phase2(GruStream<SX, SH> &st, int voff, int 
                 else ah = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, ah, 0, 0, 0);
             }
         }
+        // activation slices two at a time, as in gru_phase (one, four, eight at a time: 35.1 / 34.2 / 34.0 against 33.7 ms)
         if (c & 1) { epi(c - 1); epi(c); }
         // (with one wave per SIMD the accumulators live in the accumulation registers: the tie must not pull them into VGPRs -- a "+v" here
         //  costs 64 register moves per chunk, measured 93 instead of 64 cycles per MFMA)
@@ -1095,10 +1097,8 @@ __device__ __forceinline__ void gru_phase2(GruStream<SX, SH> &st, int voff, int 
         for (int j = 0; j < CH; ++j)
             if (lo + j < hi) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-#ifndef GW_NOMIX
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#endif
                 if (NV > 0 && (c & 1)) __builtin_amdgcn_sched_group_barrier(0x002, 2 * NV, 0);
             }
         __builtin_amdgcn_sched_barrier(0);
@@ -1174,11 +1174,7 @@ __global__ void __launch_bounds__(256) k_gru_wave(int E, const float *__restrict
             const float ng = pdp_tanhf_abs(tq[c]);
             const float hnew = (hq[c] - ng) * zg[c] + ng;
             const float mk = MASK ? Mk[row0 + ro] : 1.0f;
-#if defined(GW_EXP) && (GW_EXP & 1)
-            float sv = mk * hnew + (1.0f - mk) * hq[c]; asm volatile("" :: "v"(sv));
-#else
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mk * hnew + (1.0f - mk) * hq[c]), ob, ooff, ro * rowb, 0);
-#endif
         };
         for (int nb = 0; nb < NBK; ++nb) {
             const int col = 32 * nb + i;
@@ -1188,28 +1184,16 @@ __global__ void __launch_bounds__(256) k_gru_wave(int E, const float *__restrict
             const float bhr = g.b_hh[col], bhz = g.b_hh[HP + col], bhn = g.b_hh[2 * HP + col];
             f32x16 ai, ah, rg;
             if (nb == 0) gru_phase2<SX, SH, 0, 0>(st, voff, voff + HP * (int)sizeof(float), true, bir, bhr, ai, ah, [&](int) {});
-#if defined(GW_EXP) && (GW_EXP & 2)
-            else gru_phase2<SX, SH, 0, 0>(st, voff, voff + HP * (int)sizeof(float), true, bir, bhr, ai, ah, [&](int) {});
-#else
             else gru_phase2<SX, SH, 26, 0>(st, voff, voff + HP * (int)sizeof(float), true, bir, bhr, ai, ah, finish);
-#endif
 #pragma unroll
             for (int r = 0; r < 16; ++r) rg[r] = ah[r] + ai[r];
             gru_phase2<SX, SH, 16, 1>(st, voff + HP * (int)sizeof(float), voff + 2 * HP * (int)sizeof(float), true, biz, bhz, ai, ah,
-#if defined(GW_EXP) && (GW_EXP & 2)
-                                      [&](int c) { });
-#else
                                       [&](int c) { float v = pdp_sigmoidf(rg[c]); asm volatile("" : "+v"(v)); rg[c] = v; });
-#endif
 #pragma unroll
             for (int r = 0; r < 16; ++r) zg[r] = ah[r] + ai[r];
             // the stream runs on into the next block, or (weights only) into block 0 of the next tile
             gru_phase2<SX, SH, 16, 2>(st, voff + 2 * HP * (int)sizeof(float), last ? voff0 : voff + 32 * (int)sizeof(float), !last, bin, bhn, ai, ah,
-#if defined(GW_EXP) && (GW_EXP & 2)
-                                      [&](int c) { });
-#else
                                       [&](int c) { float v = pdp_sigmoidf(zg[c]); asm volatile("" : "+v"(v)); zg[c] = v; });
-#endif
             const int hc = col < H ? col : H - 1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -1221,9 +1205,7 @@ __global__ void __launch_bounds__(256) k_gru_wave(int E, const float *__restrict
         }
         // the chains of this tile are done with X / Hs (LDS operations of a wave complete in order): request the next tile's rows and
         // finish the last block while they are in flight
-#if !(defined(GW_EXP) && (GW_EXP & 4))
         if (tile + stride < ntiles) fetch(tile + stride);
-#endif
 #pragma unroll
         for (int c = 0; c < 16; ++c) finish(c);
     }
@@ -1369,7 +1351,7 @@ extern "C" int pdp_neural_gru(pdp_problem *p, const pdp_gru_desc *d, const float
     hipLaunchKernelGGL(k_edge_active, dim3(1024), dim3(256), 0, st, E, p->graph_map, p->var_inst, active_mask, rowmask);
     pdp_timed_scope timed(PDP_TK_GRU, st);
     const bool plain = getenv("PDP_NEURAL_GRU_PLAIN") != nullptr;
-    if (!plain && d->H == 128 && (g.Kpx == 130 || g.Kpx == 4)) {
+    if (!plain && d->H == 128 && (g.Kpx == 130 || g.Kpx == 4) && !(g.Kpx == 130 && getenv("PDP_NEURAL_GRU_WAVE"))) {
         // hidden width 128 with a 129-wide input (np-nd-np, config 3) or a 4- / 3-wide one (p-nd-np: surveys + sign): pipelined kernel on
         // the full tiles, the plain one on the ragged tail
         const int full = E / TM, tail = E - full * TM;
@@ -1386,6 +1368,23 @@ extern "C" int pdp_neural_gru(pdp_problem *p, const pdp_gru_desc *d, const float
         }
         if (tail > 0) {
             const size_t o = (size_t)full * TM;
+            hipLaunchKernelGGL(k_gru, dim3(1), dim3(NTN), lds, st, tail, state + o * g.dx, p->edge_sign + o, h + o * g.H, rowmask + o, g,
+                               out + o * g.H, 1);
+        }
+        PDP_LAUNCH_CHECK();
+        return PDP_OK;
+    }
+    if (!plain && getenv("PDP_NEURAL_GRU_WAVE") && d->H == 128 && g.Kpx == 130) {
+        const int full = E / WT, tail = E - full * WT;
+        if (full > 0) {
+            const size_t ldsw = sizeof(float) * 4 * (size_t)(WT * ((g.Kpx + 1) + (g.Kph + 1)) + WT);
+            const int wgs = (full + 3) / 4;
+            const int grid = wgs < persistent_grid() ? wgs : persistent_grid();
+            s = set_lds((const void *)k_gru_wave<65, 64, 4, true>, ldsw); if (s != PDP_OK) return s;
+            hipLaunchKernelGGL((k_gru_wave<65, 64, 4, true>), dim3(grid), dim3(256), ldsw, st, E, state, p->edge_sign, h, rowmask, g, out, full);
+        }
+        if (tail > 0) {
+            const size_t o = (size_t)full * WT;
             hipLaunchKernelGGL(k_gru, dim3(1), dim3(NTN), lds, st, tail, state + o * g.dx, p->edge_sign + o, h + o * g.H, rowmask + o, g,
                                out + o * g.H, 1);
         }
