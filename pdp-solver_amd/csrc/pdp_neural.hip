@@ -40,6 +40,15 @@ __device__ __forceinline__ float act_apply(float v, int act)
     }
 }
 
+// logsigmoid of a live column, 0 for a padded one -- as a select: left to itself the compiler branches around the activation per element
+// (an exec-mask region each, which also keeps the elements' dependent chains from interleaving); the empty asm pins the value in front of it
+__device__ __forceinline__ float logsigmoid_or_zero(float x, bool live)
+{
+    float v = pdp_logsigmoidf(x);
+    asm volatile("" : "+v"(v));
+    return live ? v : 0.0f;
+}
+
 // Two 32x32 output blocks (both 32-row halves of the tile, same 32 columns):
 //   acc[mb][r] = bias[col];  acc[mb] += A[32*mb + i][k] * Wt[k][32*nb + j],  k ascending.
 // The B fragment (one float per lane and k-step, a coalesced 128-byte row segment per half-wave) is shared by the two
@@ -589,7 +598,7 @@ __global__ void __launch_bounds__(NTN) k_agg_pre_wave(int E, const float *__rest
         for (int nb = 0; nb < NB1; ++nb) {
             const int col = 32 * nb + i;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) X[acc_row(r, l) * ld + col] = (col < w.m1) ? pdp_logsigmoidf(acc[nb][r]) : 0.0f;
+            for (int r = 0; r < 16; ++r) X[acc_row(r, l) * ld + col] = logsigmoid_or_zero(acc[nb][r], col < w.m1);
             __builtin_amdgcn_sched_barrier(0);
         }
         f32x16 ac2[NB2];
@@ -652,7 +661,7 @@ __global__ void __launch_bounds__(NTN, 6) k_agg_post_pf(int E, const float *__re
         f32x16 acc[1];
         wave_chains<S3, 1, 32 * NB3>(Rt + (32 * mb + i) * ld0 + kh, w3, w.b1a + 32 * nb, acc);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) G1[(32 * mb + acc_row(r, l)) * ld1 + col] = (col < w.g) ? pdp_logsigmoidf(acc[0][r]) : 0.0f;
+        for (int r = 0; r < 16; ++r) G1[(32 * mb + acc_row(r, l)) * ld1 + col] = logsigmoid_or_zero(acc[0][r], col < w.g);
     }
     __syncthreads();
     // blend operands and result through buffer accesses with a per-tile base (lane offset in a VGPR, row offset as a scalar, rows past E
@@ -683,6 +692,177 @@ __global__ void __launch_bounds__(NTN, 6) k_agg_post_pf(int E, const float *__re
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mk[r] * nv + (1.0f - mk[r]) * po[r]), ob, lo, ((r & 3) + 8 * (r >> 2)) * ROWB, 0);
             }
         }
+    }
+}
+
+// ---- kernel 3 with a WAVE as the unit of work (config 3's shapes; opt-in: PDP_NEURAL_POST_WAVE) ------------------------------------------------
+// The form that made the hidden-150 GRU fast, tried on the post-transform: a wave owns a 32-edge tile (four waves per workgroup, one per
+// SIMD, 512 registers per lane), both layers run over all their column blocks as straight-line chains whose weights are requested two
+// chunks ahead across the layer and tile boundaries, and everything the tile reads from HBM is requested at the start of an activation
+// phase a whole phase before it is used (the gathered rows of the NEXT tile and the previous-state rows of this one in front of the hidden
+// layer's logsigmoids, the first two chunks of the next chain's weights in front of them: vector-memory results return in issue order).
+// Bit-identical, and SLOWER than k_agg_post_pf: 8.5 against 7.5 ms per call.  Measured with one piece compiled out: MFMA chains + tile
+// bookkeeping 4.6 ms (floor 3.1), logsigmoids 2.8, HBM requests 1.1 (their round trip is longer than the 3.6 us activation phase when all
+// waves of the chip burst at once; moving the row gather in front of the second activation phase changes nothing), stores 0.3 -- this
+// kernel's tile is too short (304 MFMAs, 8 us) for one wave per SIMD to cover its own memory traffic, which six waves per SIMD do for free.
+template <int STEPS, int NB, int NP>
+struct WaveChains {
+    static constexpr int T = STEPS * NB, CH = 8, NC = (T + CH - 1) / CH;
+    float aa[2][CH], bb[3][CH];
+    __amdgpu_buffer_rsrc_t wr;
+    const float *a;            // LDS: row (lane & 31) of the tile, column lane >> 5
+    int voff;
+    __device__ __forceinline__ float wl(int t) const {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wr, voff + (t / STEPS) * 32 * (int)sizeof(float),
+                                                                             (t % STEPS) * 2 * NP * (int)sizeof(float), 0));
+    }
+    __device__ __forceinline__ void head_w() {         // weights of the first two chunks
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { if (j < T) bb[0][j] = wl(j); if (CH + j < T) bb[1][j] = wl(CH + j); }
+    }
+    __device__ __forceinline__ void head_a() {         // LDS operands of the first chunk (the tile must be in LDS)
+#pragma unroll
+        for (int j = 0; j < CH; ++j) if (j < T) aa[0][j] = a[2 * (j % STEPS)];
+    }
+    __device__ __forceinline__ void run(const float *__restrict__ bias, f32x16 (&acc)[NB]) {
+        const int i = threadIdx.x & 31;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const float b0 = bias ? bias[32 * nb + i] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = b0;
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int t2 = (c + 2) * CH + j, t1 = (c + 1) * CH + j;
+                if (t2 < T) bb[(c + 2) % 3][j] = wl(t2);
+                if (t1 < T) aa[(c + 1) & 1][j] = a[2 * (t1 % STEPS)];
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int t = c * CH + j;
+                if (t < T) acc[t / STEPS] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[c & 1][j], bb[c % 3][j], acc[t / STEPS], 0, 0, 0);
+            }
+            // tie the chunk's accumulators to this point (accumulation registers: see gru_phase2), requests between the MFMAs
+            asm volatile("" : "+a"(acc[(c * CH) / STEPS]));
+            if ((c * CH + CH - 1) / STEPS != (c * CH) / STEPS && (c * CH + CH - 1) / STEPS < NB) asm volatile("" : "+a"(acc[(c * CH + CH - 1) / STEPS]));
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+                if (c * CH + j < T) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+};
+
+template <int S3, int NB3, int S4, int NB4>
+__global__ void __launch_bounds__(256) k_agg_post_wave(int E, const float *__restrict__ agg, int agg_rows, const int32_t *__restrict__ edge_row,
+                                                       const float *__restrict__ h2, const float *__restrict__ sign,
+                                                       const float *__restrict__ emask, const float *__restrict__ rowmask,
+                                                       const float *__restrict__ old, AggW w, float *__restrict__ out, int ntiles /* full 32-edge tiles */)
+{
+    static_assert(2 * S3 <= 64, "one lane per input column");
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int ld0 = 2 * S3 + 1, ld1 = 32 * NB3 + 1, WR = WT * (ld0 + ld1) + WT;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, i = l & 31, kh = l >> 5;
+    float *Rt = sm + wave * WR, *G1 = Rt + WT * ld0, *Mk = G1 + WT * ld1;
+    const int A = w.a, ROWA = A * (int)sizeof(float), ROWB = w.out * (int)sizeof(float);
+    WaveChains<S3, NB3, 32 * NB3> c3;
+    WaveChains<S4, NB4, 32 * NB4> c4;
+    c3.wr = __builtin_amdgcn_make_buffer_rsrc((void *)w.Wt1a, 0, 2 * S3 * 32 * NB3 * (int)sizeof(float), 0x00020000);
+    c4.wr = __builtin_amdgcn_make_buffer_rsrc((void *)w.Wt2a, 0, 2 * S4 * 32 * NB4 * (int)sizeof(float), 0x00020000);
+    c3.voff = (kh * 32 * NB3 + i) * (int)sizeof(float); c4.voff = (kh * 32 * NB4 + i) * (int)sizeof(float);
+    c3.a = Rt + i * ld0 + kh; c4.a = G1 + i * ld1 + kh;
+    const __amdgpu_buffer_rsrc_t ab = __builtin_amdgcn_make_buffer_rsrc((void *)agg, 0, agg_rows * ROWA, 0x00020000);
+    auto tile_rsrc = [&](const void *base, int e0, int row_bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)base + (size_t)e0 * row_bytes), 0, WT * row_bytes, 0x00020000);
+    };
+    // registers of the tile under way: gathered rows (agg, own h2), edge sign / edge mask / row mask / row ids (one per lane < 32)
+    float pa[WT], ph[WT], psg = 0.0f, pem = 1.0f, pmk = 1.0f;
+    int er_next = 0;                                       // row ids of the tile whose rows are gathered next
+    auto fetch_ids = [&](int tile) { er_next = __builtin_amdgcn_raw_buffer_load_b32(tile_rsrc(edge_row, tile * WT, 4), l * 4, 0, 0); };
+    auto fetch_rows = [&](int tile) {                      // uses er_next
+        const int e0 = tile * WT;
+        const __amdgpu_buffer_rsrc_t hb = tile_rsrc(h2, e0, ROWA);
+#pragma unroll
+        for (int r = 0; r < WT; ++r) {
+            const int row = __builtin_amdgcn_readlane(er_next, r);
+            pa[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ab, l * 4, row * ROWA, 0));
+            ph[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hb, l * 4, r * ROWA, 0));
+        }
+        psg = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(tile_rsrc(sign, e0, 4), l * 4, 0, 0));
+        if (emask) pem = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(tile_rsrc(emask, e0, 4), l * 4, 0, 0));
+        if (rowmask) pmk = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(tile_rsrc(rowmask, e0, 4), l * 4, 0, 0));
+    };
+    const bool in_a = l < A, in_s = l == A && w.fd;        // lane = column of the input row: aggregated message, edge sign, zero pad
+    auto deposit = [&]() {
+        if (l < 2 * S3) {                                  // one divergent region; inside it selects only
+#pragma unroll
+            for (int r = 0; r < WT; ++r) {
+                const float hv = ph[r];
+                const float own = emask ? hv * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pem), r)) : hv;
+                const float sg = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, psg), r));
+                Rt[r * ld0 + l] = in_a ? (0.0f + pa[r]) - own : (in_s ? sg : 0.0f);
+            }
+            if (l < WT) Mk[l] = pmk;
+        }
+    };
+    const int stride = gridDim.x * 4;
+    int tile = blockIdx.x * 4 + wave;
+    if (tile < ntiles) {
+        fetch_ids(tile);
+        c3.head_w();
+        fetch_rows(tile);
+        if (tile + stride < ntiles) fetch_ids(tile + stride);
+        deposit();
+    }
+    for (; tile < ntiles; tile += stride) {
+        const int e0 = tile * WT;
+        c3.head_a();
+        f32x16 acc3[NB3];
+        c3.run(w.b1a, acc3);
+        // in front of the hidden layer's activations: the first weights of the output layer, then everything that comes from HBM
+        c4.head_w();
+        const __amdgpu_buffer_rsrc_t pb = tile_rsrc(old, e0, ROWB), ob = tile_rsrc(out, e0, ROWB);
+        const int lo = 4 * kh * ROWB + i * (int)sizeof(float);
+        float po[NB4][16];
+#pragma unroll
+        for (int nb = 0; nb < NB4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                po[nb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pb, (32 * nb + i < w.out) ? lo + nb * 128 : 0x40000000, ((r & 3) + 8 * (r >> 2)) * ROWB, 0));
+        const bool more = tile + stride < ntiles;
+        if (more) { fetch_rows(tile + stride); if (tile + 2 * stride < ntiles) fetch_ids(tile + 2 * stride); }
+#pragma unroll
+        for (int nb = 0; nb < NB3; ++nb) {
+            const int col = 32 * nb + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) G1[acc_row(r, l) * ld1 + col] = logsigmoid_or_zero(acc3[nb][r], col < w.g);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        c4.head_a();
+        f32x16 acc4[NB4];
+        c4.run(nullptr, acc4);
+        c3.head_w();                                       // the next tile's first weights, in front of the stores
+        float mk[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mk[r] = rowmask ? Mk[4 * kh + (r & 3) + 8 * (r >> 2)] : 1.0f;
+#pragma unroll
+        for (int nb = 0; nb < NB4; ++nb) {
+            const int so = (32 * nb + i < w.out) ? lo + nb * 128 : 0x40000000;      // a column past the row is stored nowhere
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float nv = pdp_logsigmoidf(acc4[nb][r]);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mk[r] * nv + (1.0f - mk[r]) * po[nb][r]), ob, so, ((r & 3) + 8 * (r >> 2)) * ROWB, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) deposit();                               // every chain has consumed its operands (LDS operations of a wave complete in order)
     }
 }
 
@@ -1311,7 +1491,33 @@ extern "C" int pdp_neural_aggregate_edges(pdp_problem *p, const pdp_agg_desc *d,
     const bool post_res = getenv("PDP_NEURAL_POST_RESIDENT") != nullptr;
     const bool post_plain = getenv("PDP_NEURAL_POST_PLAIN") != nullptr;
     pdp_timed_scope timed_post(PDP_TK_AGG_POST, st);
-    if (!post_res && !post_plain && w.Kp3 == 52 && w.Np3 == 128 && w.Kp4 == 100 && ((w.Np4 == 128 && w.out == 128) || (w.Np4 == 160 && w.out == 150))) {
+    const bool shape_pf = w.Kp3 == 52 && w.Np3 == 128 && w.Kp4 == 100 && ((w.Np4 == 128 && w.out == 128) || (w.Np4 == 160 && w.out == 150));
+    if (!post_res && !post_plain && shape_pf && getenv("PDP_NEURAL_POST_WAVE") && (int64_t)R * w.a * 4 < ((int64_t)1 << 31) && E >= WT) {
+        // opt-in (measured slower, see the kernel's comment): a wave per 32-edge tile on the full tiles, the workgroup-tile kernel on the ragged tail
+        const int full = E / WT, tail = E - full * WT;
+        const size_t ldsw = sizeof(float) * 4 * (size_t)(WT * (53 + 129) + WT);
+        const int wgs = (full + 3) / 4;
+        const int grid = wgs < persistent_grid() ? wgs : persistent_grid();
+        const size_t ldsp = sizeof(float) * (size_t)TM * (53 + 129);
+        const size_t o = (size_t)full * WT;
+        if (w.Np4 == 128) {
+            s = set_lds((const void *)k_agg_post_wave<26, 4, 50, 4>, ldsw); if (s != PDP_OK) return s;
+            hipLaunchKernelGGL((k_agg_post_wave<26, 4, 50, 4>), dim3(grid), dim3(256), ldsw, st, E, agg, R, edge_row, h2, p->edge_sign, edge_mask, rowmask, old, w, out, full);
+            if (tail > 0) {
+                s = set_lds((const void *)k_agg_post_pf<26, 4, 50, 4>, ldsp); if (s != PDP_OK) return s;
+                hipLaunchKernelGGL((k_agg_post_pf<26, 4, 50, 4>), dim3(1), dim3(NTN), ldsp, st, tail, agg, edge_row + o, h2 + o * w.a, p->edge_sign + o,
+                                   edge_mask ? edge_mask + o : nullptr, rowmask + o, old + o * w.out, w, out + o * w.out);
+            }
+        } else {
+            s = set_lds((const void *)k_agg_post_wave<26, 4, 50, 5>, ldsw); if (s != PDP_OK) return s;
+            hipLaunchKernelGGL((k_agg_post_wave<26, 4, 50, 5>), dim3(grid), dim3(256), ldsw, st, E, agg, R, edge_row, h2, p->edge_sign, edge_mask, rowmask, old, w, out, full);
+            if (tail > 0) {
+                s = set_lds((const void *)k_agg_post_pf<26, 4, 50, 5>, ldsp); if (s != PDP_OK) return s;
+                hipLaunchKernelGGL((k_agg_post_pf<26, 4, 50, 5>), dim3(1), dim3(NTN), ldsp, st, tail, agg, edge_row + o, h2 + o * w.a, p->edge_sign + o,
+                                   edge_mask ? edge_mask + o : nullptr, rowmask + o, old + o * w.out, w, out + o * w.out);
+            }
+        }
+    } else if (!post_res && !post_plain && shape_pf) {
         // hidden 128 (BASELINE configs) or 150 (the reference's shipped predict config) with the 100 / 50 inner widths
         const size_t ldsp = sizeof(float) * (size_t)TM * (53 + 129);
         if (w.Np4 == 128) {

@@ -21,9 +21,13 @@ def dev_agg(w, fd):
 
 
 @pytest.mark.parametrize('H,m1,a,g,grid', [(32, 100, 50, 100, None), (128, 100, 50, 100, None), (20, 36, 17, 40, None),
-                                           (128, 100, 50, 100, 3), (32, 100, 50, 100, 2), (150, 100, 50, 100, None), (150, 100, 50, 100, 2)])
+                                           (128, 100, 50, 100, 3), (32, 100, 50, 100, 2), (150, 100, 50, 100, None), (150, 100, 50, 100, 2),
+                                           (128, 100, 50, 100, -2), (150, 100, 50, 100, -1)])
 def test_aggregator_gru_predict_bit_exact(oracle, monkeypatch, H, m1, a, g, grid):
     from pdp import native
+    if grid and grid < 0:   # the opt-in wave-per-tile forms: post-transform (PDP_NEURAL_POST_WAVE), GRU cell at hidden 128 (PDP_NEURAL_GRU_WAVE)
+        monkeypatch.setenv('PDP_NEURAL_POST_WAVE', '1'); monkeypatch.setenv('PDP_NEURAL_GRU_WAVE', '1')
+        grid = -grid
     if grid:          # persistent kernels: many tiles per workgroup (cross-tile prefetch and the pipelined GRU's carried epilogue)
         monkeypatch.setenv('PDP_NEURAL_GRID', str(grid))
     b = random_batch(batch=9, n=25, mixed=True, seed=77)
