@@ -1434,24 +1434,31 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
                 for (int k = a; k < bnd; ++k) acc = acc + X[e2p[k]];
                 S[r] = acc;
             };
+            // (branch-free up to the one wave-uniform test: a lane without a row in the group reads row 0 and stores to the spare
+            //  slot S[m] -- the per-row exec-mask regions of the first form were most of the instructions of a group, and the clause
+            //  waves are the critical path of this phase)
+            const bool can_group = m > 0 && ne >= 3;
             auto clause_group = [&](int j0, int cnt) {
-                int r[4], a[4]; bool ok[4]; bool all3 = true;
+                int r[4], fa[4], fb[4]; bool in[4]; bool all3 = can_group;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    r[i] = ((j0 + i) << 6) + lane; ok[i] = i < cnt && r[i] < m; a[i] = 0;
-                    if (ok[i]) { a[i] = f_ptr[r[i]]; all3 = all3 && (f_ptr[r[i] + 1] - a[i] == 3); }
+                    r[i] = ((j0 + i) << 6) + lane; in[i] = i < cnt && r[i] < m;
+                    const int rr = in[i] ? r[i] : 0;
+                    fa[i] = f_ptr[rr]; fb[i] = f_ptr[rr + 1];
                 }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) all3 = all3 && (!in[i] || fb[i] - fa[i] == 3);
                 if (__builtin_amdgcn_ballot_w64(!all3) == 0) {
                     uint16_t e[4][3]; float x[4][3];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) if (ok[i]) { e[i][0] = e2p[a[i]]; e[i][1] = e2p[a[i] + 1]; e[i][2] = e2p[a[i] + 2]; }
+                    for (int i = 0; i < 4; ++i) { e[i][0] = e2p[fa[i]]; e[i][1] = e2p[fa[i] + 1]; e[i][2] = e2p[fa[i] + 2]; }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) if (ok[i]) { x[i][0] = X[e[i][0]]; x[i][1] = X[e[i][1]]; x[i][2] = X[e[i][2]]; }
+                    for (int i = 0; i < 4; ++i) { x[i][0] = X[e[i][0]]; x[i][1] = X[e[i][1]]; x[i][2] = X[e[i][2]]; }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) if (ok[i]) { float acc = 0.0f; acc = acc + x[i][0]; acc = acc + x[i][1]; acc = acc + x[i][2]; S[r[i]] = acc; }
+                    for (int i = 0; i < 4; ++i) { float acc = 0.0f; acc = acc + x[i][0]; acc = acc + x[i][1]; acc = acc + x[i][2]; S[in[i] ? r[i] : m] = acc; }
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) if (ok[i]) clause_row(r[i]);
+                    for (int i = 0; i < 4; ++i) if (in[i]) clause_row(r[i]);
                 }
             };
             if (!PROF_SKIP(2)) {
