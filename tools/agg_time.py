@@ -17,11 +17,13 @@ torch.manual_seed(5)
 state = torch.randn(E, H, device=dev) * 0.5
 old = torch.randn(E, H, device=dev) * 0.5
 am = (torch.rand(p.B, device=dev) > 0.1).to(torch.uint8)
+p.refresh_edge_mask()
+em = p.edge_mask if os.environ.get('AGG_EDGE_MASK', '1') != '0' else None      # the solver always passes the edge mask
 for by_var in (True, False):
-    out = p.neural_aggregate_edges(aw, by_var, state, None, am, old); torch.cuda.synchronize()
+    out = p.neural_aggregate_edges(aw, by_var, state, em, am, old); torch.cuda.synchronize()
     native.kernel_timing(True)
     for i in range(reps):
-        out = p.neural_aggregate_edges(aw, by_var, state, None, am, old)
+        out = p.neural_aggregate_edges(aw, by_var, state, em, am, old)
     torch.cuda.synchronize()
     tm = native.kernel_timing_read()
     native.kernel_timing(False)
