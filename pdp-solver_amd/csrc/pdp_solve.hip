@@ -2082,7 +2082,11 @@ static int ensure_bytes(char **ptr, size_t *have, size_t need)
 // PDP_SOLVE_TEAM_WIDE_EDGES=<e> moves the threshold of the wide form (0: never).  (The plan itself: pdp_team_plan, pdp_problem.hip.)
 static int launch_hbm(pdp_problem *p, SolveParams sp, int count, hipStream_t s_, bool wide = false)
 {
-    int tnt = 256;              // measured on the mixed headline batch (tools/mixed_batch_time.py): 256 x 32 beats 512 x 32 and 1024 x 16 next to the LDS-resident kernel
+    // Team workgroup size.  Next to the LDS-resident kernel (per-instance routing of a mixed batch): 256 -- measured on the mixed headline batch
+    // (tools/mixed_batch_time.py), 256 x 32 beats 512 x 32 and 1024 x 16.  With the chip to itself (`wide`: exact single-instance mode, whole
+    // batches of big instances) a team has one workgroup per CU, and 256 threads are one wave per SIMD with nothing to cover the gathers:
+    // 1024 -- a forward of 100 sweeps at n = 20 000 / 100 000 / 300 000 / 1 000 000: 28 / 31 / 69 / 230 -> 18 / 26 / 52 / 154 ms.
+    int tnt = wide ? 1024 : 256;
     if (const char *env = getenv("PDP_SOLVE_TEAM_THREADS")) { const int v = atoi(env); if (v == 256 || v == 512 || v == 1024) tnt = v; }
     TeamLaunch tl;
     { const int st_ = pdp_team_plan(p, count, wide, tnt, &tl, s_); if (st_ != PDP_OK) return st_; }

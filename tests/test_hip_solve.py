@@ -478,13 +478,17 @@ def test_small_batches_fall_back_to_lockstep(oracle, B, n, alpha, T, seeds):
         assert lock > 0          # some of these batches did take the lock-step launch
 
 
+@pytest.mark.parametrize('threads', [None, '256', '512'])
 @pytest.mark.parametrize('n_big', [1, 3])
-def test_wide_teams_across_xcds(oracle, monkeypatch, n_big):
+def test_wide_teams_across_xcds(oracle, monkeypatch, n_big, threads):
     """Big instances with nothing LDS-resident next to them get chip-wide teams (workgroups on all XCDs, agent-scope barriers issued by
-    one wave per workgroup); the threshold is lowered so that instances the oracle finishes in seconds qualify.  One instance alone (exact
-    mode) and three in a batch (speculative mode, host-driven loop): end state = the oracle's, bit for bit."""
+    one wave per workgroup; 1 024 threads per workgroup by default, the other sizes through PDP_SOLVE_TEAM_THREADS); the threshold is lowered
+    so that instances the oracle finishes in seconds qualify.  One instance alone (exact mode) and three in a batch (speculative mode,
+    host-driven loop): end state = the oracle's, bit for bit."""
     from pdp.factorgraph import dataset
     monkeypatch.setenv('PDP_SOLVE_TEAM_WIDE_EDGES', '10000')
+    if threads:
+        monkeypatch.setenv('PDP_SOLVE_TEAM_THREADS', threads)
     items = [dataset.random_ksat_items(1, 2600 + 150 * i, 3, m=int(3.5 * (2600 + 150 * i)), seed=4300 + i)[0] for i in range(n_big)]
     b = dataset.collate_segment(items)
     hp, res, q, fs, am, iters, used_lds, spec_ok = run_pair(oracle, b, 60, 0.05, 8)
