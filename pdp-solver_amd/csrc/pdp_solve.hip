@@ -1498,12 +1498,14 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
                 float opp = (0.5f * (1.0f - s)) * pos + (0.5f * (1.0f + s)) * neg;
                 if constexpr (FORCE) opp = opp + ((force == -s) ? L1 : L0);
                 const f4v ex = exp4_fin_le30((f4v){agg, same + opp, same, opp});
-                const float eta_new = 1.0f * ex.x + (1.0f - 1.0f) * eta_old;
+                // mask * new + (1 - mask) * old with mask == 1: (+0) * old + new as ONE fused operation -- the product is an exact zero (or NaN),
+                // so fusing rounds nothing differently; the unfused form is a multiply and an add per slot
+                const float eta_new = __builtin_fmaf(1.0f - 1.0f, eta_old, ex.x);
                 const float dc = ex.y;
                 const float A = ex.z, Bv = ex.w;
                 const float qu = A * (1.0f - Bv), qs = Bv * (1.0f - A);
                 const float total = (qu + qs) + dc;
-                const float qu_new = 1.0f * (qu / total) + (1.0f - 1.0f) * QU[p];
+                const float qu_new = __builtin_fmaf(1.0f - 1.0f, QU[p], qu / total);
                 nan_acc = nan_acc + (eta_new - eta_new);     // stays 0 unless a survey is NaN (surveys are <= 1)
                 QU[p] = qu_new;
                 Enew[p] = eta_new;
