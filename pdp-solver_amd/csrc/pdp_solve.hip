@@ -1491,11 +1491,16 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
                 const float agg = S[c] - X[p];                  // the reference's 0 + S is a no-op: a sum that starts at +0 is never -0
                 const float force = RF ? frc_of(pw) : (FORCE ? L.FRC[p] : 0.0f);
                 const float pos = Pv[v], neg = Nv[v];
-                float same = (0.5f * (1.0f + s)) * pos + (0.5f * (1.0f - s)) * neg;
+                // The reference's (0.5 (1 + s)) * pos + (0.5 (1 - s)) * neg has coefficients 1 and 0: one product is the sum itself, the other an
+                // exact zero.  R1 stores Pv / Nv so that they are never -0 (sums that start at +0), never infinite (sums of clamped logs) and NaN
+                // only together (each gets 0 * the other): x + (+-0) == x then, so the expression is the SELECTED sum -- two selects on the slot's
+                // sign bit instead of the coefficient arithmetic, two packed multiplies and the adds.
+                const bool neg_lit = (pw & 0x8000u) != 0;
+                float same = neg_lit ? neg : pos;
                 same = same - Y[p];
                 // without an external force both log terms are log(1) = +0: adding it can only turn a -0 into +0, which exp ignores
                 if constexpr (FORCE) same = same + ((force == s) ? L1 : L0);
-                float opp = (0.5f * (1.0f - s)) * pos + (0.5f * (1.0f + s)) * neg;
+                float opp = neg_lit ? pos : neg;
                 if constexpr (FORCE) opp = opp + ((force == -s) ? L1 : L0);
                 const f4v ex = exp4_fin_le30((f4v){agg, same + opp, same, opp});
                 // mask * new + (1 - mask) * old with mask == 1: (+0) * old + new as ONE fused operation -- the product is an exact zero (or NaN),
@@ -1506,7 +1511,7 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
                 const float qu = A * (1.0f - Bv), qs = Bv * (1.0f - A);
                 const float total = (qu + qs) + dc;
                 const float qu_new = __builtin_fmaf(1.0f - 1.0f, QU[p], qu / total);
-                nan_acc = nan_acc + (eta_new - eta_new);     // stays 0 unless a survey is NaN (surveys are <= 1)
+                nan_acc = __builtin_fmaf(0.0f, eta_new, nan_acc);  // stays 0 unless a survey is NaN (surveys are <= 1, never infinite)
                 QU[p] = qu_new;
                 Enew[p] = eta_new;
                 if (has_prev) {
