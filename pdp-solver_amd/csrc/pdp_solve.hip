@@ -901,7 +901,10 @@ __device__ __forceinline__ f4v exp4_fin_le30(f4v x)
 
 __device__ __forceinline__ f4v log4_fin(f4v x, float eps)
 {
-    const f4v xm = __builtin_elementwise_max(x, (f4v)(eps));
+    // max(x, eps) on the bit patterns: for x >= +0 the integer order is the float order, a negative x (or -0) is a negative integer and gives
+    // eps like the float maximum, and whatever a NaN gives is replaced by the re-injection at the end -- one instruction per element, where
+    // the float maximum of a value loaded from memory costs a canonicalisation first
+    const f4v xm = __builtin_bit_cast(f4v, __builtin_elementwise_max(__builtin_bit_cast(i4v, x), __builtin_bit_cast(i4v, (f4v)(eps))));
     f4v m; i4v e;
     m.x = __builtin_amdgcn_frexp_mantf(xm.x); m.y = __builtin_amdgcn_frexp_mantf(xm.y); m.z = __builtin_amdgcn_frexp_mantf(xm.z); m.w = __builtin_amdgcn_frexp_mantf(xm.w);
     e.x = __builtin_amdgcn_frexp_expf(xm.x); e.y = __builtin_amdgcn_frexp_expf(xm.y); e.z = __builtin_amdgcn_frexp_expf(xm.z); e.w = __builtin_amdgcn_frexp_expf(xm.w);
@@ -934,7 +937,7 @@ typedef int i2v __attribute__((ext_vector_type(2)));
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2v log2_fin(f2v x, float eps)             // two-wide twin of log4_fin for the ragged last trip
 {
-    const f2v xm = __builtin_elementwise_max(x, (f2v)(eps));
+    const f2v xm = __builtin_bit_cast(f2v, __builtin_elementwise_max(__builtin_bit_cast(i2v, x), __builtin_bit_cast(i2v, (f2v)(eps))));
     f2v m; i2v e;
     m.x = __builtin_amdgcn_frexp_mantf(xm.x); m.y = __builtin_amdgcn_frexp_mantf(xm.y);
     e.x = __builtin_amdgcn_frexp_expf(xm.x); e.y = __builtin_amdgcn_frexp_expf(xm.y);
