@@ -695,13 +695,14 @@ __global__ void __launch_bounds__(NTN, 6) k_agg_post_pf(int E, const float *__re
     }
 }
 
-// ---- kernel 3 with a WAVE as the unit of work (config 3's shapes; opt-in: PDP_NEURAL_POST_WAVE) ------------------------------------------------
+// ---- kernel 3 with a WAVE as the unit of work (default at hidden 150, opt-in at hidden 128: PDP_NEURAL_POST_WAVE) ---------------------------
 // The form that made the hidden-150 GRU fast, tried on the post-transform: a wave owns a 32-edge tile (four waves per workgroup, one per
 // SIMD, 512 registers per lane), both layers run over all their column blocks as straight-line chains whose weights are requested two
 // chunks ahead across the layer and tile boundaries, and everything the tile reads from HBM is requested at the start of an activation
 // phase a whole phase before it is used (the gathered rows of the NEXT tile and the previous-state rows of this one in front of the hidden
 // layer's logsigmoids, the first two chunks of the next chain's weights in front of them: vector-memory results return in issue order).
-// Bit-identical, and SLOWER than k_agg_post_pf: 8.5 against 7.5 ms per call.  Measured with one piece compiled out: MFMA chains + tile
+// Bit-identical.  At hidden 128 SLOWER than k_agg_post_pf: 8.5 against 7.5 ms per call (at hidden 150, where that kernel's ten output blocks
+// take two rounds of its eight waves, 9.8 against 10.2 ms).  Measured with one piece compiled out: MFMA chains + tile
 // bookkeeping 4.6 ms (floor 3.1), logsigmoids 2.8, HBM requests 1.1 (their round trip is longer than the 3.6 us activation phase when all
 // waves of the chip burst at once; moving the row gather in front of the second activation phase changes nothing), stores 0.3 -- this
 // kernel's tile is too short (304 MFMAs, 8 us) for one wave per SIMD to cover its own memory traffic, which six waves per SIMD do for free.
@@ -1492,8 +1493,11 @@ extern "C" int pdp_neural_aggregate_edges(pdp_problem *p, const pdp_agg_desc *d,
     const bool post_plain = getenv("PDP_NEURAL_POST_PLAIN") != nullptr;
     pdp_timed_scope timed_post(PDP_TK_AGG_POST, st);
     const bool shape_pf = w.Kp3 == 52 && w.Np3 == 128 && w.Kp4 == 100 && ((w.Np4 == 128 && w.out == 128) || (w.Np4 == 160 && w.out == 150));
-    if (!post_res && !post_plain && shape_pf && getenv("PDP_NEURAL_POST_WAVE") && (int64_t)R * w.a * 4 < ((int64_t)1 << 31) && E >= WT) {
-        // opt-in (measured slower, see the kernel's comment): a wave per 32-edge tile on the full tiles, the workgroup-tile kernel on the ragged tail
+    // the wave-per-tile form: default at hidden 150 (five output column blocks leave two of eight waves busy in the workgroup kernel's second
+    // round: 10.2 -> 9.8 ms per call), opt-in at hidden 128 where it is slower (PDP_NEURAL_POST_WAVE; PDP_NEURAL_POST_PF forces the other form)
+    const bool post_wave = getenv("PDP_NEURAL_POST_WAVE") != nullptr || (w.out == 150 && getenv("PDP_NEURAL_POST_PF") == nullptr);
+    if (!post_res && !post_plain && shape_pf && post_wave && (int64_t)R * w.a * 4 < ((int64_t)1 << 31) && E >= WT) {
+        // a wave per 32-edge tile on the full tiles, the workgroup-tile kernel on the ragged tail
         const int full = E / WT, tail = E - full * WT;
         const size_t ldsw = sizeof(float) * 4 * (size_t)(WT * (53 + 129) + WT);
         const int wgs = (full + 3) / 4;

@@ -25,8 +25,12 @@ def dev_agg(w, fd):
                                            (128, 100, 50, 100, -2), (150, 100, 50, 100, -1)])
 def test_aggregator_gru_predict_bit_exact(oracle, monkeypatch, H, m1, a, g, grid):
     from pdp import native
-    if grid and grid < 0:   # the opt-in wave-per-tile forms: post-transform (PDP_NEURAL_POST_WAVE), GRU cell at hidden 128 (PDP_NEURAL_GRU_WAVE)
-        monkeypatch.setenv('PDP_NEURAL_POST_WAVE', '1'); monkeypatch.setenv('PDP_NEURAL_GRU_WAVE', '1')
+    if grid and grid < 0:   # the forms that are not the default of their width: at hidden 128 the wave-per-tile post-transform and GRU cell
+        # (PDP_NEURAL_POST_WAVE, PDP_NEURAL_GRU_WAVE), at hidden 150 the workgroup-tile post-transform and the window GRU kernel
+        if H == 150:
+            monkeypatch.setenv('PDP_NEURAL_POST_PF', '1'); monkeypatch.setenv('PDP_NEURAL_GRU_WINDOW', '1')
+        else:
+            monkeypatch.setenv('PDP_NEURAL_POST_WAVE', '1'); monkeypatch.setenv('PDP_NEURAL_GRU_WAVE', '1')
         grid = -grid
     if grid:          # persistent kernels: many tiles per workgroup (cross-tile prefetch and the pipelined GRU's carried epilogue)
         monkeypatch.setenv('PDP_NEURAL_GRID', str(grid))
