@@ -761,17 +761,23 @@ struct WaveChains {
     }
 };
 
-template <int S3, int NB3, int S4, int NB4>
-__global__ void __launch_bounds__(256) k_agg_post_wave(int E, const float *__restrict__ agg, int agg_rows, const int32_t *__restrict__ edge_row,
+// NW = 4: one wave per SIMD, separate input / hidden regions, everything of the next tile requested a phase ahead.  NW = 8: two waves per
+// SIMD (256 registers each) -- the input block shares the hidden layer's region (it is dead when the hidden layer is written, and the next
+// tile's is dropped in after the output chain has read the hidden layer), the previous-state rows are requested in front of the hidden
+// layer's activations and the next tile's rows in front of the output layer's, and the other wave of the SIMD covers what is still exposed.
+template <int S3, int NB3, int S4, int NB4, int NW>
+__global__ void __launch_bounds__(64 * NW) k_agg_post_wave(int E, const float *__restrict__ agg, int agg_rows, const int32_t *__restrict__ edge_row,
                                                        const float *__restrict__ h2, const float *__restrict__ sign,
                                                        const float *__restrict__ emask, const float *__restrict__ rowmask,
                                                        const float *__restrict__ old, AggW w, float *__restrict__ out, int ntiles /* full 32-edge tiles */)
 {
     static_assert(2 * S3 <= 64, "one lane per input column");
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    constexpr int ld0 = 2 * S3 + 1, ld1 = 32 * NB3 + 1, WR = WT * (ld0 + ld1) + WT;
+    constexpr bool LATE = NW == 8;
+    constexpr int ld0 = 2 * S3 + 1, ld1 = 32 * NB3 + 1, WR = (LATE ? WT * ld1 : WT * (ld0 + ld1)) + WT;
+    static_assert(ld0 <= ld1, "the input block fits the hidden layer's region");
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, i = l & 31, kh = l >> 5;
-    float *Rt = sm + wave * WR, *G1 = Rt + WT * ld0, *Mk = G1 + WT * ld1;
+    float *Rt = sm + wave * WR, *G1 = LATE ? Rt : Rt + WT * ld0, *Mk = G1 + WT * ld1;
     const int A = w.a, ROWA = A * (int)sizeof(float), ROWB = w.out * (int)sizeof(float);
     WaveChains<S3, NB3, 32 * NB3> c3;
     WaveChains<S4, NB4, 32 * NB4> c4;
@@ -813,8 +819,8 @@ __global__ void __launch_bounds__(256) k_agg_post_wave(int E, const float *__res
             if (l < WT) Mk[l] = pmk;
         }
     };
-    const int stride = gridDim.x * 4;
-    int tile = blockIdx.x * 4 + wave;
+    const int stride = gridDim.x * NW;
+    int tile = blockIdx.x * NW + wave;
     if (tile < ntiles) {
         fetch_ids(tile);
         c3.head_w();
@@ -832,13 +838,17 @@ __global__ void __launch_bounds__(256) k_agg_post_wave(int E, const float *__res
         const __amdgpu_buffer_rsrc_t pb = tile_rsrc(old, e0, ROWB), ob = tile_rsrc(out, e0, ROWB);
         const int lo = 4 * kh * ROWB + i * (int)sizeof(float);
         float po[NB4][16];
-#pragma unroll
-        for (int nb = 0; nb < NB4; ++nb)
+        auto load_po = [&](int nb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 po[nb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pb, (32 * nb + i < w.out) ? lo + nb * 128 : 0x40000000, ((r & 3) + 8 * (r >> 2)) * ROWB, 0));
+        };
+        if (!LATE) {
+#pragma unroll
+            for (int nb = 0; nb < NB4; ++nb) load_po(nb);
+        }
         const bool more = tile + stride < ntiles;
-        if (more) { fetch_rows(tile + stride); if (tile + 2 * stride < ntiles) fetch_ids(tile + 2 * stride); }
+        if (!LATE && more) { fetch_rows(tile + stride); if (tile + 2 * stride < ntiles) fetch_ids(tile + 2 * stride); }
 #pragma unroll
         for (int nb = 0; nb < NB3; ++nb) {
             const int col = 32 * nb + i;
@@ -853,8 +863,10 @@ __global__ void __launch_bounds__(256) k_agg_post_wave(int E, const float *__res
         float mk[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) mk[r] = rowmask ? Mk[4 * kh + (r & 3) + 8 * (r >> 2)] : 1.0f;
+        if (LATE) load_po(0);                              // NW = 8: the previous-state rows one output block ahead
 #pragma unroll
         for (int nb = 0; nb < NB4; ++nb) {
+            if (LATE && nb + 1 < NB4) load_po(nb + 1);
             const int so = (32 * nb + i < w.out) ? lo + nb * 128 : 0x40000000;      // a column past the row is stored nowhere
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -863,6 +875,9 @@ __global__ void __launch_bounds__(256) k_agg_post_wave(int E, const float *__res
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        // (NW = 8: 256 registers do not hold the next tile's rows next to the output accumulators and the previous-state rows -- they are
+        //  requested here and dropped in as they arrive; the SIMD's other wave runs meanwhile)
+        if (LATE && more) { fetch_rows(tile + stride); if (tile + 2 * stride < ntiles) fetch_ids(tile + 2 * stride); }
         if (more) deposit();                               // every chain has consumed its operands (LDS operations of a wave complete in order)
     }
 }
@@ -1499,28 +1514,32 @@ extern "C" int pdp_neural_aggregate_edges(pdp_problem *p, const pdp_agg_desc *d,
     if (!post_res && !post_plain && shape_pf && post_wave && (int64_t)R * w.a * 4 < ((int64_t)1 << 31) && E >= WT) {
         // a wave per 32-edge tile on the full tiles, the workgroup-tile kernel on the ragged tail
         const int full = E / WT, tail = E - full * WT;
-        const size_t ldsw = sizeof(float) * 4 * (size_t)(WT * (53 + 129) + WT);
-        const int wgs = (full + 3) / 4;
+        const bool eight = getenv("PDP_NEURAL_POST_WAVE8") != nullptr;            // two waves per SIMD (the input block shares the hidden layer's region)
+        const int nwv = eight ? 8 : 4;
+        const size_t ldsw = sizeof(float) * nwv * (size_t)(WT * (eight ? 129 : 53 + 129) + WT);
+        const int wgs = (full + nwv - 1) / nwv;
         const int grid = wgs < persistent_grid() ? wgs : persistent_grid();
         const size_t ldsp = sizeof(float) * (size_t)TM * (53 + 129);
         const size_t o = (size_t)full * WT;
+#define PDP_POST_WAVE_LAUNCH(NB4_, NW_) \
+        { s = set_lds((const void *)k_agg_post_wave<26, 4, 50, NB4_, NW_>, ldsw); if (s != PDP_OK) return s; \
+          hipLaunchKernelGGL((k_agg_post_wave<26, 4, 50, NB4_, NW_>), dim3(grid), dim3(64 * NW_), ldsw, st, E, agg, R, edge_row, h2, p->edge_sign, edge_mask, rowmask, old, w, out, full); }
         if (w.Np4 == 128) {
-            s = set_lds((const void *)k_agg_post_wave<26, 4, 50, 4>, ldsw); if (s != PDP_OK) return s;
-            hipLaunchKernelGGL((k_agg_post_wave<26, 4, 50, 4>), dim3(grid), dim3(256), ldsw, st, E, agg, R, edge_row, h2, p->edge_sign, edge_mask, rowmask, old, w, out, full);
+            if (eight) PDP_POST_WAVE_LAUNCH(4, 8) else PDP_POST_WAVE_LAUNCH(4, 4)
             if (tail > 0) {
                 s = set_lds((const void *)k_agg_post_pf<26, 4, 50, 4>, ldsp); if (s != PDP_OK) return s;
                 hipLaunchKernelGGL((k_agg_post_pf<26, 4, 50, 4>), dim3(1), dim3(NTN), ldsp, st, tail, agg, edge_row + o, h2 + o * w.a, p->edge_sign + o,
                                    edge_mask ? edge_mask + o : nullptr, rowmask + o, old + o * w.out, w, out + o * w.out);
             }
         } else {
-            s = set_lds((const void *)k_agg_post_wave<26, 4, 50, 5>, ldsw); if (s != PDP_OK) return s;
-            hipLaunchKernelGGL((k_agg_post_wave<26, 4, 50, 5>), dim3(grid), dim3(256), ldsw, st, E, agg, R, edge_row, h2, p->edge_sign, edge_mask, rowmask, old, w, out, full);
+            if (eight) PDP_POST_WAVE_LAUNCH(5, 8) else PDP_POST_WAVE_LAUNCH(5, 4)
             if (tail > 0) {
                 s = set_lds((const void *)k_agg_post_pf<26, 4, 50, 5>, ldsp); if (s != PDP_OK) return s;
                 hipLaunchKernelGGL((k_agg_post_pf<26, 4, 50, 5>), dim3(1), dim3(NTN), ldsp, st, tail, agg, edge_row + o, h2 + o * w.a, p->edge_sign + o,
                                    edge_mask ? edge_mask + o : nullptr, rowmask + o, old + o * w.out, w, out + o * w.out);
             }
         }
+#undef PDP_POST_WAVE_LAUNCH
     } else if (!post_res && !post_plain && shape_pf) {
         // hidden 128 (BASELINE configs) or 150 (the reference's shipped predict config) with the 100 / 50 inner widths
         const size_t ldsp = sizeof(float) * (size_t)TM * (53 + 129);
