@@ -1200,12 +1200,15 @@ __device__ __noinline__ int lds_reinforce_step(unsigned char *smem, int n, int m
         __syncthreads();
     }
     const float Lpi = pdp_safe_log(1.0f - pi, PDP_SCORER_EPS), L0 = pdp_safe_log(1.0f - pi * 0.0f, PDP_SCORER_EPS);
+    uint32_t *const codev = reinterpret_cast<uint32_t *>(L.xv2);      // per-variable force code of a renewal (xv2 is free outside the decimation)
     for (int i = tid; i < n; i += nt) {
         const int v = L.vord[i];
         const int a = L.v_ptr[v], bnd = L.v_ptr[v + 1];
-        float ext = 0.0f;
+        float pred;
         if (do_force) {
-            float pos = 0.0f, neg = 0.0f, all = 0.0f;
+            // the only ORDERED part of the renewal is the score's sums (ascending slot = ascending edge id); writing the new force to the
+            // variable's slots is a slot-parallel pass below, and the predictor's sum of the new force is deg * sign exactly
+            float ext = 0.0f, pos = 0.0f, neg = 0.0f, all = 0.0f;
             for (int p = a; p < bnd; ++p) {
                 const float f = L.Y[p];
                 const uint16_t pw = L.pvv[p];
@@ -1218,15 +1221,24 @@ __device__ __noinline__ int lds_reinforce_step(unsigned char *smem, int n, int m
             const float sc = lds_score_of(pos, neg, all, ext, Lpi, L0);
             if (sc != sc) bad = 1;
             const float sg = 0.0f + pdp_sign(sc);                   // torch.sign(NaN) is 0
-            const uint16_t code = (uint16_t)(frc_enc(sg) << PV_FRC_SHIFT);
-            // mask * sign + (1 - mask) * old with mask == 1 (old is finite here); X keeps the force the last sweep read
-            for (int p = a; p < bnd; ++p) { const uint16_t pw = L.pvv[p]; L.X[p] = frc_of(pw); L.pvv[p] = (uint16_t)((pw & ~PV_FRC_MASK) | code); }
+            codev[v] = frc_enc(sg) << PV_FRC_SHIFT;
+            pred = (sg > 0.0f && bnd > a) ? 1.0f : 0.0f;
+        } else {
+            float ext = 0.0f;
+            for (int p = a; p < bnd; ++p) ext = ext + frc_of(L.pvv[p]);
+            pred = (ext > 0.0f) ? 1.0f : 0.0f;
         }
-        ext = 0.0f;
-        for (int p = a; p < bnd; ++p) ext = ext + frc_of(L.pvv[p]);
-        const float pred = (ext > 0.0f) ? 1.0f : 0.0f;
         const float av = L.av[v];
         if (av == 1.0f) L.sol[v] = av * pred + (1.0f - av) * L.sol[v];      // only active variables take the prediction (solver.py:395-397)
+    }
+    if (do_force) {
+        __syncthreads();
+        // mask * sign + (1 - mask) * old with mask == 1 (old is finite here); X keeps the force the last sweep read
+        for (int p = tid; p < ne; p += nt) {
+            const uint16_t pw = L.pvv[p];
+            L.X[p] = frc_of(pw);
+            L.pvv[p] = (uint16_t)((pw & ~PV_FRC_MASK) | codev[pw & PV_VMASK_RF]);
+        }
     }
     return __syncthreads_or(bad);
 }
