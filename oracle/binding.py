@@ -244,7 +244,10 @@ class Problem(object):
                    rand_consumed=np.zeros(1, np.int64), walksat_steps=np.zeros(1, np.int32))
         for k in ('prediction', 'q', 'fs', 'iterations_run', 'rand_consumed', 'walksat_steps'):
             setattr(a, k, _p(res[k]))
-        if trace:
+        if trace == 'mask':                  # the per-sweep instance mask only (T*B bytes: affordable at full size)
+            res['trace_active_mask'] = np.zeros((T, self.B), np.uint8)
+            a.trace_active_mask = _p(res['trace_active_mask'])
+        elif trace:
             res['trace_active_var'] = np.zeros((T, self.V), np.float32)
             res['trace_active_fn'] = np.zeros((T, self.F), np.float32)
             res['trace_solution'] = np.zeros((T, self.V), np.float32)

@@ -151,9 +151,16 @@ class FactorGraphTrainerBase(object):
         return self._model_list, errors, losses
 
     def _predict_epoch(self, validation_loader, post_processor, batch_replication, file):
+        from pdp import parallel
+        base_seed = int(self._config.get('random_seed', 0) or 0)
         with torch.no_grad():
             for data in validation_loader:
+                # global index of this loader batch (the same whatever the rank count): keys the device-side random numbers
+                j = getattr(getattr(validation_loader, 'dataset', None), 'batch_index', 0)
                 for i in range(len(data[0])):
+                    for model in self._model_list:
+                        if hasattr(model, 'set_random_key'):
+                            model.set_random_key(parallel.batch_seed(base_seed, j, i))
                     (graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, label, misc_data) = \
                         [self._to_cuda(d[i]) for d in data]
                     self._predict_batch(graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat,
@@ -247,13 +254,19 @@ class FactorGraphTrainerBase(object):
         """Produces predictions for a (trained) PDP model (reference: base.py:451-472).
 
         Under ``torch.distributed`` (one process per GPU, ``python -m torch.distributed.run --nproc-per-node N satyr.py ...``) every rank
-        solves a contiguous shard of the instances on its own GPU -- no collective on the data path -- and the ranks meet once: an
-        all-reduce(sum) of [instances, solved, unsat clauses] and a rank-ordered gather of the result rows, which rank 0 writes.  Each
-        shard is solved as a single-process run of that shard with the same seed would solve it."""
+        forms the loader batches of the single-process run and solves a contiguous range of WHOLE batches on its own GPU -- no collective
+        on the data path -- and the ranks meet once: an all-reduce(sum) of [instances, solved, unsat clauses] and a rank-ordered gather
+        of the result rows, which rank 0 writes.  The loader batch is the reference's coupling domain (batch-global minima, NaN
+        poisoning, dynamic segments) and the random numbers are keyed by the global batch index, so the rows are those of the
+        single-process run whatever the rank count.  That needs the counter-based generator: the reference's one sequential CPU stream
+        (``rng='torch'``) is consumed batch after batch in data-dependent amounts and cannot be split, so it is refused for N > 1."""
         import io
         from pdp import parallel
         world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
         rank = torch.distributed.get_rank() if world > 1 else 0
+        if world > 1 and self._config.get('rng', 'torch') != 'philox':
+            raise native.NativeError("a run on %d ranks needs --rng philox: the reference's sequential CPU random stream (--rng torch) "
+                                     "cannot be dealt to ranks without changing the rows" % world)
         test_loader = FactorGraphDataset.get_loader(
             input_file=test_list, limit=self._config['test_batch_limit'], hidden_dim=self._config['hidden_dim'],
             batch_size=self._config['batch_size'], shuffle=False, num_workers=0,

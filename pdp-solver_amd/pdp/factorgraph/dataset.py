@@ -153,18 +153,10 @@ class FactorGraphDataset(object):
         else:
             with open(input_file, 'r') as f:
                 self._lines = [l for l in f.read().split('\n') if l.strip()]
-        self.shard_offset = 0
-        if shard is not None and shard[1] > 1 and generator is None:
-            # one process per GPU: this rank keeps a contiguous range of the instances, balanced by input size (file size / line
-            # length as the proxy of the edge count -- no rank parses the others' instances)
-            from pdp import parallel
-            rank, world = shard
-            weights = [os.path.getsize(pth) for pth, _ in self._dimacs] if self._dimacs is not None else [len(l) for l in self._lines]
-            lo, hi = parallel.shard_bounds(weights, world)[rank]
-            self._lines = self._lines[lo:hi]
-            if self._dimacs is not None:
-                self._dimacs = self._lines
-            self.shard_offset = lo
+        # one process per GPU: the loader forms the SAME batches as a single-process run and this rank iterates a contiguous range of
+        # them (pdp/parallel.py: a loader batch is the reference's coupling domain and is never split across ranks)
+        self._shard = tuple(shard) if shard is not None and shard[1] > 1 and generator is None else None
+        self.batch_index = 0          # global index of the loader batch handed out last (keys the Philox streams)
         self._limit = limit
         self._hidden_dim = hidden_dim
         self._batch_replication = batch_replication
@@ -185,10 +177,30 @@ class FactorGraphDataset(object):
             self._cache[idx] = item
         return item
 
-    def batches(self, batch_size, order=None):
-        """Yields lists of segment batches, ``batch_size`` instances per loader batch (``order``: the sampler's permutation)."""
+    def _weight(self, i):
+        "input bytes of instance i: the proxy of its edge count that needs no parsing"
+        import os
+        return os.path.getsize(self._dimacs[i][0]) if self._dimacs is not None else len(self._lines[i])
+
+    def batch_range(self, batch_size, order=None):
+        "[lo, hi) of the global loader-batch indices this process iterates (everything without a shard)"
         order = list(range(len(self))) if order is None else list(order)
-        for start in range(0, len(order), batch_size):
+        starts = list(range(0, len(order), batch_size))
+        if self._shard is None:
+            return 0, len(starts)
+        from pdp import parallel
+        rank, world = self._shard
+        weights = [sum(self._weight(i) for i in order[s:s + batch_size]) for s in starts]
+        return parallel.deal_batches(weights, world)[rank]
+
+    def batches(self, batch_size, order=None):
+        """Yields lists of segment batches, ``batch_size`` instances per loader batch (``order``: the sampler's permutation); sets
+        ``self.batch_index`` to the batch's global index before each yield.  A sharded data set yields its own range of batches only."""
+        order = list(range(len(self))) if order is None else list(order)
+        lo, hi = self.batch_range(batch_size, order)
+        for j in range(lo, hi):
+            start = j * batch_size
+            self.batch_index = j
             idx = order[start:start + batch_size]
             if self._dimacs is not None and len(idx) > 1:
                 # DIMACS files: one call parses the batch's files with a few host threads inside the native library

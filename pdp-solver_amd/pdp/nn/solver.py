@@ -151,6 +151,13 @@ class PropagatorDecimatorSolverBase(nn.Module):
     def parameter_count(self):
         return sum(p.numel() for p in self.parameters() if p.requires_grad)
 
+    def set_random_key(self, seed):
+        """Key of the device-side (Philox) random numbers of the next forward: the predict driver derives it from the run's seed and the
+        global (loader batch, segment) index, so a batch draws the same numbers on whichever rank it is solved."""
+        self._seed = int(seed)
+        if hasattr(self._predictor, '_seed'):
+            self._predictor._seed = int(seed)
+
     def save(self, export_path_base):
         torch.save(self.state_dict(), os.path.join(export_path_base, self._name))
 

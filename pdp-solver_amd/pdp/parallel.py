@@ -1,10 +1,19 @@
-"""Instance-sharded data parallelism: one process per GPU, no collective on the data path.
+"""Batch-sharded data parallelism: one process per GPU, no collective on the data path.
 
 The reference has no working multi-GPU path (``nn.DataParallel`` would scatter ``graph_map`` along dim 0, SURVEY.md
-App. B-13).  Every PDP computation is local to one CNF instance, so a batch shards by instances: each rank solves a
-contiguous range of instances (balanced by edge count) completely on its own GPU and the ranks meet exactly once, in
-an all-reduce(sum) of ``[instances, solved, unsat clauses]`` -- in test mode of the metric sums ``[accuracy, recall, loss]`` and the
-example count -- (RCCL over xGMI on a node: ``backend='nccl'``; the tests use ``gloo`` on CPU).  Result rows are gathered in rank order by the caller if it wants them.
+App. B-13).  No message crosses an instance boundary, but the reference couples the instances of one *loader batch* (base.py:252-278
+loops the DataLoader's batches, dataset.py:189-211): batch-global minima inside sparse_max / argmax, one NaN survey that stops the
+decimation of the whole batch, the dynamic segments cut from the batch's edge counts (dataset.py:36-72).  The unit
+that is dealt to ranks is therefore the WHOLE LOADER BATCH: the loader forms the same batches (and the same segments) whatever the
+rank count, rank r solves a contiguous range of them (``deal_batches``, balanced by input size) completely on its own GPU, random
+numbers are keyed by the global batch / segment index (``batch_seed``), and the ranks meet exactly once, in an all-reduce(sum) of
+``[instances, solved, unsat clauses]`` -- in test mode of the metric sums ``[accuracy, recall, loss]`` and the example count -- (RCCL
+over xGMI on a node: ``backend='nccl'``; the tests use ``gloo``).  Result rows are gathered in rank order, which is batch order.  An
+N-rank run therefore writes exactly the rows of the 1-rank run (tests/test_parallel_gloo.py, tests/test_sharded_gpu.py).
+BASELINE configs[3]: 40 000 instances with ``-z 5000`` are 8 loader batches, one per GPU.
+
+``shard_bounds`` / ``shard_items`` cut ONE batch by instances; only bench.py uses that (its synthetic batch has no loader and is timed
+in ``--isolated``-equivalent weak scaling: every rank generates its own B instances).
 """
 
 import numpy as np
@@ -38,6 +47,19 @@ def shard_bounds(edge_counts, world_size):
         bounds.append((lo, hi))
         lo = hi
     return bounds
+
+
+def deal_batches(batch_weights, world_size):
+    """Contiguous ranges [lo, hi) of loader-batch indices per rank, balanced by the batches' weights (input bytes as the proxy of the
+    edge count -- no rank parses another rank's instances).  Contiguous, so the rank-ordered gather of the rows is the loader's order.
+    With fewer batches than ranks the last ranks get an empty range: a batch is the reference's coupling domain and is never split."""
+    return shard_bounds(batch_weights, world_size)
+
+
+def batch_seed(seed, batch_index, segment_index=0):
+    """The 64-bit Philox key of segment ``segment_index`` of loader batch ``batch_index`` (global indices, the same on every rank
+    count).  (0, 0) keeps the run's seed, so a single-batch run draws what a direct ``forward`` call with that seed draws."""
+    return (int(seed) + 0x9E3779B97F4A7C15 * int(batch_index) + 0xC2B2AE3D27D4EB4F * int(segment_index)) & 0xFFFFFFFFFFFFFFFF
 
 
 def shard_items(items, rank, world_size):
@@ -80,14 +102,20 @@ def gather_rows(rows, group=None):
     return [r for part in out for r in part]
 
 
-def solve_sharded(items, solve_fn, rank=None, world_size=None, device=None):
-    """Run ``solve_fn(list_of_items) -> (solved [b] array-like, unsat [b] array-like, rows list)`` on this rank's shard and
-    reduce the counters.  ``solve_fn`` is the native forward in production and the CPU oracle in the gloo tests."""
+def solve_sharded(batches, solve_fn, rank=None, world_size=None, device=None):
+    """``batches``: the loader batches of the run (lists of loader items), the same list on every rank.  Runs
+    ``solve_fn(items, batch_index) -> (solved [b], unsat [b], rows list)`` on the batches dealt to this rank and reduces the counters;
+    returns (stats, all rows in loader order, this rank's [lo, hi) batch range).  ``solve_fn`` is the native forward in production and
+    the CPU oracle in the gloo tests."""
     if world_size is None:
         world_size = dist.get_world_size() if dist.is_initialized() else 1
     if rank is None:
         rank = dist.get_rank() if dist.is_initialized() else 0
-    mine, offset = shard_items(items, rank, world_size)
-    solved, unsat, rows = solve_fn(mine) if len(mine) else ([], [], [])
-    stats = reduce_stats(len(mine), float(np.sum(solved)), float(np.sum(unsat)), device=device)
-    return stats, gather_rows(rows), offset
+    lo, hi = deal_batches([sum(it[2].shape[1] for it in b) for b in batches], world_size)[rank]
+    n = n_solved = n_unsat = 0
+    rows = []
+    for j in range(lo, hi):
+        solved, unsat, r = solve_fn(batches[j], j)
+        n += len(batches[j]); n_solved += float(np.sum(solved)); n_unsat += float(np.sum(unsat)); rows += list(r)
+    stats = reduce_stats(n, n_solved, n_unsat, device=device)
+    return stats, gather_rows(rows), (lo, hi)

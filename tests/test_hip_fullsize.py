@@ -1,6 +1,7 @@
 """Full-size checks on the headline workload (BASELINE.json configs[1]: random 3-SAT n=200 m=840, batch 5000, T=100).
 
-The CPU oracle needs minutes for this batch, so parity at full size rests on properties that do not depend on the size:
+The workload bench.py times is compared with the ORACLE as a whole batch first (test_timed_workload_equals_the_oracle_on_the_whole_batch:
+one oracle process, about two minutes; Reinforce at B=1500), then through properties that do not depend on the size:
   * two independent implementations agree bit for bit: the persistent LDS-resident solver (one workgroup per instance,
     speculation + device-side NaN-poison replay) and the strict step-wise kernels (batch-wide semantics with global flag words);
     this batch is NaN-poisoned at iteration 81, so the replay machinery is exercised at scale;
@@ -40,6 +41,67 @@ def _solve(tb, T_, tol=0.02, t_max=100):
     dec = native.Decimator(hp)
     iters, lds = hp.sp_solve(q, fs, am, dec, T_, tol, t_max)
     return hp, q, fs, am, iters, lds
+
+
+def test_timed_workload_equals_the_oracle_on_the_whole_batch(big, oracle):
+    """bench.py's rank-0 batch (B=5000, n=200, m=840, T=100, tolerance 0.02, t_max 100) through pdp_sp_solve -- the call the headline number
+    times: chunked launches, NaN poison at sweep 81, device-side replay of the affected instances -- against the oracle's forward
+    (reference loop solver.py:355-386 with its batch-wide couplings) on the WHOLE batch in one process.  Everything bit for bit: messages,
+    active flags, solution, per-instance mask, executed sweeps; then the random fill with the same Philox key and the final prediction."""
+    items, host, tb = big
+    op = oracle.Problem(host['graph_map'], host['batch_variable_map'], host['batch_function_map'], host['edge_feature'])
+    res = op.forward('p-d-p', T, local_search_iterations=0, tolerance=0.02, t_max=100, seed=3, trace='mask')
+    av, af, sol, _ = op.state()                                        # after the loop and the random fill (key 3)
+    hp, q, fs, am, iters, lds = _solve(tb, T)
+    assert lds and iters == res['iterations_run'] == T
+    stats = hp.last_solve_stats
+    assert stats['replays'] > 0 and stats['hbm_instances'] == 0, stats  # the poison replay ran, every instance on the LDS-resident kernel
+    assert np.isnan(res['fs']).any()
+    np.testing.assert_array_equal(npy(q), res['q'])
+    np.testing.assert_array_equal(npy(fs), res['fs'])
+    np.testing.assert_array_equal(npy(am), res['trace_active_mask'][T - 1])
+    np.testing.assert_array_equal(npy(hp.active_variables).reshape(-1), av)
+    np.testing.assert_array_equal(npy(hp.active_functions).reshape(-1), af)
+    hp.random_fill(seed=3)
+    np.testing.assert_array_equal(npy(hp.solution).reshape(-1), sol)
+    pred = hp.update_solution(hp.solution.clone().reshape(-1).contiguous())
+    np.testing.assert_array_equal(npy(pred).reshape(-1), res['prediction'])
+    solved, unsat = hp.cnf_eval(pred.reshape(-1).contiguous())
+    o_solved, o_unsat = op.cnf_eval(res['prediction'])
+    np.testing.assert_array_equal(npy(solved).reshape(-1), o_solved.reshape(-1))
+    np.testing.assert_array_equal(npy(unsat).reshape(-1), o_unsat.reshape(-1))
+
+
+def test_reinforce_instantiation_equals_the_oracle_at_b1500(big, oracle):
+    """the persistent kernel's Reinforce instantiation (bench.py's secondary: pi 0.1, decimation probability 0.5) on the first 1 500
+    instances of the headline batch, T=100, against the oracle's loop with the same coins"""
+    from pdp import native
+    from pdp.factorgraph import dataset
+    items, _, _ = big
+    Br = 1500
+    host = dataset.collate_segment(items[:Br])
+    tb = dataset.to_torch(host, torch.device('cuda:0'))
+    coins = np.random.RandomState(11).rand(T).astype(np.float32)
+    op = oracle.Problem(host['graph_map'], host['batch_variable_map'], host['batch_function_map'], host['edge_feature'])
+    res = op.forward('reinforce', T, local_search_iterations=0, pi=0.1, decimation_probability=0.5, stream=coins, trace='mask')
+    av, af, sol, _ = op.state()
+    hp = native.Problem(tb['graph_map'], tb['batch_variable_map'], tb['batch_function_map'], tb['edge_feature'])
+    hp.simplify()
+    dev = torch.device('cuda:0')
+    q = torch.full((hp.E, 3), 1.0, device=dev) / 3.0
+    fs = torch.zeros(hp.E, 2, device=dev); fs[:, 0] = 0.5
+    am = torch.ones(hp.B, dtype=torch.uint8, device=dev)
+    iters, lds = hp.sp_solve(q, fs, am, native.Decimator(hp), T, 0.01, 0.0, pi=0.1, model=native.MODEL_REINFORCE,
+                             coins=torch.from_numpy(coins).to(dev), decimation_probability=0.5)
+    it = res['iterations_run']
+    assert lds and iters == it and res['rand_consumed'] == it
+    np.testing.assert_array_equal(npy(q), res['q'])
+    np.testing.assert_array_equal(npy(fs), res['fs'])
+    np.testing.assert_array_equal(npy(am), res['trace_active_mask'][it - 1])
+    np.testing.assert_array_equal(npy(hp.active_variables).reshape(-1), av)
+    np.testing.assert_array_equal(npy(hp.active_functions).reshape(-1), af)
+    np.testing.assert_array_equal(npy(hp.solution).reshape(-1), sol)
+    assert np.abs(res['fs'][:, 1]).sum() > 0
 
 
 def test_persistent_equals_stepwise_at_full_size(big):

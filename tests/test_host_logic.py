@@ -207,8 +207,9 @@ def test_native_dimacs_batch_reader(tmp_path):
         native.dimacs_parse_many(paths[:5] + [str(bad)] + paths[5:9], threads=3)
 
 
-def test_dataset_shards_cover_the_input_in_order(tmp_path):
-    "one process per GPU: every rank's loader keeps a contiguous range of the instances; together they cover the input once, in order"
+def test_dataset_deals_whole_loader_batches_to_ranks(tmp_path):
+    """one process per GPU: every rank's loader forms the batches of the single-process run and iterates a contiguous range of whole
+    batches; together the ranks cover every batch once, in order, with the global batch index the random key is derived from"""
     from pdp.factorgraph import dataset
     from pdp import generator
     lines = []
@@ -218,16 +219,20 @@ def test_dataset_shards_cover_the_input_in_order(tmp_path):
         lines.append(generator.json_line(n, cl, label=i % 2, name='x%d' % i))
     path = tmp_path / 'in.json'
     path.write_text("\n".join(lines) + "\n")
-    whole = dataset.FactorGraphDataset(str(path), 10 ** 9, 3)
-    for world in (2, 3, 8):
-        got, offs = [], []
-        for rank in range(world):
-            ds = dataset.FactorGraphDataset(str(path), 10 ** 9, 3, shard=(rank, world))
-            offs.append(ds.shard_offset)
-            got += [ds[i][5][0] for i in range(len(ds))]
-            assert len(ds) >= 1
-        assert got == [whole[i][5][0] for i in range(len(whole))]
-        assert offs == sorted(offs) and offs[0] == 0
+    ids = lambda segs: [[m[0] for m in s['misc_data']] for s in segs]
+    for z, limit in ((5, 10 ** 9), (4, 3 * 90 * 2)):                 # the second limit cuts every batch into dynamic segments
+        whole = dataset.FactorGraphDataset(str(path), limit, 3)
+        expected = [(whole.batch_index, ids(segs)) for segs in whole.batches(z)]
+        assert [j for j, _ in expected] == list(range((23 + z - 1) // z))
+        assert limit == 10 ** 9 or max(len(s) for _, s in expected) > 1
+        for world in (2, 3, 8):
+            got, ranges = [], []
+            for rank in range(world):
+                ds = dataset.FactorGraphDataset(str(path), limit, 3, shard=(rank, world))
+                ranges.append(ds.batch_range(z))
+                got += [(ds.batch_index, ids(segs)) for segs in ds.batches(z)]
+            assert got == expected
+            assert ranges[0][0] == 0 and ranges[-1][1] == len(expected) and all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
 
 
 def test_cnf_generators_reproduce_the_reference_for_a_seed():

@@ -1,6 +1,6 @@
-"""world_size-2 gloo tests (CPU): the instance sharder + the single all-reduce of the multi-GPU path.  The per-shard
-solve is the CPU oracle here (the checker standing in for the GPU forward), so the test pins the property the design
-relies on: sharding by instances gives the same per-instance results and the same totals as the unsharded run."""
+"""world_size-2 gloo tests (CPU): dealing whole loader batches to ranks + the single all-reduce of the multi-GPU path.  The per-batch
+solve is the CPU oracle here (the checker standing in for the GPU forward; its forward has the reference's batch-wide couplings), so
+the test pins the property the design relies on: an N-rank run writes the rows and totals of the 1-rank run."""
 import os
 import sys
 
@@ -30,15 +30,31 @@ def test_shard_bounds_cover_and_balance():
                 assert max(loads) <= edges.sum() / world + edges.max()
 
 
-def _oracle_solve(items):
+T_RUN, TOL_RUN, TMAX_RUN, W_RUN, SEED_RUN = 120, 0.05, 8, 20, 3
+
+
+def _run_items():
+    "60 instances = 5 loader batches of 12 (-z 12); batches 1, 2 and 3 hold instances whose surveys become NaN (SURVEY App. B-6)"
+    return dataset.random_ksat_items(60, 60, 3, seed=7000)
+
+
+def _run_batches(items, z=12):
+    return [items[s:s + z] for s in range(0, len(items), z)]
+
+
+def _oracle_solve(items, batch_index, want_nan=None):
+    """one loader batch through the oracle's strict (batch-coupled) p-d-p forward with the Philox key of that batch"""
     sys.path.insert(0, REPO)
     from oracle import binding
     b = dataset.collate_segment(items)
     p = binding.Problem(b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'])
-    res = p.forward('p-d-p', 25, local_search_iterations=20, tolerance=0.05, t_max=8, seed=3)
+    res = p.forward('p-d-p', T_RUN, local_search_iterations=W_RUN, tolerance=TOL_RUN, t_max=TMAX_RUN,
+                    seed=parallel.batch_seed(SEED_RUN, batch_index))
+    if want_nan is not None:
+        want_nan.append(bool(np.isnan(res['fs']).any()))
     solved, unsat = p.cnf_eval(res['prediction'])
     offs = np.concatenate(([0], np.cumsum([it[0] for it in items])))
-    rows = [(it[5][0], int(solved[i]), res['prediction'][offs[i]:offs[i + 1]].astype(int).tolist()) for i, it in enumerate(items)]
+    rows = [(it[5][0], int(solved[i]), int(unsat[i]), res['prediction'][offs[i]:offs[i + 1]].astype(int).tolist()) for i, it in enumerate(items)]
     return solved, unsat, rows
 
 
@@ -46,35 +62,55 @@ def _worker(rank, world, port, q):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    items = dataset.random_ksat_items(12, 30, 3, m=100, seed=4000)
-    stats, rows, offset = parallel.solve_sharded(items, _oracle_solve)
-    if rank == 0:
-        q.put((stats, rows))
+    stats, rows, (lo, hi) = parallel.solve_sharded(_run_batches(_run_items()), _oracle_solve)
+    q.put((rank, stats, rows, (lo, hi)))
     dist.destroy_process_group()
 
 
-def test_sharded_solve_equals_unsharded():
-    items = dataset.random_ksat_items(12, 30, 3, m=100, seed=4000)
+def test_sharded_run_writes_the_rows_of_the_unsharded_run():
+    """The property BASELINE's "identical solved-fraction at 8 GPUs" rests on: a run on N ranks = the run on one rank, row for row.
+    Five loader batches, three of them NaN-poisoned (there the reference's batch-wide couplings decide which variables are still
+    decimated, so the rows depend on which instances share a batch); two ranks deal WHOLE batches and key the random numbers by the global
+    batch index.  The expected rows come from one process that solves all five batches in order."""
+    items = _run_items()
+    batches = _run_batches(items)
+    nan_seen, exp_rows, exp_solved, exp_unsat = [], [], 0, 0
+    for j, b in enumerate(batches):
+        s, u, r = _oracle_solve(b, j, nan_seen)
+        exp_rows += r; exp_solved += int(np.sum(s)); exp_unsat += int(np.sum(u))
+    assert sum(nan_seen) >= 2, "the test input no longer poisons a batch: pick other seeds"
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000)
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    stats, rows = q.get(timeout=120)
+    got = sorted([q.get(timeout=300) for _ in range(2)], key=lambda x: x[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    # unsharded: every instance on its own (instance-local computation; Philox random numbers are indexed by the
-    # instance-local variable position only through the batch offset, so compare solved counts and per-instance solved flags
-    # of runs that see each instance with the same offsets: run the two shards here again, unsharded in-process)
-    lo_hi = parallel.shard_bounds([it[2].shape[1] for it in items], 2)
-    exp_rows, exp_solved, exp_unsat = [], 0, 0
-    for lo, hi in lo_hi:
-        s, u, r = _oracle_solve(items[lo:hi])
-        exp_rows += r; exp_solved += int(np.sum(s)); exp_unsat += int(np.sum(u))
-    assert stats == dict(instances=12, solved=exp_solved, unsat_clauses=exp_unsat, solved_fraction=exp_solved / 12.0)
-    assert rows == exp_rows
+    ranges = [g[3] for g in got]
+    assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == len(batches) and all(hi > lo for lo, hi in ranges)
+    for rank, stats, rows, _ in got:
+        assert stats == dict(instances=60, solved=exp_solved, unsat_clauses=exp_unsat, solved_fraction=exp_solved / 60.0)
+        assert rows == exp_rows
+    # the test is sensitive to the coupling domain: cutting the instance list per rank first (what a per-instance sharder does) and
+    # batching afterwards changes the rows of this input
+    lo, hi = parallel.shard_bounds([it[2].shape[1] for it in items], 2)[0]
+    cut_rows = []
+    for part in (items[lo:hi], items[hi:]):
+        for j, b in enumerate(_run_batches(part)):
+            cut_rows += _oracle_solve(b, j)[2]
+    assert [r[0] for r in cut_rows] == [r[0] for r in exp_rows] and cut_rows != exp_rows
+
+
+def test_deal_batches_and_batch_seed():
+    assert parallel.deal_batches([10, 10, 10], 2) in ([(0, 2), (2, 3)], [(0, 1), (1, 3)])
+    assert parallel.deal_batches([5], 3) == [(0, 1), (1, 1), (1, 1)]                 # a batch is never split: the other ranks stay idle
+    assert parallel.deal_batches([7] * 8, 8) == [(i, i + 1) for i in range(8)]       # configs[3]: 8 batches of 5000, one per GPU
+    assert parallel.batch_seed(42, 0, 0) == 42
+    keys = {parallel.batch_seed(42, j, i) for j in range(64) for i in range(8)}
+    assert len(keys) == 512 and all(0 <= k < 2 ** 64 for k in keys)
 
 
 def _metrics_worker(rank, world, port, q):
@@ -84,7 +120,7 @@ def _metrics_worker(rank, world, port, q):
     sys.path.insert(0, REPO)
     from oracle import binding
     items = dataset.random_ksat_items(10, 30, 3, m=100, seed=5000)
-    mine, _ = parallel.shard_items(items, rank, world)
+    mine, _ = parallel.shard_items(items, rank, world)           # (metrics are per-example sums: any partition reduces to the same means)
     b = dataset.collate_segment(mine)
     p = binding.Problem(b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'])
     pred = np.random.RandomState(7 + rank).rand(p.V).astype(np.float32)
