@@ -270,6 +270,12 @@ int pdp_train_gru(const float *x, const float *h, const float *W_ih, const float
 /* adjoint: dhnew [R,H] -> dx [R,Kx], dh [R,H], dW_ih, dW_hh, db_ih [3H], db_hh [3H]; scratch [R,7H] */
 int pdp_train_gru_backward(const float *dhnew, const float *saved, const float *x, const float *h, const float *W_ih, const float *W_hh, int64_t R, int Kx,
                            int H, float *dx, float *dh, float *dW_ih, float *dW_hh, float *db_ih, float *db_hh, float *scratch, void *stream);
+/* adjoint of pdp_sp_propagate_adapted (the adaptor form of SurveyPropagator.forward, pdp_propagate.py:163-221, as the training path runs it: no
+ * active mask): upstream g_q [E,3] (surveys) and g_eta [E] (column 0 of the function state; the force column carries no gradient, torch.sign) ->
+ * d_xlog [E] (gradient of the log-domain clause message = logsigmoid of the function projector's output) and d_eta_in [E] (gradient of
+ * fs2[:,0] = sigmoid of the variable projector's first output).  xlog / fs2 / edge_mask as handed to the forward. */
+int pdp_train_sp_adapted_backward(pdp_problem *p, const float *xlog, const float *fs2, const float *edge_mask, float pi, const float *g_q,
+                                  const float *g_eta, float *d_xlog, float *d_eta_in, void *stream);
 /* adjoint of pdp_sat_loss (SatLossEvaluator.forward, util.py:178-197) with respect to the prediction: dpred [V] = upstream * d loss / d pred */
 int pdp_sat_loss_grad(pdp_problem *p, const float *pred, float coeff, float eps, int sharpness, float upstream, float *dpred, void *stream);
 

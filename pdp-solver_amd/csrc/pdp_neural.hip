@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(NTN) k_agg_post(int E, const float *__restrict
     }
 }
 
-// ---- resident-weight forms of kernels 1 and 3 --------------------------------------------------------------------------------------------
+// ---- resident-weight form of kernel 1 --------------------------------------------------------------------------------------------------
 // The weight matrices of an aggregator half are small (W1m + W2m = 92 KB at hidden 128): fetching the B operand from L2 inside the
 // MFMA chain left the matrix cores idle for most of the time (one k-step per L2 round trip).  Here a workgroup copies both
 // matrices into LDS once and then walks over many edge tiles (persistent grid, one workgroup per CU); the next tile's input
@@ -406,71 +406,6 @@ __global__ void __launch_bounds__(NTN) k_agg_pre_res(int E, const float *__restr
                     float v = pdp_logsigmoidf(acc[r]);
                     if (emask) v = v * emask[e];
                     h2out[(size_t)e * w.a + col] = v;
-                }
-            }
-        }
-    }
-}
-
-__global__ void __launch_bounds__(NTN) k_agg_post_res(int E, const float *__restrict__ agg, const int32_t *__restrict__ edge_row,
-                                                      const float *__restrict__ h2, const float *__restrict__ sign,
-                                                      const float *__restrict__ emask, const float *__restrict__ rowmask,
-                                                      const float *__restrict__ old, AggW w, float *__restrict__ out, int ntiles)
-{
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int ld0 = w.Kp3 + 1, ld1 = w.Np3 + 1;
-    float *W3 = sm, *W4 = W3 + w.Kp3 * w.Np3, *Rt = W4 + w.Kp4 * w.Np4, *G1 = Rt + TM * ld0;
-    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-    copy_to_lds(W3, w.Wt1a, w.Kp3 * w.Np3);
-    copy_to_lds(W4, w.Wt2a, w.Kp4 * w.Np4);
-    float pre[PRE_R][PRE_C];
-    auto fetch = [&](int tile) {
-        const int e0 = tile * TM;
-#pragma unroll
-        for (int jr = 0; jr < PRE_R; ++jr) {
-            const int e = e0 + wave + NWAVES * jr;
-#pragma unroll
-            for (int jc = 0; jc < PRE_C; ++jc) {
-                const int c = l + 64 * jc;
-                float v = 0.0f;
-                if (e < E && c < w.Kp3) {
-                    if (c < w.a) {
-                        const float own = emask ? h2[(size_t)e * w.a + c] * emask[e] : h2[(size_t)e * w.a + c];
-                        v = (0.0f + agg[(size_t)edge_row[e] * w.a + c]) - own;
-                    } else if (c == w.a && w.fd) v = sign[e];
-                }
-                pre[jr][jc] = v;
-            }
-        }
-    };
-    auto deposit = [&]() {
-#pragma unroll
-        for (int jr = 0; jr < PRE_R; ++jr)
-#pragma unroll
-            for (int jc = 0; jc < PRE_C; ++jc) { const int c = l + 64 * jc; if (c < w.Kp3) Rt[(wave + NWAVES * jr) * ld0 + c] = pre[jr][jc]; }
-    };
-    int tile = blockIdx.x;
-    if (tile < ntiles) { fetch(tile); deposit(); }
-    for (; tile < ntiles; tile += gridDim.x) {
-        __syncthreads();
-        const int next = tile + gridDim.x;
-        if (next < ntiles) fetch(next);
-        lds_layer_res(Rt, ld0, w.Kp3, W3, w.Np3, w.b1a, w.g, ACT_LOGSIGMOID, G1, ld1);
-        __syncthreads();
-        if (next < ntiles) deposit();
-        const int e0 = tile * TM;
-        const int nblocks = (w.Np4 / 32) * (TM / 32);
-        for (int blk = wave; blk < nblocks; blk += NWAVES) {
-            const int nb = blk / (TM / 32), mb = blk % (TM / 32);
-            const f32x16 acc = mfma_block_lds<8>(G1, ld1, w.Kp4, W4, w.Np4, nb, mb, nullptr);
-            const int col = 32 * nb + (l & 31);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int e = e0 + 32 * mb + acc_row(r, l);
-                if (e < E && col < w.out) {
-                    const float nv = pdp_logsigmoidf(acc[r]);
-                    const float mk = rowmask ? rowmask[e] : 1.0f;
-                    out[(size_t)e * w.out + col] = mk * nv + (1.0f - mk) * old[(size_t)e * w.out + col];
                 }
             }
         }
@@ -761,23 +696,20 @@ struct WaveChains {
     }
 };
 
-// NW = 4: one wave per SIMD, separate input / hidden regions, everything of the next tile requested a phase ahead.  NW = 8: two waves per
-// SIMD (256 registers each) -- the input block shares the hidden layer's region (it is dead when the hidden layer is written, and the next
-// tile's is dropped in after the output chain has read the hidden layer), the previous-state rows are requested in front of the hidden
-// layer's activations and the next tile's rows in front of the output layer's, and the other wave of the SIMD covers what is still exposed.
-template <int S3, int NB3, int S4, int NB4, int NW>
-__global__ void __launch_bounds__(64 * NW) k_agg_post_wave(int E, const float *__restrict__ agg, int agg_rows, const int32_t *__restrict__ edge_row,
+// Four waves per workgroup, one per SIMD (512 registers per lane): separate input / hidden regions, everything of the next tile requested a phase ahead.
+#define PW_NW 4
+template <int S3, int NB3, int S4, int NB4>
+__global__ void __launch_bounds__(64 * PW_NW) k_agg_post_wave(int E, const float *__restrict__ agg, int agg_rows, const int32_t *__restrict__ edge_row,
                                                        const float *__restrict__ h2, const float *__restrict__ sign,
                                                        const float *__restrict__ emask, const float *__restrict__ rowmask,
                                                        const float *__restrict__ old, AggW w, float *__restrict__ out, int ntiles /* full 32-edge tiles */)
 {
     static_assert(2 * S3 <= 64, "one lane per input column");
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    constexpr bool LATE = NW == 8;
-    constexpr int ld0 = 2 * S3 + 1, ld1 = 32 * NB3 + 1, WR = (LATE ? WT * ld1 : WT * (ld0 + ld1)) + WT;
+    constexpr int ld0 = 2 * S3 + 1, ld1 = 32 * NB3 + 1, WR = WT * (ld0 + ld1) + WT;
     static_assert(ld0 <= ld1, "the input block fits the hidden layer's region");
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, i = l & 31, kh = l >> 5;
-    float *Rt = sm + wave * WR, *G1 = LATE ? Rt : Rt + WT * ld0, *Mk = G1 + WT * ld1;
+    float *Rt = sm + wave * WR, *G1 = Rt + WT * ld0, *Mk = G1 + WT * ld1;
     const int A = w.a, ROWA = A * (int)sizeof(float), ROWB = w.out * (int)sizeof(float);
     WaveChains<S3, NB3, 32 * NB3> c3;
     WaveChains<S4, NB4, 32 * NB4> c4;
@@ -819,8 +751,8 @@ __global__ void __launch_bounds__(64 * NW) k_agg_post_wave(int E, const float *_
             if (l < WT) Mk[l] = pmk;
         }
     };
-    const int stride = gridDim.x * NW;
-    int tile = blockIdx.x * NW + wave;
+    const int stride = gridDim.x * PW_NW;
+    int tile = blockIdx.x * PW_NW + wave;
     if (tile < ntiles) {
         fetch_ids(tile);
         c3.head_w();
@@ -843,12 +775,10 @@ __global__ void __launch_bounds__(64 * NW) k_agg_post_wave(int E, const float *_
             for (int r = 0; r < 16; ++r)
                 po[nb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pb, (32 * nb + i < w.out) ? lo + nb * 128 : 0x40000000, ((r & 3) + 8 * (r >> 2)) * ROWB, 0));
         };
-        if (!LATE) {
 #pragma unroll
-            for (int nb = 0; nb < NB4; ++nb) load_po(nb);
-        }
+        for (int nb = 0; nb < NB4; ++nb) load_po(nb);
         const bool more = tile + stride < ntiles;
-        if (!LATE && more) { fetch_rows(tile + stride); if (tile + 2 * stride < ntiles) fetch_ids(tile + 2 * stride); }
+        if (more) { fetch_rows(tile + stride); if (tile + 2 * stride < ntiles) fetch_ids(tile + 2 * stride); }
 #pragma unroll
         for (int nb = 0; nb < NB3; ++nb) {
             const int col = 32 * nb + i;
@@ -863,10 +793,8 @@ __global__ void __launch_bounds__(64 * NW) k_agg_post_wave(int E, const float *_
         float mk[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) mk[r] = rowmask ? Mk[4 * kh + (r & 3) + 8 * (r >> 2)] : 1.0f;
-        if (LATE) load_po(0);                              // NW = 8: the previous-state rows one output block ahead
 #pragma unroll
         for (int nb = 0; nb < NB4; ++nb) {
-            if (LATE && nb + 1 < NB4) load_po(nb + 1);
             const int so = (32 * nb + i < w.out) ? lo + nb * 128 : 0x40000000;      // a column past the row is stored nowhere
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -875,9 +803,6 @@ __global__ void __launch_bounds__(64 * NW) k_agg_post_wave(int E, const float *_
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // (NW = 8: 256 registers do not hold the next tile's rows next to the output accumulators and the previous-state rows -- they are
-        //  requested here and dropped in as they arrive; the SIMD's other wave runs meanwhile)
-        if (LATE && more) { fetch_rows(tile + stride); if (tile + 2 * stride < ntiles) fetch_ids(tile + 2 * stride); }
         if (more) deposit();                               // every chain has consumed its operands (LDS operations of a wave complete in order)
     }
 }
@@ -984,69 +909,6 @@ __global__ void __launch_bounds__(NTN) k_gru(int E, const float *__restrict__ st
         }
         __syncthreads();                                   // every wave is done with X / Hs
         if (next < ntiles) deposit();
-    }
-}
-
-// ---- kernel 5a: k_gru on a 128-edge LDS window -------------------------------------------------------------------------------------------
-// For hidden widths whose column blocks do not divide the 8 waves (150 -> 5 blocks: the 10 blocks of a 64-edge tile take two rounds, the
-// second with 2 waves busy) a 128-edge window gives 20 blocks = 2.5 rounds.  The window fills the LDS (155 KB at hidden 150), so the rows go
-// straight from HBM to LDS at the start of a tile instead of through a register prefetch.
-template <int TMV>
-__global__ void __launch_bounds__(NTN) k_gru_window(int E, const float *__restrict__ state, const float *__restrict__ sign,
-                                                    const float *__restrict__ hprev, const float *__restrict__ rowmask, GruW g,
-                                                    float *__restrict__ out, int ntiles)
-{
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    constexpr int RB = TMV / 32;
-    const int ldx = g.Kpx + 1, ldh = g.Kph + 1;
-    float *X = sm, *Hs = sm + TMV * ldx;
-    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int hb = g.Hp / 32;
-    const int N3 = 3 * g.Hp;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int e0 = tile * TMV;
-        __syncthreads();                                   // every wave is done with the previous window
-#pragma unroll 4
-        for (int r = wave; r < TMV; r += NWAVES) {
-            const int e = e0 + r;
-#pragma unroll
-            for (int jc = 0; jc < PRE_C; ++jc) {
-                const int c = l + 64 * jc;
-                float v = 0.0f, hv = 0.0f;
-                if (e < E && c < g.Kpx) v = (c < g.dx) ? state[(size_t)e * g.dx + c] : (c == g.dx ? sign[e] : 0.0f);
-                if (e < E && c < g.H) hv = hprev[(size_t)e * g.H + c];
-                if (c < g.Kpx) X[r * ldx + c] = v;
-                if (c < g.Kph) Hs[r * ldh + c] = hv;
-            }
-        }
-        __syncthreads();
-        for (int blk = wave; blk < hb * RB; blk += NWAVES) {
-            const int nb = blk / RB, mb = blk % RB;
-            const int col = 32 * nb + (l & 31);
-            f32x16 ia[1], ha[1], rg, zg;
-            mfma_chain<1, 8>(X, ldx, g.Kpx, g.Wt_ih, N3, nb, mb, g.b_ih, ia);
-            mfma_chain<1, 8>(Hs, ldh, g.Kph, g.Wt_hh, N3, nb, mb, g.b_hh, ha);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) rg[r] = pdp_sigmoidf(ha[0][r] + ia[0][r]);
-            mfma_chain<1, 8>(X, ldx, g.Kpx, g.Wt_ih, N3, hb + nb, mb, g.b_ih, ia);
-            mfma_chain<1, 8>(Hs, ldh, g.Kph, g.Wt_hh, N3, hb + nb, mb, g.b_hh, ha);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) zg[r] = pdp_sigmoidf(ha[0][r] + ia[0][r]);
-            mfma_chain<1, 8>(X, ldx, g.Kpx, g.Wt_ih, N3, 2 * hb + nb, mb, g.b_ih, ia);
-            mfma_chain<1, 8>(Hs, ldh, g.Kph, g.Wt_hh, N3, 2 * hb + nb, mb, g.b_hh, ha);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 32 * mb + acc_row(r, l);
-                const int e = e0 + row;
-                if (e < E && col < g.H) {
-                    const float ng = pdp_tanhf_abs(ia[0][r] + ha[0][r] * rg[r]);
-                    const float hp = Hs[row * ldh + col];
-                    const float hnew = (hp - ng) * zg[r] + ng;
-                    const float mk = rowmask ? rowmask[e] : 1.0f;
-                    out[(size_t)e * g.H + col] = mk * hnew + (1.0f - mk) * hp;
-                }
-            }
-        }
     }
 }
 

@@ -378,3 +378,99 @@ extern "C" int pdp_sat_loss_grad(pdp_problem *p, const float *pred, float coeff,
     PDP_LAUNCH_CHECK();
     return PDP_OK;
 }
+
+// ---- adjoint of the adaptor form of the SP sweep (model type p-nd-np; forward: pdp_sp_propagate_adapted, reference pdp_propagate.py:163-221) ------
+// Forward, per edge e = (variable i, clause a), sign s, edge mask m (1 when absent), instance mask 1 (the training path has no active mask):
+//   x = xlog m,  S_a = sum_{e in a} x,  eta' = X(S_a - x)                               X(t) = exp(min(t, 30))
+//   y = L(1 - eta_in) m,  P_i / N_i = sums of y over the positive / negative edges of i     L(t) = log(max(t, 1e-40))
+//   same = (s > 0 ? P : N) - y + c1,  opp = (s > 0 ? N : P) + c2   (c1, c2: constants of the external force, no gradient through sign())
+//   A = X(same), B = X(opp), dc = X(same + opp), qu = A (1 - B), qs = B (1 - A), tot = qu + qs + dc, q = [qu, qs, dc] / tot
+// torch.max / torch.min pass the gradient to the argument that wins (none on the clamped side).  One workgroup per instance: the clause
+// sums and the two signed variable sums of the forward are rebuilt, then the two adjoint row sums, all ordered (no atomics).
+__global__ void __launch_bounds__(PDP_NT) k_sp_adapted_backward(PView pv, const float *xlog, const float *fs2, const float *emask, float pi,
+                                                               const float *gq, const float *geta, float *dxlog, float *deta_in,
+                                                               float *xs, float *ys, float *ds, float *dop, float *Sw, float *Rw, float *Pw, float *Nw,
+                                                               float *dPw, float *dNw)
+{
+    const Inst I = load_inst(pv, blockIdx.x);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    xlog += I.e0; fs2 += 2 * (size_t)I.e0; gq += 3 * (size_t)I.e0; geta += I.e0; dxlog += I.e0; deta_in += I.e0;
+    xs += I.e0; ys += I.e0; ds += I.e0; dop += I.e0; Sw += I.f0; Rw += I.f0; Pw += I.v0; Nw += I.v0; dPw += I.v0; dNw += I.v0;
+    const float *em = emask ? emask + I.e0 : nullptr;
+    const float L0 = pdp_safe_log(1.0f - pi * 0.0f, PDP_SP_EPS), L1 = pdp_safe_log(1.0f - pi * 1.0f, PDP_SP_EPS);
+    for (int e = tid; e < I.e; e += nt) {
+        const float m = em ? em[e] : 1.0f;
+        xs[e] = xlog[e] * m;
+        ys[e] = pdp_safe_log(1.0f - fs2[2 * e], PDP_SP_EPS) * m;
+    }
+    __syncthreads();
+    for (int c = tid; c < I.m; c += nt) {
+        float acc = 0.0f;
+        for (int k = I.f_ptr[c]; k < I.f_ptr[c + 1]; ++k) acc = acc + xs[I.f_edges[k]];
+        Sw[c] = acc;
+    }
+    for (int v = tid; v < I.n; v += nt) {
+        float P = 0.0f, N = 0.0f;
+        for (int k = I.v_ptr[v]; k < I.v_ptr[v + 1]; ++k) {
+            const int e = I.v_edges[k];
+            if (I.sgn[e] == 1) P = P + ys[e]; else N = N + ys[e];
+        }
+        Pw[v] = P; Nw[v] = N;
+    }
+    __syncthreads();
+    // per edge: d agg (kept in dxlog until the clause sums are there), d same, d opp
+    for (int e = tid; e < I.e; e += nt) {
+        const int v = I.e_var[e], c = I.e_fn[e];
+        const float s = (float)I.sgn[e];
+        const float agg = Sw[c] - xs[e];
+        dxlog[e] = (agg < 30.0f) ? geta[e] * pdp_expf(agg) : 0.0f;
+        const float force = fs2[2 * e + 1];
+        const float same = ((s > 0.0f) ? Pw[v] : Nw[v]) - ys[e] + ((force == s) ? L1 : L0);
+        const float opp = ((s > 0.0f) ? Nw[v] : Pw[v]) + ((force == -s) ? L1 : L0);
+        const float A = pdp_safe_exp(same), Bv = pdp_safe_exp(opp), dc = pdp_safe_exp(same + opp);
+        const float qu = A * (1.0f - Bv), qs = Bv * (1.0f - A);
+        const float tot = (qu + qs) + dc;
+        const float g0 = gq[3 * e], g1 = gq[3 * e + 1], g2 = gq[3 * e + 2];
+        const float dot = (g0 * qu + g1 * qs + g2 * dc) / tot;
+        const float dqu = (g0 - dot) / tot, dqs = (g1 - dot) / tot, ddc = (g2 - dot) / tot;
+        const float dA = dqu * (1.0f - Bv) - dqs * Bv, dB = dqs * (1.0f - A) - dqu * A;
+        const float gdc = (same + opp < 30.0f) ? ddc * dc : 0.0f;
+        ds[e] = ((same < 30.0f) ? dA * A : 0.0f) + gdc;
+        dop[e] = ((opp < 30.0f) ? dB * Bv : 0.0f) + gdc;
+    }
+    __syncthreads();
+    for (int c = tid; c < I.m; c += nt) {
+        float acc = 0.0f;
+        for (int k = I.f_ptr[c]; k < I.f_ptr[c + 1]; ++k) acc = acc + dxlog[I.f_edges[k]];
+        Rw[c] = acc;
+    }
+    for (int v = tid; v < I.n; v += nt) {
+        float dP = 0.0f, dN = 0.0f;
+        for (int k = I.v_ptr[v]; k < I.v_ptr[v + 1]; ++k) {
+            const int e = I.v_edges[k];
+            if (I.sgn[e] == 1) { dP = dP + ds[e]; dN = dN + dop[e]; } else { dN = dN + ds[e]; dP = dP + dop[e]; }
+        }
+        dPw[v] = dP; dNw[v] = dN;
+    }
+    __syncthreads();
+    for (int e = tid; e < I.e; e += nt) {
+        const int v = I.e_var[e], c = I.e_fn[e];
+        const float m = em ? em[e] : 1.0f;
+        const float dagg = dxlog[e];
+        dxlog[e] = (Rw[c] - dagg) * m;                                   // x enters every OTHER edge of its clause
+        const float dy = (((I.sgn[e] == 1) ? dPw[v] : dNw[v]) - ds[e]) * m;
+        const float om = 1.0f - fs2[2 * e];
+        deta_in[e] = (om > PDP_SP_EPS) ? -dy / om : 0.0f;
+    }
+}
+
+extern "C" int pdp_train_sp_adapted_backward(pdp_problem *p, const float *xlog, const float *fs2, const float *edge_mask, float pi, const float *g_q,
+                                             const float *g_eta, float *d_xlog, float *d_eta_in, void *stream)
+{
+    PDP_REQUIRE(p && xlog && fs2 && g_q && g_eta && d_xlog && d_eta_in, "NULL argument");
+    PDP_REQUIRE(d_xlog != g_eta && d_xlog != xlog, "outputs must not alias inputs");
+    hipLaunchKernelGGL(k_sp_adapted_backward, dim3(p->B), dim3(PDP_NT), 0, ST(stream), make_view(p), xlog, fs2, edge_mask, pi, g_q, g_eta, d_xlog, d_eta_in,
+                       p->ws_e[0], p->ws_e[1], p->ws_e[2], p->ws_e[3], p->ws_f[0], p->ws_f[1], p->ws_v[0], p->ws_v[1], p->ws_v[2], p->ws_v[3]);
+    PDP_LAUNCH_CHECK();
+    return PDP_OK;
+}

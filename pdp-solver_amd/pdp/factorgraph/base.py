@@ -98,55 +98,73 @@ class FactorGraphTrainerBase(object):
                 model._global_step.data += 1
         return total_loss / max(1, total_example_num)
 
+    # model types whose training the reference itself cannot run (tests/golden/train_np_d_np_reference.json records its exception): np-d-np's
+    # prediction is sat_problem._solution -- no parameter reaches it except through values a decimation wrote -- and set_variables edits, in
+    # place, the flag tensors the scorer's autograd graph saved, so loss.backward() raises.  The classical types have no parameters.
+    UNTRAINABLE = {'np-d-np': "the reference's loss.backward() raises for this model type (identity predictor over the in-place edited solution; "
+                              "tests/golden/train_np_d_np_reference.json)",
+                   'p-d-p': 'no trainable parameters', 'walk-sat': 'no trainable parameters', 'reinforce': 'no trainable parameters'}
+
+    def _loader(self, path, limit_key, shuffle, generator=None, epoch_size=0, batch_replication=1):
+        return FactorGraphDataset.get_loader(
+            input_file=path, limit=self._config[limit_key], hidden_dim=self._config['hidden_dim'], batch_size=self._config['batch_size'],
+            shuffle=shuffle, num_workers=0, max_cache_size=self._config.get('max_cache_size', 100000), generator=generator,
+            epoch_size=epoch_size, batch_replication=batch_replication)
+
+    def _restore(self, which, last_dir, best_dir):
+        "load_model = 'best' | 'last': start a repetition from that checkpoint when its directory was given"
+        chosen = {'best': best_dir, 'last': last_dir}.get(which)
+        if chosen is not None:
+            self._load(chosen)
+
+    def _report_epoch(self, rep, epoch, errors, losses, seconds):
+        parts = ['Step {:d}: {:s} error={:s}, {:s} loss={:5.5f} |'.format(int(m._global_step.int()[0]), m._name,
+                                                                          np.array_str(errors[:, i].flatten()), m._name, losses[i])
+                 for i, m in enumerate(self._model_list)]
+        self._logger.info('Rep {:2d}, Epoch {:2d}: {:s}'.format(rep + 1, epoch + 1, ''.join(parts)))
+        self._logger.info('Time spent: %s seconds' % seconds)
+
     def train(self, train_list, validation_list, optimizer, last_export_path_base=None, best_export_path_base=None, metric_index=0,
               load_model=None, reset_step=False, generator=None, train_epoch_size=0):
-        """Trains the PDP model (reference: base.py:311-404): per epoch one pass over the (shuffled, or generated) training set and a
-        validation pass with the test-mode metrics; the last model and the best one by ``metric_index`` are checkpointed.
-        Returns (model list, errors [error_dim, models, epochs, repetitions], losses [models, epochs, repetitions])."""
-        train_loader = FactorGraphDataset.get_loader(
-            input_file=train_list[0], limit=self._config['train_batch_limit'], hidden_dim=self._config['hidden_dim'],
-            batch_size=self._config['batch_size'], shuffle=True, num_workers=0, max_cache_size=self._config.get('max_cache_size', 100000),
-            generator=generator, epoch_size=train_epoch_size)
-        validation_loader = FactorGraphDataset.get_loader(
-            input_file=validation_list[0], limit=self._config['test_batch_limit'], hidden_dim=self._config['hidden_dim'],
-            batch_size=self._config['batch_size'], shuffle=False, num_workers=0, max_cache_size=self._config.get('max_cache_size', 100000))
-        model_num = len(self._model_list)
-        errors = np.zeros((self._error_dim, model_num, self._config['epoch_num'], self._config['repetition_num']), dtype=np.float32)
-        losses = np.zeros((model_num, self._config['epoch_num'], self._config['repetition_num']), dtype=np.float32)
-        best_errors = np.repeat(np.inf, model_num)
-        for rep in range(self._config['repetition_num']):
-            if load_model == "best" and best_export_path_base is not None:
-                self._load(best_export_path_base)
-            elif load_model == "last" and last_export_path_base is not None:
-                self._load(last_export_path_base)
+        """Trains the models (contract of the reference's train(), base.py:311-404): ``repetition_num`` repetitions of ``epoch_num`` epochs;
+        an epoch is one pass over the training set (shuffled file, or ``train_epoch_size`` generated instances) followed by a validation
+        pass with the test-mode metrics.  After every epoch the models go to ``last_export_path_base``; a model goes to
+        ``best_export_path_base`` whenever its validation metric ``metric_index`` improves; at the end the loss / error histories are
+        stored there as losses.npy / errors.npy.  Returns (models, errors [error_dim, models, epochs, repetitions], losses [models,
+        epochs, repetitions])."""
+        why = self.UNTRAINABLE.get(self._config.get('model_type'))
+        if why is not None:
+            raise native.NativeError("model_type %r cannot be trained: %s" % (self._config.get('model_type'), why))
+        cfg = self._config
+        n_models, n_epochs, n_reps = len(self._model_list), cfg['epoch_num'], cfg['repetition_num']
+        feed = self._loader(train_list[0], 'train_batch_limit', True, generator, train_epoch_size)
+        held_out = self._loader(validation_list[0], 'test_batch_limit', False)
+        errors = np.zeros((self._error_dim, n_models, n_epochs, n_reps), dtype=np.float32)
+        losses = np.zeros((n_models, n_epochs, n_reps), dtype=np.float32)
+        best_so_far = np.full(n_models, np.inf)
+        for rep in range(n_reps):
+            self._restore(load_model, last_export_path_base, best_export_path_base)
             if reset_step:
                 self._reset_global_step()
-            for epoch in range(self._config['epoch_num']):
-                start_time = time.time()
-                losses[:, epoch, rep] = self._train_epoch(train_loader, optimizer)
-                errors[:, :, epoch, rep] = self._test_epoch(validation_loader, 1)
+            for epoch in range(n_epochs):
+                t0 = time.time()
+                losses[:, epoch, rep] = self._train_epoch(feed, optimizer)
+                errors[:, :, epoch, rep] = self._test_epoch(held_out, 1)
                 torch.cuda.synchronize()
-                duration = time.time() - start_time
+                seconds = time.time() - t0
                 if last_export_path_base is not None:
-                    for model in self._model_list:
-                        model.save(last_export_path_base)
+                    self._save(last_export_path_base)
                 if best_export_path_base is not None:
-                    for (i, model) in enumerate(self._model_list):
-                        if errors[metric_index, i, epoch, rep] < best_errors[i]:
-                            best_errors[i] = errors[metric_index, i, epoch, rep]
-                            model.save(best_export_path_base)
-                if self._config.get('verbose'):
-                    message = ''
-                    for (i, model) in enumerate(self._model_list):
-                        message += 'Step {:d}: {:s} error={:s}, {:s} loss={:5.5f} |'.format(
-                            int(model._global_step.int()[0]), model._name, np.array_str(errors[:, i, epoch, rep].flatten()), model._name,
-                            losses[i, epoch, rep])
-                    self._logger.info('Rep {:2d}, Epoch {:2d}: {:s}'.format(rep + 1, epoch + 1, message))
-                    self._logger.info('Time spent: %s seconds' % duration)
+                    score = errors[metric_index, :, epoch, rep]
+                    for i in np.nonzero(score < best_so_far)[0]:
+                        best_so_far[i] = score[i]
+                        self._model_list[i].save(best_export_path_base)
+                if cfg.get('verbose'):
+                    self._report_epoch(rep, epoch, errors[:, :, epoch, rep], losses[:, epoch, rep], seconds)
         if best_export_path_base is not None:
-            base = os.path.relpath(best_export_path_base)
-            np.save(os.path.join(base, "losses"), losses, allow_pickle=False)
-            np.save(os.path.join(base, "errors"), errors, allow_pickle=False)
+            where = os.path.relpath(best_export_path_base)
+            for name, history in (('losses', losses), ('errors', errors)):
+                np.save(os.path.join(where, name), history, allow_pickle=False)
             self._save(best_export_path_base)
         return self._model_list, errors, losses
 
@@ -218,37 +236,37 @@ class FactorGraphTrainerBase(object):
                 batch_variable_map=batch_variable_map, batch_function_map=batch_function_map, edge_feature=edge_feature,
                 meta_data=graph_feat)).detach().cpu().numpy()
 
-    def test(self, test_list, import_path_base=None, batch_replication=1):
-        "Tests the PDP model and generates test stats: [[file, error [error_dim, models], seconds], ...] (reference: base.py:406-449)."
+    @staticmethod
+    def _test_inputs(test_list):
+        "a list of files as given, the .json files of a directory, or one file; None for anything else"
         if isinstance(test_list, list):
-            test_files = test_list
-        elif os.path.isdir(test_list):
-            test_files = [os.path.join(test_list, f) for f in os.listdir(test_list)
-                          if os.path.isfile(os.path.join(test_list, f)) and f[-5:].lower() == '.json']
-        elif isinstance(test_list, str):
-            test_files = [test_list]
-        else:
+            return test_list
+        if isinstance(test_list, str) and os.path.isdir(test_list):
+            inside = (os.path.join(test_list, name) for name in os.listdir(test_list))
+            return [f for f in inside if os.path.isfile(f) and f.lower().endswith('.json')]
+        return [test_list] if isinstance(test_list, str) else None
+
+    def test(self, test_list, import_path_base=None, batch_replication=1):
+        """Test-mode metrics per input file (contract of the reference's test(), base.py:406-449): returns
+        [[file, errors [error_dim, models], seconds], ...]; the checkpoint under ``import_path_base`` is loaded before every file."""
+        files = self._test_inputs(test_list)
+        if files is None:
             return None
-        result = []
-        for file in test_files:
-            test_loader = FactorGraphDataset.get_loader(
-                input_file=file, limit=self._config['test_batch_limit'], hidden_dim=self._config['hidden_dim'],
-                batch_size=self._config['batch_size'], shuffle=False, num_workers=0,
-                max_cache_size=self._config.get('max_cache_size', 100000), batch_replication=batch_replication)
+        rows = []
+        for path in files:
+            loader = self._loader(path, 'test_batch_limit', False, batch_replication=batch_replication)
             if import_path_base is not None:
                 self._load(import_path_base)
-            start_time = time.time()
-            error = self._test_epoch(test_loader, batch_replication)
+            t0 = time.time()
+            error = self._test_epoch(loader, batch_replication)
             torch.cuda.synchronize()
-            duration = time.time() - start_time
+            seconds = time.time() - t0
             if self._config.get('verbose'):
-                message = ''
-                for (i, model) in enumerate(self._model_list):
-                    message += '{:s}, dataset:{:s} error={:s}|'.format(model._name, file, np.array_str(error[:, i].flatten()))
-                self._logger.info(message)
-                self._logger.info('Time spent: %s seconds' % duration)
-            result += [[file, error, duration]]
-        return result
+                self._logger.info(''.join('{:s}, dataset:{:s} error={:s}|'.format(m._name, path, np.array_str(error[:, i].flatten()))
+                                          for i, m in enumerate(self._model_list)))
+                self._logger.info('Time spent: %s seconds' % seconds)
+            rows.append([path, error, seconds])
+        return rows
 
     def predict(self, test_list, out_file, import_path_base=None, post_processor=None, batch_replication=1):
         """Produces predictions for a (trained) PDP model (reference: base.py:451-472).

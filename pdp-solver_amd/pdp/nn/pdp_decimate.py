@@ -4,7 +4,7 @@ import torch
 import torch.nn as nn
 
 from pdp import native
-from pdp.nn import pdp_predict
+from pdp.nn import pdp_predict, util
 
 
 class NeuralDecimator(nn.Module):
@@ -42,7 +42,7 @@ class NeuralDecimator(nn.Module):
 
     def forward(self, init_state, message_state, sat_problem, is_training, active_mask=None):
         variable_state, function_state = message_state
-        if is_training and torch.is_grad_enabled():
+        if util.on_train_path(self, is_training):
             # the differentiable cells of the training path (pdp_decimate.py:51-87)
             from pdp.nn import train_ops as T
             sign = sat_problem._edge_feature

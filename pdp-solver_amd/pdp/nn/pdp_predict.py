@@ -56,7 +56,8 @@ class NeuralPredictor(nn.Module):
         return self._head
 
     def forward(self, decimator_state, sat_problem, last_call=False):
-        if torch.is_grad_enabled() and decimator_state[0].requires_grad:
+        pinned = getattr(self, '_train_path', None)       # set by the solver's forward (one decision for the three plug-ins)
+        if (torch.is_grad_enabled() and decimator_state[0].requires_grad) if pinned is None else pinned:
             # the differentiable form of the training path (pdp_predict.py:49-91; trainer.py:28-29 for the head)
             from pdp.nn import train_ops as T
             em = decimator_state[2] if len(decimator_state) == 3 else None

@@ -38,7 +38,7 @@ class NeuralMessagePasser(nn.Module):
         self._mem_agg_hidden_dimension = mem_agg_hidden_dimension
 
     def forward(self, init_state, decimator_state, sat_problem, is_training, active_mask=None):
-        if is_training and torch.is_grad_enabled():
+        if util.on_train_path(self, is_training):
             return self._forward_train(init_state, decimator_state, sat_problem, active_mask)
         if is_training and self._drop_out > 0:
             raise native.NativeError("is_training with dropout needs gradients enabled (the differentiable training path)")
@@ -116,6 +116,8 @@ class SurveyPropagator(nn.Module):
             dec_q, dec_fs = decimator_state
             edge_mask = None
         init_q, init_fs = init_state
+        if self._include_adaptors and util.on_train_path(self, is_training):
+            return self._forward_train(init_state, dec_q, dec_fs, edge_mask, sat_problem, active_mask)
         am = None if active_mask is None else active_mask.reshape(-1).contiguous()
         em = None if edge_mask is None else edge_mask.reshape(-1).contiguous()
         nat = sat_problem._native
@@ -125,6 +127,23 @@ class SurveyPropagator(nn.Module):
                                         self._variable_input_projector.weight.data.contiguous())
             return nat.sp_propagate_adapted(xlog, fs2, em, am, init_q.contiguous(), init_fs.contiguous(), self._pi)
         return nat.sp_propagate(dec_q.contiguous(), dec_fs.contiguous(), em, am, init_q.contiguous(), init_fs.contiguous(), self._pi)
+
+    def _forward_train(self, init_state, dec_v, dec_f, edge_mask, sat_problem, active_mask):
+        """The differentiable sweep of the training path (pdp_propagate.py:139-221 with include_adaptors, under autograd): the two bias-free
+        projections run on the matrix cores with their adjoints (train_ops.LinearAct), the [E, 1] / [E, 2] activations are torch element-wise
+        operators, and the sweep itself is one native forward / adjoint pair (train_ops.SpAdaptedSweep).  torch.sign has no gradient, so
+        only the first row of the variable projector learns from the sweep (the reference's in-place column writes, pdp_propagate.py:180-181)."""
+        from pdp.nn import train_ops as T
+        import torch.nn.functional as F
+        xlog = F.logsigmoid(T.LinearAct.apply(dec_v, self._function_input_projector.weight, None, 'none'))
+        u = T.LinearAct.apply(dec_f, self._variable_input_projector.weight, None, 'none')
+        fs2 = torch.stack((torch.sigmoid(u[:, 0]), torch.sign(u[:, 1]).detach()), dim=1)
+        q, fs = T.SpAdaptedSweep.apply(xlog, fs2, sat_problem._native, edge_mask, self._pi)
+        if active_mask is not None:
+            mask = active_mask.reshape(-1).float()[sat_problem._batch_variable_map.long()][sat_problem._graph_map[0].long()].unsqueeze(1)
+            q = mask * q + (1 - mask) * init_state[0]
+            fs = torch.cat((mask * fs[:, :1] + (1 - mask) * init_state[1][:, :1], fs[:, 1:]), 1)
+        return q, fs
 
     def get_init_state(self, graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, randomized, batch_replication):
         "reference: pdp_propagate.py:223-237 (random draws come from the torch CPU generator, like the reference on CPU)"

@@ -173,6 +173,13 @@ class PropagatorDecimatorSolverBase(nn.Module):
         sat_problem = SATProblem((graph_map, batch_variable_map, batch_function_map, edge_feature, meta_data, None),
                                  self._device, batch_replication)
         self.last_run = dict(path='none', iterations=0, walksat_steps=0)
+        # one decision for the whole forward: the differentiable operators (tolerance-level, autograd graph kept) only when training was
+        # asked for, gradients are enabled and some parameter wants them; otherwise every plug-in runs its fused inference kernels
+        train_path = bool(is_training) and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        for plug_in in (self._propagator, self._decimator, self._predictor):
+            if plug_in is not None:
+                plug_in._train_path = train_path
+        self.last_run['train_path'] = train_path
 
         if simplify and not is_training:
             sat_problem.simplify()

@@ -117,6 +117,39 @@ class GruCell(torch.autograd.Function):
         return dx, dh, dw_ih, dw_hh, db_ih, db_hh
 
 
+class SpAdaptedSweep(torch.autograd.Function):
+    """The SP sweep of the adaptor form of SurveyPropagator (model type p-nd-np; pdp_propagate.py:163-221 as the training path runs it: no
+    active mask) on the log-domain clause message ``xlog`` [E] and the variable-side input ``fs2`` [E, 2] = [eta, force]: returns the new
+    surveys [E, 3] and the new function state [E, 2].  The force column passes through without a gradient (torch.sign)."""
+
+    @staticmethod
+    def forward(ctx, xlog, fs2, problem, edge_mask, pi):
+        ctx.xshape = xlog.shape
+        xlog, fs2 = _f(xlog.reshape(-1)), _f(fs2)
+        em = None if edge_mask is None else _f(edge_mask.reshape(-1))
+        E = xlog.numel()
+        old_q = torch.zeros(E, 3, dtype=torch.float32, device=xlog.device)         # (what an inactive instance would keep: the blend weight is 0 here)
+        old_fs = torch.zeros(E, 2, dtype=torch.float32, device=xlog.device)
+        q, fs = problem.sp_propagate_adapted(xlog, fs2, em, None, old_q, old_fs, pi)
+        ctx.save_for_backward(xlog, fs2, em if em is not None else torch.empty(0, device=xlog.device))
+        ctx.problem, ctx.pi, ctx.has_em = problem, pi, em is not None
+        return q, fs
+
+    @staticmethod
+    def backward(ctx, gq, gfs):
+        xlog, fs2, em = ctx.saved_tensors
+        gq = _f(gq)
+        geta = _f(gfs[:, 0])
+        dxlog = torch.empty_like(xlog)
+        deta = torch.empty_like(xlog)
+        native.check(native.lib().pdp_train_sp_adapted_backward(ctx.problem._h, native.ptr(xlog, torch.float32), native.ptr(fs2, torch.float32),
+                                                                native.ptr(em, torch.float32) if ctx.has_em else None, C.c_float(ctx.pi),
+                                                                native.ptr(gq, torch.float32), native.ptr(geta, torch.float32), native.ptr(dxlog),
+                                                                native.ptr(deta), native._stream()))
+        dfs2 = torch.stack((deta, torch.zeros_like(deta)), dim=1)
+        return dxlog.reshape(ctx.xshape), dfs2, None, None, None
+
+
 class SatLoss(torch.autograd.Function):
     "energy loss of a prediction (SatLossEvaluator.forward, util.py:178-197) and its gradient with respect to the prediction"
 

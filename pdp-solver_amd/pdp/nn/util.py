@@ -15,6 +15,17 @@ import torch.nn as nn
 from pdp import native
 
 
+
+def on_train_path(module, is_training):
+    """Does this call run the differentiable (autograd) path?  The solver decides ONCE per forward (PropagatorDecimatorSolverBase.forward:
+    is_training, gradients enabled, a parameter that requires them) and pins the answer on its three plug-ins, so propagator, decimator and
+    predictor never mix the bit-exact inference kernels with the tolerance-level training operators; a plug-in called on its own falls
+    back to the same rule without the parameter test.  Inference callers pass is_training=False or run under torch.no_grad()."""
+    pinned = getattr(module, '_train_path', None)
+    if pinned is not None:
+        return bool(pinned)
+    return bool(is_training) and torch.is_grad_enabled()
+
 class SatCNFEvaluator(nn.Module):
     """Clause-satisfaction check: returns (solved [B,1], unsat_clauses [B,1])  (reference: util.py:203-236).
 

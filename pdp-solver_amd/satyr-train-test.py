@@ -59,9 +59,9 @@ def run(random_seed, config_file, is_training, load_model, cpu, reset_step, use_
     best_base, last_base = os.path.join(base, 'best'), os.path.join(base, 'last')
     trainer = SatFactorGraphTrainer(config=config, use_cuda=not cpu, logger=logger)
     if is_training:
-        if config['model_type'] != 'np-nd-np':
-            raise SystemExit("satyr-train-test.py: training is built for model_type np-nd-np (the differentiable path of the fully neural "
-                             "solver); %r has no trainable native path" % (config['model_type'],))
+        why = trainer.UNTRAINABLE.get(config['model_type'])
+        if why is not None:
+            raise SystemExit("satyr-train-test.py: model_type %r cannot be trained: %s" % (config['model_type'], why))
         import torch.optim as optim
         for d in (best_base, last_base):
             os.makedirs(d, exist_ok=True)

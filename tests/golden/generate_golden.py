@@ -95,7 +95,8 @@ RS.PropagatorDecimatorSolverBase._deduplicate = _dedup
 LOG = logging.getLogger('golden')
 
 # ---- recording torch.rand -------------------------------------------------------------------
-_real_rand = torch.rand
+_TORCH_RAND = torch.rand        # the real function, saved once: what every `finally` restores
+_real_rand = torch.rand         # what the recorder calls (rf_leak feeds it from a file for one run)
 RAND_LOG = []
 
 
@@ -341,7 +342,7 @@ def run_trace(model_type, lines, T, w, seed, replication=1, cfg_kw=None, float_i
             if h is not None:
                 h.remove()
     finally:
-        torch.rand = _real_rand
+        torch.rand = _TORCH_RAND
     out['iterations_run'] = np.array([it['i']], dtype=np.int64)
     for k, v in ints.items():
         if v:
@@ -494,7 +495,7 @@ def gen_np_d_np():
             pred, (ps, ds) = m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef,
                                meta_data=None, is_training=False, iteration_num=T, check_termination=check, batch_replication=1)
     finally:
-        torch.rand = _real_rand
+        torch.rand = _TORCH_RAND
     for k, v in ints.items():
         out['trace_' + k] = np.stack(v)
     out['final_prediction'] = np_(pred[0][:, 0])
@@ -786,7 +787,7 @@ def gen_config4_mixed():
         tr.predict(os.path.join(HERE, 'config4_mixed.json'), buf, import_path_base=None, post_processor=tr._post_process_predictions,
                    batch_replication=R)
     finally:
-        torch.rand = _real_rand
+        torch.rand = _TORCH_RAND
     rows = [l for l in buf.getvalue().split('\n') if l.strip()]
     with open(os.path.join(HERE, 'config4_mixed.out.jsonl'), 'w') as f:
         f.write("\n".join(rows) + "\n")
@@ -944,6 +945,83 @@ def gen_train():
 
 
 
+def gen_train_hybrid():
+    """Training of the two hybrid model types the reference ships Train configs for (config/Train/p-prodec2-nsp-..., p-prodec2-ndec-...),
+    through the same statements as _train_batch (base.py:149-182), hidden 32, the batch of gen_train:
+    * p-nd-np (SP propagator with adaptors + GRU decimator + neural predictor; reference + the App. B-5 width shim, meta_feature_dim 0 --
+      the shipped config's meta_feature_dim 1 builds layers one column wider than the loader's data, which never carries meta data):
+      loss, per-step losses, every parameter gradient, parameters after the clipped Adam step -> train_batch_p_nd_np.npz;
+    * np-d-np (neural propagator + sequential decimator with a neural scorer + identity predictor): the prediction is sat_problem._solution,
+      which only depends on parameters through values a decimation wrote, and set_variables edits the flag tensors in place that the
+      scorer's graph saved -- loss.backward() RAISES in the reference.  The exception is the fixture (train_np_d_np_reference.json)."""
+    import torch.optim as optim
+    lines = make_lines([(18, 60, (3,))] * 4 + [(14, 40, (2, 3, 4))] * 2, seed0=6100)
+    gm, bvm, bfm, ef, lab, misc = batch_tensors(lines)
+
+    def forward_loss(tr, m, cfg, out=None):
+        lam = torch.tensor([cfg['lambda']], dtype=torch.float32)
+        state = m.get_init_state(gm, bvm, bfm, ef, None, cfg['randomized'])
+        loss = torch.zeros(1)
+        step_losses, req = [], []
+        for t in range(cfg['train_outer_recurrence_num']):
+            prediction, state = m(init_state=state, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None,
+                                  is_training=True, iteration_num=cfg['train_inner_recurrence_num'])
+            lt = tr._compute_loss(model=m, loss=tr._loss, prediction=prediction, label=lab, graph_map=gm, batch_variable_map=bvm,
+                                  batch_function_map=bfm, edge_feature=ef, meta_data=None)
+            step_losses.append(float(lt)); req.append(bool(prediction[0].requires_grad))
+            if t == 0 and out is not None:
+                out['first_prediction'] = np_(prediction[0][:, 0])
+            loss = loss + lt * lam.pow(float(cfg['train_outer_recurrence_num'] - t - 1))
+        return loss, step_losses, req
+
+    def p_nd_np():
+        cfg = train_cfg(model_type='p-nd-np', model_name='golden-p-nd-np')
+        tr, m = build(cfg, seed=777)
+        m._global_step.data = torch.tensor([3.0])
+        out = problem_arrays(gm, bvm, bfm, ef)
+        out['label'] = np_(lab)
+        for k, v in flat_state_dict(m).items():
+            out[k] = v
+        with open(os.path.join(HERE, 'state_dict_alias_map_train_pndnp.json'), 'w') as f:
+            json.dump(alias_map(m), f, indent=0, sort_keys=True)
+        torch.manual_seed(31)
+        loss, step_losses, _ = forward_loss(tr, m, cfg, out)
+        loss.backward()
+        out['loss'] = np.array([float(loss)], dtype=np.float32)
+        out['step_losses'] = np.array(step_losses, dtype=np.float32)
+        for name, prm in m.named_parameters(remove_duplicate=False):
+            if prm.grad is not None and '_module_list' not in name and name.startswith(('_propagator.', '_decimator.', '_predictor.')):
+                out['g__' + name.replace('.', '__')] = np_(prm.grad)
+        tr2, m2 = build(cfg, seed=777)
+        m2._global_step.data = torch.tensor([3.0])
+        opt = optim.Adam(tr2.get_parameter_list(), lr=1e-3, weight_decay=1e-10)
+        total = np.zeros(1, dtype=np.float32)
+        torch.manual_seed(31)
+        tr2._train_batch(total, opt, gm, bvm, bfm, ef, None, lab)
+        out['train_batch_total_loss'] = total.copy()
+        for k, v in flat_state_dict(m2).items():
+            out['after__' + k] = v
+        save('train_batch_p_nd_np', **out)
+        print('p-nd-np train_batch loss', float(loss), 'step losses', step_losses, 'gradients', len([k for k in out if k.startswith('g__')]))
+    _with_b5_shim(p_nd_np)
+
+    cfg = train_cfg(model_type='np-d-np', model_name='golden-np-d-np', tolerance=0.02, t_max=10, train_outer_recurrence_num=10)    # the shipped config's values
+    tr, m = build(cfg, seed=777)
+    torch.manual_seed(31)
+    rec = dict(model_type='np-d-np', statements='FactorGraphTrainerBase._train_batch (base.py:149-182)', torch=torch.__version__)
+    try:
+        loss, step_losses, req = forward_loss(tr, m, cfg)
+        rec['prediction_requires_grad_per_step'] = req
+        loss.backward()
+        rec['raised'] = None
+    except RuntimeError as ex:
+        rec['raised'] = type(ex).__name__
+        rec['message'] = str(ex).split('\n')[0][:200]
+    with open(os.path.join(HERE, 'train_np_d_np_reference.json'), 'w') as f:
+        json.dump(rec, f, indent=1, sort_keys=True)
+    print('np-d-np:', rec)
+
+
 def gen_generators():
     """The reference's CNF generators (src/pdp/generator.py) under fixed numpy seeds: uniform, modular and variable-modular,
     generate() and generate_complete() (the variable-modular generate_complete cannot run in the reference, App. B-11)."""
@@ -1088,3 +1166,5 @@ if __name__ == '__main__':
         gen_neural_long()
     if 'train' in what:
         gen_train()
+    if 'train_hybrid' in what:
+        gen_train_hybrid()

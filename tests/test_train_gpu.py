@@ -124,8 +124,8 @@ def _train_cfg(**kw):
     return c
 
 
-def _load(m, d, prefix='w__'):
-    alias = json.load(open(os.path.join(GOLD, 'state_dict_alias_map_train.json')))
+def _load(m, d, prefix='w__', alias_file='state_dict_alias_map_train.json'):
+    alias = json.load(open(os.path.join(GOLD, alias_file)))
     sd = {}
     for key, canon in alias.items():
         k = prefix + canon.replace('.', '__')
@@ -136,19 +136,27 @@ def _load(m, d, prefix='w__'):
     m.load_state_dict(sd, strict=True)
 
 
-def test_train_batch_equals_reference():
-    """One ``_train_batch`` (base.py:149-182) of np-nd-np, hidden 32, three outer recurrences with lambda 0.9, random initial state from the
-    torch CPU stream: the per-recurrence losses and the first prediction, the gradient of EVERY parameter after loss.backward(), and the
-    parameters after the clipped Adam step, against the reference's values for the same seeds."""
+GRAD_RTOL = 5e-4          # per element; plus GRAD_ATOL x the tensor's largest |gradient| (the sums behind a weight gradient run over all edges in
+GRAD_ATOL = 5e-4          # another order than MKL's sgemm / torch's sparse mm: elements that nearly cancel carry the tensor's absolute error)
+
+
+@pytest.mark.parametrize('model_type,golden,alias_file,min_grads', [('np-nd-np', 'train_batch', 'state_dict_alias_map_train.json', 20),
+                                                                    ('p-nd-np', 'train_batch_p_nd_np', 'state_dict_alias_map_train_pndnp.json', 19)])
+def test_train_batch_equals_reference(model_type, golden, alias_file, min_grads):
+    """One ``_train_batch`` (base.py:149-182), hidden 32, three outer recurrences with lambda 0.9, random initial state from the torch CPU
+    stream: the per-recurrence losses and the first prediction, the gradient of EVERY parameter after loss.backward(), and the parameters
+    after the clipped Adam step, against the reference's values for the same seeds -- for the fully neural solver and for p-nd-np (SP
+    propagator with learned adaptors + GRU decimator + neural predictor: config/Train/p-prodec2-nsp-cnf-3-10-pytorch.yaml's model type;
+    reference + the App. B-5 width shim)."""
     import torch.optim as optim
     from pdp.trainer import SatFactorGraphTrainer
-    d = load_golden('train_batch')
+    d = load_golden(golden)
     gm, bvm, bfm, ef = [torch.from_numpy(d[k]).to(DEV) for k in ('graph_map', 'batch_variable_map', 'batch_function_map', 'edge_feature')]
     label = torch.from_numpy(d['label']).to(DEV)
-    cfg = _train_cfg()
+    cfg = _train_cfg(model_type=model_type)
     tr = SatFactorGraphTrainer(cfg, use_cuda=True, logger=LOG)
     m = tr._model_list[0]
-    _load(m, d)
+    _load(m, d, alias_file=alias_file)
     m._global_step.data = torch.tensor([3.0], device=m._global_step.device)
     torch.manual_seed(31)
     state = m.get_init_state(gm, bvm, bfm, ef, None, cfg['randomized'])
@@ -171,13 +179,13 @@ def test_train_batch_equals_reference():
         key = 'g__' + name.replace('.', '__')
         if key in d.files:
             ref = d[key]
-            np.testing.assert_allclose(npy(prm.grad), ref, rtol=2e-3, atol=2e-3 * float(np.abs(ref).max()) + 1e-9, err_msg=name)
+            np.testing.assert_allclose(npy(prm.grad), ref, rtol=GRAD_RTOL, atol=GRAD_ATOL * float(np.abs(ref).max()) + 1e-9, err_msg=name)
             checked += 1
-    assert checked == sum(1 for k in d.files if k.startswith('g__')) and checked >= 20
+    assert checked == sum(1 for k in d.files if k.startswith('g__')) and checked >= min_grads
     # the whole step through _train_batch on a fresh model
     tr2 = SatFactorGraphTrainer(cfg, use_cuda=True, logger=LOG)
     m2 = tr2._model_list[0]
-    _load(m2, d)
+    _load(m2, d, alias_file=alias_file)
     m2._global_step.data = torch.tensor([3.0], device=m2._global_step.device)
     opt = optim.Adam(tr2.get_parameter_list(), lr=1e-3, weight_decay=1e-10)
     total = np.zeros(1, dtype=np.float32)
@@ -185,7 +193,7 @@ def test_train_batch_equals_reference():
     tr2._train_batch(total, opt, gm, bvm, bfm, ef, None, label)
     np.testing.assert_allclose(total, d['train_batch_total_loss'], rtol=2e-5)
     sd = m2.state_dict()
-    alias = json.load(open(os.path.join(GOLD, 'state_dict_alias_map_train.json')))
+    alias = json.load(open(os.path.join(GOLD, alias_file)))
     n_el = n_far = 0
     for key, canon in alias.items():
         k = 'after__w__' + canon.replace('.', '__')
@@ -194,8 +202,73 @@ def test_train_batch_equals_reference():
             assert np.abs(got - ref).max() <= 2.1e-3                           # an Adam step moves every weight by at most lr
             far = np.abs(got - ref) > 2e-6                                     # (a sign flip of a vanishing gradient is a full 2 lr apart)
             n_el += got.size; n_far += int(far.sum())
-            assert np.abs(ref - before).max() > 5e-4                           # the step moved the weights
-    assert n_el > 30000 and n_far <= 0.002 * n_el, (n_far, n_el)
+            if d['g__' + canon.replace('.', '__')].any() if ('g__' + canon.replace('.', '__')) in d.files else True:
+                assert np.abs(ref - before).max() > 5e-4, canon                # the step moved the weights
+    assert n_el > 15000 and n_far <= 0.002 * n_el, (n_far, n_el)
+
+
+def test_sp_adapted_sweep_forward_and_adjoint_vs_torch(oracle):
+    """train_ops.SpAdaptedSweep (pdp_sp_propagate_adapted / pdp_train_sp_adapted_backward) against torch autograd of the reference's
+    formulation (pdp_propagate.py:163-221 written with index_add for the sparse products), with and without an edge mask, pi 0 and 0.1."""
+    from pdp.nn import train_ops as T
+    b = random_batch(batch=11, n=30, mixed=True, seed=91)
+    hp, op = make_pair(oracle, b)
+    E = hp.E
+    gmap = torch.from_numpy(b['graph_map'].astype(np.int64)).to(DEV)
+    s = t(b['edge_feature']).reshape(-1)
+    g = torch.Generator(device='cpu'); g.manual_seed(5)
+    for pi, with_mask in ((0.0, False), (0.1, True)):
+        z = (torch.randn(E, generator=g) * 2).to(DEV).requires_grad_(True)
+        u0 = (torch.randn(E, generator=g) * 2).to(DEV).requires_grad_(True)
+        force = torch.sign(torch.randn(E, generator=g)).to(DEV)
+        em = ((torch.rand(E, generator=g) > 0.2).float().to(DEV)) if with_mask else None
+        gq = torch.randn(E, 3, generator=g).to(DEV); ge = torch.randn(E, generator=g).to(DEV)
+
+        def ours():
+            xlog = F.logsigmoid(z)
+            fs2 = torch.stack((torch.sigmoid(u0), force), 1)
+            return T.SpAdaptedSweep.apply(xlog, fs2, hp, em, pi)
+
+        def ref():
+            eps, mx = 1e-40, 30.0
+            x = F.logsigmoid(z)
+            if em is not None:
+                x = x * em
+            S = torch.zeros(hp.F, device=DEV).index_add(0, gmap[1], x)
+            eta = torch.clamp(S[gmap[1]] - x, max=mx).exp()
+            y = torch.clamp(1 - torch.sigmoid(u0), min=eps).log()
+            if em is not None:
+                y = y * em
+            P = torch.zeros(hp.V, device=DEV).index_add(0, gmap[0], y * (s > 0).float())[gmap[0]]
+            N = torch.zeros(hp.V, device=DEV).index_add(0, gmap[0], y * (s < 0).float())[gmap[0]]
+            lg = lambda c: torch.clamp(1.0 - pi * c.float(), min=eps).log()
+            same = 0.5 * (1 + s) * P + 0.5 * (1 - s) * N - y + lg(force == s)
+            opp = 0.5 * (1 - s) * P + 0.5 * (1 + s) * N + lg(force == -s)
+            dc = torch.clamp(same + opp, max=mx).exp()
+            A, B = torch.clamp(same, max=mx).exp(), torch.clamp(opp, max=mx).exp()
+            qu, qs = A * (1 - B), B * (1 - A)
+            tot = qu + qs + dc
+            return torch.stack((qu, qs, dc), 1) / tot.unsqueeze(1), torch.stack((eta, force), 1)
+
+        outs = []
+        for fn in (ours, ref):
+            z.grad = u0.grad = None
+            q, fs = fn()
+            ((q * gq).sum() + (fs[:, 0] * ge).sum()).backward()
+            outs.append((q.detach().clone(), fs.detach().clone(), z.grad.clone(), u0.grad.clone()))
+        for a, r, name in zip(outs[0], outs[1], ('q', 'fs', 'dz', 'du0')):
+            torch.testing.assert_close(a, r, rtol=2e-4, atol=2e-5 * float(r.abs().max().clamp(min=1e-3)), msg=lambda m_: '%s (pi %g): %s' % (name, pi, m_))
+
+
+def test_np_d_np_training_is_refused_like_the_reference_fails():
+    """The reference cannot train np-d-np: its prediction is sat_problem._solution (IdentityPredictor), and loss.backward() raises (the fixture
+    records the reference's own exception for _train_batch's statements).  This build refuses that model type up front, with the reason."""
+    from pdp.trainer import SatFactorGraphTrainer
+    ref = json.load(open(os.path.join(GOLD, 'train_np_d_np_reference.json')))
+    assert ref['raised'] == 'RuntimeError' and not all(ref['prediction_requires_grad_per_step'])
+    tr = SatFactorGraphTrainer(_train_cfg(model_type='np-d-np', tolerance=0.02, t_max=10), use_cuda=True, logger=LOG)
+    with pytest.raises(Exception, match='np-d-np'):
+        tr.train([os.path.join(GOLD, 'train_small.json')], [os.path.join(GOLD, 'train_small.json')], None)
 
 
 def test_train_run_equals_reference():
