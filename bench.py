@@ -289,48 +289,65 @@ def cpu_baseline_neural(args):
 # =====================================================================================================================
 # configs[2]: the neural workload (standalone with --workload neural, and as a short secondary measurement of the default run)
 # =====================================================================================================================
-# MACs per edge / per variable of the kernels of one np-nd-np iteration at hidden H, inner widths 100 / 50 / 100
-def neural_flops(H):
-    return dict(agg_pre=2.0 * ((H + 1) * 100 + 100 * 50),          # per edge and aggregator call: W1_m, W2_m
-                agg_post=2.0 * (51 * 100 + 100 * H),               # per edge: W1_a, W2_a
-                gru=2.0 * (3 * H * (H + 1) + 3 * H * H),           # per edge: W_ih, W_hh
-                predict_head=2.0 * (50 * 100 + 100 * H + H * 50 + 50))    # per VARIABLE: predictor's W1_a, W2_a + perceptron head
+# MACs per edge / per variable of the kernels of one neural iteration at hidden H, inner widths 100 / 50 / 100
+def neural_flops(H, model_type='np-nd-np'):
+    "flop per launch unit: per EDGE for agg_pre / agg_post / gru (one cell), per VARIABLE for predict_head"
+    gru_in = 2.0 * (3 * H * (H + 1) + 3 * H * H)                      # np-nd-np: [state, sign] -> 129 inputs at H = 128
+    if model_type == 'p-nd-np':                                       # surveys + sign / [eta, force] + sign: 4- and 3-wide inputs, mean of the two cells
+        gru_in = 2.0 * (3 * H * 3.5 + 3 * H * H)
+    return dict(agg_pre=2.0 * ((H + 1) * 100 + 100 * 50),            # W1_m, W2_m
+                agg_post=2.0 * (51 * 100 + 100 * H),                 # W1_a, W2_a
+                gru=gru_in,                                          # W_ih, W_hh of ONE cell
+                predict_head=2.0 * (50 * 100 + 100 * H + H * 50 + 50))    # predictor's W1_a, W2_a + perceptron head
 
 
-def make_neural_model(args, T):
+def neural_flop_per_iteration(model_type, H, E, V):
+    """algorithmic flop of one iteration (573 752 E + 48 500 V for np-nd-np at H = 128).  np-nd-np: two edge aggregators, two GRU
+    cells, the predictor's pre-transform + per-variable layers.  p-nd-np: the propagator is the SP sweep (no matrix work) behind three
+    H-long dot products per edge (the adaptors), GRU cells with 4- and 3-wide inputs, the same predictor."""
+    fl = neural_flops(H, model_type)
+    if model_type == 'np-nd-np':
+        per_edge = 2 * (fl['agg_pre'] + fl['agg_post']) + 2 * fl['gru'] + fl['agg_pre']
+    else:
+        per_edge = 2.0 * 3 * H + 2 * fl['gru'] + fl['agg_pre']
+    return per_edge * E + fl['predict_head'] * V
+
+
+def make_neural_model(args, T, model_type='np-nd-np', hidden=None):
     import logging
     import torch
     from pdp.trainer import SatFactorGraphTrainer
-    cfg = dict(model_type='np-nd-np', model_name='bench-np-nd-np', verbose=False, local_search_iteration=0, epsilon=0.5, rng='philox',
-               random_seed=1, hidden_dim=args.hidden, edge_feature_dim=1, meta_feature_dim=0, prediction_dim=1, mem_hidden_dim=100,
+    cfg = dict(model_type=model_type, model_name='bench-' + model_type, verbose=False, local_search_iteration=0, epsilon=0.5, rng='philox',
+               random_seed=1, hidden_dim=hidden or args.hidden, edge_feature_dim=1, meta_feature_dim=0, prediction_dim=1, mem_hidden_dim=100,
                agg_hidden_dim=100, mem_agg_hidden_dim=50, classifier_dim=50, test_batch_limit=1 << 62, batch_size=args.batch,
-               test_recurrence_num=T)
+               test_recurrence_num=T, tolerance=args.tolerance, t_max=args.t_max)
     torch.manual_seed(1234)
     tr = SatFactorGraphTrainer(cfg, use_cuda=True, logger=logging.getLogger('bench'))
     return tr, tr._model_list[0]
 
 
-def neural_step(tr, model, b, T):
+def neural_step(tr, model, b, T, replication=1):
     import torch
     gm, bvm, bfm, ef = b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature']
     with torch.no_grad():
-        st = model.get_init_state(gm, bvm, bfm, ef, None, randomized=False, batch_replication=1)
+        st = model.get_init_state(gm, bvm, bfm, ef, None, randomized=False, batch_replication=replication)
         model(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None,
-              is_training=False, iteration_num=T, check_termination=tr._check_recurrence_termination, batch_replication=1)
+              is_training=False, iteration_num=T, check_termination=tr._check_recurrence_termination, batch_replication=replication)
     return model.last_run['iterations']
 
 
-def neural_kernel_rooflines(native, timing, E, V, H):
-    "per-kernel lines from the library's HIP events: ms per launch, algorithmic flop per launch, TFLOP/s, fraction of the fp32 MFMA peak"
-    fl = neural_flops(H)
+def neural_kernel_rooflines(native, timing, E, V, H, model_type='np-nd-np'):
+    """per-kernel lines from the library's HIP events: ms per launch, algorithmic flop per launch, TFLOP/s, fraction of the fp32 MFMA peak.
+    E / V: edges / variables one launch covers (summed over launches when segments differ: pass the launch-weighted means).  The kernel
+    names are what the library reports it launched last (pdp_kernel_name), not literals."""
+    fl = neural_flops(H, model_type)
     out = {}
-    for key, kernels in (('agg_pre', 'k_agg_pre_wave'), ('agg_post', 'k_agg_post_pf'), ('gru', 'k_gru_wave' if H == 150 else 'k_gru_pipe'), ('predict_head', 'k_predict_rows'),
-                         ('row_sum', 'k_row_sum')):
+    for key in ('agg_pre', 'agg_post', 'gru', 'predict_head', 'row_sum'):
         ms, n = timing[key]
         if n == 0:
             continue
         per = ms / n
-        row = dict(kernel=kernels, launches=n, ms_per_launch=per)
+        row = dict(kernel=native.kernel_name(key) if key != 'row_sum' else 'k_row_sum', launches=n, ms_per_launch=per)
         if key in fl:
             flop = fl[key] * (V if key == 'predict_head' else E)
             tf = flop / (per * 1e-3) / 1e12
@@ -342,6 +359,69 @@ def neural_kernel_rooflines(native, timing, E, V, H):
         tf = (fl['agg_pre'] + fl['agg_post']) * E / (ms * 1e-3) / 1e12
         out['aggregator_call'] = dict(ms=ms, tflops=tf, frac_of_mfma_f32_peak=tf / MFMA_F32_PEAK_TFLOPS)
     return out
+
+
+def neural_shard(args, dev, native, items, model_type, hidden, T, replication=1, limit=None, walksat_steps=0, workload=''):
+    """One rank's share of a neural BASELINE config on this GPU, outside the headline's timed loop: the loader's dynamic segments (dataset.divide
+    with the reference's edge x hidden limit), T sweeps of the model per segment through the Python API (warm-up pass first), then the
+    Walk-SAT pass on the last segment's problem.  Returns the numbers every fraction is computed from."""
+    import torch
+    from pdp.factorgraph import dataset
+    edges = [it[2].shape[1] for it in items]
+    segs = dataset.divide(edges, (limit or (1 << 62)) // replication, hidden)
+    tr, model = make_neural_model(args, T, model_type, hidden)
+    batches = [dataset.to_torch(dataset.collate_segment([items[j] for j in seg]), dev) for seg in segs]
+    E_seg = [int(b['graph_map'].size(1)) * replication for b in batches]
+    V_seg = [int(b['batch_variable_map'].numel()) * replication for b in batches]
+    for b in batches:                                                  # warm-up: the same pass once (native workspaces, torch's caching allocator)
+        neural_step(tr, model, b, T, replication)
+    torch.cuda.synchronize()
+    native.kernel_timing(True)
+    t0 = time.perf_counter()
+    its = [neural_step(tr, model, b, T, replication) for b in batches]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timing = native.kernel_timing_read(); native.kernel_timing(False)
+    flop = sum(neural_flop_per_iteration(model_type, hidden, e, v) * it for e, v, it in zip(E_seg, V_seg, its))
+    tf = flop / dt / 1e12
+    n_seg = float(len(segs))
+    out = dict(workload=workload, model_type=model_type, hidden=hidden, instances=len(items), batch_replication=replication,
+               segments=[len(sg) for sg in segs], edges_per_segment_with_replicas=E_seg, iterations_per_segment=its, seconds=dt,
+               segment_iterations_per_sec=sum(its) / dt, ms_per_iteration_mean=1e3 * dt / max(1, sum(its)), flop_total=flop,
+               flop_per_iteration_mean=flop / max(1, sum(its)), path=model.last_run['path'],
+               roofline=dict(bound='mfma', achieved=tf, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s', frac=tf / MFMA_F32_PEAK_TFLOPS,
+                             note='algorithmic flop of the executed sweeps (neural_flop_per_iteration per segment) / wall time of the forwards, '
+                                  'set-up of each SATProblem included'),
+               kernels=neural_kernel_rooflines(native, timing, sum(E_seg) / n_seg, sum(V_seg) / n_seg, hidden, model_type))
+    if walksat_steps > 0:
+        prob = model._last_problem._native
+        prob.random_fill(seed=4321)
+        start = prob.solution.clone()
+        prob.local_search(start, 2, 0.5, seed=5)
+        torch.cuda.synchronize()
+        native.kernel_timing(True)
+        t0 = time.perf_counter()
+        res, steps = prob.local_search(start, walksat_steps, 0.5, seed=999)
+        torch.cuda.synchronize()
+        dtw = time.perf_counter() - t0
+        kms, kn = native.kernel_timing_read()['walksat']; native.kernel_timing(False)
+        out['walksat'] = dict(steps=steps, instances_with_replicas=prob.B, call_seconds=dtw, kernel=native.kernel_name('walksat'), kernel_ms=kms,
+                              kernel_launches=kn, flips_per_sec=steps * prob.B / dtw, us_per_step=1e6 * dtw / max(1, steps))
+    del tr, model, batches
+    torch.cuda.empty_cache()
+    return out
+
+
+def config4_items(count, seed0=1000):
+    "BASELINE configs[4]'s family (SURVEY 8(d)): k in {3,4,5} per instance, alpha_k = 0.9 x (4.27, 9.93, 21.12), n ~ U{100..500}"
+    from pdp.factorgraph import dataset
+    rng = np.random.RandomState(0)
+    alpha = {3: 0.9 * 4.27, 4: 0.9 * 9.93, 5: 0.9 * 21.12}
+    items = []
+    for i in range(count):
+        k = int(rng.choice([3, 4, 5])); n = int(rng.randint(100, 501))
+        items += dataset.random_ksat_items(1, n, k, m=int(round(alpha[k] * n)), seed=seed0 + i)
+    return items
 
 
 def bench_neural(args, dev, rank, world):
@@ -392,7 +472,7 @@ def bench_neural(args, dev, rank, world):
         iters_all = float(tot[0].item())
         value = iters_all / elapsed
         cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline_neural(args)
-        flops_iter = 573752.0 * E + 48500.0 * V
+        flops_iter = neural_flop_per_iteration('np-nd-np', args.hidden, E, V)
         achieved = flops_iter * float(np.mean(iters_done)) / (float(np.mean(step_ms)) * 1e-3) / 1e12
         print(json.dumps({
             'metric': 'pdp_iterations_per_sec', 'value': value,
@@ -404,9 +484,9 @@ def bench_neural(args, dev, rank, world):
                        'E': E, 'V': V, 'F': F, 'iterations_per_step': float(np.mean(iters_done)), 'path': model.last_run['path'],
                        'instance_iterations_per_sec': value * args.batch, 'parallelism': 'instances sharded, dp%d' % world},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / MFMA_F32_PEAK_TFLOPS,
-                         'traffic': None, 'kernel': 'k_gru_pipe / k_agg_pre_wave / k_agg_post_pf (v_mfma_f32_32x32x2_f32)',
+                         'traffic': None, 'kernel': ' / '.join(native.kernel_name(k) for k in ('gru', 'agg_pre', 'agg_post')) + ' (v_mfma_f32_32x32x2_f32)',
                          'kernels': neural_kernel_rooflines(native, timing, E, V, args.hidden),
-                         'note': 'achieved = (573752 E + 48500 V) flop per iteration x iterations / step time (whole step, all kernels); '
+                         'note': 'achieved = neural_flop_per_iteration (573752 E + 48500 V at hidden 128) x iterations / step time (whole step, all kernels); '
                                  'kernels: HIP events of the library around every launch, flop = the MACs of that kernel x 2'},
             'cpu_baseline': cpu}))
     if world > 1:
@@ -433,7 +513,7 @@ def secondary_measurements(args, dev, b, prob, native):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         timing = native.kernel_timing_read(); native.kernel_timing(False)
-        flops_iter = 573752.0 * E + 48500.0 * V
+        flops_iter = neural_flop_per_iteration('np-nd-np', saved_hidden, E, V)
         tf = flops_iter * it / dt / 1e12
         out['neural'] = dict(workload="configs[2]: 'np-nd-np' hidden_dim=%d on the same batch, T=%d, seeded random-init weights" % (saved_hidden, T),
                              iterations=it, seconds=dt, iterations_per_sec=it / dt, flop_per_iteration=flops_iter,
@@ -461,16 +541,15 @@ def secondary_measurements(args, dev, b, prob, native):
         kms, kn = timing['walksat']
         pred = prob.update_solution(res.reshape(-1).contiguous())
         solved, unsat = prob.cnf_eval(pred.reshape(-1).contiguous())
-        bytes_step = 13.0 * E + 8.0 * V                                # one full re-evaluation step of the non-incremental form
-        ach = bytes_step * steps / (kms * 1e-3) / 1e9 if kms > 0 else None
         out['walksat'] = dict(workload='%d Walk-SAT steps (epsilon 0.5, Philox) on the headline batch from the random fill' % steps_req,
-                              steps=steps, call_seconds=dt, kernel='k_walksat_lds', kernel_ms=kms, kernel_launches=kn,
-                              steps_per_sec=steps / dt, instance_steps_per_sec=steps * B / dt,
+                              steps=steps, call_seconds=dt, kernel=native.kernel_name('walksat'), kernel_ms=kms, kernel_launches=kn,
+                              steps_per_sec=steps / dt, flips_per_sec=steps * B / dt, us_per_step=(1e3 * kms / steps) if steps else None,
                               solved_fraction=float(solved.sum().item()) / B, unsat_clauses_total=float(unsat.sum().item()),
-                              roofline=dict(bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s', frac=(ach / HBM_PEAK_GBS) if ach else None,
-                                            note='streaming model 13 E + 8 V bytes per step x steps / kernel time; the kernel is LDS-resident '
-                                                 'and incremental (it touches O(degree) words per flip), so this is the fraction of what a '
-                                                 'perfect full-re-evaluation implementation could do, like the headline kernel\'s'))
+                              bound='latency: one workgroup per instance, a step = an LDS scan of the n variables into two 64-bit LDS arg-max atomics, '
+                                    'the flip, an O(degree) integer update, two workgroup barriers; every instance of the batch is resident at once '
+                                    'or in a few rounds.  The kernel is incremental and LDS-resident: the streaming model of SURVEY 8(d) (13 E + 8 V '
+                                    'bytes per full re-evaluation step) does not describe it (a fraction above 1 came out of it), so no roofline '
+                                    'fraction is claimed -- flips/s is the figure of merit; tools/ws_prof.py splits a step into its phases')
     except Exception as ex:
         out['walksat'] = dict(error=repr(ex))
     # ---- Reinforce solver: the persistent kernel's other instantiation --------------------------------------------------------------------
@@ -499,7 +578,7 @@ def secondary_measurements(args, dev, b, prob, native):
         ach = bytes_launch / (per_launch * 1e-3) / 1e9
         out['reinforce'] = dict(workload="'reinforce' (pi 0.1, decimation probability 0.5) on the headline batch, T=%d, the persistent loop" % T,
                                 iterations=it, call_seconds=dt, iterations_per_sec=it / dt, path='persistent-lds' if lds else 'persistent-hbm',
-                                kernel='k_sp_solve_lds<true, false, true, false>', kernel_launches=st['launches'], kernel_ms_per_launch=per_launch,
+                                kernel=native.kernel_name('sp_solve'), kernel_launches=st['launches'], kernel_ms_per_launch=per_launch,
                                 replay_launches=st['replays'], replay_ms=st['replay_kernel_ms'],
                                 roofline=dict(bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS,
                                               note='streaming-model bytes (41E+36V+8F per iteration) x iterations per launch / launch time'))
@@ -507,6 +586,33 @@ def secondary_measurements(args, dev, b, prob, native):
         out['reinforce'] = dict(error='speculation failed: %s' % ex)
     except Exception as ex:
         out['reinforce'] = dict(error=repr(ex))
+    return out
+
+
+def config_shard_measurements(args, dev, native):
+    """BASELINE configs[3] and configs[4] at the shape ONE GPU of the 8 gets (the 8-GPU runs deal whole loader batches to ranks, pdp/parallel.py),
+    outside the headline's timed loop: configs[3] = np-nd-np hidden 128 on 5 000 instances of n=400 m=1680 (one loader batch of 40 000 / 8)
+    for T sweeps + 1 000 Walk-SAT steps; configs[4] = p-nd-np hidden 128 on mixed k-SAT, batch_replication 4, the reference's dynamic
+    segments (limit x hidden), T sweeps + 30 Walk-SAT steps.  T is short (the sweeps cost the same each): per-sweep rates, not solved counts."""
+    from pdp.factorgraph import dataset
+    out = {}
+    T = args.secondary_neural_iters
+    try:
+        n3, b3 = 400, args.config3_batch
+        items = dataset.random_ksat_items(b3, n3, 3, m=int(round(4.2 * n3)), seed=7000001)
+        out['config3_shard'] = neural_shard(args, dev, native, items, 'np-nd-np', 128, T, walksat_steps=1000,
+                                            workload="configs[3] per GPU: 'np-nd-np' hidden_dim=128, random 3-SAT n=%d m=%d, %d instances (one loader batch of "
+                                                     "the 40 000), T=%d of 200, then 1 000 Walk-SAT steps" % (n3, int(round(4.2 * n3)), b3, T))
+        del items
+    except Exception as ex:
+        out['config3_shard'] = dict(error=repr(ex))
+    try:
+        items = config4_items(args.config4_instances)
+        out['config4_shard'] = neural_shard(args, dev, native, items, 'p-nd-np', 128, T, replication=4, limit=int(4e9), walksat_steps=30,
+                                            workload="configs[4] per GPU: 'p-nd-np' hidden_dim=128, mixed random k-SAT k in {3,4,5}, n in [100,500], %d instances, "
+                                                     "batch_replication 4, dynamic segments (-l 4e9), T=%d, then 30 Walk-SAT steps" % (args.config4_instances, T))
+    except Exception as ex:
+        out['config4_shard'] = dict(error=repr(ex))
     return out
 
 
@@ -610,6 +716,8 @@ def main():
                     'iterations only if set-up + first iteration took less than this many seconds')
     ap.add_argument('--secondary-neural-iters', type=int, default=3)
     ap.add_argument('--secondary-walksat-steps', type=int, default=1000)
+    ap.add_argument('--config3-batch', type=int, default=5000, help='instances of the configs[3] shard measurement (n = 400)')
+    ap.add_argument('--config4-instances', type=int, default=600, help='instances (before the 4 replicas) of the configs[4] shard measurement')
     ap.add_argument('--selftest-collective', action='store_true', help='the N-rank plumbing only (no GPU work); used by the gloo test')
     args = ap.parse_args()
 
@@ -751,6 +859,7 @@ def main():
                                     'this run\'s launch time)'}
             except Exception:
                 traffic, valu = None, None
+        solve_kernel_name = native.kernel_name('sp_solve')
         config = {'workload': "configs[1]: 'p-d-p' survey propagation, random 3-SAT n=%d m=%d batch=%d T=%d per GPU" % (args.n, m, args.batch, args.iters),
                   'E': E, 'V': V, 'F': F, 'iterations_per_step': it_mean, 'path': paths[0] if paths else None,
                   'instance_iterations_per_sec': value * args.batch, 'edge_updates_per_sec': value * 2 * E,
@@ -763,6 +872,9 @@ def main():
             config['solved'] = solved_fractions(args, dev, b, native, rank)
             config['secondary'] = secondary_measurements(args, dev, b, prob, native)
             config['secondary'].update(big_instance_measurements(args, dev, items, value, native))
+            del prob, b
+            torch.cuda.empty_cache()
+            config['secondary'].update(config_shard_measurements(args, dev, native))
         line = {
             'metric': 'pdp_iterations_per_sec', 'value': value,
             'unit': 'iterations/s (each iteration sweeps a batch of %d instances)' % args.batch,
@@ -770,7 +882,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': config,
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'traffic_source': src, 'valu_issue': valu, 'kernel': 'k_sp_solve_lds<false, false, false>',
+                         'traffic': traffic, 'traffic_source': src, 'valu_issue': valu, 'kernel': solve_kernel_name,
                          'note': 'achieved = streaming-model algorithmic bytes (41E+36V+8F per iteration) x iterations per launch / '
                                  'average launch duration (HIP events on the launch stream, this run); the instance state is LDS-resident, '
                                  'so the kernel is bound by VALU issue, not by HBM (DESIGN.md section 4); traffic / valu_issue come from the '

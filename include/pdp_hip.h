@@ -285,12 +285,18 @@ int pdp_sat_loss_grad(pdp_problem *p, const float *pred, float coeff, float eps,
  * of launches since the last read.  No effect on results; off by default. */
 enum { PDP_TK_AGG_PRE = 0,      /* k_agg_pre_wave / k_agg_pre_res / k_agg_pre: first half of a MessageAggregator (two layers per edge) */
        PDP_TK_ROW_SUM = 1,      /* k_row_sum: per-row sum of the pre-transformed edges */
-       PDP_TK_AGG_POST = 2,     /* k_agg_post_pf / k_agg_post_res / k_agg_post: second half (two layers per edge, masked blend) */
-       PDP_TK_GRU = 3,          /* k_gru_pipe / k_gru_window / k_gru */
+       PDP_TK_AGG_POST = 2,     /* k_agg_post_pf / k_agg_post_wave (hidden 150) / k_agg_post: second half (two layers per edge, masked blend) */
+       PDP_TK_GRU = 3,          /* k_gru_pipe (hidden 128) / k_gru_wave (hidden 150) / k_gru */
        PDP_TK_PREDICT_HEAD = 4, /* k_predict_rows: per-variable layers + perceptron head of NeuralPredictor */
-       PDP_TK_WALKSAT = 5,      /* k_walksat_lds: the persistent Walk-SAT launch(es) of pdp_local_search */
-       PDP_TK_COUNT = 6 };
+       PDP_TK_WALKSAT = 5,      /* k_walksat<uint16_t, 256>: the persistent LDS-resident Walk-SAT launch of pdp_local_search */
+       PDP_TK_COUNT = 6,
+       /* name-only keys (their times come back through pdp_solve_args) */
+       PDP_KN_SP_SOLVE = 6,     /* pass 1 of pdp_sp_solve (k_sp_solve_lds<...> / k_sp_solve<...>) */
+       PDP_KN_SP_REPLAY = 7,    /* its NaN-poison replay instantiation */
+       PDP_KN_COUNT = 8 };
 int pdp_kernel_timing(int enable);
+/* the name (with template arguments, as rocprofv3 prints it) of the kernel the library launched last for `key`; empty before the first launch */
+int pdp_kernel_name(int key, char *buf, int len);
 int pdp_kernel_timing_read(float *ms_host /*[PDP_TK_COUNT]*/, int32_t *launches_host /*[PDP_TK_COUNT]*/);
 
 /* ---- math probes (tests: device exp/log must equal the host header bit for bit) ---------------------- */

@@ -29,6 +29,9 @@ void pdp_dev_free(void *ptr);
 // ---- optional kernel timing (pdp_kernel_timing, pdp_problem.hip): events on the launch stream around a scope ------------------------
 void pdp_timing_mark(int key, hipStream_t st, bool begin);
 extern int g_pdp_timing_on;
+// name of the kernel last launched for a key (pdp_kernel_name): bench.py labels its per-kernel lines with what the library really ran
+extern const char *g_pdp_kernel_name[];
+inline void pdp_note_kernel(int key, const char *name) { g_pdp_kernel_name[key] = name; }
 struct pdp_timed_scope {
     int key; hipStream_t st;
     pdp_timed_scope(int k, hipStream_t s) : key(k), st(s) { if (g_pdp_timing_on) pdp_timing_mark(key, st, true); }

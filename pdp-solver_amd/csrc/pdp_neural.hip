@@ -12,8 +12,9 @@
 // the accumulator registers.  Row sums between the two halves of an aggregator are sequential in ascending edge id.
 //
 // Kernel map (DESIGN.md section 4.4 has the measurements behind each choice):
-//   generic shapes      k_agg_pre / k_agg_pre_res, k_row_sum, k_agg_post (/ k_agg_post_res), k_predict_rows, k_gru, k_gru_window
-//   hidden 128 and 150  k_agg_pre_wave (a wave owns a 32-edge tile through both layers), k_agg_post_pf (prefetched chains)
+//   generic shapes      k_agg_pre / k_agg_pre_res, k_row_sum, k_agg_post, k_predict_rows, k_gru
+//   hidden 128 and 150  k_agg_pre_wave (a wave owns a 32-edge tile through both layers), k_agg_post_pf (prefetched chains; at 150 the
+//                       full tiles run k_agg_post_wave, a wave per tile)
 //   hidden 128          k_gru_pipe (in-wave pipelined MFMA chains and activation slices; also the 4- / 3-input cells of p-nd-np)
 //   hidden 150          k_gru_wave (a wave owns a 32-edge tile through all five column blocks: one software pipeline per tile)
 // What bounds them: on gfx950 the f32 MFMA and the VALU share issue time on a SIMD -- their times add up whichever wave issues them --
@@ -630,7 +631,7 @@ __global__ void __launch_bounds__(NTN, 6) k_agg_post_pf(int E, const float *__re
     }
 }
 
-// ---- kernel 3 with a WAVE as the unit of work (default at hidden 150, opt-in at hidden 128: PDP_NEURAL_POST_WAVE) ---------------------------
+// ---- kernel 3 with a WAVE as the unit of work (hidden 150) ---------------------------------------------------------------------------------
 // The form that made the hidden-150 GRU fast, tried on the post-transform: a wave owns a 32-edge tile (four waves per workgroup, one per
 // SIMD, 512 registers per lane), both layers run over all their column blocks as straight-line chains whose weights are requested two
 // chunks ahead across the layer and tile boundaries, and everything the tile reads from HBM is requested at the start of an activation
@@ -1300,6 +1301,9 @@ static int set_lds(const void *fn, size_t bytes)
 static float *neural_ws(pdp_problem *p, int slot, size_t floats);
 
 #define LDS_RES_LIMIT (160 * 1024 - 512)
+// PDP_NEURAL_GENERIC=1: every operator on its generic tile kernel (k_agg_pre / k_agg_post / k_gru) -- the cross-check the full-size tests run
+// against the specialised kernels, bit for bit
+static bool generic_forced() { return getenv("PDP_NEURAL_GENERIC") != nullptr; }
 static int persistent_grid()
 {
     if (const char *e = getenv("PDP_NEURAL_GRID")) { const int v = atoi(e); if (v > 0) return v; }   // tests: many tiles per workgroup on small inputs
@@ -1315,9 +1319,8 @@ static int launch_agg_pre(int E, const float *state, const float *sign, const fl
     const int tiles = (E + TM - 1) / TM;
     const size_t lds1 = sizeof(float) * (size_t)TM * ((w.Kp1 + 1) + (w.Np1 + 1));
     const size_t res1 = sizeof(float) * ((size_t)w.Kp1 * w.Np1 + (size_t)w.Kp2 * w.Np2) + lds1;
-    const bool tile_form = getenv("PDP_NEURAL_AGG_TILE") != nullptr;
     const bool shape128 = w.din - 1 == 128 && w.Kp1 == 130, shape150 = w.din - 1 == 150 && w.Kp1 == 152;
-    if (!tile_form && (shape128 || shape150) && w.Np1 == 128 && w.Kp2 == 100 && w.Np2 == 64) {
+    if (!generic_forced() && (shape128 || shape150) && w.Np1 == 128 && w.Kp2 == 100 && w.Np2 == 64) {
         // hidden 128 (BASELINE configs) or 150 (the reference's shipped predict config) with the 100 / 50 inner widths
         const int ldw = shape128 ? 131 : 153;
         const size_t ldsw = sizeof(float) * (size_t)NWAVES * WT * ldw;
@@ -1325,14 +1328,17 @@ static int launch_agg_pre(int E, const float *state, const float *sign, const fl
         int s = set_lds(fn, ldsw); if (s != PDP_OK) return s;
         const int wt = (E + WT - 1) / WT, need = (wt + NWAVES - 1) / NWAVES;
         const int grid = need < persistent_grid() ? need : persistent_grid();
+        pdp_note_kernel(PDP_TK_AGG_PRE, shape128 ? "k_agg_pre_wave<65, 4, 50, 2>" : "k_agg_pre_wave<76, 4, 50, 2>");
         if (shape128) hipLaunchKernelGGL((k_agg_pre_wave<65, 4, 50, 2>), dim3(grid), dim3(NTN), ldsw, st, E, state, sign, edge_mask, w, h2, wt);
         else hipLaunchKernelGGL((k_agg_pre_wave<76, 4, 50, 2>), dim3(grid), dim3(NTN), ldsw, st, E, state, sign, edge_mask, w, h2, wt);
-    } else if (res1 <= LDS_RES_LIMIT && w.Kp1 <= 64 * PRE_C) {
+    } else if (!generic_forced() && res1 <= LDS_RES_LIMIT && w.Kp1 <= 64 * PRE_C) {
         int s = set_lds((const void *)k_agg_pre_res, res1); if (s != PDP_OK) return s;
         const int grid = tiles < persistent_grid() ? tiles : persistent_grid();
+        pdp_note_kernel(PDP_TK_AGG_PRE, "k_agg_pre_res");
         hipLaunchKernelGGL(k_agg_pre_res, dim3(grid), dim3(NTN), res1, st, E, state, w.din - 1, sign, edge_mask, w, h2, tiles);
     } else {
         int s = set_lds((const void *)k_agg_pre, lds1); if (s != PDP_OK) return s;
+        pdp_note_kernel(PDP_TK_AGG_PRE, "k_agg_pre");
         hipLaunchKernelGGL(k_agg_pre, dim3(tiles), dim3(NTN), lds1, st, E, state, w.din - 1, sign, edge_mask, w, h2);
     }
     return PDP_OK;
@@ -1363,60 +1369,38 @@ extern "C" int pdp_neural_aggregate_edges(pdp_problem *p, const pdp_agg_desc *d,
     { pdp_timed_scope timed(PDP_TK_ROW_SUM, st);
       hipLaunchKernelGGL(k_row_sum, dim3((unsigned)(((int64_t)R * w.a + 255) / 256)), dim3(256), 0, st, R, w.a, row_ptr, row_edges, h2, agg); }
     const int32_t *edge_row = by_variable ? p->graph_map : p->graph_map + E;
-    const size_t res3 = sizeof(float) * ((size_t)w.Kp3 * w.Np3 + (size_t)w.Kp4 * w.Np4) + lds3;
-    // the post-transform has little MFMA work per tile and a gather-heavy tile load: three small workgroups per CU (tile-per-workgroup
-    // form) overlap better than one resident one (12.8 vs 18.3 ms at config 3), so the resident form is opt-in
-    const bool post_res = getenv("PDP_NEURAL_POST_RESIDENT") != nullptr;
-    const bool post_plain = getenv("PDP_NEURAL_POST_PLAIN") != nullptr;
     pdp_timed_scope timed_post(PDP_TK_AGG_POST, st);
-    const bool shape_pf = w.Kp3 == 52 && w.Np3 == 128 && w.Kp4 == 100 && ((w.Np4 == 128 && w.out == 128) || (w.Np4 == 160 && w.out == 150));
-    // the wave-per-tile form: default at hidden 150 (five output column blocks leave two of eight waves busy in the workgroup kernel's second
-    // round: 10.2 -> 9.8 ms per call), opt-in at hidden 128 where it is slower (PDP_NEURAL_POST_WAVE; PDP_NEURAL_POST_PF forces the other form)
-    const bool post_wave = getenv("PDP_NEURAL_POST_WAVE") != nullptr || (w.out == 150 && getenv("PDP_NEURAL_POST_PF") == nullptr);
-    if (!post_res && !post_plain && shape_pf && post_wave && (int64_t)R * w.a * 4 < ((int64_t)1 << 31) && E >= WT) {
-        // a wave per 32-edge tile on the full tiles, the workgroup-tile kernel on the ragged tail
+    const bool shape_pf = !generic_forced() && w.Kp3 == 52 && w.Np3 == 128 && w.Kp4 == 100 && ((w.Np4 == 128 && w.out == 128) || (w.Np4 == 160 && w.out == 150));
+    const size_t ldsp = sizeof(float) * (size_t)TM * (53 + 129);
+    if (shape_pf && w.out == 150 && (int64_t)R * w.a * 4 < ((int64_t)1 << 31) && E >= WT) {
+        // hidden 150: a wave per 32-edge tile on the full tiles (the workgroup-tile kernel's ten output blocks take two rounds of its eight
+        // waves there: 10.2 against 9.8 ms per call at 12.6 M edges), the workgroup-tile kernel on the ragged tail
         const int full = E / WT, tail = E - full * WT;
-        const bool eight = getenv("PDP_NEURAL_POST_WAVE8") != nullptr;            // two waves per SIMD (the input block shares the hidden layer's region)
-        const int nwv = eight ? 8 : 4;
-        const size_t ldsw = sizeof(float) * nwv * (size_t)(WT * (eight ? 129 : 53 + 129) + WT);
-        const int wgs = (full + nwv - 1) / nwv;
+        const size_t ldsw = sizeof(float) * PW_NW * (size_t)(WT * (53 + 129) + WT);
+        const int wgs = (full + PW_NW - 1) / PW_NW;
         const int grid = wgs < persistent_grid() ? wgs : persistent_grid();
-        const size_t ldsp = sizeof(float) * (size_t)TM * (53 + 129);
         const size_t o = (size_t)full * WT;
-#define PDP_POST_WAVE_LAUNCH(NB4_, NW_) \
-        { s = set_lds((const void *)k_agg_post_wave<26, 4, 50, NB4_, NW_>, ldsw); if (s != PDP_OK) return s; \
-          hipLaunchKernelGGL((k_agg_post_wave<26, 4, 50, NB4_, NW_>), dim3(grid), dim3(64 * NW_), ldsw, st, E, agg, R, edge_row, h2, p->edge_sign, edge_mask, rowmask, old, w, out, full); }
-        if (w.Np4 == 128) {
-            if (eight) PDP_POST_WAVE_LAUNCH(4, 8) else PDP_POST_WAVE_LAUNCH(4, 4)
-            if (tail > 0) {
-                s = set_lds((const void *)k_agg_post_pf<26, 4, 50, 4>, ldsp); if (s != PDP_OK) return s;
-                hipLaunchKernelGGL((k_agg_post_pf<26, 4, 50, 4>), dim3(1), dim3(NTN), ldsp, st, tail, agg, edge_row + o, h2 + o * w.a, p->edge_sign + o,
-                                   edge_mask ? edge_mask + o : nullptr, rowmask + o, old + o * w.out, w, out + o * w.out);
-            }
-        } else {
-            if (eight) PDP_POST_WAVE_LAUNCH(5, 8) else PDP_POST_WAVE_LAUNCH(5, 4)
-            if (tail > 0) {
-                s = set_lds((const void *)k_agg_post_pf<26, 4, 50, 5>, ldsp); if (s != PDP_OK) return s;
-                hipLaunchKernelGGL((k_agg_post_pf<26, 4, 50, 5>), dim3(1), dim3(NTN), ldsp, st, tail, agg, edge_row + o, h2 + o * w.a, p->edge_sign + o,
-                                   edge_mask ? edge_mask + o : nullptr, rowmask + o, old + o * w.out, w, out + o * w.out);
-            }
+        s = set_lds((const void *)k_agg_post_wave<26, 4, 50, 5>, ldsw); if (s != PDP_OK) return s;
+        pdp_note_kernel(PDP_TK_AGG_POST, "k_agg_post_wave<26, 4, 50, 5>");
+        hipLaunchKernelGGL((k_agg_post_wave<26, 4, 50, 5>), dim3(grid), dim3(64 * PW_NW), ldsw, st, E, agg, R, edge_row, h2, p->edge_sign, edge_mask, rowmask, old, w, out, full);
+        if (tail > 0) {
+            s = set_lds((const void *)k_agg_post_pf<26, 4, 50, 5>, ldsp); if (s != PDP_OK) return s;
+            hipLaunchKernelGGL((k_agg_post_pf<26, 4, 50, 5>), dim3(1), dim3(NTN), ldsp, st, tail, agg, edge_row + o, h2 + o * w.a, p->edge_sign + o,
+                               edge_mask ? edge_mask + o : nullptr, rowmask + o, old + o * w.out, w, out + o * w.out);
         }
-#undef PDP_POST_WAVE_LAUNCH
-    } else if (!post_res && !post_plain && shape_pf) {
-        // hidden 128 (BASELINE configs) or 150 (the reference's shipped predict config) with the 100 / 50 inner widths
-        const size_t ldsp = sizeof(float) * (size_t)TM * (53 + 129);
+    } else if (shape_pf) {
+        // hidden 128 (BASELINE configs), and hidden 150 when the row offsets pass 31 bits: the 100 / 50 inner widths, prefetched chains
         if (w.Np4 == 128) {
             s = set_lds((const void *)k_agg_post_pf<26, 4, 50, 4>, ldsp); if (s != PDP_OK) return s;
+            pdp_note_kernel(PDP_TK_AGG_POST, "k_agg_post_pf<26, 4, 50, 4>");
             hipLaunchKernelGGL((k_agg_post_pf<26, 4, 50, 4>), dim3(tiles), dim3(NTN), ldsp, st, E, agg, edge_row, h2, p->edge_sign, edge_mask, rowmask, old, w, out);
         } else {
             s = set_lds((const void *)k_agg_post_pf<26, 4, 50, 5>, ldsp); if (s != PDP_OK) return s;
+            pdp_note_kernel(PDP_TK_AGG_POST, "k_agg_post_pf<26, 4, 50, 5>");
             hipLaunchKernelGGL((k_agg_post_pf<26, 4, 50, 5>), dim3(tiles), dim3(NTN), ldsp, st, E, agg, edge_row, h2, p->edge_sign, edge_mask, rowmask, old, w, out);
         }
-    } else if (post_res && res3 <= LDS_RES_LIMIT && w.Kp3 <= 64 * PRE_C) {
-        s = set_lds((const void *)k_agg_post_res, res3); if (s != PDP_OK) return s;
-        const int grid = tiles < persistent_grid() ? tiles : persistent_grid();
-        hipLaunchKernelGGL(k_agg_post_res, dim3(grid), dim3(NTN), res3, st, E, agg, edge_row, h2, p->edge_sign, edge_mask, rowmask, old, w, out, tiles);
     } else {
+        pdp_note_kernel(PDP_TK_AGG_POST, "k_agg_post");
         hipLaunchKernelGGL(k_agg_post, dim3(tiles), dim3(NTN), lds3, st, E, agg, edge_row, h2, p->edge_sign, edge_mask, rowmask, old, w, out);
     }
     PDP_LAUNCH_CHECK();
@@ -1441,8 +1425,11 @@ extern "C" int pdp_neural_gru(pdp_problem *p, const pdp_gru_desc *d, const float
     int s = set_lds((const void *)k_gru, lds); if (s != PDP_OK) return s;
     hipLaunchKernelGGL(k_edge_active, dim3(1024), dim3(256), 0, st, E, p->graph_map, p->var_inst, active_mask, rowmask);
     pdp_timed_scope timed(PDP_TK_GRU, st);
-    const bool plain = getenv("PDP_NEURAL_GRU_PLAIN") != nullptr;
-    if (!plain && d->H == 128 && (g.Kpx == 130 || g.Kpx == 4) && !(g.Kpx == 130 && getenv("PDP_NEURAL_GRU_WAVE"))) {
+    const bool plain = generic_forced();
+    auto ragged_tail = [&](size_t o, int tail) {
+        hipLaunchKernelGGL(k_gru, dim3(1), dim3(NTN), lds, st, tail, state + o * g.dx, p->edge_sign + o, h + o * g.H, rowmask + o, g, out + o * g.H, 1);
+    };
+    if (!plain && d->H == 128 && (g.Kpx == 130 || g.Kpx == 4)) {
         // hidden width 128 with a 129-wide input (np-nd-np, config 3) or a 4- / 3-wide one (p-nd-np: surveys + sign): pipelined kernel on
         // the full tiles, the plain one on the ragged tail
         const int full = E / TM, tail = E - full * TM;
@@ -1451,38 +1438,19 @@ extern "C" int pdp_neural_gru(pdp_problem *p, const pdp_gru_desc *d, const float
             const int grid = full < persistent_grid() ? full : persistent_grid();
             if (g.Kpx == 130) {
                 s = set_lds((const void *)k_gru_pipe<65, true>, ldsp); if (s != PDP_OK) return s;
+                pdp_note_kernel(PDP_TK_GRU, "k_gru_pipe<65, true>");
                 hipLaunchKernelGGL((k_gru_pipe<65, true>), dim3(grid), dim3(NTN), ldsp, st, E, state, p->edge_sign, h, rowmask, g, out, full);
             } else {
                 s = set_lds((const void *)k_gru_pipe<2, true>, ldsp); if (s != PDP_OK) return s;
+                pdp_note_kernel(PDP_TK_GRU, "k_gru_pipe<2, true>");
                 hipLaunchKernelGGL((k_gru_pipe<2, true>), dim3(grid), dim3(NTN), ldsp, st, E, state, p->edge_sign, h, rowmask, g, out, full);
             }
         }
-        if (tail > 0) {
-            const size_t o = (size_t)full * TM;
-            hipLaunchKernelGGL(k_gru, dim3(1), dim3(NTN), lds, st, tail, state + o * g.dx, p->edge_sign + o, h + o * g.H, rowmask + o, g,
-                               out + o * g.H, 1);
-        }
+        if (tail > 0) ragged_tail((size_t)full * TM, tail);
         PDP_LAUNCH_CHECK();
         return PDP_OK;
     }
-    if (!plain && getenv("PDP_NEURAL_GRU_WAVE") && d->H == 128 && g.Kpx == 130) {
-        const int full = E / WT, tail = E - full * WT;
-        if (full > 0) {
-            const size_t ldsw = sizeof(float) * 4 * (size_t)(WT * ((g.Kpx + 1) + (g.Kph + 1)) + WT);
-            const int wgs = (full + 3) / 4;
-            const int grid = wgs < persistent_grid() ? wgs : persistent_grid();
-            s = set_lds((const void *)k_gru_wave<65, 64, 4, true>, ldsw); if (s != PDP_OK) return s;
-            hipLaunchKernelGGL((k_gru_wave<65, 64, 4, true>), dim3(grid), dim3(256), ldsw, st, E, state, p->edge_sign, h, rowmask, g, out, full);
-        }
-        if (tail > 0) {
-            const size_t o = (size_t)full * WT;
-            hipLaunchKernelGGL(k_gru, dim3(1), dim3(NTN), lds, st, tail, state + o * g.dx, p->edge_sign + o, h + o * g.H, rowmask + o, g,
-                               out + o * g.H, 1);
-        }
-        PDP_LAUNCH_CHECK();
-        return PDP_OK;
-    }
-    if (!plain && !getenv("PDP_NEURAL_GRU_WINDOW") && d->H == 150 && g.Kpx == 152) {
+    if (!plain && d->H == 150 && g.Kpx == 152) {
         // hidden width 150 (five column blocks): a wave per 32-edge tile, four waves per workgroup, one workgroup per CU
         const int full = E / WT, tail = E - full * WT;
         if (full > 0) {
@@ -1490,23 +1458,10 @@ extern "C" int pdp_neural_gru(pdp_problem *p, const pdp_gru_desc *d, const float
             const int wgs = (full + 3) / 4;
             const int grid = wgs < persistent_grid() ? wgs : persistent_grid();
             s = set_lds((const void *)k_gru_wave<76, 75, 5, true>, ldsw); if (s != PDP_OK) return s;
+            pdp_note_kernel(PDP_TK_GRU, "k_gru_wave<76, 75, 5, true>");
             hipLaunchKernelGGL((k_gru_wave<76, 75, 5, true>), dim3(grid), dim3(256), ldsw, st, E, state, p->edge_sign, h, rowmask, g, out, full);
         }
-        if (tail > 0) {
-            const size_t o = (size_t)full * WT;
-            hipLaunchKernelGGL(k_gru, dim3(1), dim3(NTN), lds, st, tail, state + o * g.dx, p->edge_sign + o, h + o * g.H, rowmask + o, g,
-                               out + o * g.H, 1);
-        }
-        PDP_LAUNCH_CHECK();
-        return PDP_OK;
-    }
-    const size_t lds_w = sizeof(float) * (size_t)128 * ((g.Kpx + 1) + (g.Kph + 1));
-    if (!plain && ((g.Hp / 32) * 2) % NWAVES != 0 && lds_w <= LDS_RES_LIMIT) {
-        // column blocks that do not divide the waves (hidden 150): 128-edge window, 2.5 rounds instead of 2 x 2 per 128 edges
-        s = set_lds((const void *)k_gru_window<128>, lds_w); if (s != PDP_OK) return s;
-        const int tw = (E + 127) / 128;
-        const int gridw = tw < persistent_grid() ? tw : persistent_grid();
-        hipLaunchKernelGGL((k_gru_window<128>), dim3(gridw), dim3(NTN), lds_w, st, E, state, p->edge_sign, h, rowmask, g, out, tw);
+        if (tail > 0) ragged_tail((size_t)full * WT, tail);
         PDP_LAUNCH_CHECK();
         return PDP_OK;
     }
@@ -1514,6 +1469,7 @@ extern "C" int pdp_neural_gru(pdp_problem *p, const pdp_gru_desc *d, const float
     int per_cu = 1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_gru, NTN, lds) != hipSuccess || per_cu < 1) per_cu = 1;
     const int grid = tiles < per_cu * persistent_grid() ? tiles : per_cu * persistent_grid();
+    pdp_note_kernel(PDP_TK_GRU, "k_gru");
     hipLaunchKernelGGL(k_gru, dim3(grid), dim3(NTN), lds, st, E, state, p->edge_sign, h, rowmask, g, out, tiles);
     PDP_LAUNCH_CHECK();
     return PDP_OK;
@@ -1540,6 +1496,7 @@ extern "C" int pdp_neural_predict(pdp_problem *p, const pdp_agg_desc *d, const p
     { pdp_timed_scope timed(PDP_TK_ROW_SUM, st);
       hipLaunchKernelGGL(k_row_sum, dim3((unsigned)(((int64_t)V * w.a + 255) / 256)), dim3(256), 0, st, V, w.a, p->nv_ptr, p->nv_edges, h2, agg); }
     { pdp_timed_scope timed(PDP_TK_PREDICT_HEAD, st);
+      pdp_note_kernel(PDP_TK_PREDICT_HEAD, "k_predict_rows");
       hipLaunchKernelGGL(k_predict_rows, dim3((V + TM - 1) / TM), dim3(NTN), lds4, st, V, agg, w, h, pred); }
     PDP_LAUNCH_CHECK();
     return PDP_OK;

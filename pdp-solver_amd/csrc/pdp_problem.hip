@@ -38,6 +38,7 @@ extern "C" int pdp_device_count(void)
 
 // ---- kernel timing (measurement only) -------------------------------------------------------------------------------------
 int g_pdp_timing_on = 0;
+const char *g_pdp_kernel_name[PDP_KN_COUNT] = {nullptr};
 namespace {
 struct TimedSpan { int key; hipEvent_t e0, e1; bool closed; };
 std::mutex g_timing_mu;
@@ -70,6 +71,13 @@ extern "C" int pdp_kernel_timing(int enable)
     for (auto &s : g_spans) { g_event_pool.push_back(s.e0); g_event_pool.push_back(s.e1); }
     g_spans.clear();
     g_pdp_timing_on = enable ? 1 : 0;
+    return PDP_OK;
+}
+extern "C" int pdp_kernel_name(int key, char *buf, int len)
+{
+    PDP_REQUIRE(buf && len > 0 && key >= 0 && key < PDP_KN_COUNT, "bad argument");
+    const char *n = g_pdp_kernel_name[key];
+    snprintf(buf, (size_t)len, "%s", n ? n : "");
     return PDP_OK;
 }
 extern "C" int pdp_kernel_timing_read(float *ms_host, int32_t *launches_host)

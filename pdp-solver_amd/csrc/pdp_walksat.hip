@@ -794,6 +794,7 @@ static int local_search_persistent(pdp_problem *p, const float *pred, int iterat
         PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_walksat<uint16_t, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         wp.inst_list = nbig ? p->ws_fit_list : nullptr;
         pdp_timed_scope timed(PDP_TK_WALKSAT, st);
+        pdp_note_kernel(PDP_TK_WALKSAT, "k_walksat<unsigned short, 256>");
         hipLaunchKernelGGL((k_walksat<uint16_t, 256>), dim3(nfit), dim3(ws_nt), lds, st, make_view(p), wp);
     }
     if (nbig) PDP_HIP_CHECK(hipStreamWaitEvent(st, p->ws_side_ev[1], 0));

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     'pdp_sequential_decimate_apply', 'pdp_reinforce_decimate', 'pdp_reinforce_predict', 'pdp_energy',
     'pdp_energy_diff', 'pdp_random_fill', 'pdp_local_search', 'pdp_deduplicate', 'pdp_sp_solve', 'pdp_math_apply',
     'pdp_neural_aggregate_edges', 'pdp_neural_gru', 'pdp_neural_predict', 'pdp_dimacs_open', 'pdp_dimacs_read', 'pdp_dimacs_close', 'pdp_dimacs_open_many',
-    'pdp_kernel_timing', 'pdp_kernel_timing_read',
+    'pdp_kernel_timing', 'pdp_kernel_timing_read', 'pdp_kernel_name',
     'pdp_train_linear', 'pdp_train_linear_backward', 'pdp_train_row_sum', 'pdp_train_row_spread', 'pdp_train_gru', 'pdp_train_gru_backward',
     'pdp_sat_loss_grad', 'pdp_train_sp_adapted_backward',
 ]
@@ -484,6 +484,16 @@ def kernel_timing_read():
     ms = (C.c_float * len(TIMING_KEYS))(); n = (C.c_int32 * len(TIMING_KEYS))()
     check(lib().pdp_kernel_timing_read(ms, n))
     return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(TIMING_KEYS)}
+
+
+NAME_KEYS = TIMING_KEYS + ('sp_solve', 'sp_replay')                                         # include/pdp_hip.h: PDP_KN_*
+
+
+def kernel_name(key):
+    "name, with template arguments, of the kernel the library launched last for this key ('' before the first launch)"
+    buf = C.create_string_buffer(160)
+    check(lib().pdp_kernel_name(C.c_int(NAME_KEYS.index(key)), buf, C.c_int(160)))
+    return buf.value.decode('ascii')
 
 
 def math_apply(fn, x):

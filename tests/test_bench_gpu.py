@@ -23,7 +23,8 @@ def _bench(env_extra, *argv):
 
 
 def test_bench_line_small_workload():
-    line = _bench({}, '--steps', '2', '--warmup', '1', '--batch', '600', '--iters', '40', '--cpu-cores', '8', '--secondary-walksat-steps', '200')
+    line = _bench({}, '--steps', '2', '--warmup', '1', '--batch', '600', '--iters', '40', '--cpu-cores', '8', '--secondary-walksat-steps', '200',
+                  '--config3-batch', '200', '--config4-instances', '30')
     for k in ('metric', 'value', 'unit', 'n_gpus', 'rccl_ranks', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
               'data', 'config', 'roofline', 'cpu_baseline', 'cpu_baseline_torch_sparse'):
         assert k in line, k
@@ -43,7 +44,18 @@ def test_bench_line_small_workload():
     for key in ('agg_pre', 'agg_post', 'gru', 'predict_head', 'aggregator_call'):
         assert nk[key].get('ms_per_launch', nk[key].get('ms')) > 0 and 0 < nk[key]['frac_of_mfma_f32_peak'] < 1.0
     assert nk['gru']['launches'] == 2 * sec['neural']['iterations'] and nk['agg_post']['launches'] == 2 * sec['neural']['iterations']
-    assert sec['walksat']['steps'] > 0 and sec['walksat']['kernel_launches'] >= 1
+    assert nk['gru']['kernel'].startswith('k_gru_pipe<65') and nk['agg_pre']['kernel'].startswith('k_agg_pre_wave<65') and nk['agg_post']['kernel'].startswith('k_agg_post_pf<')
+    assert sec['walksat']['steps'] > 0 and sec['walksat']['kernel_launches'] >= 1 and sec['walksat']['kernel'].startswith('k_walksat<') and 'roofline' not in sec['walksat']
+    assert sec['walksat']['flips_per_sec'] > 0
+    assert rf['kernel'].startswith('k_sp_solve_lds<false, false, false') and sec['reinforce']['kernel'].startswith('k_sp_solve_lds<true, false, true')
+    # every BASELINE config has a driver-visible entry: configs[3] / configs[4] at the per-GPU shape (small sizes here)
+    c3, c4 = sec['config3_shard'], sec['config4_shard']
+    for c in (c3, c4):
+        assert 'error' not in c, c
+        assert c['seconds'] > 0 and 0 < c['roofline']['frac'] < 1.0 and c['walksat']['steps'] > 0 and c['kernels']['gru']['ms_per_launch'] > 0
+        assert abs(c['roofline']['achieved'] - c['flop_total'] / c['seconds'] / 1e12) < 1e-9 * c['roofline']['achieved']
+    assert c3['model_type'] == 'np-nd-np' and c3['instances'] == 200 and c3['segments'] == [200]
+    assert c4['model_type'] == 'p-nd-np' and c4['batch_replication'] == 4 and sum(c4['segments']) == 30 and c4['kernels']['gru']['kernel'].startswith('k_gru_pipe<2')
     assert sec['reinforce']['path'] == 'persistent-lds' and sec['reinforce']['kernel_ms_per_launch'] > 0
     for name, row in line['config']['solved'].items():
         assert 'error' not in row, row

@@ -197,8 +197,7 @@ def test_neural_operator_forms_agree_at_full_size(big, oracle, monkeypatch):
     am = (torch.rand(p.B, device=dev) > 0.2).to(torch.uint8)
     new_gru = p.neural_gru(gw, state, h, am)
     new_agg = [p.neural_aggregate_edges(aw, bv, state, None, am, h) for bv in (True, False)]
-    for k in ('PDP_NEURAL_GRU_PLAIN', 'PDP_NEURAL_AGG_TILE', 'PDP_NEURAL_POST_PLAIN'):
-        monkeypatch.setenv(k, '1')
+    monkeypatch.setenv('PDP_NEURAL_GENERIC', '1')            # every operator on its generic tile kernel
     old_gru = p.neural_gru(gw, state, h, am)
     assert torch.equal(new_gru, old_gru)
     del old_gru

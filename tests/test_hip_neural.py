@@ -22,20 +22,12 @@ def dev_agg(w, fd):
 
 @pytest.mark.parametrize('H,m1,a,g,grid', [(32, 100, 50, 100, None), (128, 100, 50, 100, None), (20, 36, 17, 40, None),
                                            (128, 100, 50, 100, 3), (32, 100, 50, 100, 2), (150, 100, 50, 100, None), (150, 100, 50, 100, 2),
-                                           (128, 100, 50, 100, -2), (150, 100, 50, 100, -1), (128, 100, 50, 100, -102), (150, 100, 50, 100, -101)])
+                                           (128, 100, 50, 100, -2), (150, 100, 50, 100, -1)])
 def test_aggregator_gru_predict_bit_exact(oracle, monkeypatch, H, m1, a, g, grid):
     from pdp import native
-    if grid and grid <= -100:   # the wave-per-tile post-transform with two waves per SIMD
-        monkeypatch.setenv('PDP_NEURAL_POST_WAVE', '1'); monkeypatch.setenv('PDP_NEURAL_POST_WAVE8', '1')
-        grid = -(grid + 100)
-    elif grid and grid < 0:   # the forms that are not the default of their width: at hidden 128 the wave-per-tile post-transform and GRU cell
-        # (PDP_NEURAL_POST_WAVE, PDP_NEURAL_GRU_WAVE), at hidden 150 the workgroup-tile post-transform and the window GRU kernel
-        if H == 150:
-            monkeypatch.setenv('PDP_NEURAL_POST_PF', '1'); monkeypatch.setenv('PDP_NEURAL_GRU_WINDOW', '1')
-        else:
-            monkeypatch.setenv('PDP_NEURAL_POST_WAVE', '1'); monkeypatch.setenv('PDP_NEURAL_GRU_WAVE', '1')
+    if grid and grid < 0:   # the generic tile kernels on the shapes that have specialised ones (PDP_NEURAL_GENERIC: the cross-check switch)
+        monkeypatch.setenv('PDP_NEURAL_GENERIC', '1')
         grid = -grid
-    grid = abs(grid) if grid else grid
     if grid:          # persistent kernels: many tiles per workgroup (cross-tile prefetch and the pipelined GRU's carried epilogue)
         monkeypatch.setenv('PDP_NEURAL_GRID', str(grid))
     b = random_batch(batch=9, n=25, mixed=True, seed=77)

@@ -1,5 +1,5 @@
 """Times the GRU cell entry point alone on the config-2 graph (5 000 x n=200 m=840) for a hidden width (default 150, the reference's shipped
-np-nd-np predict config) and checks the specialised kernel against the generic tile kernel (PDP_NEURAL_GRU_PLAIN) bit for bit at full size.
+np-nd-np predict config) and checks the specialised kernel against the generic tile kernel (PDP_NEURAL_GENERIC) bit for bit at full size.
 Usage: python tools/gru_time.py [hidden [reps]]; PDP_HIP_LIB selects another build of the library for same-box A/B runs."""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'pdp-solver_amd'))
@@ -28,6 +28,6 @@ ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps))[reps // 2]
 flop = 2.0 * E * 3 * H * (2 * H + 1)
 print('%s: gru hidden %d, E = %d: %.2f ms per call = %.1f TFLOP/s' % (os.path.basename(os.environ.get('PDP_HIP_LIB', 'product')), H, E, ms, flop / ms * 1e-9), flush=True)
 if len(sys.argv) > 3:
-    os.environ['PDP_NEURAL_GRU_PLAIN'] = '1'
+    os.environ['PDP_NEURAL_GENERIC'] = '1'
     ref = p.neural_gru(gw, state, h, am); torch.cuda.synchronize()
     print('equal to the generic tile kernel at full size:', bool(torch.equal(out, ref)), ' NaN:', int(torch.isnan(out).sum()))

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Condenses tools/profile_secondary.sh's rocprofv3 directories: per workload the kernel stats (top kernels) and, per kernel, the PMC
+counters per dispatch plus the derived ratios DESIGN.md quotes (MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES; wait share)."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+for work in sorted(os.listdir(root)):
+    wd = os.path.join(root, work)
+    if not os.path.isdir(wd):
+        continue
+    print("==== %s ====" % work)
+    for f in sorted(glob.glob(os.path.join(wd, 'trace', '**', '*kernel_stats.csv'), recursive=True)):
+        with open(f) as fh:
+            rows = list(csv.DictReader(fh))
+        for r in rows[:10]:
+            print("  %-64s calls=%-5s avg_us=%-10.1f pct=%s" % (r.get('Name', '')[:64], r.get('Calls'), float(r.get('AverageNs', 0)) / 1e3, r.get('Percentage')))
+    per = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(lambda: defaultdict(set))
+    for f in sorted(glob.glob(os.path.join(wd, 'pmc*', '**', '*counter_collection.csv'), recursive=True)):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                k = r.get('Kernel_Name', '')[:64]
+                c = r.get('Counter_Name')
+                per[k][c] += float(r.get('Counter_Value', 0) or 0); cnt[k][c].add(r.get('Dispatch_Id'))
+    for k in sorted(per, key=lambda x: -per[x].get('SQ_BUSY_CU_CYCLES', per[x].get('SQ_WAVE_CYCLES', 0.0)))[:6]:
+        v = {c: per[k][c] / max(1, len(cnt[k][c])) for c in per[k]}
+        print("  [pmc] %s" % k)
+        print("        " + "  ".join("%s=%.4g" % (c, v[c]) for c in sorted(v)))
+        if v.get('SQ_BUSY_CU_CYCLES') and 'SQ_VALU_MFMA_BUSY_CYCLES' in v:
+            print("        MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES = %.3f" % (v['SQ_VALU_MFMA_BUSY_CYCLES'] / v['SQ_BUSY_CU_CYCLES']))
+        if v.get('SQ_WAVE_CYCLES') and 'SQ_WAIT_ANY' in v:
+            print("        SQ_WAIT_ANY / SQ_WAVE_CYCLES = %.3f" % (v['SQ_WAIT_ANY'] / v['SQ_WAVE_CYCLES']))
+        if v.get('SQ_BUSY_CYCLES') and 'SQ_ACTIVE_INST_VALU' in v:
+            print("        SQ_ACTIVE_INST_VALU x 4 / (SQ_BUSY_CYCLES x SIMDs per SE?) -- raw: ACTIVE_INST_VALU=%.4g BUSY_CYCLES=%.4g" % (v['SQ_ACTIVE_INST_VALU'], v['SQ_BUSY_CYCLES']))
