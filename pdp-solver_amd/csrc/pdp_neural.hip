@@ -1307,9 +1307,7 @@ static bool generic_forced() { return getenv("PDP_NEURAL_GENERIC") != nullptr; }
 static int persistent_grid()
 {
     if (const char *e = getenv("PDP_NEURAL_GRID")) { const int v = atoi(e); if (v > 0) return v; }   // tests: many tiles per workgroup on small inputs
-    static int cus = 0;
-    if (!cus) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount; if (cus <= 0) cus = 256; }
-    return cus;
+    return pdp_device_cus();
 }
 
 // aggregator pre-transform: wave-private form (default); resident-weight persistent form when both matrices and the tile fit the LDS, tile-per-workgroup form otherwise

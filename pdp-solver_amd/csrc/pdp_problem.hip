@@ -529,7 +529,11 @@ int pdp_edge_rows(const pdp_problem *p)
 
 int pdp_device_cus()
 {
-    static int cus = 0;
-    if (!cus) { int dev = 0, v = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; else cus = 64; }
-    return cus;
+    // per device id (one process may drive several devices; a count cached for the first one would size co-resident launches -- teams,
+    // the lock-step kernel -- for the wrong chip and their spin barriers would never complete)
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 64;
+    if (!cus[dev]) { int v = 0; cus[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 64; }
+    return cus[dev];
 }

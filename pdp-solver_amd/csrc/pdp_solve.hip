@@ -2323,6 +2323,8 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
         }
     }
     hipStream_t side = p->res_side_stream;
+    // an error return between here and the final synchronisation must not leave work on the side stream that still reads the caller's arrays
+    struct SideJoin { hipStream_t s; bool on; ~SideJoin() { if (on && s) (void)hipStreamSynchronize(s); } } side_join{side, nbig > 0};
     auto launch_big = [&](const SolveParams &spx, hipStream_t s_) { return launch_hbm(p, spx, nbig, s_); };
     // ticketed LDS-resident pass (see k_sp_solve_lds): on for mixed batches; PDP_SOLVE_TICKETS=<percent of over-provisioning>, 0 = off
     int ticket_extra = nbig > 0 ? 25 : 0;
@@ -2399,6 +2401,7 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     }
     PDP_HIP_CHECK(hipMemcpyAsync(p->solve_host, ctl, host_words * 4, hipMemcpyDeviceToHost, st));
     PDP_HIP_CHECK(hipStreamSynchronize(st));
+    side_join.on = false;                                  // (every side-stream launch was joined into the main stream, which is drained)
     const SolveCtl *hctl = (const SolveCtl *)p->solve_host;
     const SolveCall *hcall = (const SolveCall *)(hctl + nchunks);
     const bool debug = getenv("PDP_DEBUG") != nullptr;
@@ -2443,8 +2446,11 @@ static bool lockstep_possible(const pdp_problem *p, const pdp_solve_args *a)
     if (a->isolate_instances || getenv("PDP_SOLVE_NO_LOCKSTEP")) return false;
     if (a->model == PDP_MODEL_REINFORCE && p->R > 1) return false;      // (Reinforce with batch replication: step-wise)
     // every workgroup must be resident at once (they wait for each other): what the device holds of this kernel, and the mailbox capacity
-    static int per_cu = 0;
-    if (!per_cu) { int v = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, (const void *)k_sp_solve<256, false, true>, 256, 0) == hipSuccess && v > 0) per_cu = v; else per_cu = 1; }
+    static int per_cu_dev[64] = {0};                              // per device id, like pdp_device_cus
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (!per_cu_dev[dev]) { int v = 0; per_cu_dev[dev] = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, (const void *)k_sp_solve<256, false, true>, 256, 0) == hipSuccess && v > 0) ? v : 1; }
+    const int per_cu = per_cu_dev[dev];
     const long resident = (long)pdp_device_cus() * (per_cu < 4 ? per_cu : 4);
     return p->B <= resident && p->B <= PDP_LOCK_MAX && p->max_e <= 65536;     // (an instance is one workgroup's work)
 }

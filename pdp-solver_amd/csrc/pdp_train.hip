@@ -147,17 +147,33 @@ static int gemm(int M, int N, int64_t K, const float *A, int64_t lda, const floa
 
 static int pick_splits(int64_t R) { int64_t s = (R + 4095) / 4096; if (s > 128) s = 128; return (int)(s < 1 ? 1 : s); }
 
-// scratch for split-K partials and column sums: grown on demand, kept (per process; training drives one stream)
-static float *g_train_scratch = nullptr; static size_t g_train_scratch_floats = 0;
-static float *train_scratch(size_t floats)
+// scratch for split-K partials and column sums: one block per (device, stream), grown on demand.  Kernels enqueued earlier on that stream may
+// still read the old block when it has to grow, so the stream is drained before the block goes back to the pool; work on another stream or
+// device never sees this block.
+#include <map>
+#include <mutex>
+#include <utility>
+namespace {
+struct TrainScratch { float *ptr; size_t floats; };
+std::mutex g_train_mu;
+std::map<std::pair<int, hipStream_t>, TrainScratch> g_train_scratch;
+}
+static float *train_scratch(size_t floats, hipStream_t st)
 {
-    if (g_train_scratch_floats < floats) {
-        if (g_train_scratch) pdp_dev_free(g_train_scratch);
-        g_train_scratch = nullptr; g_train_scratch_floats = 0;
-        if (pdp_dev_alloc((void **)&g_train_scratch, floats * sizeof(float)) != PDP_OK) return nullptr;
-        g_train_scratch_floats = floats;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_train_mu);
+    TrainScratch &sc = g_train_scratch[std::make_pair(dev, st)];
+    if (sc.floats < floats) {
+        if (sc.ptr) {
+            if (hipStreamSynchronize(st) != hipSuccess) return nullptr;
+            pdp_dev_free(sc.ptr);
+        }
+        sc.ptr = nullptr; sc.floats = 0;
+        if (pdp_dev_alloc((void **)&sc.ptr, floats * sizeof(float)) != PDP_OK) return nullptr;
+        sc.floats = floats;
     }
-    return g_train_scratch;
+    return sc.ptr;
 }
 
 // replaces: nn.Linear + activation as used by MessageAggregator / Perceptron (util.py:56,74; trainer.py:28-29): Y = act(X W^T + b)
@@ -184,7 +200,7 @@ extern "C" int pdp_train_linear_backward(const float *dY, const float *Y, const 
     int s;
     if (dX) { s = gemm<false, false>((int)R, K, N, dZ, N, W, K, dX, lddx, nullptr, TACT_NONE, 1, nullptr, st); if (s != PDP_OK) return s; }
     const int splits = pick_splits(R);
-    float *scr = train_scratch((size_t)splits * ((size_t)N * K + N) + 16);
+    float *scr = train_scratch((size_t)splits * ((size_t)N * K + N) + 16, st);
     if (!scr) return PDP_ERR_HIP;
     s = gemm<true, false>(N, K, R, dZ, N, X, ldx, dW, K, nullptr, TACT_NONE, splits, scr, st);
     if (s != PDP_OK) return s;
@@ -314,7 +330,7 @@ extern "C" int pdp_train_gru_backward(const float *dhnew, const float *saved, co
     hipLaunchKernelGGL(k_add_inplace, dim3(grid1d(R * H)), dim3(256), 0, st, R * H, dh, (const float *)dh2);
     const int splits = pick_splits(R);
     const size_t wmax = (size_t)3 * H * (Kx > H ? Kx : H);
-    float *scr = train_scratch((size_t)splits * (wmax + 3 * H) + 16);
+    float *scr = train_scratch((size_t)splits * (wmax + 3 * H) + 16, st);
     if (!scr) return PDP_ERR_HIP;
     float *part = scr + (size_t)splits * wmax;
     s = gemm<true, false>(3 * H, Kx, R, dgi, 3 * H, x, Kx, dW_ih, Kx, nullptr, TACT_NONE, splits, scr, st); if (s != PDP_OK) return s;

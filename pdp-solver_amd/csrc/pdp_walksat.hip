@@ -742,6 +742,21 @@ static int ws_prepare(pdp_problem *p)
     return PDP_OK;
 }
 
+// Everything a persistent search holds until it returns -- device scratch, the host copy of the bit maps, work on the side stream that
+// still reads the caller's arrays -- is released by this guard on EVERY path out, error returns included: the side stream is joined first.
+namespace {
+struct WsCallGuard {
+    hipStream_t side = nullptr; bool side_busy = false;
+    void *dev[2] = {nullptr, nullptr}; void *host = nullptr;
+    ~WsCallGuard()
+    {
+        if (side_busy && side) (void)hipStreamSynchronize(side);
+        for (void *d : dev) if (d) pdp_dev_free(d);
+        if (host) free(host);
+    }
+};
+}
+
 // returns PDP_OK and *done = 1 if the persistent search produced the reference result, *done = 0 if the caller must run the strict loop
 static int local_search_persistent(pdp_problem *p, const float *pred, int iterations, float epsilon, int rng_mode, const float *var_rand,
                                    const float *coin_rand, uint64_t seed, float *out, int32_t *steps_host, hipStream_t st, int *done)
@@ -754,8 +769,10 @@ static int local_search_persistent(pdp_problem *p, const float *pred, int iterat
     const size_t lds = ws_lds_bytes(p->ws_fit_n, p->ws_fit_m, p->ws_fit_e);
     const size_t bw = ((size_t)iterations + 31) / 32;               // words per bit map
     const size_t words = 2 * bw + 4;
+    WsCallGuard guard;
     uint32_t *spec = nullptr;
     { int st_ = pdp_dev_alloc((void **)&spec, words * 4 + (size_t)p->B * 4 * 3); if (st_ != PDP_OK) return st_; }
+    guard.dev[0] = spec;
     int32_t *first_sat = (int32_t *)(spec + words), *cap_b = first_sat + p->B, *list = cap_b + p->B;
     PDP_HIP_CHECK(hipMemsetAsync(spec, 0, words * 4, st));
     hipLaunchKernelGGL(k_edge_mask2, dim3(p->B, pdp_edge_rows(p)), dim3(PDP_NT), 0, st, make_view(p));       // solver.py:439-440
@@ -772,7 +789,8 @@ static int local_search_persistent(pdp_problem *p, const float *pred, int iterat
         // the instances past the LDS limit: one 1024-thread workgroup each on the HBM-resident form, on a stream of its own next to the
         // LDS-resident launch (they share nothing but the speculation bit maps)
         const size_t bytes = (size_t)p->ws_big_E * 12 + (size_t)p->ws_big_V * 12 + (size_t)p->ws_big_F * 9 + 64 + (size_t)nbig * 4 + 16;
-        { int st_ = pdp_dev_alloc((void **)&big_ws, bytes); if (st_ != PDP_OK) { pdp_dev_free(spec); return st_; } }
+        { int st_ = pdp_dev_alloc((void **)&big_ws, bytes); if (st_ != PDP_OK) return st_; }
+        guard.dev[1] = big_ws;
         WsParams wb = wp;
         wb.inst_list = p->ws_big_list; wb.big_off = p->ws_big_off;
         wb.ws_E = p->ws_big_E; wb.ws_V = p->ws_big_V; wb.ws_F = p->ws_big_F;
@@ -785,7 +803,8 @@ static int local_search_persistent(pdp_problem *p, const float *pred, int iterat
         PDP_HIP_CHECK(hipEventRecord(p->ws_side_ev[0], st)); PDP_HIP_CHECK(hipStreamWaitEvent(p->ws_side_stream, p->ws_side_ev[0], 0));
         // few big instances: a team of workgroups each (chip-wide when no LDS-resident launch runs next to it)
         TeamLaunch tl; tl.size = 1;
-        if (!getenv("PDP_WALKSAT_NO_TEAM")) { const int st_ = pdp_team_plan(p, nbig, nfit == 0, 256, &tl, p->ws_side_stream); if (st_ != PDP_OK) { pdp_dev_free(spec); pdp_dev_free(big_ws); return st_; } }
+        guard.side = p->ws_side_stream; guard.side_busy = true;
+        if (!getenv("PDP_WALKSAT_NO_TEAM")) { const int st_ = pdp_team_plan(p, nbig, nfit == 0, 256, &tl, p->ws_side_stream); if (st_ != PDP_OK) return st_; }
         if (tl.size > 1) hipLaunchKernelGGL((k_walksat_team<256>), dim3(tl.size * tl.slots), dim3(256), 0, p->ws_side_stream, make_view(p), wb, tl);
         else hipLaunchKernelGGL((k_walksat<uint32_t, 1024>), dim3(nbig), dim3(1024), 0, p->ws_side_stream, make_view(p), wb);
         PDP_HIP_CHECK(hipEventRecord(p->ws_side_ev[1], p->ws_side_stream));
@@ -802,9 +821,11 @@ static int local_search_persistent(pdp_problem *p, const float *pred, int iterat
     uint32_t *ctl = spec + 2 * bw;                       // [0] global stop step, [1] replay count
     hipLaunchKernelGGL(k_ws_group_stop, dim3((p->B0 + 255) / 256), dim3(256), 0, st, p->B0, p->R, iterations, first_sat, ctl);
     uint32_t *host = (uint32_t *)malloc(words * 4);
+    PDP_REQUIRE(host, "out of host memory");
+    guard.host = host;
     PDP_HIP_CHECK(hipMemcpyAsync(host, spec, words * 4, hipMemcpyDeviceToHost, st));
-    PDP_HIP_CHECK(hipStreamSynchronize(st));
-    if (big_ws) pdp_dev_free(big_ws);
+    PDP_HIP_CHECK(hipStreamSynchronize(st));             // (the main stream waited for the side stream's event: both are drained here)
+    guard.side_busy = false;
     const int stop = (int)host[2 * bw];
     int status = PDP_OK;
     if (p->R > 1 && stop < iterations) {
@@ -831,8 +852,6 @@ static int local_search_persistent(pdp_problem *p, const float *pred, int iterat
     }
     for (int t = 0; t < stop && t < first_finish && ok; ++t)
         if (((host[t >> 5] >> (t & 31)) & 1u) && !((host[bw + (t >> 5)] >> (t & 31)) & 1u)) ok = false;
-    free(host);
-    pdp_dev_free(spec);
     if (status != PDP_OK) return status;
     if (!ok) return PDP_OK;          // caller runs the strict loop on the untouched inputs
     if (steps_host) *steps_host = stop;

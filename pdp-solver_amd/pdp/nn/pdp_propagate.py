@@ -74,11 +74,11 @@ class NeuralMessagePasser(nn.Module):
         fs = self._variable_aggregator.forward_train(torch.cat((dec_v, sign), 1), sign, sat_problem, True, edge_mask)
         if active_mask is not None:
             fs = mask * fs + (1 - mask) * function_state
-        fs = T.dropout(fs, self._drop_out, getattr(self, '_rng', 'torch'))
+        fs = T.dropout(fs, self._drop_out, getattr(self, '_rng', 'device'))
         vs = self._function_aggregator.forward_train(torch.cat((dec_f, sign), 1), sign, sat_problem, False, edge_mask)
         if active_mask is not None:
             vs = mask * vs + (1 - mask) * variable_state
-        vs = T.dropout(vs, self._drop_out, getattr(self, '_rng', 'torch'))
+        vs = T.dropout(vs, self._drop_out, getattr(self, '_rng', 'device'))
         return vs, fs
 
     def get_init_state(self, graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, randomized, batch_replication):

@@ -172,8 +172,9 @@ class SatLoss(torch.autograd.Function):
 
 
 def dropout(x, p, rng):
-    """F.dropout(x, p, training=True) (pdp_propagate.py:80,91).  rng 'torch': the mask comes from the global CPU generator exactly as the
-    reference's --cpu_mode run draws it (the draw depends on the shape and p only); otherwise torch's device generator."""
+    """F.dropout(x, p, training=True) (pdp_propagate.py:80,91).  Default: torch's device generator.  rng 'torch' (config key dropout_rng, the
+    golden tests): the mask comes from the global CPU generator exactly as the reference's --cpu_mode run draws it (the draw depends on
+    the shape and p only) -- a host-side [E, H] mask per call, so not for real training runs."""
     if p <= 0:
         return x
     if rng == 'torch':

@@ -57,7 +57,9 @@ class SatFactorGraphTrainer(FactorGraphTrainerBase):
         elif t in ('np-nd-np', 'np-d-np', 'p-nd-np'):
             model = solver.build_neural_solver(self._device, config, Perceptron, common)
             if hasattr(model._propagator, '_drop_out'):
-                model._propagator._rng = rng                   # where the training path's dropout masks come from
+                # where the training path's dropout masks come from: the device generator (default), or -- dropout_rng: 'torch' -- the global
+                # CPU stream drawn exactly as the reference's --cpu_mode run draws it (the golden tests; it builds every mask on the host)
+                model._propagator._rng = config.get('dropout_rng', 'device')
         else:
             raise KeyError("unknown model_type %r" % (t,))
         if config.get('verbose'):
