@@ -412,6 +412,49 @@ def neural_shard(args, dev, native, items, model_type, hidden, T, replication=1,
     return out
 
 
+def train_measurement(args, dev, native):
+    """one optimizer step (`_train_batch`, base.py:149-182) per model type that trains, on a ~1 M-edge batch at hidden 128 --
+    3 outer recurrences, dropout 0.2 from the device generator, clipped Adam step.  flop = 3 x the forward's algorithmic flop (the adjoint
+    of every dense layer is two products of the forward's size) x recurrences; the fraction is against the fp32 MFMA peak."""
+    import logging
+    import torch
+    import torch.optim as optim
+    from pdp.factorgraph import dataset
+    from pdp.trainer import SatFactorGraphTrainer
+    bt = args.train_batch
+    items = dataset.random_ksat_items(bt, args.n, 3, m=int(round(4.2 * args.n)), seed=555)
+    b = dataset.to_torch(dataset.collate_segment(items), dev)
+    gm, bvm, bfm, ef = b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature']
+    label = torch.ones(bt, 1, device=dev)
+    E, V = int(gm.size(1)), int(bvm.numel())
+    out = {}
+    for mt in ('np-nd-np', 'p-nd-np'):
+        cfg = dict(model_type=mt, model_name='bench-train-' + mt, verbose=False, dropout=0.2, error_dim=3, exploration=0.1, hidden_dim=128,
+                   local_search_iteration=0, epsilon=0.5, tolerance=0.02, t_max=100, edge_feature_dim=1, meta_feature_dim=0, prediction_dim=1,
+                   mem_hidden_dim=100, agg_hidden_dim=100, mem_agg_hidden_dim=50, classifier_dim=50, loss_sharpness=5, randomized=True,
+                   train_inner_recurrence_num=1, train_outer_recurrence_num=3, clip_norm=0.65, batch_size=bt, rng='philox', random_seed=0)
+        cfg['lambda'] = 0.9
+        torch.manual_seed(99)
+        tr = SatFactorGraphTrainer(cfg, use_cuda=True, logger=logging.getLogger('bench'))
+        opt = optim.Adam(tr.get_parameter_list(), lr=1e-4, weight_decay=1e-10)
+        total = np.zeros(1, dtype=np.float32)
+        times = []
+        for rep in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            tr._train_batch(total, opt, gm, bvm, bfm, ef, None, label)
+            torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
+        dt = min(times[1:])
+        flop = 3.0 * 3 * neural_flop_per_iteration(mt, 128, E, V)
+        tf = flop / dt / 1e12
+        out[mt] = dict(seconds_per_train_batch=dt, first_call_seconds=times[0], flop=flop, tflops=tf, frac_of_mfma_f32_peak=tf / MFMA_F32_PEAK_TFLOPS,
+                       loss_finite=bool(np.isfinite(total).all()))
+        del tr, opt
+        torch.cuda.empty_cache()
+    out['workload'] = ('_train_batch: %d instances of n=%d (%d edges), hidden 128, 3 outer recurrences, dropout 0.2, clipped Adam step; '
+                       'flop = 3 x forward flop x recurrences' % (bt, args.n, E))
+    return out
+
+
 def config4_items(count, seed0=1000):
     "BASELINE configs[4]'s family (SURVEY 8(d)): k in {3,4,5} per instance, alpha_k = 0.9 x (4.27, 9.93, 21.12), n ~ U{100..500}"
     from pdp.factorgraph import dataset
@@ -607,6 +650,10 @@ def config_shard_measurements(args, dev, native):
     except Exception as ex:
         out['config3_shard'] = dict(error=repr(ex))
     try:
+        out['train'] = train_measurement(args, dev, native)
+    except Exception as ex:
+        out['train'] = dict(error=repr(ex))
+    try:
         items = config4_items(args.config4_instances)
         out['config4_shard'] = neural_shard(args, dev, native, items, 'p-nd-np', 128, T, replication=4, limit=int(4e9), walksat_steps=30,
                                             workload="configs[4] per GPU: 'p-nd-np' hidden_dim=128, mixed random k-SAT k in {3,4,5}, n in [100,500], %d instances, "
@@ -717,6 +764,7 @@ def main():
     ap.add_argument('--secondary-neural-iters', type=int, default=3)
     ap.add_argument('--secondary-walksat-steps', type=int, default=1000)
     ap.add_argument('--config3-batch', type=int, default=5000, help='instances of the configs[3] shard measurement (n = 400)')
+    ap.add_argument('--train-batch', type=int, default=400, help='instances of the training-step measurement (n = --n)')
     ap.add_argument('--config4-instances', type=int, default=600, help='instances (before the 4 replicas) of the configs[4] shard measurement')
     ap.add_argument('--selftest-collective', action='store_true', help='the N-rank plumbing only (no GPU work); used by the gloo test')
     args = ap.parse_args()

@@ -1350,12 +1350,7 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
     const bool other_rows = n < pv_.V;
     const float pi = sp.pi, tol = sp.tol, t_max = sp.t_max;
     const int T = sp.T;
-    int poison_from = REPLAY ? ctl->poison_from : (sp.call->poisoned_all ? 0 : 0x7fffffff);
-    // Pass 1 also LOOKS at the chunk's poison word while it runs: an instance whose workgroup starts after some other instance has raised
-    // a NaN at iteration t* (the launch walks the batch in a few rounds of resident workgroups) switches to the poisoned rules at t* by
-    // itself and needs no replay -- under the replay rule (an event at or after t*) it has none, whatever value below its current iteration
-    // it reads: iterations it ran un-poisoned are covered by its event record, iterations from the value on have no events.
-    const bool live_poison = !REPLAY && !sp.isolate;
+    const int poison_from = REPLAY ? ctl->poison_from : (sp.call->poisoned_all ? 0 : 0x7fffffff);
     // log(max(1 - pi * [force == +-s], eps)): two possible values per kernel (pdp_propagate.py:197,201)
     const float L0 = pdp_safe_log(1.0f - pi * 0.0f, PDP_SP_EPS), L1 = pdp_safe_log(1.0f - pi * 1.0f, PDP_SP_EPS);
 
@@ -1363,9 +1358,7 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
     PROF_MARK(0);                                            // load
     for (int t = 0; t < T; ++t) {
         if (!active) break;
-        // requested here, consumed at the decisions (the round trip hides behind the sweep)
-        uint32_t nan_live = 0xffffffffu;
-        if (live_poison && t < poison_from) nan_live = __hip_atomic_load(&ctl->nan_iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool poisoned = t >= poison_from;
         iters = t + 1;
         float *const Eold = cur ? L.EB : L.EA, *const Enew = cur ? L.EA : L.EB;
         // ---- E1: per-slot logs, two slots per trip (independent chains for the scheduler / packed fp32 ops) -------------
@@ -1673,11 +1666,9 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
         const bool below_tol = (n > 0) ? (!(bits & 16) && !(bits & 4)) : (RF ? ((other_rows ? -1.0f : -PDP_INF) <= tol) : ((other_rows ? -1.0f : -PDP_INF) < tol));
         const int z1 = bits & 1, z2 = (bits >> 1) & 1;
         nan_seen = (bits >> 2) & 1;
-        if (nan_live < (uint32_t)poison_from) poison_from = (int)__builtin_amdgcn_readfirstlane((int)nan_live);
-        const bool poisoned = t >= poison_from;
         if (nan_seen && !poisoned) {
             if (tid == 0) atomicMin(&ctl->nan_iter, (uint32_t)t);
-            if (REPLAY) violation = 1;                          // the replay pass must not find a NaN before the poison iteration it was given
+            if (poison_from != 0x7fffffff) violation = 1;
         }
         int conv = 0;
         int rf_changed = 0;
