@@ -694,11 +694,14 @@ __global__ void k_ws_group_stop(int B0, int R, int cap, const int32_t *first_sat
     for (int r = 0; r < R; ++r) { const int f = first_sat[b0 + r * B0]; mn = f < mn ? f : mn; }
     atomicMax(stop, (uint32_t)mn);
 }
-__global__ void k_ws_replay_list(int B, int stop, const int32_t *first_sat, int32_t *cap_b, int32_t *list, uint32_t *count)
+// fit_list / nfit: the instances of the LDS-resident form (NULL: all B of them); only those are listed
+__global__ void k_ws_replay_list(int B, int stop, const int32_t *first_sat, int32_t *cap_b, int32_t *list, uint32_t *count, const int32_t *fit_list, int nfit)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    cap_b[b] = stop;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    cap_b[i] = stop;
+    if (i >= nfit) return;
+    const int b = fit_list ? fit_list[i] : i;
     if (first_sat[b] > stop) list[atomicAdd(count, 1u)] = b;     // ran past the global stop in pass 1: redo with the cap
 }
 
@@ -765,7 +768,7 @@ static int local_search_persistent(pdp_problem *p, const float *pred, int iterat
     if (!p->fn_edges_identity || iterations <= 0) return PDP_OK;
     { int st_ = ws_prepare(p); if (st_ != PDP_OK) return st_; }
     const int nfit = p->ws_nfit, nbig = p->ws_nbig;
-    if (nbig && (p->R > 1 || getenv("PDP_WALKSAT_NO_ROUTING"))) return PDP_OK;      // (replica caps are replayed by the LDS-resident form only)
+    if (nbig && getenv("PDP_WALKSAT_NO_ROUTING")) return PDP_OK;
     const size_t lds = ws_lds_bytes(p->ws_fit_n, p->ws_fit_m, p->ws_fit_e);
     const size_t bw = ((size_t)iterations + 31) / 32;               // words per bit map
     const size_t words = 2 * bw + 4;
@@ -785,13 +788,23 @@ static int local_search_persistent(pdp_problem *p, const float *pred, int iterat
     int ws_nt = 256;
     if (const char *env = getenv("PDP_WALKSAT_THREADS")) { const int v = atoi(env); if (v == 64 || v == 128 || v == 256) ws_nt = v; }
     char *big_ws = nullptr;
+    WsParams wb = wp;
+    // the instances past the LDS limit: one 1024-thread workgroup each on the HBM-resident form -- few of them: a team of workgroups each, chip-wide
+    // when no LDS-resident launch runs next to it -- on stream `on` (pass 1: a stream of its own next to the LDS-resident launch; they share
+    // nothing but the speculation bit maps).  The kernels build their workspace from the problem and `pred` at entry, so a second launch with
+    // a smaller step cap (the replica truncation below) simply runs the same search again and stops earlier.
+    auto launch_big = [&](int steps_cap, bool alone, hipStream_t on) -> int {
+        wb.steps_cap = steps_cap;
+        TeamLaunch tl; tl.size = 1;
+        if (!getenv("PDP_WALKSAT_NO_TEAM")) { const int st_ = pdp_team_plan(p, nbig, alone, 256, &tl, on); if (st_ != PDP_OK) return st_; }
+        if (tl.size > 1) hipLaunchKernelGGL((k_walksat_team<256>), dim3(tl.size * tl.slots), dim3(256), 0, on, make_view(p), wb, tl);
+        else hipLaunchKernelGGL((k_walksat<uint32_t, 1024>), dim3(nbig), dim3(1024), 0, on, make_view(p), wb);
+        return PDP_OK;
+    };
     if (nbig) {
-        // the instances past the LDS limit: one 1024-thread workgroup each on the HBM-resident form, on a stream of its own next to the
-        // LDS-resident launch (they share nothing but the speculation bit maps)
         const size_t bytes = (size_t)p->ws_big_E * 12 + (size_t)p->ws_big_V * 12 + (size_t)p->ws_big_F * 9 + 64 + (size_t)nbig * 4 + 16;
         { int st_ = pdp_dev_alloc((void **)&big_ws, bytes); if (st_ != PDP_OK) return st_; }
         guard.dev[1] = big_ws;
-        WsParams wb = wp;
         wb.inst_list = p->ws_big_list; wb.big_off = p->ws_big_off;
         wb.ws_E = p->ws_big_E; wb.ws_V = p->ws_big_V; wb.ws_F = p->ws_big_F;
         wb.ws_e = (uint32_t *)big_ws; wb.ws_v = (int32_t *)(wb.ws_e + 3 * wb.ws_E); wb.ws_f = (float *)(wb.ws_v + 3 * wb.ws_V); wb.ws_u = (uint8_t *)(wb.ws_f + 2 * wb.ws_F);
@@ -801,12 +814,8 @@ static int local_search_persistent(pdp_problem *p, const float *pred, int iterat
             for (int i = 0; i < 2; ++i) PDP_HIP_CHECK(hipEventCreateWithFlags(&p->ws_side_ev[i], hipEventDisableTiming));
         }
         PDP_HIP_CHECK(hipEventRecord(p->ws_side_ev[0], st)); PDP_HIP_CHECK(hipStreamWaitEvent(p->ws_side_stream, p->ws_side_ev[0], 0));
-        // few big instances: a team of workgroups each (chip-wide when no LDS-resident launch runs next to it)
-        TeamLaunch tl; tl.size = 1;
         guard.side = p->ws_side_stream; guard.side_busy = true;
-        if (!getenv("PDP_WALKSAT_NO_TEAM")) { const int st_ = pdp_team_plan(p, nbig, nfit == 0, 256, &tl, p->ws_side_stream); if (st_ != PDP_OK) return st_; }
-        if (tl.size > 1) hipLaunchKernelGGL((k_walksat_team<256>), dim3(tl.size * tl.slots), dim3(256), 0, p->ws_side_stream, make_view(p), wb, tl);
-        else hipLaunchKernelGGL((k_walksat<uint32_t, 1024>), dim3(nbig), dim3(1024), 0, p->ws_side_stream, make_view(p), wb);
+        { const int st_ = launch_big(iterations, nfit == 0, p->ws_side_stream); if (st_ != PDP_OK) return st_; }
         PDP_HIP_CHECK(hipEventRecord(p->ws_side_ev[1], p->ws_side_stream));
     }
     if (nfit) {
@@ -830,15 +839,19 @@ static int local_search_persistent(pdp_problem *p, const float *pred, int iterat
     int status = PDP_OK;
     if (p->R > 1 && stop < iterations) {
         // replicas that were still searching at the global stop step must be truncated there (solver.py:446-449)
-        hipLaunchKernelGGL(k_ws_replay_list, dim3((p->B + 255) / 256), dim3(256), 0, st, p->B, stop, first_sat, cap_b, list, ctl + 1);
+        hipLaunchKernelGGL(k_ws_replay_list, dim3((p->B + 255) / 256), dim3(256), 0, st, p->B, stop, first_sat, cap_b, list, ctl + 1,
+                           (const int32_t *)(nbig ? p->ws_fit_list : nullptr), nfit);
         uint32_t cnt = 0;
         PDP_HIP_CHECK(hipMemcpyAsync(&cnt, ctl + 1, 4, hipMemcpyDeviceToHost, st));
         PDP_HIP_CHECK(hipStreamSynchronize(st));
+        // the big instances (not in the list: they cannot run LDS-resident) run again, all of them, with the global stop as their cap -- a search
+        // that had ended before the stop ends at the same step again (same random numbers, keyed by step), the others are cut there
+        if (nbig) { const int st_ = launch_big(stop, cnt == 0, st); if (st_ != PDP_OK) return st_; }
         if (cnt) {
             wp.inst_list = list; wp.cap_b = cap_b;
             hipLaunchKernelGGL((k_walksat<uint16_t, 256>), dim3(cnt), dim3(ws_nt), lds, st, make_view(p), wp);
-            PDP_HIP_CHECK(hipStreamSynchronize(st));
         }
+        if (cnt || nbig) PDP_HIP_CHECK(hipStreamSynchronize(st));
     }
     // speculation record: every step < stop in which some instance searched needs an exact zero somewhere.  An instance that
     // finished at step f supplies zeros for every later step (its candidates are all 0), so only steps before the first finish count.

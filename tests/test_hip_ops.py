@@ -241,6 +241,36 @@ def test_local_search_routes_big_instances(oracle, monkeypatch, mode, n_big, wit
     np.testing.assert_array_equal(npy(hout)[:, 0], oout)
 
 
+@pytest.mark.parametrize('form', ['one-workgroup', 'team'])
+@pytest.mark.parametrize('R,w', [(2, 400), (4, 150)])
+def test_local_search_replicated_batch_with_big_instances(oracle, monkeypatch, form, R, w):
+    """configs[4]'s situation: batch replication AND instances past the LDS limit of the Walk-SAT kernel.  The search of an original
+    instance ends for all its replicas at the step its first replica is satisfied, and the whole call at the step the last original is
+    (solver.py:446-449): replicas that were still searching at that global stop are run again with it as their cap -- the LDS-resident ones
+    from a list, the big ones (HBM-resident form / teams) all together.  Easy instances (alpha 3.0) so that the stop comes before the step
+    limit.  Same assignments, de-duplicated result and step count as the oracle; before, such a batch took the strict 3-launch loop."""
+    from pdp.factorgraph import dataset
+    if form == 'one-workgroup':
+        monkeypatch.setenv('PDP_WALKSAT_NO_TEAM', '1')
+    items = dataset.random_ksat_items(10, 40, 3, m=120, seed=140)
+    items += [dataset.random_ksat_items(1, 2800 + 300 * i, 3, m=int(3.0 * (2800 + 300 * i)), seed=160 + i)[0] for i in range(2)]
+    items += dataset.random_ksat_items(5, 30, 3, m=90, seed=141)
+    b = dataset.collate_segment(items)
+    hp, op = make_pair(oracle, b, replication=R)
+    hp.simplify(); op.simplify()
+    hp.random_fill(seed=77); op.random_fill(seed=77)
+    pred = op.state()[2]
+    np.testing.assert_array_equal(npy(hp.solution), pred)
+    from pdp import native
+    native.kernel_timing(True)
+    hout, hsteps = hp.local_search(t(pred), w, 0.5, seed=31)
+    launches = native.kernel_timing_read()['walksat'][1]; native.kernel_timing(False)
+    oout, osteps, _ = op.local_search(pred, w, 0.5, seed=31)
+    assert hsteps == osteps and 0 < osteps < w, (hsteps, osteps)          # the global stop came first: the truncation was exercised
+    assert launches >= 1                                                  # the persistent kernels ran (the strict loop has none of them)
+    np.testing.assert_array_equal(npy(hout)[:, 0], oout)
+
+
 @pytest.mark.parametrize('spec', BATCHES[:4])
 def test_sequential_decimator_steps(oracle, spec):
     """Drive propagate + decimate for a number of iterations through the step-wise entry points and compare
