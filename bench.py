@@ -375,13 +375,19 @@ def neural_shard(args, dev, native, items, model_type, hidden, T, replication=1,
     V_seg = [int(b['batch_variable_map'].numel()) * replication for b in batches]
     for b in batches:                                                  # warm-up: the same pass once (native workspaces, torch's caching allocator)
         neural_step(tr, model, b, T, replication)
-    torch.cuda.synchronize()
-    native.kernel_timing(True)
-    t0 = time.perf_counter()
-    its = [neural_step(tr, model, b, T, replication) for b in batches]
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    timing = native.kernel_timing_read(); native.kernel_timing(False)
+    # best of two timed passes: at 25 M edges every [E, 128] state is 12.9 GB and torch's caching allocator may still release and re-acquire
+    # blocks in the first pass after the warm-up (a forward then takes 2-3 x its steady-state time; tools/neural_forward_phases.py)
+    dt, its, timing = None, None, None
+    for _ in range(2):
+        torch.cuda.synchronize()
+        native.kernel_timing(True)
+        t0 = time.perf_counter()
+        its_ = [neural_step(tr, model, b, T, replication) for b in batches]
+        torch.cuda.synchronize()
+        dt_ = time.perf_counter() - t0
+        timing_ = native.kernel_timing_read(); native.kernel_timing(False)
+        if dt is None or dt_ < dt:
+            dt, its, timing = dt_, its_, timing_
     flop = sum(neural_flop_per_iteration(model_type, hidden, e, v) * it for e, v, it in zip(E_seg, V_seg, its))
     tf = flop / dt / 1e12
     n_seg = float(len(segs))

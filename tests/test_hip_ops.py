@@ -241,27 +241,41 @@ def test_local_search_routes_big_instances(oracle, monkeypatch, mode, n_big, wit
     np.testing.assert_array_equal(npy(hout)[:, 0], oout)
 
 
+def _planted_instance(n, m, k, seed, name):
+    "random k-SAT whose clauses all hold under the all-TRUE assignment (one literal of every clause is made positive)"
+    from pdp.factorgraph import dataset
+    rng = np.random.RandomState(seed)
+    clauses = []
+    for _ in range(m):
+        vs = rng.choice(n, size=k, replace=False) + 1
+        sg = rng.randint(0, 2, size=k) * 2 - 1
+        sg[rng.randint(k)] = 1
+        clauses.append([int(a * b) for a, b in zip(vs, sg)])
+    return dataset.instance_from_clauses(n, clauses, label=1, name=name)
+
+
 @pytest.mark.parametrize('form', ['one-workgroup', 'team'])
-@pytest.mark.parametrize('R,w', [(2, 400), (4, 150)])
+@pytest.mark.parametrize('R,w', [(2, 400), (4, 300)])
 def test_local_search_replicated_batch_with_big_instances(oracle, monkeypatch, form, R, w):
     """configs[4]'s situation: batch replication AND instances past the LDS limit of the Walk-SAT kernel.  The search of an original
     instance ends for all its replicas at the step its first replica is satisfied, and the whole call at the step the last original is
     (solver.py:446-449): replicas that were still searching at that global stop are run again with it as their cap -- the LDS-resident ones
-    from a list, the big ones (HBM-resident form / teams) all together.  Easy instances (alpha 3.0) so that the stop comes before the step
-    limit.  Same assignments, de-duplicated result and step count as the oracle; before, such a batch took the strict 3-launch loop."""
+    from a list, the big ones (HBM-resident form / teams) all together.  Planted instances started a few flips away from their planted
+    assignment, so that the stop comes before the step limit.  Same assignments and step count as the oracle; before, such a batch took the
+    strict 3-launch loop."""
+    from pdp import native
     from pdp.factorgraph import dataset
     if form == 'one-workgroup':
         monkeypatch.setenv('PDP_WALKSAT_NO_TEAM', '1')
-    items = dataset.random_ksat_items(10, 40, 3, m=120, seed=140)
-    items += [dataset.random_ksat_items(1, 2800 + 300 * i, 3, m=int(3.0 * (2800 + 300 * i)), seed=160 + i)[0] for i in range(2)]
-    items += dataset.random_ksat_items(5, 30, 3, m=90, seed=141)
+    items = [_planted_instance(40, 120, 3, 140 + i, 's%d' % i) for i in range(10)]
+    items += [_planted_instance(2800 + 300 * i, int(3.0 * (2800 + 300 * i)), 3, 160 + i, 'big%d' % i) for i in range(2)]
+    items += [_planted_instance(30, 90, 3, 180 + i, 't%d' % i) for i in range(5)]
     b = dataset.collate_segment(items)
     hp, op = make_pair(oracle, b, replication=R)
     hp.simplify(); op.simplify()
-    hp.random_fill(seed=77); op.random_fill(seed=77)
-    pred = op.state()[2]
-    np.testing.assert_array_equal(npy(hp.solution), pred)
-    from pdp import native
+    rng = np.random.RandomState(9)
+    pred = np.ones(op.V, np.float32)
+    pred[rng.choice(op.V, size=op.V // 150, replace=False)] = 0.0          # every replica starts from its own few wrong variables
     native.kernel_timing(True)
     hout, hsteps = hp.local_search(t(pred), w, 0.5, seed=31)
     launches = native.kernel_timing_read()['walksat'][1]; native.kernel_timing(False)
