@@ -420,7 +420,7 @@ def neural_shard(args, dev, native, items, model_type, hidden, T, replication=1,
 
 def train_measurement(args, dev, native):
     """one optimizer step (`_train_batch`, base.py:149-182) per model type that trains, on a ~1 M-edge batch at hidden 128 --
-    3 outer recurrences, dropout 0.2 from the device generator, clipped Adam step.  flop = 3 x the forward's algorithmic flop (the adjoint
+    3 outer recurrences, random initial states and dropout 0.2 from the device generator, clipped Adam step.  flop = 3 x the forward's algorithmic flop (the adjoint
     of every dense layer is two products of the forward's size) x recurrences; the fraction is against the fp32 MFMA peak."""
     import logging
     import torch
@@ -438,7 +438,7 @@ def train_measurement(args, dev, native):
         cfg = dict(model_type=mt, model_name='bench-train-' + mt, verbose=False, dropout=0.2, error_dim=3, exploration=0.1, hidden_dim=128,
                    local_search_iteration=0, epsilon=0.5, tolerance=0.02, t_max=100, edge_feature_dim=1, meta_feature_dim=0, prediction_dim=1,
                    mem_hidden_dim=100, agg_hidden_dim=100, mem_agg_hidden_dim=50, classifier_dim=50, loss_sharpness=5, randomized=True,
-                   train_inner_recurrence_num=1, train_outer_recurrence_num=3, clip_norm=0.65, batch_size=bt, rng='philox', random_seed=0)
+                   train_inner_recurrence_num=1, train_outer_recurrence_num=3, clip_norm=0.65, batch_size=bt, rng='philox', random_seed=0, init_rng='device')
         cfg['lambda'] = 0.9
         torch.manual_seed(99)
         tr = SatFactorGraphTrainer(cfg, use_cuda=True, logger=logging.getLogger('bench'))

@@ -115,16 +115,28 @@ __global__ void k_splitk_reduce(int64_t MN, int splits, const float *__restrict_
     }
 }
 
-// column sums of Z [R,N] in two deterministic passes: partial[s][n] over a slice of rows, then their sum
+// column sums of Z [R,N] in two deterministic passes: partial[s][n] over a slice of rows, then their sum (k_splitk_reduce).  A workgroup takes a
+// slice; its 256 threads are 256 / C row groups x C columns (C = min(N, 256) per grid column), every thread walks its rows in ascending
+// order and the row groups are folded in a fixed order through LDS -- the order of the additions depends on (R, N, slices) only.
+#define COLSUM_SLICES 1024
 __global__ void __launch_bounds__(256) k_colsum_partial(int64_t R, int N, const float *__restrict__ Z, int slices, float *__restrict__ partial)
 {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+    __shared__ float red[256];
+    const int C = N < 256 ? N : 256;                       // columns of this grid column
+    const int groups = 256 / C, g = threadIdx.x / C, c = threadIdx.x % C;
+    const int n = blockIdx.x * 256 + c;
     const int64_t per = (R + slices - 1) / slices, r0 = per * blockIdx.y, r1 = (r0 + per < R) ? r0 + per : R;
     float acc = 0.0f;
-    for (int64_t r = r0; r < r1; ++r) acc = acc + Z[r * N + n];
-    partial[(int64_t)blockIdx.y * N + n] = acc;
+    if (g < groups && n < N)
+        for (int64_t r = r0 + g; r < r1; r += groups) acc = acc + Z[r * N + n];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (g == 0 && n < N) {
+        for (int j = 1; j < groups; ++j) acc = acc + red[j * C + c];
+        partial[(int64_t)blockIdx.y * N + n] = acc;
+    }
 }
+static int colsum_slices(int64_t R) { int64_t s = (R + 255) / 256; if (s > COLSUM_SLICES) s = COLSUM_SLICES; return (int)(s < 1 ? 1 : s); }
 
 // dZ = dY * act'(Y) (element-wise), in place into out
 __global__ void k_act_backward(int64_t n, const float *__restrict__ dY, const float *__restrict__ Y, int act, float *__restrict__ out)
@@ -200,14 +212,15 @@ extern "C" int pdp_train_linear_backward(const float *dY, const float *Y, const 
     int s;
     if (dX) { s = gemm<false, false>((int)R, K, N, dZ, N, W, K, dX, lddx, nullptr, TACT_NONE, 1, nullptr, st); if (s != PDP_OK) return s; }
     const int splits = pick_splits(R);
-    float *scr = train_scratch((size_t)splits * ((size_t)N * K + N) + 16, st);
+    const int cs = colsum_slices(R);
+    float *scr = train_scratch((size_t)splits * (size_t)N * K + (size_t)cs * N + 16, st);
     if (!scr) return PDP_ERR_HIP;
     s = gemm<true, false>(N, K, R, dZ, N, X, ldx, dW, K, nullptr, TACT_NONE, splits, scr, st);
     if (s != PDP_OK) return s;
     if (db) {
         float *part = scr + (size_t)splits * N * K;
-        hipLaunchKernelGGL(k_colsum_partial, dim3((N + 255) / 256, splits), dim3(256), 0, st, R, N, (const float *)dZ, splits, part);
-        hipLaunchKernelGGL(k_splitk_reduce, dim3(grid1d(N)), dim3(256), 0, st, (int64_t)N, splits, (const float *)part, db);
+        hipLaunchKernelGGL(k_colsum_partial, dim3((N + 255) / 256, cs), dim3(256), 0, st, R, N, (const float *)dZ, cs, part);
+        hipLaunchKernelGGL(k_splitk_reduce, dim3(grid1d(N)), dim3(256), 0, st, (int64_t)N, cs, (const float *)part, db);
     }
     PDP_LAUNCH_CHECK();
     return PDP_OK;
@@ -330,15 +343,16 @@ extern "C" int pdp_train_gru_backward(const float *dhnew, const float *saved, co
     hipLaunchKernelGGL(k_add_inplace, dim3(grid1d(R * H)), dim3(256), 0, st, R * H, dh, (const float *)dh2);
     const int splits = pick_splits(R);
     const size_t wmax = (size_t)3 * H * (Kx > H ? Kx : H);
-    float *scr = train_scratch((size_t)splits * (wmax + 3 * H) + 16, st);
+    const int cs = colsum_slices(R);
+    float *scr = train_scratch((size_t)splits * wmax + (size_t)cs * 3 * H + 16, st);
     if (!scr) return PDP_ERR_HIP;
     float *part = scr + (size_t)splits * wmax;
     s = gemm<true, false>(3 * H, Kx, R, dgi, 3 * H, x, Kx, dW_ih, Kx, nullptr, TACT_NONE, splits, scr, st); if (s != PDP_OK) return s;
-    hipLaunchKernelGGL(k_colsum_partial, dim3((3 * H + 255) / 256, splits), dim3(256), 0, st, R, 3 * H, (const float *)dgi, splits, part);
-    hipLaunchKernelGGL(k_splitk_reduce, dim3(grid1d(3 * H)), dim3(256), 0, st, (int64_t)3 * H, splits, (const float *)part, db_ih);
+    hipLaunchKernelGGL(k_colsum_partial, dim3((3 * H + 255) / 256, cs), dim3(256), 0, st, R, 3 * H, (const float *)dgi, cs, part);
+    hipLaunchKernelGGL(k_splitk_reduce, dim3(grid1d(3 * H)), dim3(256), 0, st, (int64_t)3 * H, cs, (const float *)part, db_ih);
     s = gemm<true, false>(3 * H, H, R, dgh, 3 * H, h, H, dW_hh, H, nullptr, TACT_NONE, splits, scr, st); if (s != PDP_OK) return s;
-    hipLaunchKernelGGL(k_colsum_partial, dim3((3 * H + 255) / 256, splits), dim3(256), 0, st, R, 3 * H, (const float *)dgh, splits, part);
-    hipLaunchKernelGGL(k_splitk_reduce, dim3(grid1d(3 * H)), dim3(256), 0, st, (int64_t)3 * H, splits, (const float *)part, db_hh);
+    hipLaunchKernelGGL(k_colsum_partial, dim3((3 * H + 255) / 256, cs), dim3(256), 0, st, R, 3 * H, (const float *)dgh, cs, part);
+    hipLaunchKernelGGL(k_splitk_reduce, dim3(grid1d(3 * H)), dim3(256), 0, st, (int64_t)3 * H, cs, (const float *)part, db_hh);
     PDP_LAUNCH_CHECK();
     return PDP_OK;
 }

@@ -65,8 +65,9 @@ class NeuralDecimator(nn.Module):
         "reference: pdp_decimate.py:89-100"
         edge_num = graph_map.size(1) * batch_replication
         if randomized:
-            variable_state = 2.0 * torch.rand(edge_num, self._hidden_dimension, dtype=torch.float32) - 1.0
-            function_state = 2.0 * torch.rand(edge_num, self._hidden_dimension, dtype=torch.float32) - 1.0
+            where = self._device if getattr(self, '_init_rng', 'torch') == 'device' else None       # (see NeuralMessagePasser.get_init_state)
+            variable_state = 2.0 * torch.rand(edge_num, self._hidden_dimension, dtype=torch.float32, device=where) - 1.0
+            function_state = 2.0 * torch.rand(edge_num, self._hidden_dimension, dtype=torch.float32, device=where) - 1.0
             return (variable_state.to(self._device), function_state.to(self._device))
         return (torch.zeros(edge_num, self._hidden_dimension, dtype=torch.float32, device=self._device),
                 torch.zeros(edge_num, self._hidden_dimension, dtype=torch.float32, device=self._device))

@@ -85,8 +85,11 @@ class NeuralMessagePasser(nn.Module):
         "reference: pdp_propagate.py:97-108"
         edge_num = graph_map.size(1) * batch_replication
         if randomized:
-            variable_state = 2.0 * torch.rand(edge_num, self._hidden_dimension, dtype=torch.float32) - 1.0
-            function_state = 2.0 * torch.rand(edge_num, self._hidden_dimension, dtype=torch.float32) - 1.0
+            # drawn from the global CPU generator like the reference's --cpu_mode run (default: seeded runs reproduce its numbers), or on the
+            # device (config key init_rng: 'device' -- what a training run wants: 4 x [E, H] host-generated numbers per batch cost seconds)
+            where = self._device if getattr(self, '_init_rng', 'torch') == 'device' else None
+            variable_state = 2.0 * torch.rand(edge_num, self._hidden_dimension, dtype=torch.float32, device=where) - 1.0
+            function_state = 2.0 * torch.rand(edge_num, self._hidden_dimension, dtype=torch.float32, device=where) - 1.0
             return (variable_state.to(self._device), function_state.to(self._device))
         return (torch.zeros(edge_num, self._hidden_dimension, dtype=torch.float32, device=self._device),
                 torch.zeros(edge_num, self._hidden_dimension, dtype=torch.float32, device=self._device))
@@ -150,9 +153,10 @@ class SurveyPropagator(nn.Module):
         edge_num = graph_map.size(1) * batch_replication
         dev = self._device
         if randomized:
-            variable_state = torch.rand(edge_num, self._function_message_dim, dtype=torch.float32)
+            where = dev if getattr(self, '_init_rng', 'torch') == 'device' else None
+            variable_state = torch.rand(edge_num, self._function_message_dim, dtype=torch.float32, device=where)
             variable_state = variable_state / torch.sum(variable_state, 1).unsqueeze(1)
-            function_state = torch.rand(edge_num, self._variable_message_dim, dtype=torch.float32)
+            function_state = torch.rand(edge_num, self._variable_message_dim, dtype=torch.float32, device=where)
             function_state[:, 1] = 0
             return (variable_state.to(dev), function_state.to(dev))
         variable_state = torch.ones(edge_num, self._function_message_dim, dtype=torch.float32, device=dev) / self._function_message_dim

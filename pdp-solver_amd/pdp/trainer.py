@@ -60,6 +60,9 @@ class SatFactorGraphTrainer(FactorGraphTrainerBase):
                 # where the training path's dropout masks come from: the device generator (default), or -- dropout_rng: 'torch' -- the global
                 # CPU stream drawn exactly as the reference's --cpu_mode run draws it (the golden tests; it builds every mask on the host)
                 model._propagator._rng = config.get('dropout_rng', 'device')
+            # random initial states (training / test mode): the reference's CPU stream by default, 'device' for throughput
+            for plug_in in (model._propagator, model._decimator):
+                plug_in._init_rng = config.get('init_rng', 'torch')
         else:
             raise KeyError("unknown model_type %r" % (t,))
         if config.get('verbose'):

@@ -57,6 +57,10 @@ def run(random_seed, config_file, is_training, load_model, cpu, reset_step, use_
                            if os.path.isfile(os.path.join(config[key], f)) and f.endswith('.json')]
     base = os.path.join(os.path.relpath(config['model_path']), config['model_name'], str(config['version']))
     best_base, last_base = os.path.join(base, 'best'), os.path.join(base, 'last')
+    if is_training:
+        # a training run draws its random initial states on the device unless the YAML says otherwise (init_rng: 'torch' = the reference's
+        # CPU stream, which costs seconds per batch at a million edges; dropout masks come from the device generator by default as well)
+        config.setdefault('init_rng', 'device')
     trainer = SatFactorGraphTrainer(config=config, use_cuda=not cpu, logger=logger)
     if is_training:
         why = trainer.UNTRAINABLE.get(config['model_type'])
