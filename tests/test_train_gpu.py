@@ -315,7 +315,7 @@ def test_train_script_with_generator(tmp_path):
                learning_rate=0.002, exploration=0.1, verbose=False, randomized=True, train_inner_recurrence_num=1, train_outer_recurrence_num=4,
                test_recurrence_num=10, max_cache_size=100000, dropout=0.2, clip_norm=0.65, weight_decay=1e-10, loss_sharpness=5,
                train_batch_limit=4000000, test_batch_limit=40000000, generator='uniform', min_n=6, max_n=14, min_alpha=2, max_alpha=4, min_k=2, max_k=4,
-               local_search_iteration=20, epsilon=0.5, rng='torch')            # (dropout masks: the device generator, the default)
+               local_search_iteration=20, epsilon=0.5, rng='torch', init_rng='torch', dropout_rng='torch')   # seeded CPU streams: a reproducible run
     cfg['lambda'] = 1
     path = tmp_path / 'train.yaml'
     path.write_text(yaml.safe_dump(cfg))
