@@ -30,8 +30,12 @@ for work in sorted(os.listdir(root)):
         print("  [pmc] %s" % k)
         print("        " + "  ".join("%s=%.4g" % (c, v[c]) for c in sorted(v)))
         if v.get('SQ_BUSY_CU_CYCLES') and 'SQ_VALU_MFMA_BUSY_CYCLES' in v:
-            print("        MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES = %.3f" % (v['SQ_VALU_MFMA_BUSY_CYCLES'] / v['SQ_BUSY_CU_CYCLES']))
+            # SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of the four matrix pipes of a CU (= 64 x SQ_INSTS_MFMA for v_mfma_f32_32x32x2_f32),
+            # SQ_BUSY_CU_CYCLES counts cycles per busy CU: the pipe's busy fraction is their ratio / 4 SIMDs
+            print("        MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) = %.3f   (cycles per MFMA instruction: %.1f)"
+                  % (v['SQ_VALU_MFMA_BUSY_CYCLES'] / (4.0 * v['SQ_BUSY_CU_CYCLES']), v['SQ_VALU_MFMA_BUSY_CYCLES'] / max(1.0, v.get('SQ_INSTS_MFMA', 0.0))))
+            if 'SQ_INSTS_VALU' in v:
+                print("        VALU issue at 4 cycles per wave-instruction = 4 x SQ_INSTS_VALU / (4 x SQ_BUSY_CU_CYCLES) = %.3f   (MFMA + VALU = %.3f of the SIMD cycles)"
+                      % (v['SQ_INSTS_VALU'] / v['SQ_BUSY_CU_CYCLES'], (v['SQ_VALU_MFMA_BUSY_CYCLES'] / 4.0 + v['SQ_INSTS_VALU']) / v['SQ_BUSY_CU_CYCLES']))
         if v.get('SQ_WAVE_CYCLES') and 'SQ_WAIT_ANY' in v:
             print("        SQ_WAIT_ANY / SQ_WAVE_CYCLES = %.3f" % (v['SQ_WAIT_ANY'] / v['SQ_WAVE_CYCLES']))
-        if v.get('SQ_BUSY_CYCLES') and 'SQ_ACTIVE_INST_VALU' in v:
-            print("        SQ_ACTIVE_INST_VALU x 4 / (SQ_BUSY_CYCLES x SIMDs per SE?) -- raw: ACTIVE_INST_VALU=%.4g BUSY_CYCLES=%.4g" % (v['SQ_ACTIVE_INST_VALU'], v['SQ_BUSY_CYCLES']))
