@@ -50,13 +50,14 @@ __device__ __forceinline__ float tact_grad(float y, int act)
 // K in slabs of 16 through LDS.  gridDim.z > 1: split-K, slab range z of the K dimension goes to partial[z] (summed by k_splitk_reduce).
 // Epilogue (gridDim.z == 1): + bias[n], activation, optional element-wise factor (dropout mask, or the incoming gradient's act').
 #define GB 64
-#define GK 16
+#define GK 32
 template <bool TA, bool TB>
 __global__ void __launch_bounds__(256) k_gemm(int M, int N, int64_t K, const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb,
                                               float *__restrict__ C, int64_t ldc, const float *__restrict__ bias, int act, float *__restrict__ partial)
 {
     __shared__ float As[GB][GK + 1];
     __shared__ float Bs[GK][GB + 1];
+    constexpr int PER = GB * GK / 256;                     // elements of each operand tile per thread and slab
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     const int m0 = blockIdx.y * GB, n0 = blockIdx.x * GB;
     const int mb = w & 1, nb = w >> 1;
@@ -67,29 +68,46 @@ __global__ void __launch_bounds__(256) k_gemm(int M, int N, int64_t K, const flo
     const int64_t slabs = (K + GK - 1) / GK;
     const int64_t per = (slabs + gridDim.z - 1) / gridDim.z;
     const int64_t s_begin = per * blockIdx.z, s_end = (s_begin + per < slabs) ? s_begin + per : slabs;
-    for (int64_t sl = s_begin; sl < s_end; ++sl) {
+    // the next slab's operand elements are fetched into registers while the MFMAs of the current one run (the k order of the
+    // accumulation -- one ascending chain per output element -- does not depend on the slab size)
+    float ra[PER], rb[PER];
+    auto fetch = [&](int64_t sl) {
         const int64_t k0 = sl * GK;
-        // A tile: 64 rows x 16 k
-        for (int t = tid; t < GB * GK; t += 256) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int t = tid + 256 * j;
             int r, kk;
             if (TA) { r = t % GB; kk = t / GB; } else { kk = t % GK; r = t / GK; }          // the fastest index follows the storage order
             const int m = m0 + r; const int64_t k = k0 + kk;
-            float v = 0.0f;
-            if (m < M && k < K) v = TA ? A[k * lda + m] : A[(int64_t)m * lda + k];
-            As[r][kk] = v;
+            ra[j] = (m < M && k < K) ? (TA ? A[k * lda + m] : A[(int64_t)m * lda + k]) : 0.0f;
+            int c, kb;
+            if (TB) { kb = t % GK; c = t / GK; } else { c = t % GB; kb = t / GB; }
+            const int n = n0 + c; const int64_t k2 = k0 + kb;
+            rb[j] = (n < N && k2 < K) ? (TB ? B[(int64_t)n * ldb + k2] : B[k2 * ldb + n]) : 0.0f;
         }
-        for (int t = tid; t < GK * GB; t += 256) {
-            int c, kk;
-            if (TB) { kk = t % GK; c = t / GK; } else { c = t % GB; kk = t / GB; }
-            const int n = n0 + c; const int64_t k = k0 + kk;
-            float v = 0.0f;
-            if (n < N && k < K) v = TB ? B[(int64_t)n * ldb + k] : B[k * ldb + n];
-            Bs[kk][c] = v;
+    };
+    auto deposit = [&]() {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int t = tid + 256 * j;
+            int r, kk;
+            if (TA) { r = t % GB; kk = t / GB; } else { kk = t % GK; r = t / GK; }
+            As[r][kk] = ra[j];
+            int c, kb;
+            if (TB) { kb = t % GK; c = t / GK; } else { c = t % GB; kb = t / GB; }
+            Bs[kb][c] = rb[j];
         }
-        __syncthreads();
+    };
+    if (s_begin < s_end) { fetch(s_begin); deposit(); }
+    __syncthreads();
+    for (int64_t sl = s_begin; sl < s_end; ++sl) {
+        const bool more = sl + 1 < s_end;
+        if (more) fetch(sl + 1);
 #pragma unroll
         for (int s = 0; s < GK / 2; ++s)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[32 * mb + i][2 * s + kh], Bs[2 * s + kh][32 * nb + i], acc, 0, 0, 0);
+        __syncthreads();
+        if (more) deposit();
         __syncthreads();
     }
     const int col = n0 + 32 * nb + i;
