@@ -342,12 +342,15 @@ def neural_kernel_rooflines(native, timing, E, V, H, model_type='np-nd-np'):
     names are what the library reports it launched last (pdp_kernel_name), not literals."""
     fl = neural_flops(H, model_type)
     out = {}
-    for key in ('agg_pre', 'agg_post', 'gru', 'predict_head', 'row_sum'):
+    for key in ('agg_pre', 'agg_post', 'gru', 'predict_head', 'row_sum', 'sp_adaptors', 'sp_sweep'):
         ms, n = timing[key]
         if n == 0:
             continue
         per = ms / n
         row = dict(kernel=native.kernel_name(key) if key != 'row_sum' else 'k_row_sum', launches=n, ms_per_launch=per)
+        if key == 'sp_adaptors':                          # HBM-bound: the two [E, H] decimator states read once
+            gbs = 2.0 * E * H * 4 / (per * 1e-3) / 1e9
+            row.update(bytes_per_launch=2.0 * E * H * 4, gb_per_s=gbs, frac_of_hbm_peak=gbs / HBM_PEAK_GBS)
         if key in fl:
             flop = fl[key] * (V if key == 'predict_head' else E)
             tf = flop / (per * 1e-3) / 1e12

@@ -289,11 +289,13 @@ enum { PDP_TK_AGG_PRE = 0,      /* k_agg_pre_wave / k_agg_pre_res / k_agg_pre: f
        PDP_TK_GRU = 3,          /* k_gru_pipe (hidden 128) / k_gru_wave (hidden 150) / k_gru */
        PDP_TK_PREDICT_HEAD = 4, /* k_predict_rows: per-variable layers + perceptron head of NeuralPredictor */
        PDP_TK_WALKSAT = 5,      /* k_walksat<uint16_t, 256>: the persistent LDS-resident Walk-SAT launch of pdp_local_search */
-       PDP_TK_COUNT = 6,
+       PDP_TK_SP_ADAPTORS = 6,  /* k_sp_adaptors: the two projections in front of the adaptor form of the SP sweep (p-nd-np) */
+       PDP_TK_SP_SWEEP = 7,     /* k_sp_propagate<false|true>: the step-wise SP sweep (pdp_sp_propagate / pdp_sp_propagate_adapted) */
+       PDP_TK_COUNT = 8,
        /* name-only keys (their times come back through pdp_solve_args) */
-       PDP_KN_SP_SOLVE = 6,     /* pass 1 of pdp_sp_solve (k_sp_solve_lds<...> / k_sp_solve<...>) */
-       PDP_KN_SP_REPLAY = 7,    /* its NaN-poison replay instantiation */
-       PDP_KN_COUNT = 8 };
+       PDP_KN_SP_SOLVE = 8,     /* pass 1 of pdp_sp_solve (k_sp_solve_lds<...> / k_sp_solve<...>) */
+       PDP_KN_SP_REPLAY = 9,    /* its NaN-poison replay instantiation */
+       PDP_KN_COUNT = 10 };
 int pdp_kernel_timing(int enable);
 /* the name (with template arguments, as rocprofv3 prints it) of the kernel the library launched last for `key`; empty before the first launch */
 int pdp_kernel_name(int key, char *buf, int len);

@@ -274,6 +274,8 @@ extern "C" int pdp_sp_propagate(pdp_problem *p, const float *dec_q, const float 
 {
     PDP_REQUIRE(p && dec_q && dec_fs && init_q && init_fs && out_q && out_fs, "NULL argument");
     PDP_REQUIRE(out_q != dec_q && out_q != init_q && out_fs != dec_fs && out_fs != init_fs, "outputs must not alias inputs");
+    pdp_timed_scope timed(PDP_TK_SP_SWEEP, ST(stream));
+    pdp_note_kernel(PDP_TK_SP_SWEEP, "k_sp_propagate<false>");
     hipLaunchKernelGGL(k_sp_propagate<false>, dim3(p->B), dim3(PDP_NT), 0, ST(stream), make_view(p), dec_q, dec_fs, edge_mask,
                        active_mask, init_q, init_fs, pi, out_q, out_fs, p->ws_e[0], p->ws_e[1], p->ws_f[0], p->ws_v[0], p->ws_v[1]);
     PDP_LAUNCH_CHECK();
@@ -323,6 +325,8 @@ extern "C" int pdp_sp_adaptors(pdp_problem *p, int H, const float *dec_v, const 
 {
     PDP_REQUIRE(p && dec_v && dec_f && w_f && W_v && xlog && fs2 && H > 0, "NULL argument");
     const int64_t groups = ((int64_t)p->E + 63) / 64;
+    pdp_timed_scope timed(PDP_TK_SP_ADAPTORS, ST(stream));
+    pdp_note_kernel(PDP_TK_SP_ADAPTORS, "k_sp_adaptors");
     hipLaunchKernelGGL(k_sp_adaptors, dim3((unsigned)(groups < 16384 ? (groups < 1 ? 1 : groups) : 16384)), dim3(64), 0, ST(stream), p->E, H, dec_v, dec_f, w_f, W_v, xlog, fs2);
     PDP_LAUNCH_CHECK();
     return PDP_OK;
@@ -334,6 +338,8 @@ extern "C" int pdp_sp_propagate_adapted(pdp_problem *p, const float *xlog, const
 {
     PDP_REQUIRE(p && xlog && dec_fs && init_q && init_fs && out_q && out_fs, "NULL argument");
     PDP_REQUIRE(out_q != init_q && out_fs != dec_fs && out_fs != init_fs, "outputs must not alias inputs");
+    pdp_timed_scope timed(PDP_TK_SP_SWEEP, ST(stream));
+    pdp_note_kernel(PDP_TK_SP_SWEEP, "k_sp_propagate<true>");
     hipLaunchKernelGGL(k_sp_propagate<true>, dim3(p->B), dim3(PDP_NT), 0, ST(stream), make_view(p), xlog, dec_fs, edge_mask,
                        active_mask, init_q, init_fs, pi, out_q, out_fs, p->ws_e[0], p->ws_e[1], p->ws_f[0], p->ws_v[0], p->ws_v[1]);
     PDP_LAUNCH_CHECK();

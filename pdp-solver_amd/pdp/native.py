@@ -471,7 +471,7 @@ def dimacs_parse_many(paths, threads=8):
     return out
 
 
-TIMING_KEYS = ('agg_pre', 'row_sum', 'agg_post', 'gru', 'predict_head', 'walksat')       # include/pdp_hip.h: PDP_TK_*
+TIMING_KEYS = ('agg_pre', 'row_sum', 'agg_post', 'gru', 'predict_head', 'walksat', 'sp_adaptors', 'sp_sweep')       # include/pdp_hip.h: PDP_TK_*
 
 
 def kernel_timing(enable):
