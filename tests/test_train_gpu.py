@@ -362,3 +362,24 @@ def test_trained_weights_solve_held_out_instances(model_type, weights):
         assert m_.last_run['train_path'] is False
         fractions.append(float(solved.mean().item()))
     assert fractions[0] < 0.1 and fractions[1] > 0.75, fractions
+
+
+@pytest.mark.parametrize('yaml_name', ['PDP-np-nd-np-demo-h128.yaml', 'PDP-p-nd-np-demo-h128.yaml'])
+def test_cli_predicts_with_the_trained_weights(tmp_path, monkeypatch, yaml_name):
+    """train -> save -> satyr.py: the Predict YAMLs that point at models/ run the CLI on a directory of generated DIMACS files (the training
+    distribution) and most rows come back solved (T = 30, no Walk-SAT)."""
+    import satyr
+    from pdp import generator
+    ddir = tmp_path / 'cnf'
+    ddir.mkdir()
+    rng = np.random.RandomState(123)
+    for k in range(60):
+        n = int(rng.randint(10, 41)); m_ = max(1, int(rng.uniform(2.0, 4.0) * n))
+        clauses = generator.uniform_ksat(n, m_, 3, np.random.RandomState(7_000 + k))
+        (ddir / ('g%02d_1.cnf' % k)).write_text('p cnf %d %d\n' % (n, len(clauses)) + ''.join(' '.join(str(x) for x in c) + ' 0\n' for c in clauses))
+    out = tmp_path / 'out.jsonl'
+    monkeypatch.chdir(REPO)
+    satyr.main([os.path.join(REPO, 'config', 'Predict', yaml_name), str(ddir), '30', '-d', '-z', '100', '-s', '3', '-w', '0', '--rng', 'philox', '-o', str(out)])
+    rows = [json.loads(l) for l in out.read_text().split('\n') if l.strip()]
+    assert len(rows) == 60
+    assert sum(r['solved'] for r in rows) >= 42, sum(r['solved'] for r in rows)
