@@ -838,7 +838,8 @@ def main():
         prob.simplify()
         ev0.record()
         try:
-            it, lds = prob.sp_solve(q, fs, am, dec, args.iters, args.tolerance, args.t_max, time_kernels=True, isolate_instances=args.isolated)
+            it, lds = prob.sp_solve(q, fs, am, dec, args.iters, args.tolerance, args.t_max, time_kernels=True, isolate_instances=args.isolated,
+                                    inputs_disposable=True)      # like the solver class: this step's q / fs are copies of the initial state
             path = 'persistent-lds' if lds else 'persistent-hbm'
         except native.SpeculationFailed:
             raise SystemExit("bench: speculation failed on the benchmark batch (unexpected)")

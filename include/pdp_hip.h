@@ -199,6 +199,10 @@ typedef struct pdp_solve_args {
                                    * returns PDP_ERR_SPECULATION. */
     int32_t hbm_instances_host;   /* out: instances of the batch that did not fit the LDS and ran on the HBM-resident kernel inside the same chunk
                                    * loop (per-instance routing; 0 when every instance fits, the batch size when none does) */
+    int32_t inputs_disposable;    /* in: 1 = the caller does not need q / fs back when the call returns PDP_ERR_SPECULATION (it still holds the
+                                   * state it built them from, as PropagatorDecimatorSolverBase does: its init_state is never mutated,
+                                   * solver.py:355-365) -- the call then skips their call-entry snapshot (250 MB of copies on config 2).  Every
+                                   * other array is restored as always; 0 keeps the full guarantee */
 } pdp_solve_args;
 int pdp_sp_solve(pdp_problem *p, pdp_solve_args *args, void *stream);
 

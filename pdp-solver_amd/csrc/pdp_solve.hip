@@ -2057,14 +2057,18 @@ struct SolveSnapshot {
     float *q, *fs, *av, *af, *sol, *sat, *emask, *prev, *cnt; uint8_t *amask;
 };
 
-static int snapshot_copy(pdp_problem *p, pdp_solve_args *a, SolveSnapshot &s, bool save, hipStream_t st)
+// skip: bit 0 the messages q / fs (the caller declared them disposable: pdp_solve_args.inputs_disposable), bit 1 the decimator's previous
+// surveys (no previous state at call entry: the handle's has_prev flag says their content means nothing), bit 2 the edge mask (likewise
+// p->has_edge_mask).  Only the call-entry snapshot of the LDS-resident path uses it: 378 MB of copies on config 2 shrink to 25 MB.
+static int snapshot_copy(pdp_problem *p, pdp_solve_args *a, SolveSnapshot &s, bool save, hipStream_t st, int skip = 0)
 {
     const size_t E = p->E, V = p->V, F = p->F, B = p->B;
-    struct { void *live; void *snap; size_t bytes; } items[] = {
-        {a->q, s.q, 3 * E * 4}, {a->fs, s.fs, 2 * E * 4}, {p->av, s.av, V * 4}, {p->af, s.af, F * 4}, {p->sol, s.sol, V * 4},
-        {p->is_sat, s.sat, B * 4}, {p->emask, s.emask, E * 4}, {a->decimator->prev, s.prev, E * 4},
-        {a->decimator->counters, s.cnt, B * 4}, {a->active_mask, s.amask, B}};
+    struct { void *live; void *snap; size_t bytes; int skip_bit; } items[] = {
+        {a->q, s.q, 3 * E * 4, 1}, {a->fs, s.fs, 2 * E * 4, 1}, {p->av, s.av, V * 4, 0}, {p->af, s.af, F * 4, 0}, {p->sol, s.sol, V * 4, 0},
+        {p->is_sat, s.sat, B * 4, 0}, {p->emask, s.emask, E * 4, 4}, {a->decimator->prev, s.prev, E * 4, 2},
+        {a->decimator->counters, s.cnt, B * 4, 0}, {a->active_mask, s.amask, B, 0}};
     for (auto &it : items) {
+        if (skip & it.skip_bit) continue;
         if (save) PDP_HIP_CHECK(hipMemcpyAsync(it.snap, it.live, it.bytes, hipMemcpyDeviceToDevice, st));
         else PDP_HIP_CHECK(hipMemcpyAsync(it.live, it.snap, it.bytes, hipMemcpyDeviceToDevice, st));
     }
@@ -2195,6 +2199,7 @@ static int hbm_workspaces(pdp_problem *p, SolveParams &sp, bool records = true)
 
 // LDS-resident path: every launch of the call is enqueued up front (import, then per chunk: pass 1, poison decision, replay
 // list, replay, speculation check); the host reads one control block at the end.
+static bool lockstep_possible(const pdp_problem *p, const pdp_solve_args *a);
 static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, bool force, size_t lds, int nt_lds, int C)
 {
     const bool rf = a->model == PDP_MODEL_REINFORCE;
@@ -2231,7 +2236,10 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
         snap0.sat = f; f += B; snap0.emask = f; f += E; snap0.prev = f; f += E; snap0.cnt = f; f += B; snap0.amask = (uint8_t *)f;
     }
     const int had_prev0 = a->decimator->has_prev, had_emask0 = p->has_edge_mask;
-    status = snapshot_copy(p, a, snap0, true, st);
+    // (with big instances in the batch the HBM-resident kernel works in place on the caller's arrays: everything is kept then)
+    // (and a small batch whose speculation fails reruns in the lock-step launch from the restored q / fs: they are kept for it)
+    const int snap_skip = p->res_nbig ? 0 : (((a->inputs_disposable && !lockstep_possible(p, a)) ? 1 : 0) | (had_prev0 ? 0 : 2) | (had_emask0 ? 0 : 4));
+    status = snapshot_copy(p, a, snap0, true, st, snap_skip);
     if (status != PDP_OK) return status;
 
     if (rf) {
@@ -2415,7 +2423,7 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     a->solve_kernel_ms_host = solve_ms; a->replay_kernel_ms_host = replay_ms;
     if (hcall->fail) {
         // leave the caller's state exactly as it was at call entry so that it can rerun the batch step-wise
-        status = snapshot_copy(p, a, snap0, false, st);
+        status = snapshot_copy(p, a, snap0, false, st, snap_skip);
         if (status == PDP_OK) status = hipStreamSynchronize(st) == hipSuccess ? PDP_OK : PDP_ERR_HIP;
         a->decimator->has_prev = had_prev0; p->has_edge_mask = had_emask0;
         if (status != PDP_OK) return status;

@@ -101,7 +101,8 @@ class SolveArgs(C.Structure):
                 ('decimator', C.c_void_p), ('check_termination', C.c_int32), ('iterations_run_host', C.c_int32),
                 ('used_lds_host', C.c_int32), ('kernel_launches_host', C.c_int32), ('replay_launches_host', C.c_int32),
                 ('time_kernels', C.c_int32), ('solve_kernel_ms_host', C.c_float), ('replay_kernel_ms_host', C.c_float),
-                ('replicas_identical', C.c_int32), ('isolate_instances', C.c_int32), ('hbm_instances_host', C.c_int32)]
+                ('replicas_identical', C.c_int32), ('isolate_instances', C.c_int32), ('hbm_instances_host', C.c_int32),
+                ('inputs_disposable', C.c_int32)]
 
 
 class AggDesc(C.Structure):
@@ -413,8 +414,10 @@ class Problem(object):
 
     # -- persistent solve -----------------------------------------------------------------------------------------
     def sp_solve(self, q, fs, active_mask, dec, iterations, tolerance, t_max, pi=0.0, model=MODEL_SP,
-                 decimation_probability=0.5, seed=0, coins=None, check_termination=True, time_kernels=False, replicas_identical=False, isolate_instances=False):
+                 decimation_probability=0.5, seed=0, coins=None, check_termination=True, time_kernels=False, replicas_identical=False, isolate_instances=False,
+                 inputs_disposable=False):
         a = SolveArgs()
+        a.inputs_disposable = 1 if inputs_disposable else 0
         a.isolate_instances = 1 if isolate_instances else 0
         a.time_kernels = 1 if time_kernels else 0
         a.replicas_identical = 1 if replicas_identical else 0

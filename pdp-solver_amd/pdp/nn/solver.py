@@ -282,7 +282,8 @@ class PropagatorDecimatorSolverBase(nn.Module):
             iters, used_lds = nat.sp_solve(q, fs, active_mask, handle, int(iteration_num), tolerance, t_max, self._propagator._pi,
                                            check_termination=check_termination is not None,
                                            replicas_identical=sat_problem._batch_replication > 1 and getattr(self, '_replicas_same', True),
-                                           isolate_instances=self._isolated, **extra)
+                                           isolate_instances=self._isolated, inputs_disposable=True,        # q / fs are clones: init_state stays intact
+                                           **extra)
         except native.SpeculationFailed:
             if model == native.MODEL_REINFORCE:
                 torch.set_rng_state(rng_state)

@@ -97,6 +97,14 @@ def test_speculation_detects_coupling(oracle, monkeypatch):
     monkeypatch.setenv('PDP_SOLVE_NO_LOCKSTEP', '1')
     with pytest.raises(native.SpeculationFailed):
         hp.sp_solve(q, fs, am, native.Decimator(hp), 5, 0.02, 100)
+    # a caller that declares q / fs disposable (the solver class: its init_state stays intact) gets everything ELSE back -- the problem's
+    # flags and solution, the instance mask -- and the messages are its own business
+    state0 = [npy(x).copy() for x in (hp.active_variables, hp.active_functions, hp.solution, am)]
+    q2, fs2 = q.clone(), fs.clone()
+    with pytest.raises(native.SpeculationFailed):
+        hp.sp_solve(q2, fs2, am, native.Decimator(hp), 5, 0.02, 100, inputs_disposable=True)
+    for a0, x in zip(state0, (hp.active_variables, hp.active_functions, hp.solution, am)):
+        np.testing.assert_array_equal(npy(x), a0)
     # every array is back at its call-entry state; with the lock-step launch (the default for small batches) the same call succeeds
     # and equals the oracle's strict semantics
     monkeypatch.delenv('PDP_SOLVE_NO_LOCKSTEP')
