@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #define ST(s) ((hipStream_t)(s))
+#define PDP_RETRY_WITH_FORCE (-77)      // internal: sp_solve_resident -> sp_solve_speculative (never leaves the library)
 
 // instance view used by the solver: same field names as Inst, index type templated (u16 in LDS, i32 in HBM)
 template <class IT>
@@ -110,7 +111,9 @@ struct SolveCall {
     uint32_t stop;              // every instance went inactive (solver.py:383): the remaining launches return immediately
     uint32_t fail;              // a cross-instance coupling became active: the caller must rerun step-wise
     uint32_t total_iters;
-    uint32_t pad[4];
+    uint32_t force_seen;        // k_solve_import found a non-zero external force while the call runs the force-free instantiation: every
+                                // solver launch returns at once, nothing is modified, the host reruns the call with the force column
+    uint32_t pad[3];
 };
 
 // Private instance records of the LDS-resident solver.  Between two launches of a call an instance lives in HBM as the
@@ -1287,6 +1290,7 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
         index = __builtin_amdgcn_readfirstlane(sp.fit_list[index]);
     }
     if (REPLAY && (!ctl->do_replay || (uint32_t)index >= ctl->replay_count)) return;
+    if (!FORCE && sp.call->force_seen) return;              // the caller's force column is not all zeros: this instantiation must not run (the host reruns)
     const Inst G = load_inst(pv_, REPLAY ? __builtin_amdgcn_readfirstlane(sp.inst_list[index]) : index);
     __shared__ int s_inst;                                  // listed instance id, parked for the final writes (a scalar register less across the loop)
     if ((LISTED || REPLAY) && tid == 0) s_inst = G.b;
@@ -1822,7 +1826,8 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
 // canonical arrays -> static + first dynamic record (once per call; the static part once per problem)
 __global__ void __launch_bounds__(256) k_solve_import(PView pv, const float *q, const float *fs, const uint8_t *amask, const float *prev, const float *counters,
                                                       int has_prev, int build_static, char *stat, char *dyn, const int64_t *stat_off, const int64_t *dyn_off, float *prev_slots,
-                                                      const int32_t *list, int stage_cap /* slots per column of the LDS staging area */)
+                                                      const int32_t *list, int stage_cap /* slots per column of the LDS staging area */,
+                                                      SolveCall *force_check /* non-NULL: raise force_seen when fs[:, 1] holds anything but zeros */)
 {
     const Inst G = load_inst(pv, list ? list[blockIdx.x] : (int)blockIdx.x);
     const int n = G.n, m = G.m, ne = G.e, tid = threadIdx.x, nt = blockDim.x;
@@ -1836,6 +1841,12 @@ __global__ void __launch_bounds__(256) k_solve_import(PView pv, const float *q, 
     // wave load.  When the instance's columns fit the staging area they are read in EDGE order (a wave load spans 4-12 lines), parked in
     // LDS and gathered from there; records are written in slot order either way.  (solve call 12.81 -> 12.67 ms on the headline batch.)
     extern __shared__ __attribute__((aligned(16))) float stage[];
+    if (force_check) {
+        // the force column shares its cache lines with the surveys read below: no extra HBM traffic (a NaN counts as a force)
+        int some = 0;
+        for (int e = tid; e < ne; e += nt) some |= (sfs[2 * e + 1] != 0.0f) ? 1 : 0;
+        if (__syncthreads_or(some) && tid == 0) atomicOr(&force_check->force_seen, 1u);
+    }
     if (ne <= stage_cap) {
         float *sQ = stage, *sE = stage + stage_cap, *sM = stage + 2 * stage_cap, *sP = stage + 4 * stage_cap;
         int *sF = reinterpret_cast<int *>(stage + 3 * stage_cap);
@@ -1970,12 +1981,6 @@ __global__ void __launch_bounds__(256) k_big_state(PView pv, const int32_t *list
     if (tid == 0) { dst.sat[G.b] = src.sat[G.b]; dst.cnt[G.b] = src.cnt[G.b]; dst.amask[G.b] = src.amask[G.b]; }
 }
 
-__global__ void k_any_force(const float *fs, int64_t E, uint32_t *flag)
-{
-    int any = 0;
-    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) any |= (fs[2 * e + 1] != 0.0f) ? 1 : 0;
-    if (__syncthreads_or(any) && threadIdx.x == 0) atomicOr(flag, 1u);
-}
 
 // After a call of the LDS-resident loop: the instances that left inactive with iterations still to come (ghost_flag) are looked at in the
 // state they wrote back to the caller's arrays -- d_ghost_bad on the HBM-resident view.  A hit fails the call (the host restores the state).
@@ -2277,7 +2282,7 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     if (stage_bytes > 64 * 1024) PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_solve_import, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes));
     hipLaunchKernelGGL(k_solve_import, dim3(nfit), dim3(256), stage_bytes, st, make_view(p), (const float *)a->q, (const float *)a->fs, (const uint8_t *)a->active_mask,
                        (const float *)a->decimator->prev, (const float *)a->decimator->counters, a->decimator->has_prev, p->res_static_built ? 0 : 1,
-                       p->res_stat, p->res_dyn[0], stat_off, dyn_off, p->res_prev_slots, fit_list, stage_cap);
+                       p->res_stat, p->res_dyn[0], stat_off, dyn_off, p->res_prev_slots, fit_list, stage_cap, (force || rf) ? (SolveCall *)nullptr : call);
     PDP_LAUNCH_CHECK();
     p->res_static_built = 1;
 
@@ -2421,6 +2426,13 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     }
     a->kernel_launches_host = launches; a->replay_launches_host = replays;
     a->solve_kernel_ms_host = solve_ms; a->replay_kernel_ms_host = replay_ms;
+    if (!force && !rf && hcall->force_seen) {
+        // the force-free instantiation met a force column: its launches returned at once; what the big instances' kernel did in place is undone
+        status = snapshot_copy(p, a, snap0, false, st, snap_skip);
+        if (status == PDP_OK) status = hipStreamSynchronize(st) == hipSuccess ? PDP_OK : PDP_ERR_HIP;
+        a->decimator->has_prev = had_prev0; p->has_edge_mask = had_emask0;
+        return status == PDP_OK ? PDP_RETRY_WITH_FORCE : status;
+    }
     if (hcall->fail) {
         // leave the caller's state exactly as it was at call entry so that it can rerun the batch step-wise
         status = snapshot_copy(p, a, snap0, false, st, snap_skip);
@@ -2550,15 +2562,13 @@ static int sp_solve_speculative(pdp_problem *p, pdp_solve_args *a, void *stream)
     int C = 12;
     if (const char *env = getenv("PDP_SOLVE_CHUNK")) { const int v = atoi(env); if (v > 0) C = v; }
     if (C > T) C = T;
-    {
-        // does the external-force column hold anything but zeros?  (it does not for the p-d-p solver)
-        PDP_HIP_CHECK(hipMemsetAsync(p->flags + FL_N_SEL, 0, sizeof(uint32_t), st));
-        hipLaunchKernelGGL(k_any_force, dim3(1024), dim3(256), 0, st, a->fs, (int64_t)E, p->flags + FL_N_SEL);
-        uint32_t force_flag = 0;
-        PDP_HIP_CHECK(hipMemcpyAsync(&force_flag, p->flags + FL_N_SEL, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        PDP_HIP_CHECK(hipStreamSynchronize(st));
-        const bool force_r = force_flag != 0 || rf_model;
-        { int st_ = resident_prepare(p); if (st_ != PDP_OK) return st_; }
+    { int st_ = resident_prepare(p); if (st_ != PDP_OK) return st_; }
+    // Does the external-force column hold anything but zeros?  It does not for the p-d-p solver, so the call does not stop to find out: the
+    // force-free instantiation is enqueued, k_solve_import -- which reads those cache lines anyway -- raises a flag if it meets a force, every
+    // solver launch then returns before it touches anything, and the call runs once more with the force column (an extra 0.3 ms for the rare
+    // caller with an external force, instead of a scan kernel and a host round trip in every call).
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const bool force_r = attempt == 1 || rf_model;
         // per-instance routing: the instances whose image fits run LDS-resident, the others on the HBM-resident kernel in the same chunk
         // loop; the launch is sized by the largest FITTING instance (Reinforce: the force is a 2-bit code in the slot word, no column)
         const int fn_ = p->res_fit_n, fm_ = p->res_fit_m, fe_ = p->res_fit_e;
@@ -2569,9 +2579,12 @@ static int sp_solve_speculative(pdp_problem *p, pdp_solve_args *a, void *stream)
         // threads per instance: 256 for tiny instances, 512 while two workgroups share a CU, 1024 when the instance's LDS image allows
         // only one workgroup per CU (the same 16 waves per CU either way)
         const int nt_r = fe_ <= 1024 ? 256 : (lds_r > 80 * 1024 ? 1024 : 512);
-        if (fits_r) { a->hbm_instances_host = p->res_nbig; return sp_solve_resident(p, a, st, force_r, lds_r, nt_r, C); }
-        a->hbm_instances_host = p->B;
+        if (!fits_r) break;
+        a->hbm_instances_host = p->res_nbig;
+        const int rc = sp_solve_resident(p, a, st, force_r, lds_r, nt_r, C);
+        if (rc != PDP_RETRY_WITH_FORCE) return rc;
     }
+    a->hbm_instances_host = p->B;
     // ---- instances too large for the LDS: HBM-resident kernel, host-driven chunk loop -----------------------------------
 
     // one allocation: speculation record [2C] + control words + per-instance records + two snapshots (call entry, chunk entry)

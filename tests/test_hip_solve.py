@@ -52,6 +52,53 @@ def test_persistent_solve_matches_oracle_loop(oracle, spec, T, tol, t_max):
     np.testing.assert_array_equal(npy(fs), res['fs'])
 
 
+@pytest.mark.parametrize('spec,T,tol,t_max', [SPECS[0], SPECS[3]])
+def test_persistent_solve_with_an_external_force_column(oracle, spec, T, tol, t_max):
+    """The SP triple with pi > 0 and a caller-supplied external force in fs[:, 1] (pdp_propagate.py:197,201; SurveyScorer pi terms): the call
+    first enqueues the force-free instantiation, k_solve_import meets the force, every launch returns untouched and the call runs again on
+    k_sp_solve_lds<true, false, false, *> with the force column -- against the oracle's loop built from its step-wise operators (the
+    statements of solver.py:355-386), bit for bit."""
+    from pdp import native
+    pi = 0.1
+    b = random_batch(**spec)
+    hp, op = make_pair(oracle, b)
+    hp.simplify(); op.simplify()
+    E, B = op.E, op.B
+    rng = np.random.RandomState(3)
+    q = np.full((E, 3), 1.0 / 3.0, np.float32)
+    fs = np.zeros((E, 2), np.float32); fs[:, 0] = 0.5
+    fs[:, 1] = rng.choice([-1.0, 0.0, 1.0], size=E).astype(np.float32)
+    hq, hfs = t(q), t(fs)
+    ham = torch.ones(B, dtype=torch.uint8, device='cuda:0')
+    iters, used_lds = hp.sp_solve(hq, hfs, ham, native.Decimator(hp), T, tol, t_max, pi=pi)
+    assert used_lds and native.kernel_name('sp_solve').startswith('k_sp_solve_lds<true, false, false')
+    # the oracle's loop
+    oam = np.ones(B, np.uint8)
+    od = op.new_decimator()
+    use_mask, it = False, 0
+    for _ in range(T):
+        em = op.refresh_edge_mask()[0] if use_mask else None
+        q, fs = op.sp_propagate(q, fs, em, oam, q, fs, pi)
+        oam, _n = op.sequential_decimate(od, fs, oam, tol, t_max, pi)
+        _, s_ = op.refresh_edge_mask()
+        if s_ < E:
+            use_mask = True
+        pred = op.update_solution(op.state()[2])
+        oam = op.check_termination(oam, pred)
+        it += 1
+        if int(oam.sum()) <= 0:
+            break
+    op.free_decimator(od)
+    assert iters == it
+    np.testing.assert_array_equal(npy(ham), oam)
+    assert_state = op.state()
+    np.testing.assert_array_equal(npy(hp.active_variables)[:, 0], assert_state[0])
+    np.testing.assert_array_equal(npy(hp.solution), assert_state[2])
+    np.testing.assert_array_equal(npy(hq), q)
+    np.testing.assert_array_equal(npy(hfs), fs)
+    assert (assert_state[0] == 0).sum() > (np.asarray(b['batch_variable_map']).size // 50)        # decimations happened
+
+
 def test_persistent_solve_golden_trace():
     """Against the reference itself (golden trace): identical integer trajectory end state."""
     from pdp import native
