@@ -546,35 +546,23 @@ def bench_neural(args, dev, rank, world):
         dist.destroy_process_group()
 
 
-def secondary_measurements(args, dev, b, prob, native):
+def secondary_measurements(args, dev, b, prob, native, items):
     """Outside the headline's timed loop (rank 0, N = 1): the other hot kernels on the same resident batch, each with the numbers its
     roofline fraction is computed from -- configs[2]'s neural iteration (3 sweeps), 1 000 Walk-SAT steps, the Reinforce solver's forward."""
     import torch
     E, V, F, B = prob.E, prob.V, prob.F, prob.B
     out = {}
-    # ---- neural: np-nd-np hidden 128, T = 3 on the same graph -------------------------------------------------------------------------
+    # ---- neural: np-nd-np hidden 128, T = 3 on the same instances (configs[2]) --------------------------------------------------------------
     try:
         T = args.secondary_neural_iters
-        saved_hidden = args.hidden
-        tr, model = make_neural_model(args, T)
-        neural_step(tr, model, b, T)                                 # warm-up (workspaces, caching allocator)
-        torch.cuda.synchronize()
-        native.kernel_timing(True)
-        t0 = time.perf_counter()
-        it = neural_step(tr, model, b, T)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        timing = native.kernel_timing_read(); native.kernel_timing(False)
-        flops_iter = neural_flop_per_iteration('np-nd-np', saved_hidden, E, V)
-        tf = flops_iter * it / dt / 1e12
-        out['neural'] = dict(workload="configs[2]: 'np-nd-np' hidden_dim=%d on the same batch, T=%d, seeded random-init weights" % (saved_hidden, T),
-                             iterations=it, seconds=dt, iterations_per_sec=it / dt, flop_per_iteration=flops_iter,
-                             roofline=dict(bound='mfma', achieved=tf, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s', frac=tf / MFMA_F32_PEAK_TFLOPS),
-                             kernels=neural_kernel_rooflines(native, timing, E, V, saved_hidden),
-                             note='per-kernel ms: HIP events recorded by the library on the launch stream around every launch (pdp_kernel_timing); '
-                                  'flop per launch = MACs of that kernel (SURVEY.md 8(d)) x 2; peak = fp32-input MFMA')
-        del tr, model
-        torch.cuda.empty_cache()
+        out['neural'] = neural_shard(args, dev, native, items, 'np-nd-np', args.hidden, T,
+                                     workload="configs[2]: 'np-nd-np' hidden_dim=%d on the headline batch's instances, T=%d, seeded random-init weights"
+                                              % (args.hidden, T))
+        out['neural']['iterations'] = sum(out['neural']['iterations_per_segment'])
+        out['neural']['iterations_per_sec'] = out['neural']['segment_iterations_per_sec']
+        out['neural']['flop_per_iteration'] = out['neural']['flop_per_iteration_mean']
+        out['neural']['note'] = ('per-kernel ms: HIP events recorded by the library on the launch stream around every launch (pdp_kernel_timing); '
+                                 'flop per launch = MACs of that kernel (SURVEY.md 8(d)) x 2; peak = fp32-input MFMA; the better of two passes after a warm-up pass')
     except Exception as ex:                                            # a secondary measurement never costs the headline line
         out['neural'] = dict(error=repr(ex))
     # ---- Walk-SAT: 1 000 steps, Philox numbers on the device ----------------------------------------------------------------------------
@@ -928,7 +916,7 @@ def main():
                   'semantics': 'isolated instances' if args.isolated else "reference (batch-wide couplings reproduced)"}
         if world == 1 and not args.no_secondary:
             config['solved'] = solved_fractions(args, dev, b, native, rank)
-            config['secondary'] = secondary_measurements(args, dev, b, prob, native)
+            config['secondary'] = secondary_measurements(args, dev, b, prob, native, items)
             config['secondary'].update(big_instance_measurements(args, dev, items, value, native))
             del prob, b
             torch.cuda.empty_cache()
