@@ -731,6 +731,31 @@ def solved_fractions(args, dev, b, native, rank):
                              unsat_clauses_total=float(unsat.sum().item()), iterations=m.last_run['iterations'], path=m.last_run['path'])
         except Exception as ex:
             out[name] = dict(error=repr(ex))
+    # the fully neural solver with the weights this build trained on the MI355X (models/README.md): the metric's "solved %" for a neural
+    # config that does not run on random weights.  Same batch, T sweeps + the same Walk-SAT budget, Philox numbers.
+    wpath = os.path.join(REPO, 'models', 'demo-np-nd-np-h128.pt')
+    if os.path.exists(wpath):
+        name = 'np-nd-np_trained_weights_T%d_w%d' % (args.iters, args.walksat)
+        try:
+            cfg = dict(model_type='np-nd-np', model_name='bench-trained', verbose=False, local_search_iteration=args.walksat, epsilon=0.5, rng='philox',
+                       random_seed=12345 + rank, hidden_dim=128, edge_feature_dim=1, meta_feature_dim=0, prediction_dim=1, mem_hidden_dim=100,
+                       agg_hidden_dim=100, mem_agg_hidden_dim=50, classifier_dim=50, test_batch_limit=1 << 62, batch_size=args.batch,
+                       test_recurrence_num=args.iters, tolerance=args.tolerance, t_max=args.t_max)
+            tr = SatFactorGraphTrainer(cfg, use_cuda=True, logger=logging.getLogger('bench'))
+            m = tr._model_list[0]
+            m.load_state_dict(torch.load(wpath, map_location=dev), strict=True)
+            with torch.no_grad():
+                st = m.get_init_state(gm, bvm, bfm, ef, None, randomized=False, batch_replication=1)
+                pred, _ = m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None,
+                            is_training=False, iteration_num=args.iters, check_termination=tr._check_recurrence_termination, batch_replication=1)
+                solved, unsat = tr._cnf_evaluator(pred[0], gm, bvm, bfm, ef, None, sat_problem=m._last_problem)
+            out[name] = dict(solved=int(solved.sum().item()), instances=int(solved.numel()), solved_fraction=float(solved.mean().item()),
+                             unsat_clauses_total=float(unsat.sum().item()), iterations=m.last_run['iterations'], path=m.last_run['path'],
+                             weights='models/demo-np-nd-np-h128.pt (trained by tools/train_demo.py on n in [10, 40])')
+            del tr, m
+            torch.cuda.empty_cache()
+        except Exception as ex:
+            out[name] = dict(error=repr(ex))
     return out
 
 
