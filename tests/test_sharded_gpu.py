@@ -87,3 +87,20 @@ def test_two_ranks_equal_one_rank_with_dynamic_segments_and_replication(tmp_path
     one, _ = _run(argv, 1, str(tmp_path / 'one.jsonl'), 0)
     two, _ = _run(argv, 2, str(tmp_path / 'two.jsonl'), 29735)
     assert len(one) == len(items) and one == two
+
+
+def test_two_ranks_equal_one_rank_on_a_dimacs_directory(tmp_path):
+    """-d: every rank lists the directory like the converter does, forms the same loader batches from the file list (balanced by file size)
+    and parses only the files of its own batches; the output equals the single-process run's byte for byte"""
+    from pdp import generator
+    ddir = tmp_path / 'cnf'
+    ddir.mkdir()
+    rng = np.random.RandomState(4)
+    for k in range(37):
+        n = int(rng.randint(20, 90)); m = int(rng.uniform(2.5, 4.2) * n)
+        clauses = generator.uniform_ksat(n, m, 3, np.random.RandomState(600 + k))
+        (ddir / ('f%02d_%d.cnf' % (k, k % 2))).write_text('p cnf %d %d\n' % (n, len(clauses)) + ''.join(' '.join(str(x) for x in c) + ' 0\n' for c in clauses))
+    argv = [os.path.join(REPO, 'config', 'Predict', 'PDP-p-d-p-sp-pytorch.yaml'), str(ddir), '40', '-d', '-z', '8', '-s', '9', '-w', '50', '--rng', 'philox']
+    one, _ = _run(argv, 1, str(tmp_path / 'one.jsonl'), 0)
+    two, _ = _run(argv, 2, str(tmp_path / 'two.jsonl'), 29737)
+    assert len(one) == 37 and one == two
