@@ -470,16 +470,65 @@ __device__ __forceinline__ void wave_chains(const float *a /* LDS: row (lane & 3
     }
 }
 
+// A 16-column tail block of a layer for a 32-row wave tile: two 16x16 output blocks (rows 0-15 and 16-31, columns c0 .. c0+15) on
+// v_mfma_f32_16x16x4_f32, which accumulates its four k-steps in ascending order with one rounding each (tools/micro/mfma16_order.hip: 0 of 256
+// elements differ from the fmaf chain), so the block equals the oracle's chain like the 32-wide blocks do.  A 100-wide layer is then three
+// 32-wide blocks + this tail (112 columns) instead of four blocks (128): 66 half-size MFMAs instead of 65 full-size ones and half of the last
+// block's activations.  Operands as in wave_chains: LDS one 8-step chunk ahead, weights (same Wt[Kp][NP] matrix; rows past Kp are clipped to
+// zero by the descriptor) two chunks ahead.  ST = k-steps of four, the LDS rows hold zeros up to column 4 * ST.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int ST, int NP>
+__device__ __forceinline__ void wave_tail16(const float *X /* LDS tile, row stride ld */, int ld, __amdgpu_buffer_rsrc_t wr, int c0,
+                                            const float *__restrict__ bias, f32x4 (&acc)[2])
+{
+    constexpr int CH = 8, NC = (ST + CH - 1) / CH;
+    const int l = threadIdx.x & 63, j = l & 15, kq = l >> 4;
+    const float b0 = bias ? bias[c0 + j] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { acc[0][r] = b0; acc[1][r] = b0; }
+    const float *a0 = X + j * ld + kq, *a1 = X + (16 + j) * ld + kq;
+    const int voff = (kq * NP + c0 + j) * (int)sizeof(float);
+    auto wl = [&](int t) -> float { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wr, voff, t * 4 * NP * (int)sizeof(float), 0)); };
+    float aa[2][2][CH], bb[3][CH];
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+        if (q < ST) { bb[0][q] = wl(q); aa[0][0][q] = a0[4 * q]; aa[0][1][q] = a1[4 * q]; }
+        if (CH + q < ST) bb[1][q] = wl(CH + q);
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+            const int t2 = (c + 2) * CH + q, t1 = (c + 1) * CH + q;
+            if (t2 < ST) bb[(c + 2) % 3][q] = wl(t2);
+            if (t1 < ST) { aa[(c + 1) & 1][0][q] = a0[4 * t1]; aa[(c + 1) & 1][1][q] = a1[4 * t1]; }
+        }
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+            const int t = c * CH + q;
+            if (t < ST) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[c & 1][0][q], bb[c % 3][q], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[c & 1][1][q], bb[c % 3][q], acc[1], 0, 0, 0);
+            }
+        }
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // Specialised on the layer shapes (S = k-steps, NB = 32-column blocks); other shapes use the workgroup-tile kernels above.
 // k_agg_pre_wave: the input row is [128 or 150 message floats, edge sign, zero pad]: two or three dwords per lane and row, and the whole next tile is
 // fetched into registers right after the current one has been dropped into LDS, so its HBM latency hides behind both layers.
-template <int S1, int NB1, int S2, int NB2>
+template <int S1, int NB1, int S2, int NB2, bool TAIL16>
 __global__ void __launch_bounds__(NTN) k_agg_pre_wave(int E, const float *__restrict__ state, const float *__restrict__ sign,
                                                       const float *__restrict__ emask, AggW w, float *__restrict__ h2out, int ntiles)
 {
     constexpr int SD = 2 * S1 - 2, CG = (SD + 63) / 64;    // message width (input row = SD floats + sign + pad), 64-column groups of a row
     static_assert(CG <= 3, "input rows of at most 192 floats");
-    constexpr int ld = (2 * S1 > 32 * NB1 ? 2 * S1 : 32 * NB1) | 1;
+    constexpr int ST = (2 * S1 + 3) / 4;                   // TAIL16: k-steps of four of the first layer's tail block (the row is zero up to 4 ST)
+    constexpr int KW = TAIL16 ? 4 * ST : 2 * S1;
+    constexpr int ld = (KW > 32 * NB1 ? KW : 32 * NB1) | 1;
+    constexpr int NBF = TAIL16 ? NB1 - 1 : NB1;            // full 32-column blocks of the first layer
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, i = l & 31, kh = l >> 5;
     float *X = sm + wave * WT * ld;                        // this wave's region: input block, then the hidden layer
@@ -517,9 +566,15 @@ __global__ void __launch_bounds__(NTN) k_agg_pre_wave(int E, const float *__rest
 #pragma unroll
             for (int j = 0; j < CG; ++j)
                 if (64 * j + l < SD) X[r * ld + 64 * j + l] = pv[r][j];
-        if (l < WT) { X[l * ld + SD] = psg; X[l * ld + SD + 1] = 0.0f; }
-        f32x16 acc[NB1];
-        wave_chains<S1, NB1, 32 * NB1>(X + i * ld + kh, w1, w.b1m, acc);
+        if (l < WT) {
+            X[l * ld + SD] = psg;
+#pragma unroll
+            for (int c = SD + 1; c < KW; ++c) X[l * ld + c] = 0.0f;       // zero pad up to the k range the chains read
+        }
+        f32x16 acc[NBF];
+        wave_chains<S1, NBF, 32 * NB1>(X + i * ld + kh, w1, w.b1m, acc);
+        f32x4 tl[2];
+        if constexpr (TAIL16) wave_tail16<ST, 32 * NB1>(X, ld, w1, 32 * NBF, w.b1m, tl);
         // HBM requests go out here, in front of the long activation phase: vector-memory results return in issue order, so a weight load of
         // the next chain issued behind them would otherwise wait for a full HBM round trip
         if (tile + stride < ntiles) fetch(tile + stride);
@@ -531,10 +586,19 @@ __global__ void __launch_bounds__(NTN) k_agg_pre_wave(int E, const float *__rest
         }
         // every chain has consumed its operands (LDS operations of a wave complete in order): the hidden layer replaces the input block
 #pragma unroll
-        for (int nb = 0; nb < NB1; ++nb) {
+        for (int nb = 0; nb < NBF; ++nb) {
             const int col = 32 * nb + i;
 #pragma unroll
             for (int r = 0; r < 16; ++r) X[acc_row(r, l) * ld + col] = logsigmoid_or_zero(acc[nb][r], col < w.m1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (TAIL16) {
+            // C layout of the 16x16 block: register r of lane l holds row 4 (l / 16) + r, column l % 16
+            const int col = 32 * NBF + (l & 15);
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) X[(16 * hb + 4 * (l >> 4) + r) * ld + col] = logsigmoid_or_zero(tl[hb][r], col < w.m1);
             __builtin_amdgcn_sched_barrier(0);
         }
         f32x16 ac2[NB2];
@@ -1320,15 +1384,22 @@ static int launch_agg_pre(int E, const float *state, const float *sign, const fl
     const bool shape128 = w.din - 1 == 128 && w.Kp1 == 130, shape150 = w.din - 1 == 150 && w.Kp1 == 152;
     if (!generic_forced() && (shape128 || shape150) && w.Np1 == 128 && w.Kp2 == 100 && w.Np2 == 64) {
         // hidden 128 (BASELINE configs) or 150 (the reference's shipped predict config) with the 100 / 50 inner widths
-        const int ldw = shape128 ? 131 : 153;
+        // the first layer is 100 wide: three 32-column blocks + a 16-column tail (112 columns) instead of four blocks; PDP_NEURAL_NO_TAIL16
+        // keeps the four-block form (A/B runs)
+        const bool tail16 = w.m1 <= 112 && getenv("PDP_NEURAL_NO_TAIL16") == nullptr;
+        const int ldw = shape128 ? (tail16 ? 133 : 131) : 153;
         const size_t ldsw = sizeof(float) * (size_t)NWAVES * WT * ldw;
-        const void *fn = shape128 ? (const void *)k_agg_pre_wave<65, 4, 50, 2> : (const void *)k_agg_pre_wave<76, 4, 50, 2>;
+        const void *fn = shape128 ? (tail16 ? (const void *)k_agg_pre_wave<65, 4, 50, 2, true> : (const void *)k_agg_pre_wave<65, 4, 50, 2, false>)
+                                  : (tail16 ? (const void *)k_agg_pre_wave<76, 4, 50, 2, true> : (const void *)k_agg_pre_wave<76, 4, 50, 2, false>);
         int s = set_lds(fn, ldsw); if (s != PDP_OK) return s;
         const int wt = (E + WT - 1) / WT, need = (wt + NWAVES - 1) / NWAVES;
         const int grid = need < persistent_grid() ? need : persistent_grid();
-        pdp_note_kernel(PDP_TK_AGG_PRE, shape128 ? "k_agg_pre_wave<65, 4, 50, 2>" : "k_agg_pre_wave<76, 4, 50, 2>");
-        if (shape128) hipLaunchKernelGGL((k_agg_pre_wave<65, 4, 50, 2>), dim3(grid), dim3(NTN), ldsw, st, E, state, sign, edge_mask, w, h2, wt);
-        else hipLaunchKernelGGL((k_agg_pre_wave<76, 4, 50, 2>), dim3(grid), dim3(NTN), ldsw, st, E, state, sign, edge_mask, w, h2, wt);
+        pdp_note_kernel(PDP_TK_AGG_PRE, shape128 ? (tail16 ? "k_agg_pre_wave<65, 4, 50, 2, true>" : "k_agg_pre_wave<65, 4, 50, 2, false>")
+                                                 : (tail16 ? "k_agg_pre_wave<76, 4, 50, 2, true>" : "k_agg_pre_wave<76, 4, 50, 2, false>"));
+        if (shape128 && tail16) hipLaunchKernelGGL((k_agg_pre_wave<65, 4, 50, 2, true>), dim3(grid), dim3(NTN), ldsw, st, E, state, sign, edge_mask, w, h2, wt);
+        else if (shape128) hipLaunchKernelGGL((k_agg_pre_wave<65, 4, 50, 2, false>), dim3(grid), dim3(NTN), ldsw, st, E, state, sign, edge_mask, w, h2, wt);
+        else if (tail16) hipLaunchKernelGGL((k_agg_pre_wave<76, 4, 50, 2, true>), dim3(grid), dim3(NTN), ldsw, st, E, state, sign, edge_mask, w, h2, wt);
+        else hipLaunchKernelGGL((k_agg_pre_wave<76, 4, 50, 2, false>), dim3(grid), dim3(NTN), ldsw, st, E, state, sign, edge_mask, w, h2, wt);
     } else if (!generic_forced() && res1 <= LDS_RES_LIMIT && w.Kp1 <= 64 * PRE_C) {
         int s = set_lds((const void *)k_agg_pre_res, res1); if (s != PDP_OK) return s;
         const int grid = tiles < persistent_grid() ? tiles : persistent_grid();

@@ -147,7 +147,9 @@ def test_cli_dimacs_mode_runs(tmp_path):
     ddir = tmp_path / 'cnf'
     shutil.copytree(os.path.join(REPO, 'tests', 'golden', 'dimacs20'), str(ddir))
     out = tmp_path / 'out.jsonl'
-    satyr.main([os.path.join(REPO, 'config', 'Predict', 'PDP-p-d-p-walksat-pytorch.yaml'), str(ddir), '30', '-d',
+    # (the rows follow os.listdir order like the converter, and the Philox numbers are indexed by position in the batch: enough steps that some
+    #  satisfiable instance is solved whatever order this file system lists the directory in)
+    satyr.main([os.path.join(REPO, 'config', 'Predict', 'PDP-p-d-p-walksat-pytorch.yaml'), str(ddir), '400', '-d',
                 '-z', '100', '-s', '1', '--rng', 'philox', '-o', str(out)])
     rows = [json.loads(l) for l in out.read_text().split('\n') if l.strip()]
     assert len(rows) == 20 and not os.path.exists(str(ddir / 'temp_problem_file.json'))
