@@ -227,6 +227,7 @@ struct AggW {      // MessageAggregator
     int m1, a, g, out;            // valid widths
     int Kp1, Np1, Kp2, Np2, Kp3, Np3, Kp4, Np4;
     int fd;        // 1: edge sign appended to the aggregated vector (include_self = False), 0: not
+    int no_tail16; // PDP_NEURAL_NO_TAIL16: every layer in 32-column blocks (A/B runs of the 16-column tail blocks)
 };
 struct GruW {
     const float *Wt_ih, *Wt_hh, *b_ih, *b_hh;     // Wt_ih [Kpx][3*Hp], Wt_hh [Kph][3*Hp], biases [3*Hp]
@@ -477,11 +478,11 @@ __device__ __forceinline__ void wave_chains(const float *a /* LDS: row (lane & 3
 // block's activations.  Operands as in wave_chains: LDS one 8-step chunk ahead, weights (same Wt[Kp][NP] matrix; rows past Kp are clipped to
 // zero by the descriptor) two chunks ahead.  ST = k-steps of four, the LDS rows hold zeros up to column 4 * ST.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-template <int ST, int NP>
+template <int ST, int NP, int CH = 8>
 __device__ __forceinline__ void wave_tail16(const float *X /* LDS tile, row stride ld */, int ld, __amdgpu_buffer_rsrc_t wr, int c0,
                                             const float *__restrict__ bias, f32x4 (&acc)[2])
 {
-    constexpr int CH = 8, NC = (ST + CH - 1) / CH;
+    constexpr int NC = (ST + CH - 1) / CH;
     const int l = threadIdx.x & 63, j = l & 15, kq = l >> 4;
     const float b0 = bias ? bias[c0 + j] : 0.0f;
 #pragma unroll
@@ -657,7 +658,20 @@ __global__ void __launch_bounds__(NTN, 6) k_agg_post_pf(int E, const float *__re
     const int nb = wave >> 1, mb = wave & 1, col = 32 * nb + i;
     const __amdgpu_buffer_rsrc_t w3 = __builtin_amdgcn_make_buffer_rsrc((void *)(w.Wt1a + 32 * nb), 0, (2 * S3 * 32 * NB3 - 32 * nb) * (int)sizeof(float), 0x00020000);
     __syncthreads();
-    {
+    // hidden layer g wide (100): the waves of the last column block take a 16-column tail (columns 96 .. 111) when that covers the layer --
+    // half the MFMA cycles and activations of a full block; they still wait at the barrier, but the two other workgroups of the CU get the
+    // issue slots (the output layer reads columns < g only)
+    const bool tail16 = nb == NB3 - 1 && w.g <= 32 * (NB3 - 1) + 16 && (2 * S3) % 4 == 0 && !w.no_tail16;
+    if (__builtin_amdgcn_readfirstlane(tail16 ? 1 : 0)) {
+        const __amdgpu_buffer_rsrc_t w3t = __builtin_amdgcn_make_buffer_rsrc((void *)w.Wt1a, 0, 2 * S3 * 32 * NB3 * (int)sizeof(float), 0x00020000);
+        f32x4 tl[2];
+        wave_tail16<(2 * S3) / 4, 32 * NB3, 4>(Rt + 32 * mb * ld0, ld0, w3t, 32 * (NB3 - 1), w.b1a, tl);      // (short chunks: this kernel lives in 80 registers)
+        const int colt = 32 * (NB3 - 1) + (l & 15);
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) G1[(32 * mb + 16 * hb + 4 * (l >> 4) + r) * ld1 + colt] = logsigmoid_or_zero(tl[hb][r], colt < w.g);
+    } else {
         f32x16 acc[1];
         wave_chains<S3, 1, 32 * NB3>(Rt + (32 * mb + i) * ld0 + kh, w3, w.b1a + 32 * nb, acc);
 #pragma unroll
@@ -1352,6 +1366,7 @@ static AggW make_agg(const pdp_agg_desc *d)
     w.Kp2 = even_up(d->m1); w.Np2 = pad32(d->a);
     w.Kp3 = even_up(d->a + d->fd); w.Np3 = pad32(d->g);
     w.Kp4 = even_up(d->g); w.Np4 = pad32(d->out);
+    w.no_tail16 = getenv("PDP_NEURAL_NO_TAIL16") != nullptr ? 1 : 0;
     return w;
 }
 
@@ -1386,7 +1401,7 @@ static int launch_agg_pre(int E, const float *state, const float *sign, const fl
         // hidden 128 (BASELINE configs) or 150 (the reference's shipped predict config) with the 100 / 50 inner widths
         // the first layer is 100 wide: three 32-column blocks + a 16-column tail (112 columns) instead of four blocks; PDP_NEURAL_NO_TAIL16
         // keeps the four-block form (A/B runs)
-        const bool tail16 = w.m1 <= 112 && getenv("PDP_NEURAL_NO_TAIL16") == nullptr;
+        const bool tail16 = w.m1 <= 112 && !w.no_tail16;
         const int ldw = shape128 ? (tail16 ? 133 : 131) : 153;
         const size_t ldsw = sizeof(float) * (size_t)NWAVES * WT * ldw;
         const void *fn = shape128 ? (tail16 ? (const void *)k_agg_pre_wave<65, 4, 50, 2, true> : (const void *)k_agg_pre_wave<65, 4, 50, 2, false>)
