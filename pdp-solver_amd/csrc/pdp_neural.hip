@@ -777,7 +777,7 @@ struct WaveChains {
 
 // Four waves per workgroup, one per SIMD (512 registers per lane): separate input / hidden regions, everything of the next tile requested a phase ahead.
 #define PW_NW 4
-template <int S3, int NB3, int S4, int NB4>
+template <int S3, int NB3, int S4, int NB4, bool TAIL16>
 __global__ void __launch_bounds__(64 * PW_NW) k_agg_post_wave(int E, const float *__restrict__ agg, int agg_rows, const int32_t *__restrict__ edge_row,
                                                        const float *__restrict__ h2, const float *__restrict__ sign,
                                                        const float *__restrict__ emask, const float *__restrict__ rowmask,
@@ -790,7 +790,9 @@ __global__ void __launch_bounds__(64 * PW_NW) k_agg_post_wave(int E, const float
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, i = l & 31, kh = l >> 5;
     float *Rt = sm + wave * WR, *G1 = Rt + WT * ld0, *Mk = G1 + WT * ld1;
     const int A = w.a, ROWA = A * (int)sizeof(float), ROWB = w.out * (int)sizeof(float);
-    WaveChains<S3, NB3, 32 * NB3> c3;
+    constexpr int NBF = TAIL16 ? NB3 - 1 : NB3;           // full 32-column blocks of the hidden layer (TAIL16: + a 16-column tail, see wave_tail16)
+    static_assert(!TAIL16 || (2 * S3) % 4 == 0, "the tail walks the input row in k-steps of four");
+    WaveChains<S3, NBF, 32 * NB3> c3;
     WaveChains<S4, NB4, 32 * NB4> c4;
     c3.wr = __builtin_amdgcn_make_buffer_rsrc((void *)w.Wt1a, 0, 2 * S3 * 32 * NB3 * (int)sizeof(float), 0x00020000);
     c4.wr = __builtin_amdgcn_make_buffer_rsrc((void *)w.Wt2a, 0, 2 * S4 * 32 * NB4 * (int)sizeof(float), 0x00020000);
@@ -842,8 +844,10 @@ __global__ void __launch_bounds__(64 * PW_NW) k_agg_post_wave(int E, const float
     for (; tile < ntiles; tile += stride) {
         const int e0 = tile * WT;
         c3.head_a();
-        f32x16 acc3[NB3];
+        f32x16 acc3[NBF];
         c3.run(w.b1a, acc3);
+        f32x4 tl3[2];
+        if constexpr (TAIL16) wave_tail16<(2 * S3) / 4, 32 * NB3>(Rt, ld0, c3.wr, 32 * NBF, w.b1a, tl3);
         // in front of the hidden layer's activations: the first weights of the output layer, then everything that comes from HBM
         c4.head_w();
         const __amdgpu_buffer_rsrc_t pb = tile_rsrc(old, e0, ROWB), ob = tile_rsrc(out, e0, ROWB);
@@ -859,10 +863,18 @@ __global__ void __launch_bounds__(64 * PW_NW) k_agg_post_wave(int E, const float
         const bool more = tile + stride < ntiles;
         if (more) { fetch_rows(tile + stride); if (tile + 2 * stride < ntiles) fetch_ids(tile + 2 * stride); }
 #pragma unroll
-        for (int nb = 0; nb < NB3; ++nb) {
+        for (int nb = 0; nb < NBF; ++nb) {
             const int col = 32 * nb + i;
 #pragma unroll
             for (int r = 0; r < 16; ++r) G1[acc_row(r, l) * ld1 + col] = logsigmoid_or_zero(acc3[nb][r], col < w.g);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (TAIL16) {
+            const int colt = 32 * NBF + (l & 15);
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) G1[(16 * hb + 4 * (l >> 4) + r) * ld1 + colt] = logsigmoid_or_zero(tl3[hb][r], colt < w.g);
             __builtin_amdgcn_sched_barrier(0);
         }
         c4.head_a();
@@ -1464,9 +1476,11 @@ extern "C" int pdp_neural_aggregate_edges(pdp_problem *p, const pdp_agg_desc *d,
         const int wgs = (full + PW_NW - 1) / PW_NW;
         const int grid = wgs < persistent_grid() ? wgs : persistent_grid();
         const size_t o = (size_t)full * WT;
-        s = set_lds((const void *)k_agg_post_wave<26, 4, 50, 5>, ldsw); if (s != PDP_OK) return s;
-        pdp_note_kernel(PDP_TK_AGG_POST, "k_agg_post_wave<26, 4, 50, 5>");
-        hipLaunchKernelGGL((k_agg_post_wave<26, 4, 50, 5>), dim3(grid), dim3(64 * PW_NW), ldsw, st, E, agg, R, edge_row, h2, p->edge_sign, edge_mask, rowmask, old, w, out, full);
+        const bool tail16 = w.g <= 112 && !w.no_tail16;
+        s = set_lds(tail16 ? (const void *)k_agg_post_wave<26, 4, 50, 5, true> : (const void *)k_agg_post_wave<26, 4, 50, 5, false>, ldsw); if (s != PDP_OK) return s;
+        pdp_note_kernel(PDP_TK_AGG_POST, tail16 ? "k_agg_post_wave<26, 4, 50, 5, true>" : "k_agg_post_wave<26, 4, 50, 5, false>");
+        if (tail16) hipLaunchKernelGGL((k_agg_post_wave<26, 4, 50, 5, true>), dim3(grid), dim3(64 * PW_NW), ldsw, st, E, agg, R, edge_row, h2, p->edge_sign, edge_mask, rowmask, old, w, out, full);
+        else hipLaunchKernelGGL((k_agg_post_wave<26, 4, 50, 5, false>), dim3(grid), dim3(64 * PW_NW), ldsw, st, E, agg, R, edge_row, h2, p->edge_sign, edge_mask, rowmask, old, w, out, full);
         if (tail > 0) {
             s = set_lds((const void *)k_agg_post_pf<26, 4, 50, 5>, ldsp); if (s != PDP_OK) return s;
             hipLaunchKernelGGL((k_agg_post_pf<26, 4, 50, 5>), dim3(1), dim3(NTN), ldsp, st, tail, agg, edge_row + o, h2 + o * w.a, p->edge_sign + o,
