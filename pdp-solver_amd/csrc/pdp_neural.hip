@@ -50,6 +50,63 @@ __device__ __forceinline__ float logsigmoid_or_zero(float x, bool live)
     return live ? v : 0.0f;
 }
 
+// Two activations side by side on the packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): every step is the same IEEE
+// operation per element as pdp_expf_fin_le30 / pdp_logsigmoidf of include/pdp_math.h, so the results are the same bits
+// (tests/test_hip_neural.py compares whole operators with the oracle's scalar forms).  A packed instruction occupies the issue slot of
+// two plain ones on gfx950 (tools/micro/pk_rate.hip), so this is not half the time: what it buys is 35 instead of 54 instructions and
+// fewer live registers per pair, i.e. scheduling freedom -- measured per aggregator call: hidden 150 16.5 -> 15.8 / 17.0 -> 16.4 ms,
+// hidden 128 13.9 -> 13.8 / 14.65 -> 14.5 ms.  The GRU's activation slices stay scalar: packed they were 7 % slower at hidden 128
+// (22.2 -> 23.8 ms; their instruction groups are tuned to the MFMA chunks) and no faster at 150.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+// (the bits of a vector ELEMENT go through a by-value float: __builtin_bit_cast applied to `v.y` itself reads element 0 with this hipcc)
+__device__ __forceinline__ int f2i(float f) { return __builtin_bit_cast(int, f); }
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// e^x after the clamp (xc = the clamped argument, x = the argument itself for the NaN / infinity rule of the scalar forms)
+__device__ __forceinline__ f32x2 pk_exp_clamped(f32x2 xc, f32x2 x)
+{
+    const f32x2 t = xc * 1.44269504088896341f;
+    const f32x2 nf = (t + 12582912.0f) - 12582912.0f;
+    f32x2 r = pk_fma(nf, (f32x2)(-0.693359375f), xc);
+    r = pk_fma(nf, (f32x2)(2.12194440e-4f), r);
+    const f32x2 z = r * r;
+    f32x2 p = (f32x2)(1.9875691500e-4f);
+    p = pk_fma(p, r, (f32x2)(1.3981999507e-3f));
+    p = pk_fma(p, r, (f32x2)(8.3334519073e-3f));
+    p = pk_fma(p, r, (f32x2)(4.1665795894e-2f));
+    p = pk_fma(p, r, (f32x2)(1.6666665459e-1f));
+    p = pk_fma(p, r, (f32x2)(5.0000001201e-1f));
+    p = pk_fma(p, z, r);
+    p = p + 1.0f;
+    const f32x2 res = {__builtin_ldexpf(p.x, (int)nf.x), __builtin_ldexpf(p.y, (int)nf.y)};
+    return res + (x - x);                                   // NaN / infinite argument -> NaN, as in the scalar forms
+}
+__device__ __forceinline__ f32x2 pk_expf_fin_le30(f32x2 x)                                  // pdp_expf_fin_le30
+{
+    return pk_exp_clamped((f32x2){pdp_fmaxf(x.x, -104.5f), pdp_fmaxf(x.y, -104.5f)}, x);
+}
+__device__ __forceinline__ f32x2 pk_logsigmoid(f32x2 x)
+{
+    const f32x2 t = pk_expf_fin_le30((f32x2){-pdp_abs(x.x), -pdp_abs(x.y)});
+    f32x2 p = (f32x2)(5.253457930e-03f);
+    p = pk_fma(p, t, (f32x2)(-2.958850749e-02f));
+    p = pk_fma(p, t, (f32x2)(7.836166769e-02f));
+    p = pk_fma(p, t, (f32x2)(-1.367477030e-01f));
+    p = pk_fma(p, t, (f32x2)(1.911143064e-01f));
+    p = pk_fma(p, t, (f32x2)(-2.484436929e-01f));
+    p = pk_fma(p, t, (f32x2)(3.331927061e-01f));
+    p = pk_fma(p, t, (f32x2)(-4.999950230e-01f));
+    p = pk_fma(p, t, (f32x2)(1.0f));
+    const f32x2 mn = {pdp_fminf(x.x, 0.0f), pdp_fminf(x.y, 0.0f)};
+    return mn - p * t;
+}
+__device__ __forceinline__ f32x2 pk_logsigmoid_or_zero(float x0, float x1, bool live)
+{
+    f32x2 v = pk_logsigmoid((f32x2){x0, x1});
+    asm volatile("" : "+v"(v));
+    return live ? v : (f32x2)(0.0f);
+}
+
 // Two 32x32 output blocks (both 32-row halves of the tile, same 32 columns):
 //   acc[mb][r] = bias[col];  acc[mb] += A[32*mb + i][k] * Wt[k][32*nb + j],  k ascending.
 // The B fragment (one float per lane and k-step, a coalesced 128-byte row segment per half-wave) is shared by the two
@@ -590,7 +647,10 @@ __global__ void __launch_bounds__(NTN) k_agg_pre_wave(int E, const float *__rest
         for (int nb = 0; nb < NBF; ++nb) {
             const int col = 32 * nb + i;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) X[acc_row(r, l) * ld + col] = logsigmoid_or_zero(acc[nb][r], col < w.m1);
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 v = pk_logsigmoid_or_zero(acc[nb][r], acc[nb][r + 1], col < w.m1);
+                X[acc_row(r, l) * ld + col] = v.x; X[acc_row(r + 1, l) * ld + col] = v.y;
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (TAIL16) {
@@ -599,7 +659,10 @@ __global__ void __launch_bounds__(NTN) k_agg_pre_wave(int E, const float *__rest
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) X[(16 * hb + 4 * (l >> 4) + r) * ld + col] = logsigmoid_or_zero(tl[hb][r], col < w.m1);
+                for (int r = 0; r < 4; r += 2) {
+                    const f32x2 v = pk_logsigmoid_or_zero(tl[hb][r], tl[hb][r + 1], col < w.m1);
+                    X[(16 * hb + 4 * (l >> 4) + r) * ld + col] = v.x; X[(16 * hb + 4 * (l >> 4) + r + 1) * ld + col] = v.y;
+                }
             __builtin_amdgcn_sched_barrier(0);
         }
         f32x16 ac2[NB2];
@@ -611,10 +674,11 @@ __global__ void __launch_bounds__(NTN) k_agg_pre_wave(int E, const float *__rest
         for (int nb = 0; nb < NB2; ++nb) {
             if (32 * nb + i < w.a) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = pdp_logsigmoidf(ac2[nb][r]);
-                    if (emask) v = v * em[r];
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), hb, lo + nb * 128, ((r & 3) + 8 * (r >> 2)) * rowb, 0);
+                for (int r = 0; r < 16; r += 2) {
+                    f32x2 v = pk_logsigmoid((f32x2){ac2[nb][r], ac2[nb][r + 1]});
+                    if (emask) v = v * (f32x2){em[r], em[r + 1]};
+                    __builtin_amdgcn_raw_buffer_store_b32(f2i(v.x), hb, lo + nb * 128, ((r & 3) + 8 * (r >> 2)) * rowb, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(f2i(v.y), hb, lo + nb * 128, (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * rowb, 0);
                 }
             }
         }
@@ -670,12 +734,18 @@ __global__ void __launch_bounds__(NTN, 6) k_agg_post_pf(int E, const float *__re
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) G1[(32 * mb + 16 * hb + 4 * (l >> 4) + r) * ld1 + colt] = logsigmoid_or_zero(tl[hb][r], colt < w.g);
+            for (int r = 0; r < 4; r += 2) {
+                const f32x2 v = pk_logsigmoid_or_zero(tl[hb][r], tl[hb][r + 1], colt < w.g);
+                G1[(32 * mb + 16 * hb + 4 * (l >> 4) + r) * ld1 + colt] = v.x; G1[(32 * mb + 16 * hb + 4 * (l >> 4) + r + 1) * ld1 + colt] = v.y;
+            }
     } else {
         f32x16 acc[1];
         wave_chains<S3, 1, 32 * NB3>(Rt + (32 * mb + i) * ld0 + kh, w3, w.b1a + 32 * nb, acc);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) G1[(32 * mb + acc_row(r, l)) * ld1 + col] = logsigmoid_or_zero(acc[0][r], col < w.g);
+        for (int r = 0; r < 16; r += 2) {
+            const f32x2 v = pk_logsigmoid_or_zero(acc[0][r], acc[0][r + 1], col < w.g);
+            G1[(32 * mb + acc_row(r, l)) * ld1 + col] = v.x; G1[(32 * mb + acc_row(r + 1, l)) * ld1 + col] = v.y;
+        }
     }
     __syncthreads();
     // blend operands and result through buffer accesses with a per-tile base (lane offset in a VGPR, row offset as a scalar, rows past E
@@ -701,9 +771,11 @@ __global__ void __launch_bounds__(NTN, 6) k_agg_post_pf(int E, const float *__re
             mk[r] = rowmask ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mb_, lm, ((r & 3) + 8 * (r >> 2)) * (int)sizeof(float), 0)) : 1.0f;
         if (live) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float nv = pdp_logsigmoidf(acc[0][r]);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mk[r] * nv + (1.0f - mk[r]) * po[r]), ob, lo, ((r & 3) + 8 * (r >> 2)) * ROWB, 0);
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 nv = pk_logsigmoid((f32x2){acc[0][r], acc[0][r + 1]});
+                const f32x2 m2 = {mk[r], mk[r + 1]}, bl = m2 * nv + (1.0f - m2) * (f32x2){po[r], po[r + 1]};
+                __builtin_amdgcn_raw_buffer_store_b32(f2i(bl.x), ob, lo, ((r & 3) + 8 * (r >> 2)) * ROWB, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(f2i(bl.y), ob, lo, (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * ROWB, 0);
             }
         }
     }
@@ -866,7 +938,10 @@ __global__ void __launch_bounds__(64 * PW_NW) k_agg_post_wave(int E, const float
         for (int nb = 0; nb < NBF; ++nb) {
             const int col = 32 * nb + i;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) G1[acc_row(r, l) * ld1 + col] = logsigmoid_or_zero(acc3[nb][r], col < w.g);
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 v = pk_logsigmoid_or_zero(acc3[nb][r], acc3[nb][r + 1], col < w.g);
+                G1[acc_row(r, l) * ld1 + col] = v.x; G1[acc_row(r + 1, l) * ld1 + col] = v.y;
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (TAIL16) {
@@ -874,7 +949,10 @@ __global__ void __launch_bounds__(64 * PW_NW) k_agg_post_wave(int E, const float
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) G1[(16 * hb + 4 * (l >> 4) + r) * ld1 + colt] = logsigmoid_or_zero(tl3[hb][r], colt < w.g);
+                for (int r = 0; r < 4; r += 2) {
+                    const f32x2 v = pk_logsigmoid_or_zero(tl3[hb][r], tl3[hb][r + 1], colt < w.g);
+                    G1[(16 * hb + 4 * (l >> 4) + r) * ld1 + colt] = v.x; G1[(16 * hb + 4 * (l >> 4) + r + 1) * ld1 + colt] = v.y;
+                }
             __builtin_amdgcn_sched_barrier(0);
         }
         c4.head_a();
@@ -888,9 +966,11 @@ __global__ void __launch_bounds__(64 * PW_NW) k_agg_post_wave(int E, const float
         for (int nb = 0; nb < NB4; ++nb) {
             const int so = (32 * nb + i < w.out) ? lo + nb * 128 : 0x40000000;      // a column past the row is stored nowhere
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float nv = pdp_logsigmoidf(acc4[nb][r]);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mk[r] * nv + (1.0f - mk[r]) * po[nb][r]), ob, so, ((r & 3) + 8 * (r >> 2)) * ROWB, 0);
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 nv = pk_logsigmoid((f32x2){acc4[nb][r], acc4[nb][r + 1]});
+                const f32x2 m2 = {mk[r], mk[r + 1]}, bl = m2 * nv + (1.0f - m2) * (f32x2){po[nb][r], po[nb][r + 1]};
+                __builtin_amdgcn_raw_buffer_store_b32(f2i(bl.x), ob, so, ((r & 3) + 8 * (r >> 2)) * ROWB, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(f2i(bl.y), ob, so, (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * ROWB, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
