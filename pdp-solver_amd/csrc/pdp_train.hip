@@ -47,55 +47,97 @@ __device__ __forceinline__ float tact_grad(float y, int act)
 // ---- generic GEMM on the fp32 matrix cores ---------------------------------------------------------------------------------------------
 // C[M,N] = sum_k A(m,k) B(k,n);  A is stored [M,K] (TA = false, leading dimension lda) or [K,M] (TA = true);  B is stored [K,N]
 // (TB = false) or [N,K] (TB = true).  64 x 64 output tile per 256-thread workgroup, four waves with one 32 x 32 accumulator block each,
-// K in slabs of 16 through LDS.  gridDim.z > 1: split-K, slab range z of the K dimension goes to partial[z] (summed by k_splitk_reduce).
+// K in slabs of 32 through LDS.  gridDim.z > 1: split-K, slab range z of the K dimension goes to partial[z] (summed by k_splitk_reduce).
 // Epilogue (gridDim.z == 1): + bias[n], activation, optional element-wise factor (dropout mask, or the incoming gradient's act').
-#define GB 64
 #define GK 32
-template <bool TA, bool TB>
-__global__ void __launch_bounds__(256) k_gemm(int M, int N, int64_t K, const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb,
+#ifndef GEMM_MINB
+#define GEMM_MINB 6                                        // 80 registers per lane: six workgroups per CU
+#endif
+// One operand tile of a workgroup: BX values of x (rows or columns of the output) by the workgroup's k range, read through a buffer
+// descriptor based at the tile.  The per-thread offset is computed once; a slab and the thread's j-th element of it advance SCALAR offsets;
+// rows past the range are clipped by the descriptor (loads return 0).  KROW: element (x, k) is stored at P[k ld + x] (k is the row), else
+// at P[x ld + k].  (The first form of this kernel recomputed 64-bit addresses and bounds for every element of every slab.)
+template <bool KROW, int BX>
+struct GemmTile {
+    static constexpr int PER = BX * GK / 256;              // elements per thread and slab
+    __amdgpu_buffer_rsrc_t rs;
+    int voff, kk0;
+    __device__ __forceinline__ void init(const float *P, int64_t ld, int x0, int X, int64_t kbase, int64_t kend, int tid)
+    {
+        const int xs = X - x0 < BX ? X - x0 : BX;          // valid values of x in this tile (>= 1)
+        const float *base = KROW ? P + kbase * ld + x0 : P + (int64_t)x0 * ld + kbase;
+        // bytes the tile may touch: k-row layout (kend - kbase) rows of the matrix, the last one up to xs; k-minor layout xs rows, the last
+        // one up to the k range (a row x >= xs starts at xs ld >= (xs - 1) ld + range because range <= K <= ld: clipped)
+        const int64_t floats = KROW ? (kend - kbase - 1) * ld + xs : (int64_t)(xs - 1) * ld + (kend - kbase);
+        rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, kend > kbase ? (int)(floats * (int64_t)sizeof(float)) : 0, 0x00020000);
+        // element j of thread tid: t = tid + 256 j;  k-row: x = t % BX (the same for every j), k = t / BX;  k-minor: k = t % GK (the same), x = t / GK
+        if (KROW) { const int x = tid % BX; kk0 = tid / BX; voff = x < xs ? (int)((kk0 * ld + x) * (int64_t)sizeof(float)) : (int)0x80000000; }     // x past the matrix: 2 GB + (scalar offsets < 2 GB) is past every tile
+        else { kk0 = tid % GK; voff = (int)(((tid / GK) * ld + kk0) * (int64_t)sizeof(float)); }
+    }
+    // slab at krel (relative to kbase); left = valid k values from krel on
+    __device__ __forceinline__ void fetch(float (&r)[PER], int64_t krel, int64_t ld, int64_t left) const
+    {
+        const int so = (int)((KROW ? krel * ld : krel) * (int64_t)sizeof(float));
+        const int step = (int)((KROW ? (256 / BX) * ld : (256 / GK) * ld) * (int64_t)sizeof(float));      // from element j to j + 1
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, so + j * step, 0));
+            r[j] = (KROW || kk0 < left) ? v : 0.0f;        // k past the range: the next row's start in the k-minor layout
+        }
+    }
+};
+
+// A 256-thread workgroup (2 x 2 waves) computes a BM x BN output tile, every wave (BM / 64) x (BN / 64) blocks of 32 x 32 (the host side
+// instantiates 64 x 64 only, see gemm()).
+template <bool TA, bool TB, int BM, int BN>
+__global__ void __launch_bounds__(256, GEMM_MINB) k_gemm(int M, int N, int64_t K, const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb,
                                               float *__restrict__ C, int64_t ldc, const float *__restrict__ bias, int act, float *__restrict__ partial)
 {
-    __shared__ float As[GB][GK + 1];
-    __shared__ float Bs[GK][GB + 1];
-    constexpr int PER = GB * GK / 256;                     // elements of each operand tile per thread and slab
+    constexpr int RM = BM / 64, RN = BN / 64;
+    __shared__ float As[BM][GK + 1];
+    __shared__ float Bs[GK][BN + 1];
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
-    const int m0 = blockIdx.y * GB, n0 = blockIdx.x * GB;
-    const int mb = w & 1, nb = w >> 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int wm = (w & 1) * (BM / 2), wn = (w >> 1) * (BN / 2);      // this wave's corner inside the tile
     const int i = l & 31, kh = l >> 5;
-    f32x16 acc;
+    bool live[RM][RN];                                     // wave-uniform: the block has a row < M and a column < N
+    bool any = false;
+    f32x16 acc[RM][RN];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int bm = 0; bm < RM; ++bm)
+#pragma unroll
+        for (int bn = 0; bn < RN; ++bn) {
+            live[bm][bn] = m0 + wm + 32 * bm < M && n0 + wn + 32 * bn < N;
+            any = any || live[bm][bn];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[bm][bn][r] = 0.0f;
+        }
     const int64_t slabs = (K + GK - 1) / GK;
     const int64_t per = (slabs + gridDim.z - 1) / gridDim.z;
     const int64_t s_begin = per * blockIdx.z, s_end = (s_begin + per < slabs) ? s_begin + per : slabs;
+    const int64_t kbase = s_begin * GK, kend = s_end * GK < K ? s_end * GK : K;
+    GemmTile<TA, BM> ta;
+    GemmTile<!TB, BN> tb;
+    ta.init(A, lda, m0, M, kbase, kend, tid);
+    tb.init(B, ldb, n0, N, kbase, kend, tid);
     // the next slab's operand elements are fetched into registers while the MFMAs of the current one run (the k order of the
-    // accumulation -- one ascending chain per output element -- does not depend on the slab size)
-    float ra[PER], rb[PER];
+    // accumulation -- one ascending chain per output element -- does not depend on the slab or tile size)
+    float ra[GemmTile<TA, BM>::PER], rb[GemmTile<!TB, BN>::PER];
     auto fetch = [&](int64_t sl) {
-        const int64_t k0 = sl * GK;
-#pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            const int t = tid + 256 * j;
-            int r, kk;
-            if (TA) { r = t % GB; kk = t / GB; } else { kk = t % GK; r = t / GK; }          // the fastest index follows the storage order
-            const int m = m0 + r; const int64_t k = k0 + kk;
-            ra[j] = (m < M && k < K) ? (TA ? A[k * lda + m] : A[(int64_t)m * lda + k]) : 0.0f;
-            int c, kb;
-            if (TB) { kb = t % GK; c = t / GK; } else { c = t % GB; kb = t / GB; }
-            const int n = n0 + c; const int64_t k2 = k0 + kb;
-            rb[j] = (n < N && k2 < K) ? (TB ? B[(int64_t)n * ldb + k2] : B[k2 * ldb + n]) : 0.0f;
-        }
+        const int64_t krel = (sl - s_begin) * GK, left = kend - kbase - krel;
+        ta.fetch(ra, krel, lda, left);
+        tb.fetch(rb, krel, ldb, left);
     };
     auto deposit = [&]() {
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
+        for (int j = 0; j < GemmTile<TA, BM>::PER; ++j) {
             const int t = tid + 256 * j;
-            int r, kk;
-            if (TA) { r = t % GB; kk = t / GB; } else { kk = t % GK; r = t / GK; }
-            As[r][kk] = ra[j];
-            int c, kb;
-            if (TB) { kb = t % GK; c = t / GK; } else { c = t % GB; kb = t / GB; }
-            Bs[kb][c] = rb[j];
+            if (TA) As[t % BM][t / BM] = ra[j]; else As[t / GK][t % GK] = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < GemmTile<!TB, BN>::PER; ++j) {
+            const int t = tid + 256 * j;
+            if (TB) Bs[t % GK][t / GK] = rb[j]; else Bs[t / BN][t % BN] = rb[j];
         }
     };
     if (s_begin < s_end) { fetch(s_begin); deposit(); }
@@ -103,35 +145,81 @@ __global__ void __launch_bounds__(256) k_gemm(int M, int N, int64_t K, const flo
     for (int64_t sl = s_begin; sl < s_end; ++sl) {
         const bool more = sl + 1 < s_end;
         if (more) fetch(sl + 1);
+        // blocks outside [M, N] (the 129th column of a [.., 128 + sign] operand opens a block of its own) and k-steps past K (zeros in LDS)
+        // issue nothing: they would only add exact zeros
+        if (any) {
+            const int64_t left = K - sl * GK;
+            const int steps = left >= GK ? GK / 2 : (int)((left + 1) >> 1);
+            auto kstep = [&](int s2) {
+                float av[RM], bv[RN];
 #pragma unroll
-        for (int s = 0; s < GK / 2; ++s)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[32 * mb + i][2 * s + kh], Bs[2 * s + kh][32 * nb + i], acc, 0, 0, 0);
+                for (int bm = 0; bm < RM; ++bm) av[bm] = As[wm + 32 * bm + i][2 * s2 + kh];
+#pragma unroll
+                for (int bn = 0; bn < RN; ++bn) bv[bn] = Bs[2 * s2 + kh][wn + 32 * bn + i];
+#pragma unroll
+                for (int bm = 0; bm < RM; ++bm)
+#pragma unroll
+                    for (int bn = 0; bn < RN; ++bn)
+                        if (live[bm][bn]) acc[bm][bn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[bm], bv[bn], acc[bm][bn], 0, 0, 0);
+            };
+            if (steps == GK / 2) {
+#pragma unroll
+                for (int s2 = 0; s2 < GK / 2; ++s2) kstep(s2);
+            } else {
+                for (int s2 = 0; s2 < steps; ++s2) kstep(s2);
+            }
+        }
         __syncthreads();
         if (more) deposit();
         __syncthreads();
     }
-    const int col = n0 + 32 * nb + i;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = m0 + 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (row < M && col < N) {
-            if (gridDim.z > 1) partial[((int64_t)blockIdx.z * M + row) * N + col] = acc[r];
-            else {
-                float v = acc[r] + (bias ? bias[col] : 0.0f);
-                C[(int64_t)row * ldc + col] = tact(v, act);
+    for (int bm = 0; bm < RM; ++bm)
+#pragma unroll
+        for (int bn = 0; bn < RN; ++bn) {
+            const int col = n0 + wn + 32 * bn + i;
+            if (!live[bm][bn] || col >= N) continue;
+            const float bc = (gridDim.z == 1 && bias) ? bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm + 32 * bm + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (row < M) {
+                    if (gridDim.z > 1) partial[((int64_t)blockIdx.z * M + row) * N + col] = acc[bm][bn][r];
+                    else C[(int64_t)row * ldc + col] = tact(acc[bm][bn][r] + bc, act);
+                }
             }
         }
-    }
 }
 
-__global__ void k_splitk_reduce(int64_t MN, int splits, const float *__restrict__ partial, float *__restrict__ C)
+// C[i] = sum over the slices z of partial[z][i].  A workgroup takes 32 output elements; its 256 threads are 8 groups, group g adds the
+// slices z = g, g + 8, ... in ascending order (four loads in flight), and the eight group sums are folded in a fixed order through LDS: the
+// order of the additions depends on (splits) only.  (One thread per element walking all slices was latency-bound: 0.24 ms for 1 024 slices
+// of a 100 x 129 gradient.)
+#define RED_G 8
+#define RED_E 32
+__global__ void __launch_bounds__(RED_G * RED_E) k_splitk_reduce(int64_t MN, int splits, const float *__restrict__ partial, float *__restrict__ C)
 {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < MN; i += (int64_t)gridDim.x * blockDim.x) {
-        float acc = 0.0f;
-        for (int z = 0; z < splits; ++z) acc = acc + partial[(int64_t)z * MN + i];
+    __shared__ float red[RED_G * RED_E];
+    const int e = threadIdx.x % RED_E, g = threadIdx.x / RED_E;
+    const int64_t i = (int64_t)blockIdx.x * RED_E + e;
+    float acc = 0.0f;
+    if (i < MN) {
+        const float *p = partial + i;
+        int z = g;
+        for (; z + 3 * RED_G < splits; z += 4 * RED_G) {
+            const float a0 = p[(int64_t)z * MN], a1 = p[(int64_t)(z + RED_G) * MN], a2 = p[(int64_t)(z + 2 * RED_G) * MN], a3 = p[(int64_t)(z + 3 * RED_G) * MN];
+            acc = (((acc + a0) + a1) + a2) + a3;
+        }
+        for (; z < splits; z += RED_G) acc = acc + p[(int64_t)z * MN];
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (g == 0 && i < MN) {
+        for (int j = 1; j < RED_G; ++j) acc = acc + red[j * RED_E + e];
         C[i] = acc;
     }
 }
+static int reduce_grid(int64_t MN) { return (int)((MN + RED_E - 1) / RED_E); }
 
 // column sums of Z [R,N] in two deterministic passes: partial[s][n] over a slice of rows, then their sum (k_splitk_reduce).  A workgroup takes a
 // slice; its 256 threads are 256 / C row groups x C columns (C = min(N, 256) per grid column), every thread walks its rows in ascending
@@ -146,7 +234,8 @@ __global__ void __launch_bounds__(256) k_colsum_partial(int64_t R, int N, const 
     const int64_t per = (R + slices - 1) / slices, r0 = per * blockIdx.y, r1 = (r0 + per < R) ? r0 + per : R;
     float acc = 0.0f;
     if (g < groups && n < N)
-        for (int64_t r = r0 + g; r < r1; r += groups) acc = acc + Z[r * N + n];
+#pragma unroll 4
+        for (int64_t r = r0 + g; r < r1; r += groups) acc = acc + Z[r * N + n];        // (unrolled: the loads run ahead, the additions keep their order)
     red[threadIdx.x] = acc;
     __syncthreads();
     if (g == 0 && n < N) {
@@ -164,18 +253,34 @@ __global__ void k_act_backward(int64_t n, const float *__restrict__ dY, const fl
 
 static int grid1d(int64_t n) { int64_t g = (n + 255) / 256; if (g > 16384) g = 16384; return (int)(g < 1 ? 1 : g); }
 
+template <bool TA, bool TB, int BM, int BN>
+static int gemm_tiled(int M, int N, int64_t K, const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, const float *bias, int act,
+                      int splits, float *partial, hipStream_t st)
+{
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, splits > 1 ? splits : 1);
+    {   // a workgroup addresses its operand tiles with 32-bit byte offsets from the tile's base
+        const int64_t z = grid.z, slabs = (K + GK - 1) / GK, krange = ((slabs + z - 1) / z) * GK;
+        const int64_t ea = TA ? krange * lda : (int64_t)BM * lda + krange, eb = TB ? (int64_t)BN * ldb + krange : krange * ldb;
+        PDP_REQUIRE(ea < ((int64_t)1 << 29) && eb < ((int64_t)1 << 29), "GEMM operand tile past 2 GB: use more split-K slices");
+    }
+    hipLaunchKernelGGL((k_gemm<TA, TB, BM, BN>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, bias, act, partial);
+    if (splits > 1) hipLaunchKernelGGL(k_splitk_reduce, dim3(reduce_grid((int64_t)M * N)), dim3(RED_G * RED_E), 0, st, (int64_t)M * N, splits, (const float *)partial, C);
+    PDP_LAUNCH_CHECK();
+    return PDP_OK;
+}
+// Tile shape: 64 x 64 for every call.  Measured on the 1 M-edge training step (tools/train_time.py, hidden 128): 128 x 128 tiles (half the
+// operand traffic per flop, but 220 registers per lane = two workgroups per CU) take 140 ms per step against 123 ms -- the kernel is bound by
+// how many workgroups overlap their load -> LDS -> barrier chains, not by operand bandwidth.
 template <bool TA, bool TB>
 static int gemm(int M, int N, int64_t K, const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, const float *bias, int act,
                 int splits, float *partial, hipStream_t st)
 {
-    dim3 grid((N + GB - 1) / GB, (M + GB - 1) / GB, splits > 1 ? splits : 1);
-    hipLaunchKernelGGL((k_gemm<TA, TB>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, bias, act, partial);
-    if (splits > 1) hipLaunchKernelGGL(k_splitk_reduce, dim3(grid1d((int64_t)M * N)), dim3(256), 0, st, (int64_t)M * N, splits, (const float *)partial, C);
-    PDP_LAUNCH_CHECK();
-    return PDP_OK;
+    return gemm_tiled<TA, TB, 64, 64>(M, N, K, A, lda, B, ldb, C, ldc, bias, act, splits, partial, st);
 }
 
-static int pick_splits(int64_t R) { int64_t s = (R + 4095) / 4096; if (s > 128) s = 128; return (int)(s < 1 ? 1 : s); }
+// split-K of the weight gradients (K = rows of the batch, the output is a few 64 x 64 tiles): slices of >= 1024 rows, at most 1024 of them --
+// the slices are what fills the chip (at 128 slices of 8 192 rows a CU held two or three workgroups, each waiting on its own loads)
+static int pick_splits(int64_t R) { int64_t s = (R + 1023) / 1024; if (s > 1024) s = 1024; return (int)(s < 1 ? 1 : s); }
 
 // scratch for split-K partials and column sums: one block per (device, stream), grown on demand.  Kernels enqueued earlier on that stream may
 // still read the old block when it has to grow, so the stream is drained before the block goes back to the pool; work on another stream or
@@ -238,7 +343,7 @@ extern "C" int pdp_train_linear_backward(const float *dY, const float *Y, const 
     if (db) {
         float *part = scr + (size_t)splits * N * K;
         hipLaunchKernelGGL(k_colsum_partial, dim3((N + 255) / 256, cs), dim3(256), 0, st, R, N, (const float *)dZ, cs, part);
-        hipLaunchKernelGGL(k_splitk_reduce, dim3(grid1d(N)), dim3(256), 0, st, (int64_t)N, cs, (const float *)part, db);
+        hipLaunchKernelGGL(k_splitk_reduce, dim3(reduce_grid(N)), dim3(RED_G * RED_E), 0, st, (int64_t)N, cs, (const float *)part, db);
     }
     PDP_LAUNCH_CHECK();
     return PDP_OK;
@@ -367,10 +472,10 @@ extern "C" int pdp_train_gru_backward(const float *dhnew, const float *saved, co
     float *part = scr + (size_t)splits * wmax;
     s = gemm<true, false>(3 * H, Kx, R, dgi, 3 * H, x, Kx, dW_ih, Kx, nullptr, TACT_NONE, splits, scr, st); if (s != PDP_OK) return s;
     hipLaunchKernelGGL(k_colsum_partial, dim3((3 * H + 255) / 256, cs), dim3(256), 0, st, R, 3 * H, (const float *)dgi, cs, part);
-    hipLaunchKernelGGL(k_splitk_reduce, dim3(grid1d(3 * H)), dim3(256), 0, st, (int64_t)3 * H, cs, (const float *)part, db_ih);
+    hipLaunchKernelGGL(k_splitk_reduce, dim3(reduce_grid(3 * H)), dim3(RED_G * RED_E), 0, st, (int64_t)3 * H, cs, (const float *)part, db_ih);
     s = gemm<true, false>(3 * H, H, R, dgh, 3 * H, h, H, dW_hh, H, nullptr, TACT_NONE, splits, scr, st); if (s != PDP_OK) return s;
     hipLaunchKernelGGL(k_colsum_partial, dim3((3 * H + 255) / 256, cs), dim3(256), 0, st, R, 3 * H, (const float *)dgh, cs, part);
-    hipLaunchKernelGGL(k_splitk_reduce, dim3(grid1d(3 * H)), dim3(256), 0, st, (int64_t)3 * H, cs, (const float *)part, db_hh);
+    hipLaunchKernelGGL(k_splitk_reduce, dim3(reduce_grid(3 * H)), dim3(RED_G * RED_E), 0, st, (int64_t)3 * H, cs, (const float *)part, db_hh);
     PDP_LAUNCH_CHECK();
     return PDP_OK;
 }
