@@ -65,6 +65,49 @@ def test_aggregator_gru_predict_bit_exact(oracle, monkeypatch, H, m1, a, g, grid
     np.testing.assert_array_equal(npy(got), ref)
 
 
+@pytest.mark.parametrize('H,generic', [(128, False), (150, False), (32, False), (128, True)])
+def test_neural_operators_at_the_edges_of_the_activation_range(oracle, monkeypatch, H, generic):
+    """Pre-activations far outside the range the random-weight tests reach: |x| up to a few thousand (logsigmoid's exponential underflows at
+    -104.5, the sigmoids clamp at 87 / 89, tanh at 10), exact zeros, and rows holding NaN, +inf, -inf and 1e30 -- the select-free scalar forms
+    of include/pdp_math.h (the oracle) and the device's pair-wise packed forms must agree on every bit, NaN for NaN (pdp_neural.hip:
+    pk_logsigmoid, k_gru_pipe / k_gru_wave activation slices; reference: F.logsigmoid in util.py:56-74, nn.GRUCell in pdp_decimate.py:51-87)."""
+    from pdp import native
+    if generic:
+        monkeypatch.setenv('PDP_NEURAL_GENERIC', '1')
+    b = random_batch(batch=7, n=30, mixed=True, seed=91)
+    hp, op = make_pair(oracle, b)
+    hp.simplify(); op.simplify()
+    hp.refresh_edge_mask(); em, _ = op.refresh_edge_mask()
+    ev, ec, es, vi, fi = op.graph()
+    E, V, F, B = op.E, op.V, op.F, op.B
+    rng = np.random.RandomState(1000 + H)
+    state = (rng.randn(E, H) * 0.5).astype(np.float32)
+    state[rng.rand(E) < 0.3] *= 400.0                      # rows whose pre-activations run into every clamp
+    state[rng.rand(E) < 0.1] = 0.0
+    special = rng.choice(E, size=8, replace=False)
+    for row, val in zip(special, (np.nan, np.inf, -np.inf, 1e30, -1e30, np.nan, 3e38, -3e38)):
+        state[row, rng.randint(0, H)] = val
+    old = (rng.randn(E, H) * 0.5).astype(np.float32)
+    am = np.ones(B, np.uint8); am[rng.randint(0, B)] = 0
+    mask = am[vi[ev]].astype(np.float32)
+    w = rand_agg(rng, H + 1, 100, 50, 100, H, 1)
+    with np.errstate(all='ignore'):
+        for by_var, rows, nrows in ((True, ev, V), (False, ec, F)):
+            ref = oracle.aggregator(rows, nrows, state, es, em, False, w)
+            ref = mask[:, None] * ref + (1.0 - mask[:, None]) * old
+            got = npy(hp.neural_aggregate_edges(dev_agg(w, 1), by_var, t(state), hp.edge_mask, t(am), t(old)))
+            np.testing.assert_array_equal(got, ref.astype(np.float32), err_msg='aggregator by_var=%s' % by_var)
+            assert np.isnan(got).any() and np.isfinite(got).any()
+        s = lambda *sh: (rng.randn(*sh) * 0.2).astype(np.float32)
+        gw = dict(W_ih=s(3 * H, H + 1), W_hh=s(3 * H, H), b_ih=s(3 * H), b_hh=s(3 * H))
+        hprev = (rng.randn(E, H) * 0.5).astype(np.float32)
+        hprev[rng.rand(E) < 0.2] *= 300.0
+        ref = oracle.gru(state, es, hprev, mask=mask, **gw)
+        got = npy(hp.neural_gru(native.GruWeights(t(gw['W_ih']), t(gw['W_hh']), t(gw['b_ih']), t(gw['b_hh'])), t(state), t(hprev), t(am)))
+        np.testing.assert_array_equal(got, ref)
+        assert np.isnan(got).any() and np.isfinite(got).any()
+
+
 @pytest.mark.parametrize('H,grid', [(32, None), (128, None), (20, None), (128, 2)])
 def test_sp_adaptors_and_adapted_propagate_bit_exact(oracle, monkeypatch, H, grid):
     """adaptor form of the SP propagator (model type p-nd-np): the projections are k-ascending fmaf chains on both sides, so the
