@@ -1022,6 +1022,73 @@ def gen_train_hybrid():
     print('np-d-np:', rec)
 
 
+def det_weights(name, shape):
+    "parameter values both sides can rebuild from the canonical parameter name alone (no weight tensors in the fixture): U(-1, 1) / sqrt(fan_in)"
+    import zlib
+    rs = np.random.RandomState(zlib.crc32(name.encode()) & 0x7fffffff)
+    scale = 1.0 / np.sqrt(shape[-1]) if len(shape) >= 2 else 0.1
+    return (rs.uniform(-1.0, 1.0, size=shape) * scale).astype(np.float32)
+
+
+def sample_index(name, numel, count=384):
+    import zlib
+    rs = np.random.RandomState((zlib.crc32(name.encode()) ^ 0x5bd1e995) & 0x7fffffff)
+    return np.sort(rs.choice(numel, size=min(count, numel), replace=False)).astype(np.int64)
+
+
+def gen_train_h128():
+    """_train_batch's statements (base.py:149-182) at the hidden width the shipped configs train (hidden_dim 128 region; gen_train uses 32):
+    np-nd-np and p-nd-np on a batch of 8 instances, 3 outer recurrences.  The fixture carries no weight tensors: every parameter is
+    det_weights(canonical name, shape), which the test rebuilds; of every parameter gradient it keeps 384 sampled entries (sample_index),
+    the largest magnitude and the L2 norm -> train_h128_<model type>.npz (a few tens of KB each)."""
+    lines = make_lines([(40, 160, (3,))] * 6 + [(30, 100, (2, 3, 4))] * 2, seed0=6500)
+    gm, bvm, bfm, ef, lab, misc = batch_tensors(lines)
+
+    def run(model_type):
+        cfg = train_cfg(model_type=model_type, model_name='golden-h128-' + model_type, hidden_dim=128)
+        tr, m = build(cfg, seed=779)
+        m._global_step.data = torch.tensor([3.0])
+        amap = alias_map(m)
+        with torch.no_grad():
+            for k, v in m.state_dict().items():
+                if k.startswith(('_propagator.', '_decimator.', '_predictor.')) and '_module_list' not in k and amap[k] == k:
+                    v.copy_(torch.from_numpy(det_weights(k, tuple(v.shape))))
+        out = problem_arrays(gm, bvm, bfm, ef)
+        out['label'] = np_(lab)
+        torch.manual_seed(37)
+        lam = torch.tensor([cfg['lambda']], dtype=torch.float32)
+        state = m.get_init_state(gm, bvm, bfm, ef, None, cfg['randomized'])
+        loss = torch.zeros(1)
+        step_losses = []
+        for t in range(cfg['train_outer_recurrence_num']):
+            prediction, state = m(init_state=state, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None,
+                                  is_training=True, iteration_num=cfg['train_inner_recurrence_num'])
+            lt = tr._compute_loss(model=m, loss=tr._loss, prediction=prediction, label=lab, graph_map=gm, batch_variable_map=bvm,
+                                  batch_function_map=bfm, edge_feature=ef, meta_data=None)
+            step_losses.append(float(lt))
+            if t == 0:
+                out['first_prediction'] = np_(prediction[0][:, 0])
+            loss = loss + lt * lam.pow(float(cfg['train_outer_recurrence_num'] - t - 1))
+        loss.backward()
+        out['loss'] = np.array([float(loss)], dtype=np.float32)
+        out['step_losses'] = np.array(step_losses, dtype=np.float32)
+        names = []
+        for name, prm in m.named_parameters(remove_duplicate=False):
+            if prm.grad is not None and '_module_list' not in name and name.startswith(('_propagator.', '_decimator.', '_predictor.')) and amap[name] == name:
+                g = np_(prm.grad).reshape(-1)
+                key = name.replace('.', '__')
+                out['gs__' + key] = g[sample_index(name, g.size)]
+                out['gn__' + key] = np.array([np.abs(g).max(), np.sqrt((g.astype(np.float64) ** 2).sum())], dtype=np.float64)
+                names.append(name)
+        ref_map = 'state_dict_alias_map_train.json' if model_type == 'np-nd-np' else 'state_dict_alias_map_train_pndnp.json'
+        assert json.load(open(os.path.join(HERE, ref_map))) == amap          # parameter names do not depend on the hidden width: the test reuses that map
+        save('train_h128_' + model_type.replace('-', '_'), **out)
+        print(model_type, 'hidden 128: loss', float(loss), 'step losses', step_losses, 'gradients', len(names))
+
+    run('np-nd-np')
+    _with_b5_shim(lambda: run('p-nd-np'))
+
+
 def gen_generators():
     """The reference's CNF generators (src/pdp/generator.py) under fixed numpy seeds: uniform, modular and variable-modular,
     generate() and generate_complete() (the variable-modular generate_complete cannot run in the reference, App. B-11)."""
@@ -1168,3 +1235,5 @@ if __name__ == '__main__':
         gen_train()
     if 'train_hybrid' in what:
         gen_train_hybrid()
+    if 'train_h128' in what:
+        gen_train_h128()

@@ -207,6 +207,69 @@ def test_train_batch_equals_reference(model_type, golden, alias_file, min_grads)
     assert n_el > 15000 and n_far <= 0.002 * n_el, (n_far, n_el)
 
 
+def _det_weights(name, shape):
+    "tests/golden/generate_golden.py::det_weights: parameter values from the canonical parameter name alone"
+    import zlib
+    rs = np.random.RandomState(zlib.crc32(name.encode()) & 0x7fffffff)
+    scale = 1.0 / np.sqrt(shape[-1]) if len(shape) >= 2 else 0.1
+    return (rs.uniform(-1.0, 1.0, size=shape) * scale).astype(np.float32)
+
+
+def _sample_index(name, numel, count=384):
+    import zlib
+    rs = np.random.RandomState((zlib.crc32(name.encode()) ^ 0x5bd1e995) & 0x7fffffff)
+    return np.sort(rs.choice(numel, size=min(count, numel), replace=False)).astype(np.int64)
+
+
+@pytest.mark.parametrize('model_type,alias_file,min_grads', [('np-nd-np', 'state_dict_alias_map_train.json', 29), ('p-nd-np', 'state_dict_alias_map_train_pndnp.json', 19)])
+def test_train_batch_hidden128_equals_reference(model_type, alias_file, min_grads):
+    """The statements of ``_train_batch`` (base.py:149-182) at hidden 128 -- the width of the 128-wide fast kernels' shapes and of the
+    shipped training configs' order of magnitude -- on 8 instances, three outer recurrences: per-recurrence losses, first prediction, and
+    of every parameter gradient 384 sampled entries, the largest magnitude and the L2 norm, against the reference's values
+    (generate_golden.py train_h128; the fixture holds no weights: both sides build them from the parameter names)."""
+    from pdp.trainer import SatFactorGraphTrainer
+    d = load_golden('train_h128_' + model_type.replace('-', '_'))
+    gm, bvm, bfm, ef = [torch.from_numpy(d[k]).to(DEV) for k in ('graph_map', 'batch_variable_map', 'batch_function_map', 'edge_feature')]
+    label = torch.from_numpy(d['label']).to(DEV)
+    cfg = _train_cfg(model_type=model_type, hidden_dim=128)
+    tr = SatFactorGraphTrainer(cfg, use_cuda=True, logger=LOG)
+    m = tr._model_list[0]
+    alias = json.load(open(os.path.join(GOLD, alias_file)))
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = {}
+    for key, canon in alias.items():
+        sd[key] = torch.zeros(1) if key == '_global_step' else torch.from_numpy(_det_weights(canon, shapes[key]))
+    m.load_state_dict(sd, strict=True)
+    m._global_step.data = torch.tensor([3.0], device=m._global_step.device)
+    torch.manual_seed(37)
+    state = m.get_init_state(gm, bvm, bfm, ef, None, cfg['randomized'])
+    loss = torch.zeros(1, device=DEV)
+    steps = []
+    for k in range(3):
+        prediction, state = m(init_state=state, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None,
+                              is_training=True, iteration_num=1)
+        if k == 0:
+            np.testing.assert_allclose(npy(prediction[0])[:, 0], d['first_prediction'], rtol=3e-4, atol=3e-5)
+        lt = tr._compute_loss(model=m, loss=tr._loss, prediction=prediction, label=label, graph_map=gm, batch_variable_map=bvm,
+                              batch_function_map=bfm, edge_feature=ef, meta_data=None)
+        steps.append(float(lt))
+        loss = loss + lt * (0.9 ** (3 - k - 1))
+    np.testing.assert_allclose(steps, d['step_losses'], rtol=2e-5)
+    np.testing.assert_allclose(float(loss), float(d['loss'][0]), rtol=2e-5)
+    loss.backward()
+    checked = 0
+    for name, prm in m.named_parameters(remove_duplicate=False):
+        key = name.replace('.', '__')
+        if 'gs__' + key in d.files:
+            g = npy(prm.grad).reshape(-1)
+            gmax, gnorm = d['gn__' + key]
+            np.testing.assert_allclose(g[_sample_index(name, g.size)], d['gs__' + key], rtol=GRAD_RTOL, atol=GRAD_ATOL * float(gmax) + 1e-9, err_msg=name)
+            np.testing.assert_allclose(np.sqrt((g.astype(np.float64) ** 2).sum()), gnorm, rtol=2e-4, err_msg=name + ' (norm)')
+            np.testing.assert_allclose(np.abs(g).max(), gmax, rtol=1e-3, err_msg=name + ' (max)')
+            checked += 1
+    assert checked == sum(1 for k in d.files if k.startswith('gs__')) and checked >= min_grads
+
+
 def test_sp_adapted_sweep_forward_and_adjoint_vs_torch(oracle):
     """train_ops.SpAdaptedSweep (pdp_sp_propagate_adapted / pdp_train_sp_adapted_backward) against torch autograd of the reference's
     formulation (pdp_propagate.py:163-221 written with index_add for the sparse products), with and without an edge mask, pi 0 and 0.1."""
