@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(NT) k_walksat(PView pv, WsParams wp)
     constexpr int NWV = NT / 64;
     typedef typename std::conditional<HBM, int32_t, uint16_t>::type PT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    DECL_RED
+    __shared__ int redi[PDP_RED_SCRATCH];
     __shared__ int s_cnt;
     __shared__ float s_coin;
     __shared__ unsigned long long s_keys[2 * NWV];   // per-wave maxima of the two arg-max keys
