@@ -20,28 +20,32 @@ def _init_sp_state(device, edge_num, randomized):
 
 
 class NeuralPredictor(nn.Module):
-    """Aggregates the edge states at the variable nodes (deep set with self message) and classifies them
-    (reference: pdp_predict.py:18-104).  Only the variable branch exists natively (function_classifier is None in every
-    reference solver)."""
+    """Aggregates the edge states at the variable (and / or function) nodes (deep set with self message) and classifies them
+    (reference: pdp_predict.py:18-104).  The variable branch -- the one every solver of the reference's factory builds -- runs as the fused
+    native predictor; the function branch (function_classifier is None in solver.py:534,558) runs on the generic layer / row-sum operators of
+    pdp/nn/train_ops.py."""
 
     def __init__(self, device, decimator_dimension, prediction_dimension, edge_dimension, meta_data_dimension, mem_hidden_dimension,
                  agg_hidden_dimension, mem_agg_hidden_dimension, variable_classifier=None, function_classifier=None):
         super(NeuralPredictor, self).__init__()
-        if function_classifier is not None or variable_classifier is None:
-            raise native.NativeError("NeuralPredictor: the native path implements the variable classifier branch only")
         if edge_dimension != 1 or meta_data_dimension != 0 or prediction_dimension != 1:
             raise native.NativeError("NeuralPredictor: native kernels need edge_feature_dim = 1, meta_feature_dim = 0, prediction_dim = 1")
         from pdp.nn import util
         self._device = device
         self._module_list = nn.ModuleList()
         self._variable_classifier = variable_classifier
-        self._function_classifier = None
+        self._function_classifier = function_classifier
         self._hidden_dimension = decimator_dimension
-        self._variable_aggregator = util.MessageAggregator(device, decimator_dimension + edge_dimension + meta_data_dimension,
-                                                           decimator_dimension, mem_hidden_dimension, mem_agg_hidden_dimension,
-                                                           agg_hidden_dimension, 0, include_self_message=True)
-        self._module_list.append(self._variable_aggregator)
-        self._module_list.append(self._variable_classifier)
+        make = lambda: util.MessageAggregator(device, decimator_dimension + edge_dimension + meta_data_dimension, decimator_dimension,
+                                              mem_hidden_dimension, mem_agg_hidden_dimension, agg_hidden_dimension, 0, include_self_message=True)
+        if variable_classifier is not None:
+            self._variable_aggregator = make()
+            self._module_list.append(self._variable_aggregator)
+            self._module_list.append(self._variable_classifier)
+        if function_classifier is not None:
+            self._function_aggregator = make()
+            self._module_list.append(self._function_aggregator)
+            self._module_list.append(self._function_classifier)
         self._head = None
         self._head_key = None
 
@@ -55,26 +59,29 @@ class NeuralPredictor(nn.Module):
             self._head_key = key
         return self._head
 
+    @staticmethod
+    def _generic_branch(state, aggregator, classifier, sat_problem, by_variable, edge_mask):
+        "aggregator + perceptron head as generic native operators (differentiable; pdp_predict.py:67-89, trainer.py:28-29 for the head)"
+        from pdp.nn import train_ops as T
+        agg = aggregator.forward_train(torch.cat((state, sat_problem._edge_feature), 1), None, sat_problem, by_variable, edge_mask)
+        hid = T.LinearAct.apply(agg, classifier._layer1.weight, classifier._layer1.bias, 'relu')
+        out_act = 'tanh' if type(classifier).__name__ == 'PerceptronTanh' else 'sigmoid'
+        return T.LinearAct.apply(hid, classifier._layer2.weight, None, out_act)
+
     def forward(self, decimator_state, sat_problem, last_call=False):
         pinned = getattr(self, '_train_path', None)       # set by the solver's forward (one decision for the three plug-ins)
-        if (torch.is_grad_enabled() and decimator_state[0].requires_grad) if pinned is None else pinned:
-            # the differentiable form of the training path (pdp_predict.py:49-91; trainer.py:28-29 for the head)
-            from pdp.nn import train_ops as T
-            em = decimator_state[2] if len(decimator_state) == 3 else None
-            agg = self._variable_aggregator.forward_train(torch.cat((decimator_state[0], sat_problem._edge_feature), 1), None, sat_problem, True, em)
-            c = self._variable_classifier
-            hid = T.LinearAct.apply(agg, c._layer1.weight, c._layer1.bias, 'relu')
-            out_act = 'tanh' if type(c).__name__ == 'PerceptronTanh' else 'sigmoid'
-            return T.LinearAct.apply(hid, c._layer2.weight, None, out_act), None
-        if len(decimator_state) == 3:
-            decimator_variable_state, _, edge_mask = decimator_state
-            edge_mask = edge_mask.reshape(-1).contiguous()
-        else:
-            decimator_variable_state, _ = decimator_state
-            edge_mask = None
-        pred = sat_problem._native.neural_predict(self._variable_aggregator.native_weights(), self._head_weights(),
-                                                  decimator_variable_state.contiguous(), edge_mask)
-        return pred, None
+        train = (torch.is_grad_enabled() and decimator_state[0].requires_grad) if pinned is None else pinned
+        em = decimator_state[2] if len(decimator_state) == 3 else None
+        variable_prediction = function_prediction = None
+        if self._variable_classifier is not None:
+            if train:
+                variable_prediction = self._generic_branch(decimator_state[0], self._variable_aggregator, self._variable_classifier, sat_problem, True, em)
+            else:
+                variable_prediction = sat_problem._native.neural_predict(self._variable_aggregator.native_weights(), self._head_weights(),
+                                                                         decimator_state[0].contiguous(), None if em is None else em.reshape(-1).contiguous())
+        if self._function_classifier is not None:
+            function_prediction = self._generic_branch(decimator_state[1], self._function_aggregator, self._function_classifier, sat_problem, False, em)
+        return variable_prediction, function_prediction
 
     def get_init_state(self, graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, randomized, batch_replication):
         edge_num = graph_map.size(1) * batch_replication
@@ -116,14 +123,23 @@ class SurveyScorer(nn.Module):
 
     def __init__(self, device, message_dimension, include_adaptors=False, pi=0.0):
         super(SurveyScorer, self).__init__()
-        if include_adaptors:
-            raise native.NativeError("SurveyScorer(include_adaptors=True) has no native kernel")
         self._device = device
-        self._include_adaptors = False
+        self._include_adaptors = bool(include_adaptors)
         self._pi = float(pi)
+        if self._include_adaptors:
+            # a bias-free projector [message_dimension -> 2] in front of the score (pdp_predict.py:145-147): column 0 through a sigmoid is the
+            # survey, column 1 through sign the external force (:161-164).  No solver of the reference's factory asks for it.
+            self._projector = nn.Linear(message_dimension, 2, bias=False).to(device)
+            self._module_list = nn.ModuleList([self._projector])
 
     def forward(self, message_state, sat_problem, last_call=False):
-        return sat_problem._native.survey_score(message_state[1].contiguous(), self._pi), None
+        nat = sat_problem._native
+        fs = message_state[1].contiguous()
+        if self._include_adaptors:
+            # the same two k-ascending dot products per edge as the propagator's adaptor form (k_sp_adaptors; its first output is not used here)
+            W = self._projector.weight.data.contiguous()
+            _, fs = nat.sp_adaptors(fs, fs, W[0].contiguous(), W)
+        return nat.survey_score(fs, self._pi), None
 
     def get_init_state(self, graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, randomized, batch_replication):
         return _init_sp_state(self._device, graph_map.size(1) * batch_replication, randomized)

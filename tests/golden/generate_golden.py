@@ -296,6 +296,64 @@ def gen_ops(lines):
     save('ops_classical', **out)
 
 
+def gen_scorer_adaptors(lines):
+    """SurveyScorer(include_adaptors=True) (pdp_predict.py:145-152, 161-166): a bias-free projector [H -> 2] in front of the score, column 0
+    through a sigmoid (the survey), column 1 through sign (the external force).  No solver of the reference's factory builds it; the class
+    takes the flag, so the plug-in API keeps it.  Fixture: message state [E, 16], projector weight, the assignment that shapes the masks,
+    scores for pi = 0 and 0.1."""
+    gm, bvm, bfm, ef, lab, misc = batch_tensors(lines)
+    dev = torch.device('cpu')
+    E, V = gm.size(1), bvm.numel()
+    H = 16
+    out = problem_arrays(gm, bvm, bfm, ef)
+    rng = np.random.RandomState(23)
+    sp = RS.SATProblem((gm, bvm, bfm, ef, None, None), dev, 1)
+    sp.simplify()
+    assign = torch.zeros(V, 1)
+    pick = rng.choice(V, size=10, replace=False)
+    assign[pick, 0] = torch.from_numpy((rng.randint(0, 2, size=10) * 2 - 1).astype(np.float32))
+    sp.set_variables(assign)
+    out['assign'] = np_(assign[:, 0])
+    out['active_functions'] = np_(sp._active_functions[:, 0])
+    msg = torch.from_numpy(rng.randn(E, H).astype(np.float32))
+    out['message'] = np_(msg)
+    for tag, pi in (('pi0', 0.0), ('pi01', 0.1)):
+        torch.manual_seed(5)
+        sc = RP.SurveyScorer(dev, message_dimension=H, include_adaptors=True, pi=pi)
+        out['weight'] = np_(sc._projector.weight)
+        with torch.no_grad():
+            s, _ = sc((None, msg.clone()), sp)
+        out['score_' + tag] = np_(s[:, 0])
+    save('scorer_adaptors', **out)
+
+
+def gen_predictor_function_branch(lines):
+    """NeuralPredictor with BOTH classifiers (pdp_predict.py:49-91): the variable branch every solver of the factory uses and the function
+    branch none of them builds (function_classifier is None in solver.py:534,558).  Small widths; weights, the two decimator states, an edge
+    mask and both predictions."""
+    gm, bvm, bfm, ef, lab, misc = batch_tensors(lines)
+    dev = torch.device('cpu')
+    E = gm.size(1)
+    H = 8
+    out = problem_arrays(gm, bvm, bfm, ef)
+    rng = np.random.RandomState(29)
+    sp = RS.SATProblem((gm, bvm, bfm, ef, None, None), dev, 1)
+    torch.manual_seed(9)
+    pr = RP.NeuralPredictor(dev, H, 1, 1, 0, 12, 10, 6, variable_classifier=RT.Perceptron(H, 5, 1), function_classifier=RT.Perceptron(H, 7, 1))
+    for k, v in pr.state_dict().items():
+        if '_module_list' not in k:
+            out['w__' + k.replace('.', '__')] = np_(v)
+    dv = torch.from_numpy((rng.randn(E, H) * 0.7).astype(np.float32)); df = torch.from_numpy((rng.randn(E, H) * 0.7).astype(np.float32))
+    em = torch.from_numpy((rng.rand(E, 1) > 0.2).astype(np.float32))
+    out['dec_v'] = np_(dv); out['dec_f'] = np_(df); out['edge_mask'] = np_(em[:, 0])
+    with torch.no_grad():
+        pv, pf = pr((dv, df, em), sp)
+        pv2, pf2 = pr((dv, df), sp)
+    out['pred_v_masked'] = np_(pv[:, 0]); out['pred_f_masked'] = np_(pf[:, 0])
+    out['pred_v'] = np_(pv2[:, 0]); out['pred_f'] = np_(pf2[:, 0])
+    save('predictor_function_branch', **out)
+
+
 # ---- C. traces of the full solver ------------------------------------------------------------
 
 def run_trace(model_type, lines, T, w, seed, replication=1, cfg_kw=None, float_iters=(0, 1, 2, 5, 10),
@@ -1174,6 +1232,10 @@ if __name__ == '__main__':
         lines = gen_loader_and_simplify()
     if 'ops' in what:
         gen_ops(lines)
+    if 'predictor_function' in what:
+        gen_predictor_function_branch(make_lines(MIXED_SPECS, seed0=100))
+    if 'scorer_adaptors' in what:
+        gen_scorer_adaptors(make_lines(MIXED_SPECS, seed0=100))
     if 'traces' in what:
         gen_traces()
     if 'neural' in what:

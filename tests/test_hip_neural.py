@@ -145,3 +145,38 @@ def test_sp_adaptors_and_adapted_propagate_bit_exact(oracle, monkeypatch, H, gri
         ref = oracle.gru(inp, es, dv, mask=mask, **gw)
         got = hp.neural_gru(native.GruWeights(t(gw['W_ih']), t(gw['W_hh']), t(gw['b_ih']), t(gw['b_hh'])), t(inp), t(dv), t(am))
         np.testing.assert_array_equal(npy(got), ref)
+
+
+def test_neural_predictor_with_both_classifiers_equals_reference(oracle):
+    """NeuralPredictor built with a variable AND a function classifier (pdp_predict.py:49-91).  The variable branch is the fused native
+    predictor; the function branch -- no solver of the reference's factory builds it -- runs on the generic layer / row-sum operators.  Both
+    against the reference's predictions (with and without an edge mask), the function branch also against the oracle's per-clause form."""
+    from pdp.nn import pdp_predict
+    from pdp.nn.solver import SATProblem
+    from pdp.trainer import Perceptron
+    d = load_golden('predictor_function_branch')
+    dev = torch.device('cuda:0')
+    gm, bvm, bfm, ef = [t(d[k]) for k in ('graph_map', 'batch_variable_map', 'batch_function_map', 'edge_feature')]
+    sp = SATProblem((gm, bvm, bfm, ef, None, None), dev, 1)
+    H = d['dec_v'].shape[1]
+    pr = pdp_predict.NeuralPredictor(dev, H, 1, 1, 0, 12, 10, 6, variable_classifier=Perceptron(H, 5, 1), function_classifier=Perceptron(H, 7, 1)).to(dev)
+    # canonical names only: the `_module_list` entries are the same Parameter objects under a second name (SURVEY 5.4)
+    sd = {k: torch.from_numpy(d['w__' + k.replace('.', '__')]) for k in pr.state_dict().keys() if '_module_list' not in k}
+    missing, unexpected = pr.load_state_dict(sd, strict=False)
+    assert not unexpected and all('_module_list' in k for k in missing) and len(sd) == 18
+    dv, df, em = t(d['dec_v']), t(d['dec_f']), t(d['edge_mask']).reshape(-1, 1)
+    with torch.no_grad():
+        pv, pf = pr((dv, df, em), sp)
+        pv2, pf2 = pr((dv, df), sp)
+    assert tuple(pv.shape) == (sp._variable_num, 1) and tuple(pf.shape) == (sp._function_num, 1)
+    for got, key in ((pv, 'pred_v_masked'), (pf, 'pred_f_masked'), (pv2, 'pred_v'), (pf2, 'pred_f')):
+        np.testing.assert_allclose(npy(got)[:, 0], d[key], rtol=3e-5, atol=3e-6, err_msg=key)
+    # the oracle's per-clause aggregator + head (the same restatement the variable branch is pinned with)
+    op = oracle.Problem(d['graph_map'], d['batch_variable_map'], d['batch_function_map'], d['edge_feature'], 1)
+    ev, ec, es, vi, fi = op.graph()
+    g = lambda name: d['w__' + name]
+    w = dict(W1m=g('_function_aggregator___W1_m__weight'), b1m=g('_function_aggregator___W1_m__bias'), W2m=g('_function_aggregator___W2_m__weight'),
+             W1a=g('_function_aggregator___W1_a__weight'), b1a=g('_function_aggregator___W1_a__bias'), W2a=g('_function_aggregator___W2_a__weight'))
+    agg = oracle.aggregator(ec, op.F, d['dec_f'], es, d['edge_mask'], True, w)
+    ref = oracle.perceptron(agg, g('_function_classifier___layer1__weight'), g('_function_classifier___layer1__bias'), g('_function_classifier___layer2__weight'))
+    np.testing.assert_allclose(npy(pf)[:, 0], np.asarray(ref).reshape(-1), rtol=3e-6, atol=3e-7)

@@ -362,3 +362,27 @@ def test_reciprocal_exhaustive():
         b = native.math_apply('rcp', x)
         bad += int((a.view(torch.int32) != b.view(torch.int32)).sum().item())
     assert bad == 0
+
+
+def test_survey_scorer_with_adaptors_equals_oracle_and_reference(oracle):
+    """The plug-in ``SurveyScorer(include_adaptors=True)`` (pdp_predict.py:145-152, 161-208) through its module interface: projector ->
+    sigmoid / sign (k_sp_adaptors) -> k_survey_score.  Bit for bit the oracle's value; the reference's within the fp tolerance of the
+    classical operators (its projector is an sgemm, ours a k-ascending fmaf chain)."""
+    from pdp.nn import pdp_predict
+    from pdp.nn.solver import SATProblem
+    d = load_golden('scorer_adaptors')
+    gm, bvm, bfm, ef = [t(d[k]) for k in ('graph_map', 'batch_variable_map', 'batch_function_map', 'edge_feature')]
+    sp = SATProblem((gm, bvm, bfm, ef, None, None), dev(), 1)
+    sp.simplify(); sp.set_variables(t(d['assign']).reshape(-1, 1))
+    np.testing.assert_array_equal(npy(sp._active_functions).reshape(-1), d['active_functions'])
+    op = oracle.Problem(d['graph_map'], d['batch_variable_map'], d['batch_function_map'], d['edge_feature'], 1)
+    op.simplify(); op.set_variables(d['assign'])
+    W = d['weight']
+    _, fs2 = oracle.sp_adaptors(d['message'], d['message'], W[0], W)
+    for tag, pi in (('pi0', 0.0), ('pi01', 0.1)):
+        sc = pdp_predict.SurveyScorer(dev(), message_dimension=W.shape[1], include_adaptors=True, pi=pi)
+        sc.load_state_dict({'_projector.weight': torch.from_numpy(W), '_module_list.0.weight': torch.from_numpy(W)}, strict=True)
+        got, _ = sc((None, t(d['message'])), sp)
+        assert tuple(got.shape) == (sp._variable_num, 1)
+        np.testing.assert_array_equal(npy(got)[:, 0], op.survey_score(fs2, pi))
+        np.testing.assert_allclose(npy(got)[:, 0], d['score_' + tag], rtol=2e-5, atol=2e-6)

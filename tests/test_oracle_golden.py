@@ -76,6 +76,18 @@ def test_replication_layout(oracle, golden_dir):
     np.testing.assert_array_equal(es, d['rep3_edge_feature'][:, 0])
 
 
+def test_scorer_with_adaptors_equals_reference(oracle, golden_dir):
+    "SurveyScorer(include_adaptors=True) (pdp_predict.py:145-152, 161-208): projector -> sigmoid / sign -> the score, oracle against the reference"
+    d = load(golden_dir, 'scorer_adaptors')
+    p = make_problem(oracle, d)
+    p.simplify(); p.set_variables(d['assign'])
+    np.testing.assert_array_equal(p.state()[1], d['active_functions'])
+    W = d['weight']
+    _, fs2 = oracle.sp_adaptors(d['message'], d['message'], W[0], W)
+    for tag, pi in (('pi0', 0.0), ('pi01', 0.1)):
+        np.testing.assert_allclose(p.survey_score(fs2, pi), d['score_' + tag], rtol=FP_RTOL, atol=FP_ATOL)
+
+
 @pytest.fixture(scope='module')
 def ops(oracle, golden_dir):
     d = load(golden_dir, 'ops_classical')
