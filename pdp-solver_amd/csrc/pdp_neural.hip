@@ -704,18 +704,39 @@ __global__ void __launch_bounds__(NTN, 6) k_agg_post_pf(int E, const float *__re
     // arithmetic) -- the element-indexed loop of k_agg_post spends ~1000 VALU instructions per wave and tile on divisions and 64-bit
     // addresses, and VALU time adds to MFMA time on this chip
     static_assert(2 * S3 <= 64, "one lane per input column");
+    // all the tile's HBM requests go out before the first result is used: the gathered rows first (results return in issue order and the
+    // hidden layer waits for these), then the previous-state rows of this wave's first output block, which are only needed at the very end
+    float g_hv[TM / NWAVES], g_ag[TM / NWAVES], g_sg[TM / NWAVES], g_em[TM / NWAVES];
+#pragma unroll
+    for (int jr = 0; jr < TM / NWAVES; ++jr) {
+        const int e = e0 + wave + NWAVES * jr;
+        g_hv[jr] = 0.0f; g_ag[jr] = 0.0f; g_sg[jr] = 0.0f; g_em[jr] = 1.0f;
+        if (e < E) {
+            const int row = edge_row[e];
+            g_sg[jr] = sign[e];
+            if (emask) g_em[jr] = emask[e];
+            if (l < w.a) { g_hv[jr] = h2[(size_t)e * w.a + l]; g_ag[jr] = agg[(size_t)row * w.a + l]; }
+        }
+    }
+    const int ROWB = w.out * (int)sizeof(float);
+    const int rows = E - e0 < TM ? E - e0 : TM;
+    const __amdgpu_buffer_rsrc_t pb = __builtin_amdgcn_make_buffer_rsrc((void *)(old + (size_t)e0 * w.out), 0, rows * ROWB, 0x00020000);
+    float po0[16];
+    {
+        const int nb4 = wave >> 1, mb4 = wave & 1, col4 = 32 * nb4 + i;
+        const int lo = (32 * mb4 + 4 * kh) * ROWB + col4 * (int)sizeof(float);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) po0[r] = col4 < w.out ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pb, lo, ((r & 3) + 8 * (r >> 2)) * ROWB, 0)) : 0.0f;
+    }
 #pragma unroll
     for (int jr = 0; jr < TM / NWAVES; ++jr) {
         const int r = wave + NWAVES * jr, e = e0 + r;
         float v = 0.0f;
         if (e < E) {
-            const int row = edge_row[e];
-            const float sg = sign[e];
             if (l < w.a) {
-                const float hv = h2[(size_t)e * w.a + l];
-                const float own = emask ? hv * emask[e] : hv;
-                v = (0.0f + agg[(size_t)row * w.a + l]) - own;
-            } else if (l == w.a && w.fd) v = sg;
+                const float own = emask ? g_hv[jr] * g_em[jr] : g_hv[jr];
+                v = (0.0f + g_ag[jr]) - own;
+            } else if (l == w.a && w.fd) v = g_sg[jr];
         }
         if (l < 2 * S3) Rt[r * ld0 + l] = v;
     }
@@ -751,10 +772,7 @@ __global__ void __launch_bounds__(NTN, 6) k_agg_post_pf(int E, const float *__re
     // blend operands and result through buffer accesses with a per-tile base (lane offset in a VGPR, row offset as a scalar, rows past E
     // clipped by the descriptor); the previous state is requested before the last layer's chain.  The output is w.out = 128 or 150 floats
     // wide: with 5 column blocks (150) the 10 blocks of the tile go round the 8 waves twice.
-    const int ROWB = w.out * (int)sizeof(float);
-    const int rows = E - e0 < TM ? E - e0 : TM;
     const __amdgpu_buffer_rsrc_t ob = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)e0 * w.out), 0, rows * ROWB, 0x00020000);
-    const __amdgpu_buffer_rsrc_t pb = __builtin_amdgcn_make_buffer_rsrc((void *)(old + (size_t)e0 * w.out), 0, rows * ROWB, 0x00020000);
     const __amdgpu_buffer_rsrc_t mb_ = __builtin_amdgcn_make_buffer_rsrc((void *)(rowmask ? rowmask + e0 : old), 0, rows * (int)sizeof(float), 0x00020000);
     for (int blk = wave; blk < 2 * NB4; blk += NWAVES) {
         const int nb4 = blk >> 1, mb4 = blk & 1, col4 = 32 * nb4 + i;
@@ -763,7 +781,8 @@ __global__ void __launch_bounds__(NTN, 6) k_agg_post_pf(int E, const float *__re
         const int lo = (32 * mb4 + 4 * kh) * ROWB + col4 * (int)sizeof(float), lm = (32 * mb4 + 4 * kh) * (int)sizeof(float);
         float po[16], mk[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) po[r] = live ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pb, lo, ((r & 3) + 8 * (r >> 2)) * ROWB, 0)) : 0.0f;
+        for (int r = 0; r < 16; ++r)
+            po[r] = blk == wave ? po0[r] : (live ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pb, lo, ((r & 3) + 8 * (r >> 2)) * ROWB, 0)) : 0.0f);
         f32x16 acc[1];
         wave_chains<S4, 1, 32 * NB4>(G1 + (32 * mb4 + i) * ld1 + kh, w4, nullptr, acc);
 #pragma unroll
