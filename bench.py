@@ -347,7 +347,7 @@ def neural_kernel_rooflines(native, timing, E, V, H, model_type='np-nd-np'):
         if n == 0:
             continue
         per = ms / n
-        row = dict(kernel=native.kernel_name(key) if key != 'row_sum' else 'k_row_sum', launches=n, ms_per_launch=per)
+        row = dict(kernel=native.kernel_name(key), launches=n, ms_per_launch=per)
         if key == 'sp_adaptors':                          # HBM-bound: the two [E, H] decimator states read once
             gbs = 2.0 * E * H * 4 / (per * 1e-3) / 1e9
             row.update(bytes_per_launch=2.0 * E * H * 4, gb_per_s=gbs, frac_of_hbm_peak=gbs / HBM_PEAK_GBS)
