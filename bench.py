@@ -67,8 +67,15 @@ def launch_ranks(n, argv):
     return 0
 
 
+def grouped():
+    """Does this process join a torch.distributed group?  Always with several ranks; with ONE rank only on request (PDP_DIST_FORCE=1 under
+    torch.distributed.run --nproc-per-node 1): the barrier and the two all-reduces then go through RCCL on a one-GPU box exactly as they
+    do on eight, and the line says rccl_ranks = 1 with the backend that ran."""
+    return int(os.environ.get('WORLD_SIZE', '1')) > 1 or (os.environ.get('PDP_DIST_FORCE') == '1' and 'RANK' in os.environ)
+
+
 def init_ranks(args):
-    """(world, rank, local_rank, backend) of this process; initialises torch.distributed when world > 1.  backend 'nccl' is RCCL (one GPU
+    """(world, rank, local_rank, backend) of this process; initialises torch.distributed when grouped().  backend 'nccl' is RCCL (one GPU
     per rank); PDP_DIST_BACKEND=gloo lets several ranks share one GPU (checks of the N > 1 code on a single-GPU box / on CPU)."""
     import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -77,7 +84,7 @@ def init_ranks(args):
     backend = os.environ.get('PDP_DIST_BACKEND', 'nccl')
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d ranks were started" % (args.gpus, world))
-    if world > 1:
+    if grouped():
         import torch.distributed as dist
         if args.selftest_collective:
             dist.init_process_group(backend if backend != 'nccl' or torch.cuda.is_available() else 'gloo')
@@ -104,7 +111,7 @@ def selftest_collective(args):
     elapsed = 0.010 * (rank + 1)
     stats = torch.tensor([1000.0, float(rank + 1), 100.0 * args.steps], dtype=torch.float64)
     ranks = 1
-    if world > 1:
+    if grouped():
         dist.barrier()
         tmax = torch.tensor([elapsed], dtype=torch.float64); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); elapsed = float(tmax.item())
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
@@ -113,7 +120,7 @@ def selftest_collective(args):
         print(json.dumps({'metric': 'pdp_iterations_per_sec', 'selftest': True, 'value': float(stats[2].item()) / elapsed, 'n_gpus': world,
                           'rccl_ranks': ranks, 'steps': args.steps, 'warmup': args.warmup, 'instances': float(stats[0].item()),
                           'rank_sum': float(stats[1].item()), 'max_elapsed_s': elapsed}))
-    if world > 1:
+    if grouped():
         dist.destroy_process_group()
 
 
@@ -501,7 +508,7 @@ def bench_neural(args, dev, rank, world):
 
     for _ in range(args.warmup):
         step(False)
-    if world > 1:
+    if grouped():
         import torch.distributed as dist
         dist.barrier()
     native.kernel_timing(True)
@@ -513,7 +520,7 @@ def bench_neural(args, dev, rank, world):
     timing = native.kernel_timing_read(); native.kernel_timing(False)
     tot = torch.tensor([float(sum(iters_done)), elapsed], dtype=torch.float64, device=args.coll_dev)
     ranks = 1
-    if world > 1:
+    if grouped():
         import torch.distributed as dist
         dist.barrier()
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=args.coll_dev); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -541,7 +548,7 @@ def bench_neural(args, dev, rank, world):
                          'note': 'achieved = neural_flop_per_iteration (573752 E + 48500 V at hidden 128) x iterations / step time (whole step, all kernels); '
                                  'kernels: HIP events of the library around every launch, flop = the MACs of that kernel x 2'},
             'cpu_baseline': cpu}))
-    if world > 1:
+    if grouped():
         import torch.distributed as dist
         dist.destroy_process_group()
 
@@ -862,7 +869,7 @@ def main():
             kernel_ms.append(ev0.elapsed_time(ev1)); iters_done.append(it); paths.append(path); launches.append(dict(prob.last_solve_stats))
 
     def barrier():
-        if world > 1:
+        if grouped():
             import torch.distributed as dist
             dist.barrier()
 
@@ -886,7 +893,7 @@ def main():
     stats = torch.tensor([float(B), float(solved.sum().item()), float(unsat.sum().item()), elapsed, total_iters],
                          dtype=torch.float64, device=args.coll_dev)
     ranks = 1
-    if world > 1:
+    if grouped():
         import torch.distributed as dist
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=args.coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -949,7 +956,8 @@ def main():
         line = {
             'metric': 'pdp_iterations_per_sec', 'value': value,
             'unit': 'iterations/s (each iteration sweeps a batch of %d instances)' % args.batch,
-            'n_gpus': world, 'rccl_ranks': ranks, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'n_gpus': world, 'rccl_ranks': ranks, 'collective_backend': (backend if grouped() else None), 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': config,
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
@@ -961,7 +969,7 @@ def main():
             'cpu_baseline': cpu, 'cpu_baseline_torch_sparse': cpu_ts,
         }
         print(json.dumps(line))
-    if world > 1:
+    if grouped():
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -283,6 +283,30 @@ int pdp_train_sp_adapted_backward(pdp_problem *p, const float *xlog, const float
 /* adjoint of pdp_sat_loss (SatLossEvaluator.forward, util.py:178-197) with respect to the prediction: dpred [V] = upstream * d loss / d pred */
 int pdp_sat_loss_grad(pdp_problem *p, const float *pred, float coeff, float eps, int sharpness, float upstream, float *dpred, void *stream);
 
+/* ---- the reference's L0 primitives in their original call shape (a sparse COO mask instead of a problem handle) ---------------------
+ * For plug-ins written against the reference's API: they hand util.sparse_max / sparse_argmax /
+ * sparse_smooth_max and MessageAggregator.forward the torch sparse masks of SATProblem (or masks they built themselves).  The host maps
+ * the masks SATProblem built back to the resident layout (the entry points above); any other mask arrives here as its index / value
+ * arrays.  No pdp_problem is involved.
+ * replaces: util.sparse_max / sparse_argmax (util.py:257-275) for an arbitrary mask [n_rows, n_cols] given as nnz (row, col) pairs in
+ * the order of mask._indices(); x [nnz] is paired with the entries in that order (the reference builds
+ * sparse(mask._indices(), x - x.min() + 1).to_dense()); out [n_cols]; an empty column yields 0 (arg-max) / x.min() - 1 (max); NaN counts
+ * as the largest value, ties go to the smallest row.  scratch: uint64 [n_cols + 2]. */
+int pdp_coo_max(const int64_t *rows, const int64_t *cols, int64_t nnz, const float *x, int64_t n_rows, int64_t n_cols, uint64_t *scratch,
+                float *out, void *stream);
+int pdp_coo_argmax(const int64_t *rows, const int64_t *cols, int64_t nnz, const float *x, int64_t n_rows, int64_t n_cols, uint64_t *scratch,
+                   int64_t *out, void *stream);
+/* row offsets [n_rows + 1] of entries sorted by row (a coalesced torch sparse tensor) */
+int pdp_coo_row_ptr(const int64_t *sorted_rows, int64_t nnz, int64_t n_rows, int64_t *row_ptr, void *stream);
+/* replaces: torch.mm(mask, X) of util.py:60,63 for an arbitrary mask given as row offsets + columns (+ values, NULL: ones) of its row-sorted
+ * entries: out [n_rows, d] = mask X [., d] (row stride ldx) - sub (NULL: nothing subtracted; the exclude-self form of util.py:63-69);
+ * a row's entries are added in ascending entry order */
+int pdp_csr_matmul(const int64_t *row_ptr, const int64_t *cols, const float *vals, int64_t n_rows, const float *X, int d, int64_t ldx,
+                   const float *sub, float *out, void *stream);
+/* replaces: util.sparse_smooth_max (util.py:282-286) for an arbitrary mask and alpha: x [n_cols] -> out [n_rows] */
+int pdp_csr_smooth_max(const int64_t *row_ptr, const int64_t *cols, const float *vals, int64_t n_rows, const float *x, float alpha,
+                       float *out, void *stream);
+
 /* ---- kernel timing (measurement only: bench.py's per-kernel roofline lines) ------------------------------
  * When enabled, the library brackets the kernels named below with HIP events ON THEIR LAUNCH STREAM (the stream handed to the entry
  * point); pdp_kernel_timing_read synchronises on the recorded events and returns, per key, the summed device time in ms and the number

@@ -82,7 +82,9 @@ struct GemmTile {
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, so + j * step, 0));
-            r[j] = (KROW || kk0 < left) ? v : 0.0f;        // k past the range: the next row's start in the k-minor layout
+            // k past the range is masked explicitly in both layouts (k-minor: it is the next row's start; k-row: the slab offset travels in
+            // the scalar offset, which the descriptor's range check need not cover)
+            r[j] = (kk0 + (KROW ? j * (256 / BX) : 0) < left) ? v : 0.0f;
         }
     }
 };

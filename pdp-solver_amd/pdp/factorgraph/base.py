@@ -168,21 +168,45 @@ class FactorGraphTrainerBase(object):
             self._save(best_export_path_base)
         return self._model_list, errors, losses
 
-    def _predict_epoch(self, validation_loader, post_processor, batch_replication, file):
+    def _predict_epoch(self, validation_loader, post_processor, batch_replication, file, units=None):
+        """reference: base.py:252-278.  Every forward is keyed by the GLOBAL (loader batch, segment) index of its unit: the loader says where
+        a batch sits in the run (``LoaderBatch.index`` / ``.segments``); a loader without that information (torch's DataLoader, a wrapper)
+        yields every batch in order, so the position in the iteration is the index -- it cannot be a sharded one.  With ``units`` (a list)
+        the rows of a unit are appended to it as ((batch, segment), text) instead of being written to ``file``."""
+        import io
         from pdp import parallel
         base_seed = int(self._config.get('random_seed', 0) or 0)
         with torch.no_grad():
-            for data in validation_loader:
-                # global index of this loader batch (the same whatever the rank count): keys the device-side random numbers
-                j = getattr(getattr(validation_loader, 'dataset', None), 'batch_index', 0)
-                for i in range(len(data[0])):
+            for position, data in enumerate(validation_loader):
+                j = getattr(data, 'index', None)
+                segment_ids = getattr(data, 'segments', None)
+                if j is None or segment_ids is None:
+                    if units is not None and self._world() > 1:
+                        raise native.NativeError("a run on several ranks needs the loader to say which (batch, segment) units it yields "
+                                                 "(pdp.factorgraph.dataset.LoaderBatch); this loader does not")
+                    j, segment_ids = position, list(range(len(data[0])))
+                for k in range(len(data[0])):
                     for model in self._model_list:
                         if hasattr(model, 'set_random_key'):
-                            model.set_random_key(parallel.batch_seed(base_seed, j, i))
+                            model.set_random_key(parallel.batch_seed(base_seed, j, segment_ids[k]))
                     (graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, label, misc_data) = \
-                        [self._to_cuda(d[i]) for d in data]
+                        [self._to_cuda(d[k]) for d in data]
+                    sink = io.StringIO() if units is not None else file
                     self._predict_batch(graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat,
-                                        label, misc_data, post_processor, batch_replication, file)
+                                        label, misc_data, post_processor, batch_replication, sink)
+                    if units is not None:
+                        units.append(((int(j), int(segment_ids[k])), sink.getvalue()))
+
+    @staticmethod
+    def _world():
+        return torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
+
+    def _draws_from_the_host_stream(self, model):
+        "does a predict call of this model consume the global torch CPU generator (random fill, Walk-SAT coins, the Reinforce coin)?"
+        if int(getattr(model, '_local_search_iterations', 0) or 0) > 0:
+            return True
+        predictor, decimator = getattr(model, '_predictor', None), getattr(model, '_decimator', None)
+        return bool(getattr(predictor, '_random_fill', False)) or type(decimator).__name__ == 'ReinforceDecimator'
 
     def _predict_batch(self, graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, label, misc_data,
                        post_processor, batch_replication, file):
@@ -272,19 +296,28 @@ class FactorGraphTrainerBase(object):
         """Produces predictions for a (trained) PDP model (reference: base.py:451-472).
 
         Under ``torch.distributed`` (one process per GPU, ``python -m torch.distributed.run --nproc-per-node N satyr.py ...``) every rank
-        forms the loader batches of the single-process run and solves a contiguous range of WHOLE batches on its own GPU -- no collective
-        on the data path -- and the ranks meet once: an all-reduce(sum) of [instances, solved, unsat clauses] and a rank-ordered gather
-        of the result rows, which rank 0 writes.  The loader batch is the reference's coupling domain (batch-global minima, NaN
-        poisoning, dynamic segments) and the random numbers are keyed by the global batch index, so the rows are those of the
-        single-process run whatever the rank count.  That needs the counter-based generator: the reference's one sequential CPU stream
-        (``rng='torch'``) is consumed batch after batch in data-dependent amounts and cannot be split, so it is refused for N > 1."""
+        forms the loader batches of the single-process run, cuts them into the same dynamic segments and solves the segments dealt to it
+        on its own GPU -- no collective on the data path -- and the ranks meet once: an all-reduce(sum) of [instances, solved, unsat
+        clauses] and a gather of the result rows by unit index, which rank 0 writes in single-process order.  One forward = one segment
+        is the reference's coupling domain (batch-global minima, NaN poisoning) and the random numbers are keyed by the global (batch,
+        segment) index, so the rows are those of the single-process run whatever the rank count.  That needs the counter-based
+        generator: the reference's one sequential CPU stream (``rng='torch'``) is consumed unit after unit in data-dependent amounts and
+        cannot be split.  A model that draws nothing from it (np-nd-np / p-nd-np without Walk-SAT) runs on N ranks as it is; one that
+        does is switched to ``philox`` with a warning -- its rows then equal the single-process ``--rng philox`` rows."""
         import io
         from pdp import parallel
-        world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
-        rank = torch.distributed.get_rank() if world > 1 else 0
+        distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
+        world = torch.distributed.get_world_size() if distributed else 1
+        rank = torch.distributed.get_rank() if distributed else 0
         if world > 1 and self._config.get('rng', 'torch') != 'philox':
-            raise native.NativeError("a run on %d ranks needs --rng philox: the reference's sequential CPU random stream (--rng torch) "
-                                     "cannot be dealt to ranks without changing the rows" % world)
+            for model in self._model_list:
+                if self._draws_from_the_host_stream(model):
+                    self._logger.warning("%d ranks: model %s draws random numbers; the reference's sequential CPU stream (--rng torch) cannot be "
+                                         "dealt to ranks, switching to --rng philox (the rows equal a single-process --rng philox run)"
+                                         % (world, model._name))
+                    model._rng = 'philox'
+                    if hasattr(model._predictor, '_rng'):
+                        model._predictor._rng = 'philox'
         test_loader = FactorGraphDataset.get_loader(
             input_file=test_list, limit=self._config['test_batch_limit'], hidden_dim=self._config['hidden_dim'],
             batch_size=self._config['batch_size'], shuffle=False, num_workers=0,
@@ -294,17 +327,23 @@ class FactorGraphTrainerBase(object):
             self._load(import_path_base)
         start_time = time.time()
         self._run_stats = [0, 0, 0]                       # instances, solved, unsatisfied clauses (filled by the post-processor)
-        sink = io.StringIO() if world > 1 else out_file
-        self._predict_epoch(test_loader, post_processor, batch_replication, sink)
+        units = [] if distributed else None
+        self._predict_epoch(test_loader, post_processor, batch_replication, out_file, units=units)
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
+            # the one collective of the path (RCCL when the group's backend is nccl: the counters live on the GPU then), also at world size 1
             on_gpu = torch.distributed.get_backend() == 'nccl'
             self.last_stats = parallel.reduce_stats(*self._run_stats, device=self._device if on_gpu else None)
-            parts = parallel.gather_rows([sink.getvalue()])
+            self.last_stats['ranks'] = world
+            self.last_stats['backend'] = torch.distributed.get_backend()
+            if self._config.get('verbose'):
+                self._logger.info('rank %d of %d solved %d units (forward calls): %s' % (rank, world, len(units), [u for u, _ in units][:32]))
+            parts = parallel.gather_units(units)
             if rank == 0:
                 out_file.write("".join(parts))
         else:
             self.last_stats = parallel.reduce_stats(*self._run_stats)
         if self._config.get('verbose'):
             self._logger.info('Time spent: %s seconds' % (time.time() - start_time))
-            self._logger.info('instances %(instances)d, solved %(solved)d, unsatisfied clauses %(unsat_clauses)d' % self.last_stats)
+            self._logger.info('instances %(instances)d, solved %(solved)d, unsatisfied clauses %(unsat_clauses)d' % self.last_stats
+                              + (' (%(ranks)d ranks, %(backend)s)' % self.last_stats if distributed else ''))

@@ -90,6 +90,29 @@ def collate_segment(items):
         batch_size=len(items))
 
 
+class SegmentList(list):
+    "the collated segments of one loader batch this process solves + where they sit in the run"
+    batch_index = 0           # global index of the loader batch
+    segment_ids = ()          # global segment index (inside the batch) of every entry
+
+
+class LoaderBatch(tuple):
+    """What the loader yields: the reference's 7-tuple of per-segment lists (dataset.py:138-187) plus ``index`` (global loader-batch index)
+    and ``segments`` (global segment index of every entry) -- the key of the device-side random numbers and of the row order."""
+    index = 0
+    segments = ()
+
+
+def json_edge_count(line):
+    "number of edges of a compact-JSON instance line without parsing it: the length of its second list"
+    try:
+        s = line.index('], [') + 4
+        e = line.index(']', s)
+    except ValueError:
+        return parse_line(line)[2].shape[1]
+    return line.count(',', s, e) + 1 if line[s:e].strip() else 0
+
+
 def collate(items, limit=40000000, hidden_dim=3, batch_replication=1):
     """Loader-batch -> list of segment batches (reference: dag_collate_fn)."""
     edge_nums = [it[2].shape[1] for it in items]
@@ -153,10 +176,10 @@ class FactorGraphDataset(object):
         else:
             with open(input_file, 'r') as f:
                 self._lines = [l for l in f.read().split('\n') if l.strip()]
-        # one process per GPU: the loader forms the SAME batches as a single-process run and this rank iterates a contiguous range of
-        # them (pdp/parallel.py: a loader batch is the reference's coupling domain and is never split across ranks)
+        # one process per GPU: the loader forms the SAME batches and cuts the SAME segments as a single-process run; this rank collates and
+        # yields the segments dealt to it (pdp/parallel.py: one forward = one segment is the reference's coupling domain)
         self._shard = tuple(shard) if shard is not None and shard[1] > 1 and generator is None else None
-        self.batch_index = 0          # global index of the loader batch handed out last (keys the Philox streams)
+        self.batch_index = 0          # global index of the loader batch handed out last
         self._limit = limit
         self._hidden_dim = hidden_dim
         self._batch_replication = batch_replication
@@ -177,49 +200,58 @@ class FactorGraphDataset(object):
             self._cache[idx] = item
         return item
 
-    def _weight(self, i):
-        "input bytes of instance i: the proxy of its edge count that needs no parsing"
-        import os
-        return os.path.getsize(self._dimacs[i][0]) if self._dimacs is not None else len(self._lines[i])
+    def _edge_count(self, i):
+        "edges of instance i, as cheaply as the input format allows (a JSON line is not parsed for it; a DIMACS file is)"
+        if i in self._cache:
+            return self._cache[i][2].shape[1]
+        if self._dimacs is not None:
+            return self[i][2].shape[1]
+        return json_edge_count(self._lines[i])
 
-    def batch_range(self, batch_size, order=None):
-        "[lo, hi) of the global loader-batch indices this process iterates (everything without a shard)"
-        order = list(range(len(self))) if order is None else list(order)
-        starts = list(range(0, len(order), batch_size))
-        if self._shard is None:
-            return 0, len(starts)
-        from pdp import parallel
-        rank, world = self._shard
-        weights = [sum(self._weight(i) for i in order[s:s + batch_size]) for s in starts]
-        return parallel.deal_batches(weights, world)[rank]
+    def _parse_batch(self, idx):
+        "DIMACS files: one call parses the not yet cached files of a batch with a few host threads inside the native library"
+        import os
+        from pdp import native
+        todo = [i for i in idx if i not in self._cache]
+        tmp = {}
+        if len(todo) > 1:
+            parsed = native.dimacs_parse_many([self._dimacs[i][0] for i in todo], threads=min(8, os.cpu_count() or 1))
+            for i, (vn, cn, sv, ci) in zip(todo, parsed):
+                path, label = self._dimacs[i]
+                item = (vn, cn, np.stack((np.abs(sv) - 1, ci - 1)).astype(np.int32), np.sign(sv).astype(np.float32), float(label), [os.path.split(path)[1]])
+                if len(self._cache) < self._max_cache_size:
+                    self._cache[i] = item
+                else:
+                    tmp[i] = item
+        return tmp
 
     def batches(self, batch_size, order=None):
-        """Yields lists of segment batches, ``batch_size`` instances per loader batch (``order``: the sampler's permutation); sets
-        ``self.batch_index`` to the batch's global index before each yield.  A sharded data set yields its own range of batches only."""
+        """Yields one ``SegmentList`` per loader batch of ``batch_size`` instances (``order``: the sampler's permutation) with the batch's
+        global index and the global ids of its segments.  A sharded data set cuts every batch into the same segments as the unsharded
+        one (from the edge counts alone), keeps the segments ``parallel.deal_units`` assigns to its rank, and skips batches of which it
+        owns nothing."""
+        from pdp import parallel
         order = list(range(len(self))) if order is None else list(order)
-        lo, hi = self.batch_range(batch_size, order)
-        for j in range(lo, hi):
-            start = j * batch_size
-            self.batch_index = j
+        loads = [0] * (self._shard[1] if self._shard is not None else 1)
+        for j, start in enumerate(range(0, len(order), batch_size)):
             idx = order[start:start + batch_size]
-            if self._dimacs is not None and len(idx) > 1:
-                # DIMACS files: one call parses the batch's files with a few host threads inside the native library
-                import os
-                from pdp import native
-                todo = [i for i in idx if i not in self._cache]
-                parsed = native.dimacs_parse_many([self._dimacs[i][0] for i in todo], threads=min(8, os.cpu_count() or 1))
-                for i, (vn, cn, sv, ci) in zip(todo, parsed):
-                    path, label = self._dimacs[i]
-                    item = (vn, cn, np.stack((np.abs(sv) - 1, ci - 1)).astype(np.int32), np.sign(sv).astype(np.float32), float(label), [os.path.split(path)[1]])
-                    if len(self._cache) < self._max_cache_size:
-                        self._cache[i] = item
-                    else:
-                        self._cache.setdefault('_tmp', {})[i] = item
-                tmp = self._cache.pop('_tmp', {})
-                items = [self._cache[i] if i in self._cache else tmp[i] for i in idx]
+            tmp = self._parse_batch(idx) if self._dimacs is not None else {}
+            get = lambda i: tmp[i] if i in tmp else self[i]
+            if self._shard is None:
+                out = SegmentList(collate([get(i) for i in idx], self._limit, self._hidden_dim, self._batch_replication))
+                out.segment_ids = list(range(len(out)))
             else:
-                items = [self[i] for i in idx]
-            yield collate(items, self._limit, self._hidden_dim, self._batch_replication)
+                rank, world = self._shard
+                edges = [tmp[i][2].shape[1] if i in tmp else self._edge_count(i) for i in idx]
+                segments = divide(edges, self._limit // self._batch_replication, self._hidden_dim)
+                owners = parallel.deal_units([sum(edges[k] for k in seg) for seg in segments], world, loads)
+                mine = [s for s, o in enumerate(owners) if o == rank]
+                if not mine:
+                    continue
+                out = SegmentList(collate_segment([get(idx[k]) for k in segments[s]]) for s in mine)
+                out.segment_ids = mine
+            out.batch_index = self.batch_index = j
+            yield out
 
     @staticmethod
     def get_loader(input_file, limit, hidden_dim, batch_size, shuffle=False, num_workers=0, max_cache_size=100000,
@@ -243,11 +275,13 @@ class FactorGraphDataset(object):
                     g = torch.Generator(); g.manual_seed(seed)
                     order = torch.randperm(len(ds), generator=g).tolist()
                 for segs in ds.batches(batch_size, order):
-                    yield ([torch.from_numpy(s['graph_map']) for s in segs],
-                           [torch.from_numpy(s['batch_variable_map']) for s in segs],
-                           [torch.from_numpy(s['batch_function_map']) for s in segs],
-                           [torch.from_numpy(s['edge_feature']) for s in segs],
-                           [None for _ in segs],
-                           [torch.from_numpy(s['label']) for s in segs],
-                           [s['misc_data'] for s in segs])
+                    data = LoaderBatch(([torch.from_numpy(s['graph_map']) for s in segs],
+                                        [torch.from_numpy(s['batch_variable_map']) for s in segs],
+                                        [torch.from_numpy(s['batch_function_map']) for s in segs],
+                                        [torch.from_numpy(s['edge_feature']) for s in segs],
+                                        [None for _ in segs],
+                                        [torch.from_numpy(s['label']) for s in segs],
+                                        [s['misc_data'] for s in segs]))
+                    data.index, data.segments = segs.batch_index, list(segs.segment_ids)
+                    yield data
         return _Loader()

@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = [
     'pdp_kernel_timing', 'pdp_kernel_timing_read', 'pdp_kernel_name',
     'pdp_train_linear', 'pdp_train_linear_backward', 'pdp_train_row_sum', 'pdp_train_row_spread', 'pdp_train_gru', 'pdp_train_gru_backward',
     'pdp_sat_loss_grad', 'pdp_train_sp_adapted_backward',
+    'pdp_coo_max', 'pdp_coo_argmax', 'pdp_coo_row_ptr', 'pdp_csr_matmul', 'pdp_csr_smooth_max',
 ]
 
 
@@ -434,6 +435,51 @@ class Problem(object):
                                      solve_kernel_ms=float(a.solve_kernel_ms_host), replay_kernel_ms=float(a.replay_kernel_ms_host),
                                      hbm_instances=int(a.hbm_instances_host))
         return int(a.iterations_run_host), bool(a.used_lds_host)
+
+
+# -- the reference's L0 primitives on a sparse COO mask (include/pdp_hip.h: pdp_coo_*, pdp_csr_*) -------------------------------------------
+def coo_reduce(kind, rows, cols, x, n_rows, n_cols):
+    "util.sparse_max ('max') / sparse_argmax ('argmax') of x [nnz] paired with the entries (rows[i], cols[i]) of a [n_rows, n_cols] mask"
+    require_gpu()
+    nnz = int(rows.numel())
+    scratch = torch.empty(n_cols + 2, dtype=torch.int64, device=x.device)
+    out = torch.empty(n_cols, dtype=torch.float32 if kind == 'max' else torch.int64, device=x.device)
+    fn = lib().pdp_coo_max if kind == 'max' else lib().pdp_coo_argmax
+    check(fn(ptr(rows, torch.int64, nnz, 'mask rows'), ptr(cols, torch.int64, nnz, 'mask columns'), C.c_int64(nnz), ptr(x, torch.float32, nnz, 'x'),
+             C.c_int64(n_rows), C.c_int64(n_cols), ptr(scratch), ptr(out), _stream()))
+    return out
+
+
+class CsrMask(object):
+    "row offsets / columns / values of the row-sorted entries of a sparse mask [n_rows, n_cols] (built once per mask, cached on the tensor)"
+
+    def __init__(self, mask):
+        require_gpu()
+        m = mask if mask.is_coalesced() else mask.coalesce()
+        idx = m.indices()
+        self.n_rows, self.n_cols = int(mask.size(0)), int(mask.size(1))
+        self.rows = idx[0].contiguous()
+        self.cols = idx[1].contiguous()
+        self.vals = m.values().to(torch.float32).contiguous()
+        self.nnz = int(self.cols.numel())
+        self.row_ptr = torch.empty(self.n_rows + 1, dtype=torch.int64, device=mask.device)
+        check(lib().pdp_coo_row_ptr(ptr(self.rows, torch.int64), C.c_int64(self.nnz), C.c_int64(self.n_rows), ptr(self.row_ptr), _stream()))
+
+    def matmul(self, X, sub=None):
+        "mask @ X (- sub): X [n_cols, d] dense"
+        d = int(X.size(1))
+        if X.size(0) != self.n_cols:
+            raise NativeError("mask [%d, %d] times a matrix with %d rows" % (self.n_rows, self.n_cols, X.size(0)))
+        out = torch.empty(self.n_rows, d, dtype=torch.float32, device=X.device)
+        check(lib().pdp_csr_matmul(ptr(self.row_ptr), ptr(self.cols), ptr(self.vals), C.c_int64(self.n_rows), ptr(X, torch.float32, self.n_cols * d, 'X'),
+                                   C.c_int(d), C.c_int64(d), ptr(sub, torch.float32, self.n_rows * d, 'sub') if sub is not None else None, ptr(out), _stream()))
+        return out
+
+    def smooth_max(self, x, alpha):
+        out = torch.empty(self.n_rows, 1, dtype=torch.float32, device=x.device)
+        check(lib().pdp_csr_smooth_max(ptr(self.row_ptr), ptr(self.cols), ptr(self.vals), C.c_int64(self.n_rows), ptr(x, torch.float32, self.n_cols, 'x'),
+                                       C.c_float(alpha), ptr(out), _stream()))
+        return out
 
 
 def dimacs_parse(path):

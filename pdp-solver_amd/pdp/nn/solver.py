@@ -13,6 +13,7 @@ Keeps the reference's class names, constructor arguments and ``forward`` / ``get
 """
 
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -27,6 +28,22 @@ from pdp.nn import pdp_propagate, pdp_decimate, pdp_predict, util
 
 class SATProblem(object):
     "A batch of CNF instances resident in HBM (reference: solver.py:19-285)."
+
+    _live = weakref.WeakValueDictionary()         # id(graph tensor) -> problem that owns it (see handle_of)
+
+    @classmethod
+    def handle_of(cls, graph_map, variable_count):
+        """The native handle of the live problem that owns ``graph_map`` (its ``_graph_map`` attribute, or the tensor it was built from) and
+        has ``variable_count`` variables: lets the evaluators, which the reference calls with bare tensors (trainer.py:153-155), reuse the
+        resident batch instead of rebuilding it.  None if there is no such problem."""
+        p = cls._live.get(id(graph_map))
+        if p is None:
+            return None
+        if graph_map is p._graph_map and variable_count == p._variable_num:
+            return p._native
+        if graph_map is p._orig[0] and variable_count * p._batch_replication == p._variable_num:
+            return p._native if p._batch_replication == 1 else p._native_unreplicated()
+        return None
 
     def __init__(self, data_batch, device, batch_replication=1):
         self._device = device
@@ -56,6 +73,8 @@ class SATProblem(object):
         self._is_sat = self._native.is_sat
         self._edge_mask = None
         self._masks = {}
+        SATProblem._live[id(self._graph_map)] = self
+        SATProblem._live[id(graph_map)] = self
 
     def _native_unreplicated(self):
         "handle on the original (non-replicated) batch, used by evaluators that look at de-duplicated predictions"
@@ -84,8 +103,23 @@ class SATProblem(object):
         return torch.sparse_coo_tensor(torch.stack([rows.long(), cols.long()]), vals, shape, device=self._device)
 
     def _mask_tuple(self, kind):
+        """The reference's mask tuples (solver.py:84-178) as real torch sparse tensors, built on first use.  Each tensor is tagged with
+        (problem, tuple, position) so that pdp.nn.util maps it back to the resident layout when a plug-in hands it to sparse_max /
+        sparse_argmax / sparse_smooth_max / MessageAggregator; torch.mm on them works as in the reference."""
         if kind in self._masks:
             return self._masks[kind]
+        if kind == 'replication':
+            # solver.py:84-99: replica r of instance i is row i + r * B0; None without replication (the reference has no attribute then;
+            # its _deduplicate tests `_batch_replication <= 1` first, solver.py:404)
+            out = None
+            if self._batch_replication > 1:
+                B, R = self._batch_size, self._batch_replication
+                b0 = B // R
+                m = self._sparse(torch.arange(B, device=self._device), torch.arange(b0, device=self._device).repeat(R),
+                                 torch.ones(B, device=self._device), (B, b0))
+                out = (util.tag_mask(m, self, kind, 0), util.tag_mask(m.transpose(0, 1), self, kind, 1))
+            self._masks[kind] = out
+            return out
         gm, E, V, F, B = self._graph_map, self._edge_num, self._variable_num, self._function_num, self._batch_size
         er = torch.arange(E, device=self._device)
         ef = self._edge_feature.reshape(-1)
@@ -104,6 +138,7 @@ class SATProblem(object):
             out = (m, m.transpose(0, 1), sm, sm.transpose(0, 1))
         else:
             raise KeyError(kind)
+        out = tuple(util.tag_mask(t, self, kind, i) for i, t in enumerate(out))
         self._masks[kind] = out
         return out
 
@@ -113,6 +148,7 @@ class SATProblem(object):
     _signed_mask_tuple = property(lambda self: self._mask_tuple('signed'))
     _batch_mask_tuple = property(lambda self: self._mask_tuple('batch'))
     _vf_mask_tuple = property(lambda self: self._mask_tuple('vf'))
+    _replication_mask_tuple = property(lambda self: self._mask_tuple('replication'))
 
 
 ###############################################################
@@ -181,17 +217,23 @@ class PropagatorDecimatorSolverBase(nn.Module):
                 plug_in._train_path = train_path
         self.last_run['train_path'] = train_path
 
-        if simplify and not is_training:
-            sat_problem.simplify()
+        try:
+            if simplify and not is_training:
+                sat_problem.simplify()
 
-        if self._propagator is not None and self._decimator is not None:
-            propagator_state, decimator_state = self._forward_core(init_propagator_state, init_decimator_state,
-                                                                   sat_problem, iteration_num, is_training, check_termination)
-        else:
-            decimator_state = None
-            propagator_state = None
+            if self._propagator is not None and self._decimator is not None:
+                propagator_state, decimator_state = self._forward_core(init_propagator_state, init_decimator_state,
+                                                                       sat_problem, iteration_num, is_training, check_termination)
+            else:
+                decimator_state = None
+                propagator_state = None
 
-        prediction = self._predictor(decimator_state, sat_problem, True)
+            prediction = self._predictor(decimator_state, sat_problem, True)
+        finally:
+            # the pin lives for this forward only: a plug-in called on its own afterwards decides by is_training / grad mode again
+            for plug_in in (self._propagator, self._decimator, self._predictor):
+                if plug_in is not None:
+                    plug_in._train_path = None
 
         if not is_training:
             prediction = self._local_search(prediction, sat_problem, batch_replication)

@@ -84,6 +84,26 @@ class RowAggregate(torch.autograd.Function):
         return ds, None, None, None
 
 
+class MaskMatmul(torch.autograd.Function):
+    """torch.mm(mask, x) for an arbitrary sparse mask (util.py:60,63 with a mask that is not a SATProblem's own): entries in row-sorted order,
+    added per row in ascending entry order (pdp_csr_matmul).  The adjoint is the same product with the transposed mask."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        from pdp.nn import util
+        ctx.mask = mask
+        return util._csr(mask).matmul(_f(x))
+
+    @staticmethod
+    def backward(ctx, dout):
+        from pdp.nn import util
+        mt = getattr(ctx.mask, '_pdp_transposed', None)
+        if mt is None:
+            mt = ctx.mask.transpose(0, 1)
+            ctx.mask._pdp_transposed = mt
+        return util._csr(mt).matmul(_f(dout)), None
+
+
 class GruCell(torch.autograd.Function):
     "torch.nn.GRUCell (gate order r, z, n) on the fp32 matrix cores"
 

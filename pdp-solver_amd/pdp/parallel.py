@@ -1,16 +1,23 @@
-"""Batch-sharded data parallelism: one process per GPU, no collective on the data path.
+"""Segment-sharded data parallelism: one process per GPU, no collective on the data path.
 
 The reference has no working multi-GPU path (``nn.DataParallel`` would scatter ``graph_map`` along dim 0, SURVEY.md
-App. B-13).  No message crosses an instance boundary, but the reference couples the instances of one *loader batch* (base.py:252-278
-loops the DataLoader's batches, dataset.py:189-211): batch-global minima inside sparse_max / argmax, one NaN survey that stops the
-decimation of the whole batch, the dynamic segments cut from the batch's edge counts (dataset.py:36-72).  The unit
-that is dealt to ranks is therefore the WHOLE LOADER BATCH: the loader forms the same batches (and the same segments) whatever the
-rank count, rank r solves a contiguous range of them (``deal_batches``, balanced by input size) completely on its own GPU, random
-numbers are keyed by the global batch / segment index (``batch_seed``), and the ranks meet exactly once, in an all-reduce(sum) of
-``[instances, solved, unsat clauses]`` -- in test mode of the metric sums ``[accuracy, recall, loss]`` and the example count -- (RCCL
-over xGMI on a node: ``backend='nccl'``; the tests use ``gloo``).  Result rows are gathered in rank order, which is batch order.  An
-N-rank run therefore writes exactly the rows of the 1-rank run (tests/test_parallel_gloo.py, tests/test_sharded_gpu.py).
-BASELINE configs[3]: 40 000 instances with ``-z 5000`` are 8 loader batches, one per GPU.
+App. B-13).  No message crosses an instance boundary, but the reference couples the instances of one ``forward`` call: batch-global
+minima inside sparse_max / argmax, one NaN survey that stops the decimation of everything in the call.  One
+``forward`` is one dynamic SEGMENT of a loader batch (base.py:252-278 loops ``for i in range(len(data[0]))`` over the segments
+``DynamicBatchDivider.divide`` cut from the batch's edge counts, dataset.py:24-74) -- so the segment, not the loader batch, is the unit
+that may move between GPUs without changing a row.  Every rank enumerates the same (loader batch, segment) units (the loader forms the
+batches and cuts the segments from the edge counts alone, without collating anything), the units of a batch are dealt by
+longest-processing-time-first on their edge counts onto the least loaded rank (``deal_units``; the loads carry over from batch to
+batch, so a run of many one-segment batches and a run of one batch with many segments both keep every GPU busy), random numbers are
+keyed by the global (batch, segment) index (``batch_seed``), and the ranks meet exactly once, in an all-reduce(sum) of ``[instances,
+solved, unsat clauses]`` -- in test mode of the metric sums ``[accuracy, recall, loss]`` and the example count -- (RCCL over xGMI on a
+node: ``backend='nccl'``; the CPU tests use ``gloo``).  Result rows travel with their unit index and rank 0 writes them in unit order,
+which is the single-process order.  An N-rank run therefore writes exactly the rows of the 1-rank run (tests/test_parallel_gloo.py,
+tests/test_sharded_gpu.py).  BASELINE configs[3]: 40 000 instances with ``-z 5000`` are 8 one-segment batches, one per GPU;
+configs[4] (dynamic batching, ``-b 4``): a loader batch falls into many segments, which spread over the 8 GPUs.
+
+What could split further: ``--isolated`` removes the couplings inside a segment, so there single instances could be dealt; and the
+strict semantics could be kept across GPUs with a two-flag all-reduce per sweep.  Neither is built.
 
 ``shard_bounds`` / ``shard_items`` cut ONE batch by instances; only bench.py uses that (its synthetic batch has no loader and is timed
 in ``--isolated``-equivalent weak scaling: every rank generates its own B instances).
@@ -50,10 +57,24 @@ def shard_bounds(edge_counts, world_size):
 
 
 def deal_batches(batch_weights, world_size):
-    """Contiguous ranges [lo, hi) of loader-batch indices per rank, balanced by the batches' weights (input bytes as the proxy of the
-    edge count -- no rank parses another rank's instances).  Contiguous, so the rank-ordered gather of the rows is the loader's order.
-    With fewer batches than ranks the last ranks get an empty range: a batch is the reference's coupling domain and is never split."""
+    """Contiguous ranges [lo, hi) of loader-batch indices per rank, balanced by the batches' weights.  (The round-3 dealer; the predict
+    path now deals segments with ``deal_units``.  Kept for callers that want contiguous ranges.)"""
     return shard_bounds(batch_weights, world_size)
+
+
+def deal_units(weights, world_size, loads=None):
+    """Owner rank of each unit (segment) of one loader batch: the units are taken heaviest first (ties: lowest index) and each goes to the
+    rank with the smallest load so far (ties: lowest rank).  ``loads`` (a list of ``world_size`` numbers, updated in place) carries the
+    load from batch to batch.  Pure function of its arguments: every rank computes the same table, nothing is exchanged."""
+    world_size = int(world_size)
+    if loads is None:
+        loads = [0] * world_size
+    owners = [0] * len(weights)
+    for u in sorted(range(len(weights)), key=lambda k: (-int(weights[k]), k)):
+        r = min(range(world_size), key=lambda k: (loads[k], k))
+        owners[u] = r
+        loads[r] += int(weights[u])
+    return owners
 
 
 def batch_seed(seed, batch_index, segment_index=0):
@@ -102,20 +123,35 @@ def gather_rows(rows, group=None):
     return [r for part in out for r in part]
 
 
-def solve_sharded(batches, solve_fn, rank=None, world_size=None, device=None):
-    """``batches``: the loader batches of the run (lists of loader items), the same list on every rank.  Runs
-    ``solve_fn(items, batch_index) -> (solved [b], unsat [b], rows list)`` on the batches dealt to this rank and reduces the counters;
-    returns (stats, all rows in loader order, this rank's [lo, hi) batch range).  ``solve_fn`` is the native forward in production and
-    the CPU oracle in the gloo tests."""
+def gather_units(units, group=None):
+    """``units``: this rank's [((batch, segment), payload), ...].  Returns the payloads of all ranks in (batch, segment) order -- the order
+    the single-process run produces them in.  A rank without units contributes an empty list."""
+    return [payload for _, payload in sorted(gather_rows(units, group), key=lambda kv: kv[0])]
+
+
+def solve_sharded(batches, solve_fn, rank=None, world_size=None, device=None, limit=None, hidden_dim=1):
+    """``batches``: the loader batches of the run (lists of loader items), the same list on every rank; ``limit`` / ``hidden_dim``: the
+    dynamic-batching budget that cuts a batch into segments (None: one segment per batch).  Runs ``solve_fn(items, batch_index,
+    segment_index) -> (solved [b], unsat [b], rows list)`` on the units dealt to this rank and reduces the counters; returns (stats, all
+    rows in single-process order, this rank's [(batch, segment), ...]).  ``solve_fn`` is the native forward in production and the CPU
+    oracle in the gloo tests."""
+    from pdp.factorgraph import dataset
     if world_size is None:
         world_size = dist.get_world_size() if dist.is_initialized() else 1
     if rank is None:
         rank = dist.get_rank() if dist.is_initialized() else 0
-    lo, hi = deal_batches([sum(it[2].shape[1] for it in b) for b in batches], world_size)[rank]
     n = n_solved = n_unsat = 0
-    rows = []
-    for j in range(lo, hi):
-        solved, unsat, r = solve_fn(batches[j], j)
-        n += len(batches[j]); n_solved += float(np.sum(solved)); n_unsat += float(np.sum(unsat)); rows += list(r)
+    units, mine, loads = [], [], [0] * world_size
+    for j, batch in enumerate(batches):
+        edges = [it[2].shape[1] for it in batch]
+        segments = [list(range(len(batch)))] if limit is None else dataset.divide(edges, limit, hidden_dim)
+        owners = deal_units([sum(edges[k] for k in seg) for seg in segments], world_size, loads)
+        for i, seg in enumerate(segments):
+            if owners[i] != rank:
+                continue
+            items = [batch[k] for k in seg]
+            solved, unsat, r = solve_fn(items, j, i)
+            n += len(items); n_solved += float(np.sum(solved)); n_unsat += float(np.sum(unsat))
+            units.append(((j, i), list(r))); mine.append((j, i))
     stats = reduce_stats(n, n_solved, n_unsat, device=device)
-    return stats, gather_rows(rows), (lo, hi)
+    return stats, [row for part in gather_units(units) for row in part], mine

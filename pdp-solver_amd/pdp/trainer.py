@@ -63,6 +63,11 @@ class SatFactorGraphTrainer(FactorGraphTrainerBase):
             # random initial states (training / test mode): the reference's CPU stream by default, 'device' for throughput
             for plug_in in (model._propagator, model._decimator):
                 plug_in._init_rng = config.get('init_rng', 'torch')
+            if config.get('dropout', 0) or config.get('init_rng', 'torch') != 'torch':
+                # said once: a YAML with `rng: torch` and a seed no longer pins these two streams to the reference's --cpu_mode draws by itself
+                self._logger.info("random sources: dropout masks from %r (config key dropout_rng), random initial states from %r (init_rng), random fill / "
+                                  "Walk-SAT from %r (rng); 'torch' = the reference's global CPU stream" % (model._propagator._rng if hasattr(model._propagator, '_rng') else 'n/a',
+                                                                                                        config.get('init_rng', 'torch'), rng))
         else:
             raise KeyError("unknown model_type %r" % (t,))
         if config.get('verbose'):

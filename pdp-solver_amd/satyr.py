@@ -104,8 +104,11 @@ def main(argv=None):
     config['persistent'] = not config['stepwise']
 
     # one process per GPU under torch.distributed.run: instances are sharded across the ranks (pdp/factorgraph/base.py::predict)
+    # PDP_DIST_FORCE=1 joins the process group at world size 1 as well (torch.distributed.run --nproc-per-node 1): the all-reduce and the
+    # row gather then run through RCCL on a one-GPU box exactly as they do on eight
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world > 1:
+    grouped = world > 1 or (os.environ.get('PDP_DIST_FORCE') == '1' and 'RANK' in os.environ)
+    if grouped:
         import torch.distributed as dist
         # PDP_DIST_BACKEND=gloo lets several ranks share one GPU (checks of the sharded path on a single-GPU box); RCCL needs one GPU each
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % max(1, torch.cuda.device_count()))
@@ -115,7 +118,7 @@ def main(argv=None):
     finally:
         if temp_file_name is not None and os.path.exists(temp_file_name):
             os.remove(temp_file_name)
-        if world > 1:
+        if grouped:
             import torch.distributed as dist
             dist.destroy_process_group()
     if world == 1 or int(os.environ.get('RANK', '0')) == 0:

@@ -1194,6 +1194,54 @@ def gen_subsumption():
 
 # ---- E. CLI -------------------------------------------------------------------------------------
 
+def gen_foreign_plugin():
+    """tests/golden/foreign_plugin.py -- a plug-in triple written against the reference's API only -- run INSIDE the reference (CPU): records
+    the batch, the parameters the reference's constructors drew, the per-sweep integer trajectory (which variable each instance fixed, the
+    active flags, the active mask), the scores behind the decisions, the final states and the prediction.  The generator refuses a fixture
+    that sits on a near tie (relative gap between the best and the second-best candidate of a decision below 1e-3)."""
+    spec = importlib.util.spec_from_file_location('foreign_plugin', os.path.join(HERE, 'foreign_plugin.py'))
+    fp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fp)                 # `from pdp.nn import solver, util` resolves to the reference here
+    assert fp.util is RU and fp.solver is RS
+    lines = make_lines([(30, 96, (3,)), (24, 70, (2, 3, 4)), (36, 120, (3,)), (28, 80, (3, 4)), (20, 64, (3,)), (32, 100, (2, 3))], seed0=7700)
+    gm, bvm, bfm, ef, lab, misc = batch_tensors(lines)
+    dev = torch.device('cpu')
+    T, R, w = 14, 2, 6
+    for seed in range(99, 140):                 # the first run seed whose decisions are all clear of a tie
+        model = fp.build_solver(dev, local_search_iterations=w)
+        RAND_LOG.clear()
+        torch.rand = _rec_rand
+        try:
+            out = fp.run(model, dev, gm, bvm, bfm, ef, iterations=T, batch_replication=R, seed=seed)
+        finally:
+            torch.rand = _TORCH_RAND
+        trace = out['trace']
+        margins = np.array([t['margin'] for t in trace], np.float64)
+        decided = np.stack([np_(t['decided']) for t in trace])
+        if margins.min() > 1e-3 and (decided >= 0).sum() >= 8:
+            break
+    assert (decided >= 0).sum() >= 8, "the fixture should contain decimation steps"
+    assert margins.min() > 1e-3, "a decision of the fixture sits on a near tie: %r" % (margins,)
+    arrs = problem_arrays(gm, bvm, bfm, ef)
+    for k, v in model.state_dict().items():
+        arrs['w::' + k] = np_(v)
+    for i, x in enumerate(out['states'][0]):
+        arrs['final_prop_%d' % i] = np_(x)
+    for i, x in enumerate(out['states'][1]):
+        arrs['final_dec_%d' % i] = np_(x)
+    save('foreign_plugin', meta=np.array([T, w, seed, R], np.int64), rand_sizes=np.array([r.size for r in RAND_LOG], np.int64),
+         trace_decided=decided, trace_margin=margins,
+         trace_active_variables=np.stack([np_(t['active_variables']) for t in trace]),
+         trace_active_functions=np.stack([np_(t['active_functions']) for t in trace]),
+         trace_active_mask=np.stack([np_(t['active_mask']) for t in trace]),
+         trace_score=np.stack([np_(t['score']) for t in trace]), trace_pressure=np.stack([np_(t['pressure']) for t in trace]),
+         check_log=np.array(out['check_log'], np.float64), final_prediction=np_(out['prediction'])[:, 0],
+         final_solved=np_(out['solved'])[:, 0], final_unsat=np_(out['unsat'])[:, 0],
+         counts_variables=np_(out['counts'][0])[:, 0], counts_functions=np_(out['counts'][1])[:, 0], **arrs)
+    print('foreign_plugin: %d sweeps recorded, %d decisions, smallest decision gap %.3g, solved %s'
+          % (len(trace), int((decided >= 0).sum()), margins.min(), np_(out['solved'])[:, 0].astype(int).tolist()))
+
+
 def gen_cli():
     import runpy
     import shutil
@@ -1285,6 +1333,8 @@ if __name__ == '__main__':
         am = d['trace_active_mask']
         print('rf_leak: iterations', int(d['iterations_run'][0]), 'instance 0 inactive from', int(np.argmax(am[:, 0] == 0)), 'NaN entries in the final state',
               int(np.isnan(d['final_dec_1']).sum()), int(np.isnan(d['final_dec_0']).sum()), 'at sweep 75/76/77:', [int(np.isnan(d['prop_fs_%d' % t]).sum()) for t in (75, 76, 77)])
+    if 'foreign' in what:
+        gen_foreign_plugin()
     if 'cli' in what:
         gen_cli()
     if 'config0' in what:

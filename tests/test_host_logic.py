@@ -207,11 +207,12 @@ def test_native_dimacs_batch_reader(tmp_path):
         native.dimacs_parse_many(paths[:5] + [str(bad)] + paths[5:9], threads=3)
 
 
-def test_dataset_deals_whole_loader_batches_to_ranks(tmp_path):
-    """one process per GPU: every rank's loader forms the batches of the single-process run and iterates a contiguous range of whole
-    batches; together the ranks cover every batch once, in order, with the global batch index the random key is derived from"""
+def test_dataset_deals_segments_to_ranks(tmp_path):
+    """one process per GPU: every rank's loader forms the batches of the single-process run, cuts them into the same dynamic segments
+    (from the edge counts alone) and collates the segments dealt to it; together the ranks cover every (batch, segment) unit exactly
+    once with the content of the single-process run, and ONE loader batch that falls into several segments keeps several ranks busy"""
     from pdp.factorgraph import dataset
-    from pdp import generator
+    from pdp import generator, parallel
     lines = []
     for i in range(23):
         n = 10 + 3 * (i % 5)
@@ -219,20 +220,46 @@ def test_dataset_deals_whole_loader_batches_to_ranks(tmp_path):
         lines.append(generator.json_line(n, cl, label=i % 2, name='x%d' % i))
     path = tmp_path / 'in.json'
     path.write_text("\n".join(lines) + "\n")
-    ids = lambda segs: [[m[0] for m in s['misc_data']] for s in segs]
-    for z, limit in ((5, 10 ** 9), (4, 3 * 90 * 2)):                 # the second limit cuts every batch into dynamic segments
+    for l in lines:                                                  # the edge count read off the line = the parsed one
+        assert dataset.json_edge_count(l) == dataset.parse_line(l)[2].shape[1]
+    assert dataset.json_edge_count('[[1, 0], [], [], 0, []]') == 0 and dataset.json_edge_count('[[1,1],[1],[1],0,[]]') == 1
+    ids = lambda seg: [m[0] for m in seg['misc_data']]
+    for z, limit in ((5, 10 ** 9), (4, 3 * 90 * 2), (23, 3 * 90 * 2)):    # the 2nd / 3rd limit cut every batch into dynamic segments; 3rd: ONE batch
         whole = dataset.FactorGraphDataset(str(path), limit, 3)
-        expected = [(whole.batch_index, ids(segs)) for segs in whole.batches(z)]
-        assert [j for j, _ in expected] == list(range((23 + z - 1) // z))
-        assert limit == 10 ** 9 or max(len(s) for _, s in expected) > 1
+        expected = {}
+        for segs in whole.batches(z):
+            assert segs.segment_ids == list(range(len(segs)))
+            for i, seg in zip(segs.segment_ids, segs):
+                expected[(segs.batch_index, i)] = (ids(seg), seg['graph_map'].tolist())
+        assert sorted({j for j, _ in expected}) == list(range((23 + z - 1) // z))
+        assert limit == 10 ** 9 or len(expected) > (23 + z - 1) // z
         for world in (2, 3, 8):
-            got, ranges = [], []
+            got, per_rank = {}, []
             for rank in range(world):
                 ds = dataset.FactorGraphDataset(str(path), limit, 3, shard=(rank, world))
-                ranges.append(ds.batch_range(z))
-                got += [(ds.batch_index, ids(segs)) for segs in ds.batches(z)]
+                mine = 0
+                for segs in ds.batches(z):
+                    assert len(segs) == len(segs.segment_ids) > 0
+                    for i, seg in zip(segs.segment_ids, segs):
+                        assert (segs.batch_index, i) not in got
+                        got[(segs.batch_index, i)] = (ids(seg), seg['graph_map'].tolist())
+                        mine += seg['graph_map'].shape[1]
+                per_rank.append(mine)
             assert got == expected
-            assert ranges[0][0] == 0 and ranges[-1][1] == len(expected) and all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+            busy = sum(1 for e in per_rank if e > 0)
+            assert busy == min(world, len(expected))                    # also with a single loader batch (z = 23)
+            if len(expected) >= 4 * world:
+                assert max(per_rank) <= sum(per_rank) / world + max(len(v[1][0]) for v in expected.values())
+    # the dealer: heaviest first onto the least loaded rank, loads carried across batches, a pure function
+    assert parallel.deal_units([5, 9, 5, 1], 2) == [1, 0, 1, 0]
+    loads = [0, 0, 0]
+    assert parallel.deal_units([4], 3, loads) == [0] and parallel.deal_units([4], 3, loads) == [1] and parallel.deal_units([4, 4], 3, loads) == [2, 0]
+    assert loads == [8, 4, 4]
+    assert parallel.deal_units([], 4) == []
+    # the loader tuple says where it sits in the run
+    loader = dataset.FactorGraphDataset.get_loader(str(path), 3 * 90 * 2, 3, 4, shard=(1, 2))
+    seen = [(d.index, d.segments, len(d[0])) for d in loader]
+    assert seen and all(len(segs) == n for _, segs, n in seen) and all(isinstance(d, tuple) and len(d) == 7 for d in loader)
 
 
 def test_cnf_generators_reproduce_the_reference_for_a_seed():

@@ -1,6 +1,7 @@
-"""world_size-2 gloo tests (CPU): dealing whole loader batches to ranks + the single all-reduce of the multi-GPU path.  The per-batch
-solve is the CPU oracle here (the checker standing in for the GPU forward; its forward has the reference's batch-wide couplings), so
-the test pins the property the design relies on: an N-rank run writes the rows and totals of the 1-rank run."""
+"""world_size-2 gloo tests (CPU): dealing (loader batch, segment) units to ranks + the single all-reduce of the multi-GPU path.  The
+per-unit solve is the CPU oracle here (the checker standing in for the GPU forward; its forward has the reference's couplings between
+the instances of one call), so the test pins the property the design relies on: an N-rank run writes the rows and totals of the 1-rank
+run."""
 import os
 import sys
 
@@ -42,14 +43,14 @@ def _run_batches(items, z=12):
     return [items[s:s + z] for s in range(0, len(items), z)]
 
 
-def _oracle_solve(items, batch_index, want_nan=None):
-    """one loader batch through the oracle's strict (batch-coupled) p-d-p forward with the Philox key of that batch"""
+def _oracle_solve(items, batch_index, segment_index=0, want_nan=None):
+    """one unit (segment of a loader batch) through the oracle's strict (coupled) p-d-p forward with the Philox key of that unit"""
     sys.path.insert(0, REPO)
     from oracle import binding
     b = dataset.collate_segment(items)
     p = binding.Problem(b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'])
     res = p.forward('p-d-p', T_RUN, local_search_iterations=W_RUN, tolerance=TOL_RUN, t_max=TMAX_RUN,
-                    seed=parallel.batch_seed(SEED_RUN, batch_index))
+                    seed=parallel.batch_seed(SEED_RUN, batch_index, segment_index))
     if want_nan is not None:
         want_nan.append(bool(np.isnan(res['fs']).any()))
     solved, unsat = p.cnf_eval(res['prediction'])
@@ -58,39 +59,43 @@ def _oracle_solve(items, batch_index, want_nan=None):
     return solved, unsat, rows
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, z=12, limit=None):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    stats, rows, (lo, hi) = parallel.solve_sharded(_run_batches(_run_items()), _oracle_solve)
-    q.put((rank, stats, rows, (lo, hi)))
+    stats, rows, mine = parallel.solve_sharded(_run_batches(_run_items(), z), _oracle_solve, limit=limit)
+    q.put((rank, stats, rows, mine))
     dist.destroy_process_group()
+
+
+def _spawn(world, port, *args):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return got
 
 
 def test_sharded_run_writes_the_rows_of_the_unsharded_run():
     """The property BASELINE's "identical solved-fraction at 8 GPUs" rests on: a run on N ranks = the run on one rank, row for row.
     Five loader batches, three of them NaN-poisoned (there the reference's batch-wide couplings decide which variables are still
-    decimated, so the rows depend on which instances share a batch); two ranks deal WHOLE batches and key the random numbers by the global
-    batch index.  The expected rows come from one process that solves all five batches in order."""
+    decimated, so the rows depend on which instances share a forward call); two ranks deal whole units and key the random numbers by the
+    global (batch, segment) index.  The expected rows come from one process that solves all five batches in order."""
     items = _run_items()
     batches = _run_batches(items)
     nan_seen, exp_rows, exp_solved, exp_unsat = [], [], 0, 0
     for j, b in enumerate(batches):
-        s, u, r = _oracle_solve(b, j, nan_seen)
+        s, u, r = _oracle_solve(b, j, 0, nan_seen)
         exp_rows += r; exp_solved += int(np.sum(s)); exp_unsat += int(np.sum(u))
     assert sum(nan_seen) >= 2, "the test input no longer poisons a batch: pick other seeds"
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    got = sorted([q.get(timeout=300) for _ in range(2)], key=lambda x: x[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    ranges = [g[3] for g in got]
-    assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == len(batches) and all(hi > lo for lo, hi in ranges)
+    got = _spawn(2, 29500 + (os.getpid() % 2000))
+    units = [g[3] for g in got]
+    assert sorted(units[0] + units[1]) == [(j, 0) for j in range(len(batches))] and all(len(u) >= 2 for u in units)
     for rank, stats, rows, _ in got:
         assert stats == dict(instances=60, solved=exp_solved, unsat_clauses=exp_unsat, solved_fraction=exp_solved / 60.0)
         assert rows == exp_rows
@@ -102,6 +107,55 @@ def test_sharded_run_writes_the_rows_of_the_unsharded_run():
         for j, b in enumerate(_run_batches(part)):
             cut_rows += _oracle_solve(b, j)[2]
     assert [r[0] for r in cut_rows] == [r[0] for r in exp_rows] and cut_rows != exp_rows
+
+
+def test_one_loader_batch_cut_into_segments_keeps_both_ranks_busy():
+    """configs[4]'s shape in small: ONE loader batch (-z 60) that the dynamic-batching budget cuts into >= 4 segments.  The segments are
+    the reference's forward calls, so they are what is dealt: every one of two (and of three) ranks gets work, and the rows equal the
+    single-process rows of the same segments in segment order."""
+    items = _run_items()
+    edges = [it[2].shape[1] for it in items]
+    limit = 14 * max(edges)
+    segments = dataset.divide(edges, limit, 1)
+    assert len(segments) >= 4
+    exp_rows, exp_solved, exp_unsat = [], 0, 0
+    for i, seg in enumerate(segments):
+        s, u, r = _oracle_solve([items[k] for k in seg], 0, i)
+        exp_rows += r; exp_solved += int(np.sum(s)); exp_unsat += int(np.sum(u))
+    for world, port in ((2, 33500), (3, 35500)):
+        got = _spawn(world, port + (os.getpid() % 2000), 60, limit)
+        units = [g[3] for g in got]
+        assert sorted(sum(units, [])) == [(0, i) for i in range(len(segments))] and all(len(u) >= 1 for u in units)
+        for rank, stats, rows, _ in got:
+            assert stats == dict(instances=60, solved=exp_solved, unsat_clauses=exp_unsat, solved_fraction=exp_solved / 60.0)
+            assert rows == exp_rows
+
+
+def _idle_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    stats, rows, mine = parallel.solve_sharded([_run_items()[:6]], _oracle_solve)          # one unit, two ranks
+    q.put((rank, stats, rows, mine))
+    dist.destroy_process_group()
+
+
+def test_a_rank_without_units_still_meets_the_collectives():
+    "fewer units than ranks: the idle rank contributes zeros to the all-reduce and an empty list to the gather, and sees the full result"
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 37500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_idle_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    s, u, r = _oracle_solve(_run_items()[:6], 0, 0)
+    assert got[0][3] == [(0, 0)] and got[1][3] == []
+    for rank, stats, rows, _ in got:
+        assert stats['instances'] == 6 and stats['solved'] == int(np.sum(s)) and rows == r
 
 
 def test_deal_batches_and_batch_seed():

@@ -1,8 +1,9 @@
 """N ranks = 1 rank, row for row (BASELINE's "identical solved-fraction at 8 GPUs"), on the GPU through the CLI.
 
 The box has one GPU, so the two ranks share it (gloo instead of RCCL: RCCL wants one GPU per rank; the data path has no collective, the
-single all-reduce of the counters and the gather of the rows work the same on both back ends).  The unsharded run is the same satyr.py in
-one process.  Inputs have at least three loader batches; the middle batch of the p-d-p input is the NaN-poisoned one of
+single all-reduce of the counters and the gather of the rows work the same on both back ends).  RCCL itself runs at world size 1
+(PDP_DIST_FORCE=1: test_rccl_runs_the_collectives_at_world_size_one).  The unsharded run is the same satyr.py in one process.
+Inputs have at least three loader batches; the middle batch of the p-d-p input is the NaN-poisoned one of
 tests/golden/headline_n200_poison.npz (reference run: first NaN at sweep 81, nothing of the batch is decimated afterwards), so the
 rows depend on which instances share a batch -- the coupling domain the dealer must keep (reference: base.py:252-278, dataset.py:189-211).
 """
@@ -29,15 +30,19 @@ def _lines(items):
     return out
 
 
-def _run(argv, ranks, out, port):
+def _run(argv, ranks, out, port, force_env=None):
     env = dict(os.environ)
-    if ranks > 1:
+    if force_env:
+        env.update(force_env)
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks), '--master-addr', '127.0.0.1',
+               '--master-port', str(port), SATYR] + argv + ['-o', out]
+    elif ranks > 1:
         env['PDP_DIST_BACKEND'] = 'gloo'
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks), '--master-addr', '127.0.0.1',
                '--master-port', str(port), SATYR] + argv + ['-o', out]
     else:
         cmd = [sys.executable, SATYR] + argv + ['-o', out]
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=env, timeout=900)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=env, timeout=900, cwd=REPO)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     return [l for l in open(out).read().split('\n') if l.strip()], r.stderr
 
@@ -65,12 +70,64 @@ def test_two_ranks_write_the_rows_of_one_rank_with_a_poisoned_batch(tmp_path):
     assert tail and ('solved %d,' % sum(r['solved'] for r in rows)) in tail[-1] and ('clauses %d' % sum(r['unsat_clauses'] for r in rows)) in tail[-1]
     # loader batch 1 is the golden's poisoned batch, in its order
     assert [r['ID'] for r in rows[z:2 * z]] == [it[5][0] for it in poison]
-    # --rng torch cannot be dealt to ranks: refused, not silently different
-    env = dict(os.environ, PDP_DIST_BACKEND='gloo')
-    bad = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-                          '--master-port', '29733', SATYR] + [a for a in argv if a not in ('--rng', 'philox')] + ['-o', str(tmp_path / 'bad.jsonl')],
-                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=env, timeout=600)
-    assert bad.returncode != 0 and '--rng philox' in bad.stderr
+    # the default --rng torch cannot be dealt to ranks (one sequential host stream): a model that draws from it is switched to philox
+    # with a warning, and writes the philox rows -- a torch.distributed.run command without --rng keeps working
+    dflt, log = _run([a for a in argv if a not in ('--rng', 'philox')], 2, str(tmp_path / 'dflt.jsonl'), 29733)
+    assert dflt == one and 'switching to --rng philox' in log
+
+
+def test_two_ranks_share_one_loader_batch_cut_into_segments(tmp_path):
+    """configs[4]'s shape: ONE loader batch (-z >= the instance count) that the batch limit cuts into >= 4 dynamic segments, -b 4.  The unit
+    that is dealt is the segment (= one forward call of the reference, base.py:252-278), so both ranks work on the one batch, and the
+    rows are the single-process rows.  p-nd-np draws no random number without Walk-SAT: it runs on two ranks with the default --rng."""
+    import re
+    from pdp.factorgraph import dataset
+    items = []
+    for i in range(40):
+        items += dataset.random_ksat_items(1, 60 + 9 * (i % 7), 3 + (i % 3), seed=97000 + i)
+    path = tmp_path / 'one_batch.json'
+    path.write_text("\n".join(_lines(items)) + "\n")
+    edges = [it[2].shape[1] for it in items]
+    limit = 4 * 3 * max(edges) * 9                      # -b 4, hidden_dim 3 (p-d-p): about nine of the largest instances per segment
+    assert len(dataset.divide(edges, limit // 4, 3)) >= 4
+    base = [str(path), '30', '-z', '64', '-s', '5', '-b', '4', '-l', str(limit), '-v']
+    pdp = [os.path.join(REPO, 'config', 'Predict', 'PDP-p-d-p-sp-pytorch.yaml')] + base + ['-w', '40', '--rng', 'philox']
+    one, _ = _run(pdp, 1, str(tmp_path / 'one.jsonl'), 0)
+    two, log = _run(pdp, 2, str(tmp_path / 'two.jsonl'), 29741)
+    assert len(one) == len(items) and one == two
+    units = {int(m.group(1)): int(m.group(2)) for m in re.finditer(r'rank (\d) of 2 solved (\d+) units', log)}
+    assert set(units) == {0, 1} and min(units.values()) >= 2 and sum(units.values()) == len(dataset.divide(edges, limit // 4, 3))
+    # the hybrid model of configs[4] with the weights trained here, default --rng (nothing is drawn with -w 0): also equal, no switch
+    hyb = [os.path.join(REPO, 'config', 'Predict', 'PDP-p-nd-np-demo-h128.yaml'), str(path), '12', '-z', '64', '-s', '5', '-b', '4', '-w', '0',
+           '-l', str(4 * 128 * max(edges) * 9), '-v']
+    one, _ = _run(hyb, 1, str(tmp_path / 'h_one.jsonl'), 0)
+    two, log = _run(hyb, 2, str(tmp_path / 'h_two.jsonl'), 29743)
+    assert len(one) == len(items) and one == two and 'switching to --rng philox' not in log
+    units = {int(m.group(1)): int(m.group(2)) for m in re.finditer(r'rank (\d) of 2 solved (\d+) units', log)}
+    assert set(units) == {0, 1} and min(units.values()) >= 1
+
+
+def test_rccl_runs_the_collectives_at_world_size_one(tmp_path):
+    """All the collective evidence a one-GPU box can give: under ``torch.distributed.run --nproc-per-node 1`` with PDP_DIST_FORCE=1 the CLI
+    and bench.py join an ``nccl`` (= RCCL) process group of one rank; the device-side all-reduce of the counters, the object gather of
+    the rows, bench.py's barrier + MAX / SUM all-reduces complete on the GPU back end, and the rows equal the run without a group."""
+    from pdp.factorgraph import dataset
+    items = dataset.random_ksat_items(30, 60, 3, seed=98000)
+    path = tmp_path / 'in.json'
+    path.write_text("\n".join(_lines(items)) + "\n")
+    argv = [os.path.join(REPO, 'config', 'Predict', 'PDP-p-d-p-sp-pytorch.yaml'), str(path), '40', '-z', '12', '-s', '3', '-w', '30', '-v']
+    plain, _ = _run(argv, 1, str(tmp_path / 'plain.jsonl'), 0)
+    forced, log = _run(argv, 1, str(tmp_path / 'forced.jsonl'), 29745, force_env={'PDP_DIST_FORCE': '1'})
+    assert len(plain) == 30 and plain == forced
+    assert '(1 ranks, nccl)' in log and 'rank 0 of 1 solved 3 units' in log
+    env = dict(os.environ, PDP_DIST_FORCE='1')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+                        '--master-port', '29747', os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--batch', '400',
+                        '--no-cpu-baseline', '--no-secondary'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=env,
+                       timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    line = json.loads([l for l in r.stdout.split('\n') if l.startswith('{') and '"metric"' in l][-1])
+    assert line['rccl_ranks'] == 1 and line['n_gpus'] == 1 and line['collective_backend'] == 'nccl' and line['value'] > 0
 
 
 def test_two_ranks_equal_one_rank_with_dynamic_segments_and_replication(tmp_path):
