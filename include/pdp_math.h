@@ -47,10 +47,47 @@ PDP_HD float pdp_abs(float x) { return pdp_bits2f(pdp_f2bits(x) & 0x7fffffffu); 
 /* 2^n for -126 <= n <= 127 */
 PDP_HD float pdp_pow2i(int n) { return pdp_bits2f((uint32_t)(n + 127) << 23); }
 
+/* ---- opt-in fast build (-DPDP_FAST_MATH, device code only: libpdp_hip_fast.so) ---------------------------------------------------
+ * Every function of this header keeps its name, domain and special-value behaviour; on the device its value comes from the
+ * transcendental unit (v_exp_f32 = 2^x, v_log_f32 = log2 x, v_rcp_f32; about 1 ulp each) instead of the IEEE-only polynomials below.
+ * The results are NOT the oracle's bits any more -- about 1-2 ulp from them -- so this build is gated by the reference-held fixtures
+ * only (integer trajectories equal, floats within the tolerances written in the tests: tests/test_fast_build_gpu.py), never by the
+ * bit-exact suite; the parity build stays the default.  What the hardware units do not do by themselves is done here explicitly:
+ *   exp: v_exp_f32 flushes denormal results, and 2^(x log2 e) loses |x| 2^-24 in the product -- the argument is split into an integer n and
+ *        a fraction f carried in two floats (the product's exact residual + the low part of log2 e), the unit sees only f in [-0.5, 0.5],
+ *        and v_ldexp_f32 applies 2^n with one correct rounding, also into the denormal range (the reference relies on exp(-92.1) = 1e-40);
+ *   log: v_log_f32 flushes denormal arguments -- v_frexp_mant / v_frexp_exp split x = m 2^e exactly (denormals included, log(1e-40) = -92.1)
+ *        and the unit sees only m in [0.5, 1). */
+#if defined(PDP_FAST_MATH) && (defined(__HIP_DEVICE_COMPILE__))
+#define PDP_FAST_DEVICE 1
+PDP_HD float pdp_fmaxf_dev(float a, float b) { return __builtin_fmaxf(a, b); }     /* v_max_f32 / v_min_f32: the non-NaN operand wins */
+PDP_HD float pdp_fminf_dev(float a, float b) { return __builtin_fminf(a, b); }
+/* e^x for a finite x (any magnitude) or NaN */
+PDP_HD float pdp_hw_expf(float x)
+{
+    const float t = x * 1.44269502162933349609375f;                     /* float(log2 e) */
+    const float n = __builtin_rintf(t);                                   /* v_rndne_f32 */
+    float lo = fmaf(x, 1.44269502162933349609375f, -t);                  /* what the product dropped, exactly */
+    lo = fmaf(x, 1.92596299112661746e-8f, lo);                           /* + x * (log2 e - float(log2 e)) */
+    const float f = (t - n) + lo;
+    return __builtin_ldexpf(__builtin_amdgcn_exp2f(f), (int)n);          /* NaN: every step carries it, (int)NaN = 0 */
+}
+/* log(x) for x > 0 (denormals included); 0 -> -inf, negative -> NaN, NaN -> NaN; +inf is the caller's business */
+PDP_HD float pdp_hw_logf(float x)
+{
+    const float m = __builtin_amdgcn_frexp_mantf(x);
+    const int e = __builtin_amdgcn_frexp_expf(x);
+    return ((float)e + __builtin_amdgcn_logf(m)) * 0.693147180559945309f;
+}
+#endif
+
 /* e^x.  Result is correctly scaled into the denormal range (single final rounding).
  * Written branch-free (selects only): on gfx950 early returns would become divergent exec-mask branches. */
 PDP_HD float pdp_expf(float x)
 {
+#ifdef PDP_FAST_DEVICE
+    { const float r = pdp_hw_expf(pdp_fminf_dev(pdp_fmaxf_dev(x, -150.0f), 89.0f)); return (x != x) ? x : r; }
+#endif
     const int is_nan = (x != x);
     float xc = is_nan ? 0.0f : x;
     xc = (xc > 89.0f) ? 89.0f : xc;
@@ -80,6 +117,9 @@ PDP_HD float pdp_expf(float x)
 /* natural log, x > 0 expected (denormals fine); x == 0 -> -inf, x < 0 -> NaN.  Branch-free like pdp_expf. */
 PDP_HD float pdp_logf(float x)
 {
+#ifdef PDP_FAST_DEVICE
+    { const float r = pdp_hw_logf(x); return (pdp_f2bits(x) == 0x7f800000u) ? x : r; }
+#endif
     const int is_nan = (x != x);
     const uint32_t u0 = pdp_f2bits(x);
     const int is_inf = (u0 == 0x7f800000u);
@@ -136,6 +176,9 @@ PDP_HD float pdp_scale2(float p, int n)
 /* e^x for x <= 30 or NaN (the argument of safe_exp after its clamp) */
 PDP_HD float pdp_expf_le30(float x)
 {
+#ifdef PDP_FAST_DEVICE
+    { const float r = pdp_hw_expf(pdp_fmaxf_dev(x, -150.0f)); return (x != x) ? x : r; }
+#endif
     const float xc = (x < -104.5f) ? -104.5f : x;          /* NaN stays NaN and is returned unchanged below */
     const float t = xc * 1.44269504088896341f;
     const float nf = (t + 12582912.0f) - 12582912.0f;
@@ -158,6 +201,9 @@ PDP_HD float pdp_expf_le30(float x)
 /* log(x) for finite x > 0 (denormals included) or NaN */
 PDP_HD float pdp_logf_pos(float x)
 {
+#ifdef PDP_FAST_DEVICE
+    return pdp_hw_logf(x);
+#endif
     const uint32_t u0 = pdp_f2bits(x);
     const int den = u0 < 0x00800000u;
     const float xn = x * (den ? 8388608.0f : 1.0f);
@@ -203,6 +249,9 @@ PDP_HD float pdp_fmaxf(float a, float b)
 /* log(max(x, eps)) for a finite-or-NaN x and eps > 0 (the reference's safe_log on everything the SP update feeds it) */
 PDP_HD float pdp_safe_log_fin(float x, float eps)
 {
+#ifdef PDP_FAST_DEVICE
+    return pdp_hw_logf(pdp_fmaxf(x, eps)) + (x - x);
+#endif
     const float xm = pdp_fmaxf(x, eps);                     /* NaN -> eps here, NaN again through the last line */
 #if defined(__HIP_DEVICE_COMPILE__)
     float m = __builtin_amdgcn_frexp_mantf(xm);             /* xm = m * 2^e, m in [0.5, 1), exact, denormals included */
@@ -241,6 +290,9 @@ PDP_HD float pdp_safe_log_fin(float x, float eps)
  * No "x < -104 -> 0" select: p * 2^n rounds to zero by itself there (e^-104 = 0.486 * 2^-149). */
 PDP_HD float pdp_expf_fin_le30(float x)
 {
+#ifdef PDP_FAST_DEVICE
+    return pdp_hw_expf(pdp_fmaxf(x, -150.0f)) + (x - x);
+#endif
     const float xc = pdp_fmaxf(x, -104.5f);
     const float t = xc * 1.44269504088896341f;
     const float nf = (t + 12582912.0f) - 12582912.0f;
@@ -273,6 +325,9 @@ PDP_HD float pdp_fminf(float a, float b)
 /* e^min(x, hi) for any finite x or NaN: underflows to 0; with hi = 89 it overflows to +inf (p * 2^128) like expf */
 PDP_HD float pdp_expf_fin_hi(float x, float hi)
 {
+#ifdef PDP_FAST_DEVICE
+    return pdp_hw_expf(pdp_fminf(pdp_fmaxf(x, -150.0f), hi)) + (x - x);
+#endif
     const float xc = pdp_fminf(pdp_fmaxf(x, -104.5f), hi);
     const float t = xc * 1.44269504088896341f;
     const float nf = (t + 12582912.0f) - 12582912.0f;
@@ -297,6 +352,12 @@ PDP_HD float pdp_expf_fin(float x) { return pdp_expf_fin_hi(x, 89.0f); }
  * 27 instead of 50 VALU instructions per element on gfx950, which matters because f32 MFMA and VALU time add up on a SIMD. */
 PDP_HD float pdp_logsigmoidf(float x)
 {
+#ifdef PDP_FAST_DEVICE
+    {   /* min(x, 0) - log1p(e^-|x|): e^-|x| underflows to 0 past 87 (v_exp_f32 flushes), where log1p of it is below 1e-38 anyway */
+        const float t = __builtin_amdgcn_exp2f(-1.44269504088896341f * pdp_abs(x));
+        return fmaf(-0.693147180559945309f, __builtin_amdgcn_logf(1.0f + t), pdp_fminf(x, 0.0f));
+    }
+#endif
     const float t = pdp_expf_fin_le30(-pdp_abs(x));
     float p = 5.253457930e-03f;
     p = fmaf(p, t, -2.958850749e-02f);
@@ -316,6 +377,9 @@ PDP_HD float pdp_logsigmoidf(float x)
  * 1.06e9 of them with the IEEE division, which is what the host side (the oracle) computes here. */
 PDP_HD float pdp_rcp_ge1(float d)
 {
+#ifdef PDP_FAST_DEVICE
+    return __builtin_amdgcn_rcpf(d);
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
     float r = __builtin_amdgcn_rcpf(d);
     const float e = fmaf(-d, r, 1.0f);
@@ -332,12 +396,27 @@ PDP_HD float pdp_rcp_ge1(float d)
 
 /* torch.sigmoid(x) = 1 / (1 + exp(-x)).  The exponent is clamped at 87 so that the denominator stays in the range of pdp_rcp_ge1: for
  * x < -87 the result is 1.6e-38 where torch's decays on to 0 through the denormals -- a difference of at most 1.6e-38. */
-PDP_HD float pdp_sigmoidf(float x) { return pdp_rcp_ge1(1.0f + pdp_expf_fin_hi(-x, 87.0f)); }
+PDP_HD float pdp_sigmoidf(float x)
+{
+#ifdef PDP_FAST_DEVICE
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * pdp_fmaxf(x, -87.0f))) + (x - x);
+#endif
+    return pdp_rcp_ge1(1.0f + pdp_expf_fin_hi(-x, 87.0f));
+}
 
 /* tanh(x) = em / (em + 2), em = e^{2|x|} - 1 without cancellation: with 2|x| = n ln2 + r the polynomial part q = e^r - 1 is
  * the exact answer for n == 0.  |x| is clamped at 10 (tanh(10) rounds to 1). */
 PDP_HD float pdp_tanhf(float x)
 {
+#ifdef PDP_FAST_DEVICE
+    {   /* em / (em + 2) with em = e^{2|x|} - 1; below 2^-6 the subtraction would cancel: x (1 - x^2 / 3) there */
+        const float a = pdp_fminf(pdp_abs(x), 10.0f);
+        const float em = __builtin_amdgcn_exp2f(2.88539008177792681f * a) - 1.0f;
+        const float big = em * __builtin_amdgcn_rcpf(em + 2.0f);
+        const float v = (a < 0.015625f) ? fmaf(a * a, -0.333333333f * a, a) : big;
+        return pdp_bits2f(pdp_f2bits(v) | (pdp_f2bits(x) & 0x80000000u)) + (x - x);
+    }
+#endif
     const float a = pdp_fminf(pdp_abs(x), 10.0f);
     const float y = a + a;
     const float t = y * 1.44269504088896341f;
@@ -365,6 +444,14 @@ PDP_HD float pdp_tanhf(float x)
  * (no expm1 reconstruction, no n == 0 select). */
 PDP_HD float pdp_tanhf_abs(float x)
 {
+#ifdef PDP_FAST_DEVICE
+    {
+        const float a = pdp_fminf(pdp_abs(x), 10.0f);
+        const float r = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.88539008177792681f * a) + 1.0f);
+        const float v = 1.0f - (r + r);
+        return pdp_bits2f(pdp_f2bits(v) | (pdp_f2bits(x) & 0x80000000u)) + (x - x);
+    }
+#endif
     const float a = pdp_fminf(pdp_abs(x), 10.0f);
     const float t = pdp_expf_fin(a + a);
     const float r = pdp_rcp_ge1(t + 1.0f);                  /* t + 1 in [2, e^20 + 1] */

@@ -85,6 +85,11 @@ __device__ __forceinline__ f32x2 pk_expf_fin_le30(f32x2 x)                      
 {
     return pk_exp_clamped((f32x2){pdp_fmaxf(x.x, -104.5f), pdp_fmaxf(x.y, -104.5f)}, x);
 }
+#ifdef PDP_FAST_MATH
+// the opt-in fast build (include/pdp_math.h): the scalar pdp_logsigmoidf on the transcendental unit, element by element (a packed form has
+// nothing to pack: the work is two v_exp_f32 / v_log_f32 pairs)
+__device__ __forceinline__ f32x2 pk_logsigmoid(f32x2 x) { return (f32x2){pdp_logsigmoidf(x.x), pdp_logsigmoidf(x.y)}; }
+#else
 __device__ __forceinline__ f32x2 pk_logsigmoid(f32x2 x)
 {
     const f32x2 t = pk_expf_fin_le30((f32x2){-pdp_abs(x.x), -pdp_abs(x.y)});
@@ -100,6 +105,7 @@ __device__ __forceinline__ f32x2 pk_logsigmoid(f32x2 x)
     const f32x2 mn = {pdp_fminf(x.x, 0.0f), pdp_fminf(x.y, 0.0f)};
     return mn - p * t;
 }
+#endif
 __device__ __forceinline__ f32x2 pk_logsigmoid_or_zero(float x0, float x1, bool live)
 {
     f32x2 v = pk_logsigmoid((f32x2){x0, x1});

@@ -878,6 +878,41 @@ typedef int i4v __attribute__((ext_vector_type(4)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f4v vfma(f4v a, f4v b, f4v c) { return __builtin_elementwise_fma(a, b, c); }
 
+#ifdef PDP_FAST_MATH
+// the opt-in fast build (include/pdp_math.h, PDP_FAST_MATH): the same split as pdp_hw_expf / pdp_hw_logf, four wide.  The arguments of
+// this kernel are finite sums of at most 16 383 clamped logs (> -1.6e6) or NaN: the low part of the product stays below 1/4, nothing to clamp.
+__device__ __forceinline__ f4v exp4_fin_le30(f4v x)
+{
+    const f4v t = x * 1.44269502162933349609375f;
+    const f4v n = __builtin_elementwise_rint(t);
+    f4v lo = vfma(x, (f4v)(1.44269502162933349609375f), -t);
+    lo = vfma(x, (f4v)(1.92596299112661746e-8f), lo);
+    const f4v f = (t - n) + lo;
+    const i4v ni = __builtin_convertvector(n, i4v);
+    f4v res;
+    res.x = __builtin_ldexpf(__builtin_amdgcn_exp2f(f.x), ni.x); res.y = __builtin_ldexpf(__builtin_amdgcn_exp2f(f.y), ni.y);
+    res.z = __builtin_ldexpf(__builtin_amdgcn_exp2f(f.z), ni.z); res.w = __builtin_ldexpf(__builtin_amdgcn_exp2f(f.w), ni.w);
+    return res;
+}
+__device__ __forceinline__ f4v log4_fin(f4v x, float eps)
+{
+    const f4v xm = __builtin_bit_cast(f4v, __builtin_elementwise_max(__builtin_bit_cast(i4v, x), __builtin_bit_cast(i4v, (f4v)(eps))));
+    f4v l; i4v e;
+    l.x = __builtin_amdgcn_logf(__builtin_amdgcn_frexp_mantf(xm.x)); l.y = __builtin_amdgcn_logf(__builtin_amdgcn_frexp_mantf(xm.y));
+    l.z = __builtin_amdgcn_logf(__builtin_amdgcn_frexp_mantf(xm.z)); l.w = __builtin_amdgcn_logf(__builtin_amdgcn_frexp_mantf(xm.w));
+    e.x = __builtin_amdgcn_frexp_expf(xm.x); e.y = __builtin_amdgcn_frexp_expf(xm.y); e.z = __builtin_amdgcn_frexp_expf(xm.z); e.w = __builtin_amdgcn_frexp_expf(xm.w);
+    const f4v r = (__builtin_convertvector(e, f4v) + l) * 0.693147180559945309f;
+    return vfma((f4v)(0.0f), x, r);          // a NaN whose sign bit is set went to eps in the integer maximum: re-injected
+}
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef int i2v __attribute__((ext_vector_type(2)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2v log2_fin(f2v x, float eps)
+{
+    const f4v r = log4_fin((f4v){x.x, x.y, x.x, x.y}, eps);
+    return (f2v){r.x, r.y};
+}
+#else
 __device__ __forceinline__ f4v exp4_fin_le30(f4v x)
 {
     const f4v xc = __builtin_elementwise_max(x, (f4v)(-104.5f));
@@ -967,6 +1002,7 @@ __device__ __forceinline__ f2v log2_fin(f2v x, float eps)             // two-wid
     r = __builtin_elementwise_fma(fe, (f2v)(0.693359375f), r);
     return __builtin_elementwise_fma((f2v)(0.0f), x, r);
 }
+#endif
 
 // cross-lane helpers without the LDS crossbar (a __shfl is a ds_bpermute round trip of ~100 cycles):
 // OR of a 7-bit flag set over the wave, one ballot per bit; exchange with lane ^ 1 through a DPP quad permute.

@@ -88,7 +88,7 @@ def test_two_ranks_share_one_loader_batch_cut_into_segments(tmp_path):
     path = tmp_path / 'one_batch.json'
     path.write_text("\n".join(_lines(items)) + "\n")
     edges = [it[2].shape[1] for it in items]
-    limit = 4 * 3 * max(edges) * 9                      # -b 4, hidden_dim 3 (p-d-p): about nine of the largest instances per segment
+    limit = 4 * 3 * max(edges) * 4                      # -b 4, hidden_dim 3 (p-d-p): about four of the largest instances per segment
     assert len(dataset.divide(edges, limit // 4, 3)) >= 4
     base = [str(path), '30', '-z', '64', '-s', '5', '-b', '4', '-l', str(limit), '-v']
     pdp = [os.path.join(REPO, 'config', 'Predict', 'PDP-p-d-p-sp-pytorch.yaml')] + base + ['-w', '40', '--rng', 'philox']
@@ -99,7 +99,7 @@ def test_two_ranks_share_one_loader_batch_cut_into_segments(tmp_path):
     assert set(units) == {0, 1} and min(units.values()) >= 2 and sum(units.values()) == len(dataset.divide(edges, limit // 4, 3))
     # the hybrid model of configs[4] with the weights trained here, default --rng (nothing is drawn with -w 0): also equal, no switch
     hyb = [os.path.join(REPO, 'config', 'Predict', 'PDP-p-nd-np-demo-h128.yaml'), str(path), '12', '-z', '64', '-s', '5', '-b', '4', '-w', '0',
-           '-l', str(4 * 128 * max(edges) * 9), '-v']
+           '-l', str(4 * 128 * max(edges) * 4), '-v']
     one, _ = _run(hyb, 1, str(tmp_path / 'h_one.jsonl'), 0)
     two, log = _run(hyb, 2, str(tmp_path / 'h_two.jsonl'), 29743)
     assert len(one) == len(items) and one == two and 'switching to --rng philox' not in log
