@@ -553,6 +553,65 @@ def bench_neural(args, dev, rank, world):
         dist.destroy_process_group()
 
 
+def fast_build_measurement(args, dev, native, host_batch, items, parity_solved):
+    """The headline step loop once more on the opt-in fast build (libpdp_hip_fast.so: device math on v_exp_f32 / v_log_f32 / v_rcp_f32;
+    gated by the reference-held fixtures only, tests/test_fast_build_gpu.py) -- the same --warmup / --steps on the same resident batch --
+    and configs[2]'s neural iteration on it.  Reported next to the line's `value`, which is always the parity build's.  Runs last:
+    every handle of the parity library is gone by then (a handle belongs to the library that made it)."""
+    import torch
+    from pdp.factorgraph import dataset
+    out = {'build': 'libpdp_hip_fast.so (PDP_BUILD=fast / pdp.native.use_build)', 'gate': 'tests/test_fast_build_gpu.py'}
+    previous = native.use_build('fast')
+    try:
+        b = dataset.to_torch(host_batch, dev)
+        prob = native.Problem(b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'], batch_size=args.batch)
+        E, V, F, B = prob.E, prob.V, prob.F, prob.B
+        L = native.lib()
+        launches, iters_done = [], []
+
+        def step(record):
+            q = torch.full((E, 3), 1.0, device=dev); q.div_(3.0)
+            fs = torch.zeros(E, 2, device=dev); fs[:, 0] = 0.5
+            am = torch.ones(B, dtype=torch.uint8, device=dev); dec = native.Decimator(prob)
+            native.check(L.pdp_problem_bind_state(prob._h, native.ptr(prob.active_variables), native.ptr(prob.active_functions), native.ptr(prob.solution),
+                                                  native.ptr(prob.is_sat), native.ptr(prob.edge_mask), native._stream()))
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            prob.simplify()
+            it, _ = prob.sp_solve(q, fs, am, dec, args.iters, args.tolerance, args.t_max, time_kernels=True, isolate_instances=args.isolated, inputs_disposable=True)
+            torch.cuda.synchronize()
+            if record:
+                launches.append((time.perf_counter() - t0, dict(prob.last_solve_stats))); iters_done.append(it)
+        for _ in range(args.warmup):
+            step(False)
+        for _ in range(args.steps):
+            step(True)
+        elapsed = sum(t for t, _ in launches)
+        n_launch = float(np.mean([l['launches'] for _, l in launches]))
+        launch_ms = float(np.mean([l['solve_kernel_ms'] for _, l in launches])) / n_launch
+        bytes_launch = algorithmic_bytes_per_iteration(E, V, F) * float(np.mean(iters_done)) / n_launch
+        prob.random_fill(seed=12345)
+        res, _ = prob.local_search(prob.solution.clone(), args.walksat, 0.5, seed=999)
+        pred = prob.update_solution(res.reshape(-1).contiguous())
+        solved, unsat = prob.cnf_eval(pred.reshape(-1).contiguous())
+        out.update(value=float(sum(iters_done)) / elapsed, ms_per_step=1e3 * elapsed / args.steps, kernel=native.kernel_name('sp_solve'),
+                   kernel_ms_per_launch=launch_ms, roofline_frac=bytes_launch / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   solved_fraction=float(solved.sum().item()) / B, solved_fraction_parity_build=parity_solved,
+                   unsat_clauses_total=float(unsat.sum().item()),
+                   note='per-step time here is the host clock around bind + simplify + solve of each step (initial states built outside it)')
+        del prob, b
+        torch.cuda.empty_cache()
+        if not args.no_secondary:
+            try:
+                out['neural'] = neural_shard(args, dev, native, items, 'np-nd-np', args.hidden, args.secondary_neural_iters,
+                                             workload="configs[2] on the fast build: 'np-nd-np' hidden %d, same batch" % args.hidden)
+            except Exception as ex:                          # measurement only: never take the headline line down
+                out['neural'] = dict(error=repr(ex))
+    finally:
+        torch.cuda.empty_cache()
+        native.use_build(previous)
+    return out
+
+
 def secondary_measurements(args, dev, b, prob, native, items):
     """Outside the headline's timed loop (rank 0, N = 1): the other hot kernels on the same resident batch, each with the numbers its
     roofline fraction is computed from -- configs[2]'s neural iteration (3 sweeps), 1 000 Walk-SAT steps, the Reinforce solver's forward."""
@@ -781,6 +840,7 @@ def main():
                     help="sp: configs[1] (headline metric); neural: configs[2] 'np-nd-np' hidden_dim=128 on the same graph (fp32 MFMA)")
     ap.add_argument('--hidden', type=int, default=128)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fast-build', action='store_true', help='skip the rerun of the headline loop on the opt-in fast build (config.fast_build)')
     ap.add_argument('--no-secondary', action='store_true', help='skip config.secondary (neural / Walk-SAT / Reinforce) and the long solved-fraction runs')
     ap.add_argument('--isolated', action='store_true', help="sp workload: every instance solved on its own (no batch-wide couplings of the "
                     "reference, hence no NaN-poison replay); the default is the reference's strict semantics")
@@ -953,6 +1013,13 @@ def main():
             del prob, b
             torch.cuda.empty_cache()
             config['secondary'].update(config_shard_measurements(args, dev, native))
+        if world == 1 and not args.no_fast_build:
+            try:
+                prob = b = None
+                torch.cuda.empty_cache()
+                config['fast_build'] = fast_build_measurement(args, dev, native, host_batch, items, n_solved / n_inst)
+            except Exception as ex:
+                config['fast_build'] = dict(error=repr(ex))
         line = {
             'metric': 'pdp_iterations_per_sec', 'value': value,
             'unit': 'iterations/s (each iteration sweeps a batch of %d instances)' % args.batch,

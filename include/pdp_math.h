@@ -409,11 +409,11 @@ PDP_HD float pdp_sigmoidf(float x)
 PDP_HD float pdp_tanhf(float x)
 {
 #ifdef PDP_FAST_DEVICE
-    {   /* em / (em + 2) with em = e^{2|x|} - 1; below 2^-6 the subtraction would cancel: x (1 - x^2 / 3) there */
+    {   /* 1 - 2 / (e^{2|x|} + 1): absolute error about 1e-7 (the relative accuracy of the parity form near 0 is not kept; the value feeds a
+         * sign and an arg-max of magnitudes in the np-d-np scorer head, util.py:250-251) */
         const float a = pdp_fminf(pdp_abs(x), 10.0f);
-        const float em = __builtin_amdgcn_exp2f(2.88539008177792681f * a) - 1.0f;
-        const float big = em * __builtin_amdgcn_rcpf(em + 2.0f);
-        const float v = (a < 0.015625f) ? fmaf(a * a, -0.333333333f * a, a) : big;
+        const float r = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.88539008177792681f * a) + 1.0f);
+        const float v = 1.0f - (r + r);
         return pdp_bits2f(pdp_f2bits(v) | (pdp_f2bits(x) & 0x80000000u)) + (x - x);
     }
 #endif

@@ -11,7 +11,14 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('PDP_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'csrc', 'libpdp_hip.so')   # PDP_HIP_LIB: A/B builds
+# two builds of the same sources (csrc/Makefile): 'parity' -- the default, IEEE-only device math, the oracle's bits -- and the opt-in 'fast'
+# (device math on the transcendental unit, include/pdp_math.h PDP_FAST_MATH; gated by the reference-held fixtures only).  PDP_BUILD=fast
+# selects it for a process, use_build() inside one; PDP_HIP_LIB names any other file (A/B builds).
+BUILDS = {'parity': 'libpdp_hip.so', 'fast': 'libpdp_hip_fast.so'}
+BUILD = os.environ.get('PDP_BUILD', 'parity')
+if BUILD not in BUILDS:
+    raise ImportError("PDP_BUILD must be one of %s, got %r" % (sorted(BUILDS), BUILD))
+LIB_PATH = os.environ.get('PDP_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'csrc', BUILDS[BUILD])
 
 PDP_OK = 0
 PDP_ERR_SPECULATION = 5
@@ -57,6 +64,20 @@ def lib():
             if name != 'pdp_last_error':
                 getattr(_lib, name).restype = C.c_int
     return _lib
+
+
+def use_build(name):
+    """Switch this process to the other build of the library.  Handles (Problem, Decimator, weight descriptors) belong to the library that
+    made them: drop every one of them first.  Returns the previous build's name."""
+    global _lib, LIB_PATH, BUILD
+    if name not in BUILDS:
+        raise NativeError("unknown build %r (have %s)" % (name, sorted(BUILDS)))
+    previous = BUILD
+    if name != BUILD:
+        BUILD = name
+        LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', BUILDS[name])
+        _lib = None
+    return previous
 
 
 def check(status):

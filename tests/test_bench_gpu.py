@@ -60,6 +60,12 @@ def test_bench_line_small_workload():
     for name, row in line['config']['solved'].items():
         assert 'error' not in row, row
         assert 0 <= row['solved'] <= row['instances'] == 600
+    # the opt-in fast build is measured next to the headline, never instead of it: same kernel, same workload, its own library
+    fb = line['config']['fast_build']
+    assert 'error' not in fb, fb
+    assert fb['kernel'] == rf['kernel'] and fb['value'] > 0 and fb['kernel_ms_per_launch'] > 0 and 0 < fb['roofline_frac'] < 2.0
+    assert 'error' not in fb['neural'] and fb['neural']['kernels']['agg_post']['ms_per_launch'] > 0
+    assert abs(fb['solved_fraction'] - fb['solved_fraction_parity_build']) <= 0.01
 
 
 def test_bench_launcher_two_ranks_on_one_gpu():

@@ -1,0 +1,108 @@
+"""The opt-in fast build (libpdp_hip_fast.so: device math on v_exp_f32 / v_log_f32 / v_rcp_f32, include/pdp_math.h PDP_FAST_MATH).
+
+Its results are not the oracle's bits, so it is gated by what the REFERENCE holds only: every golden trace's integer trajectory and the CLI
+rows equal, floats within the tolerances those tests already state (tests/test_api_forward.py, tests/test_foreign_plugin.py,
+tests/test_train_gpu.py run unchanged with PDP_BUILD=fast), the accuracy of the device functions against float64, and the solved counts
+of the headline batch equal to the parity build's.  The parity build stays the default and keeps the whole bit-exact suite."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reference_held_fixtures_pass_on_the_fast_build():
+    "the three test files whose expectations all come from the reference, in a process that loads the fast library"
+    env = dict(os.environ, PDP_BUILD='fast')
+    files = ['tests/test_api_forward.py', 'tests/test_foreign_plugin.py', 'tests/test_train_gpu.py']
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider'] + files, cwd=REPO, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-6000:]
+    assert ' passed' in r.stdout and 'failed' not in r.stdout.split('\n')[-2]
+    # ... and the process really ran on the fast library
+    probe = subprocess.run([sys.executable, '-c', "import sys; sys.path.insert(0, 'pdp-solver_amd'); from pdp import native; native.lib(); print(native.BUILD, native.LIB_PATH)"],
+                           cwd=REPO, env=env, stdout=subprocess.PIPE, universal_newlines=True, timeout=300)
+    assert probe.stdout.split()[0] == 'fast' and probe.stdout.strip().endswith('libpdp_hip_fast.so')
+
+
+def _ulp_err(got, want64):
+    want32 = want64.astype(np.float32)
+    ulp = np.maximum(np.abs(np.spacing(want32)).astype(np.float64), 1.4012984643e-45)
+    return np.abs(got.astype(np.float64) - want64) / ulp
+
+
+def test_device_math_of_the_fast_build_against_float64():
+    """the transcendental-unit forms: a few ulp on the ranges the path uses, denormals handled explicitly (the reference relies on
+    log(1e-40) = -92.1034 and exp(-92.1034) = 1e-40), special values as the parity forms"""
+    from pdp import native
+    prev = native.use_build('fast')
+    try:
+        dev = torch.device('cuda:0')
+        rng = np.random.RandomState(3)
+        f = lambda a: torch.from_numpy(np.asarray(a, np.float32)).to(dev)
+        g = lambda name, a: native.math_apply(name, f(a)).cpu().numpy()
+        x = np.concatenate([rng.uniform(-104, 30, 200000), rng.uniform(-3, 3, 200000), [-92.1034, -87.5, -103.9, 0.0, 30.0, -1e-30]]).astype(np.float32)
+        e = g('exp_fin', x)
+        assert _ulp_err(e, np.exp(x.astype(np.float64))).max() <= 4.0
+        assert abs(float(g('exp_fin', [-92.1034])[0]) - 1e-40) <= 2e-45
+        se = g('safe_exp', np.concatenate([x, [31.0, 1e30, np.inf]]).astype(np.float32))
+        assert _ulp_err(se[:-3], np.exp(np.minimum(x.astype(np.float64), 30.0))).max() <= 4.0 and np.all(se[-3:] == se[-3]) and abs(se[-1] / np.exp(30.0) - 1) < 3e-7
+        y = np.concatenate([10.0 ** rng.uniform(-44.5, 0.3, 300000), rng.uniform(0.5, 1.0, 100000), [1e-40, 1.4e-45, 1.0, 0.99999994]]).astype(np.float32)
+        lg = g('safe_log_fin', y)
+        want = np.log(np.maximum(y.astype(np.float64), 1e-40))
+        # log2 m + e is exact to an ulp of the SUM: near x = 1 that is an absolute, not a relative, statement
+        assert np.all(np.abs(lg.astype(np.float64) - want) <= 3.0 * np.maximum(np.abs(np.spacing(want.astype(np.float32))), 1.2e-7))
+        assert abs(float(g('safe_log_fin', [1e-40])[0]) + 92.1034) < 2e-5 and abs(float(g('safe_log_fin', [0.0])[0]) + 92.1034) < 2e-5
+        z = np.concatenate([rng.uniform(-30, 30, 300000), [-100.0, 100.0, 0.0]]).astype(np.float32)
+        z64 = z.astype(np.float64)
+        ls = g('logsigmoid', z)
+        assert np.all(np.abs(ls - (np.minimum(z64, 0) - np.log1p(np.exp(-np.abs(z64))))) <= 2e-7 * np.maximum(1.0, np.abs(z64)))
+        assert np.all(np.abs(g('sigmoid', z) - 1.0 / (1.0 + np.exp(-z64))) <= 2.5e-7)
+        assert np.all(np.abs(g('tanh', z) - np.tanh(z64)) <= 3e-7) and np.all(np.abs(g('tanh_abs', z) - np.tanh(z64)) <= 3e-7)
+        nan = g('exp_fin', [np.nan])[0], g('safe_log_fin', [np.nan])[0], g('logsigmoid', [np.nan])[0], g('sigmoid', [np.nan])[0], g('tanh', [np.nan])[0]
+        assert all(v != v for v in nan)
+        assert g('exp', [np.inf])[0] == np.inf and g('exp', [-np.inf])[0] == 0.0 and g('log', [0.0])[0] == -np.inf and g('log', [np.inf])[0] == np.inf
+        assert np.isnan(g('log', [-1.0])[0])
+    finally:
+        native.use_build(prev)
+
+
+def test_headline_family_solved_counts_equal_the_parity_build():
+    """random 3-SAT n=200 m=840, 600 instances (a NaN-poisoned batch like the headline), T=100 + Walk-SAT: the two builds run the same
+    number of sweeps, poison the batch in the same sweep, fix almost the same variables and solve the same number of instances"""
+    from pdp import native
+    from pdp.factorgraph import dataset
+    dev = torch.device('cuda:0')
+    B = 600
+    b = dataset.to_torch(dataset.collate_segment(dataset.random_ksat_items(B, 200, 3, m=840, seed=0)), dev)
+    out = {}
+    prev = native.BUILD
+    try:
+        for build in ('parity', 'fast'):
+            native.use_build(build)
+            prob = native.Problem(b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'], batch_size=B)
+            prob.simplify()
+            q = torch.full((prob.E, 3), 1.0, device=dev) / 3.0; fs = torch.zeros(prob.E, 2, device=dev); fs[:, 0] = 0.5
+            am = torch.ones(B, dtype=torch.uint8, device=dev); dec = native.Decimator(prob)
+            it, lds = prob.sp_solve(q, fs, am, dec, 100, 0.02, 100, inputs_disposable=True)
+            replays = prob.last_solve_stats['replays']
+            prob.random_fill(seed=5)
+            o, ws = prob.local_search(prob.solution.clone(), 100, 0.5, seed=6)
+            pred = prob.update_solution(o.reshape(-1).contiguous())
+            solved, unsat = prob.cnf_eval(pred.reshape(-1).contiguous())
+            out[build] = dict(iters=it, lds=lds, replays=replays, av=prob.active_variables.cpu().numpy().copy(), q=q.cpu().numpy(),
+                              solved=int(solved.sum().item()), unsat=int(unsat.sum().item()))
+            del prob, dec
+    finally:
+        native.use_build(prev)
+    a, c = out['parity'], out['fast']
+    assert (a['iters'], a['lds'], a['replays']) == (c['iters'], c['lds'], c['replays'])
+    assert np.array_equal(np.isnan(a['q']).any(axis=1), np.isnan(c['q']).any(axis=1))         # the same instances carry the NaN
+    assert (a['av'] == c['av']).mean() >= 0.9995                                             # decimated variables: all but a handful
+    assert a['solved'] == c['solved'] and abs(a['unsat'] - c['unsat']) <= max(3, a['unsat'] // 500)
