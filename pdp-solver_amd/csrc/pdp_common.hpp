@@ -78,6 +78,7 @@ enum {
     FL_ITERS_RUN = 14,
     FL_WS_STEPS = 15,
     FL_PERM_ZERO = 16,   // first iteration from which an exited instance guarantees exact zeros
+    FL_TEAM_TIMEOUT = 17,// sticky: a team barrier ran out of patience (the team's workgroups were not resident together); results are void
     FL_COUNT = 32
 };
 
@@ -359,7 +360,16 @@ struct Teamed : Base {
     uint32_t *bar;              // arrival counter, zeroed before the launch; it only grows: barrier k is complete at k * size arrivals
     uint32_t *box;              // [2][size][PDP_BOX_WORDS] reduction mailboxes, alternating with the parity of the barrier they ride on
     mutable uint32_t epoch;     // team barriers passed (identical on every thread of the team)
+    // A team's workgroups wait for each other, so all of them must be resident at once.  The launches are sized for that (pdp_team_plan,
+    // lockstep_possible), but nothing GUARANTEES it -- another process on the GPU, a changed occupancy -- and a barrier that can never
+    // complete would hang the process.  The wait is therefore bounded: after spin_limit polls (seconds; a legitimate wait is micro- to
+    // milliseconds) the barrier gives up, marks the team's workspace so that its other workgroups give up at their next poll, and the team
+    // is `failed` from then on: barriers return at once, reductions return their identity (every fix-point loop ends), the kernel runs
+    // to its end and reports the failure through its violation / FL_TEAM_TIMEOUT word; the host restores the state and fails over.
+    mutable uint32_t failed;
+    uint32_t spin_limit;
 };
+#define PDP_SPIN_LIMIT_DEFAULT (1u << 24)                // polls of ~0.5 us each
 #define PDP_TEAM_MAX 256                                 // team size of one instance (mailbox reads: thread r folds ranks r, r + blockDim, ...)
 #define PDP_LOCK_MAX 1024                                // workgroups of a lock-step launch (one instance each)
 #define PDP_BOX_WORDS 8                                   // words of one rank's mailbox
@@ -374,10 +384,11 @@ template <class B> __device__ __forceinline__ int team_nt(const Teamed<B> &t) { 
 // (s_waitcnt vmcnt(0)), and a reader only has to drop its CU's vector cache (buffer_inv).
 template <class B> __device__ __forceinline__ void team_sync(const Teamed<B> &t)
 {
-    if (t.size == 1) { __syncthreads(); return; }
+    if (t.size == 1 || t.failed) { __syncthreads(); return; }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // this wave's stores have left the CU's write-through vector cache
     __syncthreads();
     t.epoch += 1;
+    int gave_up = 0;
     if (threadIdx.x < PDP_WAVE) {
         // One wave speaks for the workgroup.  Team on several XCDs: the release writes this XCD's L2 back (every wave's stores are in it
         // by now), the acquire drops the vector cache and the stale L2 lines.  Team on one XCD: the L2 is the point of coherence, only
@@ -386,13 +397,22 @@ template <class B> __device__ __forceinline__ void team_sync(const Teamed<B> &t)
         if (threadIdx.x == 0) {
             __hip_atomic_fetch_add(t.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t target = t.epoch * (uint32_t)t.size;
-            while (__hip_atomic_load(t.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+            uint32_t polls = 0;
+            while (__hip_atomic_load(t.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                // every 1024th poll: out of patience, or has another workgroup of the team given up already (word 1 of the counter's line)?
+                if ((++polls & 0x3ffu) == 0u && (polls >= t.spin_limit || __hip_atomic_load(t.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                    __hip_atomic_store(t.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    gave_up = 1;
+                    break;
+                }
+            }
         }
         if (t.same_xcd == 1) asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
         else if (!t.same_xcd) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         // (same_xcd == 2: the workgroups exchange mailbox words only -- agent-scope atomics -- and no cache has to be touched)
     }
-    __syncthreads();
+    if (__syncthreads_or(gave_up)) t.failed = 1u;                       // workgroup-uniform
 }
 // A mailbox written for the barrier of epoch e is read right after that barrier; the next writer of the same half has passed
 // barrier e + 1, which every workgroup only reaches after its reads.  Thread r of every workgroup fetches rank r's mailbox (all
@@ -409,6 +429,7 @@ __device__ __forceinline__ T team_reduce(const Teamed<B> &t, T v, Op op, T ident
     uint32_t *box = team_box(t);
     if (threadIdx.x == 0) box_put(&box[PDP_BOX_WORDS * t.rank], __builtin_bit_cast(uint32_t, v));
     team_sync(t);
+    if (t.failed) return identity;
     T theirs = identity;          // thread r folds the mailboxes of ranks r, r + blockDim, ...
     for (int r = (int)threadIdx.x; r < t.size; r += (int)blockDim.x) theirs = op(theirs, __builtin_bit_cast(T, box_get(&box[PDP_BOX_WORDS * r])));
     return block_reduce(theirs, op, identity, scratch);
@@ -420,6 +441,7 @@ template <class B> __device__ __forceinline__ int team_any(const Teamed<B> &t, i
     uint32_t *box = team_box(t);
     if (threadIdx.x == 0) box_put(&box[PDP_BOX_WORDS * t.rank], (uint32_t)x);
     team_sync(t);
+    if (t.failed) return 0;                                            // "nothing changed anywhere": every fix-point loop of a failed team ends
     int theirs = 0;
     for (int r = (int)threadIdx.x; r < t.size; r += (int)blockDim.x) theirs |= (int)(box_get(&box[PDP_BOX_WORDS * r]) != 0u);
     return __syncthreads_or(theirs);
@@ -431,6 +453,7 @@ template <class B> __device__ __forceinline__ ArgPair team_argmax(const Teamed<B
     uint32_t *box = team_box(t);
     if (threadIdx.x == 0) { box_put(&box[PDP_BOX_WORDS * t.rank], __float_as_uint(r.v)); box_put(&box[PDP_BOX_WORDS * t.rank + 1], (uint32_t)r.i); }
     team_sync(t);
+    if (t.failed) { ArgPair none; none.v = 0.0f; none.i = -1; return none; }
     float ov = 0.0f; int oi = -1;
     for (int r = (int)threadIdx.x; r < t.size; r += (int)blockDim.x) {
         const float rv = __uint_as_float(box_get(&box[PDP_BOX_WORDS * r])); const int ri = (int)box_get(&box[PDP_BOX_WORDS * r + 1]);
@@ -441,7 +464,8 @@ template <class B> __device__ __forceinline__ ArgPair team_argmax(const Teamed<B
 // Places this workgroup in its team (launch numbering: slot-minor over `slots`) and makes the first barrier: with full agent-scope
 // fences, to find out whether the whole team sits on one XCD (HW_REG_XCC_ID = 20, bits 3:0).  Returns the slot of the launch, or -1 for a
 // padding workgroup (one-XCD teams pad the slot count to the XCD count so that a team's workgroups share an XCD).
-struct TeamLaunch { int size, count, slots, no_xcd; uint32_t *ws; };
+struct TeamLaunch { int size, count, slots, no_xcd; uint32_t *ws; uint32_t spin_limit; };
+uint32_t pdp_spin_limit();                     // PDP_TEAM_SPIN_LIMIT (polls) or the default: how long a team barrier waits before it gives up
 struct pdp_problem;
 int pdp_simplify_lds(pdp_problem *p, hipStream_t st);      // pdp_solve.hip: simplify() with the instances in LDS; 0 if the batch does not qualify
 int pdp_device_cus();                         // CUs of the current device (workgroups that are certainly resident together)
@@ -452,7 +476,8 @@ __device__ __forceinline__ int team_begin(Teamed<B> &t, const TeamLaunch &tl, in
 {
     const int slot = (int)blockIdx.x % tl.slots;
     if (slot >= tl.count) return -1;
-    t.rank = (int)blockIdx.x / tl.slots; t.size = tl.size; t.epoch = 0;
+    t.rank = (int)blockIdx.x / tl.slots; t.size = tl.size; t.epoch = 0; t.failed = 0u;
+    t.spin_limit = tl.spin_limit ? tl.spin_limit : PDP_SPIN_LIMIT_DEFAULT;
     t.bar = tl.ws + (size_t)slot * PDP_TEAM_WORDS; t.box = t.bar + 32;
     t.same_xcd = 0;
     const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf);

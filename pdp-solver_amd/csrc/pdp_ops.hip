@@ -15,7 +15,7 @@ __global__ void k_reset_flags(uint32_t *flags)
     const int i = threadIdx.x;
     if (i >= FL_COUNT) return;
     if (i == FL_GMIN0 || i == FL_GMIN1 || i == FL_GMIN2) flags[i] = PDP_ENC_PLUS_INF;
-    else if (i == FL_LAYOUT_BAD || i == FL_SPEC_VIOLATION) { /* sticky */ }
+    else if (i == FL_LAYOUT_BAD || i == FL_SPEC_VIOLATION || i == FL_TEAM_TIMEOUT) { /* sticky */ }
     else flags[i] = 0u;
 }
 static inline void reset_flags(pdp_problem *p, hipStream_t st) { hipLaunchKernelGGL(k_reset_flags, dim3(1), dim3(64), 0, st, p->flags); }
@@ -46,6 +46,7 @@ __global__ void __launch_bounds__(PDP_NT) k_simplify(PView pv, float *assign_ws,
     static_cast<Inst &>(I) = load_inst(pv, slot);
     const SimplifyScratch s = make_scratch(I, assign_ws, deg, sdeg, fv, ff, ff2, redi);
     d_simplify(I, s, pv.is_sat + I.b);
+    if constexpr (TEAM) { if (I.failed && threadIdx.x == 0) atomicOr(&pv.flags[FL_TEAM_TIMEOUT], 1u); }
 }
 
 // set_variables: assignment lives in caller memory [V]; guard_slot < 0 -> always run
@@ -65,6 +66,7 @@ __global__ void __launch_bounds__(PDP_NT) k_set_variables(PView pv, float *assig
     d_set_variable_core(I, s0);
     const SimplifyScratch s = make_scratch(I, assign_ws, deg, sdeg, fv, ff, ff2, redi);
     d_simplify(I, s, pv.is_sat + I.b);
+    if constexpr (TEAM) { if (I.failed && threadIdx.x == 0) atomicOr(&pv.flags[FL_TEAM_TIMEOUT], 1u); }
 }
 
 // few big instances: teams (chip-wide when the instances are huge: nothing else runs next to these launches)
@@ -128,6 +130,11 @@ static int read_flags(pdp_problem *p, hipStream_t st)
 {
     PDP_HIP_CHECK(hipMemcpyAsync(p->flags_host, p->flags, FL_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     PDP_HIP_CHECK(hipStreamSynchronize(st));
+    if (p->flags_host[FL_TEAM_TIMEOUT]) {
+        pdp_set_error("a team of workgroups that shares one big instance was not resident together: its barrier gave up instead of hanging; "
+                      "the problem's state is void (is another process using this GPU?)");
+        return PDP_ERR_HIP;
+    }
     return PDP_OK;
 }
 
@@ -400,6 +407,7 @@ __global__ void __launch_bounds__(PDP_NT) k_cnf_eval(PView pv, const float *pred
         solved[I.b] = (max_sat == bv) ? 1.0f : 0.0f;
         unsat[I.b] = max_sat - bv;
     }
+    if constexpr (TEAM) { if (I.failed && threadIdx.x == 0) atomicOr(&pv.flags[FL_TEAM_TIMEOUT], 1u); }
 }
 
 static int launch_cnf_eval(pdp_problem *p, const float *pred, float *solved, float *unsat, hipStream_t st)

@@ -506,6 +506,7 @@ int pdp_team_plan(pdp_problem *p, int count, bool wide, int threads, TeamLaunch 
     if (go_wide) { while (size * 2 <= cap && (size_t)count * size * 2 <= (size_t)cus && (size_t)p->max_e >= (size_t)size * 2 * threads * 2) size *= 2; }
     else { while (size * 2 <= cap && per_xcd * size * 2 <= per_xcd_cus && (size_t)p->max_e >= (size_t)size * 2 * threads * 2) size *= 2; }
     out->size = size; out->count = count; out->no_xcd = getenv("PDP_SOLVE_TEAM_AGENT_FENCES") ? 1 : 0; out->ws = nullptr;
+    out->spin_limit = pdp_spin_limit();
     // slot-minor numbering; one-XCD teams pad the slot count to the XCD count so that a team's workgroups share an XCD
     out->slots = go_wide ? count : ((count + 7) & ~7);
     if (size > 1) {
@@ -514,6 +515,12 @@ int pdp_team_plan(pdp_problem *p, int count, bool wide, int threads, TeamLaunch 
         out->ws = p->team_ws;
     }
     return PDP_OK;
+}
+
+uint32_t pdp_spin_limit()
+{
+    if (const char *env = getenv("PDP_TEAM_SPIN_LIMIT")) { const long long v = atoll(env); if (v >= 1024 && v <= 0xffffffffll) return (uint32_t)v; }
+    return PDP_SPIN_LIMIT_DEFAULT;
 }
 
 int pdp_edge_rows(const pdp_problem *p)

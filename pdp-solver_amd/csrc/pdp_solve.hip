@@ -81,6 +81,8 @@ struct SolveParams {
     const int32_t *fit_list;    // NULL: instance = blockIdx.x
     const int32_t *big_list;    // HBM-resident kernel: NULL: instance = blockIdx.x
     int hbm_device_ctl;         // HBM-resident kernel: 1 = stop / poison / replay decisions come from ctl / call (else from the host: poison_from)
+    uint32_t spin_limit;        // team / lock-step barriers: polls before a wait gives up (0: the default; pdp_spin_limit())
+    int lock_size;              // lock-step launch: workgroups the batch barrier waits for (0: the grid; a test makes it one too many)
     int hbm_replay;             // HBM-resident kernel under device control: this launch is the replay pass
     uint32_t *w_perm_zero, *w_iters_run, *w_violation;   // HBM-resident kernel: where its control words go (pv.flags slots, or the chunk's SolveCtl)
     // teams (k_sp_solve<NT, true>): team_size workgroups per instance, team_count instances, numbered slot-minor over team_slots
@@ -340,6 +342,7 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
         // the team is the long pole of a mixed batch and shares its CUs with the LDS-resident kernel's waves: let the scheduler prefer it
         __builtin_amdgcn_s_setprio(3);
         TeamLaunch tl; tl.size = sp.team_size; tl.count = sp.team_count; tl.slots = sp.team_slots; tl.no_xcd = sp.team_no_xcd; tl.ws = sp.team_ws;
+        tl.spin_limit = sp.spin_limit;
         slot = team_begin(I, tl, redi);
         if (slot < 0) return;
     }
@@ -431,7 +434,8 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
     // (scorer: a NaN score reaches the sequential decimator's coefficient sum; Reinforce takes torch.sign of it, which is 0 for a NaN)
     auto ghost_bad = [&]() -> int { return d_ghost_bad(I, sp.pi, L0h, L1h, use_em != 0, !rf); };
     if constexpr (LOCK) {
-        BT.rank = (int)blockIdx.x; BT.size = (int)gridDim.x; BT.epoch = 0; BT.same_xcd = 2; BT.bar = sp.team_ws; BT.box = BT.bar + 32;
+        BT.rank = (int)blockIdx.x; BT.size = sp.lock_size ? sp.lock_size : (int)gridDim.x; BT.epoch = 0; BT.same_xcd = 2; BT.bar = sp.team_ws; BT.box = BT.bar + 32;
+        BT.failed = 0u; BT.spin_limit = sp.spin_limit ? sp.spin_limit : PDP_SPIN_LIMIT_DEFAULT;
         if (!active) frozen();
     }
 #ifdef PDP_PHASE_PROF
@@ -756,6 +760,10 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
     int any_inactive = 0;
     for (int v = tid; v < n; v += nt) any_inactive |= (I.av[v] == 0.0f) ? 1 : 0;
     any_inactive = team_any(I, any_inactive);
+    // a team barrier (or the lock-step batch's) gave up: what this launch computed is void -- reported like a failed speculation, the host
+    // restores the call-entry state and fails over to the strict step-wise loop
+    if constexpr (TEAM) { if (I.failed) violation = 1; }
+    if constexpr (LOCK) { if (BT.failed) violation = 1; }
     if (tid == 0) {
         if (any_inactive) atomicMin(sp.w_perm_zero, (uint32_t)iters);
         sp.amask[G.b] = (uint8_t)active;
@@ -2161,6 +2169,7 @@ static int launch_hbm(pdp_problem *p, SolveParams sp, int count, hipStream_t s_,
     { const int st_ = pdp_team_plan(p, count, wide, tnt, &tl, s_); if (st_ != PDP_OK) return st_; }
     if (tl.size > 1) {
         sp.team_size = tl.size; sp.team_count = tl.count; sp.team_slots = tl.slots; sp.team_ws = tl.ws; sp.team_no_xcd = tl.no_xcd;
+        sp.spin_limit = tl.spin_limit;
         if (tnt == 1024) hipLaunchKernelGGL((k_sp_solve<1024, true>), dim3(tl.size * tl.slots), dim3(1024), 0, s_, make_view(p), sp);
         else if (tnt == 512) hipLaunchKernelGGL((k_sp_solve<512, true>), dim3(tl.size * tl.slots), dim3(512), 0, s_, make_view(p), sp);
         else hipLaunchKernelGGL((k_sp_solve<256, true>), dim3(tl.size * tl.slots), dim3(256), 0, s_, make_view(p), sp);
@@ -2529,7 +2538,10 @@ static int sp_solve_lockstep(pdp_problem *p, pdp_solve_args *a, hipStream_t st)
     { const int st_ = hbm_workspaces(p, sp); if (st_ != PDP_OK) return st_; }
     if (!p->team_ws) { int st_ = pdp_dev_alloc((void **)&p->team_ws, sizeof(uint32_t) * 256 * PDP_TEAM_WORDS); if (st_ != PDP_OK) return st_; }
     PDP_HIP_CHECK(hipMemsetAsync(p->team_ws, 0, sizeof(uint32_t) * PDP_TEAM_WORDS, st));
-    sp.team_ws = p->team_ws;
+    sp.team_ws = p->team_ws; sp.spin_limit = pdp_spin_limit();
+    // (test hook: PDP_DEBUG_LOCK_EXTRA=1 makes the batch barrier wait for a workgroup that does not exist -- the bounded wait must give up,
+    //  report a violation, and the call must fail over instead of hanging)
+    sp.lock_size = getenv("PDP_DEBUG_LOCK_EXTRA") ? p->B + 1 : 0;
     PDP_HIP_CHECK(hipMemsetAsync(p->flags + FL_PERM_ZERO, 0xff, sizeof(uint32_t), st));
     PDP_HIP_CHECK(hipMemsetAsync(p->flags + FL_SPEC_VIOLATION, 0, sizeof(uint32_t) * 2, st));
     hipLaunchKernelGGL((k_sp_solve<256, false, true>), dim3(p->B), dim3(256), 0, st, make_view(p), sp);

@@ -684,6 +684,7 @@ __global__ void __launch_bounds__(NT) k_walksat_team(PView pv, WsParams wp, Team
             if (zero32) atomicOr(&wp.spec_zero[w], zero32);
         }
     }
+    if (TT.failed && threadIdx.x == 0) atomicOr(&pv.flags[FL_TEAM_TIMEOUT], 1u);      // a team barrier gave up (pdp_common.hpp): the search is void
 }
 
 __global__ void k_ws_group_stop(int B0, int R, int cap, const int32_t *first_sat, uint32_t *stop /*max over originals of min over replicas*/)
@@ -865,6 +866,16 @@ static int local_search_persistent(pdp_problem *p, const float *pred, int iterat
     }
     for (int t = 0; t < stop && t < first_finish && ok; ++t)
         if (((host[t >> 5] >> (t & 31)) & 1u) && !((host[bw + (t >> 5)] >> (t & 31)) & 1u)) ok = false;
+    if (status == PDP_OK && nbig) {
+        // the big instances ran as teams of workgroups: did one of their barriers give up (workgroups not resident together)?
+        uint32_t timed_out = 0;
+        if (hipMemcpy(&timed_out, p->flags + FL_TEAM_TIMEOUT, 4, hipMemcpyDeviceToHost) != hipSuccess) status = PDP_ERR_HIP;
+        else if (timed_out) {
+            pdp_set_error("Walk-SAT: a team of workgroups that shares one big instance was not resident together: its barrier gave up instead of "
+                          "hanging; the search result is void (is another process using this GPU?)");
+            status = PDP_ERR_HIP;
+        }
+    }
     if (status != PDP_OK) return status;
     if (!ok) return PDP_OK;          // caller runs the strict loop on the untouched inputs
     if (steps_host) *steps_host = stop;

@@ -113,6 +113,25 @@ def test_nan_leak_into_an_inactive_instance_fails_over_to_the_stepwise_loop(pers
     assert position[nxt] == int(d['iterations_run'][0])
 
 
+def test_a_batch_barrier_that_cannot_complete_gives_up_and_the_call_fails_over(monkeypatch):
+    """The lock-step launch (replicas that differ: trace_pdp_rep3_randinit) makes its workgroups wait for each other.  If they are not all
+    resident the wait could never end; it is bounded (csrc/pdp_common.hpp: team_sync).  PDP_DEBUG_LOCK_EXTRA makes the barrier wait for a
+    workgroup that does not exist: the launch must give up within the (here: short) limit, report the failure like a failed speculation, the
+    library restores the state, and the solver reaches the reference's result on the strict step-wise loop -- no hang, no garbage."""
+    import time
+    monkeypatch.setenv('PDP_DEBUG_LOCK_EXTRA', '1')
+    monkeypatch.setenv('PDP_TEAM_SPIN_LIMIT', '8192')
+    t0 = time.time()
+    d, tr, m, pred, states, batch = run_golden('trace_pdp_rep3_randinit', 'p-d-p', persistent=True, tolerance=0.05, t_max=6)
+    assert time.time() - t0 < 120
+    assert m.last_run['path'] == 'stepwise'
+    np.testing.assert_array_equal(pred[0].cpu().numpy()[:, 0], d['final_prediction'])
+    monkeypatch.delenv('PDP_DEBUG_LOCK_EXTRA')
+    d, tr, m, pred, states, batch = run_golden('trace_pdp_rep3_randinit', 'p-d-p', persistent=True, tolerance=0.05, t_max=6)
+    assert m.last_run['path'] == 'persistent-hbm'
+    np.testing.assert_array_equal(pred[0].cpu().numpy()[:, 0], d['final_prediction'])
+
+
 def test_post_processing_rows():
     d, tr, m, pred, states, (gm, bvm, bfm, ef) = run_golden('trace_pdp_easy_ws', 'p-d-p', tolerance=0.05, t_max=10)
     B = int(bvm.max()) + 1
