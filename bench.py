@@ -335,11 +335,13 @@ def make_neural_model(args, T, model_type='np-nd-np', hidden=None):
 
 def neural_step(tr, model, b, T, replication=1):
     import torch
+    from pdp.nn.solver import OwnedState
     gm, bvm, bfm, ef = b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature']
     with torch.no_grad():
-        st = model.get_init_state(gm, bvm, bfm, ef, None, randomized=False, batch_replication=replication)
-        model(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None,
-              is_training=False, iteration_num=T, check_termination=tr._check_recurrence_termination, batch_replication=replication)
+        # exactly what FactorGraphTrainerBase._predict_batch does: the initial state is handed over, not kept
+        model.forward(init_state=OwnedState(model.get_init_state(gm, bvm, bfm, ef, None, randomized=False, batch_replication=replication)),
+                      graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None,
+                      is_training=False, iteration_num=T, check_termination=tr._check_recurrence_termination, batch_replication=replication)
     return model.last_run['iterations']
 
 
@@ -388,6 +390,7 @@ def neural_shard(args, dev, native, items, model_type, hidden, T, replication=1,
     # best of two timed passes: at 25 M edges every [E, 128] state is 12.9 GB and torch's caching allocator may still release and re-acquire
     # blocks in the first pass after the warm-up (a forward then takes 2-3 x its steady-state time; tools/neural_forward_phases.py)
     dt, its, timing = None, None, None
+    torch.cuda.reset_peak_memory_stats()
     for _ in range(2):
         torch.cuda.synchronize()
         native.kernel_timing(True)
@@ -405,6 +408,9 @@ def neural_shard(args, dev, native, items, model_type, hidden, T, replication=1,
                segments=[len(sg) for sg in segs], edges_per_segment_with_replicas=E_seg, iterations_per_segment=its, seconds=dt,
                segment_iterations_per_sec=sum(its) / dt, ms_per_iteration_mean=1e3 * dt / max(1, sum(its)), flop_total=flop,
                flop_per_iteration_mean=flop / max(1, sum(its)), path=model.last_run['path'],
+               # device memory of the timed passes: torch's allocator (the [E, H] states; the library's own workspaces are not in it)
+               max_memory_reserved_gb=torch.cuda.max_memory_reserved() / 1e9, max_memory_allocated_gb=torch.cuda.max_memory_allocated() / 1e9,
+               state_tensor_gb=max(E_seg) * hidden * 4 / 1e9,
                roofline=dict(bound='mfma', achieved=tf, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s', frac=tf / MFMA_F32_PEAK_TFLOPS,
                              note='algorithmic flop of the executed sweeps (neural_flop_per_iteration per segment) / wall time of the forwards, '
                                   'set-up of each SATProblem included'),

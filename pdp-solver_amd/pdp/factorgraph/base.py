@@ -14,6 +14,7 @@ import torch
 
 from pdp import native
 from pdp.factorgraph.dataset import FactorGraphDataset
+from pdp.nn.solver import OwnedState
 
 
 class FactorGraphTrainerBase(object):
@@ -212,12 +213,14 @@ class FactorGraphTrainerBase(object):
                        post_processor, batch_replication, file):
         "reference: base.py:280-305"
         for model in self._model_list:
-            state = model.get_init_state(graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat,
-                                         randomized=False, batch_replication=batch_replication)
-            prediction, _ = model(init_state=state, graph_map=graph_map, batch_variable_map=batch_variable_map,
-                                  batch_function_map=batch_function_map, edge_feature=edge_feature, meta_data=graph_feat,
-                                  is_training=False, iteration_num=self._config['test_recurrence_num'],
-                                  check_termination=self._check_recurrence_termination, batch_replication=batch_replication)
+            # the initial state is handed over, not kept (and `forward` is called without nn.Module's wrapper frames, which would hold the
+            # keyword arguments for the whole call): its [E, H] tensors are released after the first sweep (pdp.nn.solver: forward)
+            prediction, _ = model.forward(init_state=OwnedState(model.get_init_state(graph_map, batch_variable_map, batch_function_map, edge_feature,
+                                                                                     graph_feat, randomized=False, batch_replication=batch_replication)),
+                                          graph_map=graph_map, batch_variable_map=batch_variable_map,
+                                          batch_function_map=batch_function_map, edge_feature=edge_feature, meta_data=graph_feat,
+                                          is_training=False, iteration_num=self._config['test_recurrence_num'],
+                                          check_termination=self._check_recurrence_termination, batch_replication=batch_replication)
             if post_processor is not None and callable(post_processor):
                 message = post_processor(model, prediction, graph_map, batch_variable_map, batch_function_map,
                                          edge_feature, graph_feat, label, misc_data)

@@ -155,6 +155,19 @@ class SATProblem(object):
 ### The Solver Classes
 ###############################################################
 
+class OwnedState(list):
+    """An initial state whose ownership travels with the call: ``model.forward(init_state=OwnedState(model.get_init_state(...)), ...)``.
+    A Python caller keeps its arguments alive for the whole call (they stay on its evaluation stack), so a plain tuple pins the four
+    [E, H] initial tensors of a neural solver until ``forward`` returns -- 52 GB on the configs[3] shard -- although they are dead after the
+    first sweep.  ``forward`` empties an OwnedState as soon as it has unpacked it; what the caller still holds is an empty list.  The
+    predict / test drivers use it; a plain tuple works as in the reference (and is kept alive by its owner, as in the reference)."""
+
+    def take(self):
+        items = tuple(self)
+        self.clear()
+        return items
+
+
 def _is_standard_termination(check_termination):
     "the trainer's CNF-check callback (trainer.py:150-162) is implemented inside the persistent kernel"
     return check_termination is not None and getattr(check_termination, '_pdp_standard_termination', False)
@@ -204,7 +217,12 @@ class PropagatorDecimatorSolverBase(nn.Module):
     def forward(self, init_state, graph_map, batch_variable_map, batch_function_map, edge_feature,
                 meta_data, is_training=True, iteration_num=1, check_termination=None, simplify=True, batch_replication=1):
         native.require_gpu()
-        init_propagator_state, init_decimator_state = init_state
+        # The initial state is only needed until the first sweep has read it.  It travels down in an OwnedState box that the frame which
+        # finally uses it empties: no frame on the way keeps a reference, and a caller that hands over an OwnedState itself -- the predict /
+        # test drivers do -- lets the four [E, H] tensors go after the first sweep (52 GB on the configs[3] shard).  A caller that keeps
+        # a plain tuple keeps the tensors, as with the reference.
+        owned = OwnedState(init_state.take() if isinstance(init_state, OwnedState) else init_state)
+        del init_state
         batch_replication = 1 if is_training else batch_replication
         sat_problem = SATProblem((graph_map, batch_variable_map, batch_function_map, edge_feature, meta_data, None),
                                  self._device, batch_replication)
@@ -222,8 +240,7 @@ class PropagatorDecimatorSolverBase(nn.Module):
                 sat_problem.simplify()
 
             if self._propagator is not None and self._decimator is not None:
-                propagator_state, decimator_state = self._forward_core(init_propagator_state, init_decimator_state,
-                                                                       sat_problem, iteration_num, is_training, check_termination)
+                propagator_state, decimator_state = self._forward_core(owned, None, sat_problem, iteration_num, is_training, check_termination)
             else:
                 decimator_state = None
                 propagator_state = None
@@ -289,6 +306,9 @@ class PropagatorDecimatorSolverBase(nn.Module):
         return self._replicas_same or model == native.MODEL_SP
 
     def _forward_core(self, init_propagator_state, init_decimator_state, sat_problem, iteration_num, is_training, check_termination):
+        # (reference signature; `forward` passes the two states in one OwnedState box as the first argument)
+        box = init_propagator_state if isinstance(init_propagator_state, OwnedState) else OwnedState((init_propagator_state, init_decimator_state))
+        init_propagator_state, init_decimator_state = box[0], box[1]
         can = self._can_run_persistent(sat_problem, is_training, check_termination, tuple(init_propagator_state[:2]) + tuple(init_decimator_state[:2]))
         if self._isolated and not can:
             raise native.NativeError("isolated-instance mode runs on the persistent SP loop only (p-d-p, standard termination check)")
@@ -296,8 +316,8 @@ class PropagatorDecimatorSolverBase(nn.Module):
             out = self._forward_core_persistent(init_propagator_state, init_decimator_state, sat_problem, iteration_num, check_termination)
             if out is not None:
                 return out
-        return self._forward_core_stepwise(init_propagator_state, init_decimator_state, sat_problem, iteration_num,
-                                           is_training, check_termination)
+        del init_propagator_state, init_decimator_state                # (see forward: this frame lets go of the initial state)
+        return self._forward_core_stepwise(box, None, sat_problem, iteration_num, is_training, check_termination)
 
     def _forward_core_persistent(self, init_propagator_state, init_decimator_state, sat_problem, iteration_num, check_termination):
         """the whole loop of solver.py:355-386 in one kernel launch; None if the speculation failed.  The first sweep reads the
@@ -345,8 +365,11 @@ class PropagatorDecimatorSolverBase(nn.Module):
 
     def _forward_core_stepwise(self, init_propagator_state, init_decimator_state, sat_problem, iteration_num, is_training, check_termination):
         "generic plug-in loop, statement for statement the reference's (solver.py:355-386)"
-        propagator_state = init_propagator_state
-        decimator_state = init_decimator_state
+        if isinstance(init_propagator_state, OwnedState):
+            propagator_state, decimator_state = init_propagator_state.take()     # the box is empty now: these two names are the only references
+        else:
+            propagator_state, decimator_state = init_propagator_state, init_decimator_state
+        del init_propagator_state, init_decimator_state          # one name per state: the old tensors go when a sweep replaces them
         if check_termination is None:
             active_mask = None
         else:
