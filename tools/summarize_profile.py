@@ -7,6 +7,7 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
+prefix = sys.argv[2] if len(sys.argv) > 2 else ''      # 'fast_': the passes of the opt-in fast build (profile_bench.sh)
 
 
 def find(pattern):
@@ -15,7 +16,7 @@ def find(pattern):
 
 print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
 for f in find('*kernel_stats.csv'):
-    if '/trace/' not in f:
+    if '/%strace/' % prefix not in f:
         continue
     with open(f) as fh:
         rows = list(csv.DictReader(fh))
@@ -26,7 +27,7 @@ print()
 print("== PMC counters per kernel (sum over dispatches / dispatches) ==")
 for d in ('pmc1', 'pmc2', 'pmc5', 'pmc6', 'pmc7', 'pmc3', 'pmc4'):
     for f in find('*counter_collection.csv'):
-        if '/%s/' % d not in f:
+        if '/%s%s/' % (prefix, d) not in f:
             continue
         acc = defaultdict(lambda: defaultdict(float))
         cnt = defaultdict(set)
@@ -47,7 +48,7 @@ import json
 vals = {}
 for d, name in (('pmc3', 'FETCH_SIZE'), ('pmc4', 'WRITE_SIZE')):
     for f in find('*counter_collection.csv'):
-        if '/%s/' % d not in f:
+        if '/%s%s/' % (prefix, d) not in f:
             continue
         tot, disp = 0.0, set()
         with open(f) as fh:
@@ -60,6 +61,6 @@ if 'FETCH_SIZE' in vals and 'WRITE_SIZE' in vals:
     out = dict(FETCH_SIZE_KiB_per_launch=vals['FETCH_SIZE'], WRITE_SIZE_KiB_per_launch=vals['WRITE_SIZE'],
                k_sp_solve_lds_bytes_per_launch=(2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0,
                note='2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes; average over the launches of k_sp_solve_lds<false, false, false> (one per chunk of 12 iterations; the poison replay is k_sp_solve_lds<false, true, false>)')
-    json.dump(out, open(os.path.join(root, 'pmc_traffic.json'), 'w'), indent=1)
+    json.dump(out, open(os.path.join(root, prefix + 'pmc_traffic.json'), 'w'), indent=1)
     print()
     print('== HBM traffic of k_sp_solve_lds per launch:', json.dumps(out))
