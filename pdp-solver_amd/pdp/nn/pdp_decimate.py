@@ -14,8 +14,9 @@ class NeuralDecimator(nn.Module):
     def __init__(self, device, message_dimension, meta_data_dimension, hidden_dimension, mem_hidden_dimension,
                  mem_agg_hidden_dimension, agg_hidden_dimension, edge_dimension, dropout):
         super(NeuralDecimator, self).__init__()
-        if edge_dimension != 1 or meta_data_dimension != 0:
-            raise native.NativeError("NeuralDecimator: native kernels need edge_feature_dim = 1 and meta_feature_dim = 0")
+        if edge_dimension != 1:
+            raise native.NativeError("NeuralDecimator: edge_feature_dim = 1 only (the loader's edge feature is the literal's sign)")
+        self._meta_dim = meta_data_dimension       # > 0: graph features appended to the cells' inputs (pdp_decimate.py:63-65, 72-73, 80-81) -> generic GRU operator
         self._device = device
         self._module_list = nn.ModuleList()
         self._drop_out = dropout
@@ -42,13 +43,15 @@ class NeuralDecimator(nn.Module):
 
     def forward(self, init_state, message_state, sat_problem, is_training, active_mask=None):
         variable_state, function_state = message_state
-        if util.on_train_path(self, is_training):
-            # the differentiable cells of the training path (pdp_decimate.py:51-87)
+        if util.on_train_path(self, is_training) or self._meta_dim > 0 or sat_problem._meta_data is not None:
+            # the differentiable cells of the training path (pdp_decimate.py:51-87); also what runs when graph features widen the inputs
             from pdp.nn import train_ops as T
             sign = sat_problem._edge_feature
+            gf = sat_problem.edge_meta()
+            extra = (sign,) if gf is None else (sign, gf)
             cv, cf = self._variable_rnn_cell, self._function_rnn_cell
-            nv = T.GruCell.apply(torch.cat((variable_state, sign), 1), init_state[0], cv.weight_ih, cv.weight_hh, cv.bias_ih, cv.bias_hh)
-            nf = T.GruCell.apply(torch.cat((function_state, sign), 1), init_state[1], cf.weight_ih, cf.weight_hh, cf.bias_ih, cf.bias_hh)
+            nv = T.GruCell.apply(torch.cat((variable_state,) + extra, 1), init_state[0], cv.weight_ih, cv.weight_hh, cv.bias_ih, cv.bias_hh)
+            nf = T.GruCell.apply(torch.cat((function_state,) + extra, 1), init_state[1], cf.weight_ih, cf.weight_hh, cf.bias_ih, cf.bias_hh)
             if active_mask is not None:
                 mask = active_mask.reshape(-1).float()[sat_problem._batch_variable_map.long()][sat_problem._graph_map[0].long()].unsqueeze(1)
                 nv = mask * nv + (1 - mask) * init_state[0]; nf = mask * nf + (1 - mask) * init_state[1]

@@ -28,8 +28,9 @@ class NeuralPredictor(nn.Module):
     def __init__(self, device, decimator_dimension, prediction_dimension, edge_dimension, meta_data_dimension, mem_hidden_dimension,
                  agg_hidden_dimension, mem_agg_hidden_dimension, variable_classifier=None, function_classifier=None):
         super(NeuralPredictor, self).__init__()
-        if edge_dimension != 1 or meta_data_dimension != 0 or prediction_dimension != 1:
-            raise native.NativeError("NeuralPredictor: native kernels need edge_feature_dim = 1, meta_feature_dim = 0, prediction_dim = 1")
+        if edge_dimension != 1 or prediction_dimension != 1:
+            raise native.NativeError("NeuralPredictor: edge_feature_dim = 1 and prediction_dim = 1 only")
+        self._meta_dim = meta_data_dimension       # > 0: graph features appended to the aggregator's input (pdp_predict.py:57-59, 71-72) -> generic operators
         from pdp.nn import util
         self._device = device
         self._module_list = nn.ModuleList()
@@ -63,7 +64,9 @@ class NeuralPredictor(nn.Module):
     def _generic_branch(state, aggregator, classifier, sat_problem, by_variable, edge_mask):
         "aggregator + perceptron head as generic native operators (differentiable; pdp_predict.py:67-89, trainer.py:28-29 for the head)"
         from pdp.nn import train_ops as T
-        agg = aggregator.forward_train(torch.cat((state, sat_problem._edge_feature), 1), None, sat_problem, by_variable, edge_mask)
+        gf = sat_problem.edge_meta()
+        rows = (state, sat_problem._edge_feature) if gf is None else (state, sat_problem._edge_feature, gf)
+        agg = aggregator.forward_train(torch.cat(rows, 1), None, sat_problem, by_variable, edge_mask)
         hid = T.LinearAct.apply(agg, classifier._layer1.weight, classifier._layer1.bias, 'relu')
         out_act = 'tanh' if type(classifier).__name__ == 'PerceptronTanh' else 'sigmoid'
         return T.LinearAct.apply(hid, classifier._layer2.weight, None, out_act)
@@ -71,6 +74,7 @@ class NeuralPredictor(nn.Module):
     def forward(self, decimator_state, sat_problem, last_call=False):
         pinned = getattr(self, '_train_path', None)       # set by the solver's forward (one decision for the three plug-ins)
         train = (torch.is_grad_enabled() and decimator_state[0].requires_grad) if pinned is None else pinned
+        train = train or self._meta_dim > 0 or sat_problem._meta_data is not None       # graph features: generic operators
         em = decimator_state[2] if len(decimator_state) == 3 else None
         variable_prediction = function_prediction = None
         if self._variable_classifier is not None:

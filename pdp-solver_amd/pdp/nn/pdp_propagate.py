@@ -19,11 +19,12 @@ class NeuralMessagePasser(nn.Module):
     def __init__(self, device, edge_dimension, decimator_dimension, meta_data_dimension, hidden_dimension, mem_hidden_dimension,
                  mem_agg_hidden_dimension, agg_hidden_dimension, dropout):
         super(NeuralMessagePasser, self).__init__()
-        if edge_dimension != 1 or meta_data_dimension != 0:
-            raise native.NativeError("NeuralMessagePasser: native kernels need edge_feature_dim = 1 and meta_feature_dim = 0")
+        if edge_dimension != 1:
+            raise native.NativeError("NeuralMessagePasser: edge_feature_dim = 1 only (the loader's edge feature is the literal's sign)")
         self._device = device
         self._module_list = nn.ModuleList()
         self._drop_out = dropout
+        self._meta_dim = meta_data_dimension       # > 0: graph features are appended to every edge's input (pdp_propagate.py:59-61, 74-75, 85-86) -> generic operators
         self._variable_aggregator = util.MessageAggregator(device, decimator_dimension + edge_dimension + meta_data_dimension,
                                                            hidden_dimension, mem_hidden_dimension, mem_agg_hidden_dimension,
                                                            agg_hidden_dimension, edge_dimension, include_self_message=False)
@@ -40,6 +41,9 @@ class NeuralMessagePasser(nn.Module):
     def forward(self, init_state, decimator_state, sat_problem, is_training, active_mask=None):
         if util.on_train_path(self, is_training):
             return self._forward_train(init_state, decimator_state, sat_problem, active_mask)
+        if self._meta_dim > 0 or sat_problem._meta_data is not None:
+            # graph features: the fused kernels take [state | sign] rows only; the layers and row sums run as generic native operators
+            return self._forward_train(init_state, decimator_state, sat_problem, active_mask, dropout=bool(is_training))
         if is_training and self._drop_out > 0:
             raise native.NativeError("is_training with dropout needs gradients enabled (the differentiable training path)")
         if len(decimator_state) == 3:
@@ -59,7 +63,7 @@ class NeuralMessagePasser(nn.Module):
                                                     decimator_function_state.contiguous(), edge_mask, am, variable_state.contiguous())
         return variable_state, function_state
 
-    def _forward_train(self, init_state, decimator_state, sat_problem, active_mask):
+    def _forward_train(self, init_state, decimator_state, sat_problem, active_mask, dropout=True):
         "the differentiable sweep of the training path (pdp_propagate.py:47-95 with is_training=True): aggregators + dropout"
         from pdp.nn import train_ops as T
         if len(decimator_state) == 3:
@@ -71,14 +75,18 @@ class NeuralMessagePasser(nn.Module):
         sign = sat_problem._edge_feature
         if active_mask is not None:
             mask = active_mask.reshape(-1).float()[sat_problem._batch_variable_map.long()][sat_problem._graph_map[0].long()].unsqueeze(1)
-        fs = self._variable_aggregator.forward_train(torch.cat((dec_v, sign), 1), sign, sat_problem, True, edge_mask)
+        gf = sat_problem.edge_meta()
+        extra = (sign,) if gf is None else (sign, gf)
+        fs = self._variable_aggregator.forward_train(torch.cat((dec_v,) + extra, 1), sign, sat_problem, True, edge_mask)
         if active_mask is not None:
             fs = mask * fs + (1 - mask) * function_state
-        fs = T.dropout(fs, self._drop_out, getattr(self, '_rng', 'device'))
-        vs = self._function_aggregator.forward_train(torch.cat((dec_f, sign), 1), sign, sat_problem, False, edge_mask)
+        if dropout:
+            fs = T.dropout(fs, self._drop_out, getattr(self, '_rng', 'device'))
+        vs = self._function_aggregator.forward_train(torch.cat((dec_f,) + extra, 1), sign, sat_problem, False, edge_mask)
         if active_mask is not None:
             vs = mask * vs + (1 - mask) * variable_state
-        vs = T.dropout(vs, self._drop_out, getattr(self, '_rng', 'device'))
+        if dropout:
+            vs = T.dropout(vs, self._drop_out, getattr(self, '_rng', 'device'))
         return vs, fs
 
     def get_init_state(self, graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, randomized, batch_replication):

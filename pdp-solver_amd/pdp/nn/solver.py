@@ -49,14 +49,18 @@ class SATProblem(object):
         self._device = device
         self._batch_replication = batch_replication
         graph_map, batch_variable_map, batch_function_map, edge_feature, meta_data, _ = data_batch
-        if meta_data is not None:
-            raise native.NativeError("meta_data (graph features) is not supported by the native path "
-                                     "(has_meta_data is False in every reference config)")
         self._orig = (graph_map, batch_variable_map, batch_function_map, edge_feature)
         self._native = native.Problem(graph_map, batch_variable_map, batch_function_map, edge_feature,
                                       replication=batch_replication)
         self._native1 = None
+        # per-instance graph features [B0, M] (solver.py:35; replicated like the batch, :76-77).  No shipped config has them
+        # (has_meta_data is False, trainer.py:39, and the loader yields None); the neural plug-ins take them on their generic operators.
         self._meta_data = None
+        if meta_data is not None:
+            self._meta_data = meta_data.to(torch.float32)
+            if batch_replication > 1:
+                self._meta_data = self._meta_data.repeat(batch_replication, 1)
+        self._edge_meta = None
         self._variable_num = self._native.V
         self._function_num = self._native.F
         self._edge_num = self._native.E
@@ -75,6 +79,16 @@ class SATProblem(object):
         self._masks = {}
         SATProblem._live[id(self._graph_map)] = self
         SATProblem._live[id(graph_map)] = self
+
+    def edge_meta(self):
+        """[E, M]: the graph features of every edge's instance -- what the reference computes as
+        mm(variable_mask_transpose, mm(b_variable_mask, meta_data)) (pdp_propagate.py:59-61), a gather here; None without meta data"""
+        if self._meta_data is None:
+            return None
+        if self._edge_meta is None:
+            inst = self._batch_variable_map.long()[self._graph_map[0].long()]
+            self._edge_meta = self._meta_data[inst].contiguous()
+        return self._edge_meta
 
     def _native_unreplicated(self):
         "handle on the original (non-replicated) batch, used by evaluators that look at de-duplicated predictions"

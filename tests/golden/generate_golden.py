@@ -1194,6 +1194,63 @@ def gen_subsumption():
 
 # ---- E. CLI -------------------------------------------------------------------------------------
 
+def gen_meta_data():
+    """np-nd-np with graph features (meta_feature_dim = 3): no shipped config has them and the loader never yields any, but the plug-in API
+    takes them (pdp_propagate.py:59-61, pdp_decimate.py:63-65, pdp_predict.py:57-59, solver.py:76-77).  A predict-style forward with
+    batch replication 2 and Walk-SAT (recorded random stream), and a training-style forward + backward of the energy loss."""
+    lines = make_lines([(16, 50, (3,))] * 4 + [(12, 34, (2, 3, 4))] * 2, seed0=3100)
+    gm, bvm, bfm, ef, lab, misc = batch_tensors(lines)
+    H, M, T, w = 16, 3, 4, 5
+    cfg = base_cfg('np-nd-np', hidden_dim=H, meta_feature_dim=M, mem_hidden_dim=20, agg_hidden_dim=20, mem_agg_hidden_dim=10, classifier_dim=10,
+                   local_search_iteration=w)
+    tr, m = build(cfg, seed=4321)
+    B = int(bvm.max()) + 1
+    torch.manual_seed(5)
+    meta = torch.randn(B, M)
+    out = problem_arrays(gm, bvm, bfm, ef)
+    out['meta_data'] = np_(meta)
+    for k, v in m.state_dict().items():
+        if '_module_list' not in k:                      # the aliases share storage with these
+            out['w::' + k] = np_(v)
+    RAND_LOG.clear()
+    torch.rand = _rec_rand
+    try:
+        torch.manual_seed(9)
+        with torch.no_grad():
+            st = m.get_init_state(gm, bvm, bfm, ef, meta, randomized=True, batch_replication=2)        # (the test redraws it: same seed, same stream)
+            out['init_checksum'] = np.array([float(x.double().sum()) for x in st[0] + st[1]])
+            pred, (ps, ds) = m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=meta,
+                               is_training=False, iteration_num=T, check_termination=tr._check_recurrence_termination, batch_replication=2)
+    finally:
+        torch.rand = _TORCH_RAND
+    out['rand_sizes'] = np.array([r.size for r in RAND_LOG], np.int64)
+    out['final_prediction'] = np_(pred[0])[:, 0]
+    for i, x in enumerate(ps):
+        out['final_prop_%d' % i] = np_(x)
+    for i, x in enumerate(ds):
+        out['final_dec_%d' % i] = np_(x)
+    # training style: two outer recurrences from zeros, loss = energy, gradients of the layers that see the meta columns
+    m.zero_grad()
+    st = m.get_init_state(gm, bvm, bfm, ef, meta, randomized=False)
+    loss = torch.zeros(1)
+    for t in range(2):
+        pred, st = m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=meta,
+                     is_training=True, iteration_num=2)
+        loss = loss + tr._compute_loss(model=m, loss=None, prediction=pred, label=lab, graph_map=gm, batch_variable_map=bvm,
+                                       batch_function_map=bfm, edge_feature=ef, meta_data=meta)
+    loss.backward()
+    out['train_loss'] = np_(loss)
+    out['train_prediction'] = np_(pred[0])[:, 0]
+    for name in ('_propagator._variable_aggregator._W1_m.weight', '_propagator._function_aggregator._W1_m.weight',
+                 '_decimator._variable_rnn_cell.weight_ih', '_decimator._function_rnn_cell.weight_ih',
+                 '_predictor._variable_aggregator._W1_m.weight', '_predictor._variable_classifier._layer2.weight'):
+        obj = m
+        for part in name.split('.'):
+            obj = getattr(obj, part)
+        out['grad::' + name] = np_(obj.grad)
+    save('meta_data_np_nd_np', meta=np.array([T, w, H, M], np.int64), **out)
+
+
 def gen_foreign_plugin():
     """tests/golden/foreign_plugin.py -- a plug-in triple written against the reference's API only -- run INSIDE the reference (CPU): records
     the batch, the parameters the reference's constructors drew, the per-sweep integer trajectory (which variable each instance fixed, the
@@ -1335,6 +1392,8 @@ if __name__ == '__main__':
               int(np.isnan(d['final_dec_1']).sum()), int(np.isnan(d['final_dec_0']).sum()), 'at sweep 75/76/77:', [int(np.isnan(d['prop_fs_%d' % t]).sum()) for t in (75, 76, 77)])
     if 'foreign' in what:
         gen_foreign_plugin()
+    if 'meta' in what:
+        gen_meta_data()
     if 'cli' in what:
         gen_cli()
     if 'config0' in what:

@@ -573,3 +573,58 @@ def test_walksat_random_stream_in_pieces(monkeypatch, name, model_type, kw, chun
     assignment of the previous piece: with one step (or a few) per piece the golden outputs and the generator position must not change."""
     monkeypatch.setenv('PDP_WALKSAT_RNG_CHUNK', chunk)
     test_forward_equals_reference_golden(name, model_type, kw, True)
+
+
+def test_graph_features_meta_data_equal_the_reference():
+    """np-nd-np with meta_feature_dim = 3 (`meta_data`, which no shipped config uses): the neural plug-ins append the
+    instance's graph features to every edge's input and run on the generic native operators.  Fixture: the reference's predict-style
+    forward (batch replication 2, Walk-SAT with its random stream) and a training-style forward + backward (meta_data_np_nd_np.npz)."""
+    from pdp.trainer import SatFactorGraphTrainer
+    d = load_golden('meta_data_np_nd_np')
+    T, w, H, M = [int(x) for x in d['meta']]
+    dev = torch.device('cuda:0')
+    tr = SatFactorGraphTrainer(cfg('np-nd-np', hidden_dim=H, edge_feature_dim=1, meta_feature_dim=M, prediction_dim=1, mem_hidden_dim=20, agg_hidden_dim=20,
+                                   mem_agg_hidden_dim=10, classifier_dim=10, local_search_iteration=w, loss_sharpness=5, dropout=0), use_cuda=True, logger=LOG)
+    m = tr._model_list[0]
+    sd = {k[3:]: torch.from_numpy(d[k]) for k in d.files if k.startswith('w::')}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all('_module_list' in k for k in missing)          # only the aliases are not in the file; they share storage
+    gm = torch.from_numpy(d['graph_map']).to(dev); bvm = torch.from_numpy(d['batch_variable_map']).to(dev)
+    bfm = torch.from_numpy(d['batch_function_map']).to(dev); ef = torch.from_numpy(d['edge_feature']).to(dev)
+    meta = torch.from_numpy(d['meta_data']).to(dev)
+    # the random initial state comes from the host stream like the reference's (same seed: same tensors); Walk-SAT goes on in that stream
+    torch.manual_seed(9)
+    with torch.no_grad():
+        st = m.get_init_state(gm, bvm, bfm, ef, meta, randomized=True, batch_replication=2)
+    np.testing.assert_allclose([float(x.double().sum()) for x in st[0] + st[1]], d['init_checksum'], rtol=1e-12)
+    with torch.no_grad():
+        pred, (ps, ds) = m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=meta,
+                           is_training=False, iteration_num=T, check_termination=tr._check_recurrence_termination, batch_replication=2)
+    assert m.last_run['path'] == 'stepwise'
+    np.testing.assert_array_equal(pred[0].cpu().numpy()[:, 0] > 0.5, d['final_prediction'] > 0.5)
+    np.testing.assert_allclose(pred[0].cpu().numpy()[:, 0], d['final_prediction'], rtol=3e-4, atol=3e-5)
+    for i, x in enumerate(ps):
+        np.testing.assert_allclose(x.cpu().numpy(), d['final_prop_%d' % i], rtol=3e-4, atol=3e-5)
+    for i, x in enumerate(ds):
+        np.testing.assert_allclose(x.cpu().numpy(), d['final_dec_%d' % i], rtol=3e-4, atol=3e-5)
+    # training style
+    lab = torch.zeros(int(bvm.max()) + 1, 1, device=dev)
+    m.zero_grad()
+    state = m.get_init_state(gm, bvm, bfm, ef, meta, randomized=False)
+    loss = torch.zeros(1, device=dev)
+    for t in range(2):
+        pred, state = m(init_state=state, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=meta,
+                        is_training=True, iteration_num=2)
+        loss = loss + tr._compute_loss(model=m, loss=None, prediction=pred, label=lab, graph_map=gm, batch_variable_map=bvm,
+                                       batch_function_map=bfm, edge_feature=ef, meta_data=meta)
+    loss.backward()
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), d['train_loss'], rtol=2e-5)
+    np.testing.assert_allclose(pred[0].detach().cpu().numpy()[:, 0], d['train_prediction'], rtol=3e-4, atol=3e-6)
+    for k in d.files:
+        if k.startswith('grad::'):
+            obj = m
+            for part in k[6:].split('.'):
+                obj = getattr(obj, part)
+            want = d[k]
+            np.testing.assert_allclose(obj.grad.cpu().numpy(), want, rtol=2e-3, atol=2e-5 * float(np.abs(want).max()), err_msg=k)
+            assert float(np.abs(want[:, -M:]).max()) > 0 or 'layer2' in k            # the meta columns carry gradient
