@@ -210,7 +210,7 @@ class MessageAggregator(nn.Module):
         mask of a SATProblem (pdp_train_row_sum / _spread) and on the mask's own index lists otherwise (pdp_csr_matmul).  Differentiable."""
         native.require_gpu()
         owner = mask_owner(mask)
-        if owner is not None and owner[1] == 'graph' and owner[2] in (0, 2):
+        if owner is not None and owner[1] == 'graph' and owner[2] in (0, 2) and state.size(0) == owner[0]._edge_num:
             return self.forward_train(state, feature, owner[0], owner[2] == 0, edge_mask)
         return self.forward_train(state, feature, None, None, edge_mask, masks=(mask, mask_transpose))
 
