@@ -236,6 +236,11 @@ def test_bench_launcher_starts_the_ranks_it_is_asked_for():
     assert abs(line['value'] - 2 * 400.0 / 0.02) < 1e-6                                                                # whole-job aggregate / max time
     bad = _run_bench({'PDP_DIST_BACKEND': 'gloo', 'PDP_BENCH_FAIL_RANK': '1'}, '--gpus', '2', '--selftest-collective')
     assert bad.returncode != 0 and not [l for l in bad.stdout.split('\n') if l.startswith('{')]
+    # the driver's largest launch: 8 ranks (gloo on CPU here), same plumbing
+    r8 = _run_bench({'PDP_DIST_BACKEND': 'gloo'}, '--gpus', '8', '--steps', '4', '--warmup', '1', '--selftest-collective')
+    assert r8.returncode == 0, r8.stderr[-2000:]
+    l8 = json.loads([l for l in r8.stdout.split('\n') if l.strip()][-1])
+    assert l8['n_gpus'] == 8 and l8['rccl_ranks'] == 8 and l8['instances'] == 8000.0 and l8['rank_sum'] == 36.0 and abs(l8['max_elapsed_s'] - 0.08) < 1e-12
     # a rank count that does not match --gpus is refused, not silently run as one rank
     mism = _run_bench({'WORLD_SIZE': '1', 'RANK': '0'}, '--gpus', '2', '--selftest-collective')
     assert mism.returncode != 0 and 'WORLD_SIZE' in (mism.stderr + mism.stdout)
