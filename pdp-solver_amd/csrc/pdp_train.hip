@@ -81,9 +81,9 @@ struct GemmTile {
         const int step = (int)((KROW ? (256 / BX) * ld : (256 / GK) * ld) * (int64_t)sizeof(float));      // from element j to j + 1
         // k past the range is masked explicitly in both layouts (k-minor: it is the next row's start; k-row: the slab offset travels in the
         // scalar offset, which the descriptor's range check need not cover).  Only the LAST slab of a range can hold such a k, and `left`
-        // is uniform: full slabs of the k-row layout take the loop without the per-element test (with the test in every slab the two
-        // k-row GEMMs -- dX and the split-K dW -- ran 2.5-3.5 x slower: 113 -> 200 ms per training step)
-        if (KROW && left >= GK) {
+        // is uniform: full slabs take the loop without the per-element test (with the test in every slab the two k-row GEMMs -- dX and
+        // the split-K dW -- ran 2.5-3.5 x slower: 113 -> 200 ms per training step)
+        if (left >= GK) {
 #pragma unroll
             for (int j = 0; j < PER; ++j) r[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, so + j * step, 0));
         } else {
