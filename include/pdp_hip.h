@@ -141,6 +141,12 @@ int pdp_reinforce_predict(pdp_problem *p, const float *fs, float *pred, void *st
 int pdp_energy(pdp_problem *p, const float *assignment, float *energy, float *unsat_functions, void *stream);
 /* replaces: _compute_energy_diff (solver.py:469-484) using the bound _edge_mask: -> delta [V] */
 int pdp_energy_diff(pdp_problem *p, const float *assignment, float *delta, void *stream);
+/* The in-kernel (PDP_RNG_PHILOX) draws of pdp_random_fill / pdp_local_search are Philox counters of the variable's / the instance's index
+ * inside the forward (pdp_predict.py:125-126 draws rand(n_active), solver.py:457,460 rand(V,1) and rand(B): one number per variable /
+ * instance of the batch).  When the batch of this problem is a contiguous PART of a larger forward solved elsewhere (isolated instances
+ * dealt to several GPUs, pdp/parallel.py) the caller states where the part starts: the draws are then those of the whole forward.
+ * Replication 1 only.  Default 0, 0. */
+int pdp_problem_set_rng_base(pdp_problem *p, uint32_t first_variable, uint32_t first_instance);
 /* replaces: IdentityPredictor.forward(last_call=True) random fill (pdp_predict.py:121-126).
  * PDP_RNG_STREAM: values [n_active] are consumed in variable order; PDP_RNG_PHILOX: in-kernel. */
 int pdp_random_fill(pdp_problem *p, int rng_mode, const float *values, uint64_t seed, void *stream);

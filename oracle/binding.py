@@ -77,6 +77,9 @@ class Problem(object):
         L.orc_problem_dims(self._h, _p(dims))
         self.E, self.V, self.F, self.B, self.R = [int(x) for x in dims]
 
+    def set_rng_base(self, first_variable, first_instance):
+        lib().orc_problem_set_rng_base(self._h, C.c_uint32(int(first_variable)), C.c_uint32(int(first_instance)))
+
     def __del__(self):
         try:
             if self._h:

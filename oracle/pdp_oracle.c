@@ -44,6 +44,7 @@ typedef struct orc_problem {
     float *is_sat;            /* [B] sat_problem._is_sat           (solver.py:54) */
     float *edge_mask;         /* [E] sat_problem._edge_mask or NULL-equivalent (has_edge_mask) */
     int has_edge_mask;
+    uint32_t rng_var_base, rng_inst_base;   /* Philox counters start here: the batch is a contiguous part of a larger forward (include/pdp_hip.h: pdp_problem_set_rng_base) */
 } orc_problem;
 
 static void *xcalloc(size_t n, size_t s) { void *p = calloc(n ? n : 1, s); if (!p) { fprintf(stderr, "oracle: OOM\n"); abort(); } return p; }
@@ -101,6 +102,11 @@ ORC_API orc_problem *orc_problem_create(int E, int V, int F, const int32_t *grap
     for (int b = 0; b < p->B; ++b) p->is_sat[b] = 0.5f;
     p->has_edge_mask = 0;
     return p;
+}
+
+ORC_API void orc_problem_set_rng_base(orc_problem *p, uint32_t first_variable, uint32_t first_instance)
+{
+    p->rng_var_base = first_variable; p->rng_inst_base = first_instance;
 }
 
 ORC_API void orc_problem_destroy(orc_problem *p)
@@ -824,13 +830,13 @@ static int local_search(orc_problem *p, const float *pred, int iterations, float
             for (int k = p->var_ptr[v]; k < p->var_ptr[v + 1]; ++k) acc = acc + unsat_fn[p->edge_fn[p->var_edges[k]]];
             acc = acc * p->active_var[v];
             const float u = (rng->mode == 0) ? rng_next_stream(rng)
-                                             : pdp_philox_uniform(rng->seed, PDP_RNG_STREAM_WSVAR, (uint32_t)it, (uint32_t)v);
+                                             : pdp_philox_uniform(rng->seed, PDP_RNG_STREAM_WSVAR, (uint32_t)it, p->rng_var_base + (uint32_t)v);
             uv[v] = ((acc > 0.0f) ? 1.0f : 0.0f) * u;
         }
         orc_instance_argmax(p, uv, randind);
         for (int b = 0; b < B; ++b) {
             const float u = (rng->mode == 0) ? rng_next_stream(rng)
-                                             : pdp_philox_uniform(rng->seed, PDP_RNG_STREAM_WSCOIN, (uint32_t)it, (uint32_t)b);
+                                             : pdp_philox_uniform(rng->seed, PDP_RNG_STREAM_WSCOIN, (uint32_t)it, p->rng_inst_base + (uint32_t)b);
             const int64_t coin = (u > epsilon) ? 1 : 0;
             const int64_t ind = coin * greedy[b] + (1 - coin) * randind[b];
             greedy[b] = ind;
@@ -865,7 +871,7 @@ static void random_fill(orc_problem *p, orc_rng *rng)
     for (int v = 0; v < p->V; ++v) {
         if (p->active_var[v] > 0.0f) {
             p->solution[v] = (rng->mode == 0) ? rng_next_stream(rng)
-                                              : pdp_philox_uniform(rng->seed, PDP_RNG_STREAM_FILL, 0u, (uint32_t)v);
+                                              : pdp_philox_uniform(rng->seed, PDP_RNG_STREAM_FILL, 0u, p->rng_var_base + (uint32_t)v);
         }
     }
 }

@@ -137,6 +137,7 @@ struct pdp_problem {
     uint32_t *team_ws;          // barrier counters and reduction mailboxes of the workgroup teams (k_sp_solve<NT, true>)
     hipStream_t res_side_stream; hipEvent_t res_side_ev[2];   // the big instances' launches overlap the LDS-resident kernel on a stream of their own
     float *nws[4]; size_t nws_floats[4];             // neural workspaces (grow on demand)
+    uint32_t rng_var_base, rng_inst_base;            // pdp_problem_set_rng_base: position of this batch inside the forward it is a part of
 };
 
 struct pdp_decimator {
@@ -155,6 +156,7 @@ struct PView {
     float *av, *af, *sol, *is_sat, *emask;
     uint32_t *flags;
     int B, R, B0, V, F, E;
+    uint32_t rng_v0, rng_b0;    // added to the variable / instance index of every Philox counter (0 unless the batch is a part of a forward)
 };
 
 static inline PView make_view(const pdp_problem *p)
@@ -166,6 +168,7 @@ static inline PView make_view(const pdp_problem *p)
     v.var_inst = p->var_inst; v.fn_inst = p->fn_inst;
     v.av = p->av; v.af = p->af; v.sol = p->sol; v.is_sat = p->is_sat; v.emask = p->emask;
     v.flags = p->flags; v.B = p->B; v.R = p->R; v.B0 = p->B0; v.V = p->V; v.F = p->F; v.E = p->E;
+    v.rng_v0 = p->rng_var_base; v.rng_b0 = p->rng_inst_base;
     return v;
 }
 

@@ -456,6 +456,14 @@ extern "C" int pdp_problem_create(pdp_problem **out, int E, int V, int F, int B,
     return PDP_OK;
 }
 
+extern "C" int pdp_problem_set_rng_base(pdp_problem *p, uint32_t first_variable, uint32_t first_instance)
+{
+    PDP_REQUIRE(p, "NULL problem");
+    PDP_REQUIRE(p->R == 1 || (first_variable == 0u && first_instance == 0u), "a part of a forward cannot be replicated (replica r of variable v has index v + r * V)");
+    p->rng_var_base = first_variable; p->rng_inst_base = first_instance;
+    return PDP_OK;
+}
+
 extern "C" int pdp_problem_dims(const pdp_problem *p, int32_t *d)
 {
     PDP_REQUIRE(p && d, "NULL argument");

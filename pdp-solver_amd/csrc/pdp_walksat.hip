@@ -104,10 +104,10 @@ __global__ void k_fill_stream(int V, const float *av, const int32_t *rank, const
     for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < V; v += (int64_t)gridDim.x * blockDim.x)
         if (av[v] > 0.0f) sol[v] = values[rank[v]];
 }
-__global__ void k_fill_philox(int V, const float *av, uint64_t seed, float *sol)
+__global__ void k_fill_philox(int V, const float *av, uint64_t seed, uint32_t base, float *sol)
 {
     for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < V; v += (int64_t)gridDim.x * blockDim.x)
-        if (av[v] > 0.0f) sol[v] = pdp_philox_uniform(seed, PDP_RNG_STREAM_FILL, 0u, (uint32_t)v);
+        if (av[v] > 0.0f) sol[v] = pdp_philox_uniform(seed, PDP_RNG_STREAM_FILL, 0u, base + (uint32_t)v);
 }
 
 extern "C" int pdp_random_fill(pdp_problem *p, int rng_mode, const float *values, uint64_t seed, void *stream)
@@ -115,7 +115,7 @@ extern "C" int pdp_random_fill(pdp_problem *p, int rng_mode, const float *values
     PDP_REQUIRE(p && p->av, "NULL argument / state not bound");
     hipStream_t st = ST(stream);
     if (rng_mode == PDP_RNG_PHILOX) {
-        hipLaunchKernelGGL(k_fill_philox, dim3(grid_for(p->V)), dim3(256), 0, st, p->V, p->av, seed, p->sol);
+        hipLaunchKernelGGL(k_fill_philox, dim3(grid_for(p->V)), dim3(256), 0, st, p->V, p->av, seed, p->rng_var_base, p->sol);
     } else {
         PDP_REQUIRE(values, "stream mode needs the drawn values");
         hipLaunchKernelGGL(k_active_flags, dim3(grid_for(p->V)), dim3(256), 0, st, p->V, p->av, p->ws_vi[0]);
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(PDP_NT) k_ws_delta(PView pv, const float *a, c
         for (int k = I.v_ptr[v]; k < I.v_ptr[v + 1]; ++k) acc = acc + (float)unsat_u8[I.f0 + I.e_fn[I.v_edges[k]]];
         acc = acc * I.av[v];
         const float u = (rng_mode == PDP_RNG_STREAM) ? var_rand[I.v0 + v]
-                                                     : pdp_philox_uniform(seed, PDP_RNG_STREAM_WSVAR, (uint32_t)step, (uint32_t)(I.v0 + v));
+                                                     : pdp_philox_uniform(seed, PDP_RNG_STREAM_WSVAR, (uint32_t)step, pv.rng_v0 + (uint32_t)(I.v0 + v));
         const float r = ((acc > 0.0f) ? 1.0f : 0.0f) * u;
         uv[I.v0 + v] = r;
         if (r != r) nn = true; else if (r < m) m = r;
@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(PDP_NT) k_ws_flip(PView pv, float *a, const fl
     const int randi = d_instance_argmax(I, uv + I.v0, pv.flags[FL_NAN0] ? PDP_NAN : gmin, redf, redi);
     if (threadIdx.x == 0 && unsat_b[I.b] > 0.0f && I.n > 0) {
         const float u = (rng_mode == PDP_RNG_STREAM) ? coin_rand[I.b]
-                                                     : pdp_philox_uniform(seed, PDP_RNG_STREAM_WSCOIN, (uint32_t)step, (uint32_t)I.b);
+                                                     : pdp_philox_uniform(seed, PDP_RNG_STREAM_WSCOIN, (uint32_t)step, pv.rng_b0 + (uint32_t)I.b);
         const int ind = (u > epsilon) ? greedy : randi;
         a[I.v0 + ind] = -a[I.v0 + ind];
     }
@@ -380,11 +380,11 @@ __global__ void __launch_bounds__(NT) k_walksat(PView pv, WsParams wp)
     const int cap = wp.cap_b ? wp.cap_b[G.b] : wp.steps_cap;
     auto var_rand = [&](int step, int v) -> float {
         return (wp.rng_mode == PDP_RNG_STREAM) ? wp.var_rand[(size_t)step * pv.V + G.v0 + v]
-                                               : pdp_philox_uniform(wp.seed, PDP_RNG_STREAM_WSVAR, (uint32_t)step, (uint32_t)(G.v0 + v));
+                                               : pdp_philox_uniform(wp.seed, PDP_RNG_STREAM_WSVAR, (uint32_t)step, pv.rng_v0 + (uint32_t)(G.v0 + v));
     };
     auto coin_rand = [&](int step) -> float {
         return (wp.rng_mode == PDP_RNG_STREAM) ? wp.coin_rand[(size_t)step * pv.B + G.b]
-                                               : pdp_philox_uniform(wp.seed, PDP_RNG_STREAM_WSCOIN, (uint32_t)step, (uint32_t)G.b);
+                                               : pdp_philox_uniform(wp.seed, PDP_RNG_STREAM_WSCOIN, (uint32_t)step, pv.rng_b0 + (uint32_t)G.b);
     };
     int first_sat = cap;
     uint32_t used32 = 0, zero32 = 0;                            // thread 0: speculation bits of the current block of 32 steps
@@ -574,11 +574,11 @@ __global__ void __launch_bounds__(NT) k_walksat_team(PView pv, WsParams wp, Team
     const int cap = wp.steps_cap;
     auto var_rand = [&](int step, int v) -> float {
         return (wp.rng_mode == PDP_RNG_STREAM) ? wp.var_rand[(size_t)step * pv.V + G.v0 + v]
-                                               : pdp_philox_uniform(wp.seed, PDP_RNG_STREAM_WSVAR, (uint32_t)step, (uint32_t)(G.v0 + v));
+                                               : pdp_philox_uniform(wp.seed, PDP_RNG_STREAM_WSVAR, (uint32_t)step, pv.rng_v0 + (uint32_t)(G.v0 + v));
     };
     auto coin_rand = [&](int step) -> float {
         return (wp.rng_mode == PDP_RNG_STREAM) ? wp.coin_rand[(size_t)step * pv.B + G.b]
-                                               : pdp_philox_uniform(wp.seed, PDP_RNG_STREAM_WSCOIN, (uint32_t)step, (uint32_t)G.b);
+                                               : pdp_philox_uniform(wp.seed, PDP_RNG_STREAM_WSCOIN, (uint32_t)step, pv.rng_b0 + (uint32_t)G.b);
     };
     // block-wide maxima of the two keys and the OR of the flag: every thread gets them
     auto block_keys = [&](unsigned long long &kg, unsigned long long &kr, int &hz) {

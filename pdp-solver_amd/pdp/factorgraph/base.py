@@ -186,17 +186,18 @@ class FactorGraphTrainerBase(object):
                         raise native.NativeError("a run on several ranks needs the loader to say which (batch, segment) units it yields "
                                                  "(pdp.factorgraph.dataset.LoaderBatch); this loader does not")
                     j, segment_ids = position, list(range(len(data[0])))
+                parts = getattr(data, 'parts', None)         # isolated instances dealt to ranks: (part, first variable, first instance)
                 for k in range(len(data[0])):
                     for model in self._model_list:
                         if hasattr(model, 'set_random_key'):
-                            model.set_random_key(parallel.batch_seed(base_seed, j, segment_ids[k]))
+                            model.set_random_key(parallel.batch_seed(base_seed, j, segment_ids[k]), *(parts[k][1:] if parts else ()))
                     (graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, label, misc_data) = \
                         [self._to_cuda(d[k]) for d in data]
                     sink = io.StringIO() if units is not None else file
                     self._predict_batch(graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat,
                                         label, misc_data, post_processor, batch_replication, sink)
                     if units is not None:
-                        units.append(((int(j), int(segment_ids[k])), sink.getvalue()))
+                        units.append(((int(j), int(segment_ids[k])) + ((int(parts[k][0]),) if parts else ()), sink.getvalue()))
 
     @staticmethod
     def _world():
@@ -321,11 +322,16 @@ class FactorGraphTrainerBase(object):
                     model._rng = 'philox'
                     if hasattr(model._predictor, '_rng'):
                         model._predictor._rng = 'philox'
+        # --isolated removes the couplings inside a forward: there the unit that may move is the instance, and every segment is cut into one
+        # contiguous instance range per rank (a part; its Philox counters start where the part starts, SATProblem / pdp_problem_set_rng_base)
+        split = world > 1 and int(batch_replication) == 1 and all(getattr(m, '_isolated', False) for m in self._model_list)
+        if split and self._config.get('verbose'):
+            self._logger.info('isolated instances: every segment is cut into %d instance ranges, one per rank' % world)
         test_loader = FactorGraphDataset.get_loader(
             input_file=test_list, limit=self._config['test_batch_limit'], hidden_dim=self._config['hidden_dim'],
             batch_size=self._config['batch_size'], shuffle=False, num_workers=0,
             max_cache_size=self._config.get('max_cache_size', 100000), batch_replication=batch_replication,
-            shard=(rank, world) if world > 1 else None)
+            shard=(rank, world) if world > 1 else None, split_instances=split)
         if import_path_base is not None:
             self._load(import_path_base)
         start_time = time.time()

@@ -94,6 +94,7 @@ class SegmentList(list):
     "the collated segments of one loader batch this process solves + where they sit in the run"
     batch_index = 0           # global index of the loader batch
     segment_ids = ()          # global segment index (inside the batch) of every entry
+    parts = None              # isolated instances dealt to ranks: per entry (part index, first variable, first instance) inside its segment
 
 
 class LoaderBatch(tuple):
@@ -101,6 +102,7 @@ class LoaderBatch(tuple):
     and ``segments`` (global segment index of every entry) -- the key of the device-side random numbers and of the row order."""
     index = 0
     segments = ()
+    parts = None              # see SegmentList.parts
 
 
 def json_edge_count(line):
@@ -111,6 +113,15 @@ def json_edge_count(line):
     except ValueError:
         return parse_line(line)[2].shape[1]
     return line.count(',', s, e) + 1 if line[s:e].strip() else 0
+
+
+def json_variable_count(line):
+    "number of variables of a compact-JSON instance line without parsing it: the first number of its header [[n, m], ..."
+    try:
+        s = line.index('[[') + 2
+        return int(line[s:line.index(',', s)])
+    except ValueError:
+        return parse_line(line)[0]
 
 
 def collate(items, limit=40000000, hidden_dim=3, batch_replication=1):
@@ -162,7 +173,8 @@ class FactorGraphDataset(object):
     converter (dimacs2json.py) would have produced.  With a ``generator`` (training, dataset.py:84-104) every item is a fresh
     ``generator.generate()`` instance and the data set has ``epoch_size`` items."""
 
-    def __init__(self, input_file, limit, hidden_dim, max_cache_size=100000, batch_replication=1, shard=None, generator=None, epoch_size=0):
+    def __init__(self, input_file, limit, hidden_dim, max_cache_size=100000, batch_replication=1, shard=None, generator=None, epoch_size=0,
+                 split_instances=False):
         import os
         self._input_file = input_file
         self._dimacs = None
@@ -179,6 +191,8 @@ class FactorGraphDataset(object):
         # one process per GPU: the loader forms the SAME batches and cuts the SAME segments as a single-process run; this rank collates and
         # yields the segments dealt to it (pdp/parallel.py: one forward = one segment is the reference's coupling domain)
         self._shard = tuple(shard) if shard is not None and shard[1] > 1 and generator is None else None
+        # isolated instances (no coupling inside a segment): every segment is cut into one contiguous instance range per rank instead
+        self._split_instances = bool(split_instances) and self._shard is not None and int(batch_replication) == 1
         self.batch_index = 0          # global index of the loader batch handed out last
         self._limit = limit
         self._hidden_dim = hidden_dim
@@ -207,6 +221,15 @@ class FactorGraphDataset(object):
         if self._dimacs is not None:
             return self[i][2].shape[1]
         return json_edge_count(self._lines[i])
+
+    def _variable_count(self, i, tmp=()):
+        if i in tmp:
+            return tmp[i][0]
+        if i in self._cache:
+            return self._cache[i][0]
+        if self._dimacs is not None:
+            return self[i][0]
+        return json_variable_count(self._lines[i])
 
     def _parse_batch(self, idx):
         "DIMACS files: one call parses the not yet cached files of a batch with a few host threads inside the native library"
@@ -244,6 +267,20 @@ class FactorGraphDataset(object):
                 rank, world = self._shard
                 edges = [tmp[i][2].shape[1] if i in tmp else self._edge_count(i) for i in idx]
                 segments = divide(edges, self._limit // self._batch_replication, self._hidden_dim)
+                if self._split_instances:
+                    out, ids, parts = SegmentList(), [], []
+                    for s, seg in enumerate(segments):
+                        lo, hi = parallel.shard_bounds([edges[k] for k in seg], world)[rank]
+                        if hi > lo:
+                            out.append(collate_segment([get(idx[k]) for k in seg[lo:hi]]))
+                            ids.append(s)
+                            parts.append((rank, sum(self._variable_count(idx[k], tmp) for k in seg[:lo]), lo))
+                    if not ids:
+                        continue
+                    out.segment_ids, out.parts = ids, parts
+                    out.batch_index = self.batch_index = j
+                    yield out
+                    continue
                 owners = parallel.deal_units([sum(edges[k] for k in seg) for seg in segments], world, loads)
                 mine = [s for s, o in enumerate(owners) if o == rank]
                 if not mine:
@@ -255,10 +292,11 @@ class FactorGraphDataset(object):
 
     @staticmethod
     def get_loader(input_file, limit, hidden_dim, batch_size, shuffle=False, num_workers=0, max_cache_size=100000,
-                   use_cuda=True, generator=None, epoch_size=0, batch_replication=1, shard=None):
+                   use_cuda=True, generator=None, epoch_size=0, batch_replication=1, shard=None, split_instances=False):
         """Signature-compatible constructor (reference: dataset.py:189-211); returns an iterable of
         reference-shaped 7-tuples of per-segment lists."""
-        ds = FactorGraphDataset(input_file, limit, hidden_dim, max_cache_size, batch_replication, shard=shard, generator=generator, epoch_size=epoch_size)
+        ds = FactorGraphDataset(input_file, limit, hidden_dim, max_cache_size, batch_replication, shard=shard, generator=generator, epoch_size=epoch_size,
+                                split_instances=split_instances)
 
         class _Loader(object):
             dataset = ds
@@ -282,6 +320,6 @@ class FactorGraphDataset(object):
                                         [None for _ in segs],
                                         [torch.from_numpy(s['label']) for s in segs],
                                         [s['misc_data'] for s in segs]))
-                    data.index, data.segments = segs.batch_index, list(segs.segment_ids)
+                    data.index, data.segments, data.parts = segs.batch_index, list(segs.segment_ids), segs.parts
                     yield data
         return _Loader()

@@ -27,7 +27,7 @@ MODEL_SP, MODEL_WALKSAT, MODEL_REINFORCE = 0, 1, 2
 
 EXPORTED_SYMBOLS = [
     'pdp_abi_version', 'pdp_last_error', 'pdp_device_count', 'pdp_problem_create', 'pdp_problem_destroy',
-    'pdp_problem_dims', 'pdp_problem_export_graph', 'pdp_problem_bind_state', 'pdp_simplify', 'pdp_set_variables',
+    'pdp_problem_dims', 'pdp_problem_set_rng_base', 'pdp_problem_export_graph', 'pdp_problem_bind_state', 'pdp_simplify', 'pdp_set_variables',
     'pdp_refresh_edge_mask', 'pdp_smooth_max', 'pdp_instance_max', 'pdp_instance_argmax', 'pdp_sp_propagate', 'pdp_sp_adaptors', 'pdp_sp_propagate_adapted',
     'pdp_survey_score', 'pdp_cnf_eval', 'pdp_sat_loss', 'pdp_update_solution', 'pdp_check_termination', 'pdp_decimator_create',
     'pdp_decimator_destroy', 'pdp_decimator_reset', 'pdp_sequential_decimate', 'pdp_sequential_decimate_gate',
@@ -392,6 +392,10 @@ class Problem(object):
         d = torch.empty(self.V, 1, dtype=torch.float32, device=self.device)
         check(lib().pdp_energy_diff(self._h, ptr(assignment, torch.float32, self.V), ptr(d), _stream()))
         return d
+
+    def set_rng_base(self, first_variable, first_instance):
+        """this batch is a contiguous part of a larger forward: the Philox draws are counted from there (include/pdp_hip.h)"""
+        check(lib().pdp_problem_set_rng_base(self._h, C.c_uint32(int(first_variable)), C.c_uint32(int(first_instance))))
 
     def random_fill(self, values=None, seed=0):
         mode = RNG_STREAM if values is not None else RNG_PHILOX

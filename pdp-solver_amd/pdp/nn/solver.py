@@ -214,10 +214,13 @@ class PropagatorDecimatorSolverBase(nn.Module):
     def parameter_count(self):
         return sum(p.numel() for p in self.parameters() if p.requires_grad)
 
-    def set_random_key(self, seed):
+    def set_random_key(self, seed, first_variable=0, first_instance=0):
         """Key of the device-side (Philox) random numbers of the next forward: the predict driver derives it from the run's seed and the
-        global (loader batch, segment) index, so a batch draws the same numbers on whichever rank it is solved."""
+        global (loader batch, segment) index, so a batch draws the same numbers on whichever rank it is solved.  ``first_variable`` /
+        ``first_instance``: the next forward solves a contiguous PART of that segment (isolated instances dealt to ranks,
+        pdp/parallel.py) which starts there -- its variables and instances draw what they draw when the segment is solved whole."""
         self._seed = int(seed)
+        self._rng_base = (int(first_variable), int(first_instance))
         if hasattr(self._predictor, '_seed'):
             self._predictor._seed = int(seed)
 
@@ -240,6 +243,8 @@ class PropagatorDecimatorSolverBase(nn.Module):
         batch_replication = 1 if is_training else batch_replication
         sat_problem = SATProblem((graph_map, batch_variable_map, batch_function_map, edge_feature, meta_data, None),
                                  self._device, batch_replication)
+        if getattr(self, '_rng_base', (0, 0)) != (0, 0):
+            sat_problem._native.set_rng_base(*self._rng_base)
         self.last_run = dict(path='none', iterations=0, walksat_steps=0)
         # one decision for the whole forward: the differentiable operators (tolerance-level, autograd graph kept) only when training was
         # asked for, gradients are enabled and some parameter wants them; otherwise every plug-in runs its fused inference kernels

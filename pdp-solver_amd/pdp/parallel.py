@@ -16,8 +16,15 @@ which is the single-process order.  An N-rank run therefore writes exactly the r
 tests/test_sharded_gpu.py).  BASELINE configs[3]: 40 000 instances with ``-z 5000`` are 8 one-segment batches, one per GPU;
 configs[4] (dynamic batching, ``-b 4``): a loader batch falls into many segments, which spread over the 8 GPUs.
 
-What could split further: ``--isolated`` removes the couplings inside a segment, so there single instances could be dealt; and the
-strict semantics could be kept across GPUs with a two-flag all-reduce per sweep.  Neither is built.
+``--isolated`` (every instance solved on its own: none of the couplings above) makes the INSTANCE the unit: every segment is then cut
+into one contiguous instance range per rank, balanced by edges (``shard_bounds``) -- a *part* -- so a run of fewer segments than GPUs,
+down to one forward, uses every GPU.  The Philox counters of a part start at the part's first variable / instance inside its segment
+(``pdp_problem_set_rng_base``), so an instance draws what it draws when the segment is solved whole and the N-rank rows are the 1-rank
+``--isolated --rng philox`` rows (tests/test_sharded_gpu.py).  Batch replication keeps segment dealing (replica r of variable v has index
+v + r V: no contiguous base).  One batch-global quantity is left in Walk-SAT -- the minimum of a step's candidate vector inside
+util.sparse_argmax, 0 whenever any variable of the forward is not in an unsatisfied clause -- a part whose every variable is in an
+unsatisfied clause while the whole segment has one that is not would round one comparison differently; not observed, not excluded.
+The strict semantics could be kept across GPUs with a per-chunk exchange of the poison sweep; that is not built.
 
 ``shard_bounds`` / ``shard_items`` cut ONE batch by instances; only bench.py uses that (its synthetic batch has no loader and is timed
 in ``--isolated``-equivalent weak scaling: every rank generates its own B instances).
@@ -129,12 +136,13 @@ def gather_units(units, group=None):
     return [payload for _, payload in sorted(gather_rows(units, group), key=lambda kv: kv[0])]
 
 
-def solve_sharded(batches, solve_fn, rank=None, world_size=None, device=None, limit=None, hidden_dim=1):
+def solve_sharded(batches, solve_fn, rank=None, world_size=None, device=None, limit=None, hidden_dim=1, split_instances=False):
     """``batches``: the loader batches of the run (lists of loader items), the same list on every rank; ``limit`` / ``hidden_dim``: the
     dynamic-batching budget that cuts a batch into segments (None: one segment per batch).  Runs ``solve_fn(items, batch_index,
     segment_index) -> (solved [b], unsat [b], rows list)`` on the units dealt to this rank and reduces the counters; returns (stats, all
     rows in single-process order, this rank's [(batch, segment), ...]).  ``solve_fn`` is the native forward in production and the CPU
-    oracle in the gloo tests."""
+    oracle in the gloo tests.  ``split_instances`` (isolated instances): every segment is cut into one instance range per rank and
+    ``solve_fn(items, batch_index, segment_index, first_variable, first_instance)`` solves this rank's part; units are (batch, segment, part)."""
     from pdp.factorgraph import dataset
     if world_size is None:
         world_size = dist.get_world_size() if dist.is_initialized() else 1
@@ -145,13 +153,20 @@ def solve_sharded(batches, solve_fn, rank=None, world_size=None, device=None, li
     for j, batch in enumerate(batches):
         edges = [it[2].shape[1] for it in batch]
         segments = [list(range(len(batch)))] if limit is None else dataset.divide(edges, limit, hidden_dim)
-        owners = deal_units([sum(edges[k] for k in seg) for seg in segments], world_size, loads)
+        owners = deal_units([sum(edges[k] for k in seg) for seg in segments], world_size, loads) if not split_instances else None
         for i, seg in enumerate(segments):
-            if owners[i] != rank:
-                continue
-            items = [batch[k] for k in seg]
-            solved, unsat, r = solve_fn(items, j, i)
+            if split_instances:
+                lo, hi = shard_bounds([edges[k] for k in seg], world_size)[rank]
+                if hi <= lo:
+                    continue
+                items, key = [batch[k] for k in seg[lo:hi]], (j, i, rank)
+                solved, unsat, r = solve_fn(items, j, i, sum(int(batch[k][0]) for k in seg[:lo]), lo)
+            else:
+                if owners[i] != rank:
+                    continue
+                items, key = [batch[k] for k in seg], (j, i)
+                solved, unsat, r = solve_fn(items, j, i)
             n += len(items); n_solved += float(np.sum(solved)); n_unsat += float(np.sum(unsat))
-            units.append(((j, i), list(r))); mine.append((j, i))
+            units.append((key, list(r))); mine.append(key)
     stats = reduce_stats(n, n_solved, n_unsat, device=device)
     return stats, [row for part in gather_units(units) for row in part], mine

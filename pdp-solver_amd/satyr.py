@@ -75,7 +75,8 @@ def main(argv=None):
     parser.add_argument('--rng', help='Random source for random fill / Walk-SAT', choices=['torch', 'philox'], default='torch')
     parser.add_argument('--stepwise', help='Disable the persistent one-launch PDP loop', action='store_true')
     parser.add_argument('--isolated', help='Solve every instance on its own: none of the batch-wide couplings of the reference '
-                        '(global minima, NaN poisoning of the whole batch); p-d-p only, results differ from the reference where those couplings act',
+                        '(global minima, NaN poisoning of the whole batch); p-d-p only, results differ from the reference where those couplings act.  On several ranks (torch.distributed.run) '
+                        'the instances of every forward are then spread over all GPUs',
                         action='store_true')
     args = vars(parser.parse_args(argv))
 

@@ -513,6 +513,61 @@ def test_isolated_mode_properties():
     assert int(av_all.sum()) < int(av_strict.sum())                             # isolated: decimation went on after sweep 81
 
 
+def test_isolated_forward_equals_single_instance_oracle_forwards():
+    """What 'isolated' means, pinned to the oracle: a forward of ONE instance has none of the reference's cross-instance couplings, so the
+    isolated forward of a batch must give every instance exactly what the oracle's strict forward gives it when it is alone in the call --
+    surveys, decimation, random fill and Walk-SAT included, with the instance's Philox counters at its place in the batch.  The batch is
+    the golden poisoned one (four instances whose surveys turn NaN at sweep 81).  Then the same batch solved in two and three contiguous
+    parts (``set_random_key(key, first_variable, first_instance)``: what a rank of an N-GPU --isolated run does) gives the same
+    predictions -- the property the instance dealing of pdp/parallel.py rests on."""
+    from pdp.trainer import SatFactorGraphTrainer
+    from pdp.factorgraph import dataset
+    from pdp import parallel
+    from oracle import binding
+    d = load_golden('headline_n200_poison')
+    n, mcl, T, seed, sweeps = [int(x) for x in d['meta']]
+    dev = torch.device('cuda:0')
+    items = []
+    for sd in d['seeds'][:14]:
+        items += dataset.random_ksat_items(1, n, 3, m=mcl, seed=int(sd))
+    items += dataset.random_ksat_items(6, 90, 3, seed=515)
+    W, key = 40, parallel.batch_seed(11, 3, 2)
+    tr = SatFactorGraphTrainer(cfg('p-d-p', local_search_iteration=W, tolerance=0.02, t_max=100, isolated=True, rng='philox'), use_cuda=True, logger=LOG)
+    m = tr._model_list[0]
+
+    def run(part, v0=0, b0=0):
+        b = dataset.to_torch(dataset.collate_segment(part), dev)
+        m.set_random_key(key, v0, b0)
+        with torch.no_grad():
+            st = m.get_init_state(b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'], None, randomized=False, batch_replication=1)
+            pred, _ = m(init_state=st, graph_map=b['graph_map'], batch_variable_map=b['batch_variable_map'], batch_function_map=b['batch_function_map'],
+                        edge_feature=b['edge_feature'], meta_data=None, is_training=False, iteration_num=T,
+                        check_termination=tr._check_recurrence_termination, batch_replication=1)
+        assert m.last_run['path'] == 'persistent-lds'
+        return pred[0].reshape(-1).cpu().numpy()
+
+    whole = run(items)
+    offs = np.concatenate(([0], np.cumsum([it[0] for it in items])))
+    nan_instances = 0
+    for k, it in enumerate(items):
+        b = dataset.collate_segment([it])
+        p = binding.Problem(b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'])
+        p.set_rng_base(int(offs[k]), k)
+        res = p.forward('p-d-p', T, local_search_iterations=W, tolerance=0.02, t_max=100, seed=key)
+        nan_instances += bool(np.isnan(res['fs']).any())
+        np.testing.assert_array_equal(whole[offs[k]:offs[k + 1]], res['prediction'], err_msg='instance %d' % k)
+    assert nan_instances >= 2
+    edges = [it[2].shape[1] for it in items]
+    for world in (2, 3):
+        parts = []
+        for lo, hi in parallel.shard_bounds(edges, world):
+            parts.append(run(items[lo:hi], int(offs[lo]), lo))
+        np.testing.assert_array_equal(np.concatenate(parts), whole)
+    lo, hi = parallel.shard_bounds(edges, 2)[1]
+    assert not np.array_equal(run(items[lo:hi]), whole[offs[lo]:])          # without the base a part draws other numbers
+    m.set_random_key(key)
+
+
 @pytest.mark.parametrize('alpha,n,B,T,w,has_nan,R', [(3.6, 120, 96, 80, 0, False, 1), (4.2, 200, 64, 45, 25, False, 1), (2.5, 60, 40, 50, 0, False, 1),
                                                     (4.2, 200, 64, 60, 25, True, 1), (4.2, 200, 1500, 100, 0, True, 1), (3.8, 80, 30, 40, 20, False, 3)])
 def test_reinforce_persistent_equals_stepwise(alpha, n, B, T, w, has_nan, R):

@@ -207,6 +207,55 @@ def test_native_dimacs_batch_reader(tmp_path):
         native.dimacs_parse_many(paths[:5] + [str(bad)] + paths[5:9], threads=3)
 
 
+def test_dataset_deals_instance_ranges_of_isolated_runs(tmp_path):
+    """--isolated: the instance is the unit.  Every segment of every loader batch is cut into one contiguous instance range per rank (a
+    part); the parts of a segment, in rank order, are the segment of the single-process run, and a part knows the index of its first
+    variable / instance inside that segment (where its Philox counters start).  ONE segment keeps every rank busy.  Batch replication
+    keeps the segment dealing."""
+    from pdp.factorgraph import dataset
+    from pdp import generator
+    lines = []
+    for i in range(23):
+        n = 10 + 3 * (i % 5)
+        cl = generator.uniform_ksat(n, 3 * n, 3, np.random.RandomState(i))
+        lines.append(generator.json_line(n, cl, label=i % 2, name='x%d' % i))
+        assert dataset.json_variable_count(lines[-1]) == n
+    assert dataset.json_variable_count('[[7,3],[1],[1],0,[]]') == 7
+    path = tmp_path / 'in.json'
+    path.write_text("\n".join(lines) + "\n")
+    ids = lambda seg: [m[0] for m in seg['misc_data']]
+    for z, limit in ((23, 10 ** 9), (5, 10 ** 9), (23, 3 * 90 * 2)):
+        whole = dataset.FactorGraphDataset(str(path), limit, 3)
+        expected = {(segs.batch_index, i): seg for segs in whole.batches(z) for i, seg in zip(segs.segment_ids, segs)}
+        for world in (2, 3, 8):
+            got = {}
+            for rank in range(world):
+                ds = dataset.FactorGraphDataset(str(path), limit, 3, shard=(rank, world), split_instances=True)
+                for segs in ds.batches(z):
+                    assert len(segs) == len(segs.segment_ids) == len(segs.parts) > 0
+                    for i, seg, (part, v0, b0) in zip(segs.segment_ids, segs, segs.parts):
+                        assert part == rank
+                        got.setdefault((segs.batch_index, i), []).append((part, v0, b0, seg))
+            assert sorted(got) == sorted(expected)
+            for key, parts in got.items():
+                exp = expected[key]
+                parts.sort(key=lambda t: t[0])
+                assert len(parts) == min(world, exp['batch_size'])                        # every rank has a part while instances remain
+                assert sum((ids(seg) for _, _, _, seg in parts), []) == ids(exp)
+                v_at, b_at = 0, 0
+                for part, v0, b0, seg in parts:
+                    assert (v0, b0) == (v_at, b_at)
+                    nv = seg['batch_variable_map'].size
+                    # the part is the slice of the segment: same edges, variable ids shifted by v0
+                    sel = (exp['graph_map'][0] >= v0) & (exp['graph_map'][0] < v0 + nv)
+                    assert np.array_equal(exp['graph_map'][0][sel] - v0, seg['graph_map'][0])
+                    assert np.array_equal(exp['batch_variable_map'][v0:v0 + nv] - b0, seg['batch_variable_map'])
+                    v_at += nv; b_at += seg['batch_size']
+                assert v_at == exp['batch_variable_map'].size and b_at == exp['batch_size']
+    ds = dataset.FactorGraphDataset(str(path), 10 ** 9, 3, batch_replication=2, shard=(0, 2), split_instances=True)
+    assert all(segs.parts is None for segs in ds.batches(5))
+
+
 def test_dataset_deals_segments_to_ranks(tmp_path):
     """one process per GPU: every rank's loader forms the batches of the single-process run, cuts them into the same dynamic segments
     (from the edge counts alone) and collates the segments dealt to it; together the ranks cover every (batch, segment) unit exactly

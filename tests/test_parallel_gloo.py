@@ -131,6 +131,68 @@ def test_one_loader_batch_cut_into_segments_keeps_both_ranks_busy():
             assert rows == exp_rows
 
 
+def _oracle_solve_isolated(items, batch_index, segment_index=0, first_variable=0, first_instance=0):
+    """a contiguous part of a segment with every instance solved on its own (a forward of one instance has none of the reference's
+    cross-instance couplings: that IS the isolated semantics) -- the instance's Philox counters are those of its place in the segment"""
+    sys.path.insert(0, REPO)
+    from oracle import binding
+    solved, unsat, rows = [], [], []
+    v0 = int(first_variable)
+    for k, it in enumerate(items):
+        b = dataset.collate_segment([it])
+        p = binding.Problem(b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'])
+        p.set_rng_base(v0, int(first_instance) + k)
+        res = p.forward('p-d-p', T_RUN, local_search_iterations=W_RUN, tolerance=TOL_RUN, t_max=TMAX_RUN,
+                        seed=parallel.batch_seed(SEED_RUN, batch_index, segment_index))
+        s, u = p.cnf_eval(res['prediction'])
+        solved.append(int(s[0])); unsat.append(int(u[0]))
+        rows.append((it[5][0], int(s[0]), int(u[0]), res['prediction'].astype(int).tolist()))
+        v0 += int(it[0])
+    return np.asarray(solved), np.asarray(unsat), rows
+
+
+def _isolated_worker(rank, world, port, q, z, limit):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    stats, rows, mine = parallel.solve_sharded(_run_batches(_run_items()[:24], z), _oracle_solve_isolated, limit=limit, split_instances=True)
+    q.put((rank, stats, rows, mine))
+    dist.destroy_process_group()
+
+
+def test_isolated_instances_are_dealt_as_instance_ranges():
+    """--isolated: ONE forward (one loader batch, one segment) is spread over all ranks as contiguous instance ranges, and the rows are
+    those of the single process that solves the segment whole -- including the random fill and the Walk-SAT draws, whose Philox counters
+    are the variable's / instance's index inside the SEGMENT (a part starts counting at its first variable / instance).  Also with the
+    batch cut into dynamic segments: every segment is spread."""
+    items = _run_items()[:24]
+    edges = [it[2].shape[1] for it in items]
+    for z, limit, world, port in ((24, None, 2, 37500), (24, None, 3, 39500), (24, 7 * max(edges), 2, 41500)):
+        segments = [list(range(24))] if limit is None else dataset.divide(edges, limit, 1)
+        exp_rows, exp_solved, exp_unsat = [], 0, 0
+        for i, seg in enumerate(segments):
+            s, u, r = _oracle_solve_isolated([items[k] for k in seg], 0, i)
+            exp_rows += r; exp_solved += int(np.sum(s)); exp_unsat += int(np.sum(u))
+        ctx = mp.get_context('spawn')
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_isolated_worker, args=(r, world, port + (os.getpid() % 2000), q, z, limit)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = sorted([q.get(timeout=300) for _ in range(world)], key=lambda x: x[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        for rank, stats, rows, mine in got:
+            assert mine == [(0, i, rank) for i in range(len(segments))]                   # a part of every segment on every rank
+            assert stats == dict(instances=24, solved=exp_solved, unsat_clauses=exp_unsat, solved_fraction=exp_solved / 24.0)
+            assert rows == exp_rows
+    # the counters matter: without the part's base the still-undecided variables are filled with other numbers
+    lo, hi = parallel.shard_bounds(edges, 2)[1]
+    shifted = _oracle_solve_isolated(items[lo:hi], 0, 0, sum(it[0] for it in items[:lo]), lo)[2]
+    unshifted = _oracle_solve_isolated(items[lo:hi], 0, 0)[2]
+    assert shifted == _oracle_solve_isolated(items, 0, 0)[2][lo:hi] and shifted != unshifted
+
+
 def _idle_worker(rank, world, port, q):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)

@@ -107,6 +107,35 @@ def test_two_ranks_share_one_loader_batch_cut_into_segments(tmp_path):
     assert set(units) == {0, 1} and min(units.values()) >= 1
 
 
+def test_isolated_run_spreads_one_forward_over_the_ranks(tmp_path):
+    """--isolated removes the couplings inside a forward, so the instance is the unit: ONE loader batch that is ONE segment (config 2's
+    shape: fewer forwards than GPUs) is cut into one contiguous instance range per rank, and two / three ranks write the rows of the
+    single process -- random fill and Walk-SAT draws included (a part's Philox counters start at its first variable / instance inside
+    the segment).  The batch holds the golden poisoned instances: with the couplings on, their NaN would decide the other rows."""
+    from pdp.factorgraph import dataset
+    d = load_golden('headline_n200_poison')
+    n, mcl, T, seed, sweeps = [int(x) for x in d['meta']]
+    items = dataset.random_ksat_items(21, 120, 3, seed=94000)
+    for sd in d['seeds'][:10]:
+        items += dataset.random_ksat_items(1, n, 3, m=mcl, seed=int(sd))
+    items += dataset.random_ksat_items(30, n, 3, m=mcl, seed=95000)
+    path = tmp_path / 'in.json'
+    path.write_text("\n".join(_lines(items)) + "\n")
+    argv = [os.path.join(REPO, 'config', 'Predict', 'PDP-p-d-p-sp-pytorch.yaml'), str(path), str(T), '-z', '5000', '-s', '11', '-w', '60',
+            '--rng', 'philox', '--isolated', '-v']
+    one, _ = _run(argv, 1, str(tmp_path / 'one.jsonl'), 0)
+    assert len(one) == len(items)
+    for ranks, port in ((2, 29751), (3, 29753)):
+        many, log = _run(argv, ranks, str(tmp_path / ('r%d.jsonl' % ranks)), port)
+        assert many == one
+        assert 'one per rank' in log
+        for r in range(ranks):
+            assert ('rank %d of %d solved 1 units (forward calls): [(0, 0, %d)]' % (r, ranks, r)) in log
+    # the strict run of the same batch differs (the NaN instances stop everybody's decimation), so the test sees the semantics it is about
+    strict, _ = _run([a for a in argv if a != '--isolated'], 1, str(tmp_path / 'strict.jsonl'), 0)
+    assert strict != one
+
+
 def test_rccl_runs_the_collectives_at_world_size_one(tmp_path):
     """All the collective evidence a one-GPU box can give: under ``torch.distributed.run --nproc-per-node 1`` with PDP_DIST_FORCE=1 the CLI
     and bench.py join an ``nccl`` (= RCCL) process group of one rank; the device-side all-reduce of the counters, the object gather of
