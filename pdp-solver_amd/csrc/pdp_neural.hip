@@ -1211,10 +1211,12 @@ __device__ __forceinline__ void gru_phase(const float *xa, const float *ha, __am
     }
 }
 
-template <int SX, bool MASK>
+// SAVE (training forward, pdp_train_gru_fused): the gates the adjoint needs leave with the result -- saved [E, 4 H] = r | z | n | gh_n
+// (what k_gru_point writes after two GEMMs that store and re-read gi, gh [E, 3 H] each).
+template <int SX, bool MASK, bool SAVE = false>
 __global__ void __launch_bounds__(NTN) k_gru_pipe(int E, const float *__restrict__ state, const float *__restrict__ sign,
                                                   const float *__restrict__ hprev, const float *__restrict__ rowmask, GruW g,
-                                                  float *__restrict__ out, int ntiles /* full tiles only */)
+                                                  float *__restrict__ out, int ntiles /* full tiles only */, float *__restrict__ saved = nullptr)
 {
     constexpr int SH = 64, H = 128;
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -1268,6 +1270,7 @@ __global__ void __launch_bounds__(NTN) k_gru_pipe(int E, const float *__restrict
     const __amdgpu_buffer_rsrc_t wh = __builtin_amdgcn_make_buffer_rsrc((void *)g.Wt_hh, 0, 2 * SH * N3 * (int)sizeof(float), 0x00020000);
     const int voff = (kh * N3 + col) * (int)sizeof(float);
     const int ooff = ((32 * mb + 4 * kh) * H + col) * (int)sizeof(float);
+    const int soff = ((32 * mb + 4 * kh) * 4 * H + col) * (int)sizeof(float);        // the same element of a saved row (4 H wide)
     const float bir = g.b_ih[col], biz = g.b_ih[H + col], bin = g.b_ih[2 * H + col];
     const float bhr = g.b_hh[col], bhz = g.b_hh[H + col], bhn = g.b_hh[2 * H + col];
     const int row0 = 32 * mb + 4 * kh;                    // acc_row(r, l) = row0 - 32 mb + (r & 3) + 8 (r >> 2)
@@ -1286,12 +1289,14 @@ __global__ void __launch_bounds__(NTN) k_gru_pipe(int E, const float *__restrict
         f32x16 ai, ah, rg;
         const __amdgpu_buffer_rsrc_t ob = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)e_prev * H), 0, TM * H * (int)sizeof(float), 0x00020000);
         const float *mp = Mk + ((ms + 2) % 3) * TM + row0;
+        const __amdgpu_buffer_rsrc_t sbp = __builtin_amdgcn_make_buffer_rsrc((void *)(saved + (SAVE ? (size_t)e_prev * 4 * H : 0)), 0, SAVE ? TM * 4 * H * (int)sizeof(float) : 0, 0x00020000);
         gru_phase<SX, SH, 26>(xa_b, ha_b, wi, wh, voff, ws, bir, bhr, ai, ah, [&](int c) {
             const int ro = (c & 3) + 8 * (c >> 2);
             const float ng = pdp_tanhf_abs(tq[c]);
             const float hnew = (hq[c] - ng) * zg[c] + ng;
             const float mk = mp[ro];
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mk * hnew + (1.0f - mk) * hq[c]), ob, ooff, ro * H * (int)sizeof(float), 0);
+            if (SAVE) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ng), sbp, soff + 2 * H * (int)sizeof(float), ro * 4 * H * (int)sizeof(float), 0);
         });
 #pragma unroll
         for (int r = 0; r < 16; ++r) rg[r] = ah[r] + ai[r];
@@ -1305,11 +1310,23 @@ __global__ void __launch_bounds__(NTN) k_gru_pipe(int E, const float *__restrict
             tq[r] = ai[r] + ah[r] * rg[r];
             hq[r] = Hs[par * TB + (row0 + (r & 3) + 8 * (r >> 2)) * ldh + col];
         }
+        if (SAVE) {
+            const __amdgpu_buffer_rsrc_t sb = __builtin_amdgcn_make_buffer_rsrc((void *)(saved + (size_t)tile * TM * 4 * H), 0, TM * 4 * H * (int)sizeof(float), 0x00020000);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ro = ((r & 3) + 8 * (r >> 2)) * 4 * H * (int)sizeof(float);
+                const float vr = rg[r], vz = zg[r], vg = ah[r];     // (scalars first: __builtin_bit_cast of a vector ELEMENT takes element 0 with this compiler)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, vr), sb, soff, ro, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, vz), sb, soff + H * (int)sizeof(float), ro, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, vg), sb, soff + 3 * H * (int)sizeof(float), ro, 0);
+            }
+        }
         e_prev = tile * TM;
     }
     if (blockIdx.x < ntiles) {
         const __amdgpu_buffer_rsrc_t ob = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)e_prev * H), 0, TM * H * (int)sizeof(float), 0x00020000);
         const float *mp = Mk + ((ms + 2) % 3) * TM + row0;   // ms was advanced once more when the loop ended
+        const __amdgpu_buffer_rsrc_t sbp = __builtin_amdgcn_make_buffer_rsrc((void *)(saved + (SAVE ? (size_t)e_prev * 4 * H : 0)), 0, SAVE ? TM * 4 * H * (int)sizeof(float) : 0, 0x00020000);
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             const int ro = (c & 3) + 8 * (c >> 2);
@@ -1317,6 +1334,7 @@ __global__ void __launch_bounds__(NTN) k_gru_pipe(int E, const float *__restrict
             const float hnew = (hq[c] - ng) * zg[c] + ng;
             const float mk = mp[ro];
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mk * hnew + (1.0f - mk) * hq[c]), ob, ooff, ro * H * (int)sizeof(float), 0);
+            if (SAVE) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ng), sbp, soff + 2 * H * (int)sizeof(float), ro * 4 * H * (int)sizeof(float), 0);
         }
     }
 }
@@ -1717,6 +1735,29 @@ extern "C" int pdp_neural_gru(pdp_problem *p, const pdp_gru_desc *d, const float
     const int grid = tiles < per_cu * persistent_grid() ? tiles : per_cu * persistent_grid();
     pdp_note_kernel(PDP_TK_GRU, "k_gru");
     hipLaunchKernelGGL(k_gru, dim3(grid), dim3(NTN), lds, st, E, state, p->edge_sign, h, rowmask, g, out, tiles);
+    PDP_LAUNCH_CHECK();
+    return PDP_OK;
+}
+
+// Training forward of the hidden-128 cell on the pipelined inference kernel (include/pdp_hip.h): R rows, R a multiple of 64.
+extern "C" int pdp_train_gru_fused(const pdp_gru_desc *d, const float *state, const float *sign, const float *h, int64_t R, float *hnew, float *saved,
+                                   void *stream)
+{
+    PDP_REQUIRE(d && state && sign && h && hnew && saved, "NULL argument");
+    PDP_REQUIRE(d->H == 128 && d->dx == 128, "the fused training cell is the 129 -> 128 one");
+    PDP_REQUIRE(R >= 0 && R % TM == 0 && R < ((int64_t)1 << 31), "row count must be a multiple of the 64-row tile");
+    PDP_REQUIRE(hnew != h, "output must not alias the hidden state");
+    if (R == 0) return PDP_OK;
+    hipStream_t st = ST(stream);
+    GruW g;
+    g.Wt_ih = d->Wt_ih; g.Wt_hh = d->Wt_hh; g.b_ih = d->b_ih; g.b_hh = d->b_hh; g.dx = d->dx; g.H = d->H;
+    g.Kpx = even_up(d->dx + 1); g.Kph = even_up(d->H); g.Hp = pad32(d->H);
+    const size_t lds = sizeof(float) * (size_t)TM * ((g.Kpx + 1) + (g.Kph + 1));
+    const size_t ldsp = 2 * lds + sizeof(float) * 3 * TM;
+    const int full = (int)(R / TM);
+    const int grid = full < persistent_grid() ? full : persistent_grid();
+    int s = set_lds((const void *)k_gru_pipe<65, false, true>, ldsp); if (s != PDP_OK) return s;
+    hipLaunchKernelGGL((k_gru_pipe<65, false, true>), dim3(grid), dim3(NTN), ldsp, st, (int)R, state, sign, h, (const float *)nullptr, g, hnew, full, saved);
     PDP_LAUNCH_CHECK();
     return PDP_OK;
 }

@@ -201,6 +201,151 @@ __global__ void __launch_bounds__(256, GEMM_MINB) k_gemm(int M, int N, int64_t K
         }
 }
 
+// ---- row-stripe GEMM for the products whose M is the number of rows of the batch (millions) and whose N, K are layer widths -------------
+// C[M,N] = act(A[M,K] B + bias);  TB: B(k,n) = W[n ldw + k] (the layer's forward, W = weight [N,K]);  else B(k,n) = W[k ldw + n] (dX = dZ W).
+// The B operand of a chunk of NB x 32 output columns lives in LDS for the whole launch (Bs[n][k], k contiguous, row pitch KP with KP / 4 odd:
+// the ds_read_b128 of a lane group falls on 16 different 16-byte slots); workgroups are persistent and walk stripes of WAVES x 32 rows, wave w
+// owning rows 32 w .. 32 w + 31 of the stripe: its A operand is used by no other wave, so it goes from global memory straight to the
+// registers the MFMAs read -- no LDS round trip, no barrier in the loop.  A lane (row i, half kh) loads the float4 A[i][8 g + 4 kh .. + 3] of
+// group g (8 k values); the four v_mfma_f32_32x32x2 steps of a group take k = 8 g + s from the lanes of half 0 and k = 8 g + 4 + s from half 1,
+// for A and B alike (the order of the k terms inside a group is a permutation of the ascending one: training is compared within a
+// tolerance).  Four groups (one 128-byte line per row) are in flight while the previous four are multiplied.  K past the matrix: zeros in Bs,
+// and the last, partial group of A is loaded element by element.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// ACT: the epilogue's activation as a compile-time constant (one inlined copy of one function); -1: the run-time switch
+template <bool TB, int NB, int ACT, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES, 4) k_gemm_rows(int M, int N, int K, const float *__restrict__ A, int64_t lda, const float *__restrict__ W, int64_t ldw,
+                                                   float *__restrict__ C, int64_t ldc, const float *__restrict__ bias, int act_rt, int KP)
+{
+    extern __shared__ float Bs[];                          // [NB * 32][KP], then the chunk's bias [NB * 32]
+    constexpr int NT = 64 * WAVES, ROWS = 32 * WAVES;
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, i = l & 31, kh = l >> 5;
+    const int n0 = blockIdx.y * NB * 32;
+    if (TB) {
+        for (int idx = tid; idx < NB * 32 * KP; idx += NT) {
+            const int n = idx / KP, k = idx - n * KP;
+            Bs[idx] = (n0 + n < N && k < K) ? W[(int64_t)(n0 + n) * ldw + k] : 0.0f;
+        }
+    } else {
+        for (int idx = tid; idx < NB * 32 * KP; idx += NT) {
+            const int k = idx / (NB * 32), n = idx - k * (NB * 32);
+            Bs[n * KP + k] = (n0 + n < N && k < K) ? W[(int64_t)k * ldw + n0 + n] : 0.0f;
+        }
+    }
+    float *biasS = Bs + NB * 32 * KP;
+    if (tid < NB * 32) biasS[tid] = (bias && n0 + tid < N) ? bias[n0 + tid] : 0.0f;
+    __syncthreads();
+    const int G = (K + 7) >> 3;                            // groups of 8 k
+    const int SSF = (K >> 3) >> 2;                         // super-slabs of four whole groups
+    const int TG = G - 4 * SSF;                            // 0 .. 4 groups behind them (the last one may be partial): the tail slab, index SSF
+    const int SS = SSF + (TG > 0 ? 1 : 0);
+    const int stripes = (M + ROWS - 1) / ROWS;
+    const float *brow = Bs + (size_t)i * KP + 4 * kh;       // + 32 nb KP + 8 g
+    // Every slab is fetched by the same four 16-byte buffer loads (the number of loads in flight never depends on the data, so the counter the
+    // compiler waits on is exact): descriptor based at the stripe's first row and ending with the matrix (rows past M and bytes past the
+    // matrix read 0), per-lane offset = the lane's row and half, scalar offset = the slab.  What a tail slab reads past K is the start of the
+    // next row: masked to 0 below before it meets the (zero) B entries -- a NaN there must not reach this row.
+    const int voff = (int)((((int64_t)(32 * w + i)) * lda + 4 * kh) * (int64_t)sizeof(float));
+    auto load = [&](f32x4 (&r)[4], int st, int ss) {
+        const int64_t row0 = (int64_t)st * ROWS;
+        int64_t bytes = ((int64_t)(M - 1 - row0) * lda + K) * (int64_t)sizeof(float);
+        bytes = bytes < 0x7fffffff ? bytes : 0x7fffffff;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(A + row0 * lda), 0, (int)bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            r[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (int)((32 * ss + 8 * j) * sizeof(float)), 0));
+    };
+    // bit (4 j + c): element c of group j of the tail slab lies inside K
+    uint32_t tail_ok = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (32 * SSF + 8 * j + 4 * kh + c < K) tail_ok |= 1u << (4 * j + c);
+#ifdef GEMM_ROWS_PRIO
+    { const int pr = ((w >> 2) & 1) | ((blockIdx.x & 1) << 1);         // (wave-uniform)
+      if (pr == 0) __builtin_amdgcn_s_setprio(0); else if (pr == 1) __builtin_amdgcn_s_setprio(1); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3); }
+#endif
+    f32x4 cur[4], nxt[4];
+    f32x16 acc[NB];
+    // The MFMAs are fed (B, A): a block is C^T, lane (row i, half kh) holds columns 8 q + 4 kh + c (q = r >> 2, c = r & 3) of its row -- four
+    // consecutive floats per register quad, stored as 16 bytes.  (Fed (A, B) a lane holds one column of 16 rows: 64 dword stores per block
+    // row instead of 16 float4 ones made the kernel 25-40 % slower.  Staging the block through LDS for 128-byte row pieces was slower again.)
+    auto epilogue = [&](int st) {
+        const int row = st * ROWS + 32 * w + i;
+        if (row < M) {
+            float *crow = C + (int64_t)row * ldc + n0 + 4 * kh;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int col = n0 + 32 * nb + 8 * q + 4 * kh;
+                    if (col >= N) continue;
+                    const f32x4 bq = *(const f32x4 *)(biasS + 32 * nb + 8 * q + 4 * kh);
+                    f32x4 v;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = tact(acc[nb][4 * q + c] + bq[c], ACT >= 0 ? ACT : act_rt);
+                    float *dst = crow + 32 * nb + 8 * q;
+#ifdef GEMM_ROWS_NOSTORE
+                    asm volatile("" :: "v"(v));
+                    if (act_rt != 77) continue;
+#endif
+                    if (col + 3 < N) *(f32x4u *)dst = v;
+                    else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) if (col + c < N) dst[c] = v[c];
+                    }
+                }
+        }
+    };
+    auto group = [&](const f32x4 &a, int g) {
+        f32x4 bv[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bv[nb] = *(const f32x4 *)(brow + (size_t)32 * nb * KP + 8 * g);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[nb][c], a[c], acc[nb], 0, 0, 0);
+    };
+    int st = blockIdx.x;
+    if (st < stripes) load(cur, st, 0);
+    for (; st < stripes; st += gridDim.x) {
+        // the slab after (st, ss): the next one of this stripe, or the first one of the workgroup's next stripe (none left: this one again)
+        auto load_next = [&](int ss) {
+            const bool last = ss + 1 == SS;
+            const int st2 = !last ? st : (st + (int)gridDim.x < stripes ? st + (int)gridDim.x : st);
+            load(nxt, st2, last ? 0 : ss + 1);
+        };
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
+        for (int ss = 0; ss < SSF; ++ss) {
+            load_next(ss);
+            __builtin_amdgcn_sched_barrier(0);             // the loads are issued here, 64 NB / 4 MFMAs ahead of their use -- not sunk to it
+#pragma unroll
+            for (int j = 0; j < 4; ++j) group(cur[j], 4 * ss + j);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+        }
+        if (TG > 0) {
+            load_next(SSF);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) cur[j][c] = (tail_ok >> (4 * j + c) & 1u) ? cur[j][c] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (j < TG) group(cur[j], 4 * SSF + j);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+        }
+        epilogue(st);
+    }
+}
+
 // C[i] = sum over the slices z of partial[z][i].  A workgroup takes 32 output elements; its 256 threads are 8 groups, group g adds the
 // slices z = g, g + 8, ... in ascending order (four loads in flight), and the eight group sums are folded in a fixed order through LDS: the
 // order of the additions depends on (splits) only.  (One thread per element walking all slices was latency-bound: 0.24 ms for 1 024 slices
@@ -321,12 +466,61 @@ static float *train_scratch(size_t floats, hipStream_t st)
     return sc.ptr;
 }
 
+// The products over the rows of the batch (forward and dX) on the row-stripe kernel when the B chunk fits the LDS twice per CU; else the tiled one.
+#ifndef GEMM_ROWS_WAVES
+#define GEMM_ROWS_WAVES 8                 // 512 threads, two workgroups per CU: four waves per SIMD
+#endif
+static size_t gemm_rows_lds(int nb, int KP) { return ((size_t)nb * 32 * KP + nb * 32) * sizeof(float); }
+template <bool TB, int NB, int ACT>
+static int gemm_rows_launch(int M, int N, int K, const float *A, int64_t lda, const float *W, int64_t ldw, float *C, int64_t ldc, const float *bias, int act,
+                            int chunks, int KP, hipStream_t st)
+{
+    const size_t lds = gemm_rows_lds(NB, KP);
+    static bool attr_set = false;
+    if (!attr_set) {
+        PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_gemm_rows<TB, NB, ACT, GEMM_ROWS_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int stripes = (M + 32 * GEMM_ROWS_WAVES - 1) / (32 * GEMM_ROWS_WAVES);
+#ifndef GEMM_ROWS_GRID
+#define GEMM_ROWS_GRID 1
+#endif
+    int gx = (GEMM_ROWS_GRID * (16 / GEMM_ROWS_WAVES) * pdp_device_cus() + chunks - 1) / chunks;
+    if (gx > stripes) gx = stripes;
+    hipLaunchKernelGGL((k_gemm_rows<TB, NB, ACT, GEMM_ROWS_WAVES>), dim3(gx, chunks), dim3(64 * GEMM_ROWS_WAVES), lds, st, M, N, K, A, lda, W, ldw, C, ldc, bias, act, KP);
+    PDP_LAUNCH_CHECK();
+    return PDP_OK;
+}
+template <bool TB, int NB>
+static int gemm_rows_act(int M, int N, int K, const float *A, int64_t lda, const float *W, int64_t ldw, float *C, int64_t ldc, const float *bias, int act,
+                         int chunks, int KP, hipStream_t st)
+{
+    if (act == TACT_NONE) return gemm_rows_launch<TB, NB, TACT_NONE>(M, N, K, A, lda, W, ldw, C, ldc, bias, act, chunks, KP, st);
+    if (TB && act == TACT_LOGSIGMOID) return gemm_rows_launch<TB, NB, TB ? TACT_LOGSIGMOID : TACT_NONE>(M, N, K, A, lda, W, ldw, C, ldc, bias, act, chunks, KP, st);
+    return gemm<false, TB>(M, N, K, A, lda, W, ldw, C, ldc, bias, act, 1, nullptr, st);        // relu / sigmoid / tanh: the predictor's small layers
+}
+template <bool TB>
+static int gemm_rows(int M, int N, int K, const float *A, int64_t lda, const float *W, int64_t ldw, float *C, int64_t ldc, const float *bias, int act, hipStream_t st)
+{
+    static const bool tiled_only = [] { const char *e = getenv("PDP_TRAIN_GEMM"); return e && !strcmp(e, "tiled"); }();
+    const int blocks = (N + 31) / 32, chunks = (blocks + 3) / 4, nb = (blocks + chunks - 1) / chunks;
+    const int KP = ((K + 7) / 8) * 8 + 4;
+    if (tiled_only || M < 4096 || gemm_rows_lds(nb, KP) * (16 / GEMM_ROWS_WAVES) > 160 * 1024)
+        return gemm<false, TB>(M, N, K, A, lda, W, ldw, C, ldc, bias, act, 1, nullptr, st);
+    switch (nb) {
+    case 1: return gemm_rows_act<TB, 1>(M, N, K, A, lda, W, ldw, C, ldc, bias, act, chunks, KP, st);
+    case 2: return gemm_rows_act<TB, 2>(M, N, K, A, lda, W, ldw, C, ldc, bias, act, chunks, KP, st);
+    case 3: return gemm_rows_act<TB, 3>(M, N, K, A, lda, W, ldw, C, ldc, bias, act, chunks, KP, st);
+    default: return gemm_rows_act<TB, 4>(M, N, K, A, lda, W, ldw, C, ldc, bias, act, chunks, KP, st);
+    }
+}
+
 // replaces: nn.Linear + activation as used by MessageAggregator / Perceptron (util.py:56,74; trainer.py:28-29): Y = act(X W^T + b)
 extern "C" int pdp_train_linear(const float *X, int64_t R, int K, int64_t ldx, const float *W, const float *b, int N, int act, float *Y, void *stream)
 {
     PDP_REQUIRE(X && W && Y && R >= 0 && K > 0 && N > 0 && R < (int64_t)1 << 31, "bad argument");
     if (R == 0) return PDP_OK;
-    return gemm<false, true>((int)R, N, K, X, ldx, W, K, Y, N, b, act, 1, nullptr, ST(stream));
+    return gemm_rows<true>((int)R, N, K, X, ldx, W, K, Y, N, b, act, ST(stream));
 }
 
 // its adjoint: dZ = dY * act'(Y);  dX = dZ W  (NULL: not needed);  dW = dZ^T X;  db = column sums of dZ (NULL: no bias).
@@ -343,7 +537,7 @@ extern "C" int pdp_train_linear_backward(const float *dY, const float *Y, const 
     }
     hipLaunchKernelGGL(k_act_backward, dim3(grid1d(R * N)), dim3(256), 0, st, R * N, dY, Y, act, dZ);
     int s;
-    if (dX) { s = gemm<false, false>((int)R, K, N, dZ, N, W, K, dX, lddx, nullptr, TACT_NONE, 1, nullptr, st); if (s != PDP_OK) return s; }
+    if (dX) { s = gemm_rows<false>((int)R, K, N, dZ, N, W, K, dX, lddx, nullptr, TACT_NONE, st); if (s != PDP_OK) return s; }
     const int splits = pick_splits(R);
     const int cs = colsum_slices(R);
     float *scr = train_scratch((size_t)splits * (size_t)N * K + (size_t)cs * N + 16, st);
@@ -452,8 +646,8 @@ extern "C" int pdp_train_gru(const float *x, const float *h, const float *W_ih, 
     if (R == 0) return PDP_OK;
     hipStream_t st = ST(stream);
     float *gi = scratch, *gh = scratch + (size_t)R * 3 * H;
-    int s = gemm<false, true>((int)R, 3 * H, Kx, x, Kx, W_ih, Kx, gi, 3 * H, b_ih, TACT_NONE, 1, nullptr, st); if (s != PDP_OK) return s;
-    s = gemm<false, true>((int)R, 3 * H, H, h, H, W_hh, H, gh, 3 * H, b_hh, TACT_NONE, 1, nullptr, st); if (s != PDP_OK) return s;
+    int s = gemm_rows<true>((int)R, 3 * H, Kx, x, Kx, W_ih, Kx, gi, 3 * H, b_ih, TACT_NONE, st); if (s != PDP_OK) return s;
+    s = gemm_rows<true>((int)R, 3 * H, H, h, H, W_hh, H, gh, 3 * H, b_hh, TACT_NONE, st); if (s != PDP_OK) return s;
     hipLaunchKernelGGL(k_gru_point, dim3(grid1d(R * H)), dim3(256), 0, st, R, H, (const float *)gi, (const float *)gh, h, hnew, saved);
     PDP_LAUNCH_CHECK();
     return PDP_OK;
@@ -471,8 +665,8 @@ extern "C" int pdp_train_gru_backward(const float *dhnew, const float *saved, co
     }
     float *dgi = scratch, *dgh = scratch + (size_t)R * 3 * H, *dh2 = dgh + (size_t)R * 3 * H;
     hipLaunchKernelGGL(k_gru_point_backward, dim3(grid1d(R * H)), dim3(256), 0, st, R, H, dhnew, saved, h, dgi, dgh, dh);
-    int s = gemm<false, false>((int)R, Kx, 3 * H, dgi, 3 * H, W_ih, Kx, dx, Kx, nullptr, TACT_NONE, 1, nullptr, st); if (s != PDP_OK) return s;
-    s = gemm<false, false>((int)R, H, 3 * H, dgh, 3 * H, W_hh, H, dh2, H, nullptr, TACT_NONE, 1, nullptr, st); if (s != PDP_OK) return s;
+    int s = gemm_rows<false>((int)R, Kx, 3 * H, dgi, 3 * H, W_ih, Kx, dx, Kx, nullptr, TACT_NONE, st); if (s != PDP_OK) return s;
+    s = gemm_rows<false>((int)R, H, 3 * H, dgh, 3 * H, W_hh, H, dh2, H, nullptr, TACT_NONE, st); if (s != PDP_OK) return s;
     hipLaunchKernelGGL(k_add_inplace, dim3(grid1d(R * H)), dim3(256), 0, st, R * H, dh, (const float *)dh2);
     const int splits = pick_splits(R);
     const size_t wmax = (size_t)3 * H * (Kx > H ? Kx : H);

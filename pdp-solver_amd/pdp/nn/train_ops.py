@@ -7,6 +7,7 @@ the graph, accumulates the parameter gradients and runs the optimizer the caller
 """
 
 import ctypes as C
+import os
 
 import torch
 
@@ -108,16 +109,37 @@ class GruCell(torch.autograd.Function):
     "torch.nn.GRUCell (gate order r, z, n) on the fp32 matrix cores"
 
     @staticmethod
-    def forward(ctx, x, h, w_ih, w_hh, b_ih, b_hh):
+    def forward(ctx, x, h, w_ih, w_hh, b_ih, b_hh, packed=None, state=None, sign=None):
+        """``packed``: the cell's weights as ``native.GruWeights`` (the inference layout).  With it the 129 -> 128 cell runs its full 64-row
+        tiles in one launch of the pipelined inference kernel, which also writes the gates the adjoint needs; the rows behind the last
+        full tile take the two-GEMM form.  ``state`` [R, 128] / ``sign`` [R]: the two pieces x = [state | sign] was concatenated from
+        (the kernel reads them where they lie; their gradient travels through x)."""
         x, h, w_ih, w_hh, b_ih, b_hh = [_f(t) for t in (x, h, w_ih, w_hh, b_ih, b_hh)]
         R, Kx = x.shape
         H = h.shape[1]
         hnew = torch.empty_like(h)
         saved = torch.empty(R, 4 * H, dtype=torch.float32, device=x.device)
-        scratch = torch.empty(R, 6 * H, dtype=torch.float32, device=x.device)
-        native.check(native.lib().pdp_train_gru(native.ptr(x, torch.float32), native.ptr(h, torch.float32), native.ptr(w_ih), native.ptr(w_hh), native.ptr(b_ih),
-                                                native.ptr(b_hh), C.c_int64(R), C.c_int(Kx), C.c_int(H), native.ptr(hnew), native.ptr(saved), native.ptr(scratch),
-                                                native._stream()))
+        full = 0
+        if packed is not None and H == 128 and Kx == 129 and os.environ.get('PDP_TRAIN_GRU', 'fused') == 'fused':
+            full = (R // 64) * 64
+            if full:
+                # the kernel wants the state rows contiguous [full, 128] and the sign column contiguous [full]
+                state = _f(state.detach()) if state is not None else x[:full, :128].contiguous()
+                sign = _f(sign.detach().reshape(-1)) if sign is not None else x[:full, 128].contiguous()
+                native.check(native.lib().pdp_train_gru_fused(C.byref(packed.desc), native.ptr(state, torch.float32), native.ptr(sign, torch.float32),
+                                                              native.ptr(h, torch.float32), C.c_int64(full), native.ptr(hnew), native.ptr(saved), native._stream()))
+        if full < R:
+            xt, ht = x[full:].contiguous(), h[full:].contiguous()
+            hn_t = torch.empty_like(ht)
+            sv_t = torch.empty(R - full, 4 * H, dtype=torch.float32, device=x.device)
+            scratch = torch.empty(R - full, 6 * H, dtype=torch.float32, device=x.device)
+            native.check(native.lib().pdp_train_gru(native.ptr(xt, torch.float32), native.ptr(ht, torch.float32), native.ptr(w_ih), native.ptr(w_hh), native.ptr(b_ih),
+                                                    native.ptr(b_hh), C.c_int64(R - full), C.c_int(Kx), C.c_int(H), native.ptr(hn_t), native.ptr(sv_t), native.ptr(scratch),
+                                                    native._stream()))
+            if full:
+                hnew[full:] = hn_t; saved[full:] = sv_t
+            else:
+                hnew, saved = hn_t, sv_t
         ctx.save_for_backward(x, h, w_ih, w_hh, saved)
         return hnew
 
@@ -134,7 +156,7 @@ class GruCell(torch.autograd.Function):
         native.check(native.lib().pdp_train_gru_backward(native.ptr(dhnew, torch.float32), native.ptr(saved), native.ptr(x), native.ptr(h), native.ptr(w_ih),
                                                          native.ptr(w_hh), C.c_int64(R), C.c_int(Kx), C.c_int(H), native.ptr(dx), native.ptr(dh), native.ptr(dw_ih),
                                                          native.ptr(dw_hh), native.ptr(db_ih), native.ptr(db_hh), native.ptr(scratch), native._stream()))
-        return dx, dh, dw_ih, dw_hh, db_ih, db_hh
+        return dx, dh, dw_ih, dw_hh, db_ih, db_hh, None, None, None
 
 
 class SpAdaptedSweep(torch.autograd.Function):

@@ -25,7 +25,11 @@ def _leaf(*shape, scale=0.3, seed=0):
 
 
 @pytest.mark.parametrize('R,K,N,act', [(1000, 33, 100, 'logsigmoid'), (77, 100, 50, 'logsigmoid'), (4097, 51, 128, 'relu'), (300, 50, 1, 'sigmoid'),
-                                       (65, 129, 150, 'tanh'), (5000, 151, 100, 'none')])
+                                       (65, 129, 150, 'tanh'), (5000, 151, 100, 'none'),
+                                       # the row-stripe kernel (>= 4 096 rows, act none / logsigmoid; forward and dX): whole and partial k slabs,
+                                       # one to four column blocks, two and three column chunks, a ragged last stripe
+                                       (8200, 129, 100, 'logsigmoid'), (4200, 100, 50, 'logsigmoid'), (4100, 51, 100, 'none'), (4099, 7, 33, 'none'),
+                                       (6000, 129, 384, 'none'), (4500, 129, 129, 'none'), (4097, 128, 3, 'logsigmoid'), (4608, 32, 64, 'none')])
 def test_linear_forward_and_adjoint_vs_torch(R, K, N, act):
     from pdp.nn import train_ops as T
     x, w, b = _leaf(R, K, seed=1), _leaf(N, K, seed=2), _leaf(N, seed=3)
@@ -58,6 +62,43 @@ def test_gru_forward_and_adjoint_vs_torch():
         hr.backward(g)
         ref = [hr.detach(), x.grad, h.grad] + [p_.grad for p_ in cell.parameters()]
         for a, r, name in zip(got, ref, ('h', 'dx', 'dh', 'dW_ih', 'dW_hh', 'db_ih', 'db_hh')):
+            torch.testing.assert_close(a, r, rtol=3e-4, atol=3e-4 * float(r.abs().max().clamp(min=1e-3)), msg=lambda m: '%s (R=%d): %s' % (name, R, m))
+
+
+def test_fused_gru_forward_equals_the_two_gemm_form():
+    """The 129 -> 128 cell of the training path runs its full 64-row tiles in one launch of the pipelined inference kernel, which also writes
+    the gates the adjoint reads (r | z | n | W_hn h + b_hn); rows behind the last full tile take the two-GEMM form.  Same results as that
+    form on all rows, and the gradients through the saved gates equal torch's."""
+    from pdp import native
+    from pdp.nn import train_ops as T
+
+    class Ctx(object):
+        def save_for_backward(self, *a):
+            self.saved = a
+
+    for R in (64 * 37 + 13, 64 * 5, 40):
+        cell = torch.nn.GRUCell(129, 128).to(DEV)
+        state, h = _leaf(R, 128, seed=6), _leaf(R, 128, seed=7)
+        sign = torch.sign(torch.randn(R, 1, device=DEV))
+        packed = native.GruWeights(cell.weight_ih.data, cell.weight_hh.data, cell.bias_ih.data, cell.bias_hh.data)
+        x = torch.cat((state, sign), 1)
+        c1, c2 = Ctx(), Ctx()
+        with torch.no_grad():
+            h1 = T.GruCell.forward(c1, x, h, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh, packed, state, sign)
+            h2 = T.GruCell.forward(c2, x, h, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh)
+        torch.testing.assert_close(h1, h2, rtol=0, atol=2e-6)
+        torch.testing.assert_close(c1.saved[4], c2.saved[4], rtol=0, atol=4e-6)
+        g = torch.randn(R, 128, device=DEV)
+        hn = T.GruCell.apply(x, h, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh, packed, state, sign)
+        hn.backward(g)
+        got = [hn.detach().clone(), state.grad.clone(), h.grad.clone()] + [p_.grad.clone() for p_ in cell.parameters()]
+        state.grad = h.grad = None
+        for p_ in cell.parameters():
+            p_.grad = None
+        hr = cell(torch.cat((state, sign), 1), h)
+        hr.backward(g)
+        ref = [hr.detach(), state.grad, h.grad] + [p_.grad for p_ in cell.parameters()]
+        for a, r, name in zip(got, ref, ('h', 'dstate', 'dh', 'dW_ih', 'dW_hh', 'db_ih', 'db_hh')):
             torch.testing.assert_close(a, r, rtol=3e-4, atol=3e-4 * float(r.abs().max().clamp(min=1e-3)), msg=lambda m: '%s (R=%d): %s' % (name, R, m))
 
 

@@ -1,0 +1,16 @@
+cd /tmp; export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/train_prof; rm -rf $OUT; mkdir -p $OUT
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/rows -o t -- python3 $GRAFT_REPO_ROOT/tools/train_time.py > $OUT/rows.log 2>&1
+export PDP_TRAIN_GEMM=tiled
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/tiled -o t -- python3 $GRAFT_REPO_ROOT/tools/train_time.py > $OUT/tiled.log 2>&1
+python3 - <<'PY'
+import csv, glob, os
+root=os.environ['GRAFT_REPO_ROOT']+'/gpurun_out/train_prof'
+for m in ('rows','tiled'):
+    f=glob.glob(root+'/'+m+'/**/*kernel_stats.csv', recursive=True)[0]
+    rows=list(csv.DictReader(open(f)))
+    tot=sum(float(r['TotalDurationNs']) for r in rows)
+    print(m, 'total %.1f ms'%(tot/1e6))
+    for r in rows[:16]:
+        print('  %-100s %5d %8.2f ms %5.1f%% avg %7.1f us'%(r['Name'][:100],int(r['Calls']),float(r['TotalDurationNs'])/1e6,100*float(r['TotalDurationNs'])/tot,float(r['AverageNs'])/1e3))
+PY
