@@ -281,7 +281,7 @@ int pdp_train_gru(const float *x, const float *h, const float *W_ih, const float
  * saved [R,4H]: no gi / gh round trip through memory.  Weights in the descriptor layout of the inference cell -- transposed, padded; R a multiple of 64 (the caller runs
  * pdp_train_gru on the rows behind the last full tile). */
 int pdp_train_gru_fused(const pdp_gru_desc *d, const float *state, const float *sign, const float *h, int64_t R, float *hnew, float *saved, void *stream);
-/* adjoint: dhnew [R,H] -> dx [R,Kx], dh [R,H], dW_ih, dW_hh, db_ih [3H], db_hh [3H]; scratch [R,7H] */
+/* adjoint: dhnew [R,H] -> dx [R,Kx], dh [R,H], dW_ih, dW_hh, db_ih [3H], db_hh [3H]; scratch [R,6H] (a [R,7H] block is fine) */
 int pdp_train_gru_backward(const float *dhnew, const float *saved, const float *x, const float *h, const float *W_ih, const float *W_hh, int64_t R, int Kx,
                            int H, float *dx, float *dh, float *dW_ih, float *dW_hh, float *db_ih, float *db_hh, float *scratch, void *stream);
 /* adjoint of pdp_sp_propagate_adapted (the adaptor form of SurveyPropagator.forward, pdp_propagate.py:163-221, as the training path runs it: no

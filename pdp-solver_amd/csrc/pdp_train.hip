@@ -20,7 +20,7 @@
 #define ST(s) ((hipStream_t)(s))
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { TACT_NONE = 0, TACT_LOGSIGMOID = 1, TACT_RELU = 2, TACT_SIGMOID = 3, TACT_TANH = 4 };
+enum { TACT_NONE = 0, TACT_LOGSIGMOID = 1, TACT_RELU = 2, TACT_SIGMOID = 3, TACT_TANH = 4, TACT_ACCUMULATE = 0x100 /* k_gemm: C += ... */ };
 
 __device__ __forceinline__ float tact(float v, int act)
 {
@@ -195,7 +195,11 @@ __global__ void __launch_bounds__(256, GEMM_MINB) k_gemm(int M, int N, int64_t K
                 const int row = m0 + wm + 32 * bm + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 if (row < M) {
                     if (gridDim.z > 1) partial[((int64_t)blockIdx.z * M + row) * N + col] = acc[bm][bn][r];
-                    else C[(int64_t)row * ldc + col] = tact(acc[bm][bn][r] + bc, act);
+                    else {
+                        float *cp = C + (int64_t)row * ldc + col;
+                        const float v = tact(acc[bm][bn][r] + bc, act & 0xff);
+                        *cp = (act & TACT_ACCUMULATE) ? *cp + v : v;
+                    }
                 }
             }
         }
@@ -406,6 +410,40 @@ __global__ void k_act_backward(int64_t n, const float *__restrict__ dY, const fl
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = dY[i] * tact_grad(Y[i], act);
 }
 
+// dZ = dY * act'(Y) AND the column sums of dZ (the bias gradient) in the same pass over the rows: the thread layout of k_colsum_partial
+// (256 / C row groups x C columns, every thread walks its rows of a slice in ascending order), partial[slice][n] summed by k_splitk_reduce.
+// dZ may alias dY (act none: nothing is written then).
+__global__ void __launch_bounds__(256) k_act_backward_colsum(int64_t R, int N, const float *__restrict__ dY, const float *__restrict__ Y, int act, float *__restrict__ dZ,
+                                                             int slices, float *__restrict__ partial)
+{
+    __shared__ float red[256];
+    const int C = N < 256 ? N : 256;
+    const int groups = 256 / C, g = threadIdx.x / C, c = threadIdx.x % C;
+    const int n = blockIdx.x * 256 + c;
+    const int64_t per = (R + slices - 1) / slices, r0 = per * blockIdx.y, r1 = (r0 + per < R) ? r0 + per : R;
+    float acc = 0.0f;
+    if (g < groups && n < N) {
+        if (act == TACT_NONE && dZ == dY) {
+#pragma unroll 4
+            for (int64_t r = r0 + g; r < r1; r += groups) acc = acc + dY[r * N + n];
+        } else {
+#pragma unroll 4
+            for (int64_t r = r0 + g; r < r1; r += groups) {
+                const float v = dY[r * N + n] * tact_grad(Y[r * N + n], act);
+                dZ[r * N + n] = v;
+                acc = acc + v;
+            }
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (g == 0 && n < N) {
+        for (int j = 1; j < groups; ++j) acc = acc + red[j * C + c];
+        partial[(int64_t)blockIdx.y * N + n] = acc;
+    }
+}
+static int act_colsum_slices(int64_t R) { int64_t s = (R + 63) / 64; if (s > 4096) s = 4096; return (int)(s < 1 ? 1 : s); }
+
 static int grid1d(int64_t n) { int64_t g = (n + 255) / 256; if (g > 16384) g = 16384; return (int)(g < 1 ? 1 : g); }
 
 template <bool TA, bool TB, int BM, int BN>
@@ -483,9 +521,11 @@ static int gemm_rows_launch(int M, int N, int K, const float *A, int64_t lda, co
     }
     const int stripes = (M + 32 * GEMM_ROWS_WAVES - 1) / (32 * GEMM_ROWS_WAVES);
 #ifndef GEMM_ROWS_GRID
-#define GEMM_ROWS_GRID 1
+#define GEMM_ROWS_GRID 3                 // column chunks > 1: three times the resident workgroups (measured 1 / 2 / 3 / 6: 71 / 80 / 91 / 88 TFLOP/s at 129 x 384); one chunk: the resident count
 #endif
-    int gx = (GEMM_ROWS_GRID * (16 / GEMM_ROWS_WAVES) * pdp_device_cus() + chunks - 1) / chunks;
+    static const int grid_mul = [] { const char *e = getenv("PDP_GEMM_ROWS_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : GEMM_ROWS_GRID; }();
+    static const bool grid_all = getenv("PDP_GEMM_ROWS_GRID_ALL") != nullptr;
+    int gx = ((chunks > 1 || grid_all ? grid_mul : 1) * (16 / GEMM_ROWS_WAVES) * pdp_device_cus() + chunks - 1) / chunks;
     if (gx > stripes) gx = stripes;
     hipLaunchKernelGGL((k_gemm_rows<TB, NB, ACT, GEMM_ROWS_WAVES>), dim3(gx, chunks), dim3(64 * GEMM_ROWS_WAVES), lds, st, M, N, K, A, lda, W, ldw, C, ldc, bias, act, KP);
     PDP_LAUNCH_CHECK();
@@ -535,20 +575,21 @@ extern "C" int pdp_train_linear_backward(const float *dY, const float *Y, const 
         if (db) PDP_HIP_CHECK(hipMemsetAsync(db, 0, sizeof(float) * (size_t)N, st));
         return PDP_OK;
     }
-    hipLaunchKernelGGL(k_act_backward, dim3(grid1d(R * N)), dim3(256), 0, st, R * N, dY, Y, act, dZ);
-    int s;
-    if (dX) { s = gemm_rows<false>((int)R, K, N, dZ, N, W, K, dX, lddx, nullptr, TACT_NONE, st); if (s != PDP_OK) return s; }
     const int splits = pick_splits(R);
-    const int cs = colsum_slices(R);
+    const int cs = act_colsum_slices(R);
     float *scr = train_scratch((size_t)splits * (size_t)N * K + (size_t)cs * N + 16, st);
     if (!scr) return PDP_ERR_HIP;
+    if (db) {
+        // one pass: dZ and the bias gradient's partial column sums
+        float *part = scr + (size_t)splits * N * K;
+        hipLaunchKernelGGL(k_act_backward_colsum, dim3((N + 255) / 256, cs), dim3(256), 0, st, R, N, dY, Y, act, dZ, cs, part);
+        hipLaunchKernelGGL(k_splitk_reduce, dim3(reduce_grid(N)), dim3(RED_G * RED_E), 0, st, (int64_t)N, cs, (const float *)part, db);
+    } else if (!(act == TACT_NONE && dZ == dY))
+        hipLaunchKernelGGL(k_act_backward, dim3(grid1d(R * N)), dim3(256), 0, st, R * N, dY, Y, act, dZ);
+    int s;
+    if (dX) { s = gemm_rows<false>((int)R, K, N, dZ, N, W, K, dX, lddx, nullptr, TACT_NONE, st); if (s != PDP_OK) return s; }
     s = gemm<true, false>(N, K, R, dZ, N, X, ldx, dW, K, nullptr, TACT_NONE, splits, scr, st);
     if (s != PDP_OK) return s;
-    if (db) {
-        float *part = scr + (size_t)splits * N * K;
-        hipLaunchKernelGGL(k_colsum_partial, dim3((N + 255) / 256, cs), dim3(256), 0, st, R, N, (const float *)dZ, cs, part);
-        hipLaunchKernelGGL(k_splitk_reduce, dim3(reduce_grid(N)), dim3(RED_G * RED_E), 0, st, (int64_t)N, cs, (const float *)part, db);
-    }
     PDP_LAUNCH_CHECK();
     return PDP_OK;
 }
@@ -615,27 +656,44 @@ __global__ void k_gru_point(int64_t R, int H, const float *__restrict__ gi, cons
         sv[c] = r; sv[H + c] = z; sv[2 * H + c] = n; sv[3 * H + c] = ghn;
     }
 }
-__global__ void k_gru_point_backward(int64_t R, int H, const float *__restrict__ dhn, const float *__restrict__ saved, const float *__restrict__ h,
-                                     float *__restrict__ dgi, float *__restrict__ dgh, float *__restrict__ dh)
+// The same thread layout as k_act_backward_colsum: thread (row group g, column c) walks the rows of its slice, so the four column sums the
+// bias gradients are made of -- dr, dz, dn (b_ih = dr | dz | dn) and dn r (b_hh = dr | dz | dn r) -- come out of the pass that writes dgi /
+// dgh, as partial[slice][4][H].
+__global__ void __launch_bounds__(256) k_gru_point_backward(int64_t R, int H, const float *__restrict__ dhn, const float *__restrict__ saved, const float *__restrict__ h,
+                                                            float *__restrict__ dgi, float *__restrict__ dgh, float *__restrict__ dh, int slices, float *__restrict__ partial)
 {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < R * H; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t e = i / H; const int c = (int)(i % H);
-        const float *sv = saved + e * 4 * H;
-        const float r = sv[c], z = sv[H + c], n = sv[2 * H + c], ghn = sv[3 * H + c];
-        const float g = dhn[i];
-        const float dn_pre = g * (1.0f - z) * (1.0f - n * n);
-        const float dz_pre = g * (h[i] - n) * z * (1.0f - z);
-        const float dr_pre = dn_pre * ghn * r * (1.0f - r);
-        float *a = dgi + e * 3 * H, *b = dgh + e * 3 * H;
-        a[c] = dr_pre; b[c] = dr_pre;
-        a[H + c] = dz_pre; b[H + c] = dz_pre;
-        a[2 * H + c] = dn_pre; b[2 * H + c] = dn_pre * r;
-        dh[i] = g * z;                                   // the direct path; the W_hh path is added by the caller's GEMM (beta = 1 below)
+    __shared__ float red[4][256];
+    const int Cw = H < 256 ? H : 256;
+    const int groups = 256 / Cw, g = threadIdx.x / Cw, cl = threadIdx.x % Cw;
+    const int c = blockIdx.x * 256 + cl;
+    const int64_t per = (R + slices - 1) / slices, r0 = per * blockIdx.y, r1 = (r0 + per < R) ? r0 + per : R;
+    float s_r = 0.0f, s_z = 0.0f, s_n = 0.0f, s_nr = 0.0f;
+    if (g < groups && c < H) {
+#pragma unroll 2
+        for (int64_t e = r0 + g; e < r1; e += groups) {
+            const float *sv = saved + e * 4 * H;
+            const float r = sv[c], z = sv[H + c], n = sv[2 * H + c], ghn = sv[3 * H + c];
+            const int64_t i = e * H + c;
+            const float gd = dhn[i];
+            const float dn_pre = gd * (1.0f - z) * (1.0f - n * n);
+            const float dz_pre = gd * (h[i] - n) * z * (1.0f - z);
+            const float dr_pre = dn_pre * ghn * r * (1.0f - r);
+            const float dnr = dn_pre * r;
+            float *a = dgi + e * 3 * H, *b = dgh + e * 3 * H;
+            a[c] = dr_pre; b[c] = dr_pre;
+            a[H + c] = dz_pre; b[H + c] = dz_pre;
+            a[2 * H + c] = dn_pre; b[2 * H + c] = dnr;
+            dh[i] = gd * z;                              // the direct path; the W_hh path is added by the caller's GEMM (accumulating epilogue)
+            s_r = s_r + dr_pre; s_z = s_z + dz_pre; s_n = s_n + dn_pre; s_nr = s_nr + dnr;
+        }
     }
-}
-__global__ void k_add_inplace(int64_t n, float *__restrict__ y, const float *__restrict__ x)
-{
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = y[i] + x[i];
+    red[0][threadIdx.x] = s_r; red[1][threadIdx.x] = s_z; red[2][threadIdx.x] = s_n; red[3][threadIdx.x] = s_nr;
+    __syncthreads();
+    if (g == 0 && c < H) {
+        for (int j = 1; j < groups; ++j) { s_r = s_r + red[0][j * Cw + cl]; s_z = s_z + red[1][j * Cw + cl]; s_n = s_n + red[2][j * Cw + cl]; s_nr = s_nr + red[3][j * Cw + cl]; }
+        float *p = partial + (int64_t)blockIdx.y * 4 * H;
+        p[c] = s_r; p[H + c] = s_z; p[2 * H + c] = s_n; p[3 * H + c] = s_nr;
+    }
 }
 
 // scratch [R, 6H]: gi | gh
@@ -652,7 +710,7 @@ extern "C" int pdp_train_gru(const float *x, const float *h, const float *W_ih, 
     PDP_LAUNCH_CHECK();
     return PDP_OK;
 }
-// scratch [R, 6H + H]: dgi | dgh | W_hh path of dh
+// scratch [R, 6H]: dgi | dgh (callers may still hand over [R, 7H])
 extern "C" int pdp_train_gru_backward(const float *dhnew, const float *saved, const float *x, const float *h, const float *W_ih, const float *W_hh, int64_t R,
                                       int Kx, int H, float *dx, float *dh, float *dW_ih, float *dW_hh, float *db_ih, float *db_hh, float *scratch, void *stream)
 {
@@ -663,23 +721,23 @@ extern "C" int pdp_train_gru_backward(const float *dhnew, const float *saved, co
         PDP_HIP_CHECK(hipMemsetAsync(db_ih, 0, sizeof(float) * 3 * (size_t)H, st)); PDP_HIP_CHECK(hipMemsetAsync(db_hh, 0, sizeof(float) * 3 * (size_t)H, st));
         return PDP_OK;
     }
-    float *dgi = scratch, *dgh = scratch + (size_t)R * 3 * H, *dh2 = dgh + (size_t)R * 3 * H;
-    hipLaunchKernelGGL(k_gru_point_backward, dim3(grid1d(R * H)), dim3(256), 0, st, R, H, dhnew, saved, h, dgi, dgh, dh);
-    int s = gemm_rows<false>((int)R, Kx, 3 * H, dgi, 3 * H, W_ih, Kx, dx, Kx, nullptr, TACT_NONE, st); if (s != PDP_OK) return s;
-    s = gemm_rows<false>((int)R, H, 3 * H, dgh, 3 * H, W_hh, H, dh2, H, nullptr, TACT_NONE, st); if (s != PDP_OK) return s;
-    hipLaunchKernelGGL(k_add_inplace, dim3(grid1d(R * H)), dim3(256), 0, st, R * H, dh, (const float *)dh2);
+    float *dgi = scratch, *dgh = scratch + (size_t)R * 3 * H;
     const int splits = pick_splits(R);
     const size_t wmax = (size_t)3 * H * (Kx > H ? Kx : H);
-    const int cs = colsum_slices(R);
-    float *scr = train_scratch((size_t)splits * wmax + (size_t)cs * 3 * H + 16, st);
+    const int cs = act_colsum_slices(R);
+    float *scr = train_scratch((size_t)splits * wmax + (size_t)cs * 4 * H + 4 * H + 16, st);
     if (!scr) return PDP_ERR_HIP;
-    float *part = scr + (size_t)splits * wmax;
+    float *part = scr + (size_t)splits * wmax, *sums = part + (size_t)cs * 4 * H;          // sums [4 H] = dr | dz | dn | dn r
+    hipLaunchKernelGGL(k_gru_point_backward, dim3((H + 255) / 256, cs), dim3(256), 0, st, R, H, dhnew, saved, h, dgi, dgh, dh, cs, part);
+    hipLaunchKernelGGL(k_splitk_reduce, dim3(reduce_grid(4 * H)), dim3(RED_G * RED_E), 0, st, (int64_t)4 * H, cs, (const float *)part, sums);
+    PDP_HIP_CHECK(hipMemcpyAsync(db_ih, sums, sizeof(float) * 3 * (size_t)H, hipMemcpyDeviceToDevice, st));
+    PDP_HIP_CHECK(hipMemcpyAsync(db_hh, sums, sizeof(float) * 2 * (size_t)H, hipMemcpyDeviceToDevice, st));
+    PDP_HIP_CHECK(hipMemcpyAsync(db_hh + 2 * (size_t)H, sums + 3 * (size_t)H, sizeof(float) * (size_t)H, hipMemcpyDeviceToDevice, st));
+    int s = gemm_rows<false>((int)R, Kx, 3 * H, dgi, 3 * H, W_ih, Kx, dx, Kx, nullptr, TACT_NONE, st); if (s != PDP_OK) return s;
+    // dh += dgh W_hh: the tiled kernel's accumulating epilogue (dh holds the direct path)
+    s = gemm<false, false>((int)R, H, 3 * H, dgh, 3 * H, W_hh, H, dh, H, nullptr, TACT_NONE | TACT_ACCUMULATE, 1, nullptr, st); if (s != PDP_OK) return s;
     s = gemm<true, false>(3 * H, Kx, R, dgi, 3 * H, x, Kx, dW_ih, Kx, nullptr, TACT_NONE, splits, scr, st); if (s != PDP_OK) return s;
-    hipLaunchKernelGGL(k_colsum_partial, dim3((3 * H + 255) / 256, cs), dim3(256), 0, st, R, 3 * H, (const float *)dgi, cs, part);
-    hipLaunchKernelGGL(k_splitk_reduce, dim3(reduce_grid(3 * H)), dim3(RED_G * RED_E), 0, st, (int64_t)3 * H, cs, (const float *)part, db_ih);
     s = gemm<true, false>(3 * H, H, R, dgh, 3 * H, h, H, dW_hh, H, nullptr, TACT_NONE, splits, scr, st); if (s != PDP_OK) return s;
-    hipLaunchKernelGGL(k_colsum_partial, dim3((3 * H + 255) / 256, cs), dim3(256), 0, st, R, 3 * H, (const float *)dgh, cs, part);
-    hipLaunchKernelGGL(k_splitk_reduce, dim3(reduce_grid(3 * H)), dim3(RED_G * RED_E), 0, st, (int64_t)3 * H, cs, (const float *)part, db_hh);
     PDP_LAUNCH_CHECK();
     return PDP_OK;
 }
