@@ -534,7 +534,10 @@ __global__ void __launch_bounds__(NTN) k_agg_pre_res(int E, const float *__restr
 // NB column blocks of one layer as one straight-line sequence of NB * STEPS MFMAs (block after block, each block one k-ordered chain):
 // the A operands (LDS) are read one 8-step chunk ahead, the weight fragments (L2, buffer loads: lane offset in a VGPR, k-step offset as a
 // scalar) two chunks ahead, so no MFMA waits for an operand and the prefetch runs on across the block boundaries.
-template <int STEPS, int NB, int NP>
+// SWAP: the MFMAs are fed (weights, activations) -- the block comes out transposed: lane (i, kh) then holds ROW i of the tile, its register
+// r = 4 q + c the column 8 q + 4 kh + c (four consecutive columns per register quad: 16-byte loads / stores of the surrounding rows).  Every
+// element is the same chain of the same products in the same k order (a * b = b * a), so the values are bit-identical; no bias in this form.
+template <int STEPS, int NB, int NP, bool SWAP = false>
 __device__ __forceinline__ void wave_chains(const float *a /* LDS: row (lane & 31) of the block, column lane >> 5 */, __amdgpu_buffer_rsrc_t wr,
                                             const float *__restrict__ bias, f32x16 (&acc)[NB])
 {
@@ -568,7 +571,8 @@ __device__ __forceinline__ void wave_chains(const float *a /* LDS: row (lane & 3
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             const int t = c * CH + j;
-            if (t < T) acc[t / STEPS] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[c & 1][j], bb[c % 3][j], acc[t / STEPS], 0, 0, 0);
+            if (t < T) acc[t / STEPS] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(bb[c % 3][j], aa[c & 1][j], acc[t / STEPS], 0, 0, 0)
+                                             : __builtin_amdgcn_mfma_f32_32x32x2f32(aa[c & 1][j], bb[c % 3][j], acc[t / STEPS], 0, 0, 0);
         }
         // pure arithmetic is not ordered against scheduling barriers by itself: tie the chunk's accumulators to this point
         asm volatile("" : "+v"(acc[(c * CH) / STEPS]));
@@ -770,12 +774,27 @@ __global__ void __launch_bounds__(NTN, 6) k_agg_post_pf(int E, const float *__re
     const int ROWB = w.out * (int)sizeof(float);
     const int rows = E - e0 < TM ? E - e0 : TM;
     const __amdgpu_buffer_rsrc_t pb = __builtin_amdgcn_make_buffer_rsrc((void *)(old + (size_t)e0 * w.out), 0, rows * ROWB, 0x00020000);
+    // QUADS (a 128-wide output: NB4 == 4): the output layer's blocks come out transposed (wave_chains SWAP) -- a lane owns one row and, per
+    // register quad, four consecutive columns, so the previous state arrives in four 16-byte loads, the result leaves in four 16-byte stores
+    // and the row mask is one load (was: 16 + 16 + 16 dword accesses per block; this kernel issues ~76 MFMAs per wave and tile, so its
+    // vector-memory instruction count is what the matrix pipe waits behind)
+    constexpr bool QUADS = NB4 == 4;
     float po0[16];
     {
         const int nb4 = wave >> 1, mb4 = wave & 1, col4 = 32 * nb4 + i;
+        if constexpr (QUADS) {
+            const int lo4 = (32 * mb4 + i) * ROWB + (32 * nb4 + 4 * kh) * (int)sizeof(float);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pb, lo4, q * 32, 0));
+#pragma unroll
+                for (int c = 0; c < 4; ++c) po0[4 * q + c] = v[c];
+            }
+        } else {
         const int lo = (32 * mb4 + 4 * kh) * ROWB + col4 * (int)sizeof(float);
 #pragma unroll
         for (int r = 0; r < 16; ++r) po0[r] = col4 < w.out ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pb, lo, ((r & 3) + 8 * (r >> 2)) * ROWB, 0)) : 0.0f;
+        }
     }
 #pragma unroll
     for (int jr = 0; jr < TM / NWAVES; ++jr) {
@@ -823,6 +842,24 @@ __global__ void __launch_bounds__(NTN, 6) k_agg_post_pf(int E, const float *__re
     // wide: with 5 column blocks (150) the 10 blocks of the tile go round the 8 waves twice.
     const __amdgpu_buffer_rsrc_t ob = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)e0 * w.out), 0, rows * ROWB, 0x00020000);
     const __amdgpu_buffer_rsrc_t mb_ = __builtin_amdgcn_make_buffer_rsrc((void *)(rowmask ? rowmask + e0 : old), 0, rows * (int)sizeof(float), 0x00020000);
+    if constexpr (QUADS) {
+        // one block per wave (2 NB4 == NWAVES)
+        const int nb4 = wave >> 1, mb4 = wave & 1;
+        const __amdgpu_buffer_rsrc_t w4 = __builtin_amdgcn_make_buffer_rsrc((void *)(w.Wt2a + 32 * nb4), 0, (2 * S4 * 32 * NB4 - 32 * nb4) * (int)sizeof(float), 0x00020000);
+        const int lo4 = (32 * mb4 + i) * ROWB + (32 * nb4 + 4 * kh) * (int)sizeof(float);
+        f32x16 acc[1];
+        wave_chains<S4, 1, 32 * NB4, true>(G1 + (32 * mb4 + i) * ld1 + kh, w4, nullptr, acc);
+        const float mk = rowmask ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mb_, (32 * mb4 + i) * (int)sizeof(float), 0, 0)) : 1.0f;
+        const f32x2 m2 = {mk, mk};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x2 n0 = pk_logsigmoid((f32x2){acc[0][4 * q], acc[0][4 * q + 1]}), n1 = pk_logsigmoid((f32x2){acc[0][4 * q + 2], acc[0][4 * q + 3]});
+            const f32x2 b0 = m2 * n0 + (1.0f - m2) * (f32x2){po0[4 * q], po0[4 * q + 1]}, b1 = m2 * n1 + (1.0f - m2) * (f32x2){po0[4 * q + 2], po0[4 * q + 3]};
+            const f32x4 v = {b0.x, b0.y, b1.x, b1.y};
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), ob, lo4, q * 32, 0);
+        }
+    } else {
     for (int blk = wave; blk < 2 * NB4; blk += NWAVES) {
         const int nb4 = blk >> 1, mb4 = blk & 1, col4 = 32 * nb4 + i;
         const bool live = col4 < w.out;                   // the last block of a 150-wide output has 22 live columns
@@ -846,6 +883,7 @@ __global__ void __launch_bounds__(NTN, 6) k_agg_post_pf(int E, const float *__re
                 __builtin_amdgcn_raw_buffer_store_b32(f2i(bl.y), ob, lo, (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * ROWB, 0);
             }
         }
+    }
     }
 }
 
