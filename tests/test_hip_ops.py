@@ -241,6 +241,38 @@ def test_local_search_routes_big_instances(oracle, monkeypatch, mode, n_big, wit
     np.testing.assert_array_equal(npy(hout)[:, 0], oout)
 
 
+@pytest.mark.parametrize('form', ['persistent', 'persistent-big-team', 'persistent-big-one-workgroup', 'strict'])
+def test_philox_counters_start_at_the_parts_base(oracle, monkeypatch, form):
+    """pdp_problem_set_rng_base: the batch is a contiguous part of a larger forward, and the in-kernel Philox draws of the random fill and of
+    Walk-SAT count variables / instances from the part's place in it.  Every form of the search takes the base -- the LDS-resident persistent
+    kernel, its HBM-resident form for instances past the LDS limit (a team and one workgroup), the strict step-wise loop -- and equals the
+    oracle with the same base; without the base the draws are others."""
+    from pdp.factorgraph import dataset
+    if form == 'strict':
+        monkeypatch.setenv('PDP_WALKSAT_STRICT', '1')
+    if form == 'persistent-big-one-workgroup':
+        monkeypatch.setenv('PDP_WALKSAT_NO_TEAM', '1')
+    items = dataset.random_ksat_items(12, 60, 3, m=250, seed=70)
+    if form.startswith('persistent-big'):
+        items = items[:6] + [dataset.random_ksat_items(1, 3000, 3, m=11400, seed=71)[0]] + items[6:]
+    b = dataset.collate_segment(items)
+    w = 50
+    outs = []
+    for base in ((123457, 4321), (0, 0)):
+        hp, op = make_pair(oracle, b)
+        hp.simplify(); op.simplify()
+        hp.set_rng_base(*base); op.set_rng_base(*base)
+        hp.random_fill(seed=777); op.random_fill(seed=777)
+        assert_state_equal(hp, op)
+        pred = op.state()[2]
+        hout, hsteps = hp.local_search(t(pred), w, 0.5, seed=555)
+        oout, osteps, _ = op.local_search(pred, w, 0.5, seed=555)
+        assert hsteps == osteps and (oout != pred).any()
+        np.testing.assert_array_equal(npy(hout)[:, 0], oout)
+        outs.append((pred.copy(), oout.copy()))
+    assert not np.array_equal(outs[0][0], outs[1][0]) and not np.array_equal(outs[0][1], outs[1][1])
+
+
 def _planted_instance(n, m, k, seed, name):
     "random k-SAT whose clauses all hold under the all-TRUE assignment (one literal of every clause is made positive)"
     from pdp.factorgraph import dataset
