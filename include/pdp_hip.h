@@ -267,6 +267,15 @@ int pdp_train_linear(const float *X, int64_t R, int K, int64_t ldx, const float 
 /* adjoint: dZ = dY * act'(Y) (dZ [R,N]: scratch, may alias dY); dX [R,K] = dZ W (NULL: skipped); dW [N,K] = dZ^T X; db [N] = column sums (NULL: no bias) */
 int pdp_train_linear_backward(const float *dY, const float *Y, const float *X, int64_t R, int K, int64_t ldx, const float *W, int N, int act,
                               float *dZ, float *dX, int64_t lddx, float *dW, float *db, void *stream);
+/* The same layer on an operand whose LAST column is stored apart -- Y = act([X | xs] W^T + b) with X [R,K], xs [R] (the edge sign the reference
+ * concatenates in front of every layer of the training path, pdp_propagate.py:66-67, util.py:71-72), W [N, K + 1]: the K-wide block runs on the
+ * row-stripe GEMM, the last column is a rank-one term of its epilogue; no [R, K + 1] copy is made.  Only for shapes that kernel takes
+ * (pdp_train_linear_s_supported != 0: >= 4 096 rows, act none / logsigmoid, the weight chunk fits the LDS); otherwise concatenate. */
+int pdp_train_linear_s_supported(int64_t R, int K, int N, int act);
+int pdp_train_linear_s(const float *X, const float *xs, int64_t R, int K, int64_t ldx, const float *W, const float *b, int N, int act, float *Y, void *stream);
+/* adjoint: dX [R,K] = dZ W[:, :K] (NULL: skipped); dW [N, K + 1] = [ dZ^T X | dZ^T xs ]; db [N] (NULL: no bias); xs has no gradient */
+int pdp_train_linear_s_backward(const float *dY, const float *Y, const float *X, const float *xs, int64_t R, int K, int64_t ldx, const float *W, int N, int act,
+                                float *dZ, float *dX, int64_t lddx, float *dW, float *db, void *stream);
 /* replaces: torch.mm(mask, state) of MessageAggregator.forward (util.py:60): x [E,A] -> out [rows,A], ordered sum over the edges of every
  * variable (by_variable != 0) or clause */
 int pdp_train_row_sum(pdp_problem *p, int by_variable, const float *x, int A, float *out, void *stream);
@@ -284,6 +293,9 @@ int pdp_train_gru_fused(const pdp_gru_desc *d, const float *state, const float *
 /* adjoint: dhnew [R,H] -> dx [R,Kx], dh [R,H], dW_ih, dW_hh, db_ih [3H], db_hh [3H]; scratch [R,6H] (a [R,7H] block is fine) */
 int pdp_train_gru_backward(const float *dhnew, const float *saved, const float *x, const float *h, const float *W_ih, const float *W_hh, int64_t R, int Kx,
                            int H, float *dx, float *dh, float *dW_ih, float *dW_hh, float *db_ih, float *db_hh, float *scratch, void *stream);
+/* the adjoint for a cell whose input is [state [R,Ks] | xs [R]] held apart (W_ih [3H, Ks + 1]): dstate [R,Ks], dW_ih [3H, Ks + 1]; scratch [R,6H] */
+int pdp_train_gru_backward_s(const float *dhnew, const float *saved, const float *state, const float *xs, const float *h, const float *W_ih, const float *W_hh,
+                             int64_t R, int Ks, int H, float *dstate, float *dh, float *dW_ih, float *dW_hh, float *db_ih, float *db_hh, float *scratch, void *stream);
 /* adjoint of pdp_sp_propagate_adapted (the adaptor form of SurveyPropagator.forward, pdp_propagate.py:163-221, as the training path runs it: no
  * active mask): upstream g_q [E,3] (surveys) and g_eta [E] (column 0 of the function state; the force column carries no gradient, torch.sign) ->
  * d_xlog [E] (gradient of the log-domain clause message = logsigmoid of the function projector's output) and d_eta_in [E] (gradient of

@@ -215,14 +215,15 @@ __global__ void __launch_bounds__(256, GEMM_MINB) k_gemm(int M, int N, int64_t K
 // for A and B alike (the order of the k terms inside a group is a permutation of the ascending one: training is compared within a
 // tolerance).  Four groups (one 128-byte line per row) are in flight while the previous four are multiplied.  K past the matrix: zeros in Bs,
 // and the last, partial group of A is loaded element by element.
+struct RowsExtra { const float *xs; const float *ws; int64_t ws_ld; };        // rank-one term of the row-stripe GEMM: C += xs[row] * ws[col * ws_ld]
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ACT: the epilogue's activation as a compile-time constant (one inlined copy of one function); -1: the run-time switch
 template <bool TB, int NB, int ACT, int WAVES>
 __global__ void __launch_bounds__(64 * WAVES, 4) k_gemm_rows(int M, int N, int K, const float *__restrict__ A, int64_t lda, const float *__restrict__ W, int64_t ldw,
-                                                   float *__restrict__ C, int64_t ldc, const float *__restrict__ bias, int act_rt, int KP)
+                                                   float *__restrict__ C, int64_t ldc, const float *__restrict__ bias, int act_rt, int KP, RowsExtra ex)
 {
-    extern __shared__ float Bs[];                          // [NB * 32][KP], then the chunk's bias [NB * 32]
+    extern __shared__ float Bs[];                          // [NB * 32][KP], then the chunk's bias [NB * 32] and rank-one column vector [NB * 32]
     constexpr int NT = 64 * WAVES, ROWS = 32 * WAVES;
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, i = l & 31, kh = l >> 5;
     const int n0 = blockIdx.y * NB * 32;
@@ -238,7 +239,11 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_gemm_rows(int M, int N, int K
         }
     }
     float *biasS = Bs + NB * 32 * KP;
-    if (tid < NB * 32) biasS[tid] = (bias && n0 + tid < N) ? bias[n0 + tid] : 0.0f;
+    float *wsS = biasS + NB * 32;                            // ex: C += xs[row] * ws[col] (the operand's separate last column, pdp_train_linear_s)
+    if (tid < NB * 32) {
+        biasS[tid] = (bias && n0 + tid < N) ? bias[n0 + tid] : 0.0f;
+        wsS[tid] = (ex.ws && n0 + tid < N) ? ex.ws[(int64_t)(n0 + tid) * ex.ws_ld] : 0.0f;
+    }
     __syncthreads();
     const int G = (K + 7) >> 3;                            // groups of 8 k
     const int SSF = (K >> 3) >> 2;                         // super-slabs of four whole groups
@@ -281,6 +286,7 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_gemm_rows(int M, int N, int K
     auto epilogue = [&](int st) {
         const int row = st * ROWS + 32 * w + i;
         if (row < M) {
+            const float xs = ex.xs ? ex.xs[row] : 0.0f;
             float *crow = C + (int64_t)row * ldc + n0 + 4 * kh;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
@@ -288,10 +294,10 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_gemm_rows(int M, int N, int K
                 for (int q = 0; q < 4; ++q) {
                     const int col = n0 + 32 * nb + 8 * q + 4 * kh;
                     if (col >= N) continue;
-                    const f32x4 bq = *(const f32x4 *)(biasS + 32 * nb + 8 * q + 4 * kh);
+                    const f32x4 bq = *(const f32x4 *)(biasS + 32 * nb + 8 * q + 4 * kh), wq = *(const f32x4 *)(wsS + 32 * nb + 8 * q + 4 * kh);
                     f32x4 v;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = tact(acc[nb][4 * q + c] + bq[c], ACT >= 0 ? ACT : act_rt);
+                    for (int c = 0; c < 4; ++c) v[c] = tact(fmaf(xs, wq[c], acc[nb][4 * q + c]) + bq[c], ACT >= 0 ? ACT : act_rt);
                     float *dst = crow + 32 * nb + 8 * q;
 #ifdef GEMM_ROWS_NOSTORE
                     asm volatile("" :: "v"(v));
@@ -416,36 +422,52 @@ __global__ void k_act_backward(int64_t n, const float *__restrict__ dY, const fl
 // dZ = dY * act'(Y) AND the column sums of dZ (the bias gradient) in the same pass over the rows: the thread layout of k_colsum_partial
 // (256 / C row groups x C columns, every thread walks its rows of a slice in ascending order), partial[slice][n] summed by k_splitk_reduce.
 // dZ may alias dY (act none: nothing is written then).
+// xs (may be NULL): a second set of sums weighted by xs[row] -- the gradient of the weight column that multiplies the operand's separate
+// last column (pdp_train_linear_s): partial2[slice][n].
 __global__ void __launch_bounds__(256) k_act_backward_colsum(int64_t R, int N, const float *__restrict__ dY, const float *__restrict__ Y, int act, float *__restrict__ dZ,
-                                                             int slices, float *__restrict__ partial)
+                                                             int slices, float *__restrict__ partial, const float *__restrict__ xs, float *__restrict__ partial2)
 {
-    __shared__ float red[256];
+    __shared__ float red[256], red2[256];
     const int C = N < 256 ? N : 256;
     const int groups = 256 / C, g = threadIdx.x / C, c = threadIdx.x % C;
     const int n = blockIdx.x * 256 + c;
     const int64_t per = (R + slices - 1) / slices, r0 = per * blockIdx.y, r1 = (r0 + per < R) ? r0 + per : R;
-    float acc = 0.0f;
+    float acc = 0.0f, acc2 = 0.0f;
     if (g < groups && n < N) {
         if (act == TACT_NONE && dZ == dY) {
 #pragma unroll 4
-            for (int64_t r = r0 + g; r < r1; r += groups) acc = acc + dY[r * N + n];
+            for (int64_t r = r0 + g; r < r1; r += groups) { const float v = dY[r * N + n]; acc = acc + v; if (xs) acc2 = fmaf(v, xs[r], acc2); }
         } else {
 #pragma unroll 4
             for (int64_t r = r0 + g; r < r1; r += groups) {
                 const float v = dY[r * N + n] * tact_grad(Y[r * N + n], act);
                 dZ[r * N + n] = v;
                 acc = acc + v;
+                if (xs) acc2 = fmaf(v, xs[r], acc2);
             }
         }
     }
-    red[threadIdx.x] = acc;
+    red[threadIdx.x] = acc; red2[threadIdx.x] = acc2;
     __syncthreads();
     if (g == 0 && n < N) {
-        for (int j = 1; j < groups; ++j) acc = acc + red[j * C + c];
+        for (int j = 1; j < groups; ++j) { acc = acc + red[j * C + c]; acc2 = acc2 + red2[j * C + c]; }
         partial[(int64_t)blockIdx.y * N + n] = acc;
+        if (xs) partial2[(int64_t)blockIdx.y * N + n] = acc2;
     }
 }
-static int act_colsum_slices(int64_t R) { int64_t s = (R + 63) / 64; if (s > 4096) s = 4096; return (int)(s < 1 ? 1 : s); }
+// dW [N, K + 1] = [ dWx [N, K] | dws [N] ]
+__global__ void k_assemble_dw(int N, int K, const float *__restrict__ dWx, const float *__restrict__ dws, float *__restrict__ dW)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)N * (K + 1); i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / (K + 1)), k = (int)(i % (K + 1));
+        dW[i] = k < K ? dWx[(int64_t)n * K + k] : dws[n];
+    }
+}
+static int act_colsum_slices(int64_t R)
+{
+    static const int cap = [] { const char *e = getenv("PDP_COLSUM_SLICES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2048; }();
+    int64_t s = (R + 63) / 64; if (s > cap) s = cap; return (int)(s < 1 ? 1 : s);
+}
 
 static int grid1d(int64_t n) { int64_t g = (n + 255) / 256; if (g > 16384) g = 16384; return (int)(g < 1 ? 1 : g); }
 
@@ -511,10 +533,10 @@ static float *train_scratch(size_t floats, hipStream_t st)
 #ifndef GEMM_ROWS_WAVES
 #define GEMM_ROWS_WAVES 8                 // 512 threads, two workgroups per CU: four waves per SIMD
 #endif
-static size_t gemm_rows_lds(int nb, int KP) { return ((size_t)nb * 32 * KP + nb * 32) * sizeof(float); }
+static size_t gemm_rows_lds(int nb, int KP) { return ((size_t)nb * 32 * KP + 2 * nb * 32) * sizeof(float); }
 template <bool TB, int NB, int ACT>
 static int gemm_rows_launch(int M, int N, int K, const float *A, int64_t lda, const float *W, int64_t ldw, float *C, int64_t ldc, const float *bias, int act,
-                            int chunks, int KP, hipStream_t st)
+                            int chunks, int KP, hipStream_t st, RowsExtra ex)
 {
     const size_t lds = gemm_rows_lds(NB, KP);
     static bool attr_set = false;
@@ -530,31 +552,43 @@ static int gemm_rows_launch(int M, int N, int K, const float *A, int64_t lda, co
     static const bool grid_all = getenv("PDP_GEMM_ROWS_GRID_ALL") != nullptr;
     int gx = ((chunks > 1 || grid_all ? grid_mul : 1) * (16 / GEMM_ROWS_WAVES) * pdp_device_cus() + chunks - 1) / chunks;
     if (gx > stripes) gx = stripes;
-    hipLaunchKernelGGL((k_gemm_rows<TB, NB, ACT, GEMM_ROWS_WAVES>), dim3(gx, chunks), dim3(64 * GEMM_ROWS_WAVES), lds, st, M, N, K, A, lda, W, ldw, C, ldc, bias, act, KP);
+    hipLaunchKernelGGL((k_gemm_rows<TB, NB, ACT, GEMM_ROWS_WAVES>), dim3(gx, chunks), dim3(64 * GEMM_ROWS_WAVES), lds, st, M, N, K, A, lda, W, ldw, C, ldc, bias, act, KP, ex);
     PDP_LAUNCH_CHECK();
     return PDP_OK;
 }
 template <bool TB, int NB>
 static int gemm_rows_act(int M, int N, int K, const float *A, int64_t lda, const float *W, int64_t ldw, float *C, int64_t ldc, const float *bias, int act,
-                         int chunks, int KP, hipStream_t st)
+                         int chunks, int KP, hipStream_t st, RowsExtra ex)
 {
-    if (act == TACT_NONE) return gemm_rows_launch<TB, NB, TACT_NONE>(M, N, K, A, lda, W, ldw, C, ldc, bias, act, chunks, KP, st);
-    if (TB && act == TACT_LOGSIGMOID) return gemm_rows_launch<TB, NB, TB ? TACT_LOGSIGMOID : TACT_NONE>(M, N, K, A, lda, W, ldw, C, ldc, bias, act, chunks, KP, st);
+    if (act == TACT_NONE) return gemm_rows_launch<TB, NB, TACT_NONE>(M, N, K, A, lda, W, ldw, C, ldc, bias, act, chunks, KP, st, ex);
+    if (TB && act == TACT_LOGSIGMOID) return gemm_rows_launch<TB, NB, TB ? TACT_LOGSIGMOID : TACT_NONE>(M, N, K, A, lda, W, ldw, C, ldc, bias, act, chunks, KP, st, ex);
+    if (ex.xs) return PDP_ERR_UNSUPPORTED;                                                             // (callers ask gemm_rows_fits first)
     return gemm<false, TB>(M, N, K, A, lda, W, ldw, C, ldc, bias, act, 1, nullptr, st);        // relu / sigmoid / tanh: the predictor's small layers
 }
-template <bool TB>
-static int gemm_rows(int M, int N, int K, const float *A, int64_t lda, const float *W, int64_t ldw, float *C, int64_t ldc, const float *bias, int act, hipStream_t st)
+// does the row-stripe kernel take this product (else the tiled one does)?
+static bool gemm_rows_fits(int M, int N, int K, int act, bool TB)
 {
     static const bool tiled_only = [] { const char *e = getenv("PDP_TRAIN_GEMM"); return e && !strcmp(e, "tiled"); }();
     const int blocks = (N + 31) / 32, chunks = (blocks + 3) / 4, nb = (blocks + chunks - 1) / chunks;
     const int KP = ((K + 7) / 8) * 8 + 4;
-    if (tiled_only || M < 4096 || gemm_rows_lds(nb, KP) * (16 / GEMM_ROWS_WAVES) > 160 * 1024)
+    if (tiled_only || M < 4096 || gemm_rows_lds(nb, KP) * (16 / GEMM_ROWS_WAVES) > 160 * 1024) return false;
+    return act == TACT_NONE || (TB && act == TACT_LOGSIGMOID);
+}
+template <bool TB>
+static int gemm_rows(int M, int N, int K, const float *A, int64_t lda, const float *W, int64_t ldw, float *C, int64_t ldc, const float *bias, int act, hipStream_t st,
+                     RowsExtra ex = RowsExtra{nullptr, nullptr, 0})
+{
+    const int blocks = (N + 31) / 32, chunks = (blocks + 3) / 4, nb = (blocks + chunks - 1) / chunks;
+    const int KP = ((K + 7) / 8) * 8 + 4;
+    if (!gemm_rows_fits(M, N, K, act, TB)) {
+        if (ex.xs) return PDP_ERR_UNSUPPORTED;
         return gemm<false, TB>(M, N, K, A, lda, W, ldw, C, ldc, bias, act, 1, nullptr, st);
+    }
     switch (nb) {
-    case 1: return gemm_rows_act<TB, 1>(M, N, K, A, lda, W, ldw, C, ldc, bias, act, chunks, KP, st);
-    case 2: return gemm_rows_act<TB, 2>(M, N, K, A, lda, W, ldw, C, ldc, bias, act, chunks, KP, st);
-    case 3: return gemm_rows_act<TB, 3>(M, N, K, A, lda, W, ldw, C, ldc, bias, act, chunks, KP, st);
-    default: return gemm_rows_act<TB, 4>(M, N, K, A, lda, W, ldw, C, ldc, bias, act, chunks, KP, st);
+    case 1: return gemm_rows_act<TB, 1>(M, N, K, A, lda, W, ldw, C, ldc, bias, act, chunks, KP, st, ex);
+    case 2: return gemm_rows_act<TB, 2>(M, N, K, A, lda, W, ldw, C, ldc, bias, act, chunks, KP, st, ex);
+    case 3: return gemm_rows_act<TB, 3>(M, N, K, A, lda, W, ldw, C, ldc, bias, act, chunks, KP, st, ex);
+    default: return gemm_rows_act<TB, 4>(M, N, K, A, lda, W, ldw, C, ldc, bias, act, chunks, KP, st, ex);
     }
 }
 
@@ -585,7 +619,7 @@ extern "C" int pdp_train_linear_backward(const float *dY, const float *Y, const 
     if (db) {
         // one pass: dZ and the bias gradient's partial column sums
         float *part = scr + (size_t)splits * N * K;
-        hipLaunchKernelGGL(k_act_backward_colsum, dim3((N + 255) / 256, cs), dim3(256), 0, st, R, N, dY, Y, act, dZ, cs, part);
+        hipLaunchKernelGGL(k_act_backward_colsum, dim3((N + 255) / 256, cs), dim3(256), 0, st, R, N, dY, Y, act, dZ, cs, part, (const float *)nullptr, (float *)nullptr);
         hipLaunchKernelGGL(k_splitk_reduce, dim3(reduce_grid(N)), dim3(RED_G * RED_E), 0, st, (int64_t)N, cs, (const float *)part, db);
     } else if (!(act == TACT_NONE && dZ == dY))
         hipLaunchKernelGGL(k_act_backward, dim3(grid1d(R * N)), dim3(256), 0, st, R * N, dY, Y, act, dZ);
@@ -593,6 +627,48 @@ extern "C" int pdp_train_linear_backward(const float *dY, const float *Y, const 
     if (dX) { s = gemm_rows<false>((int)R, K, N, dZ, N, W, K, dX, lddx, nullptr, TACT_NONE, st); if (s != PDP_OK) return s; }
     s = gemm<true, false>(N, K, R, dZ, N, X, ldx, dW, K, nullptr, TACT_NONE, splits, scr, st);
     if (s != PDP_OK) return s;
+    PDP_LAUNCH_CHECK();
+    return PDP_OK;
+}
+
+// ---- Linear on an operand whose last column lives apart: Y = act([X | xs] W^T + b), X [R,K], xs [R], W [N, K + 1] -----------------------------
+// The training path's layers read [state | edge sign]: the reference concatenates (pdp_propagate.py:66-67, util.py:71-72); here the K-wide
+// block goes through the row-stripe GEMM (K = 128: four whole slabs, no tail) and the sign column is a rank-one term of its epilogue.
+extern "C" int pdp_train_linear_s_supported(int64_t R, int K, int N, int act)
+{
+    return R < ((int64_t)1 << 31) && gemm_rows_fits((int)R, N, K, act, true) && gemm_rows_fits((int)R, K, N, TACT_NONE, false) ? 1 : 0;
+}
+extern "C" int pdp_train_linear_s(const float *X, const float *xs, int64_t R, int K, int64_t ldx, const float *W, const float *b, int N, int act, float *Y, void *stream)
+{
+    PDP_REQUIRE(X && xs && W && Y && R >= 0 && K > 0 && N > 0, "bad argument");
+    PDP_REQUIRE(pdp_train_linear_s_supported(R, K, N, act), "shape outside the row-stripe kernel (ask pdp_train_linear_s_supported; concatenate and use pdp_train_linear)");
+    if (R == 0) return PDP_OK;
+    return gemm_rows<true>((int)R, N, K, X, ldx, W, K + 1, Y, N, b, act, ST(stream), RowsExtra{xs, W + K, (int64_t)K + 1});
+}
+// adjoint: dZ = dY * act'(Y);  dX [R,K] = dZ W[:, :K];  dW [N, K + 1] = [ dZ^T X | dZ^T xs ];  db = column sums (NULL: no bias).  No gradient for xs.
+extern "C" int pdp_train_linear_s_backward(const float *dY, const float *Y, const float *X, const float *xs, int64_t R, int K, int64_t ldx, const float *W, int N,
+                                           int act, float *dZ, float *dX, int64_t lddx, float *dW, float *db, void *stream)
+{
+    PDP_REQUIRE(dY && Y && X && xs && W && dZ && dW && R >= 0 && R < (int64_t)1 << 31, "bad argument");
+    hipStream_t st = ST(stream);
+    if (R == 0) {
+        PDP_HIP_CHECK(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)N * (K + 1), st));
+        if (db) PDP_HIP_CHECK(hipMemsetAsync(db, 0, sizeof(float) * (size_t)N, st));
+        return PDP_OK;
+    }
+    const int splits = pick_splits(R);
+    const int cs = act_colsum_slices(R);
+    float *scr = train_scratch((size_t)splits * (size_t)N * K + (size_t)N * K + 2 * (size_t)cs * N + 2 * (size_t)N + 16, st);
+    if (!scr) return PDP_ERR_HIP;
+    float *dWx = scr + (size_t)splits * N * K, *part = dWx + (size_t)N * K, *part2 = part + (size_t)cs * N, *dbs = part2 + (size_t)cs * N, *dws = dbs + N;
+    hipLaunchKernelGGL(k_act_backward_colsum, dim3((N + 255) / 256, cs), dim3(256), 0, st, R, N, dY, Y, act, dZ, cs, part, xs, part2);
+    hipLaunchKernelGGL(k_splitk_reduce, dim3(reduce_grid(N)), dim3(RED_G * RED_E), 0, st, (int64_t)N, cs, (const float *)part, db ? db : dbs);
+    hipLaunchKernelGGL(k_splitk_reduce, dim3(reduce_grid(N)), dim3(RED_G * RED_E), 0, st, (int64_t)N, cs, (const float *)part2, dws);
+    int s;
+    if (dX) { s = gemm_rows<false>((int)R, K, N, dZ, N, W, K + 1, dX, lddx, nullptr, TACT_NONE, st); if (s != PDP_OK) return s; }
+    s = gemm<true, false>(N, K, R, dZ, N, X, ldx, dWx, K, nullptr, TACT_NONE, splits, scr, st);
+    if (s != PDP_OK) return s;
+    hipLaunchKernelGGL(k_assemble_dw, dim3(grid1d((int64_t)N * (K + 1))), dim3(256), 0, st, N, K, (const float *)dWx, (const float *)dws, dW);
     PDP_LAUNCH_CHECK();
     return PDP_OK;
 }
@@ -663,14 +739,16 @@ __global__ void k_gru_point(int64_t R, int H, const float *__restrict__ gi, cons
 // bias gradients are made of -- dr, dz, dn (b_ih = dr | dz | dn) and dn r (b_hh = dr | dz | dn r) -- come out of the pass that writes dgi /
 // dgh, as partial[slice][4][H].
 __global__ void __launch_bounds__(256) k_gru_point_backward(int64_t R, int H, const float *__restrict__ dhn, const float *__restrict__ saved, const float *__restrict__ h,
-                                                            float *__restrict__ dgi, float *__restrict__ dgh, float *__restrict__ dh, int slices, float *__restrict__ partial)
+                                                            float *__restrict__ dgi, float *__restrict__ dgh, float *__restrict__ dh, int slices, float *__restrict__ partial,
+                                                            const float *__restrict__ xs /* NULL, or the input's separate last column: + dr xs | dz xs | dn xs */)
 {
-    __shared__ float red[4][256];
+    __shared__ float red[7][256];
     const int Cw = H < 256 ? H : 256;
     const int groups = 256 / Cw, g = threadIdx.x / Cw, cl = threadIdx.x % Cw;
     const int c = blockIdx.x * 256 + cl;
     const int64_t per = (R + slices - 1) / slices, r0 = per * blockIdx.y, r1 = (r0 + per < R) ? r0 + per : R;
-    float s_r = 0.0f, s_z = 0.0f, s_n = 0.0f, s_nr = 0.0f;
+    float s_r = 0.0f, s_z = 0.0f, s_n = 0.0f, s_nr = 0.0f, x_r = 0.0f, x_z = 0.0f, x_n = 0.0f;
+    const int NS = xs ? 7 : 4;
     if (g < groups && c < H) {
 #pragma unroll 2
         for (int64_t e = r0 + g; e < r1; e += groups) {
@@ -688,14 +766,20 @@ __global__ void __launch_bounds__(256) k_gru_point_backward(int64_t R, int H, co
             a[2 * H + c] = dn_pre; b[2 * H + c] = dnr;
             dh[i] = gd * z;                              // the direct path; the W_hh path is added by the caller's GEMM (accumulating epilogue)
             s_r = s_r + dr_pre; s_z = s_z + dz_pre; s_n = s_n + dn_pre; s_nr = s_nr + dnr;
+            if (xs) { const float xv = xs[e]; x_r = fmaf(dr_pre, xv, x_r); x_z = fmaf(dz_pre, xv, x_z); x_n = fmaf(dn_pre, xv, x_n); }
         }
     }
     red[0][threadIdx.x] = s_r; red[1][threadIdx.x] = s_z; red[2][threadIdx.x] = s_n; red[3][threadIdx.x] = s_nr;
+    red[4][threadIdx.x] = x_r; red[5][threadIdx.x] = x_z; red[6][threadIdx.x] = x_n;
     __syncthreads();
     if (g == 0 && c < H) {
-        for (int j = 1; j < groups; ++j) { s_r = s_r + red[0][j * Cw + cl]; s_z = s_z + red[1][j * Cw + cl]; s_n = s_n + red[2][j * Cw + cl]; s_nr = s_nr + red[3][j * Cw + cl]; }
-        float *p = partial + (int64_t)blockIdx.y * 4 * H;
+        for (int j = 1; j < groups; ++j) {
+            s_r = s_r + red[0][j * Cw + cl]; s_z = s_z + red[1][j * Cw + cl]; s_n = s_n + red[2][j * Cw + cl]; s_nr = s_nr + red[3][j * Cw + cl];
+            x_r = x_r + red[4][j * Cw + cl]; x_z = x_z + red[5][j * Cw + cl]; x_n = x_n + red[6][j * Cw + cl];
+        }
+        float *p = partial + (int64_t)blockIdx.y * NS * H;
         p[c] = s_r; p[H + c] = s_z; p[2 * H + c] = s_n; p[3 * H + c] = s_nr;
+        if (xs) { p[4 * H + c] = x_r; p[5 * H + c] = x_z; p[6 * H + c] = x_n; }
     }
 }
 
@@ -731,7 +815,7 @@ extern "C" int pdp_train_gru_backward(const float *dhnew, const float *saved, co
     float *scr = train_scratch((size_t)splits * wmax + (size_t)cs * 4 * H + 4 * H + 16, st);
     if (!scr) return PDP_ERR_HIP;
     float *part = scr + (size_t)splits * wmax, *sums = part + (size_t)cs * 4 * H;          // sums [4 H] = dr | dz | dn | dn r
-    hipLaunchKernelGGL(k_gru_point_backward, dim3((H + 255) / 256, cs), dim3(256), 0, st, R, H, dhnew, saved, h, dgi, dgh, dh, cs, part);
+    hipLaunchKernelGGL(k_gru_point_backward, dim3((H + 255) / 256, cs), dim3(256), 0, st, R, H, dhnew, saved, h, dgi, dgh, dh, cs, part, (const float *)nullptr);
     hipLaunchKernelGGL(k_splitk_reduce, dim3(reduce_grid(4 * H)), dim3(RED_G * RED_E), 0, st, (int64_t)4 * H, cs, (const float *)part, sums);
     PDP_HIP_CHECK(hipMemcpyAsync(db_ih, sums, sizeof(float) * 3 * (size_t)H, hipMemcpyDeviceToDevice, st));
     PDP_HIP_CHECK(hipMemcpyAsync(db_hh, sums, sizeof(float) * 2 * (size_t)H, hipMemcpyDeviceToDevice, st));
@@ -740,6 +824,42 @@ extern "C" int pdp_train_gru_backward(const float *dhnew, const float *saved, co
     // dh += dgh W_hh: the tiled kernel's accumulating epilogue (dh holds the direct path)
     s = gemm<false, false>((int)R, H, 3 * H, dgh, 3 * H, W_hh, H, dh, H, nullptr, TACT_NONE | TACT_ACCUMULATE, 1, nullptr, st); if (s != PDP_OK) return s;
     s = gemm<true, false>(3 * H, Kx, R, dgi, 3 * H, x, Kx, dW_ih, Kx, nullptr, TACT_NONE, splits, scr, st); if (s != PDP_OK) return s;
+    s = gemm<true, false>(3 * H, H, R, dgh, 3 * H, h, H, dW_hh, H, nullptr, TACT_NONE, splits, scr, st); if (s != PDP_OK) return s;
+    PDP_LAUNCH_CHECK();
+    return PDP_OK;
+}
+
+// The same adjoint for a cell whose input is [state [R,H'] | xs [R]] held apart (W_ih [3H, H' + 1]): dstate = dgi W_ih[:, :H'] (one column
+// block less than the concatenated form), dW_ih = [ dgi^T state | dgi^T xs ] -- the last column comes out of the pointwise pass as three more
+// column sums -- and xs (the edge sign) has no gradient.  scratch [R, 6H].
+extern "C" int pdp_train_gru_backward_s(const float *dhnew, const float *saved, const float *state, const float *xs, const float *h, const float *W_ih,
+                                        const float *W_hh, int64_t R, int Ks, int H, float *dstate, float *dh, float *dW_ih, float *dW_hh, float *db_ih, float *db_hh,
+                                        float *scratch, void *stream)
+{
+    PDP_REQUIRE(dhnew && saved && state && xs && h && W_ih && W_hh && dstate && dh && dW_ih && dW_hh && db_ih && db_hh && scratch && R < (int64_t)1 << 31, "bad argument");
+    hipStream_t st = ST(stream);
+    const int Kx = Ks + 1;
+    if (R == 0) {
+        PDP_HIP_CHECK(hipMemsetAsync(dW_ih, 0, sizeof(float) * 3 * (size_t)H * Kx, st)); PDP_HIP_CHECK(hipMemsetAsync(dW_hh, 0, sizeof(float) * 3 * (size_t)H * H, st));
+        PDP_HIP_CHECK(hipMemsetAsync(db_ih, 0, sizeof(float) * 3 * (size_t)H, st)); PDP_HIP_CHECK(hipMemsetAsync(db_hh, 0, sizeof(float) * 3 * (size_t)H, st));
+        return PDP_OK;
+    }
+    float *dgi = scratch, *dgh = scratch + (size_t)R * 3 * H;
+    const int splits = pick_splits(R);
+    const size_t wmax = (size_t)3 * H * (Ks > H ? Ks : H);
+    const int cs = act_colsum_slices(R);
+    float *scr = train_scratch((size_t)splits * wmax + wmax + (size_t)cs * 7 * H + 7 * H + 16, st);
+    if (!scr) return PDP_ERR_HIP;
+    float *dWx = scr + (size_t)splits * wmax, *part = dWx + wmax, *sums = part + (size_t)cs * 7 * H;       // sums [7 H] = dr | dz | dn | dn r | dr xs | dz xs | dn xs
+    hipLaunchKernelGGL(k_gru_point_backward, dim3((H + 255) / 256, cs), dim3(256), 0, st, R, H, dhnew, saved, h, dgi, dgh, dh, cs, part, xs);
+    hipLaunchKernelGGL(k_splitk_reduce, dim3(reduce_grid(7 * H)), dim3(RED_G * RED_E), 0, st, (int64_t)7 * H, cs, (const float *)part, sums);
+    PDP_HIP_CHECK(hipMemcpyAsync(db_ih, sums, sizeof(float) * 3 * (size_t)H, hipMemcpyDeviceToDevice, st));
+    PDP_HIP_CHECK(hipMemcpyAsync(db_hh, sums, sizeof(float) * 2 * (size_t)H, hipMemcpyDeviceToDevice, st));
+    PDP_HIP_CHECK(hipMemcpyAsync(db_hh + 2 * (size_t)H, sums + 3 * (size_t)H, sizeof(float) * (size_t)H, hipMemcpyDeviceToDevice, st));
+    int s = gemm_rows<false>((int)R, Ks, 3 * H, dgi, 3 * H, W_ih, Kx, dstate, Ks, nullptr, TACT_NONE, st); if (s != PDP_OK) return s;
+    s = gemm<false, false>((int)R, H, 3 * H, dgh, 3 * H, W_hh, H, dh, H, nullptr, TACT_NONE | TACT_ACCUMULATE, 1, nullptr, st); if (s != PDP_OK) return s;
+    s = gemm<true, false>(3 * H, Ks, R, dgi, 3 * H, state, Ks, dWx, Ks, nullptr, TACT_NONE, splits, scr, st); if (s != PDP_OK) return s;
+    hipLaunchKernelGGL(k_assemble_dw, dim3(grid1d((int64_t)3 * H * Kx)), dim3(256), 0, st, 3 * H, Ks, (const float *)dWx, (const float *)(sums + 4 * (size_t)H), dW_ih);
     s = gemm<true, false>(3 * H, H, R, dgh, 3 * H, h, H, dW_hh, H, nullptr, TACT_NONE, splits, scr, st); if (s != PDP_OK) return s;
     PDP_LAUNCH_CHECK();
     return PDP_OK;

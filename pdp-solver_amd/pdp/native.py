@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = [
     'pdp_energy_diff', 'pdp_random_fill', 'pdp_local_search', 'pdp_deduplicate', 'pdp_sp_solve', 'pdp_math_apply',
     'pdp_neural_aggregate_edges', 'pdp_neural_gru', 'pdp_neural_predict', 'pdp_dimacs_open', 'pdp_dimacs_read', 'pdp_dimacs_close', 'pdp_dimacs_open_many',
     'pdp_kernel_timing', 'pdp_kernel_timing_read', 'pdp_kernel_name',
-    'pdp_train_linear', 'pdp_train_linear_backward', 'pdp_train_row_sum', 'pdp_train_row_spread', 'pdp_train_gru', 'pdp_train_gru_fused', 'pdp_train_gru_backward',
+    'pdp_train_linear', 'pdp_train_linear_backward', 'pdp_train_linear_s_supported', 'pdp_train_linear_s', 'pdp_train_linear_s_backward', 'pdp_train_row_sum', 'pdp_train_row_spread', 'pdp_train_gru', 'pdp_train_gru_fused', 'pdp_train_gru_backward', 'pdp_train_gru_backward_s',
     'pdp_sat_loss_grad', 'pdp_train_sp_adapted_backward',
     'pdp_coo_max', 'pdp_coo_argmax', 'pdp_coo_row_ptr', 'pdp_csr_matmul', 'pdp_csr_smooth_max',
 ]

@@ -50,12 +50,18 @@ class NeuralDecimator(nn.Module):
             gf = sat_problem.edge_meta()
             extra = (sign,) if gf is None else (sign, gf)
             cv, cf = self._variable_rnn_cell, self._function_rnn_cell
-            # hidden 128 without graph features: the forward of a cell is one launch of the pipelined inference kernel (train_ops.GruCell)
-            fused = gf is None and self._hidden_dimension == 128 and variable_state.size(1) == 128
-            pv = (self._weights('v', cv), variable_state, sign) if fused else ()
-            pf = (self._weights('f', cf), function_state, sign) if fused else ()
-            nv = T.GruCell.apply(torch.cat((variable_state,) + extra, 1), init_state[0], cv.weight_ih, cv.weight_hh, cv.bias_ih, cv.bias_hh, *pv)
-            nf = T.GruCell.apply(torch.cat((function_state,) + extra, 1), init_state[1], cf.weight_ih, cf.weight_hh, cf.bias_ih, cf.bias_hh, *pf)
+            # hidden 128 without graph features: the cell runs on its two input pieces (train_ops.GruCellS: forward = one launch of the
+            # pipelined inference kernel, no [E, 129] concatenation); PDP_TRAIN_CAT=1: the concatenated form of rounds 1-3
+            import os
+            fused = gf is None and self._hidden_dimension == 128 and variable_state.size(1) == 128 and function_state.size(1) == 128
+            if fused and os.environ.get('PDP_TRAIN_CAT', '0') != '1':
+                nv = T.GruCellS.apply(variable_state, sign, init_state[0], cv.weight_ih, cv.weight_hh, cv.bias_ih, cv.bias_hh, self._weights('v', cv))
+                nf = T.GruCellS.apply(function_state, sign, init_state[1], cf.weight_ih, cf.weight_hh, cf.bias_ih, cf.bias_hh, self._weights('f', cf))
+            else:
+                pv = (self._weights('v', cv), variable_state, sign) if fused else ()
+                pf = (self._weights('f', cf), function_state, sign) if fused else ()
+                nv = T.GruCell.apply(torch.cat((variable_state,) + extra, 1), init_state[0], cv.weight_ih, cv.weight_hh, cv.bias_ih, cv.bias_hh, *pv)
+                nf = T.GruCell.apply(torch.cat((function_state,) + extra, 1), init_state[1], cf.weight_ih, cf.weight_hh, cf.bias_ih, cf.bias_hh, *pf)
             if active_mask is not None:
                 mask = active_mask.reshape(-1).float()[sat_problem._batch_variable_map.long()][sat_problem._graph_map[0].long()].unsqueeze(1)
                 nv = mask * nv + (1 - mask) * init_state[0]; nf = mask * nf + (1 - mask) * init_state[1]

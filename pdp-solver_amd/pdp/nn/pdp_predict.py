@@ -65,8 +65,10 @@ class NeuralPredictor(nn.Module):
         "aggregator + perceptron head as generic native operators (differentiable; pdp_predict.py:67-89, trainer.py:28-29 for the head)"
         from pdp.nn import train_ops as T
         gf = sat_problem.edge_meta()
-        rows = (state, sat_problem._edge_feature) if gf is None else (state, sat_problem._edge_feature, gf)
-        agg = aggregator.forward_train(torch.cat(rows, 1), None, sat_problem, by_variable, edge_mask)
+        if gf is None:
+            agg = aggregator.forward_train(state, None, sat_problem, by_variable, edge_mask, state_feature=sat_problem._edge_feature)
+        else:
+            agg = aggregator.forward_train(torch.cat((state, sat_problem._edge_feature, gf), 1), None, sat_problem, by_variable, edge_mask)
         hid = T.LinearAct.apply(agg, classifier._layer1.weight, classifier._layer1.bias, 'relu')
         out_act = 'tanh' if type(classifier).__name__ == 'PerceptronTanh' else 'sigmoid'
         return T.LinearAct.apply(hid, classifier._layer2.weight, None, out_act)

@@ -77,12 +77,19 @@ class NeuralMessagePasser(nn.Module):
             mask = active_mask.reshape(-1).float()[sat_problem._batch_variable_map.long()][sat_problem._graph_map[0].long()].unsqueeze(1)
         gf = sat_problem.edge_meta()
         extra = (sign,) if gf is None else (sign, gf)
-        fs = self._variable_aggregator.forward_train(torch.cat((dec_v,) + extra, 1), sign, sat_problem, True, edge_mask)
+        # [state | sign] in front of the aggregators: the sign column travels apart (no [E, H + 1] copy) unless graph features widen the input
+        if gf is None:
+            fs = self._variable_aggregator.forward_train(dec_v, sign, sat_problem, True, edge_mask, state_feature=sign)
+        else:
+            fs = self._variable_aggregator.forward_train(torch.cat((dec_v,) + extra, 1), sign, sat_problem, True, edge_mask)
         if active_mask is not None:
             fs = mask * fs + (1 - mask) * function_state
         if dropout:
             fs = T.dropout(fs, self._drop_out, getattr(self, '_rng', 'device'))
-        vs = self._function_aggregator.forward_train(torch.cat((dec_f,) + extra, 1), sign, sat_problem, False, edge_mask)
+        if gf is None:
+            vs = self._function_aggregator.forward_train(dec_f, sign, sat_problem, False, edge_mask, state_feature=sign)
+        else:
+            vs = self._function_aggregator.forward_train(torch.cat((dec_f,) + extra, 1), sign, sat_problem, False, edge_mask)
         if active_mask is not None:
             vs = mask * vs + (1 - mask) * variable_state
         if dropout:

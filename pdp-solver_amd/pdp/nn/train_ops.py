@@ -51,6 +51,52 @@ class LinearAct(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class LinearActS(torch.autograd.Function):
+    """y = act([x | xs] W^T + b) with the operand's last column ``xs`` [R] held apart (the edge sign in front of the training path's layers):
+    no [R, K + 1] concatenation is made -- the K-wide block runs on the row-stripe GEMM, the column is a rank-one term of its epilogue
+    (include/pdp_hip.h: pdp_train_linear_s).  ``xs`` gets no gradient.  Use ``linear_sign`` below, which falls back to the concatenation
+    for shapes the kernel does not take."""
+
+    @staticmethod
+    def forward(ctx, x, xs, weight, bias, act):
+        x, xs, weight = _f(x), _f(xs.reshape(-1)), _f(weight)
+        R, K = x.shape
+        N = weight.shape[0]
+        y = torch.empty(R, N, dtype=torch.float32, device=x.device)
+        native.check(native.lib().pdp_train_linear_s(native.ptr(x, torch.float32), native.ptr(xs, torch.float32), C.c_int64(R), C.c_int(K), C.c_int64(K),
+                                                     native.ptr(weight, torch.float32), native.ptr(_f(bias), torch.float32), C.c_int(N), C.c_int(ACT[act]),
+                                                     native.ptr(y), native._stream()))
+        ctx.save_for_backward(x, xs, weight, y)
+        ctx.act, ctx.has_bias = act, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, xs, weight, y = ctx.saved_tensors
+        dy = _f(dy)
+        R, K = x.shape
+        N = weight.shape[0]
+        dz = torch.empty_like(dy)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(weight)
+        db = torch.empty(N, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        native.check(native.lib().pdp_train_linear_s_backward(native.ptr(dy, torch.float32), native.ptr(y), native.ptr(x), native.ptr(xs), C.c_int64(R), C.c_int(K),
+                                                              C.c_int64(K), native.ptr(weight), C.c_int(N), C.c_int(ACT[ctx.act]), native.ptr(dz), native.ptr(dx),
+                                                              C.c_int64(K), native.ptr(dw), native.ptr(db), native._stream()))
+        return dx, None, dw, db, None
+
+
+def linear_sign(x, sign, weight, bias, act):
+    """act([x | sign] W^T + b) for ``sign`` [R, 1]: without the concatenation where the row-stripe kernel takes the shape, with it otherwise
+    (``PDP_TRAIN_CAT=1``: always with it -- the form of rounds 1-3, for A/B measurements)."""
+    R, K = x.shape
+    N = weight.shape[0]
+    if (sign.dim() == 2 and sign.size(1) == 1 and weight.shape[1] == K + 1 and os.environ.get('PDP_TRAIN_CAT', '0') != '1'
+            and native.lib().pdp_train_linear_s_supported(C.c_int64(R), C.c_int(K), C.c_int(N), C.c_int(ACT[act]))):
+        return LinearActS.apply(x, sign, weight, bias, act)
+    return LinearAct.apply(torch.cat((x, sign), 1), weight, bias, act)
+
+
 class RowAggregate(torch.autograd.Function):
     """Deep-set aggregation over the rows of the factor graph (util.py:60-69): the ordered sum of the edge values of every variable
     (by_variable) or clause; with include_self False every edge gets its row's sum minus its own value ([E, A]), else the rows ([rows, A])."""
@@ -157,6 +203,53 @@ class GruCell(torch.autograd.Function):
                                                          native.ptr(w_hh), C.c_int64(R), C.c_int(Kx), C.c_int(H), native.ptr(dx), native.ptr(dh), native.ptr(dw_ih),
                                                          native.ptr(dw_hh), native.ptr(db_ih), native.ptr(db_hh), native.ptr(scratch), native._stream()))
         return dx, dh, dw_ih, dw_hh, db_ih, db_hh, None, None, None
+
+
+class GruCellS(torch.autograd.Function):
+    """The 129 -> 128 cell of the neural decimator on its two input pieces ``state`` [R, 128] and ``sign`` [R, 1] (torch.nn.GRUCell on their
+    concatenation): the forward is one launch of the pipelined inference kernel on the full 64-row tiles (the ragged tail takes the
+    two-GEMM form on a concatenated copy of its <= 63 rows), the adjoint multiplies by W_ih[:, :128] only (the sign has no gradient) and gets
+    the last column of dW_ih from the pointwise pass.  ``packed``: the weights as native.GruWeights."""
+
+    @staticmethod
+    def forward(ctx, state, sign, h, w_ih, w_hh, b_ih, b_hh, packed):
+        state, sign, h, w_ih, w_hh, b_ih, b_hh = [_f(t) for t in (state, sign.reshape(-1), h, w_ih, w_hh, b_ih, b_hh)]
+        R, Ks = state.shape
+        H = h.shape[1]
+        hnew = torch.empty_like(h)
+        saved = torch.empty(R, 4 * H, dtype=torch.float32, device=state.device)
+        full = (R // 64) * 64
+        if full:
+            native.check(native.lib().pdp_train_gru_fused(C.byref(packed.desc), native.ptr(state, torch.float32), native.ptr(sign, torch.float32),
+                                                          native.ptr(h, torch.float32), C.c_int64(full), native.ptr(hnew), native.ptr(saved), native._stream()))
+        if full < R:
+            xt = torch.cat((state[full:], sign[full:].unsqueeze(1)), 1).contiguous()
+            ht = h[full:].contiguous()
+            hn_t = torch.empty_like(ht)
+            sv_t = torch.empty(R - full, 4 * H, dtype=torch.float32, device=state.device)
+            scratch = torch.empty(R - full, 6 * H, dtype=torch.float32, device=state.device)
+            native.check(native.lib().pdp_train_gru(native.ptr(xt, torch.float32), native.ptr(ht, torch.float32), native.ptr(w_ih), native.ptr(w_hh), native.ptr(b_ih),
+                                                    native.ptr(b_hh), C.c_int64(R - full), C.c_int(Ks + 1), C.c_int(H), native.ptr(hn_t), native.ptr(sv_t),
+                                                    native.ptr(scratch), native._stream()))
+            hnew[full:] = hn_t; saved[full:] = sv_t
+        ctx.save_for_backward(state, sign, h, w_ih, w_hh, saved)
+        return hnew
+
+    @staticmethod
+    def backward(ctx, dhnew):
+        state, sign, h, w_ih, w_hh, saved = ctx.saved_tensors
+        dhnew = _f(dhnew)
+        R, Ks = state.shape
+        H = h.shape[1]
+        dstate, dh = torch.empty_like(state), torch.empty_like(h)
+        dw_ih, dw_hh = torch.empty_like(w_ih), torch.empty_like(w_hh)
+        db_ih = torch.empty(3 * H, dtype=torch.float32, device=state.device); db_hh = torch.empty_like(db_ih)
+        scratch = torch.empty(R, 6 * H, dtype=torch.float32, device=state.device)
+        native.check(native.lib().pdp_train_gru_backward_s(native.ptr(dhnew, torch.float32), native.ptr(saved), native.ptr(state), native.ptr(sign), native.ptr(h),
+                                                           native.ptr(w_ih), native.ptr(w_hh), C.c_int64(R), C.c_int(Ks), C.c_int(H), native.ptr(dstate), native.ptr(dh),
+                                                           native.ptr(dw_ih), native.ptr(dw_hh), native.ptr(db_ih), native.ptr(db_hh), native.ptr(scratch),
+                                                           native._stream()))
+        return dstate, None, dh, dw_ih, dw_hh, db_ih, db_hh, None
 
 
 class SpAdaptedSweep(torch.autograd.Function):

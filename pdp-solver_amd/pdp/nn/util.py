@@ -214,15 +214,22 @@ class MessageAggregator(nn.Module):
             return self.forward_train(state, feature, owner[0], owner[2] == 0, edge_mask)
         return self.forward_train(state, feature, None, None, edge_mask, masks=(mask, mask_transpose))
 
-    def forward_train(self, state, feature, sat_problem, by_variable, edge_mask=None, masks=None):
+    def forward_train(self, state, feature, sat_problem, by_variable, edge_mask=None, masks=None, state_feature=None):
         """The differentiable form (training; reference: util.py:51-77): ``state`` [E, input_dimension] already carries the appended edge
-        feature, ``feature`` [E, feature_dimension] (or None) is appended after the aggregation.  Every layer and the row aggregation is a
-        native forward / adjoint pair (pdp/nn/train_ops.py).  ``masks`` = (mask, mask_transpose) replaces the problem's own rows."""
+        feature -- or ``state`` is [E, input_dimension - 1] and ``state_feature`` [E, 1] is that last column held apart (no concatenation is
+        made where the row-stripe GEMM takes the layer, train_ops.linear_sign); ``feature`` [E, feature_dimension] (or None) is appended
+        after the aggregation, the same way.  Every layer and the row aggregation is a native forward / adjoint pair (pdp/nn/train_ops.py).
+        ``masks`` = (mask, mask_transpose) replaces the problem's own rows."""
         from pdp.nn import train_ops as T
         s = state
         if self._has_pre:
-            s = T.LinearAct.apply(s, self._W1_m.weight, self._W1_m.bias, 'logsigmoid')
+            if state_feature is not None:
+                s = T.linear_sign(s, state_feature, self._W1_m.weight, self._W1_m.bias, 'logsigmoid')
+            else:
+                s = T.LinearAct.apply(s, self._W1_m.weight, self._W1_m.bias, 'logsigmoid')
             s = T.LinearAct.apply(s, self._W2_m.weight, None, 'logsigmoid')
+        elif state_feature is not None:
+            s = torch.cat((s, state_feature), 1)
         if edge_mask is not None:
             s = s * edge_mask
         if masks is None:
@@ -231,11 +238,16 @@ class MessageAggregator(nn.Module):
             agg = T.MaskMatmul.apply(s, masks[0])
             if not self._include_self_message:
                 agg = T.MaskMatmul.apply(agg, masks[1]) - (s * edge_mask if edge_mask is not None else s)
-        if feature is not None:
-            agg = torch.cat((agg, feature), 1)
         if self._has_post:
-            agg = T.LinearAct.apply(agg, self._W1_a.weight, self._W1_a.bias, 'logsigmoid')
+            if feature is not None and feature.dim() == 2 and feature.size(1) == 1:
+                agg = T.linear_sign(agg, feature, self._W1_a.weight, self._W1_a.bias, 'logsigmoid')
+            else:
+                if feature is not None:
+                    agg = torch.cat((agg, feature), 1)
+                agg = T.LinearAct.apply(agg, self._W1_a.weight, self._W1_a.bias, 'logsigmoid')
             agg = T.LinearAct.apply(agg, self._W2_a.weight, None, 'logsigmoid')
+        elif feature is not None:
+            agg = torch.cat((agg, feature), 1)
         return agg
 
 

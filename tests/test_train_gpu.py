@@ -65,6 +65,58 @@ def test_gru_forward_and_adjoint_vs_torch():
             torch.testing.assert_close(a, r, rtol=3e-4, atol=3e-4 * float(r.abs().max().clamp(min=1e-3)), msg=lambda m: '%s (R=%d): %s' % (name, R, m))
 
 
+@pytest.mark.parametrize('R,K,N,act', [(8200, 128, 100, 'logsigmoid'), (4100, 50, 100, 'logsigmoid'), (5000, 128, 384, 'none'), (4099, 7, 33, 'none'), (300, 128, 100, 'logsigmoid')])
+def test_linear_on_a_separate_sign_column_vs_torch(R, K, N, act):
+    """act([x | sign] W^T + b) without the concatenation (train_ops.linear_sign -> LinearActS: the K-wide block on the row-stripe GEMM, the sign
+    column a rank-one term of its epilogue; dW's last column from the dZ pass) against torch on the concatenated operand; the last case is
+    below the kernel's row threshold and takes the concatenating fallback."""
+    from pdp.nn import train_ops as T
+    x, w, b = _leaf(R, K, seed=11), _leaf(N, K + 1, seed=12), _leaf(N, seed=13)
+    sign = torch.sign(torch.randn(R, 1, device=DEV))
+    fn = {'logsigmoid': F.logsigmoid, 'none': lambda z: z}[act]
+    g = torch.randn(R, N, device=DEV)
+    y = T.linear_sign(x, sign, w, b, act)
+    y.backward(g)
+    got = [y.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone()]
+    for p_ in (x, w, b):
+        p_.grad = None
+    yr = fn(F.linear(torch.cat((x, sign), 1), w, b))
+    yr.backward(g)
+    for a, r, name in zip(got, (yr.detach(), x.grad, w.grad, b.grad), ('y', 'dx', 'dw', 'db')):
+        torch.testing.assert_close(a, r, rtol=2e-4, atol=2e-4 * float(r.abs().max().clamp(min=1e-3)), msg=lambda m: name + ': ' + m)
+    # and without a bias
+    x.grad = w.grad = None
+    y = T.linear_sign(x, sign, w, None, act); y.backward(g)
+    got = [y.detach().clone(), x.grad.clone(), w.grad.clone()]
+    x.grad = w.grad = None
+    yr = fn(F.linear(torch.cat((x, sign), 1), w)); yr.backward(g)
+    for a, r, name in zip(got, (yr.detach(), x.grad, w.grad), ('y', 'dx', 'dw')):
+        torch.testing.assert_close(a, r, rtol=2e-4, atol=2e-4 * float(r.abs().max().clamp(min=1e-3)), msg=lambda m: name + ' (no bias): ' + m)
+
+
+def test_gru_cell_on_its_two_input_pieces_vs_torch():
+    "train_ops.GruCellS (state [R,128], sign [R,1] held apart; forward on the inference kernel, adjoint without the sign column) against torch.nn.GRUCell"
+    from pdp import native
+    from pdp.nn import train_ops as T
+    for R in (64 * 41 + 7, 128, 33):
+        cell = torch.nn.GRUCell(129, 128).to(DEV)
+        state, h = _leaf(R, 128, seed=21), _leaf(R, 128, seed=22)
+        sign = torch.sign(torch.randn(R, 1, device=DEV))
+        packed = native.GruWeights(cell.weight_ih.data, cell.weight_hh.data, cell.bias_ih.data, cell.bias_hh.data)
+        g = torch.randn(R, 128, device=DEV)
+        hn = T.GruCellS.apply(state, sign, h, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh, packed)
+        hn.backward(g)
+        got = [hn.detach().clone(), state.grad.clone(), h.grad.clone()] + [p_.grad.clone() for p_ in cell.parameters()]
+        state.grad = h.grad = None
+        for p_ in cell.parameters():
+            p_.grad = None
+        hr = cell(torch.cat((state, sign), 1), h)
+        hr.backward(g)
+        ref = [hr.detach(), state.grad, h.grad] + [p_.grad for p_ in cell.parameters()]
+        for a, r, name in zip(got, ref, ('h', 'dstate', 'dh', 'dW_ih', 'dW_hh', 'db_ih', 'db_hh')):
+            torch.testing.assert_close(a, r, rtol=3e-4, atol=3e-4 * float(r.abs().max().clamp(min=1e-3)), msg=lambda m: '%s (R=%d): %s' % (name, R, m))
+
+
 def test_fused_gru_forward_equals_the_two_gemm_form():
     """The 129 -> 128 cell of the training path runs its full 64-row tiles in one launch of the pipelined inference kernel, which also writes
     the gates the adjoint reads (r | z | n | W_hn h + b_hn); rows behind the last full tile take the two-GEMM form.  Same results as that
