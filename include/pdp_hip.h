@@ -286,7 +286,8 @@ int pdp_train_row_spread(pdp_problem *p, int by_variable, const float *rows, con
  * saved [R,4H] = r | z | n | W_hn h + b_hn for the adjoint; scratch [R,6H] */
 int pdp_train_gru(const float *x, const float *h, const float *W_ih, const float *W_hh, const float *b_ih, const float *b_hh, int64_t R, int Kx, int H,
                   float *hnew, float *saved, float *scratch, void *stream);
-/* the same forward for the 129 -> 128 cell (x = [state [R,128] | sign [R]]) in ONE launch of the pipelined inference kernel, which also writes
+/* the same forward for the hidden-128 cells of the shipped models (x = [state [R,dx] | sign [R]], dx = 128: np-nd-np, dx = 2 or 3: p-nd-np) in ONE
+ * launch of the pipelined inference kernel, which also writes
  * saved [R,4H]: no gi / gh round trip through memory.  Weights in the descriptor layout of the inference cell -- transposed, padded; R a multiple of 64 (the caller runs
  * pdp_train_gru on the rows behind the last full tile). */
 int pdp_train_gru_fused(const pdp_gru_desc *d, const float *state, const float *sign, const float *h, int64_t R, float *hnew, float *saved, void *stream);

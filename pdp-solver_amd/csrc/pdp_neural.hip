@@ -1782,7 +1782,7 @@ extern "C" int pdp_train_gru_fused(const pdp_gru_desc *d, const float *state, co
                                    void *stream)
 {
     PDP_REQUIRE(d && state && sign && h && hnew && saved, "NULL argument");
-    PDP_REQUIRE(d->H == 128 && d->dx == 128, "the fused training cell is the 129 -> 128 one");
+    PDP_REQUIRE(d->H == 128 && (d->dx == 128 || (d->dx >= 1 && d->dx <= 3)), "the fused training cells are 129 -> 128 (np-nd-np) and 3 / 4 -> 128 (p-nd-np)");
     PDP_REQUIRE(R >= 0 && R % TM == 0 && R < ((int64_t)1 << 31), "row count must be a multiple of the 64-row tile");
     PDP_REQUIRE(hnew != h, "output must not alias the hidden state");
     if (R == 0) return PDP_OK;
@@ -1794,8 +1794,15 @@ extern "C" int pdp_train_gru_fused(const pdp_gru_desc *d, const float *state, co
     const size_t ldsp = 2 * lds + sizeof(float) * 3 * TM;
     const int full = (int)(R / TM);
     const int grid = full < persistent_grid() ? full : persistent_grid();
-    int s = set_lds((const void *)k_gru_pipe<65, false, true>, ldsp); if (s != PDP_OK) return s;
-    hipLaunchKernelGGL((k_gru_pipe<65, false, true>), dim3(grid), dim3(NTN), ldsp, st, (int)R, state, sign, h, (const float *)nullptr, g, hnew, full, saved);
+    int s;
+    if (g.Kpx == 130) {
+        s = set_lds((const void *)k_gru_pipe<65, false, true>, ldsp); if (s != PDP_OK) return s;
+        hipLaunchKernelGGL((k_gru_pipe<65, false, true>), dim3(grid), dim3(NTN), ldsp, st, (int)R, state, sign, h, (const float *)nullptr, g, hnew, full, saved);
+    } else {
+        PDP_REQUIRE(g.Kpx == 4, "narrow cell: 3 or 4 input columns");
+        s = set_lds((const void *)k_gru_pipe<2, false, true>, ldsp); if (s != PDP_OK) return s;
+        hipLaunchKernelGGL((k_gru_pipe<2, false, true>), dim3(grid), dim3(NTN), ldsp, st, (int)R, state, sign, h, (const float *)nullptr, g, hnew, full, saved);
+    }
     PDP_LAUNCH_CHECK();
     return PDP_OK;
 }

@@ -53,7 +53,8 @@ class NeuralDecimator(nn.Module):
             # hidden 128 without graph features: the cell runs on its two input pieces (train_ops.GruCellS: forward = one launch of the
             # pipelined inference kernel, no [E, 129] concatenation); PDP_TRAIN_CAT=1: the concatenated form of rounds 1-3
             import os
-            fused = gf is None and self._hidden_dimension == 128 and variable_state.size(1) == 128 and function_state.size(1) == 128
+            ok = lambda t_: t_.size(1) == 128 or 2 <= t_.size(1) <= 3                # np-nd-np's [E, 128] messages, p-nd-np's surveys [E, 3] / [E, 2]
+            fused = gf is None and self._hidden_dimension == 128 and ok(variable_state) and ok(function_state)
             if fused and os.environ.get('PDP_TRAIN_CAT', '0') != '1':
                 nv = T.GruCellS.apply(variable_state, sign, init_state[0], cv.weight_ih, cv.weight_hh, cv.bias_ih, cv.bias_hh, self._weights('v', cv))
                 nf = T.GruCellS.apply(function_state, sign, init_state[1], cf.weight_ih, cf.weight_hh, cf.bias_ih, cf.bias_hh, self._weights('f', cf))

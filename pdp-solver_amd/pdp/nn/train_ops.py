@@ -206,8 +206,8 @@ class GruCell(torch.autograd.Function):
 
 
 class GruCellS(torch.autograd.Function):
-    """The 129 -> 128 cell of the neural decimator on its two input pieces ``state`` [R, 128] and ``sign`` [R, 1] (torch.nn.GRUCell on their
-    concatenation): the forward is one launch of the pipelined inference kernel on the full 64-row tiles (the ragged tail takes the
+    """A hidden-128 cell of the neural decimator on its two input pieces ``state`` [R, Ks] (Ks = 128: np-nd-np; 3 / 2: p-nd-np's surveys) and
+    ``sign`` [R, 1] (torch.nn.GRUCell on their concatenation): the forward is one launch of the pipelined inference kernel on the full 64-row tiles (the ragged tail takes the
     two-GEMM form on a concatenated copy of its <= 63 rows), the adjoint multiplies by W_ih[:, :128] only (the sign has no gradient) and gets
     the last column of dW_ih from the pointwise pass.  ``packed``: the weights as native.GruWeights."""
 

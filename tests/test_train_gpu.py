@@ -95,12 +95,12 @@ def test_linear_on_a_separate_sign_column_vs_torch(R, K, N, act):
 
 
 def test_gru_cell_on_its_two_input_pieces_vs_torch():
-    "train_ops.GruCellS (state [R,128], sign [R,1] held apart; forward on the inference kernel, adjoint without the sign column) against torch.nn.GRUCell"
+    "train_ops.GruCellS (state [R,Ks], sign [R,1] held apart; forward on the inference kernel, adjoint without the sign column) against torch.nn.GRUCell"
     from pdp import native
     from pdp.nn import train_ops as T
-    for R in (64 * 41 + 7, 128, 33):
-        cell = torch.nn.GRUCell(129, 128).to(DEV)
-        state, h = _leaf(R, 128, seed=21), _leaf(R, 128, seed=22)
+    for R, Ks in ((64 * 41 + 7, 128), (128, 128), (33, 128), (64 * 9 + 5, 3), (64 * 3, 2)):      # Ks = 3 / 2: p-nd-np's survey columns
+        cell = torch.nn.GRUCell(Ks + 1, 128).to(DEV)
+        state, h = _leaf(R, Ks, seed=21), _leaf(R, 128, seed=22)
         sign = torch.sign(torch.randn(R, 1, device=DEV))
         packed = native.GruWeights(cell.weight_ih.data, cell.weight_hh.data, cell.bias_ih.data, cell.bias_hh.data)
         g = torch.randn(R, 128, device=DEV)
