@@ -154,6 +154,58 @@ def test_fused_gru_forward_equals_the_two_gemm_form():
             torch.testing.assert_close(a, r, rtol=3e-4, atol=3e-4 * float(r.abs().max().clamp(min=1e-3)), msg=lambda m: '%s (R=%d): %s' % (name, R, m))
 
 
+def _rel_to_max(a, r):
+    return float((a.double() - r).abs().max() / r.abs().max().clamp(min=1e-30))
+
+
+@pytest.mark.parametrize('R,K,N,act', [(1000, 33, 100, 'logsigmoid'), (4097, 51, 128, 'relu'), (8200, 129, 100, 'logsigmoid'), (6000, 129, 384, 'none'),
+                                       (100000, 129, 100, 'logsigmoid')])
+def test_linear_and_its_adjoint_against_float64(R, K, N, act):
+    """The tolerance of the fp32-vs-fp32 comparisons above (rtol 2e-4) says little about near-cancelling sums.  Against the same operator in
+    float64 every output -- y, dX, dW (a sum over all R rows), db -- is within 4e-6 of the tensor's largest magnitude, with and without the
+    separate sign column (tools/train_accuracy.py prints the figures next to torch's own fp32 error, which is 2-9 x larger on dW)."""
+    from pdp.nn import train_ops as T
+    fn = {'logsigmoid': F.logsigmoid, 'relu': torch.relu, 'none': lambda z: z}[act]
+    g = torch.randn(R, N, device=DEV)
+    x, w, b = _leaf(R, K, seed=1), _leaf(N, K, seed=2), _leaf(N, seed=3)
+    y = T.LinearAct.apply(x, w, b, act); y.backward(g)
+    xd, wd, bd = [t_.detach().double().requires_grad_(True) for t_ in (x, w, b)]
+    yr = fn(F.linear(xd, wd, bd)); yr.backward(g.double())
+    for a, r, name in zip((y.detach(), x.grad, w.grad, b.grad), (yr.detach(), xd.grad, wd.grad, bd.grad), ('y', 'dx', 'dw', 'db')):
+        assert _rel_to_max(a, r) < 4e-6, (name, _rel_to_max(a, r))
+    if act != 'relu':
+        x, w, b = _leaf(R, K, seed=4), _leaf(N, K + 1, seed=5), _leaf(N, seed=6)
+        sign = torch.sign(torch.randn(R, 1, device=DEV))
+        y = T.linear_sign(x, sign, w, b, act); y.backward(g)
+        xd, wd, bd = [t_.detach().double().requires_grad_(True) for t_ in (x, w, b)]
+        yr = fn(F.linear(torch.cat((xd, sign.double()), 1), wd, bd)); yr.backward(g.double())
+        for a, r, name in zip((y.detach(), x.grad, w.grad, b.grad), (yr.detach(), xd.grad, wd.grad, bd.grad), ('y', 'dx', 'dw', 'db')):
+            assert _rel_to_max(a, r) < 4e-6, (name + ' (sign column apart)', _rel_to_max(a, r))
+
+
+@pytest.mark.parametrize('R,Ks', [(64 * 41 + 7, 128), (64 * 9 + 5, 3), (50000, 128)])
+def test_gru_cell_and_its_adjoint_against_float64(R, Ks):
+    "the cell on its two input pieces (forward: the pipelined inference kernel) against torch.nn.GRUCell in float64: everything within 4e-6 of the tensor's largest magnitude"
+    import copy
+    from pdp import native
+    from pdp.nn import train_ops as T
+    cell = torch.nn.GRUCell(Ks + 1, 128).to(DEV)
+    state, h = _leaf(R, Ks, seed=21), _leaf(R, 128, seed=22)
+    sign = torch.sign(torch.randn(R, 1, device=DEV))
+    packed = native.GruWeights(cell.weight_ih.data, cell.weight_hh.data, cell.bias_ih.data, cell.bias_hh.data)
+    g = torch.randn(R, 128, device=DEV)
+    hn = T.GruCellS.apply(state, sign, h, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh, packed); hn.backward(g)
+    got = [hn.detach(), state.grad, h.grad] + [p_.grad for p_ in cell.parameters()]
+    cd = copy.deepcopy(cell).double()
+    for p_ in cd.parameters():
+        p_.grad = None
+    sd, hd = state.detach().double().requires_grad_(True), h.detach().double().requires_grad_(True)
+    hr = cd(torch.cat((sd, sign.double()), 1), hd); hr.backward(g.double())
+    ref = [hr.detach(), sd.grad, hd.grad] + [p_.grad for p_ in cd.parameters()]
+    for a, r, name in zip(got, ref, ('h', 'dstate', 'dh', 'dW_ih', 'dW_hh', 'db_ih', 'db_hh')):
+        assert _rel_to_max(a, r) < 4e-6, (name, _rel_to_max(a, r))
+
+
 @pytest.mark.parametrize('by_variable,include_self', [(True, False), (False, False), (True, True)])
 def test_row_aggregate_forward_and_adjoint_vs_torch(oracle, by_variable, include_self):
     from pdp.nn import train_ops as T
