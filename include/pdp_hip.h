@@ -147,6 +147,18 @@ int pdp_energy_diff(pdp_problem *p, const float *assignment, float *delta, void 
  * dealt to several GPUs, pdp/parallel.py) the caller states where the part starts: the draws are then those of the whole forward.
  * Replication 1 only.  Default 0, 0. */
 int pdp_problem_set_rng_base(pdp_problem *p, uint32_t first_variable, uint32_t first_instance);
+/* One COUPLED forward solved by several processes (one per GPU), each holding a contiguous part of the batch (pdp_problem_set_rng_base says
+ * where).  The reference couples the instances of a forward through batch-wide reductions -- the first sweep with a NaN survey (it stops the
+ * decimation of the whole batch), the exact zero inside util.sparse_max / sparse_argmax's x - min(x) + 1, the executed sweeps, and the same
+ * zero in every Walk-SAT step.  The chunked LDS-resident solver (pdp_sp_solve) and the persistent Walk-SAT
+ * (pdp_local_search) take these from a few control words per chunk; with a callback set they hand those words to it between the launches and
+ * continue with what it returns: fn(user, mins, n_mins, maxs, n_maxs, ors, n_ors) replaces every element by its minimum / maximum /
+ * bit-wise OR over all parts, in place (host memory), and returns 0.  Every part calls it the same number of times (the control flow depends
+ * on the merged words only).  Restrictions: SP triple, no batch replication, every instance of a part fits the LDS-resident solver; a failed
+ * speculation cannot fall back to the step-wise loop across processes: PDP_ERR_SPECULATION / PDP_ERR_UNSUPPORTED go to the caller.
+ * NULL removes the callback. */
+typedef int (*pdp_exchange_fn)(void *user, uint32_t *mins, int n_mins, uint32_t *maxs, int n_maxs, uint32_t *ors, int n_ors);
+int pdp_problem_set_exchange(pdp_problem *p, pdp_exchange_fn fn, void *user);
 /* replaces: IdentityPredictor.forward(last_call=True) random fill (pdp_predict.py:121-126).
  * PDP_RNG_STREAM: values [n_active] are consumed in variable order; PDP_RNG_PHILOX: in-kernel. */
 int pdp_random_fill(pdp_problem *p, int rng_mode, const float *values, uint64_t seed, void *stream);

@@ -138,6 +138,11 @@ struct pdp_problem {
     hipStream_t res_side_stream; hipEvent_t res_side_ev[2];   // the big instances' launches overlap the LDS-resident kernel on a stream of their own
     float *nws[4]; size_t nws_floats[4];             // neural workspaces (grow on demand)
     uint32_t rng_var_base, rng_inst_base;            // pdp_problem_set_rng_base: position of this batch inside the forward it is a part of
+    // pdp_problem_set_exchange: the batch is a part of a COUPLED forward solved by several processes -- the reductions the reference takes over
+    // the whole batch are completed across the parts through this host callback (element-wise min / max / or over all parts, in place)
+    int (*exchange)(void *user, uint32_t *mins, int n_mins, uint32_t *maxs, int n_maxs, uint32_t *ors, int n_ors);
+    void *exchange_user;
+    uint32_t *exchange_host; size_t exchange_host_words;   // pinned staging block of the callback's arrays
 };
 
 struct pdp_decimator {
@@ -472,6 +477,7 @@ uint32_t pdp_spin_limit();                     // PDP_TEAM_SPIN_LIMIT (polls) or
 struct pdp_problem;
 int pdp_simplify_lds(pdp_problem *p, hipStream_t st);      // pdp_solve.hip: simplify() with the instances in LDS; 0 if the batch does not qualify
 int pdp_device_cus();                         // CUs of the current device (workgroups that are certainly resident together)
+int pdp_exchange_call(pdp_problem *p, const uint32_t *mins, int n_mins, const uint32_t *maxs, int n_maxs, const uint32_t *ors, int n_ors, uint32_t **out);   // pdp_problem.hip
 int pdp_edge_rows(const pdp_problem *p);     // workgroups per instance of the flat per-edge kernels (gridDim.y): 1 unless an instance is big
 int pdp_team_plan(pdp_problem *p, int count, bool wide, int threads, TeamLaunch *out, hipStream_t st);
 template <class B>

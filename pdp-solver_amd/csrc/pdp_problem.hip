@@ -320,6 +320,7 @@ extern "C" int pdp_problem_destroy(pdp_problem *p)
     if (p->flags_host) (void)hipHostFree(p->flags_host);
     if (p->solve_blob) pdp_dev_free(p->solve_blob);
     if (p->solve_host) (void)hipHostFree(p->solve_host);
+    if (p->exchange_host) (void)hipHostFree(p->exchange_host);
     if (p->solve_extra_v) pdp_dev_free(p->solve_extra_v);
     if (p->solve_rec) pdp_dev_free(p->solve_rec);
     void *res[] = {p->res_stat_off, p->res_stat, p->res_dyn[0], p->res_dyn[1], p->res_prev_slots, p->res_ctl, p->res_fit_list, p->res_big_list, p->res_is_big, p->res_big_snap};
@@ -461,6 +462,33 @@ extern "C" int pdp_problem_set_rng_base(pdp_problem *p, uint32_t first_variable,
     PDP_REQUIRE(p, "NULL problem");
     PDP_REQUIRE(p->R == 1 || (first_variable == 0u && first_instance == 0u), "a part of a forward cannot be replicated (replica r of variable v has index v + r * V)");
     p->rng_var_base = first_variable; p->rng_inst_base = first_instance;
+    return PDP_OK;
+}
+
+extern "C" int pdp_problem_set_exchange(pdp_problem *p, int (*fn)(void *, uint32_t *, int, uint32_t *, int, uint32_t *, int), void *user)
+{
+    PDP_REQUIRE(p, "NULL problem");
+    PDP_REQUIRE(!fn || p->R == 1, "a coupled forward over several processes cannot be replicated");
+    p->exchange = fn; p->exchange_user = user;
+    return PDP_OK;
+}
+// the staging block of the exchange: mins | maxs | ors in one pinned allocation
+int pdp_exchange_call(pdp_problem *p, const uint32_t *mins, int n_mins, const uint32_t *maxs, int n_maxs, const uint32_t *ors, int n_ors, uint32_t **out)
+{
+    const size_t words = (size_t)n_mins + n_maxs + n_ors;
+    if (p->exchange_host_words < words) {
+        if (p->exchange_host) (void)hipHostFree(p->exchange_host);
+        p->exchange_host = nullptr; p->exchange_host_words = 0;
+        PDP_HIP_CHECK(hipHostMalloc((void **)&p->exchange_host, (words + 64) * 4));
+        p->exchange_host_words = words + 64;
+    }
+    uint32_t *h = p->exchange_host;
+    for (int i = 0; i < n_mins; ++i) h[i] = mins[i];
+    for (int i = 0; i < n_maxs; ++i) h[n_mins + i] = maxs[i];
+    for (int i = 0; i < n_ors; ++i) h[n_mins + n_maxs + i] = ors[i];
+    const int rc = p->exchange(p->exchange_user, h, n_mins, h + n_mins, n_maxs, h + n_mins + n_maxs, n_ors);
+    if (rc != 0) { pdp_set_error("the exchange callback of a coupled multi-process forward failed"); return PDP_ERR_INVALID; }
+    *out = h;
     return PDP_OK;
 }
 

@@ -2383,8 +2383,11 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     const int big_copy_wgs = nbig >= 256 ? 1 : (256 / (nbig > 0 ? nbig : 1) < 32 ? 256 / (nbig > 0 ? nbig : 1) : 32);      // workgroups per instance of the save / restore copies
     if (const char *env = getenv("PDP_DEBUG_SKIP")) sp.debug_skip = atoi(env);
     int done = 0;
+    const bool xch = p->exchange != nullptr;              // (pdp_sp_solve admits the hook only for batches this loop takes whole)
+    bool x_poisoned = false, x_replay = false, x_stop = false;        // host mirrors of call->poisoned_all / ctl->do_replay / call->stop (all derived from merged words)
     for (int k = 0; k < nchunks; ++k) {
         const int c = (T - done) < C ? (T - done) : C;
+        x_replay = false;
         sp.T = c; sp.chunk_start = done; sp.final_chunk = (done + c >= T) ? 1 : 0;
         sp.has_prev = (k == 0) ? a->decimator->has_prev : 1;
         sp.has_edge_mask = (k == 0) ? p->has_edge_mask : 1;
@@ -2433,6 +2436,39 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
             if (timed) PDP_HIP_CHECK(hipEventRecord(p->res_events[4 * k + 2 * pass + 1], st));
             if (nbig && pass == 1) { PDP_HIP_CHECK(hipEventRecord(p->res_side_ev[1], side)); PDP_HIP_CHECK(hipStreamWaitEvent(st, p->res_side_ev[1], 0)); }
             if (nbig && pass == 0) { PDP_HIP_CHECK(hipEventRecord(p->res_side_ev[1], side)); PDP_HIP_CHECK(hipStreamWaitEvent(st, p->res_side_ev[1], 0)); }   // join: pass 1 of the big instances
+            if (xch && !x_stop && (pass == 0 || x_replay)) {
+                // A coupled forward spread over several processes: what the reference reduces over the WHOLE batch -- the first NaN sweep, the
+                // exact-zero record of the batch-global minimum, the executed sweeps -- is completed across the parts before the device-side
+                // control of this chunk reads it (pass 0), and again after a poison replay (the replayed instances run on).
+                SolveCtl hc;
+                PDP_HIP_CHECK(hipMemcpyAsync(&hc, ctl + k, sizeof(hc), hipMemcpyDeviceToHost, st));
+                std::vector<uint32_t> bits(2 * (size_t)c);
+                if (pass == 0) {
+                    PDP_HIP_CHECK(hipMemcpyAsync(bits.data(), sp.spec_used, (size_t)c * 4, hipMemcpyDeviceToHost, st));
+                    PDP_HIP_CHECK(hipMemcpyAsync(bits.data() + c, sp.spec_zero, (size_t)c * 4, hipMemcpyDeviceToHost, st));
+                }
+                PDP_HIP_CHECK(hipStreamSynchronize(st));
+                if (pass == 0 || x_replay) {
+                    const uint32_t mins[2] = {hc.nan_iter, hc.perm_zero}, maxs[1] = {hc.iters_run};
+                    std::vector<uint32_t> ors(1 + (pass == 0 ? 2 * (size_t)c : 0));
+                    ors[0] = hc.violation;
+                    if (pass == 0) for (int t = 0; t < 2 * c; ++t) ors[1 + t] = bits[t];
+                    uint32_t *m = nullptr;
+                    { const int st_ = pdp_exchange_call(p, mins, pass == 0 ? 2 : 0, maxs, 1, ors.data(), (int)ors.size(), &m); if (st_ != PDP_OK) return st_; }
+                    const uint32_t *mm = m, *mx = m + (pass == 0 ? 2 : 0), *mo = mx + 1;
+                    if (pass == 0) { hc.nan_iter = mm[0]; hc.perm_zero = mm[1]; }
+                    hc.iters_run = mx[0]; hc.violation = mo[0];
+                    // (only the four merged words go back: the kernels own the rest of the block)
+                    PDP_HIP_CHECK(hipMemcpyAsync(&ctl[k].nan_iter, &hc.nan_iter, 4 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+                    if (pass == 0) {
+                        PDP_HIP_CHECK(hipMemcpyAsync((void *)sp.spec_used, mo + 1, (size_t)c * 4, hipMemcpyHostToDevice, st));
+                        PDP_HIP_CHECK(hipMemcpyAsync((void *)sp.spec_zero, mo + 1 + c, (size_t)c * 4, hipMemcpyHostToDevice, st));
+                    }
+                    PDP_HIP_CHECK(hipStreamSynchronize(st));          // (the staging block is reused by the next exchange)
+                    if (pass == 0) { x_replay = !x_poisoned && hc.nan_iter < (uint32_t)c; if (x_replay) x_poisoned = true; }
+                    if (pass == 1 || !x_replay) { if (hc.iters_run < (uint32_t)c) x_stop = true; }
+                }
+            }
             if (pass == 0) {
                 hipLaunchKernelGGL(k_solve_post, dim3(1), dim3(1), 0, st, ctl + k, call, c, (int)a->isolate_instances);
                 hipLaunchKernelGGL(k_replay_list, dim3((p->B + 255) / 256), dim3(256), 0, st, p->B, (const int32_t *)last_event, ctl + k, (const SolveCall *)call, replay_list,
@@ -2452,7 +2488,14 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     PDP_HIP_CHECK(hipStreamSynchronize(st));
     side_join.on = false;                                  // (every side-stream launch was joined into the main stream, which is drained)
     const SolveCtl *hctl = (const SolveCtl *)p->solve_host;
-    const SolveCall *hcall = (const SolveCall *)(hctl + nchunks);
+    SolveCall *hcall = (SolveCall *)(hctl + nchunks);
+    if (xch) {
+        // the parts agree on the outcome: a failed speculation anywhere (the ghost check is local) fails the forward everywhere
+        const uint32_t maxs[1] = {hcall->total_iters}, ors[2] = {hcall->fail, hcall->force_seen};
+        uint32_t *m = nullptr;
+        { const int st_ = pdp_exchange_call(p, nullptr, 0, maxs, 1, ors, 2, &m); if (st_ != PDP_OK) return st_; }
+        hcall->total_iters = m[0]; hcall->fail = m[1]; hcall->force_seen = m[2];
+    }
     const bool debug = getenv("PDP_DEBUG") != nullptr;
     int launches = 0, replays = 0;
     float solve_ms = 0.0f, replay_ms = 0.0f;
@@ -2568,6 +2611,17 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
     PDP_REQUIRE(p && a && p->av, "NULL argument / state not bound");
     PDP_REQUIRE(a->model == PDP_MODEL_SP || a->model == PDP_MODEL_REINFORCE, "persistent solve: SP and Reinforce triples only");
     PDP_REQUIRE(a->q && a->fs && a->active_mask && a->decimator, "NULL state array");
+    if (p->exchange) {
+        // one coupled forward over several processes (pdp_problem_set_exchange): the chunked LDS-resident loop completes its batch-wide
+        // reductions across the parts; the other routes (lock-step launch, HBM-resident instances, step-wise fallback) are single-process
+        PDP_REQUIRE(a->model == PDP_MODEL_SP && p->R == 1 && !a->isolate_instances, "coupled multi-process forward: the SP triple without batch replication");
+        { const int st_ = resident_prepare(p); if (st_ != PDP_OK) return st_; }
+        if (p->res_nbig > 0 || !p->fn_edges_identity) {
+            pdp_set_error("coupled multi-process forward: every instance of the part must fit the LDS-resident solver");
+            return PDP_ERR_UNSUPPORTED;
+        }
+        return sp_solve_speculative(p, a, stream);          // PDP_ERR_SPECULATION: the caller cannot rerun step-wise across processes
+    }
     if (p->R > 1 && !a->replicas_identical) {
         // replicas that start from different states couple through the termination rule: lock-step, or not at all
         a->iterations_run_host = 0; a->used_lds_host = 0; a->kernel_launches_host = 0; a->replay_launches_host = 0; a->hbm_instances_host = 0;
@@ -2606,7 +2660,8 @@ static int sp_solve_speculative(pdp_problem *p, pdp_solve_args *a, void *stream)
     // iteration for 10-19 of 20 random instances) -- but its batch-global minima are its own: the HBM-resident kernel computes them
     // (sp.exact), nothing is speculated, recorded or replayed, and the whole loop is one launch (a team of workgroups when the instance is big).
     // (the same holds for the R identical replicas of one instance: every replica's own minimum is the batch's)
-    const bool exact = (B == 1 || (p->B0 == 1 && a->replicas_identical)) && !a->isolate_instances && getenv("PDP_SOLVE_NO_EXACT") == nullptr;
+    const bool exact = (B == 1 || (p->B0 == 1 && a->replicas_identical)) && !a->isolate_instances && getenv("PDP_SOLVE_NO_EXACT") == nullptr &&
+                       !p->exchange;                       // (a part of one instance is not a batch of one)
     int C = 12;
     if (const char *env = getenv("PDP_SOLVE_CHUNK")) { const int v = atoi(env); if (v > 0) C = v; }
     if (C > T) C = T;
@@ -2632,6 +2687,7 @@ static int sp_solve_speculative(pdp_problem *p, pdp_solve_args *a, void *stream)
         const int rc = sp_solve_resident(p, a, st, force_r, lds_r, nt_r, C);
         if (rc != PDP_RETRY_WITH_FORCE) return rc;
     }
+    if (p->exchange) { pdp_set_error("coupled multi-process forward: the part did not take the LDS-resident loop"); return PDP_ERR_UNSUPPORTED; }
     a->hbm_instances_host = p->B;
     // ---- instances too large for the LDS: HBM-resident kernel, host-driven chunk loop -----------------------------------
 

@@ -864,7 +864,17 @@ static int local_search_persistent(pdp_problem *p, const float *pred, int iterat
         for (int b = 0; b < p->B; ++b) first_finish = fs_host[b] < first_finish ? fs_host[b] : first_finish;
         free(fs_host);
     }
-    for (int t = 0; t < stop && t < first_finish && ok; ++t)
+    int stop_all = stop;
+    if (p->exchange && status == PDP_OK) {
+        // a coupled forward over several processes: the record of the batch-global minimum is completed across the parts (an exact zero in
+        // ANY part serves every part; the first finished instance of the whole batch; the step at which the whole batch was solved)
+        const uint32_t mins[1] = {(uint32_t)first_finish}, maxs[1] = {(uint32_t)stop};
+        uint32_t *m = nullptr;
+        { const int st_ = pdp_exchange_call(p, mins, 1, maxs, 1, host, (int)(2 * bw), &m); if (st_ != PDP_OK) return st_; }
+        first_finish = (int)m[0]; stop_all = (int)m[1];
+        for (size_t i = 0; i < 2 * (size_t)bw; ++i) host[i] = m[2 + i];
+    }
+    for (int t = 0; t < stop_all && t < first_finish && ok; ++t)
         if (((host[t >> 5] >> (t & 31)) & 1u) && !((host[bw + (t >> 5)] >> (t & 31)) & 1u)) ok = false;
     if (status == PDP_OK && nbig) {
         // the big instances ran as teams of workgroups: did one of their barriers give up (workgroups not resident together)?
@@ -877,6 +887,11 @@ static int local_search_persistent(pdp_problem *p, const float *pred, int iterat
         }
     }
     if (status != PDP_OK) return status;
+    if (!ok && p->exchange) {
+        pdp_set_error("Walk-SAT of a coupled multi-process forward: a step's batch-global minimum was not 0 in any part; the strict loop that "
+                      "computes it is single-process -- run the forward on one GPU");
+        return PDP_ERR_UNSUPPORTED;
+    }
     if (!ok) return PDP_OK;          // caller runs the strict loop on the untouched inputs
     if (steps_host) *steps_host = stop;
     *done = 1;
@@ -890,6 +905,7 @@ extern "C" int pdp_local_search(pdp_problem *p, const float *pred, int iteration
     PDP_REQUIRE(p && p->av && pred && out, "NULL argument / state not bound");
     PDP_REQUIRE(rng_mode == PDP_RNG_PHILOX || iterations == 0 || (var_rand && coin_rand), "stream mode needs the drawn values");
     hipStream_t st = ST(stream);
+    PDP_REQUIRE(!p->exchange || (!getenv("PDP_WALKSAT_STRICT") && p->R == 1), "coupled multi-process forward: the persistent Walk-SAT only");
     if (!getenv("PDP_WALKSAT_STRICT")) {
         int done = 0;
         const int rc = local_search_persistent(p, pred, iterations, epsilon, rng_mode, var_rand, coin_rand, seed, out, steps_host, st, &done);

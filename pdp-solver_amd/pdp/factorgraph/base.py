@@ -324,14 +324,23 @@ class FactorGraphTrainerBase(object):
                         model._predictor._rng = 'philox'
         # --isolated removes the couplings inside a forward: there the unit that may move is the instance, and every segment is cut into one
         # contiguous instance range per rank (a part; its Philox counters start where the part starts, SATProblem / pdp_problem_set_rng_base)
-        split = world > 1 and int(batch_replication) == 1 and all(getattr(m, '_isolated', False) for m in self._model_list)
+        isolated = all(getattr(m, '_isolated', False) for m in self._model_list)
+        coupled = bool(self._config.get('split_forward')) and not isolated
+        if coupled and world > 1 and int(batch_replication) != 1:
+            raise native.NativeError("--split-forward: without batch replication (replica r of variable v has index v + r V: no contiguous parts)")
+        split = world > 1 and int(batch_replication) == 1 and (isolated or coupled)
         if split and self._config.get('verbose'):
-            self._logger.info('isolated instances: every segment is cut into %d instance ranges, one per rank' % world)
+            self._logger.info('%s: every segment is cut into %d instance ranges, one per rank'
+                              % ('isolated instances' if isolated else 'coupled forwards spread over the ranks (--split-forward)', world))
+        for model in self._model_list:
+            if hasattr(model, '_exchange'):
+                # --split-forward: the reference's batch-wide reductions are completed across the parts (pdp/parallel.py: make_exchange)
+                model._exchange = parallel.make_exchange(self._device) if (split and coupled) else None
         test_loader = FactorGraphDataset.get_loader(
             input_file=test_list, limit=self._config['test_batch_limit'], hidden_dim=self._config['hidden_dim'],
             batch_size=self._config['batch_size'], shuffle=False, num_workers=0,
             max_cache_size=self._config.get('max_cache_size', 100000), batch_replication=batch_replication,
-            shard=(rank, world) if world > 1 else None, split_instances=split)
+            shard=(rank, world) if world > 1 else None, split_instances=split, split_coupled=split and coupled)
         if import_path_base is not None:
             self._load(import_path_base)
         start_time = time.time()

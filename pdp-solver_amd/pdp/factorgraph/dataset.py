@@ -174,7 +174,7 @@ class FactorGraphDataset(object):
     ``generator.generate()`` instance and the data set has ``epoch_size`` items."""
 
     def __init__(self, input_file, limit, hidden_dim, max_cache_size=100000, batch_replication=1, shard=None, generator=None, epoch_size=0,
-                 split_instances=False):
+                 split_instances=False, split_coupled=False):
         import os
         self._input_file = input_file
         self._dimacs = None
@@ -193,6 +193,8 @@ class FactorGraphDataset(object):
         self._shard = tuple(shard) if shard is not None and shard[1] > 1 and generator is None else None
         # isolated instances (no coupling inside a segment): every segment is cut into one contiguous instance range per rank instead
         self._split_instances = bool(split_instances) and self._shard is not None and int(batch_replication) == 1
+        # the parts stay coupled (--split-forward): every rank takes part in the exchanges of every forward, so every segment needs an instance per rank
+        self._split_coupled = bool(split_coupled) and self._split_instances
         self.batch_index = 0          # global index of the loader batch handed out last
         self._limit = limit
         self._hidden_dim = hidden_dim
@@ -270,6 +272,9 @@ class FactorGraphDataset(object):
                 if self._split_instances:
                     out, ids, parts = SegmentList(), [], []
                     for s, seg in enumerate(segments):
+                        if self._split_coupled and len(seg) < world:
+                            raise ValueError("--split-forward: segment %d of loader batch %d has %d instances for %d ranks (every rank takes part in "
+                                             "every forward): use fewer ranks, or --isolated" % (s, j, len(seg), world))
                         lo, hi = parallel.shard_bounds([edges[k] for k in seg], world)[rank]
                         if hi > lo:
                             out.append(collate_segment([get(idx[k]) for k in seg[lo:hi]]))
@@ -292,11 +297,11 @@ class FactorGraphDataset(object):
 
     @staticmethod
     def get_loader(input_file, limit, hidden_dim, batch_size, shuffle=False, num_workers=0, max_cache_size=100000,
-                   use_cuda=True, generator=None, epoch_size=0, batch_replication=1, shard=None, split_instances=False):
+                   use_cuda=True, generator=None, epoch_size=0, batch_replication=1, shard=None, split_instances=False, split_coupled=False):
         """Signature-compatible constructor (reference: dataset.py:189-211); returns an iterable of
         reference-shaped 7-tuples of per-segment lists."""
         ds = FactorGraphDataset(input_file, limit, hidden_dim, max_cache_size, batch_replication, shard=shard, generator=generator, epoch_size=epoch_size,
-                                split_instances=split_instances)
+                                split_instances=split_instances, split_coupled=split_coupled)
 
         class _Loader(object):
             dataset = ds

@@ -27,7 +27,7 @@ MODEL_SP, MODEL_WALKSAT, MODEL_REINFORCE = 0, 1, 2
 
 EXPORTED_SYMBOLS = [
     'pdp_abi_version', 'pdp_last_error', 'pdp_device_count', 'pdp_problem_create', 'pdp_problem_destroy',
-    'pdp_problem_dims', 'pdp_problem_set_rng_base', 'pdp_problem_export_graph', 'pdp_problem_bind_state', 'pdp_simplify', 'pdp_set_variables',
+    'pdp_problem_dims', 'pdp_problem_set_rng_base', 'pdp_problem_set_exchange', 'pdp_problem_export_graph', 'pdp_problem_bind_state', 'pdp_simplify', 'pdp_set_variables',
     'pdp_refresh_edge_mask', 'pdp_smooth_max', 'pdp_instance_max', 'pdp_instance_argmax', 'pdp_sp_propagate', 'pdp_sp_adaptors', 'pdp_sp_propagate_adapted',
     'pdp_survey_score', 'pdp_cnf_eval', 'pdp_sat_loss', 'pdp_update_solution', 'pdp_check_termination', 'pdp_decimator_create',
     'pdp_decimator_destroy', 'pdp_decimator_reset', 'pdp_sequential_decimate', 'pdp_sequential_decimate_gate',
@@ -114,6 +114,9 @@ def ptr(t, dtype=None, numel=None, name='tensor'):
     if numel is not None and t.numel() != numel:
         raise NativeError("%s must have %d elements, got %d" % (name, numel, t.numel()))
     return C.c_void_p(t.data_ptr())
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32), C.c_int)
 
 
 class SolveArgs(C.Structure):
@@ -396,6 +399,28 @@ class Problem(object):
     def set_rng_base(self, first_variable, first_instance):
         """this batch is a contiguous part of a larger forward: the Philox draws are counted from there (include/pdp_hip.h)"""
         check(lib().pdp_problem_set_rng_base(self._h, C.c_uint32(int(first_variable)), C.c_uint32(int(first_instance))))
+
+    def set_exchange(self, fn):
+        """``fn(mins, maxs, ors)``: three numpy uint32 arrays to be replaced, in place, by their element-wise minimum / maximum / bit-wise OR
+        over all parts of a coupled forward solved by several processes (include/pdp_hip.h: pdp_problem_set_exchange); None removes it."""
+        if fn is None:
+            self._exchange_cb = None
+            check(lib().pdp_problem_set_exchange(self._h, None, None))
+            return
+        import numpy as np
+
+        def trampoline(user, mins, n_mins, maxs, n_maxs, ors, n_ors):
+            try:
+                view = lambda ptr, n: np.ctypeslib.as_array(ptr, shape=(n,)) if n > 0 else np.zeros(0, np.uint32)
+                fn(view(mins, n_mins), view(maxs, n_maxs), view(ors, n_ors))
+                return 0
+            except Exception:                      # an exception must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._exchange_cb = EXCHANGE_FN(trampoline)          # (kept alive as long as the problem uses it)
+        check(lib().pdp_problem_set_exchange(self._h, self._exchange_cb, None))
 
     def random_fill(self, values=None, seed=0):
         mode = RNG_STREAM if values is not None else RNG_PHILOX

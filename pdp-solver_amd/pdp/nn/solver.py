@@ -208,6 +208,7 @@ class PropagatorDecimatorSolverBase(nn.Module):
         self._rng = rng                  # 'torch': reference-compatible CPU generator stream, 'philox': on device
         self._seed = seed
         self._persistent = persistent    # allow the one-launch persistent loop when the plug-ins permit it
+        self._exchange = None            # callable: this process solves a PART of every forward, the batch-wide reductions are completed by it (pdp/parallel.py)
         self._isolated = False           # True: "fixed" semantics -- instances solved on their own, no batch-wide couplings (persistent loop only)
         self.last_run = {}               # diagnostics of the most recent forward (iterations, path taken ...)
 
@@ -245,6 +246,10 @@ class PropagatorDecimatorSolverBase(nn.Module):
                                  self._device, batch_replication)
         if getattr(self, '_rng_base', (0, 0)) != (0, 0):
             sat_problem._native.set_rng_base(*self._rng_base)
+        if self._exchange is not None:
+            if is_training or batch_replication != 1:
+                raise native.NativeError("a forward spread over several processes: prediction without batch replication only")
+            sat_problem._native.set_exchange(self._exchange)
         self.last_run = dict(path='none', iterations=0, walksat_steps=0)
         # one decision for the whole forward: the differentiable operators (tolerance-level, autograd graph kept) only when training was
         # asked for, gradients are enabled and some parameter wants them; otherwise every plug-in runs its fused inference kernels
@@ -331,10 +336,15 @@ class PropagatorDecimatorSolverBase(nn.Module):
         can = self._can_run_persistent(sat_problem, is_training, check_termination, tuple(init_propagator_state[:2]) + tuple(init_decimator_state[:2]))
         if self._isolated and not can:
             raise native.NativeError("isolated-instance mode runs on the persistent SP loop only (p-d-p, standard termination check)")
+        if self._exchange is not None and not can:
+            raise native.NativeError("a coupled forward spread over several processes runs on the persistent SP loop only (p-d-p, standard termination check)")
         if can:
             out = self._forward_core_persistent(init_propagator_state, init_decimator_state, sat_problem, iteration_num, check_termination)
             if out is not None:
                 return out
+            if self._exchange is not None:
+                raise native.NativeError("a coupled forward spread over several processes met a coupling only the step-wise loop reproduces "
+                                         "(batch-global minimum != 0); that loop is single-process: run this input on one GPU or with --isolated")
         del init_propagator_state, init_decimator_state                # (see forward: this frame lets go of the initial state)
         return self._forward_core_stepwise(box, None, sat_problem, iteration_num, is_training, check_termination)
 

@@ -24,7 +24,10 @@ down to one forward, uses every GPU.  The Philox counters of a part start at the
 v + r V: no contiguous base).  One batch-global quantity is left in Walk-SAT -- the minimum of a step's candidate vector inside
 util.sparse_argmax, 0 whenever any variable of the forward is not in an unsatisfied clause -- a part whose every variable is in an
 unsatisfied clause while the whole segment has one that is not would round one comparison differently; not observed, not excluded.
-The strict semantics could be kept across GPUs with a per-chunk exchange of the poison sweep; that is not built.
+The strict (coupled) semantics across GPUs: ``--split-forward`` cuts the segments the same way and completes the reference's batch-wide
+reductions across the parts -- per 12-sweep chunk of the persistent solver one small all-gather of its control words (first NaN sweep: min,
+exact-zero record of the batch-global minimum: or, executed sweeps: max), one more after a poison replay, one for the Walk-SAT record
+(``make_exchange`` -> ``native.Problem.set_exchange`` -> C ABI ``pdp_problem_set_exchange``); the rows are those of the 1-rank strict run.
 
 ``shard_bounds`` / ``shard_items`` cut ONE batch by instances; only bench.py uses that (its synthetic batch has no loader and is timed
 in ``--isolated``-equivalent weak scaling: every rank generates its own B instances).
@@ -118,6 +121,26 @@ def reduce_test_metrics(error_sums, n_examples, device=None, group=None):
     vals = t.cpu().numpy()
     n = float(vals[-1])
     return (vals[:-1].reshape(sums.shape) / n if n else vals[:-1].reshape(sums.shape)), int(n)
+
+
+def make_exchange(device=None, group=None):
+    """The callback of a coupled forward spread over the ranks (native.Problem.set_exchange): element-wise min / max / bit-wise OR of three
+    small uint32 arrays over all ranks, in one all-gather (RCCL on the device when the group's backend is nccl, gloo on the host)."""
+    def exchange(mins, maxs, ors):
+        n = (mins.size, maxs.size, ors.size)
+        mine = torch.from_numpy(np.concatenate((mins, maxs, ors)).astype(np.int64))
+        on_gpu = dist.get_backend(group) == 'nccl'
+        if on_gpu:
+            mine = mine.to(device)
+        world = dist.get_world_size(group)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        every = torch.stack(parts).cpu().numpy().astype(np.uint32)
+        mins[:] = every[:, :n[0]].min(axis=0) if n[0] else mins
+        maxs[:] = every[:, n[0]:n[0] + n[1]].max(axis=0) if n[1] else maxs
+        if n[2]:
+            ors[:] = np.bitwise_or.reduce(every[:, n[0] + n[1]:], axis=0)
+    return exchange
 
 
 def gather_rows(rows, group=None):

@@ -78,6 +78,9 @@ def main(argv=None):
                         '(global minima, NaN poisoning of the whole batch); p-d-p only, results differ from the reference where those couplings act.  On several ranks (torch.distributed.run) '
                         'the instances of every forward are then spread over all GPUs',
                         action='store_true')
+    parser.add_argument('--split-forward', dest='split_forward', help='On several ranks: spread EVERY forward over all GPUs (one contiguous instance range '
+                        'per rank) and keep the couplings of the reference -- its batch-wide reductions are completed across the ranks chunk by chunk; '
+                        'p-d-p, -b 1; the rows are those of the single-process run', action='store_true')
     args = vars(parser.parse_args(argv))
 
     with open(args['model_config'], 'r') as f:

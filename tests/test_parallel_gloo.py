@@ -193,6 +193,40 @@ def test_isolated_instances_are_dealt_as_instance_ranges():
     assert shifted == _oracle_solve_isolated(items, 0, 0)[2][lo:hi] and shifted != unshifted
 
 
+def _exchange_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    ex = parallel.make_exchange()
+    out = []
+    for rnd in range(3):                                                    # several exchanges in a row, as a chunked forward makes them
+        mins = np.array([100 + 7 * rank + rnd, 0xffffffff if rank else 5], dtype=np.uint32)
+        maxs = np.array([rank * 3 + rnd], dtype=np.uint32)
+        ors = np.array([1 << rank, 0x80000000 if rank == world - 1 else 0, 0], dtype=np.uint32)
+        ex(mins, maxs, ors)
+        out.append((mins.tolist(), maxs.tolist(), ors.tolist()))
+    ex(np.zeros(0, np.uint32), np.array([rank], np.uint32), np.zeros(0, np.uint32))      # empty arrays are fine
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_the_exchange_of_a_coupled_forward_reduces_min_max_or():
+    "parallel.make_exchange: element-wise min / max / bit-wise OR over the ranks, in place, full 32-bit range (what --split-forward hands to the native solver)"
+    for world, port in ((2, 43500), (3, 45500)):
+        ctx = mp.get_context('spawn')
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_exchange_worker, args=(r, world, port + (os.getpid() % 2000), q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        for rank, out in got:
+            for rnd, (mins, maxs, ors) in enumerate(out):
+                assert mins == [100 + rnd, 5] and maxs == [(world - 1) * 3 + rnd] and ors == [(1 << world) - 1, 0x80000000, 0]
+
+
 def _idle_worker(rank, world, port, q):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)

@@ -136,6 +136,41 @@ def test_isolated_run_spreads_one_forward_over_the_ranks(tmp_path):
     assert strict != one
 
 
+def test_split_forward_keeps_the_couplings_across_ranks(tmp_path):
+    """--split-forward: ONE coupled forward (one loader batch, one segment: config 2's shape) is spread over the ranks as contiguous instance
+    ranges, and the reference's batch-wide reductions are completed across them -- per 12-sweep chunk one exchange of the persistent solver's
+    control words (first NaN sweep, exact-zero record, executed sweeps), one more after the poison replay, one for the Walk-SAT record.  The
+    batch holds the golden NaN-producing instances: their NaN at sweep 81 stops the decimation of EVERY instance, also of those on the other
+    ranks, so the rows depend on the exchange -- and two / three ranks write the rows of the single process.  (--isolated gives other rows.)"""
+    from pdp.factorgraph import dataset
+    d = load_golden('headline_n200_poison')
+    n, mcl, T, seed, sweeps = [int(x) for x in d['meta']]
+    items = dataset.random_ksat_items(20, n, 3, m=mcl, seed=96000)
+    for sd in d['seeds'][:8]:
+        items += dataset.random_ksat_items(1, n, 3, m=mcl, seed=int(sd))          # (the NaN instances land in the LAST part)
+    path = tmp_path / 'in.json'
+    path.write_text("\n".join(_lines(items)) + "\n")
+    argv = [os.path.join(REPO, 'config', 'Predict', 'PDP-p-d-p-sp-pytorch.yaml'), str(path), str(T), '-z', '5000', '-s', '11', '-w', '60',
+            '--rng', 'philox', '-v']
+    one, _ = _run(argv, 1, str(tmp_path / 'one.jsonl'), 0)
+    iso, _ = _run(argv + ['--isolated'], 1, str(tmp_path / 'iso.jsonl'), 0)
+    assert len(one) == len(items) and iso != one, "the couplings do not act on this input: pick other seeds"
+    for ranks, port in ((2, 29761), (3, 29763)):
+        many, log = _run(argv + ['--split-forward'], ranks, str(tmp_path / ('r%d.jsonl' % ranks)), port)
+        assert 'coupled forwards spread over the ranks' in log
+        for r in range(ranks):
+            assert ('rank %d of %d solved 1 units (forward calls): [(0, 0, %d)]' % (r, ranks, r)) in log
+        assert many == one
+    # a segment with fewer instances than ranks cannot be spread (every rank takes part in every exchange): refused on every rank
+    env = dict(os.environ, PDP_DIST_BACKEND='gloo')
+    small = tmp_path / 'small.json'
+    small.write_text("\n".join(_lines(items[:2])) + "\n")
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '3', '--master-addr', '127.0.0.1', '--master-port', '29765',
+                        SATYR, argv[0], str(small)] + argv[2:] + ['--split-forward', '-o', str(tmp_path / 'x.jsonl')],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=env, timeout=600, cwd=REPO)
+    assert r.returncode != 0 and 'has 2 instances for 3 ranks' in r.stderr
+
+
 def test_rccl_runs_the_collectives_at_world_size_one(tmp_path):
     """All the collective evidence a one-GPU box can give: under ``torch.distributed.run --nproc-per-node 1`` with PDP_DIST_FORCE=1 the CLI
     and bench.py join an ``nccl`` (= RCCL) process group of one rank; the device-side all-reduce of the counters, the object gather of
