@@ -328,7 +328,9 @@ class FactorGraphTrainerBase(object):
         coupled = bool(self._config.get('split_forward')) and not isolated
         if coupled and world > 1 and int(batch_replication) != 1:
             raise native.NativeError("--split-forward: without batch replication (replica r of variable v has index v + r V: no contiguous parts)")
-        split = world > 1 and int(batch_replication) == 1 and (isolated or coupled)
+        # (PDP_DIST_FORCE=1: also in a group of ONE rank -- the exchange's collective then runs through RCCL on a one-GPU box)
+        forced = distributed and os.environ.get('PDP_DIST_FORCE') == '1'
+        split = (world > 1 or forced) and int(batch_replication) == 1 and (isolated or coupled)
         if split and self._config.get('verbose'):
             self._logger.info('%s: every segment is cut into %d instance ranges, one per rank'
                               % ('isolated instances' if isolated else 'coupled forwards spread over the ranks (--split-forward)', world))
@@ -340,7 +342,7 @@ class FactorGraphTrainerBase(object):
             input_file=test_list, limit=self._config['test_batch_limit'], hidden_dim=self._config['hidden_dim'],
             batch_size=self._config['batch_size'], shuffle=False, num_workers=0,
             max_cache_size=self._config.get('max_cache_size', 100000), batch_replication=batch_replication,
-            shard=(rank, world) if world > 1 else None, split_instances=split, split_coupled=split and coupled)
+            shard=(rank, world) if (world > 1 or split) else None, split_instances=split, split_coupled=split and coupled)
         if import_path_base is not None:
             self._load(import_path_base)
         start_time = time.time()

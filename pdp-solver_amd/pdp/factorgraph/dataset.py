@@ -190,7 +190,7 @@ class FactorGraphDataset(object):
                 self._lines = [l for l in f.read().split('\n') if l.strip()]
         # one process per GPU: the loader forms the SAME batches and cuts the SAME segments as a single-process run; this rank collates and
         # yields the segments dealt to it (pdp/parallel.py: one forward = one segment is the reference's coupling domain)
-        self._shard = tuple(shard) if shard is not None and shard[1] > 1 and generator is None else None
+        self._shard = tuple(shard) if shard is not None and (shard[1] > 1 or split_instances) and generator is None else None
         # isolated instances (no coupling inside a segment): every segment is cut into one contiguous instance range per rank instead
         self._split_instances = bool(split_instances) and self._shard is not None and int(batch_replication) == 1
         # the parts stay coupled (--split-forward): every rank takes part in the exchanges of every forward, so every segment needs an instance per rank

@@ -184,6 +184,21 @@ def test_rccl_runs_the_collectives_at_world_size_one(tmp_path):
     forced, log = _run(argv, 1, str(tmp_path / 'forced.jsonl'), 29745, force_env={'PDP_DIST_FORCE': '1'})
     assert len(plain) == 30 and plain == forced
     assert '(1 ranks, nccl)' in log and 'rank 0 of 1 solved 3 units' in log
+    # --split-forward in the group of one: the exchange of the coupled forward (an all-gather of a few words per chunk) runs through RCCL too
+    # (on a batch large enough for the persistent solver's speculation to hold -- a dozen n = 60 instances fail it, and a coupled forward
+    #  over several processes has no step-wise fallback: that input is refused with a message, checked below)
+    big = dataset.random_ksat_items(40, 200, 3, m=840, seed=98100)
+    bpath = tmp_path / 'big.json'
+    bpath.write_text("\n".join(_lines(big)) + "\n")
+    bargv = [argv[0], str(bpath), '40', '-z', '5000', '-s', '3', '-w', '30', '--rng', 'philox', '-v']
+    bplain, _ = _run(bargv, 1, str(tmp_path / 'bplain.jsonl'), 0)
+    split, log = _run(bargv + ['--split-forward'], 1, str(tmp_path / 'split.jsonl'), 29749, force_env={'PDP_DIST_FORCE': '1'})
+    assert split == bplain and 'coupled forwards spread over the ranks' in log and '(1 ranks, nccl)' in log and '[(0, 0, 0)]' in log
+    env = dict(os.environ, PDP_DIST_FORCE='1')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port', '29751',
+                        SATYR] + argv + ['--rng', 'philox', '--split-forward', '-o', str(tmp_path / 'refused.jsonl')],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=env, timeout=600, cwd=REPO)
+    assert r.returncode != 0 and 'only the step-wise loop reproduces' in r.stderr
     env = dict(os.environ, PDP_DIST_FORCE='1')
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
                         '--master-port', '29747', os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--batch', '400',
