@@ -161,6 +161,11 @@ def test_split_forward_keeps_the_couplings_across_ranks(tmp_path):
         for r in range(ranks):
             assert ('rank %d of %d solved 1 units (forward calls): [(0, 0, %d)]' % (r, ranks, r)) in log
         assert many == one
+    # dynamic segments: the batch limit cuts the loader batch into three forwards (10 + 10 + 8 instances, sorted by size), each spread over both ranks
+    seg_argv = argv + ['-l', str(10 * 3 * max(it[2].shape[1] for it in items))]
+    one_s, _ = _run(seg_argv, 1, str(tmp_path / 'one_s.jsonl'), 0)
+    two_s, log = _run(seg_argv + ['--split-forward'], 2, str(tmp_path / 'two_s.jsonl'), 29767)
+    assert two_s == one_s and '[(0, 0, 1), (0, 1, 1), (0, 2, 1)]' in log
     # a segment with fewer instances than ranks cannot be spread (every rank takes part in every exchange): refused on every rank
     env = dict(os.environ, PDP_DIST_BACKEND='gloo')
     small = tmp_path / 'small.json'
