@@ -194,8 +194,36 @@ class FactorGraphTrainerBase(object):
                     (graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, label, misc_data) = \
                         [self._to_cuda(d[k]) for d in data]
                     sink = io.StringIO() if units is not None else file
-                    self._predict_batch(graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat,
-                                        label, misc_data, post_processor, batch_replication, sink)
+                    try:
+                        self._predict_batch(graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat,
+                                            label, misc_data, post_processor, batch_replication, sink)
+                    except native.CoupledForwardFailed:
+                        # --split-forward, and this segment's speculation failed (every part raises: the outcome is agreed on across the parts
+                        # before any later collective).  Small batches do that -- the exact zero the persistent solver counts on is supplied by
+                        # SOME variable of a large batch.  The rank of the first part solves the segment whole, with the single-process loops
+                        # (lock-step / step-wise) and the segment's own Philox key; the other parts contribute no rows for this unit.
+                        whole = getattr(data, 'whole', None)
+                        if whole is None:
+                            raise
+                        if self._config.get('verbose'):
+                            self._logger.info('segment (%d, %d): the coupled forward needs the single-process loop; solved whole on rank of part 0' % (j, segment_ids[k]))
+                        sink = io.StringIO() if units is not None else file
+                        if parts[k][0] == 0:
+                            seg = whole[k]()
+                            saved = [(m, getattr(m, '_exchange', None)) for m in self._model_list]
+                            try:
+                                for m in self._model_list:
+                                    if hasattr(m, '_exchange'):
+                                        m._exchange = None
+                                    if hasattr(m, 'set_random_key'):
+                                        m.set_random_key(parallel.batch_seed(base_seed, j, segment_ids[k]))
+                                t_ = lambda a: self._to_cuda(torch.from_numpy(a))
+                                self._predict_batch(t_(seg['graph_map']), t_(seg['batch_variable_map']), t_(seg['batch_function_map']), t_(seg['edge_feature']), None,
+                                                    t_(seg['label']), seg['misc_data'], post_processor, batch_replication, sink)
+                            finally:
+                                for m, ex in saved:
+                                    if hasattr(m, '_exchange'):
+                                        m._exchange = ex
                     if units is not None:
                         units.append(((int(j), int(segment_ids[k])) + ((int(parts[k][0]),) if parts else ()), sink.getvalue()))
 

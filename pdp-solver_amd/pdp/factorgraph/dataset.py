@@ -95,6 +95,7 @@ class SegmentList(list):
     batch_index = 0           # global index of the loader batch
     segment_ids = ()          # global segment index (inside the batch) of every entry
     parts = None              # isolated instances dealt to ranks: per entry (part index, first variable, first instance) inside its segment
+    whole = None              # --split-forward: per entry a callable that collates the WHOLE segment (the single-process fallback of a failed speculation)
 
 
 class LoaderBatch(tuple):
@@ -103,6 +104,7 @@ class LoaderBatch(tuple):
     index = 0
     segments = ()
     parts = None              # see SegmentList.parts
+    whole = None              # see SegmentList.whole
 
 
 def json_edge_count(line):
@@ -270,7 +272,7 @@ class FactorGraphDataset(object):
                 edges = [tmp[i][2].shape[1] if i in tmp else self._edge_count(i) for i in idx]
                 segments = divide(edges, self._limit // self._batch_replication, self._hidden_dim)
                 if self._split_instances:
-                    out, ids, parts = SegmentList(), [], []
+                    out, ids, parts, whole = SegmentList(), [], [], []
                     for s, seg in enumerate(segments):
                         if self._split_coupled and len(seg) < world:
                             raise ValueError("--split-forward: segment %d of loader batch %d has %d instances for %d ranks (every rank takes part in "
@@ -280,9 +282,11 @@ class FactorGraphDataset(object):
                             out.append(collate_segment([get(idx[k]) for k in seg[lo:hi]]))
                             ids.append(s)
                             parts.append((rank, sum(self._variable_count(idx[k], tmp) for k in seg[:lo]), lo))
+                            whole.append(lambda seg=seg: collate_segment([get(idx[k]) for k in seg]))
                     if not ids:
                         continue
                     out.segment_ids, out.parts = ids, parts
+                    out.whole = whole if self._split_coupled else None
                     out.batch_index = self.batch_index = j
                     yield out
                     continue
@@ -326,5 +330,6 @@ class FactorGraphDataset(object):
                                         [torch.from_numpy(s['label']) for s in segs],
                                         [s['misc_data'] for s in segs]))
                     data.index, data.segments, data.parts = segs.batch_index, list(segs.segment_ids), segs.parts
+                    data.whole = segs.whole
                     yield data
         return _Loader()

@@ -49,6 +49,12 @@ class SpeculationFailed(NativeError):
     """The persistent solver met one of the reference's cross-instance couplings; rerun step-wise."""
 
 
+class CoupledForwardFailed(NativeError):
+    """A coupled forward spread over several processes (--split-forward) met a coupling only the single-process loops reproduce (the
+    batch-global minimum of a sweep was not 0 in any part).  Every part raises it (the outcome is agreed on across the parts); the predict
+    driver then solves that segment whole on the rank of its first part."""
+
+
 _lib = None
 
 

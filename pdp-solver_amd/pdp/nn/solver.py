@@ -343,8 +343,8 @@ class PropagatorDecimatorSolverBase(nn.Module):
             if out is not None:
                 return out
             if self._exchange is not None:
-                raise native.NativeError("a coupled forward spread over several processes met a coupling only the step-wise loop reproduces "
-                                         "(batch-global minimum != 0); that loop is single-process: run this input on one GPU or with --isolated")
+                raise native.CoupledForwardFailed("a coupled forward spread over several processes met a coupling only the step-wise loop "
+                                                  "reproduces (batch-global minimum != 0); that loop is single-process")
         del init_propagator_state, init_decimator_state                # (see forward: this frame lets go of the initial state)
         return self._forward_core_stepwise(box, None, sat_problem, iteration_num, is_training, check_termination)
 

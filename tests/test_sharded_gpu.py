@@ -190,8 +190,7 @@ def test_rccl_runs_the_collectives_at_world_size_one(tmp_path):
     assert len(plain) == 30 and plain == forced
     assert '(1 ranks, nccl)' in log and 'rank 0 of 1 solved 3 units' in log
     # --split-forward in the group of one: the exchange of the coupled forward (an all-gather of a few words per chunk) runs through RCCL too
-    # (on a batch large enough for the persistent solver's speculation to hold -- a dozen n = 60 instances fail it, and a coupled forward
-    #  over several processes has no step-wise fallback: that input is refused with a message, checked below)
+    # (on a batch large enough for the persistent solver's speculation to hold; the dozen-instance batches of the first input: below)
     big = dataset.random_ksat_items(40, 200, 3, m=840, seed=98100)
     bpath = tmp_path / 'big.json'
     bpath.write_text("\n".join(_lines(big)) + "\n")
@@ -199,11 +198,13 @@ def test_rccl_runs_the_collectives_at_world_size_one(tmp_path):
     bplain, _ = _run(bargv, 1, str(tmp_path / 'bplain.jsonl'), 0)
     split, log = _run(bargv + ['--split-forward'], 1, str(tmp_path / 'split.jsonl'), 29749, force_env={'PDP_DIST_FORCE': '1'})
     assert split == bplain and 'coupled forwards spread over the ranks' in log and '(1 ranks, nccl)' in log and '[(0, 0, 0)]' in log
-    env = dict(os.environ, PDP_DIST_FORCE='1')
-    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port', '29751',
-                        SATYR] + argv + ['--rng', 'philox', '--split-forward', '-o', str(tmp_path / 'refused.jsonl')],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=env, timeout=600, cwd=REPO)
-    assert r.returncode != 0 and 'only the step-wise loop reproduces' in r.stderr
+    # the small batches of the first input fail the speculation: every part agrees on that, and the rank of the segment's first part solves the
+    # segment whole with the single-process loops -- same rows again
+    pplain, _ = _run(argv + ['--rng', 'philox'], 1, str(tmp_path / 'pplain.jsonl'), 0)
+    fell, log = _run(argv + ['--rng', 'philox', '--split-forward'], 1, str(tmp_path / 'fell.jsonl'), 29751, force_env={'PDP_DIST_FORCE': '1'})
+    assert fell == pplain and 'needs the single-process loop' in log
+    fell2, log = _run(argv + ['--rng', 'philox', '--split-forward'], 2, str(tmp_path / 'fell2.jsonl'), 29753)
+    assert fell2 == pplain and 'needs the single-process loop' in log
     env = dict(os.environ, PDP_DIST_FORCE='1')
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
                         '--master-port', '29747', os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--batch', '400',
