@@ -28,6 +28,8 @@ The strict (coupled) semantics across GPUs: ``--split-forward`` cuts the segment
 reductions across the parts -- per 12-sweep chunk of the persistent solver one small all-gather of its control words (first NaN sweep: min,
 exact-zero record of the batch-global minimum: or, executed sweeps: max), one more after a poison replay, one for the Walk-SAT record
 (``make_exchange`` -> ``native.Problem.set_exchange`` -> C ABI ``pdp_problem_set_exchange``); the rows are those of the 1-rank strict run.
+A segment whose speculation fails (small batches: no variable supplies the exact zero of the batch-global minimum) is solved whole by the
+rank of its first part with the single-process loops -- the parts agree on the outcome before any later collective.
 
 ``shard_bounds`` / ``shard_items`` cut ONE batch by instances; only bench.py uses that (its synthetic batch has no loader and is timed
 in ``--isolated``-equivalent weak scaling: every rank generates its own B instances).
