@@ -213,9 +213,9 @@ def test_rccl_runs_the_collectives_at_world_size_one(tmp_path):
     # the small batches of the first input fail the speculation: every part agrees on that, and the rank of the segment's first part solves the
     # segment whole with the single-process loops -- same rows again
     pplain, _ = _run(argv + ['--rng', 'philox'], 1, str(tmp_path / 'pplain.jsonl'), 0)
-    fell, log = _run(argv + ['--rng', 'philox', '--split-forward'], 1, str(tmp_path / 'fell.jsonl'), 29751, force_env={'PDP_DIST_FORCE': '1'})
+    fell, log = _run(argv + ['--rng', 'philox', '--split-forward'], 1, str(tmp_path / 'fell.jsonl'), 29771, force_env={'PDP_DIST_FORCE': '1'})
     assert fell == pplain and 'needs the single-process loop' in log
-    fell2, log = _run(argv + ['--rng', 'philox', '--split-forward'], 2, str(tmp_path / 'fell2.jsonl'), 29753)
+    fell2, log = _run(argv + ['--rng', 'philox', '--split-forward'], 2, str(tmp_path / 'fell2.jsonl'), 29773)
     assert fell2 == pplain and 'needs the single-process loop' in log
     env = dict(os.environ, PDP_DIST_FORCE='1')
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
