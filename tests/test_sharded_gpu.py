@@ -166,6 +166,12 @@ def test_split_forward_keeps_the_couplings_across_ranks(tmp_path):
     one_s, _ = _run(seg_argv, 1, str(tmp_path / 'one_s.jsonl'), 0)
     two_s, log = _run(seg_argv + ['--split-forward'], 2, str(tmp_path / 'two_s.jsonl'), 29767)
     assert two_s == one_s and '[(0, 0, 1), (0, 1, 1), (0, 2, 1)]' in log
+    # the pure Walk-SAT solver (model type walk-sat: random fill + local search, no message passing): its record of the batch-global minimum is
+    # completed across the parts the same way
+    ws_argv = [os.path.join(REPO, 'config', 'Predict', 'PDP-p-d-p-walksat-pytorch.yaml'), str(path), '300', '-z', '5000', '-s', '11', '--rng', 'philox', '-v']
+    ws_one, _ = _run(ws_argv, 1, str(tmp_path / 'ws_one.jsonl'), 0)
+    ws_two, _ = _run(ws_argv + ['--split-forward'], 2, str(tmp_path / 'ws_two.jsonl'), 29769)
+    assert ws_two == ws_one and len(ws_one) == len(items)
     # a segment with fewer instances than ranks cannot be spread (every rank takes part in every exchange): refused on every rank
     env = dict(os.environ, PDP_DIST_BACKEND='gloo')
     small = tmp_path / 'small.json'
