@@ -241,11 +241,12 @@ __device__ __forceinline__ T wave_reduce(T v, Op op, T identity)
     return v;
 }
 
+// (nt: the workgroup size, for callers that must not fetch blockDim -- out-of-line device functions read it from the dispatch packet in memory)
 template <typename T, typename Op>
-__device__ __forceinline__ T block_reduce(T v, Op op, T identity, T *scratch)
+__device__ __forceinline__ T block_reduce(T v, Op op, T identity, T *scratch, int nt = (int)blockDim.x)
 {
     const int lane = threadIdx.x & (PDP_WAVE - 1), wid = threadIdx.x / PDP_WAVE;
-    const int nw = (blockDim.x + PDP_WAVE - 1) / PDP_WAVE;
+    const int nw = (nt + PDP_WAVE - 1) / PDP_WAVE;
     v = wave_reduce(v, op, identity);
     if (lane == PDP_WAVE - 1) scratch[wid] = v;
     __syncthreads();

@@ -123,7 +123,8 @@ struct SolveCall {
 // gather through the CSR, and the record a launch resumed from stays intact, which is the snapshot the poison replay needs.
 //   static  (per problem): pvv | e2p | v_ptr | f_ptr | vord (variables by descending degree)
 //   dynamic (two copies, ping-pong): header | QU | E | pcc | af | av | sol
-struct DynHeader { uint32_t active, done, perm_zero, simplified; float cnt, is_sat, pad1, pad2; };   // simplified: 0 unknown, 1 the state is a simplify() fix-point, 2 it is not
+struct DynHeader { uint32_t active, done, perm_zero, simplified; float cnt, is_sat; int32_t nsat_p1; float pad2; };   // nsat_p1: satisfied clauses under `sol` + 1 (0: not counted yet)
+//   // simplified: 0 unknown, 1 the state is a simplify() fix-point, 2 it is not
 struct BlobLayout { size_t pvv, e2p, vptr, fptr, vord, stat_bytes, hdr, QU, E, pcc, af, av, sol, dyn_bytes; };
 __host__ __device__ inline BlobLayout blob_layout(int n, int m, int ne)
 {
@@ -783,6 +784,8 @@ __global__ void __launch_bounds__(NT) k_sp_solve(PView pv, SolveParams sp)
 // =====================================================================================================================
 struct LView {   // what the shared simplification routines see: "edge id" == slot
     int b, n, m, e;
+    int nt;      // workgroup size (team_nt: the out-of-line routines must not read blockDim from the dispatch packet)
+    int *red;    // >= PDP_RED_SMALL words of LDS scratch for team_any
     struct EVar { const uint16_t *pv; int mask; __device__ __forceinline__ int operator[](int p) const { return pv[p] & mask; } } e_var;   // mask 0x3fff; 0x1fff when bits 13-14 hold the Reinforce force
     struct EFn { const uint16_t *pc; __device__ __forceinline__ int operator[](int p) const { return pc[p] & 0x3fff; } } e_fn;
     struct Sgn { const uint16_t *pv; __device__ __forceinline__ int operator[](int p) const { return (pv[p] & 0x8000) ? -1 : 1; } } sgn;
@@ -842,26 +845,26 @@ __device__ __forceinline__ LdsArrays carve_all(unsigned char *cp, int n, int m, 
     L.vord = carve<uint16_t>(cp, n);
     return L;
 }
-__device__ __forceinline__ LView make_lview(const LdsArrays &L, int b, int n, int m, int ne, int vmask = 0x3fff)
+__device__ __forceinline__ LView make_lview(const LdsArrays &L, int b, int n, int m, int ne, int nt, int *red, int vmask = 0x3fff)
 {
     LView I;
-    I.b = b; I.n = n; I.m = m; I.e = ne;
+    I.b = b; I.n = n; I.m = m; I.e = ne; I.nt = nt; I.red = red;
     I.e_var.pv = L.pvv; I.e_var.mask = vmask; I.e_fn.pc = L.pcc; I.sgn.pv = L.pvv; I.f_edges = L.e2p; I.v_ptr = L.v_ptr; I.f_ptr = L.f_ptr;
     I.av = L.av; I.af = L.af; I.sol = L.sol;
     return I;
 }
 #define UNI(x) __builtin_amdgcn_readfirstlane(x)
 #ifdef PDP_PHASE_PROF
-__device__ unsigned long long g_phase_cycles[24];
+__device__ unsigned long long g_phase_cycles[40];
 // per-phase sums stay in registers and are flushed once per launch: one atomic per phase and iteration from 5000 workgroups
 // onto the same 16 words more than doubled the kernel time
-#define PROF_DECL unsigned long long _t0 = __builtin_readcyclecounter(), _t1; uint32_t _acc[13] = {0};
+#define PROF_DECL unsigned long long _t0 = __builtin_readcyclecounter(), _t1; uint32_t _acc[20] = {0};
 #define PROF_MARK(i) do { _t1 = __builtin_readcyclecounter(); _acc[i] += (uint32_t)(_t1 - _t0); _t0 = _t1; } while (0)
-#define PROF_FLUSH() do { if (threadIdx.x == 0) { _Pragma("unroll") for (int _i = 0; _i < 13; ++_i) if (_acc[_i]) atomicAdd(&g_phase_cycles[_i], (unsigned long long)_acc[_i]); } } while (0)
+#define PROF_FLUSH() do { if (threadIdx.x == 0) { _Pragma("unroll") for (int _i = 0; _i < 20; ++_i) if (_acc[_i]) atomicAdd(&g_phase_cycles[_i < 13 ? _i : _i + 11], (unsigned long long)_acc[_i]); } } while (0)
 extern "C" int pdp_debug_phase_cycles(unsigned long long *out_host, int reset)
 {
-    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 24) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[24] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)) != hipSuccess) return 1; }
+    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 40) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[40] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)) != hipSuccess) return 1; }
     return 0;
 }
 #define PROF_COUNT(i) do { _acc[i] += 1u; } while (0)
@@ -912,14 +915,7 @@ __device__ __forceinline__ f4v log4_fin(f4v x, float eps)
     const f4v r = (__builtin_convertvector(e, f4v) + l) * 0.693147180559945309f;
     return vfma((f4v)(0.0f), x, r);          // a NaN whose sign bit is set went to eps in the integer maximum: re-injected
 }
-typedef float f2v __attribute__((ext_vector_type(2)));
-typedef int i2v __attribute__((ext_vector_type(2)));
-typedef unsigned u2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2v log2_fin(f2v x, float eps)
-{
-    const f4v r = log4_fin((f4v){x.x, x.y, x.x, x.y}, eps);
-    return (f2v){r.x, r.y};
-}
+__device__ __forceinline__ f4v exp4_sum(f4v x) { return exp4_fin_le30(x); }
 #else
 __device__ __forceinline__ f4v exp4_fin_le30(f4v x)
 {
@@ -943,6 +939,33 @@ __device__ __forceinline__ f4v exp4_fin_le30(f4v x)
     // a NaN / infinite argument comes back as NaN (the clamp dropped it): (+0) * x + res as one fused operation -- for a finite x the product
     // is an exact zero, like the x - x of the scalar form in pdp_math.h, at a third of its instructions
     return vfma((f4v)(0.0f), x, res);
+}
+
+// The same four exps for arguments that are FINITE (any magnitude down to -4e6) or NaN, without the clamp and without the re-injection:
+// * a NaN argument makes t, nf, r and p NaN, v_cvt_i32_f32 turns the NaN exponent into 0 and v_ldexp_f32 returns the NaN: it arrives by itself;
+// * an argument below -104.5 needs no clamp: nf = rint(x log2 e) <= -151 (below -2^22 the rounding trick may leave a half-integer, the
+//   conversion truncates it), r = x - nf ln 2 stays within (-1, 1), so p < 2.8 and p * 2^n < 2^-150 rounds to +0 -- what the clamped form
+//   returns there (e^-104.5 = 0.59 * 2^-150).  Between -104.5 and 30 the two forms are the same instructions.
+// E2 evaluates sums of clamped logs (never infinite), so it takes this form: 5 VALU instructions and 2 packed fmas fewer per slot.
+__device__ __forceinline__ f4v exp4_sum(f4v xc)
+{
+    const f4v t = xc * 1.44269504088896341f;
+    const f4v nf = (t + 12582912.0f) - 12582912.0f;
+    f4v r = vfma(nf, (f4v)(-0.693359375f), xc);
+    r = vfma(nf, (f4v)(2.12194440e-4f), r);
+    const f4v z = r * r;
+    f4v p = (f4v)(1.9875691500e-4f);
+    p = vfma(p, r, (f4v)(1.3981999507e-3f));
+    p = vfma(p, r, (f4v)(8.3334519073e-3f));
+    p = vfma(p, r, (f4v)(4.1665795894e-2f));
+    p = vfma(p, r, (f4v)(1.6666665459e-1f));
+    p = vfma(p, r, (f4v)(5.0000001201e-1f));
+    p = vfma(p, z, r);
+    p = p + 1.0f;
+    const i4v n = __builtin_convertvector(nf, i4v);
+    f4v res;
+    res.x = __builtin_ldexpf(p.x, n.x); res.y = __builtin_ldexpf(p.y, n.y); res.z = __builtin_ldexpf(p.z, n.z); res.w = __builtin_ldexpf(p.w, n.w);
+    return res;
 }
 
 __device__ __forceinline__ f4v log4_fin(f4v x, float eps)
@@ -978,38 +1001,6 @@ __device__ __forceinline__ f4v log4_fin(f4v x, float eps)
     return vfma((f4v)(0.0f), x, r);          // NaN / inf re-injection as in exp4_fin_le30 (arguments are >= +0 here: the product is +0)
 }
 
-typedef float f2v __attribute__((ext_vector_type(2)));
-typedef int i2v __attribute__((ext_vector_type(2)));
-typedef unsigned u2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2v log2_fin(f2v x, float eps)             // two-wide twin of log4_fin for the ragged last trip
-{
-    const f2v xm = __builtin_bit_cast(f2v, __builtin_elementwise_max(__builtin_bit_cast(i2v, x), __builtin_bit_cast(i2v, (f2v)(eps))));
-    f2v m; i2v e;
-    m.x = __builtin_amdgcn_frexp_mantf(xm.x); m.y = __builtin_amdgcn_frexp_mantf(xm.y);
-    e.x = __builtin_amdgcn_frexp_expf(xm.x); e.y = __builtin_amdgcn_frexp_expf(xm.y);
-    const u2v lt = (__builtin_bit_cast(u2v, m) - 0x3f3504f3u) >> 31;
-    const i2v lti = __builtin_bit_cast(i2v, lt);
-    e = e - lti;
-    m.x = __builtin_ldexpf(m.x, lti.x); m.y = __builtin_ldexpf(m.y, lti.y);
-    m = m - 1.0f;
-    const f2v z = m * m;
-    f2v y = (f2v)(7.0376836292e-2f);
-    y = __builtin_elementwise_fma(y, m, (f2v)(-1.1514610310e-1f));
-    y = __builtin_elementwise_fma(y, m, (f2v)(1.1676998740e-1f));
-    y = __builtin_elementwise_fma(y, m, (f2v)(-1.2420140846e-1f));
-    y = __builtin_elementwise_fma(y, m, (f2v)(1.4249322787e-1f));
-    y = __builtin_elementwise_fma(y, m, (f2v)(-1.6668057665e-1f));
-    y = __builtin_elementwise_fma(y, m, (f2v)(2.0000714765e-1f));
-    y = __builtin_elementwise_fma(y, m, (f2v)(-2.4999993993e-1f));
-    y = __builtin_elementwise_fma(y, m, (f2v)(3.3333331174e-1f));
-    y = (y * m) * z;
-    const f2v fe = __builtin_convertvector(e, f2v);
-    y = __builtin_elementwise_fma(fe, (f2v)(-2.12194440e-4f), y);
-    y = __builtin_elementwise_fma((f2v)(-0.5f), z, y);
-    f2v r = m + y;
-    r = __builtin_elementwise_fma(fe, (f2v)(0.693359375f), r);
-    return __builtin_elementwise_fma((f2v)(0.0f), x, r);
-}
 #endif
 
 // cross-lane helpers without the LDS crossbar (a __shfl is a ds_bpermute round trip of ~100 cycles):
@@ -1057,25 +1048,70 @@ __device__ __forceinline__ float lds_score_of(float pos, float neg, float all, f
     return pdp_expf_fin_le30(pdp_min_c(l1 - total, 30.0f)) - pdp_expf_fin_le30(pdp_min_c(l0 - total, 30.0f));
 }
 
-// P6, cold: SurveyScorer + arg-max + set_variables (pdp_decimate.py:152-171).  Returns 1 if a variable was fixed;
-// *spec gets bit 0 "coeff has an exact zero", bit 1 "NaN coefficient".
-template <bool FORCE>
-__device__ __noinline__ int lds_decimate(unsigned char *smem, int b, int n, int m, int ne, int cur, int active, float pi,
-                                         float *is_sat_b, int *spec, int *verified)
+// What the cold, out-of-line routines of the LDS-resident solver share with the kernel.  A non-kernel function that names a __shared__
+// variable (or the dynamic LDS array) finds it through a table in memory, reads blockDim from the dispatch packet and spills what it
+// touches of the caller's registers: ~7 600 cycles per call on the headline batch, as much as the routine's own work.  So the kernel
+// hands over the LDS byte offsets of the instance image and of this block (laundered through an asm, or the optimiser would propagate the
+// symbol back in), the workgroup size, and takes every result back in the return value -- no pointer to a local (it would live in scratch).
+struct ColdShared {
+    unsigned long long key;          // arg-max key of the decimation (ds_max_u64)
+    int flags, found;                // OR-reductions of the decimation
+    float is_sat;                    // SATProblem._is_sat of the instance (solver.py:251-252)
+    int red[PDP_RED_SMALL];          // scratch of the general simplification routines
+};
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+__device__ __forceinline__ uint32_t lds_offset_of(const void *p)
 {
-    __shared__ int redi2[PDP_RED_SMALL];
+    uint32_t off = (uint32_t)(uintptr_t)(lds_u8 *)p;
+    asm volatile("" : "+s"(off));
+    return off;
+}
+template <class T> __device__ __forceinline__ T *lds_at(uint32_t off) { return (T *)(lds_u8 *)(uintptr_t)off; }
+// the general routines of pdp_device.hpp on an LDS view: workgroup size from the view, not from the dispatch packet
+__device__ __forceinline__ int team_nt(const LView &I) { return I.nt; }
+template <typename T, typename Op>
+__device__ __forceinline__ T team_reduce(const LView &I, T v, Op op, T identity, T *scratch) { return block_reduce(v, op, identity, scratch, I.nt); }
+// (HIP's __syncthreads_or reads the three block dimensions from memory)
+__device__ __forceinline__ int team_any(const LView &I, int x) { return block_reduce(x ? 1 : 0, OpOrI(), 0, I.red, I.nt); }
+
+// P6, cold: SurveyScorer + arg-max + set_variables (pdp_decimate.py:152-171).  Returns bit 0: a variable was fixed; bit 1: "coeff has an
+// exact zero", bit 2: "NaN coefficient" (the speculation record); bits 3-4: the new value of `verified`.
+#define DEC_FIXED 1
+#define DEC_SPEC_SHIFT 1
+#define DEC_VERIFIED_SHIFT 3
+template <bool FORCE>
+__device__ __noinline__ int lds_decimate(uint32_t smem_off, uint32_t cold_off, int nt, int n, int m, int ne, int cur, int active, float pi, int verified)
+{
+    unsigned char *const smem = lds_at<unsigned char>(smem_off);
+    ColdShared *const cs = lds_at<ColdShared>(cold_off);
     const LdsArrays L = carve_all(smem, n, m, ne, FORCE);
-    const LView I = make_lview(L, b, n, m, ne);
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     float *Enew = cur ? L.EA : L.EB;
     float *score = L.xv2, *assign = L.coeff;
     DEC_PROF_DECL
-    for (int p = tid; p < ne; p += nt)
-        L.Y[p] = pdp_safe_log_fin(1.0f - Enew[p], PDP_SCORER_EPS) * (0.0f + L.af[L.pcc[p] & 0x3fff]);   // surveys are finite or NaN
+    // scorer, per slot: log(max(1 - eta, eps)) * active_clause (pdp_predict.py:168-172), four slots per trip as one 4-vector; the
+    // remainder (fewer than 4 nt slots) is dealt in quarters to the first lanes, so that the other waves skip the trip
+    {
+        const int full = ne / (4 * nt), rem = ne - full * 4 * nt, quarter = (rem + 3) >> 2;
+        for (int k = 0; k <= full; ++k) {
+            const bool tail = k == full;
+            if (tail && tid >= quarter) break;
+            const int st = tail ? quarter : nt, p0 = k * 4 * nt + tid;
+            int p[4]; bool in[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { p[j] = p0 + j * st; in[j] = p[j] < ne; if (!in[j]) p[j] = p0; }
+            const f4v lg = log4_fin((f4v){1.0f - Enew[p[0]], 1.0f - Enew[p[1]], 1.0f - Enew[p[2]], 1.0f - Enew[p[3]]}, PDP_SCORER_EPS);   // surveys are finite or NaN
+            const float r[4] = {lg.x, lg.y, lg.z, lg.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (in[j]) L.Y[p[j]] = r[j] * (0.0f + L.af[L.pcc[p[j]] & 0x3fff]);
+        }
+    }
+    if (tid == 0) { cs->key = 0ull; cs->flags = 0; cs->found = 0; }
     __syncthreads();
     DEC_PROF_MARK(16);                                // scorer: edge logs
     const float Lpi = pdp_safe_log(1.0f - pi, PDP_SCORER_EPS), L0 = pdp_safe_log(1.0f - pi * 0.0f, PDP_SCORER_EPS);
     int flags = 0;                                   // 1: a coefficient is exactly 0, 2: some coefficient is non-zero, 4: NaN coefficient
+    unsigned long long key = 0ull;                   // util.sparse_argmax on (coeff - 0) + 1: larger value wins, first index wins ties
     for (int i = tid; i < n; i += nt) {
         const int v = L.vord[i];                     // degree-sorted: the lanes of a wave run loops of similar length
         float ext = 0.0f, pos = 0.0f, neg = 0.0f, all = 0.0f;
@@ -1110,27 +1146,29 @@ __device__ __noinline__ int lds_decimate(unsigned char *smem, int b, int n, int 
         if (co == 0.0f) flags |= 1;
         if (co != 0.0f) flags |= 2;
         if (co != co) flags |= 4;
+        // (keys need NaN-free values: with a NaN coefficient the winner is not used)
+        const unsigned long long kv = argkey((co - 0.0f) + 1.0f, v);
+        key = kv > key ? kv : key;
     }
-    flags = block_reduce(flags, OpOrI(), 0, redi2);    // (its barriers also publish score / coeff)
-    const int z3 = flags & 1, anynz = (flags >> 1) & 1, cn = (flags >> 2) & 1;
-    *spec = (z3 ? 1 : 0) | (cn ? 2 : 0);
-    DEC_PROF_MARK(17);                                // scorer: per-variable sums + score + flag reduction
-    // util.sparse_argmax on (coeff - 0) + 1: larger value wins, first index wins ties.  Keys need NaN-free values: with a NaN
-    // coefficient (cn) the result is not used
-    int li;
-    {
-        __shared__ unsigned long long keys2[PDP_RED_SMALL];
-        unsigned long long k = 0ull;
-        for (int v = tid; v < n; v += nt) { const unsigned long long kv = argkey((L.coeff[v] - 0.0f) + 1.0f, v); k = kv > k ? kv : k; }
-        li = argkey_index(block_max_u64(k, keys2));
-    }
-    if (!(active && anynz && !cn && li >= 0)) return 0;
-    const float sgn_li = pdp_sign(score[li]);
+    // one reduction for the flags and the arg-max: DPP inside the wave, one ds_or / ds_max_u64 per wave, one barrier (which also
+    // publishes score / coeff)
+    flags = wave_reduce(flags, OpOrI(), 0);
+    key = wave_max_u64(key);
+    if (lane == 63) { if (flags) atomicOr(&cs->flags, flags); if (key) atomicMax(&cs->key, key); }
     __syncthreads();
+    flags = UNI(cs->flags);
+    const int z3 = flags & 1, anynz = (flags >> 1) & 1, cn = (flags >> 2) & 1;
+    int ret = ((z3 ? 1 : 0) | (cn ? 2 : 0)) << DEC_SPEC_SHIFT;
+    DEC_PROF_MARK(17);                                // scorer: per-variable sums + score + flag / arg-max reduction
+    const unsigned long long kwin = cs->key;
+    const int li = UNI(argkey_index(kwin));
+    if (!(active && anynz && !cn && li >= 0)) return ret | (verified << DEC_VERIFIED_SHIFT);
+    const float sgn_li = pdp_sign(score[li]);
     DEC_PROF_MARK(18);                                // arg-max
+    const LView I = make_lview(L, 0, n, m, ne, nt, cs->red);  // (the view's batch id is unused)
     SimplifyScratch ss;
     ss.assign = assign; ss.deg = reinterpret_cast<int32_t *>(L.xv1); ss.sdeg = reinterpret_cast<int32_t *>(L.xv2);
-    ss.flag_v = L.flag_v; ss.flag_f = reinterpret_cast<uint8_t *>(L.S); ss.flag_f2 = ss.flag_f + ((m + 15) & ~15); ss.red = redi2;
+    ss.flag_v = L.flag_v; ss.flag_f = reinterpret_cast<uint8_t *>(L.S); ss.flag_f2 = ss.flag_f + ((m + 15) & ~15); ss.red = cs->red;
 
     // ---- fast path ------------------------------------------------------------------------------------------------
     // A problem that went through simplify() has no active unit clause and no active pure variable (both loops of
@@ -1139,7 +1177,7 @@ __device__ __noinline__ int lds_decimate(unsigned char *smem, int b, int n, int 
     // variables of the clauses it satisfied, so the full-instance sweeps of the reference shrink to the neighbourhood of
     // the variable.  The invariant is checked once per launch (the state may have been written from outside); anything
     // the neighbourhood scan finds is handed to the general routines, which redo the reference's sweeps.
-    if (*verified == 0) {
+    if (verified == 0) {
         int bad = 0;
         for (int c = tid; c < m; c += nt) {
             if (L.af[c] == 1.0f) {
@@ -1163,10 +1201,11 @@ __device__ __noinline__ int lds_decimate(unsigned char *smem, int b, int n, int 
                 if (d == (sd < 0 ? -sd : sd)) bad = 1;
             }
         }
-        *verified = __syncthreads_or(bad) ? 2 : 1;
+        verified = block_reduce(bad, OpOrI(), 0, cs->red, nt) ? 2 : 1;
         DEC_PROF_MARK(19);                            // fix-point verification (once per call)
     }
-    if (*verified == 1) {
+    ret |= DEC_FIXED | (verified << DEC_VERIFIED_SHIFT);
+    if (verified == 1) {
         const int a = L.v_ptr[li], deg_li = L.v_ptr[li + 1] - a;
         const bool neg_li = sgn_li < 0.0f;
         // _set_variable_core for a one-hot assignment: a clause is switched off iff one of its literals of `li` is satisfied
@@ -1210,14 +1249,18 @@ __device__ __noinline__ int lds_decimate(unsigned char *smem, int b, int n, int 
                 if (d == (sd < 0 ? -sd : sd)) pure = 1;
             }
         }
-        const int found = block_reduce((single ? 1 : 0) | (pure ? 2 : 0), OpOrI(), 0, redi2);
+        // (`single` / `pure` are rare: the lanes that found one raise the bit themselves, one barrier joins them)
+        if (single) atomicOr(&cs->found, 1);
+        if (pure) atomicOr(&cs->found, 2);
+        __syncthreads();
+        const int found = UNI(cs->found);
         DEC_PROF_MARK(21);                            // unit-clause / pure-variable scans
 #ifdef PDP_PHASE_PROF
         if (threadIdx.x == 0) { if (found & 1) atomicAdd(&g_phase_cycles[22], 1ull); else if (found & 2) atomicAdd(&g_phase_cycles[23], 1ull); }
 #endif
-        if (found & 1) d_simplify(I, ss, is_sat_b);         // a unit clause: the general routines redo the reference's sweeps
+        if (found & 1) d_simplify(I, ss, &cs->is_sat);      // a unit clause: the general routines redo the reference's sweeps
         else if (found & 2) d_peel(I, ss);
-        return 1;
+        return ret;
     }
 
     // ---- general path: the reference's sweeps over the whole instance -------------------------------------------------
@@ -1226,8 +1269,8 @@ __device__ __noinline__ int lds_decimate(unsigned char *smem, int b, int n, int 
     if (tid == 0) assign[li] = sgn_li;
     __syncthreads();
     d_set_variable_core(I, ss);
-    d_simplify(I, ss, is_sat_b);
-    return 1;
+    d_simplify(I, ss, &cs->is_sat);
+    return ret;
 }
 
 // Reinforce triple, cold: the force update of ReinforceDecimator.forward (pdp_decimate.py:218-232: SurveyScorer on the new surveys and
@@ -1235,10 +1278,11 @@ __device__ __noinline__ int lds_decimate(unsigned char *smem, int b, int n, int 
 // sum of the force over the variable's edges > 0) and _update_solution (solver.py:388-399).  A variable's slots are contiguous and
 // read by its own thread only, so the new force is written in the same pass; the old force goes to X (free between E2 and the next E1):
 // the write-back rebuilds q_s / q_dc of the last sweep, which read the old force.  Returns 1 if a score was NaN.
-__device__ __noinline__ int lds_reinforce_step(unsigned char *smem, int n, int m, int ne, int cur, float pi, int do_force)
+__device__ __noinline__ int lds_reinforce_step(uint32_t smem_off, uint32_t cold_off, int nt, int n, int m, int ne, int cur, float pi, int do_force)
 {
-    const LdsArrays L = carve_all(smem, n, m, ne, false);
-    const int tid = threadIdx.x, nt = blockDim.x;
+    ColdShared *const cs = lds_at<ColdShared>(cold_off);
+    const LdsArrays L = carve_all(lds_at<unsigned char>(smem_off), n, m, ne, false);
+    const int tid = threadIdx.x;
     int bad = 0;
     if (do_force) {
         const float *Enew = cur ? L.EA : L.EB;
@@ -1287,16 +1331,7 @@ __device__ __noinline__ int lds_reinforce_step(unsigned char *smem, int n, int m
             L.pvv[p] = (uint16_t)((pw & ~PV_FRC_MASK) | codev[pw & PV_VMASK_RF]);
         }
     }
-    return __syncthreads_or(bad);
-}
-
-template <bool FORCE, bool RF = false>
-__device__ __noinline__ int lds_cnf_count(unsigned char *smem, int b, int n, int m, int ne)
-{
-    __shared__ int redi3[PDP_RED_SMALL];
-    const LdsArrays L = carve_all(smem, n, m, ne, FORCE && !RF);
-    const LView I = make_lview(L, b, n, m, ne, RF ? PV_VMASK_RF : 0x3fff);
-    return d_cnf_sat_count(I, L.sol, redi3);
+    return block_reduce(bad, OpOrI(), 0, cs->red, nt);
 }
 
 // REPLAY: the poison-replay pass over ctl->replay_count listed instances (a separate instantiation, so that profilers list
@@ -1379,11 +1414,13 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
             for (int p = tid; p < ne; p += nt) L.FRC[p] = sfs[2 * G.v_edges[p] + 1];
         }
     }
-    __shared__ float s_is_sat;
+    __shared__ __attribute__((aligned(16))) ColdShared s_cold;  // what the out-of-line routines share with the kernel (incl. SATProblem._is_sat)
     constexpr int SPEC_LOCAL = 64;
     __shared__ uint8_t s_spec_used[SPEC_LOCAL], s_spec_zero[SPEC_LOCAL];
+    __shared__ int s_flag_or[2];                            // P5: the OR of the waves' flag sets, one word per sweep parity
+    __shared__ int s_sat_count;                             // P8: satisfied clauses, summed over the waves
     if (tid < SPEC_LOCAL) { s_spec_used[tid] = 0; s_spec_zero[tid] = 0; }
-    if (tid == 0) s_is_sat = hdr.is_sat;
+    if (tid == 0) { s_cold.is_sat = hdr.is_sat; s_flag_or[0] = 0; s_flag_or[1] = 0; s_sat_count = 0; }
     __syncthreads();
 
     int active = hdr.active ? 1 : 0;
@@ -1392,7 +1429,8 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
     int prev_from_global = (sp.has_prev && sp.prev_slots) ? 1 : 0;     // later launches: the previous surveys are the loaded ones
     int use_em = sp.has_edge_mask, last_use_em = 0, em_dirty = 0;
     float cnt = hdr.cnt;
-    int iters = 0, did_prop = 0, nsat = -1, violation = 0, cur = 0;
+    int iters = 0, did_prop = 0, violation = 0, cur = 0;
+    int nsat = (int)hdr.nsat_p1 - 1;         // clauses satisfied by `sol` (-1: not counted yet); it only changes with a decimation, so later launches inherit it
     int rf_last_flip = 0;                    // Reinforce: the force was renewed after the last sweep (X holds the one that sweep read)
     int simplified = (int)hdr.simplified;   // 0: unknown, 1: the state is a simplify() fix-point (checked at the first decimation of a call), 2: it is not
     const bool other_rows = n < pv_.V;
@@ -1410,30 +1448,33 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
         iters = t + 1;
         float *const Eold = cur ? L.EB : L.EA, *const Enew = cur ? L.EA : L.EB;
         // ---- E1: per-slot logs, two slots per trip (independent chains for the scheduler / packed fp32 ops) -------------
-        if (!PROF_SKIP(1))
-        for (int p0 = tid; p0 < ne; p0 += 2 * nt) {
-            const int p1 = p0 + nt;
-            const bool has1 = p1 < ne;
-            const int q1 = has1 ? p1 : p0;
-            float x0, x1, y0, y1;
-            if (__builtin_amdgcn_ballot_w64(has1) != 0) {
+        // Full trips take slots (p, p + nt); the remainder (fewer than 2 nt slots) is split in two halves that the first `half` lanes take
+        // the same way, so that the waves beyond it skip the trip: 2 520 slots on 512 threads are two full trips and 472 slots that four
+        // waves take as pairs, where eight waves took one slot each at the price of a pair.  (Four slots per trip -- every wave one
+        // trip, two waves the remainder -- was measured in round 5: +3 % on the launch; the phase ends with its slowest wave, and that
+        // form gives two waves four 4-vectors where this one gives four waves three.)
+        if (!PROF_SKIP(1)) {
+            const int full = ne / (2 * nt), rem = ne - full * 2 * nt, half = (rem + 1) >> 1;
+            for (int k = 0; k <= full; ++k) {
+                const bool tail = k == full;
+                if (tail && tid >= half) break;
+                const int p0 = k * 2 * nt + tid, p1 = p0 + (tail ? half : nt);
+                const bool has1 = p1 < ne;
+                const int q1 = has1 ? p1 : p0;
                 const f4v lg = log4_fin((f4v){QU[p0], QU[q1], 1.0f - Eold[p0], 1.0f - Eold[q1]}, PDP_SP_EPS);
-                x0 = lg.x; x1 = lg.y; y0 = lg.z; y1 = lg.w;
-            } else {                                        // ragged last trip: one slot per lane
-                const f2v lg = log2_fin((f2v){QU[p0], 1.0f - Eold[p0]}, PDP_SP_EPS);
-                x0 = lg.x; y0 = lg.y; x1 = x0; y1 = y0;
-            }
-            if (use_em) {
-                uint16_t c0 = pcc[p0], c1 = pcc[q1];
-                const float em0 = bit15_to_float(c0), em1 = bit15_to_float(c1);
-                x0 = x0 * em0; y0 = y0 * em0; x1 = x1 * em1; y1 = y1 * em1;
-                if (em_dirty) {
-                    pcc[p0] = (uint16_t)((c0 & ~PC_EM_USED) | ((c0 & PC_EM) ? PC_EM_USED : 0));
-                    if (has1) pcc[p1] = (uint16_t)((c1 & ~PC_EM_USED) | ((c1 & PC_EM) ? PC_EM_USED : 0));
+                float x0 = lg.x, x1 = lg.y, y0 = lg.z, y1 = lg.w;
+                if (use_em) {
+                    uint16_t c0 = pcc[p0], c1 = pcc[q1];
+                    const float em0 = bit15_to_float(c0), em1 = bit15_to_float(c1);
+                    x0 = x0 * em0; y0 = y0 * em0; x1 = x1 * em1; y1 = y1 * em1;
+                    if (em_dirty) {
+                        pcc[p0] = (uint16_t)((c0 & ~PC_EM_USED) | ((c0 & PC_EM) ? PC_EM_USED : 0));
+                        if (has1) pcc[p1] = (uint16_t)((c1 & ~PC_EM_USED) | ((c1 & PC_EM) ? PC_EM_USED : 0));
+                    }
                 }
+                X[p0] = x0; Y[p0] = y0;
+                if (has1) { X[p1] = x1; Y[p1] = y1; }
             }
-            X[p0] = x0; Y[p0] = y0;
-            if (has1) { X[p1] = x1; Y[p1] = y1; }
         }
         last_use_em = use_em; em_dirty = 0;
         __syncthreads();
@@ -1529,6 +1570,8 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
             if (!PROF_SKIP(2)) {
                 if (!PROF_SKIP(32)) for (int i = wid; i < nvi; i += nw) var_rows(i);
                 // clause items go to the waves without a variable item (a variable row is several times longer), in contiguous chunks
+                // (letting the wave with the last, nearly empty variable item take clause items too -- 14 items over five waves instead of
+                //  four -- was measured in round 5: +0.9 % on the launch)
                 const int first = (nvi < nw) ? nvi : nw;
                 const int helpers = nw - first;
                 int j_begin, j_end, j_step;
@@ -1541,6 +1584,7 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
                 }
             }
         }
+        if (tid == 0) { s_flag_or[(t + 1) & 1] = 0; s_sat_count = 0; }
         __syncthreads();
         PROF_MARK(2);                                        // R1
         // ---- E2: new survey, new q_u, smooth-max weights -----------------------------------------------------------
@@ -1567,7 +1611,7 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
                 if constexpr (FORCE) same = same + ((force == s) ? L1 : L0);
                 float opp = neg_lit ? pos : neg;
                 if constexpr (FORCE) opp = opp + ((force == -s) ? L1 : L0);
-                const f4v ex = exp4_fin_le30((f4v){agg, same + opp, same, opp});
+                const f4v ex = exp4_sum((f4v){agg, same + opp, same, opp});
                 // mask * new + (1 - mask) * old with mask == 1: (+0) * old + new as ONE fused operation -- the product is an exact zero (or NaN),
                 // so fusing rounds nothing differently; the unfused form is a multiply and an add per slot
                 const float eta_new = __builtin_fmaf(1.0f - 1.0f, eta_old, ex.x);
@@ -1576,7 +1620,6 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
                 const float qu = A * (1.0f - Bv), qs = Bv * (1.0f - A);
                 const float total = (qu + qs) + dc;
                 const float qu_new = __builtin_fmaf(1.0f - 1.0f, QU[p], qu / total);
-                nan_acc = __builtin_fmaf(0.0f, eta_new, nan_acc);  // stays 0 unless a survey is NaN (surveys are <= 1, never infinite)
                 QU[p] = qu_new;
                 Enew[p] = eta_new;
                 if (has_prev) {
@@ -1584,6 +1627,10 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
                     float d = pdp_abs(pe - eta_new);
                     if (use_em) d = d * bit15_to_float(cw);
                     Y[p] = d;                               // the smooth-max weights exp(30 d) are only built when P4 cannot decide without them
+                } else {
+                    // a NaN survey: with a previous survey every slot's |difference| is NaN too and P4's sums flag it (its S1 covers every slot
+                    // of the instance); only the first sweep of a solve without one has to look here
+                    nan_acc = __builtin_fmaf(0.0f, eta_new, nan_acc);  // stays 0 unless a survey is NaN (surveys are <= 1, never infinite)
                 }
             }
         }
@@ -1620,7 +1667,7 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
                     int p = lo;
                     for (; p + 1 < hi; p += 2) {
                         const float e0 = Enew[p], e1 = Enew[p + 1], d0 = Y[p], d1 = Y[p + 1];
-                        emax = fmaxf(emax, fmaxf(e0, e1));           // NaN surveys are flagged in E2 already
+                        emax = fmaxf(emax, fmaxf(e0, e1));           // (a NaN survey is dropped here and caught by S1 below)
                         S1 += d0 + d1; S2 = fmaf(d0, d0, fmaf(d1, d1, S2)); D = fmaxf(D, fmaxf(d0, d1));
                     }
                     if (p < hi) { const float e0 = Enew[p], d0 = Y[p]; emax = fmaxf(emax, e0); S1 += d0; S2 = fmaf(d0, d0, S2); D = fmaxf(D, d0); }
@@ -1635,31 +1682,39 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
                 if (a_v == 1.0f && emax >= 4.76837158203125e-7f * deg) bits |= 8;
                 if (!has_prev) continue;
                 float code = 0.0f;
-                if (S1 != S1) bits |= 4;                    // a NaN survey difference
+                bool bounds = false;
+                if (S1 != S1) bits |= 4;                    // a NaN survey difference (or a NaN survey: E2 leaves that to this test)
                 else if (a_v == 0.0f || D == 0.0f) bits |= (0.0f < tol) ? 2 : (2 | 16);   // smooth max * active == 0 exactly
                 else if (!(D >= 1e-30f)) { bits |= 64; code = 2.0f; }                      // the quotient may round to zero: exact
                 else if (D * 1.0001f < tol_lo) { }                                        // smooth max <= D: below the tolerance
-                else if (D >= 1e-15f) {
-                    // the bounds above, cross-multiplied by D so that no division is needed
-                    const float W = pdp_expf_fin_le30(30.0f * D), Wm1 = W - 1.0f;
-                    const float ubn = fmaf(S2, Wm1, S1 * D), ubd = D * fmaf(30.0f, S1, deg);
-                    const float lbn = D * (fmaf(D, W, S1 - D) + 30.0f * (S2 - D * D)), lbd = fmaf(S1, Wm1, D * deg);
-                    if (lbn * 0.9999f >= tol_hi * lbd) bits |= 16;
-                    else if (!(ubn * 1.0001f < tol_lo * ubd)) { bits |= 32; code = 1.0f; }
-                }
+                else if (S1 * 0.9999f >= tol_hi * deg) bits |= 16;                        // smooth max >= mean (the weights exp(30 d) grow with d): above it, no exp
+                else if (D >= 1e-15f) bounds = true;
                 else { bits |= 32; code = 1.0f; }
+                // One variable that proves "not converged" settles the instance (P5b and the decision only look at the undecided ones when
+                // nobody did), so a wave that holds such a variable skips the bounds of its other variables -- the exp of the bounds is most of
+                // this phase's instructions, and far from convergence nearly every wave holds one.
+                if (__builtin_amdgcn_ballot_w64(bounds) != 0 && __builtin_amdgcn_ballot_w64((bits & 16) != 0) == 0) {
+                    if (bounds) {
+                        // the bounds above, cross-multiplied by D so that no division is needed
+                        const float W = pdp_expf_fin_le30(30.0f * D), Wm1 = W - 1.0f;
+                        const float ubn = fmaf(S2, Wm1, S1 * D), ubd = D * fmaf(30.0f, S1, deg);
+                        const float lbn = D * (fmaf(D, W, S1 - D) + 30.0f * (S2 - D * D)), lbd = fmaf(S1, Wm1, D * deg);
+                        if (lbn * 0.9999f >= tol_hi * lbd) bits |= 16;
+                        else if (!(ubn * 1.0001f < tol_lo * ubd)) { bits |= 32; code = 1.0f; }
+                    }
+                }
                 amb[v] = code;
             }
         }
         PROF_MARK(4);                                        // P4
         // ---- P5: one fused workgroup reduction of the flag bits ------------------------------------------------------------
+        // (one LDS word per sweep parity collects the waves' sets with ds_or: one barrier and one broadcast read, where a slot per wave
+        //  took two barriers and nw reads; the other parity's word is cleared by thread 0 behind this sweep's R1 barrier, after every
+        //  wave has used it -- in the previous sweep -- and before the next sweep's P5)
         bits = wave_or_bits7(bits);
-        if (lane == 0) redi[wid] = bits;
+        if (lane == 0 && bits) atomicOr(&s_flag_or[t & 1], bits);
         __syncthreads();
-        bits = 0;
-        for (int i = 0; i < nw; ++i) bits |= redi[i];
-        __syncthreads();
-        bits = UNI(bits);                                    // workgroup-uniform: keep the control flow scalar
+        bits = UNI(s_flag_or[t & 1]);                        // workgroup-uniform: keep the control flow scalar
         // ---- P5b (rare): exact smooth max of the marked variables (util.py:282-286 + :267-275 with the global min at 0)
         if ((bits & 64) || ((bits & 32) && !(bits & 16))) {
             PROF_COUNT(9);
@@ -1746,16 +1801,17 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
             const int flip = (sp.coins[sp.chunk_start + t] < sp.dprob) && active;
             rf_last_flip = flip;
             if (flip || nsat < 0) {
-                if (UNI(lds_reinforce_step(smem, n, m, ne, cur, pi, flip)) && !nan_seen) violation = 1;    // a NaN score without a NaN survey: not expected
+                if (UNI(lds_reinforce_step(lds_offset_of(smem), lds_offset_of(&s_cold), nt, n, m, ne, cur, pi, flip)) && !nan_seen) violation = 1;    // a NaN score without a NaN survey: not expected
                 rf_changed = 1;
             }
         }
+        PROF_MARK(13);                                       // gate + bookkeeping of every sweep
         // ---- P6: decimation (rare, out of line) ------------------------------------------------------------------------------
         int decimated = 0;
         if (!RF && has_prev && conv && !poisoned && !nan_seen && !PROF_SKIP(16)) {
-            int spec_bits = 0;
-            decimated = UNI(lds_decimate<FORCE>(smem, 0, n, m, ne, cur, active, pi, &s_is_sat, &spec_bits, &simplified));    // (the view's batch id is unused)
-            spec_bits = UNI(spec_bits); simplified = UNI(simplified);
+            const int dr = UNI(lds_decimate<FORCE>(lds_offset_of(smem), lds_offset_of(&s_cold), nt, n, m, ne, cur, active, pi, simplified));
+            decimated = dr & DEC_FIXED; simplified = (dr >> DEC_VERIFIED_SHIFT) & 3;
+            const int spec_bits = (dr >> DEC_SPEC_SHIFT) & 3;
             used |= 4u;
             if (spec_bits & 1) zero |= 4u;
             if (spec_bits & 2) violation = 1;
@@ -1770,26 +1826,63 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
             if (t < SPEC_LOCAL) { s_spec_used[t] = (uint8_t)used; s_spec_zero[t] = (uint8_t)zero; }
             else { atomicOr(&sp.spec_used[t], used); if (zero) atomicOr(&sp.spec_zero[t], zero); }
         }
-        // ---- P7: edge-mask refresh (only changes after a decimation) ------------------------------------------------------
-        if (decimated || !use_em) {
-            const float *const av = L.av, *const af = L.af;
-            for (int p = tid; p < ne; p += nt) {
-                const uint16_t cw = pcc[p];
-                const float a = 0.0f + av[pvv[p] & VM];
-                const float b = 0.0f + af[cw & 0x3fff];
-                const bool em = (a * b) == 1.0f;
-                pcc[p] = (uint16_t)((cw & ~PC_EM) | (em ? PC_EM : 0));
+        // ---- P7: edge-mask refresh (only changes after a decimation) and P8: termination check --------------------------------
+        // (trainer.py:150-162 through SatCNFEvaluator, util.py:226-236: the count of satisfied clauses only changes when `sol` does;
+        //  the two passes share one barrier, and the count's reduction is one DPP sum per wave + one ds_add per wave)
+        {
+            const bool refresh = decimated || !use_em;
+            const bool recount = sp.check_termination && (decimated || rf_changed || nsat < 0);
+            if (refresh) {
+                const float *const av = L.av, *const af = L.af;
+                for (int p = tid; p < ne; p += nt) {
+                    const uint16_t cw = pcc[p];
+                    const float a = 0.0f + av[pvv[p] & VM];
+                    const float b = 0.0f + af[cw & 0x3fff];
+                    const bool em = (a * b) == 1.0f;
+                    pcc[p] = (uint16_t)((cw & ~PC_EM) | (em ? PC_EM : 0));
+                }
+                use_em = 1; em_dirty = 1;
+                PROF_COUNT(17);
             }
-            use_em = 1; em_dirty = 1;
-            __syncthreads();
-        }
-        // ---- P8: termination check ---------------------------------------------------------------------------------------------
-        if (sp.check_termination) {
-            if (decimated || rf_changed || nsat < 0) nsat = UNI((lds_cnf_count<FORCE, RF>(smem, 0, n, m, ne)));
-            if (active && nsat == m) active = 0;
+            PROF_MARK(14);                                   // P7
+            if (recount) {
+                const uint16_t *const e2p = L.e2p, *const f_ptr = L.f_ptr;
+                const float *const sol = L.sol;
+                auto lit = [&](int k) {                      // literal value (s x + (1 - s) / 2) > 0.5, util.py:228-231
+                    const uint16_t pw = pvv[e2p[k]];
+                    const float sg = slot_sign(pw);
+                    float ev = 0.0f + sg * sol[pw & VM];
+                    ev = ev + (1.0f - sg) / 2.0f;
+                    return (ev > 0.5f) ? 1.0f : 0.0f;
+                };
+                int cs = 0;
+                for (int c0 = tid; c0 < m; c0 += 2 * nt) {    // two clauses per trip: the three-level LDS chains of both in flight together
+                    const int c1 = c0 + nt;
+                    const bool has1 = c1 < m;
+                    const int d1 = has1 ? c1 : c0;
+                    const int a0 = f_ptr[c0], b0 = f_ptr[c0 + 1], a1 = f_ptr[d1], b1 = f_ptr[d1 + 1];
+                    if (__builtin_amdgcn_ballot_w64(b0 - a0 != 3 || b1 - a1 != 3) == 0) {
+                        const float t0 = lit(a0), t1 = lit(a0 + 1), t2 = lit(a0 + 2), u0 = lit(a1), u1 = lit(a1 + 1), u2 = lit(a1 + 2);
+                        float cl0 = 0.0f, cl1 = 0.0f;
+                        cl0 = cl0 + t0; cl0 = cl0 + t1; cl0 = cl0 + t2; cl1 = cl1 + u0; cl1 = cl1 + u1; cl1 = cl1 + u2;
+                        cs += ((cl0 > 0.0f) ? 1 : 0) + ((has1 && cl1 > 0.0f) ? 1 : 0);
+                    } else {
+                        float cl0 = 0.0f, cl1 = 0.0f;
+                        for (int k = a0; k < b0; ++k) cl0 = cl0 + lit(k);
+                        if (has1) for (int k = a1; k < b1; ++k) cl1 = cl1 + lit(k);
+                        cs += ((cl0 > 0.0f) ? 1 : 0) + ((has1 && cl1 > 0.0f) ? 1 : 0);
+                    }
+                }
+                cs = wave_reduce(cs, OpAddI(), 0);
+                if (lane == 63 && cs) atomicAdd(&s_sat_count, cs);
+                PROF_COUNT(16);
+            }
+            if (refresh || recount) __syncthreads();
+            if (recount) nsat = UNI(s_sat_count);            // (thread 0 clears the word behind the next sweep's R1 barrier)
+            if (sp.check_termination && active && nsat == m) active = 0;
         }
         has_prev = 1; prev_from_global = 0; cur ^= 1;
-        PROF_MARK(7);                                        // P7 + P8
+        PROF_MARK(15);                                       // P8
     }
 
     // ---- leave: either the instance is finished (inactive, or the loop ends here) and its results go to the caller's arrays,
@@ -1854,10 +1947,10 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
     if (tid == 0) {
         DynHeader h;
         h.active = (uint32_t)active; h.done = finishing ? 1u : 0u; h.perm_zero = (finishing && any_inactive) ? 1u : 0u; h.simplified = (uint32_t)simplified;
-        h.cnt = cnt; h.is_sat = s_is_sat; h.pad1 = 0.0f; h.pad2 = 0.0f;
+        h.cnt = cnt; h.is_sat = s_cold.is_sat; h.nsat_p1 = nsat + 1; h.pad2 = 0.0f;
         *reinterpret_cast<DynHeader *>(dout + BL.hdr) = h;
         const int gb = (LISTED || REPLAY) ? *(volatile int *)&s_inst : G.b;
-        if (finishing) { sp.amask[gb] = (uint8_t)active; sp.counters[gb] = cnt; pv_.is_sat[gb] = s_is_sat; }
+        if (finishing) { sp.amask[gb] = (uint8_t)active; sp.counters[gb] = cnt; pv_.is_sat[gb] = s_cold.is_sat; }
         // left inactive with iterations still to come: k_ghost_check looks at its frozen state after the call (see d_ghost_bad)
         if (finishing && !active && !(sp.final_chunk && iters >= T)) sp.ghost_flag[gb] = 1;
         if (any_inactive) atomicMin(&ctl->perm_zero, (uint32_t)iters);
@@ -1951,7 +2044,7 @@ __global__ void __launch_bounds__(256) k_solve_import(PView pv, const float *q, 
         DynHeader h;
         h.active = amask[G.b] ? 1u : 0u; h.done = h.active ? 0u : 1u;      // an instance that enters inactive never runs: nothing to write back
         h.perm_zero = (h.done && any_inactive) ? 1u : 0u; h.simplified = 0;
-        h.cnt = counters[G.b]; h.is_sat = pv.is_sat[G.b]; h.pad1 = 0.0f; h.pad2 = 0.0f;
+        h.cnt = counters[G.b]; h.is_sat = pv.is_sat[G.b]; h.nsat_p1 = 0; h.pad2 = 0.0f;
         *reinterpret_cast<DynHeader *>(dy + BL.hdr) = h;
     }
 }
@@ -2080,7 +2173,7 @@ __global__ void __launch_bounds__(256) k_simplify_lds(PView pv)
     for (int c = tid; c < m; c += nt) af[c] = G.af[c];
     __syncthreads();
     LView I;
-    I.b = G.b; I.n = n; I.m = m; I.e = ne;
+    I.b = G.b; I.n = n; I.m = m; I.e = ne; I.nt = nt; I.red = redi;
     I.e_var.pv = pvv; I.e_var.mask = 0x3fff; I.e_fn.pc = pcc; I.sgn.pv = pvv; I.f_edges = e2p; I.v_ptr = v_ptr; I.f_ptr = f_ptr;
     I.av = av; I.af = af; I.sol = sol;
     SimplifyScratch ss;

@@ -8,7 +8,7 @@ NAME=$1; EXTRA=$2; shift 2 || true
 FILES=${@:-pdp_neural.hip}
 B=/tmp/pdp_variant_$NAME; rm -rf $B; mkdir -p $B
 OBJS=""
-for f in pdp_problem pdp_ops pdp_walksat pdp_solve pdp_neural pdp_train pdp_dimacs; do
+for f in pdp_problem pdp_ops pdp_walksat pdp_solve pdp_neural pdp_train pdp_dimacs pdp_coo; do
     if echo " $FILES " | grep -q " $f.hip "; then
         /opt/rocm/bin/hipcc $EXTRA -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function -Wno-unused-result -Wno-pass-failed -I$C -c $C/$f.hip -o $B/$f.o
         OBJS="$OBJS $B/$f.o"
