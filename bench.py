@@ -15,7 +15,9 @@ rank and WORLD_SIZE must equal --gpus.  Rank 0 prints ONE JSON line.
 
 At N = 1 the line also carries, outside the headline's timed loop: `cpu_baseline` (the C oracle over all host cores at the full batch;
 `cpu_baseline_torch_sparse`: the PyTorch-CPU restatement of the reference's sparse-mm formulation) and `config.secondary`
-(configs[2]'s neural kernels with per-kernel rooflines, Walk-SAT, the Reinforce solver)."""
+(configs[2]'s neural kernels with per-kernel rooflines, Walk-SAT, the Reinforce solver).  The nested objects do not survive the driver's
+record (it keeps the scalars of `config` and the last 8 KB of stdout): `benchlib.secondary.driver_summary` repeats every BASELINE config's
+figures as flat scalars in `config` and, as `summary`, at the end of the line.  Helpers: tools/benchlib/."""
 
 import argparse
 import json
@@ -27,15 +29,13 @@ import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(REPO, 'pdp-solver_amd'))
+sys.path.insert(0, os.path.join(REPO, 'tools'))
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 vector peak
-N_SIMD, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, 2.4 GHz
-
-
-def algorithmic_bytes_per_iteration(E, V, F):
-    "SURVEY.md section 8(d): streaming model of one SP iteration, 41 B/edge + 36 B/variable + 8 B/clause"
-    return 41 * E + 36 * V + 8 * F
+from benchlib import HBM_PEAK_GBS, N_SIMD, CLOCK_HZ, algorithmic_bytes_per_iteration, grouped       # noqa: E402
+from benchlib.cpu_baselines import cpu_baseline_all_cores, cpu_baseline_torch_sparse                  # noqa: E402
+from benchlib.neural import bench_neural                                                              # noqa: E402
+from benchlib.secondary import (fast_build_measurement, secondary_measurements, config_shard_measurements, big_instance_measurements,   # noqa: E402
+                                solved_fractions, driver_summary)
 
 
 # =====================================================================================================================
@@ -65,13 +65,6 @@ def launch_ranks(n, argv):
         return 1
     print(lines[-1])
     return 0
-
-
-def grouped():
-    """Does this process join a torch.distributed group?  Always with several ranks; with ONE rank only on request (PDP_DIST_FORCE=1 under
-    torch.distributed.run --nproc-per-node 1): the barrier and the two all-reduces then go through RCCL on a one-GPU box exactly as they
-    do on eight, and the line says rccl_ranks = 1 with the backend that ran."""
-    return int(os.environ.get('WORLD_SIZE', '1')) > 1 or (os.environ.get('PDP_DIST_FORCE') == '1' and 'RANK' in os.environ)
 
 
 def init_ranks(args):
@@ -122,713 +115,6 @@ def selftest_collective(args):
                           'rank_sum': float(stats[1].item()), 'max_elapsed_s': elapsed}))
     if grouped():
         dist.destroy_process_group()
-
-
-# =====================================================================================================================
-# CPU baselines (rank 0, N = 1; run BEFORE the GPU is touched: the oracle workers are forked)
-# =====================================================================================================================
-_CPU_ITEMS = None
-
-
-def _oracle_worker(job):
-    lo, hi, iters, tol, t_max = job
-    from oracle import binding
-    from pdp.factorgraph import dataset
-    b = dataset.collate_segment(_CPU_ITEMS[lo:hi])
-    p = binding.Problem(b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'])
-    res = p.forward('p-d-p', iters, local_search_iterations=0, tolerance=tol, t_max=t_max, seed=1)
-    return (hi - lo) * res['iterations_run']
-
-
-def effective_cores():
-    """host cores this process may really use: min(os.cpu_count(), the scheduler affinity mask, the cgroup CPU quota).  On the GPU boxes of
-    this pool os.cpu_count() reports every hardware thread of the host (256) while the container's quota is far smaller; worker pools and
-    torch thread counts sized by cpu_count() then oversubscribe and run many times slower than one thread per usable core."""
-    n = os.cpu_count() or 1
-    try:
-        n = min(n, len(os.sched_getaffinity(0)))
-    except (AttributeError, OSError):
-        pass
-    quota = None
-    try:
-        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]                      # cgroup v2
-        if q != 'max':
-            quota = float(q) / float(per)
-    except (OSError, ValueError):
-        try:
-            q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read()); per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
-            if q > 0:
-                quota = q / per
-        except (OSError, ValueError):
-            pass
-    if quota is not None:
-        n = min(n, max(1, int(quota + 0.5)))
-    return max(1, n)
-
-
-def cpu_model_name():
-    try:
-        for l in open('/proc/cpuinfo'):
-            if l.startswith('model name'):
-                return l.split(':', 1)[1].strip()
-    except OSError:
-        pass
-    return 'unknown'
-
-
-def cpu_baseline_all_cores(args, items):
-    """The C oracle (single-threaded restatement of the reference's algorithm, oracle/pdp_oracle.c) on EVERY host core: the full batch of
-    the headline workload cut into one contiguous sub-batch per worker process, every sub-batch run for the full T iterations.  (Each
-    sub-batch is a batch of its own for the reference's batch-wide couplings; this is a throughput baseline.)"""
-    import multiprocessing as mp
-    global _CPU_ITEMS
-    sys.path.insert(0, REPO)
-    from oracle import binding
-    binding.build()
-    cores = effective_cores()
-    if args.cpu_cores:
-        cores = min(cores, args.cpu_cores)
-    B = len(items) if args.cpu_full_batch else min(len(items), args.cpu_sample_batch)
-    _CPU_ITEMS = items[:B]
-    workers = min(cores, B)
-    bounds = [(B * w) // workers for w in range(workers + 1)]
-    jobs = [(bounds[w], bounds[w + 1], args.iters, args.tolerance, args.t_max) for w in range(workers)]
-    ctx = mp.get_context('fork')
-    with ctx.Pool(workers) as pool:
-        pool.map(_oracle_worker, [(0, 1, 1, args.tolerance, args.t_max)] * workers)       # start the workers, load the library
-        t0 = time.perf_counter()
-        done = pool.map(_oracle_worker, jobs, chunksize=1)
-        dt = time.perf_counter() - t0
-    _CPU_ITEMS = None
-    inst_iters = float(sum(done)) / dt
-    return dict(value=inst_iters / args.batch, unit='iterations/s (batch of %d instances)' % args.batch, cores=workers, kind='port',
-                cpu_model=cpu_model_name(), host_hardware_threads=os.cpu_count(),
-                sample='the oracle on %d worker processes (one per usable host core: min of cpu_count %d, affinity, cgroup quota), %d instances x '
-                       '%d iterations of the headline batch in %.2f s (%.0f instance-iterations/s)%s'
-                       % (workers, os.cpu_count() or 1, B, args.iters, dt, inst_iters, '' if B == args.batch else ', scaled linearly to the batch'))
-
-
-def cpu_baseline_torch_sparse(args, items):
-    """The reference's own formulation on the CPU: sparse COO masks + torch.mm + the dense [V x B] matrices of sparse_max / sparse_argmax
-    (oracle/torch_sparse_port.py, an own restatement of the op sequence; the reference itself cannot travel to this box), with
-    torch.set_num_threads(all cores) as src/pdp/factorgraph/base.py:43-50 does.  B = 500 for 3 iterations, then the full batch: its cost is
-    quadratic in B (20 GB dense matrix per reduction at B = 5000), so the full batch runs 2 iterations and the second one -- the first with
-    a convergence test -- is the per-iteration figure."""
-    import torch
-    sys.path.insert(0, REPO)
-    from oracle import torch_sparse_port as port
-    from pdp.factorgraph import dataset
-    cores = effective_cores()
-    if args.cpu_cores:
-        cores = min(cores, args.cpu_cores)
-    torch.set_num_threads(cores)
-    out = dict(unit='iterations/s (batch of B instances)', cores=cores, kind='port', cpu_model=cpu_model_name(), runs=[])
-    def mem_available_gb():
-        try:
-            for l in open('/proc/meminfo'):
-                if l.startswith('MemAvailable'):
-                    return float(l.split()[1]) / 1e6
-        except OSError:
-            pass
-        return 0.0
-
-    for B, T in ((500, 3), (args.batch, 2)):
-        if B > len(items) or (B > 500 and not args.cpu_full_batch):
-            continue
-        need_gb = 3.0 * 4e-9 * B * (B * args.n)                     # three live dense [V x B] fp32 matrices at the worst point
-        if B > 500 and mem_available_gb() < need_gb + 16.0:
-            out['skipped'] = 'B=%d needs ~%.0f GB of host memory for the dense [V x B] matrices (%.0f GB available)' % (B, need_gb, mem_available_gb())
-            continue
-        b = dataset.collate_segment(items[:B])
-        t0 = time.perf_counter()
-        P = port.SparseBatch(b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'])
-        with torch.no_grad():
-            P.simplify()
-            setup = time.perf_counter() - t0
-            times = []
-            # the full batch stops after the first iteration when set-up + that iteration exceed the budget of the default run (the
-            # steady-state iterations add the convergence test: two more dense [V x B] reductions each)
-            port.forward_loop(P, T, tolerance=args.tolerance, t_max=args.t_max, simplify=False, times=times,
-                              max_seconds=None if B <= 500 else max(0.0, args.cpu_torch_budget_s - setup))
-        steady = times[1:] if len(times) > 1 else times
-        per_iter = float(np.mean(steady))
-        out['runs'].append(dict(B=B, iterations=len(times), seconds_per_iteration=per_iter, first_iteration_s=times[0], setup_s=setup,
-                                iterations_per_s=1.0 / per_iter, instance_iterations_per_s=B / per_iter))
-        del P
-    if out['runs']:
-        last = out['runs'][-1]
-        out['value'] = last['iterations_per_s'] * last['B'] / float(args.batch) if last['B'] != args.batch else last['iterations_per_s']
-        out['sample'] = 'torch sparse-mm restatement, %d threads: ' % cores + '; '.join(
-            'B=%d: %.2f s per iteration (%d iterations run)' % (r['B'], r['seconds_per_iteration'], r['iterations']) for r in out['runs'])
-    return out
-
-
-def cpu_baseline_neural(args):
-    """The oracle's operators of one np-nd-np iteration (2 edge aggregators, 2 GRU cells, predictor aggregator + head), single thread,
-    on a few instances of the same family with random weights of the same shapes; scaled linearly to the batch."""
-    sys.path.insert(0, REPO)
-    from oracle import binding
-    from pdp.factorgraph import dataset
-    binding.build()
-    H = args.hidden
-    bs = max(1, min(400, args.batch, int(400 * 200 / max(1, args.n))))       # ~1 M edges however large the instances are (400 instances at n = 200)
-    b = dataset.collate_segment(dataset.random_ksat_items(bs, args.n, 3, m=int(round(4.2 * args.n)), seed=777))
-    gm = np.asarray(b['graph_map']); ev, ec = gm[0].astype(np.int32), gm[1].astype(np.int32)
-    es = np.asarray(b['edge_feature'], dtype=np.float32).reshape(-1)
-    E, V, F = ev.size, int(np.asarray(b['batch_variable_map']).size), int(np.asarray(b['batch_function_map']).size)
-    rng = np.random.RandomState(1)
-    r = lambda *sh: (rng.randn(*sh) * 0.2).astype(np.float32)
-    agg = lambda fd: dict(W1m=r(100, H + 1), b1m=r(100), W2m=r(50, 100), W1a=r(100, 50 + fd), b1a=r(100), W2a=r(H, 100))
-    wv, wf, wp = agg(1), agg(1), agg(0)
-    gv = dict(W_ih=r(3 * H, H + 1), W_hh=r(3 * H, H), b_ih=r(3 * H), b_hh=r(3 * H)); gf = dict(gv)
-    head = (r(50, H), r(50), r(1, 50))
-    dv, df, pv, pf = r(E, H), r(E, H), r(E, H), r(E, H)
-    t0 = time.perf_counter()
-    pf2 = binding.aggregator(ev, V, dv, es, None, False, wv); pv2 = binding.aggregator(ec, F, df, es, None, False, wf)
-    dv2 = binding.gru(pv2, es, dv, **gv); df2 = binding.gru(pf2, es, df, **gf)
-    binding.perceptron(binding.aggregator(ev, V, dv2, es, None, True, wp), *head)
-    dt = time.perf_counter() - t0
-    return dict(value=bs / dt / args.batch, unit='iterations/s (batch of %d instances)' % args.batch, cores=1, kind='port',
-                sample='one np-nd-np iteration (2 aggregators, 2 GRU cells, predictor) of %d instances of the same n=%d family, hidden %d, '
-                       'in %.1f s, scaled linearly to the batch' % (bs, args.n, H, dt))
-
-
-# =====================================================================================================================
-# configs[2]: the neural workload (standalone with --workload neural, and as a short secondary measurement of the default run)
-# =====================================================================================================================
-# MACs per edge / per variable of the kernels of one neural iteration at hidden H, inner widths 100 / 50 / 100 (SURVEY.md 8(d))
-def neural_flops(H, model_type='np-nd-np'):
-    "flop per launch unit: per EDGE for agg_pre / agg_post / gru (one cell), per VARIABLE for predict_head"
-    gru_in = 2.0 * (3 * H * (H + 1) + 3 * H * H)                      # np-nd-np: [state, sign] -> 129 inputs at H = 128
-    if model_type == 'p-nd-np':                                       # surveys + sign / [eta, force] + sign: 4- and 3-wide inputs, mean of the two cells
-        gru_in = 2.0 * (3 * H * 3.5 + 3 * H * H)
-    return dict(agg_pre=2.0 * ((H + 1) * 100 + 100 * 50),            # W1_m, W2_m
-                agg_post=2.0 * (51 * 100 + 100 * H),                 # W1_a, W2_a
-                gru=gru_in,                                          # W_ih, W_hh of ONE cell
-                predict_head=2.0 * (50 * 100 + 100 * H + H * 50 + 50))    # predictor's W1_a, W2_a + perceptron head
-
-
-def neural_flop_per_iteration(model_type, H, E, V):
-    """algorithmic flop of one iteration (573 752 E + 48 500 V for np-nd-np at H = 128).  np-nd-np: two edge aggregators, two GRU
-    cells, the predictor's pre-transform + per-variable layers.  p-nd-np: the propagator is the SP sweep (no matrix work) behind three
-    H-long dot products per edge (the adaptors), GRU cells with 4- and 3-wide inputs, the same predictor."""
-    fl = neural_flops(H, model_type)
-    if model_type == 'np-nd-np':
-        per_edge = 2 * (fl['agg_pre'] + fl['agg_post']) + 2 * fl['gru'] + fl['agg_pre']
-    else:
-        per_edge = 2.0 * 3 * H + 2 * fl['gru'] + fl['agg_pre']
-    return per_edge * E + fl['predict_head'] * V
-
-
-def make_neural_model(args, T, model_type='np-nd-np', hidden=None):
-    import logging
-    import torch
-    from pdp.trainer import SatFactorGraphTrainer
-    cfg = dict(model_type=model_type, model_name='bench-' + model_type, verbose=False, local_search_iteration=0, epsilon=0.5, rng='philox',
-               random_seed=1, hidden_dim=hidden or args.hidden, edge_feature_dim=1, meta_feature_dim=0, prediction_dim=1, mem_hidden_dim=100,
-               agg_hidden_dim=100, mem_agg_hidden_dim=50, classifier_dim=50, test_batch_limit=1 << 62, batch_size=args.batch,
-               test_recurrence_num=T, tolerance=args.tolerance, t_max=args.t_max)
-    torch.manual_seed(1234)
-    tr = SatFactorGraphTrainer(cfg, use_cuda=True, logger=logging.getLogger('bench'))
-    return tr, tr._model_list[0]
-
-
-def neural_step(tr, model, b, T, replication=1):
-    import torch
-    from pdp.nn.solver import OwnedState
-    gm, bvm, bfm, ef = b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature']
-    with torch.no_grad():
-        # exactly what FactorGraphTrainerBase._predict_batch does: the initial state is handed over, not kept
-        model.forward(init_state=OwnedState(model.get_init_state(gm, bvm, bfm, ef, None, randomized=False, batch_replication=replication)),
-                      graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None,
-                      is_training=False, iteration_num=T, check_termination=tr._check_recurrence_termination, batch_replication=replication)
-    return model.last_run['iterations']
-
-
-def neural_kernel_rooflines(native, timing, E, V, H, model_type='np-nd-np'):
-    """per-kernel lines from the library's HIP events: ms per launch, algorithmic flop per launch, TFLOP/s, fraction of the fp32 MFMA peak.
-    E / V: edges / variables one launch covers (summed over launches when segments differ: pass the launch-weighted means).  The kernel
-    names are what the library reports it launched last (pdp_kernel_name), not literals."""
-    fl = neural_flops(H, model_type)
-    out = {}
-    for key in ('agg_pre', 'agg_post', 'gru', 'predict_head', 'row_sum', 'sp_adaptors', 'sp_sweep'):
-        ms, n = timing[key]
-        if n == 0:
-            continue
-        per = ms / n
-        row = dict(kernel=native.kernel_name(key), launches=n, ms_per_launch=per)
-        if key == 'sp_adaptors':                          # HBM-bound: the two [E, H] decimator states read once
-            gbs = 2.0 * E * H * 4 / (per * 1e-3) / 1e9
-            row.update(bytes_per_launch=2.0 * E * H * 4, gb_per_s=gbs, frac_of_hbm_peak=gbs / HBM_PEAK_GBS)
-        if key in fl:
-            flop = fl[key] * (V if key == 'predict_head' else E)
-            tf = flop / (per * 1e-3) / 1e12
-            row.update(flop_per_launch=flop, tflops=tf, frac_of_mfma_f32_peak=tf / MFMA_F32_PEAK_TFLOPS)
-        out[key] = row
-    if 'agg_pre' in out and 'agg_post' in out:
-        # one MessageAggregator call of the propagator = pre + row sum + post (the pre launches also serve the predictor: per launch figures)
-        ms = out['agg_pre']['ms_per_launch'] + out['agg_post']['ms_per_launch'] + out.get('row_sum', {}).get('ms_per_launch', 0.0)
-        tf = (fl['agg_pre'] + fl['agg_post']) * E / (ms * 1e-3) / 1e12
-        out['aggregator_call'] = dict(ms=ms, tflops=tf, frac_of_mfma_f32_peak=tf / MFMA_F32_PEAK_TFLOPS)
-    return out
-
-
-def neural_shard(args, dev, native, items, model_type, hidden, T, replication=1, limit=None, walksat_steps=0, workload=''):
-    """One rank's share of a neural BASELINE config on this GPU, outside the headline's timed loop: the loader's dynamic segments (dataset.divide
-    with the reference's edge x hidden limit), T sweeps of the model per segment through the Python API (warm-up pass first), then the
-    Walk-SAT pass on the last segment's problem.  Returns the numbers every fraction is computed from."""
-    import torch
-    from pdp.factorgraph import dataset
-    edges = [it[2].shape[1] for it in items]
-    segs = dataset.divide(edges, (limit or (1 << 62)) // replication, hidden)
-    tr, model = make_neural_model(args, T, model_type, hidden)
-    batches = [dataset.to_torch(dataset.collate_segment([items[j] for j in seg]), dev) for seg in segs]
-    E_seg = [int(b['graph_map'].size(1)) * replication for b in batches]
-    V_seg = [int(b['batch_variable_map'].numel()) * replication for b in batches]
-    for b in batches:                                                  # warm-up: the same pass once (native workspaces, torch's caching allocator)
-        neural_step(tr, model, b, T, replication)
-    # best of two timed passes: at 25 M edges every [E, 128] state is 12.9 GB and torch's caching allocator may still release and re-acquire
-    # blocks in the first pass after the warm-up (a forward then takes 2-3 x its steady-state time; tools/neural_forward_phases.py)
-    dt, its, timing = None, None, None
-    torch.cuda.reset_peak_memory_stats()
-    for _ in range(2):
-        torch.cuda.synchronize()
-        native.kernel_timing(True)
-        t0 = time.perf_counter()
-        its_ = [neural_step(tr, model, b, T, replication) for b in batches]
-        torch.cuda.synchronize()
-        dt_ = time.perf_counter() - t0
-        timing_ = native.kernel_timing_read(); native.kernel_timing(False)
-        if dt is None or dt_ < dt:
-            dt, its, timing = dt_, its_, timing_
-    flop = sum(neural_flop_per_iteration(model_type, hidden, e, v) * it for e, v, it in zip(E_seg, V_seg, its))
-    tf = flop / dt / 1e12
-    n_seg = float(len(segs))
-    out = dict(workload=workload, model_type=model_type, hidden=hidden, instances=len(items), batch_replication=replication,
-               segments=[len(sg) for sg in segs], edges_per_segment_with_replicas=E_seg, iterations_per_segment=its, seconds=dt,
-               segment_iterations_per_sec=sum(its) / dt, ms_per_iteration_mean=1e3 * dt / max(1, sum(its)), flop_total=flop,
-               flop_per_iteration_mean=flop / max(1, sum(its)), path=model.last_run['path'],
-               # device memory of the timed passes: torch's allocator (the [E, H] states; the library's own workspaces are not in it)
-               max_memory_reserved_gb=torch.cuda.max_memory_reserved() / 1e9, max_memory_allocated_gb=torch.cuda.max_memory_allocated() / 1e9,
-               state_tensor_gb=max(E_seg) * hidden * 4 / 1e9,
-               roofline=dict(bound='mfma', achieved=tf, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s', frac=tf / MFMA_F32_PEAK_TFLOPS,
-                             note='algorithmic flop of the executed sweeps (neural_flop_per_iteration per segment) / wall time of the forwards, '
-                                  'set-up of each SATProblem included'),
-               kernels=neural_kernel_rooflines(native, timing, sum(E_seg) / n_seg, sum(V_seg) / n_seg, hidden, model_type))
-    if walksat_steps > 0:
-        prob = model._last_problem._native
-        prob.random_fill(seed=4321)
-        start = prob.solution.clone()
-        prob.local_search(start, 2, 0.5, seed=5)
-        torch.cuda.synchronize()
-        native.kernel_timing(True)
-        t0 = time.perf_counter()
-        res, steps = prob.local_search(start, walksat_steps, 0.5, seed=999)
-        torch.cuda.synchronize()
-        dtw = time.perf_counter() - t0
-        kms, kn = native.kernel_timing_read()['walksat']; native.kernel_timing(False)
-        out['walksat'] = dict(steps=steps, instances_with_replicas=prob.B, call_seconds=dtw, kernel=native.kernel_name('walksat'), kernel_ms=kms,
-                              kernel_launches=kn, flips_per_sec=steps * prob.B / dtw, us_per_step=1e6 * dtw / max(1, steps))
-    del tr, model, batches
-    torch.cuda.empty_cache()
-    return out
-
-
-def train_measurement(args, dev, native):
-    """one optimizer step (`_train_batch`, base.py:149-182) per model type that trains, on a ~1 M-edge batch at hidden 128 --
-    3 outer recurrences, random initial states and dropout 0.2 from the device generator, clipped Adam step.  flop = 3 x the forward's algorithmic flop (the adjoint
-    of every dense layer is two products of the forward's size) x recurrences; the fraction is against the fp32 MFMA peak."""
-    import logging
-    import torch
-    import torch.optim as optim
-    from pdp.factorgraph import dataset
-    from pdp.trainer import SatFactorGraphTrainer
-    bt = args.train_batch
-    items = dataset.random_ksat_items(bt, args.n, 3, m=int(round(4.2 * args.n)), seed=555)
-    b = dataset.to_torch(dataset.collate_segment(items), dev)
-    gm, bvm, bfm, ef = b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature']
-    label = torch.ones(bt, 1, device=dev)
-    E, V = int(gm.size(1)), int(bvm.numel())
-    out = {}
-    for mt in ('np-nd-np', 'p-nd-np'):
-        cfg = dict(model_type=mt, model_name='bench-train-' + mt, verbose=False, dropout=0.2, error_dim=3, exploration=0.1, hidden_dim=128,
-                   local_search_iteration=0, epsilon=0.5, tolerance=0.02, t_max=100, edge_feature_dim=1, meta_feature_dim=0, prediction_dim=1,
-                   mem_hidden_dim=100, agg_hidden_dim=100, mem_agg_hidden_dim=50, classifier_dim=50, loss_sharpness=5, randomized=True,
-                   train_inner_recurrence_num=1, train_outer_recurrence_num=3, clip_norm=0.65, batch_size=bt, rng='philox', random_seed=0, init_rng='device')
-        cfg['lambda'] = 0.9
-        torch.manual_seed(99)
-        tr = SatFactorGraphTrainer(cfg, use_cuda=True, logger=logging.getLogger('bench'))
-        opt = optim.Adam(tr.get_parameter_list(), lr=1e-4, weight_decay=1e-10)
-        total = np.zeros(1, dtype=np.float32)
-        times = []
-        for rep in range(3):
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            tr._train_batch(total, opt, gm, bvm, bfm, ef, None, label)
-            torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
-        dt = min(times[1:])
-        flop = 3.0 * 3 * neural_flop_per_iteration(mt, 128, E, V)
-        tf = flop / dt / 1e12
-        out[mt] = dict(seconds_per_train_batch=dt, first_call_seconds=times[0], flop=flop, tflops=tf, frac_of_mfma_f32_peak=tf / MFMA_F32_PEAK_TFLOPS,
-                       loss_finite=bool(np.isfinite(total).all()))
-        del tr, opt
-        torch.cuda.empty_cache()
-    out['workload'] = ('_train_batch: %d instances of n=%d (%d edges), hidden 128, 3 outer recurrences, dropout 0.2, clipped Adam step; '
-                       'flop = 3 x forward flop x recurrences' % (bt, args.n, E))
-    return out
-
-
-def config4_items(count, seed0=1000):
-    "BASELINE configs[4]'s family (SURVEY 8(d)): k in {3,4,5} per instance, alpha_k = 0.9 x (4.27, 9.93, 21.12), n ~ U{100..500}"
-    from pdp.factorgraph import dataset
-    rng = np.random.RandomState(0)
-    alpha = {3: 0.9 * 4.27, 4: 0.9 * 9.93, 5: 0.9 * 21.12}
-    items = []
-    for i in range(count):
-        k = int(rng.choice([3, 4, 5])); n = int(rng.randint(100, 501))
-        items += dataset.random_ksat_items(1, n, k, m=int(round(alpha[k] * n)), seed=seed0 + i)
-    return items
-
-
-def bench_neural(args, dev, rank, world):
-    """configs[2]: fully neural PDP (np-nd-np, hidden_dim 128, layer widths 100/100/50/50) on random 3-SAT n=200.
-    A step = T iterations of propagate (2 deep-set aggregators) / decimate (2 GRU cells) / predict / terminate on a resident
-    batch with seeded random-init weights (the reference ships none).  SURVEY.md 8(d): 573 752 flop per edge and
-    48 500 per variable and iteration, all in fp32 MFMA."""
-    import torch
-    from pdp import native
-    from pdp.factorgraph import dataset
-    T = args.iters
-    m_cl = int(round(4.2 * args.n))
-    items = dataset.random_ksat_items(args.batch, args.n, 3, m=m_cl, seed=1000003 * rank)
-    b = dataset.to_torch(dataset.collate_segment(items), dev)
-    tr, model = make_neural_model(args, T)
-    E, V, F = b['graph_map'].size(1), b['batch_variable_map'].numel(), b['batch_function_map'].numel()
-    iters_done, step_ms = [], []
-
-    def step(record):
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        it = neural_step(tr, model, b, T)
-        torch.cuda.synchronize()
-        if record:
-            step_ms.append(1e3 * (time.perf_counter() - t0)); iters_done.append(it)
-
-    for _ in range(args.warmup):
-        step(False)
-    if grouped():
-        import torch.distributed as dist
-        dist.barrier()
-    native.kernel_timing(True)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    timing = native.kernel_timing_read(); native.kernel_timing(False)
-    tot = torch.tensor([float(sum(iters_done)), elapsed], dtype=torch.float64, device=args.coll_dev)
-    ranks = 1
-    if grouped():
-        import torch.distributed as dist
-        dist.barrier()
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=args.coll_dev); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        ranks = dist.get_world_size()
-    if rank == 0:
-        iters_all = float(tot[0].item())
-        value = iters_all / elapsed
-        cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline_neural(args)
-        flops_iter = neural_flop_per_iteration('np-nd-np', args.hidden, E, V)
-        achieved = flops_iter * float(np.mean(iters_done)) / (float(np.mean(step_ms)) * 1e-3) / 1e12
-        print(json.dumps({
-            'metric': 'pdp_iterations_per_sec', 'value': value,
-            'unit': 'iterations/s (each iteration sweeps a batch of %d instances)' % args.batch, 'n_gpus': world, 'rccl_ranks': ranks, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': "configs[2]: 'np-nd-np' hidden_dim=%d (100/100/50/50), random 3-SAT n=%d m=%d batch=%d T=%d per GPU, "
-                                   "seeded random-init weights" % (args.hidden, args.n, m_cl, args.batch, T),
-                       'E': E, 'V': V, 'F': F, 'iterations_per_step': float(np.mean(iters_done)), 'path': model.last_run['path'],
-                       'instance_iterations_per_sec': value * args.batch, 'parallelism': 'instances sharded, dp%d' % world},
-            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / MFMA_F32_PEAK_TFLOPS,
-                         'traffic': None, 'kernel': ' / '.join(native.kernel_name(k) for k in ('gru', 'agg_pre', 'agg_post')) + ' (v_mfma_f32_32x32x2_f32)',
-                         'kernels': neural_kernel_rooflines(native, timing, E, V, args.hidden),
-                         'note': 'achieved = neural_flop_per_iteration (573752 E + 48500 V at hidden 128) x iterations / step time (whole step, all kernels); '
-                                 'kernels: HIP events of the library around every launch, flop = the MACs of that kernel x 2'},
-            'cpu_baseline': cpu}))
-    if grouped():
-        import torch.distributed as dist
-        dist.destroy_process_group()
-
-
-def fast_build_measurement(args, dev, native, host_batch, items, parity_solved):
-    """The headline step loop once more on the opt-in fast build (libpdp_hip_fast.so: device math on v_exp_f32 / v_log_f32 / v_rcp_f32;
-    gated by the reference-held fixtures only, tests/test_fast_build_gpu.py) -- the same --warmup / --steps on the same resident batch --
-    and configs[2]'s neural iteration on it.  Reported next to the line's `value`, which is always the parity build's.  Runs last:
-    every handle of the parity library is gone by then (a handle belongs to the library that made it)."""
-    import torch
-    from pdp.factorgraph import dataset
-    out = {'build': 'libpdp_hip_fast.so (PDP_BUILD=fast / pdp.native.use_build)', 'gate': 'tests/test_fast_build_gpu.py'}
-    previous = native.use_build('fast')
-    try:
-        b = dataset.to_torch(host_batch, dev)
-        prob = native.Problem(b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'], batch_size=args.batch)
-        E, V, F, B = prob.E, prob.V, prob.F, prob.B
-        L = native.lib()
-        launches, iters_done = [], []
-
-        def step(record):
-            q = torch.full((E, 3), 1.0, device=dev); q.div_(3.0)
-            fs = torch.zeros(E, 2, device=dev); fs[:, 0] = 0.5
-            am = torch.ones(B, dtype=torch.uint8, device=dev); dec = native.Decimator(prob)
-            native.check(L.pdp_problem_bind_state(prob._h, native.ptr(prob.active_variables), native.ptr(prob.active_functions), native.ptr(prob.solution),
-                                                  native.ptr(prob.is_sat), native.ptr(prob.edge_mask), native._stream()))
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            prob.simplify()
-            it, _ = prob.sp_solve(q, fs, am, dec, args.iters, args.tolerance, args.t_max, time_kernels=True, isolate_instances=args.isolated, inputs_disposable=True)
-            torch.cuda.synchronize()
-            if record:
-                launches.append((time.perf_counter() - t0, dict(prob.last_solve_stats))); iters_done.append(it)
-        for _ in range(args.warmup):
-            step(False)
-        for _ in range(args.steps):
-            step(True)
-        elapsed = sum(t for t, _ in launches)
-        n_launch = float(np.mean([l['launches'] for _, l in launches]))
-        launch_ms = float(np.mean([l['solve_kernel_ms'] for _, l in launches])) / n_launch
-        bytes_launch = algorithmic_bytes_per_iteration(E, V, F) * float(np.mean(iters_done)) / n_launch
-        prob.random_fill(seed=12345)
-        res, _ = prob.local_search(prob.solution.clone(), args.walksat, 0.5, seed=999)
-        pred = prob.update_solution(res.reshape(-1).contiguous())
-        solved, unsat = prob.cnf_eval(pred.reshape(-1).contiguous())
-        out.update(value=float(sum(iters_done)) / elapsed, ms_per_step=1e3 * elapsed / args.steps, kernel=native.kernel_name('sp_solve'),
-                   kernel_ms_per_launch=launch_ms, roofline_frac=bytes_launch / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                   solved_fraction=float(solved.sum().item()) / B, solved_fraction_parity_build=parity_solved,
-                   unsat_clauses_total=float(unsat.sum().item()),
-                   note='per-step time here is the host clock around bind + simplify + solve of each step (initial states built outside it)')
-        del prob, b
-        torch.cuda.empty_cache()
-        if not args.no_secondary:
-            try:
-                out['neural'] = neural_shard(args, dev, native, items, 'np-nd-np', args.hidden, args.secondary_neural_iters,
-                                             workload="configs[2] on the fast build: 'np-nd-np' hidden %d, same batch" % args.hidden)
-            except Exception as ex:                          # measurement only: never take the headline line down
-                out['neural'] = dict(error=repr(ex))
-    finally:
-        torch.cuda.empty_cache()
-        native.use_build(previous)
-    return out
-
-
-def secondary_measurements(args, dev, b, prob, native, items):
-    """Outside the headline's timed loop (rank 0, N = 1): the other hot kernels on the same resident batch, each with the numbers its
-    roofline fraction is computed from -- configs[2]'s neural iteration (3 sweeps), 1 000 Walk-SAT steps, the Reinforce solver's forward."""
-    import torch
-    E, V, F, B = prob.E, prob.V, prob.F, prob.B
-    out = {}
-    # ---- neural: np-nd-np hidden 128, T = 3 on the same instances (configs[2]) --------------------------------------------------------------
-    try:
-        T = args.secondary_neural_iters
-        out['neural'] = neural_shard(args, dev, native, items, 'np-nd-np', args.hidden, T,
-                                     workload="configs[2]: 'np-nd-np' hidden_dim=%d on the headline batch's instances, T=%d, seeded random-init weights"
-                                              % (args.hidden, T))
-        out['neural']['iterations'] = sum(out['neural']['iterations_per_segment'])
-        out['neural']['iterations_per_sec'] = out['neural']['segment_iterations_per_sec']
-        out['neural']['flop_per_iteration'] = out['neural']['flop_per_iteration_mean']
-        out['neural']['note'] = ('per-kernel ms: HIP events recorded by the library on the launch stream around every launch (pdp_kernel_timing); '
-                                 'flop per launch = MACs of that kernel (SURVEY.md 8(d)) x 2; peak = fp32-input MFMA; the better of two passes after a warm-up pass')
-    except Exception as ex:                                            # a secondary measurement never costs the headline line
-        out['neural'] = dict(error=repr(ex))
-    # ---- Walk-SAT: 1 000 steps, Philox numbers on the device ----------------------------------------------------------------------------
-    try:
-        steps_req = args.secondary_walksat_steps
-        prob.random_fill(seed=4321)
-        start = prob.solution.clone()
-        prob.local_search(start, 10, 0.5, seed=5)                     # warm-up
-        torch.cuda.synchronize()
-        native.kernel_timing(True)
-        t0 = time.perf_counter()
-        res, steps = prob.local_search(start, steps_req, 0.5, seed=999)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        timing = native.kernel_timing_read(); native.kernel_timing(False)
-        kms, kn = timing['walksat']
-        pred = prob.update_solution(res.reshape(-1).contiguous())
-        solved, unsat = prob.cnf_eval(pred.reshape(-1).contiguous())
-        out['walksat'] = dict(workload='%d Walk-SAT steps (epsilon 0.5, Philox) on the headline batch from the random fill' % steps_req,
-                              steps=steps, call_seconds=dt, kernel=native.kernel_name('walksat'), kernel_ms=kms, kernel_launches=kn,
-                              steps_per_sec=steps / dt, flips_per_sec=steps * B / dt, us_per_step=(1e3 * kms / steps) if steps else None,
-                              solved_fraction=float(solved.sum().item()) / B, unsat_clauses_total=float(unsat.sum().item()),
-                              bound='latency: one workgroup per instance, a step = an LDS scan of the n variables into two 64-bit LDS arg-max atomics, '
-                                    'the flip, an O(degree) integer update, two workgroup barriers; every instance of the batch is resident at once '
-                                    'or in a few rounds.  The kernel is incremental and LDS-resident: the streaming model of SURVEY 8(d) (13 E + 8 V '
-                                    'bytes per full re-evaluation step) does not describe it (a fraction above 1 came out of it), so no roofline '
-                                    'fraction is claimed -- flips/s is the figure of merit; tools/ws_prof.py splits a step into its phases')
-    except Exception as ex:
-        out['walksat'] = dict(error=repr(ex))
-    # ---- Reinforce solver: the persistent kernel's other instantiation --------------------------------------------------------------------
-    try:
-        T = args.iters
-        L = native.lib()
-        q = torch.empty(E, 3, device=dev); fs = torch.empty(E, 2, device=dev)
-        am = torch.empty(B, dtype=torch.uint8, device=dev)
-        dec = native.Decimator(prob)
-        g = torch.Generator(device='cpu'); g.manual_seed(77)
-        coins = torch.rand(T, generator=g).to(dev)
-        runs = []
-        for rep in range(3):
-            native.check(L.pdp_problem_bind_state(prob._h, native.ptr(prob.active_variables), native.ptr(prob.active_functions),
-                                                  native.ptr(prob.solution), native.ptr(prob.is_sat), native.ptr(prob.edge_mask), native._stream()))
-            q.fill_(1.0); q.div_(3.0); fs.zero_(); fs[:, 0] = 0.5; am.fill_(1); dec.reset()
-            prob.simplify()
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            it, lds = prob.sp_solve(q, fs, am, dec, T, 0.01, 0.0, pi=0.1, model=native.MODEL_REINFORCE, coins=coins, decimation_probability=0.5,
-                                    time_kernels=True)
-            torch.cuda.synchronize()
-            runs.append((time.perf_counter() - t0, it, lds, dict(prob.last_solve_stats)))
-        dt, it, lds, st = runs[-1]
-        per_launch = st['solve_kernel_ms'] / max(1, st['launches'])
-        bytes_launch = algorithmic_bytes_per_iteration(E, V, F) * it / max(1, st['launches'])
-        ach = bytes_launch / (per_launch * 1e-3) / 1e9
-        out['reinforce'] = dict(workload="'reinforce' (pi 0.1, decimation probability 0.5) on the headline batch, T=%d, the persistent loop" % T,
-                                iterations=it, call_seconds=dt, iterations_per_sec=it / dt, path='persistent-lds' if lds else 'persistent-hbm',
-                                kernel=native.kernel_name('sp_solve'), kernel_launches=st['launches'], kernel_ms_per_launch=per_launch,
-                                replay_launches=st['replays'], replay_ms=st['replay_kernel_ms'],
-                                roofline=dict(bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS,
-                                              note='streaming-model bytes (41E+36V+8F per iteration) x iterations per launch / launch time'))
-    except native.SpeculationFailed as ex:
-        out['reinforce'] = dict(error='speculation failed: %s' % ex)
-    except Exception as ex:
-        out['reinforce'] = dict(error=repr(ex))
-    return out
-
-
-def config_shard_measurements(args, dev, native):
-    """BASELINE configs[3] and configs[4] at the shape ONE GPU of the 8 gets (the 8-GPU runs deal whole loader batches to ranks, pdp/parallel.py),
-    outside the headline's timed loop: configs[3] = np-nd-np hidden 128 on 5 000 instances of n=400 m=1680 (one loader batch of 40 000 / 8)
-    for T sweeps + 1 000 Walk-SAT steps; configs[4] = p-nd-np hidden 128 on mixed k-SAT, batch_replication 4, the reference's dynamic
-    segments (limit x hidden), T sweeps + 30 Walk-SAT steps.  T is short (the sweeps cost the same each): per-sweep rates, not solved counts."""
-    from pdp.factorgraph import dataset
-    out = {}
-    T = args.secondary_neural_iters
-    try:
-        n3, b3 = 400, args.config3_batch
-        items = dataset.random_ksat_items(b3, n3, 3, m=int(round(4.2 * n3)), seed=7000001)
-        out['config3_shard'] = neural_shard(args, dev, native, items, 'np-nd-np', 128, T, walksat_steps=1000,
-                                            workload="configs[3] per GPU: 'np-nd-np' hidden_dim=128, random 3-SAT n=%d m=%d, %d instances (one loader batch of "
-                                                     "the 40 000), T=%d of 200, then 1 000 Walk-SAT steps" % (n3, int(round(4.2 * n3)), b3, T))
-        del items
-    except Exception as ex:
-        out['config3_shard'] = dict(error=repr(ex))
-    try:
-        out['train'] = train_measurement(args, dev, native)
-    except Exception as ex:
-        out['train'] = dict(error=repr(ex))
-    try:
-        items = config4_items(args.config4_instances)
-        out['config4_shard'] = neural_shard(args, dev, native, items, 'p-nd-np', 128, T, replication=4, limit=int(4e9), walksat_steps=30,
-                                            workload="configs[4] per GPU: 'p-nd-np' hidden_dim=128, mixed random k-SAT k in {3,4,5}, n in [100,500], %d instances, "
-                                                     "batch_replication 4, dynamic segments (-l 4e9), T=%d, then 30 Walk-SAT steps" % (args.config4_instances, T))
-    except Exception as ex:
-        out['config4_shard'] = dict(error=repr(ex))
-    return out
-
-
-def big_instance_measurements(args, dev, items, headline_value, native):
-    """Instances past the LDS limit: (a) the headline batch plus ONE instance of n = 4 000 (50 400 edges): per-instance
-    routing, the big instance as a workgroup team next to the LDS-resident pass; (b) one instance of n = 100 000 alone in its batch: the
-    exact single-instance mode.  Same tolerance / t_max / T as the headline; best of three calls each."""
-    import torch
-    from pdp.factorgraph import dataset
-    out = {}
-
-    def run(its, reps=3):
-        bb = dataset.to_torch(dataset.collate_segment(its), dev)
-        hp = native.Problem(bb['graph_map'], bb['batch_variable_map'], bb['batch_function_map'], bb['edge_feature'])
-        L = native.lib()
-        q = torch.empty(hp.E, 3, device=dev); fs = torch.empty(hp.E, 2, device=dev); am = torch.empty(hp.B, dtype=torch.uint8, device=dev)
-        dec = native.Decimator(hp)
-        best = None
-        for _ in range(reps):
-            native.check(L.pdp_problem_bind_state(hp._h, native.ptr(hp.active_variables), native.ptr(hp.active_functions), native.ptr(hp.solution),
-                                                  native.ptr(hp.is_sat), native.ptr(hp.edge_mask), native._stream()))
-            q.fill_(1.0); q.div_(3.0); fs.zero_(); fs[:, 0] = 0.5; am.fill_(1); dec.reset(); hp.simplify()
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            it, lds = hp.sp_solve(q, fs, am, dec, args.iters, args.tolerance, args.t_max)
-            torch.cuda.synchronize(); dt = time.perf_counter() - t0
-            best = (dt, it, lds) if best is None or dt < best[0] else best
-        return best, dict(hp.last_solve_stats), hp.E
-
-    try:
-        big = dataset.random_ksat_items(1, 4000, 3, m=int(round(4.2 * 4000)), seed=99)
-        (dt0, it0, _), _, _ = run(items)
-        (dt, it, lds), st, E = run(items + big)
-        out['mixed_batch'] = dict(workload='the headline batch + one instance of n=4000 (%d edges): per-instance routing' % big[0][2].shape[1],
-                                  iterations=it, call_seconds=dt, iterations_per_sec=it / dt, plain_batch_iterations_per_sec=it0 / dt0,
-                                  fraction_of_plain_batch=(it / dt) / (it0 / dt0), lds_resident=bool(lds), hbm_instances=st['hbm_instances'])
-    except Exception as ex:
-        out['mixed_batch'] = dict(error=repr(ex))
-    try:
-        n1 = 100000
-        one = dataset.random_ksat_items(1, n1, 3, m=int(round(3.5 * n1)), seed=11)
-        (dt, it, lds), st, E = run(one)
-        out['single_instance'] = dict(workload='one instance of n=%d (%d edges, alpha 3.5) alone in its batch: exact single-instance mode, one launch' % (n1, E),
-                                      iterations=it, call_seconds=dt, iterations_per_sec=it / dt, edge_updates_per_sec=2.0 * E * it / dt,
-                                      lds_resident=bool(lds), hbm_instances=st['hbm_instances'], kernel_launches=st['launches'])
-    except Exception as ex:
-        out['single_instance'] = dict(error=repr(ex))
-    return out
-
-
-def solved_fractions(args, dev, b, native, rank):
-    """The metric's "(and solved %)": the whole forward (simplify, T sweeps, random fill, w Walk-SAT steps, Philox numbers) at the headline
-    setting and at a longer one, with the reference's batch-wide semantics and with isolated instances.  Untimed."""
-    import logging
-    import torch
-    from pdp.trainer import SatFactorGraphTrainer
-    out = {}
-    gm, bvm, bfm, ef = b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature']
-    for name, T, w, iso in (('T%d_w%d_reference_semantics' % (args.iters, args.walksat), args.iters, args.walksat, False),
-                            ('T1000_w1000_reference_semantics', 1000, 1000, False), ('T1000_w1000_isolated_instances', 1000, 1000, True)):
-        try:
-            tr = SatFactorGraphTrainer(dict(model_type='p-d-p', model_name='bench', verbose=False, local_search_iteration=w, epsilon=0.5,
-                                            tolerance=args.tolerance, t_max=args.t_max, rng='philox', random_seed=12345 + rank, hidden_dim=3,
-                                            isolated=iso, test_batch_limit=1 << 62, batch_size=args.batch, test_recurrence_num=T),
-                                       use_cuda=True, logger=logging.getLogger('bench'))
-            m = tr._model_list[0]
-            with torch.no_grad():
-                st = m.get_init_state(gm, bvm, bfm, ef, None, randomized=False, batch_replication=1)
-                pred, _ = m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None,
-                            is_training=False, iteration_num=T, check_termination=tr._check_recurrence_termination, batch_replication=1)
-                solved, unsat = tr._cnf_evaluator(pred[0], gm, bvm, bfm, ef, None, sat_problem=m._last_problem)
-            out[name] = dict(solved=int(solved.sum().item()), instances=int(solved.numel()), solved_fraction=float(solved.mean().item()),
-                             unsat_clauses_total=float(unsat.sum().item()), iterations=m.last_run['iterations'], path=m.last_run['path'])
-        except Exception as ex:
-            out[name] = dict(error=repr(ex))
-    # the fully neural solver with the weights this build trained on the MI355X (models/README.md): the metric's "solved %" for a neural
-    # config that does not run on random weights.  Same batch, T sweeps + the same Walk-SAT budget, Philox numbers.
-    wpath = os.path.join(REPO, 'models', 'demo-np-nd-np-h128.pt')
-    if os.path.exists(wpath):
-        name = 'np-nd-np_trained_weights_T%d_w%d' % (args.iters, args.walksat)
-        try:
-            cfg = dict(model_type='np-nd-np', model_name='bench-trained', verbose=False, local_search_iteration=args.walksat, epsilon=0.5, rng='philox',
-                       random_seed=12345 + rank, hidden_dim=128, edge_feature_dim=1, meta_feature_dim=0, prediction_dim=1, mem_hidden_dim=100,
-                       agg_hidden_dim=100, mem_agg_hidden_dim=50, classifier_dim=50, test_batch_limit=1 << 62, batch_size=args.batch,
-                       test_recurrence_num=args.iters, tolerance=args.tolerance, t_max=args.t_max)
-            tr = SatFactorGraphTrainer(cfg, use_cuda=True, logger=logging.getLogger('bench'))
-            m = tr._model_list[0]
-            m.load_state_dict(torch.load(wpath, map_location=dev), strict=True)
-            with torch.no_grad():
-                st = m.get_init_state(gm, bvm, bfm, ef, None, randomized=False, batch_replication=1)
-                pred, _ = m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None,
-                            is_training=False, iteration_num=args.iters, check_termination=tr._check_recurrence_termination, batch_replication=1)
-                solved, unsat = tr._cnf_evaluator(pred[0], gm, bvm, bfm, ef, None, sat_problem=m._last_problem)
-            out[name] = dict(solved=int(solved.sum().item()), instances=int(solved.numel()), solved_fraction=float(solved.mean().item()),
-                             unsat_clauses_total=float(unsat.sum().item()), iterations=m.last_run['iterations'], path=m.last_run['path'],
-                             weights='models/demo-np-nd-np-h128.pt (trained by tools/train_demo.py on n in [10, 40])')
-            del tr, m
-            torch.cuda.empty_cache()
-        except Exception as ex:
-            out[name] = dict(error=repr(ex))
-    return out
 
 
 def main():
@@ -1026,6 +312,8 @@ def main():
                 config['fast_build'] = fast_build_measurement(args, dev, native, host_batch, items, n_solved / n_inst)
             except Exception as ex:
                 config['fast_build'] = dict(error=repr(ex))
+        summary = driver_summary(config)                # flat scalars of every BASELINE config: what the driver's record keeps
+        config.update(summary)
         line = {
             'metric': 'pdp_iterations_per_sec', 'value': value,
             'unit': 'iterations/s (each iteration sweeps a batch of %d instances)' % args.batch,
@@ -1040,6 +328,9 @@ def main():
                                  'so the kernel is bound by VALU issue, not by HBM (DESIGN.md section 4); traffic / valu_issue come from the '
                                  'committed PMC summary named in their source fields, not from this run'},
             'cpu_baseline': cpu, 'cpu_baseline_torch_sparse': cpu_ts,
+            'summary': dict(summary, headline_it_per_s=value, headline_ms_per_step=1e3 * elapsed / args.steps, headline_kernel_ms_per_launch=launch_ms,
+                            headline_frac_hbm_model=achieved / HBM_PEAK_GBS,
+                            headline_valu_issue_frac_at_2_cycles=(valu or {}).get('issue_frac_at_2_cycles')),      # last: inside the tail of stdout
         }
         print(json.dumps(line))
     if grouped():

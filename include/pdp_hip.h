@@ -22,7 +22,9 @@
 extern "C" {
 #endif
 
-#define PDP_ABI_VERSION 1
+/* 2 (round 5): pdp_train_gru_backward's scratch contract and the training entry points added in round 4; a coupled multi-process forward
+ * (pdp_problem_set_exchange) reports PDP_ERR_SPECULATION on EVERY part when one part cannot take the resident loops */
+#define PDP_ABI_VERSION 2
 
 enum {
     PDP_OK = 0,

@@ -1782,7 +1782,7 @@ extern "C" int pdp_train_gru_fused(const pdp_gru_desc *d, const float *state, co
                                    void *stream)
 {
     PDP_REQUIRE(d && state && sign && h && hnew && saved, "NULL argument");
-    PDP_REQUIRE(d->H == 128 && (d->dx == 128 || (d->dx >= 1 && d->dx <= 3)), "the fused training cells are 129 -> 128 (np-nd-np) and 3 / 4 -> 128 (p-nd-np)");
+    PDP_REQUIRE(d->H == 128 && (d->dx == 128 || d->dx == 2 || d->dx == 3), "the fused training cells are 129 -> 128 (np-nd-np) and 3 / 4 -> 128 (p-nd-np)");
     PDP_REQUIRE(R >= 0 && R % TM == 0 && R < ((int64_t)1 << 31), "row count must be a multiple of the 64-row tile");
     PDP_REQUIRE(hnew != h, "output must not alias the hidden state");
     if (R == 0) return PDP_OK;

@@ -2709,9 +2709,23 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
         // reductions across the parts; the other routes (lock-step launch, HBM-resident instances, step-wise fallback) are single-process
         PDP_REQUIRE(a->model == PDP_MODEL_SP && p->R == 1 && !a->isolate_instances, "coupled multi-process forward: the SP triple without batch replication");
         { const int st_ = resident_prepare(p); if (st_ != PDP_OK) return st_; }
-        if (p->res_nbig > 0 || !p->fn_edges_identity) {
-            pdp_set_error("coupled multi-process forward: every instance of the part must fit the LDS-resident solver");
-            return PDP_ERR_UNSUPPORTED;
+        // Whether a part can take the resident loop is a LOCAL fact (an instance past the LDS limit, a clause-major edge order it does not
+        // have), and the other parts are about to wait in the first chunk's exchange: the parts agree on it BEFORE anything else.  One part
+        // that cannot -> every part returns PDP_ERR_SPECULATION (nothing was touched), which the host turns into "solve the segment whole
+        // on one rank" (pdp.native.CoupledForwardFailed -> FactorGraphTrainerBase._predict_epoch).
+        const size_t lds_x = lds2_bytes_for(p->res_fit_n, p->res_fit_m, p->res_fit_e, true);       // (with the force column: either instantiation must fit)
+        const bool can_resident = p->res_nbig == 0 && p->fn_edges_identity && p->res_nfit > 0 && lds_x <= 160 * 1024 - 1024 &&
+                                  getenv("PDP_SOLVE_FORCE_HBM") == nullptr;
+        {
+            const uint32_t ors[1] = {can_resident ? 0u : 1u};
+            uint32_t *m = nullptr;
+            const int st_ = pdp_exchange_call(p, nullptr, 0, nullptr, 0, ors, 1, &m);
+            if (st_ != PDP_OK) return st_;
+            if (m[0]) {
+                pdp_set_error(can_resident ? "coupled multi-process forward: another part cannot take the LDS-resident solver; solve the segment on one process"
+                                           : "coupled multi-process forward: every instance of the part must fit the LDS-resident solver; solve the segment on one process");
+                return PDP_ERR_SPECULATION;
+            }
         }
         return sp_solve_speculative(p, a, stream);          // PDP_ERR_SPECULATION: the caller cannot rerun step-wise across processes
     }

@@ -539,11 +539,9 @@ static int gemm_rows_launch(int M, int N, int K, const float *A, int64_t lda, co
                             int chunks, int KP, hipStream_t st, RowsExtra ex)
 {
     const size_t lds = gemm_rows_lds(NB, KP);
-    static bool attr_set = false;
-    if (!attr_set) {
-        PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_gemm_rows<TB, NB, ACT, GEMM_ROWS_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    // (set on every launch, like the solver kernels do: the attribute belongs to the function ON THE CURRENT DEVICE, and a process-wide
+    //  "already set" flag would leave a second device -- or a second thread racing the first -- with the 64 KB default)
+    PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_gemm_rows<TB, NB, ACT, GEMM_ROWS_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const int stripes = (M + 32 * GEMM_ROWS_WAVES - 1) / (32 * GEMM_ROWS_WAVES);
 #ifndef GEMM_ROWS_GRID
 #define GEMM_ROWS_GRID 3                 // column chunks > 1: three times the resident workgroups (measured 1 / 2 / 3 / 6: 71 / 80 / 91 / 88 TFLOP/s at 129 x 384); one chunk: the resident count

@@ -766,7 +766,24 @@ static int local_search_persistent(pdp_problem *p, const float *pred, int iterat
                                    const float *coin_rand, uint64_t seed, float *out, int32_t *steps_host, hipStream_t st, int *done)
 {
     *done = 0;
-    if (!p->fn_edges_identity || iterations <= 0) return PDP_OK;
+    if (iterations <= 0) return PDP_OK;
+    if (p->exchange) {
+        // A coupled forward over several processes: whether THIS part can take the persistent search is a local fact (its edge order, a
+        // big instance with the routing switched off), and a part that left for the strict loop would skip the collectives the others
+        // issue.  The parts agree first; one that cannot -> every part reports PDP_ERR_SPECULATION with its inputs untouched, and the host
+        // solves the segment whole on one process (pdp.native.CoupledForwardFailed).
+        int can = p->fn_edges_identity ? 1 : 0;
+        if (can) { int st_ = ws_prepare(p); if (st_ != PDP_OK) return st_; if (p->ws_nbig && getenv("PDP_WALKSAT_NO_ROUTING")) can = 0; }
+        const uint32_t ors[1] = {can ? 0u : 1u};
+        uint32_t *m = nullptr;
+        { const int st_ = pdp_exchange_call(p, nullptr, 0, nullptr, 0, ors, 1, &m); if (st_ != PDP_OK) return st_; }
+        if (m[0]) {
+            pdp_set_error("Walk-SAT of a coupled multi-process forward: a part cannot take the persistent search (edge order / routing switch); "
+                          "solve the segment on one process");
+            return PDP_ERR_SPECULATION;
+        }
+    }
+    if (!p->fn_edges_identity) return PDP_OK;
     { int st_ = ws_prepare(p); if (st_ != PDP_OK) return st_; }
     const int nfit = p->ws_nfit, nbig = p->ws_nbig;
     if (nbig && getenv("PDP_WALKSAT_NO_ROUTING")) return PDP_OK;
@@ -888,9 +905,10 @@ static int local_search_persistent(pdp_problem *p, const float *pred, int iterat
     }
     if (status != PDP_OK) return status;
     if (!ok && p->exchange) {
+        // (every part sees the same completed record, so every part takes this exit: the host solves the segment whole on one process)
         pdp_set_error("Walk-SAT of a coupled multi-process forward: a step's batch-global minimum was not 0 in any part; the strict loop that "
-                      "computes it is single-process -- run the forward on one GPU");
-        return PDP_ERR_UNSUPPORTED;
+                      "computes it is single-process -- the segment is solved on one process");
+        return PDP_ERR_SPECULATION;
     }
     if (!ok) return PDP_OK;          // caller runs the strict loop on the untouched inputs
     if (steps_host) *steps_host = stop;
@@ -911,6 +929,10 @@ extern "C" int pdp_local_search(pdp_problem *p, const float *pred, int iteration
         const int rc = local_search_persistent(p, pred, iterations, epsilon, rng_mode, var_rand, coin_rand, seed, out, steps_host, st, &done);
         if (rc != PDP_OK) return rc;
         if (done) return PDP_OK;
+    }
+    if (p->exchange) {        // (not reached: the persistent search of a coupled forward either finishes or reports; the strict loop has no exchange)
+        pdp_set_error("coupled multi-process forward: the strict Walk-SAT loop is single-process");
+        return PDP_ERR_SPECULATION;
     }
     const PView pv = make_view(p);
     float *a = p->ws_v[0], *negdelta = p->ws_v[1], *uv = p->ws_v[2], *unsat_b = p->ws_b[0];

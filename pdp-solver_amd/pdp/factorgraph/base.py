@@ -194,6 +194,7 @@ class FactorGraphTrainerBase(object):
                     (graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, label, misc_data) = \
                         [self._to_cuda(d[k]) for d in data]
                     sink = io.StringIO() if units is not None else file
+                    stats_before = list(getattr(self, '_run_stats', []))
                     try:
                         self._predict_batch(graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat,
                                             label, misc_data, post_processor, batch_replication, sink)
@@ -208,6 +209,8 @@ class FactorGraphTrainerBase(object):
                         if self._config.get('verbose'):
                             self._logger.info('segment (%d, %d): the coupled forward needs the single-process loop; solved whole on rank of part 0' % (j, segment_ids[k]))
                         sink = io.StringIO() if units is not None else file
+                        if stats_before:
+                            self._run_stats[:] = stats_before      # (models of the list that finished before the failing one counted their rows already)
                         if parts[k][0] == 0:
                             seg = whole[k]()
                             saved = [(m, getattr(m, '_exchange', None)) for m in self._model_list]
@@ -341,9 +344,13 @@ class FactorGraphTrainerBase(object):
         distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
         world = torch.distributed.get_world_size() if distributed else 1
         rank = torch.distributed.get_rank() if distributed else 0
+        rng_saved = []                                   # (object, its _rng before this call): the switch below lasts for this call only
         if world > 1 and self._config.get('rng', 'torch') != 'philox':
             for model in self._model_list:
                 if self._draws_from_the_host_stream(model):
+                    rng_saved.append((model, model._rng))
+                    if hasattr(model._predictor, '_rng'):
+                        rng_saved.append((model._predictor, model._predictor._rng))
                     self._logger.warning("%d ranks: model %s draws random numbers; the reference's sequential CPU stream (--rng torch) cannot be "
                                          "dealt to ranks, switching to --rng philox (the rows equal a single-process --rng philox run)"
                                          % (world, model._name))
@@ -376,7 +383,11 @@ class FactorGraphTrainerBase(object):
         start_time = time.time()
         self._run_stats = [0, 0, 0]                       # instances, solved, unsatisfied clauses (filled by the post-processor)
         units = [] if distributed else None
-        self._predict_epoch(test_loader, post_processor, batch_replication, out_file, units=units)
+        try:
+            self._predict_epoch(test_loader, post_processor, batch_replication, out_file, units=units)
+        finally:
+            for obj, rng in rng_saved:                    # a later single-process call on the same trainer draws from the host stream again
+                obj._rng = rng
         torch.cuda.synchronize()
         if distributed:
             # the one collective of the path (RCCL when the group's backend is nccl: the counters live on the GPU then), also at world size 1

@@ -477,7 +477,14 @@ class PropagatorDecimatorSolverBase(nn.Module):
                         torch.rand(done * (V + B))     # consume exactly what the reference consumes
                     break
         else:
-            out, steps = nat.local_search(pred, w, self._epsilon, seed=self._seed)
+            try:
+                out, steps = nat.local_search(pred, w, self._epsilon, seed=self._seed)
+            except native.SpeculationFailed as ex:
+                if self._exchange is None:
+                    raise
+                # one part of a coupled forward cannot take the persistent search, or a step's batch-global minimum was not 0 anywhere: every
+                # part gets this status (the library agrees on it across the parts), and the segment is solved whole by one process
+                raise native.CoupledForwardFailed(str(ex))
         sat_problem._edge_mask = nat.edge_mask
         self.last_run['walksat_steps'] = steps
         return out, prediction[1]

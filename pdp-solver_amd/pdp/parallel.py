@@ -68,12 +68,6 @@ def shard_bounds(edge_counts, world_size):
     return bounds
 
 
-def deal_batches(batch_weights, world_size):
-    """Contiguous ranges [lo, hi) of loader-batch indices per rank, balanced by the batches' weights.  (The round-3 dealer; the predict
-    path now deals segments with ``deal_units``.  Kept for callers that want contiguous ranges.)"""
-    return shard_bounds(batch_weights, world_size)
-
-
 def deal_units(weights, world_size, loads=None):
     """Owner rank of each unit (segment) of one loader batch: the units are taken heaviest first (ties: lowest index) and each goes to the
     rank with the smallest load so far (ties: lowest rank).  ``loads`` (a list of ``world_size`` numbers, updated in place) carries the
@@ -127,17 +121,24 @@ def reduce_test_metrics(error_sums, n_examples, device=None, group=None):
 
 def make_exchange(device=None, group=None):
     """The callback of a coupled forward spread over the ranks (native.Problem.set_exchange): element-wise min / max / bit-wise OR of three
-    small uint32 arrays over all ranks, in one all-gather (RCCL on the device when the group's backend is nccl, gloo on the host)."""
+    small uint32 arrays over all ranks, in ONE collective (all_gather_into_tensor of the concatenated words: RCCL on the device when the
+    group's backend is nccl -- the staging tensors live there and are reused from call to call --, gloo on the host)."""
+    staged = {}
+
     def exchange(mins, maxs, ors):
         n = (mins.size, maxs.size, ors.size)
-        mine = torch.from_numpy(np.concatenate((mins, maxs, ors)).astype(np.int64))
-        on_gpu = dist.get_backend(group) == 'nccl'
-        if on_gpu:
-            mine = mine.to(device)
+        total = n[0] + n[1] + n[2]
         world = dist.get_world_size(group)
-        parts = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(parts, mine, group=group)
-        every = torch.stack(parts).cpu().numpy().astype(np.uint32)
+        on_gpu = dist.get_backend(group) == 'nccl'
+        key = (total, world, on_gpu)
+        if key not in staged:
+            dev = device if on_gpu else 'cpu'
+            staged.clear()
+            staged[key] = (torch.empty(total, dtype=torch.int64, device=dev), torch.empty(world * total, dtype=torch.int64, device=dev))
+        mine, every_t = staged[key]
+        mine.copy_(torch.from_numpy(np.concatenate((mins, maxs, ors)).astype(np.int64)))
+        dist.all_gather_into_tensor(every_t, mine, group=group)
+        every = every_t.view(world, total).cpu().numpy().astype(np.uint32)
         mins[:] = every[:, :n[0]].min(axis=0) if n[0] else mins
         maxs[:] = every[:, n[0]:n[0] + n[1]].max(axis=0) if n[1] else maxs
         if n[2]:
@@ -145,19 +146,37 @@ def make_exchange(device=None, group=None):
     return exchange
 
 
-def gather_rows(rows, group=None):
-    "rank-ordered list of every rank's result rows (python objects; host side only)"
+def gather_rows(rows, group=None, dst=0):
+    """Rank-ordered list of every rank's result rows ON RANK ``dst`` (the other ranks get their own rows back: only the writer needs the
+    rest).  The rows are pickled once per rank and travel as ONE padded uint8 tensor per rank in one ``gather`` to the writer (RCCL on the
+    device under nccl) -- ``all_gather_object`` handed every rank every row: 8 x 8 x 6.5 MB for configs[3] (40 000 rows of 400 values),
+    where the writer needs 8 x 6.5 MB once.  The lengths travel first, in one small all-gather."""
     if not (dist.is_available() and dist.is_initialized()):
         return list(rows)
-    world = dist.get_world_size(group)
-    out = [None] * world
-    dist.all_gather_object(out, list(rows), group=group)
-    return [r for part in out for r in part]
+    import pickle
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    on_gpu = dist.get_backend(group) == 'nccl'
+    dev = torch.device('cuda', torch.cuda.current_device()) if on_gpu else torch.device('cpu')
+    blob = np.frombuffer(pickle.dumps(list(rows), protocol=pickle.HIGHEST_PROTOCOL), dtype=np.uint8)
+    sizes = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes, torch.tensor([blob.size], dtype=torch.int64, device=dev), group=group)
+    sizes = [int(x) for x in sizes.cpu().tolist()]
+    cap = max(max(sizes), 1)
+    mine = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    mine[:blob.size] = torch.from_numpy(blob.copy()).to(dev)
+    parts = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == dst else None
+    dist.gather(mine, parts, dst=dst, group=group)
+    if rank != dst:
+        return list(rows)
+    out = []
+    for r in range(world):
+        out += pickle.loads(parts[r][:sizes[r]].cpu().numpy().tobytes())
+    return out
 
 
 def gather_units(units, group=None):
-    """``units``: this rank's [((batch, segment), payload), ...].  Returns the payloads of all ranks in (batch, segment) order -- the order
-    the single-process run produces them in.  A rank without units contributes an empty list."""
+    """``units``: this rank's [((batch, segment), payload), ...].  Returns -- on rank 0; the other ranks get their own -- the payloads of
+    all ranks in (batch, segment) order: the order the single-process run produces them in.  A rank without units contributes an empty list."""
     return [payload for _, payload in sorted(gather_rows(units, group), key=lambda kv: kv[0])]
 
 

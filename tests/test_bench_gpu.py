@@ -66,6 +66,16 @@ def test_bench_line_small_workload():
     assert fb['kernel'] == rf['kernel'] and fb['value'] > 0 and fb['kernel_ms_per_launch'] > 0 and 0 < fb['roofline_frac'] < 2.0
     assert 'error' not in fb['neural'] and fb['neural']['kernels']['agg_post']['ms_per_launch'] > 0
     assert abs(fb['solved_fraction'] - fb['solved_fraction_parity_build']) <= 0.01
+    # what the driver's record keeps (scalars of `config`, the tail of stdout): every BASELINE config's figures, flat, and last in the line
+    sm = line['summary']
+    assert list(line.keys())[-1] == 'summary'
+    for key in ('configs2_np_nd_np_h128_it_per_s', 'configs2_np_nd_np_h128_frac_mfma_f32', 'configs3_shard_n400_frac_mfma_f32', 'configs4_shard_p_nd_np_b4_frac_mfma_f32',
+                'configs2_kernel_agg_post_frac_mfma_f32', 'configs2_kernel_gru_ms', 'fast_build_it_per_s', 'fast_build_configs2_frac_mfma_f32', 'walksat_1000_flips_per_s',
+                'reinforce_it_per_s', 'train_np_nd_np_frac_mfma_f32', 'headline_it_per_s', 'headline_frac_hbm_model'):
+        assert isinstance(sm[key], float) and sm[key] > 0, key
+    assert sm['configs2_np_nd_np_h128_frac_mfma_f32'] == sec['neural']['roofline']['frac'] == line['config']['configs2_np_nd_np_h128_frac_mfma_f32']
+    assert sm['configs3_shard_n400_frac_mfma_f32'] == c3['roofline']['frac'] and sm['fast_build_it_per_s'] == fb['value']
+    assert len(json.dumps(sm)) < 6000
 
 
 def test_bench_launcher_two_ranks_on_one_gpu():

@@ -182,6 +182,38 @@ def test_split_forward_keeps_the_couplings_across_ranks(tmp_path):
     assert r.returncode != 0 and 'has 2 instances for 3 ranks' in r.stderr
 
 
+def test_split_forward_falls_back_when_one_part_cannot_take_the_resident_loop(tmp_path):
+    """Whether a part of a coupled forward can take the LDS-resident loops is a local fact -- here the LAST part holds an instance past the
+    LDS limit -- and the other parts are about to wait in the first chunk's exchange.  The parts agree on it before anything else
+    (pdp_sp_solve / pdp_local_search: one OR across the parts), every part reports the failed speculation, and the rank of part 0 solves
+    the segment whole: the rows of the single process, no hang, no abort.  Same for the pure Walk-SAT model with the routing switched off."""
+    from pdp.factorgraph import dataset
+    items = dataset.random_ksat_items(13, 200, 3, m=840, seed=97000) + dataset.random_ksat_items(1, 1000, 3, seed=97100)
+    path = tmp_path / 'in.json'
+    path.write_text("\n".join(_lines(items)) + "\n")
+    argv = [os.path.join(REPO, 'config', 'Predict', 'PDP-p-d-p-sp-pytorch.yaml'), str(path), '40', '-z', '5000', '-s', '11', '-w', '40',
+            '--rng', 'philox', '-v', '-l', '4e9']
+    one, _ = _run(argv, 1, str(tmp_path / 'one.jsonl'), 0)
+    two, log = _run(argv + ['--split-forward'], 2, str(tmp_path / 'two.jsonl'), 29775)
+    assert len(one) == len(items) and two == one
+    assert 'solved whole on rank of part 0' in log
+    ws_argv = [os.path.join(REPO, 'config', 'Predict', 'PDP-p-d-p-walksat-pytorch.yaml'), str(path), '60', '-z', '5000', '-s', '11', '--rng', 'philox', '-v', '-l', '4e9']
+    env = {'PDP_WALKSAT_NO_ROUTING': '1'}
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        ws_one, _ = _run(ws_argv, 1, str(tmp_path / 'ws_one.jsonl'), 0)
+        ws_two, log = _run(ws_argv + ['--split-forward'], 2, str(tmp_path / 'ws_two.jsonl'), 29777)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert ws_two == ws_one and len(ws_one) == len(items)
+    assert 'solved whole on rank of part 0' in log
+
+
 def test_split_soak_short():
     """tools/split_soak.py for a few seconds: random batches (NaN-producing instances at random places, 30-130 sweeps, with and without
     Walk-SAT) cut into 2-4 parts that run in threads of one process -- the coupled form with an in-memory exchange, the isolated form without --
