@@ -192,12 +192,12 @@ def test_split_forward_falls_back_when_one_part_cannot_take_the_resident_loop(tm
     path = tmp_path / 'in.json'
     path.write_text("\n".join(_lines(items)) + "\n")
     argv = [os.path.join(REPO, 'config', 'Predict', 'PDP-p-d-p-sp-pytorch.yaml'), str(path), '40', '-z', '5000', '-s', '11', '-w', '40',
-            '--rng', 'philox', '-v', '-l', '4e9']
+            '--rng', 'philox', '-v', '-l', '4000000000']
     one, _ = _run(argv, 1, str(tmp_path / 'one.jsonl'), 0)
     two, log = _run(argv + ['--split-forward'], 2, str(tmp_path / 'two.jsonl'), 29775)
     assert len(one) == len(items) and two == one
     assert 'solved whole on rank of part 0' in log
-    ws_argv = [os.path.join(REPO, 'config', 'Predict', 'PDP-p-d-p-walksat-pytorch.yaml'), str(path), '60', '-z', '5000', '-s', '11', '--rng', 'philox', '-v', '-l', '4e9']
+    ws_argv = [os.path.join(REPO, 'config', 'Predict', 'PDP-p-d-p-walksat-pytorch.yaml'), str(path), '60', '-z', '5000', '-s', '11', '--rng', 'philox', '-v', '-l', '4000000000']
     env = {'PDP_WALKSAT_NO_ROUTING': '1'}
     saved = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
