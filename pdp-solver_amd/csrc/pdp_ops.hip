@@ -223,43 +223,51 @@ extern "C" int pdp_instance_argmax(pdp_problem *p, const float *x, int64_t *out,
 // ---- K1-K3 ------------------------------------------------------------------------------------------------------
 // LOGX: dq is [E] and already holds the log-domain clause message (the adaptor form of the propagator, model type p-nd-np:
 // logsigmoid of a learned projection, pdp_propagate.py:166-167) instead of [E,3] surveys whose first column goes through safe_log
-template <bool LOGX>
+// PHASE -1: the whole sweep in one launch, one workgroup per instance (its barriers separate the three phases).  PHASE 0 / 1 / 2: one
+// phase per launch with gridDim.y workgroups per instance -- what a batch takes that cannot fill the chip with a workgroup per instance
+// (the reference's default memory limit cuts configs[4] with -b 4 into segments of <= 31 instances x 4 replicas, up to 47 520 edges each:
+// 124 workgroups of 256 threads ran the sweep in 0.35 ms, as long as 20 M edges take in one segment).  Same statements per edge / row.
+template <bool LOGX, int PHASE>
 __global__ void __launch_bounds__(PDP_NT) k_sp_propagate(PView pv, const float *dq, const float *dfs, const float *emask,
                                                          const uint8_t *amask, const float *iq, const float *ifs, float pi,
                                                          float *oq, float *ofs, float *xs, float *ys, float *Sw, float *Pw, float *Nw)
 {
     const Inst I = load_inst(pv, blockIdx.x);
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int nt = (int)blockDim.x * (PHASE < 0 ? 1 : (int)gridDim.y), tid = (int)threadIdx.x + (PHASE < 0 ? 0 : (int)blockIdx.y * (int)blockDim.x);
     dq += (LOGX ? 1 : 3) * (size_t)I.e0; dfs += 2 * (size_t)I.e0; iq += 3 * (size_t)I.e0; ifs += 2 * (size_t)I.e0;
     oq += 3 * (size_t)I.e0; ofs += 2 * (size_t)I.e0;
     xs += I.e0; ys += I.e0; Sw += I.f0; Pw += I.v0; Nw += I.v0;
     const float *em = emask ? emask + I.e0 : nullptr;
     const float mask = amask ? (0.0f + (0.0f + (float)amask[I.b])) : 1.0f;
     const float L0 = pdp_safe_log(1.0f - pi * 0.0f, PDP_SP_EPS), L1 = pdp_safe_log(1.0f - pi * 1.0f, PDP_SP_EPS);
+    if (PHASE < 0 || PHASE == 0)
     for (int e = tid; e < I.e; e += nt) {
         float x = LOGX ? dq[e] : pdp_safe_log(dq[3 * e], PDP_SP_EPS);
         float y = pdp_safe_log(1.0f - dfs[2 * e], PDP_SP_EPS);
         if (em) { x = x * em[e]; y = y * em[e]; }
         xs[e] = x; ys[e] = y;
     }
-    __syncthreads();
-    for (int c = tid; c < I.m; c += nt) {
-        float acc = 0.0f;
-        for (int k = I.f_ptr[c]; k < I.f_ptr[c + 1]; ++k) acc = acc + xs[I.f_edges[k]];
-        Sw[c] = acc;
-    }
-    for (int v = tid; v < I.n; v += nt) {
-        float P = 0.0f, N = 0.0f;
-        for (int k = I.v_ptr[v]; k < I.v_ptr[v + 1]; ++k) {
-            const int e = I.v_edges[k];
-            const float y = ys[e];
-            const int sg = I.sgn[e];
-            P = P + ((sg == 1) ? 1.0f : 0.0f) * y;
-            N = N + ((sg == -1) ? 1.0f : 0.0f) * y;
+    if (PHASE < 0) __syncthreads();
+    if (PHASE < 0 || PHASE == 1) {
+        for (int c = tid; c < I.m; c += nt) {
+            float acc = 0.0f;
+            for (int k = I.f_ptr[c]; k < I.f_ptr[c + 1]; ++k) acc = acc + xs[I.f_edges[k]];
+            Sw[c] = acc;
         }
-        Pw[v] = P; Nw[v] = N;
+        for (int v = tid; v < I.n; v += nt) {
+            float P = 0.0f, N = 0.0f;
+            for (int k = I.v_ptr[v]; k < I.v_ptr[v + 1]; ++k) {
+                const int e = I.v_edges[k];
+                const float y = ys[e];
+                const int sg = I.sgn[e];
+                P = P + ((sg == 1) ? 1.0f : 0.0f) * y;
+                N = N + ((sg == -1) ? 1.0f : 0.0f) * y;
+            }
+            Pw[v] = P; Nw[v] = N;
+        }
     }
-    __syncthreads();
+    if (PHASE < 0) __syncthreads();
+    if (PHASE < 0 || PHASE == 2)
     for (int e = tid; e < I.e; e += nt) {
         const int v = I.e_var[e], c = I.e_fn[e];
         const float s = (float)I.sgn[e];
@@ -275,6 +283,40 @@ __global__ void __launch_bounds__(PDP_NT) k_sp_propagate(PView pv, const float *
     }
 }
 
+// workgroups per instance of the phase-split sweep: 1 (the fused launch) while a workgroup per instance fills the chip, otherwise enough
+// to have ~4 workgroups per CU, but no more than the largest instance has edges for (64 per thread at least)
+static int sp_sweep_rows(const pdp_problem *p)
+{
+    if (getenv("PDP_SP_SWEEP_FUSED")) return 1;
+    const long cus = pdp_device_cus();
+    if ((long)p->B >= 2 * cus || p->B <= 0) return 1;
+    long rows = (4 * cus + p->B - 1) / p->B;
+    const long by_size = ((long)p->max_e + 4L * PDP_NT - 1) / (4L * PDP_NT);
+    if (rows > by_size) rows = by_size;
+    if (rows > 64) rows = 64;
+    return rows < 2 ? 1 : (int)rows;
+}
+template <bool LOGX>
+static void sp_sweep_launch(pdp_problem *p, const float *dq, const float *dfs, const float *edge_mask, const uint8_t *active_mask, const float *init_q,
+                            const float *init_fs, float pi, float *out_q, float *out_fs, hipStream_t st)
+{
+    const int rows = sp_sweep_rows(p);
+    const PView pv = make_view(p);
+    if (rows == 1) {
+        pdp_note_kernel(PDP_TK_SP_SWEEP, LOGX ? "k_sp_propagate<true>" : "k_sp_propagate<false>");
+        hipLaunchKernelGGL((k_sp_propagate<LOGX, -1>), dim3(p->B), dim3(PDP_NT), 0, st, pv, dq, dfs, edge_mask, active_mask, init_q, init_fs, pi, out_q, out_fs,
+                           p->ws_e[0], p->ws_e[1], p->ws_f[0], p->ws_v[0], p->ws_v[1]);
+        return;
+    }
+    pdp_note_kernel(PDP_TK_SP_SWEEP, LOGX ? "k_sp_propagate<true> in three phases" : "k_sp_propagate<false> in three phases");
+    hipLaunchKernelGGL((k_sp_propagate<LOGX, 0>), dim3(p->B, rows), dim3(PDP_NT), 0, st, pv, dq, dfs, edge_mask, active_mask, init_q, init_fs, pi, out_q, out_fs,
+                       p->ws_e[0], p->ws_e[1], p->ws_f[0], p->ws_v[0], p->ws_v[1]);
+    hipLaunchKernelGGL((k_sp_propagate<LOGX, 1>), dim3(p->B, rows), dim3(PDP_NT), 0, st, pv, dq, dfs, edge_mask, active_mask, init_q, init_fs, pi, out_q, out_fs,
+                       p->ws_e[0], p->ws_e[1], p->ws_f[0], p->ws_v[0], p->ws_v[1]);
+    hipLaunchKernelGGL((k_sp_propagate<LOGX, 2>), dim3(p->B, rows), dim3(PDP_NT), 0, st, pv, dq, dfs, edge_mask, active_mask, init_q, init_fs, pi, out_q, out_fs,
+                       p->ws_e[0], p->ws_e[1], p->ws_f[0], p->ws_v[0], p->ws_v[1]);
+}
+
 extern "C" int pdp_sp_propagate(pdp_problem *p, const float *dec_q, const float *dec_fs, const float *edge_mask,
                                 const uint8_t *active_mask, const float *init_q, const float *init_fs, float pi,
                                 float *out_q, float *out_fs, void *stream)
@@ -282,9 +324,7 @@ extern "C" int pdp_sp_propagate(pdp_problem *p, const float *dec_q, const float 
     PDP_REQUIRE(p && dec_q && dec_fs && init_q && init_fs && out_q && out_fs, "NULL argument");
     PDP_REQUIRE(out_q != dec_q && out_q != init_q && out_fs != dec_fs && out_fs != init_fs, "outputs must not alias inputs");
     pdp_timed_scope timed(PDP_TK_SP_SWEEP, ST(stream));
-    pdp_note_kernel(PDP_TK_SP_SWEEP, "k_sp_propagate<false>");
-    hipLaunchKernelGGL(k_sp_propagate<false>, dim3(p->B), dim3(PDP_NT), 0, ST(stream), make_view(p), dec_q, dec_fs, edge_mask,
-                       active_mask, init_q, init_fs, pi, out_q, out_fs, p->ws_e[0], p->ws_e[1], p->ws_f[0], p->ws_v[0], p->ws_v[1]);
+    sp_sweep_launch<false>(p, dec_q, dec_fs, edge_mask, active_mask, init_q, init_fs, pi, out_q, out_fs, ST(stream));
     PDP_LAUNCH_CHECK();
     return PDP_OK;
 }
@@ -346,9 +386,7 @@ extern "C" int pdp_sp_propagate_adapted(pdp_problem *p, const float *xlog, const
     PDP_REQUIRE(p && xlog && dec_fs && init_q && init_fs && out_q && out_fs, "NULL argument");
     PDP_REQUIRE(out_q != init_q && out_fs != dec_fs && out_fs != init_fs, "outputs must not alias inputs");
     pdp_timed_scope timed(PDP_TK_SP_SWEEP, ST(stream));
-    pdp_note_kernel(PDP_TK_SP_SWEEP, "k_sp_propagate<true>");
-    hipLaunchKernelGGL(k_sp_propagate<true>, dim3(p->B), dim3(PDP_NT), 0, ST(stream), make_view(p), xlog, dec_fs, edge_mask,
-                       active_mask, init_q, init_fs, pi, out_q, out_fs, p->ws_e[0], p->ws_e[1], p->ws_f[0], p->ws_v[0], p->ws_v[1]);
+    sp_sweep_launch<true>(p, xlog, dec_fs, edge_mask, active_mask, init_q, init_fs, pi, out_q, out_fs, ST(stream));
     PDP_LAUNCH_CHECK();
     return PDP_OK;
 }

@@ -18,6 +18,7 @@ import json
 import logging
 import os
 import sys
+import time
 import tempfile
 import warnings
 
@@ -713,6 +714,44 @@ def gen_headline_poison():
 
 
 
+def gen_headline_mid(B=800, w=100):
+    """The headline family at a batch between the toy fixture above and the benchmark's 5 000: the four NaN-producing instances + the first
+    B - 4 instances of bench.py's rank-0 batch, T = 100 sweeps, then the random fill and `w` Walk-SAT steps of the full forward (solver.py:324-353,
+    433-467) on the reference's own torch.rand stream (torch.manual_seed(7)).  Minutes of CPU: the reference densifies [V x B] per reduction."""
+    seeds = [2499, 2776, 3533, 4730] + list(range(0, B - 4))
+    lines = _headline_lines(seeds)
+    cfg = base_cfg('p-d-p', local_search_iteration=w, epsilon=0.5, tolerance=0.02, t_max=100)
+    tr, m = build(cfg)
+    gm, bvm, bfm, ef, lab, misc = batch_tensors(lines)
+    T = 100
+    counts, nan_iter = [], []
+    orig_check = tr._check_recurrence_termination
+
+    def check(active, prediction, sp):
+        orig_check(active, prediction, sp)
+        counts.append(int(sp._active_variables.sum().item()))
+
+    def prop_hook(mod, inp, outp):
+        if not nan_iter and bool(torch.isnan(outp[0]).any()):
+            nan_iter.append(len(counts))
+
+    h = m._propagator.register_forward_hook(prop_hook)
+    torch.manual_seed(7)
+    t0 = time.time()
+    with torch.no_grad():
+        st = m.get_init_state(gm, bvm, bfm, ef, None, randomized=False, batch_replication=1)
+        pred, (ps, ds) = m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None,
+                           is_training=False, iteration_num=T, check_termination=check, batch_replication=1)
+    h.remove()
+    ev = RU.SatCNFEvaluator(torch.device('cpu'))
+    solved, unsat = ev(pred[0], gm, bvm, bfm, ef, None)
+    print('headline_mid: B=%d, %d sweeps, first NaN %s, solved %d, unsat clauses %d, %.0f s' % (B, len(counts), nan_iter, int(solved.sum()), int(unsat.sum()), time.time() - t0))
+    save('headline_n200_mid', seeds=np.array(seeds, dtype=np.int64), meta=np.array([200, 840, T, 7, len(counts), w], dtype=np.int64),
+         active_variable_count=np.array(counts, dtype=np.int64), first_nan_sweep=np.array(nan_iter or [-1], dtype=np.int64),
+         final_bits=np.packbits((np_(pred[0][:, 0]) > 0.5).astype(np.uint8)), variable_num=np.array([int(bvm.numel())], dtype=np.int64),
+         final_solved=np_(solved[:, 0]).astype(np.uint8), final_unsat=np_(unsat[:, 0]).astype(np.int32))
+
+
 def gen_headline_neural():
     """np-nd-np, hidden 128 (configs[2]) on 6 instances of bench.py's family (n=200 m=840): per-sweep predictions of the reference with the
     seeded weights of gen_neural's h128 model (same constructor seed, so trace_neural_h128.npz holds these tensors)."""
@@ -1353,6 +1392,8 @@ if __name__ == '__main__':
         gen_test_metrics()
     if 'headline' in what:
         gen_headline_poison()
+    if 'headline_mid' in what:
+        gen_headline_mid()
     if 'generators' in what:
         gen_generators()
     if 'subsume' in what:

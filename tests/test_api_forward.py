@@ -359,6 +359,51 @@ def test_test_mode_metrics_equal_reference_golden():
 
 
 @pytest.mark.parametrize('persistent', [True, False])
+def test_headline_family_at_800_instances_equals_reference(persistent):
+    """The headline family pinned to the REFERENCE at a non-toy size (round-4 verdict, item 7): 800 instances of bench.py's rank-0 batch
+    (the four NaN-producing ones + instances 0..795), T = 100 sweeps, random fill and 100 Walk-SAT steps on the reference's own torch.rand
+    stream -- `tests/golden/generate_golden.py headline_mid` ran the unmodified reference for five minutes on this input (first NaN in sweep
+    81, then no decimation anywhere in the batch; 0 of 800 solved, 17 317 unsatisfied clauses).  The persistent loop (speculation + poison
+    replay + persistent Walk-SAT) and the step-wise loop must end in the reference's final assignment bit for bit, with its per-instance
+    solved flags and clause counts; the step-wise loop also walks the reference's active-variable counts sweep by sweep."""
+    from pdp.trainer import SatFactorGraphTrainer
+    from pdp.factorgraph import dataset
+    d = load_golden('headline_n200_mid')
+    n, mcl, T, seed, sweeps, w = [int(x) for x in d['meta']]
+    items = []
+    for sd in d['seeds']:
+        items += dataset.random_ksat_items(1, n, 3, m=mcl, seed=int(sd))
+    assert len(items) == 800
+    dev = torch.device('cuda:0')
+    b = dataset.to_torch(dataset.collate_segment(items), dev)
+    gm, bvm, bfm, ef = b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature']
+    assert bvm.numel() == int(d['variable_num'][0])
+    tr = SatFactorGraphTrainer(cfg('p-d-p', local_search_iteration=w, epsilon=0.5, persistent=persistent, tolerance=0.02, t_max=100), use_cuda=True, logger=LOG)
+    m = tr._model_list[0]
+    counts = []
+
+    def check(active, prediction, sp):
+        tr._check_recurrence_termination(active, prediction, sp)
+        counts.append(int(sp._active_variables.sum().item()))
+
+    check._pdp_standard_termination = persistent          # the persistent loop implements the standard callback itself
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        st = m.get_init_state(gm, bvm, bfm, ef, None, randomized=False, batch_replication=1)
+        pred, _ = m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None,
+                    is_training=False, iteration_num=T, check_termination=check, batch_replication=1)
+    assert m.last_run['iterations'] == sweeps and m.last_run['path'] == ('persistent-lds' if persistent else 'stepwise')
+    bits = np.packbits((pred[0].cpu().numpy()[:, 0] > 0.5).astype(np.uint8))
+    np.testing.assert_array_equal(bits, d['final_bits'])
+    solved, unsat = tr._cnf_evaluator(pred[0], gm, bvm, bfm, ef, None, sat_problem=m._last_problem)
+    np.testing.assert_array_equal(solved.cpu().numpy()[:, 0].astype(np.uint8), d['final_solved'])
+    np.testing.assert_array_equal(unsat.cpu().numpy()[:, 0].astype(np.int32), d['final_unsat'])
+    assert int(d['first_nan_sweep'][0]) == 80 and int(unsat.sum().item()) == 17317
+    if not persistent:
+        np.testing.assert_array_equal(np.array(counts), d['active_variable_count'])
+
+
+@pytest.mark.parametrize('persistent', [True, False])
 def test_headline_family_with_nan_poison_equals_reference(persistent):
     """BASELINE configs[1]'s instance family (uniform 3-SAT n=200 m=840) at a batch the reference can run: 50 instances of bench.py's
     rank-0 batch, among them the four whose surveys become NaN (0/0 in the SP update, pdp_propagate.py:215-216).  In the reference the

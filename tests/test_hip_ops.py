@@ -161,6 +161,35 @@ def test_sp_propagate_score_cnf(oracle, spec, pi):
     np.testing.assert_array_equal(npy(ham), op.check_termination(np.ones(B, np.uint8), pred))
 
 
+def test_sp_sweep_in_three_phases_equals_the_fused_launch(oracle, monkeypatch):
+    """A batch that cannot fill the chip with one workgroup per instance (the small dynamic segments of configs[4] under the reference's
+    default memory limit) takes the step-wise SP sweep as three launches with several workgroups per instance; same statements per edge and
+    row, so the results are those of the one-launch form -- and the oracle's -- bit for bit, in both input forms (surveys / log-domain)."""
+    from pdp import native
+    hp, op, rng = prepared_pair(oracle, dict(batch=5, n=400, k=3, seed=21))
+    E, B = op.E, op.B
+    q = rng.rand(E, 3).astype(np.float32); q /= q.sum(1, keepdims=True); q[rng.rand(E) < 0.05, 0] = 0
+    fs = rng.rand(E, 2).astype(np.float32); fs[rng.rand(E) < 0.05, 0] = 1.0
+    fs[:, 1] = rng.randint(-1, 2, size=E)
+    iq = rng.rand(E, 3).astype(np.float32); ifs = rng.rand(E, 2).astype(np.float32)
+    am = (rng.rand(B) > 0.3).astype(np.uint8)
+    xlog = (-rng.rand(E) * 5).astype(np.float32)
+    em, _ = op.refresh_edge_mask()
+    got = {}
+    for fused in (False, True):
+        if fused:
+            monkeypatch.setenv('PDP_SP_SWEEP_FUSED', '1')
+        a = hp.sp_propagate(t(q), t(fs), hp.edge_mask, t(am), t(iq), t(ifs), 0.1)
+        name = native.kernel_name('sp_sweep')
+        b = hp.sp_propagate_adapted(t(xlog), t(fs), hp.edge_mask, t(am), t(iq), t(ifs), 0.1)
+        assert ('three phases' in name) == (not fused) and ('three phases' in native.kernel_name('sp_sweep')) == (not fused)
+        got[fused] = [npy(x) for x in a + b]
+    for x, y in zip(got[False], got[True]):
+        np.testing.assert_array_equal(x, y)
+    oq, ofs = op.sp_propagate(q, fs, em, am, iq, ifs, 0.1)
+    np.testing.assert_array_equal(got[False][0], oq); np.testing.assert_array_equal(got[False][1], ofs)
+
+
 @pytest.mark.parametrize('spec', BATCHES[:4])
 def test_energy_and_walksat_pieces(oracle, spec):
     hp, op, rng = prepared_pair(oracle, spec)
