@@ -1377,6 +1377,233 @@ __global__ void __launch_bounds__(NTN) k_gru_pipe(int E, const float *__restrict
     }
 }
 
+#ifdef PDP_FAST_MATH
+// ---- kernel 5b', opt-in fast build only: the hidden-128 cell on three-term bf16 products -------------------------------------------------
+// The f32 MFMA runs at the f32 vector rate: a gate of this cell is 129 v_mfma_f32_32x32x2_f32 per wave.  Here both operands are split into
+// bf16 high + low parts (x = hi + lo, 16 mantissa bits together) and a k-block of 16 is hi hi + hi lo + lo hi on v_mfma_f32_32x32x16_bf16
+// with fp32 accumulation: 51 instructions per gate.  tools/micro/bf16x3_probe.hip: 3.7e-6 of the largest |C| on a 32 x 32 x 256 product
+// (the fp32 chain: 4.8e-7; operands merely rounded to bf16: 1.9e-3) -- inside the tolerances the fast build is gated with
+// (tests/test_fast_build_gpu.py), never in the parity build, whose oracle chain is the fp32 fma.
+// Layout: the tile rows are split ONCE, when they are deposited in LDS (hi and lo bf16 take the 4 bytes the float took), and every wave of
+// the tile reads ready 16-byte fragments; the weights are split per call into [k / 8][3 H][8] so that a lane's fragment is one 16-byte load.
+// The previous hidden value of the blend is the caller's fp32 row (re-read from L2), not the split one.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+#define BF3_XS 152        /* bf16 per row of the input part: 144 used (128 message + sign + zero pad), row stride 76 dwords = 19 x 16 bytes (odd: no 16-byte bank conflicts) */
+#define BF3_HS 136        /* bf16 per row of the hidden part: 128 used, 68 dwords = 17 x 16 bytes */
+#define BF3_KX 144
+__device__ __forceinline__ uint32_t bf3_pack_hi(float a, float b, float &ra, float &rb)
+{
+    const __bf16 ha = (__bf16)a, hb = (__bf16)b;            // round to nearest even
+    ra = a - (float)ha; rb = b - (float)hb;                  // exact: the residual of a rounding fits a float
+    return (uint32_t)__builtin_bit_cast(uint16_t, ha) | ((uint32_t)__builtin_bit_cast(uint16_t, hb) << 16);
+}
+__device__ __forceinline__ uint32_t bf3_pack(float a, float b)
+{
+    return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)a) | ((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)b) << 16);
+}
+// Wt [K][N3] fp32 (k-major, the layout of the f32 kernels) -> hi / lo [Kpad / 8][N3][8] bf16, zero rows behind K
+__global__ void k_bf3_split_weights(const float *__restrict__ Wt, int K, int Kpad, int N3, uint32_t *__restrict__ hi, uint32_t *__restrict__ lo)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (Kpad / 8) * N3) return;
+    const int k8 = idx / N3, col = idx - k8 * N3;
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k0 = 8 * k8 + 2 * j;
+        const float a = k0 < K ? Wt[(size_t)k0 * N3 + col] : 0.0f, b = k0 + 1 < K ? Wt[(size_t)(k0 + 1) * N3 + col] : 0.0f;
+        float ra, rb;
+        h[j] = bf3_pack_hi(a, b, ra, rb); l[j] = bf3_pack(ra, rb);
+    }
+    reinterpret_cast<uint4 *>(hi)[idx] = make_uint4(h[0], h[1], h[2], h[3]);
+    reinterpret_cast<uint4 *>(lo)[idx] = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+// WIDE: the 129-wide input of np-nd-np (message + sign), split like the hidden part.  Narrow (p-nd-np: 2 or 3 survey columns + sign = K 4): the
+// input part stays two f32 MFMA steps on an fp32 tile column block (nothing to gain on K = 4), the hidden part runs on the split products.
+template <bool WIDE, bool MASK>
+__global__ void __launch_bounds__(NTN) k_gru_bf3(int E, const float *__restrict__ state, const float *__restrict__ sign, const float *__restrict__ hprev,
+                                                 const float *__restrict__ rowmask, const uint32_t *__restrict__ wxh, const uint32_t *__restrict__ wxl,
+                                                 const uint32_t *__restrict__ whh, const uint32_t *__restrict__ whl, const float *__restrict__ Wt_ih, int dx,
+                                                 const float *__restrict__ b_ih, const float *__restrict__ b_hh, float *__restrict__ out, int ntiles /* full tiles only */)
+{
+    constexpr int H = 128, N3 = 3 * H;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    // two tile buffers, used alternately (as in k_gru_pipe); per buffer Xh | Xl | Hh | Hl (narrow: an fp32 [TM][5] block in place of Xh | Xl)
+    constexpr int XW = WIDE ? TM * BF3_XS : 320;             // dwords of the input part of a buffer
+    constexpr int TBW = XW + TM * BF3_HS;                    // dwords per buffer
+    uint32_t *const T32 = reinterpret_cast<uint32_t *>(sm);
+    float *const Mk = sm + 2 * TBW;                          // [3][TM] row masks of the previous, the current and the next tile
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    // the next tile's rows travel in two halves (rows jr < 4 during the first gate, the others during the second): 256 registers per wave
+    // hold the accumulators, the carried gates and the operand fragments, and any spill costs the launch a scratch allocation
+    constexpr int PH = PRE_R / 2;
+    float2 px[PH], ph[PH];
+    float psg = 0.0f;
+    auto fetch = [&](int tile, int half) {
+        const int e0 = tile * TM;
+#pragma unroll
+        for (int jr = 0; jr < PH; ++jr) {
+            const size_t e = (size_t)(e0 + wave + NWAVES * (jr + PH * half));
+            if constexpr (WIDE) px[jr] = reinterpret_cast<const float2 *>(state + e * H)[l];
+            else px[jr].x = (l < dx) ? state[e * dx + l] : (l == dx ? sign[e] : 0.0f);
+            ph[jr] = reinterpret_cast<const float2 *>(hprev + e * H)[l];
+        }
+        if (half == 0) {
+            if (WIDE && wave == 0) psg = sign[e0 + l];
+            if (wave == 1) psg = MASK ? rowmask[e0 + l] : 1.0f;
+        }
+    };
+    auto deposit = [&](int par, int mslot, int half) {
+        uint32_t *Xh = T32 + par * TBW, *Xl = Xh + TM * (BF3_XS / 2), *Hh = T32 + par * TBW + XW, *Hl = Hh + TM * (BF3_HS / 2);
+#pragma unroll
+        for (int jr = 0; jr < PH; ++jr) {
+            const int r = wave + NWAVES * (jr + PH * half);
+            float ra, rb;
+            if constexpr (WIDE) { Xh[r * (BF3_XS / 2) + l] = bf3_pack_hi(px[jr].x, px[jr].y, ra, rb); Xl[r * (BF3_XS / 2) + l] = bf3_pack(ra, rb); }
+            else { if (l < 4) reinterpret_cast<float *>(Xh)[r * 5 + l] = px[jr].x; }
+            Hh[r * (BF3_HS / 2) + l] = bf3_pack_hi(ph[jr].x, ph[jr].y, ra, rb); Hl[r * (BF3_HS / 2) + l] = bf3_pack(ra, rb);
+        }
+        if (half == 0) {
+            if (WIDE && wave == 0) Xh[l * (BF3_XS / 2) + H / 2] = bf3_pack(psg, 0.0f);    // columns 128 (the sign: +-1 is a bf16) and 129
+            if (wave == 1) Mk[mslot * TM + l] = psg;
+        }
+    };
+    if constexpr (WIDE) {
+        // the pad columns 130 .. 151 of both parts and the low part of the sign column: zero, never overwritten
+        for (int idx = threadIdx.x; idx < 2 * TM * 12; idx += NTN) {
+            const int b = idx / (TM * 12), r = (idx / 12) % TM, c = idx % 12;
+            uint32_t *Xh = T32 + b * TBW, *Xl = Xh + TM * (BF3_XS / 2);
+            if (c > 0) Xh[r * (BF3_XS / 2) + H / 2 + c] = 0u;
+            Xl[r * (BF3_XS / 2) + H / 2 + c] = 0u;
+        }
+    }
+    if (threadIdx.x < TM) Mk[2 * TM + threadIdx.x] = 0.0f;
+    const int nb = wave >> 1, mb = wave & 1, i = l & 31, kq = l >> 5;
+    const int col = 32 * nb + i;
+    const __amdgpu_buffer_rsrc_t rxh = __builtin_amdgcn_make_buffer_rsrc((void *)wxh, 0, WIDE ? (BF3_KX / 8) * N3 * 16 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rxl = __builtin_amdgcn_make_buffer_rsrc((void *)wxl, 0, WIDE ? (BF3_KX / 8) * N3 * 16 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rhh = __builtin_amdgcn_make_buffer_rsrc((void *)whh, 0, (H / 8) * N3 * 16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rhl = __builtin_amdgcn_make_buffer_rsrc((void *)whl, 0, (H / 8) * N3 * 16, 0x00020000);
+    const int wstep = 2 * N3 * 16;                            // bytes per k-block of 16 (two k8 rows)
+    const int ooff = ((32 * mb + 4 * kq) * H + col) * (int)sizeof(float);
+    const float bir = b_ih[col], biz = b_ih[H + col], bin = b_ih[2 * H + col];
+    const float bhr = b_hh[col], bhz = b_hh[H + col], bhn = b_hh[2 * H + col];
+    const int row0 = 32 * mb + 4 * kq;
+    // narrow: the four weight values of this lane per gate (k = kq and 2 + kq), kept in registers
+    float wn[3][2];
+    if constexpr (!WIDE) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) { wn[g][0] = Wt_ih[(size_t)kq * N3 + g * H + col]; wn[g][1] = Wt_ih[(size_t)(2 + kq) * N3 + g * H + col]; }
+    }
+    f32x16 tq, zg;                                         // carried: tanh argument, update gate (the previous hidden value is re-read per slice)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { tq[r] = 0.0f; zg[r] = 0.0f; }
+    int tile = blockIdx.x;
+    if (tile < ntiles) { fetch(tile, 0); deposit(0, 0, 0); fetch(tile, 1); deposit(0, 0, 1); }
+    int e_prev = tile * TM;
+    int par = 0, ms = 0;
+    for (; tile < ntiles; tile += gridDim.x, par ^= 1, ms = (ms + 1) % 3) {
+        __syncthreads();
+        const int next = tile + gridDim.x;
+        if (next < ntiles) fetch(next, 0);
+        const uint16_t *Xh = reinterpret_cast<const uint16_t *>(T32 + par * TBW), *Xl = Xh + TM * BF3_XS;
+        const uint16_t *Hh = reinterpret_cast<const uint16_t *>(T32 + par * TBW + XW), *Hl = Hh + TM * BF3_HS;
+        const uint16_t *axh = Xh + (32 * mb + i) * BF3_XS + 8 * kq, *axl = Xl + (32 * mb + i) * BF3_XS + 8 * kq;
+        const uint16_t *ahh = Hh + (32 * mb + i) * BF3_HS + 8 * kq, *ahl = Hl + (32 * mb + i) * BF3_HS + 8 * kq;
+        const float *xf = reinterpret_cast<const float *>(Xh) + (32 * mb + i) * 5 + kq;
+        f32x16 ai, ah, rg;
+        // one gate: 9 k-blocks of the input part and 8 of the hidden part, alternating (two accumulators: no MFMA waits for the one before
+        // it), weight fragments one block ahead, two activation slices of the previous gate per block pair
+        auto phase = [&](int gate, float bi, float bh, auto &&epi) {
+            const int voff = (kq * N3 + gate * H + col) * 16;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ai[r] = bi; ah[r] = bh; }
+            // the weight fragments (L2) are requested one block ahead, the tile fragments (LDS) when the block before has issued: the
+            // activation slices that follow cover the LDS round trip, and the registers of a second copy are not there (256 per wave)
+            bf16x8 a_xh, a_xl, a_hh, a_hl, b_xh[2], b_xl[2], b_hh[2], b_hl[2];
+            constexpr int NSX = WIDE ? BF3_KX / 16 : 0, NS = WIDE ? BF3_KX / 16 : H / 16;
+            auto loadB = [&](int s, int q) {
+                if (s < NSX) {
+                    b_xh[q] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rxh, voff, s * wstep, 0));
+                    b_xl[q] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rxl, voff, s * wstep, 0));
+                }
+                if (s < H / 16) {
+                    b_hh[q] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rhh, voff, s * wstep, 0));
+                    b_hl[q] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rhl, voff, s * wstep, 0));
+                }
+            };
+            auto loadA = [&](int s) {
+                if (s < NSX) { a_xh = *reinterpret_cast<const bf16x8 *>(axh + 16 * s); a_xl = *reinterpret_cast<const bf16x8 *>(axl + 16 * s); }
+                if (s < H / 16) { a_hh = *reinterpret_cast<const bf16x8 *>(ahh + 16 * s); a_hl = *reinterpret_cast<const bf16x8 *>(ahl + 16 * s); }
+            };
+            loadB(0, 0); loadA(0);
+            if constexpr (!WIDE) {
+                ai = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[0], wn[gate][0], ai, 0, 0, 0);
+                ai = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[2], wn[gate][1], ai, 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int q = s & 1;
+                if (s + 1 < NS) loadB(s + 1, q ^ 1);
+                const bool xpart = s < NSX, hpart = s < H / 16;
+                if (xpart) ai = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_xh, b_xh[q], ai, 0, 0, 0);
+                if (hpart) ah = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hh, b_hh[q], ah, 0, 0, 0);
+                if (xpart) ai = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_xh, b_xl[q], ai, 0, 0, 0);
+                if (hpart) ah = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hh, b_hl[q], ah, 0, 0, 0);
+                if (xpart) ai = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_xl, b_xh[q], ai, 0, 0, 0);
+                if (hpart) ah = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hl, b_hh[q], ah, 0, 0, 0);
+                asm volatile("" : "+v"(ai), "+v"(ah));
+                if (s + 1 < NS) loadA(s + 1);
+                if (hpart) { epi(2 * s); epi(2 * s + 1); }
+                __builtin_amdgcn_sched_barrier(0);            // nothing moves across blocks: later blocks' loads would pile up in registers
+            }
+        };
+        const __amdgpu_buffer_rsrc_t ob = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)e_prev * H), 0, TM * H * (int)sizeof(float), 0x00020000);
+        // the previous tile's hidden rows (fp32, from L2): slice c's value is requested two slices earlier
+        const __amdgpu_buffer_rsrc_t hb = __builtin_amdgcn_make_buffer_rsrc((void *)(hprev + (size_t)e_prev * H), 0, TM * H * (int)sizeof(float), 0x00020000);
+        auto hload = [&](int c) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hb, ooff, ((c & 3) + 8 * (c >> 2)) * H * (int)sizeof(float), 0)); };
+        float hq2[2] = {hload(0), hload(1)};
+        const float *mp = Mk + ((ms + 2) % 3) * TM + row0;
+        phase(0, bir, bhr, [&](int c) {
+            const int ro = (c & 3) + 8 * (c >> 2);
+            const float hqc = hq2[c & 1];
+            if (c + 2 < 16) hq2[c & 1] = hload(c + 2);
+            const float ng = pdp_tanhf_abs(tq[c]);
+            const float hnew = (hqc - ng) * zg[c] + ng;
+            const float mk = mp[ro];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mk * hnew + (1.0f - mk) * hqc), ob, ooff, ro * H * (int)sizeof(float), 0);
+        });
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rg[r] = ah[r] + ai[r];
+        if (next < ntiles) { deposit(par ^ 1, (ms + 1) % 3, 0); fetch(next, 1); }
+        phase(1, biz, bhz, [&](int c) { float v = pdp_sigmoidf(rg[c]); asm volatile("" : "+v"(v)); rg[c] = v; });
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zg[r] = ah[r] + ai[r];
+        if (next < ntiles) deposit(par ^ 1, (ms + 1) % 3, 1);
+        phase(2, bin, bhn, [&](int c) { float v = pdp_sigmoidf(zg[c]); asm volatile("" : "+v"(v)); zg[c] = v; });
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tq[r] = ai[r] + ah[r] * rg[r];
+        e_prev = tile * TM;
+    }
+    if (blockIdx.x < ntiles) {
+        const __amdgpu_buffer_rsrc_t ob = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)e_prev * H), 0, TM * H * (int)sizeof(float), 0x00020000);
+        const __amdgpu_buffer_rsrc_t hb = __builtin_amdgcn_make_buffer_rsrc((void *)(hprev + (size_t)e_prev * H), 0, TM * H * (int)sizeof(float), 0x00020000);
+        const float *mp = Mk + ((ms + 2) % 3) * TM + row0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int ro = (c & 3) + 8 * (c >> 2);
+            const float hqc = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hb, ooff, ro * H * (int)sizeof(float), 0));
+            const float ng = pdp_tanhf_abs(tq[c]);
+            const float hnew = (hqc - ng) * zg[c] + ng;
+            const float mk = mp[ro];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mk * hnew + (1.0f - mk) * hqc), ob, ooff, ro * H * (int)sizeof(float), 0);
+        }
+    }
+}
+#endif
+
 // ---- kernel 5c: the pipelined cell with a WAVE as the unit of work (hidden widths whose column blocks do not divide eight waves) --------
 // Hidden 150 (the reference's shipped np-nd-np predict config) has five 32-column blocks: the ten blocks of a 64-edge tile leave two of
 // eight waves busy in a second round, whatever the window.  Here a wave owns a 32-edge tile from its rows to the stored result and walks
@@ -1738,6 +1965,28 @@ extern "C" int pdp_neural_gru(pdp_problem *p, const pdp_gru_desc *d, const float
         if (full > 0) {
             const size_t ldsp = 2 * lds + sizeof(float) * 3 * TM;        // two tile buffers + three mask rows
             const int grid = full < persistent_grid() ? full : persistent_grid();
+#ifdef PDP_FAST_MATH
+            if (!getenv("PDP_GRU_NO_BF16X3")) {
+                // three-term bf16 products (k_gru_bf3): the weights are split per call (99 072 values, microseconds) into a workspace
+                const bool wide = g.Kpx == 130;
+                const size_t wx = (size_t)(BF3_KX / 8) * 3 * 128 * 4, wh = (size_t)(128 / 8) * 3 * 128 * 4;        // dwords per part
+                uint32_t *wsp = (uint32_t *)neural_ws(p, 3, 2 * (wx + wh));
+                if (!wsp) return PDP_ERR_HIP;
+                uint32_t *wxh = wsp, *wxl = wxh + wx, *whh = wxl + wx, *whl = whh + wh;
+                if (wide) hipLaunchKernelGGL(k_bf3_split_weights, dim3(((BF3_KX / 8) * 384 + 255) / 256), dim3(256), 0, st, g.Wt_ih, g.Kpx, BF3_KX, 384, wxh, wxl);
+                hipLaunchKernelGGL(k_bf3_split_weights, dim3(((128 / 8) * 384 + 255) / 256), dim3(256), 0, st, g.Wt_hh, g.Kph, 128, 384, whh, whl);
+                const size_t ldsb = (size_t)2 * ((wide ? TM * BF3_XS : 320) + TM * BF3_HS) * 4 + sizeof(float) * 3 * TM;
+                if (wide) {
+                    s = set_lds((const void *)k_gru_bf3<true, true>, ldsb); if (s != PDP_OK) return s;
+                    pdp_note_kernel(PDP_TK_GRU, "k_gru_bf3<true, true>");
+                    hipLaunchKernelGGL((k_gru_bf3<true, true>), dim3(grid), dim3(NTN), ldsb, st, E, state, p->edge_sign, h, rowmask, wxh, wxl, whh, whl, g.Wt_ih, g.dx, g.b_ih, g.b_hh, out, full);
+                } else {
+                    s = set_lds((const void *)k_gru_bf3<false, true>, ldsb); if (s != PDP_OK) return s;
+                    pdp_note_kernel(PDP_TK_GRU, "k_gru_bf3<false, true>");
+                    hipLaunchKernelGGL((k_gru_bf3<false, true>), dim3(grid), dim3(NTN), ldsb, st, E, state, p->edge_sign, h, rowmask, wxh, wxl, whh, whl, g.Wt_ih, g.dx, g.b_ih, g.b_hh, out, full);
+                }
+            } else
+#endif
             if (g.Kpx == 130) {
                 s = set_lds((const void *)k_gru_pipe<65, true>, ldsp); if (s != PDP_OK) return s;
                 pdp_note_kernel(PDP_TK_GRU, "k_gru_pipe<65, true>");

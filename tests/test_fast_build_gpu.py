@@ -73,6 +73,55 @@ def test_device_math_of_the_fast_build_against_float64():
         native.use_build(prev)
 
 
+@pytest.mark.parametrize('dx', [128, 3, 2])
+def test_gru_on_three_term_bf16_products_against_float64(dx):
+    """The fast build runs the hidden-128 GRU cell on bf16 MFMAs with both operands split into high + low parts (hi hi + hi lo + lo hi, fp32
+    accumulation: `k_gru_bf3`, csrc/pdp_neural.hip; reference `nn.GRUCell`, pdp_decimate.py:38-41,75,83).  Against a float64 evaluation of the
+    same cell the error stays within 2e-5 of the largest |h'| -- the parity build's fp32 chain is at 2e-6 on the same input -- for the 129-wide
+    input of np-nd-np and the 4- / 3-wide ones of p-nd-np; rows of inactive instances pass through unchanged, bit for bit."""
+    from pdp import native
+    from pdp.factorgraph import dataset
+    dev = torch.device('cuda:0')
+    b = dataset.to_torch(dataset.collate_segment(dataset.random_ksat_items(40, 200, 3, m=840, seed=3)), dev)
+    torch.manual_seed(11)
+    cell = torch.nn.GRUCell(dx + 1, 128).to(dev)
+    prev = native.BUILD
+    out = {}
+    try:
+        for build in ('parity', 'fast'):
+            native.use_build(build)
+            prob = native.Problem(b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'])
+            E = prob.E
+            g = torch.Generator(device='cpu'); g.manual_seed(5)
+            state = (torch.randn(E, dx, generator=g) * 0.7).to(dev); h = (torch.randn(E, 128, generator=g) * 0.5).to(dev)
+            am = torch.ones(prob.B, dtype=torch.uint8, device=dev); am[::5] = 0
+            w = native.GruWeights(cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh)
+            out[build] = prob.neural_gru(w, state, h, am).cpu().numpy()
+            name = native.kernel_name('gru')
+            assert name.startswith('k_gru_bf3<') if build == 'fast' else name.startswith('k_gru_pipe<'), name
+            sign = prob.edge_sign.cpu().numpy() if hasattr(prob, 'edge_sign') else None
+    finally:
+        native.use_build(prev)
+    # float64 reference of the cell on [state | sign] (the sign column is the loader's edge feature)
+    ef = b['edge_feature'].cpu().numpy().reshape(-1).astype(np.float64)
+    x = np.concatenate([state.cpu().numpy().astype(np.float64), ef[:, None]], axis=1)
+    h64 = h.cpu().numpy().astype(np.float64)
+    Wi, Wh = cell.weight_ih.detach().cpu().numpy().astype(np.float64), cell.weight_hh.detach().cpu().numpy().astype(np.float64)
+    bi, bh = cell.bias_ih.detach().cpu().numpy().astype(np.float64), cell.bias_hh.detach().cpu().numpy().astype(np.float64)
+    gi, gh = x @ Wi.T + bi, h64 @ Wh.T + bh
+    sg = lambda v: 1.0 / (1.0 + np.exp(-v))
+    r, z = sg(gi[:, :128] + gh[:, :128]), sg(gi[:, 128:256] + gh[:, 128:256])
+    n = np.tanh(gi[:, 256:] + r * gh[:, 256:])
+    want = (1.0 - z) * n + z * h64
+    inst = b['batch_variable_map'].cpu().numpy()[b['graph_map'].cpu().numpy()[0]]
+    live = am.cpu().numpy()[inst] == 1
+    scale = np.abs(want).max()
+    err_fast = np.abs(out['fast'][live] - want[live]).max() / scale
+    err_parity = np.abs(out['parity'][live] - want[live]).max() / scale
+    assert err_parity < 3e-6 and err_fast < 2e-5, (err_parity, err_fast)
+    np.testing.assert_array_equal(out['fast'][~live], h.cpu().numpy()[~live])
+
+
 def test_headline_family_solved_counts_equal_the_parity_build():
     """random 3-SAT n=200 m=840, 600 instances (a NaN-poisoned batch like the headline), T=100 + Walk-SAT: the two builds run the same
     number of sweeps, poison the batch in the same sweep, fix almost the same variables and solve the same number of instances"""

@@ -62,6 +62,18 @@ def fast_build_measurement(args, dev, native, host_batch, items, parity_solved):
             try:
                 out['neural'] = neural_shard(args, dev, native, items, 'np-nd-np', args.hidden, args.secondary_neural_iters,
                                              workload="configs[2] on the fast build: 'np-nd-np' hidden %d, same batch" % args.hidden)
+                # the fast build's GRU runs on three-term bf16 products (k_gru_bf3): the fp32-MFMA fraction above is a comparison with the
+                # parity build, not a bound.  Its own bounds: the bf16 MFMA peak / 3 for the cell's flop, and the HBM stream of a call.
+                nk = out['neural'].get('kernels', {}).get('gru')
+                if nk and str(nk.get('kernel', '')).startswith('k_gru_bf3'):
+                    E = out['neural']['edges_per_segment_with_replicas'][0]
+                    stream = 3.0 * E * args.hidden * 4 + 1.0 * E * args.hidden * 4        # state + hidden in, hidden out, hidden once more for the blend (L2 / MALL)
+                    sec = nk['ms_per_launch'] * 1e-3
+                    nk.update(dtype='bf16x3 -> f32 (hi hi + hi lo + lo hi, fp32 accumulation)',
+                              roofline_bf16x3=dict(bound='mfma', achieved=nk['tflops'], peak=2500.0 / 3.0, unit='TFLOP/s', frac=nk['tflops'] / (2500.0 / 3.0)),
+                              roofline_hbm=dict(bound='hbm', achieved=stream / sec / 1e9, peak=HBM_PEAK_GBS, unit='GB/s', frac=stream / sec / 1e9 / HBM_PEAK_GBS,
+                                                bytes_per_launch=stream))
+                    out['neural']['dtype'] = 'f32 activations and aggregator layers; GRU products bf16x3 -> f32'
             except Exception as ex:                          # measurement only: never take the headline line down
                 out['neural'] = dict(error=repr(ex))
     finally:
