@@ -1602,6 +1602,258 @@ __global__ void __launch_bounds__(NTN) k_gru_bf3(int E, const float *__restrict_
         }
     }
 }
+
+// ---- the aggregator's second half (hidden 128) on three-term bf16 products, fast build only ---------------------------------------------
+// k_agg_post_pf's workgroup tile (64 edges, 8 waves, three workgroups per CU) with both layers as split products: the 52-wide input block
+// and the 100-wide hidden layer live in LDS as bf16 high + low parts (the bytes of the float), every wave's block is 4 (7) k-blocks of 16
+// x three matrix instructions instead of 26 (50) f32 steps.  The 16-column tail of the f32 kernel is not needed: a full 32-column block of
+// the hidden layer is 12 instructions here.  Output block transposed (operands swapped) for 16-byte stores, as in the f32 kernel.
+#define BF3_RS 72         /* bf16 per row of the input block: 64 used (52 + zero pad), 36 dwords = 9 x 16 bytes */
+#define BF3_GS 120        /* bf16 per row of the hidden layer: 112 used (100 + zero pad), 60 dwords = 15 x 16 bytes */
+template <int NS, bool SWAP>
+__device__ __forceinline__ f32x16 bf3_block(const uint16_t *ah, const uint16_t *al, __amdgpu_buffer_rsrc_t wh, __amdgpu_buffer_rsrc_t wl, int voff, int wstep, float bias)
+{
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bias;
+    bf16x8 bh[2], bl[2];
+    bh[0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wh, voff, 0, 0));
+    bl[0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wl, voff, 0, 0));
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int q = s & 1;
+        if (s + 1 < NS) {
+            bh[q ^ 1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wh, voff, (s + 1) * wstep, 0));
+            bl[q ^ 1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wl, voff, (s + 1) * wstep, 0));
+        }
+        const bf16x8 xh = *reinterpret_cast<const bf16x8 *>(ah + 16 * s), xl = *reinterpret_cast<const bf16x8 *>(al + 16 * s);
+        if (SWAP) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[q], xh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[q], xh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[q], xl, acc, 0, 0, 0);
+        } else {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh[q], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl[q], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh[q], acc, 0, 0, 0);
+        }
+    }
+    return acc;
+}
+// two column blocks of one row block at once: the tile fragments are read once per k-block and the two accumulators alternate, so that no
+// matrix instruction waits for the one before it (a wave alone on its chains: the wave-private kernels run two waves per SIMD)
+template <int NS, bool SWAP>
+__device__ __forceinline__ void bf3_block2(const uint16_t *ah, const uint16_t *al, __amdgpu_buffer_rsrc_t wh, __amdgpu_buffer_rsrc_t wl, int voff0, int voff1, int wstep,
+                                           f32x16 &acc0, f32x16 &acc1)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    bf16x8 bh[2][2], bl[2][2];
+    auto loadB = [&](int s, int q) {
+        bh[q][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wh, voff0, s * wstep, 0));
+        bl[q][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wl, voff0, s * wstep, 0));
+        bh[q][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wh, voff1, s * wstep, 0));
+        bl[q][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wl, voff1, s * wstep, 0));
+    };
+    loadB(0, 0);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int q = s & 1;
+        if (s + 1 < NS) loadB(s + 1, q ^ 1);
+        const bf16x8 xh = *reinterpret_cast<const bf16x8 *>(ah + 16 * s), xl = *reinterpret_cast<const bf16x8 *>(al + 16 * s);
+        if (SWAP) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[q][0], xh, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[q][1], xh, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[q][0], xh, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[q][1], xh, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[q][0], xl, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[q][1], xl, acc1, 0, 0, 0);
+        } else {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh[q][0], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh[q][1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl[q][0], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl[q][1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh[q][0], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh[q][1], acc1, 0, 0, 0);
+        }
+    }
+}
+__device__ __forceinline__ void bf3_store1(uint16_t *hi, uint16_t *lo, float v)
+{
+    const __bf16 h = (__bf16)v;
+    *hi = __builtin_bit_cast(uint16_t, h); *lo = __builtin_bit_cast(uint16_t, (__bf16)(v - (float)h));
+}
+__global__ void __launch_bounds__(NTN, 6) k_agg_post_bf3(int E, const float *__restrict__ agg, const int32_t *__restrict__ edge_row,
+                                                         const float *__restrict__ h2, const float *__restrict__ sign, const float *__restrict__ emask,
+                                                         const float *__restrict__ rowmask, const float *__restrict__ old, AggW w,
+                                                         const uint32_t *__restrict__ w3h, const uint32_t *__restrict__ w3l,
+                                                         const uint32_t *__restrict__ w4h, const uint32_t *__restrict__ w4l, float *__restrict__ out)
+{
+    constexpr int K3 = 64, K4 = 112, N = 128;               // padded k ranges, columns of both layers (100 -> 128, 128)
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    uint16_t *Rh = reinterpret_cast<uint16_t *>(sm), *Rl = Rh + TM * BF3_RS, *Gh = Rl + TM * BF3_RS, *Gl = Gh + TM * BF3_GS;
+    const int e0 = blockIdx.x * TM;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, i = l & 31, kq = l >> 5;
+    float g_hv[TM / NWAVES], g_ag[TM / NWAVES], g_sg[TM / NWAVES], g_em[TM / NWAVES];
+#pragma unroll
+    for (int jr = 0; jr < TM / NWAVES; ++jr) {
+        const int e = e0 + wave + NWAVES * jr;
+        g_hv[jr] = 0.0f; g_ag[jr] = 0.0f; g_sg[jr] = 0.0f; g_em[jr] = 1.0f;
+        if (e < E) {
+            const int row = edge_row[e];
+            g_sg[jr] = sign[e];
+            if (emask) g_em[jr] = emask[e];
+            if (l < w.a) { g_hv[jr] = h2[(size_t)e * w.a + l]; g_ag[jr] = agg[(size_t)row * w.a + l]; }
+        }
+    }
+    const int ROWB = w.out * (int)sizeof(float);
+    const int rows = E - e0 < TM ? E - e0 : TM;
+    const __amdgpu_buffer_rsrc_t pb = __builtin_amdgcn_make_buffer_rsrc((void *)(old + (size_t)e0 * w.out), 0, rows * ROWB, 0x00020000);
+    const int nb = wave >> 1, mb = wave & 1, col = 32 * nb + i;
+    const int lo4 = (32 * mb + i) * ROWB + (32 * nb + 4 * kq) * (int)sizeof(float);
+    float po0[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pb, lo4, q * 32, 0));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) po0[4 * q + c] = v[c];
+    }
+#pragma unroll
+    for (int jr = 0; jr < TM / NWAVES; ++jr) {
+        const int r = wave + NWAVES * jr, e = e0 + r;
+        float v = 0.0f;
+        if (e < E) {
+            if (l < w.a) {
+                const float own = emask ? g_hv[jr] * g_em[jr] : g_hv[jr];
+                v = (0.0f + g_ag[jr]) - own;
+            } else if (l == w.a && w.fd) v = g_sg[jr];
+        }
+        bf3_store1(Rh + r * BF3_RS + l, Rl + r * BF3_RS + l, v);            // columns 52 .. 63: zero
+    }
+    __syncthreads();
+    {
+        const __amdgpu_buffer_rsrc_t r3h = __builtin_amdgcn_make_buffer_rsrc((void *)w3h, 0, (K3 / 8) * N * 16, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r3l = __builtin_amdgcn_make_buffer_rsrc((void *)w3l, 0, (K3 / 8) * N * 16, 0x00020000);
+        const float b0 = col < w.g ? w.b1a[col] : 0.0f;
+        const f32x16 acc = bf3_block<K3 / 16, false>(Rh + (32 * mb + i) * BF3_RS + 8 * kq, Rl + (32 * mb + i) * BF3_RS + 8 * kq, r3h, r3l, (kq * N + col) * 16, 2 * N * 16, b0);
+        if (col < K4) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 v = pk_logsigmoid_or_zero(acc[r], acc[r + 1], col < w.g);
+                bf3_store1(Gh + (32 * mb + acc_row(r, l)) * BF3_GS + col, Gl + (32 * mb + acc_row(r, l)) * BF3_GS + col, v.x);
+                bf3_store1(Gh + (32 * mb + acc_row(r + 1, l)) * BF3_GS + col, Gl + (32 * mb + acc_row(r + 1, l)) * BF3_GS + col, v.y);
+            }
+        }
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t ob = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)e0 * w.out), 0, rows * ROWB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mb_ = __builtin_amdgcn_make_buffer_rsrc((void *)(rowmask ? rowmask + e0 : old), 0, rows * (int)sizeof(float), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r4h = __builtin_amdgcn_make_buffer_rsrc((void *)w4h, 0, (K4 / 8) * N * 16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r4l = __builtin_amdgcn_make_buffer_rsrc((void *)w4l, 0, (K4 / 8) * N * 16, 0x00020000);
+    // operands swapped: lane (i, kq) holds ROW 32 mb + i of the tile, register 4 q + c the column 32 nb + 8 q + 4 kq + c
+    const f32x16 acc = bf3_block<K4 / 16, true>(Gh + (32 * mb + i) * BF3_GS + 8 * kq, Gl + (32 * mb + i) * BF3_GS + 8 * kq, r4h, r4l, (kq * N + col) * 16, 2 * N * 16, 0.0f);
+    const float mk = rowmask ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mb_, (32 * mb + i) * (int)sizeof(float), 0, 0)) : 1.0f;
+    const f32x2 m2 = {mk, mk};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x2 n0 = pk_logsigmoid((f32x2){acc[4 * q], acc[4 * q + 1]}), n1 = pk_logsigmoid((f32x2){acc[4 * q + 2], acc[4 * q + 3]});
+        const f32x2 b0 = m2 * n0 + (1.0f - m2) * (f32x2){po0[4 * q], po0[4 * q + 1]}, b1 = m2 * n1 + (1.0f - m2) * (f32x2){po0[4 * q + 2], po0[4 * q + 3]};
+        const f32x4 v = {b0.x, b0.y, b1.x, b1.y};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), ob, lo4, q * 32, 0);
+    }
+}
+
+// ---- the aggregator's first half (hidden 128) on three-term bf16 products, fast build only -----------------------------------------------
+// k_agg_pre_wave's form -- a wave owns a 32-edge tile from its input rows to the stored [E, 50] result, no workgroup barrier -- with the
+// 130-wide input block and the 100-wide hidden layer as bf16 high + low parts in the wave's LDS region (the hidden layer replaces the input
+// block, as there).  First layer: four 32-column blocks x 9 k-blocks x three matrix instructions, transposed (operands swapped) so that a
+// lane holds four consecutive columns of a row and the split hidden values leave in 8-byte stores; second layer two blocks x 7 k-blocks.
+__global__ void __launch_bounds__(NTN) k_agg_pre_bf3(int E, const float *__restrict__ state, const float *__restrict__ sign, const float *__restrict__ emask, AggW w,
+                                                     const uint32_t *__restrict__ w1h, const uint32_t *__restrict__ w1l, const uint32_t *__restrict__ w2h,
+                                                     const uint32_t *__restrict__ w2l, float *__restrict__ h2out, int ntiles)
+{
+    constexpr int SD = 128, K1 = BF3_KX, K2 = 112, N1 = 128, N2 = 64;
+    constexpr int REG = WT * BF3_XS * 2;                     // dwords of a wave's region: input block hi | lo (the hidden layer, 2 x WT x BF3_GS bf16, is smaller)
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, i = l & 31, kq = l >> 5;
+    uint32_t *const X32 = reinterpret_cast<uint32_t *>(sm) + wave * (REG / 2);
+    uint16_t *const Xh = reinterpret_cast<uint16_t *>(X32), *const Xl = Xh + WT * BF3_XS;
+    uint16_t *const Hh = Xh, *const Hl = Xh + WT * BF3_GS;
+    const __amdgpu_buffer_rsrc_t r1h = __builtin_amdgcn_make_buffer_rsrc((void *)w1h, 0, (K1 / 8) * N1 * 16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1l = __builtin_amdgcn_make_buffer_rsrc((void *)w1l, 0, (K1 / 8) * N1 * 16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2h = __builtin_amdgcn_make_buffer_rsrc((void *)w2h, 0, (K2 / 8) * N2 * 16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2l = __builtin_amdgcn_make_buffer_rsrc((void *)w2l, 0, (K2 / 8) * N2 * 16, 0x00020000);
+    auto tile_rsrc = [&](const float *base, int e0, int row_bytes) {
+        const int rows = E - e0 < WT ? E - e0 : WT;
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(base + (size_t)e0 * (row_bytes / (int)sizeof(float))), 0, rows * row_bytes, 0x00020000);
+    };
+    float2 pv[WT];
+    float psg = 0.0f;
+    auto fetch = [&](int tile) {
+        const int e0 = tile * WT;
+#pragma unroll
+        for (int r = 0; r < WT; ++r) pv[r] = (e0 + r < E) ? reinterpret_cast<const float2 *>(state + (size_t)(e0 + r) * SD)[l] : make_float2(0.0f, 0.0f);
+        psg = (l < WT && e0 + l < E) ? sign[e0 + l] : 0.0f;
+    };
+    // first layer's bias per register of the transposed block: column 32 nb + 8 q + 4 kq + c
+    const int stride = gridDim.x * NWAVES;
+    int tile = blockIdx.x * NWAVES + wave;
+    if (tile < ntiles) fetch(tile);
+    for (; tile < ntiles; tile += stride) {
+        const int e0 = tile * WT;
+#pragma unroll
+        for (int r = 0; r < WT; ++r) {
+            float ra, rb;
+            X32[r * (BF3_XS / 2) + l] = bf3_pack_hi(pv[r].x, pv[r].y, ra, rb);
+            X32[WT * (BF3_XS / 2) + r * (BF3_XS / 2) + l] = bf3_pack(ra, rb);
+        }
+        if (l < WT) {
+            // columns 128 (the sign: +-1 is a bf16) .. 143: the hidden layer of the previous tile stood here
+            uint4 z = make_uint4(bf3_pack(psg, 0.0f), 0u, 0u, 0u), zz = make_uint4(0u, 0u, 0u, 0u);
+            uint4 *hrow = reinterpret_cast<uint4 *>(Xh + l * BF3_XS + SD), *lrow = reinterpret_cast<uint4 *>(Xl + l * BF3_XS + SD);
+            hrow[0] = z; hrow[1] = zz; lrow[0] = zz; lrow[1] = zz;
+        }
+        f32x16 acc[4];
+        bf3_block2<K1 / 16, true>(Xh + i * BF3_XS + 8 * kq, Xl + i * BF3_XS + 8 * kq, r1h, r1l, (kq * N1 + i) * 16, (kq * N1 + 32 + i) * 16, 2 * N1 * 16, acc[0], acc[1]);
+        bf3_block2<K1 / 16, true>(Xh + i * BF3_XS + 8 * kq, Xl + i * BF3_XS + 8 * kq, r1h, r1l, (kq * N1 + 64 + i) * 16, (kq * N1 + 96 + i) * 16, 2 * N1 * 16, acc[2], acc[3]);
+        if (tile + stride < ntiles) fetch(tile + stride);
+        float em[16];
+        if (emask) {
+            const __amdgpu_buffer_rsrc_t eb = tile_rsrc(emask, e0, (int)sizeof(float));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) em[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(eb, 16 * kq, ((r & 3) + 8 * (r >> 2)) * 4, 0));
+        }
+        // every chain has consumed its operands (LDS operations of a wave complete in order): the hidden layer replaces the input block.
+        // Transposed blocks: lane (i, kq) holds row i, register 4 q + c the column 32 nb + 8 q + 4 kq + c -- four columns per 8-byte store
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c0 = 32 * nb + 8 * q + 4 * kq;
+                if (c0 < K2) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(w.b1m + c0);
+                    const f32x2 v0 = pk_logsigmoid_or_zero(acc[nb][4 * q] + b4[0], acc[nb][4 * q + 1] + b4[1], c0 < w.m1);
+                    const f32x2 v1 = pk_logsigmoid_or_zero(acc[nb][4 * q + 2] + b4[2], acc[nb][4 * q + 3] + b4[3], c0 + 2 < w.m1);
+                    float r0, r1, r2, r3;
+                    const uint32_t h0 = bf3_pack_hi(v0.x, v0.y, r0, r1), h1 = bf3_pack_hi(v1.x, v1.y, r2, r3);
+                    *reinterpret_cast<uint2 *>(Hh + i * BF3_GS + c0) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2 *>(Hl + i * BF3_GS + c0) = make_uint2(bf3_pack(r0, r1), bf3_pack(r2, r3));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x16 ac2[2];
+        bf3_block2<K2 / 16, false>(Hh + i * BF3_GS + 8 * kq, Hl + i * BF3_GS + 8 * kq, r2h, r2l, (kq * N2 + i) * 16, (kq * N2 + 32 + i) * 16, 2 * N2 * 16, ac2[0], ac2[1]);
+        const int rowb = w.a * (int)sizeof(float);                           // h2 rows are a floats wide
+        const __amdgpu_buffer_rsrc_t hb = tile_rsrc(h2out, e0, rowb);
+        const int lo = 4 * kq * rowb + i * (int)sizeof(float);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            if (32 * nb + i < w.a) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    f32x2 v = pk_logsigmoid((f32x2){ac2[nb][r], ac2[nb][r + 1]});
+                    if (emask) v = v * (f32x2){em[r], em[r + 1]};
+                    __builtin_amdgcn_raw_buffer_store_b32(f2i(v.x), hb, lo + nb * 128, ((r & 3) + 8 * (r >> 2)) * rowb, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(f2i(v.y), hb, lo + nb * 128, (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * rowb, 0);
+                }
+            }
+        }
+    }
+}
 #endif
 
 // ---- kernel 5c: the pipelined cell with a WAVE as the unit of work (hidden widths whose column blocks do not divide eight waves) --------
@@ -1821,6 +2073,34 @@ static int set_lds(const void *fn, size_t bytes)
 }
 
 static float *neural_ws(pdp_problem *p, int slot, size_t floats);
+#ifdef PDP_FAST_MATH
+// split weights of the three-term bf16 kernels: part 0 the GRU's, 1 the aggregator's second half, 2 its first half.  One buffer per (device,
+// stream), allocated at first use and kept for the life of the process: a SATProblem lives for one forward, and a hipMalloc / hipFree pair
+// per forward stalls the device far longer than the kernels it serves (measured: 40 ms per np-nd-np iteration on some boxes).  The splits
+// are written and read in stream order, so calls on one stream never see each other's weights.
+#include <mutex>
+#include <vector>
+static uint32_t *bf3_workspace(pdp_problem *, int part, hipStream_t st)
+{
+    const size_t g = 2 * ((size_t)(144 / 8) * 384 * 4 + (size_t)(128 / 8) * 384 * 4), q = 2 * ((size_t)(64 / 8) * 128 * 4 + (size_t)(112 / 8) * 128 * 4);
+    const size_t r = 2 * ((size_t)(144 / 8) * 128 * 4 + (size_t)(112 / 8) * 64 * 4);
+    struct Slot { int dev; hipStream_t st; uint32_t *base; };
+    static std::mutex mu;
+    static std::vector<Slot> slots;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    uint32_t *base = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        for (const Slot &s : slots) if (s.dev == dev && s.st == st) base = s.base;
+        if (!base) {
+            if (hipMalloc((void **)&base, (g + q + r) * sizeof(uint32_t)) != hipSuccess) return nullptr;
+            slots.push_back(Slot{dev, st, base});
+        }
+    }
+    return part == 0 ? base : (part == 1 ? base + g : base + g + q);
+}
+#endif
 
 #define LDS_RES_LIMIT (160 * 1024 - 512)
 // PDP_NEURAL_GENERIC=1: every operator on its generic tile kernel (k_agg_pre / k_agg_post / k_gru) -- the cross-check the full-size tests run
@@ -1833,13 +2113,31 @@ static int persistent_grid()
 }
 
 // aggregator pre-transform: wave-private form (default); resident-weight persistent form when both matrices and the tile fit the LDS, tile-per-workgroup form otherwise
-static int launch_agg_pre(int E, const float *state, const float *sign, const float *edge_mask, const AggW &w, float *h2, hipStream_t st)
+static int launch_agg_pre(int E, const float *state, const float *sign, const float *edge_mask, const AggW &w, float *h2, hipStream_t st, uint32_t *bf3_ws = nullptr)
 {
     pdp_timed_scope timed(PDP_TK_AGG_PRE, st);
     const int tiles = (E + TM - 1) / TM;
     const size_t lds1 = sizeof(float) * (size_t)TM * ((w.Kp1 + 1) + (w.Np1 + 1));
     const size_t res1 = sizeof(float) * ((size_t)w.Kp1 * w.Np1 + (size_t)w.Kp2 * w.Np2) + lds1;
     const bool shape128 = w.din - 1 == 128 && w.Kp1 == 130, shape150 = w.din - 1 == 150 && w.Kp1 == 152;
+#ifdef PDP_FAST_MATH
+    if (!generic_forced() && shape128 && w.Np1 == 128 && w.Kp2 == 100 && w.Np2 == 64 && w.m1 <= 112 && (w.m1 & 3) == 0 && !getenv("PDP_AGG_NO_BF16X3")) {
+        // three-term bf16 products (k_agg_pre_bf3): both layers' weights split per call (workspace passed in by the caller)
+        const size_t w1 = (size_t)(BF3_KX / 8) * 128 * 4, w2 = (size_t)(112 / 8) * 64 * 4;
+        uint32_t *w1h = bf3_ws, *w1l = w1h + w1, *w2h = w1l + w1, *w2l = w2h + w2;
+        if (bf3_ws) {
+            hipLaunchKernelGGL(k_bf3_split_weights, dim3(((BF3_KX / 8) * 128 + 255) / 256), dim3(256), 0, st, w.Wt1m, w.Kp1, BF3_KX, 128, w1h, w1l);
+            hipLaunchKernelGGL(k_bf3_split_weights, dim3(((112 / 8) * 64 + 255) / 256), dim3(256), 0, st, w.Wt2m, w.Kp2, 112, 64, w2h, w2l);
+            const size_t ldsb = (size_t)NWAVES * WT * BF3_XS * 2 * 2;
+            int s = set_lds((const void *)k_agg_pre_bf3, ldsb); if (s != PDP_OK) return s;
+            const int wt = (E + WT - 1) / WT, need = (wt + NWAVES - 1) / NWAVES;
+            const int grid = need < persistent_grid() ? need : persistent_grid();
+            pdp_note_kernel(PDP_TK_AGG_PRE, "k_agg_pre_bf3");
+            hipLaunchKernelGGL(k_agg_pre_bf3, dim3(grid), dim3(NTN), ldsb, st, E, state, sign, edge_mask, w, w1h, w1l, w2h, w2l, h2, wt);
+            return PDP_OK;
+        }
+    }
+#endif
     if (!generic_forced() && (shape128 || shape150) && w.Np1 == 128 && w.Kp2 == 100 && w.Np2 == 64) {
         // hidden 128 (BASELINE configs) or 150 (the reference's shipped predict config) with the 100 / 50 inner widths
         // the first layer is 100 wide: three 32-column blocks + a 16-column tail (112 columns) instead of four blocks; PDP_NEURAL_NO_TAIL16
@@ -1889,7 +2187,11 @@ extern "C" int pdp_neural_aggregate_edges(pdp_problem *p, const pdp_agg_desc *d,
     int s = set_lds((const void *)k_agg_pre, lds1); if (s != PDP_OK) return s;
     s = set_lds((const void *)k_agg_post, lds3); if (s != PDP_OK) return s;
     hipLaunchKernelGGL(k_edge_active, dim3(1024), dim3(256), 0, st, E, p->graph_map, p->var_inst, active_mask, rowmask);
+#ifdef PDP_FAST_MATH
+    s = launch_agg_pre(E, state, p->edge_sign, edge_mask, w, h2, st, bf3_workspace(p, 2, st)); if (s != PDP_OK) return s;
+#else
     s = launch_agg_pre(E, state, p->edge_sign, edge_mask, w, h2, st); if (s != PDP_OK) return s;
+#endif
     // global CSR rows in ascending edge id: the sorted edge lists of the problem (global ids)
     const int32_t *row_ptr = by_variable ? p->nv_ptr : p->nf_ptr;
     const int32_t *row_edges = by_variable ? p->nv_edges : p->nf_edges;
@@ -1919,6 +2221,21 @@ extern "C" int pdp_neural_aggregate_edges(pdp_problem *p, const pdp_agg_desc *d,
         }
     } else if (shape_pf) {
         // hidden 128 (BASELINE configs), and hidden 150 when the row offsets pass 31 bits: the 100 / 50 inner widths, prefetched chains
+#ifdef PDP_FAST_MATH
+        if (w.Np4 == 128 && w.a <= 51 && w.g <= 112 && !getenv("PDP_AGG_NO_BF16X3")) {
+            // three-term bf16 products (k_agg_post_bf3): both layers' weights split per call into the workspace behind the GRU's
+            const size_t w3 = (size_t)(64 / 8) * 128 * 4, w4 = (size_t)(112 / 8) * 128 * 4;
+            uint32_t *wsp = bf3_workspace(p, 1, st);
+            if (!wsp) return PDP_ERR_HIP;
+            uint32_t *w3h = wsp, *w3l = w3h + w3, *w4h = w3l + w3, *w4l = w4h + w4;
+            hipLaunchKernelGGL(k_bf3_split_weights, dim3(((64 / 8) * 128 + 255) / 256), dim3(256), 0, st, w.Wt1a, w.Kp3, 64, 128, w3h, w3l);
+            hipLaunchKernelGGL(k_bf3_split_weights, dim3(((112 / 8) * 128 + 255) / 256), dim3(256), 0, st, w.Wt2a, w.Kp4, 112, 128, w4h, w4l);
+            const size_t ldsb = (size_t)TM * (BF3_RS + BF3_GS) * 2 * 2;
+            s = set_lds((const void *)k_agg_post_bf3, ldsb); if (s != PDP_OK) return s;
+            pdp_note_kernel(PDP_TK_AGG_POST, "k_agg_post_bf3");
+            hipLaunchKernelGGL(k_agg_post_bf3, dim3(tiles), dim3(NTN), ldsb, st, E, agg, edge_row, h2, p->edge_sign, edge_mask, rowmask, old, w, w3h, w3l, w4h, w4l, out);
+        } else
+#endif
         if (w.Np4 == 128) {
             s = set_lds((const void *)k_agg_post_pf<26, 4, 50, 4>, ldsp); if (s != PDP_OK) return s;
             pdp_note_kernel(PDP_TK_AGG_POST, "k_agg_post_pf<26, 4, 50, 4>");
@@ -1970,7 +2287,7 @@ extern "C" int pdp_neural_gru(pdp_problem *p, const pdp_gru_desc *d, const float
                 // three-term bf16 products (k_gru_bf3): the weights are split per call (99 072 values, microseconds) into a workspace
                 const bool wide = g.Kpx == 130;
                 const size_t wx = (size_t)(BF3_KX / 8) * 3 * 128 * 4, wh = (size_t)(128 / 8) * 3 * 128 * 4;        // dwords per part
-                uint32_t *wsp = (uint32_t *)neural_ws(p, 3, 2 * (wx + wh));
+                uint32_t *wsp = bf3_workspace(p, 0, st);
                 if (!wsp) return PDP_ERR_HIP;
                 uint32_t *wxh = wsp, *wxl = wxh + wx, *whh = wxl + wx, *whl = whh + wh;
                 if (wide) hipLaunchKernelGGL(k_bf3_split_weights, dim3(((BF3_KX / 8) * 384 + 255) / 256), dim3(256), 0, st, g.Wt_ih, g.Kpx, BF3_KX, 384, wxh, wxl);
@@ -2073,7 +2390,11 @@ extern "C" int pdp_neural_predict(pdp_problem *p, const pdp_agg_desc *d, const p
     const size_t lds4 = sizeof(float) * (size_t)TM * ((w.Kp3 + 1) + (w.Np3 + 1) + (w.Np4 + 1) + (h.Np + 1));
     int s = set_lds((const void *)k_agg_pre, lds1); if (s != PDP_OK) return s;
     s = set_lds((const void *)k_predict_rows, lds4); if (s != PDP_OK) return s;
+#ifdef PDP_FAST_MATH
+    s = launch_agg_pre(E, state, p->edge_sign, edge_mask, w, h2, st, bf3_workspace(p, 2, st)); if (s != PDP_OK) return s;
+#else
     s = launch_agg_pre(E, state, p->edge_sign, edge_mask, w, h2, st); if (s != PDP_OK) return s;
+#endif
     { pdp_timed_scope timed(PDP_TK_ROW_SUM, st);
       launch_row_sum(V, w.a, p->nv_ptr, p->nv_edges, h2, agg, st); }
     { pdp_timed_scope timed(PDP_TK_PREDICT_HEAD, st);

@@ -122,6 +122,55 @@ def test_gru_on_three_term_bf16_products_against_float64(dx):
     np.testing.assert_array_equal(out['fast'][~live], h.cpu().numpy()[~live])
 
 
+@pytest.mark.parametrize('by_variable', [True, False])
+def test_aggregator_on_three_term_bf16_products_against_float64(by_variable):
+    """The fast build runs both halves of the hidden-128 MessageAggregator (util.py:51-77; inner widths 100 / 50) on split bf16 products
+    (`k_agg_pre_bf3`, `k_agg_post_bf3`).  Against a float64 evaluation of the same call -- per-edge MLP, row sums without the edge's own term,
+    second MLP on [sum | sign], blend with the previous state where the instance is inactive -- the error stays within 5e-5 of the largest |out|
+    (the parity build: 5e-6); inactive rows pass through bit for bit."""
+    from pdp import native
+    from pdp.factorgraph import dataset
+    dev = torch.device('cuda:0')
+    b = dataset.to_torch(dataset.collate_segment(dataset.random_ksat_items(30, 200, 3, m=840, seed=4)), dev)
+    torch.manual_seed(13)
+    H = 128
+    lin = lambda i, o, bias=True: torch.nn.Linear(i, o, bias=bias).to(dev)
+    l1m, l2m, l1a, l2a = lin(H + 1, 100), lin(100, 50, False), lin(51, 100), lin(100, H, False)
+    prev = native.BUILD
+    out = {}
+    try:
+        for build in ('parity', 'fast'):
+            native.use_build(build)
+            prob = native.Problem(b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'])
+            E = prob.E
+            g = torch.Generator(device='cpu'); g.manual_seed(6)
+            state = (torch.randn(E, H, generator=g) * 0.7).to(dev); old = (torch.randn(E, H, generator=g) * 0.5).to(dev)
+            am = torch.ones(prob.B, dtype=torch.uint8, device=dev); am[::4] = 0
+            w = native.AggregatorWeights(l1m.weight, l1m.bias, l2m.weight, l1a.weight, l1a.bias, l2a.weight, 1)
+            out[build] = prob.neural_aggregate_edges(w, by_variable, state, None, am, old).cpu().numpy()
+            names = native.kernel_name('agg_pre'), native.kernel_name('agg_post')
+            assert names == (('k_agg_pre_bf3', 'k_agg_post_bf3') if build == 'fast' else ('k_agg_pre_wave<65, 4, 50, 2, true>', 'k_agg_post_pf<26, 4, 50, 4>')), names
+    finally:
+        native.use_build(prev)
+    gm = b['graph_map'].cpu().numpy()
+    row = gm[0] if by_variable else gm[1]
+    ef = b['edge_feature'].cpu().numpy().reshape(-1).astype(np.float64)
+    f64 = lambda t_: t_.detach().cpu().numpy().astype(np.float64)
+    ls = lambda v: np.minimum(v, 0.0) - np.log1p(np.exp(-np.abs(v)))
+    x = np.concatenate([f64(state), ef[:, None]], axis=1)
+    s_e = ls(ls(x @ f64(l1m.weight).T + f64(l1m.bias)) @ f64(l2m.weight).T)                        # [E, 50]
+    A = np.zeros((int(row.max()) + 1, 50)); np.add.at(A, row, s_e)
+    r = np.concatenate([A[row] - s_e, ef[:, None]], axis=1)
+    want = ls(ls(r @ f64(l1a.weight).T + f64(l1a.bias)) @ f64(l2a.weight).T)
+    inst = b['batch_variable_map'].cpu().numpy()[gm[0]]
+    live = am.cpu().numpy()[inst] == 1
+    scale = np.abs(want[live]).max()
+    err_fast = np.abs(out['fast'][live] - want[live]).max() / scale
+    err_parity = np.abs(out['parity'][live] - want[live]).max() / scale
+    assert err_parity < 5e-6 and err_fast < 5e-5, (err_parity, err_fast)
+    np.testing.assert_array_equal(out['fast'][~live], old.cpu().numpy()[~live])
+
+
 def test_headline_family_solved_counts_equal_the_parity_build():
     """random 3-SAT n=200 m=840, 600 instances (a NaN-poisoned batch like the headline), T=100 + Walk-SAT: the two builds run the same
     number of sweeps, poison the batch in the same sweep, fix almost the same variables and solve the same number of instances"""

@@ -73,7 +73,7 @@ def fast_build_measurement(args, dev, native, host_batch, items, parity_solved):
                               roofline_bf16x3=dict(bound='mfma', achieved=nk['tflops'], peak=2500.0 / 3.0, unit='TFLOP/s', frac=nk['tflops'] / (2500.0 / 3.0)),
                               roofline_hbm=dict(bound='hbm', achieved=stream / sec / 1e9, peak=HBM_PEAK_GBS, unit='GB/s', frac=stream / sec / 1e9 / HBM_PEAK_GBS,
                                                 bytes_per_launch=stream))
-                    out['neural']['dtype'] = 'f32 activations and aggregator layers; GRU products bf16x3 -> f32'
+                    out['neural']['dtype'] = 'f32 activations; GRU and aggregator products bf16x3 -> f32 (hi hi + hi lo + lo hi)'
             except Exception as ex:                          # measurement only: never take the headline line down
                 out['neural'] = dict(error=repr(ex))
     finally:
