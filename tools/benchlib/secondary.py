@@ -126,6 +126,20 @@ def secondary_measurements(args, dev, b, prob, native, items):
                                     'or in a few rounds.  The kernel is incremental and LDS-resident: the streaming model of SURVEY 8(d) (13 E + 8 V '
                                     'bytes per full re-evaluation step) does not describe it (a fraction above 1 came out of it), so no roofline '
                                     'fraction is claimed -- flips/s is the figure of merit; tools/ws_prof.py splits a step into its phases')
+        # what binds it, priced like the headline kernel's valu_issue: wave-level VALU instructions of a committed rocprofv3 pass of the same
+        # launch shape against the issue slots of the SIMDs over THIS run's kernel time (labelled with its source; not measured in this run)
+        try:
+            pm = sorted(f for f in os.listdir(os.path.join(REPO, 'profiles')) if f.endswith('_walksat_pmc.json'))
+            if pm and steps_req == 1000 and B == 5000 and args.n == 200 and kms > 0:
+                pj = json.load(open(os.path.join(REPO, 'profiles', pm[-1])))
+                insts = float(pj['SQ_INSTS_VALU_per_launch']) * steps / float(pj['steps'])
+                cyc = N_SIMD * CLOCK_HZ * kms * 1e-3
+                out['walksat']['valu_issue'] = dict(insts_per_launch=insts, issue_frac_at_2_cycles=insts * 2.0 / cyc, wait_share=pj.get('SQ_WAIT_ANY_over_SQ_WAVE_CYCLES'),
+                                                    source='profiles/' + pm[-1],
+                                                    note='SQ_INSTS_VALU of the committed pass x 2 cycles / (1024 SIMDs x 2.4 GHz x this run\'s kernel time); the waves '
+                                                         'are parked more than half of their cycles (two barriers and two LDS arg-max round trips per step): latency-bound')
+        except Exception:
+            pass
     except Exception as ex:
         out['walksat'] = dict(error=repr(ex))
     # ---- Reinforce solver: the persistent kernel's other instantiation --------------------------------------------------------------------
@@ -322,7 +336,7 @@ def driver_summary(config):
         k = 'train_' + mt.replace('-', '_') + '_ms_per_batch'
         if k in out:
             out[k] = 1e3 * out[k]
-    put('walksat_1000', sec.get('walksat'), (('flips_per_s', ('flips_per_sec',)), ('us_per_step', ('us_per_step',))))
+    put('walksat_1000', sec.get('walksat'), (('flips_per_s', ('flips_per_sec',)), ('us_per_step', ('us_per_step',)), ('valu_issue_frac_at_2_cycles', ('valu_issue', 'issue_frac_at_2_cycles'))))
     put('reinforce', sec.get('reinforce'), (('it_per_s', ('iterations_per_sec',)), ('kernel_ms_per_launch', ('kernel_ms_per_launch',)), ('frac_hbm_model', ('roofline', 'frac'))))
     for name, kern in (('agg_pre', 'agg_pre'), ('agg_post', 'agg_post'), ('gru', 'gru'), ('predict_head', 'predict_head')):
         put('configs2_kernel_' + name, ((sec.get('neural') or {}).get('kernels') or {}).get(kern), (('ms', ('ms_per_launch',)), ('frac_mfma_f32', ('frac_of_mfma_f32_peak',))))
