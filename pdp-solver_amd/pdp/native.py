@@ -213,7 +213,8 @@ class Decimator(object):
     def __init__(self, problem):
         self.problem = problem
         h = C.c_void_p()
-        check(lib().pdp_decimator_create(C.byref(h), problem._h))
+        self._made_by = lib()                         # a handle is destroyed by the library that made it, whatever build the process uses by then
+        check(self._made_by.pdp_decimator_create(C.byref(h), problem._h))
         self._h = h
 
     def reset(self):
@@ -222,7 +223,7 @@ class Decimator(object):
     def __del__(self):
         try:
             if self._h:
-                lib().pdp_decimator_destroy(self._h)
+                self._made_by.pdp_decimator_destroy(self._h)
                 self._h = None
         except Exception:
             pass
@@ -247,6 +248,7 @@ class Problem(object):
                                    ptr(gm, torch.int32), ptr(bvm, torch.int32), ptr(bfm, torch.int32), ptr(ef, torch.float32),
                                    _stream()))
         self._h = h
+        self._made_by = L                             # destroyed by the library that made it (see Decimator)
         dims = (C.c_int32 * 8)()
         check(L.pdp_problem_dims(self._h, dims))
         self.E, self.V, self.F, self.B, self.R, self.max_n, self.max_m, self.max_e = [int(x) for x in dims]
@@ -262,7 +264,7 @@ class Problem(object):
     def __del__(self):
         try:
             if self._h:
-                lib().pdp_problem_destroy(self._h)
+                self._made_by.pdp_problem_destroy(self._h)
                 self._h = None
         except Exception:
             pass

@@ -99,7 +99,8 @@ def test_gru_on_three_term_bf16_products_against_float64(dx):
             out[build] = prob.neural_gru(w, state, h, am).cpu().numpy()
             name = native.kernel_name('gru')
             assert name.startswith('k_gru_bf3<') if build == 'fast' else name.startswith('k_gru_pipe<'), name
-            sign = prob.edge_sign.cpu().numpy() if hasattr(prob, 'edge_sign') else None
+            torch.cuda.synchronize()
+            del prob, w                                        # handles belong to the library that made them (native.use_build)
     finally:
         native.use_build(prev)
     # float64 reference of the cell on [state | sign] (the sign column is the loader's edge feature)
@@ -150,6 +151,8 @@ def test_aggregator_on_three_term_bf16_products_against_float64(by_variable):
             out[build] = prob.neural_aggregate_edges(w, by_variable, state, None, am, old).cpu().numpy()
             names = native.kernel_name('agg_pre'), native.kernel_name('agg_post')
             assert names == (('k_agg_pre_bf3', 'k_agg_post_bf3') if build == 'fast' else ('k_agg_pre_wave<65, 4, 50, 2, true>', 'k_agg_post_pf<26, 4, 50, 4>')), names
+            torch.cuda.synchronize()
+            del prob, w                                        # handles belong to the library that made them (native.use_build)
     finally:
         native.use_build(prev)
     gm = b['graph_map'].cpu().numpy()
