@@ -1423,6 +1423,19 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
     if (tid == 0) { s_cold.is_sat = hdr.is_sat; s_flag_or[0] = 0; s_flag_or[1] = 0; s_sat_count = 0; }
     __syncthreads();
 
+    // P4's work item of this lane -- (variable, half row) -- is topology: fetched once per launch instead of through two dependent LDS round
+    // trips (vord -> v_ptr) in every sweep, when every item has a lane of its own (2 n <= threads).  Two registers: lo | hi, v | degree.
+    const bool p4_cached = 2 * n <= nt;
+    uint32_t p4_lohi = 0u, p4_vdeg = 0u;
+    if (p4_cached && tid < 2 * n) {
+        const int v = L.vord[tid >> 1], h = tid & 1;
+        const int a = L.v_ptr[v], bnd = L.v_ptr[v + 1];
+        const int half = (bnd - a + 1) >> 1;
+        p4_lohi = (uint32_t)(a + h * half) | ((uint32_t)(h ? bnd : a + half) << 16);
+        p4_vdeg = (uint32_t)v | ((uint32_t)(bnd - a) << 16);
+    }
+    // (the same for R1 -- the slot range of a lane's variable row in one register, clause c at the by-clause positions 3 c .. 3 c + 2 when every
+    //  clause has three literals -- was measured in round 5: no gain, the row sums' look-ups are not what the phase waits for)
     int active = hdr.active ? 1 : 0;
     int has_prev = sp.has_prev;
     int last_event = -1;
@@ -1660,10 +1673,14 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
             const float tol_lo = tol - (2e-6f + 1e-4f * pdp_abs(tol)), tol_hi = tol + (2e-6f + 1e-4f * pdp_abs(tol));
             if (!PROF_SKIP(8))
             for (int r = tid; r < 2 * n; r += nt) {
-                const int v = L.vord[r >> 1], h = r & 1;
-                const int a = v_ptr[v], bnd = v_ptr[v + 1];
-                const int half = (bnd - a + 1) >> 1;
-                const int lo = a + h * half, hi = h ? bnd : a + half;
+                int v, lo, hi, degi;
+                if (p4_cached) { lo = (int)(p4_lohi & 0xffffu); hi = (int)(p4_lohi >> 16); v = (int)(p4_vdeg & 0xffffu); degi = (int)(p4_vdeg >> 16); }
+                else {
+                    v = L.vord[r >> 1];
+                    const int h = r & 1, a = v_ptr[v], bnd = v_ptr[v + 1];
+                    const int half = (bnd - a + 1) >> 1;
+                    lo = a + h * half; hi = h ? bnd : a + half; degi = bnd - a;
+                }
                 float emax = 0.0f, S1 = 0.0f, S2 = 0.0f, D = 0.0f;
                 if (has_prev) {
                     int p = lo;
@@ -1679,7 +1696,7 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
                 emax = fmaxf(emax, lane_xor1(emax));
                 S1 += lane_xor1(S1); S2 += lane_xor1(S2); D = fmaxf(D, lane_xor1(D));
                 const float a_v = av[v];
-                const float deg = (float)(bnd - a);
+                const float deg = (float)degi;
                 if (a_v == 0.0f || !(emax > 0.0f)) bits |= 1;
                 if (a_v == 1.0f && emax >= 4.76837158203125e-7f * deg) bits |= 8;
                 if (!has_prev) continue;
