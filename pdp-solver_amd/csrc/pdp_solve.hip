@@ -887,6 +887,9 @@ extern "C" int pdp_debug_phase_cycles(unsigned long long *out_host, int reset)
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef int i4v __attribute__((ext_vector_type(4)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef int i2v __attribute__((ext_vector_type(2)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f4v vfma(f4v a, f4v b, f4v c) { return __builtin_elementwise_fma(a, b, c); }
 
 #ifdef PDP_FAST_MATH
@@ -916,6 +919,15 @@ __device__ __forceinline__ f4v log4_fin(f4v x, float eps)
     return vfma((f4v)(0.0f), x, r);          // a NaN whose sign bit is set went to eps in the integer maximum: re-injected
 }
 __device__ __forceinline__ f4v exp4_sum(f4v x) { return exp4_fin_le30(x); }
+__device__ __forceinline__ f2v log2_fin(f2v x, float eps)
+{
+    const f2v xm = __builtin_bit_cast(f2v, __builtin_elementwise_max(__builtin_bit_cast(i2v, x), __builtin_bit_cast(i2v, (f2v)(eps))));
+    f2v l; i2v e;
+    l.x = __builtin_amdgcn_logf(__builtin_amdgcn_frexp_mantf(xm.x)); l.y = __builtin_amdgcn_logf(__builtin_amdgcn_frexp_mantf(xm.y));
+    e.x = __builtin_amdgcn_frexp_expf(xm.x); e.y = __builtin_amdgcn_frexp_expf(xm.y);
+    const f2v r = (__builtin_convertvector(e, f2v) + l) * 0.693147180559945309f;
+    return __builtin_elementwise_fma((f2v)(0.0f), x, r);
+}
 #else
 __device__ __forceinline__ f4v exp4_fin_le30(f4v x)
 {
@@ -999,6 +1011,37 @@ __device__ __forceinline__ f4v log4_fin(f4v x, float eps)
     f4v r = m + y;
     r = vfma(fe, (f4v)(0.693359375f), r);
     return vfma((f4v)(0.0f), x, r);          // NaN / inf re-injection as in exp4_fin_le30 (arguments are >= +0 here: the product is +0)
+}
+
+// the same two wide (E2 takes the logs of the two values a slot's update produces): the same operation per element
+__device__ __forceinline__ f2v log2_fin(f2v x, float eps)
+{
+    const f2v xm = __builtin_bit_cast(f2v, __builtin_elementwise_max(__builtin_bit_cast(i2v, x), __builtin_bit_cast(i2v, (f2v)(eps))));
+    f2v m; i2v e;
+    m.x = __builtin_amdgcn_frexp_mantf(xm.x); m.y = __builtin_amdgcn_frexp_mantf(xm.y);
+    e.x = __builtin_amdgcn_frexp_expf(xm.x); e.y = __builtin_amdgcn_frexp_expf(xm.y);
+    const u2v lt = (__builtin_bit_cast(u2v, m) - 0x3f3504f3u) >> 31;
+    e = e - __builtin_bit_cast(i2v, lt);
+    const i2v lti = __builtin_bit_cast(i2v, lt);
+    m.x = __builtin_ldexpf(m.x, lti.x); m.y = __builtin_ldexpf(m.y, lti.y);
+    m = m - 1.0f;
+    const f2v z = m * m;
+    f2v y = (f2v)(7.0376836292e-2f);
+    y = __builtin_elementwise_fma(y, m, (f2v)(-1.1514610310e-1f));
+    y = __builtin_elementwise_fma(y, m, (f2v)(1.1676998740e-1f));
+    y = __builtin_elementwise_fma(y, m, (f2v)(-1.2420140846e-1f));
+    y = __builtin_elementwise_fma(y, m, (f2v)(1.4249322787e-1f));
+    y = __builtin_elementwise_fma(y, m, (f2v)(-1.6668057665e-1f));
+    y = __builtin_elementwise_fma(y, m, (f2v)(2.0000714765e-1f));
+    y = __builtin_elementwise_fma(y, m, (f2v)(-2.4999993993e-1f));
+    y = __builtin_elementwise_fma(y, m, (f2v)(3.3333331174e-1f));
+    y = (y * m) * z;
+    const f2v fe = __builtin_convertvector(e, f2v);
+    y = __builtin_elementwise_fma(fe, (f2v)(-2.12194440e-4f), y);
+    y = __builtin_elementwise_fma((f2v)(-0.5f), z, y);
+    f2v r = m + y;
+    r = __builtin_elementwise_fma(fe, (f2v)(0.693359375f), r);
+    return __builtin_elementwise_fma((f2v)(0.0f), x, r);
 }
 
 #endif
@@ -1341,8 +1384,11 @@ __device__ __noinline__ int lds_reinforce_step(uint32_t smem_off, uint32_t cold_
 // whether the force is renewed.  Under the NaN poison the gate's batch-wide maximum is NaN: nobody leaves through the gate.
 // LISTED (pass 1 of mixed batches): the instance comes from sp.fit_list, by ticket -- a separate instantiation, because an instance id that is
 // not blockIdx.x costs a scalar register for the whole kernel and this kernel has none to spare (+3 % VALU instructions from the spill)
+#ifndef PDP_SOLVE_WAVES_PER_SIMD
+#define PDP_SOLVE_WAVES_PER_SIMD 4
+#endif
 template <bool FORCE, bool REPLAY, bool RF = false, bool LISTED = false>
-__global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams sp)
+__global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds(PView pv_, SolveParams sp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float redf[PDP_RED_SMALL];
@@ -1443,6 +1489,7 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
     int use_em = sp.has_edge_mask, last_use_em = 0, em_dirty = 0;
     float cnt = hdr.cnt;
     int iters = 0, did_prop = 0, violation = 0, cur = 0;
+    int logs_ready = 0;                      // X / Y hold the logs of the current q_u / surveys already: the last sweep's E2 left them (see E2)
     int nsat = (int)hdr.nsat_p1 - 1;         // clauses satisfied by `sol` (-1: not counted yet); it only changes with a decimation, so later launches inherit it
     int rf_last_flip = 0;                    // Reinforce: the force was renewed after the last sweep (X holds the one that sweep read)
     int simplified = (int)hdr.simplified;   // 0: unknown, 1: the state is a simplify() fix-point (checked at the first decimation of a call), 2: it is not
@@ -1466,6 +1513,8 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
         // waves take as pairs, where eight waves took one slot each at the price of a pair.  (Four slots per trip -- every wave one
         // trip, two waves the remainder -- was measured in round 5: +3 % on the launch; the phase ends with its slowest wave, and that
         // form gives two waves four 4-vectors where this one gives four waves three.)
+        // A sweep that follows a plain sweep of this launch finds its logs in place (E2 took them of the values it produced) and has no E1.
+        if (!logs_ready) {
         if (!PROF_SKIP(1)) {
             const int full = ne / (2 * nt), rem = ne - full * 2 * nt, half = (rem + 1) >> 1;
             for (int k = 0; k <= full; ++k) {
@@ -1489,8 +1538,9 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
                 if (has1) { X[p1] = x1; Y[p1] = y1; }
             }
         }
-        last_use_em = use_em; em_dirty = 0;
         __syncthreads();
+        }
+        last_use_em = use_em; em_dirty = 0;
         PROF_MARK(1);                                        // E1
         // ---- R1: per-clause sums (through e2p) and per-variable sums (contiguous), ascending edge id ------------
         {
@@ -1597,12 +1647,22 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
                 }
             }
         }
-        if (tid == 0) { s_flag_or[(t + 1) & 1] = 0; s_sat_count = 0; }
         __syncthreads();
+        // (behind this barrier every wave has left the previous sweep -- a sweep without E1 has no barrier in front of R1)
+        if (tid == 0) { s_flag_or[(t + 1) & 1] = 0; s_sat_count = 0; }
         PROF_MARK(2);                                        // R1
         // ---- E2: new survey, new q_u, smooth-max weights -----------------------------------------------------------
+        // The next sweep's E1 would take the logs of exactly the two values a slot's update stores (q_u, the survey), in the same lane order:
+        // E2 takes them here -- X / Y of the slot are this lane's own to overwrite once it has read them --, and the next sweep starts at
+        // R1: no pass over the slots to fetch and unpack them again, one workgroup barrier less.  Y no longer carries |delta eta| to P4:
+        // P4 forms it from the two survey arrays (the old one stays in place, the exit path needs it as well).  Not in the last sweep
+        // of a launch, and not in a call's first sweep (without previous surveys it looks for NaNs; with the caller's, Y hands those to P4).
+        // The two forms of the loop are separate instantiations: nothing to branch on per trip.
+        const bool fuse_logs = (t + 1 < T) && has_prev && !prev_from_global;
         float nan_acc = 0.0f;
-        {
+        const uint32_t log_em_or = use_em ? 0u : PC_EM;      // without an edge mask every slot counts
+        auto e2_pass = [&](auto fuse_c) {
+            constexpr bool FUSE = decltype(fuse_c)::value;
             const float *const S = L.S, *const Pv = L.Pv, *const Nv = L.Nv;
             // (fetching the NEXT trip's slot words while a trip computes -- the one link of the chain that depends on nothing the trip
             //  computes -- was measured in round 5: +1 % on the launch, 126 registers)
@@ -1637,20 +1697,21 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
                 const float qu_new = __builtin_fmaf(1.0f - 1.0f, QU[p], qu / total);
                 QU[p] = qu_new;
                 Enew[p] = eta_new;
-                if (has_prev) {
-                    const float pe = prev_from_global ? sp.prev_slots[G.e0 + p] : eta_old;
-                    float d = pdp_abs(pe - eta_new);
-                    if (use_em) d = d * bit15_to_float(cw);
-                    Y[p] = d;                               // the smooth-max weights exp(30 d) are only built when P4 cannot decide without them
-                } else {
+                if constexpr (FUSE) {
+                    const f2v lg = log2_fin((f2v){qu_new, 1.0f - eta_new}, PDP_SP_EPS) * bit15_to_float((uint16_t)(cw | log_em_or));
+                    X[p] = lg.x; Y[p] = lg.y;
+                } else if (!has_prev) {
                     // a NaN survey: with a previous survey every slot's |difference| is NaN too and P4's sums flag it (its S1 covers every slot
                     // of the instance); only the first sweep of a solve without one has to look here
                     nan_acc = __builtin_fmaf(0.0f, eta_new, nan_acc);  // stays 0 unless a survey is NaN (surveys are <= 1, never infinite)
-                }
+                } else if (prev_from_global) Y[p] = sp.prev_slots[G.e0 + p];
             }
-        }
+        };
+        if (fuse_logs) e2_pass(std::true_type{}); else e2_pass(std::false_type{});
         int nan_seen = (nan_acc != nan_acc) ? 1 : 0;
         did_prop = 1;
+        logs_ready = fuse_logs ? 1 : 0;
+        const float *const Dold = (has_prev && prev_from_global) ? Y : Eold;      // what P4 takes |delta eta| against
         __syncthreads();
         PROF_MARK(3);                                        // E2
         // ---- P4: per-variable smooth maxima, decided lazily.  The two batch-visible facts per instance are booleans:
@@ -1671,6 +1732,7 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
             const float *const av = L.av;
             float *const amb = L.xv1;
             const float tol_lo = tol - (2e-6f + 1e-4f * pdp_abs(tol)), tol_hi = tol + (2e-6f + 1e-4f * pdp_abs(tol));
+            const uint32_t em_or = use_em ? 0u : PC_EM;          // without an edge mask every slot counts
             if (!PROF_SKIP(8))
             for (int r = tid; r < 2 * n; r += nt) {
                 int v, lo, hi, degi;
@@ -1683,13 +1745,15 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
                 }
                 float emax = 0.0f, S1 = 0.0f, S2 = 0.0f, D = 0.0f;
                 if (has_prev) {
+                    // |delta eta| times the edge mask of the sweep, as the reference forms it (pdp_decimate.py:135-141)
+                    auto diff = [&](int q, float e) { return pdp_abs(Dold[q] - e) * bit15_to_float((uint16_t)(pcc[q] | em_or)); };
                     int p = lo;
                     for (; p + 1 < hi; p += 2) {
-                        const float e0 = Enew[p], e1 = Enew[p + 1], d0 = Y[p], d1 = Y[p + 1];
+                        const float e0 = Enew[p], e1 = Enew[p + 1], d0 = diff(p, e0), d1 = diff(p + 1, e1);
                         emax = fmaxf(emax, fmaxf(e0, e1));           // (a NaN survey is dropped here and caught by S1 below)
                         S1 += d0 + d1; S2 = fmaf(d0, d0, fmaf(d1, d1, S2)); D = fmaxf(D, fmaxf(d0, d1));
                     }
-                    if (p < hi) { const float e0 = Enew[p], d0 = Y[p]; emax = fmaxf(emax, e0); S1 += d0; S2 = fmaf(d0, d0, S2); D = fmaxf(D, d0); }
+                    if (p < hi) { const float e0 = Enew[p], d0 = diff(p, e0); emax = fmaxf(emax, e0); S1 += d0; S2 = fmaf(d0, d0, S2); D = fmaxf(D, d0); }
                 } else {
                     for (int p = lo; p < hi; ++p) emax = fmaxf(emax, Enew[p]);
                 }
@@ -1745,7 +1809,8 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
                 if (code == 2.0f || (code == 1.0f && need_decision)) {
                     float num = 0.0f, den = 0.0f;
                     for (int p = L.v_ptr[v]; p < L.v_ptr[v + 1]; ++p) {
-                        const float d = Y[p];
+                        float d = pdp_abs(Dold[p] - Enew[p]);
+                        if (use_em) d = d * bit15_to_float(pcc[p]);
                         const float c0 = pdp_expf_fin_le30(30.0f * d);
                         num = num + d * c0; den = den + c0;
                     }
@@ -1770,6 +1835,7 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
         } else {
             // exact path (rare: every active variable has only vanishing surveys): util.py:282-286 + :267-275
             for (int p = tid; p < ne; p += nt) X[p] = pdp_expf_fin_le30(30.0f * Enew[p]);
+            logs_ready = 0;
             __syncthreads();
             float mm = -PDP_INF;
             for (int v = tid; v < n; v += nt) {
@@ -1821,7 +1887,7 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
             rf_last_flip = flip;
             if (flip || nsat < 0) {
                 if (UNI(lds_reinforce_step(lds_offset_of(smem), lds_offset_of(&s_cold), nt, n, m, ne, cur, pi, flip)) && !nan_seen) violation = 1;    // a NaN score without a NaN survey: not expected
-                rf_changed = 1;
+                rf_changed = 1; logs_ready = 0;             // (X / Y are its scratch, and the force changes)
             }
         }
         PROF_MARK(13);                                       // gate + bookkeeping of every sweep
@@ -1830,6 +1896,7 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
         if (!RF && has_prev && conv && !poisoned && !nan_seen && !PROF_SKIP(16)) {
             const int dr = UNI(lds_decimate<FORCE>(lds_offset_of(smem), lds_offset_of(&s_cold), nt, n, m, ne, cur, active, pi, simplified));
             decimated = dr & DEC_FIXED; simplified = (dr >> DEC_VERIFIED_SHIFT) & 3;
+            logs_ready = 0;                                  // (X / Y are its scratch, and it rewrites surveys and q_u)
             const int spec_bits = (dr >> DEC_SPEC_SHIFT) & 3;
             used |= 4u;
             if (spec_bits & 1) zero |= 4u;
@@ -1860,7 +1927,7 @@ __global__ void __launch_bounds__(1024, 4) k_sp_solve_lds(PView pv_, SolveParams
                     const bool em = (a * b) == 1.0f;
                     pcc[p] = (uint16_t)((cw & ~PC_EM) | (em ? PC_EM : 0));
                 }
-                use_em = 1; em_dirty = 1;
+                use_em = 1; em_dirty = 1; logs_ready = 0;
                 PROF_COUNT(17);
             }
             PROF_MARK(14);                                   // P7
@@ -2807,7 +2874,8 @@ static int sp_solve_speculative(pdp_problem *p, pdp_solve_args *a, void *stream)
         const bool fits_r = p->fn_edges_identity && p->res_nfit > 0 && lds_r <= 160 * 1024 - 1024 && (!rf_model || fn_ < 8192) && mixed_ok && !hbm_forced && !exact;
         // threads per instance: 256 for tiny instances, 512 while two workgroups share a CU, 1024 when the instance's LDS image allows
         // only one workgroup per CU (the same 16 waves per CU either way)
-        const int nt_r = fe_ <= 1024 ? 256 : (lds_r > 80 * 1024 ? 1024 : 512);
+        int nt_r = fe_ <= 1024 ? 256 : (lds_r > 80 * 1024 ? 1024 : 512);
+        if (const char *env = getenv("PDP_SOLVE_LDS_THREADS")) { const int v = atoi(env); if (v >= 64 && v <= 1024 && v % 64 == 0) nt_r = v; }
         if (!fits_r) break;
         a->hbm_instances_host = p->res_nbig;
         const int rc = sp_solve_resident(p, a, st, force_r, lds_r, nt_r, C);

@@ -28,6 +28,8 @@ libs = sys.argv[1:3]
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 for r in range(reps):
     for lib in libs:
-        env = dict(os.environ, PDP_HIP_LIB=os.path.join(REPO, 'pdp-solver_amd', 'csrc', lib))
+        parts = lib.split(':')                       # lib.so[:ENV=VALUE ...]: extra environment for that arm
+        env = dict(os.environ, PDP_HIP_LIB=os.path.join(REPO, 'pdp-solver_amd', 'csrc', parts[0]))
+        env.update(kv.split('=', 1) for kv in parts[1:])
         out = subprocess.run([sys.executable, '-c', CHILD], env=env, stdout=subprocess.PIPE, universal_newlines=True).stdout.strip().split('\n')[-1]
         print(r, lib, out, flush=True)
