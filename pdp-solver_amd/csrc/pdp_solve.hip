@@ -1748,6 +1748,7 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
                     // |delta eta| times the edge mask of the sweep, as the reference forms it (pdp_decimate.py:135-141)
                     auto diff = [&](int q, float e) { return pdp_abs(Dold[q] - e) * bit15_to_float((uint16_t)(pcc[q] | em_or)); };
                     int p = lo;
+                    // (four slots per trip -- their loads in flight together -- was measured in round 5: +3 % on the launch)
                     for (; p + 1 < hi; p += 2) {
                         const float e0 = Enew[p], e1 = Enew[p + 1], d0 = diff(p, e0), d1 = diff(p + 1, e1);
                         emax = fmaxf(emax, fmaxf(e0, e1));           // (a NaN survey is dropped here and caught by S1 below)
