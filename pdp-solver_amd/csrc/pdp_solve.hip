@@ -1657,57 +1657,64 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
         // R1: no pass over the slots to fetch and unpack them again, one workgroup barrier less.  Y no longer carries |delta eta| to P4:
         // P4 forms it from the two survey arrays (the old one stays in place, the exit path needs it as well).  Not in the last sweep
         // of a launch, and not in a call's first sweep (without previous surveys it looks for NaNs; with the caller's, Y hands those to P4).
-        // The two forms of the loop are separate instantiations: nothing to branch on per trip.
+        // The two forms of the loop are separate loops: nothing to branch on per trip.
         const bool fuse_logs = (t + 1 < T) && has_prev && !prev_from_global;
         float nan_acc = 0.0f;
         const uint32_t log_em_or = use_em ? 0u : PC_EM;      // without an edge mask every slot counts
-        auto e2_pass = [&](auto fuse_c) {
-            constexpr bool FUSE = decltype(fuse_c)::value;
-            const float *const S = L.S, *const Pv = L.Pv, *const Nv = L.Nv;
-            // (fetching the NEXT trip's slot words while a trip computes -- the one link of the chain that depends on nothing the trip
-            //  computes -- was measured in round 5: +1 % on the launch, 126 registers)
-            if (!PROF_SKIP(4))
+        // one slot's update: reads the slot's words, the three row sums and its own logs, stores the new q_u and survey and returns them
+        struct SlotNew { float qu, eta; uint16_t cw; };
+        const float *const S_ = L.S, *const Pv_ = L.Pv, *const Nv_ = L.Nv;
+        auto slot_update = [&](int p) __attribute__((always_inline)) {
+            const uint16_t pw = pvv[p], cw = pcc[p];
+            const int v = pw & VM, c = cw & 0x3fff;
+            const float s = slot_sign(pw);
+            const float eta_old = Eold[p];
+            const float agg = S_[c] - X[p];                     // the reference's 0 + S is a no-op: a sum that starts at +0 is never -0
+            const float force = RF ? frc_of(pw) : (FORCE ? L.FRC[p] : 0.0f);
+            const float pos = Pv_[v], neg = Nv_[v];
+            // The reference's (0.5 (1 + s)) * pos + (0.5 (1 - s)) * neg has coefficients 1 and 0: one product is the sum itself, the other an
+            // exact zero.  R1 stores Pv / Nv so that they are never -0 (sums that start at +0), never infinite (sums of clamped logs) and NaN
+            // only together (each gets 0 * the other): x + (+-0) == x then, so the expression is the SELECTED sum -- two selects on the slot's
+            // sign bit instead of the coefficient arithmetic, two packed multiplies and the adds.
+            const bool neg_lit = (pw & 0x8000u) != 0;
+            float same = neg_lit ? neg : pos;
+            same = same - Y[p];
+            // without an external force both log terms are log(1) = +0: adding it can only turn a -0 into +0, which exp ignores
+            if constexpr (FORCE) same = same + ((force == s) ? L1 : L0);
+            float opp = neg_lit ? pos : neg;
+            if constexpr (FORCE) opp = opp + ((force == -s) ? L1 : L0);
+            const f4v ex = exp4_sum((f4v){agg, same + opp, same, opp});
+            // mask * new + (1 - mask) * old with mask == 1: (+0) * old + new as ONE fused operation -- the product is an exact zero (or NaN),
+            // so fusing rounds nothing differently; the unfused form is a multiply and an add per slot
+            const float eta_new = __builtin_fmaf(1.0f - 1.0f, eta_old, ex.x);
+            const float dc = ex.y;
+            const float A = ex.z, Bv = ex.w;
+            const float qu = A * (1.0f - Bv), qs = Bv * (1.0f - A);
+            const float total = (qu + qs) + dc;
+            const float qu_new = __builtin_fmaf(1.0f - 1.0f, QU[p], qu / total);
+            QU[p] = qu_new;
+            Enew[p] = eta_new;
+            return SlotNew{qu_new, eta_new, cw};
+        };
+        auto slot_logs = [&](int p, const SlotNew &r) __attribute__((always_inline)) {
+            const f2v lg = log2_fin((f2v){r.qu, 1.0f - r.eta}, PDP_SP_EPS) * bit15_to_float((uint16_t)(r.cw | log_em_or));
+            X[p] = lg.x; Y[p] = lg.y;
+        };
+        if (PROF_SKIP(4)) { }
+        else if (fuse_logs) {
+            // (the logs of a trip riding in the NEXT trip, so that their dependent chain of ~20 packed steps interleaves with that trip's loads, exps
+            //  and division in one basic block, was measured in round 5: +3 % on the launch)
+            for (int p = tid; p < ne; p += nt) slot_logs(p, slot_update(p));
+        } else {
             for (int p = tid; p < ne; p += nt) {
-                const uint16_t pw = pvv[p], cw = pcc[p];
-                const int v = pw & VM, c = cw & 0x3fff;
-                const float s = slot_sign(pw);
-                const float eta_old = Eold[p];
-                const float agg = S[c] - X[p];                  // the reference's 0 + S is a no-op: a sum that starts at +0 is never -0
-                const float force = RF ? frc_of(pw) : (FORCE ? L.FRC[p] : 0.0f);
-                const float pos = Pv[v], neg = Nv[v];
-                // The reference's (0.5 (1 + s)) * pos + (0.5 (1 - s)) * neg has coefficients 1 and 0: one product is the sum itself, the other an
-                // exact zero.  R1 stores Pv / Nv so that they are never -0 (sums that start at +0), never infinite (sums of clamped logs) and NaN
-                // only together (each gets 0 * the other): x + (+-0) == x then, so the expression is the SELECTED sum -- two selects on the slot's
-                // sign bit instead of the coefficient arithmetic, two packed multiplies and the adds.
-                const bool neg_lit = (pw & 0x8000u) != 0;
-                float same = neg_lit ? neg : pos;
-                same = same - Y[p];
-                // without an external force both log terms are log(1) = +0: adding it can only turn a -0 into +0, which exp ignores
-                if constexpr (FORCE) same = same + ((force == s) ? L1 : L0);
-                float opp = neg_lit ? pos : neg;
-                if constexpr (FORCE) opp = opp + ((force == -s) ? L1 : L0);
-                const f4v ex = exp4_sum((f4v){agg, same + opp, same, opp});
-                // mask * new + (1 - mask) * old with mask == 1: (+0) * old + new as ONE fused operation -- the product is an exact zero (or NaN),
-                // so fusing rounds nothing differently; the unfused form is a multiply and an add per slot
-                const float eta_new = __builtin_fmaf(1.0f - 1.0f, eta_old, ex.x);
-                const float dc = ex.y;
-                const float A = ex.z, Bv = ex.w;
-                const float qu = A * (1.0f - Bv), qs = Bv * (1.0f - A);
-                const float total = (qu + qs) + dc;
-                const float qu_new = __builtin_fmaf(1.0f - 1.0f, QU[p], qu / total);
-                QU[p] = qu_new;
-                Enew[p] = eta_new;
-                if constexpr (FUSE) {
-                    const f2v lg = log2_fin((f2v){qu_new, 1.0f - eta_new}, PDP_SP_EPS) * bit15_to_float((uint16_t)(cw | log_em_or));
-                    X[p] = lg.x; Y[p] = lg.y;
-                } else if (!has_prev) {
+                const SlotNew r = slot_update(p);
+                if (!has_prev) {
                     // a NaN survey: with a previous survey every slot's |difference| is NaN too and P4's sums flag it (its S1 covers every slot
                     // of the instance); only the first sweep of a solve without one has to look here
-                    nan_acc = __builtin_fmaf(0.0f, eta_new, nan_acc);  // stays 0 unless a survey is NaN (surveys are <= 1, never infinite)
+                    nan_acc = __builtin_fmaf(0.0f, r.eta, nan_acc);    // stays 0 unless a survey is NaN (surveys are <= 1, never infinite)
                 } else if (prev_from_global) Y[p] = sp.prev_slots[G.e0 + p];
             }
-        };
-        if (fuse_logs) e2_pass(std::true_type{}); else e2_pass(std::false_type{});
+        }
         int nan_seen = (nan_acc != nan_acc) ? 1 : 0;
         did_prop = 1;
         logs_ready = fuse_logs ? 1 : 0;
