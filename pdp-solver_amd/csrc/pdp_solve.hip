@@ -90,7 +90,8 @@ struct SolveParams {
     int team_no_xcd;            // debugging: always take the agent-scope barrier
     int exact;                  // HBM-resident kernel, single-instance batch: the batch-global minima ARE the instance's own, nothing is speculated
     int rf;                     // HBM-resident kernel: the Reinforce triple (coins, dprob as for the LDS-resident kernel; tol = the gate's 0.01)
-    int isolate;                // HBM-resident kernel: isolated instances (a NaN stays inside its instance, pass 1 is final)
+    int isolate;                // isolated instances (a NaN stays inside its instance, pass 1 is final)
+    int adopt_poison;           // LDS-resident pass 1: take a first-NaN sweep other workgroups of the launch already recorded (PDP_SOLVE_NO_ADOPT=1: off)
     int lds_tickets;            // LDS-resident kernel, pass 1: 0 = instance blockIdx.x, else the number of instances the workgroups draw tickets for
     uint8_t *ghost_flag;        // LDS-resident kernel: [B] instances that left inactive with iterations to come (checked by k_ghost_check after the call)
     uint32_t *team_ws;          // [team_count][PDP_TEAM_WORDS], zeroed before every launch
@@ -1465,6 +1466,7 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
     __shared__ uint8_t s_spec_used[SPEC_LOCAL], s_spec_zero[SPEC_LOCAL];
     __shared__ int s_flag_or[2];                            // P5: the OR of the waves' flag sets, one word per sweep parity
     __shared__ int s_sat_count;                             // P8: satisfied clauses, summed over the waves
+    __shared__ int s_poison;                                // first poisoned sweep of the chunk as this workgroup knows it (see `adopt`)
     if (tid < SPEC_LOCAL) { s_spec_used[tid] = 0; s_spec_zero[tid] = 0; }
     if (tid == 0) { s_cold.is_sat = hdr.is_sat; s_flag_or[0] = 0; s_flag_or[1] = 0; s_sat_count = 0; }
     __syncthreads();
@@ -1497,6 +1499,21 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
     const float pi = sp.pi, tol = sp.tol, t_max = sp.t_max;
     const int T = sp.T;
     const int poison_from = REPLAY ? ctl->poison_from : (sp.call->poisoned_all ? 0 : 0x7fffffff);
+    // Pass 1 of a chunk runs while other workgroups of the same launch may already have met the batch's first NaN survey.  What a workgroup
+    // does under the poison differs from what it does without only in its EVENTS (which `last_event` records, and the replay pass redoes
+    // from the poison on), so a workgroup may take any sweep >= the launch's final first-NaN sweep as poisoned at once: thread 0 looks at
+    // the chunk's record when the workgroup starts (a launch is ~10 rounds of workgroups), and from the first sweep >= the value it saw the
+    // instance runs poisoned -- it then has no event at or behind the poison and needs no replay.  The value seen can only be too large (the
+    // minimum is still being formed): then those sweeps run unpoisoned as before and the replay covers them.  Which workgroups see what depends
+    // on the dispatch order; the results do not.  (Looking once per sweep replays another 10 % fewer instances and costs 0.8 us per sweep --
+    // an agent-scope load is a round trip past the L2, and the next barrier waits for it: +0.43 ms per call against -0.24 ms of replay.)
+    const bool adopt = !REPLAY && poison_from == 0x7fffffff && !sp.isolate && sp.adopt_poison;
+    if (tid == 0) {
+        int from = poison_from;
+        if (adopt) { const uint32_t seen = __hip_atomic_load(&ctl->nan_iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (seen < (uint32_t)from) from = (int)seen; }
+        s_poison = from;
+    }
+    __syncthreads();
     // log(max(1 - pi * [force == +-s], eps)): two possible values per kernel (pdp_propagate.py:197,201)
     const float L0 = pdp_safe_log(1.0f - pi * 0.0f, PDP_SP_EPS), L1 = pdp_safe_log(1.0f - pi * 1.0f, PDP_SP_EPS);
 
@@ -1504,7 +1521,6 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
     PROF_MARK(0);                                            // load
     for (int t = 0; t < T; ++t) {
         if (!active) break;
-        const bool poisoned = t >= poison_from;
         iters = t + 1;
         float *const Eold = cur ? L.EB : L.EA, *const Enew = cur ? L.EA : L.EB;
         // ---- E1: per-slot logs, two slots per trip (independent chains for the scheduler / packed fp32 ops) -------------
@@ -1806,6 +1822,7 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
         if (lane == 0 && bits) atomicOr(&s_flag_or[t & 1], bits);
         __syncthreads();
         bits = UNI(s_flag_or[t & 1]);                        // workgroup-uniform: keep the control flow scalar
+        const bool poisoned = t >= UNI(s_poison);
         // ---- P5b (rare): exact smooth max of the marked variables (util.py:282-286 + :267-275 with the global min at 0)
         if ((bits & 64) || ((bits & 32) && !(bits & 16))) {
             PROF_COUNT(9);
@@ -2525,7 +2542,8 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     sp.prev = a->decimator->prev; sp.counters = a->decimator->counters;
     sp.check_termination = a->check_termination;
     sp.coins = a->coins; sp.dprob = a->decimation_probability;
-    sp.rf = rf ? 1 : 0; sp.isolate = a->isolate_instances ? 1 : 0;      // (read by the HBM-resident kernel of the big instances)
+    sp.rf = rf ? 1 : 0; sp.isolate = a->isolate_instances ? 1 : 0;
+    sp.adopt_poison = getenv("PDP_SOLVE_NO_ADOPT") ? 0 : 1;
     float *frc_buf[2] = {nullptr, nullptr};
     if (rf) {
         frc_buf[0] = (float *)(((uintptr_t)(replay_list + B) + 15) & ~(uintptr_t)15); frc_buf[1] = frc_buf[0] + E + 4;

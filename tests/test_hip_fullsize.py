@@ -178,6 +178,26 @@ def test_clause_counts_rederived_and_deterministic(big):
         np.testing.assert_array_equal(npy(a), npy(b))
 
 
+def test_poison_adopted_by_later_workgroups_changes_the_replay_not_the_results(big, monkeypatch):
+    """A workgroup of pass 1 that starts after another one has recorded the batch's first NaN sweep runs poisoned from there on and needs no
+    replay.  How many do depends on the dispatch order -- the results must not: the batch (poisoned at sweep 81, met two thirds
+    into that chunk's launch) ends in the same bits with the look switched off, and with short chunks that move the poison inside its launch."""
+    items, host, tb = big
+    runs = []
+    for adopt, chunk in ((True, None), (False, None), (True, '7'), (False, '7')):
+        if adopt: monkeypatch.delenv('PDP_SOLVE_NO_ADOPT', raising=False)
+        else: monkeypatch.setenv('PDP_SOLVE_NO_ADOPT', '1')
+        if chunk: monkeypatch.setenv('PDP_SOLVE_CHUNK', chunk)
+        else: monkeypatch.delenv('PDP_SOLVE_CHUNK', raising=False)
+        hp, q, fs, am, iters, lds = _solve(tb, T)
+        assert lds and iters == T
+        runs.append([npy(x).copy() for x in (q, fs, am, hp.active_variables, hp.active_functions, hp.solution, hp.is_sat)])
+    assert np.isnan(runs[0][1]).any()
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            np.testing.assert_array_equal(a, b)
+
+
 def test_neural_operator_forms_agree_at_full_size(big, oracle, monkeypatch):
     """configs[2] shapes (hidden 128, 12.6 M edges): the specialised kernels (in-wave pipelined GRU, wave-private / prefetched aggregator
     halves, many tiles per persistent workgroup) give bit for bit what the plain tile kernels give, an active mask with holes included;
