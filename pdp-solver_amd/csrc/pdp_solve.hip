@@ -91,6 +91,7 @@ struct SolveParams {
     int exact;                  // HBM-resident kernel, single-instance batch: the batch-global minima ARE the instance's own, nothing is speculated
     int rf;                     // HBM-resident kernel: the Reinforce triple (coins, dprob as for the LDS-resident kernel; tol = the gate's 0.01)
     int isolate;                // isolated instances (a NaN stays inside its instance, pass 1 is final)
+    int no_scorer_reuse;        // PDP_SOLVE_NO_SCORER_REUSE=1: the decimation's scorer always takes its own logs (A/B switch)
     int adopt_poison;           // LDS-resident pass 1: take a first-NaN sweep other workgroups of the launch already recorded (PDP_SOLVE_NO_ADOPT=1: off)
     int lds_tickets;            // LDS-resident kernel, pass 1: 0 = instance blockIdx.x, else the number of instances the workgroups draw tickets for
     uint8_t *ghost_flag;        // LDS-resident kernel: [B] instances that left inactive with iterations to come (checked by k_ghost_check after the call)
@@ -1123,8 +1124,13 @@ __device__ __forceinline__ int team_any(const LView &I, int x) { return block_re
 #define DEC_FIXED 1
 #define DEC_SPEC_SHIFT 1
 #define DEC_VERIFIED_SHIFT 3
+// y_has_logs: Y already holds log(max(1 - eta, PDP_SP_EPS)) * edge mask of the CURRENT surveys (E2 left them for the next sweep).  For an
+// active variable that is the scorer's own term -- the edge mask of its slots is the clause flag, and the two clamps only differ at
+// 1 - eta == 0 (a survey of exactly 1: the next smaller value of 1 - eta is 2^-24, above both), where the propagator's log(1e-40) is
+// replaced by the scorer's log(1e-10) on the fly; an inactive variable's coefficient is |score| * 0 either way (a NaN survey stays NaN
+// under both masks).  The pass over the slots and its barrier are skipped, and Y stays what the next sweep needs.
 template <bool FORCE>
-__device__ __noinline__ int lds_decimate(uint32_t smem_off, uint32_t cold_off, int nt, int n, int m, int ne, int cur, int active, float pi, int verified)
+__device__ __noinline__ int lds_decimate(uint32_t smem_off, uint32_t cold_off, int nt, int n, int m, int ne, int cur, int active, float pi, int verified, int y_has_logs)
 {
     unsigned char *const smem = lds_at<unsigned char>(smem_off);
     ColdShared *const cs = lds_at<ColdShared>(cold_off);
@@ -1135,7 +1141,7 @@ __device__ __noinline__ int lds_decimate(uint32_t smem_off, uint32_t cold_off, i
     DEC_PROF_DECL
     // scorer, per slot: log(max(1 - eta, eps)) * active_clause (pdp_predict.py:168-172), four slots per trip as one 4-vector; the
     // remainder (fewer than 4 nt slots) is dealt in quarters to the first lanes, so that the other waves skip the trip
-    {
+    if (!y_has_logs) {
         const int full = ne / (4 * nt), rem = ne - full * 4 * nt, quarter = (rem + 3) >> 2;
         for (int k = 0; k <= full; ++k) {
             const bool tail = k == full;
@@ -1154,6 +1160,8 @@ __device__ __noinline__ int lds_decimate(uint32_t smem_off, uint32_t cold_off, i
     __syncthreads();
     DEC_PROF_MARK(16);                                // scorer: edge logs
     const float Lpi = pdp_safe_log(1.0f - pi, PDP_SCORER_EPS), L0 = pdp_safe_log(1.0f - pi * 0.0f, PDP_SCORER_EPS);
+    // the two clamped values, from the functions that produced / would produce the terms; without the substitution the key is a NaN, which equals nothing
+    const float clamp_sp = y_has_logs ? log2_fin((f2v){0.0f, 0.0f}, PDP_SP_EPS).x : __builtin_nanf(""), clamp_sc = log4_fin((f4v)(0.0f), PDP_SCORER_EPS).x;
     int flags = 0;                                   // 1: a coefficient is exactly 0, 2: some coefficient is non-zero, 4: NaN coefficient
     unsigned long long key = 0ull;                   // util.sparse_argmax on (coeff - 0) + 1: larger value wins, first index wins ties
     for (int i = tid; i < n; i += nt) {
@@ -1161,6 +1169,7 @@ __device__ __noinline__ int lds_decimate(uint32_t smem_off, uint32_t cold_off, i
         float ext = 0.0f, pos = 0.0f, neg = 0.0f, all = 0.0f;
         auto acc = [&](float f, uint16_t pw, float frc) {
             const bool ng = (pw & 0x8000) != 0;
+            f = (f == clamp_sp) ? clamp_sc : f;
             ext = ext + frc;
             pos = pos + (ng ? 0.0f : 1.0f) * f;
             neg = neg + (ng ? 1.0f : 0.0f) * f;
@@ -1492,6 +1501,7 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
     float cnt = hdr.cnt;
     int iters = 0, did_prop = 0, violation = 0, cur = 0;
     int logs_ready = 0;                      // X / Y hold the logs of the current q_u / surveys already: the last sweep's E2 left them (see E2)
+    int mask_fix = 0;                        // ... taken under the edge mask of before a refresh: the next sweep multiplies the new one in
     int nsat = (int)hdr.nsat_p1 - 1;         // clauses satisfied by `sol` (-1: not counted yet); it only changes with a decimation, so later launches inherit it
     int rf_last_flip = 0;                    // Reinforce: the force was renewed after the last sweep (X holds the one that sweep read)
     int simplified = (int)hdr.simplified;   // 0: unknown, 1: the state is a simplify() fix-point (checked at the first decimation of a call), 2: it is not
@@ -1555,8 +1565,18 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
             }
         }
         __syncthreads();
+        } else if (mask_fix) {
+            // The logs are in place but a refresh changed the edge mask (a decimation clears flags, it never sets one): log * new mask is the old
+            // product times the new mask -- exact, x * 1 = x and (+-0) * 0 keeps its sign --, and only the slots that lost their bit change.  The
+            // bit "the mask the last propagate used" follows here, as it does in E1 (the sweep that is about to run is that propagate).
+            for (int p = tid; p < ne; p += nt) {
+                const uint16_t c = pcc[p];
+                if (!(c & PC_EM)) { X[p] = X[p] * 0.0f; Y[p] = Y[p] * 0.0f; }
+                if (((c >> 1) ^ c) & PC_EM_USED) pcc[p] = (uint16_t)((c & ~PC_EM_USED) | ((c & PC_EM) ? PC_EM_USED : 0));
+            }
+            __syncthreads();
         }
-        last_use_em = use_em; em_dirty = 0;
+        last_use_em = use_em; em_dirty = 0; mask_fix = 0;
         PROF_MARK(1);                                        // E1
         // ---- R1: per-clause sums (through e2p) and per-variable sums (contiguous), ascending edge id ------------
         {
@@ -1919,9 +1939,11 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
         // ---- P6: decimation (rare, out of line) ------------------------------------------------------------------------------
         int decimated = 0;
         if (!RF && has_prev && conv && !poisoned && !nan_seen && !PROF_SKIP(16)) {
-            const int dr = UNI(lds_decimate<FORCE>(lds_offset_of(smem), lds_offset_of(&s_cold), nt, n, m, ne, cur, active, pi, simplified));
+            // (with the next sweep's logs in Y the scorer reads them in place and leaves them there; else Y is its scratch -- and was no log before)
+            const int ylogs = (logs_ready && use_em && !sp.no_scorer_reuse) ? 1 : 0;
+            const int dr = UNI(lds_decimate<FORCE>(lds_offset_of(smem), lds_offset_of(&s_cold), nt, n, m, ne, cur, active, pi, simplified, ylogs));
             decimated = dr & DEC_FIXED; simplified = (dr >> DEC_VERIFIED_SHIFT) & 3;
-            logs_ready = 0;                                  // (X / Y are its scratch, and it rewrites surveys and q_u)
+            if (!ylogs) logs_ready = 0;
             const int spec_bits = (dr >> DEC_SPEC_SHIFT) & 3;
             used |= 4u;
             if (spec_bits & 1) zero |= 4u;
@@ -1952,7 +1974,7 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
                     const bool em = (a * b) == 1.0f;
                     pcc[p] = (uint16_t)((cw & ~PC_EM) | (em ? PC_EM : 0));
                 }
-                use_em = 1; em_dirty = 1; logs_ready = 0;
+                use_em = 1; em_dirty = 1; mask_fix = logs_ready;
                 PROF_COUNT(17);
             }
             PROF_MARK(14);                                   // P7
@@ -2544,6 +2566,7 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     sp.coins = a->coins; sp.dprob = a->decimation_probability;
     sp.rf = rf ? 1 : 0; sp.isolate = a->isolate_instances ? 1 : 0;
     sp.adopt_poison = getenv("PDP_SOLVE_NO_ADOPT") ? 0 : 1;
+    sp.no_scorer_reuse = getenv("PDP_SOLVE_NO_SCORER_REUSE") ? 1 : 0;
     float *frc_buf[2] = {nullptr, nullptr};
     if (rf) {
         frc_buf[0] = (float *)(((uintptr_t)(replay_list + B) + 15) & ~(uintptr_t)15); frc_buf[1] = frc_buf[0] + E + 4;
