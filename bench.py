@@ -276,12 +276,15 @@ def main():
             try:
                 src = 'profiles/' + pmcs[-1]
                 pj = json.load(open(os.path.join(REPO, src)))
+                # (per launch of the profiled build; a call's work is the same whatever the chunk length, so both scale with the launches per call)
+                scale = float(pj.get('launches_per_call', 9.0)) / max(n_launch, 1.0)
                 traffic = pj.get('k_sp_solve_lds_bytes_per_launch')
+                if traffic: traffic = float(traffic) * scale
                 if pj.get('SQ_INSTS_VALU_per_launch'):
                     # what binds the LDS-resident kernel: wave-level VALU instructions against the issue slots of 1024 SIMDs over the measured
                     # launch time.  A wave64 fp32 instruction occupies its SIMD for 2 cycles when the same wave has an independent instruction
                     # next and ~4 in a dependent chain (tools/micro/pk_rate.hip: 2.2 / 4.3 measured; MI355X_MICROARCH.md: 2 cycles) -- both given
-                    insts = float(pj['SQ_INSTS_VALU_per_launch'])
+                    insts = float(pj['SQ_INSTS_VALU_per_launch']) * scale
                     cyc = N_SIMD * CLOCK_HZ * launch_ms * 1e-3
                     valu = {'insts_per_launch': insts, 'cycles_per_inst_per_simd': cyc / insts, 'issue_frac_at_2_cycles': insts * 2.0 / cyc,
                             'issue_frac_at_4_cycles_dependent_chain': insts * 4.0 / cyc, 'source': src,

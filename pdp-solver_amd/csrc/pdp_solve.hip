@@ -2896,15 +2896,17 @@ static int sp_solve_speculative(pdp_problem *p, pdp_solve_args *a, void *stream)
     // The loop runs in chunks of C iterations (one launch each; the kernel resumes from the HBM state).  Chunking bounds
     // the cost of reproducing the reference's NaN poisoning: only the chunk in which the first NaN appears is partially
     // replayed, and every later chunk runs "poisoned from its first iteration" without any snapshot.
-    // chunk length, measured on MI355X (n=200, batch=5000, T=100, one NaN poison at iteration 81): 8 -> 6593, 12 -> 6837,
-    // 16 -> 6638, 25 -> 6415 iterations/s.  Short chunks bound the poison replay, long ones amortise the record copies.
+    // Chunk length: short chunks bound the poison replay, long ones amortise the launch, the record copies and the log pass of a launch's
+    // first sweep.  Measured on MI355X (n=200, batch=5000, T=100, one NaN poison at sweep 81), ms per step: round 1-4 kernels 8 / 12 / 16 / 25
+    // -> best at 12; round 5 (E2 takes the logs, later workgroups adopt the poison, so the replay is smaller and a launch's first sweep is
+    // the expensive one): 12 / 14 / 16 / 18 / 20 / 25 -> 11.19 / 11.15 / 11.08 / 10.93 / 10.91 / 10.98.
     // A batch of ONE instance has nobody to supply the exact zero the speculation counts on (tools/spec_rate.py: it fails in the first
     // iteration for 10-19 of 20 random instances) -- but its batch-global minima are its own: the HBM-resident kernel computes them
     // (sp.exact), nothing is speculated, recorded or replayed, and the whole loop is one launch (a team of workgroups when the instance is big).
     // (the same holds for the R identical replicas of one instance: every replica's own minimum is the batch's)
     const bool exact = (B == 1 || (p->B0 == 1 && a->replicas_identical)) && !a->isolate_instances && getenv("PDP_SOLVE_NO_EXACT") == nullptr &&
                        !p->exchange;                       // (a part of one instance is not a batch of one)
-    int C = 12;
+    int C = 20;
     if (const char *env = getenv("PDP_SOLVE_CHUNK")) { const int v = atoi(env); if (v > 0) C = v; }
     if (C > T) C = T;
     { int st_ = resident_prepare(p); if (st_ != PDP_OK) return st_; }

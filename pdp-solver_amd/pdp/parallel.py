@@ -25,7 +25,7 @@ v + r V: no contiguous base).  One batch-global quantity is left in Walk-SAT -- 
 util.sparse_argmax, 0 whenever any variable of the forward is not in an unsatisfied clause -- a part whose every variable is in an
 unsatisfied clause while the whole segment has one that is not would round one comparison differently; not observed, not excluded.
 The strict (coupled) semantics across GPUs: ``--split-forward`` cuts the segments the same way and completes the reference's batch-wide
-reductions across the parts -- per 12-sweep chunk of the persistent solver one small all-gather of its control words (first NaN sweep: min,
+reductions across the parts -- per chunk of sweeps of the persistent solver one small all-gather of its control words (first NaN sweep: min,
 exact-zero record of the batch-global minimum: or, executed sweeps: max), one more after a poison replay, one for the Walk-SAT record
 (``make_exchange`` -> ``native.Problem.set_exchange`` -> C ABI ``pdp_problem_set_exchange``); the rows are those of the 1-rank strict run.
 A segment whose speculation fails (small batches: no variable supplies the exact zero of the batch-global minimum) is solved whole by the

@@ -138,7 +138,7 @@ def test_isolated_run_spreads_one_forward_over_the_ranks(tmp_path):
 
 def test_split_forward_keeps_the_couplings_across_ranks(tmp_path):
     """--split-forward: ONE coupled forward (one loader batch, one segment: config 2's shape) is spread over the ranks as contiguous instance
-    ranges, and the reference's batch-wide reductions are completed across them -- per 12-sweep chunk one exchange of the persistent solver's
+    ranges, and the reference's batch-wide reductions are completed across them -- per chunk of sweeps one exchange of the persistent solver's
     control words (first NaN sweep, exact-zero record, executed sweeps), one more after the poison replay, one for the Walk-SAT record.  The
     batch holds the golden NaN-producing instances: their NaN at sweep 81 stops the decimation of EVERY instance, also of those on the other
     ranks, so the rows depend on the exchange -- and two / three ranks write the rows of the single process.  (--isolated gives other rows.)"""

@@ -60,7 +60,7 @@ for d, name in (('pmc3', 'FETCH_SIZE'), ('pmc4', 'WRITE_SIZE')):
 if 'FETCH_SIZE' in vals and 'WRITE_SIZE' in vals:
     out = dict(FETCH_SIZE_KiB_per_launch=vals['FETCH_SIZE'], WRITE_SIZE_KiB_per_launch=vals['WRITE_SIZE'],
                k_sp_solve_lds_bytes_per_launch=(2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0,
-               note='2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes; average over the launches of k_sp_solve_lds<false, false, false> (one per chunk of 12 iterations; the poison replay is k_sp_solve_lds<false, true, false>)')
+               note='2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes; average over the launches of k_sp_solve_lds<false, false, false> (one per chunk of PDP_SOLVE_CHUNK iterations, `launches_per_call` of them per 100-sweep call; the poison replay is k_sp_solve_lds<false, true, false>)')
     # wave-level VALU instructions per launch of the same kernel (pmc1 of this build and of the fast build): bench.py prices them against the
     # SIMDs' issue slots (roofline.valu_issue)
     for pre, key in (('', 'SQ_INSTS_VALU_per_launch'), ('fast_', 'SQ_INSTS_VALU_per_launch_fast_build')):
@@ -74,6 +74,8 @@ if 'FETCH_SIZE' in vals and 'WRITE_SIZE' in vals:
                         tot += float(r.get('Counter_Value', 0) or 0); disp.add(r.get('Dispatch_Id'))
             if disp:
                 out[key] = tot / len(disp)
+                if not pre:
+                    out['launches_per_call'] = len(disp) / 4.0      # the profiled command makes 4 solve calls (--steps 3 --warmup 1)
     out['source'] = 'bash tools/profile_bench.sh <tag>: rocprofv3 --kernel-trace --pmc passes of python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-fast-build; FETCH_SIZE and WRITE_SIZE in passes of their own'
     json.dump(out, open(os.path.join(root, prefix + 'pmc_traffic.json'), 'w'), indent=1)
     print()
