@@ -1109,6 +1109,92 @@ __global__ void __launch_bounds__(NTN) k_predict_rows(int V, const float *__rest
     }
 }
 
+// ---- kernel 4 on the shapes of the shipped configurations (52 -> 100 -> 128, head 128 -> <= 64 -> 1) ------------------------------------
+// Same arithmetic as k_predict_rows (every layer the k-ordered fmaf chain of its column), organised like k_agg_post_pf: one 32x32 block per
+// wave and layer with both operands prefetched, packed logsigmoids, the hidden layer's last column block as a 16-column tail -- and the head's
+// 128 -> 64 layer, which has only four 32x32 blocks for eight waves, as eight pairs of 16x16 blocks on v_mfma_f32_16x16x4_f32 (one pair per
+// wave; the instruction adds its four k-steps in ascending order with one rounding each, tools/micro/mfma16_order.hip).  The input tile
+// shares its LDS with the output layer's result and the hidden layer with the head's: 66 KB, two workgroups per CU (the generic kernel keeps
+// four tiles: 96 KB, one).
+template <int S3, int NB3, int S4, int NB4>
+__global__ void __launch_bounds__(NTN, 4) k_predict_rows_pf(int V, const float *__restrict__ agg, AggW w, HeadW hd, float *__restrict__ pred)
+{
+    static_assert(NB3 * 2 == NWAVES && NB4 * 2 == NWAVES, "one 32x32 block per wave in both aggregator layers");
+    static_assert(2 * S3 <= 64, "one lane per input column");
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int ld0 = 2 * S3 + 1, ld1 = 32 * NB3 + 1, ld2 = 32 * NB4 + 1, ld3 = 64 + 1;
+    float *O = sm, *Rt = sm, *G1 = sm + TM * ld2, *C1 = G1;          // Rt is dead when O is written, G1 when C1 is
+    const int v0 = blockIdx.x * TM;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, i = l & 31, kh = l >> 5;
+    // the tile's rows are one contiguous piece of [V, a]: a wave takes 8 rows, lane c column c
+#pragma unroll
+    for (int jr = 0; jr < TM / NWAVES; ++jr) {
+        const int r = wave + NWAVES * jr, v = v0 + r;
+        float x = 0.0f;
+        if (v < V && l < w.a) x = agg[(size_t)v * w.a + l];
+        if (l < 2 * S3) Rt[r * ld0 + l] = x;
+    }
+    const int nb = wave >> 1, mb = wave & 1, col = 32 * nb + i;
+    // (the predictor's aggregator has no sign column: 50 input columns; the k-steps past the matrix read zeros through the clipped descriptor)
+    const __amdgpu_buffer_rsrc_t w3 = __builtin_amdgcn_make_buffer_rsrc((void *)(w.Wt1a + 32 * nb), 0, (w.Kp3 * 32 * NB3 - 32 * nb) * (int)sizeof(float), 0x00020000);
+    __syncthreads();
+    const bool tail16 = nb == NB3 - 1 && w.g <= 32 * (NB3 - 1) + 16 && (2 * S3) % 4 == 0 && !w.no_tail16;
+    f32x4 tl[2];
+    if (__builtin_amdgcn_readfirstlane(tail16 ? 1 : 0)) {
+        const __amdgpu_buffer_rsrc_t w3t = __builtin_amdgcn_make_buffer_rsrc((void *)w.Wt1a, 0, w.Kp3 * 32 * NB3 * (int)sizeof(float), 0x00020000);
+        wave_tail16<(2 * S3) / 4, 32 * NB3, 4>(Rt + 32 * mb * ld0, ld0, w3t, 32 * (NB3 - 1), w.b1a, tl);
+        const int colt = 32 * (NB3 - 1) + (l & 15);
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+                const f32x2 v = pk_logsigmoid_or_zero(tl[hb][r], tl[hb][r + 1], colt < w.g);
+                G1[(32 * mb + 16 * hb + 4 * (l >> 4) + r) * ld1 + colt] = v.x; G1[(32 * mb + 16 * hb + 4 * (l >> 4) + r + 1) * ld1 + colt] = v.y;
+            }
+        // (the columns 112 .. 127 of this block are never read: the output layer's K is 2 S4 <= 112)
+    } else {
+        f32x16 acc[1];
+        wave_chains<S3, 1, 32 * NB3>(Rt + (32 * mb + i) * ld0 + kh, w3, w.b1a + 32 * nb, acc);
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const f32x2 v = pk_logsigmoid_or_zero(acc[0][r], acc[0][r + 1], col < w.g);
+            G1[(32 * mb + acc_row(r, l)) * ld1 + col] = v.x; G1[(32 * mb + acc_row(r + 1, l)) * ld1 + col] = v.y;
+        }
+    }
+    __syncthreads();                                         // G1 complete, Rt dead
+    {
+        const __amdgpu_buffer_rsrc_t w4 = __builtin_amdgcn_make_buffer_rsrc((void *)(w.Wt2a + 32 * nb), 0, (2 * S4 * 32 * NB4 - 32 * nb) * (int)sizeof(float), 0x00020000);
+        f32x16 acc[1];
+        wave_chains<S4, 1, 32 * NB4>(G1 + (32 * mb + i) * ld1 + kh, w4, nullptr, acc);
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const f32x2 v = pk_logsigmoid_or_zero(acc[0][r], acc[0][r + 1], col < w.out);
+            O[(32 * mb + acc_row(r, l)) * ld2 + col] = v.x; O[(32 * mb + acc_row(r + 1, l)) * ld2 + col] = v.y;
+        }
+    }
+    __syncthreads();                                         // O complete, G1 dead
+    {
+        // head layer 128 -> hd.Np (= 64) columns: wave = (row half, 16-column group)
+        const int rh = wave & 1, cg = wave >> 1;
+        const __amdgpu_buffer_rsrc_t w5 = __builtin_amdgcn_make_buffer_rsrc((void *)hd.Wt1, 0, 32 * NB4 * 64 * (int)sizeof(float), 0x00020000);
+        wave_tail16<(32 * NB4) / 4, 64>(O + 32 * rh * ld2, ld2, w5, 16 * cg, hd.b1, tl);
+        const int colh = 16 * cg + (l & 15);
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = tl[hb][r];
+                C1[(32 * rh + 16 * hb + 4 * (l >> 4) + r) * ld3 + colh] = (colh < hd.C) ? (v > 0.0f ? v : ((v != v) ? v : 0.0f)) : 0.0f;
+            }
+    }
+    __syncthreads();
+    if (threadIdx.x < TM && v0 + threadIdx.x < V) {
+        float acc = 0.0f;
+        for (int k = 0; k < hd.C; ++k) acc = fmaf(C1[threadIdx.x * ld3 + k], hd.w2[k], acc);
+        pred[v0 + threadIdx.x] = act_apply(acc, hd.out_act);
+    }
+}
+
 // ---- kernel 5: GRU cell on edge tiles ----------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(NTN) k_gru(int E, const float *__restrict__ state, const float *__restrict__ sign,
                                              const float *__restrict__ hprev, const float *__restrict__ rowmask, GruW g, float *__restrict__ out, int ntiles)
@@ -2398,8 +2484,17 @@ extern "C" int pdp_neural_predict(pdp_problem *p, const pdp_agg_desc *d, const p
     { pdp_timed_scope timed(PDP_TK_ROW_SUM, st);
       launch_row_sum(V, w.a, p->nv_ptr, p->nv_edges, h2, agg, st); }
     { pdp_timed_scope timed(PDP_TK_PREDICT_HEAD, st);
-      pdp_note_kernel(PDP_TK_PREDICT_HEAD, "k_predict_rows");
-      hipLaunchKernelGGL(k_predict_rows, dim3((V + TM - 1) / TM), dim3(NTN), lds4, st, V, agg, w, h, pred); }
+      const bool shape_pf = !generic_forced() && !getenv("PDP_PREDICT_GENERIC") && (w.Kp3 == 50 || w.Kp3 == 52) && w.Np3 == 128 && w.Kp4 == 100 && w.Np4 == 128 && w.out == 128 &&
+                            h.Kp == 128 && h.Np == 64 && w.a <= 52 && w.g <= 128;
+      if (shape_pf) {
+          const size_t ldsp = sizeof(float) * (size_t)TM * (129 + 129);
+          s = set_lds((const void *)k_predict_rows_pf<26, 4, 50, 4>, ldsp); if (s != PDP_OK) return s;
+          pdp_note_kernel(PDP_TK_PREDICT_HEAD, "k_predict_rows_pf<26, 4, 50, 4>");
+          hipLaunchKernelGGL((k_predict_rows_pf<26, 4, 50, 4>), dim3((V + TM - 1) / TM), dim3(NTN), ldsp, st, V, agg, w, h, pred);
+      } else {
+          pdp_note_kernel(PDP_TK_PREDICT_HEAD, "k_predict_rows");
+          hipLaunchKernelGGL(k_predict_rows, dim3((V + TM - 1) / TM), dim3(NTN), lds4, st, V, agg, w, h, pred);
+      } }
     PDP_LAUNCH_CHECK();
     return PDP_OK;
 }
