@@ -739,6 +739,8 @@ __global__ void __launch_bounds__(NTN) k_agg_pre_wave(int E, const float *__rest
 }
 
 // ---- kernel 3 with prefetched chains (config 3's shapes) ---------------------------------------------------------------------------------
+// (Round 5 measured the same kernel on 32-edge tiles with four waves per workgroup -- six workgroups per CU, barriers over four waves: 6.91 / 6.96
+//  -> 6.88 / 6.94 ms per call, noise; not kept.)
 // Same workgroup-tile structure as k_agg_post (three workgroups per CU hide its gather / previous-state / store streams), but every wave's
 // block is a straight-line wave_chains sequence: both operands prefetched instead of fetched just in time.
 template <int S3, int NB3, int S4, int NB4>
