@@ -1124,13 +1124,15 @@ __device__ __forceinline__ int team_any(const LView &I, int x) { return block_re
 #define DEC_FIXED 1
 #define DEC_SPEC_SHIFT 1
 #define DEC_VERIFIED_SHIFT 3
-// y_has_logs: Y already holds log(max(1 - eta, PDP_SP_EPS)) * edge mask of the CURRENT surveys (E2 left them for the next sweep).  For an
+// scorer_src 1: Y already holds log(max(1 - eta, PDP_SP_EPS)) * edge mask of the CURRENT surveys (E2 left them for the next sweep).  For an
 // active variable that is the scorer's own term -- the edge mask of its slots is the clause flag, and the two clamps only differ at
 // 1 - eta == 0 (a survey of exactly 1: the next smaller value of 1 - eta is 2^-24, above both), where the propagator's log(1e-40) is
 // replaced by the scorer's log(1e-10) on the fly; an inactive variable's coefficient is |score| * 0 either way (a NaN survey stays NaN
-// under both masks).  The pass over the slots and its barrier are skipped, and Y stays what the next sweep needs.
+// under both masks).  The pass over the slots is skipped, and Y stays what the next sweep needs.  scorer_src 0 / 2: the terms are taken here,
+// into Y (a sweep of the plain form: Y is free) or into the q_u array (a sweep that took the logs but may not read them here: that array
+// holds the sweep's |delta eta|, which nobody needs any more).
 template <bool FORCE>
-__device__ __noinline__ int lds_decimate(uint32_t smem_off, uint32_t cold_off, int nt, int n, int m, int ne, int cur, int active, float pi, int verified, int y_has_logs)
+__device__ __noinline__ int lds_decimate(uint32_t smem_off, uint32_t cold_off, int nt, int n, int m, int ne, int cur, int active, float pi, int verified, int scorer_src)
 {
     unsigned char *const smem = lds_at<unsigned char>(smem_off);
     ColdShared *const cs = lds_at<ColdShared>(cold_off);
@@ -1141,6 +1143,8 @@ __device__ __noinline__ int lds_decimate(uint32_t smem_off, uint32_t cold_off, i
     DEC_PROF_DECL
     // scorer, per slot: log(max(1 - eta, eps)) * active_clause (pdp_predict.py:168-172), four slots per trip as one 4-vector; the
     // remainder (fewer than 4 nt slots) is dealt in quarters to the first lanes, so that the other waves skip the trip
+    float *const SL = (scorer_src == 2) ? L.QU : L.Y;     // the scorer's per-slot terms: Y (written here, or E2's logs read in place), or the q_u array
+    const int y_has_logs = scorer_src == 1;
     if (!y_has_logs) {
         const int full = ne / (4 * nt), rem = ne - full * 4 * nt, quarter = (rem + 3) >> 2;
         for (int k = 0; k <= full; ++k) {
@@ -1153,7 +1157,7 @@ __device__ __noinline__ int lds_decimate(uint32_t smem_off, uint32_t cold_off, i
             const f4v lg = log4_fin((f4v){1.0f - Enew[p[0]], 1.0f - Enew[p[1]], 1.0f - Enew[p[2]], 1.0f - Enew[p[3]]}, PDP_SCORER_EPS);   // surveys are finite or NaN
             const float r[4] = {lg.x, lg.y, lg.z, lg.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (in[j]) L.Y[p[j]] = r[j] * (0.0f + L.af[L.pcc[p[j]] & 0x3fff]);
+            for (int j = 0; j < 4; ++j) if (in[j]) SL[p[j]] = r[j] * (0.0f + L.af[L.pcc[p[j]] & 0x3fff]);
         }
     }
     if (tid == 0) { cs->key = 0ull; cs->flags = 0; cs->found = 0; }
@@ -1180,18 +1184,18 @@ __device__ __noinline__ int lds_decimate(uint32_t smem_off, uint32_t cold_off, i
         for (; p + 7 < bnd; p += 8) {                // all loads of a batch first: one LDS round trip per eight edges
             float f[8], fr[8]; uint16_t pw[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { f[j] = L.Y[p + j]; pw[j] = L.pvv[p + j]; fr[j] = FORCE ? L.FRC[p + j] : 0.0f; }
+            for (int j = 0; j < 8; ++j) { f[j] = SL[p + j]; pw[j] = L.pvv[p + j]; fr[j] = FORCE ? L.FRC[p + j] : 0.0f; }
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc(f[j], pw[j], fr[j]);
         }
         for (; p + 3 < bnd; p += 4) {
             float f[4], fr[4]; uint16_t pw[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { f[j] = L.Y[p + j]; pw[j] = L.pvv[p + j]; fr[j] = FORCE ? L.FRC[p + j] : 0.0f; }
+            for (int j = 0; j < 4; ++j) { f[j] = SL[p + j]; pw[j] = L.pvv[p + j]; fr[j] = FORCE ? L.FRC[p + j] : 0.0f; }
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc(f[j], pw[j], fr[j]);
         }
-        for (; p < bnd; ++p) acc(L.Y[p], L.pvv[p], FORCE ? L.FRC[p] : 0.0f);
+        for (; p < bnd; ++p) acc(SL[p], L.pvv[p], FORCE ? L.FRC[p] : 0.0f);
         const float sc = lds_score_of(pos, neg, all, ext, Lpi, L0);
         const float co = (pdp_abs(sc) * L.av[v]) * 1.0f;
         score[v] = sc; L.coeff[v] = co;
@@ -1501,6 +1505,7 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
     float cnt = hdr.cnt;
     int iters = 0, did_prop = 0, violation = 0, cur = 0;
     int logs_ready = 0;                      // X / Y hold the logs of the current q_u / surveys already: the last sweep's E2 left them (see E2)
+    int qu_is_delta = 0;                     // the q_u array holds the last sweep's |delta eta| (that sweep took the logs): q_u itself is formed at the exit
     int mask_fix = 0;                        // ... taken under the edge mask of before a refresh: the next sweep multiplies the new one in
     int nsat = (int)hdr.nsat_p1 - 1;         // clauses satisfied by `sol` (-1: not counted yet); it only changes with a decimation, so later launches inherit it
     int rf_last_flip = 0;                    // Reinforce: the force was renewed after the last sweep (X holds the one that sweep read)
@@ -1690,22 +1695,26 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
         // ---- E2: new survey, new q_u, smooth-max weights -----------------------------------------------------------
         // The next sweep's E1 would take the logs of exactly the two values a slot's update stores (q_u, the survey), in the same lane order:
         // E2 takes them here -- X / Y of the slot are this lane's own to overwrite once it has read them --, and the next sweep starts at
-        // R1: no pass over the slots to fetch and unpack them again, one workgroup barrier less.  Y no longer carries |delta eta| to P4:
-        // P4 forms it from the two survey arrays (the old one stays in place, the exit path needs it as well).  Not in the last sweep
-        // of a launch, and not in a call's first sweep (without previous surveys it looks for NaNs; with the caller's, Y hands those to P4).
+        // R1: no pass over the slots to fetch and unpack them again, one workgroup barrier less.  Y then no longer carries |delta eta| to P4 --
+        // the q_u array does: nothing reads q_u itself while the logs are in place (the sticky NaN of `mask * new + (1 - mask) * old` comes
+        // from X = log(old q_u) * mask, which is NaN exactly when the old q_u is -- log(max(x, eps)) is finite for every finite x -- and the
+        // exit path forms q_u from the same sums as its two other columns).  Not in the last sweep of a launch (the record that goes to the
+        // next launch holds q_u), not in a call's first sweep, and not for Reinforce (its step uses X / Y as scratch, so every sweep needs
+        // q_u for its logs).  A sweep of the plain form stores q_u and hands |delta eta| over in Y as rounds 1-4 did.
         // The two forms of the loop are separate loops: nothing to branch on per trip.
-        const bool fuse_logs = (t + 1 < T) && has_prev && !prev_from_global;
+        const bool fuse_logs = !RF && (t + 1 < T) && has_prev && !prev_from_global;
         float nan_acc = 0.0f;
         const uint32_t log_em_or = use_em ? 0u : PC_EM;      // without an edge mask every slot counts
-        // one slot's update: reads the slot's words, the three row sums and its own logs, stores the new q_u and survey and returns them
-        struct SlotNew { float qu, eta; uint16_t cw; };
+        // one slot's update: reads the slot's words, the three row sums and its own logs, stores the new survey and returns the new values
+        struct SlotNew { float qu, eta, eta_old; uint16_t cw; };
         const float *const S_ = L.S, *const Pv_ = L.Pv, *const Nv_ = L.Nv;
         auto slot_update = [&](int p) __attribute__((always_inline)) {
             const uint16_t pw = pvv[p], cw = pcc[p];
             const int v = pw & VM, c = cw & 0x3fff;
             const float s = slot_sign(pw);
             const float eta_old = Eold[p];
-            const float agg = S_[c] - X[p];                     // the reference's 0 + S is a no-op: a sum that starts at +0 is never -0
+            const float xp = X[p];
+            const float agg = S_[c] - xp;                       // the reference's 0 + S is a no-op: a sum that starts at +0 is never -0
             const float force = RF ? frc_of(pw) : (FORCE ? L.FRC[p] : 0.0f);
             const float pos = Pv_[v], neg = Nv_[v];
             // The reference's (0.5 (1 + s)) * pos + (0.5 (1 - s)) * neg has coefficients 1 and 0: one product is the sum itself, the other an
@@ -1727,10 +1736,9 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
             const float A = ex.z, Bv = ex.w;
             const float qu = A * (1.0f - Bv), qs = Bv * (1.0f - A);
             const float total = (qu + qs) + dc;
-            const float qu_new = __builtin_fmaf(1.0f - 1.0f, QU[p], qu / total);
-            QU[p] = qu_new;
+            const float qu_new = __builtin_fmaf(1.0f - 1.0f, xp, qu / total);      // (+0) * log(old q_u): NaN iff the old q_u is NaN or infinite
             Enew[p] = eta_new;
-            return SlotNew{qu_new, eta_new, cw};
+            return SlotNew{qu_new, eta_new, eta_old, cw};
         };
         auto slot_logs = [&](int p, const SlotNew &r) __attribute__((always_inline)) {
             const f2v lg = log2_fin((f2v){r.qu, 1.0f - r.eta}, PDP_SP_EPS) * bit15_to_float((uint16_t)(r.cw | log_em_or));
@@ -1740,21 +1748,32 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
         else if (fuse_logs) {
             // (the logs of a trip riding in the NEXT trip, so that their dependent chain of ~20 packed steps interleaves with that trip's loads, exps
             //  and division in one basic block, was measured in round 5: +3 % on the launch)
-            for (int p = tid; p < ne; p += nt) slot_logs(p, slot_update(p));
+            for (int p = tid; p < ne; p += nt) {
+                const SlotNew r = slot_update(p);
+                QU[p] = pdp_abs(r.eta_old - r.eta) * bit15_to_float((uint16_t)(r.cw | log_em_or));   // |delta eta| * edge mask (pdp_decimate.py:135-141)
+                slot_logs(p, r);
+            }
         } else {
             for (int p = tid; p < ne; p += nt) {
                 const SlotNew r = slot_update(p);
+                QU[p] = r.qu;
                 if (!has_prev) {
                     // a NaN survey: with a previous survey every slot's |difference| is NaN too and P4's sums flag it (its S1 covers every slot
                     // of the instance); only the first sweep of a solve without one has to look here
                     nan_acc = __builtin_fmaf(0.0f, r.eta, nan_acc);    // stays 0 unless a survey is NaN (surveys are <= 1, never infinite)
-                } else if (prev_from_global) Y[p] = sp.prev_slots[G.e0 + p];
+                } else {
+                    const float pe = prev_from_global ? sp.prev_slots[G.e0 + p] : r.eta_old;
+                    float d = pdp_abs(pe - r.eta);
+                    if (use_em) d = d * bit15_to_float(r.cw);
+                    Y[p] = d;                               // the smooth-max weights exp(30 d) are only built when P4 cannot decide without them
+                }
             }
         }
         int nan_seen = (nan_acc != nan_acc) ? 1 : 0;
         did_prop = 1;
         logs_ready = fuse_logs ? 1 : 0;
-        const float *const Dold = (has_prev && prev_from_global) ? Y : Eold;      // what P4 takes |delta eta| against
+        qu_is_delta = logs_ready;
+        float *const Dsrc = fuse_logs ? QU : Y;              // where this sweep's |delta eta| is (dead behind P5b: the rare exact passes' scratch)
         __syncthreads();
         PROF_MARK(3);                                        // E2
         // ---- P4: per-variable smooth maxima, decided lazily.  The two batch-visible facts per instance are booleans:
@@ -1775,7 +1794,6 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
             const float *const av = L.av;
             float *const amb = L.xv1;
             const float tol_lo = tol - (2e-6f + 1e-4f * pdp_abs(tol)), tol_hi = tol + (2e-6f + 1e-4f * pdp_abs(tol));
-            const uint32_t em_or = use_em ? 0u : PC_EM;          // without an edge mask every slot counts
             if (!PROF_SKIP(8))
             for (int r = tid; r < 2 * n; r += nt) {
                 int v, lo, hi, degi;
@@ -1788,16 +1806,14 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
                 }
                 float emax = 0.0f, S1 = 0.0f, S2 = 0.0f, D = 0.0f;
                 if (has_prev) {
-                    // |delta eta| times the edge mask of the sweep, as the reference forms it (pdp_decimate.py:135-141)
-                    auto diff = [&](int q, float e) { return pdp_abs(Dold[q] - e) * bit15_to_float((uint16_t)(pcc[q] | em_or)); };
                     int p = lo;
                     // (four slots per trip -- their loads in flight together -- was measured in round 5: +3 % on the launch)
                     for (; p + 1 < hi; p += 2) {
-                        const float e0 = Enew[p], e1 = Enew[p + 1], d0 = diff(p, e0), d1 = diff(p + 1, e1);
+                        const float e0 = Enew[p], e1 = Enew[p + 1], d0 = Dsrc[p], d1 = Dsrc[p + 1];
                         emax = fmaxf(emax, fmaxf(e0, e1));           // (a NaN survey is dropped here and caught by S1 below)
                         S1 += d0 + d1; S2 = fmaf(d0, d0, fmaf(d1, d1, S2)); D = fmaxf(D, fmaxf(d0, d1));
                     }
-                    if (p < hi) { const float e0 = Enew[p], d0 = diff(p, e0); emax = fmaxf(emax, e0); S1 += d0; S2 = fmaf(d0, d0, S2); D = fmaxf(D, d0); }
+                    if (p < hi) { const float e0 = Enew[p], d0 = Dsrc[p]; emax = fmaxf(emax, e0); S1 += d0; S2 = fmaf(d0, d0, S2); D = fmaxf(D, d0); }
                 } else {
                     for (int p = lo; p < hi; ++p) emax = fmaxf(emax, Enew[p]);
                 }
@@ -1854,8 +1870,7 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
                 if (code == 2.0f || (code == 1.0f && need_decision)) {
                     float num = 0.0f, den = 0.0f;
                     for (int p = L.v_ptr[v]; p < L.v_ptr[v + 1]; ++p) {
-                        float d = pdp_abs(Dold[p] - Enew[p]);
-                        if (use_em) d = d * bit15_to_float(pcc[p]);
+                        const float d = Dsrc[p];
                         const float c0 = pdp_expf_fin_le30(30.0f * d);
                         num = num + d * c0; den = den + c0;
                     }
@@ -1879,13 +1894,12 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
             g = 1.0f;                                       // certified: the gate stays open, its exact value is never used (Reinforce has no survey gate)
         } else {
             // exact path (rare: every active variable has only vanishing surveys): util.py:282-286 + :267-275
-            for (int p = tid; p < ne; p += nt) X[p] = pdp_expf_fin_le30(30.0f * Enew[p]);
-            logs_ready = 0;
+            for (int p = tid; p < ne; p += nt) Dsrc[p] = pdp_expf_fin_le30(30.0f * Enew[p]);
             __syncthreads();
             float mm = -PDP_INF;
             for (int v = tid; v < n; v += nt) {
                 float num = 0.0f, den = 0.0f;
-                for (int p = L.v_ptr[v]; p < L.v_ptr[v + 1]; ++p) { const float c0 = X[p]; num = num + Enew[p] * c0; den = den + c0; }
+                for (int p = L.v_ptr[v]; p < L.v_ptr[v + 1]; ++p) { const float c0 = Dsrc[p]; num = num + Enew[p] * c0; den = den + c0; }
                 const float rr = (num / pdp_max_c(den, 1.0f)) * L.av[v];
                 mm = pdp_max(mm, (rr - 0.0f) + 1.0f);
             }
@@ -1940,10 +1954,9 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
         int decimated = 0;
         if (!RF && has_prev && conv && !poisoned && !nan_seen && !PROF_SKIP(16)) {
             // (with the next sweep's logs in Y the scorer reads them in place and leaves them there; else Y is its scratch -- and was no log before)
-            const int ylogs = (logs_ready && use_em && !sp.no_scorer_reuse) ? 1 : 0;
-            const int dr = UNI(lds_decimate<FORCE>(lds_offset_of(smem), lds_offset_of(&s_cold), nt, n, m, ne, cur, active, pi, simplified, ylogs));
+            const int scorer_src = !fuse_logs ? 0 : ((use_em && !sp.no_scorer_reuse) ? 1 : 2);
+            const int dr = UNI(lds_decimate<FORCE>(lds_offset_of(smem), lds_offset_of(&s_cold), nt, n, m, ne, cur, active, pi, simplified, scorer_src));
             decimated = dr & DEC_FIXED; simplified = (dr >> DEC_VERIFIED_SHIFT) & 3;
-            if (!ylogs) logs_ready = 0;
             const int spec_bits = (dr >> DEC_SPEC_SHIFT) & 3;
             used |= 4u;
             if (spec_bits & 1) zero |= 4u;
@@ -2047,8 +2060,10 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
             const float qu = A * (1.0f - Bv), qs = Bv * (1.0f - A);
             const float total = (qu + qs) + dc;
             // (1 - mask) * old keeps a NaN forever; the three columns of q turn NaN together, so q_u carries the stickiness
-            const float sticky = QU[p];
-            gq[3 * e] = QU[p];
+            // q_u: stored by a sweep of the plain form; after a sweep that took the logs, formed as that sweep formed it ((+0) * the log of the
+            // value keeps a NaN: X holds log(max(q_u, eps)) * mask of exactly that value)
+            const float sticky = qu_is_delta ? __builtin_fmaf(1.0f - 1.0f, X[p], qu / total) : QU[p];
+            gq[3 * e] = sticky;
             gq[3 * e + 1] = 1.0f * (qs / total) + (1.0f - 1.0f) * sticky;
             gq[3 * e + 2] = 1.0f * (dc / total) + (1.0f - 1.0f) * sticky;
             gfs[2 * e] = Efin[p];
