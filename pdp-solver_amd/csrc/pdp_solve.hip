@@ -91,6 +91,7 @@ struct SolveParams {
     int exact;                  // HBM-resident kernel, single-instance batch: the batch-global minima ARE the instance's own, nothing is speculated
     int rf;                     // HBM-resident kernel: the Reinforce triple (coins, dprob as for the LDS-resident kernel; tol = the gate's 0.01)
     int isolate;                // isolated instances (a NaN stays inside its instance, pass 1 is final)
+    uint32_t *risk;             // [B] LDS-resident pass 1: bits of the smallest q normalisation of the launch's last sweep (see k_order_by_risk); NULL: off
     int no_scorer_reuse;        // PDP_SOLVE_NO_SCORER_REUSE=1: the decimation's scorer always takes its own logs (A/B switch)
     int adopt_poison;           // LDS-resident pass 1: take a first-NaN sweep other workgroups of the launch already recorded (PDP_SOLVE_NO_ADOPT=1: off)
     int lds_tickets;            // LDS-resident kernel, pass 1: 0 = instance blockIdx.x, else the number of instances the workgroups draw tickets for
@@ -1479,9 +1480,10 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
     __shared__ uint8_t s_spec_used[SPEC_LOCAL], s_spec_zero[SPEC_LOCAL];
     __shared__ int s_flag_or[2];                            // P5: the OR of the waves' flag sets, one word per sweep parity
     __shared__ int s_sat_count;                             // P8: satisfied clauses, summed over the waves
+    __shared__ uint32_t s_risk;                             // smallest normalisation q_u + q_s + q_dc of the launch's last sweep (float bits, >= +0)
     __shared__ int s_poison;                                // first poisoned sweep of the chunk as this workgroup knows it (see `adopt`)
     if (tid < SPEC_LOCAL) { s_spec_used[tid] = 0; s_spec_zero[tid] = 0; }
-    if (tid == 0) { s_cold.is_sat = hdr.is_sat; s_flag_or[0] = 0; s_flag_or[1] = 0; s_sat_count = 0; }
+    if (tid == 0) { s_cold.is_sat = hdr.is_sat; s_flag_or[0] = 0; s_flag_or[1] = 0; s_sat_count = 0; s_risk = 0xffffffffu; }
     __syncthreads();
 
     // P4's work item of this lane -- (variable, half row) -- is topology: fetched once per launch instead of through two dependent LDS round
@@ -1706,7 +1708,7 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
         float nan_acc = 0.0f;
         const uint32_t log_em_or = use_em ? 0u : PC_EM;      // without an edge mask every slot counts
         // one slot's update: reads the slot's words, the three row sums and its own logs, stores the new survey and returns the new values
-        struct SlotNew { float qu, eta, eta_old; uint16_t cw; };
+        struct SlotNew { float qu, eta, eta_old, total; uint16_t cw; };
         const float *const S_ = L.S, *const Pv_ = L.Pv, *const Nv_ = L.Nv;
         auto slot_update = [&](int p) __attribute__((always_inline)) {
             const uint16_t pw = pvv[p], cw = pcc[p];
@@ -1738,7 +1740,7 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
             const float total = (qu + qs) + dc;
             const float qu_new = __builtin_fmaf(1.0f - 1.0f, xp, qu / total);      // (+0) * log(old q_u): NaN iff the old q_u is NaN or infinite
             Enew[p] = eta_new;
-            return SlotNew{qu_new, eta_new, eta_old, cw};
+            return SlotNew{qu_new, eta_new, eta_old, total, cw};
         };
         auto slot_logs = [&](int p, const SlotNew &r) __attribute__((always_inline)) {
             const f2v lg = log2_fin((f2v){r.qu, 1.0f - r.eta}, PDP_SP_EPS) * bit15_to_float((uint16_t)(r.cw | log_em_or));
@@ -1754,8 +1756,11 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
                 slot_logs(p, r);
             }
         } else {
+            // (a launch's last sweep is of this form: the smallest normalisation of the instance goes to the dispatch order of the next launch)
+            float tmin = PDP_INF;
             for (int p = tid; p < ne; p += nt) {
                 const SlotNew r = slot_update(p);
+                tmin = (r.total < tmin) ? r.total : tmin;
                 QU[p] = r.qu;
                 if (!has_prev) {
                     // a NaN survey: with a previous survey every slot's |difference| is NaN too and P4's sums flag it (its S1 covers every slot
@@ -1767,6 +1772,10 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
                     if (use_em) d = d * bit15_to_float(r.cw);
                     Y[p] = d;                               // the smooth-max weights exp(30 d) are only built when P4 cannot decide without them
                 }
+            }
+            if (sp.risk && t + 1 == T) {
+                tmin = wave_reduce(tmin, OpMinLess(), PDP_INF);
+                if (lane == 63) atomicMin(&s_risk, __float_as_uint(tmin));      // totals are >= +0 (or NaN, which sorts behind everything)
             }
         }
         int nan_seen = (nan_acc != nan_acc) ? 1 : 0;
@@ -2103,6 +2112,7 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
         if (finishing && !active && !(sp.final_chunk && iters >= T)) sp.ghost_flag[gb] = 1;
         if (any_inactive) atomicMin(&ctl->perm_zero, (uint32_t)iters);
         if (!REPLAY) sp.last_event[gb] = last_event;
+        if (sp.risk) sp.risk[gb] = finishing ? 0xffffffffu : s_risk;
         atomicMax(&ctl->iters_run, (uint32_t)iters);
         if (violation) atomicOr(&ctl->violation, 1u);
     }
@@ -2372,6 +2382,30 @@ __global__ void k_max_i32(int B, const int32_t *x, uint32_t *out)
     atomicMax(out, (uint32_t)m);
 }
 
+// Dispatch order of the next launch's pass 1: ascending by the binary exponent of the smallest q normalisation (q_u + q_s + q_dc) an instance
+// met in its last sweep.  The batch's first NaN survey is a 0 / 0 of that normalisation (pdp_propagate.py:215-216): both products of a variable
+// underflow, and they get there over several sweeps -- so the instances closest to it start in the first round of workgroups, put the NaN sweep
+// on record early, and the workgroups of the later rounds take it as their poison point at once instead of being replayed (k_sp_solve_lds:
+// `adopt`).  Only the ORDER depends on this guess: an instance's result does not depend on when it runs.  One workgroup: a counting sort over
+// the 256 exponents (finished instances and NaNs carry all ones: last), the order inside a bucket is whatever the atomics make it.
+__global__ void __launch_bounds__(1024) k_order_by_risk(int B, const uint32_t *risk, int32_t *order, const SolveCall *call)
+{
+    __shared__ int hist[256];
+    if (call->stop) return;
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += blockDim.x) atomicAdd(&hist[(risk[b] >> 23) & 255], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < 256; ++i) { const int c = hist[i]; hist[i] = run; run += c; } }
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += blockDim.x) order[atomicAdd(&hist[(risk[b] >> 23) & 255], 1)] = b;
+}
+__global__ void k_order_identity(int B, int32_t *order, uint32_t *risk)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) { order[b] = b; risk[b] = 0xffffffffu; }
+}
+
 __global__ void k_solve_ctl_init(SolveCtl *ctl, int nchunks, SolveCall *call)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2499,7 +2533,7 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     const int nchunks = (T + C - 1) / C;
     const int64_t *stat_off = p->res_stat_off, *dyn_off = p->res_stat_off + B;
     // ---- control blocks, speculation record, replay list; call-entry snapshot for the failure path ---------------------------
-    const size_t ctl_bytes = (size_t)nchunks * sizeof(SolveCtl) + sizeof(SolveCall) + 2 * (size_t)T * 4 + 2 * B * 4 + 64 +
+    const size_t ctl_bytes = (size_t)nchunks * sizeof(SolveCtl) + sizeof(SolveCall) + 2 * (size_t)T * 4 + 2 * B * 4 + 64 + 2 * (B + 16) * 4 +
                              (rf ? 2 * (E + 4) * sizeof(float) : 0) +          // Reinforce: two slot-major force columns
                              ((B + 63) & ~(size_t)63);                          // ghost flags
     int status = ensure_bytes(&p->res_ctl, &p->res_ctl_bytes, ctl_bytes);
@@ -2591,6 +2625,9 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     uint8_t *ghost_flag = rf ? (uint8_t *)(frc_buf[1] + E + 4) : (uint8_t *)(((uintptr_t)(replay_list + B) + 15) & ~(uintptr_t)15);
     PDP_HIP_CHECK(hipMemsetAsync(ghost_flag, 0, B, st));
     sp.ghost_flag = ghost_flag;
+    // dispatch order of pass 1 (k_order_by_risk): behind the ghost flags
+    uint32_t *risk = (uint32_t *)(((uintptr_t)(ghost_flag + ((B + 63) & ~(size_t)63)) + 15) & ~(uintptr_t)15);
+    int32_t *order = (int32_t *)(risk + B + 8);
     sp.last_event = last_event; sp.inst_list = replay_list;
     sp.call = call; sp.stat = p->res_stat; sp.stat_off = stat_off; sp.dyn_off = dyn_off;
     sp.fit_list = fit_list;
@@ -2622,6 +2659,12 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     int ticket_extra = nbig > 0 ? 25 : 0;
     if (const char *env = getenv("PDP_SOLVE_TICKETS")) ticket_extra = atoi(env);
     if (ticket_extra > 0 && !sp.fit_list) sp.fit_list = p->res_fit_list;        // (tickets index the list; with no big instance it holds every instance)
+    // a batch that is LDS-resident as a whole: pass 1 takes its instances in the order of k_order_by_risk (PDP_SOLVE_NO_RISK_ORDER=1: block index)
+    const bool risk_order = nbig == 0 && ticket_extra <= 0 && !sp.fit_list && nchunks > 1 && !a->isolate_instances && getenv("PDP_SOLVE_NO_RISK_ORDER") == nullptr;
+    if (risk_order) {
+        hipLaunchKernelGGL(k_order_identity, dim3((p->B + 255) / 256), dim3(256), 0, st, p->B, order, risk);
+        sp.risk = risk; sp.fit_list = order;
+    }
     const bool listed = sp.fit_list != nullptr;                                 // pass 1 runs the LISTED instantiation
     const int big_copy_wgs = nbig >= 256 ? 1 : (256 / (nbig > 0 ? nbig : 1) < 32 ? 256 / (nbig > 0 ? nbig : 1) : 32);      // workgroups per instance of the save / restore copies
     if (const char *env = getenv("PDP_DEBUG_SKIP")) sp.debug_skip = atoi(env);
@@ -2719,6 +2762,7 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
             }
         }
         hipLaunchKernelGGL(k_solve_finish, dim3(1), dim3(1), 0, st, ctl + k, call, (const uint32_t *)sp.spec_used, (const uint32_t *)sp.spec_zero, c, done, (int)a->isolate_instances);
+        if (risk_order && k + 1 < nchunks) hipLaunchKernelGGL(k_order_by_risk, dim3(1), dim3(1024), 0, st, p->B, (const uint32_t *)risk, order, (const SolveCall *)call);
         PDP_LAUNCH_CHECK();
         done += c;
     }
@@ -2914,14 +2958,16 @@ static int sp_solve_speculative(pdp_problem *p, pdp_solve_args *a, void *stream)
     // Chunk length: short chunks bound the poison replay, long ones amortise the launch, the record copies and the log pass of a launch's
     // first sweep.  Measured on MI355X (n=200, batch=5000, T=100, one NaN poison at sweep 81), ms per step: round 1-4 kernels 8 / 12 / 16 / 25
     // -> best at 12; round 5 (E2 takes the logs, later workgroups adopt the poison, so the replay is smaller and a launch's first sweep is
-    // the expensive one): 12 / 14 / 16 / 18 / 20 / 25 -> 11.19 / 11.15 / 11.08 / 10.93 / 10.91 / 10.98.
+    // the expensive one): 12 / 14 / 16 / 18 / 20 / 25 -> 11.19 / 11.15 / 11.08 / 10.93 / 10.91 / 10.98; with pass 1 dispatched in the order of
+    // k_order_by_risk (the replay shrinks to a quarter): 20 / 25 / 27 / 34 / 40 / 50 -> 9.64 / 9.45 / 9.43 / 9.42 / 9.23 / 9.42 -- flat beyond 25
+    // up to where the poison happens to sit in its chunk, and the order is a guess made at the end of the previous chunk, so not too long: 25.
     // A batch of ONE instance has nobody to supply the exact zero the speculation counts on (tools/spec_rate.py: it fails in the first
     // iteration for 10-19 of 20 random instances) -- but its batch-global minima are its own: the HBM-resident kernel computes them
     // (sp.exact), nothing is speculated, recorded or replayed, and the whole loop is one launch (a team of workgroups when the instance is big).
     // (the same holds for the R identical replicas of one instance: every replica's own minimum is the batch's)
     const bool exact = (B == 1 || (p->B0 == 1 && a->replicas_identical)) && !a->isolate_instances && getenv("PDP_SOLVE_NO_EXACT") == nullptr &&
                        !p->exchange;                       // (a part of one instance is not a batch of one)
-    int C = 20;
+    int C = 25;
     if (const char *env = getenv("PDP_SOLVE_CHUNK")) { const int v = atoi(env); if (v > 0) C = v; }
     if (C > T) C = T;
     { int st_ = resident_prepare(p); if (st_ != PDP_OK) return st_; }

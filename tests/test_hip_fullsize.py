@@ -180,13 +180,16 @@ def test_clause_counts_rederived_and_deterministic(big):
 
 def test_poison_adopted_by_later_workgroups_changes_the_replay_not_the_results(big, monkeypatch):
     """A workgroup of pass 1 that starts after another one has recorded the batch's first NaN sweep runs poisoned from there on and needs no
-    replay.  How many do depends on the dispatch order -- the results must not: the batch (poisoned at sweep 81, met two thirds
-    into that chunk's launch) ends in the same bits with the look switched off, and with short chunks that move the poison inside its launch."""
+    replay, and pass 1 dispatches the instances closest to a NaN first so that this happens early.  How many workgroups adopt depends
+    on the dispatch order -- the results must not: the batch (poisoned at sweep 81) ends in the same bits with the look switched off, in block
+    order, and with other chunk lengths that move the poison inside its launch."""
     items, host, tb = big
     runs = []
-    for adopt, chunk in ((True, None), (False, None), (True, '7'), (False, '7')):
+    for adopt, chunk, risk in ((True, None, True), (False, None, True), (True, '7', True), (False, '7', False), (True, None, False), (True, '40', True)):
         if adopt: monkeypatch.delenv('PDP_SOLVE_NO_ADOPT', raising=False)
         else: monkeypatch.setenv('PDP_SOLVE_NO_ADOPT', '1')
+        if risk: monkeypatch.delenv('PDP_SOLVE_NO_RISK_ORDER', raising=False)       # pass 1 in the order of k_order_by_risk / in block order
+        else: monkeypatch.setenv('PDP_SOLVE_NO_RISK_ORDER', '1')
         if chunk: monkeypatch.setenv('PDP_SOLVE_CHUNK', chunk)
         else: monkeypatch.delenv('PDP_SOLVE_CHUNK', raising=False)
         hp, q, fs, am, iters, lds = _solve(tb, T)
