@@ -2110,6 +2110,8 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
         if (finishing) { sp.amask[gb] = (uint8_t)active; sp.counters[gb] = cnt; pv_.is_sat[gb] = s_cold.is_sat; }
         // left inactive with iterations still to come: k_ghost_check looks at its frozen state after the call (see d_ghost_bad)
         if (finishing && !active && !(sp.final_chunk && iters >= T)) sp.ghost_flag[gb] = 1;
+        else if (REPLAY) sp.ghost_flag[gb] = 0;           // what pass 1 did with this instance behind the poison is void, its flag with it (a stale one
+                                                          // sends k_ghost_check over an instance that never froze: a spurious fail-over, seen with long chunks)
         if (any_inactive) atomicMin(&ctl->perm_zero, (uint32_t)iters);
         if (!REPLAY) sp.last_event[gb] = last_event;
         if (sp.risk) sp.risk[gb] = finishing ? 0xffffffffu : s_risk;
