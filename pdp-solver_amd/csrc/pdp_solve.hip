@@ -93,6 +93,7 @@ struct SolveParams {
     int isolate;                // isolated instances (a NaN stays inside its instance, pass 1 is final)
     uint32_t *risk;             // [B] LDS-resident pass 1: bits of the smallest q normalisation of the launch's last sweep (see k_order_by_risk); NULL: off
     int no_scorer_reuse;        // PDP_SOLVE_NO_SCORER_REUSE=1: the decimation's scorer always takes its own logs (A/B switch)
+    int no_event_look;          // PDP_SOLVE_NO_EVENT_LOOK=1: pass-1 workgroups look for a recorded NaN sweep only when they start
     int adopt_poison;           // LDS-resident pass 1: take a first-NaN sweep other workgroups of the launch already recorded (PDP_SOLVE_NO_ADOPT=1: off)
     int lds_tickets;            // LDS-resident kernel, pass 1: 0 = instance blockIdx.x, else the number of instances the workgroups draw tickets for
     uint8_t *ghost_flag;        // LDS-resident kernel: [B] instances that left inactive with iterations to come (checked by k_ghost_check after the call)
@@ -1867,7 +1868,7 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
         if (lane == 0 && bits) atomicOr(&s_flag_or[t & 1], bits);
         __syncthreads();
         bits = UNI(s_flag_or[t & 1]);                        // workgroup-uniform: keep the control flow scalar
-        const bool poisoned = t >= UNI(s_poison);
+        bool poisoned = t >= UNI(s_poison);
         // ---- P5b (rare): exact smooth max of the marked variables (util.py:282-286 + :267-275 with the global min at 0)
         if ((bits & 64) || ((bits & 32) && !(bits & 16))) {
             PROF_COUNT(9);
@@ -1925,6 +1926,13 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
         if (nan_seen && !poisoned) {
             if (tid == 0) atomicMin(&ctl->nan_iter, (uint32_t)t);
             if (poison_from != 0x7fffffff) violation = 1;
+        }
+        // An event is about to happen (the only thing the poison would change): look once more whether the batch is poisoned by now -- a workgroup
+        // of the first round started together with the one that meets the NaN, and its events come later in the chunk.  Cold: one sweep in fifteen.
+        if (adopt && !poisoned && !sp.no_event_look && ((has_prev && (below_tol || cnt >= t_max)) || (!RF && g <= 1e-10f))) {
+            if (tid == 0) { const uint32_t seen = __hip_atomic_load(&ctl->nan_iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (seen < (uint32_t)s_poison) s_poison = (int)seen; }
+            __syncthreads();
+            poisoned = t >= UNI(s_poison);
         }
         int conv = 0;
         int rf_changed = 0;
@@ -2618,6 +2626,7 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     sp.rf = rf ? 1 : 0; sp.isolate = a->isolate_instances ? 1 : 0;
     sp.adopt_poison = getenv("PDP_SOLVE_NO_ADOPT") ? 0 : 1;
     sp.no_scorer_reuse = getenv("PDP_SOLVE_NO_SCORER_REUSE") ? 1 : 0;
+    sp.no_event_look = getenv("PDP_SOLVE_NO_EVENT_LOOK") ? 1 : 0;
     float *frc_buf[2] = {nullptr, nullptr};
     if (rf) {
         frc_buf[0] = (float *)(((uintptr_t)(replay_list + B) + 15) & ~(uintptr_t)15); frc_buf[1] = frc_buf[0] + E + 4;

@@ -43,27 +43,34 @@ def _solve(tb, T_, tol=0.02, t_max=100):
     return hp, q, fs, am, iters, lds
 
 
-def test_timed_workload_equals_the_oracle_on_the_whole_batch(big, oracle):
+def test_timed_workload_equals_the_oracle_on_the_whole_batch(big, oracle, monkeypatch):
     """bench.py's rank-0 batch (B=5000, n=200, m=840, T=100, tolerance 0.02, t_max 100) through pdp_sp_solve -- the call the headline number
-    times: chunked launches, NaN poison at sweep 81, device-side replay of the affected instances -- against the oracle's forward
-    (reference loop solver.py:355-386 with its batch-wide couplings) on the WHOLE batch in one process.  Everything bit for bit: messages,
-    active flags, solution, per-instance mask, executed sweeps; then the random fill with the same Philox key and the final prediction."""
+    times: chunked launches, NaN poison at sweep 81, the poison adopted by the workgroups that can and the device-side replay of the others --
+    against the oracle's forward (reference loop solver.py:355-386 with its batch-wide couplings) on the WHOLE batch in one process.
+    Everything bit for bit: messages, active flags, solution, per-instance mask, executed sweeps; then the random fill with the same Philox key
+    and the final prediction.  Twice: as shipped (few or no instances left to replay) and with the looks for a recorded NaN switched off
+    (round 4's form: half of the batch is replayed)."""
     items, host, tb = big
     op = oracle.Problem(host['graph_map'], host['batch_variable_map'], host['batch_function_map'], host['edge_feature'])
     res = op.forward('p-d-p', T, local_search_iterations=0, tolerance=0.02, t_max=100, seed=3, trace='mask')
     av, af, sol, _ = op.state()                                        # after the loop and the random fill (key 3)
-    hp, q, fs, am, iters, lds = _solve(tb, T)
-    assert lds and iters == res['iterations_run'] == T
-    stats = hp.last_solve_stats
-    assert stats['replays'] > 0 and stats['hbm_instances'] == 0, stats  # the poison replay ran, every instance on the LDS-resident kernel
     assert np.isnan(res['fs']).any()
-    np.testing.assert_array_equal(npy(q), res['q'])
-    np.testing.assert_array_equal(npy(fs), res['fs'])
-    np.testing.assert_array_equal(npy(am), res['trace_active_mask'][T - 1])
-    np.testing.assert_array_equal(npy(hp.active_variables).reshape(-1), av)
-    np.testing.assert_array_equal(npy(hp.active_functions).reshape(-1), af)
     fixed = av == 0                                                     # decimated / simplified variables: their value is the loop's result
-    np.testing.assert_array_equal(npy(hp.solution).reshape(-1)[fixed], sol[fixed])
+    for looks in (False, True):
+        for name in ('PDP_SOLVE_NO_ADOPT', 'PDP_SOLVE_NO_RISK_ORDER', 'PDP_SOLVE_NO_EVENT_LOOK'):
+            if looks: monkeypatch.delenv(name, raising=False)
+            else: monkeypatch.setenv(name, '1')
+        hp, q, fs, am, iters, lds = _solve(tb, T)
+        assert lds and iters == res['iterations_run'] == T
+        stats = hp.last_solve_stats
+        assert stats['hbm_instances'] == 0, stats                       # every instance on the LDS-resident kernel
+        assert looks or stats['replays'] > 0, stats                     # without the looks the poison replay ran
+        np.testing.assert_array_equal(npy(q), res['q'])
+        np.testing.assert_array_equal(npy(fs), res['fs'])
+        np.testing.assert_array_equal(npy(am), res['trace_active_mask'][T - 1])
+        np.testing.assert_array_equal(npy(hp.active_variables).reshape(-1), av)
+        np.testing.assert_array_equal(npy(hp.active_functions).reshape(-1), af)
+        np.testing.assert_array_equal(npy(hp.solution).reshape(-1)[fixed], sol[fixed])
     hp.random_fill(seed=3)                                              # the final predictor call (pdp_predict.py:118-128), same Philox key
     out, _ = hp.local_search(hp.solution.clone(), 0, 0.5, seed=3)
     pred = hp.update_solution(out.reshape(-1).contiguous())
@@ -190,6 +197,8 @@ def test_poison_adopted_by_later_workgroups_changes_the_replay_not_the_results(b
         else: monkeypatch.setenv('PDP_SOLVE_NO_ADOPT', '1')
         if risk: monkeypatch.delenv('PDP_SOLVE_NO_RISK_ORDER', raising=False)       # pass 1 in the order of k_order_by_risk / in block order
         else: monkeypatch.setenv('PDP_SOLVE_NO_RISK_ORDER', '1')
+        if chunk == '7': monkeypatch.setenv('PDP_SOLVE_NO_EVENT_LOOK', '1')          # (the look in front of an event off in two of the runs)
+        else: monkeypatch.delenv('PDP_SOLVE_NO_EVENT_LOOK', raising=False)
         if chunk: monkeypatch.setenv('PDP_SOLVE_CHUNK', chunk)
         else: monkeypatch.delenv('PDP_SOLVE_CHUNK', raising=False)
         hp, q, fs, am, iters, lds = _solve(tb, T)

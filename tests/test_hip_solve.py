@@ -561,13 +561,14 @@ def test_wide_teams_across_xcds(oracle, monkeypatch, n_big, threads):
     np.testing.assert_array_equal(npy(fs), res['fs'])
 
 
-def test_mixed_batch_routing_under_nan_poison(oracle):
+def test_mixed_batch_routing_under_nan_poison(oracle, monkeypatch):
     """The NaN-poisoned batch of test_persistent_solve_reproduces_nan_poisoning with a 21 000-edge instance added: the big instance runs on
     the HBM-resident kernel, is saved at chunk entry and replayed from there once some (small) instance poisons the batch; the small
     instances are replayed selectively as before.  Everything equals the oracle's strict semantics bit for bit -- with decimations of the
     big instance before the poison and none after it."""
     from pdp.factorgraph import dataset
     from helpers import random_batch as rb
+    monkeypatch.setenv('PDP_SOLVE_NO_ADOPT', '1')          # every instance with an event behind the poison is replayed (the replay is what this test is about)
     small = rb(batch=400, n=60, k=3, seed=7000)
     # rebuild the same small instances as loader items and append the big one
     from pdp import generator
