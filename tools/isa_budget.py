@@ -31,7 +31,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "pdp-solver_amd", "csrc", "pdp_solve.hip")
-HEADLINE = "_Z14k_sp_solve_ldsILb0ELb0ELb0ELb0EEv5PView11SolveParams"
+HEADLINE = "_Z14k_sp_solve_ldsILb0ELb0ELb0ELb1EEv5PView11SolveParams"      # <false, false, false, true>: pass 1 through the dispatch list (round 5)
 
 FP = re.compile(r"^v_(pk_)?(add|sub|subrev|mul|fma|fmac|mac|mad)_(f32|legacy_f32)")
 XL = re.compile(r"^v_(readlane|writelane|readfirstlane|permlane|mov_b32_dpp|bpermute)|dpp|row_|quad_perm")
