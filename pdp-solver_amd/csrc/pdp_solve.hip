@@ -923,6 +923,15 @@ __device__ __forceinline__ f4v log4_fin(f4v x, float eps)
     return vfma((f4v)(0.0f), x, r);          // a NaN whose sign bit is set went to eps in the integer maximum: re-injected
 }
 __device__ __forceinline__ f4v exp4_sum(f4v x) { return exp4_fin_le30(x); }
+__device__ __forceinline__ float exp1_sum(float x)          // one element of exp4_fin_le30 as a scalar chain
+{
+    const float t = x * 1.44269502162933349609375f;
+    const float n = __builtin_rintf(t);
+    float lo = __builtin_fmaf(x, 1.44269502162933349609375f, -t);
+    lo = __builtin_fmaf(x, 1.92596299112661746e-8f, lo);
+    const float f = (t - n) + lo;
+    return __builtin_ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+}
 __device__ __forceinline__ f2v log2_fin(f2v x, float eps)
 {
     const f2v xm = __builtin_bit_cast(f2v, __builtin_elementwise_max(__builtin_bit_cast(i2v, x), __builtin_bit_cast(i2v, (f2v)(eps))));
@@ -982,6 +991,25 @@ __device__ __forceinline__ f4v exp4_sum(f4v xc)
     f4v res;
     res.x = __builtin_ldexpf(p.x, n.x); res.y = __builtin_ldexpf(p.y, n.y); res.z = __builtin_ldexpf(p.z, n.z); res.w = __builtin_ldexpf(p.w, n.w);
     return res;
+}
+
+// one exp of exp4_sum as a scalar chain (the same operations)
+__device__ __forceinline__ float exp1_sum(float xc)
+{
+    const float t = xc * 1.44269504088896341f;
+    const float nf = (t + 12582912.0f) - 12582912.0f;
+    float r = __builtin_fmaf(nf, -0.693359375f, xc);
+    r = __builtin_fmaf(nf, 2.12194440e-4f, r);
+    const float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    p = __builtin_fmaf(p, z, r);
+    p = p + 1.0f;
+    return __builtin_ldexpf(p, (int)nf);
 }
 
 __device__ __forceinline__ f4v log4_fin(f4v x, float eps)
@@ -1731,7 +1759,14 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
             if constexpr (FORCE) same = same + ((force == s) ? L1 : L0);
             float opp = neg_lit ? pos : neg;
             if constexpr (FORCE) opp = opp + ((force == -s) ? L1 : L0);
+#ifndef PDP_E2_PACKED_EXPS
+            // (four scalar chains: a packed fp32 instruction holds the SIMD as long as two plain ones and waits a state behind the packed step it
+            //  depends on, so the 4-vector form buys nothing here -- measured in round 5: -2.3 % on the launch, the logs likewise -1.8 %)
+            const float so = same + opp;
+            const f4v ex = {exp1_sum(agg), exp1_sum(so), exp1_sum(same), exp1_sum(opp)};
+#else
             const f4v ex = exp4_sum((f4v){agg, same + opp, same, opp});
+#endif
             // mask * new + (1 - mask) * old with mask == 1: (+0) * old + new as ONE fused operation -- the product is an exact zero (or NaN),
             // so fusing rounds nothing differently; the unfused form is a multiply and an add per slot
             const float eta_new = __builtin_fmaf(1.0f - 1.0f, eta_old, ex.x);
@@ -1744,8 +1779,16 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
             return SlotNew{qu_new, eta_new, eta_old, total, cw};
         };
         auto slot_logs = [&](int p, const SlotNew &r) __attribute__((always_inline)) {
+#ifndef PDP_E2_PACKED_LOGS
+            // (the two logs as scalar chains: the survey's log runs beside the division it does not depend on, and neither waits a state between
+            //  dependent packed steps -- measured in round 5 against the 2-vector form: -1.8 % on the launch)
+            const float em = bit15_to_float((uint16_t)(r.cw | log_em_or));
+            Y[p] = pdp_safe_log_fin(1.0f - r.eta, PDP_SP_EPS) * em;      // (needs the survey only: runs beside the division)
+            X[p] = pdp_safe_log_fin(r.qu, PDP_SP_EPS) * em;
+#else
             const f2v lg = log2_fin((f2v){r.qu, 1.0f - r.eta}, PDP_SP_EPS) * bit15_to_float((uint16_t)(r.cw | log_em_or));
             X[p] = lg.x; Y[p] = lg.y;
+#endif
         };
         if (PROF_SKIP(4)) { }
         else if (fuse_logs) {
