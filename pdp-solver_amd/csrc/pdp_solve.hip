@@ -2083,6 +2083,7 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
                 if (lane == 63 && cs) atomicAdd(&s_sat_count, cs);
                 PROF_COUNT(16);
             }
+            PROF_MARK(18);                                   // P8: the count itself (its barrier is in mark 15)
             if (refresh || recount) __syncthreads();
             if (recount) nsat = UNI(s_sat_count);            // (thread 0 clears the word behind the next sweep's R1 barrier)
             if (sp.check_termination && active && nsat == m) active = 0;
