@@ -1611,9 +1611,10 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
                 if (((c >> 1) ^ c) & PC_EM_USED) pcc[p] = (uint16_t)((c & ~PC_EM_USED) | ((c & PC_EM) ? PC_EM_USED : 0));
             }
             __syncthreads();
+            PROF_MARK(19);                                   // the mask pass behind a refresh
         }
         last_use_em = use_em; em_dirty = 0; mask_fix = 0;
-        PROF_MARK(1);                                        // E1
+        PROF_MARK(1);                                        // E1 (where it runs) + the top of the loop
         // ---- R1: per-clause sums (through e2p) and per-variable sums (contiguous), ascending edge id ------------
         {
             const uint16_t *const e2p = L.e2p, *const f_ptr = L.f_ptr, *const v_ptr = L.v_ptr;

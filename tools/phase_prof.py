@@ -26,7 +26,7 @@ for rep in range(2):
     t1.record(); torch.cuda.synchronize()
     wall_ms = t0.elapsed_time(t1)
     L.pdp_debug_phase_cycles(out, 0)
-names = {0: 'load', 1: 'E1 logs', 2: 'R1 row sums', 3: 'E2 exps/div', 4: 'P4 smooth max', 5: 'P5 reduce', 24: 'gate + bookkeeping', 6: 'P6 decimate', 25: 'P7 mask refresh', 29: 'P8 clause count (the count)', 26: 'P8 clause count (its barrier)', 8: 'write back'}
+names = {0: 'load', 1: 'E1 logs', 2: 'R1 row sums', 3: 'E2 exps/div', 4: 'P4 smooth max', 5: 'P5 reduce', 24: 'gate + bookkeeping', 6: 'P6 decimate', 25: 'P7 mask refresh', 30: 'mask pass behind a refresh', 29: 'P8 clause count (the count)', 26: 'P8 clause count (its barrier)', 8: 'write back'}
 tot = sum(out[i] for i in names)
 for i, nm in names.items():
     print("%-16s %14d cycles  %5.1f%%" % (nm, out[i], 100.0 * out[i] / tot))
