@@ -1585,6 +1585,7 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
                 const int p0 = k * 2 * nt + tid, p1 = p0 + (tail ? half : nt);
                 const bool has1 = p1 < ne;
                 const int q1 = has1 ? p1 : p0;
+                // (as four scalar chains, like E2's: +0.4 % on the launch -- two slots' logs have the packed form's parallelism anyway)
                 const f4v lg = log4_fin((f4v){QU[p0], QU[q1], 1.0f - Eold[p0], 1.0f - Eold[q1]}, PDP_SP_EPS);
                 float x0 = lg.x, x1 = lg.y, y0 = lg.z, y1 = lg.w;
                 if (use_em) {
