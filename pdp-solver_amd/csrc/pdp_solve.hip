@@ -1732,10 +1732,12 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
         // the q_u array does: nothing reads q_u itself while the logs are in place (the sticky NaN of `mask * new + (1 - mask) * old` comes
         // from X = log(old q_u) * mask, which is NaN exactly when the old q_u is -- log(max(x, eps)) is finite for every finite x -- and the
         // exit path forms q_u from the same sums as its two other columns).  Not in the last sweep of a launch (the record that goes to the
-        // next launch holds q_u), not in a call's first sweep, and not for Reinforce (its step uses X / Y as scratch, so every sweep needs
-        // q_u for its logs).  A sweep of the plain form stores q_u and hands |delta eta| over in Y as rounds 1-4 did.
+        // next launch holds q_u), not in a call's first sweep, and not in a Reinforce sweep that renews the force (that step uses X / Y as scratch,
+        // so the sweep behind it needs q_u for its logs).  A sweep of the plain form stores q_u and hands |delta eta| over in Y as rounds 1-4 did.
         // The two forms of the loop are separate loops: nothing to branch on per trip.
-        const bool fuse_logs = !RF && (t + 1 < T) && has_prev && !prev_from_global;
+        // (Reinforce: in the sweeps whose coin renews no force -- the coins of a call are drawn up front -- nothing uses X / Y as scratch either)
+        const bool rf_step_now = RF && ((sp.coins[sp.chunk_start + t] < sp.dprob) || nsat < 0);
+        const bool fuse_logs = !rf_step_now && (t + 1 < T) && has_prev && !prev_from_global;
         float nan_acc = 0.0f;
         const uint32_t log_em_or = use_em ? 0u : PC_EM;      // without an edge mask every slot counts
         // one slot's update: reads the slot's words, the three row sums and its own logs, stores the new survey and returns the new values
