@@ -13,11 +13,10 @@ launcher: it starts N ranks (one per GPU) through `python -m torch.distributed.r
 JSON line rank 0 prints, and exits non-zero if any rank fails.  Under torch.distributed.run (what the driver uses for N > 1) it is a
 rank and WORLD_SIZE must equal --gpus.  Rank 0 prints ONE JSON line.
 
-At N = 1 the line also carries, outside the headline's timed loop: `cpu_baseline` (the C oracle over all host cores at the full batch;
-`cpu_baseline_torch_sparse`: the PyTorch-CPU restatement of the reference's sparse-mm formulation) and `config.secondary`
-(configs[2]'s neural kernels with per-kernel rooflines, Walk-SAT, the Reinforce solver).  The nested objects do not survive the driver's
-record (it keeps the scalars of `config` and the last 8 KB of stdout): `benchlib.secondary.driver_summary` repeats every BASELINE config's
-figures as flat scalars in `config` and, as `summary`, at the end of the line.  Helpers: tools/benchlib/."""
+Output (benchlib/line.py): the LAST line of stdout is the record -- the contract's top-level keys, `config` of <= 25 scalars, flat `roofline`
+and `cpu_baseline`, strict JSON, < 4 KB.  At N = 1 everything else measured outside the timed loop (`cpu_baseline_torch_sparse`, configs[2]'s
+kernels with per-kernel rooflines, the configs[3] / configs[4] shards, Walk-SAT, Reinforce, training, solved fractions) is printed BEFORE it as
+short `{"detail": name, "data": ...}` lines and written unrounded to gpurun_out/bench_detail.json.  Helpers: tools/benchlib/."""
 
 import argparse
 import json
@@ -34,6 +33,7 @@ sys.path.insert(0, os.path.join(REPO, 'tools'))
 from benchlib import HBM_PEAK_GBS, N_SIMD, CLOCK_HZ, algorithmic_bytes_per_iteration, grouped       # noqa: E402
 from benchlib.cpu_baselines import cpu_baseline_all_cores, cpu_baseline_torch_sparse                  # noqa: E402
 from benchlib.neural import bench_neural                                                              # noqa: E402
+from benchlib.line import emit                                                                        # noqa: E402
 from benchlib.secondary import (fast_build_measurement, secondary_measurements, config_shard_measurements, big_instance_measurements,   # noqa: E402
                                 solved_fractions, driver_summary)
 
@@ -315,9 +315,8 @@ def main():
                 config['fast_build'] = fast_build_measurement(args, dev, native, host_batch, items, n_solved / n_inst)
             except Exception as ex:
                 config['fast_build'] = dict(error=repr(ex))
-        summary = driver_summary(config)                # flat scalars of every BASELINE config: what the driver's record keeps
-        config.update(summary)
-        line = {
+        summary = driver_summary(config)                # flat scalars of every BASELINE config (detail line "summary"; ten of them in the final line)
+        full = {
             'metric': 'pdp_iterations_per_sec', 'value': value,
             'unit': 'iterations/s (each iteration sweeps a batch of %d instances)' % args.batch,
             'n_gpus': world, 'rccl_ranks': ranks, 'collective_backend': (backend if grouped() else None), 'steps': args.steps, 'warmup': args.warmup,
@@ -331,11 +330,9 @@ def main():
                                  'so the kernel is bound by VALU issue, not by HBM (DESIGN.md section 4); traffic / valu_issue come from the '
                                  'committed PMC summary named in their source fields, not from this run'},
             'cpu_baseline': cpu, 'cpu_baseline_torch_sparse': cpu_ts,
-            'summary': dict(summary, headline_it_per_s=value, headline_ms_per_step=1e3 * elapsed / args.steps, headline_kernel_ms_per_launch=launch_ms,
-                            headline_frac_hbm_model=achieved / HBM_PEAK_GBS,
-                            headline_valu_issue_frac_at_2_cycles=(valu or {}).get('issue_frac_at_2_cycles')),      # last: inside the tail of stdout
+            'summary': summary,
         }
-        print(json.dumps(line))
+        emit(full, side_file=(world == 1))              # short {"detail": ...} lines, then the compact record as the LAST line of stdout
     if grouped():
         import torch.distributed as dist
         dist.destroy_process_group()

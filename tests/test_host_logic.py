@@ -419,3 +419,56 @@ def test_training_loader_follows_torch_dataloader_draws(tmp_path):
     g3 = cnf_generators.UniformCNFGenerator(6, 12, 2, 4, 2.0, 4.0)
     data = next(iter(FactorGraphDataset.get_loader('', limit=10 ** 9, hidden_dim=3, batch_size=1, shuffle=False, generator=g3, epoch_size=1)))
     assert data[0][0].shape[1] == np.asarray(first[2]).shape[1] and int(data[1][0].numel()) == int(first[0])
+
+
+def _bench_line_module():
+    import sys
+    tools = os.path.join(REPO, 'tools')
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    from benchlib import line
+    return line
+
+
+def test_bench_final_line_is_compact_strict_json():
+    """bench.py's record (tools/benchlib/line.py) built from a canned measurement (tests/golden/bench_measurement.json: a full measurement dict of
+    an earlier run): the LAST stdout line holds exactly the contract's keys, is strict JSON (no NaN / Infinity), nests at most two objects deep,
+    keeps `config` to <= 25 scalars and stays under 4 KB; every earlier line is a short {"detail": ...} object without the word "metric"."""
+    import io
+    line = _bench_line_module()
+    full = json.load(open(os.path.join(REPO, 'tests', 'golden', 'bench_measurement.json')))
+    full['config']['secondary']['neural']['ms_per_iteration_mean'] = float('nan')        # a non-finite figure must not reach the output
+    full['roofline']['traffic'] = float('inf')
+    buf = io.StringIO()
+    last = line.emit(full, out=buf, side_file=False)
+    lines = buf.getvalue().split('\n')
+    assert lines[-1] == '' and lines[-2] == last
+
+    def strict(s):
+        def bad(c):
+            raise ValueError(c)
+        return json.loads(s, parse_constant=bad)
+    rec = strict(last)
+    assert len(last.encode()) < 4096
+    assert tuple(rec.keys()) == ('metric', 'value', 'unit', 'n_gpus', 'rccl_ranks', 'collective_backend', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+                                 'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline')
+    for k in ('config', 'roofline', 'cpu_baseline'):
+        assert isinstance(rec[k], dict) and all(not isinstance(v, (dict, list)) for v in rec[k].values()), k
+    assert len(rec['config']) <= 25 and rec['config']['workload'].startswith('configs[1]') and rec['config']['E'] == 12600000
+    assert tuple(rec['roofline'].keys()) == ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source', 'valu_issue_frac', 'kernel')
+    assert rec['roofline']['traffic'] is None and abs(rec['roofline']['frac'] - rec['roofline']['achieved'] / rec['roofline']['peak']) < 1e-5
+    assert set(rec['cpu_baseline'].keys()) == {'value', 'unit', 'cores', 'kind', 'cpu_model', 'sample', 'torch_sparse_value', 'torch_sparse_cores'}
+    assert abs(rec['value'] - full['value']) < 1e-5 * full['value'] and rec['steps'] == 20 and rec['vs_baseline'] is None
+    assert rec['config']['configs2_frac_mfma_f32'] > 0 and rec['config']['solved_T1000_w1000'] == '100/5000'
+    details = lines[:-2]
+    assert details, 'the per-kernel measurements go to detail lines'
+    for l in details:
+        d = strict(l)
+        assert list(d.keys()) == ['detail', 'data'] and '"metric"' not in l and len(l) < 4096
+    names = [strict(l)['detail'] for l in details]
+    assert names[-1] == 'summary' and any(n.startswith('config.secondary.neural') for n in names) and 'cpu_baseline_torch_sparse' in ' '.join(names)
+    # N > 1 / --no-secondary: no nested measurements, no CPU baseline
+    slim = dict(full, cpu_baseline=None, cpu_baseline_torch_sparse=None, summary={})
+    slim['config'] = {k: v for k, v in full['config'].items() if not isinstance(v, dict)}
+    rec2 = strict(line.emit(slim, out=io.StringIO(), side_file=False))
+    assert rec2['cpu_baseline'] is None and 'configs2_it_per_s' not in rec2['config']

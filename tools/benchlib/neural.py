@@ -253,9 +253,10 @@ def bench_neural(args, dev, rank, world):
         cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline_neural(args)
         flops_iter = neural_flop_per_iteration('np-nd-np', args.hidden, E, V)
         achieved = flops_iter * float(np.mean(iters_done)) / (float(np.mean(step_ms)) * 1e-3) / 1e12
-        print(json.dumps({
+        kernels = neural_kernel_rooflines(native, timing, E, V, args.hidden)
+        line = {
             'metric': 'pdp_iterations_per_sec', 'value': value,
-            'unit': 'iterations/s (each iteration sweeps a batch of %d instances)' % args.batch, 'n_gpus': world, 'rccl_ranks': ranks, 'steps': args.steps,
+            'unit': 'iterations/s (each iteration sweeps a batch of %d instances)' % args.batch, 'n_gpus': world, 'rccl_ranks': ranks, 'collective_backend': None, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': "configs[2]: 'np-nd-np' hidden_dim=%d (100/100/50/50), random 3-SAT n=%d m=%d batch=%d T=%d per GPU, "
@@ -264,10 +265,23 @@ def bench_neural(args, dev, rank, world):
                        'instance_iterations_per_sec': value * args.batch, 'parallelism': 'instances sharded, dp%d' % world},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / MFMA_F32_PEAK_TFLOPS,
                          'traffic': None, 'kernel': ' / '.join(native.kernel_name(k) for k in ('gru', 'agg_pre', 'agg_post')) + ' (v_mfma_f32_32x32x2_f32)',
-                         'kernels': neural_kernel_rooflines(native, timing, E, V, args.hidden),
                          'note': 'achieved = neural_flop_per_iteration (573752 E + 48500 V at hidden 128) x iterations / step time (whole step, all kernels); '
                                  'kernels: HIP events of the library around every launch, flop = the MACs of that kernel x 2'},
-            'cpu_baseline': cpu}))
+            'cpu_baseline': cpu}
+        # per-kernel rooflines first (short detail lines), the compact record last (benchlib/line.py)
+        from .line import _split, _clean, _num, _short
+        details = []
+        _split('roofline.kernels', _clean(kernels, 5), details)
+        _split('roofline.note', line['roofline'].pop('note'), details)
+        for l in details:
+            print(l)
+        line['config'] = {k: _num(v) for k, v in line['config'].items()}
+        line['roofline'] = {k: _num(v) for k, v in line['roofline'].items()}
+        for k in ('value', 'ms_per_step'):
+            line[k] = _num(line[k])
+        if cpu is not None:
+            line['cpu_baseline'] = {k: (_short(v, 200) if isinstance(v, str) else _num(v)) for k, v in cpu.items()}
+        print(json.dumps(line, allow_nan=False))
     if grouped():
         import torch.distributed as dist
         dist.destroy_process_group()

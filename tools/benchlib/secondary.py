@@ -310,9 +310,8 @@ def solved_fractions(args, dev, b, native, rank):
 
 
 def driver_summary(config):
-    """Flat scalars of everything measured next to the headline: the driver's record keeps the scalars of `config` and the last 8 KB of
-    stdout, not nested objects, so every BASELINE config gets `<name>_<figure>` keys (iterations/s, ms per iteration, roofline fraction of
-    the parity build) here; bench.py puts them into `config` and, as `summary`, at the END of the line."""
+    """Flat scalars of everything measured next to the headline: every BASELINE config gets `<name>_<figure>` keys (iterations/s, ms per iteration, roofline fraction of
+    the parity build) here; bench.py prints them as the last detail line and copies ten of them into the final line's `config`."""
     out = {}
     sec = config.get('secondary') or {}
 
@@ -343,7 +342,9 @@ def driver_summary(config):
     fb = config.get('fast_build')
     if fb is not None:
         put('fast_build', fb, (('it_per_s', ('value',)), ('kernel_ms_per_launch', ('kernel_ms_per_launch',)), ('frac_hbm_model', ('roofline_frac',))))
-        put('fast_build_configs2', fb.get('neural') if isinstance(fb, dict) else None, neural_keys[:3])
+        # the fast build's neural kernels run bf16x3 products on the bf16 matrix pipe: never a fraction of the fp32 MFMA peak
+        put('fast_build_configs2', fb.get('neural') if isinstance(fb, dict) else None,
+            neural_keys[:2] + (('gru_frac_of_bf16_peak_over_3', ('kernels', 'gru', 'roofline_bf16x3', 'frac')), ('gru_frac_hbm_stream', ('kernels', 'gru', 'roofline_hbm', 'frac'))))
     for name, row in (config.get('solved') or {}).items():
         if isinstance(row, dict) and 'solved' in row:
             out['solved_' + name] = '%d/%d' % (row['solved'], row['instances'])
