@@ -1913,9 +1913,13 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
         //  wave has used it -- in the previous sweep -- and before the next sweep's P5)
         bits = wave_or_bits7(bits);
         if (lane == 0 && bits) atomicOr(&s_flag_or[t & 1], bits);
+        // s_poison is read BEFORE the barrier: its only writer inside the loop (thread 0 in the event look below) runs between this barrier and
+        // the one that closes the event look, so a read behind the barrier could see this sweep's store in one wave and not in another --
+        // `poisoned` must be workgroup-uniform (it guards barriers)
+        const int poison_known = UNI(s_poison);
         __syncthreads();
         bits = UNI(s_flag_or[t & 1]);                        // workgroup-uniform: keep the control flow scalar
-        bool poisoned = t >= UNI(s_poison);
+        bool poisoned = t >= poison_known;
         // ---- P5b (rare): exact smooth max of the marked variables (util.py:282-286 + :267-275 with the global min at 0)
         if ((bits & 64) || ((bits & 32) && !(bits & 16))) {
             PROF_COUNT(9);

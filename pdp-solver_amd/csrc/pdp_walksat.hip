@@ -930,7 +930,10 @@ extern "C" int pdp_local_search(pdp_problem *p, const float *pred, int iteration
         if (rc != PDP_OK) return rc;
         if (done) return PDP_OK;
     }
-    if (p->exchange) {        // (not reached: the persistent search of a coupled forward either finishes or reports; the strict loop has no exchange)
+    // iterations <= 0 (satyr -w 0): the persistent search declines and the loop below is init / edge mask / copy-out -- no batch-global
+    // reduction, so every part of a coupled forward runs it on its own.  With steps to do, the persistent search of a coupled forward
+    // either finished or reported above; the strict loop has no exchange.
+    if (p->exchange && iterations > 0) {
         pdp_set_error("coupled multi-process forward: the strict Walk-SAT loop is single-process");
         return PDP_ERR_SPECULATION;
     }

@@ -161,6 +161,12 @@ def test_split_forward_keeps_the_couplings_across_ranks(tmp_path):
         for r in range(ranks):
             assert ('rank %d of %d solved 1 units (forward calls): [(0, 0, %d)]' % (r, ranks, r)) in log
         assert many == one
+    # -w 0: no local search.  The zero-step Walk-SAT call is init / copy-out on every part (no batch-global reduction): the split stays a split,
+    # nothing is reported as a failed speculation and solved again whole
+    w0 = [a for a in argv]; w0[w0.index('-w') + 1] = '0'
+    one_w0, _ = _run(w0, 1, str(tmp_path / 'one_w0.jsonl'), 0)
+    two_w0, log = _run(w0 + ['--split-forward'], 2, str(tmp_path / 'two_w0.jsonl'), 29771)
+    assert two_w0 == one_w0 and len(one_w0) == len(items) and 'solved whole' not in log and 'coupled forwards spread over the ranks' in log
     # dynamic segments: the batch limit cuts the loader batch into three forwards (10 + 10 + 8 instances, sorted by size), each spread over both ranks
     seg_argv = argv + ['-l', str(10 * 3 * max(it[2].shape[1] for it in items))]
     one_s, _ = _run(seg_argv, 1, str(tmp_path / 'one_s.jsonl'), 0)
