@@ -59,6 +59,36 @@ def neural_step(tr, model, b, T, replication=1):
     return model.last_run['iterations']
 
 
+_NEURAL_PMC = None
+
+
+def issue_bound(key, kernel_name, ms_per_launch, units):
+    """What bounds an fp32-MFMA kernel on gfx950: v_mfma_f32_32x32x2_f32 occupies the SIMD's VALU issue for its 64 cycles -- an MFMA wave beside
+    a VALU wave on one SIMD takes the SUM of their times (profiles/r06_mfma_valu_overlap.txt: overlap 0.05; the bf16 MFMA overlaps 0.85) --
+    so a launch cannot be shorter than (matrix-pipe busy cycles + 2 cycles x the other VALU wave-instructions) / 1024 SIMDs / 2.4 GHz.
+    Instruction counts: the newest committed rocprofv3 PMC summary (profiles/*_neural_pmc.json; per launch at its size, scaled by this
+    launch's edges / variables), not this run; `frac` = that floor / this run's launch time."""
+    global _NEURAL_PMC
+    if _NEURAL_PMC is None:
+        _NEURAL_PMC = {}
+        try:
+            d = os.path.join(REPO, 'profiles')
+            f = sorted(x for x in os.listdir(d) if x.endswith('_neural_pmc.json'))[-1]
+            _NEURAL_PMC = json.load(open(os.path.join(d, f)))
+            _NEURAL_PMC['file'] = 'profiles/' + f
+        except (OSError, IndexError, ValueError):
+            pass
+    k = (_NEURAL_PMC.get('kernels') or {}).get(key)
+    if not k or not kernel_name or not str(kernel_name).startswith(k['kernel'].split('<')[0] + '<') or ms_per_launch <= 0:
+        return None
+    scale = float(units) / float(_NEURAL_PMC['variables' if k['unit'] == 'variables' else 'edges'])
+    mfma_cycles = k['SQ_VALU_MFMA_BUSY_CYCLES'] * scale
+    valu = (k['SQ_INSTS_VALU'] - k['SQ_INSTS_MFMA']) * scale
+    floor_ms = 1e3 * (mfma_cycles + 2.0 * valu) / (N_SIMD * CLOCK_HZ)
+    return dict(floor_ms=floor_ms, frac=floor_ms / ms_per_launch, mfma_share_of_floor=mfma_cycles / (mfma_cycles + 2.0 * valu),
+                wait_share=k.get('SQ_WAIT_ANY_over_SQ_WAVE_CYCLES'), source=_NEURAL_PMC['file'])
+
+
 def neural_kernel_rooflines(native, timing, E, V, H, model_type='np-nd-np'):
     """per-kernel lines from the library's HIP events: ms per launch, algorithmic flop per launch, TFLOP/s, fraction of the fp32 MFMA peak.
     E / V: edges / variables one launch covers (summed over launches when segments differ: pass the launch-weighted means).  The kernel
@@ -78,6 +108,9 @@ def neural_kernel_rooflines(native, timing, E, V, H, model_type='np-nd-np'):
             flop = fl[key] * (V if key == 'predict_head' else E)
             tf = flop / (per * 1e-3) / 1e12
             row.update(flop_per_launch=flop, tflops=tf, frac_of_mfma_f32_peak=tf / MFMA_F32_PEAK_TFLOPS)
+        ib = issue_bound(key, row.get('kernel'), per, V if key == 'predict_head' else E)
+        if ib:
+            row['issue_bound'] = ib
         out[key] = row
     if 'agg_pre' in out and 'agg_post' in out:
         # one MessageAggregator call of the propagator = pre + row sum + post (the pre launches also serve the predictor: per launch figures)

@@ -338,7 +338,8 @@ def driver_summary(config):
     put('walksat_1000', sec.get('walksat'), (('flips_per_s', ('flips_per_sec',)), ('us_per_step', ('us_per_step',)), ('valu_issue_frac_at_2_cycles', ('valu_issue', 'issue_frac_at_2_cycles'))))
     put('reinforce', sec.get('reinforce'), (('it_per_s', ('iterations_per_sec',)), ('kernel_ms_per_launch', ('kernel_ms_per_launch',)), ('frac_hbm_model', ('roofline', 'frac'))))
     for name, kern in (('agg_pre', 'agg_pre'), ('agg_post', 'agg_post'), ('gru', 'gru'), ('predict_head', 'predict_head')):
-        put('configs2_kernel_' + name, ((sec.get('neural') or {}).get('kernels') or {}).get(kern), (('ms', ('ms_per_launch',)), ('frac_mfma_f32', ('frac_of_mfma_f32_peak',))))
+        put('configs2_kernel_' + name, ((sec.get('neural') or {}).get('kernels') or {}).get(kern),
+            (('ms', ('ms_per_launch',)), ('frac_mfma_f32', ('frac_of_mfma_f32_peak',)), ('frac_issue_bound', ('issue_bound', 'frac'))))
     fb = config.get('fast_build')
     if fb is not None:
         put('fast_build', fb, (('it_per_s', ('value',)), ('kernel_ms_per_launch', ('kernel_ms_per_launch',)), ('frac_hbm_model', ('roofline_frac',))))
