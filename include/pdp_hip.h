@@ -24,7 +24,7 @@ extern "C" {
 
 /* 2 (round 5): pdp_train_gru_backward's scratch contract and the training entry points added in round 4; a coupled multi-process forward
  * (pdp_problem_set_exchange) reports PDP_ERR_SPECULATION on EVERY part when one part cannot take the resident loops */
-#define PDP_ABI_VERSION 2
+#define PDP_ABI_VERSION 3
 
 enum {
     PDP_OK = 0,
@@ -116,6 +116,16 @@ int pdp_sat_loss(pdp_problem *p, const float *pred, float coeff, float eps, int 
 int pdp_update_solution(pdp_problem *p, const float *pred, float *out, void *stream);
 /* replaces: SatFactorGraphTrainer._check_recurrence_termination (trainer.py:150-162), replication aware */
 int pdp_check_termination(pdp_problem *p, uint8_t *active_mask, const float *pred, void *stream);
+/* replaces: the per-sweep host read that ends the plug-in loop, `if int(active_mask.sum()) <= 0: break` (solver.py:383-384), for callers that
+ * enqueue the sweeps of a forward without waiting for them (the neural triples: one captured HIP graph per sweep parity, pdp/nn/solver.py).
+ * pdp_loop_begin clears the loop's two device words; pdp_loop_step, enqueued behind a sweep's termination check, counts the sweep and raises
+ * the stop word when no instance of active_mask [B] is active any more (active_mask NULL: no termination check, it only counts); behind
+ * the stop word the operators that write message states under an active mask (pdp_neural_aggregate_edges, pdp_neural_gru,
+ * pdp_sp_propagate / _adapted) enqueue kernels that return at once, so sweeps already in flight change nothing; pdp_loop_read waits for
+ * the stream and returns the stop word and the executed sweeps (= the reference's iteration count), and with end != 0 clears both words. */
+int pdp_loop_begin(pdp_problem *p, void *stream);
+int pdp_loop_step(pdp_problem *p, const uint8_t *active_mask, void *stream);
+int pdp_loop_read(pdp_problem *p, int32_t *stopped_host, int32_t *iterations_host, int end, void *stream);
 
 /* ---- decimators --------------------------------------------------------------------------------------
  * replaces: SequentialDecimator state (_previous_function_state, _counters; pdp_decimate.py:115-125,179-183) */

@@ -79,6 +79,8 @@ enum {
     FL_WS_STEPS = 15,
     FL_PERM_ZERO = 16,   // first iteration from which an exited instance guarantees exact zeros
     FL_TEAM_TIMEOUT = 17,// sticky: a team barrier ran out of patience (the team's workgroups were not resident together); results are void
+    FL_LOOP_STOP = 18,   // device-driven step-wise loop (pdp_loop_*): every instance has left the loop -- the state-writing kernels of later sweeps return at once
+    FL_LOOP_ITERS = 19,  // ... sweeps executed before that
     FL_COUNT = 32
 };
 

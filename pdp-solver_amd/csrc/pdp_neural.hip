@@ -61,6 +61,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 // (the bits of a vector ELEMENT go through a by-value float: __builtin_bit_cast applied to `v.y` itself reads element 0 with this hipcc)
 __device__ __forceinline__ int f2i(float f) { return __builtin_bit_cast(int, f); }
+// the row mask of k_edge_active ends with the stop word of a device-driven loop (rowmask + E is the same address for a launch on a tail of the
+// rows: its mask pointer is advanced by what its row count is short of); workgroup-uniform
+__device__ __forceinline__ bool loop_stopped(const float *rowmask, int E)
+{
+    return rowmask && __builtin_amdgcn_readfirstlane((int)__builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(rowmask) + E)) != 0;
+}
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 // e^x after the clamp (xc = the clamped argument, x = the argument itself for the NaN / infinity rule of the scalar forms)
 __device__ __forceinline__ f32x2 pk_exp_clamped(f32x2 xc, f32x2 x)
@@ -412,6 +418,7 @@ __global__ void __launch_bounds__(NTN) k_agg_post(int E, const float *__restrict
                                                   const float *__restrict__ emask, const float *__restrict__ rowmask /*[E] or NULL*/,
                                                   const float *__restrict__ old, AggW w, float *__restrict__ out)
 {
+    if (loop_stopped(rowmask, E)) return;                  // a device-driven loop has ended: this sweep writes nothing (k_edge_active)
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int ld0 = w.Kp3 + 1, ld1 = w.Np3 + 1;
     float *Rt = sm, *G1 = sm + TM * ld0;
@@ -749,6 +756,7 @@ __global__ void __launch_bounds__(NTN, 6) k_agg_post_pf(int E, const float *__re
                                                         const float *__restrict__ emask, const float *__restrict__ rowmask,
                                                         const float *__restrict__ old, AggW w, float *__restrict__ out)
 {
+    if (loop_stopped(rowmask, E)) return;                  // a device-driven loop has ended: this sweep writes nothing (k_edge_active)
     static_assert(NB3 * 2 == NWAVES && NB4 * 2 >= NWAVES, "one 32x32 block per wave in the hidden layer, one or two in the output layer");
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int ld0 = 2 * S3 + 1, ld1 = 32 * NB3 + 1;
@@ -963,6 +971,7 @@ __global__ void __launch_bounds__(64 * PW_NW) k_agg_post_wave(int E, const float
                                                        const float *__restrict__ emask, const float *__restrict__ rowmask,
                                                        const float *__restrict__ old, AggW w, float *__restrict__ out, int ntiles /* full 32-edge tiles */)
 {
+    if (loop_stopped(rowmask, E)) return;                  // a device-driven loop has ended: this sweep writes nothing (k_edge_active)
     static_assert(2 * S3 <= 64, "one lane per input column");
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int ld0 = 2 * S3 + 1, ld1 = 32 * NB3 + 1, WR = WT * (ld0 + ld1) + WT;
@@ -1201,6 +1210,7 @@ __global__ void __launch_bounds__(NTN, 4) k_predict_rows_pf(int V, const float *
 __global__ void __launch_bounds__(NTN) k_gru(int E, const float *__restrict__ state, const float *__restrict__ sign,
                                              const float *__restrict__ hprev, const float *__restrict__ rowmask, GruW g, float *__restrict__ out, int ntiles)
 {
+    if (loop_stopped(rowmask, E)) return;                  // a device-driven loop has ended: this sweep writes nothing (k_edge_active)
     // Persistent over edge tiles: the rows of the next tile are fetched into registers (8 rows per wave, all loads in flight at once)
     // while the six MFMA chains of the current tile run, and dropped into LDS between the two barriers that separate tiles.
     // (Staging the weights through LDS in k-chunks shared by all waves was tried and is slower here: 37 vs 35 ms at config 3 --
@@ -1344,6 +1354,7 @@ __global__ void __launch_bounds__(NTN) k_gru_pipe(int E, const float *__restrict
                                                   const float *__restrict__ hprev, const float *__restrict__ rowmask, GruW g,
                                                   float *__restrict__ out, int ntiles /* full tiles only */, float *__restrict__ saved = nullptr)
 {
+    if (MASK && loop_stopped(rowmask, E)) return;          // a device-driven loop has ended: this sweep writes nothing (k_edge_active)
     constexpr int SH = 64, H = 128;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int ldx = 2 * SX + 1, ldh = 2 * SH + 1;
@@ -1516,6 +1527,7 @@ __global__ void __launch_bounds__(NTN) k_gru_bf3(int E, const float *__restrict_
                                                  const uint32_t *__restrict__ whh, const uint32_t *__restrict__ whl, const float *__restrict__ Wt_ih, int dx,
                                                  const float *__restrict__ b_ih, const float *__restrict__ b_hh, float *__restrict__ out, int ntiles /* full tiles only */)
 {
+    if (MASK && loop_stopped(rowmask, E)) return;          // a device-driven loop has ended: this sweep writes nothing (k_edge_active)
     constexpr int H = 128, N3 = 3 * H;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     // two tile buffers, used alternately (as in k_gru_pipe); per buffer Xh | Xl | Hh | Hl (narrow: an fp32 [TM][5] block in place of Xh | Xl)
@@ -1770,6 +1782,7 @@ __global__ void __launch_bounds__(NTN, 6) k_agg_post_bf3(int E, const float *__r
                                                          const uint32_t *__restrict__ w3h, const uint32_t *__restrict__ w3l,
                                                          const uint32_t *__restrict__ w4h, const uint32_t *__restrict__ w4l, float *__restrict__ out)
 {
+    if (loop_stopped(rowmask, E)) return;                  // a device-driven loop has ended: this sweep writes nothing (k_edge_active)
     constexpr int K3 = 64, K4 = 112, N = 128;               // padded k ranges, columns of both layers (100 -> 128, 128)
     extern __shared__ __attribute__((aligned(16))) float sm[];
     uint16_t *Rh = reinterpret_cast<uint16_t *>(sm), *Rl = Rh + TM * BF3_RS, *Gh = Rl + TM * BF3_RS, *Gl = Gh + TM * BF3_GS;
@@ -2030,6 +2043,7 @@ __global__ void __launch_bounds__(256) k_gru_wave(int E, const float *__restrict
                                                   const float *__restrict__ hprev, const float *__restrict__ rowmask, GruW g,
                                                   float *__restrict__ out, int ntiles /* full 32-edge tiles only */)
 {
+    if (MASK && loop_stopped(rowmask, E)) return;          // a device-driven loop has ended: this sweep writes nothing (k_edge_active)
     constexpr int H = 2 * SX - 2;                          // input row = [H message floats, edge sign, zero pad]
     static_assert(2 * SH == H || 2 * SH == H + 1, "hidden rows of H floats (+ one zero when H is odd)");
     constexpr int HP = 32 * NBK, N3 = 3 * HP, CG = (H + 63) / 64;
@@ -2131,10 +2145,14 @@ __global__ void __launch_bounds__(256) k_gru_wave(int E, const float *__restrict
     }
 }
 
-// mask per edge from the per-instance active mask (K1: two chained sparse products in the reference)
+// mask per edge from the per-instance active mask (K1: two chained sparse products in the reference).  The word behind the mask, out[E], carries
+// the stop word of a device-driven loop (pdp_loop_*, FL_LOOP_STOP) to the kernels that blend a new state with the old one under this mask:
+// once every instance has left the loop they return at once (loop_stopped) -- the sweeps a captured graph still replays are exact no-ops,
+// where `0 * new + 1 * old` would turn a -0 into +0 and carry a NaN of `new` over.
 __global__ void k_edge_active(int E, const int32_t *__restrict__ gm, const int32_t *__restrict__ var_inst, const uint8_t *__restrict__ amask,
-                              float *__restrict__ out)
+                              float *__restrict__ out, const uint32_t *__restrict__ stop)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<uint32_t *>(out)[E] = stop ? *stop : 0u;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x)
         out[e] = amask ? (0.0f + (0.0f + (float)amask[var_inst[gm[e]]])) : 1.0f;
 }
@@ -2267,14 +2285,14 @@ extern "C" int pdp_neural_aggregate_edges(pdp_problem *p, const pdp_agg_desc *d,
     hipStream_t st = ST(stream);
     const AggW w = make_agg(d);
     const int E = p->E, R = by_variable ? p->V : p->F;
-    float *h2 = neural_ws(p, 0, (size_t)E * w.a), *agg = neural_ws(p, 1, (size_t)R * w.a), *rowmask = neural_ws(p, 2, (size_t)E);
+    float *h2 = neural_ws(p, 0, (size_t)E * w.a), *agg = neural_ws(p, 1, (size_t)R * w.a), *rowmask = neural_ws(p, 2, (size_t)E + 4);
     if (!h2 || !agg || !rowmask) return PDP_ERR_HIP;
     const int tiles = (E + TM - 1) / TM;
     const size_t lds1 = sizeof(float) * (size_t)TM * ((w.Kp1 + 1) + (w.Np1 + 1));
     const size_t lds3 = sizeof(float) * (size_t)TM * ((w.Kp3 + 1) + (w.Np3 + 1));
     int s = set_lds((const void *)k_agg_pre, lds1); if (s != PDP_OK) return s;
     s = set_lds((const void *)k_agg_post, lds3); if (s != PDP_OK) return s;
-    hipLaunchKernelGGL(k_edge_active, dim3(1024), dim3(256), 0, st, E, p->graph_map, p->var_inst, active_mask, rowmask);
+    hipLaunchKernelGGL(k_edge_active, dim3(1024), dim3(256), 0, st, E, p->graph_map, p->var_inst, active_mask, rowmask, p->flags + FL_LOOP_STOP);
 #ifdef PDP_FAST_MATH
     s = launch_agg_pre(E, state, p->edge_sign, edge_mask, w, h2, st, bf3_workspace(p, 2, st)); if (s != PDP_OK) return s;
 #else
@@ -2352,12 +2370,12 @@ extern "C" int pdp_neural_gru(pdp_problem *p, const pdp_gru_desc *d, const float
     g.Wt_ih = d->Wt_ih; g.Wt_hh = d->Wt_hh; g.b_ih = d->b_ih; g.b_hh = d->b_hh; g.dx = d->dx; g.H = d->H;
     g.Kpx = even_up(d->dx + 1); g.Kph = even_up(d->H); g.Hp = pad32(d->H);
     const int E = p->E;
-    float *rowmask = neural_ws(p, 2, (size_t)E);
+    float *rowmask = neural_ws(p, 2, (size_t)E + 4);
     if (!rowmask) return PDP_ERR_HIP;
     const size_t lds = sizeof(float) * (size_t)TM * ((g.Kpx + 1) + (g.Kph + 1));
     PDP_REQUIRE(g.Kpx <= 64 * PRE_C && g.Kph <= 64 * PRE_C, "GRU wider than 192 inputs is not supported by the tile prefetch");
     int s = set_lds((const void *)k_gru, lds); if (s != PDP_OK) return s;
-    hipLaunchKernelGGL(k_edge_active, dim3(1024), dim3(256), 0, st, E, p->graph_map, p->var_inst, active_mask, rowmask);
+    hipLaunchKernelGGL(k_edge_active, dim3(1024), dim3(256), 0, st, E, p->graph_map, p->var_inst, active_mask, rowmask, p->flags + FL_LOOP_STOP);
     pdp_timed_scope timed(PDP_TK_GRU, st);
     const bool plain = generic_forced();
     auto ragged_tail = [&](size_t o, int tail) {

@@ -15,7 +15,7 @@ __global__ void k_reset_flags(uint32_t *flags)
     const int i = threadIdx.x;
     if (i >= FL_COUNT) return;
     if (i == FL_GMIN0 || i == FL_GMIN1 || i == FL_GMIN2) flags[i] = PDP_ENC_PLUS_INF;
-    else if (i == FL_LAYOUT_BAD || i == FL_SPEC_VIOLATION || i == FL_TEAM_TIMEOUT) { /* sticky */ }
+    else if (i == FL_LAYOUT_BAD || i == FL_SPEC_VIOLATION || i == FL_TEAM_TIMEOUT || i == FL_LOOP_STOP || i == FL_LOOP_ITERS) { /* sticky / owned by pdp_loop_* */ }
     else flags[i] = 0u;
 }
 static inline void reset_flags(pdp_problem *p, hipStream_t st) { hipLaunchKernelGGL(k_reset_flags, dim3(1), dim3(64), 0, st, p->flags); }
@@ -230,8 +230,10 @@ extern "C" int pdp_instance_argmax(pdp_problem *p, const float *x, int64_t *out,
 template <bool LOGX, int PHASE>
 __global__ void __launch_bounds__(PDP_NT) k_sp_propagate(PView pv, const float *dq, const float *dfs, const float *emask,
                                                          const uint8_t *amask, const float *iq, const float *ifs, float pi,
-                                                         float *oq, float *ofs, float *xs, float *ys, float *Sw, float *Pw, float *Nw)
+                                                         float *oq, float *ofs, float *xs, float *ys, float *Sw, float *Pw, float *Nw,
+                                                         const uint32_t *stop /* FL_LOOP_STOP: a device-driven loop has ended, write nothing */)
 {
+    if (amask && __builtin_amdgcn_readfirstlane((int)__builtin_nontemporal_load(stop)) != 0) return;
     const Inst I = load_inst(pv, blockIdx.x);
     const int nt = (int)blockDim.x * (PHASE < 0 ? 1 : (int)gridDim.y), tid = (int)threadIdx.x + (PHASE < 0 ? 0 : (int)blockIdx.y * (int)blockDim.x);
     dq += (LOGX ? 1 : 3) * (size_t)I.e0; dfs += 2 * (size_t)I.e0; iq += 3 * (size_t)I.e0; ifs += 2 * (size_t)I.e0;
@@ -305,16 +307,16 @@ static void sp_sweep_launch(pdp_problem *p, const float *dq, const float *dfs, c
     if (rows == 1) {
         pdp_note_kernel(PDP_TK_SP_SWEEP, LOGX ? "k_sp_propagate<true>" : "k_sp_propagate<false>");
         hipLaunchKernelGGL((k_sp_propagate<LOGX, -1>), dim3(p->B), dim3(PDP_NT), 0, st, pv, dq, dfs, edge_mask, active_mask, init_q, init_fs, pi, out_q, out_fs,
-                           p->ws_e[0], p->ws_e[1], p->ws_f[0], p->ws_v[0], p->ws_v[1]);
+                           p->ws_e[0], p->ws_e[1], p->ws_f[0], p->ws_v[0], p->ws_v[1], p->flags + FL_LOOP_STOP);
         return;
     }
     pdp_note_kernel(PDP_TK_SP_SWEEP, LOGX ? "k_sp_propagate<true> in three phases" : "k_sp_propagate<false> in three phases");
     hipLaunchKernelGGL((k_sp_propagate<LOGX, 0>), dim3(p->B, rows), dim3(PDP_NT), 0, st, pv, dq, dfs, edge_mask, active_mask, init_q, init_fs, pi, out_q, out_fs,
-                       p->ws_e[0], p->ws_e[1], p->ws_f[0], p->ws_v[0], p->ws_v[1]);
+                       p->ws_e[0], p->ws_e[1], p->ws_f[0], p->ws_v[0], p->ws_v[1], p->flags + FL_LOOP_STOP);
     hipLaunchKernelGGL((k_sp_propagate<LOGX, 1>), dim3(p->B, rows), dim3(PDP_NT), 0, st, pv, dq, dfs, edge_mask, active_mask, init_q, init_fs, pi, out_q, out_fs,
-                       p->ws_e[0], p->ws_e[1], p->ws_f[0], p->ws_v[0], p->ws_v[1]);
+                       p->ws_e[0], p->ws_e[1], p->ws_f[0], p->ws_v[0], p->ws_v[1], p->flags + FL_LOOP_STOP);
     hipLaunchKernelGGL((k_sp_propagate<LOGX, 2>), dim3(p->B, rows), dim3(PDP_NT), 0, st, pv, dq, dfs, edge_mask, active_mask, init_q, init_fs, pi, out_q, out_fs,
-                       p->ws_e[0], p->ws_e[1], p->ws_f[0], p->ws_v[0], p->ws_v[1]);
+                       p->ws_e[0], p->ws_e[1], p->ws_f[0], p->ws_v[0], p->ws_v[1], p->flags + FL_LOOP_STOP);
 }
 
 extern "C" int pdp_sp_propagate(pdp_problem *p, const float *dec_q, const float *dec_fs, const float *edge_mask,
@@ -549,6 +551,44 @@ extern "C" int pdp_check_termination(pdp_problem *p, uint8_t *active_mask, const
     { const int st_ = launch_cnf_eval(p, pred, p->ws_b[0], p->ws_b[1], ST(stream)); if (st_ != PDP_OK) return st_; }
     hipLaunchKernelGGL(k_termination, dim3((p->B0 + 255) / 256), dim3(256), 0, ST(stream), p->B0, p->R, p->ws_b[0], active_mask);
     PDP_LAUNCH_CHECK();
+    return PDP_OK;
+}
+
+// ---- device-driven step-wise loop (the plug-in loop of solver.py:355-386 without its per-sweep host read) -----------------------------------
+// The host enqueues (or replays, as a captured HIP graph) one sweep after the other; pdp_loop_step closes a sweep on the device: it counts
+// the sweep and raises FL_LOOP_STOP once `int(active_mask.sum()) <= 0` (solver.py:383-384).  Behind the stop the kernels that write the
+// message states return at once (pdp_neural.hip: loop_stopped; k_sp_propagate), so whatever the host still has in flight changes nothing:
+// the states, the solution and the mask are the ones of the sweep that ended the loop, and FL_LOOP_ITERS is the reference's iteration count.
+__global__ void __launch_bounds__(256) k_loop_step(int B, const uint8_t *amask, uint32_t *words /* [stop, iterations] */)
+{
+    if (words[0]) return;
+    int any = 0;
+    if (amask) { for (int b = threadIdx.x; b < B; b += blockDim.x) any |= amask[b] ? 1 : 0; }
+    else any = 1;
+    any = __syncthreads_or(any);
+    if (threadIdx.x == 0) { words[1] += 1u; if (!any) words[0] = 1u; }
+}
+extern "C" int pdp_loop_begin(pdp_problem *p, void *stream)
+{
+    PDP_REQUIRE(p, "NULL argument");
+    PDP_HIP_CHECK(hipMemsetAsync(p->flags + FL_LOOP_STOP, 0, 2 * sizeof(uint32_t), ST(stream)));
+    return PDP_OK;
+}
+extern "C" int pdp_loop_step(pdp_problem *p, const uint8_t *active_mask, void *stream)
+{
+    PDP_REQUIRE(p, "NULL argument");
+    static_assert(FL_LOOP_ITERS == FL_LOOP_STOP + 1, "the two loop words are adjacent");
+    hipLaunchKernelGGL(k_loop_step, dim3(1), dim3(256), 0, ST(stream), p->B, active_mask, p->flags + FL_LOOP_STOP);
+    PDP_LAUNCH_CHECK();
+    return PDP_OK;
+}
+extern "C" int pdp_loop_read(pdp_problem *p, int32_t *stopped_host, int32_t *iterations_host, int end, void *stream)
+{
+    PDP_REQUIRE(p && stopped_host && iterations_host, "NULL argument");
+    PDP_HIP_CHECK(hipMemcpyAsync(p->flags_host + FL_LOOP_STOP, p->flags + FL_LOOP_STOP, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ST(stream)));
+    if (end) PDP_HIP_CHECK(hipMemsetAsync(p->flags + FL_LOOP_STOP, 0, 2 * sizeof(uint32_t), ST(stream)));    // the loop is over: later calls write again
+    PDP_HIP_CHECK(hipStreamSynchronize(ST(stream)));
+    *stopped_host = (int32_t)p->flags_host[FL_LOOP_STOP]; *iterations_host = (int32_t)p->flags_host[FL_LOOP_ITERS];
     return PDP_OK;
 }
 

@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     'pdp_abi_version', 'pdp_last_error', 'pdp_device_count', 'pdp_problem_create', 'pdp_problem_destroy',
     'pdp_problem_dims', 'pdp_problem_set_rng_base', 'pdp_problem_set_exchange', 'pdp_problem_export_graph', 'pdp_problem_bind_state', 'pdp_simplify', 'pdp_set_variables',
     'pdp_refresh_edge_mask', 'pdp_smooth_max', 'pdp_instance_max', 'pdp_instance_argmax', 'pdp_sp_propagate', 'pdp_sp_adaptors', 'pdp_sp_propagate_adapted',
-    'pdp_survey_score', 'pdp_cnf_eval', 'pdp_sat_loss', 'pdp_update_solution', 'pdp_check_termination', 'pdp_decimator_create',
+    'pdp_survey_score', 'pdp_cnf_eval', 'pdp_sat_loss', 'pdp_update_solution', 'pdp_check_termination', 'pdp_loop_begin', 'pdp_loop_step', 'pdp_loop_read', 'pdp_decimator_create',
     'pdp_decimator_destroy', 'pdp_decimator_reset', 'pdp_sequential_decimate', 'pdp_sequential_decimate_gate',
     'pdp_sequential_decimate_apply', 'pdp_reinforce_decimate', 'pdp_reinforce_predict', 'pdp_energy',
     'pdp_energy_diff', 'pdp_random_fill', 'pdp_local_search', 'pdp_deduplicate', 'pdp_sp_solve', 'pdp_math_apply',
@@ -330,13 +330,13 @@ class Problem(object):
                                     ptr(W_v, torch.float32, 2 * H, 'W_v'), ptr(xlog), ptr(fs2), _stream()))
         return xlog, fs2
 
-    def sp_propagate_adapted(self, xlog, dec_fs, edge_mask, active_mask, init_q, init_fs, pi=0.0):
-        out_q = torch.empty(self.E, 3, dtype=torch.float32, device=self.device)
-        out_fs = torch.empty(self.E, 2, dtype=torch.float32, device=self.device)
+    def sp_propagate_adapted(self, xlog, dec_fs, edge_mask, active_mask, init_q, init_fs, pi=0.0, out=None):
+        out_q = torch.empty(self.E, 3, dtype=torch.float32, device=self.device) if out is None else out[0]
+        out_fs = torch.empty(self.E, 2, dtype=torch.float32, device=self.device) if out is None else out[1]
         check(lib().pdp_sp_propagate_adapted(self._h, ptr(xlog, torch.float32, self.E, 'xlog'), ptr(dec_fs, torch.float32, 2 * self.E, 'fs2'),
                                              ptr(edge_mask, torch.float32, self.E, 'edge_mask'), ptr(active_mask, torch.uint8, self.B, 'active_mask'),
                                              ptr(init_q, torch.float32, 3 * self.E, 'init_state[0]'), ptr(init_fs, torch.float32, 2 * self.E, 'init_state[1]'),
-                                             C.c_float(pi), ptr(out_q), ptr(out_fs), _stream()))
+                                             C.c_float(pi), ptr(out_q, torch.float32, 3 * self.E, 'out[0]'), ptr(out_fs, torch.float32, 2 * self.E, 'out[1]'), _stream()))
         return out_q, out_fs
 
     def survey_score(self, fs, pi=0.0):
@@ -366,6 +366,19 @@ class Problem(object):
     def check_termination(self, active_mask, pred):
         check(lib().pdp_check_termination(self._h, ptr(active_mask, torch.uint8, self.B, 'active_mask'),
                                           ptr(pred, torch.float32, self.V, 'prediction'), _stream()))
+
+    # -- device-driven loop (pdp_loop_*): the sweeps of a forward enqueued without a host read per sweep ------------
+    def loop_begin(self):
+        check(lib().pdp_loop_begin(self._h, _stream()))
+
+    def loop_step(self, active_mask):
+        check(lib().pdp_loop_step(self._h, ptr(active_mask, torch.uint8, self.B, 'active_mask'), _stream()))
+
+    def loop_read(self, end=False):
+        "(stopped, executed sweeps); waits for the stream"
+        stopped, iters = C.c_int32(0), C.c_int32(0)
+        check(lib().pdp_loop_read(self._h, C.byref(stopped), C.byref(iters), C.c_int(1 if end else 0), _stream()))
+        return bool(stopped.value), int(iters.value)
 
     # -- decimators --------------------------------------------------------------------------------------------
     def sequential_decimate(self, dec, fs, active_mask, tolerance, t_max, pi=0.0):
@@ -450,19 +463,22 @@ class Problem(object):
         return out, chosen
 
     # -- neural plug-ins -------------------------------------------------------------------------------------------------
-    def neural_aggregate_edges(self, agg_w, by_variable, state, edge_mask, active_mask, old):
-        out = torch.empty(self.E, agg_w.desc.out, dtype=torch.float32, device=self.device)
+    def neural_aggregate_edges(self, agg_w, by_variable, state, edge_mask, active_mask, old, out=None):
+        if out is None:
+            out = torch.empty(self.E, agg_w.desc.out, dtype=torch.float32, device=self.device)
         check(lib().pdp_neural_aggregate_edges(self._h, C.byref(agg_w.desc), C.c_int(1 if by_variable else 0),
                                                ptr(state, torch.float32, self.E * (agg_w.desc.din - 1), 'state'),
                                                ptr(edge_mask, torch.float32, self.E, 'edge_mask'), ptr(active_mask, torch.uint8, self.B, 'active_mask'),
-                                               ptr(old, torch.float32, self.E * agg_w.desc.out, 'init_state'), ptr(out), _stream()))
+                                               ptr(old, torch.float32, self.E * agg_w.desc.out, 'init_state'),
+                                               ptr(out, torch.float32, self.E * agg_w.desc.out, 'out'), _stream()))
         return out
 
-    def neural_gru(self, gru_w, state, h, active_mask):
-        out = torch.empty(self.E, gru_w.desc.H, dtype=torch.float32, device=self.device)
+    def neural_gru(self, gru_w, state, h, active_mask, out=None):
+        if out is None:
+            out = torch.empty(self.E, gru_w.desc.H, dtype=torch.float32, device=self.device)
         check(lib().pdp_neural_gru(self._h, C.byref(gru_w.desc), ptr(state, torch.float32, self.E * gru_w.desc.dx, 'message_state'),
                                    ptr(h, torch.float32, self.E * gru_w.desc.H, 'init_state'), ptr(active_mask, torch.uint8, self.B, 'active_mask'),
-                                   ptr(out), _stream()))
+                                   ptr(out, torch.float32, self.E * gru_w.desc.H, 'out'), _stream()))
         return out
 
     def neural_predict(self, agg_w, head_w, state, edge_mask):
@@ -583,7 +599,17 @@ TIMING_KEYS = ('agg_pre', 'row_sum', 'agg_post', 'gru', 'predict_head', 'walksat
 
 def kernel_timing(enable):
     "bracket the library's neural / Walk-SAT kernels with HIP events on their launch stream (measurement only)"
+    global _TIMING_ON
     check(lib().pdp_kernel_timing(C.c_int(1 if enable else 0)))
+    _TIMING_ON = bool(enable)
+
+
+_TIMING_ON = False
+
+
+def kernel_timing_enabled():
+    "event pairs around every launch cannot be read back from a replayed graph: the solver's graph loop stands back while this is on"
+    return _TIMING_ON
 
 
 def kernel_timing_read():

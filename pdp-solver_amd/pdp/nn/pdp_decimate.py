@@ -69,10 +69,11 @@ class NeuralDecimator(nn.Module):
             return nv, nf
         am = None if active_mask is None else active_mask.reshape(-1).contiguous()
         nat = sat_problem._native
+        out_v, out_f = getattr(self, '_out', None) or (None, None)        # the solver's graph loop names the buffers a sweep writes
         new_variable_state = nat.neural_gru(self._weights('v', self._variable_rnn_cell), variable_state.contiguous(),
-                                            init_state[0].contiguous(), am)
+                                            init_state[0].contiguous(), am, out=out_v)
         new_function_state = nat.neural_gru(self._weights('f', self._function_rnn_cell), function_state.contiguous(),
-                                            init_state[1].contiguous(), am)
+                                            init_state[1].contiguous(), am, out=out_f)
         return new_variable_state, new_function_state
 
     def get_init_state(self, graph_map, batch_variable_map, batch_function_map, edge_feature, graph_feat, randomized, batch_replication):

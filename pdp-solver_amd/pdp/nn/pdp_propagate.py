@@ -55,12 +55,13 @@ class NeuralMessagePasser(nn.Module):
         variable_state, function_state = init_state
         am = None if active_mask is None else active_mask.reshape(-1).contiguous()
         nat = sat_problem._native
+        out_v, out_f = getattr(self, '_out', None) or (None, None)        # the solver's graph loop names the buffers a sweep writes
         # variables --> functions (pdp_propagate.py:72-78)
         function_state = nat.neural_aggregate_edges(self._variable_aggregator.native_weights(), True,
-                                                    decimator_variable_state.contiguous(), edge_mask, am, function_state.contiguous())
+                                                    decimator_variable_state.contiguous(), edge_mask, am, function_state.contiguous(), out=out_f)
         # functions --> variables (pdp_propagate.py:83-89)
         variable_state = nat.neural_aggregate_edges(self._function_aggregator.native_weights(), False,
-                                                    decimator_function_state.contiguous(), edge_mask, am, variable_state.contiguous())
+                                                    decimator_function_state.contiguous(), edge_mask, am, variable_state.contiguous(), out=out_v)
         return variable_state, function_state
 
     def _forward_train(self, init_state, decimator_state, sat_problem, active_mask, dropout=True):
@@ -143,7 +144,7 @@ class SurveyPropagator(nn.Module):
             xlog, fs2 = nat.sp_adaptors(dec_q.contiguous(), dec_fs.contiguous(),
                                         self._function_input_projector.weight.data.reshape(-1).contiguous(),
                                         self._variable_input_projector.weight.data.contiguous())
-            return nat.sp_propagate_adapted(xlog, fs2, em, am, init_q.contiguous(), init_fs.contiguous(), self._pi)
+            return nat.sp_propagate_adapted(xlog, fs2, em, am, init_q.contiguous(), init_fs.contiguous(), self._pi, out=getattr(self, '_out', None))
         return nat.sp_propagate(dec_q.contiguous(), dec_fs.contiguous(), em, am, init_q.contiguous(), init_fs.contiguous(), self._pi)
 
     def _forward_train(self, init_state, dec_v, dec_f, edge_mask, sat_problem, active_mask):

@@ -346,7 +346,101 @@ class PropagatorDecimatorSolverBase(nn.Module):
                 raise native.CoupledForwardFailed("a coupled forward spread over several processes met a coupling only the step-wise loop "
                                                   "reproduces (batch-global minimum != 0); that loop is single-process")
         del init_propagator_state, init_decimator_state                # (see forward: this frame lets go of the initial state)
+        if self._can_run_graph_loop(sat_problem, iteration_num, is_training, check_termination):
+            return self._forward_core_graph(box, sat_problem, iteration_num, check_termination)
         return self._forward_core_stepwise(box, None, sat_problem, iteration_num, is_training, check_termination)
+
+    # ---- the neural triples' loop, device-driven -------------------------------------------------------------------------------------------
+    def _can_run_graph_loop(self, sat_problem, iteration_num, is_training, check_termination):
+        """np-nd-np / p-nd-np prediction: the library's neural decimator (no variable is ever fixed: the edge mask of the first sweep is the
+        mask of every sweep) behind the neural or the adaptor-fed survey propagator, the variable-side neural predictor, the trainer's own
+        termination callback or none.  Anything else -- foreign plug-ins, training, graph features, kernel timing -- takes the step-wise loop."""
+        if is_training or os.environ.get('PDP_NO_GRAPH_LOOP') or native.kernel_timing_enabled():
+            return False
+        if int(iteration_num) < int(os.environ.get('PDP_GRAPH_LOOP_MIN_SWEEPS', '8')):
+            return False                                   # two captures per forward: a short loop is cheaper sweep by sweep
+        if check_termination is not None and not _is_standard_termination(check_termination):
+            return False
+        pr, de, pd = self._propagator, self._decimator, self._predictor
+        if type(de) is not pdp_decimate.NeuralDecimator or type(pd) is not pdp_predict.NeuralPredictor:
+            return False
+        if not (type(pr) is pdp_propagate.NeuralMessagePasser or (type(pr) is pdp_propagate.SurveyPropagator and pr._include_adaptors)):
+            return False
+        if getattr(pr, '_meta_dim', 0) or de._meta_dim or pd._meta_dim or sat_problem._meta_data is not None:
+            return False
+        if pd._variable_classifier is None or pd._function_classifier is not None:
+            return False
+        return self._exchange is None and not self._isolated and not any(getattr(m, '_train_path', False) for m in (pr, de, pd))
+
+    def _forward_core_graph(self, box, sat_problem, iteration_num, check_termination):
+        """The loop of solver.py:355-386 for the neural triples without a host round trip per sweep.  The first sweep runs as in the step-wise
+        loop (the library's workspaces come into being there, and the host learns whether an edge mask exists).  The body of every later sweep
+        -- the same plug-in calls, writing into named buffers -- is captured ONCE per parity as a HIP graph: sweep k reads state set k - 1
+        and writes set k (mod 2).  The loop's end is decided on the device (pdp_loop_step: the sweep is counted, and `active_mask.sum() <= 0`
+        raises a stop word behind which the state-writing kernels of replayed sweeps return at once); the host replays graphs, looks at the
+        stop word every few sweeps and takes the executed count from the device.  States, solution, mask and count equal the step-wise loop's
+        (tests/test_api_forward.py::test_graph_loop_equals_the_stepwise_loop)."""
+        T = int(iteration_num)
+        nat = sat_problem._native
+        propagator_state, decimator_state = box.take()
+        active_mask = None if check_termination is None else torch.ones(sat_problem._batch_size, 1, dtype=torch.uint8, device=self._device)
+        am_flat = None if active_mask is None else active_mask.reshape(-1)
+        all_active = [True]
+
+        def sweep(p_in, d_in, p_out, d_out, first):
+            self._propagator._out, self._decimator._out = p_out, d_out
+            try:
+                ps = self._propagator(p_in, d_in, sat_problem, False, active_mask)
+                ds = self._decimator(d_in, ps, sat_problem, False, active_mask)
+            finally:
+                self._propagator._out = self._decimator._out = None
+            if first:
+                all_active[0] = sat_problem.refresh_edge_mask()
+            else:
+                nat.refresh_edge_mask(False)                # same kernel, no host read of the flag (nothing is decimated: it cannot change)
+            ds = tuple(ds[:2])
+            if not all_active[0]:
+                ds = ds + (sat_problem._edge_mask,)
+            if check_termination is not None:
+                prediction = self._predictor(ds, sat_problem)
+                prediction = self._update_solution(prediction, sat_problem)
+                check_termination(active_mask, prediction, sat_problem)
+            nat.loop_step(am_flat)
+            return tuple(ps[:2]), ds
+
+        nat.loop_begin()
+        ps_a, ds_a = sweep(propagator_state, decimator_state, None, None, True)
+        del propagator_state, decimator_state               # the initial state goes (its four [E, H] tensors are dead after the first sweep)
+        iters = 1
+        if T > 1:
+            ps_b = tuple(torch.empty_like(x) for x in ps_a[:2])
+            ds_b2 = tuple(torch.empty_like(x) for x in ds_a[:2])
+            ds_b = ds_b2 + tuple(ds_a[2:])
+            graphs = []
+            pool = None
+            side = torch.cuda.Stream(device=self._device)
+            side.wait_stream(torch.cuda.current_stream())
+            for src_p, src_d, dst_p, dst_d in ((ps_a, ds_a, ps_b, ds_b2), (ps_b, ds_b, ps_a, tuple(ds_a[:2]))):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, stream=side, capture_error_mode='thread_local'):
+                    sweep(src_p, src_d, dst_p, dst_d, False)
+                pool = g.pool()
+                graphs.append(g)
+            torch.cuda.current_stream().wait_stream(side)
+            look = max(1, int(os.environ.get('PDP_GRAPH_LOOP_LOOK', '8')))
+            stopped = False
+            for k in range(2, T + 1):
+                graphs[k & 1].replay()                      # even sweeps: set a -> set b
+                if active_mask is not None and (k - 1) % look == 0 and k < T:
+                    stopped, iters = nat.loop_read()
+                    if stopped:
+                        break
+        stopped, iters = nat.loop_read(end=True)
+        if T > 1 and iters > 1 and iters % 2 == 0:
+            ps_a, ds_a = ps_b, ds_b
+        self.last_run.update(path='graph', iterations=iters)
+        self._active_mask = active_mask
+        return ps_a, ds_a
 
     def _forward_core_persistent(self, init_propagator_state, init_decimator_state, sat_problem, iteration_num, check_termination):
         """the whole loop of solver.py:355-386 in one kernel launch; None if the speculation failed.  The first sweep reads the

@@ -732,3 +732,103 @@ def test_graph_features_meta_data_equal_the_reference():
             want = d[k]
             np.testing.assert_allclose(obj.grad.cpu().numpy(), want, rtol=2e-3, atol=2e-5 * float(np.abs(want).max()), err_msg=k)
             assert float(np.abs(want[:, -M:]).max()) > 0 or 'layer2' in k            # the meta columns carry gradient
+
+
+def _mixed_small_items(count, seed0):
+    "instances small enough that random-weight predictions solve some of them in the first sweeps, next to ones that stay unsolved"
+    from pdp.factorgraph import dataset
+    items = []
+    for i in range(count):
+        rng = np.random.RandomState(seed0 + i)
+        n = int(rng.randint(4, 9)) if i % 3 else int(rng.randint(30, 60))
+        items += dataset.random_ksat_items(1, n, 3, m=int(round((1.5 if i % 3 else 4.2) * n)), seed=seed0 + 1000 + i)
+    return items
+
+
+def _graph_and_stepwise(tr, m, batch, T, R, monkeypatch, randomized=True, check=True, look=None):
+    gm, bvm, bfm, ef = batch
+    out = {}
+    for mode in ('stepwise', 'graph'):
+        if mode == 'stepwise':
+            monkeypatch.setenv('PDP_NO_GRAPH_LOOP', '1')
+        else:
+            monkeypatch.delenv('PDP_NO_GRAPH_LOOP')
+        if look is not None:
+            monkeypatch.setenv('PDP_GRAPH_LOOP_LOOK', str(look))
+        torch.manual_seed(5)
+        with torch.no_grad():
+            st = m.get_init_state(gm, bvm, bfm, ef, None, randomized=randomized, batch_replication=R)
+            pred, (ps, ds) = m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None,
+                               is_training=False, iteration_num=T, check_termination=tr._check_recurrence_termination if check else None, batch_replication=R)
+        assert m.last_run['path'] == mode
+        am = m._active_mask
+        out[mode] = dict(iters=m.last_run['iterations'], pred=pred[0].cpu().numpy().tobytes(), mask=None if am is None else am.cpu().numpy().tobytes(),
+                         states=[x.cpu().numpy().tobytes() for x in tuple(ps) + tuple(ds)], solution=m._last_problem._solution.cpu().numpy().tobytes(),
+                         active=None if am is None else int(am.sum().item()), instances=None if am is None else am.numel())
+    if look is not None:
+        monkeypatch.delenv('PDP_GRAPH_LOOP_LOOK')
+    return out['stepwise'], out['graph']
+
+
+def _neural_trainer(model_type, H):
+    from pdp.trainer import SatFactorGraphTrainer
+    torch.manual_seed(77)
+    tr = SatFactorGraphTrainer(cfg(model_type, hidden_dim=H, edge_feature_dim=1, meta_feature_dim=0, prediction_dim=1, mem_hidden_dim=100, agg_hidden_dim=100,
+                                   mem_agg_hidden_dim=50, classifier_dim=50, local_search_iteration=0, rng='philox', random_seed=3), use_cuda=True, logger=LOG)
+    return tr, tr._model_list[0]
+
+
+@pytest.mark.parametrize('model_type,H,R,count,T', [('np-nd-np', 128, 1, 70, 24), ('np-nd-np', 32, 2, 40, 17), ('p-nd-np', 128, 1, 70, 21), ('p-nd-np', 128, 3, 25, 12)])
+def test_graph_loop_equals_the_stepwise_loop(model_type, H, R, count, T, monkeypatch):
+    """The neural triples' device-driven loop (pdp/nn/solver.py::_forward_core_graph: one captured HIP graph per sweep parity, the loop's end
+    decided on the device, pdp_loop_*) against the step-wise loop with its host read per sweep: the same executed sweeps, and states, mask,
+    solution and prediction equal BYTE for byte, on batches in which random weights solve some instances along the way and not others."""
+    from pdp.factorgraph import dataset
+    dev = torch.device('cuda:0')
+    b = dataset.to_torch(dataset.collate_segment(_mixed_small_items(count, 5000 + 13 * T)), dev)
+    batch = (b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'])
+    tr, m = _neural_trainer(model_type, H)
+    a, g = _graph_and_stepwise(tr, m, batch, T, R, monkeypatch, look=5)
+    assert 0 < a['active'] < a['instances'], "the batch should hold solved and unsolved instances"
+    assert g == a
+    # without a termination callback nothing ends the loop: T sweeps, no mask
+    a, g = _graph_and_stepwise(tr, m, batch, 9, R, monkeypatch, randomized=False, check=False)
+    assert a['iters'] == 9 and a['mask'] is None and g == a
+
+
+@pytest.mark.parametrize('model_type', ['np-nd-np', 'p-nd-np'])
+def test_graph_loop_ends_where_the_stepwise_loop_ends(model_type, monkeypatch):
+    """The loop's end under the graph loop: (1) every instance has pure literals only -- simplify() decides it, the first sweep's check finds it solved whatever the prediction: the loop
+    ends after ONE sweep while the host has already replayed several more; (2) those + one easy instance that the random weights
+    solve in some sweep s with 2 < s < T - 2 (the test looks for such an instance with the step-wise loop): the stop word rises in the middle
+    of the replayed sweeps and the host notices it up to `look` sweeps late.  Executed sweeps, states, solution and prediction equal the
+    step-wise loop's byte for byte -- the sweeps replayed behind the stop word wrote nothing."""
+    from pdp.factorgraph import dataset
+    dev = torch.device('cuda:0')
+    T = 30
+    taut = [dataset.instance_from_clauses(5, [[1, 2, 3], [1, 4, 5], [2, 4, 5]], label=-1, name='t%d' % i) for i in range(12)]     # (only pure literals: simplify() decides them)
+    tr, m = _neural_trainer(model_type, 128)
+
+    def batch_of(items):
+        b = dataset.to_torch(dataset.collate_segment(items), dev)
+        return (b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'])
+    a, g = _graph_and_stepwise(tr, m, batch_of(taut), T, 1, monkeypatch, look=7)
+    assert a['iters'] == 1 and a['active'] == 0 and g == a
+    found = None
+    monkeypatch.setenv('PDP_NO_GRAPH_LOOP', '1')
+    for seed in range(200):
+        items = taut + dataset.random_ksat_items(1, 10, 3, m=15, seed=31000 + seed)
+        gm, bvm, bfm, ef = batch_of(items)
+        torch.manual_seed(5)
+        with torch.no_grad():
+            st = m.get_init_state(gm, bvm, bfm, ef, None, randomized=True, batch_replication=1)
+            m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None, is_training=False,
+              iteration_num=T, check_termination=tr._check_recurrence_termination, batch_replication=1)
+        if 2 < m.last_run['iterations'] < T - 2:
+            found = items
+            break
+    monkeypatch.delenv('PDP_NO_GRAPH_LOOP')
+    assert found is not None, "no candidate instance is solved in the middle of the loop: widen the search"
+    for look in (1, 4, 50):
+        a, g = _graph_and_stepwise(tr, m, batch_of(found), T, 1, monkeypatch, look=look)
+        assert 2 < a['iters'] < T - 2 and a['active'] == 0 and g == a

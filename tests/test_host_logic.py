@@ -82,7 +82,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, missing
     assert set(native.EXPORTED_SYMBOLS) == declared
-    assert lib.pdp_abi_version() == 2
+    assert lib.pdp_abi_version() == 3
 
 
 def test_no_gpu_means_loud_failure():

@@ -43,7 +43,7 @@ def main():
             sweeps = sum(r['iterations_per_segment'])
             inst_sweeps = sum(n * it for n, it in zip(r['segments'], r['iterations_per_segment']))
             row = dict(workload=name, limit=limit, segments=len(r['segments']), instances_per_segment_max=max(r['segments']), sweeps=sweeps,
-                       wall_s=r['seconds'], instance_sweeps_per_s=inst_sweeps * rep / r['seconds'], timed_kernel_ms=kms,
+                       wall_s=r['seconds'], loop=r['path'], wall_s_with_kernel_events=r.get('seconds_with_kernel_events'), instance_sweeps_per_s=inst_sweeps * rep / r['seconds'], timed_kernel_ms=kms,
                        gpu_busy_fraction_timed_kernels=kms * 1e-3 / r['seconds'], frac_mfma_f32=r['roofline']['frac'],
                        ms_per_segment_sweep=1e3 * r['seconds'] / max(1, sweeps))
             row['kernel_ms_total'] = {k: round(v['ms_per_launch'] * v['launches'], 2) for k, v in r['kernels'].items() if 'launches' in v}
