@@ -397,9 +397,15 @@ class FactorGraphTrainerBase(object):
             self.last_stats['backend'] = torch.distributed.get_backend()
             if self._config.get('verbose'):
                 self._logger.info('rank %d of %d solved %d units (forward calls): %s' % (rank, world, len(units), [u for u, _ in units][:32]))
+            t_gather = time.time()
             parts = parallel.gather_units(units)
+            t_gather = time.time() - t_gather
             if rank == 0:
                 out_file.write("".join(parts))
+            if self._config.get('verbose'):
+                ex = [m._exchange for m in self._model_list if getattr(m, '_exchange', None) is not None]
+                self._logger.info('rank %d of %d: gather of the result rows %.1f ms; %d exchanges of the coupled forwards, %.3f ms each'
+                                  % (rank, world, 1e3 * t_gather, sum(e.calls for e in ex), 1e3 * sum(e.seconds for e in ex) / max(1, sum(e.calls for e in ex))))
         else:
             self.last_stats = parallel.reduce_stats(*self._run_stats)
         if self._config.get('verbose'):

@@ -121,28 +121,44 @@ def reduce_test_metrics(error_sums, n_examples, device=None, group=None):
 
 def make_exchange(device=None, group=None):
     """The callback of a coupled forward spread over the ranks (native.Problem.set_exchange): element-wise min / max / bit-wise OR of three
-    small uint32 arrays over all ranks, in ONE collective (all_gather_into_tensor of the concatenated words: RCCL on the device when the
-    group's backend is nccl -- the staging tensors live there and are reused from call to call --, gloo on the host)."""
+    small uint32 arrays over all ranks, in ONE collective (all_gather_into_tensor of the concatenated words).  Under nccl (RCCL) the words
+    go host -> device -> all ranks -> host through two pinned staging tensors that live as long as the callback: two small asynchronous copies
+    and ONE stream synchronisation per exchange (the library needs the merged words on the host: its launches depend on them); under gloo
+    the collective runs on the host.  ``exchange.calls`` / ``exchange.seconds`` count what the run spent here."""
     staged = {}
 
     def exchange(mins, maxs, ors):
+        import time
+        t0 = time.perf_counter()
         n = (mins.size, maxs.size, ors.size)
         total = n[0] + n[1] + n[2]
         world = dist.get_world_size(group)
         on_gpu = dist.get_backend(group) == 'nccl'
         key = (total, world, on_gpu)
         if key not in staged:
-            dev = device if on_gpu else 'cpu'
             staged.clear()
-            staged[key] = (torch.empty(total, dtype=torch.int64, device=dev), torch.empty(world * total, dtype=torch.int64, device=dev))
-        mine, every_t = staged[key]
-        mine.copy_(torch.from_numpy(np.concatenate((mins, maxs, ors)).astype(np.int64)))
-        dist.all_gather_into_tensor(every_t, mine, group=group)
-        every = every_t.view(world, total).cpu().numpy().astype(np.uint32)
+            if on_gpu:
+                staged[key] = (torch.empty(total, dtype=torch.int32).pin_memory(), torch.empty(world * total, dtype=torch.int32).pin_memory(),
+                               torch.empty(total, dtype=torch.int32, device=device), torch.empty(world * total, dtype=torch.int32, device=device))
+            else:
+                staged[key] = (torch.empty(total, dtype=torch.int32), torch.empty(world * total, dtype=torch.int32), None, None)
+        h_in, h_out, d_in, d_out = staged[key]
+        h_in.numpy()[:] = np.concatenate((mins, maxs, ors)).astype(np.uint32).view(np.int32)        # (bit patterns: the reductions below are on uint32)
+        if on_gpu:
+            d_in.copy_(h_in, non_blocking=True)
+            dist.all_gather_into_tensor(d_out, d_in, group=group)
+            h_out.copy_(d_out, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        else:
+            dist.all_gather_into_tensor(h_out, h_in, group=group)
+        every = h_out.numpy().view(np.uint32).reshape(world, total)
         mins[:] = every[:, :n[0]].min(axis=0) if n[0] else mins
         maxs[:] = every[:, n[0]:n[0] + n[1]].max(axis=0) if n[1] else maxs
         if n[2]:
             ors[:] = np.bitwise_or.reduce(every[:, n[0] + n[1]:], axis=0)
+        exchange.calls += 1
+        exchange.seconds += time.perf_counter() - t0
+    exchange.calls, exchange.seconds = 0, 0.0
     return exchange
 
 
@@ -183,8 +199,9 @@ def gather_units(units, group=None):
 def solve_sharded(batches, solve_fn, rank=None, world_size=None, device=None, limit=None, hidden_dim=1, split_instances=False):
     """``batches``: the loader batches of the run (lists of loader items), the same list on every rank; ``limit`` / ``hidden_dim``: the
     dynamic-batching budget that cuts a batch into segments (None: one segment per batch).  Runs ``solve_fn(items, batch_index,
-    segment_index) -> (solved [b], unsat [b], rows list)`` on the units dealt to this rank and reduces the counters; returns (stats, all
-    rows in single-process order, this rank's [(batch, segment), ...]).  ``solve_fn`` is the native forward in production and the CPU
+    segment_index) -> (solved [b], unsat [b], rows list)`` on the units dealt to this rank and reduces the counters; returns (stats, rows,
+    this rank's [(batch, segment), ...]) -- `rows` is every rank's rows in single-process order ON RANK 0 ONLY (the writer); the other
+    ranks get their own rows back (gather_rows sends the rows to the writer, not to everybody).  ``solve_fn`` is the native forward in production and the CPU
     oracle in the gloo tests.  ``split_instances`` (isolated instances): every segment is cut into one instance range per rank and
     ``solve_fn(items, batch_index, segment_index, first_variable, first_instance)`` solves this rank's part; units are (batch, segment, part)."""
     from pdp.factorgraph import dataset

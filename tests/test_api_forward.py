@@ -798,37 +798,43 @@ def test_graph_loop_equals_the_stepwise_loop(model_type, H, R, count, T, monkeyp
 
 @pytest.mark.parametrize('model_type', ['np-nd-np', 'p-nd-np'])
 def test_graph_loop_ends_where_the_stepwise_loop_ends(model_type, monkeypatch):
-    """The loop's end under the graph loop: (1) every instance has pure literals only -- simplify() decides it, the first sweep's check finds it solved whatever the prediction: the loop
-    ends after ONE sweep while the host has already replayed several more; (2) those + one easy instance that the random weights
-    solve in some sweep s with 2 < s < T - 2 (the test looks for such an instance with the step-wise loop): the stop word rises in the middle
-    of the replayed sweeps and the host notices it up to `look` sweeps late.  Executed sweeps, states, solution and prediction equal the
-    step-wise loop's byte for byte -- the sweeps replayed behind the stop word wrote nothing."""
+    """The loop's end under the graph loop: (1) every instance has pure literals only -- simplify() decides it, the first sweep's check finds it
+    solved whatever the prediction: the loop ends after ONE sweep while the host has already replayed several more; (2) with the weights
+    trained here (models/README.md: they solve ~ 89 % of such instances within 30 sweeps, each in a sweep of its own) a batch that the step-wise
+    loop finishes in a sweep s with 3 <= s <= T - 3 (the test looks for one): the stop word rises in the middle of the replayed sweeps and the
+    host notices it up to `look` sweeps late.  Executed sweeps, states, mask, solution and prediction equal the step-wise loop's byte for byte --
+    the sweeps replayed behind the stop word wrote nothing."""
     from pdp.factorgraph import dataset
     dev = torch.device('cuda:0')
     T = 30
-    taut = [dataset.instance_from_clauses(5, [[1, 2, 3], [1, 4, 5], [2, 4, 5]], label=-1, name='t%d' % i) for i in range(12)]     # (only pure literals: simplify() decides them)
+    pure = [dataset.instance_from_clauses(5, [[1, 2, 3], [1, 4, 5], [2, 4, 5]], label=-1, name='t%d' % i) for i in range(12)]
     tr, m = _neural_trainer(model_type, 128)
+    m.load_state_dict(torch.load(os.path.join(REPO, 'models', 'demo-%s-h128.pt' % model_type), map_location=dev), strict=True)
 
     def batch_of(items):
         b = dataset.to_torch(dataset.collate_segment(items), dev)
         return (b['graph_map'], b['batch_variable_map'], b['batch_function_map'], b['edge_feature'])
-    a, g = _graph_and_stepwise(tr, m, batch_of(taut), T, 1, monkeypatch, look=7)
+    a, g = _graph_and_stepwise(tr, m, batch_of(pure), T, 1, monkeypatch, look=7)
     assert a['iters'] == 1 and a['active'] == 0 and g == a
-    found = None
+    found, found_at = None, 0
     monkeypatch.setenv('PDP_NO_GRAPH_LOOP', '1')
-    for seed in range(200):
-        items = taut + dataset.random_ksat_items(1, 10, 3, m=15, seed=31000 + seed)
+    for seed in range(60):
+        rng = np.random.RandomState(seed)
+        items = []
+        for j in range(10):
+            n = int(rng.randint(10, 41))
+            items += dataset.random_ksat_items(1, n, 3, m=int(round(rng.uniform(2.0, 3.6) * n)), seed=31000 + 10 * seed + j)
         gm, bvm, bfm, ef = batch_of(items)
         torch.manual_seed(5)
         with torch.no_grad():
             st = m.get_init_state(gm, bvm, bfm, ef, None, randomized=True, batch_replication=1)
             m(init_state=st, graph_map=gm, batch_variable_map=bvm, batch_function_map=bfm, edge_feature=ef, meta_data=None, is_training=False,
               iteration_num=T, check_termination=tr._check_recurrence_termination, batch_replication=1)
-        if 2 < m.last_run['iterations'] < T - 2:
-            found = items
+        if 3 <= m.last_run['iterations'] <= T - 3:
+            found, found_at = items, m.last_run['iterations']
             break
     monkeypatch.delenv('PDP_NO_GRAPH_LOOP')
-    assert found is not None, "no candidate instance is solved in the middle of the loop: widen the search"
+    assert found is not None, "no batch ends in the middle of the loop: widen the search"
     for look in (1, 4, 50):
         a, g = _graph_and_stepwise(tr, m, batch_of(found), T, 1, monkeypatch, look=look)
-        assert 2 < a['iters'] < T - 2 and a['active'] == 0 and g == a
+        assert a['iters'] == found_at and a['active'] == 0 and g == a

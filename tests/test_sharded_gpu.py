@@ -302,3 +302,56 @@ def test_two_ranks_equal_one_rank_on_a_dimacs_directory(tmp_path):
     one, _ = _run(argv, 1, str(tmp_path / 'one.jsonl'), 0)
     two, _ = _run(argv, 2, str(tmp_path / 'two.jsonl'), 29737)
     assert len(one) == 37 and one == two
+
+
+def _timing_lines(log):
+    import re
+    return [(int(m.group(1)), float(m.group(2)), int(m.group(3)), float(m.group(4)))
+            for m in re.finditer(r'rank (\d+) of \d+: gather of the result rows ([0-9.]+) ms; (\d+) exchanges of the coupled forwards, ([0-9.]+) ms each', log)]
+
+
+def test_eight_ranks_on_the_shapes_of_configs_3_and_4(tmp_path):
+    """The rank count BASELINE names, on this box's one GPU (eight gloo ranks share it: RCCL wants one GPU per rank).
+    (a) configs[3]'s shape -- 8 loader batches, one forward each, np-nd-np hidden 128 with Walk-SAT: every rank solves exactly one batch and
+        rank 0 writes the rows of the single process;
+    (b) configs[4]'s shape under the strict semantics -- ONE loader batch of mixed 3- / 4-SAT in one segment, p-d-p with --split-forward: the
+        coupled forward is spread over the eight ranks (one exchange of control words per chunk of sweeps), rows = the single process's.
+    The wall time of the row gather and of one exchange is logged per rank (gloo here; RCCL on a node) and printed with -s."""
+    import re
+    from pdp.factorgraph import dataset
+    # ---- (a) -------------------------------------------------------------------------------------------------------------------------
+    items = []
+    for i in range(8 * 12):
+        items += dataset.random_ksat_items(1, 40 + (i % 5) * 8, 3, seed=88000 + i)
+    path = tmp_path / 'c3.json'
+    path.write_text("\n".join(_lines(items)) + "\n")
+    argv = [os.path.join(REPO, 'config', 'Predict', 'PDP-np-nd-np-demo-h128.yaml'), str(path), '12', '-z', '12', '-s', '3', '-w', '50', '--rng', 'philox',
+            '-l', '4000000000', '-v']
+    one, _ = _run(argv, 1, str(tmp_path / 'c3_one.jsonl'), 0)
+    eight, log = _run(argv, 8, str(tmp_path / 'c3_eight.jsonl'), 29781)
+    assert len(one) == len(items) and eight == one
+    units = {int(m.group(1)): int(m.group(2)) for m in re.finditer(r'rank (\d) of 8 solved (\d+) units', log)}
+    assert units == {r: 1 for r in range(8)}
+    t3 = _timing_lines(log)
+    assert len(t3) == 8 and all(n_ex == 0 for _, _, n_ex, _ in t3)
+    print('configs[3] shape, 8 gloo ranks on one GPU: gather of %d rows %.1f ms on the writer' % (len(items), [g for r, g, _, _ in t3 if r == 0][0]))
+    # ---- (b) -------------------------------------------------------------------------------------------------------------------------
+    items = []
+    for i in range(64):
+        # (mixed 3- / 4-SAT; every instance fits the LDS-resident solver -- a coupled forward runs on that one only, a part that cannot take it
+        #  sends the whole segment to one rank: test_split_forward_falls_back_...)
+        k = 4 if i % 3 == 0 else 3
+        items += dataset.random_ksat_items(1, (40 + 3 * (i % 7)) if k == 4 else (60 + 7 * (i % 9)), k, seed=89000 + i)
+    path = tmp_path / 'c4.json'
+    path.write_text("\n".join(_lines(items)) + "\n")
+    argv = [os.path.join(REPO, 'config', 'Predict', 'PDP-p-d-p-sp-pytorch.yaml'), str(path), '60', '-z', '5000', '-s', '11', '-w', '40', '--rng', 'philox',
+            '-l', '4000000000', '-v']
+    one, _ = _run(argv, 1, str(tmp_path / 'c4_one.jsonl'), 0)
+    eight, log = _run(argv + ['--split-forward'], 8, str(tmp_path / 'c4_eight.jsonl'), 29783)
+    assert len(one) == len(items) and eight == one
+    assert 'coupled forwards spread over the ranks' in log
+    t4 = _timing_lines(log)
+    assert len(t4) == 8
+    assert 'solved whole' not in log and all(n_ex >= 3 for _, _, n_ex, _ in t4)         # 60 sweeps = 3 chunks of 25 (+ the Walk-SAT record)
+    print('configs[4] shape (strict, --split-forward), 8 gloo ranks on one GPU: %d exchanges per rank, %.3f ms each (max over ranks); gather %.1f ms'
+          % (max(n for _, _, n, _ in t4), max(ms for _, _, _, ms in t4), [g for r, g, _, _ in t4 if r == 0][0]))
