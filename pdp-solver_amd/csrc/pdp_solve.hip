@@ -812,11 +812,11 @@ __device__ __forceinline__ float frc_of(uint16_t pw) { return frc_dec(((uint32_t
 #define PC_EM 0x8000u      /* current edge mask bit */
 #define PC_EM_USED 0x4000u /* edge mask bit the last propagate used (needed to rebuild q_s / q_dc at exit) */
 
-static size_t lds2_bytes_for(int n, int m, int e, bool force)
+static size_t lds2_bytes_for(int n, int m, int e)
 {
     auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     size_t s = 0;
-    s += (force ? 6 : 5) * a16((size_t)e * 4);                 // QU, EA, EB, X, Y (, FORCE)
+    s += 5 * a16((size_t)e * 4);                               // QU, EA, EB, X, Y (an external force is a 2-bit code in the slot word)
     s += 3 * a16((size_t)e * 2);                               // pv, pc, e2p
     s += a16((size_t)(n + 1) * 2) + a16((size_t)(m + 1) * 2);  // v_ptr, f_ptr
     s += a16((size_t)(m + 8) * 4) + a16((size_t)m * 4);        // S (aliases flag_f/flag_f2), af
@@ -829,17 +829,16 @@ static size_t lds2_bytes_for(int n, int m, int e, bool force)
 // every LDS array of the v2 kernel, derived from (base, n, m, e): cold code re-derives them instead of keeping ~25
 // pointers alive across the hot loop (they would spill out of the SGPR file)
 struct LdsArrays {
-    float *QU, *EA, *EB, *X, *Y, *FRC;
+    float *QU, *EA, *EB, *X, *Y;
     uint16_t *pvv, *pcc, *e2p, *v_ptr, *f_ptr;
     float *S, *af, *av, *sol, *Pv, *Nv, *xv1, *xv2, *coeff;
     uint8_t *flag_v;
     uint16_t *vord;      // variables in order of descending degree: a wave of 64 consecutive entries runs loops of similar length
 };
-__device__ __forceinline__ LdsArrays carve_all(unsigned char *cp, int n, int m, int ne, bool force)
+__device__ __forceinline__ LdsArrays carve_all(unsigned char *cp, int n, int m, int ne)
 {
     LdsArrays L;
     L.QU = carve<float>(cp, ne); L.EA = carve<float>(cp, ne); L.EB = carve<float>(cp, ne); L.X = carve<float>(cp, ne); L.Y = carve<float>(cp, ne);
-    L.FRC = force ? carve<float>(cp, ne) : nullptr;
     L.pvv = carve<uint16_t>(cp, ne); L.pcc = carve<uint16_t>(cp, ne); L.e2p = carve<uint16_t>(cp, ne);
     L.v_ptr = carve<uint16_t>(cp, n + 1); L.f_ptr = carve<uint16_t>(cp, m + 1);
     L.S = carve<float>(cp, m + 8); L.af = carve<float>(cp, m);
@@ -1166,7 +1165,8 @@ __device__ __noinline__ int lds_decimate(uint32_t smem_off, uint32_t cold_off, i
 {
     unsigned char *const smem = lds_at<unsigned char>(smem_off);
     ColdShared *const cs = lds_at<ColdShared>(cold_off);
-    const LdsArrays L = carve_all(smem, n, m, ne, FORCE);
+    const LdsArrays L = carve_all(smem, n, m, ne);
+    constexpr int VMD = FORCE ? PV_VMASK_RF : 0x3fff;       // variable id of a slot word (with a force two of its bits are the force code)
     const int tid = threadIdx.x, lane = tid & 63;
     float *Enew = cur ? L.EA : L.EB;
     float *score = L.xv2, *assign = L.coeff;
@@ -1214,18 +1214,18 @@ __device__ __noinline__ int lds_decimate(uint32_t smem_off, uint32_t cold_off, i
         for (; p + 7 < bnd; p += 8) {                // all loads of a batch first: one LDS round trip per eight edges
             float f[8], fr[8]; uint16_t pw[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { f[j] = SL[p + j]; pw[j] = L.pvv[p + j]; fr[j] = FORCE ? L.FRC[p + j] : 0.0f; }
+            for (int j = 0; j < 8; ++j) { f[j] = SL[p + j]; pw[j] = L.pvv[p + j]; fr[j] = FORCE ? frc_of(pw[j]) : 0.0f; }
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc(f[j], pw[j], fr[j]);
         }
         for (; p + 3 < bnd; p += 4) {
             float f[4], fr[4]; uint16_t pw[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { f[j] = SL[p + j]; pw[j] = L.pvv[p + j]; fr[j] = FORCE ? L.FRC[p + j] : 0.0f; }
+            for (int j = 0; j < 4; ++j) { f[j] = SL[p + j]; pw[j] = L.pvv[p + j]; fr[j] = FORCE ? frc_of(pw[j]) : 0.0f; }
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc(f[j], pw[j], fr[j]);
         }
-        for (; p < bnd; ++p) acc(SL[p], L.pvv[p], FORCE ? L.FRC[p] : 0.0f);
+        for (; p < bnd; ++p) { const uint16_t pw1 = L.pvv[p]; acc(SL[p], pw1, FORCE ? frc_of(pw1) : 0.0f); }
         const float sc = lds_score_of(pos, neg, all, ext, Lpi, L0);
         const float co = (pdp_abs(sc) * L.av[v]) * 1.0f;
         score[v] = sc; L.coeff[v] = co;
@@ -1252,7 +1252,7 @@ __device__ __noinline__ int lds_decimate(uint32_t smem_off, uint32_t cold_off, i
     if (!(active && anynz && !cn && li >= 0)) return ret | (verified << DEC_VERIFIED_SHIFT);
     const float sgn_li = pdp_sign(score[li]);
     DEC_PROF_MARK(18);                                // arg-max
-    const LView I = make_lview(L, 0, n, m, ne, nt, cs->red);  // (the view's batch id is unused)
+    const LView I = make_lview(L, 0, n, m, ne, nt, cs->red, VMD);  // (the view's batch id is unused)
     SimplifyScratch ss;
     ss.assign = assign; ss.deg = reinterpret_cast<int32_t *>(L.xv1); ss.sdeg = reinterpret_cast<int32_t *>(L.xv2);
     ss.flag_v = L.flag_v; ss.flag_f = reinterpret_cast<uint8_t *>(L.S); ss.flag_f2 = ss.flag_f + ((m + 15) & ~15); ss.red = cs->red;
@@ -1269,7 +1269,7 @@ __device__ __noinline__ int lds_decimate(uint32_t smem_off, uint32_t cold_off, i
         for (int c = tid; c < m; c += nt) {
             if (L.af[c] == 1.0f) {
                 float deg = 0.0f;
-                for (int k = L.f_ptr[c]; k < L.f_ptr[c + 1]; ++k) deg = deg + L.av[L.pvv[L.e2p[k]] & 0x3fff];
+                for (int k = L.f_ptr[c]; k < L.f_ptr[c + 1]; ++k) deg = deg + L.av[L.pvv[L.e2p[k]] & VMD];
                 if (deg == 1.0f) bad = 1;
             }
         }
@@ -1303,7 +1303,7 @@ __device__ __noinline__ int lds_decimate(uint32_t smem_off, uint32_t cold_off, i
             if (satisfied && L.af[c] == 1.0f) {
                 L.af[c] = 0.0f;
                 for (int k = L.f_ptr[c]; k < L.f_ptr[c + 1]; ++k) {
-                    const int u = L.pvv[L.e2p[k]] & 0x3fff;
+                    const int u = L.pvv[L.e2p[k]] & VMD;
                     if (u != li && L.av[u] == 1.0f) L.flag_v[u] = 1;      // lost a clause: may have become pure
                 }
             }
@@ -1316,7 +1316,7 @@ __device__ __noinline__ int lds_decimate(uint32_t smem_off, uint32_t cold_off, i
             const int c = L.pcc[a + j] & 0x3fff;
             if (L.af[c] == 1.0f) {
                 float deg = 0.0f;
-                for (int k = L.f_ptr[c]; k < L.f_ptr[c + 1]; ++k) deg = deg + L.av[L.pvv[L.e2p[k]] & 0x3fff];
+                for (int k = L.f_ptr[c]; k < L.f_ptr[c + 1]; ++k) deg = deg + L.av[L.pvv[L.e2p[k]] & VMD];
                 if (deg == 1.0f) single = 1;
             }
         }
@@ -1368,7 +1368,7 @@ __device__ __noinline__ int lds_decimate(uint32_t smem_off, uint32_t cold_off, i
 __device__ __noinline__ int lds_reinforce_step(uint32_t smem_off, uint32_t cold_off, int nt, int n, int m, int ne, int cur, float pi, int do_force)
 {
     ColdShared *const cs = lds_at<ColdShared>(cold_off);
-    const LdsArrays L = carve_all(lds_at<unsigned char>(smem_off), n, m, ne, false);
+    const LdsArrays L = carve_all(lds_at<unsigned char>(smem_off), n, m, ne);
     const int tid = threadIdx.x;
     int bad = 0;
     if (do_force) {
@@ -1464,8 +1464,8 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
     __shared__ int s_inst;                                  // listed instance id, parked for the final writes (a scalar register less across the loop)
     if ((LISTED || REPLAY) && tid == 0) s_inst = G.b;
     const int n = G.n, m = G.m, ne = G.e;
-    const LdsArrays L = carve_all(smem, n, m, ne, FORCE && !RF);
-    constexpr int VM = RF ? PV_VMASK_RF : 0x3fff;           // variable id of a slot word
+    const LdsArrays L = carve_all(smem, n, m, ne);
+    constexpr int VM = FORCE ? PV_VMASK_RF : 0x3fff;        // variable id of a slot word (with a force: two of its bits are the force code)
     float *const QU = L.QU, *const X = L.X, *const Y = L.Y;
     uint16_t *const pvv = L.pvv, *const pcc = L.pcc;
     const BlobLayout BL = blob_layout(n, m, ne);
@@ -1490,7 +1490,7 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
             const uint4 *g = reinterpret_cast<const uint4 *>(src);
             for (int i = tid; i < (int)((bytes + 15) >> 4); i += nt) d[i] = g[i];
         };
-        if constexpr (RF) {                                                    // variable word | force code of the slot
+        if constexpr (FORCE) {                                                 // variable word | force code of the slot
             const uint16_t *spv = reinterpret_cast<const uint16_t *>(stt + BL.pvv);
             for (int p = tid; p < ne; p += nt) pvv[p] = (uint16_t)(spv[p] | (frc_enc(sp.frc_in[G.e0 + p]) << PV_FRC_SHIFT));
         } else copy16(pvv, stt + BL.pvv, (size_t)ne * 2);
@@ -1499,10 +1499,6 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
         copy16(L.vord, stt + BL.vord, (size_t)n * 2);
         copy16(QU, din + BL.QU, (size_t)ne * 4); copy16(L.EA, din + BL.E, (size_t)ne * 4); copy16(pcc, din + BL.pcc, (size_t)ne * 2);
         copy16(L.af, din + BL.af, (size_t)m * 4); copy16(L.av, din + BL.av, (size_t)n * 4); copy16(L.sol, din + BL.sol, (size_t)n * 4);
-        if constexpr (FORCE && !RF) {
-            const float *sfs = sp.src_fs + 2 * (size_t)G.e0;                   // the external-force column is an input only
-            for (int p = tid; p < ne; p += nt) L.FRC[p] = sfs[2 * G.v_edges[p] + 1];
-        }
     }
     __shared__ __attribute__((aligned(16))) ColdShared s_cold;  // what the out-of-line routines share with the kernel (incl. SATProblem._is_sat)
     constexpr int SPEC_LOCAL = 64;
@@ -1750,7 +1746,7 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
             const float eta_old = Eold[p];
             const float xp = X[p];
             const float agg = S_[c] - xp;                       // the reference's 0 + S is a no-op: a sum that starts at +0 is never -0
-            const float force = RF ? frc_of(pw) : (FORCE ? L.FRC[p] : 0.0f);
+            const float force = FORCE ? frc_of(pw) : 0.0f;
             const float pos = Pv_[v], neg = Nv_[v];
             // The reference's (0.5 (1 + s)) * pos + (0.5 (1 - s)) * neg has coefficients 1 and 0: one product is the sum itself, the other an
             // exact zero.  R1 stores Pv / Nv so that they are never -0 (sums that start at +0), never infinite (sums of clamped logs) and NaN
@@ -2117,7 +2113,7 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
             const float s = slot_sign(pw);
             float y = pdp_safe_log_fin(1.0f - Eprev[p], PDP_SP_EPS);
             if (last_use_em) y = y * ((cw & PC_EM_USED) ? 1.0f : 0.0f);
-            const float force = RF ? (rf_last_flip ? X[p] : frc_of(pw)) : (FORCE ? L.FRC[p] : 0.0f);
+            const float force = RF ? (rf_last_flip ? X[p] : frc_of(pw)) : (FORCE ? frc_of(pw) : 0.0f);
             const float pos = 0.0f + L.Pv[v], neg = 0.0f + L.Nv[v];
             float same = (0.5f * (1.0f + s)) * pos + (0.5f * (1.0f - s)) * neg;
             same = same - y;
@@ -2269,10 +2265,11 @@ __global__ void __launch_bounds__(256) k_solve_import(PView pv, const float *q, 
     }
 }
 
-// Reinforce: the force column of the caller's [E,2] state in slot order
-__global__ void __launch_bounds__(256) k_force_import(PView pv, const float *fs, float *frc, SolveCtl *ctl0)
+// the force column of the caller's [E,2] state in slot order (Reinforce; the SP triple with an external force)
+__global__ void __launch_bounds__(256) k_force_import(PView pv, const float *fs, float *frc, SolveCtl *ctl0, const uint8_t *amask)
 {
     const Inst G = load_inst(pv, blockIdx.x);
+    if (!amask[G.b]) return;                      // an instance that enters inactive never runs: its force is never read
     const float *sfs = fs + 2 * (size_t)G.e0;
     int odd = 0;
     for (int p = threadIdx.x; p < G.e; p += blockDim.x) {
@@ -2520,7 +2517,7 @@ static int launch_hbm(pdp_problem *p, SolveParams sp, int count, hipStream_t s_,
 
 static bool instance_fits_lds(int n, int m, int e)
 {
-    return lds2_bytes_for(n, m, e, false) <= 160 * 1024 - 1024 && e < 65535 && n < 16384 && m < 16384;
+    return lds2_bytes_for(n, m, e) <= 160 * 1024 - 1024 && e < 65535 && n < 16384 && m < 16384;
 }
 
 // once per problem: which instances fit the LDS (fit_list / big_list), the byte offsets of the fitting instances' records and the records'
@@ -2596,7 +2593,7 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     const int64_t *stat_off = p->res_stat_off, *dyn_off = p->res_stat_off + B;
     // ---- control blocks, speculation record, replay list; call-entry snapshot for the failure path ---------------------------
     const size_t ctl_bytes = (size_t)nchunks * sizeof(SolveCtl) + sizeof(SolveCall) + 2 * (size_t)T * 4 + 2 * B * 4 + 64 + 2 * (B + 16) * 4 +
-                             (rf ? 2 * (E + 4) * sizeof(float) : 0) +          // Reinforce: two slot-major force columns
+                             ((rf || force) ? 2 * (E + 4) * sizeof(float) : 0) +   // slot-major force column (Reinforce: two, it changes from chunk to chunk)
                              ((B + 63) & ~(size_t)63);                          // ghost flags
     int status = ensure_bytes(&p->res_ctl, &p->res_ctl_bytes, ctl_bytes);
     if (status != PDP_OK) return status;
@@ -2680,12 +2677,14 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     sp.no_scorer_reuse = getenv("PDP_SOLVE_NO_SCORER_REUSE") ? 1 : 0;
     sp.no_event_look = getenv("PDP_SOLVE_NO_EVENT_LOOK") ? 1 : 0;
     float *frc_buf[2] = {nullptr, nullptr};
-    if (rf) {
+    if (rf || force) {
+        // the external force as a 2-bit code in the slot word (0, +1, -1, NaN; any other value raises the violation flag: the call fails over
+        // to the step-wise loop, which takes the column as it is).  The SP triple only reads it (one column for all chunks).
         frc_buf[0] = (float *)(((uintptr_t)(replay_list + B) + 15) & ~(uintptr_t)15); frc_buf[1] = frc_buf[0] + E + 4;
-        hipLaunchKernelGGL(k_force_import, dim3(p->B), dim3(256), 0, st, make_view(p), (const float *)a->fs, frc_buf[0], ctl);
+        hipLaunchKernelGGL(k_force_import, dim3(p->B), dim3(256), 0, st, make_view(p), (const float *)a->fs, frc_buf[0], ctl, (const uint8_t *)a->active_mask);
     }
-    // ghost flags: behind the replay list (and the Reinforce force columns)
-    uint8_t *ghost_flag = rf ? (uint8_t *)(frc_buf[1] + E + 4) : (uint8_t *)(((uintptr_t)(replay_list + B) + 15) & ~(uintptr_t)15);
+    // ghost flags: behind the replay list (and the force columns)
+    uint8_t *ghost_flag = (rf || force) ? (uint8_t *)(frc_buf[1] + E + 4) : (uint8_t *)(((uintptr_t)(replay_list + B) + 15) & ~(uintptr_t)15);
     PDP_HIP_CHECK(hipMemsetAsync(ghost_flag, 0, B, st));
     sp.ghost_flag = ghost_flag;
     // dispatch order of pass 1 (k_order_by_risk): behind the ghost flags
@@ -2743,7 +2742,7 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
         sp.prev_slots = (k == 0 && a->decimator->has_prev) ? p->res_prev_slots : nullptr;
         sp.ctl = ctl + k; sp.spec_used = spec + done; sp.spec_zero = spec + T + done;
         sp.dyn_in = p->res_dyn[k & 1]; sp.dyn_out = p->res_dyn[(k + 1) & 1];
-        sp.frc_in = frc_buf[k & 1]; sp.frc_out = frc_buf[(k + 1) & 1];
+        sp.frc_in = rf ? frc_buf[k & 1] : frc_buf[0]; sp.frc_out = rf ? frc_buf[(k + 1) & 1] : frc_buf[1];
         if (nbig) {
             // pass 1 of the big instances goes FIRST, on the side stream: its few workgroups take their CUs before the LDS-resident kernel
             // fills the chip, and the two kernels overlap (they meet in front of k_solve_post)
@@ -2970,7 +2969,7 @@ extern "C" int pdp_sp_solve(pdp_problem *p, pdp_solve_args *a, void *stream)
         // have), and the other parts are about to wait in the first chunk's exchange: the parts agree on it BEFORE anything else.  One part
         // that cannot -> every part returns PDP_ERR_SPECULATION (nothing was touched), which the host turns into "solve the segment whole
         // on one rank" (pdp.native.CoupledForwardFailed -> FactorGraphTrainerBase._predict_epoch).
-        const size_t lds_x = lds2_bytes_for(p->res_fit_n, p->res_fit_m, p->res_fit_e, true);       // (with the force column: either instantiation must fit)
+        const size_t lds_x = lds2_bytes_for(p->res_fit_n, p->res_fit_m, p->res_fit_e);
         const bool can_resident = p->res_nbig == 0 && p->fn_edges_identity && p->res_nfit > 0 && lds_x <= 160 * 1024 - 1024 &&
                                   getenv("PDP_SOLVE_FORCE_HBM") == nullptr;
         {
@@ -3043,10 +3042,10 @@ static int sp_solve_speculative(pdp_problem *p, pdp_solve_args *a, void *stream)
         // per-instance routing: the instances whose image fits run LDS-resident, the others on the HBM-resident kernel in the same chunk
         // loop; the launch is sized by the largest FITTING instance (Reinforce: the force is a 2-bit code in the slot word, no column)
         const int fn_ = p->res_fit_n, fm_ = p->res_fit_m, fe_ = p->res_fit_e;
-        const size_t lds_r = lds2_bytes_for(fn_, fm_, fe_, force_r && !rf_model);
+        const size_t lds_r = lds2_bytes_for(fn_, fm_, fe_);
         const bool hbm_forced = getenv("PDP_SOLVE_FORCE_HBM") != nullptr;          // the switch lets the tests reach the HBM-resident kernel with small instances
         const bool mixed_ok = p->res_nbig == 0 || getenv("PDP_SOLVE_NO_ROUTING") == nullptr;
-        const bool fits_r = p->fn_edges_identity && p->res_nfit > 0 && lds_r <= 160 * 1024 - 1024 && (!rf_model || fn_ < 8192) && mixed_ok && !hbm_forced && !exact;
+        const bool fits_r = p->fn_edges_identity && p->res_nfit > 0 && lds_r <= 160 * 1024 - 1024 && (!force_r || fn_ < 8192) && mixed_ok && !hbm_forced && !exact;
         // threads per instance: 256 for tiny instances, 512 while two workgroups share a CU, 1024 when the instance's LDS image allows
         // only one workgroup per CU (the same 16 waves per CU either way)
         int nt_r = fe_ <= 1024 ? 256 : (lds_r > 80 * 1024 ? 1024 : 512);
