@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """Condenses tools/profile_secondary.sh's rocprofv3 directories: per workload the kernel stats (top kernels) and, per kernel, the PMC
-counters per dispatch plus the derived ratios DESIGN.md quotes (MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES; wait share)."""
+counters per dispatch plus the derived ratios DESIGN.md quotes (MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES; the issue share of
+the other VALU instructions at 2 cycles each -- an fp32 MFMA occupies the SIMD's VALU issue, profiles/r06_mfma_valu_overlap.txt, so the two
+ADD; wait share).  Writes <root>/neural_pmc.json = the per-launch instruction counts of the hidden-128 kernels, which bench.py's `issue_bound`
+reads (copied to profiles/<tag>_neural_pmc.json)."""
+import json
 import csv
 import glob
 import os
@@ -8,6 +12,7 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
+neural_pmc = {}
 for work in sorted(os.listdir(root)):
     wd = os.path.join(root, work)
     if not os.path.isdir(wd):
@@ -35,7 +40,19 @@ for work in sorted(os.listdir(root)):
             print("        MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) = %.3f   (cycles per MFMA instruction: %.1f)"
                   % (v['SQ_VALU_MFMA_BUSY_CYCLES'] / (4.0 * v['SQ_BUSY_CU_CYCLES']), v['SQ_VALU_MFMA_BUSY_CYCLES'] / max(1.0, v.get('SQ_INSTS_MFMA', 0.0))))
             if 'SQ_INSTS_VALU' in v:
-                print("        VALU issue at 4 cycles per wave-instruction = 4 x SQ_INSTS_VALU / (4 x SQ_BUSY_CU_CYCLES) = %.3f   (MFMA + VALU = %.3f of the SIMD cycles)"
-                      % (v['SQ_INSTS_VALU'] / v['SQ_BUSY_CU_CYCLES'], (v['SQ_VALU_MFMA_BUSY_CYCLES'] / 4.0 + v['SQ_INSTS_VALU']) / v['SQ_BUSY_CU_CYCLES']))
+                other = v['SQ_INSTS_VALU'] - v.get('SQ_INSTS_MFMA', 0.0)          # SQ_INSTS_VALU counts the MFMAs too
+                print("        other VALU issue at 2 cycles per wave-instruction = 2 x (SQ_INSTS_VALU - SQ_INSTS_MFMA) / (4 x SQ_BUSY_CU_CYCLES) = %.3f   (MFMA + VALU = %.3f of the SIMD cycles)"
+                      % (2.0 * other / (4.0 * v['SQ_BUSY_CU_CYCLES']), (v['SQ_VALU_MFMA_BUSY_CYCLES'] + 2.0 * other) / (4.0 * v['SQ_BUSY_CU_CYCLES'])))
+            if work == 'neural128':
+                for key, prefix, unit in (('gru', 'void k_gru_pipe<65', 'edges'), ('agg_pre', 'void k_agg_pre_wave<65', 'edges'), ('agg_post', 'void k_agg_post_pf<26', 'edges'),
+                                          ('predict_head', 'void k_predict_rows_pf<', 'variables')):
+                    if k.startswith(prefix) and 'SQ_INSTS_MFMA' in v:
+                        neural_pmc[key] = {'kernel': k[5:].split('(')[0], 'unit': unit, 'SQ_INSTS_VALU': v['SQ_INSTS_VALU'], 'SQ_INSTS_MFMA': v['SQ_INSTS_MFMA'],
+                                           'SQ_VALU_MFMA_BUSY_CYCLES': v['SQ_VALU_MFMA_BUSY_CYCLES'],
+                                           'SQ_WAIT_ANY_over_SQ_WAVE_CYCLES': (v['SQ_WAIT_ANY'] / v['SQ_WAVE_CYCLES']) if v.get('SQ_WAVE_CYCLES') else None}
         if v.get('SQ_WAVE_CYCLES') and 'SQ_WAIT_ANY' in v:
             print("        SQ_WAIT_ANY / SQ_WAVE_CYCLES = %.3f" % (v['SQ_WAIT_ANY'] / v['SQ_WAVE_CYCLES']))
+
+if neural_pmc:
+    json.dump({'source': 'tools/profile_secondary.sh: rocprofv3 --pmc passes of bench.py --workload neural --hidden 128 (np-nd-np on 5 000 x n=200); counters per launch',
+               'edges': 12600000, 'variables': 999999, 'kernels': neural_pmc}, open(os.path.join(root, 'neural_pmc.json'), 'w'), indent=1)
