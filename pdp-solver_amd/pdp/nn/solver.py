@@ -15,6 +15,7 @@ Keeps the reference's class names, constructor arguments and ``forward`` / ``get
 import os
 import weakref
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -336,8 +337,9 @@ class PropagatorDecimatorSolverBase(nn.Module):
         can = self._can_run_persistent(sat_problem, is_training, check_termination, tuple(init_propagator_state[:2]) + tuple(init_decimator_state[:2]))
         if self._isolated and not can:
             raise native.NativeError("isolated-instance mode runs on the persistent SP loop only (p-d-p, standard termination check)")
-        if self._exchange is not None and not can:
-            raise native.NativeError("a coupled forward spread over several processes runs on the persistent SP loop only (p-d-p, standard termination check)")
+        if self._exchange is not None and not can and not self._neural_triple(sat_problem, is_training, check_termination):
+            raise native.NativeError("a coupled forward spread over several processes runs on the persistent SP loop (p-d-p, standard termination check) "
+                                     "or on a neural triple (np-nd-np / p-nd-np prediction), whose only coupling is the end of the loop")
         if can:
             out = self._forward_core_persistent(init_propagator_state, init_decimator_state, sat_problem, iteration_num, check_termination)
             if out is not None:
@@ -351,15 +353,13 @@ class PropagatorDecimatorSolverBase(nn.Module):
         return self._forward_core_stepwise(box, None, sat_problem, iteration_num, is_training, check_termination)
 
     # ---- the neural triples' loop, device-driven -------------------------------------------------------------------------------------------
-    def _can_run_graph_loop(self, sat_problem, iteration_num, is_training, check_termination):
+    def _neural_triple(self, sat_problem, is_training, check_termination):
         """np-nd-np / p-nd-np prediction: the library's neural decimator (no variable is ever fixed: the edge mask of the first sweep is the
         mask of every sweep) behind the neural or the adaptor-fed survey propagator, the variable-side neural predictor, the trainer's own
-        termination callback or none.  Anything else -- foreign plug-ins, training, graph features, kernel timing -- takes the step-wise loop."""
-        if is_training or os.environ.get('PDP_NO_GRAPH_LOOP') or native.kernel_timing_enabled():
-            return False
-        if int(iteration_num) < int(os.environ.get('PDP_GRAPH_LOOP_MIN_SWEEPS', '8')):
-            return False                                   # two captures per forward: a short loop is cheaper sweep by sweep
-        if check_termination is not None and not _is_standard_termination(check_termination):
+        termination callback or none.  Such a forward couples its instances in ONE place: `active_mask.sum() <= 0` ends the loop for all of them
+        (solver.py:383-384) -- which is why it can run device-driven (_forward_core_graph) and, spread over several processes, needs one bit
+        per sweep from the other parts (_forward_core_stepwise with self._exchange)."""
+        if is_training or (check_termination is not None and not _is_standard_termination(check_termination)):
             return False
         pr, de, pd = self._propagator, self._decimator, self._predictor
         if type(de) is not pdp_decimate.NeuralDecimator or type(pd) is not pdp_predict.NeuralPredictor:
@@ -370,7 +370,15 @@ class PropagatorDecimatorSolverBase(nn.Module):
             return False
         if pd._variable_classifier is None or pd._function_classifier is not None:
             return False
-        return self._exchange is None and not self._isolated and not any(getattr(m, '_train_path', False) for m in (pr, de, pd))
+        return not self._isolated and not any(getattr(m, '_train_path', False) for m in (pr, de, pd))
+
+    def _can_run_graph_loop(self, sat_problem, iteration_num, is_training, check_termination):
+        "a neural triple in one process; anything else -- foreign plug-ins, training, graph features, kernel timing, a split forward -- takes the step-wise loop"
+        if os.environ.get('PDP_NO_GRAPH_LOOP') or native.kernel_timing_enabled() or self._exchange is not None:
+            return False
+        if int(iteration_num) < int(os.environ.get('PDP_GRAPH_LOOP_MIN_SWEEPS', '8')):
+            return False                                   # two captures per forward: a short loop is cheaper sweep by sweep
+        return self._neural_triple(sat_problem, is_training, check_termination)
 
     def _forward_core_graph(self, box, sat_problem, iteration_num, check_termination):
         """The loop of solver.py:355-386 for the neural triples without a host round trip per sweep.  The first sweep runs as in the step-wise
@@ -509,7 +517,13 @@ class PropagatorDecimatorSolverBase(nn.Module):
                 prediction = self._predictor(decimator_state, sat_problem)
                 prediction = self._update_solution(prediction, sat_problem)
                 check_termination(active_mask, prediction, sat_problem)
-                if int(active_mask.sum().item()) <= 0:
+                still = int(active_mask.sum().item()) > 0
+                if self._exchange is not None:
+                    # a part of a coupled forward: the loop ends when no instance of ANY part is active (one bit, OR over the parts)
+                    word = np.array([1 if still else 0], dtype=np.uint32)
+                    self._exchange(np.zeros(0, np.uint32), np.zeros(0, np.uint32), word)
+                    still = bool(word[0])
+                if not still:
                     break
         self.last_run.update(path='stepwise', iterations=iters)
         self._active_mask = active_mask

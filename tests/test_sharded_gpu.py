@@ -355,3 +355,34 @@ def test_eight_ranks_on_the_shapes_of_configs_3_and_4(tmp_path):
     assert 'solved whole' not in log and all(n_ex >= 3 for _, _, n_ex, _ in t4)         # 60 sweeps = 3 chunks of 25 (+ the Walk-SAT record)
     print('configs[4] shape (strict, --split-forward), 8 gloo ranks on one GPU: %d exchanges per rank, %.3f ms each (max over ranks); gather %.1f ms'
           % (max(n for _, _, n, _ in t4), max(ms for _, _, _, ms in t4), [g for r, g, _, _ in t4 if r == 0][0]))
+
+
+def test_split_forward_of_a_neural_triple(tmp_path):
+    """configs[2]'s shape on several GPUs: ONE loader batch, one segment, np-nd-np (the weights trained here) -- with segment dealing one rank would
+    do all the work.  A neural triple couples its instances in one place, the end of the loop (`active_mask.sum() <= 0`, solver.py:383-384), so
+    --split-forward spreads the forward over the ranks as instance ranges and completes that one bit per sweep across them (OR over the parts);
+    the Walk-SAT behind it completes its record as for p-d-p.  Two and three ranks write the rows of the single process; the run where every
+    part would stop on its own count (--isolated is refused for neural triples, so: no exchange = a single rank per part) is not what is tested
+    here -- the parts must run the SAME number of sweeps, which the log shows."""
+    import re
+    from pdp.factorgraph import dataset
+    items = []
+    rng = np.random.RandomState(4)
+    for i in range(45):
+        n = int(rng.randint(10, 41))
+        items += dataset.random_ksat_items(1, n, 3, m=int(round(rng.uniform(2.0, 4.0) * n)), seed=98000 + i)
+    path = tmp_path / 'in.json'
+    path.write_text("\n".join(_lines(items)) + "\n")
+    for cfg_name, w in (('PDP-np-nd-np-demo-h128.yaml', '30'), ('PDP-p-nd-np-demo-h128.yaml', '0')):
+        argv = [os.path.join(REPO, 'config', 'Predict', cfg_name), str(path), '25', '-z', '5000', '-s', '9', '-w', w, '--rng', 'philox', '-l', '4000000000', '-v']
+        one, _ = _run(argv, 1, str(tmp_path / 'one.jsonl'), 0)
+        assert len(one) == len(items)
+        solved = sum(json.loads(l)['solved'] for l in one)
+        assert 0 < solved < len(items), "the batch should hold instances solved along the way and unsolved ones"
+        for ranks, port in ((2, 29791), (3, 29793)):
+            many, log = _run(argv + ['--split-forward'], ranks, str(tmp_path / ('r%d.jsonl' % ranks)), port)
+            assert many == one and 'coupled forwards spread over the ranks' in log and 'solved whole' not in log
+            for r in range(ranks):
+                assert ('rank %d of %d solved 1 units (forward calls): [(0, 0, %d)]' % (r, ranks, r)) in log
+            ex = _timing_lines(log)
+            assert len(ex) == ranks and len({n_ex for _, _, n_ex, _ in ex}) == 1 and ex[0][2] >= 1      # every part took part in every exchange
