@@ -376,6 +376,8 @@ class PropagatorDecimatorSolverBase(nn.Module):
         "a neural triple in one process; anything else -- foreign plug-ins, training, graph features, kernel timing, a split forward -- takes the step-wise loop"
         if os.environ.get('PDP_NO_GRAPH_LOOP') or native.kernel_timing_enabled() or self._exchange is not None:
             return False
+        if native.BUILD != 'parity':
+            return False                                   # (the frozen fast build allocates a per-stream workspace inside its GRU call: not capturable)
         if int(iteration_num) < int(os.environ.get('PDP_GRAPH_LOOP_MIN_SWEEPS', '8')):
             return False                                   # two captures per forward: a short loop is cheaper sweep by sweep
         return self._neural_triple(sat_problem, is_training, check_termination)
