@@ -94,6 +94,7 @@ struct SolveParams {
     uint32_t *risk;             // [B] LDS-resident pass 1: bits of the smallest q normalisation of the launch's last sweep (see k_order_by_risk); NULL: off
     int no_scorer_reuse;        // PDP_SOLVE_NO_SCORER_REUSE=1: the decimation's scorer always takes its own logs (A/B switch)
     int no_event_look;          // PDP_SOLVE_NO_EVENT_LOOK=1: pass-1 workgroups look for a recorded NaN sweep only when they start
+    int rf_no_fused_step;       // PDP_SOLVE_RF_NO_FUSED_STEP=1: a Reinforce coin sweep runs E2's plain form and its step uses X / Y as scratch (round 5's form)
     int adopt_poison;           // LDS-resident pass 1: take a first-NaN sweep other workgroups of the launch already recorded (PDP_SOLVE_NO_ADOPT=1: off)
     int lds_tickets;            // LDS-resident kernel, pass 1: 0 = instance blockIdx.x, else the number of instances the workgroups draw tickets for
     uint8_t *ghost_flag;        // LDS-resident kernel: [B] instances that left inactive with iterations to come (checked by k_ghost_check after the call)
@@ -1365,18 +1366,26 @@ __device__ __noinline__ int lds_decimate(uint32_t smem_off, uint32_t cold_off, i
 // sum of the force over the variable's edges > 0) and _update_solution (solver.py:388-399).  A variable's slots are contiguous and
 // read by its own thread only, so the new force is written in the same pass; the old force goes to X (free between E2 and the next E1):
 // the write-back rebuilds q_s / q_dc of the last sweep, which read the old force.  Returns 1 if a score was NaN.
-__device__ __noinline__ int lds_reinforce_step(uint32_t smem_off, uint32_t cold_off, int nt, int n, int m, int ne, int cur, float pi, int do_force)
+// `logs`: the sweep left the NEXT sweep's logs in X / Y (E2's fused form) and |delta eta| -- dead behind P5 -- in the q_u array; they must survive
+// this step.  1: the logs were taken under the edge mask: for a slot of an ACTIVE variable Y = log(max(1 - eta, 1e-40)) * mask IS the scorer's
+// log(max(1 - eta, 1e-10)) * clause flag except at a survey of exactly 1 (substituted on the fly, as lds_decimate does); an inactive variable's
+// terms are computed where they are used.  2: no edge mask yet (Y is not masked): the terms go to the q_u array.  Either way the force the
+// sweep read is parked in the q_u array instead of X (the exit path asks qu_is_delta where it is).  0: X / Y are this step's scratch.
+__device__ __noinline__ int lds_reinforce_step(uint32_t smem_off, uint32_t cold_off, int nt, int n, int m, int ne, int cur, float pi, int do_force, int logs)
 {
     ColdShared *const cs = lds_at<ColdShared>(cold_off);
     const LdsArrays L = carve_all(lds_at<unsigned char>(smem_off), n, m, ne);
     const int tid = threadIdx.x;
     int bad = 0;
-    if (do_force) {
-        const float *Enew = cur ? L.EA : L.EB;
+    const float *const Enew = cur ? L.EA : L.EB;
+    float *const SL = (logs == 2) ? L.QU : L.Y;           // the scorer's per-slot terms
+    if (do_force && logs != 1) {
         for (int p = tid; p < ne; p += nt)
-            L.Y[p] = pdp_safe_log_fin(1.0f - Enew[p], PDP_SCORER_EPS) * (0.0f + L.af[L.pcc[p] & 0x3fff]);
+            SL[p] = pdp_safe_log_fin(1.0f - Enew[p], PDP_SCORER_EPS) * (0.0f + L.af[L.pcc[p] & 0x3fff]);
         __syncthreads();
     }
+    // the two clamped values (without the substitution the key is a NaN, which equals nothing)
+    const float clamp_sp = (logs == 1) ? pdp_safe_log_fin(0.0f, PDP_SP_EPS) : __builtin_nanf(""), clamp_sc = pdp_safe_log_fin(0.0f, PDP_SCORER_EPS);
     const float Lpi = pdp_safe_log(1.0f - pi, PDP_SCORER_EPS), L0 = pdp_safe_log(1.0f - pi * 0.0f, PDP_SCORER_EPS);
     uint32_t *const codev = reinterpret_cast<uint32_t *>(L.xv2);      // per-variable force code of a renewal (xv2 is free outside the decimation)
     for (int i = tid; i < n; i += nt) {
@@ -1387,8 +1396,10 @@ __device__ __noinline__ int lds_reinforce_step(uint32_t smem_off, uint32_t cold_
             // the only ORDERED part of the renewal is the score's sums (ascending slot = ascending edge id); writing the new force to the
             // variable's slots is a slot-parallel pass below, and the predictor's sum of the new force is deg * sign exactly
             float ext = 0.0f, pos = 0.0f, neg = 0.0f, all = 0.0f;
+            const bool in_place = logs == 1 && L.av[v] == 1.0f;       // (an inactive variable's slots carry mask 0 in Y, the scorer wants the clause flag)
             for (int p = a; p < bnd; ++p) {
-                const float f = L.Y[p];
+                float f = SL[p];
+                if (logs == 1) f = in_place ? ((f == clamp_sp) ? clamp_sc : f) : pdp_safe_log_fin(1.0f - Enew[p], PDP_SCORER_EPS) * (0.0f + L.af[L.pcc[p] & 0x3fff]);
                 const uint16_t pw = L.pvv[p];
                 const bool ng = (pw & 0x8000) != 0;
                 ext = ext + frc_of(pw);
@@ -1411,10 +1422,11 @@ __device__ __noinline__ int lds_reinforce_step(uint32_t smem_off, uint32_t cold_
     }
     if (do_force) {
         __syncthreads();
-        // mask * sign + (1 - mask) * old with mask == 1 (old is finite here); X keeps the force the last sweep read
+        // mask * sign + (1 - mask) * old with mask == 1 (old is finite here); X -- the q_u array when X holds logs -- keeps the force the last sweep read
+        float *const keep = logs ? L.QU : L.X;
         for (int p = tid; p < ne; p += nt) {
             const uint16_t pw = L.pvv[p];
-            L.X[p] = frc_of(pw);
+            keep[p] = frc_of(pw);
             L.pvv[p] = (uint16_t)((pw & ~PV_FRC_MASK) | codev[pw & PV_VMASK_RF]);
         }
     }
@@ -1733,7 +1745,7 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
         // The two forms of the loop are separate loops: nothing to branch on per trip.
         // (Reinforce: in the sweeps whose coin renews no force -- the coins of a call are drawn up front -- nothing uses X / Y as scratch either)
         const bool rf_step_now = RF && ((sp.coins[sp.chunk_start + t] < sp.dprob) || nsat < 0);
-        const bool fuse_logs = !rf_step_now && (t + 1 < T) && has_prev && !prev_from_global;
+        const bool fuse_logs = (!rf_step_now || !sp.rf_no_fused_step) && (t + 1 < T) && has_prev && !prev_from_global;
         float nan_acc = 0.0f;
         const uint32_t log_em_or = use_em ? 0u : PC_EM;      // without an edge mask every slot counts
         // one slot's update: reads the slot's words, the three row sums and its own logs, stores the new survey and returns the new values
@@ -2009,8 +2021,11 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
             const int flip = (sp.coins[sp.chunk_start + t] < sp.dprob) && active;
             rf_last_flip = flip;
             if (flip || nsat < 0) {
-                if (UNI(lds_reinforce_step(lds_offset_of(smem), lds_offset_of(&s_cold), nt, n, m, ne, cur, pi, flip)) && !nan_seen) violation = 1;    // a NaN score without a NaN survey: not expected
-                rf_changed = 1; logs_ready = 0;             // (X / Y are its scratch, and the force changes)
+                // (a sweep that took the next one's logs keeps them: the step reads the scorer's terms from Y in place, or builds them in the q_u array)
+                const int keep_logs = fuse_logs ? (use_em ? 1 : 2) : 0;
+                if (UNI(lds_reinforce_step(lds_offset_of(smem), lds_offset_of(&s_cold), nt, n, m, ne, cur, pi, flip, keep_logs)) && !nan_seen) violation = 1;    // a NaN score without a NaN survey: not expected
+                rf_changed = 1;
+                if (!keep_logs) logs_ready = 0;             // (X / Y were its scratch)
             }
         }
         PROF_MARK(13);                                       // gate + bookkeeping of every sweep
@@ -2113,7 +2128,7 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
             const float s = slot_sign(pw);
             float y = pdp_safe_log_fin(1.0f - Eprev[p], PDP_SP_EPS);
             if (last_use_em) y = y * ((cw & PC_EM_USED) ? 1.0f : 0.0f);
-            const float force = RF ? (rf_last_flip ? X[p] : frc_of(pw)) : (FORCE ? frc_of(pw) : 0.0f);
+            const float force = RF ? (rf_last_flip ? (qu_is_delta ? QU[p] : X[p]) : frc_of(pw)) : (FORCE ? frc_of(pw) : 0.0f);
             const float pos = 0.0f + L.Pv[v], neg = 0.0f + L.Nv[v];
             float same = (0.5f * (1.0f + s)) * pos + (0.5f * (1.0f - s)) * neg;
             same = same - y;
@@ -2676,6 +2691,7 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     sp.adopt_poison = getenv("PDP_SOLVE_NO_ADOPT") ? 0 : 1;
     sp.no_scorer_reuse = getenv("PDP_SOLVE_NO_SCORER_REUSE") ? 1 : 0;
     sp.no_event_look = getenv("PDP_SOLVE_NO_EVENT_LOOK") ? 1 : 0;
+    sp.rf_no_fused_step = getenv("PDP_SOLVE_RF_NO_FUSED_STEP") ? 1 : 0;
     float *frc_buf[2] = {nullptr, nullptr};
     if (rf || force) {
         // the external force as a 2-bit code in the slot word (0, +1, -1, NaN; any other value raises the violation flag: the call fails over
