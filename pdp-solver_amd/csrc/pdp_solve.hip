@@ -1494,23 +1494,30 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
         return;
     }
 
-    // ---- load: coalesced 16-byte copies of the instance record --------------------------------------------------------------
+    // ---- load: the instance record, global memory -> LDS without a register round trip (LDS-DMA), every piece in flight at once ------------
+    // (round 6.  Eleven copy loops of the form `lds[i] = global[i]` compile to load / s_waitcnt vmcnt(0) / ds_write each: eleven DEPENDENT
+    //  round trips to the records, ~31 000 workgroup-cycles per instance and launch -- what tools/phase_prof.py showed as "E1", 7.6 % of a
+    //  call.  global_load_lds_dwordx4 writes LDS at [wave-uniform base + lane x 16], which is exactly a coalesced copy; it has no result
+    //  register, so nothing waits until the one s_waitcnt in front of the barrier.)
     {
         const char *const stt = sp.stat + sp.stat_off[G.b];
-        auto copy16 = [&](void *dst, const char *src, size_t bytes) {
-            uint4 *d = reinterpret_cast<uint4 *>(dst);
-            const uint4 *g = reinterpret_cast<const uint4 *>(src);
-            for (int i = tid; i < (int)((bytes + 15) >> 4); i += nt) d[i] = g[i];
+        auto dma16 = [&](void *dst, const char *src, size_t bytes) {
+            const int n16 = (int)((bytes + 15) >> 4);
+            for (int i = tid; i < n16; i += nt)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)i * 16),
+                                                 (__attribute__((address_space(3))) void *)(reinterpret_cast<uint4 *>(dst) + (i - lane)), 16, 0, 0);
         };
+        if constexpr (!FORCE) dma16(pvv, stt + BL.pvv, (size_t)ne * 2);
+        dma16(L.e2p, stt + BL.e2p, (size_t)ne * 2);
+        dma16(L.v_ptr, stt + BL.vptr, (size_t)(n + 1) * 2); dma16(L.f_ptr, stt + BL.fptr, (size_t)(m + 1) * 2);
+        dma16(L.vord, stt + BL.vord, (size_t)n * 2);
+        dma16(QU, din + BL.QU, (size_t)ne * 4); dma16(L.EA, din + BL.E, (size_t)ne * 4); dma16(pcc, din + BL.pcc, (size_t)ne * 2);
+        dma16(L.af, din + BL.af, (size_t)m * 4); dma16(L.av, din + BL.av, (size_t)n * 4); dma16(L.sol, din + BL.sol, (size_t)n * 4);
         if constexpr (FORCE) {                                                 // variable word | force code of the slot
             const uint16_t *spv = reinterpret_cast<const uint16_t *>(stt + BL.pvv);
             for (int p = tid; p < ne; p += nt) pvv[p] = (uint16_t)(spv[p] | (frc_enc(sp.frc_in[G.e0 + p]) << PV_FRC_SHIFT));
-        } else copy16(pvv, stt + BL.pvv, (size_t)ne * 2);
-        copy16(L.e2p, stt + BL.e2p, (size_t)ne * 2);
-        copy16(L.v_ptr, stt + BL.vptr, (size_t)(n + 1) * 2); copy16(L.f_ptr, stt + BL.fptr, (size_t)(m + 1) * 2);
-        copy16(L.vord, stt + BL.vord, (size_t)n * 2);
-        copy16(QU, din + BL.QU, (size_t)ne * 4); copy16(L.EA, din + BL.E, (size_t)ne * 4); copy16(pcc, din + BL.pcc, (size_t)ne * 2);
-        copy16(L.af, din + BL.af, (size_t)m * 4); copy16(L.av, din + BL.av, (size_t)n * 4); copy16(L.sol, din + BL.sol, (size_t)n * 4);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this wave's DMAs have landed; the barrier below publishes them
     }
     __shared__ __attribute__((aligned(16))) ColdShared s_cold;  // what the out-of-line routines share with the kernel (incl. SATProblem._is_sat)
     constexpr int SPEC_LOCAL = 64;
