@@ -2218,24 +2218,56 @@ __global__ void __launch_bounds__(256) k_solve_import(PView pv, const float *q, 
     extern __shared__ __attribute__((aligned(16))) float stage[];
     if (force_check) {
         // the force column shares its cache lines with the surveys read below: no extra HBM traffic (a NaN counts as a force)
+        // (four edges per trip: independent loads, one round trip for the four)
         int some = 0;
-        for (int e = tid; e < ne; e += nt) some |= (sfs[2 * e + 1] != 0.0f) ? 1 : 0;
+        for (int e0 = tid; e0 < ne; e0 += 4 * nt) {
+            float f[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int e = e0 + j * nt; f[j] = sfs[2 * (e < ne ? e : e0) + 1]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) some |= (f[j] != 0.0f) ? 1 : 0;
+        }
         if (__syncthreads_or(some) && tid == 0) atomicOr(&force_check->force_seen, 1u);
     }
     if (ne <= stage_cap) {
         float *sQ = stage, *sE = stage + stage_cap, *sM = stage + 2 * stage_cap, *sP = stage + 4 * stage_cap;
         int *sF = reinterpret_cast<int *>(stage + 3 * stage_cap);
-        for (int e = tid; e < ne; e += nt) {
-            sQ[e] = sq[3 * e]; sE[e] = sfs[2 * e]; sM[e] = G.emask[e]; sF[e] = G.e_fn[e];
-            if (has_prev) sP[e] = prev[G.e0 + e];
+        // (both loops take several elements per trip -- all their global loads first, then the LDS traffic: a one-element loop is one round
+        //  trip per element, ten in a row per loop for n = 200 on 256 threads)
+        for (int e0 = tid; e0 < ne; e0 += 4 * nt) {
+            float qv[4], ev[4], mv[4], pv[4] = {0.0f, 0.0f, 0.0f, 0.0f}; int fn[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = (e0 + j * nt < ne) ? e0 + j * nt : e0;
+                qv[j] = sq[3 * e]; ev[j] = sfs[2 * e]; mv[j] = G.emask[e]; fn[j] = G.e_fn[e];
+                if (has_prev) pv[j] = prev[G.e0 + e];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = e0 + j * nt;
+                if (e >= ne) continue;
+                sQ[e] = qv[j]; sE[e] = ev[j]; sM[e] = mv[j]; sF[e] = fn[j];
+                if (has_prev) sP[e] = pv[j];
+            }
         }
         __syncthreads();
-        for (int p = tid; p < ne; p += nt) {
-            const int e = G.v_edges[p];
-            if (build_static) { pvv[p] = (uint16_t)(G.e_var[e] | (G.sgn[e] < 0 ? 0x8000 : 0)); e2p[e] = (uint16_t)p; }
-            pcc[p] = (uint16_t)(sF[e] | ((sM[e] == 1.0f) ? (PC_EM | PC_EM_USED) : 0));
-            QU[p] = sQ[e]; Ecur[p] = sE[e];
-            if (has_prev) prev_slots[G.e0 + p] = sP[e];
+        for (int p0 = tid; p0 < ne; p0 += 8 * nt) {
+            int e[8], evar[8], esg[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int p = p0 + j * nt; e[j] = G.v_edges[p < ne ? p : p0]; }
+            if (build_static) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { evar[j] = G.e_var[e[j]]; esg[j] = G.sgn[e[j]]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int p = p0 + j * nt;
+                if (p >= ne) continue;
+                if (build_static) { pvv[p] = (uint16_t)(evar[j] | (esg[j] < 0 ? 0x8000 : 0)); e2p[e[j]] = (uint16_t)p; }
+                pcc[p] = (uint16_t)(sF[e[j]] | ((sM[e[j]] == 1.0f) ? (PC_EM | PC_EM_USED) : 0));
+                QU[p] = sQ[e[j]]; Ecur[p] = sE[e[j]];
+                if (has_prev) prev_slots[G.e0 + p] = sP[e[j]];
+            }
         }
     } else
     // four slots per trip: the gathers through v_edges are dependent loads, keep several of them in flight
@@ -2400,11 +2432,22 @@ __global__ void __launch_bounds__(256) k_simplify_lds(PView pv)
     float *av = carve<float>(cp, n), *sol = carve<float>(cp, n), *assign = carve<float>(cp, n), *af = carve<float>(cp, m);
     int32_t *deg = carve<int32_t>(cp, n), *sdeg = carve<int32_t>(cp, n);
     uint8_t *flag_v = carve<uint8_t>(cp, n), *flag_f = carve<uint8_t>(cp, m), *flag_f2 = carve<uint8_t>(cp, m);
-    for (int p = tid; p < ne; p += nt) {
-        const int e = G.v_edges[p];
-        pvv[p] = (uint16_t)(G.e_var[e] | (G.sgn[e] < 0 ? 0x8000 : 0));
-        pcc[p] = (uint16_t)G.e_fn[e];
-        e2p[e] = (uint16_t)p;                           // edges are clause-major: edge id == position in the by-clause list
+    // (eight slots per trip: the gathers through v_edges are two levels of dependent loads, and a loop that takes one slot per trip is one
+    //  pair of round trips per slot -- twenty in a row for n = 200 on 256 threads, which is what this kernel's time was made of)
+    for (int p0 = tid; p0 < ne; p0 += 8 * nt) {
+        int e[8], ev[8], ef[8], sg[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int p = p0 + j * nt; e[j] = G.v_edges[p < ne ? p : p0]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ev[j] = G.e_var[e[j]]; sg[j] = G.sgn[e[j]]; ef[j] = G.e_fn[e[j]]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int p = p0 + j * nt;
+            if (p >= ne) continue;
+            pvv[p] = (uint16_t)(ev[j] | (sg[j] < 0 ? 0x8000 : 0));
+            pcc[p] = (uint16_t)ef[j];
+            e2p[e[j]] = (uint16_t)p;                    // edges are clause-major: edge id == position in the by-clause list
+        }
     }
     for (int v = tid; v <= n; v += nt) v_ptr[v] = (uint16_t)G.v_ptr[v];
     for (int c = tid; c <= m; c += nt) f_ptr[c] = (uint16_t)G.f_ptr[c];
