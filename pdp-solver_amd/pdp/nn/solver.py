@@ -392,7 +392,6 @@ class PropagatorDecimatorSolverBase(nn.Module):
         (tests/test_api_forward.py::test_graph_loop_equals_the_stepwise_loop)."""
         T = int(iteration_num)
         nat = sat_problem._native
-        propagator_state, decimator_state = box.take()
         active_mask = None if check_termination is None else torch.ones(sat_problem._batch_size, 1, dtype=torch.uint8, device=self._device)
         am_flat = None if active_mask is None else active_mask.reshape(-1)
         all_active = [True]
@@ -419,9 +418,24 @@ class PropagatorDecimatorSolverBase(nn.Module):
             return tuple(ps[:2]), ds
 
         nat.loop_begin()
+        ended = False
+        try:
+            ps_a, ds_a, ps_b, ds_b, iters = self._graph_loop_body(sweep, box, nat, T, active_mask)
+            ended = True
+        finally:
+            if not ended:
+                nat.loop_read(end=True)                     # whatever went wrong: the stop word must not outlive the loop (later calls would write nothing)
+        if T > 1 and iters > 1 and iters % 2 == 0:
+            ps_a, ds_a = ps_b, ds_b
+        self.last_run.update(path='graph', iterations=iters)
+        self._active_mask = active_mask
+        return ps_a, ds_a
+
+    def _graph_loop_body(self, sweep, box, nat, T, active_mask):
+        propagator_state, decimator_state = box.take()      # the box is empty now: these two names are the only references
         ps_a, ds_a = sweep(propagator_state, decimator_state, None, None, True)
         del propagator_state, decimator_state               # the initial state goes (its four [E, H] tensors are dead after the first sweep)
-        iters = 1
+        ps_b = ds_b = None
         if T > 1:
             ps_b = tuple(torch.empty_like(x) for x in ps_a[:2])
             ds_b2 = tuple(torch.empty_like(x) for x in ds_a[:2])
@@ -446,11 +460,7 @@ class PropagatorDecimatorSolverBase(nn.Module):
                     if stopped:
                         break
         stopped, iters = nat.loop_read(end=True)
-        if T > 1 and iters > 1 and iters % 2 == 0:
-            ps_a, ds_a = ps_b, ds_b
-        self.last_run.update(path='graph', iterations=iters)
-        self._active_mask = active_mask
-        return ps_a, ds_a
+        return ps_a, ds_a, ps_b, ds_b, iters
 
     def _forward_core_persistent(self, init_propagator_state, init_decimator_state, sat_problem, iteration_num, check_termination):
         """the whole loop of solver.py:355-386 in one kernel launch; None if the speculation failed.  The first sweep reads the
