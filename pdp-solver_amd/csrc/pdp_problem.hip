@@ -229,6 +229,18 @@ __global__ void k_fill(float *p, int64_t n, float v)
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
+// SATProblem's fresh state (solver.py:49-54): active flags 1, solution 0.5, _is_sat 0.5, edge mask 1
+__global__ void k_bind_fill(float *av, float *sol, int64_t V, float *af, int64_t F, float *is_sat, int64_t B, float *emask, int64_t E)
+{
+    const int64_t n = E > F ? (E > V ? E : V) : (F > V ? F : V);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < V) { av[i] = 1.0f; sol[i] = 0.5f; }
+        if (i < F) af[i] = 1.0f;
+        if (i < B) is_sat[i] = 0.5f;
+        if (i < E) emask[i] = 1.0f;
+    }
+}
+
 static inline int grid_for(int64_t n, int nt = 256) { int64_t g = (n + nt - 1) / nt; if (g < 1) g = 1; if (g > 8192) g = 8192; return (int)g; }
 
 // ---- cached device allocator ---------------------------------------------------------------------------------------------------
@@ -516,11 +528,9 @@ extern "C" int pdp_problem_bind_state(pdp_problem *p, float *av, float *af, floa
     PDP_REQUIRE(p && av && af && sol && is_sat && emask, "NULL argument");
     hipStream_t st = (hipStream_t)stream;
     p->av = av; p->af = af; p->sol = sol; p->is_sat = is_sat; p->emask = emask; p->has_edge_mask = 0;
-    hipLaunchKernelGGL(k_fill, dim3(grid_for(p->V)), dim3(256), 0, st, av, (int64_t)p->V, 1.0f);
-    hipLaunchKernelGGL(k_fill, dim3(grid_for(p->F)), dim3(256), 0, st, af, (int64_t)p->F, 1.0f);
-    hipLaunchKernelGGL(k_fill, dim3(grid_for(p->V)), dim3(256), 0, st, sol, (int64_t)p->V, 0.5f);
-    hipLaunchKernelGGL(k_fill, dim3(grid_for(p->B)), dim3(256), 0, st, is_sat, (int64_t)p->B, 0.5f);
-    hipLaunchKernelGGL(k_fill, dim3(grid_for(p->E)), dim3(256), 0, st, emask, (int64_t)p->E, 1.0f);
+    // one launch for the five arrays (five fills were five launches and their gaps: ~45 us of a 9 ms headline step)
+    hipLaunchKernelGGL(k_bind_fill, dim3(grid_for(p->E > p->F ? p->E : p->F)), dim3(256), 0, st, av, sol, (int64_t)p->V, af, (int64_t)p->F, is_sat, (int64_t)p->B,
+                       emask, (int64_t)p->E);
     PDP_LAUNCH_CHECK();
     return PDP_OK;
 }

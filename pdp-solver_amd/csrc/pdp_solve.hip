@@ -2484,6 +2484,23 @@ struct SolveSnapshot {
 // skip: bit 0 the messages q / fs (the caller declared them disposable: pdp_solve_args.inputs_disposable), bit 1 the decimator's previous
 // surveys (no previous state at call entry: the handle's has_prev flag says their content means nothing), bit 2 the edge mask (likewise
 // p->has_edge_mask).  Only the call-entry snapshot of the LDS-resident path uses it: 378 MB of copies on config 2 shrink to 25 MB.
+// up to ten device-to-device copies in ONE launch (ten hipMemcpyAsync were ten launches of the runtime's copy kernel, ~5 us each and serialised)
+struct CopyList { const char *src[10]; char *dst[10]; size_t bytes[10]; int n; };
+__global__ void __launch_bounds__(256) k_copy_list(CopyList c)
+{
+    const int k = blockIdx.y;
+    if (k >= c.n) return;
+    const size_t bytes = c.bytes[k], n16 = bytes >> 4;
+    const char *src = c.src[k]; char *dst = c.dst[k];
+    const bool aligned = ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0;
+    const size_t start = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    if (aligned) {
+        for (size_t i = start; i < n16; i += stride) reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(src)[i];
+        for (size_t i = (n16 << 4) + start; i < bytes; i += stride) dst[i] = src[i];
+    } else {
+        for (size_t i = start; i < bytes; i += stride) dst[i] = src[i];
+    }
+}
 static int snapshot_copy(pdp_problem *p, pdp_solve_args *a, SolveSnapshot &s, bool save, hipStream_t st, int skip = 0)
 {
     const size_t E = p->E, V = p->V, F = p->F, B = p->B;
@@ -2491,11 +2508,20 @@ static int snapshot_copy(pdp_problem *p, pdp_solve_args *a, SolveSnapshot &s, bo
         {a->q, s.q, 3 * E * 4, 1}, {a->fs, s.fs, 2 * E * 4, 1}, {p->av, s.av, V * 4, 0}, {p->af, s.af, F * 4, 0}, {p->sol, s.sol, V * 4, 0},
         {p->is_sat, s.sat, B * 4, 0}, {p->emask, s.emask, E * 4, 4}, {a->decimator->prev, s.prev, E * 4, 2},
         {a->decimator->counters, s.cnt, B * 4, 0}, {a->active_mask, s.amask, B, 0}};
+    CopyList c; c.n = 0;
+    size_t longest = 0;
     for (auto &it : items) {
-        if (skip & it.skip_bit) continue;
-        if (save) PDP_HIP_CHECK(hipMemcpyAsync(it.snap, it.live, it.bytes, hipMemcpyDeviceToDevice, st));
-        else PDP_HIP_CHECK(hipMemcpyAsync(it.live, it.snap, it.bytes, hipMemcpyDeviceToDevice, st));
+        if ((skip & it.skip_bit) || it.bytes == 0) continue;
+        c.src[c.n] = (const char *)(save ? it.live : it.snap); c.dst[c.n] = (char *)(save ? it.snap : it.live); c.bytes[c.n] = it.bytes;
+        if (it.bytes > longest) longest = it.bytes;
+        ++c.n;
     }
+    if (c.n == 0) return PDP_OK;
+    size_t gx = (longest / 16 + 255) / 256;
+    if (gx < 1) gx = 1;
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(k_copy_list, dim3((unsigned)gx, (unsigned)c.n), dim3(256), 0, st, c);
+    PDP_LAUNCH_CHECK();
     return PDP_OK;
 }
 
@@ -2524,17 +2550,15 @@ __global__ void __launch_bounds__(1024) k_order_by_risk(int B, const uint32_t *r
     __syncthreads();
     for (int b = threadIdx.x; b < B; b += blockDim.x) order[atomicAdd(&hist[(risk[b] >> 23) & 255], 1)] = b;
 }
-__global__ void k_order_identity(int B, int32_t *order, uint32_t *risk)
-{
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B) { order[b] = b; risk[b] = 0xffffffffu; }
-}
-
-__global__ void k_solve_ctl_init(SolveCtl *ctl, int nchunks, SolveCall *call)
+// everything a call's device-side control starts from, in one launch: the per-chunk blocks, the call block, the speculation record, the
+// ghost flags and the identity dispatch order (was: this kernel + two memsets + k_order_identity, four launches and their gaps)
+__global__ void k_solve_ctl_init(SolveCtl *ctl, int nchunks, SolveCall *call, uint32_t *spec, int spec_words, uint8_t *ghost_flag, int B, int32_t *order, uint32_t *risk)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nchunks) { SolveCtl c; memset(&c, 0, sizeof(c)); c.nan_iter = 0xffffffffu; c.perm_zero = 0xffffffffu; c.poison_from = 0x7fffffff; ctl[i] = c; }
     if (i == 0) { SolveCall z; memset(&z, 0, sizeof(z)); *call = z; }
+    if (i < spec_words) spec[i] = 0u;
+    if (i < B) { ghost_flag[i] = 0; if (order) { order[i] = i; risk[i] = 0xffffffffu; } }
 }
 
 static int ensure_bytes(char **ptr, size_t *have, size_t need)
@@ -2714,10 +2738,25 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
         for (; p->res_events_n < 4 * nchunks; ++p->res_events_n) PDP_HIP_CHECK(hipEventCreate(&p->res_events[p->res_events_n]));
     }
 
-    hipLaunchKernelGGL(k_solve_ctl_init, dim3((nchunks + 255) / 256), dim3(256), 0, st, ctl, nchunks, call);
-    PDP_HIP_CHECK(hipMemsetAsync(spec, 0, 2 * (size_t)T * 4, st));
     const int nfit = p->res_nfit, nbig = p->res_nbig;
     const int32_t *fit_list = nbig ? p->res_fit_list : nullptr;                 // all instances fit: instance = block index
+    // where the rest of the control block lies (host arithmetic only): the force columns (Reinforce / an external force), the ghost flags, the
+    // dispatch order of pass 1 -- and whether pass 1 is risk-ordered at all
+    float *frc_buf[2] = {nullptr, nullptr};
+    if (rf || force) { frc_buf[0] = (float *)(((uintptr_t)(replay_list + B) + 15) & ~(uintptr_t)15); frc_buf[1] = frc_buf[0] + E + 4; }
+    uint8_t *ghost_flag = (rf || force) ? (uint8_t *)(frc_buf[1] + E + 4) : (uint8_t *)(((uintptr_t)(replay_list + B) + 15) & ~(uintptr_t)15);
+    uint32_t *risk = (uint32_t *)(((uintptr_t)(ghost_flag + ((B + 63) & ~(size_t)63)) + 15) & ~(uintptr_t)15);
+    int32_t *order = (int32_t *)(risk + B + 8);
+    // ticketed LDS-resident pass (see k_sp_solve_lds): on for mixed batches; PDP_SOLVE_TICKETS=<percent of over-provisioning>, 0 = off
+    int ticket_extra = nbig > 0 ? 25 : 0;
+    if (const char *env = getenv("PDP_SOLVE_TICKETS")) ticket_extra = atoi(env);
+    // a batch that is LDS-resident as a whole: pass 1 takes its instances in the order of k_order_by_risk (PDP_SOLVE_NO_RISK_ORDER=1: block index)
+    const bool risk_order = nbig == 0 && ticket_extra <= 0 && !fit_list && nchunks > 1 && !a->isolate_instances && getenv("PDP_SOLVE_NO_RISK_ORDER") == nullptr;
+    {
+        const int words = 2 * T, cover = (int)B > words ? (int)B : words;
+        hipLaunchKernelGGL(k_solve_ctl_init, dim3(((cover > nchunks ? cover : nchunks) + 255) / 256), dim3(256), 0, st, ctl, nchunks, call, spec, words, ghost_flag, (int)B,
+                           risk_order ? order : (int32_t *)nullptr, risk);
+    }
     // staging area of the import: five columns of the largest fitting instance
     int stage_cap = (p->res_fit_e + 3) & ~3;
     if (stage_cap > 7936) stage_cap = 0;                                           // (159 KB / 20 bytes; 0: gather from global memory)
@@ -2742,20 +2781,12 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     sp.no_scorer_reuse = getenv("PDP_SOLVE_NO_SCORER_REUSE") ? 1 : 0;
     sp.no_event_look = getenv("PDP_SOLVE_NO_EVENT_LOOK") ? 1 : 0;
     sp.rf_no_fused_step = getenv("PDP_SOLVE_RF_NO_FUSED_STEP") ? 1 : 0;
-    float *frc_buf[2] = {nullptr, nullptr};
     if (rf || force) {
         // the external force as a 2-bit code in the slot word (0, +1, -1, NaN; any other value raises the violation flag: the call fails over
         // to the step-wise loop, which takes the column as it is).  The SP triple only reads it (one column for all chunks).
-        frc_buf[0] = (float *)(((uintptr_t)(replay_list + B) + 15) & ~(uintptr_t)15); frc_buf[1] = frc_buf[0] + E + 4;
         hipLaunchKernelGGL(k_force_import, dim3(p->B), dim3(256), 0, st, make_view(p), (const float *)a->fs, frc_buf[0], ctl, (const uint8_t *)a->active_mask);
     }
-    // ghost flags: behind the replay list (and the force columns)
-    uint8_t *ghost_flag = (rf || force) ? (uint8_t *)(frc_buf[1] + E + 4) : (uint8_t *)(((uintptr_t)(replay_list + B) + 15) & ~(uintptr_t)15);
-    PDP_HIP_CHECK(hipMemsetAsync(ghost_flag, 0, B, st));
-    sp.ghost_flag = ghost_flag;
-    // dispatch order of pass 1 (k_order_by_risk): behind the ghost flags
-    uint32_t *risk = (uint32_t *)(((uintptr_t)(ghost_flag + ((B + 63) & ~(size_t)63)) + 15) & ~(uintptr_t)15);
-    int32_t *order = (int32_t *)(risk + B + 8);
+    sp.ghost_flag = ghost_flag;                             // (cleared by k_solve_ctl_init, like the identity dispatch order)
     sp.last_event = last_event; sp.inst_list = replay_list;
     sp.call = call; sp.stat = p->res_stat; sp.stat_off = stat_off; sp.dyn_off = dyn_off;
     sp.fit_list = fit_list;
@@ -2783,16 +2814,8 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     // an error return between here and the final synchronisation must not leave work on the side stream that still reads the caller's arrays
     struct SideJoin { hipStream_t s; bool on; ~SideJoin() { if (on && s) (void)hipStreamSynchronize(s); } } side_join{side, nbig > 0};
     auto launch_big = [&](const SolveParams &spx, hipStream_t s_) { return launch_hbm(p, spx, nbig, s_); };
-    // ticketed LDS-resident pass (see k_sp_solve_lds): on for mixed batches; PDP_SOLVE_TICKETS=<percent of over-provisioning>, 0 = off
-    int ticket_extra = nbig > 0 ? 25 : 0;
-    if (const char *env = getenv("PDP_SOLVE_TICKETS")) ticket_extra = atoi(env);
     if (ticket_extra > 0 && !sp.fit_list) sp.fit_list = p->res_fit_list;        // (tickets index the list; with no big instance it holds every instance)
-    // a batch that is LDS-resident as a whole: pass 1 takes its instances in the order of k_order_by_risk (PDP_SOLVE_NO_RISK_ORDER=1: block index)
-    const bool risk_order = nbig == 0 && ticket_extra <= 0 && !sp.fit_list && nchunks > 1 && !a->isolate_instances && getenv("PDP_SOLVE_NO_RISK_ORDER") == nullptr;
-    if (risk_order) {
-        hipLaunchKernelGGL(k_order_identity, dim3((p->B + 255) / 256), dim3(256), 0, st, p->B, order, risk);
-        sp.risk = risk; sp.fit_list = order;
-    }
+    if (risk_order) { sp.risk = risk; sp.fit_list = order; }
     const bool listed = sp.fit_list != nullptr;                                 // pass 1 runs the LISTED instantiation
     const int big_copy_wgs = nbig >= 256 ? 1 : (256 / (nbig > 0 ? nbig : 1) < 32 ? 256 / (nbig > 0 ? nbig : 1) : 32);      // workgroups per instance of the save / restore copies
     if (const char *env = getenv("PDP_DEBUG_SKIP")) sp.debug_skip = atoi(env);
