@@ -67,6 +67,12 @@ __device__ __forceinline__ bool loop_stopped(const float *rowmask, int E)
 {
     return rowmask && __builtin_amdgcn_readfirstlane((int)__builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(rowmask) + E)) != 0;
 }
+// the same word for a kernel of many short workgroups: requested at entry, looked at in front of the first store -- tested at entry it is
+// one more DEPENDENT round trip in front of every tile's gathers
+__device__ __forceinline__ uint32_t loop_stop_word(const float *rowmask, int E)
+{
+    return rowmask ? (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(rowmask) + E)) : 0u;
+}
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 // e^x after the clamp (xc = the clamped argument, x = the argument itself for the NaN / infinity rule of the scalar forms)
 __device__ __forceinline__ f32x2 pk_exp_clamped(f32x2 xc, f32x2 x)
@@ -756,7 +762,7 @@ __global__ void __launch_bounds__(NTN, 6) k_agg_post_pf(int E, const float *__re
                                                         const float *__restrict__ emask, const float *__restrict__ rowmask,
                                                         const float *__restrict__ old, AggW w, float *__restrict__ out)
 {
-    if (loop_stopped(rowmask, E)) return;                  // a device-driven loop has ended: this sweep writes nothing (k_edge_active)
+    const uint32_t stop_word = loop_stop_word(rowmask, E);  // a device-driven loop has ended: this sweep writes nothing (k_edge_active); tested behind the hidden layer
     static_assert(NB3 * 2 == NWAVES && NB4 * 2 >= NWAVES, "one 32x32 block per wave in the hidden layer, one or two in the output layer");
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int ld0 = 2 * S3 + 1, ld1 = 32 * NB3 + 1;
@@ -769,16 +775,29 @@ __global__ void __launch_bounds__(NTN, 6) k_agg_post_pf(int E, const float *__re
     static_assert(2 * S3 <= 64, "one lane per input column");
     // all the tile's HBM requests go out before the first result is used: the gathered rows first (results return in issue order and the
     // hidden layer waits for these), then the previous-state rows of this wave's first output block, which are only needed at the very end
+    // (round 6: written with `if (e < E) { ... if (l < w.a) { loads } }` per row, this compiled to s_load / wait / two loads / s_waitcnt vmcnt(1) PER
+    //  ROW -- the loads sat in exec-masked blocks whose joins wait, and one register was reused for every row: eight dependent round trips
+    //  in front of every tile, the 39 % of parked wave cycles of this kernel.  Now straight-line code: the eight rows' scalar loads, then
+    //  sixteen unconditional vector loads on clamped addresses (a lane past the row reads its last column, a row past E reads row E - 1;
+    //  both are discarded below))
     float g_hv[TM / NWAVES], g_ag[TM / NWAVES], g_sg[TM / NWAVES], g_em[TM / NWAVES];
+    {
+        const int lc = l < w.a ? l : w.a - 1;
+        const float *const emp = emask ? emask : sign;        // (always a valid address: the value is dropped when there is no edge mask)
+        int ec[TM / NWAVES], rowc[TM / NWAVES];
 #pragma unroll
-    for (int jr = 0; jr < TM / NWAVES; ++jr) {
-        const int e = e0 + wave + NWAVES * jr;
-        g_hv[jr] = 0.0f; g_ag[jr] = 0.0f; g_sg[jr] = 0.0f; g_em[jr] = 1.0f;
-        if (e < E) {
-            const int row = edge_row[e];
-            g_sg[jr] = sign[e];
-            if (emask) g_em[jr] = emask[e];
-            if (l < w.a) { g_hv[jr] = h2[(size_t)e * w.a + l]; g_ag[jr] = agg[(size_t)row * w.a + l]; }
+        for (int jr = 0; jr < TM / NWAVES; ++jr) {
+            const int e = e0 + wave + NWAVES * jr;
+            ec[jr] = e < E ? e : E - 1;
+            rowc[jr] = edge_row[ec[jr]];
+            g_sg[jr] = sign[ec[jr]];
+            const float em = emp[ec[jr]];
+            g_em[jr] = emask ? em : 1.0f;
+        }
+#pragma unroll
+        for (int jr = 0; jr < TM / NWAVES; ++jr) {
+            g_hv[jr] = h2[(size_t)ec[jr] * w.a + lc];
+            g_ag[jr] = agg[(size_t)rowc[jr] * w.a + lc];
         }
     }
     const int ROWB = w.out * (int)sizeof(float);
@@ -809,13 +828,11 @@ __global__ void __launch_bounds__(NTN, 6) k_agg_post_pf(int E, const float *__re
 #pragma unroll
     for (int jr = 0; jr < TM / NWAVES; ++jr) {
         const int r = wave + NWAVES * jr, e = e0 + r;
-        float v = 0.0f;
-        if (e < E) {
-            if (l < w.a) {
-                const float own = emask ? g_hv[jr] * g_em[jr] : g_hv[jr];
-                v = (0.0f + g_ag[jr]) - own;
-            } else if (l == w.a && w.fd) v = g_sg[jr];
-        }
+        // (selects, not branches: a load whose only use sits in a conditional block is sunk into it, behind the block's wait)
+        const float own = emask ? g_hv[jr] * g_em[jr] : g_hv[jr];
+        const float inner = (0.0f + g_ag[jr]) - own;
+        float v = (l < w.a) ? inner : ((l == w.a && w.fd) ? g_sg[jr] : 0.0f);
+        v = (e < E) ? v : 0.0f;
         if (l < 2 * S3) Rt[r * ld0 + l] = v;
     }
     const int nb = wave >> 1, mb = wave & 1, col = 32 * nb + i;
@@ -847,6 +864,7 @@ __global__ void __launch_bounds__(NTN, 6) k_agg_post_pf(int E, const float *__re
         }
     }
     __syncthreads();
+    if (stop_word) return;                                  // (workgroup-uniform; every barrier of the kernel is behind us)
     // blend operands and result through buffer accesses with a per-tile base (lane offset in a VGPR, row offset as a scalar, rows past E
     // clipped by the descriptor); the previous state is requested before the last layer's chain.  The output is w.out = 128 or 150 floats
     // wide: with 5 column blocks (150) the 10 blocks of the tile go round the 8 waves twice.

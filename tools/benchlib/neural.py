@@ -85,8 +85,12 @@ def issue_bound(key, kernel_name, ms_per_launch, units):
     mfma_cycles = k['SQ_VALU_MFMA_BUSY_CYCLES'] * scale
     valu = (k['SQ_INSTS_VALU'] - k['SQ_INSTS_MFMA']) * scale
     floor_ms = 1e3 * (mfma_cycles + 2.0 * valu) / (N_SIMD * CLOCK_HZ)
-    return dict(floor_ms=floor_ms, frac=floor_ms / ms_per_launch, mfma_share_of_floor=mfma_cycles / (mfma_cycles + 2.0 * valu),
-                wait_share=k.get('SQ_WAIT_ANY_over_SQ_WAVE_CYCLES'), source=_NEURAL_PMC['file'])
+    out = dict(floor_ms=floor_ms, frac=floor_ms / ms_per_launch, mfma_share_of_floor=mfma_cycles / (mfma_cycles + 2.0 * valu),
+               wait_share=k.get('SQ_WAIT_ANY_over_SQ_WAVE_CYCLES'), source=_NEURAL_PMC['file'])
+    if k.get('clock_ghz_profiled'):
+        # the fp32-MFMA kernels run power-throttled (2.1-2.3 GHz in the profiled run): the same floor at THAT clock
+        out.update(clock_ghz_profiled=k['clock_ghz_profiled'], frac_at_profiled_clock=out['frac'] * CLOCK_HZ / (k['clock_ghz_profiled'] * 1e9))
+    return out
 
 
 def neural_kernel_rooflines(native, timing, E, V, H, model_type='np-nd-np'):

@@ -18,9 +18,12 @@ for work in sorted(os.listdir(root)):
     if not os.path.isdir(wd):
         continue
     print("==== %s ====" % work)
+    avg_us = {}
     for f in sorted(glob.glob(os.path.join(wd, 'trace', '**', '*kernel_stats.csv'), recursive=True)):
         with open(f) as fh:
             rows = list(csv.DictReader(fh))
+        for r in rows:
+            avg_us.setdefault(r.get('Name', '')[:64], float(r.get('AverageNs', 0)) / 1e3)
         for r in rows[:10]:
             print("  %-64s calls=%-5s avg_us=%-10.1f pct=%s" % (r.get('Name', '')[:64], r.get('Calls'), float(r.get('AverageNs', 0)) / 1e3, r.get('Percentage')))
     per = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(lambda: defaultdict(set))
@@ -47,8 +50,12 @@ for work in sorted(os.listdir(root)):
                 for key, prefix, unit in (('gru', 'void k_gru_pipe<65', 'edges'), ('agg_pre', 'void k_agg_pre_wave<65', 'edges'), ('agg_post', 'void k_agg_post_pf<26', 'edges'),
                                           ('predict_head', 'void k_predict_rows_pf<', 'variables')):
                     if k.startswith(prefix) and 'SQ_INSTS_MFMA' in v:
+                        # shader clock under this kernel's load: busy cycles of a CU / the kernel's duration (all 256 CUs busy for the whole launch: a lower
+                        # bound of the clock).  The fp32-MFMA kernels run throttled: 2.1-2.3 GHz, not the 2.4 GHz the peak is quoted at.
+                        us = avg_us.get(k)
                         neural_pmc[key] = {'kernel': k[5:].split('(')[0], 'unit': unit, 'SQ_INSTS_VALU': v['SQ_INSTS_VALU'], 'SQ_INSTS_MFMA': v['SQ_INSTS_MFMA'],
-                                           'SQ_VALU_MFMA_BUSY_CYCLES': v['SQ_VALU_MFMA_BUSY_CYCLES'],
+                                           'SQ_VALU_MFMA_BUSY_CYCLES': v['SQ_VALU_MFMA_BUSY_CYCLES'], 'SQ_BUSY_CU_CYCLES': v['SQ_BUSY_CU_CYCLES'],
+                                           'clock_ghz_profiled': (v['SQ_BUSY_CU_CYCLES'] / 256.0 / (us * 1e-6) / 1e9) if us else None,
                                            'SQ_WAIT_ANY_over_SQ_WAVE_CYCLES': (v['SQ_WAIT_ANY'] / v['SQ_WAVE_CYCLES']) if v.get('SQ_WAVE_CYCLES') else None}
         if v.get('SQ_WAVE_CYCLES') and 'SQ_WAIT_ANY' in v:
             print("        SQ_WAIT_ANY / SQ_WAVE_CYCLES = %.3f" % (v['SQ_WAIT_ANY'] / v['SQ_WAVE_CYCLES']))
