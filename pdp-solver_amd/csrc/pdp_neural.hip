@@ -1386,28 +1386,44 @@ __global__ void __launch_bounds__(NTN) k_gru_pipe(int E, const float *__restrict
     constexpr bool WIDE = 2 * SX - 2 == H;
     static_assert(WIDE || 2 * SX <= 64, "narrow input rows: one lane per column");
     const int dx = g.dx;
-    float2 px[PRE_R], ph[PRE_R];
+    // The next tile's rows come in by LDS-DMA (global_load_lds_dword: no register round trip, no deposit pass), issued by ONE wave per SIMD
+    // (waves 0-3, sixteen rows each).  Vector-memory results return in order, so a wave that has an HBM request in flight waits ~2 us at its
+    // next weight fragment: when all eight waves fetched, both waves of every SIMD stood there at the start of every tile and the matrix
+    // pipe idled (round 6: ~7 % of a tile); now the SIMD's other wave has only L2 weight loads on its counter and keeps the pipe busy.
+    // The narrow input row (p-nd-np: 3 or 4 columns) still goes through registers (one dword per row).
+    const bool fetcher = wave < 4;
+    float pxn[PRE_R];
     float psg = 0.0f;                                     // wave 0: edge sign (WIDE), wave 1: row mask
-    auto fetch = [&](int tile) {
+    auto dma4 = [&](float *lds_row /* wave-uniform */, const float *src /* per lane */) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)lds_row, 4, 0, 0);
+    };
+    auto fetch = [&](int tile, int par_dst) {
         const int e0 = tile * TM;
+        float *Xb = X + par_dst * TB, *Hb = Hs + par_dst * TB;
+        if (fetcher) {
 #pragma unroll
-        for (int jr = 0; jr < PRE_R; ++jr) {
-            const size_t e = (size_t)(e0 + wave + NWAVES * jr);
-            if constexpr (WIDE) px[jr] = reinterpret_cast<const float2 *>(state + e * H)[l];
-            else px[jr].x = (l < dx) ? state[e * dx + l] : (l == dx ? sign[e] : 0.0f);
-            ph[jr] = reinterpret_cast<const float2 *>(hprev + e * H)[l];
+            for (int jr = 0; jr < TM / 4; ++jr) {
+                const int r = wave + 4 * jr;
+                const size_t e = (size_t)(e0 + r);
+                if constexpr (WIDE) { dma4(Xb + r * ldx, state + e * H + l); dma4(Xb + r * ldx + 64, state + e * H + 64 + l); }
+                dma4(Hb + r * ldh, hprev + e * H + l); dma4(Hb + r * ldh + 64, hprev + e * H + 64 + l);
+            }
+        }
+        if constexpr (!WIDE) {
+#pragma unroll
+            for (int jr = 0; jr < PRE_R; ++jr) {
+                const size_t e = (size_t)(e0 + wave + NWAVES * jr);
+                pxn[jr] = (l < dx) ? state[e * dx + l] : (l == dx ? sign[e] : 0.0f);
+            }
         }
         if (WIDE && wave == 0) psg = sign[e0 + l];
         if (wave == 1) psg = MASK ? rowmask[e0 + l] : 1.0f;
     };
     auto deposit = [&](int par, int mslot) {
-        float *Xb = X + par * TB, *Hb = Hs + par * TB;
+        float *Xb = X + par * TB;
+        if constexpr (!WIDE) {
 #pragma unroll
-        for (int jr = 0; jr < PRE_R; ++jr) {
-            const int r = wave + NWAVES * jr;
-            if constexpr (WIDE) { Xb[r * ldx + 2 * l] = px[jr].x; Xb[r * ldx + 2 * l + 1] = px[jr].y; }
-            else { if (l < 2 * SX) Xb[r * ldx + l] = px[jr].x; }
-            Hb[r * ldh + 2 * l] = ph[jr].x; Hb[r * ldh + 2 * l + 1] = ph[jr].y;
+            for (int jr = 0; jr < PRE_R; ++jr) { const int r = wave + NWAVES * jr; if (l < 2 * SX) Xb[r * ldx + l] = pxn[jr]; }
         }
         if (WIDE && wave == 0) Xb[l * ldx + H] = psg;
         if (wave == 1) Mk[mslot * TM + l] = psg;
@@ -1433,13 +1449,14 @@ __global__ void __launch_bounds__(NTN) k_gru_pipe(int E, const float *__restrict
 #pragma unroll
     for (int r = 0; r < 16; ++r) { tq[r] = 0.0f; zg[r] = 0.0f; hq[r] = 0.0f; }
     int tile = blockIdx.x;
-    if (tile < ntiles) { fetch(tile); deposit(0, 0); }
+    if (tile < ntiles) { fetch(tile, 0); deposit(0, 0); }
     int e_prev = tile * TM;                               // first pass: the slices store zeros where this lane stores its results later
     int par = 0, ms = 0;                                  // tile buffer of the current tile; Mk[ms] = its masks, Mk[(ms + 2) % 3] = the previous tile's
     for (; tile < ntiles; tile += gridDim.x, par ^= 1, ms = (ms + 1) % 3) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's LDS-DMA requests of the tile have landed; the barrier publishes them
         __syncthreads();
         const int next = tile + gridDim.x;
-        if (next < ntiles) fetch(next);
+        if (next < ntiles) fetch(next, par ^ 1);            // (nobody reads the other buffer during this tile)
         const float *xa_b = xa + par * TB, *ha_b = ha + par * TB;
         f32x16 ai, ah, rg;
         const __amdgpu_buffer_rsrc_t ob = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)e_prev * H), 0, TM * H * (int)sizeof(float), 0x00020000);
