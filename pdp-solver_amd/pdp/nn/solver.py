@@ -380,6 +380,11 @@ class PropagatorDecimatorSolverBase(nn.Module):
             return False                                   # (the frozen fast build allocates a per-stream workspace inside its GRU call: not capturable)
         if int(iteration_num) < int(os.environ.get('PDP_GRAPH_LOOP_MIN_SWEEPS', '8')):
             return False                                   # two captures per forward: a short loop is cheaper sweep by sweep
+        # Large segments gain nothing (the GPU is busy either way: configs[3]'s shard runs 6.30 against 6.34 it/s) and the second state set
+        # costs memory there (117 against 91 GB reserved): the graph loop is for the small dynamic segments, where the host's round trips count
+        hidden = int(getattr(self._decimator, '_hidden_dimension', 0) or 0)
+        if sat_problem._edge_num * max(1, hidden) > int(float(os.environ.get('PDP_GRAPH_LOOP_MAX_STATE', '4e8'))):
+            return False
         return self._neural_triple(sat_problem, is_training, check_termination)
 
     def _forward_core_graph(self, box, sat_problem, iteration_num, check_termination):
