@@ -215,9 +215,10 @@ typedef struct pdp_solve_args {
     int32_t used_lds_host;        /* out: 1 if the LDS-resident variant ran */
     int32_t kernel_launches_host; /* out: launches of the solver kernel that did work (one per chunk of iterations) */
     int32_t replay_launches_host; /* out: poison-replay launches that did work */
-    int32_t time_kernels;         /* in: 1 = bracket every solver launch with HIP events and report the sums below */
+    int32_t time_kernels;         /* in: 1 = bracket every chunk launch with HIP events and report the sums below */
     float solve_kernel_ms_host;   /* out: device time of the chunk launches (time_kernels == 1) */
-    float replay_kernel_ms_host;  /* out: device time of the replay launches (time_kernels == 1) */
+    float replay_kernel_ms_host;  /* out: device time from the end of a chunk launch that was replayed to the start of the next chunk's: the replay
+                                   * launch and the four control kernels around it (time_kernels == 1) */
     int32_t replicas_identical;   /* in: 1 = the R replicas of every instance (batch replication, solver.py:56-82) start from identical state,
                                    * so their trajectories coincide and the replica-aware termination rule (trainer.py:157-160) equals the
                                    * per-replica one.  0 with replication > 1 (random initial state): the replicas couple through the

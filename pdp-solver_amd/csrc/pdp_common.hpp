@@ -126,7 +126,7 @@ struct pdp_problem {
     char *res_dyn[2]; size_t res_dyn_bytes;
     float *res_prev_slots;
     char *res_ctl; size_t res_ctl_bytes;
-    hipEvent_t *res_events; int res_events_n;       // 4 per chunk, created on demand (pdp_solve_args.time_kernels)
+    hipEvent_t *res_events; int res_events_n;       // 2 per chunk + 1, created on demand (pdp_solve_args.time_kernels)
     // per-instance routing of the persistent solver: instances whose image fits the LDS / the others (HBM-resident kernel, same chunk loop)
     int32_t *res_fit_list, *res_big_list;            // device, [res_nfit] / [res_nbig] instance ids in ascending order
     uint8_t *res_is_big;                             // device, [B]

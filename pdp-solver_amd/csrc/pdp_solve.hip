@@ -2731,11 +2731,17 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     a->used_lds_host = 1;
     // optional: HIP events around every solver launch (the caller asks for kernel times, e.g. the benchmark's roofline line)
     const bool timed = a->time_kernels != 0;
-    if (timed && p->res_events_n < 4 * nchunks) {
-        hipEvent_t *ev = (hipEvent_t *)realloc(p->res_events, sizeof(hipEvent_t) * 4 * (size_t)nchunks);
+    // An event record between two dependent launches costs 3-6 us of stream time (tools/micro/event_gap.hip), so there are as few as the two
+    // figures need: [2k] / [2k + 1] around chunk k's launch, [2 nchunks] behind the last chunk's control kernels (a replay is timed from
+    // the end of its chunk's launch to the next chunk's start); no system-scope fence on them (nothing on the host reads what the kernels wrote
+    // until the stream is drained).
+    const int n_events = 2 * nchunks + 1;
+    if (timed && p->res_events_n < n_events) {
+        hipEvent_t *ev = (hipEvent_t *)realloc(p->res_events, sizeof(hipEvent_t) * (size_t)n_events);
         PDP_REQUIRE(ev, "out of host memory");
         p->res_events = ev;
-        for (; p->res_events_n < 4 * nchunks; ++p->res_events_n) PDP_HIP_CHECK(hipEventCreate(&p->res_events[p->res_events_n]));
+        for (; p->res_events_n < n_events; ++p->res_events_n)
+            PDP_HIP_CHECK(hipEventCreateWithFlags(&p->res_events[p->res_events_n], hipEventDisableSystemFence));
     }
 
     const int nfit = p->res_nfit, nbig = p->res_nbig;
@@ -2851,7 +2857,7 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
                                    (const SolveCtl *)(ctl + k), (const SolveCall *)call);
                 { const int st_ = launch_big(sp, side); if (st_ != PDP_OK) return st_; }
             }
-            if (timed) PDP_HIP_CHECK(hipEventRecord(p->res_events[4 * k + 2 * pass], st));
+            if (timed && pass == 0) PDP_HIP_CHECK(hipEventRecord(p->res_events[2 * k], st));
             sp.lds_tickets = (pass == 0 && ticket_extra > 0) ? nfit : 0;
             const int grid_lds = sp.lds_tickets ? nfit + (int)(((int64_t)nfit * ticket_extra + 99) / 100) : nfit;
             if (pass == 0)
@@ -2870,7 +2876,7 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
             else if (force) hipLaunchKernelGGL((k_sp_solve_lds<true, true>), dim3(nfit), dim3(nt_lds), lds, st, make_view(p), sp);
             else if (pass == 0) hipLaunchKernelGGL((k_sp_solve_lds<false, false>), dim3(grid_lds), dim3(nt_lds), lds, st, make_view(p), sp);
             else hipLaunchKernelGGL((k_sp_solve_lds<false, true>), dim3(nfit), dim3(nt_lds), lds, st, make_view(p), sp);
-            if (timed) PDP_HIP_CHECK(hipEventRecord(p->res_events[4 * k + 2 * pass + 1], st));
+            if (timed && pass == 0) PDP_HIP_CHECK(hipEventRecord(p->res_events[2 * k + 1], st));
             if (nbig && pass == 1) { PDP_HIP_CHECK(hipEventRecord(p->res_side_ev[1], side)); PDP_HIP_CHECK(hipStreamWaitEvent(st, p->res_side_ev[1], 0)); }
             if (nbig && pass == 0) { PDP_HIP_CHECK(hipEventRecord(p->res_side_ev[1], side)); PDP_HIP_CHECK(hipStreamWaitEvent(st, p->res_side_ev[1], 0)); }   // join: pass 1 of the big instances
             if (xch && !x_stop && (pass == 0 || x_replay)) {
@@ -2917,6 +2923,7 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
         PDP_LAUNCH_CHECK();
         done += c;
     }
+    if (timed) PDP_HIP_CHECK(hipEventRecord(p->res_events[2 * nchunks], st));
     if (!a->isolate_instances) {
         // instances that left inactive with iterations to come: is their frozen state a fixed point of the reference's masked sweep?
         if (!nbig) { const int st_ = hbm_workspaces(p, sp, false); if (st_ != PDP_OK) return st_; }
@@ -2943,8 +2950,8 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
         launches += 1; replays += replayed ? 1 : 0;
         if (timed) {
             float ms = 0.0f;
-            PDP_HIP_CHECK(hipEventElapsedTime(&ms, p->res_events[4 * k], p->res_events[4 * k + 1])); solve_ms += ms;
-            if (replayed) { PDP_HIP_CHECK(hipEventElapsedTime(&ms, p->res_events[4 * k + 2], p->res_events[4 * k + 3])); replay_ms += ms; }
+            PDP_HIP_CHECK(hipEventElapsedTime(&ms, p->res_events[2 * k], p->res_events[2 * k + 1])); solve_ms += ms;
+            if (replayed) { PDP_HIP_CHECK(hipEventElapsedTime(&ms, p->res_events[2 * k + 1], p->res_events[2 * k + 2])); replay_ms += ms; }
         }
         if (debug)
             fprintf(stderr, "[pdp_sp_solve] chunk@%d violation=%u perm_from=%u nan_iter=%u poison_from=%d replayed=%u iters=%u lds=%zu\n", k * C,
