@@ -16,6 +16,7 @@
 // through the strict step-wise entry points (pdp_ops.hip), so results always equal the reference semantics.
 #include "pdp_device.hpp"
 #include <stdlib.h>
+#include <algorithm>
 #include <vector>
 #include <type_traits>
 
@@ -91,7 +92,7 @@ struct SolveParams {
     int exact;                  // HBM-resident kernel, single-instance batch: the batch-global minima ARE the instance's own, nothing is speculated
     int rf;                     // HBM-resident kernel: the Reinforce triple (coins, dprob as for the LDS-resident kernel; tol = the gate's 0.01)
     int isolate;                // isolated instances (a NaN stays inside its instance, pass 1 is final)
-    uint32_t *risk;             // [B] LDS-resident pass 1: bits of the smallest q normalisation of the launch's last sweep (see k_order_by_risk); NULL: off
+    uint32_t *risk;             // [B] LDS-resident pass 1: bits of the smallest q normalisation of the launch's last sweep (see k_solve_finish); NULL: off
     int no_scorer_reuse;        // PDP_SOLVE_NO_SCORER_REUSE=1: the decimation's scorer always takes its own logs (A/B switch)
     int no_event_look;          // PDP_SOLVE_NO_EVENT_LOOK=1: pass-1 workgroups look for a recorded NaN sweep only when they start
     int rf_no_fused_step;       // PDP_SOLVE_RF_NO_FUSED_STEP=1: a Reinforce coin sweep runs E2's plain form and its step uses X / Y as scratch (round 5's form)
@@ -2335,40 +2336,79 @@ __global__ void __launch_bounds__(256) k_force_import(PView pv, const float *fs,
 }
 
 // after pass 1 of a chunk: does a NaN poison the batch from this chunk on?  
-__global__ void k_solve_post(SolveCtl *ctl, SolveCall *call, int c, int isolate)
+// Between two solver launches of a chunk (one workgroup each: every launch less is ~5 us of stream time less, four times per call).
+// After pass 1: is the batch poisoned in this chunk, and which instances does the poison replay take?  Only instances with a gate /
+// convergence event at or after the poison iteration behave differently under the poison (big instances: replayed wholesale).
+__global__ void __launch_bounds__(1024) k_solve_post(SolveCtl *ctl, SolveCall *call, int c, int isolate, int B, const int32_t *last_event, int32_t *list,
+                                                     const uint8_t *is_big)
 {
-    if (call->stop) return;
-    ctl->do_replay = 0; ctl->replay_count = 0;
-    if (isolate) return;                            // isolated instances: a NaN stays inside its instance, nothing is replayed
-    if (!call->poisoned_all && ctl->nan_iter < (uint32_t)c) {
-        ctl->poison_from = (int32_t)ctl->nan_iter;
-        call->poisoned_all = 1;
-        if (ctl->violation) call->fail = 1;
-        ctl->do_replay = 1;
+    __shared__ int s_from;
+    if (threadIdx.x == 0) {
+        int from = -1;
+        if (!call->stop) {
+            ctl->do_replay = 0; ctl->replay_count = 0;
+            // (isolated instances: a NaN stays inside its instance, nothing is replayed)
+            if (!isolate && !call->poisoned_all && ctl->nan_iter < (uint32_t)c) {
+                from = (int32_t)ctl->nan_iter;
+                ctl->poison_from = from;
+                call->poisoned_all = 1;
+                if (ctl->violation) call->fail = 1;
+                ctl->do_replay = 1;
+            }
+        }
+        s_from = from;
     }
+    __syncthreads();
+    const int from = s_from;
+    if (from < 0) return;
+    for (int b = threadIdx.x; b < B; b += blockDim.x)
+        if (!(is_big && is_big[b]) && last_event[b] >= from) list[atomicAdd(&ctl->replay_count, 1u)] = b;
 }
 
-// only instances with a gate / convergence event at or after the poison iteration behave differently under the poison
-__global__ void k_replay_list(int B, const int32_t *last_event, SolveCtl *ctl, const SolveCall *call, int32_t *list, const uint8_t *is_big)
+// After the (possible) replay: speculation check of the chunk, loop control and -- `order` given -- the dispatch order of the next chunk's pass 1.
+// Dispatch order of the next launch's pass 1: ascending by the binary exponent of the smallest q normalisation (q_u + q_s + q_dc) an instance
+// met in its last sweep.  The batch's first NaN survey is a 0 / 0 of that normalisation (pdp_propagate.py:215-216): both products of a variable
+// underflow, and they get there over several sweeps -- so the instances closest to it start in the first round of workgroups, put the NaN sweep
+// on record early, and the workgroups of the later rounds take it as their poison point at once instead of being replayed (k_sp_solve_lds:
+// `adopt`).  Only the ORDER depends on this guess: an instance's result does not depend on when it runs.  One workgroup: a counting sort over
+// the 256 exponents (finished instances and NaNs carry all ones: last), the order inside a bucket is whatever the atomics make it.
+__global__ void __launch_bounds__(1024) k_solve_finish(SolveCtl *ctl, SolveCall *call, const uint32_t *spec_used, const uint32_t *spec_zero, int c, int chunk_start,
+                                                       int isolate, int B, const uint32_t *risk, int32_t *order)
 {
-    if (call->stop || !ctl->do_replay) return;
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B && !(is_big && is_big[b]) && last_event[b] >= ctl->poison_from) list[atomicAdd(&ctl->replay_count, 1u)] = b;   // (big instances: replayed wholesale)
-}
-
-// after the (possible) replay: speculation check of the chunk and loop control
-__global__ void k_solve_finish(SolveCtl *ctl, SolveCall *call, const uint32_t *spec_used, const uint32_t *spec_zero, int c, int chunk_start, int isolate)
-{
-    if (call->stop) return;
-    if (ctl->violation && !isolate) call->fail = 1;
+    __shared__ int hist[256];
+    __shared__ int s_stop;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (tid == 0) s_stop = call->stop ? 1 : 0;
+    for (int i = tid; i < 256; i += nt) hist[i] = 0;
+    __syncthreads();
+    if (s_stop) return;
     // iterations at or after the poison point are not speculated on (the reference's reductions are NaN there), and the
     // kernel records nothing in a poisoned iteration
     const int poison_from = ctl->do_replay ? ctl->poison_from : 0x7fffffff;
-    for (int t = 0; t < c && t < poison_from; ++t)
-        if (!isolate && (uint32_t)t < ctl->perm_zero && (spec_used[t] & ~spec_zero[t]) != 0u) call->fail = 1;
-    const uint32_t it = ctl->iters_run;
-    call->total_iters = (uint32_t)chunk_start + it;
-    if (it < (uint32_t)c) call->stop = 1;          // every instance went inactive inside this chunk (global early exit, solver.py:383)
+    const uint32_t perm_zero = ctl->perm_zero;
+    if (!isolate) {
+        int bad = 0;
+        for (int t = tid; t < c && t < poison_from; t += nt)
+            if ((uint32_t)t < perm_zero && (spec_used[t] & ~spec_zero[t]) != 0u) bad = 1;
+        if (bad) call->fail = 1;
+    }
+    __syncthreads();                                   // (everybody has read s_stop)
+    if (tid == 0) {
+        if (ctl->violation && !isolate) call->fail = 1;
+        const uint32_t it = ctl->iters_run;
+        call->total_iters = (uint32_t)chunk_start + it;
+        const int stop = it < (uint32_t)c ? 1 : 0;     // every instance went inactive inside this chunk (global early exit, solver.py:383)
+        if (stop) call->stop = 1;
+        s_stop = stop;
+    }
+    if (!order) return;
+    __syncthreads();
+    if (s_stop) return;
+    for (int b = tid; b < B; b += nt) atomicAdd(&hist[(risk[b] >> 23) & 255], 1);
+    __syncthreads();
+    if (tid == 0) { int run = 0; for (int i = 0; i < 256; ++i) { const int h = hist[i]; hist[i] = run; run += h; } }
+    __syncthreads();
+    for (int b = tid; b < B; b += nt) order[atomicAdd(&hist[(risk[b] >> 23) & 255], 1)] = b;
 }
 
 
@@ -2532,24 +2572,6 @@ __global__ void k_max_i32(int B, const int32_t *x, uint32_t *out)
     atomicMax(out, (uint32_t)m);
 }
 
-// Dispatch order of the next launch's pass 1: ascending by the binary exponent of the smallest q normalisation (q_u + q_s + q_dc) an instance
-// met in its last sweep.  The batch's first NaN survey is a 0 / 0 of that normalisation (pdp_propagate.py:215-216): both products of a variable
-// underflow, and they get there over several sweeps -- so the instances closest to it start in the first round of workgroups, put the NaN sweep
-// on record early, and the workgroups of the later rounds take it as their poison point at once instead of being replayed (k_sp_solve_lds:
-// `adopt`).  Only the ORDER depends on this guess: an instance's result does not depend on when it runs.  One workgroup: a counting sort over
-// the 256 exponents (finished instances and NaNs carry all ones: last), the order inside a bucket is whatever the atomics make it.
-__global__ void __launch_bounds__(1024) k_order_by_risk(int B, const uint32_t *risk, int32_t *order, const SolveCall *call)
-{
-    __shared__ int hist[256];
-    if (call->stop) return;
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
-    __syncthreads();
-    for (int b = threadIdx.x; b < B; b += blockDim.x) atomicAdd(&hist[(risk[b] >> 23) & 255], 1);
-    __syncthreads();
-    if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < 256; ++i) { const int c = hist[i]; hist[i] = run; run += c; } }
-    __syncthreads();
-    for (int b = threadIdx.x; b < B; b += blockDim.x) order[atomicAdd(&hist[(risk[b] >> 23) & 255], 1)] = b;
-}
 // everything a call's device-side control starts from, in one launch: the per-chunk blocks, the call block, the speculation record, the
 // ghost flags and the identity dispatch order (was: this kernel + two memsets + k_order_identity, four launches and their gaps)
 __global__ void k_solve_ctl_init(SolveCtl *ctl, int nchunks, SolveCall *call, uint32_t *spec, int spec_words, uint8_t *ghost_flag, int B, int32_t *order, uint32_t *risk)
@@ -2678,7 +2700,17 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     const bool rf = a->model == PDP_MODEL_REINFORCE;
     const int T = a->iterations;
     const size_t E = p->E, V = p->V, F = p->F, B = p->B;
-    const int nchunks = (T + C - 1) / C;
+    // The chunk schedule: lengths C0, C, C, ... (C0 = PDP_SOLVE_FIRST_CHUNK, default 2 C).  What a short chunk bounds is the poison replay, and a
+    // NaN needs a decimation, which needs a converged instance: the first sweeps of a call are the least likely to hold one, and a launch of 50
+    // sweeps costs 4.07 ms where two of 25 cost 4.23 (the chip drains and refills once less).  With isolated instances there is no poison and
+    // nothing to replay: the whole loop is one launch (100 sweeps: 8.78 ms against 4 x 2.30).
+    std::vector<int> cstart, clen;
+    {
+        int c0 = a->isolate_instances ? T : 2 * C;
+        if (const char *env = getenv("PDP_SOLVE_FIRST_CHUNK")) { const int v = atoi(env); if (v > 0) c0 = v; }
+        for (int d = 0; d < T;) { const int c = std::min(T - d, d == 0 ? c0 : C); cstart.push_back(d); clen.push_back(c); d += c; }
+    }
+    const int nchunks = (int)clen.size();
     const int64_t *stat_off = p->res_stat_off, *dyn_off = p->res_stat_off + B;
     // ---- control blocks, speculation record, replay list; call-entry snapshot for the failure path ---------------------------
     const size_t ctl_bytes = (size_t)nchunks * sizeof(SolveCtl) + sizeof(SolveCall) + 2 * (size_t)T * 4 + 2 * B * 4 + 64 + 2 * (B + 16) * 4 +
@@ -2756,7 +2788,7 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     // ticketed LDS-resident pass (see k_sp_solve_lds): on for mixed batches; PDP_SOLVE_TICKETS=<percent of over-provisioning>, 0 = off
     int ticket_extra = nbig > 0 ? 25 : 0;
     if (const char *env = getenv("PDP_SOLVE_TICKETS")) ticket_extra = atoi(env);
-    // a batch that is LDS-resident as a whole: pass 1 takes its instances in the order of k_order_by_risk (PDP_SOLVE_NO_RISK_ORDER=1: block index)
+    // a batch that is LDS-resident as a whole: pass 1 takes its instances in the order k_solve_finish leaves (PDP_SOLVE_NO_RISK_ORDER=1: block index)
     const bool risk_order = nbig == 0 && ticket_extra <= 0 && !fit_list && nchunks > 1 && !a->isolate_instances && getenv("PDP_SOLVE_NO_RISK_ORDER") == nullptr;
     {
         const int words = 2 * T, cover = (int)B > words ? (int)B : words;
@@ -2829,7 +2861,7 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     const bool xch = p->exchange != nullptr;              // (pdp_sp_solve admits the hook only for batches this loop takes whole)
     bool x_poisoned = false, x_replay = false, x_stop = false;        // host mirrors of call->poisoned_all / ctl->do_replay / call->stop (all derived from merged words)
     for (int k = 0; k < nchunks; ++k) {
-        const int c = (T - done) < C ? (T - done) : C;
+        const int c = clen[k];
         x_replay = false;
         sp.T = c; sp.chunk_start = done; sp.final_chunk = (done + c >= T) ? 1 : 0;
         sp.has_prev = (k == 0) ? a->decimator->has_prev : 1;
@@ -2913,13 +2945,12 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
                 }
             }
             if (pass == 0) {
-                hipLaunchKernelGGL(k_solve_post, dim3(1), dim3(1), 0, st, ctl + k, call, c, (int)a->isolate_instances);
-                hipLaunchKernelGGL(k_replay_list, dim3((p->B + 255) / 256), dim3(256), 0, st, p->B, (const int32_t *)last_event, ctl + k, (const SolveCall *)call, replay_list,
+                hipLaunchKernelGGL(k_solve_post, dim3(1), dim3(1024), 0, st, ctl + k, call, c, (int)a->isolate_instances, p->B, (const int32_t *)last_event, replay_list,
                                    (const uint8_t *)(nbig ? p->res_is_big : nullptr));
             }
         }
-        hipLaunchKernelGGL(k_solve_finish, dim3(1), dim3(1), 0, st, ctl + k, call, (const uint32_t *)sp.spec_used, (const uint32_t *)sp.spec_zero, c, done, (int)a->isolate_instances);
-        if (risk_order && k + 1 < nchunks) hipLaunchKernelGGL(k_order_by_risk, dim3(1), dim3(1024), 0, st, p->B, (const uint32_t *)risk, order, (const SolveCall *)call);
+        hipLaunchKernelGGL(k_solve_finish, dim3(1), dim3(1024), 0, st, ctl + k, call, (const uint32_t *)sp.spec_used, (const uint32_t *)sp.spec_zero, c, done, (int)a->isolate_instances,
+                           p->B, (const uint32_t *)risk, (risk_order && k + 1 < nchunks) ? order : (int32_t *)nullptr);
         PDP_LAUNCH_CHECK();
         done += c;
     }
@@ -2945,7 +2976,7 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     int launches = 0, replays = 0;
     float solve_ms = 0.0f, replay_ms = 0.0f;
     for (int k = 0; k < nchunks; ++k) {
-        if (hctl[k].iters_run == 0 && k * C >= (int)hcall->total_iters && k > 0) break;     // launches after the global early exit return at once
+        if (hctl[k].iters_run == 0 && cstart[k] >= (int)hcall->total_iters && k > 0) break;     // launches after the global early exit return at once
         const bool replayed = hctl[k].do_replay && hctl[k].replay_count;
         launches += 1; replays += replayed ? 1 : 0;
         if (timed) {
@@ -2954,7 +2985,7 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
             if (replayed) { PDP_HIP_CHECK(hipEventElapsedTime(&ms, p->res_events[2 * k + 1], p->res_events[2 * k + 2])); replay_ms += ms; }
         }
         if (debug)
-            fprintf(stderr, "[pdp_sp_solve] chunk@%d violation=%u perm_from=%u nan_iter=%u poison_from=%d replayed=%u iters=%u lds=%zu\n", k * C,
+            fprintf(stderr, "[pdp_sp_solve] chunk@%d violation=%u perm_from=%u nan_iter=%u poison_from=%d replayed=%u iters=%u lds=%zu\n", cstart[k],
                     hctl[k].violation, hctl[k].perm_zero, hctl[k].nan_iter, hctl[k].poison_from, hctl[k].do_replay ? hctl[k].replay_count : 0u, hctl[k].iters_run, lds);
     }
     a->kernel_launches_host = launches; a->replay_launches_host = replays;
@@ -3117,7 +3148,7 @@ static int sp_solve_speculative(pdp_problem *p, pdp_solve_args *a, void *stream)
     // first sweep.  Measured on MI355X (n=200, batch=5000, T=100, one NaN poison at sweep 81), ms per step: round 1-4 kernels 8 / 12 / 16 / 25
     // -> best at 12; round 5 (E2 takes the logs, later workgroups adopt the poison, so the replay is smaller and a launch's first sweep is
     // the expensive one): 12 / 14 / 16 / 18 / 20 / 25 -> 11.19 / 11.15 / 11.08 / 10.93 / 10.91 / 10.98; with pass 1 dispatched in the order of
-    // k_order_by_risk (the replay shrinks to a quarter): 20 / 25 / 27 / 34 / 40 / 50 -> 9.64 / 9.45 / 9.43 / 9.42 / 9.23 / 9.42 -- flat beyond 25
+    // the risk sort (the replay shrinks to a quarter): 20 / 25 / 27 / 34 / 40 / 50 -> 9.64 / 9.45 / 9.43 / 9.42 / 9.23 / 9.42 -- flat beyond 25
     // up to where the poison happens to sit in its chunk, and the order is a guess made at the end of the previous chunk, so not too long: 25.
     // A batch of ONE instance has nobody to supply the exact zero the speculation counts on (tools/spec_rate.py: it fails in the first
     // iteration for 10-19 of 20 random instances) -- but its batch-global minima are its own: the HBM-resident kernel computes them
