@@ -337,6 +337,7 @@ extern "C" int pdp_problem_destroy(pdp_problem *p)
     if (p->solve_rec) pdp_dev_free(p->solve_rec);
     void *res[] = {p->res_stat_off, p->res_stat, p->res_dyn[0], p->res_dyn[1], p->res_prev_slots, p->res_ctl, p->res_fit_list, p->res_big_list, p->res_is_big, p->res_big_snap};
     for (void *q : res) if (q) pdp_dev_free(q);
+    if (p->simp_topo) pdp_dev_free(p->simp_topo);
     if (p->team_ws) pdp_dev_free(p->team_ws);
     if (p->ws_fit_list) pdp_dev_free(p->ws_fit_list);
     if (p->ws_big_list) pdp_dev_free(p->ws_big_list);

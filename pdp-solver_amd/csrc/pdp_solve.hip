@@ -2460,7 +2460,12 @@ static size_t simplify_lds_bytes(int n, int m, int e)
     return 3 * a16((size_t)e * 2) + a16((size_t)(n + 1) * 2) + a16((size_t)(m + 1) * 2) + 3 * a16((size_t)n * 4) + a16((size_t)m * 4) + 2 * a16((size_t)n * 4) +
            a16((size_t)n) + 2 * a16((size_t)m);
 }
-__global__ void __launch_bounds__(256) k_simplify_lds(PView pv)
+// TOPO 0: the slot form is gathered from the problem's CSR arrays (two levels of dependent loads per slot: five sixths of this kernel's time on
+// the headline batch); 1: gathered and left in `topo` (the second simplify() of a problem); 2: read back from there, five coalesced streams of
+// 16-bit words (a problem whose state is re-bound -- pdp_problem_bind_state -- keeps its topology).
+struct SimpTopo { uint16_t *pvv, *pcc, *e2p, *vptr, *fptr; };
+template <int TOPO>
+__global__ void __launch_bounds__(256) k_simplify_lds(PView pv, SimpTopo topo)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int redi[PDP_RED_SMALL];
@@ -2472,6 +2477,20 @@ __global__ void __launch_bounds__(256) k_simplify_lds(PView pv)
     float *av = carve<float>(cp, n), *sol = carve<float>(cp, n), *assign = carve<float>(cp, n), *af = carve<float>(cp, m);
     int32_t *deg = carve<int32_t>(cp, n), *sdeg = carve<int32_t>(cp, n);
     uint8_t *flag_v = carve<uint8_t>(cp, n), *flag_f = carve<uint8_t>(cp, m), *flag_f2 = carve<uint8_t>(cp, m);
+    uint16_t *const t_pvv = topo.pvv + G.e0, *const t_pcc = topo.pcc + G.e0, *const t_e2p = topo.e2p + G.e0;
+    uint16_t *const t_vptr = topo.vptr + G.v0 + G.b, *const t_fptr = topo.fptr + G.f0 + G.b;
+    if constexpr (TOPO == 2) {
+        // (all loads of a trip first, then the LDS stores: a one-element copy loop is one round trip per element)
+        for (int p0 = tid; p0 < ne; p0 += 4 * nt) {
+            uint16_t a[4], b[4], c[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int p = p0 + j * nt, pp = p < ne ? p : p0; a[j] = t_pvv[pp]; b[j] = t_pcc[pp]; c[j] = t_e2p[pp]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int p = p0 + j * nt; if (p < ne) { pvv[p] = a[j]; pcc[p] = b[j]; e2p[p] = c[j]; } }
+        }
+        for (int v = tid; v <= n; v += nt) v_ptr[v] = t_vptr[v];
+        for (int c = tid; c <= m; c += nt) f_ptr[c] = t_fptr[c];
+    } else {
     // (eight slots per trip: the gathers through v_edges are two levels of dependent loads, and a loop that takes one slot per trip is one
     //  pair of round trips per slot -- twenty in a row for n = 200 on 256 threads, which is what this kernel's time was made of)
     for (int p0 = tid; p0 < ne; p0 += 8 * nt) {
@@ -2491,9 +2510,15 @@ __global__ void __launch_bounds__(256) k_simplify_lds(PView pv)
     }
     for (int v = tid; v <= n; v += nt) v_ptr[v] = (uint16_t)G.v_ptr[v];
     for (int c = tid; c <= m; c += nt) f_ptr[c] = (uint16_t)G.f_ptr[c];
+    }
     for (int v = tid; v < n; v += nt) { av[v] = G.av[v]; sol[v] = G.sol[v]; }
     for (int c = tid; c < m; c += nt) af[c] = G.af[c];
     __syncthreads();
+    if constexpr (TOPO == 1) {
+        for (int p = tid; p < ne; p += nt) { t_pvv[p] = pvv[p]; t_pcc[p] = pcc[p]; t_e2p[p] = e2p[p]; }
+        for (int v = tid; v <= n; v += nt) t_vptr[v] = v_ptr[v];
+        for (int c = tid; c <= m; c += nt) t_fptr[c] = f_ptr[c];
+    }
     LView I;
     I.b = G.b; I.n = n; I.m = m; I.e = ne; I.nt = nt; I.red = redi;
     I.e_var.pv = pvv; I.e_var.mask = 0x3fff; I.e_fn.pc = pcc; I.sgn.pv = pvv; I.f_edges = e2p; I.v_ptr = v_ptr; I.f_ptr = f_ptr;
@@ -2511,8 +2536,21 @@ int pdp_simplify_lds(pdp_problem *p, hipStream_t st)
     if (!p->fn_edges_identity || p->max_n >= 16384 || p->max_m >= 16384 || p->max_e >= 65536 || getenv("PDP_SIMPLIFY_HBM")) return 0;
     const size_t lds = simplify_lds_bytes(p->max_n, p->max_m, p->max_e);
     if (lds > 64 * 1024) return 0;
-    if (hipFuncSetAttribute((const void *)k_simplify_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0;
-    hipLaunchKernelGGL(k_simplify_lds, dim3(p->B), dim3(256), lds, st, make_view(p));
+    // the slot topology is kept from the second call on (a problem that is simplified once -- the solver classes make a SATProblem per batch --
+    // pays nothing for it)
+    const size_t E = p->E, rows_v = (size_t)p->V + p->B, rows_f = (size_t)p->F + p->B;
+    int mode = 0;
+    if (p->simp_calls >= 2 && p->simp_topo) mode = 2;
+    else if (p->simp_calls == 1 && !getenv("PDP_SIMPLIFY_NO_TOPO") && pdp_dev_alloc((void **)&p->simp_topo, (3 * E + rows_v + rows_f + 8) * sizeof(uint16_t)) == PDP_OK) mode = 1;
+    SimpTopo T;
+    T.pvv = p->simp_topo; T.pcc = T.pvv + E; T.e2p = T.pcc + E; T.vptr = T.e2p + E; T.fptr = T.vptr + rows_v;
+    if (!p->simp_topo) T.pvv = T.pcc = T.e2p = T.vptr = T.fptr = nullptr;
+    const void *fn = mode == 2 ? (const void *)k_simplify_lds<2> : mode == 1 ? (const void *)k_simplify_lds<1> : (const void *)k_simplify_lds<0>;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0;
+    if (mode == 2) hipLaunchKernelGGL(k_simplify_lds<2>, dim3(p->B), dim3(256), lds, st, make_view(p), T);
+    else if (mode == 1) hipLaunchKernelGGL(k_simplify_lds<1>, dim3(p->B), dim3(256), lds, st, make_view(p), T);
+    else hipLaunchKernelGGL(k_simplify_lds<0>, dim3(p->B), dim3(256), lds, st, make_view(p), T);
+    if (p->simp_calls < 2) p->simp_calls += 1;
     return 1;
 }
 

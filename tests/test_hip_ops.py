@@ -85,6 +85,35 @@ def test_layout_and_simplify(oracle, spec):
     assert all_active == (s == op.E)
 
 
+@pytest.mark.parametrize('spec', [BATCHES[1], BATCHES[3], dict(batch=50, n=30, k=3, m=60, seed=21)])
+def test_simplify_of_a_rebound_problem(oracle, spec):
+    """A problem whose state is bound afresh (pdp_problem_bind_state, as bench.py does per step) is simplified again: the LDS-resident kernel
+    gathers the slot topology on the first call, leaves it in HBM on the second and reads it back from the third on -- the same state each time,
+    also after variables were set in between."""
+    from pdp import native
+    b = random_batch(**spec)
+    hp, op = make_pair(oracle, b)
+    hp.simplify(); op.simplify()
+    assert_state_equal(hp, op)
+    av0, af0, sol0, sat0 = [np.array(x) for x in op.state()]
+    rng = np.random.RandomState(3)
+    for rep in range(4):
+        native.check(native.lib().pdp_problem_bind_state(hp._h, native.ptr(hp.active_variables), native.ptr(hp.active_functions), native.ptr(hp.solution),
+                                                         native.ptr(hp.is_sat), native.ptr(hp.edge_mask), native._stream()))
+        hp.simplify()
+        np.testing.assert_array_equal(npy(hp.active_variables)[:, 0], av0)
+        np.testing.assert_array_equal(npy(hp.active_functions)[:, 0], af0)
+        np.testing.assert_array_equal(npy(hp.solution), sol0)
+        np.testing.assert_array_equal(npy(hp.is_sat), sat0)
+    # a state that is not the fresh one: fix some variables on both sides, simplify again (the kept topology serves any state)
+    assign = np.zeros(op.V, np.float32)
+    pick = rng.choice(op.V, size=max(1, op.V // 8), replace=False)
+    assign[pick] = rng.randint(0, 2, size=len(pick)) * 2 - 1
+    hp.set_variables(t(assign)); op.set_variables(assign)
+    hp.simplify(); op.simplify()
+    assert_state_equal(hp, op)
+
+
 def test_replicated_layout(oracle):
     b = random_batch(batch=5, n=15, mixed=True, seed=11)
     hp, op = make_pair(oracle, b, replication=3)
