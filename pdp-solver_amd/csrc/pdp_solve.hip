@@ -98,7 +98,7 @@ struct SolveParams {
     int rf_no_fused_step;       // PDP_SOLVE_RF_NO_FUSED_STEP=1: a Reinforce coin sweep runs E2's plain form and its step uses X / Y as scratch (round 5's form)
     int adopt_poison;           // LDS-resident pass 1: take a first-NaN sweep other workgroups of the launch already recorded (PDP_SOLVE_NO_ADOPT=1: off)
     int lds_tickets;            // LDS-resident kernel, pass 1: 0 = instance blockIdx.x, else the number of instances the workgroups draw tickets for
-    uint8_t *ghost_flag;        // LDS-resident kernel: [B] instances that left inactive with iterations to come (checked by k_ghost_check after the call)
+    uint8_t *ghost_flag;        // LDS-resident kernel: [B] 2 = an instance that left inactive with iterations to come failed its ghost sweep (lds_ghost_bad)
     uint32_t *team_ws;          // [team_count][PDP_TEAM_WORDS], zeroed before every launch
 };
 
@@ -1150,6 +1150,75 @@ __device__ __forceinline__ T team_reduce(const LView &I, T v, Op op, T identity,
 // (HIP's __syncthreads_or reads the three block dimensions from memory)
 __device__ __forceinline__ int team_any(const LView &I, int x) { return block_reduce(x ? 1 : 0, OpOrI(), 0, I.red, I.nt); }
 
+// Ghost sweep of an instance that leaves inactive with iterations still to come (see d_ghost_bad and k_sp_solve: would the reference's masked
+// sweep over its frozen state, or the scorer on its frozen surveys, produce a non-finite value?), on the LDS image right behind the write-back:
+// the arithmetic of d_ghost_bad, statement by statement, on what the exit path just stored -- q_u (parked in the q_u array by the caller), the
+// final surveys, the edge-mask bit of the clause word, the force of the slot word.  X, Y, S, P, N are free there.  Cold: once per leaving
+// instance, while the CU's other workgroup runs on (the separate launch it replaces ran behind the call's last chunk: ~57 us of every
+// headline step for a handful of instances).  Returns 1 if something was non-finite.
+__device__ __noinline__ int lds_ghost_bad(uint32_t smem_off, uint32_t cold_off, int nt, int n, int m, int ne, int fin_is_b, float pi, int has_force, int check_score, int vmask)
+{
+    ColdShared *const cs = lds_at<ColdShared>(cold_off);
+    const LdsArrays L = carve_all(lds_at<unsigned char>(smem_off), n, m, ne);
+    const int tid = threadIdx.x;
+    const float *const Eta = fin_is_b ? L.EB : L.EA;
+    float *const s0 = L.X, *const s3 = L.Y;
+    const float L0h = pdp_safe_log(1.0f - pi * 0.0f, PDP_SP_EPS), L1h = pdp_safe_log(1.0f - pi * 1.0f, PDP_SP_EPS);
+    int bad = 0;
+    if (tid == 0) cs->found = 0;
+    for (int c = tid; c < m; c += nt) {
+        float acc = 0.0f;
+        for (int k = L.f_ptr[c]; k < L.f_ptr[c + 1]; ++k) {
+            const int p = L.e2p[k];
+            float x = pdp_safe_log(L.QU[p], PDP_SP_EPS);
+            x = x * ((L.pcc[p] & PC_EM) ? 1.0f : 0.0f);
+            s0[p] = x; acc = acc + x;
+        }
+        L.S[c] = acc;
+    }
+    for (int v = tid; v < n; v += nt) {
+        float P = 0.0f, N = 0.0f;
+        for (int p = L.v_ptr[v]; p < L.v_ptr[v + 1]; ++p) {
+            float y = pdp_safe_log(1.0f - Eta[p], PDP_SP_EPS);
+            y = y * ((L.pcc[p] & PC_EM) ? 1.0f : 0.0f);
+            s3[p] = y;
+            const bool negative = (L.pvv[p] & 0x8000u) != 0;
+            P = P + (negative ? 0.0f : 1.0f) * y;
+            N = N + (negative ? 1.0f : 0.0f) * y;
+        }
+        L.Pv[v] = P; L.Nv[v] = N;
+    }
+    __syncthreads();
+    for (int p = tid; p < ne; p += nt) {
+        const uint16_t pw = L.pvv[p];
+        const float agg = (0.0f + L.S[L.pcc[p] & 0x3fff]) - s0[p];
+        const float eta_new = pdp_safe_exp(agg);
+        const int v = pw & vmask;
+        const SpOut o = d_sp_edge(slot_sign(pw), L.Pv[v], L.Nv[v], s3[p], has_force ? frc_of(pw) : 0.0f, L0h, L1h);
+        if (!pdp_finite(eta_new) || !pdp_finite(o.qu) || !pdp_finite(o.qs) || !pdp_finite(o.dc)) bad = 1;
+    }
+    __syncthreads();
+    for (int p = tid; p < ne; p += nt) s3[p] = pdp_safe_log(1.0f - Eta[p], PDP_SCORER_EPS) * (0.0f + L.af[L.pcc[p] & 0x3fff]);
+    __syncthreads();
+    for (int v = tid; v < n; v += nt) {
+        float ext = 0.0f, pos = 0.0f, neg = 0.0f, all = 0.0f;
+        for (int p = L.v_ptr[v]; p < L.v_ptr[v + 1]; ++p) {
+            const uint16_t pw = L.pvv[p];
+            const bool negative = (pw & 0x8000u) != 0;
+            const float f = s3[p];
+            ext = ext + (has_force ? frc_of(pw) : 0.0f);
+            pos = pos + (negative ? 0.0f : 1.0f) * f;
+            neg = neg + (negative ? 1.0f : 0.0f) * f;
+            all = all + f;
+        }
+        const float sc = d_score_from_sums(pos, neg, all, ext, pi);
+        if (check_score && sc != sc) bad = 1;
+    }
+    if (bad) cs->found = 1;
+    __syncthreads();
+    return cs->found;
+}
+
 // P6, cold: SurveyScorer + arg-max + set_variables (pdp_decimate.py:152-171).  Returns bit 0: a variable was fixed; bit 1: "coeff has an
 // exact zero", bit 2: "NaN coefficient" (the speculation record); bits 3-4: the new value of `verified`.
 #define DEC_FIXED 1
@@ -2126,6 +2195,8 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
     any_inactive = __syncthreads_or(any_inactive);
     const bool finishing = did_prop && (sp.final_chunk || !active);
     float *const Efin = cur ? L.EB : L.EA, *const Eprev = cur ? L.EA : L.EB;   // after the toggle: final surveys / the ones the last sweep read
+    // left inactive with iterations still to come: its frozen state is looked at right here (lds_ghost_bad)
+    const bool ghost = finishing && !active && !(sp.final_chunk && iters >= T) && !sp.isolate;
     if (finishing) {
         float *gq = sp.q + 3 * (size_t)G.e0;
         float *gfs = sp.fs + 2 * (size_t)G.e0;
@@ -2151,6 +2222,7 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
             // q_u: stored by a sweep of the plain form; after a sweep that took the logs, formed as that sweep formed it ((+0) * the log of the
             // value keeps a NaN: X holds log(max(q_u, eps)) * mask of exactly that value)
             const float sticky = qu_is_delta ? __builtin_fmaf(1.0f - 1.0f, X[p], qu / total) : QU[p];
+            if (ghost) QU[p] = sticky;                      // (lds_ghost_bad reads the q_u the caller gets)
             gq[3 * e] = sticky;
             gq[3 * e + 1] = 1.0f * (qs / total) + (1.0f - 1.0f) * sticky;
             gq[3 * e + 2] = 1.0f * (dc / total) + (1.0f - 1.0f) * sticky;
@@ -2174,6 +2246,11 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
         for (int p = tid; p < ne; p += nt) { const uint16_t cw = pcc[p]; gpc[p] = (uint16_t)((cw & ~PC_EM_USED) | ((cw & PC_EM) ? PC_EM_USED : 0)); }
         if constexpr (RF) { for (int p = tid; p < ne; p += nt) sp.frc_out[G.e0 + p] = frc_of(pvv[p]); }
     }
+    int ghost_bad = 0;
+    if (ghost) {
+        __syncthreads();
+        ghost_bad = UNI(lds_ghost_bad(lds_offset_of(smem), lds_offset_of(&s_cold), nt, n, m, ne, cur ? 1 : 0, pi, (FORCE || RF) ? 1 : 0, RF ? 0 : 1, VM));
+    }
     if (tid < SPEC_LOCAL && tid < T) {
         if (s_spec_used[tid]) atomicOr(&sp.spec_used[tid], (uint32_t)s_spec_used[tid]);
         if (s_spec_zero[tid]) atomicOr(&sp.spec_zero[tid], (uint32_t)s_spec_zero[tid]);
@@ -2187,10 +2264,9 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
         *reinterpret_cast<DynHeader *>(dout + BL.hdr) = h;
         const int gb = (LISTED || REPLAY) ? *(volatile int *)&s_inst : G.b;
         if (finishing) { sp.amask[gb] = (uint8_t)active; sp.counters[gb] = cnt; pv_.is_sat[gb] = s_cold.is_sat; }
-        // left inactive with iterations still to come: k_ghost_check looks at its frozen state after the call (see d_ghost_bad)
-        if (finishing && !active && !(sp.final_chunk && iters >= T)) sp.ghost_flag[gb] = 1;
-        else if (REPLAY) sp.ghost_flag[gb] = 0;           // what pass 1 did with this instance behind the poison is void, its flag with it (a stale one
-                                                          // sends k_ghost_check over an instance that never froze: a spurious fail-over, seen with long chunks)
+        // the verdict of the ghost sweep (2: something non-finite: the call fails, k_solve_finish of the last chunk collects the flags)
+        if (ghost) sp.ghost_flag[gb] = ghost_bad ? 2 : 0;
+        else if (REPLAY) sp.ghost_flag[gb] = 0;           // what pass 1 did with this instance behind the poison is void, its flag with it
         if (any_inactive) atomicMin(&ctl->perm_zero, (uint32_t)iters);
         if (!REPLAY) sp.last_event[gb] = last_event;
         if (sp.risk) sp.risk[gb] = finishing ? 0xffffffffu : s_risk;
@@ -2203,7 +2279,8 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
 __global__ void __launch_bounds__(256) k_solve_import(PView pv, const float *q, const float *fs, const uint8_t *amask, const float *prev, const float *counters,
                                                       int has_prev, int build_static, char *stat, char *dyn, const int64_t *stat_off, const int64_t *dyn_off, float *prev_slots,
                                                       const int32_t *list, int stage_cap /* slots per column of the LDS staging area */,
-                                                      SolveCall *force_check /* non-NULL: raise force_seen when fs[:, 1] holds anything but zeros */)
+                                                      SolveCall *force_check /* non-NULL: raise force_seen when fs[:, 1] holds anything but zeros */,
+                                                      int use_em /* 0: the problem has no edge mask yet (all ones) */)
 {
     const Inst G = load_inst(pv, list ? list[blockIdx.x] : (int)blockIdx.x);
     const int n = G.n, m = G.m, ne = G.e, tid = threadIdx.x, nt = blockDim.x;
@@ -2231,23 +2308,26 @@ __global__ void __launch_bounds__(256) k_solve_import(PView pv, const float *q, 
         if (__syncthreads_or(some) && tid == 0) atomicOr(&force_check->force_seen, 1u);
     }
     if (ne <= stage_cap) {
-        float *sQ = stage, *sE = stage + stage_cap, *sM = stage + 2 * stage_cap, *sP = stage + 4 * stage_cap;
-        int *sF = reinterpret_cast<int *>(stage + 3 * stage_cap);
+        // staged per edge: q_u, the survey, the slot's clause word with its mask bits (16 bits) and -- only when the decimator has one -- the
+        // previous survey: 10 or 14 bytes per edge, so that six (four) workgroups share a CU where 20 bytes let three
+        float *sQ = stage, *sE = stage + stage_cap, *sP = stage + 2 * stage_cap;
+        uint16_t *sC = reinterpret_cast<uint16_t *>(stage + (has_prev ? 3 : 2) * stage_cap);
         // (both loops take several elements per trip -- all their global loads first, then the LDS traffic: a one-element loop is one round
         //  trip per element, ten in a row per loop for n = 200 on 256 threads)
         for (int e0 = tid; e0 < ne; e0 += 4 * nt) {
-            float qv[4], ev[4], mv[4], pv[4] = {0.0f, 0.0f, 0.0f, 0.0f}; int fn[4];
+            float qv[4], ev[4], mv[4] = {1.0f, 1.0f, 1.0f, 1.0f}, pv[4] = {0.0f, 0.0f, 0.0f, 0.0f}; int fn[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int e = (e0 + j * nt < ne) ? e0 + j * nt : e0;
-                qv[j] = sq[3 * e]; ev[j] = sfs[2 * e]; mv[j] = G.emask[e]; fn[j] = G.e_fn[e];
+                qv[j] = sq[3 * e]; ev[j] = sfs[2 * e]; fn[j] = G.e_fn[e];
+                if (use_em) mv[j] = G.emask[e];                       // (no edge mask yet: all ones, pdp_problem_bind_state)
                 if (has_prev) pv[j] = prev[G.e0 + e];
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int e = e0 + j * nt;
                 if (e >= ne) continue;
-                sQ[e] = qv[j]; sE[e] = ev[j]; sM[e] = mv[j]; sF[e] = fn[j];
+                sQ[e] = qv[j]; sE[e] = ev[j]; sC[e] = (uint16_t)(fn[j] | ((mv[j] == 1.0f) ? (PC_EM | PC_EM_USED) : 0));
                 if (has_prev) sP[e] = pv[j];
             }
         }
@@ -2265,7 +2345,7 @@ __global__ void __launch_bounds__(256) k_solve_import(PView pv, const float *q, 
                 const int p = p0 + j * nt;
                 if (p >= ne) continue;
                 if (build_static) { pvv[p] = (uint16_t)(evar[j] | (esg[j] < 0 ? 0x8000 : 0)); e2p[e[j]] = (uint16_t)p; }
-                pcc[p] = (uint16_t)(sF[e[j]] | ((sM[e[j]] == 1.0f) ? (PC_EM | PC_EM_USED) : 0));
+                pcc[p] = sC[e[j]];
                 QU[p] = sQ[e[j]]; Ecur[p] = sE[e[j]];
                 if (has_prev) prev_slots[G.e0 + p] = sP[e[j]];
             }
@@ -2278,7 +2358,7 @@ __global__ void __launch_bounds__(256) k_solve_import(PView pv, const float *q, 
         for (int j = 0; j < 4; ++j) { const int p = p0 + j * nt; e[j] = G.v_edges[p < ne ? p : p0]; }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            qv[j] = sq[3 * e[j]]; ev[j] = sfs[2 * e[j]]; mv[j] = G.emask[e[j]]; fn[j] = G.e_fn[e[j]];
+            qv[j] = sq[3 * e[j]]; ev[j] = sfs[2 * e[j]]; mv[j] = use_em ? G.emask[e[j]] : 1.0f; fn[j] = G.e_fn[e[j]];
             if (has_prev) pv[j] = prev[G.e0 + e[j]];
         }
 #pragma unroll
@@ -2373,11 +2453,18 @@ __global__ void __launch_bounds__(1024) k_solve_post(SolveCtl *ctl, SolveCall *c
 // `adopt`).  Only the ORDER depends on this guess: an instance's result does not depend on when it runs.  One workgroup: a counting sort over
 // the 256 exponents (finished instances and NaNs carry all ones: last), the order inside a bucket is whatever the atomics make it.
 __global__ void __launch_bounds__(1024) k_solve_finish(SolveCtl *ctl, SolveCall *call, const uint32_t *spec_used, const uint32_t *spec_zero, int c, int chunk_start,
-                                                       int isolate, int B, const uint32_t *risk, int32_t *order)
+                                                       int isolate, int B, const uint32_t *risk, int32_t *order, const uint8_t *ghost_flag)
 {
     __shared__ int hist[256];
     __shared__ int s_stop;
     const int tid = threadIdx.x, nt = blockDim.x;
+    if (ghost_flag) {
+        // (the call's last chunk) an instance that left inactive found its frozen state non-finite under the reference's masked sweep: the
+        // speculation "an inactive instance changes nothing" does not hold, the call fails over
+        int bad = 0;
+        for (int b = tid; b < B; b += nt) bad |= (ghost_flag[b] == 2) ? 1 : 0;
+        if (bad) call->fail = 1;
+    }
     if (tid == 0) s_stop = call->stop ? 1 : 0;
     for (int i = tid; i < 256; i += nt) hist[i] = 0;
     __syncthreads();
@@ -2429,26 +2516,6 @@ __global__ void __launch_bounds__(256) k_big_state(PView pv, const int32_t *list
     if (tid == 0) { dst.sat[G.b] = src.sat[G.b]; dst.cnt[G.b] = src.cnt[G.b]; dst.amask[G.b] = src.amask[G.b]; }
 }
 
-
-// After a call of the LDS-resident loop: the instances that left inactive with iterations still to come (ghost_flag) are looked at in the
-// state they wrote back to the caller's arrays -- d_ghost_bad on the HBM-resident view.  A hit fails the call (the host restores the state).
-__global__ void __launch_bounds__(256) k_ghost_check(PView pv, SolveParams sp, const uint8_t *ghost_flag, SolveCall *call)
-{
-    if (!ghost_flag[blockIdx.x]) return;
-    const Inst G = load_inst(pv, blockIdx.x);
-    float *gq = sp.q + 3 * (size_t)G.e0, *gfs = sp.fs + 2 * (size_t)G.e0;
-    SView<int32_t> I;
-    I.b = G.b; I.n = G.n; I.m = G.m; I.e = G.e;
-    I.e_var = G.e_var; I.e_fn = G.e_fn; I.v_edges = G.v_edges; I.f_edges = G.f_edges; I.v_ptr = G.v_ptr; I.f_ptr = G.f_ptr;
-    I.sgn = G.sgn; I.av = G.av; I.af = G.af; I.sol = G.sol; I.emask = G.emask;
-    I.qu = gq; I.qstride = 3; I.eta = gfs; I.estride = 2; I.force = gfs + 1; I.fstride = 2;
-    I.s0 = sp.ws_e[0] + G.e0; I.s1 = sp.ws_e[1] + G.e0; I.s2 = sp.ws_e[2] + G.e0; I.s3 = sp.ws_e[3] + G.e0;
-    I.S = sp.ws_f + G.f0;
-    I.P = sp.ws_v[0] + G.v0; I.N = sp.ws_v[1] + G.v0; I.xv1 = sp.ws_v[2] + G.v0; I.xv2 = sp.ws_v[3] + G.v0;
-    I.score = sp.ws_v[4] + G.v0; I.coeff = sp.ws_v[5] + G.v0; I.assign = sp.ws_v[6] + G.v0;
-    const float L0h = pdp_safe_log(1.0f - sp.pi * 0.0f, PDP_SP_EPS), L1h = pdp_safe_log(1.0f - sp.pi * 1.0f, PDP_SP_EPS);
-    if (d_ghost_bad(I, sp.pi, L0h, L1h, true, !sp.rf) && threadIdx.x == 0) call->fail = 1;
-}
 
 // ---- simplify() of a batch whose instances fit the LDS ----------------------------------------------------------------------------------
 // pdp_simplify's per-instance kernel walks the HBM-resident arrays: a few latency-bound passes of dependent gathers per instance (252 us
@@ -2834,14 +2901,16 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
                            risk_order ? order : (int32_t *)nullptr, risk);
     }
     // staging area of the import: five columns of the largest fitting instance
-    int stage_cap = (p->res_fit_e + 3) & ~3;
-    if (stage_cap > 7936) stage_cap = 0;                                           // (159 KB / 20 bytes; 0: gather from global memory)
+    int stage_cap = (p->res_fit_e + 7) & ~7;
+    const size_t stage_per_edge = a->decimator->has_prev ? 14 : 10;                // q_u, survey, clause word (16 bits) [, previous survey]
+    if ((size_t)stage_cap * stage_per_edge > 159 * 1024) stage_cap = 0;            // (0: gather from global memory)
     if (getenv("PDP_SOLVE_IMPORT_GATHER")) stage_cap = 0;
-    const size_t stage_bytes = (size_t)stage_cap * 5 * sizeof(float);
+    const size_t stage_bytes = (size_t)stage_cap * stage_per_edge;
     if (stage_bytes > 64 * 1024) PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_solve_import, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes));
     hipLaunchKernelGGL(k_solve_import, dim3(nfit), dim3(256), stage_bytes, st, make_view(p), (const float *)a->q, (const float *)a->fs, (const uint8_t *)a->active_mask,
                        (const float *)a->decimator->prev, (const float *)a->decimator->counters, a->decimator->has_prev, p->res_static_built ? 0 : 1,
-                       p->res_stat, p->res_dyn[0], stat_off, dyn_off, p->res_prev_slots, fit_list, stage_cap, (force || rf) ? (SolveCall *)nullptr : call);
+                       p->res_stat, p->res_dyn[0], stat_off, dyn_off, p->res_prev_slots, fit_list, stage_cap, (force || rf) ? (SolveCall *)nullptr : call,
+                       p->has_edge_mask ? 1 : 0);
     PDP_LAUNCH_CHECK();
     p->res_static_built = 1;
 
@@ -2988,16 +3057,12 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
             }
         }
         hipLaunchKernelGGL(k_solve_finish, dim3(1), dim3(1024), 0, st, ctl + k, call, (const uint32_t *)sp.spec_used, (const uint32_t *)sp.spec_zero, c, done, (int)a->isolate_instances,
-                           p->B, (const uint32_t *)risk, (risk_order && k + 1 < nchunks) ? order : (int32_t *)nullptr);
+                           p->B, (const uint32_t *)risk, (risk_order && k + 1 < nchunks) ? order : (int32_t *)nullptr,
+                           (k + 1 == nchunks && !a->isolate_instances) ? (const uint8_t *)ghost_flag : (const uint8_t *)nullptr);
         PDP_LAUNCH_CHECK();
         done += c;
     }
     if (timed) PDP_HIP_CHECK(hipEventRecord(p->res_events[2 * nchunks], st));
-    if (!a->isolate_instances) {
-        // instances that left inactive with iterations to come: is their frozen state a fixed point of the reference's masked sweep?
-        if (!nbig) { const int st_ = hbm_workspaces(p, sp, false); if (st_ != PDP_OK) return st_; }
-        hipLaunchKernelGGL(k_ghost_check, dim3(p->B), dim3(256), 0, st, make_view(p), sp, (const uint8_t *)ghost_flag, call);
-    }
     PDP_HIP_CHECK(hipMemcpyAsync(p->solve_host, ctl, host_words * 4, hipMemcpyDeviceToHost, st));
     PDP_HIP_CHECK(hipStreamSynchronize(st));
     side_join.on = false;                                  // (every side-stream launch was joined into the main stream, which is drained)

@@ -14,16 +14,9 @@ python3 - "$OUT" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + '/trace/**/*kernel_trace.csv', recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-imp = [i for i, r in enumerate(rows) if 'k_solve_import' in r['Kernel_Name']]
-# the last timed step: from the fills in front of its simplify to the kernel before the next import / the end
-lo = imp[-2] + 1 if len(imp) > 1 else 0
-for i in range(imp[-1], -1, -1):
-    if 'k_ghost_check' in rows[i]['Kernel_Name']:
-        lo = i + 1; break
-hi = len(rows)
-for i in range(imp[-1], len(rows)):
-    if 'k_ghost_check' in rows[i]['Kernel_Name']:
-        hi = i + 1; break
+fills = [i for i, r in enumerate(rows) if 'k_bind_fill' in r['Kernel_Name']]
+# a step in the middle of the run: from the fills of its bind to the kernel before the next step's
+lo, hi = fills[len(fills) // 2], fills[len(fills) // 2 + 1]
 t0 = int(rows[lo]['Start_Timestamp']); prev_end = t0
 busy = 0.0
 for r in rows[lo:hi]:
