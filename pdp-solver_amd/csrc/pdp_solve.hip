@@ -2276,11 +2276,16 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
 }
 
 // canonical arrays -> static + first dynamic record (once per call; the static part once per problem)
+// call-entry state of a pdp_sp_solve call (restored when its speculation fails)
+struct SolveSnapshot {
+    float *q, *fs, *av, *af, *sol, *sat, *emask, *prev, *cnt; uint8_t *amask;
+};
 __global__ void __launch_bounds__(256) k_solve_import(PView pv, const float *q, const float *fs, const uint8_t *amask, const float *prev, const float *counters,
                                                       int has_prev, int build_static, char *stat, char *dyn, const int64_t *stat_off, const int64_t *dyn_off, float *prev_slots,
                                                       const int32_t *list, int stage_cap /* slots per column of the LDS staging area */,
                                                       SolveCall *force_check /* non-NULL: raise force_seen when fs[:, 1] holds anything but zeros */,
-                                                      int use_em /* 0: the problem has no edge mask yet (all ones) */)
+                                                      int use_em /* 0: the problem has no edge mask yet (all ones) */,
+                                                      SolveSnapshot snap /* .av non-NULL: also take the call-entry snapshot of what is read here anyway */)
 {
     const Inst G = load_inst(pv, list ? list[blockIdx.x] : (int)blockIdx.x);
     const int n = G.n, m = G.m, ne = G.e, tid = threadIdx.x, nt = blockDim.x;
@@ -2388,10 +2393,15 @@ __global__ void __launch_bounds__(256) k_solve_import(PView pv, const float *q, 
     }
     float *av = reinterpret_cast<float *>(dy + BL.av), *sol = reinterpret_cast<float *>(dy + BL.sol), *af = reinterpret_cast<float *>(dy + BL.af);
     int any_inactive = 0;
-    for (int v = tid; v < n; v += nt) { const float a = G.av[v]; av[v] = a; sol[v] = G.sol[v]; any_inactive |= (a == 0.0f) ? 1 : 0; }
-    for (int c = tid; c < m; c += nt) af[c] = G.af[c];
+    for (int v = tid; v < n; v += nt) {
+        const float a = G.av[v], so = G.sol[v];
+        av[v] = a; sol[v] = so; any_inactive |= (a == 0.0f) ? 1 : 0;
+        if (snap.av) { snap.av[G.v0 + v] = a; snap.sol[G.v0 + v] = so; }
+    }
+    for (int c = tid; c < m; c += nt) { const float f = G.af[c]; af[c] = f; if (snap.av) snap.af[G.f0 + c] = f; }
     any_inactive = __syncthreads_or(any_inactive);
     if (tid == 0) {
+        if (snap.av) { snap.sat[G.b] = pv.is_sat[G.b]; snap.cnt[G.b] = counters[G.b]; snap.amask[G.b] = amask[G.b]; }
         DynHeader h;
         h.active = amask[G.b] ? 1u : 0u; h.done = h.active ? 0u : 1u;      // an instance that enters inactive never runs: nothing to write back
         h.perm_zero = (h.done && any_inactive) ? 1u : 0u; h.simplified = 0;
@@ -2622,9 +2632,6 @@ int pdp_simplify_lds(pdp_problem *p, hipStream_t st)
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
-struct SolveSnapshot {
-    float *q, *fs, *av, *af, *sol, *sat, *emask, *prev, *cnt; uint8_t *amask;
-};
 
 // skip: bit 0 the messages q / fs (the caller declared them disposable: pdp_solve_args.inputs_disposable), bit 1 the decimator's previous
 // surveys (no previous state at call entry: the handle's has_prev flag says their content means nothing), bit 2 the edge mask (likewise
@@ -2849,8 +2856,9 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     // (with big instances in the batch the HBM-resident kernel works in place on the caller's arrays: everything is kept then)
     // (and a small batch whose speculation fails reruns in the lock-step launch from the restored q / fs: they are kept for it)
     const int snap_skip = p->res_nbig ? 0 : (((a->inputs_disposable && !lockstep_possible(p, a)) ? 1 : 0) | (had_prev0 ? 0 : 2) | (had_emask0 ? 0 : 4));
-    status = snapshot_copy(p, a, snap0, true, st, snap_skip);
-    if (status != PDP_OK) return status;
+    // (all that is left of it are the arrays k_solve_import reads anyway, and every instance goes through the import: it takes the snapshot)
+    const bool snap_in_import = snap_skip == 7 && getenv("PDP_SOLVE_SNAPSHOT_COPY") == nullptr;
+    if (!snap_in_import) { status = snapshot_copy(p, a, snap0, true, st, snap_skip); if (status != PDP_OK) return status; }
 
     if (rf) {
         PDP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sp_solve_lds<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2910,7 +2918,7 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     hipLaunchKernelGGL(k_solve_import, dim3(nfit), dim3(256), stage_bytes, st, make_view(p), (const float *)a->q, (const float *)a->fs, (const uint8_t *)a->active_mask,
                        (const float *)a->decimator->prev, (const float *)a->decimator->counters, a->decimator->has_prev, p->res_static_built ? 0 : 1,
                        p->res_stat, p->res_dyn[0], stat_off, dyn_off, p->res_prev_slots, fit_list, stage_cap, (force || rf) ? (SolveCall *)nullptr : call,
-                       p->has_edge_mask ? 1 : 0);
+                       p->has_edge_mask ? 1 : 0, snap_in_import ? snap0 : SolveSnapshot{});
     PDP_LAUNCH_CHECK();
     p->res_static_built = 1;
 
