@@ -128,7 +128,7 @@ struct pdp_problem {
     char *res_ctl; size_t res_ctl_bytes;
     hipEvent_t *res_events; int res_events_n;       // 2 per chunk + 1, created on demand (pdp_solve_args.time_kernels)
     // k_simplify_lds: the instances' topology in the slot form it works on (16-bit words), kept from the second simplify() of a problem on
-    uint16_t *simp_topo; int simp_calls;            // [3 E + (V + B) + (F + B)]: slot words | clause of slot | edge -> slot | row pointers
+    uint16_t *simp_topo; int simp_calls;            // slot words | clause of slot | edge -> slot | row pointers, every instance's part 4-byte aligned
     // per-instance routing of the persistent solver: instances whose image fits the LDS / the others (HBM-resident kernel, same chunk loop)
     int32_t *res_fit_list, *res_big_list;            // device, [res_nfit] / [res_nbig] instance ids in ascending order
     uint8_t *res_is_big;                             // device, [B]

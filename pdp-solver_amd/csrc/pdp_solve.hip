@@ -2554,19 +2554,25 @@ __global__ void __launch_bounds__(256) k_simplify_lds(PView pv, SimpTopo topo)
     float *av = carve<float>(cp, n), *sol = carve<float>(cp, n), *assign = carve<float>(cp, n), *af = carve<float>(cp, m);
     int32_t *deg = carve<int32_t>(cp, n), *sdeg = carve<int32_t>(cp, n);
     uint8_t *flag_v = carve<uint8_t>(cp, n), *flag_f = carve<uint8_t>(cp, m), *flag_f2 = carve<uint8_t>(cp, m);
-    uint16_t *const t_pvv = topo.pvv + G.e0, *const t_pcc = topo.pcc + G.e0, *const t_e2p = topo.e2p + G.e0;
-    uint16_t *const t_vptr = topo.vptr + G.v0 + G.b, *const t_fptr = topo.fptr + G.f0 + G.b;
+    // (an instance's part of every kept array starts at an even element: 4-byte aligned for the LDS-DMA below)
+    const size_t tb_e = ((size_t)G.e0 + 2 * (size_t)G.b) & ~(size_t)1;
+    const size_t tb_v = ((size_t)G.v0 + 3 * (size_t)G.b) & ~(size_t)1, tb_f = ((size_t)G.f0 + 3 * (size_t)G.b) & ~(size_t)1;
+    uint16_t *const t_pvv = topo.pvv + tb_e, *const t_pcc = topo.pcc + tb_e, *const t_e2p = topo.e2p + tb_e;
+    uint16_t *const t_vptr = topo.vptr + tb_v, *const t_fptr = topo.fptr + tb_f;
     if constexpr (TOPO == 2) {
-        // (all loads of a trip first, then the LDS stores: a one-element copy loop is one round trip per element)
-        for (int p0 = tid; p0 < ne; p0 += 4 * nt) {
-            uint16_t a[4], b[4], c[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { const int p = p0 + j * nt, pp = p < ne ? p : p0; a[j] = t_pvv[pp]; b[j] = t_pcc[pp]; c[j] = t_e2p[pp]; }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { const int p = p0 + j * nt; if (p < ne) { pvv[p] = a[j]; pcc[p] = b[j]; e2p[p] = c[j]; } }
-        }
-        for (int v = tid; v <= n; v += nt) v_ptr[v] = t_vptr[v];
-        for (int c = tid; c <= m; c += nt) f_ptr[c] = t_fptr[c];
+        // everything the kernel reads lands in LDS by DMA (global_load_lds_dword: no register round trip, every request of the workgroup in
+        // flight at once, one wait in front of the barrier); the copy loops this replaces were a dependent round trip each
+        const int lane = tid & 63;
+        auto dma4 = [&](void *dst, const void *src, size_t bytes) {
+            const int n4 = (int)((bytes + 3) >> 2);
+            for (int i = tid; i < n4; i += nt)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(src) + (size_t)i * 4),
+                                                 (__attribute__((address_space(3))) void *)(reinterpret_cast<uint32_t *>(dst) + (i - lane)), 4, 0, 0);
+        };
+        dma4(pvv, t_pvv, (size_t)ne * 2); dma4(pcc, t_pcc, (size_t)ne * 2); dma4(e2p, t_e2p, (size_t)ne * 2);
+        dma4(v_ptr, t_vptr, (size_t)(n + 1) * 2); dma4(f_ptr, t_fptr, (size_t)(m + 1) * 2);
+        dma4(av, G.av, (size_t)n * 4); dma4(sol, G.sol, (size_t)n * 4); dma4(af, G.af, (size_t)m * 4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
     // (eight slots per trip: the gathers through v_edges are two levels of dependent loads, and a loop that takes one slot per trip is one
     //  pair of round trips per slot -- twenty in a row for n = 200 on 256 threads, which is what this kernel's time was made of)
@@ -2587,9 +2593,9 @@ __global__ void __launch_bounds__(256) k_simplify_lds(PView pv, SimpTopo topo)
     }
     for (int v = tid; v <= n; v += nt) v_ptr[v] = (uint16_t)G.v_ptr[v];
     for (int c = tid; c <= m; c += nt) f_ptr[c] = (uint16_t)G.f_ptr[c];
-    }
     for (int v = tid; v < n; v += nt) { av[v] = G.av[v]; sol[v] = G.sol[v]; }
     for (int c = tid; c < m; c += nt) af[c] = G.af[c];
+    }
     __syncthreads();
     if constexpr (TOPO == 1) {
         for (int p = tid; p < ne; p += nt) { t_pvv[p] = pvv[p]; t_pcc[p] = pcc[p]; t_e2p[p] = e2p[p]; }
@@ -2615,7 +2621,7 @@ int pdp_simplify_lds(pdp_problem *p, hipStream_t st)
     if (lds > 64 * 1024) return 0;
     // the slot topology is kept from the second call on (a problem that is simplified once -- the solver classes make a SATProblem per batch --
     // pays nothing for it)
-    const size_t E = p->E, rows_v = (size_t)p->V + p->B, rows_f = (size_t)p->F + p->B;
+    const size_t Bn = p->B, E = ((size_t)p->E + 2 * Bn + 8) & ~(size_t)7, rows_v = ((size_t)p->V + 3 * Bn + 8) & ~(size_t)7, rows_f = ((size_t)p->F + 3 * Bn + 8) & ~(size_t)7;
     int mode = 0;
     if (p->simp_calls >= 2 && p->simp_topo) mode = 2;
     else if (p->simp_calls == 1 && !getenv("PDP_SIMPLIFY_NO_TOPO") && pdp_dev_alloc((void **)&p->simp_topo, (3 * E + rows_v + rows_f + 8) * sizeof(uint16_t)) == PDP_OK) mode = 1;
