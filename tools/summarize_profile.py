@@ -67,15 +67,17 @@ if 'FETCH_SIZE' in vals and 'WRITE_SIZE' in vals:
         for f in find('*counter_collection.csv'):
             if '/%spmc1/' % pre not in f:
                 continue
-            tot, disp = 0.0, set()
+            tot, disp, calls = 0.0, set(), set()
             with open(f) as fh:
                 for r in csv.DictReader(fh):
                     if 'k_sp_solve_lds<false, false' in r.get('Kernel_Name', '') and r.get('Counter_Name') == 'SQ_INSTS_VALU':
                         tot += float(r.get('Counter_Value', 0) or 0); disp.add(r.get('Dispatch_Id'))
+                    if 'k_solve_import' in r.get('Kernel_Name', ''):
+                        calls.add(r.get('Dispatch_Id'))          # one import per pdp_sp_solve call
             if disp:
                 out[key] = tot / len(disp)
                 if not pre:
-                    out['launches_per_call'] = len(disp) / 4.0      # the profiled command makes 4 solve calls (--steps 3 --warmup 1)
+                    out['launches_per_call'] = len(disp) / float(max(1, len(calls)))
     out['source'] = 'bash tools/profile_bench.sh <tag>: rocprofv3 --kernel-trace --pmc passes of python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-fast-build; FETCH_SIZE and WRITE_SIZE in passes of their own'
     json.dump(out, open(os.path.join(root, prefix + 'pmc_traffic.json'), 'w'), indent=1)
     print()
