@@ -451,8 +451,14 @@ class PropagatorDecimatorSolverBase(nn.Module):
             side.wait_stream(torch.cuda.current_stream())
             for src_p, src_d, dst_p, dst_d in ((ps_a, ds_a, ps_b, ds_b2), (ps_b, ds_b, ps_a, tuple(ds_a[:2]))):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool, stream=side, capture_error_mode='thread_local'):
-                    sweep(src_p, src_d, dst_p, dst_d, False)
+                # (capture_begin / capture_end by hand: the torch.cuda.graph context also runs a device synchronize, gc.collect() and
+                #  empty_cache() on entry -- ~1 ms per capture, two captures per segment, with the first sweep's kernels still in flight)
+                with torch.cuda.stream(side):
+                    g.capture_begin(*(() if pool is None else (pool,)), capture_error_mode='thread_local')
+                    try:
+                        sweep(src_p, src_d, dst_p, dst_d, False)
+                    finally:
+                        g.capture_end()
                 pool = g.pool()
                 graphs.append(g)
             torch.cuda.current_stream().wait_stream(side)
