@@ -193,6 +193,28 @@ def test_persistent_solve_reproduces_nan_poisoning(oracle, spec, T, tol, t_max):
     np.testing.assert_array_equal(npy(fs), res['fs'])
 
 
+@pytest.mark.parametrize('first,chunk', [('1', '7'), ('13', '25'), ('25', '25'), ('90', '10'), ('400', '25'), (None, '64')])
+def test_chunk_schedule_does_not_change_the_result(oracle, monkeypatch, first, chunk):
+    """The loop runs as launches of PDP_SOLVE_FIRST_CHUNK (default 2 C), C, C, ... sweeps: where the chunk boundaries fall -- before, on or
+    behind the batch's first NaN, one sweep per launch, the whole loop in one launch, a first chunk past the LDS-local speculation record --
+    decides what is replayed and in which order instances are dispatched, never the result (the NaN-poisoned batch of
+    test_persistent_solve_reproduces_nan_poisoning against the oracle's loop, bit for bit)."""
+    monkeypatch.setenv('PDP_SOLVE_CHUNK', chunk)
+    if first: monkeypatch.setenv('PDP_SOLVE_FIRST_CHUNK', first)
+    else: monkeypatch.delenv('PDP_SOLVE_FIRST_CHUNK', raising=False)
+    b = random_batch(batch=400, n=60, k=3, seed=7000)
+    hp, res, q, fs, am, iters, used_lds, spec_ok = run_pair(oracle, b, 120, 0.05, 8)
+    assert np.isnan(res['fs']).any() and spec_ok and used_lds
+    it = res['iterations_run']
+    assert iters == it
+    np.testing.assert_array_equal(npy(am), res['trace_active_mask'][it - 1])
+    np.testing.assert_array_equal(npy(hp.active_variables)[:, 0], res['trace_active_var'][it - 1])
+    np.testing.assert_array_equal(npy(hp.active_functions)[:, 0], res['trace_active_fn'][it - 1])
+    np.testing.assert_array_equal(npy(hp.solution), res['trace_solution'][it - 1])
+    np.testing.assert_array_equal(npy(q), res['q'])
+    np.testing.assert_array_equal(npy(fs), res['fs'])
+
+
 @pytest.mark.parametrize('chunk', [None, '5'])
 def test_persistent_solve_resumes_across_calls(oracle, monkeypatch, chunk):
     """Two consecutive calls (the second one enters with decimator state: previous surveys, counters, edge mask) end exactly
