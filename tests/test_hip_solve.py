@@ -107,6 +107,53 @@ def test_persistent_solve_with_an_external_force_column(oracle, spec, T, tol, t_
     assert (assert_state[0] == 0).sum() > 0                                            # variables were fixed along the way
 
 
+def test_nan_force_on_instances_that_leave_early(oracle):
+    """Under-constrained instances go inactive after a few sweeps (every survey vanishes) with sweeps still to come; a NaN in their external
+    force column then reaches the frozen state through the reference's masked update (0 * NaN), which the persistent loop does not model:
+    its ghost sweep (lds_ghost_bad, on the LDS image as the instance leaves) must notice -- the call fails with every array untouched -- or
+    the call's result is the oracle's loop, bit for bit.  Never a silent difference."""
+    from pdp import native
+    pi, T, tol, t_max = 0.1, 30, 0.05, 8
+    b = random_batch(batch=60, n=30, k=3, m=18, seed=4242)
+    hp, op = make_pair(oracle, b)
+    hp.simplify(); op.simplify()
+    E, B = op.E, op.B
+    rng = np.random.RandomState(9)
+    q = np.full((E, 3), 1.0 / 3.0, np.float32)
+    fs = np.zeros((E, 2), np.float32); fs[:, 0] = 0.5
+    fs[:, 1] = rng.choice([-1.0, 0.0, 1.0], size=E).astype(np.float32)
+    fs[rng.choice(E, size=max(1, E // 40), replace=False), 1] = np.nan
+    q0, fs0 = q.copy(), fs.copy()
+    hq, hfs = t(q), t(fs)
+    ham = torch.ones(B, dtype=torch.uint8, device='cuda:0')
+    try:
+        iters, used_lds = hp.sp_solve(hq, hfs, ham, native.Decimator(hp), T, tol, t_max, pi=pi)
+    except native.SpeculationFailed:
+        np.testing.assert_array_equal(npy(hq), q0); np.testing.assert_array_equal(npy(hfs), fs0)      # nothing was touched
+        return
+    oam = np.ones(B, np.uint8)
+    od = op.new_decimator()
+    use_mask, it = False, 0
+    for _ in range(T):
+        em = op.refresh_edge_mask()[0] if use_mask else None
+        q, fs = op.sp_propagate(q, fs, em, oam, q, fs, pi)
+        oam, _n = op.sequential_decimate(od, fs, oam, tol, t_max, pi)
+        _, s_ = op.refresh_edge_mask()
+        if s_ < E:
+            use_mask = True
+        pred = op.update_solution(op.state()[2])
+        oam = op.check_termination(oam, pred)
+        it += 1
+        if int(oam.sum()) <= 0:
+            break
+    op.free_decimator(od)
+    assert iters == it
+    np.testing.assert_array_equal(npy(ham), oam)
+    np.testing.assert_array_equal(npy(hp.solution), op.state()[2])
+    np.testing.assert_array_equal(npy(hq), q)
+    np.testing.assert_array_equal(npy(hfs), fs)
+
+
 def test_persistent_solve_golden_trace():
     """Against the reference itself (golden trace): identical integer trajectory end state."""
     from pdp import native
