@@ -96,6 +96,7 @@ struct SolveParams {
     int no_scorer_reuse;        // PDP_SOLVE_NO_SCORER_REUSE=1: the decimation's scorer always takes its own logs (A/B switch)
     int no_event_look;          // PDP_SOLVE_NO_EVENT_LOOK=1: pass-1 workgroups look for a recorded NaN sweep only when they start
     int rf_no_fused_step;       // PDP_SOLVE_RF_NO_FUSED_STEP=1: a Reinforce coin sweep runs E2's plain form and its step uses X / Y as scratch (round 5's form)
+    int debug_ghost_inject;     // tests: see the exit path of k_sp_solve_lds
     int adopt_poison;           // LDS-resident pass 1: take a first-NaN sweep other workgroups of the launch already recorded (PDP_SOLVE_NO_ADOPT=1: off)
     int lds_tickets;            // LDS-resident kernel, pass 1: 0 = instance blockIdx.x, else the number of instances the workgroups draw tickets for
     uint8_t *ghost_flag;        // LDS-resident kernel: [B] 2 = an instance that left inactive with iterations to come failed its ghost sweep (lds_ghost_bad)
@@ -2222,8 +2223,10 @@ __global__ void __launch_bounds__(1024, PDP_SOLVE_WAVES_PER_SIMD) k_sp_solve_lds
             // q_u: stored by a sweep of the plain form; after a sweep that took the logs, formed as that sweep formed it ((+0) * the log of the
             // value keeps a NaN: X holds log(max(q_u, eps)) * mask of exactly that value)
             const float sticky = qu_is_delta ? __builtin_fmaf(1.0f - 1.0f, X[p], qu / total) : QU[p];
-            if (ghost) QU[p] = sticky;                      // (lds_ghost_bad reads the q_u the caller gets)
-            gq[3 * e] = sticky;
+            // (PDP_DEBUG_GHOST_INJECT=1, tests only: the first slot of a leaving instance gets a NaN q_u, so that the ghost sweep has something to find)
+            const float sticky_out = (ghost && sp.debug_ghost_inject && p == 0) ? __builtin_nanf("") : sticky;
+            if (ghost) QU[p] = sticky_out;                  // (lds_ghost_bad reads the q_u the caller gets)
+            gq[3 * e] = sticky_out;
             gq[3 * e + 1] = 1.0f * (qs / total) + (1.0f - 1.0f) * sticky;
             gq[3 * e + 2] = 1.0f * (dc / total) + (1.0f - 1.0f) * sticky;
             gfs[2 * e] = Efin[p];
@@ -2937,6 +2940,7 @@ static int sp_solve_resident(pdp_problem *p, pdp_solve_args *a, hipStream_t st, 
     sp.coins = a->coins; sp.dprob = a->decimation_probability;
     sp.rf = rf ? 1 : 0; sp.isolate = a->isolate_instances ? 1 : 0;
     sp.adopt_poison = getenv("PDP_SOLVE_NO_ADOPT") ? 0 : 1;
+    sp.debug_ghost_inject = getenv("PDP_DEBUG_GHOST_INJECT") ? 1 : 0;
     sp.no_scorer_reuse = getenv("PDP_SOLVE_NO_SCORER_REUSE") ? 1 : 0;
     sp.no_event_look = getenv("PDP_SOLVE_NO_EVENT_LOOK") ? 1 : 0;
     sp.rf_no_fused_step = getenv("PDP_SOLVE_RF_NO_FUSED_STEP") ? 1 : 0;

@@ -154,6 +154,33 @@ def test_nan_force_on_instances_that_leave_early(oracle):
     np.testing.assert_array_equal(npy(hfs), fs)
 
 
+def test_bad_ghost_sweep_fails_the_call(oracle, monkeypatch):
+    """The verdict of the in-kernel ghost sweep travels: an instance that leaves inactive with sweeps to come and whose frozen state is not
+    finite under the reference's masked sweep (here: a NaN q_u planted by PDP_DEBUG_GHOST_INJECT in the slot the instance writes back) marks
+    its flag, the last chunk's k_solve_finish collects the flags, the call fails and every array is what it was at call entry; without the
+    plant the same batch runs through and equals the oracle."""
+    from pdp import native
+    b = random_batch(batch=60, n=30, k=3, m=18, seed=4242)          # under-constrained: instances leave after a few sweeps, at different sweeps
+    T, tol, t_max = 30, 0.05, 8
+    hp, res, q, fs, am, iters, used_lds, spec_ok = run_pair(oracle, b, T, tol, t_max)
+    assert spec_ok and used_lds and (npy(am) == 0).any()             # (instances left along the way)
+    np.testing.assert_array_equal(npy(q), res['q'])
+    monkeypatch.setenv('PDP_DEBUG_GHOST_INJECT', '1')
+    monkeypatch.setenv('PDP_SOLVE_NO_LOCKSTEP', '1')                 # (a small batch whose speculation fails is otherwise served by the lock-step launch)
+    hp2, _ = make_pair(oracle, b)
+    hp2.simplify()
+    av0, sol0 = npy(hp2.active_variables).copy(), npy(hp2.solution).copy()
+    q2 = torch.full((hp2.E, 3), 1.0, device='cuda:0') / 3.0
+    fs2 = torch.zeros(hp2.E, 2, device='cuda:0'); fs2[:, 0] = 0.5
+    am2 = torch.ones(hp2.B, dtype=torch.uint8, device='cuda:0')
+    q0, fs0 = npy(q2).copy(), npy(fs2).copy()
+    with pytest.raises(native.SpeculationFailed):
+        hp2.sp_solve(q2, fs2, am2, native.Decimator(hp2), T, tol, t_max)
+    np.testing.assert_array_equal(npy(q2), q0); np.testing.assert_array_equal(npy(fs2), fs0)
+    np.testing.assert_array_equal(npy(am2), np.ones(hp2.B, np.uint8))
+    np.testing.assert_array_equal(npy(hp2.active_variables), av0); np.testing.assert_array_equal(npy(hp2.solution), sol0)
+
+
 def test_persistent_solve_golden_trace():
     """Against the reference itself (golden trace): identical integer trajectory end state."""
     from pdp import native
