@@ -198,6 +198,9 @@ def main():
     call_ms, iters_done, paths, launches = [], [], [], []
 
     step_no = [0]
+    # (the five state arrays and the stream do not change from step to step: their ctypes forms are made once)
+    bind_args = (native.ptr(prob.active_variables), native.ptr(prob.active_functions), native.ptr(prob.solution), native.ptr(prob.is_sat),
+                 native.ptr(prob.edge_mask), native._stream())
 
     def step(record, call_events=False):
         # a fresh SATProblem (solver.py:49-54: the library resets the problem's state arrays) + simplify(), then the solver on this step's
@@ -205,9 +208,7 @@ def main():
         # launches costs 3-6 us of stream time, tools/micro/event_gap.hip); the events around the whole call go on extra steps behind the timed region
         q, fs, am, dec = states[step_no[0] % n_states]
         step_no[0] += 1
-        native.check(L.pdp_problem_bind_state(prob._h, native.ptr(prob.active_variables), native.ptr(prob.active_functions),
-                                              native.ptr(prob.solution), native.ptr(prob.is_sat), native.ptr(prob.edge_mask),
-                                              native._stream()))
+        native.check(L.pdp_problem_bind_state(prob._h, *bind_args))
         prob.simplify()
         if call_events: ev0.record()
         try:
